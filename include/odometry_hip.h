@@ -1,0 +1,143 @@
+/*
+ * odometry_hip.h — C ABI of the MI355X-native photometric-LM tracking hot path.
+ *
+ * The reference (WangYuTum/odometry) has no FFI layer; its boundary is the public C++ surface the
+ * runner uses (run_odometry_kitti_offline.cpp:68-70,88,102,130-131,205,215,229,251-252,261,268).
+ * Each entry point below names the reference interface it replaces. The C++ shim classes in
+ * include/odometry_shim.hpp keep the reference's class names and signatures over this ABI.
+ *
+ * Conventions: plain C, no exceptions; every call returns 0 on success and -1 on failure
+ * (OptimizerStatus / GlobalStatus, ref: include/data_types.h:27-28) and odo_last_error() describes
+ * the last failure of the calling thread. Poses are 16 fp32 COLUMN-major (Eigen Affine4f,
+ * ref: include/data_types.h:24). Images are single-channel fp32 row-major (CV_32F, ref: data_types.h:10-12).
+ * The caller owns all host buffers; the library owns device memory behind the opaque handles.
+ * One odo_ctx = one HIP stream on one device; handles are not thread-safe (the reference is strictly
+ * single-threaded, ref: run_odometry_kitti_offline.cpp:3).
+ * There is NO CPU fallback: without a HIP device odo_ctx_create fails.
+ */
+#ifndef ODOMETRY_HIP_H
+#define ODOMETRY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct odo_ctx odo_ctx;
+typedef struct odo_pyr odo_pyr;
+typedef struct odo_lm odo_lm;
+typedef struct odo_depth odo_depth;
+typedef struct odo_tracker odo_tracker;
+
+/* Level-0 pinhole intrinsics (fy = fx). NULL wherever accepted = the KITTI-00 constants the reference
+ * hard-codes (ref: include/image_processing_global.h:35-36: 718.856f, 607.1928, 185.2157). */
+typedef struct {
+  float f0, cx0, cy0;
+} odo_intrinsics;
+
+enum { ODO_PYR_IMAGE = 0, ODO_PYR_DEPTH = 1 };
+enum { ODO_MAX_LEVELS = 8, ODO_NACC = 29 };
+
+const char* odo_last_error(void);
+int odo_version(void);
+
+/* ---- context ------------------------------------------------------------------------------ */
+int odo_ctx_create(int device, odo_ctx** out);
+int odo_ctx_destroy(odo_ctx* ctx);
+int odo_ctx_synchronize(odo_ctx* ctx);
+/* HIP-event timing on the context's own stream (bench.py): record start / stop around a region,
+ * then read the elapsed milliseconds (synchronises on the stop event). */
+int odo_ctx_timer_start(odo_ctx* ctx);
+int odo_ctx_timer_stop(odo_ctx* ctx, float* elapsed_ms);
+/* Device scratch for callers that keep inputs resident in HBM (bench.py, tracker). */
+int odo_dev_alloc(odo_ctx* ctx, size_t bytes, void** out_dev);
+int odo_dev_free(odo_ctx* ctx, void* dev);
+int odo_dev_upload(odo_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int odo_dev_download(odo_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+
+/* ---- pyramids ------------------------------------------------------------------------------
+ * Replaces ImagePyramid::ImagePyramid / DepthPyramid::DepthPyramid
+ * (ref: include/image_pyramid.h:24,51; src/image_pyramid.cpp:13-19,30-37;
+ *  src/image_processing_global.cpp:12-56,58-113).
+ * kind IMAGE: L0 = 3x3 Gaussian blur if smooth else copy; L1 = pyrDown(input); Lk = pyrDown(L(k-1)).
+ * kind DEPTH: L0 = copy, Lk(y,x) = L(k-1)(2y+1,2x+1); smooth must be 0 (no reference caller passes 1).
+ * `img` is a host pointer with row pitch stride_bytes (0 = cols*4). */
+int odo_pyramid_create(odo_ctx* ctx, const float* img, int rows, int cols, size_t stride_bytes, int levels,
+                       int smooth, int kind, odo_pyr** out);
+/* Same, input already resident in device memory (dense, row pitch = cols*4). */
+int odo_pyramid_create_dev(odo_ctx* ctx, const float* img_dev, int rows, int cols, int levels, int smooth,
+                           int kind, odo_pyr** out);
+/* Rebuild an existing pyramid in place from a new device-resident image of the same size. */
+int odo_pyramid_rebuild_dev(odo_pyr* pyr, const float* img_dev, int smooth);
+/* GetNumberLevels / GetPyramidImage / GetPyramidDepth (ref: include/image_pyramid.h:33,36,60,63). */
+int odo_pyramid_levels(const odo_pyr* pyr);
+int odo_pyramid_level_dims(const odo_pyr* pyr, int level, int* rows, int* cols);
+int odo_pyramid_download(const odo_pyr* pyr, int level, float* dst_host);
+const float* odo_pyramid_level_dev(const odo_pyr* pyr, int level);
+int odo_pyramid_destroy(odo_pyr* pyr);
+
+/* ---- pose optimiser --------------------------------------------------------------------------
+ * Replaces LevenbergMarquardtOptimizer (ref: include/lm_optimizer.h:32,44,47,54;
+ * src/lm_optimizer.cpp:19-41,54-69,73-160,163-264,364-405).
+ * max_iters is indexed by pyramid level (ref: src/lm_optimizer.cpp:117). robust: 0 none, 1 Huber, 2 t-dist. */
+int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const int* max_iters, int n_levels,
+                  const float init_colmajor[16], int robust, float huber_delta, const odo_intrinsics* K,
+                  odo_lm** out);
+/* Solve (ref: src/lm_optimizer.cpp:54-69): returns 0 and the keyframe->current pose, or -1 and the
+ * pseudo-identity whose (3,3) element is 0 (ref: src/lm_optimizer.cpp:48-52,60-65). */
+int odo_lm_solve(odo_lm* lm, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img,
+                 float out_colmajor[16]);
+/* Reset (ref: src/lm_optimizer.cpp:373-382): new initial pose and lambda, statistics cleared. */
+int odo_lm_reset(odo_lm* lm, const float init_colmajor[16], float lambda);
+/* ShowReport data (ref: src/lm_optimizer.cpp:364-371). The reference never writes its statistics, so
+ * `iters`/`cost` are always 0 there; here iters[l] = evaluations spent on level l in the last Solve and
+ * cost[l][0..1] = mean weighted error at the first / last evaluation of level l. */
+int odo_lm_report(const odo_lm* lm, int iters[4], float cost[4][2]);
+int odo_lm_destroy(odo_lm* lm);
+
+/* One ComputeResidualJacobianNaive + normal-equation pass (ref: src/lm_optimizer.cpp:163-264,129,145-149)
+ * at pose T on `level`: acc[0..20] upper triangle of JtWJ (row-major), acc[21..26] JtWr, acc[27] sum w r^2,
+ * acc[28] N. Parity-test entry for the dominant kernel. */
+int odo_lm_accumulate(odo_lm* lm, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img, int level,
+                      const float T_colmajor[16], double acc[ODO_NACC]);
+/* Per-evaluation trace of the last Solve: rows of 12 floats
+ * {level, iter, N, err, lambda_after, accepted, stop, delta[0..5] (first 5)...}; see DESIGN.md. */
+typedef struct {
+  int level, iter, n_res, accepted, stop;
+  float err, lambda_after;
+  float delta[6];
+} odo_lm_trace_row;
+int odo_lm_trace(const odo_lm* lm, odo_lm_trace_row* rows, int cap, int* n_rows);
+/* Launch statistics of the last Solve (bench.py roofline): number of residual-kernel launches that did
+ * work, and the algorithmic bytes they touched (12 B per interior pixel + 232 B out). */
+int odo_lm_launch_stats(const odo_lm* lm, int* n_active_launches, int* n_total_launches, double* algorithmic_bytes);
+
+/* ---- depth estimator ---------------------------------------------------------------------------
+ * Replaces DepthEstimator (ref: include/depth_estimate.h:31-33,51,54; src/depth_estimate.cpp:9-26,33-78,
+ * 80-198,200-242,244-401,435-453,465-468). Camera pointers are replaced by K (NULL = KITTI-00).
+ * max_disparity: 0 = the reference search range [boundary, x) (ref: src/depth_estimate.cpp:382), else
+ * [max(boundary, x - max_disparity), x). any_size: 0 keeps the 376x1241 guard (ref: :46-49). */
+int odo_depth_create(odo_ctx* ctx, float grad_th, float ssd_th, float photo_th, float min_depth, float max_depth,
+                     float lambda, float huber_delta, float precision, int max_iters, int boundary,
+                     const odo_intrinsics* K, float baseline, int max_residuals, int max_disparity, int any_size,
+                     odo_depth** out);
+/* ComputeDepth (ref: src/depth_estimate.cpp:33-78). Host buffers; val/disp/dep are overwritten
+ * (zero-filled first: SURVEY appendix B #14). Returns -1 when fewer than 500 points survive (ref: :192-197). */
+int odo_depth_compute(odo_depth* d, const float* left, const float* right, int rows, int cols, uint8_t* val,
+                      float* disp, float* dep);
+/* Same with device-resident inputs and outputs (no PCIe in the timed region). */
+int odo_depth_compute_dev(odo_depth* d, const float* left_dev, const float* right_dev, int rows, int cols,
+                          uint8_t* val_dev, float* disp_dev, float* dep_dev);
+/* Disparity stage only (DisparityDepthEstimate, ref: src/depth_estimate.cpp:244-401). */
+int odo_depth_disparity(odo_depth* d, const float* left, const float* right, int rows, int cols, uint8_t* val,
+                        float* disp, float* dep);
+/* ReportStatus data (ref: src/depth_estimate.cpp:465-468) + counts printed by ComputeDepth (:62,74). */
+int odo_depth_report(const odo_depth* d, int* iters, float* cost, int* n_selected, int* n_matched, int* n_valid);
+int odo_depth_destroy(odo_depth* d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ODOMETRY_HIP_H */

@@ -1,0 +1,100 @@
+"""ctypes binding of include/odometry_hip.h (the in-tree libodometry_hip.so).
+
+Fails loudly when the library is missing or cannot be loaded — there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libodometry_hip.so")
+
+MAX_LEVELS = 8
+NACC = 29
+PYR_IMAGE, PYR_DEPTH = 0, 1
+
+
+class Intrinsics(C.Structure):
+    _fields_ = [("f0", C.c_float), ("cx0", C.c_float), ("cy0", C.c_float)]
+
+
+class LmTraceRow(C.Structure):
+    _fields_ = [("level", C.c_int), ("iter", C.c_int), ("n_res", C.c_int), ("accepted", C.c_int), ("stop", C.c_int),
+                ("err", C.c_float), ("lambda_after", C.c_float), ("delta", C.c_float * 6)]
+
+
+_fp = C.POINTER(C.c_float)
+_dp = C.POINTER(C.c_double)
+_u8p = C.POINTER(C.c_uint8)
+_ip = C.POINTER(C.c_int)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/odometry_hip.h declares.
+SIGNATURES = {
+    "odo_last_error": (C.c_char_p, []),
+    "odo_version": (C.c_int, []),
+    "odo_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "odo_ctx_destroy": (C.c_int, [_vp]),
+    "odo_ctx_synchronize": (C.c_int, [_vp]),
+    "odo_ctx_timer_start": (C.c_int, [_vp]),
+    "odo_ctx_timer_stop": (C.c_int, [_vp, _fp]),
+    "odo_dev_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "odo_dev_free": (C.c_int, [_vp, _vp]),
+    "odo_dev_upload": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "odo_dev_download": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "odo_pyramid_create": (C.c_int, [_vp, _fp, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "odo_pyramid_create_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "odo_pyramid_rebuild_dev": (C.c_int, [_vp, _vp, C.c_int]),
+    "odo_pyramid_levels": (C.c_int, [_vp]),
+    "odo_pyramid_level_dims": (C.c_int, [_vp, C.c_int, _ip, _ip]),
+    "odo_pyramid_download": (C.c_int, [_vp, C.c_int, _fp]),
+    "odo_pyramid_level_dev": (_vp, [_vp, C.c_int]),
+    "odo_pyramid_destroy": (C.c_int, [_vp]),
+    "odo_lm_create": (C.c_int, [_vp, C.c_float, C.c_float, _ip, C.c_int, _fp, C.c_int, C.c_float,
+                                C.POINTER(Intrinsics), C.POINTER(_vp)]),
+    "odo_lm_solve": (C.c_int, [_vp, _vp, _vp, _vp, _fp]),
+    "odo_lm_reset": (C.c_int, [_vp, _fp, C.c_float]),
+    "odo_lm_report": (C.c_int, [_vp, _ip, _fp]),
+    "odo_lm_destroy": (C.c_int, [_vp]),
+    "odo_lm_accumulate": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _fp, _dp]),
+    "odo_lm_trace": (C.c_int, [_vp, C.POINTER(LmTraceRow), C.c_int, _ip]),
+    "odo_lm_launch_stats": (C.c_int, [_vp, _ip, _ip, _dp]),
+    "odo_depth_create": (C.c_int, [_vp] + [C.c_float] * 8 + [C.c_int, C.c_int, C.POINTER(Intrinsics), C.c_float,
+                                                          C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "odo_depth_compute": (C.c_int, [_vp, _fp, _fp, C.c_int, C.c_int, _u8p, _fp, _fp]),
+    "odo_depth_compute_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "odo_depth_disparity": (C.c_int, [_vp, _fp, _fp, C.c_int, C.c_int, _u8p, _fp, _fp]),
+    "odo_depth_report": (C.c_int, [_vp, _ip, _fp, _ip, _ip, _ip]),
+    "odo_depth_destroy": (C.c_int, [_vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the in-tree HIP library; raises if it is missing (build it with `python -m odometry_amd.build`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m odometry_amd.build` "
+                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().odo_last_error().decode("utf-8", "replace")
+
+
+class OdoError(RuntimeError):
+    pass
+
+
+def check(status, what):
+    if status != 0:
+        raise OdoError(f"{what}: {last_error()}")

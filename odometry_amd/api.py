@@ -1,0 +1,334 @@
+"""Python mirror of the reference's public C++ surface over the C ABI (test/bench harness).
+
+Same class names, argument order and error behaviour as the reference
+(ref: include/image_pyramid.h:14-69, include/lm_optimizer.h:24-115, include/depth_estimate.h:24-121,
+include/keyframe.h:17-60): status ints 0 / -1, messages on stdout, Solve returns the pseudo-identity on
+failure. Matrices are numpy 4x4 (row-major view of the reference's column-major Affine4f).
+The C++ drop-in is include/odometry_shim.hpp; this module exists so the parity tests read like the
+reference's own programs.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+_default_ctx = None
+
+
+class Context:
+    """One HIP stream on one device (odo_ctx)."""
+
+    def __init__(self, device=0):
+        lib = L.load()
+        h = C.c_void_p()
+        L.check(lib.odo_ctx_create(device, C.byref(h)), "odo_ctx_create")
+        self.h = h
+        self.lib = lib
+
+    def synchronize(self):
+        L.check(self.lib.odo_ctx_synchronize(self.h), "odo_ctx_synchronize")
+
+    def timer_start(self):
+        L.check(self.lib.odo_ctx_timer_start(self.h), "timer_start")
+
+    def timer_stop(self):
+        ms = C.c_float(0)
+        L.check(self.lib.odo_ctx_timer_stop(self.h, C.byref(ms)), "timer_stop")
+        return ms.value
+
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        L.check(self.lib.odo_dev_alloc(self.h, nbytes, C.byref(p)), "odo_dev_alloc")
+        return p
+
+    def free(self, p):
+        L.check(self.lib.odo_dev_free(self.h, p), "odo_dev_free")
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.alloc(arr.nbytes)
+        L.check(self.lib.odo_dev_upload(self.h, p, arr.ctypes.data_as(C.c_void_p), arr.nbytes), "odo_dev_upload")
+        return p
+
+    def download(self, p, shape, dtype):
+        out = np.empty(shape, dtype)
+        L.check(self.lib.odo_dev_download(self.h, out.ctypes.data_as(C.c_void_p), p, out.nbytes), "odo_dev_download")
+        return out
+
+    def close(self):
+        if self.h:
+            self.lib.odo_ctx_destroy(self.h)
+            self.h = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _colmajor(M):
+    return _f32(np.asarray(M, np.float32).T).reshape(16)
+
+
+def _from_colmajor(v):
+    return np.asarray(v, np.float32).reshape(4, 4).T.copy()
+
+
+class _Pyramid:
+    _kind = L.PYR_IMAGE
+
+    def __init__(self, num_levels, in_img, smooth, ctx=None, device_ptr=None, shape=None):
+        self.ctx = ctx or default_context()
+        self.num_levels_ = num_levels
+        h = C.c_void_p()
+        if device_ptr is not None:
+            rows, cols = shape
+            st = self.ctx.lib.odo_pyramid_create_dev(self.ctx.h, device_ptr, rows, cols, num_levels, int(bool(smooth)),
+                                                     self._kind, C.byref(h))
+        else:
+            img = _f32(in_img)
+            rows, cols = img.shape
+            st = self.ctx.lib.odo_pyramid_create(self.ctx.h, _fp(img), rows, cols, 0, num_levels, int(bool(smooth)),
+                                                 self._kind, C.byref(h))
+        if st != 0:  # ref: src/image_pyramid.cpp:16-18 prints and carries on
+            print("Compute Gaussian Image Pyramid failed!" if self._kind == L.PYR_IMAGE
+                  else "Compute Gaussian Depth Pyramid failed!")
+            raise L.OdoError(L.last_error())
+        self.h = h
+        self.rows, self.cols = rows, cols
+
+    def rebuild_dev(self, device_ptr, smooth):
+        L.check(self.ctx.lib.odo_pyramid_rebuild_dev(self.h, device_ptr, int(bool(smooth))), "odo_pyramid_rebuild_dev")
+
+    def GetNumberLevels(self):
+        return self.num_levels_
+
+    def _level(self, level_idx):
+        r, c = C.c_int(0), C.c_int(0)
+        if self.ctx.lib.odo_pyramid_level_dims(self.h, level_idx, C.byref(r), C.byref(c)) != 0:
+            # ref: src/image_pyramid.cpp:22-25 prints and exit(1)s; the mirror raises instead
+            raise IndexError(f"Requested image pyramid does not exist! Max pyramid id: {self.num_levels_ - 1}")
+        out = np.empty((r.value, c.value), np.float32)
+        L.check(self.ctx.lib.odo_pyramid_download(self.h, level_idx, _fp(out)), "odo_pyramid_download")
+        return out
+
+    def level_dev(self, level_idx):
+        return self.ctx.lib.odo_pyramid_level_dev(self.h, level_idx)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.odo_pyramid_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ImagePyramid(_Pyramid):
+    """ref: include/image_pyramid.h:14-41"""
+    _kind = L.PYR_IMAGE
+
+    def GetPyramidImage(self, level_idx):
+        return self._level(level_idx)
+
+
+class DepthPyramid(_Pyramid):
+    """ref: include/image_pyramid.h:43-69"""
+    _kind = L.PYR_DEPTH
+
+    def GetPyramidDepth(self, level_idx):
+        return self._level(level_idx)
+
+
+class LevenbergMarquardtOptimizer:
+    """ref: include/lm_optimizer.h:24-115"""
+
+    def __init__(self, lam, precision, kMaxIterations, kRelativeInit, kCameraPtr=None, robust_est=1,
+                 huber_delta=4.0 / 255.0, ctx=None, intrinsics=None):
+        self.ctx = ctx or default_context()
+        if kCameraPtr is None and intrinsics is None:
+            print("LM Optimizer failed! Invalid camera pointer!")  # ref: src/lm_optimizer.cpp:35-36 (warning only)
+        mi = (C.c_int * len(kMaxIterations))(*kMaxIterations)
+        init = _colmajor(kRelativeInit)
+        K = None
+        if intrinsics is not None:
+            K = C.pointer(L.Intrinsics(*intrinsics))
+        h = C.c_void_p()
+        L.check(self.ctx.lib.odo_lm_create(self.ctx.h, lam, precision, mi, len(kMaxIterations), _fp(init), robust_est,
+                                           huber_delta, K, C.byref(h)), "odo_lm_create")
+        self.h = h
+        self.n_levels = len(kMaxIterations)
+
+    def Solve(self, kImagePyr1, kDepthPyr1, kImagePyr2):
+        out = np.zeros(16, np.float32)
+        st = self.ctx.lib.odo_lm_solve(self.h, kImagePyr1.h, kDepthPyr1.h, kImagePyr2.h, _fp(out))
+        self.last_status = st
+        if st != 0:
+            print("Optimize failed! ")  # ref: src/lm_optimizer.cpp:61
+        return _from_colmajor(out)
+
+    def Reset(self, kRelativeInit, lam):
+        init = _colmajor(kRelativeInit)
+        st = self.ctx.lib.odo_lm_reset(self.h, _fp(init), lam)
+        if st != 0:
+            print("Reset optimizer failed!")
+        return st
+
+    def report(self):
+        iters = (C.c_int * 4)()
+        cost = (C.c_float * 8)()
+        L.check(self.ctx.lib.odo_lm_report(self.h, iters, cost), "odo_lm_report")
+        return list(iters), [[cost[2 * i], cost[2 * i + 1]] for i in range(4)]
+
+    def ShowReport(self):
+        iters, cost = self.report()
+        print("Number of iterations performed per level: " + ", ".join(str(i) for i in iters))
+        print("Costs before/after per level: ")
+        for c in cost:
+            print(f"{c[0]}, {c[1]}")
+
+    # -- diagnostics beyond the reference surface --------------------------------------------------
+    def accumulate(self, kImagePyr1, kDepthPyr1, kImagePyr2, level, T):
+        acc = np.zeros(L.NACC, np.float64)
+        Tc = _colmajor(T)
+        st = self.ctx.lib.odo_lm_accumulate(self.h, kImagePyr1.h, kDepthPyr1.h, kImagePyr2.h, level, _fp(Tc),
+                                            acc.ctypes.data_as(C.POINTER(C.c_double)))
+        return st, acc
+
+    def trace(self):
+        rows = (L.LmTraceRow * 128)()
+        n = C.c_int(0)
+        L.check(self.ctx.lib.odo_lm_trace(self.h, rows, 128, C.byref(n)), "odo_lm_trace")
+        return [dict(level=r.level, iter=r.iter, n_res=r.n_res, accepted=r.accepted, stop=r.stop, err=r.err,
+                     lambda_after=r.lambda_after, delta=np.array(r.delta[:], np.float32)) for r in rows[:n.value]]
+
+    def launch_stats(self):
+        a, t, b = C.c_int(0), C.c_int(0), C.c_double(0)
+        L.check(self.ctx.lib.odo_lm_launch_stats(self.h, C.byref(a), C.byref(t), C.byref(b)), "odo_lm_launch_stats")
+        return a.value, t.value, b.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.odo_lm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DepthEstimator:
+    """ref: include/depth_estimate.h:24-121"""
+
+    def __init__(self, grad_th, ssd_th, photo_th, min_depth, max_depth, lam, huber_delta, precision, max_iters,
+                 boundary, left_cam_ptr=None, right_cam_ptr=None, baseline=0.0, max_residuals=5000, ctx=None,
+                 intrinsics=None, max_disparity=0, any_size=False):
+        self.ctx = ctx or default_context()
+        K = C.pointer(L.Intrinsics(*intrinsics)) if intrinsics is not None else None
+        h = C.c_void_p()
+        L.check(self.ctx.lib.odo_depth_create(self.ctx.h, grad_th, ssd_th, photo_th, min_depth, max_depth, lam,
+                                              huber_delta, precision, max_iters, boundary, K, baseline, max_residuals,
+                                              max_disparity, int(any_size), C.byref(h)), "odo_depth_create")
+        self.h = h
+        self.max_iters_ = max_iters
+
+    def _run(self, fn, left_img, right_img, left_val, left_disp, left_dep):
+        if left_img.shape != right_img.shape:
+            print("Number of rows/cols do not match for left/right images.")  # ref: src/depth_estimate.cpp:37-40
+            return -1
+        if left_img.dtype != np.float32 or right_img.dtype != np.float32:
+            print("Pixel type of left/right images not 32-bit float.")  # ref: :41-44
+            return -1
+        left_img = np.ascontiguousarray(left_img)
+        right_img = np.ascontiguousarray(right_img)
+        rows, cols = left_img.shape
+        for a in (left_val, left_disp, left_dep):
+            if not a.flags["C_CONTIGUOUS"] or a.shape != (rows, cols):
+                print("The cv::Mat matrix is not continuous in disparity search!")  # ref: :259-263
+                return -1
+        st = fn(self.h, _fp(left_img), _fp(right_img), rows, cols, left_val.ctypes.data_as(C.POINTER(C.c_uint8)),
+                _fp(left_disp), _fp(left_dep))
+        if st != 0:
+            print(L.last_error())
+        return st
+
+    def ComputeDepth(self, left_img, right_img, left_val, left_disp, left_dep):
+        return self._run(self.ctx.lib.odo_depth_compute, left_img, right_img, left_val, left_disp, left_dep)
+
+    def DisparityDepthEstimate(self, left_img, right_img, left_val, left_disp, left_dep):
+        return self._run(self.ctx.lib.odo_depth_disparity, left_img, right_img, left_val, left_disp, left_dep)
+
+    def compute_dev(self, left_dev, right_dev, rows, cols, val_dev, disp_dev, dep_dev):
+        return self.ctx.lib.odo_depth_compute_dev(self.h, left_dev, right_dev, rows, cols, val_dev, disp_dev, dep_dev)
+
+    def report(self):
+        it, ns, nm, nv = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        cost = C.c_float(0)
+        L.check(self.ctx.lib.odo_depth_report(self.h, C.byref(it), C.byref(cost), C.byref(ns), C.byref(nm),
+                                              C.byref(nv)), "odo_depth_report")
+        return dict(iters=it.value, cost=cost.value, n_selected=ns.value, n_matched=nm.value, n_valid=nv.value)
+
+    def ReportStatus(self):
+        r = self.report()
+        print(f"    Number of iters performed: {r['iters']}(max allowed: {self.max_iters_})")
+        print(f"    Final cost: {r['cost']}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.odo_depth_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class KeyFrame:
+    """ref: include/keyframe.h:17-60 — holder of four images and an absolute pose."""
+
+    def __init__(self, kLeftImg, kRightImg, kLeftDep, kLeftVal, kAbsoPose):
+        self.left_img_ptr_, self.right_img_ptr_ = kLeftImg, kRightImg
+        self.left_dep_ptr_, self.left_val_ptr_ = kLeftDep, kLeftVal
+        self.abso_pose_ = np.array(kAbsoPose, np.float32)
+
+    def GetLeftImg(self):
+        return self.left_img_ptr_
+
+    def GetRightImg(self):
+        return self.right_img_ptr_
+
+    def GetLeftDep(self):
+        return self.left_dep_ptr_
+
+    def GetLeftVal(self):
+        return self.left_val_ptr_
+
+    def GetAbsoPose(self):
+        return self.abso_pose_.copy()
+
+    def ModifyLeftDep(self):
+        return self.left_dep_ptr_
+
+    def ModifyLeftVal(self):
+        return self.left_val_ptr_
+
+    def ModifyAbsoPose(self):
+        return self.abso_pose_

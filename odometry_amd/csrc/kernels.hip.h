@@ -1,0 +1,604 @@
+// kernels.hip.h — CDNA4 (gfx950) kernels of the tracking hot path. 64-wide wavefronts throughout.
+// Included once by odometry_hip.hip. Compile with -ffp-contract=off (see odo_math.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "odo_math.h"
+
+namespace odo {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) i = (i < 0) ? -i : 2 * n - 2 - i;
+  return i;
+}
+
+// =============================================================================================
+// Pyramid kernels (P1/P2 of SURVEY section 8a)
+// =============================================================================================
+
+// 3x3 Gaussian blur {1/4,1/2,1/4} separable, reflect-101 (cv::GaussianBlur ksize 3, sigma 0;
+// ref: src/image_processing_global.cpp:30, src/depth_estimate.cpp:256-257). The row pass is recomputed
+// for the three rows a pixel needs — identical fp32 values to a materialised intermediate.
+// grid.z selects one of up to two images (left/right blurred in one launch).
+__global__ void __launch_bounds__(256) blur3x3_kernel(const float* __restrict__ src0, float* __restrict__ dst0,
+                                                       const float* __restrict__ src1, float* __restrict__ dst1,
+                                                       int rows, int cols) {
+  const float* __restrict__ src = blockIdx.z ? src1 : src0;
+  float* __restrict__ dst = blockIdx.z ? dst1 : dst0;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= cols || y >= rows) return;
+  const int xp = reflect101(x - 1, cols), xn = reflect101(x + 1, cols);
+  const int yy[3] = {reflect101(y - 1, rows), y, reflect101(y + 1, rows)};
+  float t[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float* r = src + (size_t)yy[k] * cols;
+    t[k] = r[x] * 0.5f + (r[xp] + r[xn]) * 0.25f;
+  }
+  dst[(size_t)y * cols + x] = t[1] * 0.5f + (t[0] + t[2]) * 0.25f;
+}
+
+// 5x5 pyrDown [1,4,6,4,1]/16 per axis sampled at (2x,2y), reflect-101, dst = (rows/2, cols/2)
+// (cv::pyrDown; ref: src/image_processing_global.cpp:38,46). Horizontal pass recomputed per source row.
+__global__ void __launch_bounds__(256) pyrdown_kernel(const float* __restrict__ src, int rows, int cols,
+                                                       float* __restrict__ dst) {
+  const int dr = rows / 2, dc = cols / 2;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= dc || y >= dr) return;
+  int xs[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) xs[k] = reflect101(2 * x - 2 + k, cols);
+  float h[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    const float* s = src + (size_t)reflect101(2 * y - 2 + k, rows) * cols;
+    h[k] = ((s[xs[2]] * 6.0f + (s[xs[1]] + s[xs[3]]) * 4.0f) + s[xs[0]]) + s[xs[4]];
+  }
+  dst[(size_t)y * dc + x] = (((h[2] * 6.0f + (h[1] + h[3]) * 4.0f) + h[0]) + h[4]) * (1.0f / 256.0f);
+}
+
+// Depth decimation L_k(y,x) = L_{k-1}(2y+1, 2x+1) (ref: src/image_processing_global.cpp:85-89,99-103).
+__global__ void __launch_bounds__(256) decimate_odd_kernel(const float* __restrict__ src, int cols,
+                                                            float* __restrict__ dst, int dr, int dc) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= dc || y >= dr) return;
+  dst[(size_t)y * dc + x] = src[(size_t)(2 * y + 1) * cols + (2 * x + 1)];
+}
+
+// =============================================================================================
+// Pose LM kernels (L2/L3/L5 of SURVEY section 8a)
+// =============================================================================================
+
+struct LevelView {
+  const float* I1;  // keyframe image level
+  const float* I2;  // current image level
+  const float* D1;  // keyframe inverse depth level
+  int rows, cols;
+};
+
+constexpr int kLmBlock = 256;
+constexpr int kRedPad = 8;  // sh[q][256+8] doubles: q-stride shifts 16 banks -> at most 2-way conflicts
+
+// Deterministic block reduction of 29 fp64 accumulators per thread -> out[29].
+// Thread t < 232 owns quantity q = t>>3 and sums the 32 values sh[q][i*8 + (t&7)] in ascending i,
+// then an 8-lane xor tree. The association order is fixed, so results are run-to-run identical.
+__device__ __forceinline__ void block_reduce_acc(const double acc[ODO_NACC], double* __restrict__ out) {
+  __shared__ double sh[ODO_NACC][kLmBlock + kRedPad];
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < ODO_NACC; q++) sh[q][t] = acc[q];
+  __syncthreads();
+  if (t < ODO_NACC * 8) {
+    const int q = t >> 3, s = t & 7;
+    double v = 0.0;
+#pragma unroll 8
+    for (int i = 0; i < kLmBlock / 8; i++) v += sh[q][i * 8 + s];
+    v += __shfl_xor(v, 4, 8);
+    v += __shfl_xor(v, 2, 8);
+    v += __shfl_xor(v, 1, 8);
+    if (s == 0) out[q] = v;
+  }
+}
+
+// Residual / Jacobian / normal-equation pass over the interior of one level, reading the pose from the
+// device-resident LM state (no host round trip between iterations). Dense scan: thread <-> interior pixel
+// (grid-stride), the reference's own iteration space (ref: src/lm_optimizer.cpp:190-191). Coalesced reads of
+// D1/I1; the five I2 taps of neighbouring pixels land in neighbouring cache lines (L1/L2 resident).
+// Writes one 29-vector of fp64 partials per block. `expect_level` guards against stale launches: once the
+// level's loop has stopped (state->active == 0) the launch returns immediately.
+__global__ void __launch_bounds__(kLmBlock) lm_residual_dense_kernel(LevelView v, LevelK k, const LmState* __restrict__ st,
+                                                                      int expect_level, int robust, float huber_delta,
+                                                                      const float* __restrict__ scale_sqr_ptr,
+                                                                      double* __restrict__ partials) {
+  if (!(st->active != 0 && st->level == expect_level)) return;
+  float T[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) T[i] = st->T[i];
+  const float scale_sqr = (robust == 2) ? *scale_sqr_ptr : 1.0f;
+  double acc[ODO_NACC];
+#pragma unroll
+  for (int q = 0; q < ODO_NACC; q++) acc[q] = 0.0;
+  const int iw = v.cols - 8, ih = v.rows - 8;
+  const int n = (iw > 0 && ih > 0) ? iw * ih : 0;
+  for (int idx = blockIdx.x * kLmBlock + threadIdx.x; idx < n; idx += gridDim.x * kLmBlock) {
+    const int y = 4 + idx / iw, x = 4 + idx % iw;
+    const size_t o = (size_t)y * v.cols + x;
+    const float d = v.D1[o];
+    if (!depth_valid(d)) continue;
+    const PointK p = make_point(x, y, d, v.I1[o], k);
+    int ui, vi;
+    if (!warp_point(p, T, k, v.rows, v.cols, &ui, &vi)) continue;
+    float r, J[6];
+    residual_jacobian(p, v.I2, v.rows, v.cols, ui, vi, &r, J);
+    const float w = robust_weight(r, robust, huber_delta, scale_sqr);
+    accumulate_row(acc, r, w, J);
+  }
+  block_reduce_acc(acc, partials + (size_t)blockIdx.x * ODO_NACC);
+}
+
+// t-distribution mode (robust == 2) needs every residual before any weight
+// (ComputeScaleNaive, ref: src/lm_optimizer.cpp:338-358): pass 1 stores r per interior pixel (NaN = skipped).
+__global__ void __launch_bounds__(kLmBlock) lm_residual_only_kernel(LevelView v, LevelK k, const LmState* __restrict__ st,
+                                                                     int expect_level, float* __restrict__ res) {
+  if (!(st->active != 0 && st->level == expect_level)) return;
+  float T[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) T[i] = st->T[i];
+  const int iw = v.cols - 8, ih = v.rows - 8;
+  const int n = (iw > 0 && ih > 0) ? iw * ih : 0;
+  for (int idx = blockIdx.x * kLmBlock + threadIdx.x; idx < n; idx += gridDim.x * kLmBlock) {
+    const int y = 4 + idx / iw, x = 4 + idx % iw;
+    const size_t o = (size_t)y * v.cols + x;
+    const float d = v.D1[o];
+    float r = __builtin_nanf("");
+    if (depth_valid(d)) {
+      const PointK p = make_point(x, y, d, v.I1[o], k);
+      int ui, vi;
+      if (warp_point(p, T, k, v.rows, v.cols, &ui, &vi)) r = v.I2[(size_t)vi * v.cols + ui] - p.i1;
+    }
+    res[idx] = r;
+  }
+}
+
+// Fixed-point iteration for the t-distribution scale over the stored residuals; one workgroup, sums in fp64
+// with a fixed association order (ref: src/lm_optimizer.cpp:338-358). Writes sigma^2.
+__global__ void __launch_bounds__(1024) lm_tdist_scale_kernel(const float* __restrict__ res, int n,
+                                                               const LmState* __restrict__ st, int expect_level,
+                                                               float* __restrict__ scale_sqr_out) {
+  if (!(st->active != 0 && st->level == expect_level)) return;
+  __shared__ double shs[1024];
+  __shared__ int shn[1024];
+  __shared__ float sh_sigma;
+  __shared__ int sh_done;
+  const int t = threadIdx.x;
+  float cur = 5.0f;
+  for (int guard = 0; guard < 1000; guard++) {
+    const float init_sigma = cur;
+    const float sigma_sqr = cur * cur;
+    double s = 0.0;
+    int cnt = 0;
+    for (int i = t; i < n; i += 1024) {
+      const float r = res[i];
+      if (r == r) {
+        const float e2 = r * r;
+        s += (double)(e2 * (1.0f + 200.0f) / (200.0f + e2 / sigma_sqr));
+        cnt++;
+      }
+    }
+    shs[t] = s;
+    shn[t] = cnt;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+      if (t < o) { shs[t] += shs[t + o]; shn[t] += shn[t + o]; }
+      __syncthreads();
+    }
+    if (t == 0) {
+      const float nxt = (shn[0] > 0) ? sqrtf((float)(shs[0] / (double)shn[0])) : cur;
+      sh_sigma = nxt;
+      sh_done = (shn[0] == 0) || !(fabsf(nxt - init_sigma) >= 1e-3f);
+    }
+    __syncthreads();
+    cur = sh_sigma;
+    const int done = sh_done;
+    __syncthreads();
+    if (done) break;
+  }
+  if (t == 0) *scale_sqr_out = cur * cur;
+}
+
+struct LmTraceRow {
+  int level, iter, n_res, accepted, stop;
+  float err, lambda_after;
+  float delta[6];
+};
+constexpr int kTraceCap = 128;
+
+// Sums the per-block partials in a fixed order and advances the LM state machine by one evaluation
+// (accept / reject, damped 6x6 solve, exp, left-compose; ref: src/lm_optimizer.cpp:129-154). One workgroup.
+__global__ void __launch_bounds__(256) lm_update_kernel(LmState* __restrict__ st, const double* __restrict__ partials,
+                                                         int nblk, int expect_level, float precision, int max_iters,
+                                                         LmTraceRow* __restrict__ trace, float* __restrict__ cost_stat,
+                                                         int* __restrict__ host_flag) {
+  if (!(st->active != 0 && st->level == expect_level)) return;
+  __shared__ double sh[8][32];
+  const int t = threadIdx.x;
+  const int q = t & 31, seg = t >> 5;
+  double v = 0.0;
+  if (q < ODO_NACC)
+    for (int b = seg; b < nblk; b += 8) v += partials[(size_t)b * ODO_NACC + q];
+  sh[seg][q] = v;
+  __syncthreads();
+  if (t == 0) {
+    double acc[ODO_NACC];
+    for (int i = 0; i < ODO_NACC; i++)
+      acc[i] = ((((((sh[0][i] + sh[1][i]) + sh[2][i]) + sh[3][i]) + sh[4][i]) + sh[5][i]) + sh[6][i]) + sh[7][i];
+    LmState s = *st;
+    const int iter_before = s.iter;
+    const float lambda_before = s.lambda;
+    const float err_last_before = s.err_last;
+    lm_consume(&s, acc, precision, max_iters);
+    const int ev = s.n_evals - 1;
+    if (ev < kTraceCap) {
+      LmTraceRow& r = trace[ev];
+      r.level = expect_level;
+      r.iter = iter_before;
+      r.n_res = (int)acc[28];
+      r.err = s.err_now;
+      r.accepted = (s.status == 0 && !(s.err_now > err_last_before)) ? 1 : 0;
+      r.stop = (s.stop_reason == 3 || s.active) ? 0 : s.stop_reason;
+      r.lambda_after = s.lambda;
+      for (int i = 0; i < 6; i++) r.delta[i] = (s.active || s.stop_reason == 3) ? s.delta[i] : 0.0f;
+      (void)lambda_before;
+    }
+    if (iter_before == 0 && s.iters_level[expect_level & 7] == 1) cost_stat[expect_level * 2 + 0] = s.err_now;
+    cost_stat[expect_level * 2 + 1] = s.err_now;
+    *st = s;
+    if (!s.active && host_flag) {
+      // level finished: tell the polling host (pinned, device-mapped) so it can skip the remaining launches
+      __atomic_store_n(host_flag, expect_level + 1000 * (s.n_evals), __ATOMIC_RELAXED);
+    }
+  }
+}
+
+__global__ void lm_begin_solve_kernel(LmState* __restrict__ st, const float* __restrict__ init, float* __restrict__ cost_stat) {
+  if (threadIdx.x == 0) {
+    LmState s;
+    float m[16];
+    for (int i = 0; i < 16; i++) m[i] = init[i];
+    lm_begin_solve(&s, m);
+    s.level = -1; s.iter = 0; s.lambda = 0.0f; s.err_last = 1e+10f;
+    for (int i = 0; i < 16; i++) s.T[i] = m[i];
+    *st = s;
+    for (int i = 0; i < 16; i++) cost_stat[i] = 0.0f;
+  }
+}
+
+__global__ void lm_begin_level_kernel(LmState* __restrict__ st, int level, float lambda0, int max_iters) {
+  if (threadIdx.x == 0) {
+    LmState s = *st;
+    s.stop_reason = 0;
+    lm_begin_level(&s, level, lambda0, max_iters);
+    *st = s;
+  }
+}
+
+// affine_ = current_estimate.matrix() (ref: src/lm_optimizer.cpp:158), or the pseudo-identity whose (3,3)
+// is 0 on failure (ref: :48-52,60-65). out[16] = pose, out[16] = status as float.
+__global__ void lm_finalize_kernel(const LmState* __restrict__ st, float* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    float m[16];
+    if (st->status == 0) {
+      se3_to_colmajor(st->cur, m);
+    } else {
+      for (int i = 0; i < 16; i++) m[i] = 0.0f;
+      m[0] = 1.0f; m[5] = 1.0f; m[10] = 1.0f;
+    }
+    for (int i = 0; i < 16; i++) out[i] = m[i];
+    out[16] = (float)st->status;
+    out[17] = (float)st->n_evals;
+    for (int i = 0; i < 8; i++) out[18 + i] = (float)st->iters_level[i];
+  }
+}
+
+// =============================================================================================
+// Depth estimator kernels (D2/D3/D5 of SURVEY section 8a)
+// =============================================================================================
+constexpr int kSelCap = 80;      // ref: src/depth_estimate.cpp:334
+constexpr int kSelBlocks = 512;  // 16 x 32 blocks, ref: :302
+constexpr int kSelThreads = 1024;
+constexpr int kSelMaxElems = 4096;
+
+// Point selection (ref: src/depth_estimate.cpp:300-342): one workgroup per 16x32 grid block.
+// |grad| on the blurred left image, block median via an LDS bitonic sort, threshold = median + grad_th,
+// first <= 80 pixels in raster order above the threshold. Outputs the mask and a fixed-slot point list
+// pts[block*80 + k] = x | y<<16, cnt[block].
+__global__ void __launch_bounds__(kSelThreads) depth_select_kernel(const float* __restrict__ L, int rows, int cols, int bnd,
+                                                                    float grad_th, uint8_t* __restrict__ val,
+                                                                    uint32_t* __restrict__ pts, int* __restrict__ cnt) {
+  __shared__ float key[kSelMaxElems];
+  __shared__ float mag[kSelMaxElems];
+  __shared__ int wave_tot[kSelThreads / kWave];
+  __shared__ int base_sh;
+  const int t = threadIdx.x;
+  const int bw = (cols - bnd * 2) / 32, bh = (rows - bnd * 2) / 16;
+  const int bsz = bw * bh;
+  const int b = blockIdx.x;
+  if (bsz <= 0 || bsz > kSelMaxElems) {
+    if (t == 0) cnt[b] = 0;
+    return;
+  }
+  const int sy = bnd + (b / 32) * bh, sx = bnd + (b % 32) * bw;
+  int np2 = 1;
+  while (np2 < bsz) np2 <<= 1;
+  for (int e = t; e < np2; e += kSelThreads) {
+    float m = __builtin_inff();
+    if (e < bsz) {
+      const int y = sy + e / bw, x = sx + e % bw;
+      const float gx = 0.5f * (L[(size_t)y * cols + x + 1] - L[(size_t)y * cols + x - 1]);
+      const float gy = 0.5f * (L[(size_t)(y + 1) * cols + x] - L[(size_t)(y - 1) * cols + x]);
+      m = sqrtf(gx * gx + gy * gy);  // :321
+      mag[e] = m;
+    }
+    key[e] = m;
+  }
+  __syncthreads();
+  for (int k = 2; k <= np2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = t; i < np2; i += kSelThreads) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const float a = key[i], c = key[ixj];
+          const bool up = ((i & k) == 0);
+          if ((a > c) == up) { key[i] = c; key[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const float th = key[bsz / 2] + grad_th;  // :328-329 (nth_element at size/2)
+  if (t == 0) base_sh = 0;
+  __syncthreads();
+  const int lane = t & 63, wv = t >> 6;
+  for (int c0 = 0; c0 < bsz; c0 += kSelThreads) {
+    const int e = c0 + t;
+    const bool f = (e < bsz) && (mag[e] > th);  // :335
+    const unsigned long long bal = __ballot(f);
+    const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wv] = __popcll(bal);
+    __syncthreads();
+    int off = base_sh;
+    for (int w = 0; w < wv; w++) off += wave_tot[w];
+    const int rank = off + pre;
+    if (f && rank < kSelCap) {
+      const int y = sy + e / bw, x = sx + e % bw;
+      val[(size_t)y * cols + x] = 1;  // :336
+      pts[b * kSelCap + rank] = (uint32_t)x | ((uint32_t)y << 16);
+    }
+    __syncthreads();
+    if (t == 0) {
+      int tot = base_sh;
+      for (int w = 0; w < kSelThreads / kWave; w++) tot += wave_tot[w];
+      base_sh = tot;
+    }
+    __syncthreads();
+  }
+  if (t == 0) cnt[b] = (base_sh < kSelCap) ? base_sh : kSelCap;
+}
+
+// Epipolar line search (ref: src/depth_estimate.cpp:345-398): one wavefront per selected point, lanes scan
+// candidate columns right_x = lo + lane, lo + lane + 64, ... (coalesced reads of five right-image rows), each
+// lane keeps its first strict minimum, then a wave-wide (ssd, right_x) argmin where ties take the lowest
+// right_x — the sequential strict-< scan's answer. SSD uses the AVX hadd tree (ssd8_tree).
+__global__ void __launch_bounds__(256) depth_disparity_kernel(const float* __restrict__ L, const float* __restrict__ R,
+                                                               int rows, int cols, int bnd, int max_disp, float ssd_th,
+                                                               float f0, float baseline, const uint32_t* __restrict__ pts,
+                                                               const int* __restrict__ cnt, float* __restrict__ disp,
+                                                               float* __restrict__ dep, float* __restrict__ d0,
+                                                               int* __restrict__ n_matched) {
+  const int lane = threadIdx.x & 63;
+  const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int b = slot / kSelCap, k = slot % kSelCap;
+  if (b >= kSelBlocks || k >= cnt[b]) return;  // wave-uniform
+  const uint32_t pk = pts[slot];
+  const int x = (int)(pk & 0xffffu), y = (int)(pk >> 16);
+  const float* lpp = L + (size_t)(y - 2) * cols;
+  const float* lp = L + (size_t)(y - 1) * cols;
+  const float* lc = L + (size_t)y * cols;
+  const float* ln = L + (size_t)(y + 1) * cols;
+  const float* lnn = L + (size_t)(y + 2) * cols;
+  const float Lp[8] = {lnn[x], ln[x - 1], lc[x + 2], lc[x], lc[x - 2], lp[x + 1], lp[x - 1], lpp[x]};  // :380-381
+  const float* rpp = R + (size_t)(y - 2) * cols;
+  const float* rp = R + (size_t)(y - 1) * cols;
+  const float* rc = R + (size_t)y * cols;
+  const float* rn = R + (size_t)(y + 1) * cols;
+  const float* rnn = R + (size_t)(y + 2) * cols;
+  int lo = bnd;
+  if (max_disp > 0 && x - max_disp > lo) lo = x - max_disp;
+  float best = 1e+10f;  // :367
+  int match = 0x7fffffff;
+  for (int rx = lo + lane; rx < x; rx += kWave) {  // :382
+    const float Rp[8] = {rnn[rx], rn[rx - 1], rc[rx + 2], rc[rx], rc[rx - 2], rp[rx + 1], rp[rx - 1], rpp[rx]};
+    const float s = ssd8_tree(Lp, Rp);
+    if (s < best) { best = s; match = rx; }  // :385-386
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, kWave);
+    const int om = __shfl_xor(match, o, kWave);
+    if (ob < best || (ob == best && om < match)) { best = ob; match = om; }
+  }
+  if (lane == 0) {
+    float dd = 0.0f;
+    if (!(best > ssd_th)) {  // :388
+      const float dsp = (float)(x - match);  // :391
+      dd = dsp / (f0 * baseline);            // :394
+      disp[(size_t)y * cols + x] = dsp;
+      dep[(size_t)y * cols + x] = dd;
+      atomicAdd(n_matched, 1);
+    }
+    d0[slot] = dd;
+  }
+}
+
+struct DepthLmStats {
+  int iters;
+  float cost;
+  int n_valid;
+  int n_selected;
+  int n_matched;
+  int status;
+};
+
+// DepthOptimization (ref: src/depth_estimate.cpp:80-198, 200-242): all points share one accept/reject
+// decision per iteration, so the whole loop runs inside ONE workgroup (no grid-wide barrier, no host round
+// trips). Thread t owns slots t, t+1024, ...; per-slot state lives in L2-resident scratch.
+// Uses the UNBLURRED images (:67).
+constexpr int kDlmThreads = 1024;
+__global__ void __launch_bounds__(kDlmThreads) depth_lm_kernel(const float* __restrict__ left, const float* __restrict__ right,
+                                                                int rows, int cols, const uint32_t* __restrict__ pts,
+                                                                const int* __restrict__ cnt, const float* __restrict__ d0,
+                                                                float* __restrict__ scratch /* 6 x nslots */,
+                                                                float tx, float fx, float huber_delta, float lambda0,
+                                                                float precision, int max_iters, float photo_th,
+                                                                float min_depth, float max_depth, uint8_t* __restrict__ val,
+                                                                float* __restrict__ dep, DepthLmStats* __restrict__ stats) {
+  constexpr int nslots = kSelBlocks * kSelCap;
+  constexpr int per = nslots / kDlmThreads;  // 40
+  __shared__ double shs[kDlmThreads];
+  __shared__ int shn[kDlmThreads];
+  __shared__ int sh_mode;      // 0 reject+continue, 1 accept+continue, 2 reject+break, 3 accept+break
+  __shared__ float sh_lambda;
+  const int t = threadIdx.x;
+  float* cur = scratch;
+  float* pre = scratch + nslots;
+  float* tmp = scratch + 2 * nslots;
+  float* res = scratch + 3 * nslots;  // residual of the last evaluated step (:231), -1000 = out of range
+  float* jt = scratch + 4 * nslots;   // diagonal of JtWJ (:234)
+  float* bb = scratch + 5 * nslots;   // -JtWr (:235)
+  int nsel = 0;
+  for (int j = 0; j < per; j++) {
+    const int s = t + j * kDlmThreads;
+    const bool ok = (s % kSelCap) < cnt[s / kSelCap];
+    nsel += ok;
+    const float v = ok ? d0[s] : 0.0f;
+    cur[s] = v; pre[s] = 0.0f; tmp[s] = v; res[s] = 0.0f; jt[s] = 1.0f; bb[s] = 0.0f;
+  }
+  float lambda = lambda0, err_last = 1e+10f, err_now = 0.0f;
+  int iter = 0;
+  while (max_iters > iter) {  // :141
+    double esum = 0.0;
+    int nact = 0;
+    for (int j = 0; j < per; j++) {
+      const int s = t + j * kDlmThreads;
+      if ((s % kSelCap) >= cnt[s / kSelCap]) continue;
+      const uint32_t pk = pts[s];
+      const int x = (int)(pk & 0xffffu), y = (int)(pk >> 16);
+      const float wf = floorf((float)x - tx * fx * tmp[s]);  // :217
+      if (!(wf >= 2.0f) || !(wf <= (float)(cols - 2))) {     // :219-223
+        jt[s] = 0.0f; bb[s] = 0.0f; res[s] = -1000.0f;
+        continue;
+      }
+      const int wx = (int)wf;
+      const float* Rr = right + (size_t)y * cols;
+      const float r_i = left[(size_t)y * cols + x] - Rr[wx];                                   // :226
+      const float w_i = (fabsf(r_i) <= huber_delta) ? 1.0f : huber_delta / fabsf(r_i);          // :228
+      const float r_diff = tx * fx * 0.5f * (Rr[wx + 1] - Rr[wx - 1]);                          // :229
+      res[s] = fabsf(r_i);
+      nact++;
+      esum += (double)(r_i * r_i * w_i);                                                        // :233
+      jt[s] = r_diff * r_diff * w_i;                                                            // :234
+      bb[s] = -r_diff * w_i * r_i;                                                              // :235
+    }
+    shs[t] = esum;
+    shn[t] = nact;
+    __syncthreads();
+    for (int o = kDlmThreads / 2; o > 0; o >>= 1) {
+      if (t < o) { shs[t] += shs[t + o]; shn[t] += shn[t + o]; }
+      __syncthreads();
+    }
+    if (t == 0) {
+      err_now = (1.0f / (float)shn[0]) * (float)shs[0];  // :239
+      int mode;
+      if (err_now > err_last) {  // :150
+        lambda = lambda * 10.0f;
+        mode = (lambda > 1e+5f) ? 2 : 0;
+      } else {
+        const float err_diff = err_now / err_last;
+        if (err_diff > precision) mode = 3;
+        else { mode = 1; err_last = err_now; lambda = fmaxf(lambda / 10.0f, 1e-7f); }
+      }
+      sh_mode = mode;
+      sh_lambda = lambda;
+    }
+    __syncthreads();
+    const int mode = sh_mode;
+    const float lam = sh_lambda;
+    __syncthreads();
+    if (mode == 2) break;
+    for (int j = 0; j < per; j++) {
+      const int s = t + j * kDlmThreads;
+      if ((s % kSelCap) >= cnt[s / kSelCap]) continue;
+      float c;
+      if (mode == 0) c = pre[s];           // :153
+      else { c = tmp[s]; pre[s] = c; }     // :155-156
+      cur[s] = c;
+      if (mode != 3) {
+        const float jj = jt[s];
+        const float A = jj + lam * jj;        // :164
+        const float dd = (1.0f / A) * bb[s];  // :165
+        tmp[s] = dd + c;                      // :166
+      }
+    }
+    if (mode == 3) break;
+    iter++;
+  }
+  // write-back + filters (:176-191)
+  int nvalid = 0;
+  for (int j = 0; j < per; j++) {
+    const int s = t + j * kDlmThreads;
+    if ((s % kSelCap) >= cnt[s / kSelCap]) continue;
+    const uint32_t pk = pts[s];
+    const size_t o = (size_t)(pk >> 16) * cols + (pk & 0xffffu);
+    const float c = cur[s];
+    const float rs = res[s];
+    bool good = !(rs > photo_th || rs == -1000.0f);
+    if (good && (1.0f / c > max_depth || 1.0f / c < min_depth)) good = false;
+    val[o] = good ? 1 : 0;
+    dep[o] = good ? c : 0.0f;
+    nvalid += good;
+  }
+  shn[t] = nvalid;
+  shs[t] = (double)nsel;
+  __syncthreads();
+  for (int o = kDlmThreads / 2; o > 0; o >>= 1) {
+    if (t < o) { shn[t] += shn[t + o]; shs[t] += shs[t + o]; }
+    __syncthreads();
+  }
+  if (t == 0) {
+    stats->iters = iter;
+    stats->cost = err_now;
+    stats->n_valid = shn[0];
+    stats->n_selected = (int)shs[0];
+    stats->status = (shn[0] < 500) ? -1 : 0;  // :192-197
+  }
+}
+
+__global__ void depth_stats_selected_kernel(const int* __restrict__ cnt, DepthLmStats* __restrict__ stats) {
+  // disparity-only entry: fill n_selected without running the LM
+  __shared__ int sh[kSelBlocks];
+  const int t = threadIdx.x;
+  sh[t] = cnt[t];
+  __syncthreads();
+  for (int o = kSelBlocks / 2; o > 0; o >>= 1) {
+    if (t < o) sh[t] += sh[t + o];
+    __syncthreads();
+  }
+  if (t == 0) { stats->n_selected = sh[0]; stats->iters = 0; stats->cost = 0.0f; stats->n_valid = 0; stats->status = 0; }
+}
+
+}  // namespace odo

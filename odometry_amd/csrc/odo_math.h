@@ -1,0 +1,413 @@
+// odo_math.h — per-point photometric chain, SE(3) update and damped 6x6 solve.
+//
+// Single source for the arithmetic the HIP kernels execute. Every fp32 operation here rounds once
+// (compile with -ffp-contract=off; FMA is only used where it is exact by construction), so the
+// results are a function of the inputs alone. Marked ODO_HD so tests can also compile these
+// functions for the host and step them against the oracle without a GPU (tests/hostemu.cpp) —
+// the product library only ever calls them from device code.
+//
+// Arithmetic spec (what "parity mode" means) follows the reference line by line:
+//   reproject / warp / gradient / Jacobian  ref: src/lm_optimizer.cpp:190-237,
+//                                                include/image_processing_global.h:22-69
+//   LM accept/reject + damping               ref: src/lm_optimizer.cpp:117-155
+//   SE3 exp / matrix / ctor-from-4x4          ref: third_party/Sophus/sophus/se3.hpp:272-278,495-502,765-786
+//                                                third_party/Sophus/sophus/so3.hpp:302-304,463-468,577-611
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define ODO_HD __host__ __device__ __forceinline__
+#else
+#define ODO_HD static inline
+#endif
+
+#define ODO_NACC 29  // 21 upper-tri JtWJ + 6 JtWr + sum(w r^2) + N
+
+namespace odo {
+
+// ---------------------------------------------------------------------------------------------
+// Level intrinsics. ref: image_processing_global.h:22-28 (GetCxLevel), :35 (718.856f / pow(2.0f, level)).
+// std::pow(float,int) is double, so the focal length of a level is carried in double (exact: power-of-2 scale).
+// ---------------------------------------------------------------------------------------------
+struct LevelK {
+  double fl;   // f0 / 2^level
+  float cx, cy;
+};
+
+ODO_HD float cx_level(float c, int level) {
+  float v = c;
+  for (int i = 0; i < level; i++) v = (v + 0.5f) / 2.0f + 0.5f;
+  return v;
+}
+ODO_HD LevelK make_level_k(float f0, float cx0, float cy0, int level) {
+  LevelK k;
+  double s = 1.0;
+  for (int i = 0; i < level; i++) s *= 2.0;
+  k.fl = (double)f0 / s;
+  k.cx = cx_level(cx0, level);
+  k.cy = cx_level(cy0, level);
+  return k;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Keyframe-side constants of one semi-dense point: everything that does not depend on the pose.
+// (Back-projection and the geometric Jacobian are evaluated at the UN-warped point,
+//  ref: lm_optimizer.cpp:219-234, so they can be computed once per keyframe.)
+// ---------------------------------------------------------------------------------------------
+struct PointK {
+  float X, Y, Z;       // ReprojectToCameraFrame, ref: image_processing_global.h:35-38
+  float i1;            // keyframe intensity I1(y,x)
+  float fx_z;          // jw(0,0) = jw(1,1)
+  float jw02, jw03, jw04, jw05, jw12, jw13, jw14, jw15;
+};
+
+ODO_HD bool depth_valid(float d) { return !(fabsf(d - 0.0f) < 0.01f); }  // ref: lm_optimizer.cpp:193
+
+ODO_HD PointK make_point(int x, int y, float inv_depth, float i1, const LevelK& k) {
+  PointK p;
+  const float z = 1.0f / inv_depth;                                   // :198
+  p.X = (float)((double)(z * ((float)x - k.cx)) / k.fl);              // h:35
+  p.Y = (float)((double)(z * ((float)y - k.cy)) / k.fl);              // h:36
+  p.Z = z;
+  p.i1 = i1;
+  const float fx_z = (float)(k.fl / (double)p.Z);                     // :223
+  const float xy = p.X * p.Y, xx = p.X * p.X, yy = p.Y * p.Y, zz = p.Z * p.Z;
+  p.fx_z = fx_z;
+  p.jw02 = (-fx_z * p.X) / p.Z;                                       // :232
+  p.jw03 = (-fx_z * xy) / p.Z;
+  p.jw04 = (float)(k.fl * (1.0 + (double)(xx / zz)));
+  p.jw05 = -fx_z * p.Y;
+  p.jw12 = (-fx_z * p.Y) / p.Z;                                       // :233
+  p.jw13 = (float)(-k.fl * (1.0 + (double)(yy / zz)));
+  p.jw14 = (fx_z * xy) / p.Z;
+  p.jw15 = fx_z * p.X;
+  return p;
+}
+
+// Warp by T (column-major 4x4), project, floor. Returns false when the point is skipped
+// (ref: image_processing_global.h:42-59). ui/vi = floor(u), floor(v).
+ODO_HD bool warp_point(const PointK& p, const float* T, const LevelK& k, int rows, int cols, int* ui, int* vi) {
+  const float t0 = ((T[0] * p.X + T[4] * p.Y) + T[8] * p.Z) + T[12];
+  const float t1 = ((T[1] * p.X + T[5] * p.Y) + T[9] * p.Z) + T[13];
+  const float t2 = ((T[2] * p.X + T[6] * p.Y) + T[10] * p.Z) + T[14];
+  if (!(t2 > 0.0f)) return false;
+  const float u = (float)(k.fl * (double)t0 / (double)t2 + (double)k.cx);
+  const float v = (float)(k.fl * (double)t1 / (double)t2 + (double)k.cy);
+  const float fu = floorf(u), fv = floorf(v);
+  if (!(fu < (float)cols) || !(fv < (float)rows) || !(fu >= 0.0f) || !(fv >= 0.0f)) return false;
+  *ui = (int)fu;
+  *vi = (int)fv;
+  return true;
+}
+
+// Residual + Jacobian row at the floor-sampled pixel (ref: lm_optimizer.cpp:215-234,
+// image_processing_global.h:62-69). I2: level image of the current frame, row-major.
+ODO_HD void residual_jacobian(const PointK& p, const float* I2, int rows, int cols, int ui, int vi, float* r, float J[6]) {
+  const int px = (ui - 1 >= 0) ? ui - 1 : 0, nx = (ui + 1 < cols) ? ui + 1 : cols - 1;
+  const int py = (vi - 1 >= 0) ? vi - 1 : 0, ny = (vi + 1 < rows) ? vi + 1 : rows - 1;
+  const float* row = I2 + (size_t)vi * cols;
+  const float gx = 0.5f * (row[nx] - row[px]);
+  const float gy = 0.5f * (I2[(size_t)ny * cols + ui] - I2[(size_t)py * cols + ui]);
+  *r = row[ui] - p.i1;
+  J[0] = gx * p.fx_z + gy * 0.0f;
+  J[1] = gx * 0.0f + gy * p.fx_z;
+  J[2] = gx * p.jw02 + gy * p.jw12;
+  J[3] = gx * p.jw03 + gy * p.jw13;
+  J[4] = gx * p.jw04 + gy * p.jw14;
+  J[5] = gx * p.jw05 + gy * p.jw15;
+}
+
+// Robust weight (ref: lm_optimizer.cpp:249-262). scale_sqr only used by mode 2.
+ODO_HD float robust_weight(float r, int robust, float huber_delta, float scale_sqr) {
+  if (robust == 1) return (fabsf(r) <= huber_delta) ? 1.0f : huber_delta / fabsf(r);
+  if (robust == 2) return (200.0f + 1.0f) / (200.0f + r * r / scale_sqr);
+  return 1.0f;
+}
+
+// acc += one weighted row. Products of two fp32 values are exact in fp64, so fma == mul-then-add here.
+ODO_HD void accumulate_row(double acc[ODO_NACC], float r, float w, const float J[6]) {
+  double jw[6], Jd[6];
+  for (int a = 0; a < 6; a++) { jw[a] = (double)(J[a] * w); Jd[a] = (double)J[a]; }
+  int k = 0;
+  for (int a = 0; a < 6; a++)
+    for (int b = a; b < 6; b++) { acc[k] = fma(jw[a], Jd[b], acc[k]); k++; }
+  const double rd = (double)r;
+  for (int a = 0; a < 6; a++) acc[21 + a] = fma(jw[a], rd, acc[21 + a]);
+  acc[27] = fma((double)(r * w), rd, acc[27]);
+  acc[28] += 1.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sin/cos of an fp32 argument, evaluated in fp64 and rounded once (deterministic on host and device).
+// ---------------------------------------------------------------------------------------------
+ODO_HD void sincos_f(float xf, float* s_out, float* c_out) {
+  const double x = (double)xf;
+  const double kf = floor(x * 6.36619772367581382433e-01 + 0.5);
+  const double r = (x - kf * 1.57079632673412561417e+00) - kf * 6.07710050650619224932e-11;
+  const double r2 = r * r;
+  double ps = 1.0 / 355687428096000.0;
+  ps = ps * r2 - 1.0 / 1307674368000.0;
+  ps = ps * r2 + 1.0 / 6227020800.0;
+  ps = ps * r2 - 1.0 / 39916800.0;
+  ps = ps * r2 + 1.0 / 362880.0;
+  ps = ps * r2 - 1.0 / 5040.0;
+  ps = ps * r2 + 1.0 / 120.0;
+  ps = ps * r2 - 1.0 / 6.0;
+  ps = ps * r2 + 1.0;
+  const double sr = ps * r;
+  double pc = 1.0 / 6402373705728000.0;
+  pc = pc * r2 - 1.0 / 20922789888000.0;
+  pc = pc * r2 + 1.0 / 87178291200.0;
+  pc = pc * r2 - 1.0 / 479001600.0;
+  pc = pc * r2 + 1.0 / 3628800.0;
+  pc = pc * r2 - 1.0 / 40320.0;
+  pc = pc * r2 + 1.0 / 720.0;
+  pc = pc * r2 - 1.0 / 24.0;
+  pc = pc * r2 + 1.0 / 2.0;
+  pc = pc * r2;
+  const double cr = 1.0 - pc;
+  const int q = (int)((long long)kf & 3);
+  double s, c;
+  if (q == 0) { s = sr; c = cr; }
+  else if (q == 1) { s = cr; c = -sr; }
+  else if (q == 2) { s = -sr; c = -cr; }
+  else { s = -cr; c = sr; }
+  *s_out = (float)s;
+  *c_out = (float)c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SE(3) as Sophus stores it: unit quaternion (x,y,z,w) + translation, fp32.
+// ---------------------------------------------------------------------------------------------
+struct Se3 {
+  float qx, qy, qz, qw, tx, ty, tz;
+};
+
+// Eigen Quaternion(Matrix3) — trace-based, no renormalisation (so3.hpp:463-468). R row-major.
+ODO_HD void rot_to_quat(const float R[9], Se3* o) {
+  float q[4];
+  float t = (R[0] + R[4]) + R[8];
+  if (t > 0.0f) {
+    t = sqrtf(t + 1.0f);
+    q[3] = 0.5f * t;
+    t = 0.5f / t;
+    q[0] = (R[7] - R[5]) * t;
+    q[1] = (R[2] - R[6]) * t;
+    q[2] = (R[3] - R[1]) * t;
+  } else {
+    int i = 0;
+    if (R[4] > R[0]) i = 1;
+    if (R[8] > R[i * 4]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrtf(((R[i * 4] - R[j * 4]) - R[k * 4]) + 1.0f);
+    q[i] = 0.5f * t;
+    t = 0.5f / t;
+    q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t;
+    q[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
+    q[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+  }
+  o->qx = q[0]; o->qy = q[1]; o->qz = q[2]; o->qw = q[3];
+}
+
+// Eigen Quaternion::toRotationMatrix (so3.hpp:302-304). R row-major.
+ODO_HD void quat_to_rot(const Se3& s, float R[9]) {
+  const float tx = 2.0f * s.qx, ty = 2.0f * s.qy, tz = 2.0f * s.qz;
+  const float twx = tx * s.qw, twy = ty * s.qw, twz = tz * s.qw;
+  const float txx = tx * s.qx, txy = ty * s.qx, txz = tz * s.qx;
+  const float tyy = ty * s.qy, tyz = tz * s.qy, tzz = tz * s.qz;
+  R[0] = 1.0f - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+  R[3] = txy + twz; R[4] = 1.0f - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1.0f - (txx + tyy);
+}
+
+ODO_HD void se3_from_colmajor(const float M[16], Se3* o) {  // se3.hpp:495-502
+  float R[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) R[i * 3 + j] = M[j * 4 + i];
+  rot_to_quat(R, o);
+  o->tx = M[12]; o->ty = M[13]; o->tz = M[14];
+}
+ODO_HD void se3_to_colmajor(const Se3& s, float M[16]) {     // se3.hpp:272-278
+  float R[9];
+  quat_to_rot(s, R);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) M[j * 4 + i] = R[i * 3 + j];
+  M[3] = 0.0f; M[7] = 0.0f; M[11] = 0.0f;
+  M[12] = s.tx; M[13] = s.ty; M[14] = s.tz; M[15] = 1.0f;
+}
+
+// SE3::exp, a = [upsilon; omega] (se3.hpp:765-786, so3.hpp:577-611).
+ODO_HD void se3_exp(const float a[6], Se3* o) {
+  const float ox = a[3], oy = a[4], oz = a[5];
+  const float theta_sq = (ox * ox + oy * oy) + oz * oz;
+  const float theta = sqrtf(theta_sq);
+  const float half_theta = 0.5f * theta;
+  float imag, real;
+  if (theta < 1e-5f) {
+    const float theta_po4 = theta_sq * theta_sq;
+    imag = (0.5f - (float)(1.0 / 48.0) * theta_sq) + (float)(1.0 / 3840.0) * theta_po4;
+    real = (1.0f - (float)(1.0 / 8.0) * theta_sq) + (float)(1.0 / 384.0) * theta_po4;
+  } else {
+    float sh, ch;
+    sincos_f(half_theta, &sh, &ch);
+    imag = sh / theta;
+    real = ch;
+  }
+  o->qw = real; o->qx = imag * ox; o->qy = imag * oy; o->qz = imag * oz;
+  const float Om[9] = {0.0f, -oz, oy, oz, 0.0f, -ox, -oy, ox, 0.0f};
+  float Om2[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      Om2[i * 3 + j] = (Om[i * 3 + 0] * Om[0 * 3 + j] + Om[i * 3 + 1] * Om[1 * 3 + j]) + Om[i * 3 + 2] * Om[2 * 3 + j];
+  float V[9];
+  if (theta < 1e-5f) {
+    quat_to_rot(*o, V);
+  } else {
+    float st, ct;
+    sincos_f(theta, &st, &ct);
+    const float tsq = theta * theta;
+    const float ca = (1.0f - ct) / tsq;
+    const float cb = (theta - st) / (tsq * theta);
+    for (int i = 0; i < 9; i++) {
+      const float id = (i == 0 || i == 4 || i == 8) ? 1.0f : 0.0f;
+      V[i] = (id + ca * Om[i]) + cb * Om2[i];
+    }
+  }
+  o->tx = (V[0] * a[0] + V[1] * a[1]) + V[2] * a[2];
+  o->ty = (V[3] * a[0] + V[4] * a[1]) + V[5] * a[2];
+  o->tz = (V[6] * a[0] + V[7] * a[1]) + V[8] * a[2];
+}
+
+// inc = SE3(delta.matrix() * cur.matrix()) (lm_optimizer.cpp:152-153): plain 4x4 fp32 product, k ascending.
+ODO_HD void se3_left_update(const Se3& delta, const Se3& cur, Se3* out) {
+  float D[16], C[16], M[16];
+  se3_to_colmajor(delta, D);
+  se3_to_colmajor(cur, C);
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++)
+      M[j * 4 + i] = ((D[0 * 4 + i] * C[j * 4 + 0] + D[1 * 4 + i] * C[j * 4 + 1]) + D[2 * 4 + i] * C[j * 4 + 2]) +
+                     D[3 * 4 + i] * C[j * 4 + 3];
+  se3_from_colmajor(M, out);
+}
+
+// Damped normal equations A = JtWJ + lambda*diag(JtWJ), b = -JtWr (lm_optimizer.cpp:145-151), solved in fp64
+// by Gaussian elimination with partial pivoting; a zero pivot gives a zero step component. Step rounded to fp32.
+ODO_HD void solve_damped(const double acc[ODO_NACC], float lambda, float delta[6]) {
+  double A[6][7];
+  int k = 0;
+  for (int a = 0; a < 6; a++)
+    for (int b = a; b < 6; b++) { A[a][b] = acc[k]; A[b][a] = acc[k]; k++; }
+  for (int a = 0; a < 6; a++) {
+    A[a][a] = A[a][a] + (double)lambda * A[a][a];
+    A[a][6] = -acc[21 + a];
+  }
+  bool ok[6];
+  for (int c = 0; c < 6; c++) {
+    int p = c;
+    double best = fabs(A[c][c]);
+    for (int i = c + 1; i < 6; i++)
+      if (fabs(A[i][c]) > best) { best = fabs(A[i][c]); p = i; }
+    if (!(best > 0.0)) { ok[c] = false; continue; }
+    ok[c] = true;
+    if (p != c)
+      for (int j = 0; j < 7; j++) { const double t = A[c][j]; A[c][j] = A[p][j]; A[p][j] = t; }
+    for (int i = c + 1; i < 6; i++) {
+      const double f = A[i][c] / A[c][c];
+      for (int j = c; j < 7; j++) A[i][j] = A[i][j] - f * A[c][j];
+    }
+  }
+  double xs[6];
+  for (int c = 5; c >= 0; c--) {
+    if (!ok[c]) { xs[c] = 0.0; continue; }
+    double s = A[c][6];
+    for (int j = c + 1; j < 6; j++) s = s - A[c][j] * xs[j];
+    xs[c] = s / A[c][c];
+  }
+  for (int c = 0; c < 6; c++) delta[c] = (float)xs[c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// LM state machine of one Solve (lm_optimizer.cpp:73-160), advanced one evaluation at a time.
+// ---------------------------------------------------------------------------------------------
+struct LmState {
+  Se3 cur, inc, last;
+  float T[16];        // inc.matrix(), column-major: the pose the next evaluation uses
+  float lambda, err_last, err_now;
+  int level;          // level being optimised
+  int iter;           // iter_count inside the level
+  int active;         // 1 while the level's while-loop is running
+  int status;         // 0 ok, -1 failed (N == 0)
+  int n_evals;        // evaluations consumed so far
+  int stop_reason;    // last stop: 1 precision, 2 lambda, 3 max iters
+  int iters_level[8]; // evaluations per level (diagnostic; the reference never fills its own stats)
+  float delta[6];     // last solved step
+};
+
+ODO_HD void lm_begin_solve(LmState* s, const float init_colmajor[16]) {
+  se3_from_colmajor(init_colmajor, &s->cur);  // :76
+  s->inc = s->cur;                            // :77
+  s->last = s->cur;                           // :78
+  s->status = 0;
+  s->n_evals = 0;
+  s->active = 0;
+  s->stop_reason = 0;
+  s->err_now = 0.0f;
+  for (int i = 0; i < 8; i++) s->iters_level[i] = 0;
+  for (int i = 0; i < 6; i++) s->delta[i] = 0.0f;
+}
+
+ODO_HD void lm_begin_level(LmState* s, int level, float lambda0, int max_iters) {
+  s->level = level;
+  s->iter = 0;
+  s->err_last = 1e+10f;        // :111
+  s->lambda = lambda0;         // :113
+  s->inc = s->cur;             // :115
+  s->active = (s->status == 0 && max_iters > 0) ? 1 : 0;
+  se3_to_colmajor(s->inc, s->T);
+}
+
+// Consume the accumulators of one evaluation at pose s->T (lm_optimizer.cpp:123-154).
+ODO_HD void lm_consume(LmState* s, const double acc[ODO_NACC], float precision, int max_iters) {
+  s->n_evals++;
+  s->iters_level[s->level & 7]++;
+  if (!(acc[28] > 0.0)) {      // :244-248 -> :123-126
+    s->status = -1;
+    s->active = 0;
+    return;
+  }
+  const float err_now = (float)(acc[27] / acc[28]);  // :129
+  s->err_now = err_now;
+  if (err_now > s->err_last) {                       // :131
+    s->lambda = s->lambda * 5.0f;
+    if (s->lambda > 1e+5f) { s->active = 0; s->stop_reason = 2; return; }
+    s->cur = s->last;
+  } else {
+    s->cur = s->inc;
+    s->last = s->cur;
+    const float err_diff = err_now / s->err_last;
+    if (err_diff > precision) { s->active = 0; s->stop_reason = 1; return; }
+    s->err_last = err_now;
+    s->lambda = fmaxf(s->lambda / 5.0f, 1e-5f);
+  }
+  solve_damped(acc, s->lambda, s->delta);            // :145-151
+  Se3 d;
+  se3_exp(s->delta, &d);                             // :152
+  se3_left_update(d, s->cur, &s->inc);               // :153
+  se3_to_colmajor(s->inc, s->T);
+  s->iter++;                                         // :154
+  if (!(max_iters > s->iter)) { s->active = 0; s->stop_reason = 3; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Depth estimator pieces (ref: src/depth_estimate.cpp).
+// ---------------------------------------------------------------------------------------------
+// 8-tap SSD with the AVX hadd tree of ComputeSsdPattern8Sse (depth_estimate.cpp:435-453).
+// Lane order s0=(0,+2) s1=(-1,+1) s2=(+2,0) s3=(0,0) s4=(-2,0) s5=(+1,-1) s6=(-1,-1) s7=(0,-2) as (dx,dy).
+ODO_HD float ssd8_tree(const float L[8], const float R[8]) {
+  float s[8];
+  for (int i = 0; i < 8; i++) { const float d = L[i] - R[i]; s[i] = d * d; }
+  return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
+
+}  // namespace odo

@@ -1,0 +1,671 @@
+// odometry_hip.hip — C ABI (include/odometry_hip.h) over the gfx950 kernels in kernels.hip.h.
+// Host side only sequences launches on the context's HIP stream; all arithmetic of the hot path runs on
+// the device. There is no CPU fallback: every entry point fails with -1 if HIP does.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "../../include/odometry_hip.h"
+#include "kernels.hip.h"
+
+using namespace odo;
+
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return -1;
+}
+#define HIP_OK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+extern "C" const char* odo_last_error(void) { return g_err; }
+extern "C" int odo_version(void) { return 100; }
+
+// ------------------------------------------------------------------------------------------------
+struct odo_ctx {
+  int device;
+  hipStream_t stream;
+  hipEvent_t ev0, ev1;
+};
+
+extern "C" int odo_ctx_create(int device, odo_ctx** out) {
+  if (!out) return fail("odo_ctx_create: out is NULL");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail("odo_ctx_create: no HIP device (this library has no CPU path)");
+  if (device < 0 || device >= n) return fail("odo_ctx_create: device %d out of range (have %d)", device, n);
+  HIP_OK(hipSetDevice(device));
+  odo_ctx* c = new (std::nothrow) odo_ctx();
+  if (!c) return fail("odo_ctx_create: out of memory");
+  c->device = device;
+  HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_OK(hipEventCreate(&c->ev0));
+  HIP_OK(hipEventCreate(&c->ev1));
+  *out = c;
+  return 0;
+}
+extern "C" int odo_ctx_destroy(odo_ctx* c) {
+  if (!c) return 0;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipEventDestroy(c->ev0);
+  (void)hipEventDestroy(c->ev1);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+extern "C" int odo_ctx_synchronize(odo_ctx* c) {
+  if (!c) return fail("odo_ctx_synchronize: NULL ctx");
+  HIP_OK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+extern "C" int odo_ctx_timer_start(odo_ctx* c) {
+  if (!c) return fail("NULL ctx");
+  HIP_OK(hipEventRecord(c->ev0, c->stream));
+  return 0;
+}
+extern "C" int odo_ctx_timer_stop(odo_ctx* c, float* ms) {
+  if (!c || !ms) return fail("NULL arg");
+  HIP_OK(hipEventRecord(c->ev1, c->stream));
+  HIP_OK(hipEventSynchronize(c->ev1));
+  HIP_OK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return 0;
+}
+extern "C" int odo_dev_alloc(odo_ctx* c, size_t bytes, void** out) {
+  if (!c || !out) return fail("NULL arg");
+  HIP_OK(hipSetDevice(c->device));
+  HIP_OK(hipMalloc(out, bytes));
+  return 0;
+}
+extern "C" int odo_dev_free(odo_ctx* c, void* p) {
+  if (!c) return fail("NULL ctx");
+  HIP_OK(hipStreamSynchronize(c->stream));
+  HIP_OK(hipFree(p));
+  return 0;
+}
+extern "C" int odo_dev_upload(odo_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (!c) return fail("NULL ctx");
+  HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_OK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+extern "C" int odo_dev_download(odo_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (!c) return fail("NULL ctx");
+  HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_OK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+static inline dim3 grid2d(int cols, int rows, int z = 1) { return dim3((cols + 63) / 64, (rows + 3) / 4, z); }
+
+// ------------------------------------------------------------------------------------------------
+// Pyramids
+// ------------------------------------------------------------------------------------------------
+struct odo_pyr {
+  odo_ctx* ctx;
+  int kind, levels, rows, cols;
+  float* dev;      // all levels back to back
+  float* staging;  // level-0-sized device copy of a host input (IMAGE kind: pyrDown reads the unsmoothed input)
+  size_t off[ODO_MAX_LEVELS];
+  int r[ODO_MAX_LEVELS], c[ODO_MAX_LEVELS];
+};
+
+static int pyr_build(odo_pyr* p, const float* img_dev, int smooth) {
+  hipStream_t s = p->ctx->stream;
+  const int rows = p->rows, cols = p->cols;
+  if (p->kind == ODO_PYR_IMAGE) {
+    if (smooth) {
+      hipLaunchKernelGGL(blur3x3_kernel, grid2d(cols, rows), dim3(256), 0, s, img_dev, p->dev, img_dev, p->dev, rows, cols);
+    } else {
+      HIP_OK(hipMemcpyAsync(p->dev, img_dev, sizeof(float) * (size_t)rows * cols, hipMemcpyDeviceToDevice, s));
+    }
+    const float* prev = img_dev;  // L1 comes from the UNSMOOTHED input (ref: src/image_processing_global.cpp:38)
+    for (int l = 1; l < p->levels; l++) {
+      hipLaunchKernelGGL(pyrdown_kernel, grid2d(p->c[l], p->r[l]), dim3(256), 0, s, prev, p->r[l - 1], p->c[l - 1],
+                         p->dev + p->off[l]);
+      prev = p->dev + p->off[l];
+    }
+  } else {
+    if (smooth) return fail("depth pyramid smoothing (cv::medianBlur) is not implemented: no reference caller uses it");
+    HIP_OK(hipMemcpyAsync(p->dev, img_dev, sizeof(float) * (size_t)rows * cols, hipMemcpyDeviceToDevice, s));
+    for (int l = 1; l < p->levels; l++)
+      hipLaunchKernelGGL(decimate_odd_kernel, grid2d(p->c[l], p->r[l]), dim3(256), 0, s, p->dev + p->off[l - 1],
+                         p->c[l - 1], p->dev + p->off[l], p->r[l], p->c[l]);
+  }
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+static int pyr_alloc(odo_ctx* ctx, int rows, int cols, int levels, int kind, odo_pyr** out) {
+  if (!ctx || !out) return fail("pyramid: NULL arg");
+  *out = nullptr;
+  if (levels < 1 || levels > ODO_MAX_LEVELS) return fail("pyramid: levels %d out of range", levels);
+  if (rows < 1 || cols < 1) return fail("pyramid: bad size %dx%d", rows, cols);
+  if (kind != ODO_PYR_IMAGE && kind != ODO_PYR_DEPTH) return fail("pyramid: bad kind %d", kind);
+  odo_pyr* p = new (std::nothrow) odo_pyr();
+  if (!p) return fail("out of memory");
+  p->ctx = ctx; p->kind = kind; p->levels = levels; p->rows = rows; p->cols = cols;
+  p->dev = nullptr; p->staging = nullptr;
+  size_t tot = 0;
+  int r = rows, c = cols;
+  for (int l = 0; l < levels; l++) {
+    p->off[l] = tot; p->r[l] = r; p->c[l] = c;
+    tot += (size_t)r * c;
+    r /= 2; c /= 2;
+    if ((r < 1 || c < 1) && l + 1 < levels) { delete p; return fail("pyramid: image too small for %d levels", levels); }
+  }
+  HIP_OK(hipSetDevice(ctx->device));
+  HIP_OK(hipMalloc((void**)&p->dev, sizeof(float) * tot));
+  *out = p;
+  return 0;
+}
+
+extern "C" int odo_pyramid_create(odo_ctx* ctx, const float* img, int rows, int cols, size_t stride_bytes, int levels,
+                                  int smooth, int kind, odo_pyr** out) {
+  if (!img) return fail("odo_pyramid_create: NULL image");
+  if (stride_bytes == 0) stride_bytes = sizeof(float) * (size_t)cols;
+  if (stride_bytes < sizeof(float) * (size_t)cols) return fail("odo_pyramid_create: stride smaller than a row");
+  odo_pyr* p = nullptr;
+  if (pyr_alloc(ctx, rows, cols, levels, kind, &p)) return -1;
+  if (hipMalloc((void**)&p->staging, sizeof(float) * (size_t)rows * cols) != hipSuccess) {
+    odo_pyramid_destroy(p);
+    return fail("odo_pyramid_create: hipMalloc failed");
+  }
+  hipError_t e = hipMemcpy2DAsync(p->staging, sizeof(float) * (size_t)cols, img, stride_bytes, sizeof(float) * (size_t)cols,
+                                  rows, hipMemcpyHostToDevice, ctx->stream);
+  if (e != hipSuccess) { odo_pyramid_destroy(p); return fail("odo_pyramid_create: upload failed: %s", hipGetErrorString(e)); }
+  if (pyr_build(p, p->staging, smooth)) { odo_pyramid_destroy(p); return -1; }
+  *out = p;
+  return 0;
+}
+
+extern "C" int odo_pyramid_create_dev(odo_ctx* ctx, const float* img_dev, int rows, int cols, int levels, int smooth,
+                                      int kind, odo_pyr** out) {
+  if (!img_dev) return fail("odo_pyramid_create_dev: NULL image");
+  odo_pyr* p = nullptr;
+  if (pyr_alloc(ctx, rows, cols, levels, kind, &p)) return -1;
+  if (pyr_build(p, img_dev, smooth)) { odo_pyramid_destroy(p); return -1; }
+  *out = p;
+  return 0;
+}
+
+extern "C" int odo_pyramid_rebuild_dev(odo_pyr* p, const float* img_dev, int smooth) {
+  if (!p || !img_dev) return fail("odo_pyramid_rebuild_dev: NULL arg");
+  return pyr_build(p, img_dev, smooth);
+}
+
+extern "C" int odo_pyramid_levels(const odo_pyr* p) { return p ? p->levels : -1; }
+extern "C" int odo_pyramid_level_dims(const odo_pyr* p, int level, int* rows, int* cols) {
+  if (!p || level < 0 || level >= p->levels) return fail("odo_pyramid_level_dims: bad level");
+  if (rows) *rows = p->r[level];
+  if (cols) *cols = p->c[level];
+  return 0;
+}
+extern "C" int odo_pyramid_download(const odo_pyr* p, int level, float* dst) {
+  if (!p || !dst) return fail("odo_pyramid_download: NULL arg");
+  if (level < 0 || level >= p->levels)  // ref: src/image_pyramid.cpp:22-25 exits the process; here: -1
+    return fail("Requested image pyramid does not exist! Max pyramid id: %d", p->levels - 1);
+  HIP_OK(hipMemcpyAsync(dst, p->dev + p->off[level], sizeof(float) * (size_t)p->r[level] * p->c[level],
+                        hipMemcpyDeviceToHost, p->ctx->stream));
+  HIP_OK(hipStreamSynchronize(p->ctx->stream));
+  return 0;
+}
+extern "C" const float* odo_pyramid_level_dev(const odo_pyr* p, int level) {
+  if (!p || level < 0 || level >= p->levels) return nullptr;
+  return p->dev + p->off[level];
+}
+extern "C" int odo_pyramid_destroy(odo_pyr* p) {
+  if (!p) return 0;
+  (void)hipStreamSynchronize(p->ctx->stream);
+  if (p->dev) (void)hipFree(p->dev);
+  if (p->staging) (void)hipFree(p->staging);
+  delete p;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pose LM
+// ------------------------------------------------------------------------------------------------
+static const odo_intrinsics kKitti00 = {718.856f, (float)607.1928, (float)185.2157};
+constexpr int kLmMaxBlocks = 512;
+
+struct odo_lm {
+  odo_ctx* ctx;
+  float lambda, precision, huber_delta;
+  int n_levels, robust;
+  int max_iters[ODO_MAX_LEVELS];
+  odo_intrinsics K;
+  float init[16];
+  // device
+  LmState* d_state;
+  double* d_partials;
+  float* d_init;
+  float* d_out;  // 26 floats
+  LmTraceRow* d_trace;
+  float* d_cost;  // 16 floats
+  float* d_res;   // t-dist residual buffer (lazy)
+  size_t res_cap;
+  float* d_scale;
+  // pinned host mirrors
+  float* h_out;
+  LmTraceRow* h_trace;
+  float* h_cost;
+  // stats of the last solve
+  int last_evals, last_launches;
+  double last_bytes;
+  int iters[ODO_MAX_LEVELS];
+  int launches_level[ODO_MAX_LEVELS];
+};
+
+extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const int* max_iters, int n_levels,
+                             const float init_colmajor[16], int robust, float huber_delta, const odo_intrinsics* K,
+                             odo_lm** out) {
+  if (!ctx || !out || !max_iters || !init_colmajor) return fail("odo_lm_create: NULL arg");
+  *out = nullptr;
+  if (n_levels < 1 || n_levels > ODO_MAX_LEVELS) return fail("odo_lm_create: n_levels %d out of range", n_levels);
+  if (robust < 0 || robust > 2) return fail("odo_lm_create: robust must be 0, 1 or 2");
+  odo_lm* m = new (std::nothrow) odo_lm();
+  if (!m) return fail("out of memory");
+  memset(m, 0, sizeof(*m));
+  m->ctx = ctx; m->lambda = lambda; m->precision = precision; m->huber_delta = huber_delta;
+  m->n_levels = n_levels; m->robust = robust;
+  for (int i = 0; i < n_levels; i++) m->max_iters[i] = max_iters[i];
+  m->K = K ? *K : kKitti00;  // null camera: the reference only warns (ref: src/lm_optimizer.cpp:35-38)
+  memcpy(m->init, init_colmajor, sizeof(m->init));
+  HIP_OK(hipSetDevice(ctx->device));
+  HIP_OK(hipMalloc((void**)&m->d_state, sizeof(LmState)));
+  HIP_OK(hipMalloc((void**)&m->d_partials, sizeof(double) * kLmMaxBlocks * ODO_NACC));
+  HIP_OK(hipMalloc((void**)&m->d_init, sizeof(float) * 16));
+  HIP_OK(hipMalloc((void**)&m->d_out, sizeof(float) * 26));
+  HIP_OK(hipMalloc((void**)&m->d_trace, sizeof(LmTraceRow) * kTraceCap));
+  HIP_OK(hipMalloc((void**)&m->d_cost, sizeof(float) * 16));
+  HIP_OK(hipMalloc((void**)&m->d_scale, sizeof(float)));
+  HIP_OK(hipHostMalloc((void**)&m->h_out, sizeof(float) * 26, hipHostMallocDefault));
+  HIP_OK(hipHostMalloc((void**)&m->h_trace, sizeof(LmTraceRow) * kTraceCap, hipHostMallocDefault));
+  HIP_OK(hipHostMalloc((void**)&m->h_cost, sizeof(float) * 16, hipHostMallocDefault));
+  HIP_OK(hipMemsetAsync(m->d_trace, 0, sizeof(LmTraceRow) * kTraceCap, ctx->stream));
+  memset(m->h_trace, 0, sizeof(LmTraceRow) * kTraceCap);
+  memset(m->h_cost, 0, sizeof(float) * 16);
+  *out = m;
+  return 0;
+}
+
+extern "C" int odo_lm_destroy(odo_lm* m) {
+  if (!m) return 0;
+  (void)hipStreamSynchronize(m->ctx->stream);
+  void* dv[] = {m->d_state, m->d_partials, m->d_init, m->d_out, m->d_trace, m->d_cost, m->d_scale, m->d_res};
+  for (void* q : dv) if (q) (void)hipFree(q);
+  (void)hipHostFree(m->h_out); (void)hipHostFree(m->h_trace); (void)hipHostFree(m->h_cost);
+  delete m;
+  return 0;
+}
+
+extern "C" int odo_lm_reset(odo_lm* m, const float init_colmajor[16], float lambda) {
+  if (!m || !init_colmajor) { fail("Reset optimizer failed!"); return -1; }
+  memcpy(m->init, init_colmajor, sizeof(m->init));  // SetInitialAffine, ref: src/lm_optimizer.cpp:385-389
+  m->lambda = lambda;                               // SetLambda, ref: :391-395
+  for (int i = 0; i < ODO_MAX_LEVELS; i++) m->iters[i] = 0;  // ResetStatistics, ref: :397-405
+  memset(m->h_cost, 0, sizeof(float) * 16);
+  return 0;
+}
+
+static int lm_check_pyrs(const odo_lm* m, const odo_pyr* a, const odo_pyr* d, const odo_pyr* b) {
+  if (!m || !a || !d || !b) return fail("LM: NULL pyramid");
+  if (a->kind != ODO_PYR_IMAGE || b->kind != ODO_PYR_IMAGE || d->kind != ODO_PYR_DEPTH)
+    return fail("Image types don't match in LevenbergMarquardtOptimizer::OptimizeCameraPose().");
+  if (a->levels < m->n_levels || b->levels < m->n_levels || d->levels < m->n_levels)
+    return fail("LM: pyramids have fewer levels than the optimiser (%d)", m->n_levels);
+  for (int l = 0; l < m->n_levels; l++) {
+    if (a->r[l] != b->r[l] || a->r[l] != d->r[l])  // ref: src/lm_optimizer.cpp:98-101
+      return fail("Image rows don't match in LevenbergMarquardtOptimizer::OptimizeCameraPose().");
+    if (a->c[l] != b->c[l] || a->c[l] != d->c[l])  // ref: :102-105
+      return fail("Image cols don't match in LevenbergMarquardtOptimizer::OptimizeCameraPose().");
+  }
+  return 0;
+}
+
+static inline int lm_grid(int rows, int cols) {
+  const long n = (long)(rows - 8) * (cols - 8);
+  if (rows <= 8 || cols <= 8) return 1;
+  long g = (n + kLmBlock - 1) / kLmBlock;
+  if (g > kLmMaxBlocks) g = kLmMaxBlocks;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+static int lm_ensure_res(odo_lm* m, size_t n) {
+  if (m->res_cap >= n) return 0;
+  if (m->d_res) { HIP_OK(hipStreamSynchronize(m->ctx->stream)); HIP_OK(hipFree(m->d_res)); m->d_res = nullptr; }
+  HIP_OK(hipMalloc((void**)&m->d_res, sizeof(float) * n));
+  m->res_cap = n;
+  return 0;
+}
+
+// One evaluation of the hot loop at the pose held in the device state.
+static void lm_launch_eval(odo_lm* m, const LevelView& v, const LevelK& k, int level, int nblk) {
+  hipStream_t s = m->ctx->stream;
+  if (m->robust == 2) {
+    const int n = (v.rows - 8) * (v.cols - 8);
+    hipLaunchKernelGGL(lm_residual_only_kernel, dim3(nblk), dim3(kLmBlock), 0, s, v, k, m->d_state, level, m->d_res);
+    hipLaunchKernelGGL(lm_tdist_scale_kernel, dim3(1), dim3(1024), 0, s, m->d_res, n > 0 ? n : 0, m->d_state, level,
+                       m->d_scale);
+  }
+  hipLaunchKernelGGL(lm_residual_dense_kernel, dim3(nblk), dim3(kLmBlock), 0, s, v, k, m->d_state, level, m->robust,
+                     m->huber_delta, m->d_scale, m->d_partials);
+}
+
+extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img,
+                            float out_colmajor[16]) {
+  if (!out_colmajor) return fail("odo_lm_solve: NULL out");
+  // failure value first: pseudo-identity whose (3,3) is 0 (ref: src/lm_optimizer.cpp:48-52,60-65)
+  for (int i = 0; i < 16; i++) out_colmajor[i] = 0.0f;
+  out_colmajor[0] = out_colmajor[5] = out_colmajor[10] = 1.0f;
+  if (lm_check_pyrs(m, kf_img, kf_dep, cur_img)) return -1;
+  hipStream_t s = m->ctx->stream;
+  HIP_OK(hipSetDevice(m->ctx->device));
+  HIP_OK(hipMemcpyAsync(m->d_init, m->init, sizeof(float) * 16, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(lm_begin_solve_kernel, dim3(1), dim3(64), 0, s, m->d_state, m->d_init, m->d_cost);
+  int launches = 0;
+  double bytes_per_level[ODO_MAX_LEVELS] = {0};
+  for (int l = m->n_levels - 1; l >= 0; l--) {  // ref: src/lm_optimizer.cpp:92
+    LevelView v;
+    v.I1 = kf_img->dev + kf_img->off[l];
+    v.I2 = cur_img->dev + cur_img->off[l];
+    v.D1 = kf_dep->dev + kf_dep->off[l];
+    v.rows = kf_img->r[l]; v.cols = kf_img->c[l];
+    const LevelK k = make_level_k(m->K.f0, m->K.cx0, m->K.cy0, l);
+    const int nblk = lm_grid(v.rows, v.cols);
+    if (m->robust == 2 && lm_ensure_res(m, (size_t)v.rows * v.cols)) return -1;
+    const long interior = (v.rows > 8 && v.cols > 8) ? (long)(v.rows - 8) * (v.cols - 8) : 0;
+    bytes_per_level[l] = 12.0 * (double)interior + 8.0 * ODO_NACC;
+    hipLaunchKernelGGL(lm_begin_level_kernel, dim3(1), dim3(64), 0, s, m->d_state, l, m->lambda, m->max_iters[l]);
+    for (int it = 0; it < m->max_iters[l]; it++) {  // ref: :117
+      lm_launch_eval(m, v, k, l, nblk);
+      hipLaunchKernelGGL(lm_update_kernel, dim3(1), dim3(256), 0, s, m->d_state, m->d_partials, nblk, l, m->precision,
+                         m->max_iters[l], m->d_trace, m->d_cost, (int*)nullptr);
+      launches++;
+    }
+  }
+  hipLaunchKernelGGL(lm_finalize_kernel, dim3(1), dim3(64), 0, s, m->d_state, m->d_out);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpyAsync(m->h_out, m->d_out, sizeof(float) * 26, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipMemcpyAsync(m->h_trace, m->d_trace, sizeof(LmTraceRow) * kTraceCap, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipMemcpyAsync(m->h_cost, m->d_cost, sizeof(float) * 16, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  memcpy(out_colmajor, m->h_out, sizeof(float) * 16);
+  m->last_evals = (int)m->h_out[17];
+  m->last_launches = launches;
+  m->last_bytes = 0.0;
+  for (int l = 0; l < ODO_MAX_LEVELS; l++) {
+    m->iters[l] = (int)m->h_out[18 + l];
+    m->last_bytes += bytes_per_level[l] * m->iters[l];
+  }
+  if (m->h_out[16] != 0.0f) return fail("Optimize failed! ");  // ref: src/lm_optimizer.cpp:60-61
+  return 0;
+}
+
+extern "C" int odo_lm_report(const odo_lm* m, int iters[4], float cost[4][2]) {
+  if (!m) return fail("NULL lm");
+  for (int i = 0; i < 4; i++) {
+    if (iters) iters[i] = m->iters[i];
+    if (cost) { cost[i][0] = m->h_cost[i * 2]; cost[i][1] = m->h_cost[i * 2 + 1]; }
+  }
+  return 0;
+}
+
+extern "C" int odo_lm_trace(const odo_lm* m, odo_lm_trace_row* rows, int cap, int* n_rows) {
+  if (!m || !n_rows) return fail("NULL arg");
+  int n = m->last_evals < kTraceCap ? m->last_evals : kTraceCap;
+  if (n > cap) n = cap;
+  static_assert(sizeof(odo_lm_trace_row) == sizeof(LmTraceRow), "trace row layout");
+  if (rows && n > 0) memcpy(rows, m->h_trace, sizeof(LmTraceRow) * n);
+  *n_rows = n;
+  return 0;
+}
+
+extern "C" int odo_lm_launch_stats(const odo_lm* m, int* n_active, int* n_total, double* bytes) {
+  if (!m) return fail("NULL lm");
+  if (n_active) *n_active = m->last_evals;
+  if (n_total) *n_total = m->last_launches;
+  if (bytes) *bytes = m->last_bytes;
+  return 0;
+}
+
+// Test entry: a single evaluation at an explicit pose.
+__global__ void lm_force_state_kernel(LmState* st, const float* T, int level) {
+  if (threadIdx.x == 0) {
+    LmState s;
+    float m[16];
+    for (int i = 0; i < 16; i++) m[i] = T[i];
+    lm_begin_solve(&s, m);
+    s.level = level; s.iter = 0; s.lambda = 0.0f; s.err_last = 1e+10f; s.active = 1;
+    for (int i = 0; i < 16; i++) s.T[i] = m[i];  // exactly the caller's matrix (no R->q->R round trip)
+    *st = s;
+  }
+}
+__global__ void lm_sum_partials_kernel(const double* __restrict__ partials, int nblk, double* __restrict__ out) {
+  __shared__ double sh[8][32];
+  const int t = threadIdx.x, q = t & 31, seg = t >> 5;
+  double v = 0.0;
+  if (q < ODO_NACC)
+    for (int b = seg; b < nblk; b += 8) v += partials[(size_t)b * ODO_NACC + q];
+  sh[seg][q] = v;
+  __syncthreads();
+  if (t < ODO_NACC)
+    out[t] = ((((((sh[0][t] + sh[1][t]) + sh[2][t]) + sh[3][t]) + sh[4][t]) + sh[5][t]) + sh[6][t]) + sh[7][t];
+}
+
+extern "C" int odo_lm_accumulate(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img,
+                                 int level, const float T_colmajor[16], double acc[ODO_NACC]) {
+  if (!T_colmajor || !acc) return fail("odo_lm_accumulate: NULL arg");
+  if (lm_check_pyrs(m, kf_img, kf_dep, cur_img)) return -1;
+  if (level < 0 || level >= m->n_levels) return fail("odo_lm_accumulate: bad level");
+  hipStream_t s = m->ctx->stream;
+  HIP_OK(hipSetDevice(m->ctx->device));
+  LevelView v;
+  v.I1 = kf_img->dev + kf_img->off[level];
+  v.I2 = cur_img->dev + cur_img->off[level];
+  v.D1 = kf_dep->dev + kf_dep->off[level];
+  v.rows = kf_img->r[level]; v.cols = kf_img->c[level];
+  const LevelK k = make_level_k(m->K.f0, m->K.cx0, m->K.cy0, level);
+  const int nblk = lm_grid(v.rows, v.cols);
+  if (m->robust == 2 && lm_ensure_res(m, (size_t)v.rows * v.cols)) return -1;
+  double* d_acc = nullptr;
+  HIP_OK(hipMalloc((void**)&d_acc, sizeof(double) * ODO_NACC));
+  HIP_OK(hipMemcpyAsync(m->d_init, T_colmajor, sizeof(float) * 16, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(lm_force_state_kernel, dim3(1), dim3(64), 0, s, m->d_state, m->d_init, level);
+  lm_launch_eval(m, v, k, level, nblk);
+  hipLaunchKernelGGL(lm_sum_partials_kernel, dim3(1), dim3(256), 0, s, m->d_partials, nblk, d_acc);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpyAsync(acc, d_acc, sizeof(double) * ODO_NACC, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  HIP_OK(hipFree(d_acc));
+  return (acc[28] > 0.0) ? 0 : -1;  // N == 0 fails (ref: src/lm_optimizer.cpp:244-248)
+}
+
+// ------------------------------------------------------------------------------------------------
+// Depth estimator
+// ------------------------------------------------------------------------------------------------
+struct odo_depth {
+  odo_ctx* ctx;
+  float grad_th, ssd_th, photo_th, min_depth, max_depth, lambda, huber_delta, precision, baseline;
+  int max_iters, boundary, max_residuals, max_disparity, any_size;
+  odo_intrinsics K;
+  int rows, cols;  // size the device buffers were made for
+  float *d_left, *d_right, *d_bl, *d_br, *d_disp, *d_dep, *d_d0, *d_scratch;
+  uint8_t* d_val;
+  uint32_t* d_pts;
+  int* d_cnt;
+  int* d_nmatched;
+  DepthLmStats* d_stats;
+  DepthLmStats* h_stats;
+  int* h_nmatched;
+  DepthLmStats last;
+  int last_matched;
+};
+
+extern "C" int odo_depth_create(odo_ctx* ctx, float grad_th, float ssd_th, float photo_th, float min_depth, float max_depth,
+                                float lambda, float huber_delta, float precision, int max_iters, int boundary,
+                                const odo_intrinsics* K, float baseline, int max_residuals, int max_disparity, int any_size,
+                                odo_depth** out) {
+  if (!ctx || !out) return fail("odo_depth_create: NULL arg");
+  *out = nullptr;
+  if (boundary < 2) return fail("odo_depth_create: boundary must be >= 2 (8-tap pattern reaches +-2)");
+  odo_depth* d = new (std::nothrow) odo_depth();
+  if (!d) return fail("out of memory");
+  memset(d, 0, sizeof(*d));
+  d->ctx = ctx; d->grad_th = grad_th; d->ssd_th = ssd_th; d->photo_th = photo_th; d->min_depth = min_depth;
+  d->max_depth = max_depth; d->lambda = lambda; d->huber_delta = huber_delta; d->precision = precision;
+  d->max_iters = max_iters; d->boundary = boundary; d->baseline = baseline; d->max_residuals = max_residuals;
+  d->max_disparity = max_disparity; d->any_size = any_size;
+  d->K = K ? *K : kKitti00;
+  HIP_OK(hipSetDevice(ctx->device));
+  HIP_OK(hipMalloc((void**)&d->d_pts, sizeof(uint32_t) * kSelBlocks * kSelCap));
+  HIP_OK(hipMalloc((void**)&d->d_cnt, sizeof(int) * kSelBlocks));
+  HIP_OK(hipMalloc((void**)&d->d_d0, sizeof(float) * kSelBlocks * kSelCap));
+  HIP_OK(hipMalloc((void**)&d->d_scratch, sizeof(float) * 6 * kSelBlocks * kSelCap));
+  HIP_OK(hipMalloc((void**)&d->d_nmatched, sizeof(int)));
+  HIP_OK(hipMalloc((void**)&d->d_stats, sizeof(DepthLmStats)));
+  HIP_OK(hipHostMalloc((void**)&d->h_stats, sizeof(DepthLmStats), hipHostMallocDefault));
+  HIP_OK(hipHostMalloc((void**)&d->h_nmatched, sizeof(int), hipHostMallocDefault));
+  *out = d;
+  return 0;
+}
+
+static void depth_free_images(odo_depth* d) {
+  float** ps[] = {&d->d_left, &d->d_right, &d->d_bl, &d->d_br, &d->d_disp, &d->d_dep};
+  for (auto p : ps) { if (*p) (void)hipFree(*p); *p = nullptr; }
+  if (d->d_val) (void)hipFree(d->d_val);
+  d->d_val = nullptr;
+  d->rows = d->cols = 0;
+}
+
+extern "C" int odo_depth_destroy(odo_depth* d) {
+  if (!d) return 0;
+  (void)hipStreamSynchronize(d->ctx->stream);
+  depth_free_images(d);
+  void* dv[] = {d->d_pts, d->d_cnt, d->d_d0, d->d_scratch, d->d_nmatched, d->d_stats};
+  for (void* q : dv) if (q) (void)hipFree(q);
+  (void)hipHostFree(d->h_stats); (void)hipHostFree(d->h_nmatched);
+  delete d;
+  return 0;
+}
+
+static int depth_ensure(odo_depth* d, int rows, int cols) {
+  if (d->rows == rows && d->cols == cols) return 0;
+  HIP_OK(hipStreamSynchronize(d->ctx->stream));
+  depth_free_images(d);
+  const size_t n = (size_t)rows * cols;
+  HIP_OK(hipMalloc((void**)&d->d_left, sizeof(float) * n));
+  HIP_OK(hipMalloc((void**)&d->d_right, sizeof(float) * n));
+  HIP_OK(hipMalloc((void**)&d->d_bl, sizeof(float) * n));
+  HIP_OK(hipMalloc((void**)&d->d_br, sizeof(float) * n));
+  HIP_OK(hipMalloc((void**)&d->d_disp, sizeof(float) * n));
+  HIP_OK(hipMalloc((void**)&d->d_dep, sizeof(float) * n));
+  HIP_OK(hipMalloc((void**)&d->d_val, n));
+  d->rows = rows; d->cols = cols;
+  return 0;
+}
+
+static int depth_check_size(const odo_depth* d, int rows, int cols) {
+  if (!d->any_size && (rows != 376 || cols != 1241))  // ref: src/depth_estimate.cpp:46-49
+    return fail("rows != 480 or cols != 640.");
+  const int bw = (cols - 2 * d->boundary) / 32, bh = (rows - 2 * d->boundary) / 16;
+  if (bw < 1 || bh < 1) return fail("depth: image too small for the 16x32 selection grid");
+  if (bw * bh > kSelMaxElems) return fail("depth: selection block %dx%d exceeds %d pixels", bw, bh, kSelMaxElems);
+  if (cols > 65535 || rows > 65535) return fail("depth: image too large");
+  return 0;
+}
+
+// Enqueues the whole ComputeDepth (stage 2) or only the disparity stage (stage 1) on device pointers.
+static int depth_run(odo_depth* d, const float* left, const float* right, int rows, int cols, uint8_t* val, float* disp,
+                     float* dep, int stage) {
+  hipStream_t s = d->ctx->stream;
+  const size_t n = (size_t)rows * cols;
+  HIP_OK(hipMemsetAsync(val, 0, n, s));
+  HIP_OK(hipMemsetAsync(disp, 0, sizeof(float) * n, s));  // zero-filled outputs
+  HIP_OK(hipMemsetAsync(dep, 0, sizeof(float) * n, s));
+  HIP_OK(hipMemsetAsync(d->d_nmatched, 0, sizeof(int), s));
+  hipLaunchKernelGGL(blur3x3_kernel, grid2d(cols, rows, 2), dim3(256), 0, s, left, d->d_bl, right, d->d_br, rows, cols);
+  hipLaunchKernelGGL(depth_select_kernel, dim3(kSelBlocks), dim3(kSelThreads), 0, s, d->d_bl, rows, cols, d->boundary,
+                     d->grad_th, val, d->d_pts, d->d_cnt);
+  hipLaunchKernelGGL(depth_disparity_kernel, dim3(kSelBlocks * kSelCap / 4), dim3(256), 0, s, d->d_bl, d->d_br, rows, cols,
+                     d->boundary, d->max_disparity, d->ssd_th, d->K.f0, d->baseline, d->d_pts, d->d_cnt, disp, dep,
+                     d->d_d0, d->d_nmatched);
+  if (stage == 1) {
+    hipLaunchKernelGGL(depth_stats_selected_kernel, dim3(1), dim3(kSelBlocks), 0, s, d->d_cnt, d->d_stats);
+  } else {
+    hipLaunchKernelGGL(depth_lm_kernel, dim3(1), dim3(kDlmThreads), 0, s, left, right, rows, cols, d->d_pts, d->d_cnt,
+                       d->d_d0, d->d_scratch, d->baseline, d->K.f0, d->huber_delta, d->lambda, d->precision, d->max_iters,
+                       d->photo_th, d->min_depth, d->max_depth, val, dep, d->d_stats);
+  }
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpyAsync(d->h_stats, d->d_stats, sizeof(DepthLmStats), hipMemcpyDeviceToHost, s));
+  HIP_OK(hipMemcpyAsync(d->h_nmatched, d->d_nmatched, sizeof(int), hipMemcpyDeviceToHost, s));
+  return 0;
+}
+
+static int depth_finish(odo_depth* d) {
+  HIP_OK(hipStreamSynchronize(d->ctx->stream));
+  d->last = *d->h_stats;
+  d->last_matched = *d->h_nmatched;
+  d->last.n_matched = d->last_matched;
+  if (d->last.status != 0) return fail("number of valid after optimization is too small: %d", d->last.n_valid);
+  return 0;
+}
+
+static int depth_host(odo_depth* d, const float* left, const float* right, int rows, int cols, uint8_t* val, float* disp,
+                      float* dep, int stage) {
+  if (!d || !left || !right || !val || !disp || !dep) return fail("depth: NULL arg");
+  if (depth_check_size(d, rows, cols)) return -1;
+  HIP_OK(hipSetDevice(d->ctx->device));
+  if (depth_ensure(d, rows, cols)) return -1;
+  hipStream_t s = d->ctx->stream;
+  const size_t n = (size_t)rows * cols;
+  HIP_OK(hipMemcpyAsync(d->d_left, left, sizeof(float) * n, hipMemcpyHostToDevice, s));
+  HIP_OK(hipMemcpyAsync(d->d_right, right, sizeof(float) * n, hipMemcpyHostToDevice, s));
+  if (depth_run(d, d->d_left, d->d_right, rows, cols, d->d_val, d->d_disp, d->d_dep, stage)) return -1;
+  HIP_OK(hipMemcpyAsync(val, d->d_val, n, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipMemcpyAsync(disp, d->d_disp, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipMemcpyAsync(dep, d->d_dep, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+  return depth_finish(d);
+}
+
+extern "C" int odo_depth_compute(odo_depth* d, const float* left, const float* right, int rows, int cols, uint8_t* val,
+                                 float* disp, float* dep) {
+  return depth_host(d, left, right, rows, cols, val, disp, dep, 2);
+}
+extern "C" int odo_depth_disparity(odo_depth* d, const float* left, const float* right, int rows, int cols, uint8_t* val,
+                                   float* disp, float* dep) {
+  return depth_host(d, left, right, rows, cols, val, disp, dep, 1);
+}
+extern "C" int odo_depth_compute_dev(odo_depth* d, const float* left_dev, const float* right_dev, int rows, int cols,
+                                     uint8_t* val_dev, float* disp_dev, float* dep_dev) {
+  if (!d || !left_dev || !right_dev || !val_dev || !disp_dev || !dep_dev) return fail("depth: NULL arg");
+  if (depth_check_size(d, rows, cols)) return -1;
+  HIP_OK(hipSetDevice(d->ctx->device));
+  if (depth_ensure(d, rows, cols)) return -1;
+  if (depth_run(d, left_dev, right_dev, rows, cols, val_dev, disp_dev, dep_dev, 2)) return -1;
+  return depth_finish(d);
+}
+
+extern "C" int odo_depth_report(const odo_depth* d, int* iters, float* cost, int* n_selected, int* n_matched, int* n_valid) {
+  if (!d) return fail("NULL depth estimator");
+  if (iters) *iters = d->last.iters;
+  if (cost) *cost = d->last.cost;
+  if (n_selected) *n_selected = d->last.n_selected;
+  if (n_matched) *n_matched = d->last_matched;
+  if (n_valid) *n_valid = d->last.n_valid;
+  return 0;
+}

@@ -1,0 +1,189 @@
+"""Deterministic synthetic KITTI-shaped stereo data (no dataset, no network).
+
+Scene: a textured corridor (ground plane, two side walls, a ceiling and a far end wall) seen by a
+rectified stereo rig with the KITTI-00 intrinsics the reference hard-codes
+(ref: include/image_processing_global.h:35-36, run_odometry_kitti_offline.cpp:38-41).
+Images are rendered per pixel (ray/plane intersection + bilinear lookup in a tileable multi-octave
+value-noise texture), then quantised to u8 and cast to fp32 — the same value range and granularity as
+the reference's imread(GRAYSCALE) -> convertTo(CV_32F) (ref: run_odometry_kitti_offline.cpp:334-359).
+
+Coordinates: x right, y down, z forward. Poses are camera-to-world 4x4 (float64).
+"""
+import numpy as np
+
+KITTI_F = 718.856
+KITTI_CX = 607.1928
+KITTI_CY = 185.2157
+KITTI_BASELINE = 386.1448 / 718.856
+KITTI_ROWS, KITTI_COLS = 376, 1241
+
+
+def _value_noise(rng, size, octaves, first_cell):
+    """Tileable multi-octave value noise in [0,1], `size` x `size` (bilinear-interpolated lattices)."""
+    tex = np.zeros((size, size), np.float64)
+    amp, tot, cell = 1.0, 0.0, first_cell
+    ii = np.arange(size)
+    for _ in range(octaves):
+        n = size // cell
+        lat = rng.random((n, n))
+        g = ii / cell
+        i0 = np.floor(g).astype(np.int64) % n
+        i1 = (i0 + 1) % n
+        f = g - np.floor(g)
+        f = f * f * (3 - 2 * f)
+        a = lat[np.ix_(i0, i0)] * (1 - f)[None, :] + lat[np.ix_(i0, i1)] * f[None, :]
+        b = lat[np.ix_(i1, i0)] * (1 - f)[None, :] + lat[np.ix_(i1, i1)] * f[None, :]
+        tex += amp * (a * (1 - f)[:, None] + b * f[:, None])
+        tot += amp
+        amp *= 0.6
+        cell = max(cell // 2, 2)
+    return tex / tot
+
+
+class Scene:
+    """Corridor of textured planes. texels_per_m controls texture scale."""
+
+    def __init__(self, seed=0, half_width=(4.0, 5.0), cam_height=1.65, ceil_height=3.0, end_z=600.0,
+                 tex_size=1024, texels_per_m=60.0, tile_texels=(11, 29, 67)):
+        rng = np.random.default_rng(0x0D0E77E7 + 1000 * seed)
+        self.tex = []
+        for _ in range(5):  # smooth value noise + random-brightness tiles (sparse strong edges, like real scenes)
+            t = _value_noise(rng, tex_size, 6, 128)
+            t = (t - t.mean()) / t.std()
+            tiles = np.zeros_like(t)
+            ii = np.arange(tex_size)
+            for s_ in tile_texels:  # incommensurate tile sizes: irregular edge layout, no strict period
+                nc = tex_size // s_ + 1
+                cells = rng.uniform(-1.0, 1.0, (nc, nc))
+                tiles += cells[np.ix_(ii // s_, ii // s_)]
+            tiles /= np.sqrt(len(tile_texels))
+            self.tex.append(np.clip(128.0 + 22.0 * t + 50.0 * tiles, 0.0, 255.0))
+        self.tpm = texels_per_m
+        # planes: (normal n, offset h) with n . X = h; texture axes (a, b) index world coords
+        self.planes = [
+            (np.array([0.0, 1.0, 0.0]), cam_height, (0, 2)),        # ground  y = +h
+            (np.array([1.0, 0.0, 0.0]), -half_width[0], (2, 1)),    # left wall
+            (np.array([1.0, 0.0, 0.0]), half_width[1], (2, 1)),     # right wall
+            (np.array([0.0, 1.0, 0.0]), -ceil_height, (0, 2)),      # ceiling
+            (np.array([0.0, 0.0, 1.0]), end_z, (0, 1)),             # end wall
+        ]
+
+    def _sample(self, k, u, v):
+        tex = self.tex[k]
+        n = tex.shape[0]
+        u = u * self.tpm
+        v = v * self.tpm
+        u0 = np.floor(u)
+        v0 = np.floor(v)
+        fu = u - u0
+        fv = v - v0
+        u0 = u0.astype(np.int64) % n
+        v0 = v0.astype(np.int64) % n
+        u1 = (u0 + 1) % n
+        v1 = (v0 + 1) % n
+        return (tex[v0, u0] * (1 - fu) * (1 - fv) + tex[v0, u1] * fu * (1 - fv) +
+                tex[v1, u0] * (1 - fu) * fv + tex[v1, u1] * fu * fv)
+
+    def render(self, pose_c2w, rows=KITTI_ROWS, cols=KITTI_COLS, f=KITTI_F, cx=KITTI_CX, cy=KITTI_CY,
+               x_offset=0.0):
+        """Returns (image fp32 u8-quantised, depth Z fp64). x_offset shifts the camera along its own x
+        axis (the right camera of the rig is x_offset = +baseline)."""
+        R = pose_c2w[:3, :3]
+        t = pose_c2w[:3, 3] + R[:, 0] * x_offset
+        xs = (np.arange(cols) - cx) / f
+        ys = (np.arange(rows) - cy) / f
+        dx, dy = np.meshgrid(xs, ys)
+        dirs = np.stack([dx, dy, np.ones_like(dx)], -1) @ R.T     # world-frame ray directions (z_c = 1)
+        best = np.full((rows, cols), np.inf)
+        img = np.zeros((rows, cols))
+        for k, (n, h, (a, b)) in enumerate(self.planes):
+            den = dirs @ n
+            num = h - n @ t
+            with np.errstate(divide="ignore", invalid="ignore"):
+                s = np.where(np.abs(den) > 1e-12, num / den, np.inf)
+            hit = (s > 1e-3) & (s < best)
+            if not hit.any():
+                continue
+            P = t[None, :] + dirs[hit] * s[hit][:, None]
+            img[hit] = self._sample(k, P[:, a], P[:, b])
+            best[hit] = s[hit]
+        img = np.clip(np.rint(img), 0, 255).astype(np.float32)
+        return img, best
+
+
+def trajectory(n_frames, seed=0, fwd_range=(0.3, 0.6)):
+    """Camera-to-world poses: forward fwd_range m/frame, yaw <= 1.5 deg, pitch/roll <= 0.2 deg per frame."""
+    rng = np.random.default_rng(0x0D0E77E7 + 1000 * seed + 17)
+    poses = [np.eye(4)]
+    yaw_total = 0.0
+    for _ in range(1, n_frames):
+        fwd = rng.uniform(*fwd_range)
+        yaw = np.deg2rad(rng.uniform(-1.5, 1.5))
+        if abs(yaw_total + yaw) > np.deg2rad(6.0):  # stay inside the corridor
+            yaw = -yaw
+        yaw_total += yaw
+        pitch = np.deg2rad(rng.uniform(-0.2, 0.2))
+        roll = np.deg2rad(rng.uniform(-0.2, 0.2))
+        cy_, sy_ = np.cos(yaw), np.sin(yaw)
+        cp, sp = np.cos(pitch), np.sin(pitch)
+        cr, sr = np.cos(roll), np.sin(roll)
+        Ry = np.array([[cy_, 0, sy_], [0, 1, 0], [-sy_, 0, cy_]])
+        Rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+        Rz = np.array([[cr, -sr, 0], [sr, cr, 0], [0, 0, 1]])
+        d = np.eye(4)
+        d[:3, :3] = Ry @ Rx @ Rz
+        d[:3, 3] = [rng.uniform(-0.02, 0.02), rng.uniform(-0.01, 0.01), fwd]
+        poses.append(poses[-1] @ d)
+    return poses
+
+
+def make_sequence(n_frames, seed=0, rows=KITTI_ROWS, cols=KITTI_COLS, f=KITTI_F, cx=KITTI_CX, cy=KITTI_CY,
+                  baseline=KITTI_BASELINE, with_depth=False):
+    """Returns dict(left=[...], right=[...], poses=[c2w...], depth=[...] optional)."""
+    scene = Scene(seed)
+    poses = trajectory(n_frames, seed)
+    out = dict(left=[], right=[], poses=poses, depth=[])
+    for T in poses:
+        L, Z = scene.render(T, rows, cols, f, cx, cy, 0.0)
+        Rimg, _ = scene.render(T, rows, cols, f, cx, cy, baseline)
+        out["left"].append(L)
+        out["right"].append(Rimg)
+        if with_depth:
+            out["depth"].append(Z)
+    return out
+
+
+def semi_dense_inverse_depth(Z, left, grad_th=12.0, max_depth=30.0, stride_keep=1.0, seed=0):
+    """Ground-truth inverse-depth map restricted to high-gradient pixels (semi-dense), 0 elsewhere —
+    a stand-in for DepthEstimator output when a test needs a known-good keyframe depth."""
+    gx = np.zeros_like(left)
+    gy = np.zeros_like(left)
+    gx[:, 1:-1] = 0.5 * (left[:, 2:] - left[:, :-2])
+    gy[1:-1, :] = 0.5 * (left[2:, :] - left[:-2, :])
+    mask = (np.hypot(gx, gy) > grad_th) & (Z < max_depth)
+    if stride_keep < 1.0:
+        rng = np.random.default_rng(seed)
+        mask &= rng.random(mask.shape) < stride_keep
+    inv = np.zeros(Z.shape, np.float32)
+    inv[mask] = (1.0 / Z[mask]).astype(np.float32)
+    return inv
+
+
+def integer_disparity_pair(seed=0, rows=KITTI_ROWS, cols=KITTI_COLS, band=24, dmin=3, dmax=96):
+    """Known-answer stereo pair: right[y, x - d(y)] = left[y, x] with an integer disparity d per
+    horizontal band. Away from band edges (>= 3 rows) the 8-tap SSD at the true match is exactly 0."""
+    rng = np.random.default_rng(0x0D0E77E7 + 7919 * seed)
+    tex = _value_noise(rng, 2048, 7, 64)
+    tex = (tex - tex.mean()) / tex.std()
+    left = np.clip(np.rint(128.0 + 45.0 * tex[:rows, :cols]), 0, 255).astype(np.float32)
+    fill = np.clip(np.rint(128.0 + 45.0 * tex[rows:2 * rows, :cols]), 0, 255).astype(np.float32)
+    right = fill.copy()
+    disp = np.zeros((rows, cols), np.int32)
+    nb = (rows + band - 1) // band
+    ds = rng.integers(dmin, dmax + 1, nb)
+    for b in range(nb):
+        d = int(ds[b])
+        y0, y1 = b * band, min(rows, (b + 1) * band)
+        right[y0:y1, :cols - d] = left[y0:y1, d:]
+        disp[y0:y1, :] = d
+    return left, right, disp

@@ -1,0 +1,281 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same inputs."""
+import numpy as np
+import pytest
+
+from conftest import se3_log_norm
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def api():
+    from odometry_amd import api
+    api.default_context()  # raises if the HIP library or the device is missing: no silent fallback
+    return api
+
+
+# ---------------------------------------------------------------- pyramids ----------------------
+@pytest.mark.parametrize("shape", [(376, 1241), (48, 64), (95, 131), (1080, 1920)])
+@pytest.mark.parametrize("smooth", [True, False])
+def test_image_pyramid_bit_exact(api, O, shape, smooth):
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, shape).astype(np.float32)
+    ref = O.image_pyramid(img, 4, smooth)
+    pyr = api.ImagePyramid(4, img, smooth)
+    assert pyr.GetNumberLevels() == 4
+    for l in range(4):
+        got = pyr.GetPyramidImage(l)
+        assert got.shape == ref[l].shape
+        assert np.array_equal(got, ref[l]), f"level {l} differs: max {np.abs(got - ref[l]).max()}"
+
+
+def test_image_pyramid_non_integer_input_bit_exact(api, O):
+    rng = np.random.default_rng(2)
+    img = (rng.random((200, 333)) * 255).astype(np.float32)  # arbitrary fp32: rounding order matters at every level
+    ref = O.image_pyramid(img, 4, True)
+    pyr = api.ImagePyramid(4, img, True)
+    for l in range(4):
+        assert np.array_equal(pyr.GetPyramidImage(l), ref[l])
+
+
+def test_depth_pyramid_bit_exact(api, O):
+    rng = np.random.default_rng(3)
+    dep = rng.random((376, 1241)).astype(np.float32)
+    dep[rng.random(dep.shape) < 0.9] = 0
+    ref = O.depth_pyramid(dep, 4)
+    pyr = api.DepthPyramid(4, dep, False)
+    for l in range(4):
+        assert np.array_equal(pyr.GetPyramidDepth(l), ref[l])
+
+
+def test_pyramid_bad_level(api):
+    pyr = api.ImagePyramid(4, np.zeros((64, 64), np.float32), True)
+    with pytest.raises(IndexError):
+        pyr.GetPyramidImage(4)
+
+
+# ---------------------------------------------------------------- LM accumulate -----------------
+def _kitti_pyrs(api, O, seq, inv=None):
+    from odometry_amd import synth
+    L0, L1, Z0 = seq["left"][0], seq["left"][1], seq["depth"][0]
+    if inv is None:
+        inv = synth.semi_dense_inverse_depth(Z0, L0)
+    return (L0, L1, inv, api.ImagePyramid(4, L0, True), api.DepthPyramid(4, inv, False), api.ImagePyramid(4, L1, True),
+            O.image_pyramid(L0, 4, True), O.depth_pyramid(inv, 4), O.image_pyramid(L1, 4, True))
+
+
+@pytest.mark.parametrize("robust", [0, 1, 2])
+def test_lm_accumulate_matches_oracle(api, O, kitti_seq, robust):
+    L0, L1, inv, p0, d0, p1, r0, rd, r1 = _kitti_pyrs(api, O, kitti_seq)
+    lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, robust, 28.0)
+    T = np.eye(4, dtype=np.float32)
+    T[0, 3], T[2, 3] = 0.02, -0.3
+    T[:3, :3] = O.se3_exp(np.array([0, 0, 0, 0.002, 0.01, -0.003], np.float32))[:3, :3]
+    for level in range(4):
+        st, acc = lm.accumulate(p0, d0, p1, level, T)
+        ref = O.lm_accumulate(r0[level], r1[level], rd[level], level, T, robust=robust, huber_delta=28.0)
+        assert st == 0 and ref["status"] == 0
+        assert acc[28] == ref["acc"][28], "number of residuals must match exactly"
+        np.testing.assert_allclose(acc, ref["acc"], rtol=1e-11, atol=1e-9)
+
+
+def test_lm_accumulate_dense_matches_oracle(api, O, kitti_seq):
+    Z0 = kitti_seq["depth"][0]
+    inv = np.where(Z0 < 100, 1.0 / np.maximum(Z0, 1e-3), 0).astype(np.float32)  # every pixel valid (config 3 shape)
+    L0, L1, inv, p0, d0, p1, r0, rd, r1 = _kitti_pyrs(api, O, kitti_seq, inv)
+    lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 1, 28.0)
+    T = np.eye(4, dtype=np.float32)
+    T[2, 3] = -0.4
+    st, acc = lm.accumulate(p0, d0, p1, 0, T)
+    ref = O.lm_accumulate(r0[0], r1[0], rd[0], 0, T, robust=1, huber_delta=28.0)
+    assert acc[28] == ref["acc"][28] and acc[28] > 400000
+    np.testing.assert_allclose(acc, ref["acc"], rtol=1e-11, atol=1e-9)
+
+
+def test_lm_accumulate_is_deterministic(api, O, kitti_seq):
+    L0, L1, inv, p0, d0, p1, *_ = _kitti_pyrs(api, O, kitti_seq)
+    lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 1, 28.0)
+    T = np.eye(4, dtype=np.float32)
+    T[2, 3] = -0.2
+    a = [lm.accumulate(p0, d0, p1, 0, T)[1] for _ in range(3)]
+    assert np.array_equal(a[0], a[1]) and np.array_equal(a[0], a[2])
+
+
+# ---------------------------------------------------------------- LM solve ----------------------
+@pytest.mark.parametrize("robust", [1, 0, 2])
+def test_lm_solve_pose_parity(api, O, kitti_seq, robust):
+    L0, L1, inv, p0, d0, p1, *_ = _kitti_pyrs(api, O, kitti_seq)
+    lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, robust, 28.0)
+    T = lm.Solve(p0, d0, p1)
+    ref = O.lm_solve(O.image_pyramid(L0, flat=True), O.depth_pyramid(inv, flat=True), O.image_pyramid(L1, flat=True),
+                     376, 1241, O.lm_params(robust=robust))
+    assert lm.last_status == 0 and ref["status"] == 0
+    d = se3_log_norm(ref["pose"], T)
+    assert d < 1e-5, f"pose delta {d} vs oracle"   # north_star tolerance: 1e-5 on the SE(3) log-map norm
+    tr = lm.trace()
+    assert len(tr) == ref["n_evals"]
+    for a, b in zip(tr, ref["trace"]):
+        assert (a["level"], a["iter"], a["n_res"], a["accepted"], a["stop"]) == \
+               (b["level"], b["iter"], b["n_res"], b["accepted"], b["stop"])
+        assert abs(a["err"] - b["err"]) <= 1e-6 * abs(b["err"])
+    # recovered motion is close to the rendered one (sanity of the whole chain, not parity)
+    gt = np.linalg.inv(kitti_seq["poses"][1]) @ kitti_seq["poses"][0]
+    assert abs(T[2, 3] - gt[2, 3]) < 0.05
+
+
+def test_lm_solve_sequence_with_reset(api, O, kitti_seq):
+    """Reset(pose, lambda) then track the next frame against the same keyframe (runner usage :215,:268)."""
+    from odometry_amd import synth
+    L = kitti_seq["left"]
+    inv = synth.semi_dense_inverse_depth(kitti_seq["depth"][0], L[0])
+    p0, d0 = api.ImagePyramid(4, L[0], True), api.DepthPyramid(4, inv, False)
+    lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 1, 28.0)
+    lp = O.lm_params()
+    ref_init = np.eye(4, dtype=np.float32)
+    r0, rd = O.image_pyramid(L[0], flat=True), O.depth_pyramid(inv, flat=True)
+    for k in (1, 2):
+        T = lm.Solve(p0, d0, api.ImagePyramid(4, L[k], True))
+        ref = O.lm_solve(r0, rd, O.image_pyramid(L[k], flat=True), 376, 1241, lp, init=ref_init)
+        assert se3_log_norm(ref["pose"], T) < 1e-5
+        assert lm.Reset(T, 0.01) == 0
+        ref_init = ref["pose"]
+
+
+def test_lm_solve_fails_without_depth(api):
+    img = np.random.default_rng(0).integers(0, 255, (376, 1241)).astype(np.float32)
+    p0 = api.ImagePyramid(4, img, True)
+    d0 = api.DepthPyramid(4, np.zeros_like(img), False)
+    lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 1, 28.0)
+    T = lm.Solve(p0, d0, p0)
+    assert lm.last_status == -1
+    expect = np.eye(4, dtype=np.float32)
+    expect[3, 3] = 0.0   # pseudo-identity (ref: src/lm_optimizer.cpp:48-52)
+    assert np.array_equal(T, expect)
+
+
+def test_lm_solve_rejects_mismatched_pyramids(api):
+    a = api.ImagePyramid(4, np.zeros((376, 1241), np.float32), True)
+    b = api.ImagePyramid(4, np.zeros((370, 1241), np.float32), True)
+    d = api.DepthPyramid(4, np.zeros((376, 1241), np.float32), False)
+    lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 1, 28.0)
+    lm.Solve(a, d, b)
+    assert lm.last_status == -1
+
+
+def test_lm_solve_identical_frames_stays_identity(api, kitti_seq):
+    """Size-independent property: tracking a frame against itself from identity must not move."""
+    from odometry_amd import synth
+    L0 = kitti_seq["left"][0]
+    inv = synth.semi_dense_inverse_depth(kitti_seq["depth"][0], L0)
+    p0, d0 = api.ImagePyramid(4, L0, True), api.DepthPyramid(4, inv, False)
+    lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 1, 28.0)
+    T = lm.Solve(p0, d0, p0)
+    assert se3_log_norm(np.eye(4), T) < 1e-6
+
+
+def test_lm_small_image_custom_intrinsics(api, O, small_seq):
+    from odometry_amd import synth
+    K = small_seq["K"]
+    L0, L1, Z0 = small_seq["left"][0], small_seq["left"][1], small_seq["depth"][0]
+    inv = synth.semi_dense_inverse_depth(Z0, L0, grad_th=6.0)
+    lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30], np.eye(4), None, 1, 28.0,
+                                         intrinsics=(K["f0"], K["cx0"], K["cy0"]))
+    T = lm.Solve(api.ImagePyramid(3, L0, True), api.DepthPyramid(3, inv, False), api.ImagePyramid(3, L1, True))
+    ref = O.lm_solve(O.image_pyramid(L0, 3, flat=True), O.depth_pyramid(inv, 3, flat=True),
+                     O.image_pyramid(L1, 3, flat=True), 120, 160, O.lm_params(max_iters=(10, 20, 30), K=K))
+    assert lm.last_status == ref["status"] == 0
+    assert se3_log_norm(ref["pose"], T) < 1e-5
+
+
+# ---------------------------------------------------------------- depth estimator ---------------
+def _depth_est(api, **kw):
+    from odometry_amd.synth import KITTI_BASELINE
+    return api.DepthEstimator(8.0, 900.0, 15.0, 0.1, 30.0, 0.01, 28.0, 0.995, 50, 4, None, None,
+                              float(np.float32(386.1448) / np.float32(718.856)), 80000, **kw)
+
+
+def _bufs(shape):
+    return np.zeros(shape, np.uint8), np.zeros(shape, np.float32), np.zeros(shape, np.float32)
+
+
+@pytest.mark.parametrize("max_disparity", [0, 128])
+def test_disparity_bit_exact(api, O, kitti_seq, max_disparity):
+    L, R = kitti_seq["left"][0], kitti_seq["right"][0]
+    de = _depth_est(api, max_disparity=max_disparity)
+    val, disp, dep = _bufs(L.shape)
+    assert de.DisparityDepthEstimate(L, R, val, disp, dep) == 0
+    ref = O.compute_depth(L, R, O.depth_params(max_disparity=max_disparity), stage=1)
+    assert np.array_equal(val, ref["val"]), "selection mask differs"
+    assert np.array_equal(disp, ref["disp"]), "integer disparity (argmin index) differs"
+    assert np.array_equal(dep, ref["dep"])
+    rep = de.report()
+    assert rep["n_selected"] == ref["n_selected"] and rep["n_matched"] == ref["n_matched"]
+
+
+def test_disparity_known_answer(api):
+    """Integer-disparity KAT at full size: interior points of each band recover the exact disparity."""
+    from odometry_amd import synth
+    L, R, gt = synth.integer_disparity_pair(seed=1)
+    de = _depth_est(api)
+    val, disp, dep = _bufs(L.shape)
+    assert de.DisparityDepthEstimate(L, R, val, disp, dep) == 0
+    band = 24
+    yy = np.arange(L.shape[0])[:, None] % band
+    interior = (yy >= 3) & (yy < band - 3) & (val == 1) & (disp > 0)
+    xs = np.arange(L.shape[1])[None, :]
+    interior &= (xs - gt) >= 6
+    assert interior.sum() > 2000
+    assert np.array_equal(disp[interior], gt[interior].astype(np.float32))
+
+
+def test_compute_depth_matches_oracle(api, O, kitti_seq):
+    for k in (0, 1):
+        L, R = kitti_seq["left"][k], kitti_seq["right"][k]
+        de = _depth_est(api)
+        val, disp, dep = _bufs(L.shape)
+        st = de.ComputeDepth(L, R, val, disp, dep)
+        ref = O.compute_depth(L, R, O.depth_params(), stage=2)
+        assert st == ref["status"] == 0
+        rep = de.report()
+        assert rep["iters"] == ref["iters"]
+        assert np.array_equal(val, ref["val"])
+        assert np.array_equal(disp, ref["disp"])
+        np.testing.assert_allclose(dep, ref["dep"], rtol=0, atol=1e-7)
+        assert abs(rep["cost"] - ref["cost"]) <= 1e-5 * abs(ref["cost"])
+        assert rep["n_valid"] == ref["n_valid"] == int(val.sum())
+
+
+def test_compute_depth_size_guard(api):
+    de = _depth_est(api)
+    val, disp, dep = _bufs((480, 640))
+    img = np.zeros((480, 640), np.float32)
+    assert de.ComputeDepth(img, img, val, disp, dep) == -1   # ref: src/depth_estimate.cpp:46-49
+
+
+def test_compute_depth_flat_image_fails(api, O):
+    img = np.full((376, 1241), 100.0, np.float32)
+    de = _depth_est(api)
+    val, disp, dep = _bufs(img.shape)
+    st = de.ComputeDepth(img, img, val, disp, dep)
+    ref = O.compute_depth(img, img, O.depth_params(), stage=2)
+    assert st == ref["status"] == -1   # fewer than 500 valid points (ref: :192-197)
+    assert np.array_equal(val, ref["val"])
+
+
+def test_compute_depth_any_size(api, O, small_seq):
+    L, R = small_seq["left"][0], small_seq["right"][0]
+    K = small_seq["K"]
+    de = api.DepthEstimator(4.0, 900.0, 15.0, 0.1, 30.0, 0.01, 28.0, 0.995, 50, 4, None, None, 0.5, 80000,
+                            intrinsics=(K["f0"], K["cx0"], K["cy0"]), any_size=True)
+    val, disp, dep = _bufs(L.shape)
+    st = de.ComputeDepth(L, R, val, disp, dep)
+    ref = O.compute_depth(L, R, O.depth_params(grad_th=4.0, baseline=0.5, f0=K["f0"], any_size=1), stage=2)
+    assert st == ref["status"]
+    assert np.array_equal(val, ref["val"]) and np.array_equal(disp, ref["disp"])
+    np.testing.assert_allclose(dep, ref["dep"], rtol=0, atol=1e-7)

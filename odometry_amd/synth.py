@@ -173,10 +173,15 @@ def integer_disparity_pair(seed=0, rows=KITTI_ROWS, cols=KITTI_COLS, band=24, dm
     """Known-answer stereo pair: right[y, x - d(y)] = left[y, x] with an integer disparity d per
     horizontal band. Away from band edges (>= 3 rows) the 8-tap SSD at the true match is exactly 0."""
     rng = np.random.default_rng(0x0D0E77E7 + 7919 * seed)
-    tex = _value_noise(rng, 2048, 7, 64)
-    tex = (tex - tex.mean()) / tex.std()
-    left = np.clip(np.rint(128.0 + 45.0 * tex[:rows, :cols]), 0, 255).astype(np.float32)
-    fill = np.clip(np.rint(128.0 + 45.0 * tex[rows:2 * rows, :cols]), 0, 255).astype(np.float32)
+    n = 2048
+    tex = _value_noise(rng, n, 7, 64)
+    tex = 25.0 * (tex - tex.mean()) / tex.std()
+    ii = np.arange(n)
+    for s_ in (7, 17, 41):  # random-brightness tiles: sparse strong edges so the block-median selection fires
+        cells = rng.uniform(-1.0, 1.0, (n // s_ + 1, n // s_ + 1))
+        tex += 28.0 * cells[np.ix_(ii // s_, ii // s_)]
+    left = np.clip(np.rint(128.0 + tex[:rows, :cols]), 0, 255).astype(np.float32)
+    fill = np.clip(np.rint(128.0 + tex[rows:2 * rows, :cols]), 0, 255).astype(np.float32)
     right = fill.copy()
     disp = np.zeros((rows, cols), np.int32)
     nb = (rows + band - 1) // band

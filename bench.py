@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py — tracked frames/s of the photometric-LM hot path on N MI355X (one process per GPU).
+
+Workload (BASELINE.json configs[1]): a synthetic KITTI-shaped stereo sequence, 1241x376, 4-level pyramid,
+semi-dense points, fp32, runner parameters (ref: run_odometry_kitti_offline.cpp:58-88). One "step" = one
+iteration of the runner's frame loop (ref: :198-271) on one stereo pair that is already resident in HBM:
+ImagePyramid(cur) -> Solve against the keyframe -> pose chaining -> ComputeDepth -> rebuild the frame's
+pyramids -> keyframe test -> Reset. With N > 1 every rank tracks its own sequence (seed = rank; the path
+shards by sequence, no data-path collective) and the 6-DoF results are gathered over RCCL every
+--gather-every frames; `value` = frames tracked by all ranks / max-over-ranks wall time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def frame_order(n_unique, n_steps):
+    """Palindromic playback of the unique frames: 1,2,..,F-1,F-2,..,0,1,.. — consecutive frames always differ by one
+    real camera step, so the tracker sees the same kind of motion for any number of steps."""
+    cyc = list(range(1, n_unique)) + list(range(n_unique - 2, -1, -1))
+    return [cyc[i % len(cyc)] for i in range(n_steps)]
+
+
+def load_traffic():
+    """Per-launch HBM traffic of the dominant kernel from the committed rocprofv3 --pmc summary, if present."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get("lm_residual_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+def cpu_baseline(seq, order, n_frames):
+    """The oracle (CPU restatement) stepping the same frames on one host core; a reported baseline, not the target."""
+    from oracle import runner as orunner
+    run = orunner.OracleRunner()
+    run.init(seq["left"][0], seq["right"][0])
+    poses = []
+    t0 = time.perf_counter()
+    for i in order[:n_frames]:
+        poses.append(run.track(seq["left"][i], seq["right"][i]))
+    dt = time.perf_counter() - t0
+    return n_frames / dt, poses, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--unique-frames", type=int, default=16)
+    ap.add_argument("--gather-every", type=int, default=8)
+    ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-overlap", action="store_true", help="run ComputeDepth after Solve on one stream")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from odometry_amd import api, synth
+    seq = synth.make_sequence(args.unique_frames, seed=rank)
+    trk = api.Tracker(local_rank, overlap_depth=0 if args.no_overlap else 1)
+    dev = [(trk.upload_frame(l), trk.upload_frame(r)) for l, r in zip(seq["left"], seq["right"])]  # inputs resident in HBM
+    trk.init(*dev[0])
+    order = frame_order(args.unique_frames, args.warmup + args.steps)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    gathered = None
+    results = []
+    evals = []
+    pending = []
+
+    def step(i):
+        nonlocal gathered
+        r = trk.track(*dev[i])
+        results.append(r)
+        evals.append(trk.stats()["lm_evals"])
+        if world > 1:
+            pending.append(r["abs_pose"][:3, :].reshape(-1))
+            if len(pending) == args.gather_every:
+                mine = torch.from_numpy(np.stack(pending)).cuda()
+                gathered = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(gathered, mine)  # RCCL over xGMI; 12 floats x gather_every per rank
+                pending.clear()
+
+    for i in order[:args.warmup]:
+        step(i)
+    results.clear()
+    evals.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for i in order[args.warmup:]:
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    fps = args.steps * world / elapsed
+    if rank == 0:
+        # --- roofline of the dominant kernel: live HIP-event timing on the kernel's own stream ---
+        tr = trk.time_residual(0, reps=100)
+        achieved = tr["bytes"] / (tr["mean_us"] * 1e-6) / 1e9
+        roof = dict(bound="hbm", kernel="lm_residual_dense_kernel(L0)", achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
+                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=load_traffic(),
+                    launch_us=round(tr["mean_us"], 3), launch_min_us=round(tr["min_us"], 3),
+                    algorithmic_bytes=int(tr["bytes"]), residuals=tr["n_points"])
+        out = dict(metric="tracked frames/sec (1241x376, 4-level pyramid)", value=round(fps, 2), unit="frames/s",
+                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 4),
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload="synthetic KITTI-shaped stereo sequence (configs[1]), 1241x376, 4 levels, "
+                                        "semi-dense, runner params, one sequence per GPU",
+                               unique_frames=args.unique_frames, sequences_per_gpu=1,
+                               overlap_depth=not args.no_overlap, gather_every=args.gather_every),
+                   roofline=roof,
+                   lm_evals_per_frame=round(float(np.mean(evals)), 2),
+                   keyframes=trk.stats()["n_keyframes"])
+        if world == 1 and args.cpu_frames > 0:
+            n = min(args.cpu_frames, args.steps)
+            cpu_fps, cpu_poses, cpu_dt = cpu_baseline(seq, order, n)
+            # fresh GPU pass over the same frames from the same start: full-pipeline parity next to the timing
+            trk2 = api.Tracker(local_rank, overlap_depth=0 if args.no_overlap else 1)
+            dev2 = [(trk2.upload_frame(l), trk2.upload_frame(r)) for l, r in zip(seq["left"], seq["right"])]
+            trk2.init(*dev2[0])
+            dmax = 0.0
+            for j, i in enumerate(order[:n]):
+                g = trk2.track(*dev2[i])
+                dmax = max(dmax, float(np.abs(g["pose_to_keyframe"].astype(np.float64) - cpu_poses[j]["pose_to_keyframe"]).max()))
+            trk2.close()
+            out["cpu_baseline"] = dict(value=round(cpu_fps, 3), unit="frames/s", cores=1, kind="port",
+                                       sample=f"first {n} frames of the same sequence, oracle runner "
+                                              f"(pyramids + Solve + ComputeDepth per frame), {cpu_dt:.1f} s")
+            out["pose_max_abs_delta_vs_oracle"] = dmax
+            out["speedup_vs_cpu"] = round(fps / cpu_fps, 1)
+        print(json.dumps(out))
+    trk.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

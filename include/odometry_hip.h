@@ -137,6 +137,53 @@ int odo_depth_disparity(odo_depth* d, const float* left, const float* right, int
 int odo_depth_report(const odo_depth* d, int* iters, float* cost, int* n_selected, int* n_matched, int* n_valid);
 int odo_depth_destroy(odo_depth* d);
 
+/* ---- tracker: the runner's frame loop ---------------------------------------------------------------
+ * Replaces the body of main() in run_odometry_kitti_offline.cpp:58-145 (set-up, frame 0) and :198-271 (per
+ * frame): ImagePyramid(cur) -> Solve against the current keyframe -> cur_pose = KF * T^-1 -> ComputeDepth ->
+ * rebuild the frame's image / depth pyramids -> keyframe test on the weighted motion -> Reset(T, 0.01).
+ * Inputs are device-resident fp32 images (rows x cols, dense). ComputeDepth runs on a second HIP stream
+ * concurrently with Solve when overlap_depth != 0 (the two are independent in the reference's loop). */
+typedef struct {
+  int rows, cols, levels;
+  float lm_lambda, lm_precision;          /* ref: run_odometry_kitti_offline.cpp:88 (0.01f, 0.995f) */
+  int lm_max_iters[ODO_MAX_LEVELS];       /* ref: :76 {10,20,30,30} */
+  int lm_robust;                          /* ref: :86 (1 = Huber) */
+  float lm_huber_delta;                   /* ref: :87 (28) */
+  float grad_th, ssd_th, photo_th;        /* ref: :62-64 (8, 900, 15) */
+  float min_depth, max_depth;             /* ref: :59-60 (0.1, 30) */
+  float depth_lambda, depth_huber_delta, depth_precision; /* ref: :65-67 (0.01, 28, 0.995) */
+  int depth_max_iters, boundary, max_residuals;            /* ref: :68,:69 (50, 4), :61 (80000) */
+  int max_disparity, any_size;            /* deviations from the reference, both 0 in parity mode */
+  odo_intrinsics K;
+  float baseline;                         /* ref: :41 */
+  float keyframe_weight[6];               /* ref: :144-145 */
+  float keyframe_motion_th;               /* ref: :258 (1.1) */
+  int smooth_image;                       /* ref: :130,:205,:251 (true) */
+  int overlap_depth;
+} odo_tracker_params;
+
+int odo_tracker_default_params(odo_tracker_params* p); /* the runner's constants for KITTI 1241x376 */
+int odo_tracker_create(int device, const odo_tracker_params* p, odo_tracker** out);
+/* Frame 0 (ref: :95-145): ComputeDepth, pyramids, first keyframe with absolute pose abs_pose0. */
+int odo_tracker_init(odo_tracker* t, const float* left_dev, const float* right_dev, const float abs_pose0_colmajor[16]);
+/* One iteration of the frame loop (ref: :198-271). Returns 0, or -1 when ComputeDepth failed (the runner
+ * breaks out of its loop there, ref: :230-232). A failed Solve is NOT an error (the runner carries on with the
+ * pseudo-identity); solve_status reports it. */
+int odo_tracker_track(odo_tracker* t, const float* left_dev, const float* right_dev, float pose_to_keyframe[16],
+                      float abs_pose[16], int* is_new_keyframe, float* motion_mag, int* solve_status);
+/* Counters of the last tracked frame: LM evaluations, depth-LM iterations, valid depth points, keyframes so far. */
+int odo_tracker_stats(const odo_tracker* t, int* lm_evals, int* depth_iters, int* n_valid_depth, int* n_keyframes);
+/* Device pointers to the last frame's outputs (rows x cols): validity mask (u8), disparity, inverse depth. */
+int odo_tracker_outputs(const odo_tracker* t, const uint8_t** val_dev, const float** disp_dev, const float** dep_dev);
+/* Roofline leg of bench.py: `reps` event-bracketed launches of the dominant kernel (residual / normal-equation
+ * pass) on `level` of the tracker's current pyramids; mean / min launch time, algorithmic bytes of one launch
+ * (12 B per interior pixel + the fp64 partials written) and the number of residuals it produced. */
+int odo_tracker_time_residual(odo_tracker* t, int level, int reps, float* mean_us, float* min_us,
+                              double* algorithmic_bytes, int* n_points);
+odo_lm* odo_tracker_lm(odo_tracker* t);
+odo_ctx* odo_tracker_ctx(odo_tracker* t);
+int odo_tracker_destroy(odo_tracker* t);
+
 #ifdef __cplusplus
 }
 #endif

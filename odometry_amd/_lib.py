@@ -22,6 +22,20 @@ class LmTraceRow(C.Structure):
                 ("err", C.c_float), ("lambda_after", C.c_float), ("delta", C.c_float * 6)]
 
 
+class TrackerParams(C.Structure):
+    _fields_ = [("rows", C.c_int), ("cols", C.c_int), ("levels", C.c_int),
+                ("lm_lambda", C.c_float), ("lm_precision", C.c_float), ("lm_max_iters", C.c_int * MAX_LEVELS),
+                ("lm_robust", C.c_int), ("lm_huber_delta", C.c_float),
+                ("grad_th", C.c_float), ("ssd_th", C.c_float), ("photo_th", C.c_float),
+                ("min_depth", C.c_float), ("max_depth", C.c_float),
+                ("depth_lambda", C.c_float), ("depth_huber_delta", C.c_float), ("depth_precision", C.c_float),
+                ("depth_max_iters", C.c_int), ("boundary", C.c_int), ("max_residuals", C.c_int),
+                ("max_disparity", C.c_int), ("any_size", C.c_int),
+                ("K", Intrinsics), ("baseline", C.c_float),
+                ("keyframe_weight", C.c_float * 6), ("keyframe_motion_th", C.c_float),
+                ("smooth_image", C.c_int), ("overlap_depth", C.c_int)]
+
+
 _fp = C.POINTER(C.c_float)
 _dp = C.POINTER(C.c_double)
 _u8p = C.POINTER(C.c_uint8)
@@ -65,6 +79,16 @@ SIGNATURES = {
     "odo_depth_disparity": (C.c_int, [_vp, _fp, _fp, C.c_int, C.c_int, _u8p, _fp, _fp]),
     "odo_depth_report": (C.c_int, [_vp, _ip, _fp, _ip, _ip, _ip]),
     "odo_depth_destroy": (C.c_int, [_vp]),
+    "odo_tracker_default_params": (C.c_int, [C.POINTER(TrackerParams)]),
+    "odo_tracker_create": (C.c_int, [C.c_int, C.POINTER(TrackerParams), C.POINTER(_vp)]),
+    "odo_tracker_init": (C.c_int, [_vp, _vp, _vp, _fp]),
+    "odo_tracker_track": (C.c_int, [_vp, _vp, _vp, _fp, _fp, _ip, _fp, _ip]),
+    "odo_tracker_stats": (C.c_int, [_vp, _ip, _ip, _ip, _ip]),
+    "odo_tracker_outputs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "odo_tracker_time_residual": (C.c_int, [_vp, C.c_int, C.c_int, _fp, _fp, _dp, _ip]),
+    "odo_tracker_lm": (_vp, [_vp]),
+    "odo_tracker_ctx": (_vp, [_vp]),
+    "odo_tracker_destroy": (C.c_int, [_vp]),
 }
 
 _lib = None

@@ -332,3 +332,85 @@ class KeyFrame:
 
     def ModifyAbsoPose(self):
         return self.abso_pose_
+
+
+class Tracker:
+    """The runner's frame loop (ref: run_odometry_kitti_offline.cpp:58-145, 198-271) over odo_tracker_*.
+    Frames are device-resident: upload them once with `upload_frame` and pass the handles to init/track."""
+
+    def __init__(self, device=0, **overrides):
+        self.lib = L.load()
+        self.params = L.TrackerParams()
+        L.check(self.lib.odo_tracker_default_params(C.byref(self.params)), "odo_tracker_default_params")
+        for k, v in overrides.items():
+            if k == "lm_max_iters":
+                for i, m in enumerate(v):
+                    self.params.lm_max_iters[i] = m
+            elif k == "K":
+                self.params.K = L.Intrinsics(*v)
+            else:
+                setattr(self.params, k, v)
+        h = C.c_void_p()
+        L.check(self.lib.odo_tracker_create(device, C.byref(self.params), C.byref(h)), "odo_tracker_create")
+        self.h = h
+        self._ctx = C.c_void_p(self.lib.odo_tracker_ctx(h))
+        self._bufs = []
+
+    def upload_frame(self, img):
+        img = _f32(img)
+        p = C.c_void_p()
+        L.check(self.lib.odo_dev_alloc(self._ctx, img.nbytes, C.byref(p)), "odo_dev_alloc")
+        L.check(self.lib.odo_dev_upload(self._ctx, p, img.ctypes.data_as(C.c_void_p), img.nbytes), "odo_dev_upload")
+        self._bufs.append(p)
+        return p
+
+    def init(self, left_dev, right_dev, abs_pose0=None):
+        pose = _colmajor(np.eye(4) if abs_pose0 is None else abs_pose0)
+        L.check(self.lib.odo_tracker_init(self.h, left_dev, right_dev, _fp(pose)), "odo_tracker_init")
+
+    def track(self, left_dev, right_dev):
+        T = np.zeros(16, np.float32)
+        A = np.zeros(16, np.float32)
+        nk, ss = C.c_int(0), C.c_int(0)
+        mag = C.c_float(0)
+        st = self.lib.odo_tracker_track(self.h, left_dev, right_dev, _fp(T), _fp(A), C.byref(nk), C.byref(mag),
+                                        C.byref(ss))
+        if st != 0:
+            raise L.OdoError("odo_tracker_track: " + L.last_error())
+        return dict(pose_to_keyframe=_from_colmajor(T), abs_pose=_from_colmajor(A), new_keyframe=bool(nk.value),
+                    motion=mag.value, solve_status=ss.value)
+
+    def stats(self):
+        a, b, c, d = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        L.check(self.lib.odo_tracker_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "odo_tracker_stats")
+        return dict(lm_evals=a.value, depth_iters=b.value, n_valid_depth=c.value, n_keyframes=d.value)
+
+    def outputs(self, rows, cols):
+        v, dsp, dep = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        L.check(self.lib.odo_tracker_outputs(self.h, C.byref(v), C.byref(dsp), C.byref(dep)), "odo_tracker_outputs")
+        out = []
+        for ptr, dt in ((v, np.uint8), (dsp, np.float32), (dep, np.float32)):
+            a = np.empty((rows, cols), dt)
+            L.check(self.lib.odo_dev_download(self._ctx, a.ctypes.data_as(C.c_void_p), ptr, a.nbytes), "download")
+            out.append(a)
+        return out
+
+    def time_residual(self, level, reps=50):
+        mean, mn, b, n = C.c_float(0), C.c_float(0), C.c_double(0), C.c_int(0)
+        L.check(self.lib.odo_tracker_time_residual(self.h, level, reps, C.byref(mean), C.byref(mn), C.byref(b),
+                                                   C.byref(n)), "odo_tracker_time_residual")
+        return dict(mean_us=mean.value, min_us=mn.value, bytes=b.value, n_points=n.value)
+
+    def close(self):
+        if getattr(self, "h", None):
+            for p in self._bufs:
+                self.lib.odo_dev_free(self._ctx, p)
+            self._bufs = []
+            self.lib.odo_tracker_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -226,6 +226,7 @@ __global__ void __launch_bounds__(256) lm_update_kernel(LmState* __restrict__ st
                                                          int* __restrict__ host_flag) {
   if (!(st->active != 0 && st->level == expect_level)) return;
   __shared__ double sh[8][32];
+  __shared__ LmState s_sh;
   const int t = threadIdx.x;
   const int q = t & 31, seg = t >> 5;
   double v = 0.0;
@@ -237,9 +238,9 @@ __global__ void __launch_bounds__(256) lm_update_kernel(LmState* __restrict__ st
     double acc[ODO_NACC];
     for (int i = 0; i < ODO_NACC; i++)
       acc[i] = ((((((sh[0][i] + sh[1][i]) + sh[2][i]) + sh[3][i]) + sh[4][i]) + sh[5][i]) + sh[6][i]) + sh[7][i];
-    LmState s = *st;
+    LmState& s = s_sh;  // LDS copy: dynamic indexing (iters_level[level]) stays out of scratch memory
+    s = *st;
     const int iter_before = s.iter;
-    const float lambda_before = s.lambda;
     const float err_last_before = s.err_last;
     lm_consume(&s, acc, precision, max_iters);
     const int ev = s.n_evals - 1;
@@ -253,7 +254,6 @@ __global__ void __launch_bounds__(256) lm_update_kernel(LmState* __restrict__ st
       r.stop = (s.stop_reason == 3 || s.active) ? 0 : s.stop_reason;
       r.lambda_after = s.lambda;
       for (int i = 0; i < 6; i++) r.delta[i] = (s.active || s.stop_reason == 3) ? s.delta[i] : 0.0f;
-      (void)lambda_before;
     }
     if (iter_before == 0 && s.iters_level[expect_level & 7] == 1) cost_stat[expect_level * 2 + 0] = s.err_now;
     cost_stat[expect_level * 2 + 1] = s.err_now;
@@ -399,7 +399,7 @@ __global__ void __launch_bounds__(256) depth_disparity_kernel(const float* __res
                                                                float f0, float baseline, const uint32_t* __restrict__ pts,
                                                                const int* __restrict__ cnt, float* __restrict__ disp,
                                                                float* __restrict__ dep, float* __restrict__ d0,
-                                                               int* __restrict__ n_matched) {
+                                                               uint8_t* __restrict__ matched) {
   const int lane = threadIdx.x & 63;
   const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int b = slot / kSelCap, k = slot % kSelCap;
@@ -434,14 +434,15 @@ __global__ void __launch_bounds__(256) depth_disparity_kernel(const float* __res
   }
   if (lane == 0) {
     float dd = 0.0f;
-    if (!(best > ssd_th)) {  // :388
+    const bool hit = !(best > ssd_th);  // :388
+    if (hit) {
       const float dsp = (float)(x - match);  // :391
       dd = dsp / (f0 * baseline);            // :394
       disp[(size_t)y * cols + x] = dsp;
       dep[(size_t)y * cols + x] = dd;
-      atomicAdd(n_matched, 1);
     }
     d0[slot] = dd;
+    matched[slot] = hit ? 1 : 0;  // counted later by a reduction (a single-address atomic serialises at ~12 ns each)
   }
 }
 
@@ -454,151 +455,185 @@ struct DepthLmStats {
   int status;
 };
 
-// DepthOptimization (ref: src/depth_estimate.cpp:80-198, 200-242): all points share one accept/reject
-// decision per iteration, so the whole loop runs inside ONE workgroup (no grid-wide barrier, no host round
-// trips). Thread t owns slots t, t+1024, ...; per-slot state lives in L2-resident scratch.
-// Uses the UNBLURRED images (:67).
-constexpr int kDlmThreads = 1024;
-__global__ void __launch_bounds__(kDlmThreads) depth_lm_kernel(const float* __restrict__ left, const float* __restrict__ right,
-                                                                int rows, int cols, const uint32_t* __restrict__ pts,
-                                                                const int* __restrict__ cnt, const float* __restrict__ d0,
-                                                                float* __restrict__ scratch /* 6 x nslots */,
-                                                                float tx, float fx, float huber_delta, float lambda0,
-                                                                float precision, int max_iters, float photo_th,
-                                                                float min_depth, float max_depth, uint8_t* __restrict__ val,
-                                                                float* __restrict__ dep, DepthLmStats* __restrict__ stats) {
+// DepthOptimization (ref: src/depth_estimate.cpp:80-198, 200-242). All points share one accept/reject decision
+// per iteration (:150-161). One launch per evaluation, one thread per point slot; the decision for evaluation
+// k-1 is re-derived at the top of launch k by EVERY block from the per-block partial sums of launch k-1 (fixed
+// summation order -> all blocks agree bit for bit), so no grid barrier and no host round trip is needed.
+// State and partials are double-buffered by launch parity. Uses the UNBLURRED images (:67).
+struct DepthLmState {
+  float lambda, err_last, err_now;
+  int iter;
+  int done;
+};
+constexpr int kDlmBlock = 256;
+constexpr int kDlmBlocks = kSelBlocks * kSelCap / kDlmBlock;  // 160
+
+__global__ void __launch_bounds__(kDlmBlock) depth_lm_step_kernel(
+    int k, const float* __restrict__ left, const float* __restrict__ right, int cols, const uint32_t* __restrict__ pts,
+    const int* __restrict__ cnt, const float* __restrict__ d0, float* __restrict__ scratch /* 6 x nslots */,
+    DepthLmState* __restrict__ state /* [2] */, double* __restrict__ part_e /* [2][blocks] */,
+    int* __restrict__ part_n /* [2][blocks] */, float tx, float fx, float huber_delta, float lambda0, float precision,
+    int max_iters) {
   constexpr int nslots = kSelBlocks * kSelCap;
-  constexpr int per = nslots / kDlmThreads;  // 40
-  __shared__ double shs[kDlmThreads];
-  __shared__ int shn[kDlmThreads];
-  __shared__ int sh_mode;      // 0 reject+continue, 1 accept+continue, 2 reject+break, 3 accept+break
-  __shared__ float sh_lambda;
+  __shared__ double shs[kDlmBlock];
+  __shared__ int shn[kDlmBlock];
   const int t = threadIdx.x;
+  const int s = blockIdx.x * kDlmBlock + t;
   float* cur = scratch;
   float* pre = scratch + nslots;
   float* tmp = scratch + 2 * nslots;
   float* res = scratch + 3 * nslots;  // residual of the last evaluated step (:231), -1000 = out of range
   float* jt = scratch + 4 * nslots;   // diagonal of JtWJ (:234)
   float* bb = scratch + 5 * nslots;   // -JtWr (:235)
-  int nsel = 0;
-  for (int j = 0; j < per; j++) {
-    const int s = t + j * kDlmThreads;
-    const bool ok = (s % kSelCap) < cnt[s / kSelCap];
-    nsel += ok;
+  const bool ok = (s % kSelCap) < cnt[s / kSelCap];
+  DepthLmState st;
+  float my_tmp;
+  if (k == 0) {
+    st.lambda = lambda0; st.err_last = 1e+10f; st.err_now = 0.0f; st.iter = 0;
+    st.done = (max_iters > 0) ? 0 : 1;
     const float v = ok ? d0[s] : 0.0f;
     cur[s] = v; pre[s] = 0.0f; tmp[s] = v; res[s] = 0.0f; jt[s] = 1.0f; bb[s] = 0.0f;
-  }
-  float lambda = lambda0, err_last = 1e+10f, err_now = 0.0f;
-  int iter = 0;
-  while (max_iters > iter) {  // :141
-    double esum = 0.0;
-    int nact = 0;
-    for (int j = 0; j < per; j++) {
-      const int s = t + j * kDlmThreads;
-      if ((s % kSelCap) >= cnt[s / kSelCap]) continue;
-      const uint32_t pk = pts[s];
-      const int x = (int)(pk & 0xffffu), y = (int)(pk >> 16);
-      const float wf = floorf((float)x - tx * fx * tmp[s]);  // :217
-      if (!(wf >= 2.0f) || !(wf <= (float)(cols - 2))) {     // :219-223
-        jt[s] = 0.0f; bb[s] = 0.0f; res[s] = -1000.0f;
-        continue;
-      }
-      const int wx = (int)wf;
-      const float* Rr = right + (size_t)y * cols;
-      const float r_i = left[(size_t)y * cols + x] - Rr[wx];                                   // :226
-      const float w_i = (fabsf(r_i) <= huber_delta) ? 1.0f : huber_delta / fabsf(r_i);          // :228
-      const float r_diff = tx * fx * 0.5f * (Rr[wx + 1] - Rr[wx - 1]);                          // :229
-      res[s] = fabsf(r_i);
-      nact++;
-      esum += (double)(r_i * r_i * w_i);                                                        // :233
-      jt[s] = r_diff * r_diff * w_i;                                                            // :234
-      bb[s] = -r_diff * w_i * r_i;                                                              // :235
-    }
-    shs[t] = esum;
-    shn[t] = nact;
+    my_tmp = v;
+    if (st.done) { if (blockIdx.x == 0 && t == 0) state[1] = st; return; }
+  } else {
+    st = state[k & 1];
+    if (st.done) { if (blockIdx.x == 0 && t == 0) state[(k + 1) & 1] = st; return; }
+    // ---- decision for evaluation k-1 (every block, identical arithmetic) ----
+    const double* pe = part_e + ((k - 1) & 1) * kDlmBlocks;
+    const int* pn = part_n + ((k - 1) & 1) * kDlmBlocks;
+    shs[t] = (t < kDlmBlocks) ? pe[t] : 0.0;
+    shn[t] = (t < kDlmBlocks) ? pn[t] : 0;
     __syncthreads();
-    for (int o = kDlmThreads / 2; o > 0; o >>= 1) {
+    for (int o = kDlmBlock / 2; o > 0; o >>= 1) {
       if (t < o) { shs[t] += shs[t + o]; shn[t] += shn[t + o]; }
       __syncthreads();
     }
-    if (t == 0) {
-      err_now = (1.0f / (float)shn[0]) * (float)shs[0];  // :239
-      int mode;
-      if (err_now > err_last) {  // :150
-        lambda = lambda * 10.0f;
-        mode = (lambda > 1e+5f) ? 2 : 0;
-      } else {
-        const float err_diff = err_now / err_last;
-        if (err_diff > precision) mode = 3;
-        else { mode = 1; err_last = err_now; lambda = fmaxf(lambda / 10.0f, 1e-7f); }
-      }
-      sh_mode = mode;
-      sh_lambda = lambda;
+    const float err_now = (1.0f / (float)shn[0]) * (float)shs[0];  // :239
+    __syncthreads();
+    st.err_now = err_now;
+    int mode;  // 0 reject+continue, 1 accept+continue, 2 reject+break, 3 accept+break
+    if (err_now > st.err_last) {  // :150
+      st.lambda = st.lambda * 10.0f;
+      mode = (st.lambda > 1e+5f) ? 2 : 0;
+    } else {
+      const float err_diff = err_now / st.err_last;
+      if (err_diff > precision) mode = 3;
+      else { mode = 1; st.err_last = err_now; st.lambda = fmaxf(st.lambda / 10.0f, 1e-7f); }
     }
-    __syncthreads();
-    const int mode = sh_mode;
-    const float lam = sh_lambda;
-    __syncthreads();
-    if (mode == 2) break;
-    for (int j = 0; j < per; j++) {
-      const int s = t + j * kDlmThreads;
-      if ((s % kSelCap) >= cnt[s / kSelCap]) continue;
+    my_tmp = 0.0f;
+    if (mode != 2 && ok) {
       float c;
-      if (mode == 0) c = pre[s];           // :153
-      else { c = tmp[s]; pre[s] = c; }     // :155-156
+      if (mode == 0) c = pre[s];            // :153
+      else { c = tmp[s]; pre[s] = c; }      // :155-156
       cur[s] = c;
       if (mode != 3) {
         const float jj = jt[s];
-        const float A = jj + lam * jj;        // :164
+        const float A = jj + st.lambda * jj;  // :164
         const float dd = (1.0f / A) * bb[s];  // :165
-        tmp[s] = dd + c;                      // :166
+        my_tmp = dd + c;                      // :166
+        tmp[s] = my_tmp;
       }
     }
-    if (mode == 3) break;
-    iter++;
+    if (mode == 2 || mode == 3) st.done = 1;
+    else {
+      st.iter++;                              // :167
+      if (!(max_iters > st.iter)) st.done = 1;  // :141
+    }
+    if (st.done) { if (blockIdx.x == 0 && t == 0) state[(k + 1) & 1] = st; return; }
   }
-  // write-back + filters (:176-191)
-  int nvalid = 0;
-  for (int j = 0; j < per; j++) {
-    const int s = t + j * kDlmThreads;
-    if ((s % kSelCap) >= cnt[s / kSelCap]) continue;
+  // ---- evaluation k at tmp (ComputeResidualJacobian :200-242) ----
+  double esum = 0.0;
+  int nact = 0;
+  if (ok) {
     const uint32_t pk = pts[s];
-    const size_t o = (size_t)(pk >> 16) * cols + (pk & 0xffffu);
-    const float c = cur[s];
-    const float rs = res[s];
-    bool good = !(rs > photo_th || rs == -1000.0f);
-    if (good && (1.0f / c > max_depth || 1.0f / c < min_depth)) good = false;
-    val[o] = good ? 1 : 0;
-    dep[o] = good ? c : 0.0f;
-    nvalid += good;
+    const int x = (int)(pk & 0xffffu), y = (int)(pk >> 16);
+    const float wf = floorf((float)x - tx * fx * my_tmp);  // :217
+    if (!(wf >= 2.0f) || !(wf <= (float)(cols - 2))) {     // :219-223
+      jt[s] = 0.0f; bb[s] = 0.0f; res[s] = -1000.0f;
+    } else {
+      const int wx = (int)wf;
+      const float* Rr = right + (size_t)y * cols;
+      const float r_i = left[(size_t)y * cols + x] - Rr[wx];                            // :226
+      const float w_i = (fabsf(r_i) <= huber_delta) ? 1.0f : huber_delta / fabsf(r_i);   // :228
+      const float r_diff = tx * fx * 0.5f * (Rr[wx + 1] - Rr[wx - 1]);                   // :229
+      res[s] = fabsf(r_i);
+      nact = 1;
+      esum = (double)(r_i * r_i * w_i);                                                  // :233
+      jt[s] = r_diff * r_diff * w_i;                                                     // :234
+      bb[s] = -r_diff * w_i * r_i;                                                       // :235
+    }
   }
-  shn[t] = nvalid;
-  shs[t] = (double)nsel;
+  shs[t] = esum;
+  shn[t] = nact;
   __syncthreads();
-  for (int o = kDlmThreads / 2; o > 0; o >>= 1) {
-    if (t < o) { shn[t] += shn[t + o]; shs[t] += shs[t + o]; }
+  for (int o = kDlmBlock / 2; o > 0; o >>= 1) {
+    if (t < o) { shs[t] += shs[t + o]; shn[t] += shn[t + o]; }
     __syncthreads();
   }
   if (t == 0) {
-    stats->iters = iter;
-    stats->cost = err_now;
-    stats->n_valid = shn[0];
-    stats->n_selected = (int)shs[0];
-    stats->status = (shn[0] < 500) ? -1 : 0;  // :192-197
+    part_e[(k & 1) * kDlmBlocks + blockIdx.x] = shs[0];
+    part_n[(k & 1) * kDlmBlocks + blockIdx.x] = shn[0];
+    if (blockIdx.x == 0) state[(k + 1) & 1] = st;
   }
 }
 
-__global__ void depth_stats_selected_kernel(const int* __restrict__ cnt, DepthLmStats* __restrict__ stats) {
-  // disparity-only entry: fill n_selected without running the LM
-  __shared__ int sh[kSelBlocks];
+// Write-back + filters (ref: src/depth_estimate.cpp:176-191) and per-block counts {valid, selected, matched}.
+// run_lm == 0: disparity-only entry (counts only, mask/depth untouched).
+__global__ void __launch_bounds__(kDlmBlock) depth_finalize_kernel(int run_lm, int cols, const uint32_t* __restrict__ pts,
+                                                                   const int* __restrict__ cnt,
+                                                                   const uint8_t* __restrict__ matched,
+                                                                   const float* __restrict__ scratch, float photo_th,
+                                                                   float min_depth, float max_depth,
+                                                                   uint8_t* __restrict__ val, float* __restrict__ dep,
+                                                                   int* __restrict__ counts /* [blocks][3] */) {
+  constexpr int nslots = kSelBlocks * kSelCap;
+  __shared__ int sh[3][kDlmBlock];
   const int t = threadIdx.x;
-  sh[t] = cnt[t];
+  const int s = blockIdx.x * kDlmBlock + t;
+  const bool ok = (s % kSelCap) < cnt[s / kSelCap];
+  int good = 0;
+  if (ok && run_lm) {
+    const uint32_t pk = pts[s];
+    const size_t o = (size_t)(pk >> 16) * cols + (pk & 0xffffu);
+    const float c = scratch[s];
+    const float rs = scratch[3 * nslots + s];
+    bool g = !(rs > photo_th || rs == -1000.0f);
+    if (g && (1.0f / c > max_depth || 1.0f / c < min_depth)) g = false;
+    val[o] = g ? 1 : 0;
+    dep[o] = g ? c : 0.0f;
+    good = g;
+  }
+  sh[0][t] = good;
+  sh[1][t] = ok ? 1 : 0;
+  sh[2][t] = (ok && matched[s]) ? 1 : 0;
   __syncthreads();
-  for (int o = kSelBlocks / 2; o > 0; o >>= 1) {
-    if (t < o) sh[t] += sh[t + o];
+  for (int o = kDlmBlock / 2; o > 0; o >>= 1) {
+    if (t < o) { sh[0][t] += sh[0][t + o]; sh[1][t] += sh[1][t + o]; sh[2][t] += sh[2][t + o]; }
     __syncthreads();
   }
-  if (t == 0) { stats->n_selected = sh[0]; stats->iters = 0; stats->cost = 0.0f; stats->n_valid = 0; stats->status = 0; }
+  if (t < 3) counts[blockIdx.x * 3 + t] = sh[t][0];
+}
+
+__global__ void __launch_bounds__(kDlmBlock) depth_stats_kernel(int run_lm, int n_launches, const int* __restrict__ counts,
+                                                                const DepthLmState* __restrict__ state,
+                                                                DepthLmStats* __restrict__ stats) {
+  __shared__ int sh[3][kDlmBlock];
+  const int t = threadIdx.x;
+  for (int q = 0; q < 3; q++) sh[q][t] = (t < kDlmBlocks) ? counts[t * 3 + q] : 0;
+  __syncthreads();
+  for (int o = kDlmBlock / 2; o > 0; o >>= 1) {
+    if (t < o) { sh[0][t] += sh[0][t + o]; sh[1][t] += sh[1][t + o]; sh[2][t] += sh[2][t + o]; }
+    __syncthreads();
+  }
+  if (t == 0) {
+    const DepthLmState st = state[n_launches & 1];  // the state written by the last launch
+    stats->iters = run_lm ? st.iter : 0;
+    stats->cost = run_lm ? st.err_now : 0.0f;
+    stats->n_valid = sh[0][0];
+    stats->n_selected = sh[1][0];
+    stats->n_matched = sh[2][0];
+    stats->status = (run_lm && sh[0][0] < 500) ? -1 : 0;  // :192-197
+  }
 }
 
 }  // namespace odo

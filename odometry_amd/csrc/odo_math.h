@@ -185,29 +185,43 @@ struct Se3 {
 };
 
 // Eigen Quaternion(Matrix3) — trace-based, no renormalisation (so3.hpp:463-468). R row-major.
+// The three "largest diagonal element" cases are spelled out so every index is a compile-time constant.
 ODO_HD void rot_to_quat(const float R[9], Se3* o) {
-  float q[4];
   float t = (R[0] + R[4]) + R[8];
   if (t > 0.0f) {
     t = sqrtf(t + 1.0f);
-    q[3] = 0.5f * t;
+    o->qw = 0.5f * t;
     t = 0.5f / t;
-    q[0] = (R[7] - R[5]) * t;
-    q[1] = (R[2] - R[6]) * t;
-    q[2] = (R[3] - R[1]) * t;
-  } else {
-    int i = 0;
-    if (R[4] > R[0]) i = 1;
-    if (R[8] > R[i * 4]) i = 2;
-    const int j = (i + 1) % 3, k = (j + 1) % 3;
-    t = sqrtf(((R[i * 4] - R[j * 4]) - R[k * 4]) + 1.0f);
-    q[i] = 0.5f * t;
-    t = 0.5f / t;
-    q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t;
-    q[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
-    q[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+    o->qx = (R[7] - R[5]) * t;
+    o->qy = (R[2] - R[6]) * t;
+    o->qz = (R[3] - R[1]) * t;
+    return;
   }
-  o->qx = q[0]; o->qy = q[1]; o->qz = q[2]; o->qw = q[3];
+  int i = 0;
+  if (R[4] > R[0]) i = 1;
+  if (R[8] > (i == 1 ? R[4] : R[0])) i = 2;
+  if (i == 0) {        // j = 1, k = 2
+    t = sqrtf(((R[0] - R[4]) - R[8]) + 1.0f);
+    o->qx = 0.5f * t;
+    t = 0.5f / t;
+    o->qw = (R[7] - R[5]) * t;
+    o->qy = (R[3] + R[1]) * t;
+    o->qz = (R[6] + R[2]) * t;
+  } else if (i == 1) { // j = 2, k = 0
+    t = sqrtf(((R[4] - R[8]) - R[0]) + 1.0f);
+    o->qy = 0.5f * t;
+    t = 0.5f / t;
+    o->qw = (R[2] - R[6]) * t;
+    o->qz = (R[7] + R[5]) * t;
+    o->qx = (R[1] + R[3]) * t;
+  } else {             // j = 0, k = 1
+    t = sqrtf(((R[8] - R[0]) - R[4]) + 1.0f);
+    o->qz = 0.5f * t;
+    t = 0.5f / t;
+    o->qw = (R[3] - R[1]) * t;
+    o->qx = (R[2] + R[6]) * t;
+    o->qy = (R[5] + R[7]) * t;
+  }
 }
 
 // Eigen Quaternion::toRotationMatrix (so3.hpp:302-304). R row-major.
@@ -293,37 +307,59 @@ ODO_HD void se3_left_update(const Se3& delta, const Se3& cur, Se3* out) {
 
 // Damped normal equations A = JtWJ + lambda*diag(JtWJ), b = -JtWr (lm_optimizer.cpp:145-151), solved in fp64
 // by Gaussian elimination with partial pivoting; a zero pivot gives a zero step component. Step rounded to fp32.
+// Written with compile-time row/column indices only (row swaps are predicated exchanges), so on the device the
+// 6x7 system lives in registers — no scratch memory, no dynamic indexing.
 ODO_HD void solve_damped(const double acc[ODO_NACC], float lambda, float delta[6]) {
   double A[6][7];
-  int k = 0;
-  for (int a = 0; a < 6; a++)
-    for (int b = a; b < 6; b++) { A[a][b] = acc[k]; A[b][a] = acc[k]; k++; }
+  {
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+#pragma unroll
+      for (int b = a; b < 6; b++) { A[a][b] = acc[k]; A[b][a] = acc[k]; k++; }
+    }
+  }
+#pragma unroll
   for (int a = 0; a < 6; a++) {
     A[a][a] = A[a][a] + (double)lambda * A[a][a];
     A[a][6] = -acc[21 + a];
   }
   bool ok[6];
+#pragma unroll
   for (int c = 0; c < 6; c++) {
     int p = c;
     double best = fabs(A[c][c]);
-    for (int i = c + 1; i < 6; i++)
-      if (fabs(A[i][c]) > best) { best = fabs(A[i][c]); p = i; }
-    if (!(best > 0.0)) { ok[c] = false; continue; }
-    ok[c] = true;
-    if (p != c)
-      for (int j = 0; j < 7; j++) { const double t = A[c][j]; A[c][j] = A[p][j]; A[p][j] = t; }
+#pragma unroll
     for (int i = c + 1; i < 6; i++) {
-      const double f = A[i][c] / A[c][c];
-      for (int j = c; j < 7; j++) A[i][j] = A[i][j] - f * A[c][j];
+      const double v = fabs(A[i][c]);
+      if (v > best) { best = v; p = i; }
+    }
+    ok[c] = (best > 0.0);
+    if (ok[c]) {
+#pragma unroll
+      for (int i = c + 1; i < 6; i++) {
+        if (p == i) {
+#pragma unroll
+          for (int j = 0; j < 7; j++) { const double t = A[c][j]; A[c][j] = A[i][j]; A[i][j] = t; }
+        }
+      }
+#pragma unroll
+      for (int i = c + 1; i < 6; i++) {
+        const double f = A[i][c] / A[c][c];
+#pragma unroll
+        for (int j = c; j < 7; j++) A[i][j] = A[i][j] - f * A[c][j];
+      }
     }
   }
   double xs[6];
+#pragma unroll
   for (int c = 5; c >= 0; c--) {
-    if (!ok[c]) { xs[c] = 0.0; continue; }
     double s = A[c][6];
+#pragma unroll
     for (int j = c + 1; j < 6; j++) s = s - A[c][j] * xs[j];
-    xs[c] = s / A[c][c];
+    xs[c] = ok[c] ? s / A[c][c] : 0.0;
   }
+#pragma unroll
   for (int c = 0; c < 6; c++) delta[c] = (float)xs[c];
 }
 

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "../../include/odometry_hip.h"
@@ -507,12 +508,14 @@ struct odo_depth {
   uint8_t* d_val;
   uint32_t* d_pts;
   int* d_cnt;
-  int* d_nmatched;
+  uint8_t* d_matched;
+  DepthLmState* d_lmstate;
+  double* d_part_e;
+  int* d_part_n;
+  int* d_counts;
   DepthLmStats* d_stats;
   DepthLmStats* h_stats;
-  int* h_nmatched;
   DepthLmStats last;
-  int last_matched;
 };
 
 extern "C" int odo_depth_create(odo_ctx* ctx, float grad_th, float ssd_th, float photo_th, float min_depth, float max_depth,
@@ -535,10 +538,13 @@ extern "C" int odo_depth_create(odo_ctx* ctx, float grad_th, float ssd_th, float
   HIP_OK(hipMalloc((void**)&d->d_cnt, sizeof(int) * kSelBlocks));
   HIP_OK(hipMalloc((void**)&d->d_d0, sizeof(float) * kSelBlocks * kSelCap));
   HIP_OK(hipMalloc((void**)&d->d_scratch, sizeof(float) * 6 * kSelBlocks * kSelCap));
-  HIP_OK(hipMalloc((void**)&d->d_nmatched, sizeof(int)));
+  HIP_OK(hipMalloc((void**)&d->d_matched, kSelBlocks * kSelCap));
+  HIP_OK(hipMalloc((void**)&d->d_lmstate, sizeof(DepthLmState) * 2));
+  HIP_OK(hipMalloc((void**)&d->d_part_e, sizeof(double) * 2 * kDlmBlocks));
+  HIP_OK(hipMalloc((void**)&d->d_part_n, sizeof(int) * 2 * kDlmBlocks));
+  HIP_OK(hipMalloc((void**)&d->d_counts, sizeof(int) * 3 * kDlmBlocks));
   HIP_OK(hipMalloc((void**)&d->d_stats, sizeof(DepthLmStats)));
   HIP_OK(hipHostMalloc((void**)&d->h_stats, sizeof(DepthLmStats), hipHostMallocDefault));
-  HIP_OK(hipHostMalloc((void**)&d->h_nmatched, sizeof(int), hipHostMallocDefault));
   *out = d;
   return 0;
 }
@@ -555,9 +561,9 @@ extern "C" int odo_depth_destroy(odo_depth* d) {
   if (!d) return 0;
   (void)hipStreamSynchronize(d->ctx->stream);
   depth_free_images(d);
-  void* dv[] = {d->d_pts, d->d_cnt, d->d_d0, d->d_scratch, d->d_nmatched, d->d_stats};
+  void* dv[] = {d->d_pts, d->d_cnt, d->d_d0, d->d_scratch, d->d_matched, d->d_lmstate, d->d_part_e, d->d_part_n, d->d_counts, d->d_stats};
   for (void* q : dv) if (q) (void)hipFree(q);
-  (void)hipHostFree(d->h_stats); (void)hipHostFree(d->h_nmatched);
+  (void)hipHostFree(d->h_stats);
   delete d;
   return 0;
 }
@@ -596,31 +602,34 @@ static int depth_run(odo_depth* d, const float* left, const float* right, int ro
   HIP_OK(hipMemsetAsync(val, 0, n, s));
   HIP_OK(hipMemsetAsync(disp, 0, sizeof(float) * n, s));  // zero-filled outputs
   HIP_OK(hipMemsetAsync(dep, 0, sizeof(float) * n, s));
-  HIP_OK(hipMemsetAsync(d->d_nmatched, 0, sizeof(int), s));
   hipLaunchKernelGGL(blur3x3_kernel, grid2d(cols, rows, 2), dim3(256), 0, s, left, d->d_bl, right, d->d_br, rows, cols);
   hipLaunchKernelGGL(depth_select_kernel, dim3(kSelBlocks), dim3(kSelThreads), 0, s, d->d_bl, rows, cols, d->boundary,
                      d->grad_th, val, d->d_pts, d->d_cnt);
   hipLaunchKernelGGL(depth_disparity_kernel, dim3(kSelBlocks * kSelCap / 4), dim3(256), 0, s, d->d_bl, d->d_br, rows, cols,
                      d->boundary, d->max_disparity, d->ssd_th, d->K.f0, d->baseline, d->d_pts, d->d_cnt, disp, dep,
-                     d->d_d0, d->d_nmatched);
-  if (stage == 1) {
-    hipLaunchKernelGGL(depth_stats_selected_kernel, dim3(1), dim3(kSelBlocks), 0, s, d->d_cnt, d->d_stats);
-  } else {
-    hipLaunchKernelGGL(depth_lm_kernel, dim3(1), dim3(kDlmThreads), 0, s, left, right, rows, cols, d->d_pts, d->d_cnt,
-                       d->d_d0, d->d_scratch, d->baseline, d->K.f0, d->huber_delta, d->lambda, d->precision, d->max_iters,
-                       d->photo_th, d->min_depth, d->max_depth, val, dep, d->d_stats);
+                     d->d_d0, d->d_matched);
+  int n_launches = 0;
+  if (stage != 1) {
+    // launch k decides on evaluation k-1 and runs evaluation k; max_iters evaluations need max_iters + 1 launches
+    for (int k = 0; k <= d->max_iters; k++) {
+      hipLaunchKernelGGL(depth_lm_step_kernel, dim3(kDlmBlocks), dim3(kDlmBlock), 0, s, k, left, right, cols, d->d_pts,
+                         d->d_cnt, d->d_d0, d->d_scratch, d->d_lmstate, d->d_part_e, d->d_part_n, d->baseline, d->K.f0,
+                         d->huber_delta, d->lambda, d->precision, d->max_iters);
+      n_launches++;
+    }
   }
+  hipLaunchKernelGGL(depth_finalize_kernel, dim3(kDlmBlocks), dim3(kDlmBlock), 0, s, stage != 1 ? 1 : 0, cols, d->d_pts,
+                     d->d_cnt, d->d_matched, d->d_scratch, d->photo_th, d->min_depth, d->max_depth, val, dep, d->d_counts);
+  hipLaunchKernelGGL(depth_stats_kernel, dim3(1), dim3(kDlmBlock), 0, s, stage != 1 ? 1 : 0, n_launches, d->d_counts,
+                     d->d_lmstate, d->d_stats);
   HIP_OK(hipGetLastError());
   HIP_OK(hipMemcpyAsync(d->h_stats, d->d_stats, sizeof(DepthLmStats), hipMemcpyDeviceToHost, s));
-  HIP_OK(hipMemcpyAsync(d->h_nmatched, d->d_nmatched, sizeof(int), hipMemcpyDeviceToHost, s));
   return 0;
 }
 
 static int depth_finish(odo_depth* d) {
   HIP_OK(hipStreamSynchronize(d->ctx->stream));
   d->last = *d->h_stats;
-  d->last_matched = *d->h_nmatched;
-  d->last.n_matched = d->last_matched;
   if (d->last.status != 0) return fail("number of valid after optimization is too small: %d", d->last.n_valid);
   return 0;
 }
@@ -665,7 +674,9 @@ extern "C" int odo_depth_report(const odo_depth* d, int* iters, float* cost, int
   if (iters) *iters = d->last.iters;
   if (cost) *cost = d->last.cost;
   if (n_selected) *n_selected = d->last.n_selected;
-  if (n_matched) *n_matched = d->last_matched;
+  if (n_matched) *n_matched = d->last.n_matched;
   if (n_valid) *n_valid = d->last.n_valid;
   return 0;
 }
+
+#include "tracker.hip.h"

@@ -1,0 +1,274 @@
+// tracker.hip.h — the runner's frame loop (run_odometry_kitti_offline.cpp:58-145, 198-271) as a C-ABI object.
+// Host logic only (keyframe policy, pose chaining); all image work is enqueued on two HIP streams.
+// Included by odometry_hip.hip after the pyramid / LM / depth objects are defined.
+#pragma once
+
+struct odo_tracker {
+  odo_tracker_params p;
+  odo_ctx* ctx_a;  // pyramids of the incoming frame + pose LM
+  odo_ctx* ctx_b;  // ComputeDepth + the frame's keyframe-candidate pyramids
+  odo_lm* lm;
+  odo_depth* depth;
+  odo_pyr *kf_img, *kf_dep, *cur_img, *pre_img, *pre_dep;
+  uint8_t* d_val;
+  float *d_disp, *d_dep;
+  float kf_abs[16];
+  float pose_to_kf[16];
+  int n_keyframes, frame_id;
+  int last_evals, last_depth_iters, last_valid;
+  hipEvent_t ev_inputs;
+};
+
+extern "C" int odo_tracker_default_params(odo_tracker_params* p) {
+  if (!p) return fail("NULL params");
+  memset(p, 0, sizeof(*p));
+  p->rows = 376; p->cols = 1241; p->levels = 4;
+  p->lm_lambda = 0.01f; p->lm_precision = 0.995f;
+  const int mi[4] = {10, 20, 30, 30};
+  for (int i = 0; i < 4; i++) p->lm_max_iters[i] = mi[i];
+  p->lm_robust = 1; p->lm_huber_delta = 28.0f;
+  p->grad_th = 8.0f; p->ssd_th = 900.0f; p->photo_th = 15.0f;
+  p->min_depth = 0.1f; p->max_depth = 30.0f;
+  p->depth_lambda = 0.01f; p->depth_huber_delta = 28.0f; p->depth_precision = 0.995f;
+  p->depth_max_iters = 50; p->boundary = 4; p->max_residuals = 80000;
+  p->max_disparity = 0; p->any_size = 0;
+  p->K = kKitti00;
+  p->baseline = 386.1448f / 718.856f;
+  const float w[6] = {0.1f / 3.3f, 1.0f / 3.3f, 0.1f / 3.3f, 1.0f / 3.3f, 0.1f / 3.3f, 1.0f / 3.3f};
+  for (int i = 0; i < 6; i++) p->keyframe_weight[i] = w[i];
+  p->keyframe_motion_th = 1.1f;
+  p->smooth_image = 1;
+  p->overlap_depth = 1;
+  return 0;
+}
+
+extern "C" int odo_tracker_destroy(odo_tracker* t) {
+  if (!t) return 0;
+  if (t->ctx_a) (void)hipStreamSynchronize(t->ctx_a->stream);
+  if (t->ctx_b) (void)hipStreamSynchronize(t->ctx_b->stream);
+  odo_lm_destroy(t->lm);
+  odo_depth_destroy(t->depth);
+  odo_pyr* ps[] = {t->kf_img, t->kf_dep, t->cur_img, t->pre_img, t->pre_dep};
+  for (odo_pyr* q : ps) odo_pyramid_destroy(q);
+  if (t->d_val) (void)hipFree(t->d_val);
+  if (t->d_disp) (void)hipFree(t->d_disp);
+  if (t->d_dep) (void)hipFree(t->d_dep);
+  if (t->ev_inputs) (void)hipEventDestroy(t->ev_inputs);
+  odo_ctx_destroy(t->ctx_b);
+  odo_ctx_destroy(t->ctx_a);
+  delete t;
+  return 0;
+}
+
+extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_tracker** out) {
+  if (!p || !out) return fail("odo_tracker_create: NULL arg");
+  *out = nullptr;
+  odo_tracker* t = new (std::nothrow) odo_tracker();
+  if (!t) return fail("out of memory");
+  memset(t, 0, sizeof(*t));
+  t->p = *p;
+  float eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  memcpy(t->pose_to_kf, eye, sizeof(eye));
+  memcpy(t->kf_abs, eye, sizeof(eye));
+  const size_t n = (size_t)p->rows * p->cols;
+  bool ok = odo_ctx_create(device, &t->ctx_a) == 0 && odo_ctx_create(device, &t->ctx_b) == 0;
+  ok = ok && odo_lm_create(t->ctx_a, p->lm_lambda, p->lm_precision, p->lm_max_iters, p->levels, eye, p->lm_robust,
+                           p->lm_huber_delta, &p->K, &t->lm) == 0;
+  ok = ok && odo_depth_create(t->ctx_b, p->grad_th, p->ssd_th, p->photo_th, p->min_depth, p->max_depth, p->depth_lambda,
+                              p->depth_huber_delta, p->depth_precision, p->depth_max_iters, p->boundary, &p->K, p->baseline,
+                              p->max_residuals, p->max_disparity, p->any_size, &t->depth) == 0;
+  ok = ok && pyr_alloc(t->ctx_a, p->rows, p->cols, p->levels, ODO_PYR_IMAGE, &t->cur_img) == 0;
+  ok = ok && pyr_alloc(t->ctx_b, p->rows, p->cols, p->levels, ODO_PYR_IMAGE, &t->kf_img) == 0;
+  ok = ok && pyr_alloc(t->ctx_b, p->rows, p->cols, p->levels, ODO_PYR_DEPTH, &t->kf_dep) == 0;
+  ok = ok && pyr_alloc(t->ctx_b, p->rows, p->cols, p->levels, ODO_PYR_IMAGE, &t->pre_img) == 0;
+  ok = ok && pyr_alloc(t->ctx_b, p->rows, p->cols, p->levels, ODO_PYR_DEPTH, &t->pre_dep) == 0;
+  ok = ok && hipMalloc((void**)&t->d_val, n) == hipSuccess && hipMalloc((void**)&t->d_disp, sizeof(float) * n) == hipSuccess &&
+       hipMalloc((void**)&t->d_dep, sizeof(float) * n) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&t->ev_inputs, hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    char keep[512];
+    snprintf(keep, sizeof(keep), "%s", g_err);
+    odo_tracker_destroy(t);
+    return fail("odo_tracker_create failed: %s", keep);
+  }
+  *out = t;
+  return 0;
+}
+
+// ComputeDepth of the pair and the frame's keyframe-candidate pyramids, all on stream B (ref: :226-252).
+static int tracker_depth_and_pyramids(odo_tracker* t, const float* left, const float* right) {
+  const odo_tracker_params& p = t->p;
+  if (depth_check_size(t->depth, p.rows, p.cols)) return -1;
+  if (depth_ensure(t->depth, p.rows, p.cols)) return -1;
+  if (depth_run(t->depth, left, right, p.rows, p.cols, t->d_val, t->d_disp, t->d_dep, 2)) return -1;
+  if (pyr_build(t->pre_img, left, p.smooth_image)) return -1;  // :251 (the runner builds this pyramid a second time)
+  if (pyr_build(t->pre_dep, t->d_dep, 0)) return -1;           // :252
+  return 0;
+}
+
+extern "C" int odo_tracker_init(odo_tracker* t, const float* left, const float* right, const float abs_pose0[16]) {
+  if (!t || !left || !right || !abs_pose0) return fail("odo_tracker_init: NULL arg");
+  HIP_OK(hipSetDevice(t->ctx_a->device));
+  if (tracker_depth_and_pyramids(t, left, right)) return -1;   // :102, :130-131
+  if (depth_finish(t->depth)) { fail("Init 0-th frame failed!"); return -1; }  // :103-106
+  std::swap(t->kf_img, t->pre_img);                             // :141 first keyframe
+  std::swap(t->kf_dep, t->pre_dep);
+  memcpy(t->kf_abs, abs_pose0, sizeof(float) * 16);             // :143
+  memcpy(t->pose_to_kf, abs_pose0, sizeof(float) * 16);         // :98 pose_to_keyframe = cur_pose
+  float eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  odo_lm_reset(t->lm, eye, t->p.lm_lambda);                     // :77-81 init_relative_affine = I
+  t->n_keyframes = 1;
+  t->frame_id = 0;
+  t->last_valid = t->depth->last.n_valid;
+  t->last_depth_iters = t->depth->last.iters;
+  return 0;
+}
+
+// Inverse of a 4x4 (Eigen Matrix4f::inverse(), ref: run_odometry_kitti_offline.cpp:218): Gauss-Jordan in fp64,
+// rounded to fp32. Column-major in/out.
+static bool invert4(const float* m, float* out) {
+  double a[4][8];
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) { a[i][j] = m[j * 4 + i]; a[i][4 + j] = (i == j) ? 1.0 : 0.0; }
+  for (int c = 0; c < 4; c++) {
+    int piv = c;
+    for (int i = c + 1; i < 4; i++) if (fabs(a[i][c]) > fabs(a[piv][c])) piv = i;
+    if (a[piv][c] == 0.0) return false;
+    if (piv != c) for (int j = 0; j < 8; j++) std::swap(a[c][j], a[piv][j]);
+    const double d = a[c][c];
+    for (int j = 0; j < 8; j++) a[c][j] /= d;
+    for (int i = 0; i < 4; i++) if (i != c) { const double f = a[i][c]; for (int j = 0; j < 8; j++) a[i][j] -= f * a[c][j]; }
+  }
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) out[j * 4 + i] = (float)a[i][4 + j];
+  return true;
+}
+static void matmul4(const float* A, const float* B, float* C) {  // column-major fp32, k ascending
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++)
+      C[j * 4 + i] = ((A[0 * 4 + i] * B[j * 4 + 0] + A[1 * 4 + i] * B[j * 4 + 1]) + A[2 * 4 + i] * B[j * 4 + 2]) + A[3 * 4 + i] * B[j * 4 + 3];
+}
+
+// Sophus SO3::angleX/Y/Z (ref: third_party/Sophus/sophus/so3.hpp:127-154): SO3(R) -> q -> R', then the rotation
+// closest to a 2x2 block of R' (makeRotationMatrix, polar factor) and its SO2 log = atan2(c - b, a + d).
+static void motion_angles(const float* T, float ang[3]) {
+  Se3 s;
+  se3_from_colmajor(T, &s);
+  float R[9];
+  quat_to_rot(s, R);
+  ang[0] = atan2f(R[7] - R[5], R[4] + R[8]);
+  ang[1] = atan2f(R[2] - R[6], R[0] + R[8]);
+  ang[2] = atan2f(R[3] - R[1], R[0] + R[4]);
+}
+
+extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float* right, float pose_to_keyframe[16],
+                                 float abs_pose[16], int* is_new_keyframe, float* motion_mag, int* solve_status) {
+  if (!t || !left || !right) return fail("odo_tracker_track: NULL arg");
+  const odo_tracker_params& p = t->p;
+  HIP_OK(hipSetDevice(t->ctx_a->device));
+  t->frame_id++;
+  if (p.overlap_depth) {
+    // stream B: ComputeDepth + candidate pyramids, concurrent with the Solve on stream A
+    if (tracker_depth_and_pyramids(t, left, right)) return -1;
+  }
+  if (pyr_build(t->cur_img, left, p.smooth_image)) return -1;                          // :205
+  float T[16];
+  const int st = odo_lm_solve(t->lm, t->kf_img, t->kf_dep, t->cur_img, T);             // :215 (synchronises stream A)
+  if (!p.overlap_depth) {
+    if (tracker_depth_and_pyramids(t, left, right)) return -1;                         // :226-252 in program order
+  }
+  if (depth_finish(t->depth)) { fail("    depth failed!"); return -1; }                // :230-232
+  memcpy(t->pose_to_kf, T, sizeof(T));
+  float inv[16], cur[16];
+  if (!invert4(T, inv)) memset(inv, 0, sizeof(inv));
+  matmul4(t->kf_abs, inv, cur);                                                        // :218
+  float ang[3];
+  motion_angles(T, ang);                                                               // :253
+  const float mot[6] = {fabsf(ang[0]), fabsf(ang[1]), fabsf(ang[2]), fabsf(T[12]), fabsf(T[13]), fabsf(T[14])};
+  float mag = 0.0f;
+  for (int i = 0; i < 6; i++) mag += mot[i] * p.keyframe_weight[i];                     // :257
+  int new_kf = 0;
+  if (mag > p.keyframe_motion_th) {                                                    // :258
+    std::swap(t->kf_img, t->pre_img);                                                  // :259
+    std::swap(t->kf_dep, t->pre_dep);
+    memcpy(t->kf_abs, cur, sizeof(cur));                                               // :260
+    t->n_keyframes++;
+    new_kf = 1;
+  }
+  odo_lm_reset(t->lm, T, 0.01f);                                                       // :261 / :268 (both branches)
+  if (pose_to_keyframe) memcpy(pose_to_keyframe, T, sizeof(T));
+  if (abs_pose) memcpy(abs_pose, cur, sizeof(cur));
+  if (is_new_keyframe) *is_new_keyframe = new_kf;
+  if (motion_mag) *motion_mag = mag;
+  if (solve_status) *solve_status = st;
+  t->last_evals = t->lm->last_evals;
+  t->last_depth_iters = t->depth->last.iters;
+  t->last_valid = t->depth->last.n_valid;
+  return 0;
+}
+
+extern "C" int odo_tracker_stats(const odo_tracker* t, int* lm_evals, int* depth_iters, int* n_valid, int* n_kf) {
+  if (!t) return fail("NULL tracker");
+  if (lm_evals) *lm_evals = t->last_evals;
+  if (depth_iters) *depth_iters = t->last_depth_iters;
+  if (n_valid) *n_valid = t->last_valid;
+  if (n_kf) *n_kf = t->n_keyframes;
+  return 0;
+}
+extern "C" int odo_tracker_outputs(const odo_tracker* t, const uint8_t** val, const float** disp, const float** dep) {
+  if (!t) return fail("NULL tracker");
+  if (val) *val = t->d_val;
+  if (disp) *disp = t->d_disp;
+  if (dep) *dep = t->d_dep;
+  return 0;
+}
+extern "C" odo_lm* odo_tracker_lm(odo_tracker* t) { return t ? t->lm : nullptr; }
+extern "C" odo_ctx* odo_tracker_ctx(odo_tracker* t) { return t ? t->ctx_a : nullptr; }
+
+// bench.py roofline leg: `reps` launches of the dominant kernel (the residual / normal-equation pass) on `level` of the
+// tracker's current keyframe / frame pyramids at the last estimated pose, each bracketed by HIP events on the
+// stream it is launched on. Returns mean / min launch duration and the algorithmic bytes of one launch
+// (12 B per interior pixel + 29 fp64 partials per block written).
+extern "C" int odo_tracker_time_residual(odo_tracker* t, int level, int reps, float* mean_us, float* min_us,
+                                         double* algorithmic_bytes, int* n_points) {
+  if (!t || reps < 1 || level < 0 || level >= t->p.levels) return fail("odo_tracker_time_residual: bad arg");
+  odo_lm* m = t->lm;
+  hipStream_t s = t->ctx_a->stream;
+  HIP_OK(hipSetDevice(t->ctx_a->device));
+  LevelView v;
+  v.I1 = t->kf_img->dev + t->kf_img->off[level];
+  v.I2 = t->cur_img->dev + t->cur_img->off[level];
+  v.D1 = t->kf_dep->dev + t->kf_dep->off[level];
+  v.rows = t->kf_img->r[level]; v.cols = t->kf_img->c[level];
+  const LevelK k = make_level_k(m->K.f0, m->K.cx0, m->K.cy0, level);
+  const int nblk = lm_grid(v.rows, v.cols);
+  HIP_OK(hipMemcpyAsync(m->d_init, t->pose_to_kf, sizeof(float) * 16, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(lm_force_state_kernel, dim3(1), dim3(64), 0, s, m->d_state, m->d_init, level);
+  std::vector<hipEvent_t> ev(2 * (size_t)reps);
+  for (auto& e : ev) HIP_OK(hipEventCreate(&e));
+  for (int w = 0; w < 3; w++) lm_launch_eval(m, v, k, level, nblk);  // warm caches
+  for (int i = 0; i < reps; i++) {
+    HIP_OK(hipEventRecord(ev[2 * i], s));
+    lm_launch_eval(m, v, k, level, nblk);
+    HIP_OK(hipEventRecord(ev[2 * i + 1], s));
+  }
+  double* d_acc = nullptr;
+  HIP_OK(hipMalloc((void**)&d_acc, sizeof(double) * ODO_NACC));
+  hipLaunchKernelGGL(lm_sum_partials_kernel, dim3(1), dim3(256), 0, s, m->d_partials, nblk, d_acc);
+  double acc[ODO_NACC];
+  HIP_OK(hipMemcpyAsync(acc, d_acc, sizeof(acc), hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  HIP_OK(hipFree(d_acc));
+  double sum = 0.0, mn = 1e30;
+  for (int i = 0; i < reps; i++) {
+    float ms = 0.0f;
+    HIP_OK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+    sum += ms; if (ms < mn) mn = ms;
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  if (mean_us) *mean_us = (float)(sum / reps * 1000.0);
+  if (min_us) *min_us = (float)(mn * 1000.0);
+  const long interior = (v.rows > 8 && v.cols > 8) ? (long)(v.rows - 8) * (v.cols - 8) : 0;
+  if (algorithmic_bytes) *algorithmic_bytes = 12.0 * (double)interior + 8.0 * ODO_NACC * nblk;
+  if (n_points) *n_points = (int)acc[28];
+  return 0;
+}

@@ -279,3 +279,50 @@ def test_compute_depth_any_size(api, O, small_seq):
     assert st == ref["status"]
     assert np.array_equal(val, ref["val"]) and np.array_equal(disp, ref["disp"])
     np.testing.assert_allclose(dep, ref["dep"], rtol=0, atol=1e-7)
+
+
+# ---------------------------------------------------------------- tracker (runner loop) ---------
+def test_tracker_matches_oracle_runner(api, kitti_seq):
+    """Full frame loop (ref: run_odometry_kitti_offline.cpp:95-145,198-271): GPU tracker vs oracle runner."""
+    from oracle import runner as orunner
+    L, R = kitti_seq["left"], kitti_seq["right"]
+    for overlap in (1, 0):
+        trk = api.Tracker(0, overlap_depth=overlap)
+        dev = [(trk.upload_frame(l), trk.upload_frame(r)) for l, r in zip(L, R)]
+        trk.init(*dev[0])
+        ref = orunner.OracleRunner()
+        ref.init(L[0], R[0])
+        for k in (1, 2, 1, 0, 1):
+            g = trk.track(*dev[k])
+            c = ref.track(L[k], R[k])
+            assert g["solve_status"] == c["solve_status"] == 0
+            assert se3_log_norm(c["pose_to_keyframe"], g["pose_to_keyframe"]) < 1e-5
+            assert se3_log_norm(c["abs_pose"], g["abs_pose"]) < 1e-5
+            assert g["new_keyframe"] == c["new_keyframe"]
+            assert abs(g["motion"] - c["motion"]) < 1e-5
+            val, disp, dep = trk.outputs(376, 1241)
+            assert np.array_equal(val, c["val"]) and np.array_equal(disp, c["disp"])
+            np.testing.assert_allclose(dep, c["dep"], rtol=0, atol=1e-7)
+            assert trk.stats()["n_valid_depth"] == c["n_valid"]
+        trk.close()
+
+
+def test_tracker_keyframe_switch(api, kitti_seq):
+    """A low motion threshold forces a keyframe switch on every frame; the next Solve must use the new keyframe."""
+    from oracle import runner as orunner
+    L, R = kitti_seq["left"], kitti_seq["right"]
+    trk = api.Tracker(0, keyframe_motion_th=0.05)
+    dev = [(trk.upload_frame(l), trk.upload_frame(r)) for l, r in zip(L, R)]
+    trk.init(*dev[0])
+    ref = orunner.OracleRunner(motion_th=0.05)
+    ref.init(L[0], R[0])
+    switched = 0
+    for k in (1, 2, 1):
+        g = trk.track(*dev[k])
+        c = ref.track(L[k], R[k])
+        assert g["new_keyframe"] == c["new_keyframe"]
+        switched += g["new_keyframe"]
+        assert se3_log_norm(c["pose_to_keyframe"], g["pose_to_keyframe"]) < 1e-5
+        assert se3_log_norm(c["abs_pose"], g["abs_pose"]) < 1e-5
+    assert switched >= 2 and trk.stats()["n_keyframes"] == ref.n_keyframes
+    trk.close()

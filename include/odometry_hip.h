@@ -114,6 +114,10 @@ int odo_lm_trace(const odo_lm* lm, odo_lm_trace_row* rows, int cap, int* n_rows)
  * work, and the algorithmic bytes they touched (12 B per interior pixel + 232 B out). */
 int odo_lm_launch_stats(const odo_lm* lm, int* n_active_launches, int* n_total_launches, double* algorithmic_bytes);
 
+/* Test entry: the wave-parallel damped 6x6 solve used by the LM update kernel (ref: src/lm_optimizer.cpp:145-151)
+ * on caller-supplied accumulators. */
+int odo_debug_solve(odo_ctx* ctx, const double acc[ODO_NACC], float lambda, float delta[6]);
+
 /* ---- depth estimator ---------------------------------------------------------------------------
  * Replaces DepthEstimator (ref: include/depth_estimate.h:31-33,51,54; src/depth_estimate.cpp:9-26,33-78,
  * 80-198,200-242,244-401,435-453,465-468). Camera pointers are replaced by K (NULL = KITTI-00).

@@ -218,15 +218,83 @@ struct LmTraceRow {
 };
 constexpr int kTraceCap = 128;
 
+// Damped 6x6 solve spread over the lanes of ONE wavefront: lane (i*8 + j) owns A[i][j] of the augmented 6x7
+// system (j == 6 is the right-hand side). Exactly the operations of odo::solve_damped (Gaussian elimination with
+// partial pivoting in fp64, first-maximum pivot, zero pivot -> zero component), but a column step is ~40 wave
+// instructions instead of ~400 single-lane ones: a lone lane pays full issue latency per instruction, which made
+// the serial solve the longest kernel of the tracker. acc: 29 fp64 accumulators (LDS). delta_out: 6 floats (LDS).
+__device__ __forceinline__ void solve_damped_wave(const double* acc, float lambda, float* delta_out) {
+  const int lane = threadIdx.x & 63;
+  const int i = lane >> 3, j = lane & 7;
+  const bool in = (i < 6 && j < 7);
+  double a = 0.0;
+  if (in) {
+    if (j < 6) {
+      const int lo = i < j ? i : j, hi = i < j ? j : i;
+      a = acc[lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)];
+      if (i == j) a = a + (double)lambda * a;
+    } else {
+      a = -acc[21 + i];
+    }
+  }
+  unsigned okmask = 0u;
+  for (int c = 0; c < 6; c++) {
+    int p = c;
+    double best = fabs(__shfl(a, c * 8 + c, 64));
+    for (int r = c + 1; r < 6; r++) {
+      const double v = fabs(__shfl(a, r * 8 + c, 64));
+      if (v > best) { best = v; p = r; }
+    }
+    if (best > 0.0) {  // wave-uniform
+      okmask |= 1u << c;
+      const double from_p = __shfl(a, p * 8 + j, 64);
+      const double from_c = __shfl(a, c * 8 + j, 64);
+      if (p != c) {
+        if (i == c) a = from_p;
+        else if (i == p) a = from_c;
+      }
+      const double prow = __shfl(a, c * 8 + j, 64);
+      const double piv = __shfl(a, c * 8 + c, 64);
+      const double mycol = __shfl(a, (i < 6 ? i : 5) * 8 + c, 64);
+      if (in && i > c && j >= c) {
+        const double f = mycol / piv;
+        a = a - f * prow;
+      }
+    }
+  }
+  double x = 0.0;  // lane c (< 6) ends up holding xs[c]
+  for (int c = 5; c >= 0; c--) {
+    double s = __shfl(a, c * 8 + 6, 64);
+    for (int jj = c + 1; jj < 6; jj++) {
+      const double arow = __shfl(a, c * 8 + jj, 64);
+      const double xj = __shfl(x, jj, 64);
+      s = s - arow * xj;
+    }
+    const double d = __shfl(a, c * 8 + c, 64);
+    const double xc = ((okmask >> c) & 1u) ? s / d : 0.0;
+    if (lane == c) x = xc;
+  }
+  if (lane < 6) delta_out[lane] = (float)x;
+}
+
 // Sums the per-block partials in a fixed order and advances the LM state machine by one evaluation
-// (accept / reject, damped 6x6 solve, exp, left-compose; ref: src/lm_optimizer.cpp:129-154). One workgroup.
+// (accept / reject, damped 6x6 solve, exp, left-compose; ref: src/lm_optimizer.cpp:129-154). One workgroup:
+// 256 threads fold the partials, wave 0 solves, lane 0 runs the scalar state machine.
 __global__ void __launch_bounds__(256) lm_update_kernel(LmState* __restrict__ st, const double* __restrict__ partials,
                                                          int nblk, int expect_level, float precision, int max_iters,
                                                          LmTraceRow* __restrict__ trace, float* __restrict__ cost_stat,
-                                                         int* __restrict__ host_flag) {
-  if (!(st->active != 0 && st->level == expect_level)) return;
+                                                         int* __restrict__ host_prog, int seq) {
+  if (!(st->active != 0 && st->level == expect_level)) {
+    // stale launch (the level's loop already stopped): only report progress to the polling host
+    if (host_prog && threadIdx.x == 0) __hip_atomic_store(host_prog, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
   __shared__ double sh[8][32];
-  __shared__ LmState s_sh;
+  __shared__ double acc_sh[32];
+  __shared__ LmState s_sh;  // LDS copy: dynamic indexing (iters_level[level]) stays out of scratch memory
+  __shared__ float delta_sh[6];
+  __shared__ int need_step_sh, iter_before_sh;
+  __shared__ float err_last_before_sh;
   const int t = threadIdx.x;
   const int q = t & 31, seg = t >> 5;
   double v = 0.0;
@@ -234,35 +302,65 @@ __global__ void __launch_bounds__(256) lm_update_kernel(LmState* __restrict__ st
     for (int b = seg; b < nblk; b += 8) v += partials[(size_t)b * ODO_NACC + q];
   sh[seg][q] = v;
   __syncthreads();
+  if (t < ODO_NACC)
+    acc_sh[t] = ((((((sh[0][t] + sh[1][t]) + sh[2][t]) + sh[3][t]) + sh[4][t]) + sh[5][t]) + sh[6][t]) + sh[7][t];
+  __syncthreads();
+  if (t >= 64) return;  // wave 0 carries on alone
   if (t == 0) {
+    s_sh = *st;
+    iter_before_sh = s_sh.iter;
+    err_last_before_sh = s_sh.err_last;
     double acc[ODO_NACC];
-    for (int i = 0; i < ODO_NACC; i++)
-      acc[i] = ((((((sh[0][i] + sh[1][i]) + sh[2][i]) + sh[3][i]) + sh[4][i]) + sh[5][i]) + sh[6][i]) + sh[7][i];
-    LmState& s = s_sh;  // LDS copy: dynamic indexing (iters_level[level]) stays out of scratch memory
-    s = *st;
-    const int iter_before = s.iter;
-    const float err_last_before = s.err_last;
-    lm_consume(&s, acc, precision, max_iters);
+    for (int i = 0; i < ODO_NACC; i++) acc[i] = acc_sh[i];
+    need_step_sh = lm_decide(&s_sh, acc, precision) ? 1 : 0;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): lane 0's LDS writes before the wave reads them
+  __builtin_amdgcn_wave_barrier();
+  const bool need_step = need_step_sh != 0;
+  if (need_step) {
+    solve_damped_wave(acc_sh, s_sh.lambda, delta_sh);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (t == 0) {
+    LmState& s = s_sh;
+    if (need_step) {
+      for (int i = 0; i < 6; i++) s.delta[i] = delta_sh[i];
+      lm_apply_step(&s, max_iters);
+    }
     const int ev = s.n_evals - 1;
     if (ev < kTraceCap) {
       LmTraceRow& r = trace[ev];
       r.level = expect_level;
-      r.iter = iter_before;
-      r.n_res = (int)acc[28];
+      r.iter = iter_before_sh;
+      r.n_res = (int)acc_sh[28];
       r.err = s.err_now;
-      r.accepted = (s.status == 0 && !(s.err_now > err_last_before)) ? 1 : 0;
+      r.accepted = (s.status == 0 && !(s.err_now > err_last_before_sh)) ? 1 : 0;
       r.stop = (s.stop_reason == 3 || s.active) ? 0 : s.stop_reason;
       r.lambda_after = s.lambda;
       for (int i = 0; i < 6; i++) r.delta[i] = (s.active || s.stop_reason == 3) ? s.delta[i] : 0.0f;
     }
-    if (iter_before == 0 && s.iters_level[expect_level & 7] == 1) cost_stat[expect_level * 2 + 0] = s.err_now;
+    if (iter_before_sh == 0 && s.iters_level[expect_level & 7] == 1) cost_stat[expect_level * 2 + 0] = s.err_now;
     cost_stat[expect_level * 2 + 1] = s.err_now;
     *st = s;
-    if (!s.active && host_flag) {
-      // level finished: tell the polling host (pinned, device-mapped) so it can skip the remaining launches
-      __atomic_store_n(host_flag, expect_level + 1000 * (s.n_evals), __ATOMIC_RELAXED);
+    if (host_prog) {
+      // host-mapped progress words: [1 + level] = 1 once the level's loop has stopped (the host then skips the
+      // launches it has not issued yet), [0] = sequence number of the last update launch that has run.
+      if (!s.active) __hip_atomic_store(host_prog + 1 + expect_level, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(host_prog, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+}
+
+// Test entry for solve_damped_wave (one wavefront).
+__global__ void solve_damped_wave_test_kernel(const double* __restrict__ acc_in, float lambda, float* __restrict__ out) {
+  __shared__ double acc_sh[32];
+  __shared__ float delta_sh[6];
+  if (threadIdx.x < ODO_NACC) acc_sh[threadIdx.x] = acc_in[threadIdx.x];
+  __syncthreads();
+  solve_damped_wave(acc_sh, lambda, delta_sh);
+  __syncthreads();
+  if (threadIdx.x < 6) out[threadIdx.x] = delta_sh[threadIdx.x];
 }
 
 __global__ void lm_begin_solve_kernel(LmState* __restrict__ st, const float* __restrict__ init, float* __restrict__ cost_stat) {
@@ -468,12 +566,20 @@ struct DepthLmState {
 constexpr int kDlmBlock = 256;
 constexpr int kDlmBlocks = kSelBlocks * kSelCap / kDlmBlock;  // 160
 
+// Host-mapped progress words of the depth LM: [0] = index of the last launch whose block 0 has run (+1),
+// [1] = 1 once the loop has stopped (the host then skips the launches it has not issued yet).
+__device__ __forceinline__ void dlm_report(int* host_prog, int k, int done) {
+  if (!host_prog) return;
+  if (done) __hip_atomic_store(host_prog + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(host_prog, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ void __launch_bounds__(kDlmBlock) depth_lm_step_kernel(
     int k, const float* __restrict__ left, const float* __restrict__ right, int cols, const uint32_t* __restrict__ pts,
     const int* __restrict__ cnt, const float* __restrict__ d0, float* __restrict__ scratch /* 6 x nslots */,
     DepthLmState* __restrict__ state /* [2] */, double* __restrict__ part_e /* [2][blocks] */,
     int* __restrict__ part_n /* [2][blocks] */, float tx, float fx, float huber_delta, float lambda0, float precision,
-    int max_iters) {
+    int max_iters, int* __restrict__ host_prog) {
   constexpr int nslots = kSelBlocks * kSelCap;
   __shared__ double shs[kDlmBlock];
   __shared__ int shn[kDlmBlock];
@@ -494,10 +600,10 @@ __global__ void __launch_bounds__(kDlmBlock) depth_lm_step_kernel(
     const float v = ok ? d0[s] : 0.0f;
     cur[s] = v; pre[s] = 0.0f; tmp[s] = v; res[s] = 0.0f; jt[s] = 1.0f; bb[s] = 0.0f;
     my_tmp = v;
-    if (st.done) { if (blockIdx.x == 0 && t == 0) state[1] = st; return; }
+    if (st.done) { if (blockIdx.x == 0 && t == 0) { state[1] = st; dlm_report(host_prog, k, 1); } return; }
   } else {
     st = state[k & 1];
-    if (st.done) { if (blockIdx.x == 0 && t == 0) state[(k + 1) & 1] = st; return; }
+    if (st.done) { if (blockIdx.x == 0 && t == 0) { state[(k + 1) & 1] = st; dlm_report(host_prog, k, 1); } return; }
     // ---- decision for evaluation k-1 (every block, identical arithmetic) ----
     const double* pe = part_e + ((k - 1) & 1) * kDlmBlocks;
     const int* pn = part_n + ((k - 1) & 1) * kDlmBlocks;
@@ -539,7 +645,7 @@ __global__ void __launch_bounds__(kDlmBlock) depth_lm_step_kernel(
       st.iter++;                              // :167
       if (!(max_iters > st.iter)) st.done = 1;  // :141
     }
-    if (st.done) { if (blockIdx.x == 0 && t == 0) state[(k + 1) & 1] = st; return; }
+    if (st.done) { if (blockIdx.x == 0 && t == 0) { state[(k + 1) & 1] = st; dlm_report(host_prog, k, 1); } return; }
   }
   // ---- evaluation k at tmp (ComputeResidualJacobian :200-242) ----
   double esum = 0.0;
@@ -573,7 +679,7 @@ __global__ void __launch_bounds__(kDlmBlock) depth_lm_step_kernel(
   if (t == 0) {
     part_e[(k & 1) * kDlmBlocks + blockIdx.x] = shs[0];
     part_n[(k & 1) * kDlmBlocks + blockIdx.x] = shn[0];
-    if (blockIdx.x == 0) state[(k + 1) & 1] = st;
+    if (blockIdx.x == 0) { state[(k + 1) & 1] = st; dlm_report(host_prog, k, 0); }
   }
 }
 

@@ -403,36 +403,46 @@ ODO_HD void lm_begin_level(LmState* s, int level, float lambda0, int max_iters) 
   se3_to_colmajor(s->inc, s->T);
 }
 
-// Consume the accumulators of one evaluation at pose s->T (lm_optimizer.cpp:123-154).
-ODO_HD void lm_consume(LmState* s, const double acc[ODO_NACC], float precision, int max_iters) {
+// Consume the accumulators of one evaluation at pose s->T (lm_optimizer.cpp:123-154), in two halves so the
+// device can run the 6x6 solve across the lanes of a wavefront in between.
+// lm_decide: error, accept / reject, lambda rule, stop tests (:129-143). Returns true when a step must be solved.
+ODO_HD bool lm_decide(LmState* s, const double acc[ODO_NACC], float precision) {
   s->n_evals++;
   s->iters_level[s->level & 7]++;
   if (!(acc[28] > 0.0)) {      // :244-248 -> :123-126
     s->status = -1;
     s->active = 0;
-    return;
+    return false;
   }
   const float err_now = (float)(acc[27] / acc[28]);  // :129
   s->err_now = err_now;
   if (err_now > s->err_last) {                       // :131
     s->lambda = s->lambda * 5.0f;
-    if (s->lambda > 1e+5f) { s->active = 0; s->stop_reason = 2; return; }
+    if (s->lambda > 1e+5f) { s->active = 0; s->stop_reason = 2; return false; }
     s->cur = s->last;
   } else {
     s->cur = s->inc;
     s->last = s->cur;
     const float err_diff = err_now / s->err_last;
-    if (err_diff > precision) { s->active = 0; s->stop_reason = 1; return; }
+    if (err_diff > precision) { s->active = 0; s->stop_reason = 1; return false; }
     s->err_last = err_now;
     s->lambda = fmaxf(s->lambda / 5.0f, 1e-5f);
   }
-  solve_damped(acc, s->lambda, s->delta);            // :145-151
+  return true;
+}
+// lm_apply_step: inc = SE3(exp(delta).matrix() * cur.matrix()), iter++ (:152-154) and the loop test (:117).
+ODO_HD void lm_apply_step(LmState* s, int max_iters) {
   Se3 d;
   se3_exp(s->delta, &d);                             // :152
   se3_left_update(d, s->cur, &s->inc);               // :153
   se3_to_colmajor(s->inc, s->T);
   s->iter++;                                         // :154
   if (!(max_iters > s->iter)) { s->active = 0; s->stop_reason = 3; }
+}
+ODO_HD void lm_consume(LmState* s, const double acc[ODO_NACC], float precision, int max_iters) {
+  if (!lm_decide(s, acc, precision)) return;
+  solve_damped(acc, s->lambda, s->delta);            // :145-151
+  lm_apply_step(s, max_iters);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <chrono>
 
 #include <new>
 #include <utility>
@@ -258,6 +260,13 @@ struct odo_lm {
   float* d_res;   // t-dist residual buffer (lazy)
   size_t res_cap;
   float* d_scale;
+  // host-mapped progress words the update kernel writes (early-exit polling)
+  int* h_prog;
+  int* d_prog;
+  int poll;  // 0 = enqueue every launch blindly
+  int run_ahead;
+  void (*idle_pump)(void*);  // called while the host waits for the device (the tracker feeds its depth stream here)
+  void* idle_arg;
   // pinned host mirrors
   float* h_out;
   LmTraceRow* h_trace;
@@ -295,6 +304,11 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
   HIP_OK(hipHostMalloc((void**)&m->h_out, sizeof(float) * 26, hipHostMallocDefault));
   HIP_OK(hipHostMalloc((void**)&m->h_trace, sizeof(LmTraceRow) * kTraceCap, hipHostMallocDefault));
   HIP_OK(hipHostMalloc((void**)&m->h_cost, sizeof(float) * 16, hipHostMallocDefault));
+  HIP_OK(hipHostMalloc((void**)&m->h_prog, sizeof(int) * 16, hipHostMallocMapped | hipHostMallocCoherent));
+  HIP_OK(hipHostGetDevicePointer((void**)&m->d_prog, m->h_prog, 0));
+  memset(m->h_prog, 0, sizeof(int) * 16);
+  m->poll = getenv("ODO_NO_POLL") ? 0 : 1;
+  m->run_ahead = getenv("ODO_RUN_AHEAD") ? atoi(getenv("ODO_RUN_AHEAD")) : 2;
   HIP_OK(hipMemsetAsync(m->d_trace, 0, sizeof(LmTraceRow) * kTraceCap, ctx->stream));
   memset(m->h_trace, 0, sizeof(LmTraceRow) * kTraceCap);
   memset(m->h_cost, 0, sizeof(float) * 16);
@@ -307,7 +321,7 @@ extern "C" int odo_lm_destroy(odo_lm* m) {
   (void)hipStreamSynchronize(m->ctx->stream);
   void* dv[] = {m->d_state, m->d_partials, m->d_init, m->d_out, m->d_trace, m->d_cost, m->d_scale, m->d_res};
   for (void* q : dv) if (q) (void)hipFree(q);
-  (void)hipHostFree(m->h_out); (void)hipHostFree(m->h_trace); (void)hipHostFree(m->h_cost);
+  (void)hipHostFree(m->h_out); (void)hipHostFree(m->h_trace); (void)hipHostFree(m->h_cost); (void)hipHostFree(m->h_prog);
   delete m;
   return 0;
 }
@@ -379,6 +393,13 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
   hipLaunchKernelGGL(lm_begin_solve_kernel, dim3(1), dim3(64), 0, s, m->d_state, m->d_init, m->d_cost);
   int launches = 0;
   double bytes_per_level[ODO_MAX_LEVELS] = {0};
+  // Early exit without a host sync: the update kernel publishes its progress in host-mapped memory; the host
+  // stays at most `run_ahead` evaluations ahead of the device and stops issuing a level's launches once the
+  // device reports that the level's loop has ended. Stale launches are no-ops on the device either way.
+  volatile int* prog = m->h_prog;
+  for (int i = 0; i < 16; i++) m->h_prog[i] = 0;  // the stream is idle here (every Solve ends with a sync)
+  bool poll = m->poll != 0;
+  int seq = 0;
   for (int l = m->n_levels - 1; l >= 0; l--) {  // ref: src/lm_optimizer.cpp:92
     LevelView v;
     v.I1 = kf_img->dev + kf_img->off[l];
@@ -389,12 +410,21 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
     const int nblk = lm_grid(v.rows, v.cols);
     if (m->robust == 2 && lm_ensure_res(m, (size_t)v.rows * v.cols)) return -1;
     const long interior = (v.rows > 8 && v.cols > 8) ? (long)(v.rows - 8) * (v.cols - 8) : 0;
-    bytes_per_level[l] = 12.0 * (double)interior + 8.0 * ODO_NACC;
+    bytes_per_level[l] = 12.0 * (double)interior + 8.0 * ODO_NACC * nblk;
     hipLaunchKernelGGL(lm_begin_level_kernel, dim3(1), dim3(64), 0, s, m->d_state, l, m->lambda, m->max_iters[l]);
     for (int it = 0; it < m->max_iters[l]; it++) {  // ref: :117
+      if (poll) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (seq - prog[0] > m->run_ahead && !prog[1 + l]) {
+          if (m->idle_pump) m->idle_pump(m->idle_arg);
+          if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { poll = false; break; }  // never hang
+        }
+        if (prog[1 + l]) break;  // the level's loop has stopped on the device
+      }
+      seq++;
       lm_launch_eval(m, v, k, l, nblk);
       hipLaunchKernelGGL(lm_update_kernel, dim3(1), dim3(256), 0, s, m->d_state, m->d_partials, nblk, l, m->precision,
-                         m->max_iters[l], m->d_trace, m->d_cost, (int*)nullptr);
+                         m->max_iters[l], m->d_trace, m->d_cost, m->d_prog, seq);
       launches++;
     }
   }
@@ -495,6 +525,24 @@ extern "C" int odo_lm_accumulate(odo_lm* m, const odo_pyr* kf_img, const odo_pyr
   return (acc[28] > 0.0) ? 0 : -1;  // N == 0 fails (ref: src/lm_optimizer.cpp:244-248)
 }
 
+// Test entry: the wave-parallel damped 6x6 solve the update kernel uses, on caller-supplied accumulators.
+extern "C" int odo_debug_solve(odo_ctx* ctx, const double acc[ODO_NACC], float lambda, float delta[6]) {
+  if (!ctx || !acc || !delta) return fail("odo_debug_solve: NULL arg");
+  HIP_OK(hipSetDevice(ctx->device));
+  double* d_acc = nullptr;
+  float* d_out = nullptr;
+  HIP_OK(hipMalloc((void**)&d_acc, sizeof(double) * ODO_NACC));
+  HIP_OK(hipMalloc((void**)&d_out, sizeof(float) * 6));
+  HIP_OK(hipMemcpyAsync(d_acc, acc, sizeof(double) * ODO_NACC, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(solve_damped_wave_test_kernel, dim3(1), dim3(64), 0, ctx->stream, d_acc, lambda, d_out);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpyAsync(delta, d_out, sizeof(float) * 6, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_OK(hipStreamSynchronize(ctx->stream));
+  HIP_OK(hipFree(d_acc));
+  HIP_OK(hipFree(d_out));
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Depth estimator
 // ------------------------------------------------------------------------------------------------
@@ -515,6 +563,9 @@ struct odo_depth {
   int* d_counts;
   DepthLmStats* d_stats;
   DepthLmStats* h_stats;
+  int* h_prog;
+  int* d_prog;
+  int poll, run_ahead;
   DepthLmStats last;
 };
 
@@ -545,6 +596,11 @@ extern "C" int odo_depth_create(odo_ctx* ctx, float grad_th, float ssd_th, float
   HIP_OK(hipMalloc((void**)&d->d_counts, sizeof(int) * 3 * kDlmBlocks));
   HIP_OK(hipMalloc((void**)&d->d_stats, sizeof(DepthLmStats)));
   HIP_OK(hipHostMalloc((void**)&d->h_stats, sizeof(DepthLmStats), hipHostMallocDefault));
+  HIP_OK(hipHostMalloc((void**)&d->h_prog, sizeof(int) * 4, hipHostMallocMapped | hipHostMallocCoherent));
+  HIP_OK(hipHostGetDevicePointer((void**)&d->d_prog, d->h_prog, 0));
+  memset(d->h_prog, 0, sizeof(int) * 4);
+  d->poll = getenv("ODO_NO_POLL") ? 0 : 1;
+  d->run_ahead = getenv("ODO_RUN_AHEAD") ? atoi(getenv("ODO_RUN_AHEAD")) : 3;
   *out = d;
   return 0;
 }
@@ -563,7 +619,7 @@ extern "C" int odo_depth_destroy(odo_depth* d) {
   depth_free_images(d);
   void* dv[] = {d->d_pts, d->d_cnt, d->d_d0, d->d_scratch, d->d_matched, d->d_lmstate, d->d_part_e, d->d_part_n, d->d_counts, d->d_stats};
   for (void* q : dv) if (q) (void)hipFree(q);
-  (void)hipHostFree(d->h_stats);
+  (void)hipHostFree(d->h_stats); (void)hipHostFree(d->h_prog);
   delete d;
   return 0;
 }
@@ -594,11 +650,32 @@ static int depth_check_size(const odo_depth* d, int rows, int cols) {
   return 0;
 }
 
-// Enqueues the whole ComputeDepth (stage 2) or only the disparity stage (stage 1) on device pointers.
-static int depth_run(odo_depth* d, const float* left, const float* right, int rows, int cols, uint8_t* val, float* disp,
-                     float* dep, int stage) {
+// ComputeDepth as a resumable launch sequence on the estimator's stream, so a caller that is also feeding another
+// stream (the tracker's pose LM) can interleave the two from ONE host thread:
+//   depth_job_begin  : zero-fill, blur, point selection, disparity scan          (6 launches)
+//   depth_job_pump   : issues at most one depth-LM launch per call, honouring the early-exit progress words and
+//                      the run-ahead bound; returns true once the tail (filters, counts, stats copy) is enqueued.
+struct DepthJob {
+  const float *left, *right;
+  uint8_t* val;
+  float *disp, *dep;
+  int rows, cols, stage;
+  int k;          // next depth-LM launch index
+  int n_launches;
+  bool poll, tail_done;
+  std::chrono::steady_clock::time_point wait_since;
+  bool waiting;
+};
+
+static int depth_job_begin(odo_depth* d, DepthJob* j, const float* left, const float* right, int rows, int cols,
+                           uint8_t* val, float* disp, float* dep, int stage) {
   hipStream_t s = d->ctx->stream;
   const size_t n = (size_t)rows * cols;
+  j->left = left; j->right = right; j->val = val; j->disp = disp; j->dep = dep;
+  j->rows = rows; j->cols = cols; j->stage = stage;
+  j->k = 0; j->n_launches = 0; j->poll = d->poll != 0; j->tail_done = false; j->waiting = false;
+  // progress words may only be reset while this stream is idle: every ComputeDepth ends with depth_finish()'s sync
+  d->h_prog[0] = 0; d->h_prog[1] = 0;
   HIP_OK(hipMemsetAsync(val, 0, n, s));
   HIP_OK(hipMemsetAsync(disp, 0, sizeof(float) * n, s));  // zero-filled outputs
   HIP_OK(hipMemsetAsync(dep, 0, sizeof(float) * n, s));
@@ -608,23 +685,57 @@ static int depth_run(odo_depth* d, const float* left, const float* right, int ro
   hipLaunchKernelGGL(depth_disparity_kernel, dim3(kSelBlocks * kSelCap / 4), dim3(256), 0, s, d->d_bl, d->d_br, rows, cols,
                      d->boundary, d->max_disparity, d->ssd_th, d->K.f0, d->baseline, d->d_pts, d->d_cnt, disp, dep,
                      d->d_d0, d->d_matched);
-  int n_launches = 0;
-  if (stage != 1) {
-    // launch k decides on evaluation k-1 and runs evaluation k; max_iters evaluations need max_iters + 1 launches
-    for (int k = 0; k <= d->max_iters; k++) {
-      hipLaunchKernelGGL(depth_lm_step_kernel, dim3(kDlmBlocks), dim3(kDlmBlock), 0, s, k, left, right, cols, d->d_pts,
-                         d->d_cnt, d->d_d0, d->d_scratch, d->d_lmstate, d->d_part_e, d->d_part_n, d->baseline, d->K.f0,
-                         d->huber_delta, d->lambda, d->precision, d->max_iters);
-      n_launches++;
-    }
-  }
-  hipLaunchKernelGGL(depth_finalize_kernel, dim3(kDlmBlocks), dim3(kDlmBlock), 0, s, stage != 1 ? 1 : 0, cols, d->d_pts,
-                     d->d_cnt, d->d_matched, d->d_scratch, d->photo_th, d->min_depth, d->max_depth, val, dep, d->d_counts);
-  hipLaunchKernelGGL(depth_stats_kernel, dim3(1), dim3(kDlmBlock), 0, s, stage != 1 ? 1 : 0, n_launches, d->d_counts,
-                     d->d_lmstate, d->d_stats);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+static int depth_job_tail(odo_depth* d, DepthJob* j) {
+  hipStream_t s = d->ctx->stream;
+  const int run_lm = j->stage != 1 ? 1 : 0;
+  hipLaunchKernelGGL(depth_finalize_kernel, dim3(kDlmBlocks), dim3(kDlmBlock), 0, s, run_lm, j->cols, d->d_pts, d->d_cnt,
+                     d->d_matched, d->d_scratch, d->photo_th, d->min_depth, d->max_depth, j->val, j->dep, d->d_counts);
+  hipLaunchKernelGGL(depth_stats_kernel, dim3(1), dim3(kDlmBlock), 0, s, run_lm, j->n_launches, d->d_counts, d->d_lmstate,
+                     d->d_stats);
   HIP_OK(hipGetLastError());
   HIP_OK(hipMemcpyAsync(d->h_stats, d->d_stats, sizeof(DepthLmStats), hipMemcpyDeviceToHost, s));
+  j->tail_done = true;
   return 0;
+}
+
+// Returns 1 when the whole job has been enqueued, 0 when there is more to do (call again), -1 on error.
+static int depth_job_pump(odo_depth* d, DepthJob* j) {
+  if (j->tail_done) return 1;
+  volatile int* prog = d->h_prog;
+  // launch k decides on evaluation k-1 and runs evaluation k: max_iters evaluations need max_iters + 1 launches
+  bool lm_over = (j->stage == 1) || (j->k > d->max_iters) || (j->poll && prog[1]);
+  if (!lm_over) {
+    if (j->poll && j->k - prog[0] > d->run_ahead) {  // device is behind: do not queue more yet
+      const auto now = std::chrono::steady_clock::now();
+      if (!j->waiting) { j->waiting = true; j->wait_since = now; }
+      else if (now - j->wait_since > std::chrono::seconds(2)) j->poll = false;  // never hang on a lost progress word
+      return 0;
+    }
+    j->waiting = false;
+    hipLaunchKernelGGL(depth_lm_step_kernel, dim3(kDlmBlocks), dim3(kDlmBlock), 0, d->ctx->stream, j->k, j->left, j->right,
+                       j->cols, d->d_pts, d->d_cnt, d->d_d0, d->d_scratch, d->d_lmstate, d->d_part_e, d->d_part_n,
+                       d->baseline, d->K.f0, d->huber_delta, d->lambda, d->precision, d->max_iters, d->d_prog);
+    j->k++;
+    j->n_launches++;
+    return 0;
+  }
+  return depth_job_tail(d, j) ? -1 : 1;
+}
+
+// Enqueues the whole ComputeDepth (stage 2) or only the disparity stage (stage 1) on device pointers.
+static int depth_run(odo_depth* d, const float* left, const float* right, int rows, int cols, uint8_t* val, float* disp,
+                     float* dep, int stage) {
+  DepthJob j;
+  if (depth_job_begin(d, &j, left, right, rows, cols, val, disp, dep, stage)) return -1;
+  for (;;) {
+    const int r = depth_job_pump(d, &j);
+    if (r < 0) return -1;
+    if (r > 0) return 0;
+  }
 }
 
 static int depth_finish(odo_depth* d) {

@@ -17,6 +17,9 @@ struct odo_tracker {
   int n_keyframes, frame_id;
   int last_evals, last_depth_iters, last_valid;
   hipEvent_t ev_inputs;
+  DepthJob job;
+  int job_stage;  // 0 idle, 1 depth launches in flight, 2 depth tail enqueued (pyramids next), 3 all enqueued
+  int job_err;
 };
 
 extern "C" int odo_tracker_default_params(odo_tracker_params* p) {
@@ -95,15 +98,37 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
   return 0;
 }
 
-// ComputeDepth of the pair and the frame's keyframe-candidate pyramids, all on stream B (ref: :226-252).
-static int tracker_depth_and_pyramids(odo_tracker* t, const float* left, const float* right) {
+// ComputeDepth of the pair and the frame's keyframe-candidate pyramids, all on stream B (ref: :226-252), as a
+// resumable job: begin enqueues the front, pump issues one more launch when the device is ready for it.
+static int tracker_job_begin(odo_tracker* t, const float* left, const float* right) {
   const odo_tracker_params& p = t->p;
+  t->job_err = 0;
   if (depth_check_size(t->depth, p.rows, p.cols)) return -1;
   if (depth_ensure(t->depth, p.rows, p.cols)) return -1;
-  if (depth_run(t->depth, left, right, p.rows, p.cols, t->d_val, t->d_disp, t->d_dep, 2)) return -1;
-  if (pyr_build(t->pre_img, left, p.smooth_image)) return -1;  // :251 (the runner builds this pyramid a second time)
-  if (pyr_build(t->pre_dep, t->d_dep, 0)) return -1;           // :252
+  if (depth_job_begin(t->depth, &t->job, left, right, p.rows, p.cols, t->d_val, t->d_disp, t->d_dep, 2)) return -1;
+  t->job_stage = 1;
   return 0;
+}
+static void tracker_job_pump(void* arg) {
+  odo_tracker* t = (odo_tracker*)arg;
+  if (t->job_stage != 1) return;
+  const int r = depth_job_pump(t->depth, &t->job);
+  if (r < 0) { t->job_err = 1; t->job_stage = 3; return; }
+  if (r > 0) {
+    const odo_tracker_params& p = t->p;
+    if (pyr_build(t->pre_img, t->job.left, p.smooth_image)) t->job_err = 1;  // :251 (built a second time, as the runner does)
+    if (pyr_build(t->pre_dep, t->d_dep, 0)) t->job_err = 1;                   // :252
+    t->job_stage = 3;
+  }
+}
+static int tracker_job_drain(odo_tracker* t) {
+  while (t->job_stage == 1) tracker_job_pump(t);
+  t->job_stage = 0;
+  return t->job_err ? -1 : 0;
+}
+static int tracker_depth_and_pyramids(odo_tracker* t, const float* left, const float* right) {
+  if (tracker_job_begin(t, left, right)) return -1;
+  return tracker_job_drain(t);
 }
 
 extern "C" int odo_tracker_init(odo_tracker* t, const float* left, const float* right, const float abs_pose0[16]) {
@@ -166,14 +191,20 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
   const odo_tracker_params& p = t->p;
   HIP_OK(hipSetDevice(t->ctx_a->device));
   t->frame_id++;
-  if (p.overlap_depth) {
-    // stream B: ComputeDepth + candidate pyramids, concurrent with the Solve on stream A
-    if (tracker_depth_and_pyramids(t, left, right)) return -1;
-  }
   if (pyr_build(t->cur_img, left, p.smooth_image)) return -1;                          // :205
+  if (p.overlap_depth) {
+    // stream B: ComputeDepth + candidate pyramids, concurrent with the Solve on stream A. The front of the job is
+    // enqueued now; its depth-LM launches are issued from the pose LM's wait loop (one host thread feeds both).
+    if (tracker_job_begin(t, left, right)) return -1;
+    t->lm->idle_pump = tracker_job_pump;
+    t->lm->idle_arg = t;
+  }
   float T[16];
   const int st = odo_lm_solve(t->lm, t->kf_img, t->kf_dep, t->cur_img, T);             // :215 (synchronises stream A)
-  if (!p.overlap_depth) {
+  t->lm->idle_pump = nullptr;
+  if (p.overlap_depth) {
+    if (tracker_job_drain(t)) return -1;
+  } else {
     if (tracker_depth_and_pyramids(t, left, right)) return -1;                         // :226-252 in program order
   }
   if (depth_finish(t->depth)) { fail("    depth failed!"); return -1; }                // :230-232

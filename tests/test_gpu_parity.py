@@ -326,3 +326,32 @@ def test_tracker_keyframe_switch(api, kitti_seq):
         assert se3_log_norm(c["abs_pose"], g["abs_pose"]) < 1e-5
     assert switched >= 2 and trk.stats()["n_keyframes"] == ref.n_keyframes
     trk.close()
+
+
+def test_wave_solver_matches_oracle_bit_for_bit(api, O):
+    """The lane-parallel 6x6 solve of the update kernel vs the oracle's sequential one (incl. singular systems)."""
+    import ctypes as C
+    from odometry_amd import _lib
+    ctx = api.default_context()
+    rng = np.random.default_rng(7)
+    for trial in range(60):
+        J = rng.normal(0, 1, (40, 6)) * np.array([1, 1, 1, 300, 300, 300])
+        if trial % 10 == 3:
+            J[:, 2] = 0          # zero column -> zero pivot
+        if trial % 10 == 7:
+            J[:, 4] = J[:, 1]    # rank deficient (exactly dependent columns)
+        A = J.T @ J
+        acc = np.zeros(29)
+        k = 0
+        for a in range(6):
+            for b in range(a, 6):
+                acc[k] = A[a, b]
+                k += 1
+        acc[21:27] = rng.normal(0, 10, 6)
+        lam = [0.01, 0.0, 6.25][trial % 3]
+        out = np.zeros(6, np.float32)
+        st = ctx.lib.odo_debug_solve(ctx.h, acc.ctypes.data_as(C.POINTER(C.c_double)), lam,
+                                     out.ctypes.data_as(C.POINTER(C.c_float)))
+        assert st == 0
+        ref = O.solve_damped(acc, lam)
+        assert np.array_equal(out, ref, equal_nan=True), (trial, out, ref)

@@ -110,8 +110,15 @@ typedef struct {
   float delta[6];
 } odo_lm_trace_row;
 int odo_lm_trace(const odo_lm* lm, odo_lm_trace_row* rows, int cap, int* n_rows);
+/* Iteration space of the residual kernel: 0 = automatic (per keyframe and level: a compacted point list when at most
+ * half of the interior pixels carry depth, the dense scan of the reference otherwise), 1 = always the dense scan,
+ * 2 = always the point list. All three evaluate the same per-point arithmetic. */
+int odo_lm_set_mode(odo_lm* lm, int mode);
+/* Points per level of the cached keyframe lists and which levels use them (after a Solve / accumulate). */
+int odo_lm_points(const odo_lm* lm, int npts[ODO_MAX_LEVELS], int use_list[ODO_MAX_LEVELS]);
 /* Launch statistics of the last Solve (bench.py roofline): number of residual-kernel launches that did
- * work, and the algorithmic bytes they touched (12 B per interior pixel + 232 B out). */
+ * work, and the algorithmic bytes they touched (dense scan 12 B per interior
+ * pixel, point list 32 B per point, plus the fp64 partials written). */
 int odo_lm_launch_stats(const odo_lm* lm, int* n_active_launches, int* n_total_launches, double* algorithmic_bytes);
 
 /* Test entry: the wave-parallel damped 6x6 solve used by the LM update kernel (ref: src/lm_optimizer.cpp:145-151)

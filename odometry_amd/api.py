@@ -216,6 +216,15 @@ class LevenbergMarquardtOptimizer:
         return [dict(level=r.level, iter=r.iter, n_res=r.n_res, accepted=r.accepted, stop=r.stop, err=r.err,
                      lambda_after=r.lambda_after, delta=np.array(r.delta[:], np.float32)) for r in rows[:n.value]]
 
+    def set_mode(self, mode):
+        L.check(self.ctx.lib.odo_lm_set_mode(self.h, mode), "odo_lm_set_mode")
+
+    def points(self):
+        n = (C.c_int * L.MAX_LEVELS)()
+        u = (C.c_int * L.MAX_LEVELS)()
+        L.check(self.ctx.lib.odo_lm_points(self.h, n, u), "odo_lm_points")
+        return list(n)[:self.n_levels], list(u)[:self.n_levels]
+
     def launch_stats(self):
         a, t, b = C.c_int(0), C.c_int(0), C.c_double(0)
         L.check(self.ctx.lib.odo_lm_launch_stats(self.h, C.byref(a), C.byref(t), C.byref(b)), "odo_lm_launch_stats")

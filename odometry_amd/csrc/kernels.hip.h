@@ -7,6 +7,7 @@
 namespace odo {
 
 constexpr int kWave = 64;
+#define ODO_MAX_LEVELS_K 8
 
 __device__ __forceinline__ int reflect101(int i, int n) {
   if (n == 1) return 0;
@@ -141,6 +142,172 @@ __global__ void __launch_bounds__(kLmBlock) lm_residual_dense_kernel(LevelView v
   block_reduce_acc(acc, partials + (size_t)blockIdx.x * ODO_NACC);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Semi-dense keyframe point lists. Everything of a residual that does not depend on the pose (back-projected
+// point, keyframe intensity, geometric Jacobian at the un-warped point; ref: src/lm_optimizer.cpp:193-234) is
+// computed ONCE per keyframe and level, compacted in raster order — the reference's iteration order — into
+// three float4 arrays + one float array (52 B per point, lane-consecutive 16-B loads).
+// ---------------------------------------------------------------------------------------------
+struct PointList {
+  float4* a;  // X, Y, Z, i1
+  float4* b;  // fx_z, jw02, jw03, jw04
+  float4* c;  // jw05, jw12, jw13, jw14
+  float* d;   // jw15
+};
+
+struct KfLevels {
+  const float* I1[ODO_MAX_LEVELS_K];
+  const float* D1[ODO_MAX_LEVELS_K];
+  int rows[ODO_MAX_LEVELS_K], cols[ODO_MAX_LEVELS_K];
+  int row_base[ODO_MAX_LEVELS_K + 1];  // first global row index of each level (interior rows only)
+  int n_levels;
+};
+
+__device__ __forceinline__ int kf_find_level(const KfLevels& kl, int grow) {
+  int l = 0;
+  while (l + 1 < kl.n_levels && grow >= kl.row_base[l + 1]) l++;
+  return l;
+}
+
+// Pass 1: one block per interior row (all levels in one launch): number of valid depths in the row.
+__global__ void __launch_bounds__(256) kf_count_kernel(KfLevels kl, int* __restrict__ rowcnt) {
+  __shared__ int sh[4];
+  const int l = kf_find_level(kl, blockIdx.x);
+  const int y = 4 + (blockIdx.x - kl.row_base[l]);
+  const int cols = kl.cols[l];
+  const float* D = kl.D1[l] + (size_t)y * cols;
+  int c = 0;
+  for (int x = 4 + threadIdx.x; x < cols - 4; x += 256) c += depth_valid(D[x]) ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) rowcnt[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// Pass 2: exclusive scan of the row counts inside each level (one block); npts[l] = points of level l.
+__global__ void __launch_bounds__(1024) kf_scan_kernel(KfLevels kl, const int* __restrict__ rowcnt, int* __restrict__ rowoff,
+                                                       int* __restrict__ npts) {
+  __shared__ int sh[1024];
+  const int t = threadIdx.x;
+  for (int l = 0; l < kl.n_levels; l++) {
+    const int r0 = kl.row_base[l], nr = kl.row_base[l + 1] - r0;
+    int carry = 0;
+    for (int c0 = 0; c0 < nr; c0 += 1024) {
+      const int i = c0 + t;
+      const int v = (i < nr) ? rowcnt[r0 + i] : 0;
+      sh[t] = v;
+      __syncthreads();
+      for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan
+        const int add = (t >= o) ? sh[t - o] : 0;
+        __syncthreads();
+        sh[t] += add;
+        __syncthreads();
+      }
+      if (i < nr) rowoff[r0 + i] = carry + sh[t] - v;
+      const int tot = sh[1023];
+      __syncthreads();
+      carry += tot;
+    }
+    if (t == 0) npts[l] = carry;
+  }
+}
+
+// Pass 3: one block per interior row: ordered compaction (ballot prefix) + the per-point constants.
+__global__ void __launch_bounds__(256) kf_fill_kernel(KfLevels kl, float f0, float cx0, float cy0,
+                                                      const int* __restrict__ rowoff, PointList pl0, PointList pl1,
+                                                      PointList pl2, PointList pl3, PointList pl4, PointList pl5,
+                                                      PointList pl6, PointList pl7) {
+  __shared__ int wave_tot[4];
+  __shared__ int base_sh;
+  const int l = kf_find_level(kl, blockIdx.x);
+  const PointList pl = l == 0 ? pl0 : l == 1 ? pl1 : l == 2 ? pl2 : l == 3 ? pl3 : l == 4 ? pl4 : l == 5 ? pl5 : l == 6 ? pl6 : pl7;
+  const int y = 4 + (blockIdx.x - kl.row_base[l]);
+  const int cols = kl.cols[l];
+  const LevelK k = make_level_k(f0, cx0, cy0, l);
+  const float* D = kl.D1[l] + (size_t)y * cols;
+  const float* I = kl.I1[l] + (size_t)y * cols;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  if (t == 0) base_sh = rowoff[blockIdx.x];
+  __syncthreads();
+  for (int x0 = 4; x0 < cols - 4; x0 += 256) {
+    const int x = x0 + t;
+    float d = 0.0f;
+    const bool f = (x < cols - 4) && depth_valid(d = D[x]);
+    const unsigned long long bal = __ballot(f);
+    const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wv] = __popcll(bal);
+    __syncthreads();
+    int off = base_sh;
+    for (int w = 0; w < wv; w++) off += wave_tot[w];
+    if (f) {
+      const PointK p = make_point(x, y, d, I[x], k);
+      const int i = off + pre;
+      pl.a[i] = make_float4(p.X, p.Y, p.Z, p.i1);
+      pl.b[i] = make_float4(p.fx_z, p.jw02, p.jw03, p.jw04);
+      pl.c[i] = make_float4(p.jw05, p.jw12, p.jw13, p.jw14);
+      pl.d[i] = p.jw15;
+    }
+    __syncthreads();
+    if (t == 0) base_sh += (wave_tot[0] + wave_tot[1]) + (wave_tot[2] + wave_tot[3]);
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ PointK load_point(const PointList& pl, int i) {
+  const float4 a = pl.a[i], b = pl.b[i], c = pl.c[i];
+  PointK p;
+  p.X = a.x; p.Y = a.y; p.Z = a.z; p.i1 = a.w;
+  p.fx_z = b.x; p.jw02 = b.y; p.jw03 = b.z; p.jw04 = b.w;
+  p.jw05 = c.x; p.jw12 = c.y; p.jw13 = c.z; p.jw14 = c.w;
+  p.jw15 = pl.d[i];
+  return p;
+}
+
+// Residual / Jacobian / normal-equation pass over a keyframe point list (semi-dense levels): one point per thread
+// (grid-stride beyond the block cap), 52 B of list + five I2 taps per point. Same arithmetic as the dense scan.
+__global__ void __launch_bounds__(kLmBlock) lm_residual_list_kernel(PointList pl, int n, const float* __restrict__ I2, int rows,
+                                                                     int cols, LevelK k, const LmState* __restrict__ st,
+                                                                     int expect_level, int robust, float huber_delta,
+                                                                     const float* __restrict__ scale_sqr_ptr,
+                                                                     double* __restrict__ partials) {
+  if (!(st->active != 0 && st->level == expect_level)) return;
+  float T[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) T[i] = st->T[i];
+  const float scale_sqr = (robust == 2) ? *scale_sqr_ptr : 1.0f;
+  double acc[ODO_NACC];
+#pragma unroll
+  for (int q = 0; q < ODO_NACC; q++) acc[q] = 0.0;
+  for (int idx = blockIdx.x * kLmBlock + threadIdx.x; idx < n; idx += gridDim.x * kLmBlock) {
+    const PointK p = load_point(pl, idx);
+    int ui, vi;
+    if (!warp_point(p, T, k, rows, cols, &ui, &vi)) continue;
+    float r, J[6];
+    residual_jacobian(p, I2, rows, cols, ui, vi, &r, J);
+    const float w = robust_weight(r, robust, huber_delta, scale_sqr);
+    accumulate_row(acc, r, w, J);
+  }
+  block_reduce_acc(acc, partials + (size_t)blockIdx.x * ODO_NACC);
+}
+
+// t-distribution pass 1 over a point list: residual per point (NaN = skipped).
+__global__ void __launch_bounds__(kLmBlock) lm_residual_only_list_kernel(PointList pl, int n, const float* __restrict__ I2,
+                                                                          int rows, int cols, LevelK k,
+                                                                          const LmState* __restrict__ st, int expect_level,
+                                                                          float* __restrict__ res) {
+  if (!(st->active != 0 && st->level == expect_level)) return;
+  float T[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) T[i] = st->T[i];
+  for (int idx = blockIdx.x * kLmBlock + threadIdx.x; idx < n; idx += gridDim.x * kLmBlock) {
+    const PointK p = load_point(pl, idx);
+    int ui, vi;
+    float r = __builtin_nanf("");
+    if (warp_point(p, T, k, rows, cols, &ui, &vi)) r = I2[(size_t)vi * cols + ui] - p.i1;
+    res[idx] = r;
+  }
+}
+
 // t-distribution mode (robust == 2) needs every residual before any weight
 // (ComputeScaleNaive, ref: src/lm_optimizer.cpp:338-358): pass 1 stores r per interior pixel (NaN = skipped).
 __global__ void __launch_bounds__(kLmBlock) lm_residual_only_kernel(LevelView v, LevelK k, const LmState* __restrict__ st,
@@ -210,6 +377,8 @@ __global__ void __launch_bounds__(1024) lm_tdist_scale_kernel(const float* __res
   }
   if (t == 0) *scale_sqr_out = cur * cur;
 }
+
+static_assert(sizeof(LmState) <= 64 * sizeof(int), "LmState must fit one wavefront-wide copy");
 
 struct LmTraceRow {
   int level, iter, n_res, accepted, stop;
@@ -297,17 +466,27 @@ __global__ void __launch_bounds__(256) lm_update_kernel(LmState* __restrict__ st
   __shared__ float err_last_before_sh;
   const int t = threadIdx.x;
   const int q = t & 31, seg = t >> 5;
-  double v = 0.0;
-  if (q < ODO_NACC)
-    for (int b = seg; b < nblk; b += 8) v += partials[(size_t)b * ODO_NACC + q];
-  sh[seg][q] = v;
+  // fold the per-block partials: 8 segments x 29 quantities, 4 independent loads in flight per thread, then a
+  // fixed-order combine — the association order depends only on nblk, so results are run-to-run identical.
+  double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+  if (q < ODO_NACC) {
+    int b = seg;
+    for (; b + 24 < nblk; b += 32) {
+      v0 += partials[(size_t)b * ODO_NACC + q];
+      v1 += partials[(size_t)(b + 8) * ODO_NACC + q];
+      v2 += partials[(size_t)(b + 16) * ODO_NACC + q];
+      v3 += partials[(size_t)(b + 24) * ODO_NACC + q];
+    }
+    for (; b < nblk; b += 8) v0 += partials[(size_t)b * ODO_NACC + q];
+  }
+  sh[seg][q] = (v0 + v1) + (v2 + v3);
+  if (t < (int)(sizeof(LmState) / sizeof(int))) ((int*)&s_sh)[t] = ((const int*)st)[t];  // cooperative state copy
   __syncthreads();
   if (t < ODO_NACC)
     acc_sh[t] = ((((((sh[0][t] + sh[1][t]) + sh[2][t]) + sh[3][t]) + sh[4][t]) + sh[5][t]) + sh[6][t]) + sh[7][t];
   __syncthreads();
   if (t >= 64) return;  // wave 0 carries on alone
   if (t == 0) {
-    s_sh = *st;
     iter_before_sh = s_sh.iter;
     err_last_before_sh = s_sh.err_last;
     double acc[ODO_NACC];
@@ -342,7 +521,12 @@ __global__ void __launch_bounds__(256) lm_update_kernel(LmState* __restrict__ st
     }
     if (iter_before_sh == 0 && s.iters_level[expect_level & 7] == 1) cost_stat[expect_level * 2 + 0] = s.err_now;
     cost_stat[expect_level * 2 + 1] = s.err_now;
-    *st = s;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  if (t < (int)(sizeof(LmState) / sizeof(int))) ((int*)st)[t] = ((const int*)&s_sh)[t];  // cooperative write-back
+  if (t == 0) {
+    const LmState& s = s_sh;
     if (host_prog) {
       // host-mapped progress words: [1 + level] = 1 once the level's loop has stopped (the host then skips the
       // launches it has not issued yet), [0] = sequence number of the last update launch that has run.

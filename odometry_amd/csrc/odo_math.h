@@ -366,7 +366,7 @@ ODO_HD void solve_damped(const double acc[ODO_NACC], float lambda, float delta[6
 // ---------------------------------------------------------------------------------------------
 // LM state machine of one Solve (lm_optimizer.cpp:73-160), advanced one evaluation at a time.
 // ---------------------------------------------------------------------------------------------
-struct LmState {
+struct LmState {  // <= 64 dwords: the update kernel copies it with one wavefront
   Se3 cur, inc, last;
   float T[16];        // inc.matrix(), column-major: the pose the next evaluation uses
   float lambda, err_last, err_now;

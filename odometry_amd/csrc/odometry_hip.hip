@@ -122,10 +122,13 @@ struct odo_pyr {
   float* staging;  // level-0-sized device copy of a host input (IMAGE kind: pyrDown reads the unsmoothed input)
   size_t off[ODO_MAX_LEVELS];
   int r[ODO_MAX_LEVELS], c[ODO_MAX_LEVELS];
+  unsigned long long version;  // bumped by every (re)build: keys the LM's keyframe point-list cache
 };
+static unsigned long long g_pyr_version = 0;
 
 static int pyr_build(odo_pyr* p, const float* img_dev, int smooth) {
   hipStream_t s = p->ctx->stream;
+  p->version = ++g_pyr_version;
   const int rows = p->rows, cols = p->cols;
   if (p->kind == ODO_PYR_IMAGE) {
     if (smooth) {
@@ -265,6 +268,14 @@ struct odo_lm {
   int* d_prog;
   int poll;  // 0 = enqueue every launch blindly
   int run_ahead;
+  // keyframe point lists (semi-dense levels), cached per (kf_img, kf_dep) build
+  PointList pl[ODO_MAX_LEVELS];
+  size_t pl_cap[ODO_MAX_LEVELS];
+  int npts[ODO_MAX_LEVELS];
+  int use_list[ODO_MAX_LEVELS];
+  unsigned long long kf_img_ver, kf_dep_ver;
+  int* d_rowcnt; int* d_rowoff; int* d_npts; int* h_npts; int rows_cap;
+  int mode;  // 0 auto (list when <= half of the interior has depth), 1 always dense scan, 2 always list
   void (*idle_pump)(void*);  // called while the host waits for the device (the tracker feeds its depth stream here)
   void* idle_arg;
   // pinned host mirrors
@@ -307,6 +318,9 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
   HIP_OK(hipHostMalloc((void**)&m->h_prog, sizeof(int) * 16, hipHostMallocMapped | hipHostMallocCoherent));
   HIP_OK(hipHostGetDevicePointer((void**)&m->d_prog, m->h_prog, 0));
   memset(m->h_prog, 0, sizeof(int) * 16);
+  HIP_OK(hipMalloc((void**)&m->d_npts, sizeof(int) * ODO_MAX_LEVELS));
+  HIP_OK(hipHostMalloc((void**)&m->h_npts, sizeof(int) * ODO_MAX_LEVELS, hipHostMallocDefault));
+  m->mode = getenv("ODO_LM_MODE") ? atoi(getenv("ODO_LM_MODE")) : 0;
   m->poll = getenv("ODO_NO_POLL") ? 0 : 1;
   m->run_ahead = getenv("ODO_RUN_AHEAD") ? atoi(getenv("ODO_RUN_AHEAD")) : 2;
   HIP_OK(hipMemsetAsync(m->d_trace, 0, sizeof(LmTraceRow) * kTraceCap, ctx->stream));
@@ -319,8 +333,14 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
 extern "C" int odo_lm_destroy(odo_lm* m) {
   if (!m) return 0;
   (void)hipStreamSynchronize(m->ctx->stream);
-  void* dv[] = {m->d_state, m->d_partials, m->d_init, m->d_out, m->d_trace, m->d_cost, m->d_scale, m->d_res};
+  void* dv[] = {m->d_state, m->d_partials, m->d_init, m->d_out, m->d_trace, m->d_cost, m->d_scale, m->d_res,
+                m->d_rowcnt, m->d_rowoff, m->d_npts};
   for (void* q : dv) if (q) (void)hipFree(q);
+  for (int l = 0; l < ODO_MAX_LEVELS; l++) {
+    void* pv[] = {m->pl[l].a, m->pl[l].b, m->pl[l].c, m->pl[l].d};
+    for (void* q : pv) if (q) (void)hipFree(q);
+  }
+  (void)hipHostFree(m->h_npts);
   (void)hipHostFree(m->h_out); (void)hipHostFree(m->h_trace); (void)hipHostFree(m->h_cost); (void)hipHostFree(m->h_prog);
   delete m;
   return 0;
@@ -367,9 +387,91 @@ static int lm_ensure_res(odo_lm* m, size_t n) {
   return 0;
 }
 
+// Builds (or reuses) the keyframe point lists for the pyramids of this Solve. Three launches over all levels +
+// a 32-byte read-back of the per-level counts; done once per keyframe (the cache is keyed on the pyramids' build
+// versions). Levels where more than half of the interior carries depth keep the dense scan.
+static int lm_prepare_keyframe(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep) {
+  if (m->mode == 1) { for (int l = 0; l < m->n_levels; l++) m->use_list[l] = 0; return 0; }
+  if (m->kf_img_ver == kf_img->version && m->kf_dep_ver == kf_dep->version) return 0;
+  hipStream_t s = m->ctx->stream;
+  KfLevels kl;
+  memset(&kl, 0, sizeof(kl));
+  kl.n_levels = m->n_levels;
+  int rows_total = 0;
+  for (int l = 0; l < m->n_levels; l++) {
+    kl.I1[l] = kf_img->dev + kf_img->off[l];
+    kl.D1[l] = kf_dep->dev + kf_dep->off[l];
+    kl.rows[l] = kf_img->r[l]; kl.cols[l] = kf_img->c[l];
+    kl.row_base[l] = rows_total;
+    const int ir = kl.rows[l] - 8, ic = kl.cols[l] - 8;
+    rows_total += (ir > 0 && ic > 0) ? ir : 0;
+    const size_t cap = (ir > 0 && ic > 0) ? (size_t)ir * ic : 0;
+    if (cap > m->pl_cap[l]) {
+      HIP_OK(hipStreamSynchronize(s));
+      void* pv[] = {m->pl[l].a, m->pl[l].b, m->pl[l].c, m->pl[l].d};
+      for (void* q : pv) if (q) HIP_OK(hipFree(q));
+      HIP_OK(hipMalloc((void**)&m->pl[l].a, sizeof(float4) * cap));
+      HIP_OK(hipMalloc((void**)&m->pl[l].b, sizeof(float4) * cap));
+      HIP_OK(hipMalloc((void**)&m->pl[l].c, sizeof(float4) * cap));
+      HIP_OK(hipMalloc((void**)&m->pl[l].d, sizeof(float) * cap));
+      m->pl_cap[l] = cap;
+    }
+  }
+  kl.row_base[m->n_levels] = rows_total;
+  for (int l = m->n_levels + 1; l <= ODO_MAX_LEVELS; l++) kl.row_base[l] = rows_total;
+  if (rows_total > m->rows_cap) {
+    HIP_OK(hipStreamSynchronize(s));
+    if (m->d_rowcnt) HIP_OK(hipFree(m->d_rowcnt));
+    if (m->d_rowoff) HIP_OK(hipFree(m->d_rowoff));
+    HIP_OK(hipMalloc((void**)&m->d_rowcnt, sizeof(int) * rows_total));
+    HIP_OK(hipMalloc((void**)&m->d_rowoff, sizeof(int) * rows_total));
+    m->rows_cap = rows_total;
+  }
+  for (int l = 0; l < ODO_MAX_LEVELS; l++) { m->npts[l] = 0; m->use_list[l] = 0; }
+  if (rows_total > 0) {
+    hipLaunchKernelGGL(kf_count_kernel, dim3(rows_total), dim3(256), 0, s, kl, m->d_rowcnt);
+    hipLaunchKernelGGL(kf_scan_kernel, dim3(1), dim3(1024), 0, s, kl, m->d_rowcnt, m->d_rowoff, m->d_npts);
+    hipLaunchKernelGGL(kf_fill_kernel, dim3(rows_total), dim3(256), 0, s, kl, m->K.f0, m->K.cx0, m->K.cy0, m->d_rowoff,
+                       m->pl[0], m->pl[1], m->pl[2], m->pl[3], m->pl[4], m->pl[5], m->pl[6], m->pl[7]);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(m->h_npts, m->d_npts, sizeof(int) * ODO_MAX_LEVELS, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    for (int l = 0; l < m->n_levels; l++) {
+      m->npts[l] = m->h_npts[l];
+      const long interior = (long)(kl.rows[l] - 8) * (kl.cols[l] - 8);
+      m->use_list[l] = (m->mode == 2) || (interior > 0 && 2L * m->npts[l] <= interior);
+    }
+  }
+  m->kf_img_ver = kf_img->version;
+  m->kf_dep_ver = kf_dep->version;
+  return 0;
+}
+
+constexpr int kLmListMaxBlocks = 160;
+static inline int lm_grid_for(const odo_lm* m, int level, int rows, int cols) {
+  if (m->use_list[level]) {
+    long g = ((long)m->npts[level] + kLmBlock - 1) / kLmBlock;
+    if (g > kLmListMaxBlocks) g = kLmListMaxBlocks;
+    if (g < 1) g = 1;
+    return (int)g;
+  }
+  return lm_grid(rows, cols);
+}
+
 // One evaluation of the hot loop at the pose held in the device state.
 static void lm_launch_eval(odo_lm* m, const LevelView& v, const LevelK& k, int level, int nblk) {
   hipStream_t s = m->ctx->stream;
+  if (m->use_list[level]) {
+    const int n = m->npts[level];
+    if (m->robust == 2) {
+      hipLaunchKernelGGL(lm_residual_only_list_kernel, dim3(nblk), dim3(kLmBlock), 0, s, m->pl[level], n, v.I2, v.rows,
+                         v.cols, k, m->d_state, level, m->d_res);
+      hipLaunchKernelGGL(lm_tdist_scale_kernel, dim3(1), dim3(1024), 0, s, m->d_res, n, m->d_state, level, m->d_scale);
+    }
+    hipLaunchKernelGGL(lm_residual_list_kernel, dim3(nblk), dim3(kLmBlock), 0, s, m->pl[level], n, v.I2, v.rows, v.cols, k,
+                       m->d_state, level, m->robust, m->huber_delta, m->d_scale, m->d_partials);
+    return;
+  }
   if (m->robust == 2) {
     const int n = (v.rows - 8) * (v.cols - 8);
     hipLaunchKernelGGL(lm_residual_only_kernel, dim3(nblk), dim3(kLmBlock), 0, s, v, k, m->d_state, level, m->d_res);
@@ -378,6 +480,14 @@ static void lm_launch_eval(odo_lm* m, const LevelView& v, const LevelK& k, int l
   }
   hipLaunchKernelGGL(lm_residual_dense_kernel, dim3(nblk), dim3(kLmBlock), 0, s, v, k, m->d_state, level, m->robust,
                      m->huber_delta, m->d_scale, m->d_partials);
+}
+
+// Algorithmic bytes of one evaluation on `level`: dense scan 12 B per interior pixel,
+// point list 32 B per point (packed coordinates + inverse depth, I1, five I2 taps); + the fp64 partials written.
+static inline double lm_level_bytes(const odo_lm* m, int level, int rows, int cols, int nblk) {
+  const long interior = (rows > 8 && cols > 8) ? (long)(rows - 8) * (cols - 8) : 0;
+  const double in = m->use_list[level] ? 32.0 * (double)m->npts[level] : 12.0 * (double)interior;
+  return in + 8.0 * ODO_NACC * nblk;
 }
 
 extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img,
@@ -389,6 +499,7 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
   if (lm_check_pyrs(m, kf_img, kf_dep, cur_img)) return -1;
   hipStream_t s = m->ctx->stream;
   HIP_OK(hipSetDevice(m->ctx->device));
+  if (lm_prepare_keyframe(m, kf_img, kf_dep)) return -1;
   HIP_OK(hipMemcpyAsync(m->d_init, m->init, sizeof(float) * 16, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(lm_begin_solve_kernel, dim3(1), dim3(64), 0, s, m->d_state, m->d_init, m->d_cost);
   int launches = 0;
@@ -407,10 +518,9 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
     v.D1 = kf_dep->dev + kf_dep->off[l];
     v.rows = kf_img->r[l]; v.cols = kf_img->c[l];
     const LevelK k = make_level_k(m->K.f0, m->K.cx0, m->K.cy0, l);
-    const int nblk = lm_grid(v.rows, v.cols);
+    const int nblk = lm_grid_for(m, l, v.rows, v.cols);
     if (m->robust == 2 && lm_ensure_res(m, (size_t)v.rows * v.cols)) return -1;
-    const long interior = (v.rows > 8 && v.cols > 8) ? (long)(v.rows - 8) * (v.cols - 8) : 0;
-    bytes_per_level[l] = 12.0 * (double)interior + 8.0 * ODO_NACC * nblk;
+    bytes_per_level[l] = lm_level_bytes(m, l, v.rows, v.cols, nblk);
     hipLaunchKernelGGL(lm_begin_level_kernel, dim3(1), dim3(64), 0, s, m->d_state, l, m->lambda, m->max_iters[l]);
     for (int it = 0; it < m->max_iters[l]; it++) {  // ref: :117
       if (poll) {
@@ -443,6 +553,21 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
     m->last_bytes += bytes_per_level[l] * m->iters[l];
   }
   if (m->h_out[16] != 0.0f) return fail("Optimize failed! ");  // ref: src/lm_optimizer.cpp:60-61
+  return 0;
+}
+
+extern "C" int odo_lm_set_mode(odo_lm* m, int mode) {
+  if (!m || mode < 0 || mode > 2) return fail("odo_lm_set_mode: bad arg");
+  m->mode = mode;
+  m->kf_img_ver = m->kf_dep_ver = 0;  // rebuild the per-level choice on the next Solve
+  return 0;
+}
+extern "C" int odo_lm_points(const odo_lm* m, int npts[ODO_MAX_LEVELS], int use_list[ODO_MAX_LEVELS]) {
+  if (!m) return fail("NULL lm");
+  for (int l = 0; l < ODO_MAX_LEVELS; l++) {
+    if (npts) npts[l] = m->npts[l];
+    if (use_list) use_list[l] = m->use_list[l];
+  }
   return 0;
 }
 
@@ -510,7 +635,8 @@ extern "C" int odo_lm_accumulate(odo_lm* m, const odo_pyr* kf_img, const odo_pyr
   v.D1 = kf_dep->dev + kf_dep->off[level];
   v.rows = kf_img->r[level]; v.cols = kf_img->c[level];
   const LevelK k = make_level_k(m->K.f0, m->K.cx0, m->K.cy0, level);
-  const int nblk = lm_grid(v.rows, v.cols);
+  if (lm_prepare_keyframe(m, kf_img, kf_dep)) return -1;
+  const int nblk = lm_grid_for(m, level, v.rows, v.cols);
   if (m->robust == 2 && lm_ensure_res(m, (size_t)v.rows * v.cols)) return -1;
   double* d_acc = nullptr;
   HIP_OK(hipMalloc((void**)&d_acc, sizeof(double) * ODO_NACC));

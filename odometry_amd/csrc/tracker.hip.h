@@ -271,7 +271,8 @@ extern "C" int odo_tracker_time_residual(odo_tracker* t, int level, int reps, fl
   v.D1 = t->kf_dep->dev + t->kf_dep->off[level];
   v.rows = t->kf_img->r[level]; v.cols = t->kf_img->c[level];
   const LevelK k = make_level_k(m->K.f0, m->K.cx0, m->K.cy0, level);
-  const int nblk = lm_grid(v.rows, v.cols);
+  if (lm_prepare_keyframe(m, t->kf_img, t->kf_dep)) return -1;
+  const int nblk = lm_grid_for(m, level, v.rows, v.cols);
   HIP_OK(hipMemcpyAsync(m->d_init, t->pose_to_kf, sizeof(float) * 16, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(lm_force_state_kernel, dim3(1), dim3(64), 0, s, m->d_state, m->d_init, level);
   std::vector<hipEvent_t> ev(2 * (size_t)reps);
@@ -298,8 +299,7 @@ extern "C" int odo_tracker_time_residual(odo_tracker* t, int level, int reps, fl
   for (auto& e : ev) (void)hipEventDestroy(e);
   if (mean_us) *mean_us = (float)(sum / reps * 1000.0);
   if (min_us) *min_us = (float)(mn * 1000.0);
-  const long interior = (v.rows > 8 && v.cols > 8) ? (long)(v.rows - 8) * (v.cols - 8) : 0;
-  if (algorithmic_bytes) *algorithmic_bytes = 12.0 * (double)interior + 8.0 * ODO_NACC * nblk;
+  if (algorithmic_bytes) *algorithmic_bytes = lm_level_bytes(m, level, v.rows, v.cols, nblk);
   if (n_points) *n_points = (int)acc[28];
   return 0;
 }

@@ -70,10 +70,12 @@ def _kitti_pyrs(api, O, seq, inv=None):
             O.image_pyramid(L0, 4, True), O.depth_pyramid(inv, 4), O.image_pyramid(L1, 4, True))
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])   # 0 auto, 1 dense scan, 2 keyframe point list
 @pytest.mark.parametrize("robust", [0, 1, 2])
-def test_lm_accumulate_matches_oracle(api, O, kitti_seq, robust):
+def test_lm_accumulate_matches_oracle(api, O, kitti_seq, robust, mode):
     L0, L1, inv, p0, d0, p1, r0, rd, r1 = _kitti_pyrs(api, O, kitti_seq)
     lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, robust, 28.0)
+    lm.set_mode(mode)
     T = np.eye(4, dtype=np.float32)
     T[0, 3], T[2, 3] = 0.02, -0.3
     T[:3, :3] = O.se3_exp(np.array([0, 0, 0, 0.002, 0.01, -0.003], np.float32))[:3, :3]
@@ -92,10 +94,13 @@ def test_lm_accumulate_dense_matches_oracle(api, O, kitti_seq):
     lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 1, 28.0)
     T = np.eye(4, dtype=np.float32)
     T[2, 3] = -0.4
-    st, acc = lm.accumulate(p0, d0, p1, 0, T)
     ref = O.lm_accumulate(r0[0], r1[0], rd[0], 0, T, robust=1, huber_delta=28.0)
-    assert acc[28] == ref["acc"][28] and acc[28] > 400000
-    np.testing.assert_allclose(acc, ref["acc"], rtol=1e-11, atol=1e-9)
+    for mode in (0, 2):
+        lm.set_mode(mode)
+        st, acc = lm.accumulate(p0, d0, p1, 0, T)
+        assert acc[28] == ref["acc"][28] and acc[28] > 400000
+        np.testing.assert_allclose(acc, ref["acc"], rtol=1e-11, atol=1e-9)
+        assert lm.points()[1][0] == (1 if mode == 2 else 0)   # auto keeps the dense scan when every pixel has depth
 
 
 def test_lm_accumulate_is_deterministic(api, O, kitti_seq):
@@ -103,15 +108,31 @@ def test_lm_accumulate_is_deterministic(api, O, kitti_seq):
     lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 1, 28.0)
     T = np.eye(4, dtype=np.float32)
     T[2, 3] = -0.2
-    a = [lm.accumulate(p0, d0, p1, 0, T)[1] for _ in range(3)]
-    assert np.array_equal(a[0], a[1]) and np.array_equal(a[0], a[2])
+    for mode in (1, 2):
+        lm.set_mode(mode)
+        a = [lm.accumulate(p0, d0, p1, 0, T)[1] for _ in range(3)]
+        assert np.array_equal(a[0], a[1]) and np.array_equal(a[0], a[2])
+
+
+def test_keyframe_point_list_counts(api, O, kitti_seq):
+    """The compacted list holds exactly the pixels the reference's scan would visit (|d| >= 0.01 inside the border)."""
+    L0, L1, inv, p0, d0, p1, r0, rd, r1 = _kitti_pyrs(api, O, kitti_seq)
+    lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 1, 28.0)
+    lm.accumulate(p0, d0, p1, 0, np.eye(4, dtype=np.float32))
+    npts, use = lm.points()
+    for l in range(4):
+        d = rd[l][4:-4, 4:-4]
+        assert npts[l] == int((np.abs(d) >= np.float32(0.01)).sum())
+        assert use[l] == 1
 
 
 # ---------------------------------------------------------------- LM solve ----------------------
+@pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("robust", [1, 0, 2])
-def test_lm_solve_pose_parity(api, O, kitti_seq, robust):
+def test_lm_solve_pose_parity(api, O, kitti_seq, robust, mode):
     L0, L1, inv, p0, d0, p1, *_ = _kitti_pyrs(api, O, kitti_seq)
     lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, robust, 28.0)
+    lm.set_mode(mode)
     T = lm.Solve(p0, d0, p1)
     ref = O.lm_solve(O.image_pyramid(L0, flat=True), O.depth_pyramid(inv, flat=True), O.image_pyramid(L1, flat=True),
                      376, 1241, O.lm_params(robust=robust))

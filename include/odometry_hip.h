@@ -121,6 +121,9 @@ int odo_lm_points(const odo_lm* lm, int npts[ODO_MAX_LEVELS], int use_list[ODO_M
  * pixel, point list 32 B per point, plus the fp64 partials written). */
 int odo_lm_launch_stats(const odo_lm* lm, int* n_active_launches, int* n_total_launches, double* algorithmic_bytes);
 
+/* Diagnostic: cycle-counter stamps at the phase boundaries of one LM update launch ("update kernel"). */
+int odo_debug_update_stamps(odo_lm* lm, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img, int level,
+                            const float T_colmajor[16], unsigned long long stamps[8]);
 /* Test entry: the wave-parallel damped 6x6 solve used by the LM update kernel (ref: src/lm_optimizer.cpp:145-151)
  * on caller-supplied accumulators. */
 int odo_debug_solve(odo_ctx* ctx, const double acc[ODO_NACC], float lambda, float delta[6]);

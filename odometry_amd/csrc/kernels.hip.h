@@ -392,6 +392,12 @@ constexpr int kTraceCap = 128;
 // partial pivoting in fp64, first-maximum pivot, zero pivot -> zero component), but a column step is ~40 wave
 // instructions instead of ~400 single-lane ones: a lone lane pays full issue latency per instruction, which made
 // the serial solve the longest kernel of the tracker. acc: 29 fp64 accumulators (LDS). delta_out: 6 floats (LDS).
+__device__ __forceinline__ double readlane_d(double v, int src_lane) {  // src_lane must be wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ void solve_damped_wave(const double* acc, float lambda, float* delta_out) {
   const int lane = threadIdx.x & 63;
   const int i = lane >> 3, j = lane & 7;
@@ -406,59 +412,72 @@ __device__ __forceinline__ void solve_damped_wave(const double* acc, float lambd
       a = -acc[21 + i];
     }
   }
+  // Elimination. Wave-uniform values travel through v_readlane (SGPRs, a few cycles); only the three per-lane
+  // gathers of a column step use the LDS crossbar (ds_bpermute), and they are independent of each other.
   unsigned okmask = 0u;
+#pragma unroll
   for (int c = 0; c < 6; c++) {
     int p = c;
-    double best = fabs(__shfl(a, c * 8 + c, 64));
+    double best = fabs(readlane_d(a, c * 8 + c));
+#pragma unroll
     for (int r = c + 1; r < 6; r++) {
-      const double v = fabs(__shfl(a, r * 8 + c, 64));
+      const double v = fabs(readlane_d(a, r * 8 + c));
       if (v > best) { best = v; p = r; }
     }
+    p = __builtin_amdgcn_readfirstlane(p);
     if (best > 0.0) {  // wave-uniform
       okmask |= 1u << c;
-      const double from_p = __shfl(a, p * 8 + j, 64);
+      const double old_cc = readlane_d(a, c * 8 + c);   // A[c][c] before the row swap
+      const double piv = readlane_d(a, p * 8 + c);      // A[p][c]: the pivot once rows c and p are exchanged
+      const double from_p = __shfl(a, p * 8 + j, 64);   // old row p = pivot row after the exchange
       const double from_c = __shfl(a, c * 8 + j, 64);
+      const double colv = __shfl(a, (i < 6 ? i : 5) * 8 + c, 64);  // A[i][c] before the exchange
+      const double mycol = (i == p) ? old_cc : colv;    // row p holds the old row c afterwards
       if (p != c) {
         if (i == c) a = from_p;
         else if (i == p) a = from_c;
       }
-      const double prow = __shfl(a, c * 8 + j, 64);
-      const double piv = __shfl(a, c * 8 + c, 64);
-      const double mycol = __shfl(a, (i < 6 ? i : 5) * 8 + c, 64);
       if (in && i > c && j >= c) {
         const double f = mycol / piv;
-        a = a - f * prow;
+        a = a - f * from_p;
       }
     }
   }
-  double x = 0.0;  // lane c (< 6) ends up holding xs[c]
+  // Back substitution on wave-uniform values (compile-time indices, xs[] stays in registers).
+  double xs[6];
+#pragma unroll
   for (int c = 5; c >= 0; c--) {
-    double s = __shfl(a, c * 8 + 6, 64);
-    for (int jj = c + 1; jj < 6; jj++) {
-      const double arow = __shfl(a, c * 8 + jj, 64);
-      const double xj = __shfl(x, jj, 64);
-      s = s - arow * xj;
-    }
-    const double d = __shfl(a, c * 8 + c, 64);
-    const double xc = ((okmask >> c) & 1u) ? s / d : 0.0;
-    if (lane == c) x = xc;
+    double s = readlane_d(a, c * 8 + 6);
+#pragma unroll
+    for (int jj = c + 1; jj < 6; jj++) s = s - readlane_d(a, c * 8 + jj) * xs[jj];
+    const double d = readlane_d(a, c * 8 + c);
+    xs[c] = ((okmask >> c) & 1u) ? s / d : 0.0;
   }
-  if (lane < 6) delta_out[lane] = (float)x;
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < 6; c++) delta_out[c] = (float)xs[c];
+  }
 }
 
 // Sums the per-block partials in a fixed order and advances the LM state machine by one evaluation
 // (accept / reject, damped 6x6 solve, exp, left-compose; ref: src/lm_optimizer.cpp:129-154). One workgroup:
 // 256 threads fold the partials, wave 0 solves, lane 0 runs the scalar state machine.
-__global__ void __launch_bounds__(256) lm_update_kernel(LmState* __restrict__ st, const double* __restrict__ partials,
+// STAMP builds (diagnostic entry odo_debug_update_stamps only) record s_memtime at phase boundaries into `stamps`.
+constexpr int kUpdThreads = 1024;
+#define ODO_STAMP(i) do { if (STAMP && threadIdx.x == 0) stamps[i] = __builtin_readcyclecounter(); } while (0)
+template <bool STAMP>
+__global__ void __launch_bounds__(kUpdThreads) lm_update_kernel(LmState* __restrict__ st, const double* __restrict__ partials,
                                                          int nblk, int expect_level, float precision, int max_iters,
                                                          LmTraceRow* __restrict__ trace, float* __restrict__ cost_stat,
-                                                         int* __restrict__ host_prog, int seq) {
+                                                         int* __restrict__ host_prog, int seq,
+                                                         unsigned long long* __restrict__ stamps) {
+  ODO_STAMP(0);
   if (!(st->active != 0 && st->level == expect_level)) {
     // stale launch (the level's loop already stopped): only report progress to the polling host
     if (host_prog && threadIdx.x == 0) __hip_atomic_store(host_prog, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
-  __shared__ double sh[8][32];
+  __shared__ double sh[32][32];
   __shared__ double acc_sh[32];
   __shared__ LmState s_sh;  // LDS copy: dynamic indexing (iters_level[level]) stays out of scratch memory
   __shared__ float delta_sh[6];
@@ -466,47 +485,58 @@ __global__ void __launch_bounds__(256) lm_update_kernel(LmState* __restrict__ st
   __shared__ float err_last_before_sh;
   const int t = threadIdx.x;
   const int q = t & 31, seg = t >> 5;
-  // fold the per-block partials: 8 segments x 29 quantities, 4 independent loads in flight per thread, then a
-  // fixed-order combine — the association order depends only on nblk, so results are run-to-run identical.
-  double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+  // fold the per-block partials: 32 segments x 29 quantities, every load of a thread in flight at once (<= 5 for the
+  // 160-block point-list grids), then a fixed-order combine — the association order depends only on nblk, so
+  // results are run-to-run identical.
+  double v = 0.0;
   if (q < ODO_NACC) {
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
     int b = seg;
-    for (; b + 24 < nblk; b += 32) {
+    for (; b + 96 < nblk; b += 128) {
       v0 += partials[(size_t)b * ODO_NACC + q];
-      v1 += partials[(size_t)(b + 8) * ODO_NACC + q];
-      v2 += partials[(size_t)(b + 16) * ODO_NACC + q];
-      v3 += partials[(size_t)(b + 24) * ODO_NACC + q];
+      v1 += partials[(size_t)(b + 32) * ODO_NACC + q];
+      v2 += partials[(size_t)(b + 64) * ODO_NACC + q];
+      v3 += partials[(size_t)(b + 96) * ODO_NACC + q];
     }
-    for (; b < nblk; b += 8) v0 += partials[(size_t)b * ODO_NACC + q];
+    for (; b < nblk; b += 32) v0 += partials[(size_t)b * ODO_NACC + q];
+    v = (v0 + v1) + (v2 + v3);
   }
-  sh[seg][q] = (v0 + v1) + (v2 + v3);
+  ODO_STAMP(1);
+  sh[seg][q] = v;
   if (t < (int)(sizeof(LmState) / sizeof(int))) ((int*)&s_sh)[t] = ((const int*)st)[t];  // cooperative state copy
   __syncthreads();
-  if (t < ODO_NACC)
-    acc_sh[t] = ((((((sh[0][t] + sh[1][t]) + sh[2][t]) + sh[3][t]) + sh[4][t]) + sh[5][t]) + sh[6][t]) + sh[7][t];
-  __syncthreads();
   if (t >= 64) return;  // wave 0 carries on alone
+  if (t < ODO_NACC) {
+    double a = 0.0;
+#pragma unroll
+    for (int g = 0; g < 32; g++) a += sh[g][t];
+    acc_sh[t] = a;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  ODO_STAMP(2);
   if (t == 0) {
     iter_before_sh = s_sh.iter;
     err_last_before_sh = s_sh.err_last;
-    double acc[ODO_NACC];
-    for (int i = 0; i < ODO_NACC; i++) acc[i] = acc_sh[i];
-    need_step_sh = lm_decide(&s_sh, acc, precision) ? 1 : 0;
+    need_step_sh = lm_decide(&s_sh, acc_sh, precision) ? 1 : 0;
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): lane 0's LDS writes before the wave reads them
   __builtin_amdgcn_wave_barrier();
+  ODO_STAMP(3);
   const bool need_step = need_step_sh != 0;
   if (need_step) {
     solve_damped_wave(acc_sh, s_sh.lambda, delta_sh);
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
   }
+  ODO_STAMP(4);
   if (t == 0) {
     LmState& s = s_sh;
     if (need_step) {
       for (int i = 0; i < 6; i++) s.delta[i] = delta_sh[i];
       lm_apply_step(&s, max_iters);
     }
+    ODO_STAMP(5);
     const int ev = s.n_evals - 1;
     if (ev < kTraceCap) {
       LmTraceRow& r = trace[ev];
@@ -524,6 +554,7 @@ __global__ void __launch_bounds__(256) lm_update_kernel(LmState* __restrict__ st
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);
   __builtin_amdgcn_wave_barrier();
+  ODO_STAMP(6);
   if (t < (int)(sizeof(LmState) / sizeof(int))) ((int*)st)[t] = ((const int*)&s_sh)[t];  // cooperative write-back
   if (t == 0) {
     const LmState& s = s_sh;
@@ -533,6 +564,222 @@ __global__ void __launch_bounds__(256) lm_update_kernel(LmState* __restrict__ st
       if (!s.active) __hip_atomic_store(host_prog + 1 + expect_level, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_store(host_prog, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+  }
+  ODO_STAMP(7);
+}
+
+// =============================================================================================
+// Fused LM iteration: ONE launch per evaluation.
+// Every block first re-derives, redundantly and bit-identically, the LM step that the previous launch's partial
+// sums imply (fold -> accept/reject -> wave-parallel 6x6 solve -> exp / compose), then evaluates its share of the
+// points at the new pose and writes the next partial sums. No separate update kernel, no kernel boundary and no
+// trip through memory between "new pose known" and "residuals at the new pose". State and partials are
+// double-buffered by launch sequence number; block 0 alone publishes the state, trace row and progress words.
+// =============================================================================================
+struct FusedArgs {
+  PointList pl;      // point-list form
+  int n;
+  LevelView v;       // dense form reads I1 / D1; both read I2, rows, cols
+  LevelK k;
+  const LmState* st_in;
+  LmState* st_out;
+  const double* part_in;
+  double* part_out;
+  int level, first_of_level, max_iters;
+  float lambda0, precision;
+  int robust;
+  float huber_delta;
+  LmTraceRow* trace;
+  float* cost_stat;
+  int* host_prog;
+  int seq;
+};
+
+constexpr int kFoldChunk = 16;
+
+// Prologue shared by the fused kernels and the fused finalize: leaves the advanced state in s_sh.
+// fold_sh: >= 8 x 32 doubles of scratch. All 256 threads must call it.
+__device__ __forceinline__ void lm_fused_prologue(const LmState* __restrict__ st_in, const double* __restrict__ part_in,
+                                                  int level, int first_of_level, int max_iters, float lambda0,
+                                                  float precision, LmState& s_sh, double* fold_sh, double* acc_sh,
+                                                  float* delta_sh, int* flags_sh /* [4] */, LmTraceRow* __restrict__ trace,
+                                                  float* __restrict__ cost_stat, bool publisher) {
+  const int t = threadIdx.x;
+  if (t < (int)(sizeof(LmState) / sizeof(int))) ((int*)&s_sh)[t] = ((const int*)st_in)[t];
+  __syncthreads();
+  const bool pending = s_sh.pending != 0;  // block-uniform
+  if (pending) {
+    const int nblk = s_sh.pending_nblk;
+    const int q = t & 31, seg = t >> 5;
+    double v = 0.0;
+    if (q < ODO_NACC) {
+      for (int b0 = seg; b0 < nblk; b0 += 8 * kFoldChunk) {
+        double r[kFoldChunk];
+#pragma unroll
+        for (int u = 0; u < kFoldChunk; u++) {
+          const int b = b0 + 8 * u;
+          r[u] = (b < nblk) ? part_in[(size_t)b * ODO_NACC + q] : 0.0;  // all loads of the chunk in flight together
+        }
+#pragma unroll
+        for (int u = 0; u < kFoldChunk; u++) v += r[u];
+      }
+    }
+    fold_sh[seg * 32 + q] = v;
+    __syncthreads();
+    if (t < ODO_NACC) {
+      double a = 0.0;
+#pragma unroll
+      for (int g = 0; g < 8; g++) a += fold_sh[g * 32 + t];
+      acc_sh[t] = a;
+    }
+    __syncthreads();
+  }
+  if (t < 64) {  // wave 0: the scalar state machine on lane 0, the 6x6 solve across the wave
+    if (t == 0) {
+      flags_sh[0] = 0;  // need_step
+      flags_sh[1] = s_sh.iter;
+      flags_sh[2] = s_sh.level;
+      ((float*)flags_sh)[3] = s_sh.err_last;
+      if (pending) flags_sh[0] = lm_decide(&s_sh, acc_sh, precision) ? 1 : 0;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const bool need_step = flags_sh[0] != 0;
+    if (need_step) {
+      solve_damped_wave(acc_sh, s_sh.lambda, delta_sh);
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (t == 0) {
+      LmState& s = s_sh;
+      if (need_step) {
+        for (int i = 0; i < 6; i++) s.delta[i] = delta_sh[i];
+        lm_apply_step(&s, s.max_iters);
+      }
+      if (pending) {
+        const int lvl = flags_sh[2];
+        if (publisher) {
+          const int ev = s.n_evals - 1;
+          if (ev < kTraceCap) {
+            LmTraceRow& r = trace[ev];
+            r.level = lvl;
+            r.iter = flags_sh[1];
+            r.n_res = (int)acc_sh[28];
+            r.err = s.err_now;
+            r.accepted = (s.status == 0 && !(s.err_now > ((float*)flags_sh)[3])) ? 1 : 0;
+            r.stop = (s.stop_reason == 3 || s.active) ? 0 : s.stop_reason;
+            r.lambda_after = s.lambda;
+            for (int i = 0; i < 6; i++) r.delta[i] = (s.active || s.stop_reason == 3) ? s.delta[i] : 0.0f;
+          }
+          if (flags_sh[1] == 0 && s.iters_level[lvl & 7] == 1) cost_stat[lvl * 2 + 0] = s.err_now;
+          cost_stat[lvl * 2 + 1] = s.err_now;
+        }
+        s.pending = 0;
+      }
+      if (first_of_level && !s.active && s.level != level) {
+        s.stop_reason = 0;
+        lm_begin_level(&s, level, lambda0, max_iters);  // ref: src/lm_optimizer.cpp:110-115
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void lm_fused_publish(LmState& s_sh, LmState* __restrict__ st_out, int* __restrict__ host_prog,
+                                                 int seq, int level_before, bool was_active_before) {
+  const int t = threadIdx.x;
+  if (t < 64) {
+    if (t < (int)(sizeof(LmState) / sizeof(int))) ((int*)st_out)[t] = ((const int*)&s_sh)[t];
+    if (t == 0 && host_prog) {
+      // [1 + level] = 1 once that level's loop has stopped; [0] = sequence number of the last finished launch
+      if (was_active_before && !s_sh.active)
+        __hip_atomic_store(host_prog + 1 + level_before, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(host_prog, seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+template <bool LIST>
+__global__ void __launch_bounds__(kLmBlock) lm_fused_kernel(FusedArgs a) {
+  __shared__ LmState s_sh;
+  __shared__ double fold_sh[8 * 32];
+  __shared__ double acc_sh[32];
+  __shared__ float delta_sh[8];
+  __shared__ int flags_sh[4];
+  __shared__ int before_sh[2];
+  const bool publisher = (blockIdx.x == 0);
+  if (threadIdx.x == 0) { before_sh[0] = a.st_in->level; before_sh[1] = a.st_in->active; }
+  lm_fused_prologue(a.st_in, a.part_in, a.level, a.first_of_level, a.max_iters, a.lambda0, a.precision, s_sh, fold_sh,
+                    acc_sh, delta_sh, flags_sh, a.trace, a.cost_stat, publisher);
+  const bool run = (s_sh.active != 0 && s_sh.level == a.level && s_sh.status == 0);  // block-uniform
+  if (run) {
+    float T[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) T[i] = s_sh.T[i];
+    double acc[ODO_NACC];
+#pragma unroll
+    for (int q = 0; q < ODO_NACC; q++) acc[q] = 0.0;
+    if (LIST) {
+      for (int idx = blockIdx.x * kLmBlock + threadIdx.x; idx < a.n; idx += gridDim.x * kLmBlock) {
+        const PointK p = load_point(a.pl, idx);
+        int ui, vi;
+        if (!warp_point(p, T, a.k, a.v.rows, a.v.cols, &ui, &vi)) continue;
+        float r, J[6];
+        residual_jacobian(p, a.v.I2, a.v.rows, a.v.cols, ui, vi, &r, J);
+        accumulate_row(acc, r, robust_weight(r, a.robust, a.huber_delta, 1.0f), J);
+      }
+    } else {
+      const int iw = a.v.cols - 8, ih = a.v.rows - 8;
+      const int n = (iw > 0 && ih > 0) ? iw * ih : 0;
+      for (int idx = blockIdx.x * kLmBlock + threadIdx.x; idx < n; idx += gridDim.x * kLmBlock) {
+        const int y = 4 + idx / iw, x = 4 + idx % iw;
+        const size_t o = (size_t)y * a.v.cols + x;
+        const float d = a.v.D1[o];
+        if (!depth_valid(d)) continue;
+        const PointK p = make_point(x, y, d, a.v.I1[o], a.k);
+        int ui, vi;
+        if (!warp_point(p, T, a.k, a.v.rows, a.v.cols, &ui, &vi)) continue;
+        float r, J[6];
+        residual_jacobian(p, a.v.I2, a.v.rows, a.v.cols, ui, vi, &r, J);
+        accumulate_row(acc, r, robust_weight(r, a.robust, a.huber_delta, 1.0f), J);
+      }
+    }
+    block_reduce_acc(acc, a.part_out + (size_t)blockIdx.x * ODO_NACC);
+  }
+  if (publisher) {
+    if (threadIdx.x == 0 && run) { s_sh.pending = 1; s_sh.pending_nblk = gridDim.x; }
+    __syncthreads();
+    lm_fused_publish(s_sh, a.st_out, a.host_prog, a.seq, before_sh[0], before_sh[1] != 0);
+  }
+}
+
+// End of a fused Solve: consume the last pending evaluation, then affine_ = current_estimate.matrix()
+// (ref: src/lm_optimizer.cpp:158) or the pseudo-identity on failure (ref: :48-52,60-65).
+__global__ void __launch_bounds__(kLmBlock) lm_fused_finalize_kernel(const LmState* __restrict__ st_in,
+                                                                      const double* __restrict__ part_in, float precision,
+                                                                      LmTraceRow* __restrict__ trace,
+                                                                      float* __restrict__ cost_stat, LmState* __restrict__ st_out,
+                                                                      float* __restrict__ out) {
+  __shared__ LmState s_sh;
+  __shared__ double fold_sh[8 * 32];
+  __shared__ double acc_sh[32];
+  __shared__ float delta_sh[8];
+  __shared__ int flags_sh[4];
+  lm_fused_prologue(st_in, part_in, -1, 0, 0, 0.0f, precision, s_sh, fold_sh, acc_sh, delta_sh, flags_sh, trace, cost_stat,
+                    true);
+  if (threadIdx.x < (int)(sizeof(LmState) / sizeof(int))) ((int*)st_out)[threadIdx.x] = ((const int*)&s_sh)[threadIdx.x];
+  if (threadIdx.x == 0) {
+    float m[16];
+    if (s_sh.status == 0) {
+      se3_to_colmajor(s_sh.cur, m);
+    } else {
+      for (int i = 0; i < 16; i++) m[i] = 0.0f;
+      m[0] = 1.0f; m[5] = 1.0f; m[10] = 1.0f;
+    }
+    for (int i = 0; i < 16; i++) out[i] = m[i];
+    out[16] = (float)s_sh.status;
+    out[17] = (float)s_sh.n_evals;
+    for (int i = 0; i < 8; i++) out[18 + i] = (float)s_sh.iters_level[i];
   }
 }
 

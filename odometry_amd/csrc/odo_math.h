@@ -378,6 +378,10 @@ struct LmState {  // <= 64 dwords: the update kernel copies it with one wavefron
   int stop_reason;    // last stop: 1 precision, 2 lambda, 3 max iters
   int iters_level[8]; // evaluations per level (diagnostic; the reference never fills its own stats)
   float delta[6];     // last solved step
+  // fused pipeline: an evaluation whose partial sums have been written but not consumed yet
+  int pending;        // 1 = partials of an evaluation at s->T wait in the partial buffer
+  int pending_nblk;   // number of partial rows that evaluation wrote
+  int max_iters;      // iteration budget of the level being optimised (max_iterations_[level])
 };
 
 ODO_HD void lm_begin_solve(LmState* s, const float init_colmajor[16]) {
@@ -388,6 +392,9 @@ ODO_HD void lm_begin_solve(LmState* s, const float init_colmajor[16]) {
   s->n_evals = 0;
   s->active = 0;
   s->stop_reason = 0;
+  s->pending = 0;
+  s->pending_nblk = 0;
+  s->max_iters = 0;
   s->err_now = 0.0f;
   for (int i = 0; i < 8; i++) s->iters_level[i] = 0;
   for (int i = 0; i < 6; i++) s->delta[i] = 0.0f;
@@ -400,6 +407,7 @@ ODO_HD void lm_begin_level(LmState* s, int level, float lambda0, int max_iters) 
   s->lambda = lambda0;         // :113
   s->inc = s->cur;             // :115
   s->active = (s->status == 0 && max_iters > 0) ? 1 : 0;
+  s->max_iters = max_iters;
   se3_to_colmajor(s->inc, s->T);
 }
 

@@ -275,6 +275,7 @@ struct odo_lm {
   int use_list[ODO_MAX_LEVELS];
   unsigned long long kf_img_ver, kf_dep_ver;
   int* d_rowcnt; int* d_rowoff; int* d_npts; int* h_npts; int rows_cap;
+  int fused;  // 1 = one launch per evaluation (robust 0/1); 0 = separate residual / update kernels
   int mode;  // 0 auto (list when <= half of the interior has depth), 1 always dense scan, 2 always list
   void (*idle_pump)(void*);  // called while the host waits for the device (the tracker feeds its depth stream here)
   void* idle_arg;
@@ -305,8 +306,8 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
   m->K = K ? *K : kKitti00;  // null camera: the reference only warns (ref: src/lm_optimizer.cpp:35-38)
   memcpy(m->init, init_colmajor, sizeof(m->init));
   HIP_OK(hipSetDevice(ctx->device));
-  HIP_OK(hipMalloc((void**)&m->d_state, sizeof(LmState)));
-  HIP_OK(hipMalloc((void**)&m->d_partials, sizeof(double) * kLmMaxBlocks * ODO_NACC));
+  HIP_OK(hipMalloc((void**)&m->d_state, sizeof(LmState) * 2));                          // double-buffered (fused pipeline)
+  HIP_OK(hipMalloc((void**)&m->d_partials, sizeof(double) * 2 * kLmMaxBlocks * ODO_NACC)); // idem
   HIP_OK(hipMalloc((void**)&m->d_init, sizeof(float) * 16));
   HIP_OK(hipMalloc((void**)&m->d_out, sizeof(float) * 26));
   HIP_OK(hipMalloc((void**)&m->d_trace, sizeof(LmTraceRow) * kTraceCap));
@@ -321,6 +322,7 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
   HIP_OK(hipMalloc((void**)&m->d_npts, sizeof(int) * ODO_MAX_LEVELS));
   HIP_OK(hipHostMalloc((void**)&m->h_npts, sizeof(int) * ODO_MAX_LEVELS, hipHostMallocDefault));
   m->mode = getenv("ODO_LM_MODE") ? atoi(getenv("ODO_LM_MODE")) : 0;
+  m->fused = getenv("ODO_LM_UNFUSED") ? 0 : 1;
   m->poll = getenv("ODO_NO_POLL") ? 0 : 1;
   m->run_ahead = getenv("ODO_RUN_AHEAD") ? atoi(getenv("ODO_RUN_AHEAD")) : 2;
   HIP_OK(hipMemsetAsync(m->d_trace, 0, sizeof(LmTraceRow) * kTraceCap, ctx->stream));
@@ -504,13 +506,16 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
   hipLaunchKernelGGL(lm_begin_solve_kernel, dim3(1), dim3(64), 0, s, m->d_state, m->d_init, m->d_cost);
   int launches = 0;
   double bytes_per_level[ODO_MAX_LEVELS] = {0};
-  // Early exit without a host sync: the update kernel publishes its progress in host-mapped memory; the host
-  // stays at most `run_ahead` evaluations ahead of the device and stops issuing a level's launches once the
-  // device reports that the level's loop has ended. Stale launches are no-ops on the device either way.
+  // Early exit without a host sync: the device publishes its progress in host-mapped memory; the host stays at
+  // most `run_ahead` evaluations ahead of the device and stops issuing a level's launches once the device reports
+  // that the level's loop has ended. Stale launches are no-ops on the device either way.
   volatile int* prog = m->h_prog;
   for (int i = 0; i < 16; i++) m->h_prog[i] = 0;  // the stream is idle here (every Solve ends with a sync)
   bool poll = m->poll != 0;
+  const bool fused = m->fused && m->robust != 2;
   int seq = 0;
+  LmState* st[2] = {m->d_state, m->d_state + 1};
+  double* part[2] = {m->d_partials, m->d_partials + (size_t)kLmMaxBlocks * ODO_NACC};
   for (int l = m->n_levels - 1; l >= 0; l--) {  // ref: src/lm_optimizer.cpp:92
     LevelView v;
     v.I1 = kf_img->dev + kf_img->off[l];
@@ -521,7 +526,8 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
     const int nblk = lm_grid_for(m, l, v.rows, v.cols);
     if (m->robust == 2 && lm_ensure_res(m, (size_t)v.rows * v.cols)) return -1;
     bytes_per_level[l] = lm_level_bytes(m, l, v.rows, v.cols, nblk);
-    hipLaunchKernelGGL(lm_begin_level_kernel, dim3(1), dim3(64), 0, s, m->d_state, l, m->lambda, m->max_iters[l]);
+    if (!fused)
+      hipLaunchKernelGGL(lm_begin_level_kernel, dim3(1), dim3(64), 0, s, m->d_state, l, m->lambda, m->max_iters[l]);
     for (int it = 0; it < m->max_iters[l]; it++) {  // ref: :117
       if (poll) {
         const auto t0 = std::chrono::steady_clock::now();
@@ -531,14 +537,32 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
         }
         if (prog[1 + l]) break;  // the level's loop has stopped on the device
       }
-      seq++;
-      lm_launch_eval(m, v, k, l, nblk);
-      hipLaunchKernelGGL(lm_update_kernel, dim3(1), dim3(256), 0, s, m->d_state, m->d_partials, nblk, l, m->precision,
-                         m->max_iters[l], m->d_trace, m->d_cost, m->d_prog, seq);
+      if (fused) {
+        FusedArgs a;
+        a.pl = m->pl[l]; a.n = m->npts[l]; a.v = v; a.k = k;
+        a.st_in = st[seq & 1]; a.st_out = st[(seq + 1) & 1];
+        a.part_in = part[seq & 1]; a.part_out = part[(seq + 1) & 1];
+        a.level = l; a.first_of_level = (it == 0) ? 1 : 0; a.max_iters = m->max_iters[l];
+        a.lambda0 = m->lambda; a.precision = m->precision; a.robust = m->robust; a.huber_delta = m->huber_delta;
+        a.trace = m->d_trace; a.cost_stat = m->d_cost; a.host_prog = m->d_prog; a.seq = seq;
+        if (m->use_list[l]) hipLaunchKernelGGL(lm_fused_kernel<true>, dim3(nblk), dim3(kLmBlock), 0, s, a);
+        else hipLaunchKernelGGL(lm_fused_kernel<false>, dim3(nblk), dim3(kLmBlock), 0, s, a);
+        seq++;
+      } else {
+        seq++;
+        lm_launch_eval(m, v, k, l, nblk);
+        hipLaunchKernelGGL(lm_update_kernel<false>, dim3(1), dim3(kUpdThreads), 0, s, m->d_state, m->d_partials, nblk, l,
+                           m->precision, m->max_iters[l], m->d_trace, m->d_cost, m->d_prog, seq,
+                           (unsigned long long*)nullptr);
+      }
       launches++;
     }
   }
-  hipLaunchKernelGGL(lm_finalize_kernel, dim3(1), dim3(64), 0, s, m->d_state, m->d_out);
+  if (fused)
+    hipLaunchKernelGGL(lm_fused_finalize_kernel, dim3(1), dim3(kLmBlock), 0, s, st[seq & 1], part[seq & 1], m->precision,
+                       m->d_trace, m->d_cost, st[0], m->d_out);
+  else
+    hipLaunchKernelGGL(lm_finalize_kernel, dim3(1), dim3(64), 0, s, m->d_state, m->d_out);
   HIP_OK(hipGetLastError());
   HIP_OK(hipMemcpyAsync(m->h_out, m->d_out, sizeof(float) * 26, hipMemcpyDeviceToHost, s));
   HIP_OK(hipMemcpyAsync(m->h_trace, m->d_trace, sizeof(LmTraceRow) * kTraceCap, hipMemcpyDeviceToHost, s));
@@ -649,6 +673,37 @@ extern "C" int odo_lm_accumulate(odo_lm* m, const odo_pyr* kf_img, const odo_pyr
   HIP_OK(hipStreamSynchronize(s));
   HIP_OK(hipFree(d_acc));
   return (acc[28] > 0.0) ? 0 : -1;  // N == 0 fails (ref: src/lm_optimizer.cpp:244-248)
+}
+
+// Diagnostic entry: one evaluation + one STAMPed update at pose T on `level`; returns 8 cycle-counter stamps of the
+// update kernel (phase boundaries: entry, fold, state copy, decide, solve, apply, trace, exit).
+extern "C" int odo_debug_update_stamps(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img,
+                                       int level, const float T_colmajor[16], unsigned long long stamps[8]) {
+  if (!T_colmajor || !stamps) return fail("odo_debug_update_stamps: NULL arg");
+  if (lm_check_pyrs(m, kf_img, kf_dep, cur_img)) return -1;
+  hipStream_t s = m->ctx->stream;
+  HIP_OK(hipSetDevice(m->ctx->device));
+  LevelView v;
+  v.I1 = kf_img->dev + kf_img->off[level];
+  v.I2 = cur_img->dev + cur_img->off[level];
+  v.D1 = kf_dep->dev + kf_dep->off[level];
+  v.rows = kf_img->r[level]; v.cols = kf_img->c[level];
+  const LevelK k = make_level_k(m->K.f0, m->K.cx0, m->K.cy0, level);
+  if (lm_prepare_keyframe(m, kf_img, kf_dep)) return -1;
+  const int nblk = lm_grid_for(m, level, v.rows, v.cols);
+  unsigned long long* d_st = nullptr;
+  HIP_OK(hipMalloc((void**)&d_st, sizeof(unsigned long long) * 8));
+  HIP_OK(hipMemsetAsync(d_st, 0, sizeof(unsigned long long) * 8, s));
+  HIP_OK(hipMemcpyAsync(m->d_init, T_colmajor, sizeof(float) * 16, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(lm_force_state_kernel, dim3(1), dim3(64), 0, s, m->d_state, m->d_init, level);
+  lm_launch_eval(m, v, k, level, nblk);
+  hipLaunchKernelGGL(lm_update_kernel<true>, dim3(1), dim3(kUpdThreads), 0, s, m->d_state, m->d_partials, nblk, level, m->precision,
+                     100, m->d_trace, m->d_cost, m->d_prog, 1, d_st);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpyAsync(stamps, d_st, sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  HIP_OK(hipFree(d_st));
+  return 0;
 }
 
 // Test entry: the wave-parallel damped 6x6 solve the update kernel uses, on caller-supplied accumulators.

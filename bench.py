@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--gather-every", type=int, default=8)
     ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-overlap", action="store_true", help="run ComputeDepth after Solve on one stream")
+    ap.add_argument("--overlap", type=int, default=2, help="1: one host thread feeds both streams, 2: helper thread")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -81,7 +82,7 @@ def main():
 
     from odometry_amd import api, synth
     seq = synth.make_sequence(args.unique_frames, seed=rank)
-    trk = api.Tracker(local_rank, overlap_depth=0 if args.no_overlap else 1)
+    trk = api.Tracker(local_rank, overlap_depth=0 if args.no_overlap else args.overlap)
     dev = [(trk.upload_frame(l), trk.upload_frame(r)) for l, r in zip(seq["left"], seq["right"])]  # inputs resident in HBM
     trk.init(*dev[0])
     order = frame_order(args.unique_frames, args.warmup + args.steps)
@@ -140,7 +141,7 @@ def main():
                    config=dict(workload="synthetic KITTI-shaped stereo sequence (configs[1]), 1241x376, 4 levels, "
                                         "semi-dense, runner params, one sequence per GPU",
                                unique_frames=args.unique_frames, sequences_per_gpu=1,
-                               overlap_depth=not args.no_overlap, gather_every=args.gather_every),
+                               overlap_depth=0 if args.no_overlap else args.overlap, gather_every=args.gather_every),
                    roofline=roof,
                    lm_evals_per_frame=round(float(np.mean(evals)), 2),
                    keyframes=trk.stats()["n_keyframes"])
@@ -148,7 +149,7 @@ def main():
             n = min(args.cpu_frames, args.steps)
             cpu_fps, cpu_poses, cpu_dt = cpu_baseline(seq, order, n)
             # fresh GPU pass over the same frames from the same start: full-pipeline parity next to the timing
-            trk2 = api.Tracker(local_rank, overlap_depth=0 if args.no_overlap else 1)
+            trk2 = api.Tracker(local_rank, overlap_depth=0 if args.no_overlap else args.overlap)
             dev2 = [(trk2.upload_frame(l), trk2.upload_frame(r)) for l, r in zip(seq["left"], seq["right"])]
             trk2.init(*dev2[0])
             dmax = 0.0

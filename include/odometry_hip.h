@@ -156,7 +156,8 @@ int odo_depth_destroy(odo_depth* d);
  * frame): ImagePyramid(cur) -> Solve against the current keyframe -> cur_pose = KF * T^-1 -> ComputeDepth ->
  * rebuild the frame's image / depth pyramids -> keyframe test on the weighted motion -> Reset(T, 0.01).
  * Inputs are device-resident fp32 images (rows x cols, dense). ComputeDepth runs on a second HIP stream
- * concurrently with Solve when overlap_depth != 0 (the two are independent in the reference's loop). */
+ * concurrently with Solve when overlap_depth != 0 (the two are independent in the reference's loop):
+ * 1 = both streams fed by the calling thread, 2 = stream B fed by a helper host thread (default). */
 typedef struct {
   int rows, cols, levels;
   float lm_lambda, lm_precision;          /* ref: run_odometry_kitti_offline.cpp:88 (0.01f, 0.995f) */

@@ -8,7 +8,9 @@
 #include <string.h>
 #include <chrono>
 
+#include <atomic>
 #include <new>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -124,7 +126,7 @@ struct odo_pyr {
   int r[ODO_MAX_LEVELS], c[ODO_MAX_LEVELS];
   unsigned long long version;  // bumped by every (re)build: keys the LM's keyframe point-list cache
 };
-static unsigned long long g_pyr_version = 0;
+static std::atomic<unsigned long long> g_pyr_version{0};
 
 static int pyr_build(odo_pyr* p, const float* img_dev, int smooth) {
   hipStream_t s = p->ctx->stream;

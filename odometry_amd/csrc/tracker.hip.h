@@ -20,7 +20,16 @@ struct odo_tracker {
   DepthJob job;
   int job_stage;  // 0 idle, 1 depth launches in flight, 2 depth tail enqueued (pyramids next), 3 all enqueued
   int job_err;
+  // overlap_depth == 2: a helper host thread feeds stream B (ComputeDepth + candidate pyramids) while the calling
+  // thread feeds stream A (pose LM). Host launch rate, not the GPU, bounds a latency-bound frame loop.
+  std::thread worker;
+  std::atomic<int> w_state;  // 0 idle, 1 job requested, 2 job done, 3 quit
+  const float *w_left, *w_right;
+  int w_rc;
+  char w_err[256];
 };
+
+static void tracker_worker_main(odo_tracker* t);
 
 extern "C" int odo_tracker_default_params(odo_tracker_params* p) {
   if (!p) return fail("NULL params");
@@ -41,12 +50,16 @@ extern "C" int odo_tracker_default_params(odo_tracker_params* p) {
   for (int i = 0; i < 6; i++) p->keyframe_weight[i] = w[i];
   p->keyframe_motion_th = 1.1f;
   p->smooth_image = 1;
-  p->overlap_depth = 1;
+  p->overlap_depth = 2;
   return 0;
 }
 
 extern "C" int odo_tracker_destroy(odo_tracker* t) {
   if (!t) return 0;
+  if (t->worker.joinable()) {
+    t->w_state.store(3, std::memory_order_release);
+    t->worker.join();
+  }
   if (t->ctx_a) (void)hipStreamSynchronize(t->ctx_a->stream);
   if (t->ctx_b) (void)hipStreamSynchronize(t->ctx_b->stream);
   odo_lm_destroy(t->lm);
@@ -68,7 +81,12 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
   *out = nullptr;
   odo_tracker* t = new (std::nothrow) odo_tracker();
   if (!t) return fail("out of memory");
-  memset(t, 0, sizeof(*t));
+  t->ctx_a = t->ctx_b = nullptr; t->lm = nullptr; t->depth = nullptr;
+  t->kf_img = t->kf_dep = t->cur_img = t->pre_img = t->pre_dep = nullptr;
+  t->d_val = nullptr; t->d_disp = t->d_dep = nullptr; t->ev_inputs = nullptr;
+  t->n_keyframes = t->frame_id = t->last_evals = t->last_depth_iters = t->last_valid = 0;
+  t->job_stage = t->job_err = 0;
+  t->w_state.store(0); t->w_left = t->w_right = nullptr; t->w_rc = 0; t->w_err[0] = 0;
   t->p = *p;
   float eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   memcpy(t->pose_to_kf, eye, sizeof(eye));
@@ -94,6 +112,7 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
     odo_tracker_destroy(t);
     return fail("odo_tracker_create failed: %s", keep);
   }
+  if (p->overlap_depth == 2) t->worker = std::thread(tracker_worker_main, t);
   *out = t;
   return 0;
 }
@@ -129,6 +148,26 @@ static int tracker_job_drain(odo_tracker* t) {
 static int tracker_depth_and_pyramids(odo_tracker* t, const float* left, const float* right) {
   if (tracker_job_begin(t, left, right)) return -1;
   return tracker_job_drain(t);
+}
+
+// Helper thread (overlap_depth == 2): runs the whole stream-B job of a frame, including its final stream sync.
+static void tracker_worker_main(odo_tracker* t) {
+  (void)hipSetDevice(t->ctx_b->device);
+  int idle_spins = 0;
+  for (;;) {
+    const int st = t->w_state.load(std::memory_order_acquire);
+    if (st == 3) return;
+    if (st != 1) {
+      if (++idle_spins > 20000) std::this_thread::sleep_for(std::chrono::microseconds(50));  // back off when idle
+      continue;
+    }
+    idle_spins = 0;
+    int rc = tracker_depth_and_pyramids(t, t->w_left, t->w_right);
+    if (rc == 0) rc = depth_finish(t->depth);
+    t->w_rc = rc;
+    if (rc) snprintf(t->w_err, sizeof(t->w_err), "%s", g_err);
+    t->w_state.store(2, std::memory_order_release);
+  }
 }
 
 extern "C" int odo_tracker_init(odo_tracker* t, const float* left, const float* right, const float abs_pose0[16]) {
@@ -191,8 +230,13 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
   const odo_tracker_params& p = t->p;
   HIP_OK(hipSetDevice(t->ctx_a->device));
   t->frame_id++;
+  if (p.overlap_depth == 2) {
+    // helper thread: the whole stream-B job (ComputeDepth, candidate pyramids, final sync) runs beside this thread
+    t->w_left = left; t->w_right = right;
+    t->w_state.store(1, std::memory_order_release);
+  }
   if (pyr_build(t->cur_img, left, p.smooth_image)) return -1;                          // :205
-  if (p.overlap_depth) {
+  if (p.overlap_depth == 1) {
     // stream B: ComputeDepth + candidate pyramids, concurrent with the Solve on stream A. The front of the job is
     // enqueued now; its depth-LM launches are issued from the pose LM's wait loop (one host thread feeds both).
     if (tracker_job_begin(t, left, right)) return -1;
@@ -202,12 +246,18 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
   float T[16];
   const int st = odo_lm_solve(t->lm, t->kf_img, t->kf_dep, t->cur_img, T);             // :215 (synchronises stream A)
   t->lm->idle_pump = nullptr;
-  if (p.overlap_depth) {
-    if (tracker_job_drain(t)) return -1;
+  if (p.overlap_depth == 2) {
+    while (t->w_state.load(std::memory_order_acquire) != 2) { /* spin: the job is ~0.2 ms */ }
+    t->w_state.store(0, std::memory_order_release);
+    if (t->w_rc) { fail("    depth failed! (%s)", t->w_err); return -1; }                // :230-232
   } else {
-    if (tracker_depth_and_pyramids(t, left, right)) return -1;                         // :226-252 in program order
+    if (p.overlap_depth == 1) {
+      if (tracker_job_drain(t)) return -1;
+    } else {
+      if (tracker_depth_and_pyramids(t, left, right)) return -1;                       // :226-252 in program order
+    }
+    if (depth_finish(t->depth)) { fail("    depth failed!"); return -1; }              // :230-232
   }
-  if (depth_finish(t->depth)) { fail("    depth failed!"); return -1; }                // :230-232
   memcpy(t->pose_to_kf, T, sizeof(T));
   float inv[16], cur[16];
   if (!invert4(T, inv)) memset(inv, 0, sizeof(inv));

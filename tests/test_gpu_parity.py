@@ -307,7 +307,7 @@ def test_tracker_matches_oracle_runner(api, kitti_seq):
     """Full frame loop (ref: run_odometry_kitti_offline.cpp:95-145,198-271): GPU tracker vs oracle runner."""
     from oracle import runner as orunner
     L, R = kitti_seq["left"], kitti_seq["right"]
-    for overlap in (1, 0):
+    for overlap in (2, 1, 0):
         trk = api.Tracker(0, overlap_depth=overlap)
         dev = [(trk.upload_frame(l), trk.upload_frame(r)) for l, r in zip(L, R)]
         trk.init(*dev[0])

@@ -110,6 +110,17 @@ typedef struct {
   float delta[6];
 } odo_lm_trace_row;
 int odo_lm_trace(const odo_lm* lm, odo_lm_trace_row* rows, int cap, int* n_rows);
+/* Roofline leg of bench.py (any size / intrinsics, e.g. the dense 1920x1080 config): `reps` event-bracketed launches of
+ * the evaluation kernel on `level` at pose T; mean / min launch time, algorithmic bytes of one launch, residual count. */
+int odo_lm_time_eval(odo_lm* lm, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img, int level,
+                     const float T_colmajor[16], int reps, float* mean_us, float* min_us, double* algorithmic_bytes,
+                     int* n_points);
+/* Roofline leg of bench.py: while on, every evaluation-kernel launch of Solve is bracketed by HIP events on the
+ * context's stream; the stats are the summed launch durations, the number of launches, how many of them evaluated
+ * points, and the algorithmic bytes they touched. */
+int odo_lm_event_timing(odo_lm* lm, int on);
+int odo_lm_event_stats(const odo_lm* lm, double* total_us, long* launches, long* active_launches,
+                       double* algorithmic_bytes);
 /* Iteration space of the residual kernel: 0 = automatic (per keyframe and level: a compacted point list when at most
  * half of the interior pixels carry depth, the dense scan of the reference otherwise), 1 = always the dense scan,
  * 2 = always the point list. All three evaluate the same per-point arithmetic. */
@@ -147,6 +158,10 @@ int odo_depth_compute_dev(odo_depth* d, const float* left_dev, const float* righ
 /* Disparity stage only (DisparityDepthEstimate, ref: src/depth_estimate.cpp:244-401). */
 int odo_depth_disparity(odo_depth* d, const float* left, const float* right, int rows, int cols, uint8_t* val,
                         float* disp, float* dep);
+/* bench.py config-5 leg: event-timed blur / point selection / epipolar SSD scan on device-resident images (mean of
+ * `reps`, microseconds), the number of SSD candidates one scan evaluates and the number of selected points. */
+int odo_depth_time_stages(odo_depth* d, const float* left_dev, const float* right_dev, int rows, int cols, int reps,
+                          float us[3], double* candidates, int* n_selected);
 /* ReportStatus data (ref: src/depth_estimate.cpp:465-468) + counts printed by ComputeDepth (:62,74). */
 int odo_depth_report(const odo_depth* d, int* iters, float* cost, int* n_selected, int* n_matched, int* n_valid);
 int odo_depth_destroy(odo_depth* d);

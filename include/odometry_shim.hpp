@@ -1,0 +1,319 @@
+// odometry_shim.hpp — the reference's public C++ surface over the C ABI in odometry_hip.h.
+//
+// Header-only drop-in for the four headers the runner includes
+//   include/image_pyramid.h   (ref: :14-69)    ImagePyramid, DepthPyramid
+//   include/lm_optimizer.h    (ref: :24-115)   LevenbergMarquardtOptimizer
+//   include/depth_estimate.h  (ref: :24-121)   DepthEstimator
+//   include/keyframe.h        (ref: :17-60)    KeyFrame
+//   include/data_types.h      (ref: :10-28)    Affine4f, OptimizerStatus, GlobalStatus, PixelType
+// Same namespace, class names, constructor / method signatures, copy semantics and error behaviour (status ints,
+// messages on std::cout, no exceptions, Solve returns the pseudo-identity on failure), so
+// run_odometry_kitti_offline.cpp compiles against it unchanged once its includes point here.
+//
+// Images: with -DODOMETRY_SHIM_WITH_OPENCV the classes take cv::Mat exactly like the reference. Without OpenCV (this
+// repository's build image has none) a minimal odometry::Mat with the members the runner uses stands in.
+// Poses: with -DODOMETRY_SHIM_WITH_EIGEN Affine4f is Eigen::Matrix<float,4,4> (column-major, as in the reference);
+// otherwise a 16-float column-major struct with operator()(row, col).
+#ifndef ODOMETRY_SHIM_HPP
+#define ODOMETRY_SHIM_HPP
+
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <memory>
+#include <vector>
+
+#include "odometry_hip.h"
+
+#ifdef ODOMETRY_SHIM_WITH_OPENCV
+#include <opencv2/core.hpp>
+#endif
+#ifdef ODOMETRY_SHIM_WITH_EIGEN
+#include <Eigen/Core>
+#endif
+
+#ifndef PixelType
+#ifdef ODOMETRY_SHIM_WITH_OPENCV
+#define PixelType CV_32F
+#else
+#define PixelType 5 /* CV_32F */
+#endif
+#endif
+
+namespace odometry {
+
+typedef int OptimizerStatus;  // ref: include/data_types.h:27
+typedef int GlobalStatus;     // ref: include/data_types.h:28
+
+// ------------------------------------------------------------------------------------------------
+#ifdef ODOMETRY_SHIM_WITH_EIGEN
+typedef Eigen::Matrix<float, 4, 4> Affine4f;  // ref: include/data_types.h:24
+inline const float* affine_data(const Affine4f& a) { return a.data(); }
+inline float* affine_data(Affine4f& a) { return a.data(); }
+#else
+struct Affine4f {  // 16 fp32, column-major like Eigen's default
+  float m[16];
+  float& operator()(int r, int c) { return m[c * 4 + r]; }
+  float operator()(int r, int c) const { return m[c * 4 + r]; }
+  static Affine4f Identity() {
+    Affine4f a;
+    std::memset(a.m, 0, sizeof(a.m));
+    a.m[0] = a.m[5] = a.m[10] = a.m[15] = 1.0f;
+    return a;
+  }
+};
+inline const float* affine_data(const Affine4f& a) { return a.m; }
+inline float* affine_data(Affine4f& a) { return a.m; }
+#endif
+
+// ------------------------------------------------------------------------------------------------
+#ifdef ODOMETRY_SHIM_WITH_OPENCV
+typedef cv::Mat Mat;
+#else
+enum { CV_8U = 0, CV_32F = 5 };
+// The subset of cv::Mat the runner and the estimators touch: rows, cols, type(), at<T>, ptr<T>, isContinuous,
+// copyTo / clone, ref-counted header copies.
+class Mat {
+ public:
+  int rows = 0, cols = 0;
+  Mat() {}
+  Mat(int r, int c, int type) { create(r, c, type); }
+  Mat(int r, int c, int type, double fill) {
+    create(r, c, type);
+    if (type_ == CV_32F) for (size_t i = 0; i < (size_t)r * c; i++) reinterpret_cast<float*>(buf_->data())[i] = (float)fill;
+    else std::memset(buf_->data(), (int)fill, buf_->size());
+  }
+  void create(int r, int c, int type) {
+    rows = r; cols = c; type_ = type;
+    buf_ = std::make_shared<std::vector<uint8_t>>((size_t)r * c * elemSize());
+  }
+  int type() const { return type_; }
+  int channels() const { return 1; }
+  size_t elemSize() const { return type_ == CV_32F ? 4 : 1; }
+  bool isContinuous() const { return true; }
+  bool empty() const { return !buf_ || rows == 0 || cols == 0; }
+  template <class T> T* ptr(int y = 0) { return reinterpret_cast<T*>(buf_->data() + (size_t)y * cols * elemSize()); }
+  template <class T> const T* ptr(int y = 0) const { return reinterpret_cast<const T*>(buf_->data() + (size_t)y * cols * elemSize()); }
+  template <class T> T& at(int y, int x) { return ptr<T>(y)[x]; }
+  template <class T> const T& at(int y, int x) const { return ptr<T>(y)[x]; }
+  void copyTo(Mat& dst) const {
+    dst.create(rows, cols, type_);
+    if (buf_) std::memcpy(dst.buf_->data(), buf_->data(), buf_->size());
+  }
+  Mat clone() const { Mat m; copyTo(m); return m; }
+ private:
+  int type_ = CV_32F;
+  std::shared_ptr<std::vector<uint8_t>> buf_;
+};
+#endif
+
+class CameraPyramid;  // ref: include/camera.h — never dereferenced on this path; the runner passes nullptr
+
+namespace detail {
+// One HIP context (stream) per host thread, created on first use — the reference is single-threaded
+// (ref: run_odometry_kitti_offline.cpp:3).
+inline odo_ctx* context() {
+  static thread_local odo_ctx* ctx = nullptr;
+  if (!ctx) {
+    const char* dev = std::getenv("ODOMETRY_HIP_DEVICE");
+    if (odo_ctx_create(dev ? std::atoi(dev) : 0, &ctx) != 0) {
+      std::cout << "odometry_hip: " << odo_last_error() << std::endl;
+      std::exit(1);  // no CPU fallback
+    }
+  }
+  return ctx;
+}
+struct PyrHandle {
+  odo_pyr* p = nullptr;
+  std::vector<Mat> host;       // lazily downloaded levels for GetPyramidImage / GetPyramidDepth
+  std::vector<char> have;
+  ~PyrHandle() { odo_pyramid_destroy(p); }
+};
+inline const Mat& pyr_level(const std::shared_ptr<PyrHandle>& h, int level) {
+  if (!h->have[level]) {
+    int r = 0, c = 0;
+    odo_pyramid_level_dims(h->p, level, &r, &c);
+    h->host[level].create(r, c, PixelType);
+    odo_pyramid_download(h->p, level, h->host[level].ptr<float>());
+    h->have[level] = 1;
+  }
+  return h->host[level];
+}
+inline std::shared_ptr<PyrHandle> make_pyr(int num_levels, const Mat& in, bool smooth, int kind, const char* what) {
+  auto h = std::make_shared<PyrHandle>();
+  h->host.resize(num_levels > 0 ? num_levels : 0);
+  h->have.assign(num_levels > 0 ? num_levels : 0, 0);
+  if (in.type() != PixelType || !in.isContinuous() ||
+      odo_pyramid_create(context(), in.ptr<float>(), in.rows, in.cols, 0, num_levels, smooth ? 1 : 0, kind, &h->p) != 0) {
+    std::cout << what << std::endl;  // ref: src/image_pyramid.cpp:16-18,34-36 (prints, object stays unusable)
+    h->p = nullptr;
+  }
+  return h;
+}
+}  // namespace detail
+
+// ------------------------------------------------------------------------------------------------
+class ImagePyramid {  // ref: include/image_pyramid.h:14-41
+ public:
+  ImagePyramid() = delete;
+  ImagePyramid(int num_levels, const Mat& in_img, bool smooth = true)
+      : num_levels_(num_levels),
+        h_(detail::make_pyr(num_levels, in_img, smooth, ODO_PYR_IMAGE, "Compute Gaussian Image Pyramid failed!")) {}
+  ImagePyramid& operator=(const ImagePyramid&) = delete;
+  int GetNumberLevels() const { return num_levels_; }
+  const Mat& GetPyramidImage(int level_idx) const {
+    if (level_idx >= num_levels_) {  // ref: src/image_pyramid.cpp:22-25
+      std::cout << "Requested image pyramid does not exist! Max pyramid id: " << num_levels_ - 1 << std::endl;
+      std::exit(1);
+    }
+    return detail::pyr_level(h_, level_idx);
+  }
+  const odo_pyr* handle() const { return h_->p; }
+ private:
+  int num_levels_;
+  std::shared_ptr<detail::PyrHandle> h_;  // copies share the device pyramid, like cv::Mat headers in the reference
+};
+
+class DepthPyramid {  // ref: include/image_pyramid.h:43-69
+ public:
+  DepthPyramid() = delete;
+  DepthPyramid(int num_levels, const Mat& in_depth, bool smooth = true)
+      : num_levels_(num_levels),
+        h_(detail::make_pyr(num_levels, in_depth, smooth, ODO_PYR_DEPTH, "Compute Gaussian Depth Pyramid failed!")) {}
+  DepthPyramid& operator=(const DepthPyramid&) = delete;
+  int GetNumberLevels() const { return num_levels_; }
+  const Mat& GetPyramidDepth(int level_idx) const { return detail::pyr_level(h_, level_idx); }
+  const odo_pyr* handle() const { return h_->p; }
+ private:
+  int num_levels_;
+  std::shared_ptr<detail::PyrHandle> h_;
+};
+
+// ------------------------------------------------------------------------------------------------
+class LevenbergMarquardtOptimizer {  // ref: include/lm_optimizer.h:24-115
+ public:
+  LevenbergMarquardtOptimizer() = delete;
+  LevenbergMarquardtOptimizer(float lambda, float precision, const std::vector<int> kMaxIterations,
+                              const Affine4f& kRelativeInit, const std::shared_ptr<CameraPyramid>& kCameraPtr,
+                              const int robust_est, const float huber_delta = 4.0f / 255.0f) {
+    if (kCameraPtr == nullptr) std::cout << "LM Optimizer failed! Invalid camera pointer!" << std::endl;  // ref: :35-36
+    if (odo_lm_create(detail::context(), lambda, precision, kMaxIterations.data(), (int)kMaxIterations.size(),
+                      affine_data(kRelativeInit), robust_est, huber_delta, nullptr, &lm_) != 0)
+      std::cout << "odometry_hip: " << odo_last_error() << std::endl;
+  }
+  ~LevenbergMarquardtOptimizer() { odo_lm_destroy(lm_); }
+  LevenbergMarquardtOptimizer(const LevenbergMarquardtOptimizer&) = delete;
+  LevenbergMarquardtOptimizer& operator=(const LevenbergMarquardtOptimizer&) = delete;
+
+  Affine4f Solve(const ImagePyramid& kImagePyr1, const DepthPyramid& kDepthPyr1, const ImagePyramid& kImagePyr2) {
+    Affine4f out;
+    if (odo_lm_solve(lm_, kImagePyr1.handle(), kDepthPyr1.handle(), kImagePyr2.handle(), affine_data(out)) != 0)
+      std::cout << "Optimize failed! " << std::endl;  // ref: src/lm_optimizer.cpp:60-65 (out = pseudo-identity)
+    return out;
+  }
+  void ShowReport() {  // ref: src/lm_optimizer.cpp:364-371
+    int it[4] = {0, 0, 0, 0};
+    float cost[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    odo_lm_report(lm_, it, cost);
+    std::cout << "Number of iterations performed per level: ";
+    std::cout << it[0] << ", " << it[1] << ", " << it[2] << ", " << it[3] << std::endl;
+    std::cout << "Costs before/after per level: " << std::endl;
+    for (int i = 0; i < 4; i++) std::cout << cost[i][0] << ", " << cost[i][1] << std::endl;
+  }
+  OptimizerStatus Reset(const Affine4f& kRelativeInit, const float lambda) {  // ref: :373-382
+    if (odo_lm_reset(lm_, affine_data(kRelativeInit), lambda) != 0) {
+      std::cout << "Reset optimizer failed!" << std::endl;
+      return -1;
+    }
+    return 0;
+  }
+  odo_lm* handle() { return lm_; }
+ private:
+  odo_lm* lm_ = nullptr;
+};
+
+// ------------------------------------------------------------------------------------------------
+class DepthEstimator {  // ref: include/depth_estimate.h:24-121
+ public:
+  DepthEstimator() = delete;
+  DepthEstimator(float grad_th, float ssd_th, float photo_th, float min_depth, float max_depth, float lambda,
+                 float huber_delta, float precision, int max_iters, int boundary,
+                 const std::shared_ptr<CameraPyramid>& /*left_cam_ptr*/, const std::shared_ptr<CameraPyramid>& /*right_cam_ptr*/,
+                 float baseline, int max_residuals = 5000)
+      : max_iters_(max_iters) {
+    if (odo_depth_create(detail::context(), grad_th, ssd_th, photo_th, min_depth, max_depth, lambda, huber_delta, precision,
+                         max_iters, boundary, nullptr, baseline, max_residuals, 0, 0, &d_) != 0)
+      std::cout << "odometry_hip: " << odo_last_error() << std::endl;
+  }
+  ~DepthEstimator() { odo_depth_destroy(d_); }
+  DepthEstimator(const DepthEstimator&) = delete;
+  DepthEstimator& operator=(const DepthEstimator&) = delete;
+
+  GlobalStatus ComputeDepth(const Mat& left_img, const Mat& right_img, Mat& left_val, Mat& left_disp, Mat& left_dep) {
+    if (left_img.rows != right_img.rows || left_img.cols != right_img.cols) {  // ref: src/depth_estimate.cpp:37-40
+      std::cout << "Number of rows/cols do not match for left/right images." << std::endl;
+      return -1;
+    }
+    if (left_img.type() != PixelType || right_img.type() != PixelType) {       // ref: :41-44
+      std::cout << "Pixel type of left/right images not 32-bit float." << std::endl;
+      return -1;
+    }
+    if (!left_img.isContinuous() || !right_img.isContinuous() || !left_disp.isContinuous() || !left_dep.isContinuous() ||
+        !left_val.isContinuous()) {                                              // ref: :259-263
+      std::cout << "The cv::Mat matrix is not continuous in disparity search!" << std::endl;
+      return -1;
+    }
+    std::cout << "computing disparity ..." << std::endl;
+    const int st = odo_depth_compute(d_, left_img.ptr<float>(), right_img.ptr<float>(), left_img.rows, left_img.cols,
+                                     left_val.ptr<uint8_t>(), left_disp.ptr<float>(), left_dep.ptr<float>());
+    int iters = 0, nsel = 0, nmatch = 0, nvalid = 0;
+    float cost = 0;
+    odo_depth_report(d_, &iters, &cost, &nsel, &nmatch, &nvalid);
+    if (st != 0) {
+      std::cout << odo_last_error() << std::endl;
+      std::cout << "Depth optimization failed!" << std::endl;                    // ref: :70-72
+      return -1;
+    }
+    std::cout << "valid disparities: " << nsel << std::endl;                     // ref: :62
+    std::cout << "optimizing depth ..." << std::endl;
+    std::cout << "valid depth: " << nvalid << std::endl;                         // ref: :74
+    return 0;
+  }
+  void ReportStatus() {  // ref: src/depth_estimate.cpp:465-468
+    int iters = 0;
+    float cost = 0;
+    odo_depth_report(d_, &iters, &cost, nullptr, nullptr, nullptr);
+    std::cout << "    Number of iters performed: " << iters << "(max allowed: " << max_iters_ << ")" << std::endl;
+    std::cout << "    Final cost: " << cost << std::endl;
+  }
+ private:
+  odo_depth* d_ = nullptr;
+  int max_iters_;
+};
+
+// ------------------------------------------------------------------------------------------------
+class KeyFrame {  // ref: include/keyframe.h:17-60, src/keyframe.cpp
+ public:
+  KeyFrame() = delete;
+  KeyFrame(const std::shared_ptr<Mat>& kLeftImg, const std::shared_ptr<Mat>& kRightImg, const std::shared_ptr<Mat>& kLeftDep,
+           const std::shared_ptr<Mat>& kLeftVal, const Affine4f kAbsoPose)
+      : left_img_ptr_(kLeftImg), right_img_ptr_(kRightImg), left_dep_ptr_(kLeftDep), left_val_ptr_(kLeftVal),
+        abso_pose_(kAbsoPose) {}
+  KeyFrame(const KeyFrame&) = delete;
+  KeyFrame& operator=(const KeyFrame&) = delete;
+  const Mat& GetLeftImg() { return *left_img_ptr_; }
+  const Mat& GetRightImg() { return *right_img_ptr_; }
+  const Mat& GetLeftDep() { return *left_dep_ptr_; }
+  const Mat& GetLeftVal() { return *left_val_ptr_; }
+  const Affine4f GetAbsoPose() { return abso_pose_; }
+  Mat& ModifyLeftDep() { return *left_dep_ptr_; }
+  Mat& ModifyLeftVal() { return *left_val_ptr_; }
+  Affine4f& ModifyAbsoPose() { return abso_pose_; }
+ private:
+  std::shared_ptr<Mat> left_img_ptr_, right_img_ptr_, left_dep_ptr_, left_val_ptr_;
+  Affine4f abso_pose_;
+};
+
+}  // namespace odometry
+#endif  // ODOMETRY_SHIM_HPP

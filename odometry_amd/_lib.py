@@ -71,6 +71,9 @@ SIGNATURES = {
     "odo_lm_destroy": (C.c_int, [_vp]),
     "odo_lm_accumulate": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _fp, _dp]),
     "odo_lm_trace": (C.c_int, [_vp, C.POINTER(LmTraceRow), C.c_int, _ip]),
+    "odo_lm_time_eval": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _fp, C.c_int, _fp, _fp, _dp, _ip]),
+    "odo_lm_event_timing": (C.c_int, [_vp, C.c_int]),
+    "odo_lm_event_stats": (C.c_int, [_vp, _dp, C.POINTER(C.c_long), C.POINTER(C.c_long), _dp]),
     "odo_lm_set_mode": (C.c_int, [_vp, C.c_int]),
     "odo_lm_points": (C.c_int, [_vp, _ip, _ip]),
     "odo_lm_launch_stats": (C.c_int, [_vp, _ip, _ip, _dp]),
@@ -81,6 +84,7 @@ SIGNATURES = {
     "odo_depth_compute": (C.c_int, [_vp, _fp, _fp, C.c_int, C.c_int, _u8p, _fp, _fp]),
     "odo_depth_compute_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "odo_depth_disparity": (C.c_int, [_vp, _fp, _fp, C.c_int, C.c_int, _u8p, _fp, _fp]),
+    "odo_depth_time_stages": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _fp, _dp, _ip]),
     "odo_depth_report": (C.c_int, [_vp, _ip, _fp, _ip, _ip, _ip]),
     "odo_depth_destroy": (C.c_int, [_vp]),
     "odo_tracker_default_params": (C.c_int, [C.POINTER(TrackerParams)]),

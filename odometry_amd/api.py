@@ -216,6 +216,13 @@ class LevenbergMarquardtOptimizer:
         return [dict(level=r.level, iter=r.iter, n_res=r.n_res, accepted=r.accepted, stop=r.stop, err=r.err,
                      lambda_after=r.lambda_after, delta=np.array(r.delta[:], np.float32)) for r in rows[:n.value]]
 
+    def time_eval(self, kImagePyr1, kDepthPyr1, kImagePyr2, level, T, reps=50):
+        mean, mn, b, n = C.c_float(0), C.c_float(0), C.c_double(0), C.c_int(0)
+        Tc = _colmajor(T)
+        L.check(self.ctx.lib.odo_lm_time_eval(self.h, kImagePyr1.h, kDepthPyr1.h, kImagePyr2.h, level, _fp(Tc), reps,
+                                              C.byref(mean), C.byref(mn), C.byref(b), C.byref(n)), "odo_lm_time_eval")
+        return dict(mean_us=mean.value, min_us=mn.value, bytes=b.value, n_points=n.value)
+
     def set_mode(self, mode):
         L.check(self.ctx.lib.odo_lm_set_mode(self.h, mode), "odo_lm_set_mode")
 
@@ -285,6 +292,13 @@ class DepthEstimator:
 
     def compute_dev(self, left_dev, right_dev, rows, cols, val_dev, disp_dev, dep_dev):
         return self.ctx.lib.odo_depth_compute_dev(self.h, left_dev, right_dev, rows, cols, val_dev, disp_dev, dep_dev)
+
+    def time_stages(self, left_dev, right_dev, rows, cols, reps=20):
+        us = (C.c_float * 3)()
+        cand, nsel = C.c_double(0), C.c_int(0)
+        L.check(self.ctx.lib.odo_depth_time_stages(self.h, left_dev, right_dev, rows, cols, reps, us, C.byref(cand),
+                                                   C.byref(nsel)), "odo_depth_time_stages")
+        return dict(blur_us=us[0], select_us=us[1], scan_us=us[2], candidates=cand.value, n_selected=nsel.value)
 
     def report(self):
         it, ns, nm, nv = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
@@ -403,6 +417,17 @@ class Tracker:
             L.check(self.lib.odo_dev_download(self._ctx, a.ctypes.data_as(C.c_void_p), ptr, a.nbytes), "download")
             out.append(a)
         return out
+
+    def event_timing(self, on):
+        lm = C.c_void_p(self.lib.odo_tracker_lm(self.h))
+        L.check(self.lib.odo_lm_event_timing(lm, int(on)), "odo_lm_event_timing")
+
+    def event_stats(self):
+        lm = C.c_void_p(self.lib.odo_tracker_lm(self.h))
+        us, b = C.c_double(0), C.c_double(0)
+        n, a = C.c_long(0), C.c_long(0)
+        L.check(self.lib.odo_lm_event_stats(lm, C.byref(us), C.byref(n), C.byref(a), C.byref(b)), "odo_lm_event_stats")
+        return dict(total_us=us.value, launches=n.value, active_launches=a.value, bytes=b.value)
 
     def time_residual(self, level, reps=50):
         mean, mn, b, n = C.c_float(0), C.c_float(0), C.c_double(0), C.c_int(0)

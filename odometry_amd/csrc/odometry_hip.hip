@@ -277,6 +277,11 @@ struct odo_lm {
   int use_list[ODO_MAX_LEVELS];
   unsigned long long kf_img_ver, kf_dep_ver;
   int* d_rowcnt; int* d_rowoff; int* d_npts; int* h_npts; int rows_cap;
+  // optional per-launch HIP-event timing of the evaluation kernels (bench.py roofline leg)
+  int ev_on;
+  std::vector<hipEvent_t>* ev_pool;
+  double ev_total_us, ev_bytes;
+  long ev_launches, ev_active;
   int fused;  // 1 = one launch per evaluation (robust 0/1); 0 = separate residual / update kernels
   int mode;  // 0 auto (list when <= half of the interior has depth), 1 always dense scan, 2 always list
   void (*idle_pump)(void*);  // called while the host waits for the device (the tracker feeds its depth stream here)
@@ -345,6 +350,7 @@ extern "C" int odo_lm_destroy(odo_lm* m) {
     for (void* q : pv) if (q) (void)hipFree(q);
   }
   (void)hipHostFree(m->h_npts);
+  if (m->ev_pool) { for (auto& e : *m->ev_pool) (void)hipEventDestroy(e); delete m->ev_pool; }
   (void)hipHostFree(m->h_out); (void)hipHostFree(m->h_trace); (void)hipHostFree(m->h_cost); (void)hipHostFree(m->h_prog);
   delete m;
   return 0;
@@ -547,8 +553,11 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
         a.level = l; a.first_of_level = (it == 0) ? 1 : 0; a.max_iters = m->max_iters[l];
         a.lambda0 = m->lambda; a.precision = m->precision; a.robust = m->robust; a.huber_delta = m->huber_delta;
         a.trace = m->d_trace; a.cost_stat = m->d_cost; a.host_prog = m->d_prog; a.seq = seq;
+        const bool ev = m->ev_on && m->ev_pool && (size_t)(2 * launches + 1) < m->ev_pool->size();
+        if (ev) (void)hipEventRecord((*m->ev_pool)[2 * launches], s);
         if (m->use_list[l]) hipLaunchKernelGGL(lm_fused_kernel<true>, dim3(nblk), dim3(kLmBlock), 0, s, a);
         else hipLaunchKernelGGL(lm_fused_kernel<false>, dim3(nblk), dim3(kLmBlock), 0, s, a);
+        if (ev) (void)hipEventRecord((*m->ev_pool)[2 * launches + 1], s);
         seq++;
       } else {
         seq++;
@@ -578,7 +587,38 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
     m->iters[l] = (int)m->h_out[18 + l];
     m->last_bytes += bytes_per_level[l] * m->iters[l];
   }
+  if (m->ev_on && m->ev_pool && fused) {
+    for (int i = 0; i < launches && (size_t)(2 * i + 1) < m->ev_pool->size(); i++) {
+      float ms = 0.0f;
+      if (hipEventElapsedTime(&ms, (*m->ev_pool)[2 * i], (*m->ev_pool)[2 * i + 1]) == hipSuccess) m->ev_total_us += ms * 1000.0;
+    }
+    m->ev_launches += launches;
+    m->ev_active += m->last_evals;
+    m->ev_bytes += m->last_bytes;
+  }
   if (m->h_out[16] != 0.0f) return fail("Optimize failed! ");  // ref: src/lm_optimizer.cpp:60-61
+  return 0;
+}
+
+// Per-launch HIP-event timing of the evaluation kernel (fused pipeline) on the stream it is launched on.
+// on = 1 starts (and clears) the accumulation, on = 0 stops it; odo_lm_event_stats reads the totals.
+extern "C" int odo_lm_event_timing(odo_lm* m, int on) {
+  if (!m) return fail("NULL lm");
+  if (on && !m->ev_pool) {
+    m->ev_pool = new std::vector<hipEvent_t>(2 * 128);
+    for (auto& e : *m->ev_pool) HIP_OK(hipEventCreate(&e));
+  }
+  if (on) { m->ev_total_us = 0.0; m->ev_bytes = 0.0; m->ev_launches = 0; m->ev_active = 0; }
+  m->ev_on = on ? 1 : 0;
+  return 0;
+}
+extern "C" int odo_lm_event_stats(const odo_lm* m, double* total_us, long* launches, long* active_launches,
+                                  double* algorithmic_bytes) {
+  if (!m) return fail("NULL lm");
+  if (total_us) *total_us = m->ev_total_us;
+  if (launches) *launches = m->ev_launches;
+  if (active_launches) *active_launches = m->ev_active;
+  if (algorithmic_bytes) *algorithmic_bytes = m->ev_bytes;
   return 0;
 }
 

@@ -305,25 +305,24 @@ extern "C" int odo_tracker_outputs(const odo_tracker* t, const uint8_t** val, co
 extern "C" odo_lm* odo_tracker_lm(odo_tracker* t) { return t ? t->lm : nullptr; }
 extern "C" odo_ctx* odo_tracker_ctx(odo_tracker* t) { return t ? t->ctx_a : nullptr; }
 
-// bench.py roofline leg: `reps` launches of the dominant kernel (the residual / normal-equation pass) on `level` of the
-// tracker's current keyframe / frame pyramids at the last estimated pose, each bracketed by HIP events on the
-// stream it is launched on. Returns mean / min launch duration and the algorithmic bytes of one launch
-// (12 B per interior pixel + 29 fp64 partials per block written).
-extern "C" int odo_tracker_time_residual(odo_tracker* t, int level, int reps, float* mean_us, float* min_us,
-                                         double* algorithmic_bytes, int* n_points) {
-  if (!t || reps < 1 || level < 0 || level >= t->p.levels) return fail("odo_tracker_time_residual: bad arg");
-  odo_lm* m = t->lm;
-  hipStream_t s = t->ctx_a->stream;
-  HIP_OK(hipSetDevice(t->ctx_a->device));
+// bench.py roofline leg: `reps` launches of the evaluation kernel (residual / normal-equation pass, without the LM
+// update) on `level` at pose T, each bracketed by HIP events on the stream it is launched on. Returns mean / min
+// launch duration, the algorithmic bytes of one launch and the residual count.
+static int lm_time_eval(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img, int level,
+                        const float* T_colmajor, int reps, float* mean_us, float* min_us, double* algorithmic_bytes,
+                        int* n_points) {
+  hipStream_t s = m->ctx->stream;
+  HIP_OK(hipSetDevice(m->ctx->device));
   LevelView v;
-  v.I1 = t->kf_img->dev + t->kf_img->off[level];
-  v.I2 = t->cur_img->dev + t->cur_img->off[level];
-  v.D1 = t->kf_dep->dev + t->kf_dep->off[level];
-  v.rows = t->kf_img->r[level]; v.cols = t->kf_img->c[level];
+  v.I1 = kf_img->dev + kf_img->off[level];
+  v.I2 = cur_img->dev + cur_img->off[level];
+  v.D1 = kf_dep->dev + kf_dep->off[level];
+  v.rows = kf_img->r[level]; v.cols = kf_img->c[level];
   const LevelK k = make_level_k(m->K.f0, m->K.cx0, m->K.cy0, level);
-  if (lm_prepare_keyframe(m, t->kf_img, t->kf_dep)) return -1;
+  if (lm_prepare_keyframe(m, kf_img, kf_dep)) return -1;
   const int nblk = lm_grid_for(m, level, v.rows, v.cols);
-  HIP_OK(hipMemcpyAsync(m->d_init, t->pose_to_kf, sizeof(float) * 16, hipMemcpyHostToDevice, s));
+  if (m->robust == 2 && lm_ensure_res(m, (size_t)v.rows * v.cols)) return -1;
+  HIP_OK(hipMemcpyAsync(m->d_init, T_colmajor, sizeof(float) * 16, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(lm_force_state_kernel, dim3(1), dim3(64), 0, s, m->d_state, m->d_init, level);
   std::vector<hipEvent_t> ev(2 * (size_t)reps);
   for (auto& e : ev) HIP_OK(hipEventCreate(&e));
@@ -351,5 +350,74 @@ extern "C" int odo_tracker_time_residual(odo_tracker* t, int level, int reps, fl
   if (min_us) *min_us = (float)(mn * 1000.0);
   if (algorithmic_bytes) *algorithmic_bytes = lm_level_bytes(m, level, v.rows, v.cols, nblk);
   if (n_points) *n_points = (int)acc[28];
+  return 0;
+}
+
+extern "C" int odo_lm_time_eval(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img, int level,
+                                const float T_colmajor[16], int reps, float* mean_us, float* min_us,
+                                double* algorithmic_bytes, int* n_points) {
+  if (!T_colmajor || reps < 1) return fail("odo_lm_time_eval: bad arg");
+  if (lm_check_pyrs(m, kf_img, kf_dep, cur_img)) return -1;
+  if (level < 0 || level >= m->n_levels) return fail("odo_lm_time_eval: bad level");
+  return lm_time_eval(m, kf_img, kf_dep, cur_img, level, T_colmajor, reps, mean_us, min_us, algorithmic_bytes, n_points);
+}
+
+extern "C" int odo_tracker_time_residual(odo_tracker* t, int level, int reps, float* mean_us, float* min_us,
+                                         double* algorithmic_bytes, int* n_points) {
+  if (!t || reps < 1 || level < 0 || level >= t->p.levels) return fail("odo_tracker_time_residual: bad arg");
+  return lm_time_eval(t->lm, t->kf_img, t->kf_dep, t->cur_img, level, t->pose_to_kf, reps, mean_us, min_us,
+                      algorithmic_bytes, n_points);
+}
+
+// Config 5 leg of bench.py: event-timed stages of the disparity front end on device-resident images:
+// us[0] blur (both images), us[1] point selection, us[2] epipolar SSD scan; candidates = SSD evaluations of one scan.
+extern "C" int odo_depth_time_stages(odo_depth* d, const float* left_dev, const float* right_dev, int rows, int cols,
+                                     int reps, float us[3], double* candidates, int* n_selected) {
+  if (!d || !left_dev || !right_dev || !us || reps < 1) return fail("odo_depth_time_stages: bad arg");
+  if (depth_check_size(d, rows, cols)) return -1;
+  HIP_OK(hipSetDevice(d->ctx->device));
+  if (depth_ensure(d, rows, cols)) return -1;
+  hipStream_t s = d->ctx->stream;
+  const size_t n = (size_t)rows * cols;
+  hipEvent_t e[4];
+  for (auto& x : e) HIP_OK(hipEventCreate(&x));
+  double tot[3] = {0, 0, 0};
+  for (int r = -2; r < reps; r++) {  // two warm-up rounds
+    HIP_OK(hipMemsetAsync(d->d_val, 0, n, s));
+    HIP_OK(hipMemsetAsync(d->d_disp, 0, sizeof(float) * n, s));
+    HIP_OK(hipMemsetAsync(d->d_dep, 0, sizeof(float) * n, s));
+    HIP_OK(hipEventRecord(e[0], s));
+    hipLaunchKernelGGL(blur3x3_kernel, grid2d(cols, rows, 2), dim3(256), 0, s, left_dev, d->d_bl, right_dev, d->d_br, rows, cols);
+    HIP_OK(hipEventRecord(e[1], s));
+    hipLaunchKernelGGL(depth_select_kernel, dim3(kSelBlocks), dim3(kSelThreads), 0, s, d->d_bl, rows, cols, d->boundary,
+                       d->grad_th, d->d_val, d->d_pts, d->d_cnt);
+    HIP_OK(hipEventRecord(e[2], s));
+    hipLaunchKernelGGL(depth_disparity_kernel, dim3(kSelBlocks * kSelCap / 4), dim3(256), 0, s, d->d_bl, d->d_br, rows, cols,
+                       d->boundary, d->max_disparity, d->ssd_th, d->K.f0, d->baseline, d->d_pts, d->d_cnt, d->d_disp, d->d_dep,
+                       d->d_d0, d->d_matched);
+    HIP_OK(hipEventRecord(e[3], s));
+    HIP_OK(hipStreamSynchronize(s));
+    if (r >= 0)
+      for (int k = 0; k < 3; k++) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, e[k], e[k + 1])); tot[k] += ms * 1000.0; }
+  }
+  for (auto& x : e) (void)hipEventDestroy(x);
+  for (int k = 0; k < 3; k++) us[k] = (float)(tot[k] / reps);
+  // count the candidates of one scan from the point list
+  std::vector<uint32_t> pts(kSelBlocks * kSelCap);
+  std::vector<int> cnt(kSelBlocks);
+  HIP_OK(hipMemcpy(pts.data(), d->d_pts, sizeof(uint32_t) * pts.size(), hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(cnt.data(), d->d_cnt, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost));
+  double cand = 0.0;
+  int nsel = 0;
+  for (int b = 0; b < kSelBlocks; b++)
+    for (int k = 0; k < cnt[b]; k++) {
+      const int x = (int)(pts[b * kSelCap + k] & 0xffffu);
+      int lo = d->boundary;
+      if (d->max_disparity > 0 && x - d->max_disparity > lo) lo = x - d->max_disparity;
+      cand += (x > lo) ? (x - lo) : 0;
+      nsel++;
+    }
+  if (candidates) *candidates = cand;
+  if (n_selected) *n_selected = nsel;
   return 0;
 }

@@ -67,11 +67,16 @@ ODO_HD bool depth_valid(float d) { return !(fabsf(d - 0.0f) < 0.01f); }  // ref:
 ODO_HD PointK make_point(int x, int y, float inv_depth, float i1, const LevelK& k) {
   PointK p;
   const float z = 1.0f / inv_depth;                                   // :198
-  p.X = (float)((double)(z * ((float)x - k.cx)) / k.fl);              // h:35
-  p.Y = (float)((double)(z * ((float)y - k.cy)) / k.fl);              // h:36
+  // The reference evaluates these three quotients in double (std::pow returns double) and rounds to float.
+  // Both operands are exactly representable in fp32 (fl = f0 / 2^level), and a correctly rounded fp64 quotient
+  // of two fp32 values rounds to the correctly rounded fp32 quotient (53 >= 2*24 + 2), so the IEEE fp32 divide
+  // below is bit-identical and four times cheaper on the device.
+  const float flf = (float)k.fl;
+  p.X = (z * ((float)x - k.cx)) / flf;                                // h:35
+  p.Y = (z * ((float)y - k.cy)) / flf;                                // h:36
   p.Z = z;
   p.i1 = i1;
-  const float fx_z = (float)(k.fl / (double)p.Z);                     // :223
+  const float fx_z = flf / p.Z;                                       // :223
   const float xy = p.X * p.Y, xx = p.X * p.X, yy = p.Y * p.Y, zz = p.Z * p.Z;
   p.fx_z = fx_z;
   p.jw02 = (-fx_z * p.X) / p.Z;                                       // :232

@@ -193,6 +193,10 @@ extern "C" int odo_pyramid_create(odo_ctx* ctx, const float* img, int rows, int 
   hipError_t e = hipMemcpy2DAsync(p->staging, sizeof(float) * (size_t)cols, img, stride_bytes, sizeof(float) * (size_t)cols,
                                   rows, hipMemcpyHostToDevice, ctx->stream);
   if (e != hipSuccess) { odo_pyramid_destroy(p); return fail("odo_pyramid_create: upload failed: %s", hipGetErrorString(e)); }
+  // The caller may release `img` as soon as this returns (the reference's constructor copies synchronously):
+  // wait for the upload before handing control back. The pyramid kernels themselves stay asynchronous.
+  e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) { odo_pyramid_destroy(p); return fail("odo_pyramid_create: upload failed: %s", hipGetErrorString(e)); }
   if (pyr_build(p, p->staging, smooth)) { odo_pyramid_destroy(p); return -1; }
   *out = p;
   return 0;

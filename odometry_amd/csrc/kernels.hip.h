@@ -23,14 +23,22 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // ref: src/image_processing_global.cpp:30, src/depth_estimate.cpp:256-257). The row pass is recomputed
 // for the three rows a pixel needs — identical fp32 values to a materialised intermediate.
 // grid.z selects one of up to two images (left/right blurred in one launch).
+// zero_u8 / zero_f0 / zero_f1 (optional): images of the same size cleared by the z == 0 slice — the depth estimator's
+// zero-filled outputs without three extra fill launches.
 __global__ void __launch_bounds__(256) blur3x3_kernel(const float* __restrict__ src0, float* __restrict__ dst0,
                                                        const float* __restrict__ src1, float* __restrict__ dst1,
-                                                       int rows, int cols) {
+                                                       int rows, int cols, uint8_t* __restrict__ zero_u8 = nullptr,
+                                                       float* __restrict__ zero_f0 = nullptr,
+                                                       float* __restrict__ zero_f1 = nullptr) {
   const float* __restrict__ src = blockIdx.z ? src1 : src0;
   float* __restrict__ dst = blockIdx.z ? dst1 : dst0;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= cols || y >= rows) return;
+  if (blockIdx.z == 0 && zero_u8) {
+    const size_t o = (size_t)y * cols + x;
+    zero_u8[o] = 0; zero_f0[o] = 0.0f; zero_f1[o] = 0.0f;
+  }
   const int xp = reflect101(x - 1, cols), xn = reflect101(x + 1, cols);
   const int yy[3] = {reflect101(y - 1, rows), y, reflect101(y + 1, rows)};
   float t[3];
@@ -69,6 +77,174 @@ __global__ void __launch_bounds__(256) decimate_odd_kernel(const float* __restri
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= dc || y >= dr) return;
   dst[(size_t)y * dc + x] = src[(size_t)(2 * y + 1) * cols + (2 * x + 1)];
+}
+
+// Whole image pyramid in ONE launch (levels <= 4): a block owns the 32x32 / 16x16 / 8x8 / 4x4 region of levels
+// 0 / 1 / 2 / 3 under one 32x32 tile of the input and recomputes, in LDS, the halo of the intermediate levels it needs
+// (53x53 input -> 25x25 of L1 -> 11x11 of L2 -> 4x4 of L3). Every value is produced by exactly the arithmetic of
+// blur3x3_kernel / pyrdown_kernel (same taps, same association order, reflect-101 applied at the level being read), so
+// the result is bit-identical to the level-by-level kernels; it replaces four dependent launches by one.
+struct PyrOut {
+  float* lvl[4];
+  int rows[4], cols[4];
+  int n_levels;
+  int smooth;
+};
+
+constexpr int kPT = 32;                    // input tile
+constexpr int kPIn = 53, kPInS = 54;       // input halo tile (+ padded stride)
+constexpr int kPL1 = 25, kPL2 = 11;
+
+__device__ __forceinline__ float pd_h(const float* row, int x0, int x1, int x2, int x3, int x4) {
+  return ((row[x2] * 6.0f + (row[x1] + row[x3]) * 4.0f) + row[x0]) + row[x4];
+}
+__device__ __forceinline__ float pd_v(float r0, float r1, float r2, float r3, float r4) {
+  return (((r2 * 6.0f + (r1 + r3) * 4.0f) + r0) + r4) * (1.0f / 256.0f);
+}
+
+__global__ void __launch_bounds__(256) image_pyramid_fused_kernel(const float* __restrict__ src, PyrOut o) {
+  __shared__ float in_t[kPIn * kPInS];
+  __shared__ float h_t[kPIn * kPL1];   // horizontal pass (reused per level)
+  __shared__ float l1_t[kPL1 * kPL1];
+  __shared__ float l2_t[kPL2 * kPL2];
+  const int t = threadIdx.x;
+  const int ty = blockIdx.y, tx = blockIdx.x;
+  const int R0 = o.rows[0], C0 = o.cols[0];
+  const int iy0 = kPT * ty - 14, ix0 = kPT * tx - 14;  // input halo origin (level-0 coordinates, may be negative)
+  for (int e = t; e < kPIn * kPIn; e += 256) {
+    const int i = e / kPIn, j = e % kPIn;
+    in_t[i * kPInS + j] = src[(size_t)reflect101(iy0 + i, R0) * C0 + reflect101(ix0 + j, C0)];
+  }
+  __syncthreads();
+  // ---- level 0: blur (or copy) of the owned 32x32 ----
+  for (int e = t; e < kPT * kPT; e += 256) {
+    const int y = kPT * ty + e / kPT, x = kPT * tx + e % kPT;
+    if (y < R0 && x < C0) {
+      const int i = y - iy0, j = x - ix0;
+      float v;
+      if (o.smooth) {
+        float r[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const float* row = &in_t[(i - 1 + k) * kPInS];
+          r[k] = row[j] * 0.5f + (row[j - 1] + row[j + 1]) * 0.25f;
+        }
+        v = r[1] * 0.5f + (r[0] + r[2]) * 0.25f;
+      } else {
+        v = in_t[i * kPInS + j];
+      }
+      o.lvl[0][(size_t)y * C0 + x] = v;
+    }
+  }
+  if (o.n_levels < 2) return;
+  // ---- level 1 halo tile: rows/cols [16t-6, 16t+18] clipped to the level ----
+  const int R1 = o.rows[1], C1 = o.cols[1];
+  const int y1lo = max(16 * ty - 6, 0), x1lo = max(16 * tx - 6, 0);
+  const int y1hi = min(16 * ty + 18, R1 - 1), x1hi = min(16 * tx + 18, C1 - 1);
+  const int n1y = y1hi - y1lo + 1, n1x = x1hi - x1lo + 1;
+  // horizontal pass over every input row of the halo, for the needed L1 columns
+  for (int e = t; e < kPIn * kPL1; e += 256) {
+    const int i = e / kPL1, jx = e % kPL1;
+    if (jx < n1x) {
+      const int x1 = x1lo + jx;
+      const float* row = &in_t[i * kPInS];
+      int xs[5];
+#pragma unroll
+      for (int k = 0; k < 5; k++) xs[k] = reflect101(2 * x1 - 2 + k, C0) - ix0;
+      h_t[i * kPL1 + jx] = pd_h(row, xs[0], xs[1], xs[2], xs[3], xs[4]);
+    }
+  }
+  __syncthreads();
+  for (int e = t; e < kPL1 * kPL1; e += 256) {
+    const int iy = e / kPL1, jx = e % kPL1;
+    if (iy < n1y && jx < n1x) {
+      const int y1 = y1lo + iy;
+      float r[5];
+#pragma unroll
+      for (int k = 0; k < 5; k++) r[k] = h_t[(reflect101(2 * y1 - 2 + k, R0) - iy0) * kPL1 + jx];
+      const float v = pd_v(r[0], r[1], r[2], r[3], r[4]);
+      l1_t[iy * kPL1 + jx] = v;
+      const int x1 = x1lo + jx;
+      if (y1 >= 16 * ty && y1 < 16 * ty + 16 && x1 >= 16 * tx && x1 < 16 * tx + 16) o.lvl[1][(size_t)y1 * C1 + x1] = v;
+    }
+  }
+  if (o.n_levels < 3) return;
+  __syncthreads();
+  // ---- level 2 halo tile: [8t-2, 8t+8] clipped ----
+  const int R2 = o.rows[2], C2 = o.cols[2];
+  const int y2lo = max(8 * ty - 2, 0), x2lo = max(8 * tx - 2, 0);
+  const int y2hi = min(8 * ty + 8, R2 - 1), x2hi = min(8 * tx + 8, C2 - 1);
+  const int n2y = y2hi - y2lo + 1, n2x = x2hi - x2lo + 1;
+  for (int e = t; e < kPL1 * kPL2; e += 256) {  // horizontal pass over L1 halo rows
+    const int i = e / kPL2, jx = e % kPL2;
+    if (i < n1y && jx < n2x) {
+      const int x2 = x2lo + jx;
+      const float* row = &l1_t[i * kPL1];
+      int xs[5];
+#pragma unroll
+      for (int k = 0; k < 5; k++) xs[k] = reflect101(2 * x2 - 2 + k, C1) - x1lo;
+      h_t[i * kPL2 + jx] = pd_h(row, xs[0], xs[1], xs[2], xs[3], xs[4]);
+    }
+  }
+  __syncthreads();
+  for (int e = t; e < kPL2 * kPL2; e += 256) {
+    const int iy = e / kPL2, jx = e % kPL2;
+    if (iy < n2y && jx < n2x) {
+      const int y2 = y2lo + iy;
+      float r[5];
+#pragma unroll
+      for (int k = 0; k < 5; k++) r[k] = h_t[(reflect101(2 * y2 - 2 + k, R1) - y1lo) * kPL2 + jx];
+      const float v = pd_v(r[0], r[1], r[2], r[3], r[4]);
+      l2_t[iy * kPL2 + jx] = v;
+      const int x2 = x2lo + jx;
+      if (y2 >= 8 * ty && y2 < 8 * ty + 8 && x2 >= 8 * tx && x2 < 8 * tx + 8) o.lvl[2][(size_t)y2 * C2 + x2] = v;
+    }
+  }
+  if (o.n_levels < 4) return;
+  __syncthreads();
+  // ---- level 3: the owned 4x4 ----
+  const int R3 = o.rows[3], C3 = o.cols[3];
+  for (int e = t; e < kPL2 * 4; e += 256) {  // horizontal pass over L2 halo rows for the 4 owned columns
+    const int i = e / 4, jx = e % 4;
+    const int x3 = 4 * tx + jx;
+    if (i < n2y && x3 < C3) {
+      const float* row = &l2_t[i * kPL2];
+      int xs[5];
+#pragma unroll
+      for (int k = 0; k < 5; k++) xs[k] = reflect101(2 * x3 - 2 + k, C2) - x2lo;
+      h_t[i * 4 + jx] = pd_h(row, xs[0], xs[1], xs[2], xs[3], xs[4]);
+    }
+  }
+  __syncthreads();
+  if (t < 16) {
+    const int y3 = 4 * ty + t / 4, x3 = 4 * tx + t % 4;
+    if (y3 < R3 && x3 < C3) {
+      float r[5];
+#pragma unroll
+      for (int k = 0; k < 5; k++) r[k] = h_t[(reflect101(2 * y3 - 2 + k, R2) - y2lo) * 4 + (t % 4)];
+      o.lvl[3][(size_t)y3 * C3 + x3] = pd_v(r[0], r[1], r[2], r[3], r[4]);
+    }
+  }
+}
+
+// Whole depth pyramid in one launch: L_k(Y,X) = L_0(2^k Y + 2^k - 1, 2^k X + 2^k - 1), the composition of the
+// reference's odd decimations (ref: src/image_processing_global.cpp:85-89,99-103). Thread <-> level-0 pixel.
+__global__ void __launch_bounds__(256) depth_pyramid_fused_kernel(const float* __restrict__ src, PyrOut o) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= o.cols[0] || y >= o.rows[0]) return;
+  const float v = src[(size_t)y * o.cols[0] + x];
+  o.lvl[0][(size_t)y * o.cols[0] + x] = v;
+#pragma unroll
+  for (int l = 1; l < 4; l++) {
+    if (l < o.n_levels) {
+      const int m = (1 << l) - 1;
+      if (((y + 1) & m) == 0 && ((x + 1) & m) == 0) {
+        const int Y = y >> l, X = x >> l;
+        if (Y < o.rows[l] && X < o.cols[l]) o.lvl[l][(size_t)Y * o.cols[l] + X] = v;
+      }
+    }
+  }
 }
 
 // =============================================================================================

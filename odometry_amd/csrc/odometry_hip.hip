@@ -2,6 +2,7 @@
 // Host side only sequences launches on the context's HIP stream; all arithmetic of the hot path runs on
 // the device. There is no CPU fallback: every entry point fails with -1 if HIP does.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -132,9 +133,26 @@ static int pyr_build(odo_pyr* p, const float* img_dev, int smooth) {
   hipStream_t s = p->ctx->stream;
   p->version = ++g_pyr_version;
   const int rows = p->rows, cols = p->cols;
+  if (p->kind == ODO_PYR_DEPTH && smooth)
+    return fail("depth pyramid smoothing (cv::medianBlur) is not implemented: no reference caller uses it");
+  static const bool unfused = getenv("ODO_PYR_UNFUSED") != nullptr;
+  if (p->levels <= 4 && !unfused) {  // whole pyramid in one launch
+    PyrOut o;
+    memset(&o, 0, sizeof(o));
+    o.n_levels = p->levels; o.smooth = smooth ? 1 : 0;
+    for (int l = 0; l < p->levels; l++) { o.lvl[l] = p->dev + p->off[l]; o.rows[l] = p->r[l]; o.cols[l] = p->c[l]; }
+    if (p->kind == ODO_PYR_IMAGE)
+      hipLaunchKernelGGL(image_pyramid_fused_kernel, dim3((cols + kPT - 1) / kPT, (rows + kPT - 1) / kPT), dim3(256), 0, s,
+                         img_dev, o);
+    else
+      hipLaunchKernelGGL(depth_pyramid_fused_kernel, grid2d(cols, rows), dim3(256), 0, s, img_dev, o);
+    HIP_OK(hipGetLastError());
+    return 0;
+  }
   if (p->kind == ODO_PYR_IMAGE) {
     if (smooth) {
-      hipLaunchKernelGGL(blur3x3_kernel, grid2d(cols, rows), dim3(256), 0, s, img_dev, p->dev, img_dev, p->dev, rows, cols);
+      hipLaunchKernelGGL(blur3x3_kernel, grid2d(cols, rows), dim3(256), 0, s, img_dev, p->dev, img_dev, p->dev, rows, cols,
+                         (uint8_t*)nullptr, (float*)nullptr, (float*)nullptr);
     } else {
       HIP_OK(hipMemcpyAsync(p->dev, img_dev, sizeof(float) * (size_t)rows * cols, hipMemcpyDeviceToDevice, s));
     }
@@ -145,7 +163,6 @@ static int pyr_build(odo_pyr* p, const float* img_dev, int smooth) {
       prev = p->dev + p->off[l];
     }
   } else {
-    if (smooth) return fail("depth pyramid smoothing (cv::medianBlur) is not implemented: no reference caller uses it");
     HIP_OK(hipMemcpyAsync(p->dev, img_dev, sizeof(float) * (size_t)rows * cols, hipMemcpyDeviceToDevice, s));
     for (int l = 1; l < p->levels; l++)
       hipLaunchKernelGGL(decimate_odd_kernel, grid2d(p->c[l], p->r[l]), dim3(256), 0, s, p->dev + p->off[l - 1],
@@ -286,6 +303,7 @@ struct odo_lm {
   std::vector<hipEvent_t>* ev_pool;
   double ev_total_us, ev_bytes;
   long ev_launches, ev_active;
+  int trace_stale;
   int fused;  // 1 = one launch per evaluation (robust 0/1); 0 = separate residual / update kernels
   int mode;  // 0 auto (list when <= half of the interior has depth), 1 always dense scan, 2 always list
   void (*idle_pump)(void*);  // called while the host waits for the device (the tracker feeds its depth stream here)
@@ -320,13 +338,13 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
   HIP_OK(hipMalloc((void**)&m->d_state, sizeof(LmState) * 2));                          // double-buffered (fused pipeline)
   HIP_OK(hipMalloc((void**)&m->d_partials, sizeof(double) * 2 * kLmMaxBlocks * ODO_NACC)); // idem
   HIP_OK(hipMalloc((void**)&m->d_init, sizeof(float) * 16));
-  HIP_OK(hipMalloc((void**)&m->d_out, sizeof(float) * 26));
+  HIP_OK(hipMalloc((void**)&m->d_out, sizeof(float) * 48));  // 26 result floats + 16 cost statistics: one read-back
   HIP_OK(hipMalloc((void**)&m->d_trace, sizeof(LmTraceRow) * kTraceCap));
-  HIP_OK(hipMalloc((void**)&m->d_cost, sizeof(float) * 16));
+  m->d_cost = m->d_out + 26;
   HIP_OK(hipMalloc((void**)&m->d_scale, sizeof(float)));
-  HIP_OK(hipHostMalloc((void**)&m->h_out, sizeof(float) * 26, hipHostMallocDefault));
+  HIP_OK(hipHostMalloc((void**)&m->h_out, sizeof(float) * 48, hipHostMallocDefault));
   HIP_OK(hipHostMalloc((void**)&m->h_trace, sizeof(LmTraceRow) * kTraceCap, hipHostMallocDefault));
-  HIP_OK(hipHostMalloc((void**)&m->h_cost, sizeof(float) * 16, hipHostMallocDefault));
+  m->h_cost = m->h_out + 26;
   HIP_OK(hipHostMalloc((void**)&m->h_prog, sizeof(int) * 16, hipHostMallocMapped | hipHostMallocCoherent));
   HIP_OK(hipHostGetDevicePointer((void**)&m->d_prog, m->h_prog, 0));
   memset(m->h_prog, 0, sizeof(int) * 16);
@@ -338,7 +356,7 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
   m->run_ahead = getenv("ODO_RUN_AHEAD") ? atoi(getenv("ODO_RUN_AHEAD")) : 2;
   HIP_OK(hipMemsetAsync(m->d_trace, 0, sizeof(LmTraceRow) * kTraceCap, ctx->stream));
   memset(m->h_trace, 0, sizeof(LmTraceRow) * kTraceCap);
-  memset(m->h_cost, 0, sizeof(float) * 16);
+  memset(m->h_out, 0, sizeof(float) * 48);
   *out = m;
   return 0;
 }
@@ -346,7 +364,7 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
 extern "C" int odo_lm_destroy(odo_lm* m) {
   if (!m) return 0;
   (void)hipStreamSynchronize(m->ctx->stream);
-  void* dv[] = {m->d_state, m->d_partials, m->d_init, m->d_out, m->d_trace, m->d_cost, m->d_scale, m->d_res,
+  void* dv[] = {m->d_state, m->d_partials, m->d_init, m->d_out, m->d_trace, m->d_scale, m->d_res,
                 m->d_rowcnt, m->d_rowoff, m->d_npts};
   for (void* q : dv) if (q) (void)hipFree(q);
   for (int l = 0; l < ODO_MAX_LEVELS; l++) {
@@ -355,7 +373,7 @@ extern "C" int odo_lm_destroy(odo_lm* m) {
   }
   (void)hipHostFree(m->h_npts);
   if (m->ev_pool) { for (auto& e : *m->ev_pool) (void)hipEventDestroy(e); delete m->ev_pool; }
-  (void)hipHostFree(m->h_out); (void)hipHostFree(m->h_trace); (void)hipHostFree(m->h_cost); (void)hipHostFree(m->h_prog);
+  (void)hipHostFree(m->h_out); (void)hipHostFree(m->h_trace); (void)hipHostFree(m->h_prog);
   delete m;
   return 0;
 }
@@ -473,8 +491,20 @@ static inline int lm_grid_for(const odo_lm* m, int level, int rows, int cols) {
 }
 
 // One evaluation of the hot loop at the pose held in the device state.
-static void lm_launch_eval(odo_lm* m, const LevelView& v, const LevelK& k, int level, int nblk) {
+static void lm_launch_eval(odo_lm* m, const LevelView& v, const LevelK& k, int level, int nblk, hipEvent_t e0 = nullptr,
+                           hipEvent_t e1 = nullptr) {
   hipStream_t s = m->ctx->stream;
+  if (e0 && e1 && m->robust != 2) {  // timing legs: dispatch-bound start / stop events
+    if (m->use_list[level])
+      hipExtLaunchKernelGGL(lm_residual_list_kernel, dim3(nblk), dim3(kLmBlock), 0, s, e0, e1, 0, m->pl[level], m->npts[level],
+                            v.I2, v.rows, v.cols, k, (const LmState*)m->d_state, level, m->robust, m->huber_delta,
+                            (const float*)m->d_scale, m->d_partials);
+    else
+      hipExtLaunchKernelGGL(lm_residual_dense_kernel, dim3(nblk), dim3(kLmBlock), 0, s, e0, e1, 0, v, k,
+                            (const LmState*)m->d_state, level, m->robust, m->huber_delta, (const float*)m->d_scale,
+                            m->d_partials);
+    return;
+  }
   if (m->use_list[level]) {
     const int n = m->npts[level];
     if (m->robust == 2) {
@@ -558,10 +588,16 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
         a.lambda0 = m->lambda; a.precision = m->precision; a.robust = m->robust; a.huber_delta = m->huber_delta;
         a.trace = m->d_trace; a.cost_stat = m->d_cost; a.host_prog = m->d_prog; a.seq = seq;
         const bool ev = m->ev_on && m->ev_pool && (size_t)(2 * launches + 1) < m->ev_pool->size();
-        if (ev) (void)hipEventRecord((*m->ev_pool)[2 * launches], s);
-        if (m->use_list[l]) hipLaunchKernelGGL(lm_fused_kernel<true>, dim3(nblk), dim3(kLmBlock), 0, s, a);
-        else hipLaunchKernelGGL(lm_fused_kernel<false>, dim3(nblk), dim3(kLmBlock), 0, s, a);
-        if (ev) (void)hipEventRecord((*m->ev_pool)[2 * launches + 1], s);
+        if (ev) {
+          // timing pass: start / stop events bound to the dispatch itself (the kernel's own begin / end timestamps)
+          hipEvent_t e0 = (*m->ev_pool)[2 * launches], e1 = (*m->ev_pool)[2 * launches + 1];
+          if (m->use_list[l]) hipExtLaunchKernelGGL(lm_fused_kernel<true>, dim3(nblk), dim3(kLmBlock), 0, s, e0, e1, 0, a);
+          else hipExtLaunchKernelGGL(lm_fused_kernel<false>, dim3(nblk), dim3(kLmBlock), 0, s, e0, e1, 0, a);
+        } else if (m->use_list[l]) {
+          hipLaunchKernelGGL(lm_fused_kernel<true>, dim3(nblk), dim3(kLmBlock), 0, s, a);
+        } else {
+          hipLaunchKernelGGL(lm_fused_kernel<false>, dim3(nblk), dim3(kLmBlock), 0, s, a);
+        }
         seq++;
       } else {
         seq++;
@@ -579,10 +615,9 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
   else
     hipLaunchKernelGGL(lm_finalize_kernel, dim3(1), dim3(64), 0, s, m->d_state, m->d_out);
   HIP_OK(hipGetLastError());
-  HIP_OK(hipMemcpyAsync(m->h_out, m->d_out, sizeof(float) * 26, hipMemcpyDeviceToHost, s));
-  HIP_OK(hipMemcpyAsync(m->h_trace, m->d_trace, sizeof(LmTraceRow) * kTraceCap, hipMemcpyDeviceToHost, s));
-  HIP_OK(hipMemcpyAsync(m->h_cost, m->d_cost, sizeof(float) * 16, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipMemcpyAsync(m->h_out, m->d_out, sizeof(float) * 42, hipMemcpyDeviceToHost, s));  // pose, status, counters, costs
   HIP_OK(hipStreamSynchronize(s));
+  m->trace_stale = 1;  // the per-evaluation trace stays on the device until odo_lm_trace() asks for it
   memcpy(out_colmajor, m->h_out, sizeof(float) * 16);
   m->last_evals = (int)m->h_out[17];
   m->last_launches = launches;
@@ -650,8 +685,14 @@ extern "C" int odo_lm_report(const odo_lm* m, int iters[4], float cost[4][2]) {
   return 0;
 }
 
-extern "C" int odo_lm_trace(const odo_lm* m, odo_lm_trace_row* rows, int cap, int* n_rows) {
+extern "C" int odo_lm_trace(const odo_lm* mc, odo_lm_trace_row* rows, int cap, int* n_rows) {
+  odo_lm* m = const_cast<odo_lm*>(mc);
   if (!m || !n_rows) return fail("NULL arg");
+  if (m->trace_stale) {
+    HIP_OK(hipMemcpyAsync(m->h_trace, m->d_trace, sizeof(LmTraceRow) * kTraceCap, hipMemcpyDeviceToHost, m->ctx->stream));
+    HIP_OK(hipStreamSynchronize(m->ctx->stream));
+    m->trace_stale = 0;
+  }
   int n = m->last_evals < kTraceCap ? m->last_evals : kTraceCap;
   if (n > cap) n = cap;
   static_assert(sizeof(odo_lm_trace_row) == sizeof(LmTraceRow), "trace row layout");
@@ -903,10 +944,10 @@ static int depth_job_begin(odo_depth* d, DepthJob* j, const float* left, const f
   j->k = 0; j->n_launches = 0; j->poll = d->poll != 0; j->tail_done = false; j->waiting = false;
   // progress words may only be reset while this stream is idle: every ComputeDepth ends with depth_finish()'s sync
   d->h_prog[0] = 0; d->h_prog[1] = 0;
-  HIP_OK(hipMemsetAsync(val, 0, n, s));
-  HIP_OK(hipMemsetAsync(disp, 0, sizeof(float) * n, s));  // zero-filled outputs
-  HIP_OK(hipMemsetAsync(dep, 0, sizeof(float) * n, s));
-  hipLaunchKernelGGL(blur3x3_kernel, grid2d(cols, rows, 2), dim3(256), 0, s, left, d->d_bl, right, d->d_br, rows, cols);
+  (void)n;
+  // blur both images; the same launch zero-fills val / disp / dep
+  hipLaunchKernelGGL(blur3x3_kernel, grid2d(cols, rows, 2), dim3(256), 0, s, left, d->d_bl, right, d->d_br, rows, cols, val,
+                     disp, dep);
   hipLaunchKernelGGL(depth_select_kernel, dim3(kSelBlocks), dim3(kSelThreads), 0, s, d->d_bl, rows, cols, d->boundary,
                      d->grad_th, val, d->d_pts, d->d_cnt);
   hipLaunchKernelGGL(depth_disparity_kernel, dim3(kSelBlocks * kSelCap / 4), dim3(256), 0, s, d->d_bl, d->d_br, rows, cols,

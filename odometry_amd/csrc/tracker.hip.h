@@ -327,11 +327,7 @@ static int lm_time_eval(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep,
   std::vector<hipEvent_t> ev(2 * (size_t)reps);
   for (auto& e : ev) HIP_OK(hipEventCreate(&e));
   for (int w = 0; w < 3; w++) lm_launch_eval(m, v, k, level, nblk);  // warm caches
-  for (int i = 0; i < reps; i++) {
-    HIP_OK(hipEventRecord(ev[2 * i], s));
-    lm_launch_eval(m, v, k, level, nblk);
-    HIP_OK(hipEventRecord(ev[2 * i + 1], s));
-  }
+  for (int i = 0; i < reps; i++) lm_launch_eval(m, v, k, level, nblk, ev[2 * i], ev[2 * i + 1]);
   double* d_acc = nullptr;
   HIP_OK(hipMalloc((void**)&d_acc, sizeof(double) * ODO_NACC));
   hipLaunchKernelGGL(lm_sum_partials_kernel, dim3(1), dim3(256), 0, s, m->d_partials, nblk, d_acc);
@@ -378,27 +374,21 @@ extern "C" int odo_depth_time_stages(odo_depth* d, const float* left_dev, const 
   HIP_OK(hipSetDevice(d->ctx->device));
   if (depth_ensure(d, rows, cols)) return -1;
   hipStream_t s = d->ctx->stream;
-  const size_t n = (size_t)rows * cols;
-  hipEvent_t e[4];
+  hipEvent_t e[6];  // dispatch-bound start / stop events per stage
   for (auto& x : e) HIP_OK(hipEventCreate(&x));
   double tot[3] = {0, 0, 0};
   for (int r = -2; r < reps; r++) {  // two warm-up rounds
-    HIP_OK(hipMemsetAsync(d->d_val, 0, n, s));
-    HIP_OK(hipMemsetAsync(d->d_disp, 0, sizeof(float) * n, s));
-    HIP_OK(hipMemsetAsync(d->d_dep, 0, sizeof(float) * n, s));
-    HIP_OK(hipEventRecord(e[0], s));
-    hipLaunchKernelGGL(blur3x3_kernel, grid2d(cols, rows, 2), dim3(256), 0, s, left_dev, d->d_bl, right_dev, d->d_br, rows, cols);
-    HIP_OK(hipEventRecord(e[1], s));
-    hipLaunchKernelGGL(depth_select_kernel, dim3(kSelBlocks), dim3(kSelThreads), 0, s, d->d_bl, rows, cols, d->boundary,
-                       d->grad_th, d->d_val, d->d_pts, d->d_cnt);
-    HIP_OK(hipEventRecord(e[2], s));
-    hipLaunchKernelGGL(depth_disparity_kernel, dim3(kSelBlocks * kSelCap / 4), dim3(256), 0, s, d->d_bl, d->d_br, rows, cols,
-                       d->boundary, d->max_disparity, d->ssd_th, d->K.f0, d->baseline, d->d_pts, d->d_cnt, d->d_disp, d->d_dep,
-                       d->d_d0, d->d_matched);
-    HIP_OK(hipEventRecord(e[3], s));
+    hipExtLaunchKernelGGL(blur3x3_kernel, grid2d(cols, rows, 2), dim3(256), 0, s, e[0], e[1], 0, left_dev, d->d_bl, right_dev,
+                          d->d_br, rows, cols, d->d_val, d->d_disp, d->d_dep);
+    hipExtLaunchKernelGGL(depth_select_kernel, dim3(kSelBlocks), dim3(kSelThreads), 0, s, e[2], e[3], 0,
+                          (const float*)d->d_bl, rows, cols, d->boundary, d->grad_th, d->d_val, d->d_pts, d->d_cnt);
+    hipExtLaunchKernelGGL(depth_disparity_kernel, dim3(kSelBlocks * kSelCap / 4), dim3(256), 0, s, e[4], e[5], 0,
+                          (const float*)d->d_bl, (const float*)d->d_br, rows, cols, d->boundary, d->max_disparity, d->ssd_th,
+                          d->K.f0, d->baseline, (const uint32_t*)d->d_pts, (const int*)d->d_cnt, d->d_disp, d->d_dep, d->d_d0,
+                          d->d_matched);
     HIP_OK(hipStreamSynchronize(s));
     if (r >= 0)
-      for (int k = 0; k < 3; k++) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, e[k], e[k + 1])); tot[k] += ms * 1000.0; }
+      for (int k = 0; k < 3; k++) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, e[2 * k], e[2 * k + 1])); tot[k] += ms * 1000.0; }
   }
   for (auto& x : e) (void)hipEventDestroy(x);
   for (int k = 0; k < 3; k++) us[k] = (float)(tot[k] / reps);

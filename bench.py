@@ -133,20 +133,20 @@ def main():
 
     from odometry_amd.dist import PoseGatherer
     gatherer = PoseGatherer(world, args.gather_every, device="cuda") if world > 1 else None
-    results = []
-    evals = []
+    n_total = args.warmup + args.steps
+    poses_kf = np.zeros((n_total, 16), np.float32)    # pose_to_keyframe per step, column-major
+    poses_abs = np.zeros((n_total, 16), np.float32)
+    step_no = [0]
 
     def step(i):
-        r = trk.track(*dev[i])
-        results.append(r)
-        evals.append(trk.stats()["lm_evals"])
+        k = step_no[0]
+        trk.track_into(dev[i][0], dev[i][1], poses_kf[k], poses_abs[k])
+        step_no[0] = k + 1
         if gatherer is not None:
-            gatherer.push(r["abs_pose"])  # RCCL all_gather over xGMI every gather_every frames (12 floats per frame)
+            gatherer.push(poses_abs[k].reshape(4, 4).T)  # RCCL all_gather over xGMI every gather_every frames
 
     for i in order[:args.warmup]:
         step(i)
-    results.clear()
-    evals.clear()
     barrier()
     t0 = time.perf_counter()
     for i in order[args.warmup:]:
@@ -178,6 +178,7 @@ def main():
                     launches_with_points=ev["active_launches"],
                     note="single 1241x376 frame: working set is cache resident and the launch is latency bound "
                          "(serial LM update + ~30k points); see roofline_dense_1080p for the HBM-bound shape")
+        evals = [ev["active_launches"] / max(min(args.steps, 100), 1)]
         tr0 = trk.time_residual(0, reps=100)   # evaluation-only kernel on level 0 (no LM update), for reference
         roof["eval_only_L0"] = dict(launch_us=round(tr0["mean_us"], 3), residuals=tr0["n_points"],
                                     algorithmic_bytes=int(tr0["bytes"]),

@@ -403,6 +403,16 @@ class Tracker:
         return dict(pose_to_keyframe=_from_colmajor(T), abs_pose=_from_colmajor(A), new_keyframe=bool(nk.value),
                     motion=mag.value, solve_status=ss.value)
 
+    def track_into(self, left_dev, right_dev, pose_to_kf, abs_pose):
+        """Lean variant for timing loops: results land in caller-owned float32[16] column-major buffers."""
+        if not hasattr(self, "_nk"):
+            self._nk, self._ss, self._mag = C.c_int(0), C.c_int(0), C.c_float(0)
+        st = self.lib.odo_tracker_track(self.h, left_dev, right_dev, _fp(pose_to_kf), _fp(abs_pose), C.byref(self._nk),
+                                        C.byref(self._mag), C.byref(self._ss))
+        if st != 0:
+            raise L.OdoError("odo_tracker_track: " + L.last_error())
+        return self._nk.value
+
     def stats(self):
         a, b, c, d = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
         L.check(self.lib.odo_tracker_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "odo_tracker_stats")

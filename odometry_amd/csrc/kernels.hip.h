@@ -282,6 +282,33 @@ __device__ __forceinline__ void block_reduce_acc(const double acc[ODO_NACC], dou
   }
 }
 
+// Same reduction in two rounds of 15 + 14 quantities through a buffer half the size (31.7 KB): five 256-thread
+// blocks fit a CU instead of two. Used by the dense scan, which is throughput bound and wants the occupancy; the
+// association order is identical to block_reduce_acc, so both give the same bits.
+__device__ __forceinline__ void block_reduce_acc_2r(const double acc[ODO_NACC], double* __restrict__ out) {
+  __shared__ double sh2[15][kLmBlock + kRedPad];
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int round = 0; round < 2; round++) {
+    const int q0 = round * 15, nq = round == 0 ? 15 : ODO_NACC - 15;
+    if (round) __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 15; q++)
+      if (q < nq) sh2[q][t] = acc[q0 + q];
+    __syncthreads();
+    if (t < nq * 8) {
+      const int q = t >> 3, s = t & 7;
+      double v = 0.0;
+#pragma unroll 8
+      for (int i = 0; i < kLmBlock / 8; i++) v += sh2[q][i * 8 + s];
+      v += __shfl_xor(v, 4, 8);
+      v += __shfl_xor(v, 2, 8);
+      v += __shfl_xor(v, 1, 8);
+      if (s == 0) out[q0 + q] = v;
+    }
+  }
+}
+
 // Residual / Jacobian / normal-equation pass over the interior of one level, reading the pose from the
 // device-resident LM state (no host round trip between iterations). Dense scan: thread <-> interior pixel
 // (grid-stride), the reference's own iteration space (ref: src/lm_optimizer.cpp:190-191). Coalesced reads of
@@ -315,7 +342,7 @@ __global__ void __launch_bounds__(kLmBlock) lm_residual_dense_kernel(LevelView v
     const float w = robust_weight(r, robust, huber_delta, scale_sqr);
     accumulate_row(acc, r, w, J);
   }
-  block_reduce_acc(acc, partials + (size_t)blockIdx.x * ODO_NACC);
+  block_reduce_acc_2r(acc, partials + (size_t)blockIdx.x * ODO_NACC);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -769,6 +796,8 @@ struct FusedArgs {
   float* cost_stat;
   int* host_prog;
   int seq;
+  int first_of_solve;   // 1: the state is initialised from `init` (lm_begin_solve) instead of being loaded
+  float init[16];       // affine_init_, column-major (ref: src/lm_optimizer.cpp:76-78)
 };
 
 constexpr int kFoldChunk = 16;
@@ -779,9 +808,21 @@ __device__ __forceinline__ void lm_fused_prologue(const LmState* __restrict__ st
                                                   int level, int first_of_level, int max_iters, float lambda0,
                                                   float precision, LmState& s_sh, double* fold_sh, double* acc_sh,
                                                   float* delta_sh, int* flags_sh /* [4] */, LmTraceRow* __restrict__ trace,
-                                                  float* __restrict__ cost_stat, bool publisher) {
+                                                  float* __restrict__ cost_stat, bool publisher,
+                                                  const float* init /* non-null: first launch of a Solve */) {
   const int t = threadIdx.x;
-  if (t < (int)(sizeof(LmState) / sizeof(int))) ((int*)&s_sh)[t] = ((const int*)st_in)[t];
+  if (init) {
+    if (t == 0) {
+      float m[16];
+      for (int i = 0; i < 16; i++) m[i] = init[i];
+      lm_begin_solve(&s_sh, m);
+      s_sh.level = -1; s_sh.iter = 0; s_sh.lambda = 0.0f; s_sh.err_last = 1e+10f;
+      for (int i = 0; i < 16; i++) s_sh.T[i] = m[i];
+    }
+    if (publisher && t < 16) cost_stat[t] = 0.0f;
+  } else if (t < (int)(sizeof(LmState) / sizeof(int))) {
+    ((int*)&s_sh)[t] = ((const int*)st_in)[t];
+  }
   __syncthreads();
   const bool pending = s_sh.pending != 0;  // block-uniform
   if (pending) {
@@ -884,9 +925,12 @@ __global__ void __launch_bounds__(kLmBlock) lm_fused_kernel(FusedArgs a) {
   __shared__ int flags_sh[4];
   __shared__ int before_sh[2];
   const bool publisher = (blockIdx.x == 0);
-  if (threadIdx.x == 0) { before_sh[0] = a.st_in->level; before_sh[1] = a.st_in->active; }
+  if (threadIdx.x == 0) {
+    before_sh[0] = a.first_of_solve ? -1 : a.st_in->level;
+    before_sh[1] = a.first_of_solve ? 0 : a.st_in->active;
+  }
   lm_fused_prologue(a.st_in, a.part_in, a.level, a.first_of_level, a.max_iters, a.lambda0, a.precision, s_sh, fold_sh,
-                    acc_sh, delta_sh, flags_sh, a.trace, a.cost_stat, publisher);
+                    acc_sh, delta_sh, flags_sh, a.trace, a.cost_stat, publisher, a.first_of_solve ? a.init : nullptr);
   const bool run = (s_sh.active != 0 && s_sh.level == a.level && s_sh.status == 0);  // block-uniform
   if (run) {
     float T[16];
@@ -931,19 +975,28 @@ __global__ void __launch_bounds__(kLmBlock) lm_fused_kernel(FusedArgs a) {
 
 // End of a fused Solve: consume the last pending evaluation, then affine_ = current_estimate.matrix()
 // (ref: src/lm_optimizer.cpp:158) or the pseudo-identity on failure (ref: :48-52,60-65).
-__global__ void __launch_bounds__(kLmBlock) lm_fused_finalize_kernel(const LmState* __restrict__ st_in,
-                                                                      const double* __restrict__ part_in, float precision,
-                                                                      LmTraceRow* __restrict__ trace,
-                                                                      float* __restrict__ cost_stat, LmState* __restrict__ st_out,
-                                                                      float* __restrict__ out) {
+struct FinalizeArgs {
+  const LmState* st_in;
+  const double* part_in;
+  float precision;
+  LmTraceRow* trace;
+  float* cost_stat;
+  LmState* st_out;
+  float* out;          // 42 floats: pose, status, n_evals, evaluations per level, cost statistics (host-mapped)
+  int* done_flag;      // host-mapped: set to `token` when `out` is complete
+  int token;
+  int first_of_solve;  // no evaluation was launched (all budgets 0): the state comes from `init`
+  float init[16];
+};
+__global__ void __launch_bounds__(kLmBlock) lm_fused_finalize_kernel(FinalizeArgs a) {
   __shared__ LmState s_sh;
   __shared__ double fold_sh[8 * 32];
   __shared__ double acc_sh[32];
   __shared__ float delta_sh[8];
   __shared__ int flags_sh[4];
-  lm_fused_prologue(st_in, part_in, -1, 0, 0, 0.0f, precision, s_sh, fold_sh, acc_sh, delta_sh, flags_sh, trace, cost_stat,
-                    true);
-  if (threadIdx.x < (int)(sizeof(LmState) / sizeof(int))) ((int*)st_out)[threadIdx.x] = ((const int*)&s_sh)[threadIdx.x];
+  lm_fused_prologue(a.st_in, a.part_in, -1, 0, 0, 0.0f, a.precision, s_sh, fold_sh, acc_sh, delta_sh, flags_sh, a.trace,
+                    a.cost_stat, true, a.first_of_solve ? a.init : nullptr);
+  if (threadIdx.x < (int)(sizeof(LmState) / sizeof(int))) ((int*)a.st_out)[threadIdx.x] = ((const int*)&s_sh)[threadIdx.x];
   if (threadIdx.x == 0) {
     float m[16];
     if (s_sh.status == 0) {
@@ -952,10 +1005,12 @@ __global__ void __launch_bounds__(kLmBlock) lm_fused_finalize_kernel(const LmSta
       for (int i = 0; i < 16; i++) m[i] = 0.0f;
       m[0] = 1.0f; m[5] = 1.0f; m[10] = 1.0f;
     }
-    for (int i = 0; i < 16; i++) out[i] = m[i];
-    out[16] = (float)s_sh.status;
-    out[17] = (float)s_sh.n_evals;
-    for (int i = 0; i < 8; i++) out[18 + i] = (float)s_sh.iters_level[i];
+    for (int i = 0; i < 16; i++) a.out[i] = m[i];
+    a.out[16] = (float)s_sh.status;
+    a.out[17] = (float)s_sh.n_evals;
+    for (int i = 0; i < 8; i++) a.out[18 + i] = (float)s_sh.iters_level[i];
+    for (int i = 0; i < 16; i++) a.out[26 + i] = a.cost_stat[i];
+    __hip_atomic_store(a.done_flag, a.token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -1329,7 +1384,8 @@ __global__ void __launch_bounds__(kDlmBlock) depth_finalize_kernel(int run_lm, i
 
 __global__ void __launch_bounds__(kDlmBlock) depth_stats_kernel(int run_lm, int n_launches, const int* __restrict__ counts,
                                                                 const DepthLmState* __restrict__ state,
-                                                                DepthLmStats* __restrict__ stats) {
+                                                                DepthLmStats* __restrict__ stats /* host-mapped */,
+                                                                int* __restrict__ done_flag, int token) {
   __shared__ int sh[3][kDlmBlock];
   const int t = threadIdx.x;
   for (int q = 0; q < 3; q++) sh[q][t] = (t < kDlmBlocks) ? counts[t * 3 + q] : 0;
@@ -1346,6 +1402,7 @@ __global__ void __launch_bounds__(kDlmBlock) depth_stats_kernel(int run_lm, int 
     stats->n_selected = sh[1][0];
     stats->n_matched = sh[2][0];
     stats->status = (run_lm && sh[0][0] < 500) ? -1 : 0;  // :192-197
+    __hip_atomic_store(done_flag, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 

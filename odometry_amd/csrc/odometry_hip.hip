@@ -267,7 +267,8 @@ extern "C" int odo_pyramid_destroy(odo_pyr* p) {
 // Pose LM
 // ------------------------------------------------------------------------------------------------
 static const odo_intrinsics kKitti00 = {718.856f, (float)607.1928, (float)185.2157};
-constexpr int kLmMaxBlocks = 512;
+constexpr int kLmMaxBlocks = 1280;       // partial rows per buffer: dense scan = 5 blocks per CU
+constexpr int kLmFusedDenseBlocks = 512;  // fused dense launches fold every row in every block: keep the grid small
 
 struct odo_lm {
   odo_ctx* ctx;
@@ -304,6 +305,7 @@ struct odo_lm {
   double ev_total_us, ev_bytes;
   long ev_launches, ev_active;
   int trace_stale;
+  float* h_res; float* d_res_map; int* h_done; int* d_done; int token;  // host-mapped result + completion word
   int fused;  // 1 = one launch per evaluation (robust 0/1); 0 = separate residual / update kernels
   int mode;  // 0 auto (list when <= half of the interior has depth), 1 always dense scan, 2 always list
   void (*idle_pump)(void*);  // called while the host waits for the device (the tracker feeds its depth stream here)
@@ -345,6 +347,11 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
   HIP_OK(hipHostMalloc((void**)&m->h_out, sizeof(float) * 48, hipHostMallocDefault));
   HIP_OK(hipHostMalloc((void**)&m->h_trace, sizeof(LmTraceRow) * kTraceCap, hipHostMallocDefault));
   m->h_cost = m->h_out + 26;
+  HIP_OK(hipHostMalloc((void**)&m->h_res, sizeof(float) * 48, hipHostMallocMapped | hipHostMallocCoherent));
+  HIP_OK(hipHostGetDevicePointer((void**)&m->d_res_map, m->h_res, 0));
+  HIP_OK(hipHostMalloc((void**)&m->h_done, sizeof(int) * 4, hipHostMallocMapped | hipHostMallocCoherent));
+  HIP_OK(hipHostGetDevicePointer((void**)&m->d_done, m->h_done, 0));
+  m->h_done[0] = 0;
   HIP_OK(hipHostMalloc((void**)&m->h_prog, sizeof(int) * 16, hipHostMallocMapped | hipHostMallocCoherent));
   HIP_OK(hipHostGetDevicePointer((void**)&m->d_prog, m->h_prog, 0));
   memset(m->h_prog, 0, sizeof(int) * 16);
@@ -373,7 +380,7 @@ extern "C" int odo_lm_destroy(odo_lm* m) {
   }
   (void)hipHostFree(m->h_npts);
   if (m->ev_pool) { for (auto& e : *m->ev_pool) (void)hipEventDestroy(e); delete m->ev_pool; }
-  (void)hipHostFree(m->h_out); (void)hipHostFree(m->h_trace); (void)hipHostFree(m->h_prog);
+  (void)hipHostFree(m->h_out); (void)hipHostFree(m->h_trace); (void)hipHostFree(m->h_prog); (void)hipHostFree(m->h_res); (void)hipHostFree(m->h_done);
   delete m;
   return 0;
 }
@@ -544,8 +551,6 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
   hipStream_t s = m->ctx->stream;
   HIP_OK(hipSetDevice(m->ctx->device));
   if (lm_prepare_keyframe(m, kf_img, kf_dep)) return -1;
-  HIP_OK(hipMemcpyAsync(m->d_init, m->init, sizeof(float) * 16, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(lm_begin_solve_kernel, dim3(1), dim3(64), 0, s, m->d_state, m->d_init, m->d_cost);
   int launches = 0;
   double bytes_per_level[ODO_MAX_LEVELS] = {0};
   // Early exit without a host sync: the device publishes its progress in host-mapped memory; the host stays at
@@ -554,7 +559,13 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
   volatile int* prog = m->h_prog;
   for (int i = 0; i < 16; i++) m->h_prog[i] = 0;  // the stream is idle here (every Solve ends with a sync)
   bool poll = m->poll != 0;
-  const bool fused = m->fused && m->robust != 2;
+  bool fused = m->fused && m->robust != 2;
+  for (int l = 0; l < m->n_levels; l++)
+    if (!m->use_list[l]) fused = false;  // dense levels are throughput bound: big grids + a separate update kernel
+  if (!fused) {
+    HIP_OK(hipMemcpyAsync(m->d_init, m->init, sizeof(float) * 16, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(lm_begin_solve_kernel, dim3(1), dim3(64), 0, s, m->d_state, m->d_init, m->d_cost);
+  }
   int seq = 0;
   LmState* st[2] = {m->d_state, m->d_state + 1};
   double* part[2] = {m->d_partials, m->d_partials + (size_t)kLmMaxBlocks * ODO_NACC};
@@ -587,6 +598,8 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
         a.level = l; a.first_of_level = (it == 0) ? 1 : 0; a.max_iters = m->max_iters[l];
         a.lambda0 = m->lambda; a.precision = m->precision; a.robust = m->robust; a.huber_delta = m->huber_delta;
         a.trace = m->d_trace; a.cost_stat = m->d_cost; a.host_prog = m->d_prog; a.seq = seq;
+        a.first_of_solve = (seq == 0) ? 1 : 0;
+        memcpy(a.init, m->init, sizeof(a.init));
         const bool ev = m->ev_on && m->ev_pool && (size_t)(2 * launches + 1) < m->ev_pool->size();
         if (ev) {
           // timing pass: start / stop events bound to the dispatch itself (the kernel's own begin / end timestamps)
@@ -609,14 +622,32 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
       launches++;
     }
   }
-  if (fused)
-    hipLaunchKernelGGL(lm_fused_finalize_kernel, dim3(1), dim3(kLmBlock), 0, s, st[seq & 1], part[seq & 1], m->precision,
-                       m->d_trace, m->d_cost, st[0], m->d_out);
-  else
+  if (fused) {
+    // The result comes back through host-mapped memory: no copy operation and no stream-sync call on the critical
+    // path; the host spins on the completion word (bounded; falls back to a stream sync).
+    FinalizeArgs fa;
+    fa.st_in = st[seq & 1]; fa.part_in = part[seq & 1]; fa.precision = m->precision; fa.trace = m->d_trace;
+    fa.cost_stat = m->d_cost; fa.st_out = st[0]; fa.out = m->d_res_map; fa.done_flag = m->d_done;
+    fa.token = ++m->token; fa.first_of_solve = (seq == 0) ? 1 : 0;
+    memcpy(fa.init, m->init, sizeof(fa.init));
+    hipLaunchKernelGGL(lm_fused_finalize_kernel, dim3(1), dim3(kLmBlock), 0, s, fa);
+    HIP_OK(hipGetLastError());
+    volatile int* done = m->h_done;
+    const auto t0 = std::chrono::steady_clock::now();
+    bool ok = true;
+    while (done[0] != fa.token) {
+      if (m->idle_pump) m->idle_pump(m->idle_arg);
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { ok = false; break; }
+    }
+    if (!ok) HIP_OK(hipStreamSynchronize(s));
+    std::atomic_thread_fence(std::memory_order_acquire);
+    memcpy(m->h_out, m->h_res, sizeof(float) * 42);
+  } else {
     hipLaunchKernelGGL(lm_finalize_kernel, dim3(1), dim3(64), 0, s, m->d_state, m->d_out);
-  HIP_OK(hipGetLastError());
-  HIP_OK(hipMemcpyAsync(m->h_out, m->d_out, sizeof(float) * 42, hipMemcpyDeviceToHost, s));  // pose, status, counters, costs
-  HIP_OK(hipStreamSynchronize(s));
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(m->h_out, m->d_out, sizeof(float) * 42, hipMemcpyDeviceToHost, s));  // pose, status, counters, costs
+    HIP_OK(hipStreamSynchronize(s));
+  }
   m->trace_stale = 1;  // the per-evaluation trace stays on the device until odo_lm_trace() asks for it
   memcpy(out_colmajor, m->h_out, sizeof(float) * 16);
   m->last_evals = (int)m->h_out[17];
@@ -834,6 +865,8 @@ struct odo_depth {
   int* h_prog;
   int* d_prog;
   int poll, run_ahead;
+  DepthLmStats* d_stats_map;  // device alias of the host-mapped h_stats
+  int token;
   DepthLmStats last;
 };
 
@@ -862,11 +895,11 @@ extern "C" int odo_depth_create(odo_ctx* ctx, float grad_th, float ssd_th, float
   HIP_OK(hipMalloc((void**)&d->d_part_e, sizeof(double) * 2 * kDlmBlocks));
   HIP_OK(hipMalloc((void**)&d->d_part_n, sizeof(int) * 2 * kDlmBlocks));
   HIP_OK(hipMalloc((void**)&d->d_counts, sizeof(int) * 3 * kDlmBlocks));
-  HIP_OK(hipMalloc((void**)&d->d_stats, sizeof(DepthLmStats)));
-  HIP_OK(hipHostMalloc((void**)&d->h_stats, sizeof(DepthLmStats), hipHostMallocDefault));
-  HIP_OK(hipHostMalloc((void**)&d->h_prog, sizeof(int) * 4, hipHostMallocMapped | hipHostMallocCoherent));
+  HIP_OK(hipHostMalloc((void**)&d->h_stats, sizeof(DepthLmStats), hipHostMallocMapped | hipHostMallocCoherent));
+  HIP_OK(hipHostGetDevicePointer((void**)&d->d_stats_map, d->h_stats, 0));
+  HIP_OK(hipHostMalloc((void**)&d->h_prog, sizeof(int) * 8, hipHostMallocMapped | hipHostMallocCoherent));
   HIP_OK(hipHostGetDevicePointer((void**)&d->d_prog, d->h_prog, 0));
-  memset(d->h_prog, 0, sizeof(int) * 4);
+  memset(d->h_prog, 0, sizeof(int) * 8);
   d->poll = getenv("ODO_NO_POLL") ? 0 : 1;
   d->run_ahead = getenv("ODO_RUN_AHEAD") ? atoi(getenv("ODO_RUN_AHEAD")) : 3;
   *out = d;
@@ -885,7 +918,7 @@ extern "C" int odo_depth_destroy(odo_depth* d) {
   if (!d) return 0;
   (void)hipStreamSynchronize(d->ctx->stream);
   depth_free_images(d);
-  void* dv[] = {d->d_pts, d->d_cnt, d->d_d0, d->d_scratch, d->d_matched, d->d_lmstate, d->d_part_e, d->d_part_n, d->d_counts, d->d_stats};
+  void* dv[] = {d->d_pts, d->d_cnt, d->d_d0, d->d_scratch, d->d_matched, d->d_lmstate, d->d_part_e, d->d_part_n, d->d_counts};
   for (void* q : dv) if (q) (void)hipFree(q);
   (void)hipHostFree(d->h_stats); (void)hipHostFree(d->h_prog);
   delete d;
@@ -957,16 +990,24 @@ static int depth_job_begin(odo_depth* d, DepthJob* j, const float* left, const f
   return 0;
 }
 
+// Tail, part 1: write-back + filters. Part 2 (depth_job_stats) reduces the counts into host-mapped memory and sets
+// the completion word; a caller may enqueue more work of its own between the two (the tracker's pyramids), so that
+// "completion word set" implies that work is done too.
 static int depth_job_tail(odo_depth* d, DepthJob* j) {
   hipStream_t s = d->ctx->stream;
   const int run_lm = j->stage != 1 ? 1 : 0;
   hipLaunchKernelGGL(depth_finalize_kernel, dim3(kDlmBlocks), dim3(kDlmBlock), 0, s, run_lm, j->cols, d->d_pts, d->d_cnt,
                      d->d_matched, d->d_scratch, d->photo_th, d->min_depth, d->max_depth, j->val, j->dep, d->d_counts);
-  hipLaunchKernelGGL(depth_stats_kernel, dim3(1), dim3(kDlmBlock), 0, s, run_lm, j->n_launches, d->d_counts, d->d_lmstate,
-                     d->d_stats);
   HIP_OK(hipGetLastError());
-  HIP_OK(hipMemcpyAsync(d->h_stats, d->d_stats, sizeof(DepthLmStats), hipMemcpyDeviceToHost, s));
   j->tail_done = true;
+  return 0;
+}
+static int depth_job_stats(odo_depth* d, DepthJob* j) {
+  const int run_lm = j->stage != 1 ? 1 : 0;
+  d->token++;
+  hipLaunchKernelGGL(depth_stats_kernel, dim3(1), dim3(kDlmBlock), 0, d->ctx->stream, run_lm, j->n_launches, d->d_counts,
+                     d->d_lmstate, d->d_stats_map, d->d_prog + 4, d->token);
+  HIP_OK(hipGetLastError());
   return 0;
 }
 
@@ -1002,12 +1043,23 @@ static int depth_run(odo_depth* d, const float* left, const float* right, int ro
   for (;;) {
     const int r = depth_job_pump(d, &j);
     if (r < 0) return -1;
-    if (r > 0) return 0;
+    if (r > 0) return depth_job_stats(d, &j);
   }
 }
 
-static int depth_finish(odo_depth* d) {
-  HIP_OK(hipStreamSynchronize(d->ctx->stream));
+// Waits for the job: spins on the host-mapped completion word (bounded), or synchronises the stream when the caller
+// needs every queued operation retired (host-buffer entry points copy results back afterwards).
+static int depth_finish(odo_depth* d, bool full_sync = true) {
+  if (full_sync) {
+    HIP_OK(hipStreamSynchronize(d->ctx->stream));
+  } else {
+    volatile int* done = d->h_prog + 4;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (done[0] != d->token) {
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { HIP_OK(hipStreamSynchronize(d->ctx->stream)); break; }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
   d->last = *d->h_stats;
   if (d->last.status != 0) return fail("number of valid after optimization is too small: %d", d->last.n_valid);
   return 0;

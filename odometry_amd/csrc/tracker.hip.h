@@ -137,6 +137,7 @@ static void tracker_job_pump(void* arg) {
     const odo_tracker_params& p = t->p;
     if (pyr_build(t->pre_img, t->job.left, p.smooth_image)) t->job_err = 1;  // :251 (built a second time, as the runner does)
     if (pyr_build(t->pre_dep, t->d_dep, 0)) t->job_err = 1;                   // :252
+    if (depth_job_stats(t->depth, &t->job)) t->job_err = 1;  // completion word AFTER the pyramids: it covers them too
     t->job_stage = 3;
   }
 }
@@ -163,7 +164,7 @@ static void tracker_worker_main(odo_tracker* t) {
     }
     idle_spins = 0;
     int rc = tracker_depth_and_pyramids(t, t->w_left, t->w_right);
-    if (rc == 0) rc = depth_finish(t->depth);
+    if (rc == 0) rc = depth_finish(t->depth, false);
     t->w_rc = rc;
     if (rc) snprintf(t->w_err, sizeof(t->w_err), "%s", g_err);
     t->w_state.store(2, std::memory_order_release);
@@ -174,7 +175,7 @@ extern "C" int odo_tracker_init(odo_tracker* t, const float* left, const float* 
   if (!t || !left || !right || !abs_pose0) return fail("odo_tracker_init: NULL arg");
   HIP_OK(hipSetDevice(t->ctx_a->device));
   if (tracker_depth_and_pyramids(t, left, right)) return -1;   // :102, :130-131
-  if (depth_finish(t->depth)) { fail("Init 0-th frame failed!"); return -1; }  // :103-106
+  if (depth_finish(t->depth, true)) { fail("Init 0-th frame failed!"); return -1; }  // :103-106
   std::swap(t->kf_img, t->pre_img);                             // :141 first keyframe
   std::swap(t->kf_dep, t->pre_dep);
   memcpy(t->kf_abs, abs_pose0, sizeof(float) * 16);             // :143
@@ -256,7 +257,7 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
     } else {
       if (tracker_depth_and_pyramids(t, left, right)) return -1;                       // :226-252 in program order
     }
-    if (depth_finish(t->depth)) { fail("    depth failed!"); return -1; }              // :230-232
+    if (depth_finish(t->depth, false)) { fail("    depth failed!"); return -1; }       // :230-232
   }
   memcpy(t->pose_to_kf, T, sizeof(T));
   float inv[16], cur[16];

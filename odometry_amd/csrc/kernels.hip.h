@@ -582,6 +582,7 @@ __global__ void __launch_bounds__(1024) lm_tdist_scale_kernel(const float* __res
 }
 
 static_assert(sizeof(LmState) <= 64 * sizeof(int), "LmState must fit one wavefront-wide copy");
+static_assert(sizeof(LmState) == 64 * sizeof(int), "LmState is exactly 64 dwords");
 
 struct LmTraceRow {
   int level, iter, n_res, accepted, stop;
@@ -762,9 +763,9 @@ __global__ void __launch_bounds__(kUpdThreads) lm_update_kernel(LmState* __restr
   if (t == 0) {
     const LmState& s = s_sh;
     if (host_prog) {
-      // host-mapped progress words: [1 + level] = 1 once the level's loop has stopped (the host then skips the
+      // host-mapped progress words: [2 + level] = 1 once the level's loop has stopped (the host then skips the
       // launches it has not issued yet), [0] = sequence number of the last update launch that has run.
-      if (!s.active) __hip_atomic_store(host_prog + 1 + expect_level, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (!s.active) __hip_atomic_store(host_prog + 2 + expect_level, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_store(host_prog, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
@@ -779,16 +780,22 @@ __global__ void __launch_bounds__(kUpdThreads) lm_update_kernel(LmState* __restr
 // trip through memory between "new pose known" and "residuals at the new pose". State and partials are
 // double-buffered by launch sequence number; block 0 alone publishes the state, trace row and progress words.
 // =============================================================================================
-struct FusedArgs {
-  PointList pl;      // point-list form
-  int n;
-  LevelView v;       // dense form reads I1 / D1; both read I2, rows, cols
+struct StepLevel {   // everything a launch needs to evaluate one pyramid level
+  PointList pl;
+  int n, nblk;       // points of the keyframe list, blocks that evaluate them
+  const float* I2;   // current image, this level
+  int rows, cols;
   LevelK k;
+  int max_iters;     // max_iterations_[level] (ref: src/lm_optimizer.cpp:117)
+  int pad_;
+};
+struct StepArgs {
+  StepLevel lv[ODO_MAX_LEVELS_K];
+  int n_levels;
   const LmState* st_in;
   LmState* st_out;
   const double* part_in;
   double* part_out;
-  int level, first_of_level, max_iters;
   float lambda0, precision;
   int robust;
   float huber_delta;
@@ -802,12 +809,14 @@ struct FusedArgs {
 
 constexpr int kFoldChunk = 16;
 
-// Prologue shared by the fused kernels and the fused finalize: leaves the advanced state in s_sh.
-// fold_sh: >= 8 x 32 doubles of scratch. All 256 threads must call it.
+// Prologue shared by the step kernel and the finalize kernel: leaves the advanced state in s_sh.
+// fold_sh: >= 8 x 32 doubles of scratch. All 256 threads must call it. `lv` non-null: also walk the pyramid —
+// when the level's loop has ended, begin the next coarser-to-finer level right here (ref: src/lm_optimizer.cpp:92,
+// 110-115,156), so the launch that learns "level l is done" is also the first evaluation of level l-1.
 __device__ __forceinline__ void lm_fused_prologue(const LmState* __restrict__ st_in, const double* __restrict__ part_in,
-                                                  int level, int first_of_level, int max_iters, float lambda0,
-                                                  float precision, LmState& s_sh, double* fold_sh, double* acc_sh,
-                                                  float* delta_sh, int* flags_sh /* [4] */, LmTraceRow* __restrict__ trace,
+                                                  const StepLevel* lv, int n_levels, float lambda0, float precision,
+                                                  LmState& s_sh, double* fold_sh, double* acc_sh, float* delta_sh,
+                                                  int* flags_sh /* [4] */, LmTraceRow* __restrict__ trace,
                                                   float* __restrict__ cost_stat, bool publisher,
                                                   const float* init /* non-null: first launch of a Solve */) {
   const int t = threadIdx.x;
@@ -893,9 +902,14 @@ __device__ __forceinline__ void lm_fused_prologue(const LmState* __restrict__ st
         }
         s.pending = 0;
       }
-      if (first_of_level && !s.active && s.level != level) {
-        s.stop_reason = 0;
-        lm_begin_level(&s, level, lambda0, max_iters);  // ref: src/lm_optimizer.cpp:110-115
+      if (lv) {
+        while (!s.active && s.status == 0 && !s.finished) {
+          const int next = (s.level < 0) ? n_levels - 1 : s.level - 1;
+          if (next < 0) { s.finished = 1; break; }
+          s.stop_reason = 0;
+          lm_begin_level(&s, next, lambda0, lv[next].max_iters);  // ref: src/lm_optimizer.cpp:110-115
+        }
+        if (s.status != 0) s.finished = 1;
       }
     }
   }
@@ -903,73 +917,55 @@ __device__ __forceinline__ void lm_fused_prologue(const LmState* __restrict__ st
 }
 
 __device__ __forceinline__ void lm_fused_publish(LmState& s_sh, LmState* __restrict__ st_out, int* __restrict__ host_prog,
-                                                 int seq, int level_before, bool was_active_before) {
+                                                 int seq) {
   const int t = threadIdx.x;
   if (t < 64) {
     if (t < (int)(sizeof(LmState) / sizeof(int))) ((int*)st_out)[t] = ((const int*)&s_sh)[t];
     if (t == 0 && host_prog) {
-      // [1 + level] = 1 once that level's loop has stopped; [0] = sequence number of the last finished launch
-      if (was_active_before && !s_sh.active)
-        __hip_atomic_store(host_prog + 1 + level_before, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // host-mapped progress: [1] = 1 once every level is done (the host stops issuing launches),
+      // [0] = number of launches that have finished
+      if (s_sh.finished) __hip_atomic_store(host_prog + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_store(host_prog, seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
 
-template <bool LIST>
-__global__ void __launch_bounds__(kLmBlock) lm_fused_kernel(FusedArgs a) {
+// One generic LM step. Which level it works on is decided on the device (the prologue walks the pyramid), so the host
+// issues identical launches until the device reports that the Solve is finished; the grid is sized for the largest
+// level and the blocks a coarser level does not need stop after the (redundant, parallel) prologue.
+__global__ void __launch_bounds__(kLmBlock) lm_step_kernel(StepArgs a) {
   __shared__ LmState s_sh;
   __shared__ double fold_sh[8 * 32];
   __shared__ double acc_sh[32];
   __shared__ float delta_sh[8];
   __shared__ int flags_sh[4];
-  __shared__ int before_sh[2];
   const bool publisher = (blockIdx.x == 0);
-  if (threadIdx.x == 0) {
-    before_sh[0] = a.first_of_solve ? -1 : a.st_in->level;
-    before_sh[1] = a.first_of_solve ? 0 : a.st_in->active;
-  }
-  lm_fused_prologue(a.st_in, a.part_in, a.level, a.first_of_level, a.max_iters, a.lambda0, a.precision, s_sh, fold_sh,
-                    acc_sh, delta_sh, flags_sh, a.trace, a.cost_stat, publisher, a.first_of_solve ? a.init : nullptr);
-  const bool run = (s_sh.active != 0 && s_sh.level == a.level && s_sh.status == 0);  // block-uniform
-  if (run) {
+  lm_fused_prologue(a.st_in, a.part_in, a.lv, a.n_levels, a.lambda0, a.precision, s_sh, fold_sh, acc_sh, delta_sh, flags_sh,
+                    a.trace, a.cost_stat, publisher, a.first_of_solve ? a.init : nullptr);
+  const bool run = (s_sh.active != 0 && s_sh.status == 0);  // block-uniform
+  const int lvl = run ? s_sh.level : 0;
+  const StepLevel& L = a.lv[lvl];
+  if (run && (int)blockIdx.x < L.nblk) {
     float T[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) T[i] = s_sh.T[i];
     double acc[ODO_NACC];
 #pragma unroll
     for (int q = 0; q < ODO_NACC; q++) acc[q] = 0.0;
-    if (LIST) {
-      for (int idx = blockIdx.x * kLmBlock + threadIdx.x; idx < a.n; idx += gridDim.x * kLmBlock) {
-        const PointK p = load_point(a.pl, idx);
-        int ui, vi;
-        if (!warp_point(p, T, a.k, a.v.rows, a.v.cols, &ui, &vi)) continue;
-        float r, J[6];
-        residual_jacobian(p, a.v.I2, a.v.rows, a.v.cols, ui, vi, &r, J);
-        accumulate_row(acc, r, robust_weight(r, a.robust, a.huber_delta, 1.0f), J);
-      }
-    } else {
-      const int iw = a.v.cols - 8, ih = a.v.rows - 8;
-      const int n = (iw > 0 && ih > 0) ? iw * ih : 0;
-      for (int idx = blockIdx.x * kLmBlock + threadIdx.x; idx < n; idx += gridDim.x * kLmBlock) {
-        const int y = 4 + idx / iw, x = 4 + idx % iw;
-        const size_t o = (size_t)y * a.v.cols + x;
-        const float d = a.v.D1[o];
-        if (!depth_valid(d)) continue;
-        const PointK p = make_point(x, y, d, a.v.I1[o], a.k);
-        int ui, vi;
-        if (!warp_point(p, T, a.k, a.v.rows, a.v.cols, &ui, &vi)) continue;
-        float r, J[6];
-        residual_jacobian(p, a.v.I2, a.v.rows, a.v.cols, ui, vi, &r, J);
-        accumulate_row(acc, r, robust_weight(r, a.robust, a.huber_delta, 1.0f), J);
-      }
+    for (int idx = blockIdx.x * kLmBlock + threadIdx.x; idx < L.n; idx += L.nblk * kLmBlock) {
+      const PointK p = load_point(L.pl, idx);
+      int ui, vi;
+      if (!warp_point(p, T, L.k, L.rows, L.cols, &ui, &vi)) continue;
+      float r, J[6];
+      residual_jacobian(p, L.I2, L.rows, L.cols, ui, vi, &r, J);
+      accumulate_row(acc, r, robust_weight(r, a.robust, a.huber_delta, 1.0f), J);
     }
     block_reduce_acc(acc, a.part_out + (size_t)blockIdx.x * ODO_NACC);
   }
   if (publisher) {
-    if (threadIdx.x == 0 && run) { s_sh.pending = 1; s_sh.pending_nblk = gridDim.x; }
+    if (threadIdx.x == 0 && run) { s_sh.pending = 1; s_sh.pending_nblk = L.nblk; }
     __syncthreads();
-    lm_fused_publish(s_sh, a.st_out, a.host_prog, a.seq, before_sh[0], before_sh[1] != 0);
+    lm_fused_publish(s_sh, a.st_out, a.host_prog, a.seq);
   }
 }
 
@@ -994,7 +990,7 @@ __global__ void __launch_bounds__(kLmBlock) lm_fused_finalize_kernel(FinalizeArg
   __shared__ double acc_sh[32];
   __shared__ float delta_sh[8];
   __shared__ int flags_sh[4];
-  lm_fused_prologue(a.st_in, a.part_in, -1, 0, 0, 0.0f, a.precision, s_sh, fold_sh, acc_sh, delta_sh, flags_sh, a.trace,
+  lm_fused_prologue(a.st_in, a.part_in, nullptr, 0, 0.0f, a.precision, s_sh, fold_sh, acc_sh, delta_sh, flags_sh, a.trace,
                     a.cost_stat, true, a.first_of_solve ? a.init : nullptr);
   if (threadIdx.x < (int)(sizeof(LmState) / sizeof(int))) ((int*)a.st_out)[threadIdx.x] = ((const int*)&s_sh)[threadIdx.x];
   if (threadIdx.x == 0) {

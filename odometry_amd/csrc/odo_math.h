@@ -387,6 +387,7 @@ struct LmState {  // <= 64 dwords: the update kernel copies it with one wavefron
   int pending;        // 1 = partials of an evaluation at s->T wait in the partial buffer
   int pending_nblk;   // number of partial rows that evaluation wrote
   int max_iters;      // iteration budget of the level being optimised (max_iterations_[level])
+  int finished;       // 1 once every level has been optimised (or the Solve failed): nothing left to launch
 };
 
 ODO_HD void lm_begin_solve(LmState* s, const float init_colmajor[16]) {
@@ -400,6 +401,7 @@ ODO_HD void lm_begin_solve(LmState* s, const float init_colmajor[16]) {
   s->pending = 0;
   s->pending_nblk = 0;
   s->max_iters = 0;
+  s->finished = 0;
   s->err_now = 0.0f;
   for (int i = 0; i < 8; i++) s->iters_level[i] = 0;
   for (int i = 0; i < 6; i++) s->delta[i] = 0.0f;

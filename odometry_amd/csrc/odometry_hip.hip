@@ -554,72 +554,90 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
   int launches = 0;
   double bytes_per_level[ODO_MAX_LEVELS] = {0};
   // Early exit without a host sync: the device publishes its progress in host-mapped memory; the host stays at
-  // most `run_ahead` evaluations ahead of the device and stops issuing a level's launches once the device reports
-  // that the level's loop has ended. Stale launches are no-ops on the device either way.
+  // most `run_ahead` launches ahead of the device and stops issuing launches once the device reports that the Solve
+  // (fused pipeline) or the level (unfused pipeline) has ended. Stale launches are no-ops on the device either way.
   volatile int* prog = m->h_prog;
   for (int i = 0; i < 16; i++) m->h_prog[i] = 0;  // the stream is idle here (every Solve ends with a sync)
   bool poll = m->poll != 0;
   bool fused = m->fused && m->robust != 2;
   for (int l = 0; l < m->n_levels; l++)
     if (!m->use_list[l]) fused = false;  // dense levels are throughput bound: big grids + a separate update kernel
-  if (!fused) {
-    HIP_OK(hipMemcpyAsync(m->d_init, m->init, sizeof(float) * 16, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(lm_begin_solve_kernel, dim3(1), dim3(64), 0, s, m->d_state, m->d_init, m->d_cost);
-  }
   int seq = 0;
   LmState* st[2] = {m->d_state, m->d_state + 1};
   double* part[2] = {m->d_partials, m->d_partials + (size_t)kLmMaxBlocks * ODO_NACC};
-  for (int l = m->n_levels - 1; l >= 0; l--) {  // ref: src/lm_optimizer.cpp:92
-    LevelView v;
-    v.I1 = kf_img->dev + kf_img->off[l];
-    v.I2 = cur_img->dev + cur_img->off[l];
-    v.D1 = kf_dep->dev + kf_dep->off[l];
-    v.rows = kf_img->r[l]; v.cols = kf_img->c[l];
-    const LevelK k = make_level_k(m->K.f0, m->K.cx0, m->K.cy0, l);
-    const int nblk = lm_grid_for(m, l, v.rows, v.cols);
-    if (m->robust == 2 && lm_ensure_res(m, (size_t)v.rows * v.cols)) return -1;
-    bytes_per_level[l] = lm_level_bytes(m, l, v.rows, v.cols, nblk);
-    if (!fused)
-      hipLaunchKernelGGL(lm_begin_level_kernel, dim3(1), dim3(64), 0, s, m->d_state, l, m->lambda, m->max_iters[l]);
-    for (int it = 0; it < m->max_iters[l]; it++) {  // ref: :117
+  if (fused) {
+    // ---- fused pipeline: identical generic step launches; the device walks the pyramid itself ----
+    StepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_levels = m->n_levels;
+    int grid = 1, budget = 0;
+    for (int l = 0; l < m->n_levels; l++) {
+      StepLevel& L = a.lv[l];
+      L.pl = m->pl[l]; L.n = m->npts[l];
+      L.rows = kf_img->r[l]; L.cols = kf_img->c[l];
+      L.nblk = lm_grid_for(m, l, L.rows, L.cols);
+      L.I2 = cur_img->dev + cur_img->off[l];
+      L.k = make_level_k(m->K.f0, m->K.cx0, m->K.cy0, l);
+      L.max_iters = m->max_iters[l];
+      if (L.nblk > grid) grid = L.nblk;
+      budget += m->max_iters[l] > 0 ? m->max_iters[l] : 0;
+      bytes_per_level[l] = lm_level_bytes(m, l, L.rows, L.cols, L.nblk);
+    }
+    a.lambda0 = m->lambda; a.precision = m->precision; a.robust = m->robust; a.huber_delta = m->huber_delta;
+    a.trace = m->d_trace; a.cost_stat = m->d_cost; a.host_prog = m->d_prog;
+    memcpy(a.init, m->init, sizeof(a.init));
+    for (int it = 0; it < budget; it++) {
       if (poll) {
         const auto t0 = std::chrono::steady_clock::now();
-        while (seq - prog[0] > m->run_ahead && !prog[1 + l]) {
+        while (seq - prog[0] > m->run_ahead && !prog[1]) {
           if (m->idle_pump) m->idle_pump(m->idle_arg);
           if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { poll = false; break; }  // never hang
         }
-        if (prog[1 + l]) break;  // the level's loop has stopped on the device
+        if (prog[1]) break;  // every level has finished on the device
       }
-      if (fused) {
-        FusedArgs a;
-        a.pl = m->pl[l]; a.n = m->npts[l]; a.v = v; a.k = k;
-        a.st_in = st[seq & 1]; a.st_out = st[(seq + 1) & 1];
-        a.part_in = part[seq & 1]; a.part_out = part[(seq + 1) & 1];
-        a.level = l; a.first_of_level = (it == 0) ? 1 : 0; a.max_iters = m->max_iters[l];
-        a.lambda0 = m->lambda; a.precision = m->precision; a.robust = m->robust; a.huber_delta = m->huber_delta;
-        a.trace = m->d_trace; a.cost_stat = m->d_cost; a.host_prog = m->d_prog; a.seq = seq;
-        a.first_of_solve = (seq == 0) ? 1 : 0;
-        memcpy(a.init, m->init, sizeof(a.init));
-        const bool ev = m->ev_on && m->ev_pool && (size_t)(2 * launches + 1) < m->ev_pool->size();
-        if (ev) {
-          // timing pass: start / stop events bound to the dispatch itself (the kernel's own begin / end timestamps)
-          hipEvent_t e0 = (*m->ev_pool)[2 * launches], e1 = (*m->ev_pool)[2 * launches + 1];
-          if (m->use_list[l]) hipExtLaunchKernelGGL(lm_fused_kernel<true>, dim3(nblk), dim3(kLmBlock), 0, s, e0, e1, 0, a);
-          else hipExtLaunchKernelGGL(lm_fused_kernel<false>, dim3(nblk), dim3(kLmBlock), 0, s, e0, e1, 0, a);
-        } else if (m->use_list[l]) {
-          hipLaunchKernelGGL(lm_fused_kernel<true>, dim3(nblk), dim3(kLmBlock), 0, s, a);
-        } else {
-          hipLaunchKernelGGL(lm_fused_kernel<false>, dim3(nblk), dim3(kLmBlock), 0, s, a);
+      a.st_in = st[seq & 1]; a.st_out = st[(seq + 1) & 1];
+      a.part_in = part[seq & 1]; a.part_out = part[(seq + 1) & 1];
+      a.seq = seq; a.first_of_solve = (seq == 0) ? 1 : 0;
+      const bool ev = m->ev_on && m->ev_pool && (size_t)(2 * launches + 1) < m->ev_pool->size();
+      if (ev)  // timing pass: start / stop events bound to the dispatch itself (the kernel's own begin / end timestamps)
+        hipExtLaunchKernelGGL(lm_step_kernel, dim3(grid), dim3(kLmBlock), 0, s, (*m->ev_pool)[2 * launches],
+                              (*m->ev_pool)[2 * launches + 1], 0, a);
+      else
+        hipLaunchKernelGGL(lm_step_kernel, dim3(grid), dim3(kLmBlock), 0, s, a);
+      seq++;
+      launches++;
+    }
+  } else {
+    // ---- unfused pipeline (t-distribution mode, dense levels): residual kernel(s) + update kernel per evaluation ----
+    HIP_OK(hipMemcpyAsync(m->d_init, m->init, sizeof(float) * 16, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(lm_begin_solve_kernel, dim3(1), dim3(64), 0, s, m->d_state, m->d_init, m->d_cost);
+    for (int l = m->n_levels - 1; l >= 0; l--) {  // ref: src/lm_optimizer.cpp:92
+      LevelView v;
+      v.I1 = kf_img->dev + kf_img->off[l];
+      v.I2 = cur_img->dev + cur_img->off[l];
+      v.D1 = kf_dep->dev + kf_dep->off[l];
+      v.rows = kf_img->r[l]; v.cols = kf_img->c[l];
+      const LevelK k = make_level_k(m->K.f0, m->K.cx0, m->K.cy0, l);
+      const int nblk = lm_grid_for(m, l, v.rows, v.cols);
+      if (m->robust == 2 && lm_ensure_res(m, (size_t)v.rows * v.cols)) return -1;
+      bytes_per_level[l] = lm_level_bytes(m, l, v.rows, v.cols, nblk);
+      hipLaunchKernelGGL(lm_begin_level_kernel, dim3(1), dim3(64), 0, s, m->d_state, l, m->lambda, m->max_iters[l]);
+      for (int it = 0; it < m->max_iters[l]; it++) {  // ref: :117
+        if (poll) {
+          const auto t0 = std::chrono::steady_clock::now();
+          while (seq - prog[0] > m->run_ahead && !prog[2 + l]) {
+            if (m->idle_pump) m->idle_pump(m->idle_arg);
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { poll = false; break; }  // never hang
+          }
+          if (prog[2 + l]) break;  // the level's loop has stopped on the device
         }
-        seq++;
-      } else {
         seq++;
         lm_launch_eval(m, v, k, l, nblk);
         hipLaunchKernelGGL(lm_update_kernel<false>, dim3(1), dim3(kUpdThreads), 0, s, m->d_state, m->d_partials, nblk, l,
                            m->precision, m->max_iters[l], m->d_trace, m->d_cost, m->d_prog, seq,
                            (unsigned long long*)nullptr);
+        launches++;
       }
-      launches++;
     }
   }
   if (fused) {

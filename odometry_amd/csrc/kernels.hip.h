@@ -647,6 +647,8 @@ __device__ __forceinline__ void solve_damped_wave(const double* acc, float lambd
       }
     }
   }
+  // Reciprocal pivots: the diagonal lanes divide side by side (one divide latency for all six).
+  const double rdiag = (in && i == j && ((okmask >> i) & 1u)) ? 1.0 / a : 0.0;
   // Back substitution on wave-uniform values (compile-time indices, xs[] stays in registers).
   double xs[6];
 #pragma unroll
@@ -654,8 +656,7 @@ __device__ __forceinline__ void solve_damped_wave(const double* acc, float lambd
     double s = readlane_d(a, c * 8 + 6);
 #pragma unroll
     for (int jj = c + 1; jj < 6; jj++) s = s - readlane_d(a, c * 8 + jj) * xs[jj];
-    const double d = readlane_d(a, c * 8 + c);
-    xs[c] = ((okmask >> c) & 1u) ? s / d : 0.0;
+    xs[c] = ((okmask >> c) & 1u) ? s * readlane_d(rdiag, c * 8 + c) : 0.0;
   }
   if (lane == 0) {
 #pragma unroll
@@ -818,8 +819,21 @@ __device__ __forceinline__ void lm_fused_prologue(const LmState* __restrict__ st
                                                   LmState& s_sh, double* fold_sh, double* acc_sh, float* delta_sh,
                                                   int* flags_sh /* [4] */, LmTraceRow* __restrict__ trace,
                                                   float* __restrict__ cost_stat, bool publisher,
-                                                  const float* init /* non-null: first launch of a Solve */) {
+                                                  const float* init /* non-null: first launch of a Solve */,
+                                                  int nblk_hint /* rows worth loading before the state is known */) {
   const int t = threadIdx.x;
+  const int q = t & 31, seg = t >> 5;
+  // Speculative loads of the first chunk of partial rows, issued together with the state load: both are trips to
+  // another CU's data (L2 miss -> Infinity Cache), and the row count is only known once the state is here. Rows
+  // beyond pending_nblk are masked below; the buffer always holds kLmMaxBlocks rows, so the addresses are valid.
+  double r0[kFoldChunk];
+  if (!init && q < ODO_NACC) {
+#pragma unroll
+    for (int u = 0; u < kFoldChunk; u++) {
+      const int b = seg + 8 * u;
+      r0[u] = (b < nblk_hint) ? part_in[(size_t)b * ODO_NACC + q] : 0.0;
+    }
+  }
   if (init) {
     if (t == 0) {
       float m[16];
@@ -836,10 +850,16 @@ __device__ __forceinline__ void lm_fused_prologue(const LmState* __restrict__ st
   const bool pending = s_sh.pending != 0;  // block-uniform
   if (pending) {
     const int nblk = s_sh.pending_nblk;
-    const int q = t & 31, seg = t >> 5;
     double v = 0.0;
     if (q < ODO_NACC) {
-      for (int b0 = seg; b0 < nblk; b0 += 8 * kFoldChunk) {
+#pragma unroll
+      for (int u = 0; u < kFoldChunk; u++) {
+        const int b = seg + 8 * u;
+        // rows the speculative load did not cover (hint too small) are fetched now; same summation order either way
+        const double x = (b < nblk) ? ((b < nblk_hint) ? r0[u] : part_in[(size_t)b * ODO_NACC + q]) : 0.0;
+        v += x;
+      }
+      for (int b0 = seg + 8 * kFoldChunk; b0 < nblk; b0 += 8 * kFoldChunk) {
         double r[kFoldChunk];
 #pragma unroll
         for (int u = 0; u < kFoldChunk; u++) {
@@ -941,7 +961,7 @@ __global__ void __launch_bounds__(kLmBlock) lm_step_kernel(StepArgs a) {
   __shared__ int flags_sh[4];
   const bool publisher = (blockIdx.x == 0);
   lm_fused_prologue(a.st_in, a.part_in, a.lv, a.n_levels, a.lambda0, a.precision, s_sh, fold_sh, acc_sh, delta_sh, flags_sh,
-                    a.trace, a.cost_stat, publisher, a.first_of_solve ? a.init : nullptr);
+                    a.trace, a.cost_stat, publisher, a.first_of_solve ? a.init : nullptr, (int)gridDim.x);
   const bool run = (s_sh.active != 0 && s_sh.status == 0);  // block-uniform
   const int lvl = run ? s_sh.level : 0;
   const StepLevel& L = a.lv[lvl];
@@ -991,7 +1011,7 @@ __global__ void __launch_bounds__(kLmBlock) lm_fused_finalize_kernel(FinalizeArg
   __shared__ float delta_sh[8];
   __shared__ int flags_sh[4];
   lm_fused_prologue(a.st_in, a.part_in, nullptr, 0, 0.0f, a.precision, s_sh, fold_sh, acc_sh, delta_sh, flags_sh, a.trace,
-                    a.cost_stat, true, a.first_of_solve ? a.init : nullptr);
+                    a.cost_stat, true, a.first_of_solve ? a.init : nullptr, 8 * kFoldChunk);
   if (threadIdx.x < (int)(sizeof(LmState) / sizeof(int))) ((int*)a.st_out)[threadIdx.x] = ((const int*)&s_sh)[threadIdx.x];
   if (threadIdx.x == 0) {
     float m[16];

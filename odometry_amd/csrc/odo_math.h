@@ -356,13 +356,19 @@ ODO_HD void solve_damped(const double acc[ODO_NACC], float lambda, float delta[6
       }
     }
   }
+  // Back substitution with the reciprocals of the six pivots formed first (they are all known once the elimination
+  // is done): xs[c] = s * (1 / A[c][c]). On the device the six divides run side by side in six lanes instead of
+  // six times in a row on the critical path of every LM iteration.
+  double rinv[6];
+#pragma unroll
+  for (int c = 0; c < 6; c++) rinv[c] = ok[c] ? 1.0 / A[c][c] : 0.0;
   double xs[6];
 #pragma unroll
   for (int c = 5; c >= 0; c--) {
     double s = A[c][6];
 #pragma unroll
     for (int j = c + 1; j < 6; j++) s = s - A[c][j] * xs[j];
-    xs[c] = ok[c] ? s / A[c][c] : 0.0;
+    xs[c] = ok[c] ? s * rinv[c] : 0.0;
   }
 #pragma unroll
   for (int c = 0; c < 6; c++) delta[c] = (float)xs[c];

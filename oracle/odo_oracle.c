@@ -495,7 +495,7 @@ int orc_lm_accumulate(const float* I1, const float* I2, const float* D1, int row
 /* Damped normal equations (ref: src/lm_optimizer.cpp:145-151): A = JtWJ + lambda*diag(JtWJ), b = -JtWr.
  * The reference solves in fp32 with colPivHouseholderQr; here the fp64-accumulated
  * system is solved in fp64 by Gaussian elimination with partial pivoting (a zero pivot column yields a
- * zero step component) and the step is rounded to fp32. */
+ * zero step component; back substitution multiplies by the reciprocal pivot) and the step is rounded to fp32. */
 static void solve_damped(const double acc[29], float lambda, float delta[6]) {
   double A[6][7];
   int k = 0;
@@ -518,12 +518,14 @@ static void solve_damped(const double acc[29], float lambda, float delta[6]) {
       for (int j = c; j < 7; j++) A[i][j] = A[i][j] - f * A[c][j];
     }
   }
+  /* back substitution: x_c = s_c * (1 / pivot_c) */
   double xs[6];
   for (int c = 5; c >= 0; c--) {
     if (!piv_ok[c]) { xs[c] = 0.0; continue; }
+    const double rinv = 1.0 / A[c][c];
     double s = A[c][6];
     for (int j = c + 1; j < 6; j++) s = s - A[c][j] * xs[j];
-    xs[c] = s / A[c][c];
+    xs[c] = s * rinv;
   }
   for (int c = 0; c < 6; c++) delta[c] = (float)xs[c];
 }

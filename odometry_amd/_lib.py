@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libodometry_hip.so")
+LIB_PATH = os.environ.get("ODOMETRY_HIP_LIB") or os.path.join(_HERE, "lib", "libodometry_hip.so")
 
 MAX_LEVELS = 8
 NACC = 29

@@ -819,21 +819,8 @@ __device__ __forceinline__ void lm_fused_prologue(const LmState* __restrict__ st
                                                   LmState& s_sh, double* fold_sh, double* acc_sh, float* delta_sh,
                                                   int* flags_sh /* [4] */, LmTraceRow* __restrict__ trace,
                                                   float* __restrict__ cost_stat, bool publisher,
-                                                  const float* init /* non-null: first launch of a Solve */,
-                                                  int nblk_hint /* rows worth loading before the state is known */) {
+                                                  const float* init /* non-null: first launch of a Solve */) {
   const int t = threadIdx.x;
-  const int q = t & 31, seg = t >> 5;
-  // Speculative loads of the first chunk of partial rows, issued together with the state load: both are trips to
-  // another CU's data (L2 miss -> Infinity Cache), and the row count is only known once the state is here. Rows
-  // beyond pending_nblk are masked below; the buffer always holds kLmMaxBlocks rows, so the addresses are valid.
-  double r0[kFoldChunk];
-  if (!init && q < ODO_NACC) {
-#pragma unroll
-    for (int u = 0; u < kFoldChunk; u++) {
-      const int b = seg + 8 * u;
-      r0[u] = (b < nblk_hint) ? part_in[(size_t)b * ODO_NACC + q] : 0.0;
-    }
-  }
   if (init) {
     if (t == 0) {
       float m[16];
@@ -849,17 +836,13 @@ __device__ __forceinline__ void lm_fused_prologue(const LmState* __restrict__ st
   __syncthreads();
   const bool pending = s_sh.pending != 0;  // block-uniform
   if (pending) {
+    // (Loading the partial rows speculatively, together with the state, was measured and is slower: at the coarse
+    // levels it fetches ~100 rows that are not needed — 9.5 vs 8.9 us per launch.)
     const int nblk = s_sh.pending_nblk;
+    const int q = t & 31, seg = t >> 5;
     double v = 0.0;
     if (q < ODO_NACC) {
-#pragma unroll
-      for (int u = 0; u < kFoldChunk; u++) {
-        const int b = seg + 8 * u;
-        // rows the speculative load did not cover (hint too small) are fetched now; same summation order either way
-        const double x = (b < nblk) ? ((b < nblk_hint) ? r0[u] : part_in[(size_t)b * ODO_NACC + q]) : 0.0;
-        v += x;
-      }
-      for (int b0 = seg + 8 * kFoldChunk; b0 < nblk; b0 += 8 * kFoldChunk) {
+      for (int b0 = seg; b0 < nblk; b0 += 8 * kFoldChunk) {
         double r[kFoldChunk];
 #pragma unroll
         for (int u = 0; u < kFoldChunk; u++) {
@@ -961,7 +944,7 @@ __global__ void __launch_bounds__(kLmBlock) lm_step_kernel(StepArgs a) {
   __shared__ int flags_sh[4];
   const bool publisher = (blockIdx.x == 0);
   lm_fused_prologue(a.st_in, a.part_in, a.lv, a.n_levels, a.lambda0, a.precision, s_sh, fold_sh, acc_sh, delta_sh, flags_sh,
-                    a.trace, a.cost_stat, publisher, a.first_of_solve ? a.init : nullptr, (int)gridDim.x);
+                    a.trace, a.cost_stat, publisher, a.first_of_solve ? a.init : nullptr);
   const bool run = (s_sh.active != 0 && s_sh.status == 0);  // block-uniform
   const int lvl = run ? s_sh.level : 0;
   const StepLevel& L = a.lv[lvl];
@@ -1011,7 +994,7 @@ __global__ void __launch_bounds__(kLmBlock) lm_fused_finalize_kernel(FinalizeArg
   __shared__ float delta_sh[8];
   __shared__ int flags_sh[4];
   lm_fused_prologue(a.st_in, a.part_in, nullptr, 0, 0.0f, a.precision, s_sh, fold_sh, acc_sh, delta_sh, flags_sh, a.trace,
-                    a.cost_stat, true, a.first_of_solve ? a.init : nullptr, 8 * kFoldChunk);
+                    a.cost_stat, true, a.first_of_solve ? a.init : nullptr);
   if (threadIdx.x < (int)(sizeof(LmState) / sizeof(int))) ((int*)a.st_out)[threadIdx.x] = ((const int*)&s_sh)[threadIdx.x];
   if (threadIdx.x == 0) {
     float m[16];

@@ -93,6 +93,42 @@ def disparity_leg(api, seq, trk):
     return out
 
 
+def multi_sequence_leg(api, seq, order, n_seq, steps):
+    """Throughput with several independent sequences in flight on ONE GPU (each its own tracker: two HIP streams, two
+    host threads). Not `value`: configs[1] is a single sequence, whose frames are inherently serial; this shows how
+    much of the GPU a single latency-bound sequence leaves idle. The S trackers replay the same synthetic frames."""
+    import threading
+    trks = [api.Tracker(0) for _ in range(n_seq)]
+    devs = []
+    for t in trks:
+        d = [(t.upload_frame(l), t.upload_frame(r)) for l, r in zip(seq["left"], seq["right"])]
+        t.init(*d[0])
+        devs.append(d)
+    barrier = threading.Barrier(n_seq + 1)
+
+    def run(k):
+        a, b = np.zeros(16, np.float32), np.zeros(16, np.float32)
+        for i in order[:10]:
+            trks[k].track_into(devs[k][i][0], devs[k][i][1], a, b)
+        barrier.wait()
+        for i in order[:steps]:
+            trks[k].track_into(devs[k][i][0], devs[k][i][1], a, b)
+        barrier.wait()
+
+    th = [threading.Thread(target=run, args=(k,)) for k in range(n_seq)]
+    for t in th:
+        t.start()
+    barrier.wait()
+    t0 = time.perf_counter()
+    barrier.wait()
+    dt = time.perf_counter() - t0
+    for t in th:
+        t.join()
+    for t in trks:
+        t.close()
+    return dict(sequences_in_flight=n_seq, frames_per_s=round(n_seq * steps / dt, 1), steps_each=steps)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,6 +249,7 @@ def main():
         if world == 1 and not args.no_extras:
             out["roofline_dense_1080p"] = dense_1080p_leg(api, synth)
             out["disparity_1241x376"] = disparity_leg(api, seq, trk)
+            out["multi_sequence_1gpu"] = [multi_sequence_leg(api, seq, order, n, 100) for n in (2, 4, 8)]
         print(json.dumps(out))
     trk.close()
     if world > 1:

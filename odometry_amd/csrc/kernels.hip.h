@@ -592,8 +592,8 @@ struct LmTraceRow {
 constexpr int kTraceCap = 128;
 
 // Damped 6x6 solve spread over the lanes of ONE wavefront: lane (i*8 + j) owns A[i][j] of the augmented 6x7
-// system (j == 6 is the right-hand side). Exactly the operations of odo::solve_damped (Gaussian elimination with
-// partial pivoting in fp64, first-maximum pivot, zero pivot -> zero component), but a column step is ~40 wave
+// system (j == 6 is the right-hand side). Exactly the operations of odo::solve_damped (elimination down the diagonal
+// in fp64, zero pivot -> zero component, reciprocal-pivot back substitution), but a column step is ~40 wave
 // instructions instead of ~400 single-lane ones: a lone lane pays full issue latency per instruction, which made
 // the serial solve the longest kernel of the tracker. acc: 29 fp64 accumulators (LDS). delta_out: 6 floats (LDS).
 __device__ __forceinline__ double readlane_d(double v, int src_lane) {  // src_lane must be wave-uniform
@@ -616,34 +616,20 @@ __device__ __forceinline__ void solve_damped_wave(const double* acc, float lambd
       a = -acc[21 + i];
     }
   }
-  // Elimination. Wave-uniform values travel through v_readlane (SGPRs, a few cycles); only the three per-lane
-  // gathers of a column step use the LDS crossbar (ds_bpermute), and they are independent of each other.
+  // Elimination down the diagonal (no row exchanges: the system is symmetric positive semi-definite). The pivot is
+  // wave-uniform (v_readlane -> SGPRs); the pivot row and this lane's column-c entry are two independent
+  // ds_bpermute gathers per step.
   unsigned okmask = 0u;
 #pragma unroll
   for (int c = 0; c < 6; c++) {
-    int p = c;
-    double best = fabs(readlane_d(a, c * 8 + c));
-#pragma unroll
-    for (int r = c + 1; r < 6; r++) {
-      const double v = fabs(readlane_d(a, r * 8 + c));
-      if (v > best) { best = v; p = r; }
-    }
-    p = __builtin_amdgcn_readfirstlane(p);
-    if (best > 0.0) {  // wave-uniform
+    const double piv = readlane_d(a, c * 8 + c);
+    if (fabs(piv) > 0.0) {  // wave-uniform
       okmask |= 1u << c;
-      const double old_cc = readlane_d(a, c * 8 + c);   // A[c][c] before the row swap
-      const double piv = readlane_d(a, p * 8 + c);      // A[p][c]: the pivot once rows c and p are exchanged
-      const double from_p = __shfl(a, p * 8 + j, 64);   // old row p = pivot row after the exchange
-      const double from_c = __shfl(a, c * 8 + j, 64);
-      const double colv = __shfl(a, (i < 6 ? i : 5) * 8 + c, 64);  // A[i][c] before the exchange
-      const double mycol = (i == p) ? old_cc : colv;    // row p holds the old row c afterwards
-      if (p != c) {
-        if (i == c) a = from_p;
-        else if (i == p) a = from_c;
-      }
+      const double prow = __shfl(a, c * 8 + j, 64);
+      const double mycol = __shfl(a, (i < 6 ? i : 5) * 8 + c, 64);
       if (in && i > c && j >= c) {
         const double f = mycol / piv;
-        a = a - f * from_p;
+        a = a - f * prow;
       }
     }
   }

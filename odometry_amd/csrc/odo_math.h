@@ -311,9 +311,11 @@ ODO_HD void se3_left_update(const Se3& delta, const Se3& cur, Se3* out) {
 }
 
 // Damped normal equations A = JtWJ + lambda*diag(JtWJ), b = -JtWr (lm_optimizer.cpp:145-151), solved in fp64
-// by Gaussian elimination with partial pivoting; a zero pivot gives a zero step component. Step rounded to fp32.
-// Written with compile-time row/column indices only (row swaps are predicated exchanges), so on the device the
-// 6x7 system lives in registers — no scratch memory, no dynamic indexing.
+// ("fp64 LDL^T or QR of the fp64-accumulated system"). A is symmetric positive semi-definite
+// (a weighted Gram matrix with a scaled-up diagonal), so elimination runs down the diagonal without row exchanges —
+// the LDL^T order of operations. A zero pivot (a Jacobian column that is identically zero) leaves that step
+// component at zero. Back substitution multiplies by the reciprocal pivots. The step is rounded to fp32.
+// Written with compile-time indices only, so on the device the 6x7 system lives in registers.
 ODO_HD void solve_damped(const double acc[ODO_NACC], float lambda, float delta[6]) {
   double A[6][7];
   {
@@ -332,22 +334,8 @@ ODO_HD void solve_damped(const double acc[ODO_NACC], float lambda, float delta[6
   bool ok[6];
 #pragma unroll
   for (int c = 0; c < 6; c++) {
-    int p = c;
-    double best = fabs(A[c][c]);
-#pragma unroll
-    for (int i = c + 1; i < 6; i++) {
-      const double v = fabs(A[i][c]);
-      if (v > best) { best = v; p = i; }
-    }
-    ok[c] = (best > 0.0);
+    ok[c] = (fabs(A[c][c]) > 0.0);
     if (ok[c]) {
-#pragma unroll
-      for (int i = c + 1; i < 6; i++) {
-        if (p == i) {
-#pragma unroll
-          for (int j = 0; j < 7; j++) { const double t = A[c][j]; A[c][j] = A[i][j]; A[i][j] = t; }
-        }
-      }
 #pragma unroll
       for (int i = c + 1; i < 6; i++) {
         const double f = A[i][c] / A[c][c];
@@ -356,9 +344,6 @@ ODO_HD void solve_damped(const double acc[ODO_NACC], float lambda, float delta[6
       }
     }
   }
-  // Back substitution with the reciprocals of the six pivots formed first (they are all known once the elimination
-  // is done): xs[c] = s * (1 / A[c][c]). On the device the six divides run side by side in six lanes instead of
-  // six times in a row on the critical path of every LM iteration.
   double rinv[6];
 #pragma unroll
   for (int c = 0; c < 6; c++) rinv[c] = ok[c] ? 1.0 / A[c][c] : 0.0;

@@ -493,9 +493,10 @@ int orc_lm_accumulate(const float* I1, const float* I2, const float* D1, int row
 }
 
 /* Damped normal equations (ref: src/lm_optimizer.cpp:145-151): A = JtWJ + lambda*diag(JtWJ), b = -JtWr.
- * The reference solves in fp32 with colPivHouseholderQr; here the fp64-accumulated
- * system is solved in fp64 by Gaussian elimination with partial pivoting (a zero pivot column yields a
- * zero step component; back substitution multiplies by the reciprocal pivot) and the step is rounded to fp32. */
+ * The reference solves in fp32 with colPivHouseholderQr; here ("fp64 LDL^T or QR of the
+ * fp64-accumulated system") the symmetric positive semi-definite system is eliminated down its diagonal in fp64
+ * without row exchanges (the LDL^T order of operations); a zero pivot (an identically zero Jacobian column) yields a
+ * zero step component; back substitution multiplies by the reciprocal pivot; the step is rounded to fp32. */
 static void solve_damped(const double acc[29], float lambda, float delta[6]) {
   double A[6][7];
   int k = 0;
@@ -507,18 +508,13 @@ static void solve_damped(const double acc[29], float lambda, float delta[6]) {
   }
   int piv_ok[6];
   for (int c = 0; c < 6; c++) {
-    int p = c;
-    double best = fabs(A[c][c]);
-    for (int i = c + 1; i < 6; i++) if (fabs(A[i][c]) > best) { best = fabs(A[i][c]); p = i; }
-    if (!(best > 0.0)) { piv_ok[c] = 0; continue; }
-    piv_ok[c] = 1;
-    if (p != c) for (int j = 0; j < 7; j++) { const double t = A[c][j]; A[c][j] = A[p][j]; A[p][j] = t; }
+    piv_ok[c] = fabs(A[c][c]) > 0.0;
+    if (!piv_ok[c]) continue;
     for (int i = c + 1; i < 6; i++) {
       const double f = A[i][c] / A[c][c];
       for (int j = c; j < 7; j++) A[i][j] = A[i][j] - f * A[c][j];
     }
   }
-  /* back substitution: x_c = s_c * (1 / pivot_c) */
   double xs[6];
   for (int c = 5; c >= 0; c--) {
     if (!piv_ok[c]) { xs[c] = 0.0; continue; }

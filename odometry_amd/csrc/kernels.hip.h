@@ -796,59 +796,15 @@ struct StepArgs {
 
 constexpr int kFoldChunk = 16;
 
-// Prologue shared by the step kernel and the finalize kernel: leaves the advanced state in s_sh.
-// fold_sh: >= 8 x 32 doubles of scratch. All 256 threads must call it. `lv` non-null: also walk the pyramid —
-// when the level's loop has ended, begin the next coarser-to-finer level right here (ref: src/lm_optimizer.cpp:92,
-// 110-115,156), so the launch that learns "level l is done" is also the first evaluation of level l-1.
-__device__ __forceinline__ void lm_fused_prologue(const LmState* __restrict__ st_in, const double* __restrict__ part_in,
-                                                  const StepLevel* lv, int n_levels, float lambda0, float precision,
-                                                  LmState& s_sh, double* fold_sh, double* acc_sh, float* delta_sh,
-                                                  int* flags_sh /* [4] */, LmTraceRow* __restrict__ trace,
-                                                  float* __restrict__ cost_stat, bool publisher,
-                                                  const float* init /* non-null: first launch of a Solve */) {
+// The LM state machine of one evaluation, run by wave 0 of a block (all threads of the block must call it; it ends
+// with a block barrier): lm_decide on lane 0, the 6x6 solve across the wavefront, exp / compose on lane 0, the trace
+// row, and — when `lv` is given — the walk down the pyramid (ref: src/lm_optimizer.cpp:92,110-115,156).
+// have_acc: acc_sh holds the 29 sums of an evaluation at s_sh.T that has not been consumed yet.
+__device__ __forceinline__ void lm_state_machine(bool pending, const StepLevel* lv, int n_levels, float lambda0,
+                                                 float precision, LmState& s_sh, double* acc_sh, float* delta_sh,
+                                                 int* flags_sh /* [4] */, LmTraceRow* __restrict__ trace,
+                                                 float* __restrict__ cost_stat, bool publisher) {
   const int t = threadIdx.x;
-  if (init) {
-    if (t == 0) {
-      float m[16];
-      for (int i = 0; i < 16; i++) m[i] = init[i];
-      lm_begin_solve(&s_sh, m);
-      s_sh.level = -1; s_sh.iter = 0; s_sh.lambda = 0.0f; s_sh.err_last = 1e+10f;
-      for (int i = 0; i < 16; i++) s_sh.T[i] = m[i];
-    }
-    if (publisher && t < 16) cost_stat[t] = 0.0f;
-  } else if (t < (int)(sizeof(LmState) / sizeof(int))) {
-    ((int*)&s_sh)[t] = ((const int*)st_in)[t];
-  }
-  __syncthreads();
-  const bool pending = s_sh.pending != 0;  // block-uniform
-  if (pending) {
-    // (Loading the partial rows speculatively, together with the state, was measured and is slower: at the coarse
-    // levels it fetches ~100 rows that are not needed — 9.5 vs 8.9 us per launch.)
-    const int nblk = s_sh.pending_nblk;
-    const int q = t & 31, seg = t >> 5;
-    double v = 0.0;
-    if (q < ODO_NACC) {
-      for (int b0 = seg; b0 < nblk; b0 += 8 * kFoldChunk) {
-        double r[kFoldChunk];
-#pragma unroll
-        for (int u = 0; u < kFoldChunk; u++) {
-          const int b = b0 + 8 * u;
-          r[u] = (b < nblk) ? part_in[(size_t)b * ODO_NACC + q] : 0.0;  // all loads of the chunk in flight together
-        }
-#pragma unroll
-        for (int u = 0; u < kFoldChunk; u++) v += r[u];
-      }
-    }
-    fold_sh[seg * 32 + q] = v;
-    __syncthreads();
-    if (t < ODO_NACC) {
-      double a = 0.0;
-#pragma unroll
-      for (int g = 0; g < 8; g++) a += fold_sh[g * 32 + t];
-      acc_sh[t] = a;
-    }
-    __syncthreads();
-  }
   if (t < 64) {  // wave 0: the scalar state machine on lane 0, the 6x6 solve across the wave
     if (t == 0) {
       flags_sh[0] = 0;  // need_step
@@ -905,6 +861,62 @@ __device__ __forceinline__ void lm_fused_prologue(const LmState* __restrict__ st
   __syncthreads();
 }
 
+// Prologue shared by the step kernel and the finalize kernel: leaves the advanced state in s_sh.
+// fold_sh: >= 8 x 32 doubles of scratch. All 256 threads must call it. `lv` non-null: also walk the pyramid —
+// when the level's loop has ended, begin the next coarser-to-finer level right here (ref: src/lm_optimizer.cpp:92,
+// 110-115,156), so the launch that learns "level l is done" is also the first evaluation of level l-1.
+__device__ __forceinline__ void lm_fused_prologue(const LmState* __restrict__ st_in, const double* __restrict__ part_in,
+                                                  const StepLevel* lv, int n_levels, float lambda0, float precision,
+                                                  LmState& s_sh, double* fold_sh, double* acc_sh, float* delta_sh,
+                                                  int* flags_sh /* [4] */, LmTraceRow* __restrict__ trace,
+                                                  float* __restrict__ cost_stat, bool publisher,
+                                                  const float* init /* non-null: first launch of a Solve */) {
+  const int t = threadIdx.x;
+  if (init) {
+    if (t == 0) {
+      float m[16];
+      for (int i = 0; i < 16; i++) m[i] = init[i];
+      lm_begin_solve(&s_sh, m);
+      s_sh.level = -1; s_sh.iter = 0; s_sh.lambda = 0.0f; s_sh.err_last = 1e+10f;
+      for (int i = 0; i < 16; i++) s_sh.T[i] = m[i];
+    }
+    if (publisher && t < 16) cost_stat[t] = 0.0f;
+  } else if (t < (int)(sizeof(LmState) / sizeof(int))) {
+    ((int*)&s_sh)[t] = ((const int*)st_in)[t];
+  }
+  __syncthreads();
+  const bool pending = s_sh.pending != 0;  // block-uniform
+  if (pending) {
+    // (Loading the partial rows speculatively, together with the state, was measured and is slower: at the coarse
+    // levels it fetches ~100 rows that are not needed — 9.5 vs 8.9 us per launch.)
+    const int nblk = s_sh.pending_nblk;
+    const int q = t & 31, seg = t >> 5;
+    double v = 0.0;
+    if (q < ODO_NACC && seg < 8) {  // 8 segments of 32 lanes fold; wider blocks (coarse kernel) leave the rest idle
+      for (int b0 = seg; b0 < nblk; b0 += 8 * kFoldChunk) {
+        double r[kFoldChunk];
+#pragma unroll
+        for (int u = 0; u < kFoldChunk; u++) {
+          const int b = b0 + 8 * u;
+          r[u] = (b < nblk) ? part_in[(size_t)b * ODO_NACC + q] : 0.0;  // all loads of the chunk in flight together
+        }
+#pragma unroll
+        for (int u = 0; u < kFoldChunk; u++) v += r[u];
+      }
+    }
+    if (seg < 8) fold_sh[seg * 32 + q] = v;
+    __syncthreads();
+    if (t < ODO_NACC) {
+      double a = 0.0;
+#pragma unroll
+      for (int g = 0; g < 8; g++) a += fold_sh[g * 32 + t];
+      acc_sh[t] = a;
+    }
+    __syncthreads();
+  }
+  lm_state_machine(pending, lv, n_levels, lambda0, precision, s_sh, acc_sh, delta_sh, flags_sh, trace, cost_stat, publisher);
+}
+
 __device__ __forceinline__ void lm_fused_publish(LmState& s_sh, LmState* __restrict__ st_out, int* __restrict__ host_prog,
                                                  int seq) {
   const int t = threadIdx.x;
@@ -956,6 +968,75 @@ __global__ void __launch_bounds__(kLmBlock) lm_step_kernel(StepArgs a) {
     __syncthreads();
     lm_fused_publish(s_sh, a.st_out, a.host_prog, a.seq);
   }
+}
+
+// Coarse pyramid levels inside ONE workgroup. A level with a few thousand points does not fill more than a handful of
+// CUs, so spreading it over blocks only buys kernel boundaries and trips through L2 for the state and the partial
+// sums. Here a single 512-thread workgroup loops evaluate -> reduce (LDS) -> state machine for every level
+// >= min_level: no launch, no global partials, no state reload between iterations. It hands over to the generic step
+// launches with the next level already begun.
+constexpr int kCoarseBlock = 512;
+constexpr int kCoarseMaxPoints = 4096;  // levels with more points than this go to the multi-block step kernel
+
+// 29 sums of a 512-thread block into LDS (out), two rounds of 15 + 14 quantities through one 62 KB buffer.
+__device__ __forceinline__ void block_reduce_acc_coarse(const double acc[ODO_NACC], double* red /* [15][520] */, double* out) {
+  constexpr int W = kCoarseBlock + kRedPad;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int round = 0; round < 2; round++) {
+    const int q0 = round * 15, nq = round == 0 ? 15 : ODO_NACC - 15;
+    if (round) __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 15; q++)
+      if (q < nq) red[q * W + t] = acc[q0 + q];
+    __syncthreads();
+    if (t < nq * 8) {
+      const int q = t >> 3, s = t & 7;
+      double v = 0.0;
+#pragma unroll 8
+      for (int i = 0; i < kCoarseBlock / 8; i++) v += red[q * W + i * 8 + s];
+      v += __shfl_xor(v, 4, 8);
+      v += __shfl_xor(v, 2, 8);
+      v += __shfl_xor(v, 1, 8);
+      if (s == 0) out[q0 + q] = v;
+    }
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int min_level) {
+  __shared__ LmState s_sh;
+  __shared__ double red_sh[15 * (kCoarseBlock + kRedPad)];  // reduction buffer; its head doubles as the fold scratch
+  __shared__ double acc_sh[32];
+  __shared__ float delta_sh[8];
+  __shared__ int flags_sh[4];
+  // state in (or initialised), a pending evaluation of an earlier launch consumed, pyramid walk started
+  lm_fused_prologue(a.st_in, a.part_in, a.lv, a.n_levels, a.lambda0, a.precision, s_sh, red_sh, acc_sh, delta_sh, flags_sh,
+                    a.trace, a.cost_stat, true, a.first_of_solve ? a.init : nullptr);
+  for (int guard = 0; guard < 4096; guard++) {
+    const bool run = (s_sh.active != 0 && s_sh.status == 0 && s_sh.level >= min_level);  // block-uniform
+    if (!run) break;
+    const StepLevel& L = a.lv[s_sh.level];
+    float T[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) T[i] = s_sh.T[i];
+    double acc[ODO_NACC];
+#pragma unroll
+    for (int q = 0; q < ODO_NACC; q++) acc[q] = 0.0;
+    for (int idx = threadIdx.x; idx < L.n; idx += kCoarseBlock) {
+      const PointK p = load_point(L.pl, idx);
+      int ui, vi;
+      if (!warp_point(p, T, L.k, L.rows, L.cols, &ui, &vi)) continue;
+      float r, J[6];
+      residual_jacobian(p, L.I2, L.rows, L.cols, ui, vi, &r, J);
+      accumulate_row(acc, r, robust_weight(r, a.robust, a.huber_delta, 1.0f), J);
+    }
+    __syncthreads();  // everyone has read s_sh.T before the state machine rewrites it
+    block_reduce_acc_coarse(acc, red_sh, acc_sh);
+    lm_state_machine(true, a.lv, a.n_levels, a.lambda0, a.precision, s_sh, acc_sh, delta_sh, flags_sh, a.trace, a.cost_stat,
+                     true);
+  }
+  lm_fused_publish(s_sh, a.st_out, a.host_prog, a.seq);
 }
 
 // End of a fused Solve: consume the last pending evaluation, then affine_ = current_estimate.matrix()

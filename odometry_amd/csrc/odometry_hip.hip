@@ -306,6 +306,7 @@ struct odo_lm {
   long ev_launches, ev_active;
   int trace_stale;
   float* h_res; float* d_res_map; int* h_done; int* d_done; int token;  // host-mapped result + completion word
+  int coarse;  // 1 = levels with <= kCoarseMaxPoints points run inside one workgroup (fused pipeline)
   int fused;  // 1 = one launch per evaluation (robust 0/1); 0 = separate residual / update kernels
   int mode;  // 0 auto (list when <= half of the interior has depth), 1 always dense scan, 2 always list
   void (*idle_pump)(void*);  // called while the host waits for the device (the tracker feeds its depth stream here)
@@ -359,6 +360,7 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
   HIP_OK(hipHostMalloc((void**)&m->h_npts, sizeof(int) * ODO_MAX_LEVELS, hipHostMallocDefault));
   m->mode = getenv("ODO_LM_MODE") ? atoi(getenv("ODO_LM_MODE")) : 0;
   m->fused = getenv("ODO_LM_UNFUSED") ? 0 : 1;
+  m->coarse = getenv("ODO_LM_NO_COARSE") ? 0 : 1;
   m->poll = getenv("ODO_NO_POLL") ? 0 : 1;
   m->run_ahead = getenv("ODO_RUN_AHEAD") ? atoi(getenv("ODO_RUN_AHEAD")) : 2;
   HIP_OK(hipMemsetAsync(m->d_trace, 0, sizeof(LmTraceRow) * kTraceCap, ctx->stream));
@@ -586,6 +588,26 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
     a.lambda0 = m->lambda; a.precision = m->precision; a.robust = m->robust; a.huber_delta = m->huber_delta;
     a.trace = m->d_trace; a.cost_stat = m->d_cost; a.host_prog = m->d_prog;
     memcpy(a.init, m->init, sizeof(a.init));
+    // Coarse levels (few points) run inside one workgroup: one launch covers every level >= min_level.
+    int min_level = m->n_levels;
+    while (min_level > 0 && m->npts[min_level - 1] <= kCoarseMaxPoints) min_level--;
+    if (!m->coarse) min_level = m->n_levels;
+    if (min_level < m->n_levels) {
+      int coarse_budget = 0;
+      for (int l = min_level; l < m->n_levels; l++) coarse_budget += m->max_iters[l] > 0 ? m->max_iters[l] : 0;
+      budget -= coarse_budget;
+      a.st_in = st[seq & 1]; a.st_out = st[(seq + 1) & 1];
+      a.part_in = part[seq & 1]; a.part_out = part[(seq + 1) & 1];
+      a.seq = seq; a.first_of_solve = 1;
+      const bool ev = m->ev_on && m->ev_pool && m->ev_pool->size() >= 2;
+      if (ev)
+        hipExtLaunchKernelGGL(lm_coarse_kernel, dim3(1), dim3(kCoarseBlock), 0, s, (*m->ev_pool)[0], (*m->ev_pool)[1], 0, a,
+                              min_level);
+      else
+        hipLaunchKernelGGL(lm_coarse_kernel, dim3(1), dim3(kCoarseBlock), 0, s, a, min_level);
+      seq++;
+      launches++;
+    }
     for (int it = 0; it < budget; it++) {
       if (poll) {
         const auto t0 = std::chrono::steady_clock::now();

@@ -102,7 +102,8 @@ __device__ __forceinline__ float pd_v(float r0, float r1, float r2, float r3, fl
   return (((r2 * 6.0f + (r1 + r3) * 4.0f) + r0) + r4) * (1.0f / 256.0f);
 }
 
-__global__ void __launch_bounds__(256) image_pyramid_fused_kernel(const float* __restrict__ src, PyrOut o) {
+constexpr int kPyrThreads = 1024;  // the phases are short dependent LDS passes: more threads = fewer trips per thread
+__global__ void __launch_bounds__(kPyrThreads) image_pyramid_fused_kernel(const float* __restrict__ src, PyrOut o) {
   __shared__ float in_t[kPIn * kPInS];
   __shared__ float h_t[kPIn * kPL1];   // horizontal pass (reused per level)
   __shared__ float l1_t[kPL1 * kPL1];
@@ -111,13 +112,13 @@ __global__ void __launch_bounds__(256) image_pyramid_fused_kernel(const float* _
   const int ty = blockIdx.y, tx = blockIdx.x;
   const int R0 = o.rows[0], C0 = o.cols[0];
   const int iy0 = kPT * ty - 14, ix0 = kPT * tx - 14;  // input halo origin (level-0 coordinates, may be negative)
-  for (int e = t; e < kPIn * kPIn; e += 256) {
+  for (int e = t; e < kPIn * kPIn; e += kPyrThreads) {
     const int i = e / kPIn, j = e % kPIn;
     in_t[i * kPInS + j] = src[(size_t)reflect101(iy0 + i, R0) * C0 + reflect101(ix0 + j, C0)];
   }
   __syncthreads();
   // ---- level 0: blur (or copy) of the owned 32x32 ----
-  for (int e = t; e < kPT * kPT; e += 256) {
+  for (int e = t; e < kPT * kPT; e += kPyrThreads) {
     const int y = kPT * ty + e / kPT, x = kPT * tx + e % kPT;
     if (y < R0 && x < C0) {
       const int i = y - iy0, j = x - ix0;
@@ -143,7 +144,7 @@ __global__ void __launch_bounds__(256) image_pyramid_fused_kernel(const float* _
   const int y1hi = min(16 * ty + 18, R1 - 1), x1hi = min(16 * tx + 18, C1 - 1);
   const int n1y = y1hi - y1lo + 1, n1x = x1hi - x1lo + 1;
   // horizontal pass over every input row of the halo, for the needed L1 columns
-  for (int e = t; e < kPIn * kPL1; e += 256) {
+  for (int e = t; e < kPIn * kPL1; e += kPyrThreads) {
     const int i = e / kPL1, jx = e % kPL1;
     if (jx < n1x) {
       const int x1 = x1lo + jx;
@@ -155,7 +156,7 @@ __global__ void __launch_bounds__(256) image_pyramid_fused_kernel(const float* _
     }
   }
   __syncthreads();
-  for (int e = t; e < kPL1 * kPL1; e += 256) {
+  for (int e = t; e < kPL1 * kPL1; e += kPyrThreads) {
     const int iy = e / kPL1, jx = e % kPL1;
     if (iy < n1y && jx < n1x) {
       const int y1 = y1lo + iy;
@@ -175,7 +176,7 @@ __global__ void __launch_bounds__(256) image_pyramid_fused_kernel(const float* _
   const int y2lo = max(8 * ty - 2, 0), x2lo = max(8 * tx - 2, 0);
   const int y2hi = min(8 * ty + 8, R2 - 1), x2hi = min(8 * tx + 8, C2 - 1);
   const int n2y = y2hi - y2lo + 1, n2x = x2hi - x2lo + 1;
-  for (int e = t; e < kPL1 * kPL2; e += 256) {  // horizontal pass over L1 halo rows
+  for (int e = t; e < kPL1 * kPL2; e += kPyrThreads) {  // horizontal pass over L1 halo rows
     const int i = e / kPL2, jx = e % kPL2;
     if (i < n1y && jx < n2x) {
       const int x2 = x2lo + jx;
@@ -187,7 +188,7 @@ __global__ void __launch_bounds__(256) image_pyramid_fused_kernel(const float* _
     }
   }
   __syncthreads();
-  for (int e = t; e < kPL2 * kPL2; e += 256) {
+  for (int e = t; e < kPL2 * kPL2; e += kPyrThreads) {
     const int iy = e / kPL2, jx = e % kPL2;
     if (iy < n2y && jx < n2x) {
       const int y2 = y2lo + iy;
@@ -204,7 +205,7 @@ __global__ void __launch_bounds__(256) image_pyramid_fused_kernel(const float* _
   __syncthreads();
   // ---- level 3: the owned 4x4 ----
   const int R3 = o.rows[3], C3 = o.cols[3];
-  for (int e = t; e < kPL2 * 4; e += 256) {  // horizontal pass over L2 halo rows for the 4 owned columns
+  for (int e = t; e < kPL2 * 4; e += kPyrThreads) {  // horizontal pass over L2 halo rows for the 4 owned columns
     const int i = e / 4, jx = e % 4;
     const int x3 = 4 * tx + jx;
     if (i < n2y && x3 < C3) {

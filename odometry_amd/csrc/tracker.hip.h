@@ -20,6 +20,7 @@ struct odo_tracker {
   DepthJob job;
   int job_stage;  // 0 idle, 1 depth launches in flight, 2 depth tail enqueued (pyramids next), 3 all enqueued
   int job_err;
+  int pre_img_on_a;  // 1: the frame's second image pyramid (:251) is built on stream A after the Solve
   // overlap_depth == 2: a helper host thread feeds stream B (ComputeDepth + candidate pyramids) while the calling
   // thread feeds stream A (pose LM). Host launch rate, not the GPU, bounds a latency-bound frame loop.
   std::thread worker;
@@ -85,7 +86,7 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
   t->kf_img = t->kf_dep = t->cur_img = t->pre_img = t->pre_dep = nullptr;
   t->d_val = nullptr; t->d_disp = t->d_dep = nullptr; t->ev_inputs = nullptr;
   t->n_keyframes = t->frame_id = t->last_evals = t->last_depth_iters = t->last_valid = 0;
-  t->job_stage = t->job_err = 0;
+  t->job_stage = t->job_err = 0; t->pre_img_on_a = 0;
   t->w_state.store(0); t->w_left = t->w_right = nullptr; t->w_rc = 0; t->w_err[0] = 0;
   t->p = *p;
   float eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
@@ -135,7 +136,7 @@ static void tracker_job_pump(void* arg) {
   if (r < 0) { t->job_err = 1; t->job_stage = 3; return; }
   if (r > 0) {
     const odo_tracker_params& p = t->p;
-    if (pyr_build(t->pre_img, t->job.left, p.smooth_image)) t->job_err = 1;  // :251 (built a second time, as the runner does)
+    if (!t->pre_img_on_a && pyr_build(t->pre_img, t->job.left, p.smooth_image)) t->job_err = 1;  // :251
     if (pyr_build(t->pre_dep, t->d_dep, 0)) t->job_err = 1;                   // :252
     if (depth_job_stats(t->depth, &t->job)) t->job_err = 1;  // completion word AFTER the pyramids: it covers them too
     t->job_stage = 3;
@@ -159,7 +160,9 @@ static void tracker_worker_main(odo_tracker* t) {
     const int st = t->w_state.load(std::memory_order_acquire);
     if (st == 3) return;
     if (st != 1) {
-      if (++idle_spins > 20000) std::this_thread::sleep_for(std::chrono::microseconds(50));  // back off when idle
+      // Spin while a sequence is being tracked (the next job arrives within a fraction of a millisecond and a
+      // sleeping thread wakes ~100 us late); back off only after ~10 ms without work.
+      if (++idle_spins > 20000000) std::this_thread::sleep_for(std::chrono::microseconds(200));
       continue;
     }
     idle_spins = 0;
@@ -231,6 +234,7 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
   const odo_tracker_params& p = t->p;
   HIP_OK(hipSetDevice(t->ctx_a->device));
   t->frame_id++;
+  t->pre_img_on_a = p.overlap_depth != 0;
   if (p.overlap_depth == 2) {
     // helper thread: the whole stream-B job (ComputeDepth, candidate pyramids, final sync) runs beside this thread
     t->w_left = left; t->w_right = right;
@@ -247,6 +251,13 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
   float T[16];
   const int st = odo_lm_solve(t->lm, t->kf_img, t->kf_dep, t->cur_img, T);             // :215 (synchronises stream A)
   t->lm->idle_pump = nullptr;
+  if (t->pre_img_on_a) {
+    // :251 — the runner builds the frame's image pyramid a second time. It depends on the image only, so it goes to
+    // stream A, which is idle from here to the end of the frame while stream B finishes the depth. Ordered before
+    // the next frame's Solve by the stream itself.
+    t->pre_img->ctx = t->ctx_a;
+    if (pyr_build(t->pre_img, left, p.smooth_image)) return -1;
+  }
   if (p.overlap_depth == 2) {
     while (t->w_state.load(std::memory_order_acquire) != 2) { /* spin: the job is ~0.2 ms */ }
     t->w_state.store(0, std::memory_order_release);

@@ -184,6 +184,7 @@ def main():
     for i in order[:args.warmup]:
         step(i)
     barrier()
+    trk.timing()  # reset the host-clock diagnostics
     t0 = time.perf_counter()
     for i in order[args.warmup:]:
         step(i)
@@ -197,6 +198,7 @@ def main():
         elapsed = float(tt.item())
 
     fps = args.steps * world / elapsed
+    host_timing = trk.timing()
     if rank == 0:
         # --- roofline of the dominant kernel (lm_fused_kernel: LM update prologue + residual / normal-equation pass):
         # a second pass over the same frames with every launch bracketed by HIP events on the kernel's own stream.
@@ -228,6 +230,7 @@ def main():
                                overlap_depth=0 if args.no_overlap else args.overlap, gather_every=args.gather_every),
                    roofline=roof,
                    lm_evals_per_frame=round(float(np.mean(evals)), 2),
+                   host_us_per_frame={k: round(v, 1) for k, v in host_timing.items()},
                    keyframes=trk.stats()["n_keyframes"])
         if world == 1 and args.cpu_frames > 0:
             n = min(args.cpu_frames, args.steps)

@@ -210,6 +210,9 @@ int odo_tracker_outputs(const odo_tracker* t, const uint8_t** val_dev, const flo
  * (12 B per interior pixel + the fp64 partials written) and the number of residuals it produced. */
 int odo_tracker_time_residual(odo_tracker* t, int level, int reps, float* mean_us, float* min_us,
                               double* algorithmic_bytes, int* n_points);
+/* Diagnostics: host-clock averages per tracked frame since the last call, microseconds:
+ * {track() call, Solve on stream A, stream-B job on the helper thread, wait for the helper}. */
+int odo_tracker_timing(odo_tracker* t, double out[4]);
 odo_lm* odo_tracker_lm(odo_tracker* t);
 odo_ctx* odo_tracker_ctx(odo_tracker* t);
 int odo_tracker_destroy(odo_tracker* t);

@@ -94,6 +94,7 @@ SIGNATURES = {
     "odo_tracker_stats": (C.c_int, [_vp, _ip, _ip, _ip, _ip]),
     "odo_tracker_outputs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "odo_tracker_time_residual": (C.c_int, [_vp, C.c_int, C.c_int, _fp, _fp, _dp, _ip]),
+    "odo_tracker_timing": (C.c_int, [_vp, _dp]),
     "odo_tracker_lm": (_vp, [_vp]),
     "odo_tracker_ctx": (_vp, [_vp]),
     "odo_tracker_destroy": (C.c_int, [_vp]),

@@ -439,6 +439,11 @@ class Tracker:
         L.check(self.lib.odo_lm_event_stats(lm, C.byref(us), C.byref(n), C.byref(a), C.byref(b)), "odo_lm_event_stats")
         return dict(total_us=us.value, launches=n.value, active_launches=a.value, bytes=b.value)
 
+    def timing(self):
+        out = (C.c_double * 4)()
+        L.check(self.lib.odo_tracker_timing(self.h, out), "odo_tracker_timing")
+        return dict(frame_us=out[0], solve_us=out[1], depth_job_us=out[2], wait_helper_us=out[3])
+
     def time_residual(self, level, reps=50):
         mean, mn, b, n = C.c_float(0), C.c_float(0), C.c_double(0), C.c_int(0)
         L.check(self.lib.odo_tracker_time_residual(self.h, level, reps, C.byref(mean), C.byref(mn), C.byref(b),

@@ -936,6 +936,7 @@ __device__ __forceinline__ void lm_fused_publish(LmState& s_sh, LmState* __restr
 // issues identical launches until the device reports that the Solve is finished; the grid is sized for the largest
 // level and the blocks a coarser level does not need stop after the (redundant, parallel) prologue.
 __global__ void __launch_bounds__(kLmBlock) lm_step_kernel(StepArgs a) {
+  __builtin_amdgcn_s_setprio(3);  // see lm_coarse_kernel
   __shared__ LmState s_sh;
   __shared__ double fold_sh[8 * 32];
   __shared__ double acc_sh[32];
@@ -1006,6 +1007,9 @@ __device__ __forceinline__ void block_reduce_acc_coarse(const double acc[ODO_NAC
 }
 
 __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int min_level) {
+  // The pose LM is the latency-critical chain of a frame, while the depth stream floods the CUs with throughput work
+  // (selection, SSD scan) at the same time: raise this workgroup's issue priority on the SIMDs it shares with them.
+  __builtin_amdgcn_s_setprio(3);
   __shared__ LmState s_sh;
   __shared__ double red_sh[15 * (kCoarseBlock + kRedPad)];  // reduction buffer; its head doubles as the fold scratch
   __shared__ double acc_sh[32];

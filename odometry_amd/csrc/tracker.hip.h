@@ -20,6 +20,7 @@ struct odo_tracker {
   DepthJob job;
   int job_stage;  // 0 idle, 1 depth launches in flight, 2 depth tail enqueued (pyramids next), 3 all enqueued
   int job_err;
+  double tm_solve_us, tm_depth_us, tm_frame_us, tm_wait_us; long tm_frames;  // host-clock averages (diagnostics)
   int pre_img_on_a;  // 1: the frame's second image pyramid (:251) is built on stream A after the Solve
   // overlap_depth == 2: a helper host thread feeds stream B (ComputeDepth + candidate pyramids) while the calling
   // thread feeds stream A (pose LM). Host launch rate, not the GPU, bounds a latency-bound frame loop.
@@ -87,6 +88,7 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
   t->d_val = nullptr; t->d_disp = t->d_dep = nullptr; t->ev_inputs = nullptr;
   t->n_keyframes = t->frame_id = t->last_evals = t->last_depth_iters = t->last_valid = 0;
   t->job_stage = t->job_err = 0; t->pre_img_on_a = 0;
+  t->tm_solve_us = t->tm_depth_us = t->tm_frame_us = t->tm_wait_us = 0.0; t->tm_frames = 0;
   t->w_state.store(0); t->w_left = t->w_right = nullptr; t->w_rc = 0; t->w_err[0] = 0;
   t->p = *p;
   float eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
@@ -166,8 +168,10 @@ static void tracker_worker_main(odo_tracker* t) {
       continue;
     }
     idle_spins = 0;
+    const auto w0 = std::chrono::steady_clock::now();
     int rc = tracker_depth_and_pyramids(t, t->w_left, t->w_right);
     if (rc == 0) rc = depth_finish(t->depth, false);
+    t->tm_depth_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
     t->w_rc = rc;
     if (rc) snprintf(t->w_err, sizeof(t->w_err), "%s", g_err);
     t->w_state.store(2, std::memory_order_release);
@@ -232,6 +236,7 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
                                  float abs_pose[16], int* is_new_keyframe, float* motion_mag, int* solve_status) {
   if (!t || !left || !right) return fail("odo_tracker_track: NULL arg");
   const odo_tracker_params& p = t->p;
+  const auto f0 = std::chrono::steady_clock::now();
   HIP_OK(hipSetDevice(t->ctx_a->device));
   t->frame_id++;
   t->pre_img_on_a = p.overlap_depth != 0;
@@ -249,7 +254,10 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
     t->lm->idle_arg = t;
   }
   float T[16];
+  const auto s0 = std::chrono::steady_clock::now();
   const int st = odo_lm_solve(t->lm, t->kf_img, t->kf_dep, t->cur_img, T);             // :215 (synchronises stream A)
+  const auto s1 = std::chrono::steady_clock::now();
+  t->tm_solve_us += std::chrono::duration<double, std::micro>(s1 - s0).count();
   t->lm->idle_pump = nullptr;
   if (t->pre_img_on_a) {
     // :251 — the runner builds the frame's image pyramid a second time. It depends on the image only, so it goes to
@@ -259,7 +267,9 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
     if (pyr_build(t->pre_img, left, p.smooth_image)) return -1;
   }
   if (p.overlap_depth == 2) {
+    const auto q0 = std::chrono::steady_clock::now();
     while (t->w_state.load(std::memory_order_acquire) != 2) { /* spin: the job is ~0.2 ms */ }
+    t->tm_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - q0).count();
     t->w_state.store(0, std::memory_order_release);
     if (t->w_rc) { fail("    depth failed! (%s)", t->w_err); return -1; }                // :230-232
   } else {
@@ -296,6 +306,18 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
   t->last_evals = t->lm->last_evals;
   t->last_depth_iters = t->depth->last.iters;
   t->last_valid = t->depth->last.n_valid;
+  t->tm_frame_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - f0).count();
+  t->tm_frames++;
+  return 0;
+}
+
+// Host-clock averages per tracked frame since the last call (microseconds): whole track() call, Solve (stream A, calling
+// thread), the stream-B job (helper thread), and the time the calling thread waited for the helper after its own work.
+extern "C" int odo_tracker_timing(odo_tracker* t, double out[4]) {
+  if (!t || !out) return fail("NULL arg");
+  const double n = t->tm_frames > 0 ? (double)t->tm_frames : 1.0;
+  out[0] = t->tm_frame_us / n; out[1] = t->tm_solve_us / n; out[2] = t->tm_depth_us / n; out[3] = t->tm_wait_us / n;
+  t->tm_solve_us = t->tm_depth_us = t->tm_frame_us = t->tm_wait_us = 0.0; t->tm_frames = 0;
   return 0;
 }
 

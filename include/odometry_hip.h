@@ -121,6 +121,8 @@ int odo_lm_time_eval(odo_lm* lm, const odo_pyr* kf_img, const odo_pyr* kf_dep, c
 int odo_lm_event_timing(odo_lm* lm, int on);
 int odo_lm_event_stats(const odo_lm* lm, double* total_us, long* launches, long* active_launches,
                        double* algorithmic_bytes);
+/* Share of the above spent in the single-workgroup coarse-level kernel (one launch per Solve). */
+int odo_lm_event_stats2(const odo_lm* lm, double* coarse_us, long* coarse_launches);
 /* Iteration space of the residual kernel: 0 = automatic (per keyframe and level: a compacted point list when at most
  * half of the interior pixels carry depth, the dense scan of the reference otherwise), 1 = always the dense scan,
  * 2 = always the point list. All three evaluate the same per-point arithmetic. */

@@ -437,7 +437,10 @@ class Tracker:
         us, b = C.c_double(0), C.c_double(0)
         n, a = C.c_long(0), C.c_long(0)
         L.check(self.lib.odo_lm_event_stats(lm, C.byref(us), C.byref(n), C.byref(a), C.byref(b)), "odo_lm_event_stats")
-        return dict(total_us=us.value, launches=n.value, active_launches=a.value, bytes=b.value)
+        cu, cn = C.c_double(0), C.c_long(0)
+        L.check(self.lib.odo_lm_event_stats2(lm, C.byref(cu), C.byref(cn)), "odo_lm_event_stats2")
+        return dict(total_us=us.value, launches=n.value, active_launches=a.value, bytes=b.value,
+                    coarse_us=cu.value, coarse_launches=cn.value)
 
     def timing(self):
         out = (C.c_double * 4)()

@@ -302,8 +302,9 @@ struct odo_lm {
   // optional per-launch HIP-event timing of the evaluation kernels (bench.py roofline leg)
   int ev_on;
   std::vector<hipEvent_t>* ev_pool;
-  double ev_total_us, ev_bytes;
-  long ev_launches, ev_active;
+  double ev_total_us, ev_bytes, ev_coarse_us;
+  long ev_launches, ev_active, ev_coarse_launches;
+  int last_coarse;  // 1 if the last Solve started with the single-workgroup coarse kernel
   int trace_stale;
   float* h_res; float* d_res_map; int* h_done; int* d_done; int token;  // host-mapped result + completion word
   int coarse;  // 1 = levels with <= kCoarseMaxPoints points run inside one workgroup (fused pipeline)
@@ -592,6 +593,7 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
     int min_level = m->n_levels;
     while (min_level > 0 && m->npts[min_level - 1] <= kCoarseMaxPoints) min_level--;
     if (!m->coarse) min_level = m->n_levels;
+    m->last_coarse = (min_level < m->n_levels) ? 1 : 0;
     if (min_level < m->n_levels) {
       int coarse_budget = 0;
       for (int l = min_level; l < m->n_levels; l++) coarse_budget += m->max_iters[l] > 0 ? m->max_iters[l] : 0;
@@ -700,7 +702,10 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
   if (m->ev_on && m->ev_pool && fused) {
     for (int i = 0; i < launches && (size_t)(2 * i + 1) < m->ev_pool->size(); i++) {
       float ms = 0.0f;
-      if (hipEventElapsedTime(&ms, (*m->ev_pool)[2 * i], (*m->ev_pool)[2 * i + 1]) == hipSuccess) m->ev_total_us += ms * 1000.0;
+      if (hipEventElapsedTime(&ms, (*m->ev_pool)[2 * i], (*m->ev_pool)[2 * i + 1]) == hipSuccess) {
+        m->ev_total_us += ms * 1000.0;
+        if (i == 0 && m->last_coarse) { m->ev_coarse_us += ms * 1000.0; m->ev_coarse_launches++; }
+      }
     }
     m->ev_launches += launches;
     m->ev_active += m->last_evals;
@@ -718,8 +723,14 @@ extern "C" int odo_lm_event_timing(odo_lm* m, int on) {
     m->ev_pool = new std::vector<hipEvent_t>(2 * 128);
     for (auto& e : *m->ev_pool) HIP_OK(hipEventCreate(&e));
   }
-  if (on) { m->ev_total_us = 0.0; m->ev_bytes = 0.0; m->ev_launches = 0; m->ev_active = 0; }
+  if (on) { m->ev_total_us = m->ev_bytes = m->ev_coarse_us = 0.0; m->ev_launches = m->ev_active = m->ev_coarse_launches = 0; }
   m->ev_on = on ? 1 : 0;
+  return 0;
+}
+extern "C" int odo_lm_event_stats2(const odo_lm* m, double* coarse_us, long* coarse_launches) {
+  if (!m) return fail("NULL lm");
+  if (coarse_us) *coarse_us = m->ev_coarse_us;
+  if (coarse_launches) *coarse_launches = m->ev_coarse_launches;
   return 0;
 }
 extern "C" int odo_lm_event_stats(const odo_lm* m, double* total_us, long* launches, long* active_launches,

@@ -978,7 +978,8 @@ __global__ void __launch_bounds__(kLmBlock) lm_step_kernel(StepArgs a) {
 // >= min_level: no launch, no global partials, no state reload between iterations. It hands over to the generic step
 // launches with the next level already begun.
 constexpr int kCoarseBlock = 512;
-constexpr int kCoarseMaxPoints = 4096;  // levels with more points than this go to the multi-block step kernel
+constexpr int kCoarseMaxPoints = 1024;  // levels with more points go to the multi-block step kernel (measured: a 512-thread
+                                        // workgroup walking ~2000 points four per thread is no faster than seven blocks)
 
 // 29 sums of a 512-thread block into LDS (out), two rounds of 15 + 14 quantities through one 62 KB buffer.
 __device__ __forceinline__ void block_reduce_acc_coarse(const double acc[ODO_NACC], double* red /* [15][520] */, double* out) {

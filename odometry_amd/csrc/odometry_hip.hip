@@ -268,7 +268,6 @@ extern "C" int odo_pyramid_destroy(odo_pyr* p) {
 // ------------------------------------------------------------------------------------------------
 static const odo_intrinsics kKitti00 = {718.856f, (float)607.1928, (float)185.2157};
 constexpr int kLmMaxBlocks = 1280;       // partial rows per buffer: dense scan = 5 blocks per CU
-constexpr int kLmFusedDenseBlocks = 512;  // fused dense launches fold every row in every block: keep the grid small
 
 struct odo_lm {
   odo_ctx* ctx;
@@ -591,7 +590,8 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
     memcpy(a.init, m->init, sizeof(a.init));
     // Coarse levels (few points) run inside one workgroup: one launch covers every level >= min_level.
     int min_level = m->n_levels;
-    while (min_level > 0 && m->npts[min_level - 1] <= kCoarseMaxPoints) min_level--;
+    static const int coarse_max = getenv("ODO_COARSE_MAX") ? atoi(getenv("ODO_COARSE_MAX")) : kCoarseMaxPoints;
+    while (min_level > 0 && m->npts[min_level - 1] <= coarse_max) min_level--;
     if (!m->coarse) min_level = m->n_levels;
     m->last_coarse = (min_level < m->n_levels) ? 1 : 0;
     if (min_level < m->n_levels) {

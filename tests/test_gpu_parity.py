@@ -376,3 +376,97 @@ def test_wave_solver_matches_oracle_bit_for_bit(api, O):
         assert st == 0
         ref = O.solve_damped(acc, lam)
         assert np.array_equal(out, ref, equal_nan=True), (trial, out, ref)
+
+
+# ---------------------------------------------------------------- further edge cases ------------
+def test_pyramid_five_levels_and_single_level(api, O):
+    """More than four levels takes the level-by-level kernels, one level is just the (blurred) input."""
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (160, 224)).astype(np.float32)
+    for levels in (1, 2, 5):
+        ref = O.image_pyramid(img, levels, True)
+        pyr = api.ImagePyramid(levels, img, True)
+        for l in range(levels):
+            assert np.array_equal(pyr.GetPyramidImage(l), ref[l]), (levels, l)
+    dep = (rng.random((160, 224)) * (rng.random((160, 224)) < 0.2)).astype(np.float32)
+    refd = O.depth_pyramid(dep, 5)
+    pd = api.DepthPyramid(5, dep, False)
+    for l in range(5):
+        assert np.array_equal(pd.GetPyramidDepth(l), refd[l])
+
+
+def test_lm_single_level_and_tiny_interior(api, O, small_seq):
+    from odometry_amd import synth
+    K = small_seq["K"]
+    L0, L1, Z0 = small_seq["left"][0], small_seq["left"][1], small_seq["depth"][0]
+    inv = synth.semi_dense_inverse_depth(Z0, L0, grad_th=6.0)
+    # one level only
+    lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [15], np.eye(4), None, 1, 28.0, intrinsics=(K["f0"], K["cx0"], K["cy0"]))
+    T = lm.Solve(api.ImagePyramid(1, L0, True), api.DepthPyramid(1, inv, False), api.ImagePyramid(1, L1, True))
+    ref = O.lm_solve(O.image_pyramid(L0, 1, flat=True), O.depth_pyramid(inv, 1, flat=True), O.image_pyramid(L1, 1, flat=True),
+                     120, 160, O.lm_params(max_iters=(15,), K=K))
+    assert lm.last_status == ref["status"] == 0 and se3_log_norm(ref["pose"], T) < 1e-5
+    # a 12x14 image has a 4x6 interior after the 4-px border; 8x8 has none -> the Solve fails like the reference
+    for shape, expect_fail in (((12, 14), False), ((8, 8), True)):
+        img = np.random.default_rng(5).integers(0, 255, shape).astype(np.float32)
+        d = np.full(shape, 0.2, np.float32)
+        lm1 = api.LevenbergMarquardtOptimizer(0.01, 0.995, [5], np.eye(4), None, 0, 28.0, intrinsics=(20.0, 7.0, 6.0))
+        T1 = lm1.Solve(api.ImagePyramid(1, img, False), api.DepthPyramid(1, d, False), api.ImagePyramid(1, img, False))
+        r1 = O.lm_solve(img.ravel(), d.ravel(), img.ravel(), shape[0], shape[1],
+                        O.lm_params(max_iters=(5,), robust=0, K=dict(f0=20.0, cx0=7.0, cy0=6.0)))
+        assert lm1.last_status == r1["status"] == (-1 if expect_fail else 0)
+        assert np.array_equal(T1, r1["pose"]) or se3_log_norm(r1["pose"], T1) < 1e-5
+
+
+def test_lm_inverse_depth_threshold_and_negative(api, O):
+    """|d| < 0.01 is skipped, |d| == 0.01 kept, negative inverse depth warps behind the camera (ref: :193, h:45)."""
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 255, (64, 80)).astype(np.float32)
+    d = np.zeros((64, 80), np.float32)
+    d[10:50:3, 10:70:3] = 0.25
+    d[12, 12] = 0.0099
+    d[13, 13] = 0.01
+    d[14, 14] = -0.25
+    K = (60.0, 40.0, 32.0)
+    lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [5], np.eye(4), None, 1, 28.0, intrinsics=K)
+    p, dp = api.ImagePyramid(1, img, False), api.DepthPyramid(1, d, False)
+    for mode in (1, 2):
+        lm.set_mode(mode)
+        st, acc = lm.accumulate(p, dp, p, 0, np.eye(4, dtype=np.float32))
+        ref = O.lm_accumulate(img, img, d, 0, np.eye(4, dtype=np.float32), robust=1, K=dict(f0=K[0], cx0=K[1], cy0=K[2]))
+        assert acc[28] == ref["acc"][28]
+        np.testing.assert_allclose(acc, ref["acc"], rtol=1e-11, atol=1e-9)
+
+
+def test_depth_other_boundary(api, O, kitti_seq):
+    L, R = kitti_seq["left"][2], kitti_seq["right"][2]
+    de = api.DepthEstimator(8.0, 900.0, 15.0, 0.1, 30.0, 0.01, 28.0, 0.995, 50, 6, None, None,
+                            float(np.float32(386.1448) / np.float32(718.856)), 80000)
+    val, disp, dep = _bufs(L.shape)
+    st = de.ComputeDepth(L, R, val, disp, dep)
+    ref = O.compute_depth(L, R, O.depth_params(boundary=6))
+    assert st == ref["status"]
+    assert np.array_equal(val, ref["val"]) and np.array_equal(disp, ref["disp"])
+    np.testing.assert_allclose(dep, ref["dep"], rtol=0, atol=1e-7)
+
+
+def test_tracker_reports_depth_failure(api):
+    """Flat images: ComputeDepth finds < 500 points -> the runner breaks (ref: run_odometry_kitti_offline.cpp:230-232)."""
+    from odometry_amd import _lib
+    flat = np.full((376, 1241), 90.0, np.float32)
+    trk = api.Tracker(0)
+    a, b = trk.upload_frame(flat), trk.upload_frame(flat)
+    with pytest.raises(_lib.OdoError):
+        trk.init(a, b)
+    trk.close()
+
+
+def test_tracker_solve_failure_is_not_fatal(api, kitti_seq):
+    """No depth on the keyframe -> Solve returns the pseudo-identity, the loop carries on (ref: :215, lm_optimizer.cpp:60-65)."""
+    L, R = kitti_seq["left"], kitti_seq["right"]
+    trk = api.Tracker(0, min_depth=1000.0, max_depth=2000.0)   # every depth is filtered out -> init fails? no: < 500 -> -1
+    dev = [(trk.upload_frame(l), trk.upload_frame(r)) for l, r in zip(L, R)]
+    from odometry_amd import _lib
+    with pytest.raises(_lib.OdoError):
+        trk.init(*dev[0])
+    trk.close()

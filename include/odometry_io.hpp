@@ -1,0 +1,297 @@
+// odometry_io.hpp — KITTI-style ingest and result files for a runner built on odometry_shim.hpp, std-only.
+//
+// SURVEY section 8(f) ranks 2 and 3 (the rows either side of the hot path):
+//   * pose file reader          ref: run_odometry_kitti_offline.cpp:287-332 (load_gt_pose: 12 floats per line, row-major 3x4)
+//   * KITTI pose writer         ref: :374-430 (save_txt: std::to_string of each float, single spaces, one line per frame)
+//   * translation-error eval    ref: :361-372 (eval_pose: ||t_pred - t_gt|| per frame and its mean)
+//   * 8-bit grey PNG reader     ref: :334-359 (load_data: cv::imread(IMREAD_GRAYSCALE) -> convertTo(CV_32F), values 0..255)
+// The reference uses OpenCV for the PNGs; this image has none, so the decoder (zlib inflate + PNG unfiltering for
+// colour type 0, bit depth 8, non-interlaced — what KITTI odometry grey images are) is written out here.
+#ifndef ODOMETRY_IO_HPP
+#define ODOMETRY_IO_HPP
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace odometry {
+namespace io {
+
+struct Pose34 {  // row-major 3x4, like Eigen::Matrix<float,3,4,RowMajor> in the runner
+  float m[12];
+};
+
+// ---- pose files ------------------------------------------------------------------------------
+// Reads up to `max_frames` lines (0 = all). Returns false if the file cannot be opened or a line is short.
+inline bool load_gt_poses(const std::string& path, std::vector<Pose34>& out, size_t max_frames = 0) {
+  std::ifstream f(path);
+  if (!f.is_open()) return false;
+  std::string line;
+  out.clear();
+  while ((max_frames == 0 || out.size() < max_frames) && std::getline(f, line)) {
+    if (line.empty()) continue;
+    std::istringstream ss(line);
+    Pose34 p;
+    for (int i = 0; i < 12; i++) {
+      double v;
+      if (!(ss >> v)) return false;
+      p.m[i] = (float)v;  // the runner parses with atof and narrows to float (ref: :323-324)
+    }
+    out.push_back(p);
+  }
+  return max_frames == 0 || out.size() == max_frames;
+}
+
+// One line per pose, 12 values, std::to_string formatting (6 decimals), single spaces (ref: :404-421).
+inline bool save_poses_kitti(const std::string& path, const std::vector<Pose34>& poses) {
+  std::ofstream f(path, std::ios::out | std::ios::trunc);
+  if (!f.is_open()) return false;
+  for (const Pose34& p : poses) {
+    std::string line;
+    for (int i = 0; i < 12; i++) {
+      line += std::to_string(p.m[i]);
+      if (i != 11) line += " ";
+    }
+    f << line << std::endl;
+  }
+  return true;
+}
+
+// ||t_pred - t_gt|| per frame (fp32, like Eigen's norm on float vectors); returns the mean over `n` frames.
+inline float eval_translation_error(const std::vector<Pose34>& gt, const std::vector<Pose34>& pred, size_t n,
+                                    std::vector<float>* per_frame = nullptr) {
+  float sum = 0.0f;
+  if (per_frame) per_frame->clear();
+  for (size_t i = 0; i < n && i < gt.size() && i < pred.size(); i++) {
+    const float dx = pred[i].m[3] - gt[i].m[3], dy = pred[i].m[7] - gt[i].m[7], dz = pred[i].m[11] - gt[i].m[11];
+    const float e = std::sqrt(dx * dx + dy * dy + dz * dz);
+    sum += e;
+    if (per_frame) per_frame->push_back(e);
+  }
+  return n ? sum / (float)n : 0.0f;
+}
+
+// KITTI odometry image path: <root>/sequences/<seq>/image_<cam>/<%06d>.png (ref: :335-338)
+inline std::string kitti_image_path(const std::string& dataset_root, const std::string& seq, int cam, int frame_id) {
+  char name[32];
+  std::snprintf(name, sizeof(name), "%06d.png", frame_id);
+  return dataset_root + "/sequences/" + seq + "/image_" + std::to_string(cam) + "/" + name;
+}
+
+// ---- zlib inflate (RFC 1950 / 1951), enough for PNG IDAT streams -----------------------------
+namespace detail {
+struct BitReader {
+  const uint8_t* p;
+  size_t n, pos = 0;
+  uint32_t bitbuf = 0;
+  int bitcnt = 0;
+  bool ok = true;
+  BitReader(const uint8_t* d, size_t len) : p(d), n(len) {}
+  uint32_t bits(int c) {
+    while (bitcnt < c) {
+      if (pos >= n) { ok = false; return 0; }
+      bitbuf |= (uint32_t)p[pos++] << bitcnt;
+      bitcnt += 8;
+    }
+    const uint32_t v = bitbuf & ((c == 32) ? 0xffffffffu : ((1u << c) - 1u));
+    bitbuf >>= c;
+    bitcnt -= c;
+    return v;
+  }
+  void align() { bitbuf = 0; bitcnt = 0; }
+};
+struct Huff {
+  uint16_t count[16];
+  uint16_t symbol[320];
+  void build(const uint8_t* len, int n) {
+    std::memset(count, 0, sizeof(count));
+    for (int i = 0; i < n; i++) count[len[i]]++;
+    count[0] = 0;
+    uint16_t offs[16];
+    offs[1] = 0;
+    for (int i = 1; i < 15; i++) offs[i + 1] = offs[i] + count[i];
+    for (int i = 0; i < n; i++)
+      if (len[i]) symbol[offs[len[i]]++] = (uint16_t)i;
+  }
+  int decode(BitReader& br) const {  // canonical Huffman decoding, one bit at a time
+    int code = 0, first = 0, index = 0;
+    for (int l = 1; l <= 15; l++) {
+      code |= (int)br.bits(1);
+      if (!br.ok) return -1;
+      const int c = count[l];
+      if (code - c < first) return symbol[index + (code - first)];
+      index += c;
+      first += c;
+      first <<= 1;
+      code <<= 1;
+    }
+    return -1;
+  }
+};
+inline bool inflate(const uint8_t* in, size_t n, std::vector<uint8_t>& out) {
+  static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115,
+                                     131, 163, 195, 227, 258};
+  static const uint16_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+  static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537,
+                                     2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+  static const uint16_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12,
+                                    13, 13};
+  if (n < 6) return false;
+  if ((in[0] & 0x0f) != 8 || ((in[0] << 8 | in[1]) % 31) != 0 || (in[1] & 0x20)) return false;  // zlib header, no dict
+  BitReader br(in + 2, n - 2);
+  int last;
+  do {
+    last = (int)br.bits(1);
+    const int type = (int)br.bits(2);
+    if (!br.ok) return false;
+    if (type == 0) {
+      br.align();
+      if (br.pos + 4 > br.n) return false;
+      const uint32_t len = br.p[br.pos] | (br.p[br.pos + 1] << 8), nlen = br.p[br.pos + 2] | (br.p[br.pos + 3] << 8);
+      br.pos += 4;
+      if ((len ^ 0xffffu) != nlen || br.pos + len > br.n) return false;
+      out.insert(out.end(), br.p + br.pos, br.p + br.pos + len);
+      br.pos += len;
+    } else if (type == 1 || type == 2) {
+      Huff hl, hd;
+      uint8_t lens[320];
+      if (type == 1) {
+        for (int i = 0; i < 144; i++) lens[i] = 8;
+        for (int i = 144; i < 256; i++) lens[i] = 9;
+        for (int i = 256; i < 280; i++) lens[i] = 7;
+        for (int i = 280; i < 288; i++) lens[i] = 8;
+        hl.build(lens, 288);
+        for (int i = 0; i < 30; i++) lens[i] = 5;
+        hd.build(lens, 30);
+      } else {
+        static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        const int nlen = (int)br.bits(5) + 257, ndist = (int)br.bits(5) + 1, ncode = (int)br.bits(4) + 4;
+        if (!br.ok || nlen > 286 || ndist > 30) return false;
+        uint8_t cl[19];
+        std::memset(cl, 0, sizeof(cl));
+        for (int i = 0; i < ncode; i++) cl[order[i]] = (uint8_t)br.bits(3);
+        Huff hc;
+        hc.build(cl, 19);
+        int idx = 0;
+        while (idx < nlen + ndist) {
+          const int sym = hc.decode(br);
+          if (sym < 0) return false;
+          if (sym < 16) lens[idx++] = (uint8_t)sym;
+          else {
+            int rep, val = 0;
+            if (sym == 16) { if (idx == 0) return false; val = lens[idx - 1]; rep = 3 + (int)br.bits(2); }
+            else if (sym == 17) rep = 3 + (int)br.bits(3);
+            else rep = 11 + (int)br.bits(7);
+            if (idx + rep > nlen + ndist) return false;
+            while (rep--) lens[idx++] = (uint8_t)val;
+          }
+        }
+        hl.build(lens, nlen);
+        hd.build(lens + nlen, ndist);
+      }
+      for (;;) {
+        const int sym = hl.decode(br);
+        if (sym < 0 || !br.ok) return false;
+        if (sym < 256) out.push_back((uint8_t)sym);
+        else if (sym == 256) break;
+        else {
+          const int li = sym - 257;
+          if (li >= 29) return false;
+          const int len = lbase[li] + (int)br.bits(lext[li]);
+          const int ds = hd.decode(br);
+          if (ds < 0 || ds >= 30) return false;
+          const size_t dist = dbase[ds] + br.bits(dext[ds]);
+          if (!br.ok || dist > out.size()) return false;
+          const size_t from = out.size() - dist;
+          for (int i = 0; i < len; i++) out.push_back(out[from + i]);
+        }
+      }
+    } else {
+      return false;
+    }
+  } while (!last);
+  return true;
+}
+inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+inline int paeth(int a, int b, int c) {
+  const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+  return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+}  // namespace detail
+
+// Decodes an 8-bit greyscale, non-interlaced PNG into `pixels` (row-major, width x height). Returns false on any
+// other PNG flavour or a malformed file (the runner exits when imread returns an empty Mat, ref: :343-346).
+inline bool read_png_gray8(const std::string& path, std::vector<uint8_t>& pixels, int& width, int& height) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f.is_open()) return false;
+  std::vector<uint8_t> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
+  if (d.size() < 8 + 25 || std::memcmp(d.data(), sig, 8) != 0) return false;
+  size_t pos = 8;
+  std::vector<uint8_t> idat;
+  width = height = 0;
+  bool have_ihdr = false;
+  while (pos + 12 <= d.size()) {
+    const uint32_t len = detail::be32(&d[pos]);
+    const char* type = (const char*)&d[pos + 4];
+    if (pos + 12 + (size_t)len > d.size()) return false;
+    const uint8_t* body = &d[pos + 8];
+    if (!std::memcmp(type, "IHDR", 4)) {
+      if (len != 13) return false;
+      width = (int)detail::be32(body);
+      height = (int)detail::be32(body + 4);
+      if (body[8] != 8 || body[9] != 0 || body[10] != 0 || body[11] != 0 || body[12] != 0) return false;  // 8-bit grey only
+      have_ihdr = true;
+    } else if (!std::memcmp(type, "IDAT", 4)) {
+      idat.insert(idat.end(), body, body + len);
+    } else if (!std::memcmp(type, "IEND", 4)) {
+      break;
+    }
+    pos += 12 + (size_t)len;
+  }
+  if (!have_ihdr || width <= 0 || height <= 0) return false;
+  std::vector<uint8_t> raw;
+  raw.reserve((size_t)(width + 1) * height);
+  if (!detail::inflate(idat.data(), idat.size(), raw)) return false;
+  if (raw.size() != (size_t)(width + 1) * height) return false;
+  pixels.assign((size_t)width * height, 0);
+  for (int y = 0; y < height; y++) {
+    const uint8_t ft = raw[(size_t)y * (width + 1)];
+    const uint8_t* src = &raw[(size_t)y * (width + 1) + 1];
+    uint8_t* cur = &pixels[(size_t)y * width];
+    const uint8_t* up = y ? &pixels[(size_t)(y - 1) * width] : nullptr;
+    for (int x = 0; x < width; x++) {
+      const int a = x ? cur[x - 1] : 0, b = up ? up[x] : 0, c = (x && up) ? up[x - 1] : 0;
+      int v = src[x];
+      switch (ft) {
+        case 0: break;
+        case 1: v += a; break;
+        case 2: v += b; break;
+        case 3: v += (a + b) / 2; break;
+        case 4: v += detail::paeth(a, b, c); break;
+        default: return false;
+      }
+      cur[x] = (uint8_t)v;
+    }
+  }
+  return true;
+}
+
+// imread(GRAYSCALE) -> convertTo(CV_32F): fp32 pixels in 0..255 (ref: :342-348).
+inline bool read_png_gray_f32(const std::string& path, std::vector<float>& pixels, int& width, int& height) {
+  std::vector<uint8_t> u8;
+  if (!read_png_gray8(path, u8, width, height)) return false;
+  pixels.resize(u8.size());
+  for (size_t i = 0; i < u8.size(); i++) pixels[i] = (float)u8[i];
+  return true;
+}
+
+}  // namespace io
+}  // namespace odometry
+#endif  // ODOMETRY_IO_HPP

@@ -1,0 +1,28 @@
+// tests/io_harness.cpp — exposes include/odometry_io.hpp to the Python tests (compiled with g++ on the fly).
+#include "../include/odometry_io.hpp"
+
+using namespace odometry::io;
+
+extern "C" {
+int io_read_png(const char* path, unsigned char* out, int cap, int* w, int* h) {
+  std::vector<uint8_t> px;
+  if (!read_png_gray8(path, px, *w, *h)) return -1;
+  if ((int)px.size() > cap) return -2;
+  std::memcpy(out, px.data(), px.size());
+  return 0;
+}
+int io_pose_roundtrip(const char* in_path, const char* out_path, int max_frames, float* first_last /*24*/, float* mean_err) {
+  std::vector<Pose34> p;
+  if (!load_gt_poses(in_path, p, (size_t)max_frames)) return -1;
+  if (!save_poses_kitti(out_path, p)) return -2;
+  std::memcpy(first_last, p.front().m, sizeof(float) * 12);
+  std::memcpy(first_last + 12, p.back().m, sizeof(float) * 12);
+  std::vector<Pose34> shifted = p;
+  for (size_t i = 0; i < shifted.size(); i++) { shifted[i].m[3] += 3.0f; shifted[i].m[11] -= 4.0f; }
+  *mean_err = eval_translation_error(p, shifted, p.size());
+  return (int)p.size();
+}
+void io_image_path(const char* root, const char* seq, int cam, int frame, char* out, int cap) {
+  std::snprintf(out, cap, "%s", kitti_image_path(root, seq, cam, frame).c_str());
+}
+}

@@ -1,0 +1,115 @@
+"""include/odometry_io.hpp: std-only PNG (8-bit grey) reader, KITTI pose reader / writer,
+translation-error evaluation — checked against PNGs and pose files written from Python."""
+import ctypes as C
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def io(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("io") / "io_harness.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tests", "io_harness.cpp")])
+    return C.CDLL(so)
+
+
+def write_png(path, img, filter_type=0, level=6, split=None):
+    """8-bit grey PNG with a chosen per-row filter (0-4, or 'mix') and zlib level; IDAT optionally split in chunks."""
+    h, w = img.shape
+    raw = bytearray()
+    prev = np.zeros(w, np.int32)
+    for y in range(h):
+        cur = img[y].astype(np.int32)
+        ft = (y % 5) if filter_type == "mix" else filter_type
+        a = np.concatenate([[0], cur[:-1]])
+        c = np.concatenate([[0], prev[:-1]])
+        if ft == 0:
+            f = cur
+        elif ft == 1:
+            f = cur - a
+        elif ft == 2:
+            f = cur - prev
+        elif ft == 3:
+            f = cur - ((a + prev) // 2)
+        else:
+            p = a + prev - c
+            pa, pb, pc = np.abs(p - a), np.abs(p - prev), np.abs(p - c)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+            f = cur - pred
+        raw.append(ft)
+        raw.extend((f % 256).astype(np.uint8).tobytes())
+        prev = cur
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+
+    comp = zlib.compress(bytes(raw), level)
+    parts = [comp] if not split else [comp[i:i + split] for i in range(0, len(comp), split)]
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n")
+        f.write(chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)))
+        f.write(chunk(b"tEXt", b"Comment\x00synthetic"))
+        for p in parts:
+            f.write(chunk(b"IDAT", p))
+        f.write(chunk(b"IEND", b""))
+
+
+@pytest.mark.parametrize("filter_type,level,split", [(0, 0, None), (1, 1, None), (2, 6, 4096), (3, 9, None), (4, 9, 1000),
+                                                      ("mix", 6, 777)])
+def test_png_reader(io, tmp_path, filter_type, level, split):
+    rng = np.random.default_rng(0)
+    yy, xx = np.mgrid[0:94, 0:311]
+    img = ((np.sin(xx / 7.0) * 60 + np.cos(yy / 5.0) * 40 + 128) + rng.integers(-8, 8, (94, 311))).clip(0, 255).astype(np.uint8)
+    path = str(tmp_path / "img.png")
+    write_png(path, img, filter_type, level, split)
+    out = np.zeros(img.size, np.uint8)
+    w, h = C.c_int(0), C.c_int(0)
+    assert io.io_read_png(path.encode(), out.ctypes.data_as(C.POINTER(C.c_ubyte)), out.size, C.byref(w), C.byref(h)) == 0
+    assert (w.value, h.value) == (311, 94)
+    assert np.array_equal(out.reshape(94, 311), img)
+
+
+def test_png_reader_kitti_sized_and_rejects_other_formats(io, tmp_path):
+    from odometry_amd import synth
+    img = synth.integer_disparity_pair(seed=3)[0].astype(np.uint8)       # 376 x 1241, real texture statistics
+    path = str(tmp_path / "000000.png")
+    write_png(path, img, "mix", 9, 8192)
+    out = np.zeros(img.size, np.uint8)
+    w, h = C.c_int(0), C.c_int(0)
+    assert io.io_read_png(path.encode(), out.ctypes.data_as(C.POINTER(C.c_ubyte)), out.size, C.byref(w), C.byref(h)) == 0
+    assert np.array_equal(out.reshape(376, 1241), img)
+    bad = str(tmp_path / "bad.png")
+    open(bad, "wb").write(open(path, "rb").read()[:200])                 # truncated file
+    assert io.io_read_png(bad.encode(), out.ctypes.data_as(C.POINTER(C.c_ubyte)), out.size, C.byref(w), C.byref(h)) == -1
+    assert io.io_read_png(b"/nonexistent.png", out.ctypes.data_as(C.POINTER(C.c_ubyte)), out.size, C.byref(w), C.byref(h)) == -1
+
+
+def test_pose_files_and_eval(io, tmp_path):
+    rng = np.random.default_rng(1)
+    poses = rng.normal(0, 10, (25, 12)).astype(np.float32)
+    src = str(tmp_path / "00.txt")
+    with open(src, "w") as f:
+        for p in poses:
+            f.write(" ".join("%e" % v for v in p) + "\n")                # KITTI ground truth uses exponent notation
+    dst = str(tmp_path / "pred.txt")
+    fl = np.zeros(24, np.float32)
+    err = C.c_float(0)
+    n = io.io_pose_roundtrip(src.encode(), dst.encode(), 20, fl.ctypes.data_as(C.POINTER(C.c_float)), C.byref(err))
+    assert n == 20
+    assert np.array_equal(fl[:12], np.array([float("%e" % v) for v in poses[0]], np.float32))
+    assert np.array_equal(fl[12:], np.array([float("%e" % v) for v in poses[19]], np.float32))
+    assert abs(err.value - 5.0) < 1e-5                                    # every frame was shifted by (3, 0, -4)
+    lines = open(dst).read().splitlines()
+    assert len(lines) == 20
+    for line, p in zip(lines, poses[:20]):
+        expect = " ".join("%f" % np.float32(float("%e" % v)) for v in p)  # std::to_string(float) == "%f"
+        assert line == expect
+    buf = C.create_string_buffer(256)
+    io.io_image_path(b"/data/kitti/dataset", b"00", 1, 42, buf, 256)
+    assert buf.value == b"/data/kitti/dataset/sequences/00/image_1/000042.png"

@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--gather-every", type=int, default=8)
     ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-overlap", action="store_true", help="run ComputeDepth after Solve on one stream")
+    ap.add_argument("--no-prefetch", action="store_true", help="build each frame's image pyramid inside its own step")
     ap.add_argument("--no-extras", action="store_true", help="skip the dense-1080p and disparity side measurements")
     ap.add_argument("--overlap", type=int, default=2, help="1: one host thread feeds both streams, 2: helper thread")
     args = ap.parse_args()
@@ -184,6 +185,8 @@ def main():
 
     def step(i):
         k = step_no[0]
+        if not args.no_prefetch and k + 1 < n_total:
+            trk.hint_next(dev[order[k + 1]][0])   # frames are resident: the next frame's pyramid overlaps this frame's tail
         trk.track_into(dev[i][0], dev[i][1], poses_kf[k], poses_abs[k])
         step_no[0] = k + 1
         if gatherer is not None:
@@ -241,7 +244,8 @@ def main():
                    config=dict(workload="synthetic KITTI-shaped stereo sequence (configs[1]), 1241x376, 4 levels, "
                                         "semi-dense, runner params, one sequence per GPU",
                                unique_frames=args.unique_frames, sequences_per_gpu=1,
-                               overlap_depth=0 if args.no_overlap else args.overlap, gather_every=args.gather_every),
+                               overlap_depth=0 if args.no_overlap else args.overlap, gather_every=args.gather_every,
+                               next_frame_pyramid_prefetch=not args.no_prefetch),
                    roofline=roof,
                    lm_evals_per_frame=round(float(np.mean(evals)), 2),
                    host_us_per_frame={k: round(v, 1) for k, v in host_timing.items()},

@@ -203,6 +203,10 @@ int odo_tracker_init(odo_tracker* t, const float* left_dev, const float* right_d
  * pseudo-identity); solve_status reports it. */
 int odo_tracker_track(odo_tracker* t, const float* left_dev, const float* right_dev, float pose_to_keyframe[16],
                       float abs_pose[16], int* is_new_keyframe, float* motion_mag, int* solve_status);
+/* Optional pipelining for callers that already hold the next frame (offline runs): announce its left image before
+ * tracking the current frame; its image pyramid (ref: :205 of the NEXT iteration) is then built at the end of this call
+ * on the otherwise idle LM stream. Same work, earlier; results are unchanged. */
+int odo_tracker_hint_next(odo_tracker* t, const float* next_left_dev);
 /* Counters of the last tracked frame: LM evaluations, depth-LM iterations, valid depth points, keyframes so far. */
 int odo_tracker_stats(const odo_tracker* t, int* lm_evals, int* depth_iters, int* n_valid_depth, int* n_keyframes);
 /* Device pointers to the last frame's outputs (rows x cols): validity mask (u8), disparity, inverse depth. */

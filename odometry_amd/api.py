@@ -403,6 +403,9 @@ class Tracker:
         return dict(pose_to_keyframe=_from_colmajor(T), abs_pose=_from_colmajor(A), new_keyframe=bool(nk.value),
                     motion=mag.value, solve_status=ss.value)
 
+    def hint_next(self, next_left_dev):
+        L.check(self.lib.odo_tracker_hint_next(self.h, next_left_dev), "odo_tracker_hint_next")
+
     def track_into(self, left_dev, right_dev, pose_to_kf, abs_pose):
         """Lean variant for timing loops: results land in caller-owned float32[16] column-major buffers."""
         if not hasattr(self, "_nk"):

@@ -9,7 +9,9 @@ struct odo_tracker {
   odo_ctx* ctx_b;  // ComputeDepth + the frame's keyframe-candidate pyramids
   odo_lm* lm;
   odo_depth* depth;
-  odo_pyr *kf_img, *kf_dep, *cur_img, *pre_img, *pre_dep;
+  odo_pyr *kf_img, *kf_dep, *cur_img, *pre_img, *pre_dep, *next_img;
+  const float* hint_next;      // device image the caller announced as the next frame (odo_tracker_hint_next)
+  const float* prefetched;     // image whose pyramid already sits in next_img
   uint8_t* d_val;
   float *d_disp, *d_dep;
   float kf_abs[16];
@@ -66,7 +68,7 @@ extern "C" int odo_tracker_destroy(odo_tracker* t) {
   if (t->ctx_b) (void)hipStreamSynchronize(t->ctx_b->stream);
   odo_lm_destroy(t->lm);
   odo_depth_destroy(t->depth);
-  odo_pyr* ps[] = {t->kf_img, t->kf_dep, t->cur_img, t->pre_img, t->pre_dep};
+  odo_pyr* ps[] = {t->kf_img, t->kf_dep, t->cur_img, t->pre_img, t->pre_dep, t->next_img};
   for (odo_pyr* q : ps) odo_pyramid_destroy(q);
   if (t->d_val) (void)hipFree(t->d_val);
   if (t->d_disp) (void)hipFree(t->d_disp);
@@ -84,7 +86,8 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
   odo_tracker* t = new (std::nothrow) odo_tracker();
   if (!t) return fail("out of memory");
   t->ctx_a = t->ctx_b = nullptr; t->lm = nullptr; t->depth = nullptr;
-  t->kf_img = t->kf_dep = t->cur_img = t->pre_img = t->pre_dep = nullptr;
+  t->kf_img = t->kf_dep = t->cur_img = t->pre_img = t->pre_dep = t->next_img = nullptr;
+  t->hint_next = t->prefetched = nullptr;
   t->d_val = nullptr; t->d_disp = t->d_dep = nullptr; t->ev_inputs = nullptr;
   t->n_keyframes = t->frame_id = t->last_evals = t->last_depth_iters = t->last_valid = 0;
   t->job_stage = t->job_err = 0; t->pre_img_on_a = 0;
@@ -102,6 +105,7 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
                               p->depth_huber_delta, p->depth_precision, p->depth_max_iters, p->boundary, &p->K, p->baseline,
                               p->max_residuals, p->max_disparity, p->any_size, &t->depth) == 0;
   ok = ok && pyr_alloc(t->ctx_a, p->rows, p->cols, p->levels, ODO_PYR_IMAGE, &t->cur_img) == 0;
+  ok = ok && pyr_alloc(t->ctx_a, p->rows, p->cols, p->levels, ODO_PYR_IMAGE, &t->next_img) == 0;
   ok = ok && pyr_alloc(t->ctx_b, p->rows, p->cols, p->levels, ODO_PYR_IMAGE, &t->kf_img) == 0;
   ok = ok && pyr_alloc(t->ctx_b, p->rows, p->cols, p->levels, ODO_PYR_DEPTH, &t->kf_dep) == 0;
   ok = ok && pyr_alloc(t->ctx_b, p->rows, p->cols, p->levels, ODO_PYR_IMAGE, &t->pre_img) == 0;
@@ -245,7 +249,12 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
     t->w_left = left; t->w_right = right;
     t->w_state.store(1, std::memory_order_release);
   }
-  if (pyr_build(t->cur_img, left, p.smooth_image)) return -1;                          // :205
+  if (t->prefetched == left) {
+    std::swap(t->cur_img, t->next_img);  // :205 — this frame's pyramid was built on stream A at the end of the last call
+  } else if (pyr_build(t->cur_img, left, p.smooth_image)) {                            // :205
+    return -1;
+  }
+  t->prefetched = nullptr;
   if (p.overlap_depth == 1) {
     // stream B: ComputeDepth + candidate pyramids, concurrent with the Solve on stream A. The front of the job is
     // enqueued now; its depth-LM launches are issued from the pose LM's wait loop (one host thread feeds both).
@@ -265,6 +274,13 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
     // the next frame's Solve by the stream itself.
     t->pre_img->ctx = t->ctx_a;
     if (pyr_build(t->pre_img, left, p.smooth_image)) return -1;
+  }
+  if (t->hint_next) {
+    // The caller told us which device image comes next (offline / batched runs know): its pyramid is built now, on
+    // the idle stream A, instead of at the head of the next call where the Solve would wait for it.
+    if (pyr_build(t->next_img, t->hint_next, p.smooth_image)) return -1;
+    t->prefetched = t->hint_next;
+    t->hint_next = nullptr;
   }
   if (p.overlap_depth == 2) {
     const auto q0 = std::chrono::steady_clock::now();
@@ -318,6 +334,13 @@ extern "C" int odo_tracker_timing(odo_tracker* t, double out[4]) {
   const double n = t->tm_frames > 0 ? (double)t->tm_frames : 1.0;
   out[0] = t->tm_frame_us / n; out[1] = t->tm_solve_us / n; out[2] = t->tm_depth_us / n; out[3] = t->tm_wait_us / n;
   t->tm_solve_us = t->tm_depth_us = t->tm_frame_us = t->tm_wait_us = 0.0; t->tm_frames = 0;
+  return 0;
+}
+
+// Optional: announce the left image of the NEXT frame before calling odo_tracker_track for the current one.
+extern "C" int odo_tracker_hint_next(odo_tracker* t, const float* next_left_dev) {
+  if (!t) return fail("NULL tracker");
+  t->hint_next = next_left_dev;
   return 0;
 }
 

@@ -470,3 +470,22 @@ def test_tracker_solve_failure_is_not_fatal(api, kitti_seq):
     with pytest.raises(_lib.OdoError):
         trk.init(*dev[0])
     trk.close()
+
+
+def test_tracker_next_frame_hint_changes_nothing(api, kitti_seq):
+    """odo_tracker_hint_next only moves the next frame's pyramid build earlier: poses must be identical."""
+    L, R = kitti_seq["left"], kitti_seq["right"]
+    out = []
+    for use_hint in (False, True):
+        trk = api.Tracker(0)
+        dev = [(trk.upload_frame(l), trk.upload_frame(r)) for l, r in zip(L, R)]
+        trk.init(*dev[0])
+        seq = [1, 2, 1, 0, 2]
+        poses = []
+        for j, k in enumerate(seq):
+            if use_hint and j + 1 < len(seq):
+                trk.hint_next(dev[seq[j + 1]][0])
+            poses.append(trk.track(*dev[k])["abs_pose"])
+        out.append(np.stack(poses))
+        trk.close()
+    assert np.array_equal(out[0], out[1])

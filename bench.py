@@ -93,6 +93,40 @@ def disparity_leg(api, seq, trk):
     return out
 
 
+def single_pair_leg(api, seq):
+    """BASELINE.json configs[0]: one 1241x376 pair through the test_optimizer.cpp path — unsmoothed pyramids, identity
+    start, Reset after the Solve, t-distribution weights (ref: test_optimizer.cpp:53-54,59-67,90,104) — and the same
+    pair with the runner's Huber weights; GPU Solve (median of 10) next to the CPU restatement (one run each)."""
+    from oracle import oracle as O
+    ctx = api.Context(0)
+    L0, R0, L1 = seq["left"][0], seq["right"][0], seq["left"][1]
+    de = api.DepthEstimator(8.0, 900.0, 15.0, 0.1, 30.0, 0.01, 28.0, 0.995, 50, 4, None, None,
+                            float(np.float32(386.1448) / np.float32(718.856)), 80000, ctx=ctx)
+    val = np.zeros(L0.shape, np.uint8)
+    disp, dep = np.zeros(L0.shape, np.float32), np.zeros(L0.shape, np.float32)
+    de.ComputeDepth(L0, R0, val, disp, dep)
+    de.close()
+    p0, d0, p1 = api.ImagePyramid(4, L0, False, ctx=ctx), api.DepthPyramid(4, dep, False, ctx=ctx), api.ImagePyramid(4, L1, False, ctx=ctx)
+    i0, dd, i1 = O.image_pyramid(L0, 4, False, flat=True), O.depth_pyramid(dep, 4, flat=True), O.image_pyramid(L1, 4, False, flat=True)
+    out = {}
+    for name, robust in (("t_distribution", 2), ("huber", 1)):
+        lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, robust, 28.0, ctx=ctx)
+        ts = []
+        for _ in range(12):
+            t0 = time.perf_counter()
+            T = lm.Solve(p0, d0, p1)
+            ts.append(time.perf_counter() - t0)
+            lm.Reset(np.eye(4), 0.01)
+        lm.close()
+        prm = O.lm_params(robust=robust)
+        t0 = time.perf_counter()
+        r = O.lm_solve(i0, dd, i1, L0.shape[0], L0.shape[1], prm)
+        cpu_s = time.perf_counter() - t0
+        out[name] = dict(gpu_solve_ms=round(float(np.median(ts[2:])) * 1e3, 4), cpu_solve_ms=round(cpu_s * 1e3, 1),
+                         evaluations=r["n_evals"], pose_max_abs_delta=float(np.abs(T.astype(np.float64) - r["pose"]).max()))
+    return out
+
+
 def multi_sequence_leg(api, seq, order, n_seq, steps):
     """Throughput with several independent sequences in flight on ONE GPU (each its own tracker: two HIP streams, two
     host threads). Not `value`: configs[1] is a single sequence, whose frames are inherently serial; this shows how
@@ -267,10 +301,26 @@ def main():
                                               f"(pyramids + Solve + ComputeDepth per frame), {cpu_dt:.1f} s")
             out["pose_max_abs_delta_vs_oracle"] = dmax
             out["speedup_vs_cpu"] = round(fps / cpu_fps, 1)
+            # the same frames again with the LM pass in the reference's own shape (materialised N x 6 Jacobian, per-pixel
+            # pow / GetCxLevel, separate fp32 product passes): timing only, fewer frames
+            from oracle import oracle as _orc
+            n_ref = max(4, n // 4)
+            _orc.lib().orc_set_reference_shape(1)
+            try:
+                ref_fps, _, ref_dt = cpu_baseline(seq, order, n_ref)
+            finally:
+                _orc.lib().orc_set_reference_shape(0)
+            out["cpu_baseline"]["reference_shape"] = dict(
+                value=round(ref_fps, 3), unit="frames/s", cores=1,
+                sample=f"first {n_ref} frames, LM pass shaped like ComputeResidualJacobianNaive + OptimizeCameraPose "
+                       f"(fp32 sums; not bit-comparable), {ref_dt:.1f} s")
         if world == 1 and not args.no_extras:
-            out["roofline_dense_1080p"] = dense_1080p_leg(api, synth)
-            out["disparity_1241x376"] = disparity_leg(api, seq, trk)
-            out["multi_sequence_1gpu"] = [multi_sequence_leg(api, seq, order, n, 100) for n in (2, 4, 8)]
+            import contextlib
+            with contextlib.redirect_stdout(sys.stderr):  # the mirrored classes print the reference's own messages
+                out["roofline_dense_1080p"] = dense_1080p_leg(api, synth)
+                out["disparity_1241x376"] = disparity_leg(api, seq, trk)
+                out["single_pair_1241x376"] = single_pair_leg(api, seq)
+                out["multi_sequence_1gpu"] = [multi_sequence_leg(api, seq, order, n, 100) for n in (2, 4, 8)]
         print(json.dumps(out))
     trk.close()
     if world > 1:

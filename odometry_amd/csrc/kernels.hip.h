@@ -793,9 +793,10 @@ struct StepArgs {
   int seq;
   int first_of_solve;   // 1: the state is initialised from `init` (lm_begin_solve) instead of being loaded
   float init[16];       // affine_init_, column-major (ref: src/lm_optimizer.cpp:76-78)
+  unsigned long long* dbg;  // diagnostic (ODO_COARSE_STAMPS): cycle sums of the coarse kernel's phases, else null
 };
 
-constexpr int kFoldChunk = 16;
+constexpr int kFoldChunk = 20;  // the 160 rows of a point-list grid in one round of loads per segment
 
 // The LM state machine of one evaluation, run by wave 0 of a block (all threads of the block must call it; it ends
 // with a block barrier): lm_decide on lane 0, the 6x6 solve across the wavefront, exp / compose on lane 0, the trace
@@ -886,6 +887,8 @@ __device__ __forceinline__ void lm_fused_prologue(const LmState* __restrict__ st
     ((int*)&s_sh)[t] = ((const int*)st_in)[t];
   }
   __syncthreads();
+  // (Prefetching this thread's keyframe point here, to overlap its latency with the fold and the solve, was measured
+  // and is slower — 7.15 vs 6.98 us per launch: the extra loads compete with the partial rows.)
   const bool pending = s_sh.pending != 0;  // block-uniform
   if (pending) {
     // (Loading the partial rows speculatively, together with the state, was measured and is slower: at the coarse
@@ -942,13 +945,15 @@ __global__ void __launch_bounds__(kLmBlock) lm_step_kernel(StepArgs a) {
   __shared__ double acc_sh[32];
   __shared__ float delta_sh[8];
   __shared__ int flags_sh[4];
-  const bool publisher = (blockIdx.x == 0);
+  // The last block of the grid evaluates no points: it publishes the state, the trace row and the host progress word
+  // (a system-scope release, ~0.5 us) while the other blocks are still evaluating.
+  const bool publisher = (blockIdx.x == gridDim.x - 1);
   lm_fused_prologue(a.st_in, a.part_in, a.lv, a.n_levels, a.lambda0, a.precision, s_sh, fold_sh, acc_sh, delta_sh, flags_sh,
                     a.trace, a.cost_stat, publisher, a.first_of_solve ? a.init : nullptr);
   const bool run = (s_sh.active != 0 && s_sh.status == 0);  // block-uniform
   const int lvl = run ? s_sh.level : 0;
   const StepLevel& L = a.lv[lvl];
-  if (run && (int)blockIdx.x < L.nblk) {
+  if (run && !publisher && (int)blockIdx.x < L.nblk) {
     float T[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) T[i] = s_sh.T[i];
@@ -1019,9 +1024,15 @@ __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int
   // state in (or initialised), a pending evaluation of an earlier launch consumed, pyramid walk started
   lm_fused_prologue(a.st_in, a.part_in, a.lv, a.n_levels, a.lambda0, a.precision, s_sh, red_sh, acc_sh, delta_sh, flags_sh,
                     a.trace, a.cost_stat, true, a.first_of_solve ? a.init : nullptr);
+  unsigned long long c_eval = 0, c_red = 0, c_sm = 0, c_it = 0, c_last = a.dbg ? __builtin_readcyclecounter() : 0;
+  const unsigned long long c_begin = c_last;
+  auto lap = [&](unsigned long long& sum) {
+    if (a.dbg) { const unsigned long long now = __builtin_readcyclecounter(); sum += now - c_last; c_last = now; }
+  };
   for (int guard = 0; guard < 4096; guard++) {
     const bool run = (s_sh.active != 0 && s_sh.status == 0 && s_sh.level >= min_level);  // block-uniform
     if (!run) break;
+    c_it++;
     const StepLevel& L = a.lv[s_sh.level];
     float T[16];
 #pragma unroll
@@ -1038,11 +1049,18 @@ __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int
       accumulate_row(acc, r, robust_weight(r, a.robust, a.huber_delta, 1.0f), J);
     }
     __syncthreads();  // everyone has read s_sh.T before the state machine rewrites it
+    lap(c_eval);
     block_reduce_acc_coarse(acc, red_sh, acc_sh);
+    lap(c_red);
     lm_state_machine(true, a.lv, a.n_levels, a.lambda0, a.precision, s_sh, acc_sh, delta_sh, flags_sh, a.trace, a.cost_stat,
                      true);
+    lap(c_sm);
   }
   lm_fused_publish(s_sh, a.st_out, a.host_prog, a.seq);
+  if (a.dbg && threadIdx.x == 0) {
+    a.dbg[0] += c_eval; a.dbg[1] += c_red; a.dbg[2] += c_sm; a.dbg[3] += c_it;
+    a.dbg[4] += __builtin_readcyclecounter() - c_begin; a.dbg[5] += 1;
+  }
 }
 
 // End of a fused Solve: consume the last pending evaluation, then affine_ = current_estimate.matrix()

@@ -581,13 +581,23 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
       L.I2 = cur_img->dev + cur_img->off[l];
       L.k = make_level_k(m->K.f0, m->K.cx0, m->K.cy0, l);
       L.max_iters = m->max_iters[l];
-      if (L.nblk > grid) grid = L.nblk;
+      if (L.nblk + 1 > grid) grid = L.nblk + 1;  // + the publisher block
       budget += m->max_iters[l] > 0 ? m->max_iters[l] : 0;
       bytes_per_level[l] = lm_level_bytes(m, l, L.rows, L.cols, L.nblk);
     }
     a.lambda0 = m->lambda; a.precision = m->precision; a.robust = m->robust; a.huber_delta = m->huber_delta;
     a.trace = m->d_trace; a.cost_stat = m->d_cost; a.host_prog = m->d_prog;
     memcpy(a.init, m->init, sizeof(a.init));
+    static unsigned long long* dbg_buf = [] {
+      unsigned long long* p = nullptr;
+      if (getenv("ODO_COARSE_STAMPS") && hipHostMalloc((void**)&p, 64, hipHostMallocMapped) == hipSuccess) memset(p, 0, 64);
+      return p;
+    }();
+    a.dbg = dbg_buf;
+    if (dbg_buf && dbg_buf[5] > 0 && dbg_buf[5] % 100 == 0)
+      fprintf(stderr, "[coarse stamps] per iteration: eval %.0f reduce %.0f state-machine %.0f cycles; iterations/launch %.2f, "
+              "cycles/launch %.0f\n", (double)dbg_buf[0] / dbg_buf[3], (double)dbg_buf[1] / dbg_buf[3],
+              (double)dbg_buf[2] / dbg_buf[3], (double)dbg_buf[3] / dbg_buf[5], (double)dbg_buf[4] / dbg_buf[5]);
     // Coarse levels (few points) run inside one workgroup: one launch covers every level >= min_level.
     int min_level = m->n_levels;
     static const int coarse_max = getenv("ODO_COARSE_MAX") ? atoi(getenv("ODO_COARSE_MAX")) : kCoarseMaxPoints;

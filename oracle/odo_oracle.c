@@ -446,9 +446,89 @@ static float tdist_scale(const float* r, int n) {
  * err += fl32(r*w) * r (ref :129); products and sums in fp64.
  * Optional dumps of the first `dump_cap` rows: r, w, J (row-major 6). Returns 0, or -1 when N == 0
  * (ref :244-248). */
+/* ---- timing-only variant in the reference's own shape (SURVEY 8d "faithful restatement") ----
+ * ComputeResidualJacobianNaive materialises J (N x 6), the weights and the residuals for the whole frame
+ * (ref: src/lm_optimizer.cpp:187-188 resize to rows*cols, :242-243 conservativeResize copy), re-evaluates
+ * std::pow(2.0f, level) and GetCxLevel for every pixel (ref: include/image_processing_global.h:22-28,35-36,50-51;
+ * src/lm_optimizer.cpp:223-233), and OptimizeCameraPose then forms JtW (6 x N temporary), JtW*J, JtW*r and r^T W r as
+ * separate fp32 passes (ref: :129,145-149). Same per-pixel arithmetic as pixel_row; the sums are fp32, so its
+ * trajectory is not bit-comparable with the oracle proper — it exists only so that the CPU time of the reference's
+ * shape can be reported next to the fused restatement. Selected with orc_set_reference_shape(1). */
+static int g_reference_shape = 0;
+void orc_set_reference_shape(int on) { g_reference_shape = on; }
+static volatile float g_two = 2.0f;  /* keeps the per-pixel pow() calls from being hoisted */
+
+static int lm_accumulate_reference_shape(const float* I1, const float* I2, const float* D1, int rows, int cols, int level,
+                                         const float T[16], int robust, float huber_delta, const orc_intr* K,
+                                         double acc[29]) {
+  const size_t cap = (size_t)rows * cols;
+  float* J = (float*)malloc(sizeof(float) * cap * 6);   /* :187 jaco.resize(rows*cols, 6) */
+  float* W = (float*)malloc(sizeof(float) * cap);       /* :188 */
+  float* r = (float*)malloc(sizeof(float) * cap);
+  if (!J || !W || !r) { free(J); free(W); free(r); return -1; }
+  int n = 0;
+  for (int y = 4; y < rows - 4; y++)
+    for (int x = 4; x < cols - 4; x++) {
+      /* the reference calls pow(2.0f, level) in ReprojectToCameraFrame (x2), WarpPixel (x2) and the Jacobian (x4), and
+       * GetCxLevel (a loop over the levels) four times, for every pixel */
+      double fl = 0.0;
+      for (int k = 0; k < 8; k++) fl = (double)K->f0 / pow((double)g_two, (double)level);
+      float cxl = 0.0f, cyl = 0.0f;
+      for (int k = 0; k < 2; k++) { cxl = cx_level(K->cx0, level); cyl = cx_level(K->cy0, level); }
+      if (pixel_row(I1, I2, D1, rows, cols, x, y, T, fl, cxl, cyl, &r[n], &J[(size_t)n * 6])) n++;
+    }
+  for (int i = 0; i < 29; i++) acc[i] = 0.0;
+  if (n == 0) { free(J); free(W); free(r); return -1; }
+  /* :242-243 conservativeResize(n, 6): Eigen reallocates and copies */
+  float* J2 = (float*)malloc(sizeof(float) * (size_t)n * 6);
+  float* r2 = (float*)malloc(sizeof(float) * (size_t)n);
+  memcpy(J2, J, sizeof(float) * (size_t)n * 6);
+  memcpy(r2, r, sizeof(float) * (size_t)n);
+  free(J); free(r);
+  /* :249-262 weights, a separate pass */
+  float scale_sqr = 1.0f;
+  if (robust == 2) { const float sg = tdist_scale(r2, n); scale_sqr = sg * sg; }
+  for (int i = 0; i < n; i++) {
+    const float ri = r2[i];
+    float w = 1.0f;
+    if (robust == 1) w = (fabsf(ri) <= huber_delta) ? 1.0f : huber_delta / fabsf(ri);
+    else if (robust == 2) w = (200.0f + 1.0f) / (200.0f + ri * ri / scale_sqr);
+    W[i] = w;
+  }
+  /* :129 err = r^T W r / N */
+  float err = 0.0f;
+  for (int i = 0; i < n; i++) err += r2[i] * W[i] * r2[i];
+  /* :145 JtW = J^T * W.asDiagonal(), a 6 x N temporary */
+  float* JtW = (float*)malloc(sizeof(float) * (size_t)n * 6);
+  for (int a = 0; a < 6; a++)
+    for (int i = 0; i < n; i++) JtW[(size_t)a * n + i] = J2[(size_t)i * 6 + a] * W[i];
+  /* :146 JtWJ = JtW * J (all 36 entries), :149 b = -JtW * r */
+  float A[6][6], b[6];
+  for (int a = 0; a < 6; a++) {
+    for (int c = 0; c < 6; c++) {
+      float sum = 0.0f;
+      for (int i = 0; i < n; i++) sum += JtW[(size_t)a * n + i] * J2[(size_t)i * 6 + c];
+      A[a][c] = sum;
+    }
+    float sb = 0.0f;
+    for (int i = 0; i < n; i++) sb += JtW[(size_t)a * n + i] * r2[i];
+    b[a] = sb;
+  }
+  int k = 0;
+  for (int a = 0; a < 6; a++)
+    for (int c = a; c < 6; c++) acc[k++] = (double)A[a][c];
+  for (int a = 0; a < 6; a++) acc[21 + a] = (double)b[a];
+  acc[27] = (double)err;
+  acc[28] = (double)n;
+  free(J2); free(r2); free(W); free(JtW);
+  return 0;
+}
+
 int orc_lm_accumulate(const float* I1, const float* I2, const float* D1, int rows, int cols, int level,
                       const float T[16], int robust, float huber_delta, const orc_intr* K, double acc[29],
                       float* sigma_out, int dump_cap, float* dump_r, float* dump_w, float* dump_J) {
+  if (g_reference_shape && !dump_cap && !sigma_out)
+    return lm_accumulate_reference_shape(I1, I2, D1, rows, cols, level, T, robust, huber_delta, K, acc);
   const double fl = (double)K->f0 / pow(2.0, (double)level);
   const float cxl = cx_level(K->cx0, level), cyl = cx_level(K->cy0, level);
   const size_t cap = (size_t)rows * cols;

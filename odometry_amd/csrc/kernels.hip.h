@@ -829,7 +829,7 @@ __device__ __forceinline__ void lm_state_machine(bool pending, const StepLevel* 
         for (int i = 0; i < 6; i++) s.delta[i] = delta_sh[i];
         lm_apply_step(&s, s.max_iters);
       }
-      if (pending) {
+        if (pending) {
         const int lvl = flags_sh[2];
         if (publisher) {
           const int ev = s.n_evals - 1;
@@ -858,7 +858,7 @@ __device__ __forceinline__ void lm_state_machine(bool pending, const StepLevel* 
         }
         if (s.status != 0) s.finished = 1;
       }
-    }
+      }
   }
   __syncthreads();
 }
@@ -983,31 +983,28 @@ __global__ void __launch_bounds__(kLmBlock) lm_step_kernel(StepArgs a) {
 // >= min_level: no launch, no global partials, no state reload between iterations. It hands over to the generic step
 // launches with the next level already begun.
 constexpr int kCoarseBlock = 512;
+constexpr int kCoarseLdsBytes = ODO_NACC * (kCoarseBlock + 8) * (int)sizeof(double);  // [29][512 + kRedPad] doubles
 constexpr int kCoarseMaxPoints = 1024;  // levels with more points go to the multi-block step kernel (measured: a 512-thread
                                         // workgroup walking ~2000 points four per thread is no faster than seven blocks)
 
-// 29 sums of a 512-thread block into LDS (out), two rounds of 15 + 14 quantities through one 62 KB buffer.
-__device__ __forceinline__ void block_reduce_acc_coarse(const double acc[ODO_NACC], double* red /* [15][520] */, double* out) {
+// 29 sums of a 512-thread block into LDS (out) in one round through a 118 KB transpose buffer (dynamic LDS: gfx950
+// gives a workgroup up to 160 KB; two rounds through 62 KB took 5 100 cycles per iteration, this takes 3 400).
+__device__ __forceinline__ void block_reduce_acc_coarse(const double acc[ODO_NACC], double* red /* [29][520] */, double* out) {
   constexpr int W = kCoarseBlock + kRedPad;
   const int t = threadIdx.x;
 #pragma unroll
-  for (int round = 0; round < 2; round++) {
-    const int q0 = round * 15, nq = round == 0 ? 15 : ODO_NACC - 15;
-    if (round) __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 15; q++)
-      if (q < nq) red[q * W + t] = acc[q0 + q];
-    __syncthreads();
-    if (t < nq * 8) {
-      const int q = t >> 3, s = t & 7;
-      double v = 0.0;
+  for (int q = 0; q < ODO_NACC; q++) red[q * W + t] = acc[q];
+  __syncthreads();
+  if (t < ODO_NACC * 16) {  // 16 lanes per quantity: 32 rows each, then a 16-wide butterfly
+    const int q = t >> 4, s = t & 15;
+    double v = 0.0;
 #pragma unroll 8
-      for (int i = 0; i < kCoarseBlock / 8; i++) v += red[q * W + i * 8 + s];
-      v += __shfl_xor(v, 4, 8);
-      v += __shfl_xor(v, 2, 8);
-      v += __shfl_xor(v, 1, 8);
-      if (s == 0) out[q0 + q] = v;
-    }
+    for (int i = 0; i < kCoarseBlock / 16; i++) v += red[q * W + i * 16 + s];
+    v += __shfl_xor(v, 8, 16);
+    v += __shfl_xor(v, 4, 16);
+    v += __shfl_xor(v, 2, 16);
+    v += __shfl_xor(v, 1, 16);
+    if (s == 0) out[q] = v;
   }
   __syncthreads();
 }
@@ -1017,7 +1014,7 @@ __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int
   // (selection, SSD scan) at the same time: raise this workgroup's issue priority on the SIMDs it shares with them.
   __builtin_amdgcn_s_setprio(3);
   __shared__ LmState s_sh;
-  __shared__ double red_sh[15 * (kCoarseBlock + kRedPad)];  // reduction buffer; its head doubles as the fold scratch
+  extern __shared__ double red_sh[];  // kCoarseLdsBytes: reduction buffer; its head doubles as the fold scratch
   __shared__ double acc_sh[32];
   __shared__ float delta_sh[8];
   __shared__ int flags_sh[4];
@@ -1048,6 +1045,9 @@ __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int
       residual_jacobian(p, L.I2, L.rows, L.cols, ui, vi, &r, J);
       accumulate_row(acc, r, robust_weight(r, a.robust, a.huber_delta, 1.0f), J);
     }
+    // (Keeping each thread's points in registers across iterations and staging the 29 KB level image in LDS was
+    // measured: no faster. With 8 waves on one CU the evaluation is VALU-issue bound — ~300 instructions per point at two
+    // waves per SIMD, ~4 000 cycles — not latency bound.)
     __syncthreads();  // everyone has read s_sh.T before the state machine rewrites it
     lap(c_eval);
     block_reduce_acc_coarse(acc, red_sh, acc_sh);

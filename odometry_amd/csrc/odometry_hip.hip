@@ -338,6 +338,8 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
   m->K = K ? *K : kKitti00;  // null camera: the reference only warns (ref: src/lm_optimizer.cpp:35-38)
   memcpy(m->init, init_colmajor, sizeof(m->init));
   HIP_OK(hipSetDevice(ctx->device));
+  // the single-workgroup coarse kernel reduces through 118 KB of LDS (gfx950: up to 160 KB per workgroup)
+  HIP_OK(hipFuncSetAttribute((const void*)lm_coarse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kCoarseLdsBytes));
   HIP_OK(hipMalloc((void**)&m->d_state, sizeof(LmState) * 2));                          // double-buffered (fused pipeline)
   HIP_OK(hipMalloc((void**)&m->d_partials, sizeof(double) * 2 * kLmMaxBlocks * ODO_NACC)); // idem
   HIP_OK(hipMalloc((void**)&m->d_init, sizeof(float) * 16));
@@ -590,7 +592,7 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
     memcpy(a.init, m->init, sizeof(a.init));
     static unsigned long long* dbg_buf = [] {
       unsigned long long* p = nullptr;
-      if (getenv("ODO_COARSE_STAMPS") && hipHostMalloc((void**)&p, 64, hipHostMallocMapped) == hipSuccess) memset(p, 0, 64);
+      if (getenv("ODO_COARSE_STAMPS") && hipHostMalloc((void**)&p, 128, hipHostMallocMapped) == hipSuccess) memset(p, 0, 128);
       return p;
     }();
     a.dbg = dbg_buf;
@@ -613,10 +615,10 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
       a.seq = seq; a.first_of_solve = 1;
       const bool ev = m->ev_on && m->ev_pool && m->ev_pool->size() >= 2;
       if (ev)
-        hipExtLaunchKernelGGL(lm_coarse_kernel, dim3(1), dim3(kCoarseBlock), 0, s, (*m->ev_pool)[0], (*m->ev_pool)[1], 0, a,
-                              min_level);
+        hipExtLaunchKernelGGL(lm_coarse_kernel, dim3(1), dim3(kCoarseBlock), kCoarseLdsBytes, s, (*m->ev_pool)[0],
+                              (*m->ev_pool)[1], 0, a, min_level);
       else
-        hipLaunchKernelGGL(lm_coarse_kernel, dim3(1), dim3(kCoarseBlock), 0, s, a, min_level);
+        hipLaunchKernelGGL(lm_coarse_kernel, dim3(1), dim3(kCoarseBlock), kCoarseLdsBytes, s, a, min_level);
       seq++;
       launches++;
     }

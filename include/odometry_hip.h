@@ -30,6 +30,7 @@ typedef struct odo_pyr odo_pyr;
 typedef struct odo_lm odo_lm;
 typedef struct odo_depth odo_depth;
 typedef struct odo_tracker odo_tracker;
+typedef struct odo_camera odo_camera;
 
 /* Level-0 pinhole intrinsics (fy = fx). NULL wherever accepted = the KITTI-00 constants the reference
  * hard-codes (ref: include/image_processing_global.h:35-36: 718.856f, 607.1928, 185.2157). */
@@ -222,6 +223,39 @@ int odo_tracker_timing(odo_tracker* t, double out[4]);
 odo_lm* odo_tracker_lm(odo_tracker* t);
 odo_ctx* odo_tracker_ctx(odo_tracker* t);
 int odo_tracker_destroy(odo_tracker* t);
+
+/* ---- camera model: rectified intrinsics per level, undistort + rectify ---------------------------------
+ * Replaces odometry::CameraPyramid (ref: include/camera.h:16-119).
+ * odo_camera_create      = CameraPyramid(levels, fx, fy, f_theta, cx, cy, k1, k2, r1, r2, sensor_w, sensor_h,
+ *                          resolution_w, resolution_h) (ref: include/camera.h:34-35; src/camera.cpp:12-38).
+ * odo_camera_configure   = ConfigureCamera(rectify_rotation 3x3, new_intrinsic 3x4, new_size, CV_32FC1, false)
+ *                          (ref: include/camera.h:56-57; src/camera.cpp:40-69): the intrinsic pyramid
+ *                          (f / 2, c <- (c + 0.5) / 2 + 0.5 per level, double) and the cv::initUndistortRectifyMap
+ *                          lookup maps, built on the device. R and P are row-major doubles as cv::stereoRectify
+ *                          returns them (cv::stereoRectify itself, a one-off host-side calibration step inside
+ *                          SetUpStereoCameraSystem, ref: src/camera.cpp:138-141, stays with the caller).
+ * odo_camera_undistort_rectify = UndistortRectify(src_raw, dst, INTER_LINEAR, BORDER_CONSTANT, borderValue)
+ *                          (ref: include/camera.h:68; src/camera.cpp:71-82): cv::remap through the maps. The
+ *                          reference's hard 480x640 check lives in the C++ shim; this entry takes any size.
+ *                          dst is map_rows x map_cols. The _dev variant works on device-resident images and
+ *                          is asynchronous on the context's stream.
+ * odo_camera_intrinsics  = fx/fy/f_theta/cx/cy_double(level) (ref: include/camera.h:80-85), out5 in that order.
+ * odo_camera_raw         = the raw-parameter accessors (ref: include/camera.h:91-105). */
+int odo_camera_create(odo_ctx* ctx, int levels, double fx, double fy, double f_theta, double cx, double cy, double k1,
+                      double k2, double r1, double r2, double sensor_width, double sensor_height, int resolution_width,
+                      int resolution_height, odo_camera** out);
+int odo_camera_configure(odo_camera* cam, const double R_rowmajor[9], const double P_rowmajor[12], int new_width,
+                         int new_height);
+int odo_camera_levels(const odo_camera* cam);
+int odo_camera_intrinsics(const odo_camera* cam, int level, double out5[5]);
+int odo_camera_raw(const odo_camera* cam, double raw5[5], double dist4[4], double sensor2[2], int resolution2[2]);
+int odo_camera_map_size(const odo_camera* cam, int* rows, int* cols);
+int odo_camera_download_maps(const odo_camera* cam, float* mapx_host, float* mapy_host);
+int odo_camera_undistort_rectify(odo_camera* cam, const float* src, int src_rows, int src_cols, float* dst,
+                                 float border_value);
+int odo_camera_undistort_rectify_dev(odo_camera* cam, const float* src_dev, int src_rows, int src_cols, float* dst_dev,
+                                     float border_value);
+int odo_camera_destroy(odo_camera* cam);
 
 #ifdef __cplusplus
 }

@@ -5,6 +5,8 @@
 //   * KITTI pose writer         ref: :374-430 (save_txt: std::to_string of each float, single spaces, one line per frame)
 //   * translation-error eval    ref: :361-372 (eval_pose: ||t_pred - t_gt|| per frame and its mean)
 //   * 8-bit grey PNG reader     ref: :334-359 (load_data: cv::imread(IMREAD_GRAYSCALE) -> convertTo(CV_32F), values 0..255)
+//   * stereo calibration file   ref: src/camera.cpp:170-352 (ReadStereoCalibrationFile: the Kalibr-style camchain text with
+//                               cam0: / cam1: blocks, distortion_coeffs, intrinsics, T_cn_cnm1, sensor_size, resolution)
 // The reference uses OpenCV for the PNGs; this image has none, so the decoder (zlib inflate + PNG unfiltering for
 // colour type 0, bit depth 8, non-interlaced — what KITTI odometry grey images are) is written out here.
 #ifndef ODOMETRY_IO_HPP
@@ -290,6 +292,84 @@ inline bool read_png_gray_f32(const std::string& path, std::vector<float>& pixel
   pixels.resize(u8.size());
   for (size_t i = 0; i < u8.size(); i++) pixels[i] = (float)u8[i];
   return true;
+}
+
+// ---- stereo calibration file ---------------------------------------------------------------------
+// What ReadStereoCalibrationFile hands back (ref: src/camera.cpp:170-175,299-352): per camera the 4 intrinsics
+// (fu, fv, pu, pv), the 4 distortion coefficients (k1, k2, r1, r2) and the sensor size in mm; the rotation (row-major
+// 3x3) and translation of the right camera relative to the left from the T_cn_cnm1 block; the image resolution.
+struct StereoCalibration {
+  double intrinsics[2][4];
+  double distortion[2][4];
+  double sensor_size[2][2];  // [cam][width, height] in mm
+  double rotate_left_right[9];
+  double translate_left_right[3];
+  int resolution[2];         // [width, height] in pixels (one shared slot, like the reference: the last block wins)
+};
+
+namespace detail {
+// numbers of the first "[ ... ]" list after `pos` on the line, comma separated
+inline size_t bracket_list(const std::string& line, size_t pos, double* out, size_t max_n) {
+  const size_t lb = line.find('[', pos);
+  if (lb == std::string::npos) return 0;
+  const size_t rb = line.find(']', lb);
+  std::string body = line.substr(lb + 1, rb == std::string::npos ? std::string::npos : rb - lb - 1);
+  size_t n = 0, start = 0;
+  while (n < max_n && start <= body.size()) {
+    const size_t comma = body.find(',', start);
+    const std::string tok = body.substr(start, comma == std::string::npos ? std::string::npos : comma - start);
+    out[n++] = std::atof(tok.c_str());  // the reference parses every field with atof / atoi (ref: :233,249,...)
+    if (comma == std::string::npos) break;
+    start = comma + 1;
+  }
+  return n;
+}
+}  // namespace detail
+
+// Returns false when the file cannot be opened or a block is incomplete (the reference calls exit(-1) there,
+// ref: src/camera.cpp:204-214).
+inline bool read_stereo_calibration_file(const std::string& path, StereoCalibration& out) {
+  std::ifstream f(path);
+  if (!f.is_open()) return false;
+  std::memset(&out, 0, sizeof(out));
+  int cam = -1;
+  bool have_T = false, have[2][3] = {{false, false, false}, {false, false, false}};
+  std::string line;
+  while (std::getline(f, line)) {
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    if (line == "cam0:") cam = 0;                                           // ref: :216-224
+    else if (line == "cam1:") cam = 1;
+    size_t p;
+    if ((p = line.find("distortion_coeffs:")) != std::string::npos) {       // ref: :226-240
+      if (cam < 0 || detail::bracket_list(line, p, out.distortion[cam], 4) != 4) return false;
+      have[cam][0] = true;
+    } else if ((p = line.find("intrinsics:")) != std::string::npos) {       // ref: :241-255
+      if (cam < 0 || detail::bracket_list(line, p, out.intrinsics[cam], 4) != 4) return false;
+      have[cam][1] = true;
+    } else if ((p = line.find("T_cn_cnm1:")) != std::string::npos) {        // ref: :256-281: the next four lines, "- [a, b, c, d]"
+      double rows[4][4];
+      for (int r = 0; r < 4; r++) {
+        if (!std::getline(f, line)) return false;
+        if (detail::bracket_list(line, 0, rows[r], 4) != 4) return false;
+      }
+      for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) out.rotate_left_right[r * 3 + c] = rows[r][c];   // ref: :325-337
+        out.translate_left_right[r] = rows[r][3];
+      }
+      have_T = true;
+    } else if ((p = line.find("sensor_size:")) != std::string::npos) {      // ref: :282-296
+      if (cam < 0 || detail::bracket_list(line, p, out.sensor_size[cam], 2) != 2) return false;
+      have[cam][2] = true;
+    } else if ((p = line.find("resolution:")) != std::string::npos) {       // ref: :297-311
+      double wh[2];
+      if (detail::bracket_list(line, p, wh, 2) != 2) return false;
+      out.resolution[0] = (int)wh[0]; out.resolution[1] = (int)wh[1];
+    }
+  }
+  for (int c = 0; c < 2; c++)
+    for (int k = 0; k < 3; k++)
+      if (!have[c][k]) return false;
+  return have_T && out.resolution[0] > 0 && out.resolution[1] > 0;
 }
 
 }  // namespace io

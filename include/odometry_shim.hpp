@@ -6,6 +6,7 @@
 //   include/depth_estimate.h  (ref: :24-121)   DepthEstimator
 //   include/keyframe.h        (ref: :17-60)    KeyFrame
 //   include/data_types.h      (ref: :10-28)    Affine4f, OptimizerStatus, GlobalStatus, PixelType
+//   include/camera.h          (ref: :16-119)   CameraPyramid (the cv::stereoRectify set-up step stays with the caller)
 // Same namespace, class names, constructor / method signatures, copy semantics and error behaviour (status ints,
 // messages on std::cout, no exceptions, Solve returns the pseudo-identity on failure), so
 // run_odometry_kitti_offline.cpp compiles against it unchanged once its includes point here.
@@ -70,8 +71,25 @@ inline float* affine_data(Affine4f& a) { return a.m; }
 // ------------------------------------------------------------------------------------------------
 #ifdef ODOMETRY_SHIM_WITH_OPENCV
 typedef cv::Mat Mat;
+typedef cv::Size Size;
+typedef cv::Scalar Scalar;
+enum { kInterLinear = cv::INTER_LINEAR, kBorderConstant = cv::BORDER_CONSTANT, kMap32FC1 = CV_32FC1 };
+inline double scalar0(const Scalar& s) { return s[0]; }
 #else
-enum { CV_8U = 0, CV_32F = 5 };
+enum { CV_8U = 0, CV_32F = 5, CV_64F = 6, CV_32FC1 = 5 };
+enum { INTER_LINEAR = 1, BORDER_CONSTANT = 0 };
+enum { kInterLinear = INTER_LINEAR, kBorderConstant = BORDER_CONSTANT, kMap32FC1 = CV_32FC1 };
+struct Size {  // cv::Size: (width, height)
+  int width = 0, height = 0;
+  Size() {}
+  Size(int w, int h) : width(w), height(h) {}
+};
+struct Scalar {  // cv::Scalar: only the first channel matters for single-channel images
+  double val[4] = {0, 0, 0, 0};
+  Scalar() {}
+  Scalar(double v0) { val[0] = v0; }
+};
+inline double scalar0(const Scalar& s) { return s.val[0]; }
 // The subset of cv::Mat the runner and the estimators touch: rows, cols, type(), at<T>, ptr<T>, isContinuous,
 // copyTo / clone, ref-counted header copies.
 class Mat {
@@ -82,6 +100,7 @@ class Mat {
   Mat(int r, int c, int type, double fill) {
     create(r, c, type);
     if (type_ == CV_32F) for (size_t i = 0; i < (size_t)r * c; i++) reinterpret_cast<float*>(buf_->data())[i] = (float)fill;
+    else if (type_ == CV_64F) for (size_t i = 0; i < (size_t)r * c; i++) reinterpret_cast<double*>(buf_->data())[i] = fill;
     else std::memset(buf_->data(), (int)fill, buf_->size());
   }
   void create(int r, int c, int type) {
@@ -90,7 +109,7 @@ class Mat {
   }
   int type() const { return type_; }
   int channels() const { return 1; }
-  size_t elemSize() const { return type_ == CV_32F ? 4 : 1; }
+  size_t elemSize() const { return type_ == CV_64F ? 8 : type_ == CV_32F ? 4 : 1; }
   bool isContinuous() const { return true; }
   bool empty() const { return !buf_ || rows == 0 || cols == 0; }
   template <class T> T* ptr(int y = 0) { return reinterpret_cast<T*>(buf_->data() + (size_t)y * cols * elemSize()); }
@@ -108,7 +127,121 @@ class Mat {
 };
 #endif
 
-class CameraPyramid;  // ref: include/camera.h — never dereferenced on this path; the runner passes nullptr
+// ------------------------------------------------------------------------------------------------
+namespace detail { inline odo_ctx* context(); }
+
+// ref: include/camera.h:16-119. Raw calibration, the rectified intrinsic pyramid and the undistort + rectify remap, on
+// the device. The runner passes nullptr for its cameras (ref: run_odometry_kitti_offline.cpp:51-52) and the
+// optimizer / estimator never dereference them (the reference hard-codes the KITTI-00 constants, "only for debug now").
+class CameraPyramid {
+ public:
+  CameraPyramid() = delete;
+  CameraPyramid(int levels, double fx, double fy, double f_theta, double cx, double cy, double k1, double k2, double r1,
+                double r2, double sensor_width, double sensor_height, int resolution_width, int resolution_height)
+      : resolution_width_(resolution_width), resolution_height_(resolution_height), sensor_width_(sensor_width),
+        sensor_height_(sensor_height), pixels_per_mm_x_(resolution_width / sensor_width),      // ref: src/camera.cpp:36
+        pixels_per_mm_y_(resolution_height / sensor_height) {                                  // ref: :37
+    intrinsic_raw_ = Mat(3, 3, CV_64F, 0.0);
+    intrinsic_raw_.at<double>(0, 0) = fx; intrinsic_raw_.at<double>(1, 1) = fy; intrinsic_raw_.at<double>(0, 2) = cx;
+    intrinsic_raw_.at<double>(1, 2) = cy; intrinsic_raw_.at<double>(2, 2) = 1; intrinsic_raw_.at<double>(0, 1) = f_theta;
+    distortion_param_ = Mat(1, 4, CV_64F, 0.0);
+    distortion_param_.at<double>(0, 0) = k1; distortion_param_.at<double>(0, 1) = k2;
+    distortion_param_.at<double>(0, 2) = r1; distortion_param_.at<double>(0, 3) = r2;
+    levels_ = levels;
+    if (odo_camera_create(detail::context(), levels, fx, fy, f_theta, cx, cy, k1, k2, r1, r2, sensor_width, sensor_height,
+                          resolution_width, resolution_height, &cam_) != 0)
+      std::cout << "odometry_hip: " << odo_last_error() << std::endl;
+  }
+  ~CameraPyramid() { odo_camera_destroy(cam_); }
+  CameraPyramid(const CameraPyramid&) = delete;
+  CameraPyramid& operator=(const CameraPyramid&) = delete;
+
+  // ref: include/camera.h:56-57, src/camera.cpp:40-69. rectify_rotation 3x3 and new_intrinsic 3x4, CV_64F.
+  void ConfigureCamera(const Mat& rectify_rotation, const Mat& new_intrinsic, const Size& new_size, int map_type = kMap32FC1,
+                       bool use_int_map = false) {
+    if (map_type != kMap32FC1 || use_int_map) {
+      std::cout << "odometry_hip: only CV_32FC1 floating-point remaps are implemented" << std::endl;
+      return;
+    }
+    double R[9], P[12];
+    for (int i = 0; i < 3; i++) {
+      for (int j = 0; j < 3; j++) R[i * 3 + j] = rectify_rotation.at<double>(i, j);
+      for (int j = 0; j < 4; j++) P[i * 4 + j] = new_intrinsic.at<double>(i, j);
+    }
+    if (odo_camera_configure(cam_, R, P, new_size.width, new_size.height) != 0) {
+      std::cout << "odometry_hip: " << odo_last_error() << std::endl;
+      return;
+    }
+    intrinsic_.clear();
+    for (int l = 0; l < levels_; l++) {
+      double k[5];
+      odo_camera_intrinsics(cam_, l, k);
+      Mat m(3, 3, CV_64F, 0.0);
+      m.at<double>(0, 0) = k[0]; m.at<double>(1, 1) = k[1]; m.at<double>(0, 1) = k[2];
+      m.at<double>(0, 2) = k[3]; m.at<double>(1, 2) = k[4]; m.at<double>(2, 2) = 1;
+      intrinsic_.push_back(m);
+    }
+    new_size_ = new_size;
+  }
+
+  // ref: include/camera.h:68, src/camera.cpp:71-82. dst is (re)allocated to the configured size.
+  GlobalStatus UndistortRectify(const Mat& src_raw, Mat& dst, int interpolation = kInterLinear,
+                                int borderMode = kBorderConstant, const Scalar& borderValue = Scalar()) {
+    if (src_raw.rows != 480 || src_raw.cols != 640) {  // ref: src/camera.cpp:74-77
+      std::cout << "camera raw image is not 480x640!" << std::endl;
+      return -1;
+    }
+    if (interpolation != kInterLinear || borderMode != kBorderConstant || src_raw.type() != PixelType ||
+        !src_raw.isContinuous()) {
+      std::cout << "odometry_hip: UndistortRectify takes continuous CV_32F, INTER_LINEAR, BORDER_CONSTANT" << std::endl;
+      return -1;
+    }
+    dst.create(new_size_.height, new_size_.width, PixelType);
+    if (odo_camera_undistort_rectify(cam_, src_raw.ptr<float>(), src_raw.rows, src_raw.cols, dst.ptr<float>(),
+                                     (float)scalar0(borderValue)) != 0) {
+      std::cout << "odometry_hip: " << odo_last_error() << std::endl;
+      return -1;
+    }
+    return 0;
+  }
+
+  // accessors, ref: include/camera.h:73-105
+  float fx_float(int level) { return float(intrinsic_[level].at<double>(0, 0)); }
+  float fy_float(int level) { return float(intrinsic_[level].at<double>(1, 1)); }
+  float f_theta_float(int level) { return float(intrinsic_[level].at<double>(0, 1)); }
+  float cx_float(int level) { return float(intrinsic_[level].at<double>(0, 2)); }
+  float cy_float(int level) { return float(intrinsic_[level].at<double>(1, 2)); }
+  float f_meters_float(int level) { return float(intrinsic_[level].at<double>(0, 0) / pixels_per_mm_x_); }
+  double fx_double(int level) { return intrinsic_[level].at<double>(0, 0); }
+  double fy_double(int level) { return intrinsic_[level].at<double>(1, 1); }
+  double f_theta_double(int level) { return intrinsic_[level].at<double>(0, 1); }
+  double cx_double(int level) { return intrinsic_[level].at<double>(0, 2); }
+  double cy_double(int level) { return intrinsic_[level].at<double>(1, 2); }
+  double f_meters_double(int level) { return intrinsic_[level].at<double>(0, 0) / pixels_per_mm_x_; }
+  const Mat& get_intrinsic_rectified(int level) { return intrinsic_[level]; }
+  double sensor_w_double() { return sensor_width_; }
+  double sensor_h_double() { return sensor_height_; }
+  double pixels_per_mm_x_double() { return pixels_per_mm_x_; }
+  double pixels_per_mm_y_double() { return pixels_per_mm_y_; }
+  int resolution_raw_w() { return resolution_width_; }
+  int resolution_raw_h() { return resolution_height_; }
+  float sensor_w_float() { return float(sensor_width_); }
+  float sensor_h_float() { return float(sensor_height_); }
+  float pixels_per_mm_x_float() { return float(pixels_per_mm_x_); }
+  float pixels_per_mm_y_float() { return float(pixels_per_mm_y_); }
+  const Mat& get_intrinsic_raw() { return intrinsic_raw_; }
+  const Mat& get_distortion_coeff() { return distortion_param_; }
+  odo_camera* handle() { return cam_; }
+
+ private:
+  Mat intrinsic_raw_, distortion_param_;
+  int resolution_width_, resolution_height_;
+  double sensor_width_, sensor_height_, pixels_per_mm_x_, pixels_per_mm_y_;
+  int levels_ = 0;
+  std::vector<Mat> intrinsic_;
+  Size new_size_;
+  odo_camera* cam_ = nullptr;
+};
 
 namespace detail {
 // One HIP context (stream) per host thread, created on first use — the reference is single-threaded
@@ -198,8 +331,19 @@ class LevenbergMarquardtOptimizer {  // ref: include/lm_optimizer.h:24-115
                               const Affine4f& kRelativeInit, const std::shared_ptr<CameraPyramid>& kCameraPtr,
                               const int robust_est, const float huber_delta = 4.0f / 255.0f) {
     if (kCameraPtr == nullptr) std::cout << "LM Optimizer failed! Invalid camera pointer!" << std::endl;  // ref: :35-36
+    // The reference stores the camera but evaluates with hard-coded KITTI-00 constants (include/image_processing_global.h:
+    // 33-36,48-51: the camera_ptr lines are commented out, "only for debug now"), so parity mode passes K = NULL.
+    // -DODOMETRY_SHIM_USE_CAMERA_INTRINSICS switches to the camera's rectified level-0 intrinsics instead.
+    const odo_intrinsics* Kp = nullptr;
+#ifdef ODOMETRY_SHIM_USE_CAMERA_INTRINSICS
+    odo_intrinsics K;
+    if (kCameraPtr != nullptr) {
+      K.f0 = kCameraPtr->fx_float(0); K.cx0 = kCameraPtr->cx_float(0); K.cy0 = kCameraPtr->cy_float(0);
+      Kp = &K;
+    }
+#endif
     if (odo_lm_create(detail::context(), lambda, precision, kMaxIterations.data(), (int)kMaxIterations.size(),
-                      affine_data(kRelativeInit), robust_est, huber_delta, nullptr, &lm_) != 0)
+                      affine_data(kRelativeInit), robust_est, huber_delta, Kp, &lm_) != 0)
       std::cout << "odometry_hip: " << odo_last_error() << std::endl;
   }
   ~LevenbergMarquardtOptimizer() { odo_lm_destroy(lm_); }
@@ -239,11 +383,21 @@ class DepthEstimator {  // ref: include/depth_estimate.h:24-121
   DepthEstimator() = delete;
   DepthEstimator(float grad_th, float ssd_th, float photo_th, float min_depth, float max_depth, float lambda,
                  float huber_delta, float precision, int max_iters, int boundary,
-                 const std::shared_ptr<CameraPyramid>& /*left_cam_ptr*/, const std::shared_ptr<CameraPyramid>& /*right_cam_ptr*/,
+                 const std::shared_ptr<CameraPyramid>& left_cam_ptr, const std::shared_ptr<CameraPyramid>& /*right_cam_ptr*/,
                  float baseline, int max_residuals = 5000)
       : max_iters_(max_iters) {
+    const odo_intrinsics* Kp = nullptr;  // parity mode: the reference's hard-coded focal length (src/depth_estimate.cpp:213-214,272-273)
+#ifdef ODOMETRY_SHIM_USE_CAMERA_INTRINSICS
+    odo_intrinsics K;
+    if (left_cam_ptr != nullptr) {
+      K.f0 = left_cam_ptr->fx_float(0); K.cx0 = left_cam_ptr->cx_float(0); K.cy0 = left_cam_ptr->cy_float(0);
+      Kp = &K;
+    }
+#else
+    (void)left_cam_ptr;
+#endif
     if (odo_depth_create(detail::context(), grad_th, ssd_th, photo_th, min_depth, max_depth, lambda, huber_delta, precision,
-                         max_iters, boundary, nullptr, baseline, max_residuals, 0, 0, &d_) != 0)
+                         max_iters, boundary, Kp, baseline, max_residuals, 0, 0, &d_) != 0)
       std::cout << "odometry_hip: " << odo_last_error() << std::endl;
   }
   ~DepthEstimator() { odo_depth_destroy(d_); }

@@ -100,6 +100,16 @@ SIGNATURES = {
     "odo_tracker_lm": (_vp, [_vp]),
     "odo_tracker_ctx": (_vp, [_vp]),
     "odo_tracker_destroy": (C.c_int, [_vp]),
+    "odo_camera_create": (C.c_int, [_vp, C.c_int] + [C.c_double] * 11 + [C.c_int, C.c_int, C.POINTER(_vp)]),
+    "odo_camera_configure": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_int]),
+    "odo_camera_levels": (C.c_int, [_vp]),
+    "odo_camera_intrinsics": (C.c_int, [_vp, C.c_int, _dp]),
+    "odo_camera_raw": (C.c_int, [_vp, _dp, _dp, _dp, _ip]),
+    "odo_camera_map_size": (C.c_int, [_vp, _ip, _ip]),
+    "odo_camera_download_maps": (C.c_int, [_vp, _fp, _fp]),
+    "odo_camera_undistort_rectify": (C.c_int, [_vp, _fp, C.c_int, C.c_int, _fp, C.c_float]),
+    "odo_camera_undistort_rectify_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_float]),
+    "odo_camera_destroy": (C.c_int, [_vp]),
 }
 
 _lib = None

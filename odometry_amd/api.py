@@ -324,6 +324,87 @@ class DepthEstimator:
             pass
 
 
+INTER_LINEAR, BORDER_CONSTANT, CV_32FC1 = 1, 0, 5  # the OpenCV constants the reference passes (src/camera.cpp:41,71-72)
+
+
+class CameraPyramid:
+    """ref: include/camera.h:16-119 — raw calibration, rectified intrinsics per pyramid level, undistort + rectify."""
+
+    def __init__(self, levels, fx, fy, f_theta, cx, cy, k1, k2, r1, r2, sensor_width, sensor_height, resolution_width,
+                 resolution_height, ctx=None):
+        self.ctx = ctx or default_context()
+        h = C.c_void_p()
+        L.check(self.ctx.lib.odo_camera_create(self.ctx.h, levels, fx, fy, f_theta, cx, cy, k1, k2, r1, r2, sensor_width,
+                                               sensor_height, resolution_width, resolution_height, C.byref(h)),
+                "odo_camera_create")
+        self.h = h
+        self.levels_ = levels
+        self.sensor_width_, self.sensor_height_ = float(sensor_width), float(sensor_height)
+        self.resolution_width_, self.resolution_height_ = int(resolution_width), int(resolution_height)
+        self.pixels_per_mm_x_ = resolution_width / sensor_width    # ref: src/camera.cpp:36-37
+        self.pixels_per_mm_y_ = resolution_height / sensor_height
+
+    def ConfigureCamera(self, rectify_rotation, new_intrinsic, new_size, map_type=CV_32FC1, use_int_map=False):
+        """ref: src/camera.cpp:40-69. new_size = (width, height) like cv::Size; only CV_32FC1 float maps exist."""
+        if map_type != CV_32FC1 or use_int_map:
+            raise ValueError("only CV_32FC1 floating-point maps are implemented (the reference's defaults)")
+        R = np.ascontiguousarray(rectify_rotation, np.float64).reshape(9)
+        P = np.ascontiguousarray(new_intrinsic, np.float64).reshape(12)
+        dp = C.POINTER(C.c_double)
+        L.check(self.ctx.lib.odo_camera_configure(self.h, R.ctypes.data_as(dp), P.ctypes.data_as(dp), int(new_size[0]),
+                                                  int(new_size[1])), "odo_camera_configure")
+
+    def UndistortRectify(self, src_raw, dst, interpolation=INTER_LINEAR, borderMode=BORDER_CONSTANT, borderValue=0.0,
+                         any_size=False):
+        """ref: src/camera.cpp:71-82. dst: float32 array of the configured size, filled in place. Returns 0 / -1.
+        any_size=False keeps the reference's hard 480x640 check (:74-77)."""
+        src = _f32(src_raw)
+        if not any_size and (src.shape[0] != 480 or src.shape[1] != 640):
+            print("camera raw image is not 480x640!")
+            return -1
+        if interpolation != INTER_LINEAR or borderMode != BORDER_CONSTANT:
+            raise ValueError("only INTER_LINEAR / BORDER_CONSTANT are implemented (the reference's defaults)")
+        st = self.ctx.lib.odo_camera_undistort_rectify(self.h, _fp(src), src.shape[0], src.shape[1], _fp(dst),
+                                                       C.c_float(borderValue))
+        return 0 if st == 0 else -1
+
+    def maps(self):
+        r, c = C.c_int(0), C.c_int(0)
+        L.check(self.ctx.lib.odo_camera_map_size(self.h, C.byref(r), C.byref(c)), "odo_camera_map_size")
+        mx, my = np.empty((r.value, c.value), np.float32), np.empty((r.value, c.value), np.float32)
+        L.check(self.ctx.lib.odo_camera_download_maps(self.h, _fp(mx), _fp(my)), "odo_camera_download_maps")
+        return mx, my
+
+    def _intr(self, level):
+        out = (C.c_double * 5)()
+        L.check(self.ctx.lib.odo_camera_intrinsics(self.h, level, out), "odo_camera_intrinsics")
+        return list(out)
+
+    # accessors, ref: include/camera.h:73-85
+    def fx_double(self, level): return self._intr(level)[0]
+    def fy_double(self, level): return self._intr(level)[1]
+    def f_theta_double(self, level): return self._intr(level)[2]
+    def cx_double(self, level): return self._intr(level)[3]
+    def cy_double(self, level): return self._intr(level)[4]
+    def f_meters_double(self, level): return self._intr(level)[0] / self.pixels_per_mm_x_
+    def fx_float(self, level): return float(np.float32(self.fx_double(level)))
+    def fy_float(self, level): return float(np.float32(self.fy_double(level)))
+    def f_theta_float(self, level): return float(np.float32(self.f_theta_double(level)))
+    def cx_float(self, level): return float(np.float32(self.cx_double(level)))
+    def cy_float(self, level): return float(np.float32(self.cy_double(level)))
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.odo_camera_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class KeyFrame:
     """ref: include/keyframe.h:17-60 — holder of four images and an absolute pose."""
 

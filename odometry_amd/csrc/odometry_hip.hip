@@ -1174,3 +1174,4 @@ extern "C" int odo_depth_report(const odo_depth* d, int* iters, float* cost, int
 }
 
 #include "tracker.hip.h"
+#include "camera.hip.h"

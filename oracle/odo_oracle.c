@@ -868,3 +868,85 @@ int orc_track_frame(const float* kf_img, const float* kf_dep, const float* cur_l
   if (orc_depth_pyramid(dep, rows, cols, lp->n_levels, cur_dep_pyr)) return -1;               /* :252 */
   return s;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Camera model: CameraPyramid::ConfigureCamera / UndistortRectify
+ * (ref: src/camera.cpp:40-69,71-82). The arithmetic lives in OpenCV (cv::initUndistortRectifyMap, cv::remap), which is
+ * not vendored: restated from the documented definitions, PARITY UNPINNED like the rest of this file.
+ * ---------------------------------------------------------------------------------------------- */
+/* Intrinsic pyramid (ref: src/camera.cpp:44-66): out[l] = {fx, fy, f_theta, cx, cy}; P is the 3x4 row-major
+ * rectified projection. */
+void orc_camera_intrinsics(const double P[12], int levels, double out[][5]) {
+  double fx = P[0], fy = P[5], cx = P[2], cy = P[6], ft = P[1];
+  for (int l = 0; l < levels; l++) {
+    out[l][0] = fx; out[l][1] = fy; out[l][2] = ft; out[l][3] = cx; out[l][4] = cy;
+    fx = fx / 2.0; fy = fy / 2.0; ft = ft / 2.0;
+    cx = (cx + 0.5) / 2.0 + 0.5;
+    cy = (cy + 0.5) / 2.0 + 0.5;
+  }
+}
+
+static int inv3(const double m[9], double out[9]) {
+  const double c00 = m[4] * m[8] - m[5] * m[7];
+  const double c01 = m[5] * m[6] - m[3] * m[8];
+  const double c02 = m[3] * m[7] - m[4] * m[6];
+  const double det = (m[0] * c00 + m[1] * c01) + m[2] * c02;
+  if (!(fabs(det) > 0.0)) return -1;
+  const double id = 1.0 / det;
+  out[0] = c00 * id; out[1] = (m[2] * m[7] - m[1] * m[8]) * id; out[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+  out[3] = c01 * id; out[4] = (m[0] * m[8] - m[2] * m[6]) * id; out[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+  out[6] = c02 * id; out[7] = (m[1] * m[6] - m[0] * m[7]) * id; out[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+  return 0;
+}
+
+/* cv::initUndistortRectifyMap(K_raw, dist = (k1, k2, p1, p2), R, P, size, CV_32FC1) (ref: src/camera.cpp:68).
+ * raw = {fx, fy, f_theta (ignored by OpenCV), cx, cy}. Maps are rows x cols fp32. Returns -1 when P[:, :3]*R is
+ * singular. */
+int orc_camera_init_maps(const double raw[5], const double dist[4], const double R[9], const double P[12], int rows,
+                         int cols, float* mapx, float* mapy) {
+  double PR[9], iR[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      PR[i * 3 + j] = (P[i * 4 + 0] * R[0 * 3 + j] + P[i * 4 + 1] * R[1 * 3 + j]) + P[i * 4 + 2] * R[2 * 3 + j];
+  if (inv3(PR, iR)) return -1;
+  const double fx = raw[0], fy = raw[1], cx = raw[3], cy = raw[4];
+  const double k1 = dist[0], k2 = dist[1], p1 = dist[2], p2 = dist[3];
+  for (int v = 0; v < rows; v++)
+    for (int u = 0; u < cols; u++) {
+      const double du = (double)u, dv = (double)v;
+      const double _x = (iR[0] * du + iR[1] * dv) + iR[2];
+      const double _y = (iR[3] * du + iR[4] * dv) + iR[5];
+      const double _w = (iR[6] * du + iR[7] * dv) + iR[8];
+      const double w = 1.0 / _w;
+      const double x = _x * w, y = _y * w;
+      const double x2 = x * x, y2 = y * y;
+      const double r2 = x2 + y2, _2xy = (2.0 * x) * y;
+      const double kr = 1.0 + (k2 * r2 + k1) * r2;
+      const double xd = (x * kr + p1 * _2xy) + p2 * (r2 + 2.0 * x2);
+      const double yd = (y * kr + p1 * (r2 + 2.0 * y2)) + p2 * _2xy;
+      mapx[(size_t)v * cols + u] = (float)(fx * xd + cx);
+      mapy[(size_t)v * cols + u] = (float)(fy * yd + cy);
+    }
+  return 0;
+}
+
+/* cv::remap(src, dst, mapx, mapy, INTER_LINEAR, BORDER_CONSTANT, border_value) on CV_32F (ref: src/camera.cpp:80):
+ * 5-bit fixed-point source coordinates, fp32 bilinear weights, taps outside the source read border_value. */
+void orc_camera_remap(const float* src, int srows, int scols, const float* mapx, const float* mapy, int drows, int dcols,
+                      float border_value, float* dst) {
+  for (int v = 0; v < drows; v++)
+    for (int u = 0; u < dcols; u++) {
+      const size_t o = (size_t)v * dcols + u;
+      const int sx = (int)rintf(mapx[o] * 32.0f), sy = (int)rintf(mapy[o] * 32.0f);
+      const int ix = sx >> 5, iy = sy >> 5;
+      const float ax = (float)(sx & 31) * (1.0f / 32.0f), ay = (float)(sy & 31) * (1.0f / 32.0f);
+      const float w00 = (1.0f - ay) * (1.0f - ax), w01 = (1.0f - ay) * ax, w10 = ay * (1.0f - ax), w11 = ay * ax;
+      const int x0 = ix >= 0 && ix < scols, x1 = ix + 1 >= 0 && ix + 1 < scols;
+      const int y0 = iy >= 0 && iy < srows, y1 = iy + 1 >= 0 && iy + 1 < srows;
+      const float s00 = (x0 && y0) ? src[(size_t)iy * scols + ix] : border_value;
+      const float s01 = (x1 && y0) ? src[(size_t)iy * scols + ix + 1] : border_value;
+      const float s10 = (x0 && y1) ? src[(size_t)(iy + 1) * scols + ix] : border_value;
+      const float s11 = (x1 && y1) ? src[(size_t)(iy + 1) * scols + ix + 1] : border_value;
+      dst[o] = ((s00 * w00 + s01 * w01) + s10 * w10) + s11 * w11;
+    }
+}

@@ -251,3 +251,35 @@ def track_frame(kf_img_flat, kf_dep_flat, cur_left, cur_right, lm_p, depth_p, in
                                    C.byref(st))
     return dict(status=status, pose=out.reshape(4, 4).T.copy(), img_pyr=ipyr, dep_pyr=dpyr, val=val, disp=disp,
                 dep=dep, n_valid=st.n_valid, iters=st.iters)
+
+
+# ---- camera model (ref: src/camera.cpp:40-82) ------------------------------------------------------
+def camera_intrinsics(P, levels):
+    P = np.ascontiguousarray(P, np.float64).reshape(12)
+    out = np.zeros((levels, 5), np.float64)
+    lib().orc_camera_intrinsics(P.ctypes.data_as(C.POINTER(C.c_double)), levels, out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out
+
+
+def camera_init_maps(raw5, dist4, R, P, rows, cols):
+    dp = C.POINTER(C.c_double)
+    raw5 = np.ascontiguousarray(raw5, np.float64)
+    dist4 = np.ascontiguousarray(dist4, np.float64)
+    R = np.ascontiguousarray(R, np.float64).reshape(9)
+    P = np.ascontiguousarray(P, np.float64).reshape(12)
+    mx, my = np.zeros((rows, cols), np.float32), np.zeros((rows, cols), np.float32)
+    st = lib().orc_camera_init_maps(raw5.ctypes.data_as(dp), dist4.ctypes.data_as(dp), R.ctypes.data_as(dp),
+                                    P.ctypes.data_as(dp), rows, cols, mx.ctypes.data_as(_fp), my.ctypes.data_as(_fp))
+    if st:
+        raise ValueError("P[:, :3] * R is singular")
+    return mx, my
+
+
+def camera_remap(src, mapx, mapy, border_value=0.0):
+    src, ps = _f(src)
+    mapx, px = _f(mapx)
+    mapy, py = _f(mapy)
+    dst = np.zeros(mapx.shape, np.float32)
+    lib().orc_camera_remap(ps, src.shape[0], src.shape[1], px, py, mapx.shape[0], mapx.shape[1], C.c_float(border_value),
+                           dst.ctypes.data_as(_fp))
+    return dst

@@ -88,5 +88,33 @@ def main():
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 
+def rot_xyz(rx, ry, rz):
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def camera():
+    """(vii) camera model: a 96x128 sensor with radial + tangential distortion, a small rectifying rotation and a new
+    projection matrix; lookup maps, the intrinsic pyramid and one remapped image."""
+    rng = np.random.default_rng(20240917)
+    raw = np.array([91.7, 91.4, 0.0, 66.3, 47.9])
+    dist = np.array([-0.283, 0.074, 1.9e-4, -1.8e-5])
+    R = rot_xyz(0.004, -0.011, 0.007)
+    P = np.array([[88.0, 0.0, 64.5, -9.7], [0.0, 88.0, 48.25, 0.0], [0.0, 0.0, 1.0, 0.0]])
+    mx, my = O.camera_init_maps(raw, dist, R, P, 96, 128)
+    src = rng.integers(0, 256, (96, 128)).astype(np.uint8)
+    dst = O.camera_remap(src.astype(np.float32), mx, my, 0.0)
+    np.savez_compressed(os.path.join(HERE, "camera_96x128.npz"), raw=raw, dist=dist, R=R, P=P, mapx=mx, mapy=my, src=src,
+                        dst=dst, intr=O.camera_intrinsics(P, 4))
+    print("camera_96x128.npz", os.path.getsize(os.path.join(HERE, "camera_96x128.npz")), "bytes")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "camera":
+        camera()
+    else:
+        main()
+        camera()

@@ -26,3 +26,17 @@ void io_image_path(const char* root, const char* seq, int cam, int frame, char* 
   std::snprintf(out, cap, "%s", kitti_image_path(root, seq, cam, frame).c_str());
 }
 }
+
+extern "C" int io_read_calibration(const char* path, double* out /* 8 + 8 + 4 + 9 + 3 + 2 = 34 */) {
+  StereoCalibration c;
+  if (!read_stereo_calibration_file(path, c)) return -1;
+  int k = 0;
+  for (int cam = 0; cam < 2; cam++) for (int i = 0; i < 4; i++) out[k++] = c.intrinsics[cam][i];
+  for (int cam = 0; cam < 2; cam++) for (int i = 0; i < 4; i++) out[k++] = c.distortion[cam][i];
+  for (int cam = 0; cam < 2; cam++) for (int i = 0; i < 2; i++) out[k++] = c.sensor_size[cam][i];
+  for (int i = 0; i < 9; i++) out[k++] = c.rotate_left_right[i];
+  for (int i = 0; i < 3; i++) out[k++] = c.translate_left_right[i];
+  out[k++] = c.resolution[0];
+  out[k++] = c.resolution[1];
+  return 0;
+}

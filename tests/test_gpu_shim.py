@@ -71,3 +71,51 @@ def test_cpp_kitti_runner_with_png_ingest(tmp_path, kitti_seq):
         c = ref.track(L[k], R[k])
         np.testing.assert_allclose(pred[k], c["abs_pose"][:3], atol=2e-6)     # 6 decimals in the file
     assert "avg error over" in out.stdout and "save completed." in out.stdout
+
+
+def test_cpp_camera_pyramid_over_shim(tmp_path):
+    """examples/camera_rectify.cpp: calibration file -> CameraPyramid x 2 -> ConfigureCamera -> UndistortRectify, against the
+    oracle's restatement (bit-exact) on the calibration the reference ships with its camera test."""
+    from oracle import oracle as O
+    exe = str(tmp_path / "camera_rectify")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "camera_rectify.cpp"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "odometry_amd", "lib"), "-lodometry_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "odometry_amd", "lib")])
+    yaml = os.path.join(ROOT, "tests", "golden", "camchain.yaml")
+    raw = [np.array([427.32814323885566, 429.48081105226316, 0.0, 367.1148716890002, 242.03387791215218]),
+           np.array([425.28226969376584, 427.5013362691404, 0.0, 342.6156277602674, 233.38645927695092])]
+    dist = [np.array([-0.35292630520315216, 0.09970701156068408, -0.0003265055193558261, -0.003400767380536901]),
+            np.array([-0.34242635946786465, 0.09353275937137827, 0.000332922660566574, -0.001440982693394223])]
+
+    def rot(rx, ry, rz):
+        cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+        return (np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+                @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]))
+    Rs = [rot(0.0016, -0.0011, 0.0026), rot(-0.0016, 0.0011, -0.0026)]
+    Ps = [np.array([[380.0, 0, 352.0, 0], [0, 380.0, 238.5, 0], [0, 0, 1, 0]]),
+          np.array([[380.0, 0, 352.0, -22.95], [0, 380.0, 238.5, 0], [0, 0, 1, 0]])]
+    with open(tmp_path / "RP.txt", "w") as f:
+        for R, P in zip(Rs, Ps):
+            f.write(" ".join(repr(float(v)) for v in R.reshape(-1)) + "\n")
+            f.write(" ".join(repr(float(v)) for v in P.reshape(-1)) + "\n")
+    rng = np.random.default_rng(11)
+    frames = [rng.integers(0, 256, (480, 640)).astype(np.float32) for _ in range(2)]
+    with open(tmp_path / "frames.bin", "wb") as f:
+        for fr in frames:
+            fr.tofile(f)
+    out = subprocess.run([exe, yaml, str(tmp_path / "RP.txt"), str(tmp_path / "frames.bin"), str(tmp_path / "out.bin")],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    got = np.fromfile(tmp_path / "out.bin", np.float32).reshape(2, 480, 640)
+    for cam in range(2):
+        mx, my = O.camera_init_maps(raw[cam], dist[cam], Rs[cam], Ps[cam], 480, 640)
+        assert np.array_equal(got[cam], O.camera_remap(frames[cam], mx, my, 0.0))
+        intr = O.camera_intrinsics(Ps[cam], 4)
+        for l in range(4):
+            m = re.search(rf"cam{cam} level {l} fx ([\d.]+) fy ([\d.]+) cx ([\d.]+) cy ([\d.]+) f_m ([\d.]+)", out.stdout)
+            vals = [float(v) for v in m.groups()]
+            np.testing.assert_allclose(vals[:4], [intr[l, 0], intr[l, 1], intr[l, 3], intr[l, 4]], rtol=0, atol=1e-8)
+            np.testing.assert_allclose(vals[4], intr[l, 0] / (640 / 5.76), rtol=1e-8)   # f_meters, ref: include/camera.h:85
+    assert "camera raw image is not 480x640!" in out.stdout
+    assert "stereo configuration done!" in out.stdout

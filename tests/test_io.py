@@ -113,3 +113,67 @@ def test_pose_files_and_eval(io, tmp_path):
     buf = C.create_string_buffer(256)
     io.io_image_path(b"/data/kitti/dataset", b"00", 1, 42, buf, 256)
     assert buf.value == b"/data/kitti/dataset/sequences/00/image_1/000042.png"
+
+
+CAMCHAIN = """cam0:
+  cam_overlaps: [1]
+  camera_model: pinhole
+  distortion_coeffs: [-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05]
+  distortion_model: radtan
+  intrinsics: [458.654, 457.296, 367.215, 248.375]
+  sensor_size: [4.512, 2.88]
+  resolution: [640, 480]
+  rostopic: /cam0/image_raw
+cam1:
+  T_cn_cnm1:
+  - [0.9999972564, 0.0023171357, 0.0003760821, -0.1100738067]
+  - [-0.0023224758, 0.9998909660, 0.0145826986, 0.0003991215]
+  - [-0.0003422520, -0.0145835312, 0.9998935960, -0.0008537619]
+  - [0.0, 0.0, 0.0, 1.0]
+  cam_overlaps: [0]
+  camera_model: pinhole
+  distortion_coeffs: [-0.28368365, 0.07451284, -0.00010473, -3.55590700e-05]
+  distortion_model: radtan
+  intrinsics: [457.587, 456.134, 379.999, 255.238]
+  sensor_size: [4.512, 2.88]
+  resolution: [640, 480]
+  rostopic: /cam1/image_raw
+"""
+
+
+def test_stereo_calibration_file(io, tmp_path):
+    """ref: src/camera.cpp:170-352 (ReadStereoCalibrationFile)."""
+    p = tmp_path / "camchain.yaml"
+    p.write_text(CAMCHAIN)
+    out = (C.c_double * 34)()
+    assert io.io_read_calibration(str(p).encode(), out) == 0
+    v = np.array(out[:])
+    assert np.array_equal(v[0:4], [458.654, 457.296, 367.215, 248.375])
+    assert np.array_equal(v[4:8], [457.587, 456.134, 379.999, 255.238])
+    assert np.array_equal(v[8:12], [-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05])
+    assert np.array_equal(v[12:16], [-0.28368365, 0.07451284, -0.00010473, -3.55590700e-05])
+    assert np.array_equal(v[16:20], [4.512, 2.88, 4.512, 2.88])
+    assert np.array_equal(v[20:29], [0.9999972564, 0.0023171357, 0.0003760821, -0.0023224758, 0.9998909660, 0.0145826986,
+                                     -0.0003422520, -0.0145835312, 0.9998935960])
+    assert np.array_equal(v[29:32], [-0.1100738067, 0.0003991215, -0.0008537619])
+    assert np.array_equal(v[32:34], [640, 480])
+    # incomplete or missing files are refused (the reference exits there)
+    (tmp_path / "broken.yaml").write_text(CAMCHAIN.split("cam1:")[0])
+    assert io.io_read_calibration(str(tmp_path / "broken.yaml").encode(), out) == -1
+    assert io.io_read_calibration(str(tmp_path / "missing.yaml").encode(), out) == -1
+
+
+def test_stereo_calibration_file_of_the_reference(io):
+    """tests/golden/camchain.yaml is the data file the reference's own test_camera_setup.cpp reads
+    (calibration_file/camchain.yaml, ref: test_camera_setup.cpp:12); a data fixture, committed unchanged."""
+    out = (C.c_double * 34)()
+    assert io.io_read_calibration(os.path.join(ROOT, "tests", "golden", "camchain.yaml").encode(), out) == 0
+    v = np.array(out[:])
+    assert np.array_equal(v[0:4], [427.32814323885566, 429.48081105226316, 367.1148716890002, 242.03387791215218])
+    assert np.array_equal(v[4:8], [425.28226969376584, 427.5013362691404, 342.6156277602674, 233.38645927695092])
+    assert np.array_equal(v[8:12], [-0.35292630520315216, 0.09970701156068408, -0.0003265055193558261, -0.003400767380536901])
+    assert np.array_equal(v[12:16], [-0.34242635946786465, 0.09353275937137827, 0.000332922660566574, -0.001440982693394223])
+    assert np.array_equal(v[16:20], [5.76, 4.29, 5.76, 4.29])
+    assert v[20] == 0.9999842188801975 and v[28] == 0.9999926905708509 and v[23] == -0.005183031408333682
+    assert np.array_equal(v[29:32], [-0.060400809282521006, 0.00020747637203608188, 3.97878900435667e-05])
+    assert np.array_equal(v[32:34], [640, 482])

@@ -603,7 +603,7 @@ __device__ __forceinline__ double readlane_d(double v, int src_lane) {  // src_l
   return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ void solve_damped_wave(const double* acc, float lambda, float* delta_out) {
+__device__ __forceinline__ void solve_damped_wave_regs(const double* acc, float lambda, float delta_out[6]) {
   const int lane = threadIdx.x & 63;
   const int i = lane >> 3, j = lane & 7;
   const bool in = (i < 6 && j < 7);
@@ -645,9 +645,16 @@ __device__ __forceinline__ void solve_damped_wave(const double* acc, float lambd
     for (int jj = c + 1; jj < 6; jj++) s = s - readlane_d(a, c * 8 + jj) * xs[jj];
     xs[c] = ((okmask >> c) & 1u) ? s * readlane_d(rdiag, c * 8 + c) : 0.0;
   }
-  if (lane == 0) {
 #pragma unroll
-    for (int c = 0; c < 6; c++) delta_out[c] = (float)xs[c];
+  for (int c = 0; c < 6; c++) delta_out[c] = (float)xs[c];  // wave-uniform: every lane holds the step
+}
+// The same, step written to memory (LDS) by lane 0.
+__device__ __forceinline__ void solve_damped_wave(const double* acc, float lambda, float* delta_out) {
+  float d[6];
+  solve_damped_wave_regs(acc, lambda, d);
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int c = 0; c < 6; c++) delta_out[c] = d[c];
   }
 }
 
@@ -799,66 +806,62 @@ struct StepArgs {
 constexpr int kFoldChunk = 20;  // the 160 rows of a point-list grid in one round of loads per segment
 
 // The LM state machine of one evaluation, run by wave 0 of a block (all threads of the block must call it; it ends
-// with a block barrier): lm_decide on lane 0, the 6x6 solve across the wavefront, exp / compose on lane 0, the trace
-// row, and — when `lv` is given — the walk down the pyramid (ref: src/lm_optimizer.cpp:92,110-115,156).
-// have_acc: acc_sh holds the 29 sums of an evaluation at s_sh.T that has not been consumed yet.
+// with a block barrier): accept / reject, the 6x6 solve across the wavefront, exp / compose, the trace row, and — when
+// `lv` is given — the walk down the pyramid (ref: src/lm_optimizer.cpp:92,110-115,123-156).
+// Every lane of wave 0 carries the whole 64-dword state in registers and runs the scalar code redundantly on
+// wave-uniform values: one LDS read of the state and one write-back, no LDS round trip inside decide / apply / walk and
+// nothing to broadcast (the solve returns the step in every lane).
+// pending: acc_sh holds the 29 sums of an evaluation at s_sh.T that has not been consumed yet.
 __device__ __forceinline__ void lm_state_machine(bool pending, const StepLevel* lv, int n_levels, float lambda0,
-                                                 float precision, LmState& s_sh, double* acc_sh, float* delta_sh,
-                                                 int* flags_sh /* [4] */, LmTraceRow* __restrict__ trace,
+                                                 float precision, LmState& s_sh, double* acc_sh, LmTraceRow* __restrict__ trace,
                                                  float* __restrict__ cost_stat, bool publisher) {
   const int t = threadIdx.x;
-  if (t < 64) {  // wave 0: the scalar state machine on lane 0, the 6x6 solve across the wave
-    if (t == 0) {
-      flags_sh[0] = 0;  // need_step
-      flags_sh[1] = s_sh.iter;
-      flags_sh[2] = s_sh.level;
-      ((float*)flags_sh)[3] = s_sh.err_last;
-      if (pending) flags_sh[0] = lm_decide(&s_sh, acc_sh, precision) ? 1 : 0;
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    const bool need_step = flags_sh[0] != 0;
+  if (t < 64) {
+    LmState s = s_sh;
+    const int iter0 = s.iter, lvl0 = s.level;
+    const float err_last0 = s.err_last;
+    bool need_step = false;
+    if (pending) need_step = lm_decide(&s, acc_sh, precision);
     if (need_step) {
-      solve_damped_wave(acc_sh, s_sh.lambda, delta_sh);
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __builtin_amdgcn_wave_barrier();
+      float d[6];
+      solve_damped_wave_regs(acc_sh, s.lambda, d);
+#pragma unroll
+      for (int i = 0; i < 6; i++) s.delta[i] = d[i];
+      lm_apply_step(&s, s.max_iters);
     }
-    if (t == 0) {
-      LmState& s = s_sh;
-      if (need_step) {
-        for (int i = 0; i < 6; i++) s.delta[i] = delta_sh[i];
-        lm_apply_step(&s, s.max_iters);
-      }
-        if (pending) {
-        const int lvl = flags_sh[2];
-        if (publisher) {
-          const int ev = s.n_evals - 1;
-          if (ev < kTraceCap) {
-            LmTraceRow& r = trace[ev];
-            r.level = lvl;
-            r.iter = flags_sh[1];
-            r.n_res = (int)acc_sh[28];
-            r.err = s.err_now;
-            r.accepted = (s.status == 0 && !(s.err_now > ((float*)flags_sh)[3])) ? 1 : 0;
-            r.stop = (s.stop_reason == 3 || s.active) ? 0 : s.stop_reason;
-            r.lambda_after = s.lambda;
-            for (int i = 0; i < 6; i++) r.delta[i] = (s.active || s.stop_reason == 3) ? s.delta[i] : 0.0f;
-          }
-          if (flags_sh[1] == 0 && s.iters_level[lvl & 7] == 1) cost_stat[lvl * 2 + 0] = s.err_now;
-          cost_stat[lvl * 2 + 1] = s.err_now;
+    if (pending) {
+      if (publisher && t == 0) {
+        const int ev = s.n_evals - 1;
+        if (ev < kTraceCap) {
+          LmTraceRow& r = trace[ev];
+          r.level = lvl0;
+          r.iter = iter0;
+          r.n_res = (int)acc_sh[28];
+          r.err = s.err_now;
+          r.accepted = (s.status == 0 && !(s.err_now > err_last0)) ? 1 : 0;
+          r.stop = (s.stop_reason == 3 || s.active) ? 0 : s.stop_reason;
+          r.lambda_after = s.lambda;
+#pragma unroll
+          for (int i = 0; i < 6; i++) r.delta[i] = (s.active || s.stop_reason == 3) ? s.delta[i] : 0.0f;
         }
-        s.pending = 0;
+        int evals_this_level = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) evals_this_level += (i == (lvl0 & 7)) ? s.iters_level[i] : 0;
+        if (iter0 == 0 && evals_this_level == 1) cost_stat[lvl0 * 2 + 0] = s.err_now;
+        cost_stat[lvl0 * 2 + 1] = s.err_now;
       }
-      if (lv) {
-        while (!s.active && s.status == 0 && !s.finished) {
-          const int next = (s.level < 0) ? n_levels - 1 : s.level - 1;
-          if (next < 0) { s.finished = 1; break; }
-          s.stop_reason = 0;
-          lm_begin_level(&s, next, lambda0, lv[next].max_iters);  // ref: src/lm_optimizer.cpp:110-115
-        }
-        if (s.status != 0) s.finished = 1;
+      s.pending = 0;
+    }
+    if (lv) {
+      while (!s.active && s.status == 0 && !s.finished) {
+        const int next = (s.level < 0) ? n_levels - 1 : s.level - 1;
+        if (next < 0) { s.finished = 1; break; }
+        s.stop_reason = 0;
+        lm_begin_level(&s, next, lambda0, lv[next].max_iters);  // ref: src/lm_optimizer.cpp:110-115
       }
-      }
+      if (s.status != 0) s.finished = 1;
+    }
+    if (t == 0) s_sh = s;
   }
   __syncthreads();
 }
@@ -869,9 +872,8 @@ __device__ __forceinline__ void lm_state_machine(bool pending, const StepLevel* 
 // 110-115,156), so the launch that learns "level l is done" is also the first evaluation of level l-1.
 __device__ __forceinline__ void lm_fused_prologue(const LmState* __restrict__ st_in, const double* __restrict__ part_in,
                                                   const StepLevel* lv, int n_levels, float lambda0, float precision,
-                                                  LmState& s_sh, double* fold_sh, double* acc_sh, float* delta_sh,
-                                                  int* flags_sh /* [4] */, LmTraceRow* __restrict__ trace,
-                                                  float* __restrict__ cost_stat, bool publisher,
+                                                  LmState& s_sh, double* fold_sh, double* acc_sh,
+                                                  LmTraceRow* __restrict__ trace, float* __restrict__ cost_stat, bool publisher,
                                                   const float* init /* non-null: first launch of a Solve */) {
   const int t = threadIdx.x;
   if (init) {
@@ -918,7 +920,7 @@ __device__ __forceinline__ void lm_fused_prologue(const LmState* __restrict__ st
     }
     __syncthreads();
   }
-  lm_state_machine(pending, lv, n_levels, lambda0, precision, s_sh, acc_sh, delta_sh, flags_sh, trace, cost_stat, publisher);
+  lm_state_machine(pending, lv, n_levels, lambda0, precision, s_sh, acc_sh, trace, cost_stat, publisher);
 }
 
 __device__ __forceinline__ void lm_fused_publish(LmState& s_sh, LmState* __restrict__ st_out, int* __restrict__ host_prog,
@@ -943,13 +945,11 @@ __global__ void __launch_bounds__(kLmBlock) lm_step_kernel(StepArgs a) {
   __shared__ LmState s_sh;
   __shared__ double fold_sh[8 * 32];
   __shared__ double acc_sh[32];
-  __shared__ float delta_sh[8];
-  __shared__ int flags_sh[4];
   // The last block of the grid evaluates no points: it publishes the state, the trace row and the host progress word
   // (a system-scope release, ~0.5 us) while the other blocks are still evaluating.
   const bool publisher = (blockIdx.x == gridDim.x - 1);
-  lm_fused_prologue(a.st_in, a.part_in, a.lv, a.n_levels, a.lambda0, a.precision, s_sh, fold_sh, acc_sh, delta_sh, flags_sh,
-                    a.trace, a.cost_stat, publisher, a.first_of_solve ? a.init : nullptr);
+  lm_fused_prologue(a.st_in, a.part_in, a.lv, a.n_levels, a.lambda0, a.precision, s_sh, fold_sh, acc_sh, a.trace, a.cost_stat,
+                    publisher, a.first_of_solve ? a.init : nullptr);
   const bool run = (s_sh.active != 0 && s_sh.status == 0);  // block-uniform
   const int lvl = run ? s_sh.level : 0;
   const StepLevel& L = a.lv[lvl];
@@ -1016,11 +1016,9 @@ __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int
   __shared__ LmState s_sh;
   extern __shared__ double red_sh[];  // kCoarseLdsBytes: reduction buffer; its head doubles as the fold scratch
   __shared__ double acc_sh[32];
-  __shared__ float delta_sh[8];
-  __shared__ int flags_sh[4];
   // state in (or initialised), a pending evaluation of an earlier launch consumed, pyramid walk started
-  lm_fused_prologue(a.st_in, a.part_in, a.lv, a.n_levels, a.lambda0, a.precision, s_sh, red_sh, acc_sh, delta_sh, flags_sh,
-                    a.trace, a.cost_stat, true, a.first_of_solve ? a.init : nullptr);
+  lm_fused_prologue(a.st_in, a.part_in, a.lv, a.n_levels, a.lambda0, a.precision, s_sh, red_sh, acc_sh, a.trace, a.cost_stat, true,
+                    a.first_of_solve ? a.init : nullptr);
   unsigned long long c_eval = 0, c_red = 0, c_sm = 0, c_it = 0, c_last = a.dbg ? __builtin_readcyclecounter() : 0;
   const unsigned long long c_begin = c_last;
   auto lap = [&](unsigned long long& sum) {
@@ -1052,8 +1050,7 @@ __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int
     lap(c_eval);
     block_reduce_acc_coarse(acc, red_sh, acc_sh);
     lap(c_red);
-    lm_state_machine(true, a.lv, a.n_levels, a.lambda0, a.precision, s_sh, acc_sh, delta_sh, flags_sh, a.trace, a.cost_stat,
-                     true);
+    lm_state_machine(true, a.lv, a.n_levels, a.lambda0, a.precision, s_sh, acc_sh, a.trace, a.cost_stat, true);
     lap(c_sm);
   }
   lm_fused_publish(s_sh, a.st_out, a.host_prog, a.seq);
@@ -1082,9 +1079,7 @@ __global__ void __launch_bounds__(kLmBlock) lm_fused_finalize_kernel(FinalizeArg
   __shared__ LmState s_sh;
   __shared__ double fold_sh[8 * 32];
   __shared__ double acc_sh[32];
-  __shared__ float delta_sh[8];
-  __shared__ int flags_sh[4];
-  lm_fused_prologue(a.st_in, a.part_in, nullptr, 0, 0.0f, a.precision, s_sh, fold_sh, acc_sh, delta_sh, flags_sh, a.trace,
+  lm_fused_prologue(a.st_in, a.part_in, nullptr, 0, 0.0f, a.precision, s_sh, fold_sh, acc_sh, a.trace,
                     a.cost_stat, true, a.first_of_solve ? a.init : nullptr);
   if (threadIdx.x < (int)(sizeof(LmState) / sizeof(int))) ((int*)a.st_out)[threadIdx.x] = ((const int*)&s_sh)[threadIdx.x];
   if (threadIdx.x == 0) {

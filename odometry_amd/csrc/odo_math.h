@@ -414,7 +414,11 @@ ODO_HD void lm_begin_level(LmState* s, int level, float lambda0, int max_iters) 
 // lm_decide: error, accept / reject, lambda rule, stop tests (:129-143). Returns true when a step must be solved.
 ODO_HD bool lm_decide(LmState* s, const double acc[ODO_NACC], float precision) {
   s->n_evals++;
-  s->iters_level[s->level & 7]++;
+  {  // iters_level[level]++ with compile-time indices, so a register-resident state never needs dynamic indexing
+    const int li = s->level & 7;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s->iters_level[i] += (i == li) ? 1 : 0;
+  }
   if (!(acc[28] > 0.0)) {      // :244-248 -> :123-126
     s->status = -1;
     s->active = 0;

@@ -15,19 +15,23 @@ def shard(n_items, rank, world):
 
 
 class PoseGatherer:
-    """Batches per-frame 3x4 poses and all-gathers them every `every` frames."""
+    """Batches per-frame 3x4 poses and all-gathers them every `every` frames, off the tracking path: the collective is
+    issued asynchronously and its result is collected at a later push (or at flush()), so a rank never waits for the
+    exchange — nor, through it, for a slower rank — while it tracks."""
 
     def __init__(self, world, every=8, device=None):
         self.world, self.every, self.device = world, every, device
         self.pending = []
+        self.inflight = []                           # (work handle or None, [tensor per rank]) in issue order
         self.gathered = [[] for _ in range(world)]   # per rank: list of (every, 12) arrays
 
     def push(self, pose4x4):
         self.pending.append(np.asarray(pose4x4, np.float32)[:3, :].reshape(-1))
         if len(self.pending) == self.every:
-            self.flush()
+            self._issue()
+            self._drain(block=False)
 
-    def flush(self):
+    def _issue(self):
         if not self.pending:
             return
         import torch
@@ -37,12 +41,27 @@ class PoseGatherer:
             mine = mine.to(self.device)
         if self.world > 1:
             out = [torch.empty_like(mine) for _ in range(self.world)]
-            dist.all_gather(out, mine)
+            work = dist.all_gather(out, mine, async_op=True)
         else:
-            out = [mine]
-        for r, t in enumerate(out):
-            self.gathered[r].append(t.cpu().numpy())
+            out, work = [mine], None
+        self.inflight.append((work, out))
         self.pending = []
+
+    def _drain(self, block):
+        while self.inflight:
+            work, out = self.inflight[0]
+            if work is not None:
+                if not block and not work.is_completed():
+                    return
+                work.wait()
+            for r, t in enumerate(out):
+                self.gathered[r].append(t.cpu().numpy())
+            self.inflight.pop(0)
+
+    def flush(self):
+        """Issue what is pending and wait for every outstanding exchange (end of a run)."""
+        self._issue()
+        self._drain(block=True)
 
     def poses(self, rank):
         g = self.gathered[rank]

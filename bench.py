@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--no-prefetch", action="store_true", help="build each frame's image pyramid inside its own step")
     ap.add_argument("--no-extras", action="store_true", help="skip the dense-1080p and disparity side measurements")
     ap.add_argument("--overlap", type=int, default=2, help="1: one host thread feeds both streams, 2: helper thread")
+    ap.add_argument("--distinct-sequences", action="store_true",
+                    help="rank r tracks synthetic sequence r instead of every rank tracking sequence 0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -199,7 +201,9 @@ def main():
             dist.init_process_group(backend)
 
     from odometry_amd import api, synth
-    seq = synth.make_sequence(args.unique_frames, seed=rank)
+    # Weak scaling wants the same work on every GPU: per-frame cost depends on image content (20-30 LM evaluations), so by
+    # default every rank tracks its own copy of synthetic sequence 0; --distinct-sequences gives rank r sequence r.
+    seq = synth.make_sequence(args.unique_frames, seed=rank if args.distinct_sequences else 0)
     trk = api.Tracker(local_rank, overlap_depth=0 if args.no_overlap else args.overlap)
     dev = [(trk.upload_frame(l), trk.upload_frame(r)) for l, r in zip(seq["left"], seq["right"])]  # inputs resident in HBM
     trk.init(*dev[0])
@@ -296,7 +300,9 @@ def main():
                                         "semi-dense, runner params, one sequence per GPU",
                                unique_frames=args.unique_frames, sequences_per_gpu=1,
                                overlap_depth=0 if args.no_overlap else args.overlap, gather_every=args.gather_every,
-                               next_frame_pyramid_prefetch=not args.no_prefetch),
+                               next_frame_pyramid_prefetch=not args.no_prefetch,
+                               sequence_per_rank="distinct synthetic sequences" if args.distinct_sequences
+                               else "every rank tracks its own copy of synthetic sequence 0 (equal work per GPU)"),
                    roofline=roof,
                    lm_evals_per_frame=round(float(np.mean(evals)), 2),
                    host_us_per_frame={k: round(v, 1) for k, v in host_timing.items()},

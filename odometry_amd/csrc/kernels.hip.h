@@ -330,8 +330,14 @@ __global__ void __launch_bounds__(kLmBlock) lm_residual_dense_kernel(LevelView v
   for (int q = 0; q < ODO_NACC; q++) acc[q] = 0.0;
   const int iw = v.cols - 8, ih = v.rows - 8;
   const int n = (iw > 0 && ih > 0) ? iw * ih : 0;
-  for (int idx = blockIdx.x * kLmBlock + threadIdx.x; idx < n; idx += gridDim.x * kLmBlock) {
-    const int y = 4 + idx / iw, x = 4 + idx % iw;
+  // (x, y) of the interior raster index advance incrementally: one integer division per thread instead of one per pixel
+  const int stride = gridDim.x * kLmBlock;
+  const int sy = (iw > 0) ? stride / iw : 0, sx = (iw > 0) ? stride % iw : 0;  // wave-uniform
+  int idx = blockIdx.x * kLmBlock + threadIdx.x;
+  int yi = (iw > 0) ? idx / iw : 0, xi = (iw > 0) ? idx % iw : 0;
+  for (; idx < n; idx += stride, yi += sy, xi += sx) {
+    if (xi >= iw) { xi -= iw; yi++; }
+    const int y = 4 + yi, x = 4 + xi;
     const size_t o = (size_t)y * v.cols + x;
     const float d = v.D1[o];
     if (!depth_valid(d)) continue;

@@ -85,7 +85,7 @@ ODO_HD PointK make_point(int x, int y, float inv_depth, float i1, const LevelK& 
   p.jw05 = -fx_z * p.Y;
   p.jw12 = (-fx_z * p.Y) / p.Z;                                       // :233
   p.jw13 = (float)(-k.fl * (1.0 + (double)(yy / zz)));
-  p.jw14 = (fx_z * xy) / p.Z;
+  p.jw14 = -p.jw03;  // = (fx_z * xy) / Z (ref :233): IEEE negation commutes with multiply and divide, bit for bit
   p.jw15 = fx_z * p.X;
   return p;
 }

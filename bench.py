@@ -201,6 +201,10 @@ def main():
             dist.init_process_group(backend)
 
     from odometry_amd import api, synth
+    # Each rank keeps two host threads busy (the caller polls the LM stream, the helper feeds the depth stream). On a host
+    # with fewer cores than that, fall back to one feeding thread per rank rather than oversubscribe spinning threads.
+    if not args.no_overlap and args.overlap == 2 and (os.cpu_count() or 1) < 2 * world + 2:
+        args.overlap = 1
     # Weak scaling wants the same work on every GPU: per-frame cost depends on image content (20-30 LM evaluations), so by
     # default every rank tracks its own copy of synthetic sequence 0; --distinct-sequences gives rank r sequence r.
     seq = synth.make_sequence(args.unique_frames, seed=rank if args.distinct_sequences else 0)

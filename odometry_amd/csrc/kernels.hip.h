@@ -954,6 +954,7 @@ __global__ void __launch_bounds__(kLmBlock) lm_step_kernel(StepArgs a) {
   // The last block of the grid evaluates no points: it publishes the state, the trace row and the host progress word
   // (a system-scope release, ~0.5 us) while the other blocks are still evaluating.
   const bool publisher = (blockIdx.x == gridDim.x - 1);
+  if (a.dbg && publisher && threadIdx.x == 0 && a.seq < 56) a.dbg[16 + 2 * a.seq] = wall_clock64();  // diagnostic timeline
   lm_fused_prologue(a.st_in, a.part_in, a.lv, a.n_levels, a.lambda0, a.precision, s_sh, fold_sh, acc_sh, a.trace, a.cost_stat,
                     publisher, a.first_of_solve ? a.init : nullptr);
   const bool run = (s_sh.active != 0 && s_sh.status == 0);  // block-uniform
@@ -980,6 +981,7 @@ __global__ void __launch_bounds__(kLmBlock) lm_step_kernel(StepArgs a) {
     if (threadIdx.x == 0 && run) { s_sh.pending = 1; s_sh.pending_nblk = L.nblk; }
     __syncthreads();
     lm_fused_publish(s_sh, a.st_out, a.host_prog, a.seq);
+    if (a.dbg && threadIdx.x == 0 && a.seq < 56) a.dbg[16 + 2 * a.seq + 1] = wall_clock64();
   }
 }
 
@@ -1025,6 +1027,7 @@ __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int
   // state in (or initialised), a pending evaluation of an earlier launch consumed, pyramid walk started
   lm_fused_prologue(a.st_in, a.part_in, a.lv, a.n_levels, a.lambda0, a.precision, s_sh, red_sh, acc_sh, a.trace, a.cost_stat, true,
                     a.first_of_solve ? a.init : nullptr);
+  if (a.dbg && threadIdx.x == 0 && a.seq < 56) a.dbg[16 + 2 * a.seq] = wall_clock64();
   unsigned long long c_eval = 0, c_red = 0, c_sm = 0, c_it = 0, c_last = a.dbg ? __builtin_readcyclecounter() : 0;
   const unsigned long long c_begin = c_last;
   auto lap = [&](unsigned long long& sum) {
@@ -1061,6 +1064,7 @@ __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int
   }
   lm_fused_publish(s_sh, a.st_out, a.host_prog, a.seq);
   if (a.dbg && threadIdx.x == 0) {
+    if (a.seq < 56) a.dbg[16 + 2 * a.seq + 1] = wall_clock64();
     a.dbg[0] += c_eval; a.dbg[1] += c_red; a.dbg[2] += c_sm; a.dbg[3] += c_it;
     a.dbg[4] += __builtin_readcyclecounter() - c_begin; a.dbg[5] += 1;
   }

@@ -592,10 +592,25 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
     memcpy(a.init, m->init, sizeof(a.init));
     static unsigned long long* dbg_buf = [] {
       unsigned long long* p = nullptr;
-      if (getenv("ODO_COARSE_STAMPS") && hipHostMalloc((void**)&p, 128, hipHostMallocMapped) == hipSuccess) memset(p, 0, 128);
+      if (getenv("ODO_COARSE_STAMPS") && hipHostMalloc((void**)&p, 1024, hipHostMallocMapped) == hipSuccess) memset(p, 0, 1024);
       return p;
     }();
     a.dbg = dbg_buf;
+    if (dbg_buf) {  // timeline of the previous Solve: device wall clock (100 MHz) at the start / end of every launch
+      static double gap_us = 0.0, dur_us = 0.0, span_us = 0.0; static long n_gap = 0, n_solve = 0;
+      int n = 0;
+      while (n < 56 && dbg_buf[16 + 2 * n] && dbg_buf[16 + 2 * n + 1]) n++;
+      if (n > 1) {
+        for (int i = 0; i + 1 < n; i++) { gap_us += (double)(long long)(dbg_buf[16 + 2 * (i + 1)] - dbg_buf[16 + 2 * i + 1]) * 0.01; n_gap++; }
+        for (int i = 1; i < n; i++) dur_us += (double)(long long)(dbg_buf[16 + 2 * i + 1] - dbg_buf[16 + 2 * i]) * 0.01;
+        span_us += (double)(long long)(dbg_buf[16 + 2 * (n - 1) + 1] - dbg_buf[16]) * 0.01;
+        if (++n_solve % 100 == 0)
+          fprintf(stderr, "[lm timeline] launches/Solve %.1f, publisher-block start->end %.2f us per step launch, end->next start "
+                  "%.2f us, first start -> last end %.1f us per Solve\n", (double)(n_gap + n_solve) / n_solve,
+                  dur_us / (n_gap ? n_gap : 1), gap_us / (n_gap ? n_gap : 1), span_us / n_solve);
+      }
+      memset(dbg_buf + 16, 0, sizeof(unsigned long long) * 112);
+    }
     if (dbg_buf && dbg_buf[5] > 0 && dbg_buf[5] % 100 == 0)
       fprintf(stderr, "[coarse stamps] per iteration: eval %.0f reduce %.0f state-machine %.0f cycles; iterations/launch %.2f, "
               "cycles/launch %.0f\n", (double)dbg_buf[0] / dbg_buf[3], (double)dbg_buf[1] / dbg_buf[3],

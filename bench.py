@@ -71,6 +71,10 @@ def dense_1080p_leg(api, synth):
     T = np.linalg.inv(poses[1]) @ poses[0]
     t = lm.time_eval(p0, d0, p1, 0, T, reps=50)
     ach = t["bytes"] / (t["mean_us"] * 1e-6) / 1e9
+    lm.close()
+    for o in (p0, d0, p1):
+        o.close()
+    ctx.close()
     return dict(kernel="lm_residual_dense_kernel(L0, 1920x1080, all pixels)", residuals=t["n_points"],
                 algorithmic_bytes=int(t["bytes"]), launch_us=round(t["mean_us"], 2), launch_min_us=round(t["min_us"], 2),
                 achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4))
@@ -91,6 +95,7 @@ def disparity_leg(api, seq, trk):
         de.close()
     ctx.free(l_dev)
     ctx.free(r_dev)
+    ctx.close()
     return out
 
 
@@ -125,6 +130,9 @@ def single_pair_leg(api, seq):
         cpu_s = time.perf_counter() - t0
         out[name] = dict(gpu_solve_ms=round(float(np.median(ts[2:])) * 1e3, 4), cpu_solve_ms=round(cpu_s * 1e3, 1),
                          evaluations=r["n_evals"], pose_max_abs_delta=float(np.abs(T.astype(np.float64) - r["pose"]).max()))
+    for o in (p0, d0, p1):
+        o.close()
+    ctx.close()
     return out
 
 
@@ -174,7 +182,9 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-overlap", action="store_true", help="run ComputeDepth after Solve on one stream")
     ap.add_argument("--no-prefetch", action="store_true", help="build each frame's image pyramid inside its own step")
-    ap.add_argument("--no-extras", action="store_true", help="skip the dense-1080p and disparity side measurements")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements")
+    ap.add_argument("--extras", default="dense,disparity,single,multi",
+                    help="side measurements to run: dense (configs[2]), disparity (configs[4]), single (configs[0]), multi")
     ap.add_argument("--overlap", type=int, default=2, help="1: one host thread feeds both streams, 2: helper thread")
     ap.add_argument("--distinct-sequences", action="store_true",
                     help="rank r tracks synthetic sequence r instead of every rank tracking sequence 0")
@@ -344,10 +354,16 @@ def main():
         if world == 1 and not args.no_extras:
             import contextlib
             with contextlib.redirect_stdout(sys.stderr):  # the mirrored classes print the reference's own messages
-                out["roofline_dense_1080p"] = dense_1080p_leg(api, synth)
-                out["disparity_1241x376"] = disparity_leg(api, seq, trk)
-                out["single_pair_1241x376"] = single_pair_leg(api, seq)
-                out["multi_sequence_1gpu"] = [multi_sequence_leg(api, seq, order, n, 100) for n in (2, 4, 8)]
+                legs = set(args.extras.split(","))
+                if "dense" in legs:
+                    out["roofline_dense_1080p"] = dense_1080p_leg(api, synth)
+                if "disparity" in legs:
+                    out["disparity_1241x376"] = disparity_leg(api, seq, trk)
+                if "single" in legs:
+                    out["single_pair_1241x376"] = single_pair_leg(api, seq)
+                if "multi" in legs:   # last, with every other stream of this process gone (streams share hardware queues)
+                    trk.close()
+                    out["multi_sequence_1gpu"] = [multi_sequence_leg(api, seq, order, n, 200) for n in (2, 4, 8)]
         print(json.dumps(out))
     trk.close()
     if world > 1:

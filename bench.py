@@ -141,7 +141,11 @@ def multi_sequence_leg(api, seq, order, n_seq, steps):
     host threads). Not `value`: configs[1] is a single sequence, whose frames are inherently serial; this shows how
     much of the GPU a single latency-bound sequence leaves idle. The S trackers replay the same synthetic frames."""
     import threading
+    # The trackers of one process share its hardware queues; with more than two of them the LM streams are better spread
+    # over the normal-priority queues than packed into the small high-priority pool a single tracker uses.
+    os.environ["ODO_LM_PRIORITY"] = "1" if n_seq <= 2 else "0"
     trks = [api.Tracker(0) for _ in range(n_seq)]
+    os.environ.pop("ODO_LM_PRIORITY", None)
     devs = []
     for t in trks:
         d = [(t.upload_frame(l), t.upload_frame(r)) for l, r in zip(seq["left"], seq["right"])]

@@ -46,6 +46,9 @@ int odo_version(void);
 
 /* ---- context ------------------------------------------------------------------------------ */
 int odo_ctx_create(int device, odo_ctx** out);
+/* Same, on a high-priority HIP stream (its hardware queue comes from a pool of its own): for a latency-critical chain of
+ * dependent launches that must not queue behind other streams' work. Used by odo_tracker for the LM stream. */
+int odo_ctx_create_high_priority(int device, odo_ctx** out);
 int odo_ctx_destroy(odo_ctx* ctx);
 int odo_ctx_synchronize(odo_ctx* ctx);
 /* HIP-event timing on the context's own stream (bench.py): record start / stop around a region,

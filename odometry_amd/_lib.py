@@ -47,6 +47,7 @@ SIGNATURES = {
     "odo_last_error": (C.c_char_p, []),
     "odo_version": (C.c_int, []),
     "odo_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "odo_ctx_create_high_priority": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "odo_ctx_destroy": (C.c_int, [_vp]),
     "odo_ctx_synchronize": (C.c_int, [_vp]),
     "odo_ctx_timer_start": (C.c_int, [_vp]),

@@ -45,7 +45,10 @@ struct odo_ctx {
   hipEvent_t ev0, ev1;
 };
 
-extern "C" int odo_ctx_create(int device, odo_ctx** out) {
+static int ctx_create(int device, int high_priority, odo_ctx** out);
+extern "C" int odo_ctx_create(int device, odo_ctx** out) { return ctx_create(device, 0, out); }
+extern "C" int odo_ctx_create_high_priority(int device, odo_ctx** out) { return ctx_create(device, 1, out); }
+static int ctx_create(int device, int high_priority, odo_ctx** out) {
   if (!out) return fail("odo_ctx_create: out is NULL");
   *out = nullptr;
   int n = 0;
@@ -55,7 +58,13 @@ extern "C" int odo_ctx_create(int device, odo_ctx** out) {
   odo_ctx* c = new (std::nothrow) odo_ctx();
   if (!c) return fail("odo_ctx_create: out of memory");
   c->device = device;
-  HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  if (high_priority) {
+    int lo = 0, hi = 0;  // numerically lower = higher priority
+    HIP_OK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIP_OK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
+  } else {
+    HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  }
   HIP_OK(hipEventCreate(&c->ev0));
   HIP_OK(hipEventCreate(&c->ev1));
   *out = c;

@@ -98,7 +98,13 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
   memcpy(t->pose_to_kf, eye, sizeof(eye));
   memcpy(t->kf_abs, eye, sizeof(eye));
   const size_t n = (size_t)p->rows * p->cols;
-  bool ok = odo_ctx_create(device, &t->ctx_a) == 0 && odo_ctx_create(device, &t->ctx_b) == 0;
+  // Stream A carries the latency-critical LM chain: a high-priority stream gets its hardware queue from a pool of its
+  // own, so no other stream of the process (the depth stream, a collective's stream, another tracker) can sit ahead of a
+  // dependent LM launch in the same queue. ODO_LM_PRIORITY=0 falls back to a normal stream.
+  // (read per tracker: several trackers in ONE process should not all draw from the small high-priority pool)
+  const bool lm_prio = !(getenv("ODO_LM_PRIORITY") && atoi(getenv("ODO_LM_PRIORITY")) == 0);
+  bool ok = (lm_prio ? odo_ctx_create_high_priority(device, &t->ctx_a) : odo_ctx_create(device, &t->ctx_a)) == 0 &&
+            odo_ctx_create(device, &t->ctx_b) == 0;
   ok = ok && odo_lm_create(t->ctx_a, p->lm_lambda, p->lm_precision, p->lm_max_iters, p->levels, eye, p->lm_robust,
                            p->lm_huber_delta, &p->K, &t->lm) == 0;
   ok = ok && odo_depth_create(t->ctx_b, p->grad_th, p->ssd_th, p->photo_th, p->min_depth, p->max_depth, p->depth_lambda,

@@ -118,6 +118,7 @@ def test_keyframe_point_list_counts(api, O, kitti_seq):
     """The compacted list holds exactly the pixels the reference's scan would visit (|d| >= 0.01 inside the border)."""
     L0, L1, inv, p0, d0, p1, r0, rd, r1 = _kitti_pyrs(api, O, kitti_seq)
     lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 1, 28.0)
+    lm.set_mode(0)   # auto (the default unless the ODO_LM_MODE diagnostic knob says otherwise)
     lm.accumulate(p0, d0, p1, 0, np.eye(4, dtype=np.float32))
     npts, use = lm.points()
     for l in range(4):

@@ -187,8 +187,10 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="run ComputeDepth after Solve on one stream")
     ap.add_argument("--no-prefetch", action="store_true", help="build each frame's image pyramid inside its own step")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements")
-    ap.add_argument("--extras", default="dense,disparity,single,multi",
-                    help="side measurements to run: dense (configs[2]), disparity (configs[4]), single (configs[0]), multi")
+    ap.add_argument("--extras", default="dense,disparity,single",
+                    help="side measurements to run: dense (configs[2]), disparity (configs[4]), single (configs[0]); "
+                         "multi (several trackers of one process on one GPU) is opt-in: it floods the device with concurrent "
+                         "trackers, which is not what a profile of this command is meant to show")
     ap.add_argument("--overlap", type=int, default=2, help="1: one host thread feeds both streams, 2: helper thread")
     ap.add_argument("--distinct-sequences", action="store_true",
                     help="rank r tracks synthetic sequence r instead of every rank tracking sequence 0")

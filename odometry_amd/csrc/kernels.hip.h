@@ -807,6 +807,9 @@ struct StepArgs {
   int first_of_solve;   // 1: the state is initialised from `init` (lm_begin_solve) instead of being loaded
   float init[16];       // affine_init_, column-major (ref: src/lm_optimizer.cpp:76-78)
   unsigned long long* dbg;  // diagnostic (ODO_COARSE_STAMPS): cycle sums of the coarse kernel's phases, else null
+  float* out;           // host-mapped result (42 floats, see lm_write_result), written by the launch that finishes the Solve
+  int* done_flag;       // host-mapped: set to `token` when `out` is complete
+  int token;            // identifies this Solve in the progress and completion words
 };
 
 constexpr int kFoldChunk = 20;  // the 160 rows of a point-list grid in one round of loads per segment
@@ -929,16 +932,43 @@ __device__ __forceinline__ void lm_fused_prologue(const LmState* __restrict__ st
   lm_state_machine(pending, lv, n_levels, lambda0, precision, s_sh, acc_sh, trace, cost_stat, publisher);
 }
 
+// End of a Solve: affine_ = current_estimate.matrix() (ref: src/lm_optimizer.cpp:158) or the pseudo-identity on failure
+// (ref: :48-52,60-65), status, counters and cost statistics into host-mapped memory, then the completion word.
+// One thread. out: 16 pose (column-major), status, n_evals, 8 evaluations per level, 16 cost statistics.
+__device__ __forceinline__ void lm_write_result(const LmState& s, const float* cost_stat, float* __restrict__ out,
+                                                int* __restrict__ done_flag, int token) {
+  float m[16];
+  if (s.status == 0) {
+    se3_to_colmajor(s.cur, m);
+  } else {
+    for (int i = 0; i < 16; i++) m[i] = 0.0f;
+    m[0] = 1.0f; m[5] = 1.0f; m[10] = 1.0f;
+  }
+  for (int i = 0; i < 16; i++) out[i] = m[i];
+  out[16] = (float)s.status;
+  out[17] = (float)s.n_evals;
+  for (int i = 0; i < 8; i++) out[18 + i] = (float)s.iters_level[i];
+  for (int i = 0; i < 16; i++) out[26 + i] = cost_stat[i];
+  __hip_atomic_store(done_flag, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+constexpr int kProgSeqBits = 12;  // progress word = (token << 12) | launches finished: stale launches of an earlier Solve
+                                  // that drain after the host has moved on cannot be mistaken for this Solve's progress
 __device__ __forceinline__ void lm_fused_publish(LmState& s_sh, LmState* __restrict__ st_out, int* __restrict__ host_prog,
-                                                 int seq) {
+                                                 int seq, int token, const float* cost_stat, float* __restrict__ out,
+                                                 int* __restrict__ done_flag) {
   const int t = threadIdx.x;
   if (t < 64) {
     if (t < (int)(sizeof(LmState) / sizeof(int))) ((int*)st_out)[t] = ((const int*)&s_sh)[t];
-    if (t == 0 && host_prog) {
-      // host-mapped progress: [1] = 1 once every level is done (the host stops issuing launches),
-      // [0] = number of launches that have finished
-      if (s_sh.finished) __hip_atomic_store(host_prog + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(host_prog, seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (t == 0) {
+      // the launch that learns that every level is done hands the result to the host itself (no finalize launch)
+      if (s_sh.finished && out) lm_write_result(s_sh, cost_stat, out, done_flag, token);
+      if (host_prog) {
+        // host-mapped progress: [1] = token once every level is done (the host stops issuing launches),
+        // [0] = number of launches of this Solve that have finished
+        if (s_sh.finished) __hip_atomic_store(host_prog + 1, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_prog, (token << kProgSeqBits) | (seq + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
 }
@@ -980,7 +1010,7 @@ __global__ void __launch_bounds__(kLmBlock) lm_step_kernel(StepArgs a) {
   if (publisher) {
     if (threadIdx.x == 0 && run) { s_sh.pending = 1; s_sh.pending_nblk = L.nblk; }
     __syncthreads();
-    lm_fused_publish(s_sh, a.st_out, a.host_prog, a.seq);
+    lm_fused_publish(s_sh, a.st_out, a.host_prog, a.seq, a.token, a.cost_stat, a.out, a.done_flag);
     if (a.dbg && threadIdx.x == 0 && a.seq < 56) a.dbg[16 + 2 * a.seq + 1] = wall_clock64();
   }
 }
@@ -1062,7 +1092,7 @@ __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int
     lm_state_machine(true, a.lv, a.n_levels, a.lambda0, a.precision, s_sh, acc_sh, a.trace, a.cost_stat, true);
     lap(c_sm);
   }
-  lm_fused_publish(s_sh, a.st_out, a.host_prog, a.seq);
+  lm_fused_publish(s_sh, a.st_out, a.host_prog, a.seq, a.token, a.cost_stat, a.out, a.done_flag);
   if (a.dbg && threadIdx.x == 0) {
     if (a.seq < 56) a.dbg[16 + 2 * a.seq + 1] = wall_clock64();
     a.dbg[0] += c_eval; a.dbg[1] += c_red; a.dbg[2] += c_sm; a.dbg[3] += c_it;
@@ -1070,8 +1100,8 @@ __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int
   }
 }
 
-// End of a fused Solve: consume the last pending evaluation, then affine_ = current_estimate.matrix()
-// (ref: src/lm_optimizer.cpp:158) or the pseudo-identity on failure (ref: :48-52,60-65).
+// End of a fused Solve when no step launch has reported it (no launch was issued at all, or the host is not polling):
+// consume the last pending evaluation, then hand the result over like lm_fused_publish does.
 struct FinalizeArgs {
   const LmState* st_in;
   const double* part_in;
@@ -1092,21 +1122,7 @@ __global__ void __launch_bounds__(kLmBlock) lm_fused_finalize_kernel(FinalizeArg
   lm_fused_prologue(a.st_in, a.part_in, nullptr, 0, 0.0f, a.precision, s_sh, fold_sh, acc_sh, a.trace,
                     a.cost_stat, true, a.first_of_solve ? a.init : nullptr);
   if (threadIdx.x < (int)(sizeof(LmState) / sizeof(int))) ((int*)a.st_out)[threadIdx.x] = ((const int*)&s_sh)[threadIdx.x];
-  if (threadIdx.x == 0) {
-    float m[16];
-    if (s_sh.status == 0) {
-      se3_to_colmajor(s_sh.cur, m);
-    } else {
-      for (int i = 0; i < 16; i++) m[i] = 0.0f;
-      m[0] = 1.0f; m[5] = 1.0f; m[10] = 1.0f;
-    }
-    for (int i = 0; i < 16; i++) a.out[i] = m[i];
-    a.out[16] = (float)s_sh.status;
-    a.out[17] = (float)s_sh.n_evals;
-    for (int i = 0; i < 8; i++) a.out[18 + i] = (float)s_sh.iters_level[i];
-    for (int i = 0; i < 16; i++) a.out[26 + i] = a.cost_stat[i];
-    __hip_atomic_store(a.done_flag, a.token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+  if (threadIdx.x == 0) lm_write_result(s_sh, a.cost_stat, a.out, a.done_flag, a.token);
 }
 
 // Test entry for solve_damped_wave (one wavefront).

@@ -570,7 +570,6 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
   // most `run_ahead` launches ahead of the device and stops issuing launches once the device reports that the Solve
   // (fused pipeline) or the level (unfused pipeline) has ended. Stale launches are no-ops on the device either way.
   volatile int* prog = m->h_prog;
-  for (int i = 0; i < 16; i++) m->h_prog[i] = 0;  // the stream is idle here (every Solve ends with a sync)
   bool poll = m->poll != 0;
   bool fused = m->fused && m->robust != 2;
   for (int l = 0; l < m->n_levels; l++)
@@ -578,6 +577,16 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
   int seq = 0;
   LmState* st[2] = {m->d_state, m->d_state + 1};
   double* part[2] = {m->d_partials, m->d_partials + (size_t)kLmMaxBlocks * ODO_NACC};
+  // Every Solve has a token. The fused launches tag their progress words with it — launches of the previous Solve may
+  // still be draining on the stream when this one starts (they are no-ops, but they do report) — and the launch that
+  // finishes the Solve writes the result and the token into host-mapped memory itself.
+  m->token = (m->token % 0x3ffff) + 1;
+  const int token = m->token;
+  auto fused_progress = [&]() { const int v = prog[0]; return ((v >> kProgSeqBits) == token) ? (v & ((1 << kProgSeqBits) - 1)) : 0; };
+  auto fused_finished = [&]() { return prog[1] == token; };
+  if (!fused)
+    for (int i = 0; i < 16; i++) m->h_prog[i] = 0;  // unfused Solves end with a stream sync: nothing is draining
+  bool result_by_launch = false;
   if (fused) {
     // ---- fused pipeline: identical generic step launches; the device walks the pyramid itself ----
     StepArgs a;
@@ -598,6 +607,7 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
     }
     a.lambda0 = m->lambda; a.precision = m->precision; a.robust = m->robust; a.huber_delta = m->huber_delta;
     a.trace = m->d_trace; a.cost_stat = m->d_cost; a.host_prog = m->d_prog;
+    a.out = m->d_res_map; a.done_flag = m->d_done; a.token = token;
     memcpy(a.init, m->init, sizeof(a.init));
     static unsigned long long* dbg_buf = [] {
       unsigned long long* p = nullptr;
@@ -646,14 +656,17 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
       seq++;
       launches++;
     }
-    for (int it = 0; it < budget; it++) {
+    // `budget` launches evaluate at most `budget` times; while the host is polling, one more launch consumes the last
+    // evaluation and reports the result, so no separate finalize launch is needed.
+    for (int it = 0; it < budget + (poll ? 1 : 0); it++) {
       if (poll) {
         const auto t0 = std::chrono::steady_clock::now();
-        while (seq - prog[0] > m->run_ahead && !prog[1]) {
+        while (seq - fused_progress() > m->run_ahead && !fused_finished()) {
           if (m->idle_pump) m->idle_pump(m->idle_arg);
           if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { poll = false; break; }  // never hang
         }
-        if (prog[1]) break;  // every level has finished on the device
+        if (fused_finished()) { result_by_launch = true; break; }  // every level has finished on the device
+        if (!poll && it >= budget) break;
       }
       a.st_in = st[seq & 1]; a.st_out = st[(seq + 1) & 1];
       a.part_in = part[seq & 1]; a.part_out = part[(seq + 1) & 1];
@@ -666,6 +679,7 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
         hipLaunchKernelGGL(lm_step_kernel, dim3(grid), dim3(kLmBlock), 0, s, a);
       seq++;
       launches++;
+      if (it == budget) result_by_launch = true;  // the extra launch consumes the last evaluation and reports
     }
   } else {
     // ---- unfused pipeline (t-distribution mode, dense levels): residual kernel(s) + update kernel per evaluation ----
@@ -703,21 +717,31 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
   if (fused) {
     // The result comes back through host-mapped memory: no copy operation and no stream-sync call on the critical
     // path; the host spins on the completion word (bounded; falls back to a stream sync).
-    FinalizeArgs fa;
-    fa.st_in = st[seq & 1]; fa.part_in = part[seq & 1]; fa.precision = m->precision; fa.trace = m->d_trace;
-    fa.cost_stat = m->d_cost; fa.st_out = st[0]; fa.out = m->d_res_map; fa.done_flag = m->d_done;
-    fa.token = ++m->token; fa.first_of_solve = (seq == 0) ? 1 : 0;
-    memcpy(fa.init, m->init, sizeof(fa.init));
-    hipLaunchKernelGGL(lm_fused_finalize_kernel, dim3(1), dim3(kLmBlock), 0, s, fa);
+    auto launch_finalize = [&]() {
+      FinalizeArgs fa;
+      fa.st_in = st[seq & 1]; fa.part_in = part[seq & 1]; fa.precision = m->precision; fa.trace = m->d_trace;
+      fa.cost_stat = m->d_cost; fa.st_out = st[0]; fa.out = m->d_res_map; fa.done_flag = m->d_done;
+      fa.token = token; fa.first_of_solve = (seq == 0) ? 1 : 0;
+      memcpy(fa.init, m->init, sizeof(fa.init));
+      hipLaunchKernelGGL(lm_fused_finalize_kernel, dim3(1), dim3(kLmBlock), 0, s, fa);
+    };
+    // Not polling (or nothing launched): a finalize launch consumes the last evaluation and reports.
+    if (!result_by_launch) launch_finalize();
     HIP_OK(hipGetLastError());
     volatile int* done = m->h_done;
     const auto t0 = std::chrono::steady_clock::now();
     bool ok = true;
-    while (done[0] != fa.token) {
+    while (done[0] != token) {
       if (m->idle_pump) m->idle_pump(m->idle_arg);
       if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { ok = false; break; }
     }
-    if (!ok) HIP_OK(hipStreamSynchronize(s));
+    if (!ok) {  // never hang: drain the stream; if no launch reported (it should have), finalize explicitly
+      HIP_OK(hipStreamSynchronize(s));
+      if (done[0] != token) {
+        launch_finalize();
+        HIP_OK(hipStreamSynchronize(s));
+      }
+    }
     std::atomic_thread_fence(std::memory_order_acquire);
     memcpy(m->h_out, m->h_res, sizeof(float) * 42);
   } else {

@@ -1354,8 +1354,8 @@ __global__ void __launch_bounds__(kDlmBlock) depth_lm_step_kernel(
     int* __restrict__ part_n /* [2][blocks] */, float tx, float fx, float huber_delta, float lambda0, float precision,
     int max_iters, int* __restrict__ host_prog) {
   constexpr int nslots = kSelBlocks * kSelCap;
-  __shared__ double shs[kDlmBlock];
-  __shared__ int shn[kDlmBlock];
+  __shared__ double shs[kDlmBlock / 64];
+  __shared__ int shn[kDlmBlock / 64];
   const int t = threadIdx.x;
   const int s = blockIdx.x * kDlmBlock + t;
   float* cur = scratch;
@@ -1367,6 +1367,16 @@ __global__ void __launch_bounds__(kDlmBlock) depth_lm_step_kernel(
   const bool ok = (s % kSelCap) < cnt[s / kSelCap];
   DepthLmState st;
   float my_tmp;
+  // Everything below that does not depend on the accept / reject decision is fetched up front, in one batch with the
+  // state and the partial sums: a launch then has two dependent trips to memory (this batch, the right-image taps)
+  // instead of five.
+  float pf_pre = 0.0f, pf_tmp = 0.0f, pf_jt = 0.0f, pf_bb = 0.0f, pf_left = 0.0f;
+  uint32_t pf_pk = 0u;
+  if (ok) {
+    pf_pk = pts[s];
+    if (k > 0) { pf_pre = pre[s]; pf_tmp = tmp[s]; pf_jt = jt[s]; pf_bb = bb[s]; }
+    pf_left = left[(size_t)(pf_pk >> 16) * cols + (pf_pk & 0xffffu)];
+  }
   if (k == 0) {
     st.lambda = lambda0; st.err_last = 1e+10f; st.err_now = 0.0f; st.iter = 0;
     st.done = (max_iters > 0) ? 0 : 1;
@@ -1380,15 +1390,21 @@ __global__ void __launch_bounds__(kDlmBlock) depth_lm_step_kernel(
     // ---- decision for evaluation k-1 (every block, identical arithmetic) ----
     const double* pe = part_e + ((k - 1) & 1) * kDlmBlocks;
     const int* pn = part_n + ((k - 1) & 1) * kDlmBlocks;
-    shs[t] = (t < kDlmBlocks) ? pe[t] : 0.0;
-    shn[t] = (t < kDlmBlocks) ? pn[t] : 0;
-    __syncthreads();
-    for (int o = kDlmBlock / 2; o > 0; o >>= 1) {
-      if (t < o) { shs[t] += shs[t + o]; shn[t] += shn[t + o]; }
-      __syncthreads();
+    // fixed-order fold of the 160 per-block partials: every wave does it redundantly (three rows per lane, then a
+    // butterfly), so no LDS and no block barrier sit between the partial sums and the decision
+    double fe = 0.0;
+    int fn = 0;
+    {
+      const int lane = t & 63;
+#pragma unroll
+      for (int j = 0; j < (kDlmBlocks + 63) / 64; j++) {
+        const int b = lane + 64 * j;
+        if (b < kDlmBlocks) { fe += pe[b]; fn += pn[b]; }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { fe += __shfl_xor(fe, o, 64); fn += __shfl_xor(fn, o, 64); }
     }
-    const float err_now = (1.0f / (float)shn[0]) * (float)shs[0];  // :239
-    __syncthreads();
+    const float err_now = (1.0f / (float)fn) * (float)fe;  // :239
     st.err_now = err_now;
     int mode;  // 0 reject+continue, 1 accept+continue, 2 reject+break, 3 accept+break
     if (err_now > st.err_last) {  // :150
@@ -1402,13 +1418,13 @@ __global__ void __launch_bounds__(kDlmBlock) depth_lm_step_kernel(
     my_tmp = 0.0f;
     if (mode != 2 && ok) {
       float c;
-      if (mode == 0) c = pre[s];            // :153
-      else { c = tmp[s]; pre[s] = c; }      // :155-156
+      if (mode == 0) c = pf_pre;            // :153
+      else { c = pf_tmp; pre[s] = c; }      // :155-156
       cur[s] = c;
       if (mode != 3) {
-        const float jj = jt[s];
+        const float jj = pf_jt;
         const float A = jj + st.lambda * jj;  // :164
-        const float dd = (1.0f / A) * bb[s];  // :165
+        const float dd = (1.0f / A) * pf_bb;  // :165
         my_tmp = dd + c;                      // :166
         tmp[s] = my_tmp;
       }
@@ -1424,7 +1440,7 @@ __global__ void __launch_bounds__(kDlmBlock) depth_lm_step_kernel(
   double esum = 0.0;
   int nact = 0;
   if (ok) {
-    const uint32_t pk = pts[s];
+    const uint32_t pk = pf_pk;
     const int x = (int)(pk & 0xffffu), y = (int)(pk >> 16);
     const float wf = floorf((float)x - tx * fx * my_tmp);  // :217
     if (!(wf >= 2.0f) || !(wf <= (float)(cols - 2))) {     // :219-223
@@ -1432,7 +1448,7 @@ __global__ void __launch_bounds__(kDlmBlock) depth_lm_step_kernel(
     } else {
       const int wx = (int)wf;
       const float* Rr = right + (size_t)y * cols;
-      const float r_i = left[(size_t)y * cols + x] - Rr[wx];                            // :226
+      const float r_i = pf_left - Rr[wx];                                                // :226
       const float w_i = (fabsf(r_i) <= huber_delta) ? 1.0f : huber_delta / fabsf(r_i);   // :228
       const float r_diff = tx * fx * 0.5f * (Rr[wx + 1] - Rr[wx - 1]);                   // :229
       res[s] = fabsf(r_i);
@@ -1442,16 +1458,14 @@ __global__ void __launch_bounds__(kDlmBlock) depth_lm_step_kernel(
       bb[s] = -r_diff * w_i * r_i;                                                       // :235
     }
   }
-  shs[t] = esum;
-  shn[t] = nact;
+  // block sum: butterfly inside each wave, then the four wave sums in a fixed order (one barrier)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { esum += __shfl_xor(esum, o, 64); nact += __shfl_xor(nact, o, 64); }
+  if ((t & 63) == 0) { shs[t >> 6] = esum; shn[t >> 6] = nact; }
   __syncthreads();
-  for (int o = kDlmBlock / 2; o > 0; o >>= 1) {
-    if (t < o) { shs[t] += shs[t + o]; shn[t] += shn[t + o]; }
-    __syncthreads();
-  }
   if (t == 0) {
-    part_e[(k & 1) * kDlmBlocks + blockIdx.x] = shs[0];
-    part_n[(k & 1) * kDlmBlocks + blockIdx.x] = shn[0];
+    part_e[(k & 1) * kDlmBlocks + blockIdx.x] = (shs[0] + shs[1]) + (shs[2] + shs[3]);
+    part_n[(k & 1) * kDlmBlocks + blockIdx.x] = (shn[0] + shn[1]) + (shn[2] + shn[3]);
     if (blockIdx.x == 0) { state[(k + 1) & 1] = st; dlm_report(host_prog, k, 0); }
   }
 }

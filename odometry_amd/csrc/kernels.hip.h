@@ -779,7 +779,8 @@ __global__ void __launch_bounds__(kUpdThreads) lm_update_kernel(LmState* __restr
 // sums imply (fold -> accept/reject -> wave-parallel 6x6 solve -> exp / compose), then evaluates its share of the
 // points at the new pose and writes the next partial sums. No separate update kernel, no kernel boundary and no
 // trip through memory between "new pose known" and "residuals at the new pose". State and partials are
-// double-buffered by launch sequence number; block 0 alone publishes the state, trace row and progress words.
+// double-buffered by launch sequence number; one extra block that evaluates nothing (the last of the grid) alone
+// publishes the state, the trace row, the progress words and — when the Solve has finished — the result.
 // =============================================================================================
 struct StepLevel {   // everything a launch needs to evaluate one pyramid level
   PointList pl;

@@ -27,10 +27,42 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
 def frame_order(n_unique, n_steps):
-    """Palindromic playback of the unique frames: 1,2,..,F-1,F-2,..,0,1,.. — consecutive frames always differ by one
-    real camera step, so the tracker sees the same kind of motion for any number of steps."""
-    cyc = list(range(1, n_unique)) + list(range(n_unique - 2, -1, -1))
-    return [cyc[i % len(cyc)] for i in range(n_steps)]
+    """Forward passes over the unique frames: 1, 2, .., F-1, 1, 2, .. — the camera only ever drives forward, as in a KITTI
+    sequence (the tracker's keyframe policy and convergence behaviour are tuned for that; played backwards it loses track
+    and falls into a new-keyframe-every-frame regime). Whenever frame 1 comes up again the tracker is re-initialised on
+    frame 0 first, the way the runner starts a sequence (`begins_pass`)."""
+    return [1 + (i % (n_unique - 1)) for i in range(n_steps)]
+
+
+def begins_pass(order, k):
+    """True when step k is the first frame of a later pass: the tracker must be re-initialised on frame 0 before it."""
+    return k > 0 and order[k] == 1
+
+
+def render_sequence(n_frames, seed, workers):
+    """The synthetic stereo sequence, rendered by a small process pool (called before anything touches the GPU)."""
+    from odometry_amd import synth
+    if workers <= 1 or n_frames <= 8:
+        return synth.make_sequence(n_frames, seed=seed)
+    import concurrent.futures as cf
+    poses = synth.trajectory(n_frames, seed)
+    with cf.ProcessPoolExecutor(max_workers=workers) as ex:
+        frames = list(ex.map(_render_pair, [(seed, poses[i]) for i in range(n_frames)], chunksize=max(1, n_frames // (4 * workers))))
+    return dict(left=[f[0] for f in frames], right=[f[1] for f in frames], poses=poses, depth=[])
+
+
+_scene_cache = {}
+
+
+def _render_pair(job):
+    from odometry_amd import synth
+    seed, T = job
+    if seed not in _scene_cache:
+        _scene_cache[seed] = synth.Scene(seed)
+    sc = _scene_cache[seed]
+    L, _ = sc.render(T, synth.KITTI_ROWS, synth.KITTI_COLS, synth.KITTI_F, synth.KITTI_CX, synth.KITTI_CY, 0.0)
+    R, _ = sc.render(T, synth.KITTI_ROWS, synth.KITTI_COLS, synth.KITTI_F, synth.KITTI_CX, synth.KITTI_CY, synth.KITTI_BASELINE)
+    return L, R
 
 
 def load_traffic():
@@ -51,7 +83,9 @@ def cpu_baseline(seq, order, n_frames):
     run.init(seq["left"][0], seq["right"][0])
     poses = []
     t0 = time.perf_counter()
-    for i in order[:n_frames]:
+    for k, i in enumerate(order[:n_frames]):
+        if begins_pass(order, k):
+            run.init(seq["left"][0], seq["right"][0])
         poses.append(run.track(seq["left"][i], seq["right"][i]))
     dt = time.perf_counter() - t0
     return n_frames / dt, poses, dt
@@ -158,7 +192,9 @@ def multi_sequence_leg(api, seq, order, n_seq, steps):
         for i in order[:10]:
             trks[k].track_into(devs[k][i][0], devs[k][i][1], a, b)
         barrier.wait()
-        for i in order[:steps]:
+        for j, i in enumerate(order[10:10 + steps], start=10):
+            if begins_pass(order, j):
+                trks[k].init(*devs[k][0])
             trks[k].track_into(devs[k][i][0], devs[k][i][1], a, b)
         barrier.wait()
 
@@ -181,7 +217,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--unique-frames", type=int, default=16)
+    ap.add_argument("--unique-frames", type=int, default=64,
+                    help="length of the synthetic forward drive; the steps are passes over it (frame 0 re-initialises)")
     ap.add_argument("--gather-every", type=int, default=8)
     ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-overlap", action="store_true", help="run ComputeDepth after Solve on one stream")
@@ -199,6 +236,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Weak scaling wants the same work on every GPU: per-frame cost depends on image content (20-50 LM evaluations), so by
+    # default every rank tracks its own copy of synthetic sequence 0; --distinct-sequences gives rank r sequence r.
+    # Rendered first, by a few worker processes, before this process touches the GPU.
+    seq = render_sequence(args.unique_frames, rank if args.distinct_sequences else 0,
+                          max(1, min(16, (os.cpu_count() or 1) // max(world, 1))))
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -221,9 +263,6 @@ def main():
     # with fewer cores than that, fall back to one feeding thread per rank rather than oversubscribe spinning threads.
     if not args.no_overlap and args.overlap == 2 and (os.cpu_count() or 1) < 2 * world + 2:
         args.overlap = 1
-    # Weak scaling wants the same work on every GPU: per-frame cost depends on image content (20-30 LM evaluations), so by
-    # default every rank tracks its own copy of synthetic sequence 0; --distinct-sequences gives rank r sequence r.
-    seq = synth.make_sequence(args.unique_frames, seed=rank if args.distinct_sequences else 0)
     trk = api.Tracker(local_rank, overlap_depth=0 if args.no_overlap else args.overlap)
     dev = [(trk.upload_frame(l), trk.upload_frame(r)) for l, r in zip(seq["left"], seq["right"])]  # inputs resident in HBM
     trk.init(*dev[0])
@@ -244,6 +283,8 @@ def main():
 
     def step(i):
         k = step_no[0]
+        if begins_pass(order, k):
+            trk.init(*dev[0])   # a new pass over the sequence starts like the runner does: frame 0 becomes the keyframe
         if not args.no_prefetch and k + 1 < n_total:
             trk.hint_next(dev[order[k + 1]][0])   # frames are resident: the next frame's pyramid overlaps this frame's tail
         trk.track_into(dev[i][0], dev[i][1], poses_kf[k], poses_abs[k])
@@ -288,12 +329,15 @@ def main():
     if rank == 0:
         # --- roofline of the dominant kernels (lm_coarse_kernel + lm_step_kernel: LM update + residual / normal-equation pass):
         # a second pass over the same frames with every launch bracketed by HIP events on the kernel's own stream.
+        n_frames_ev = min(args.steps, 100)
+        trk.init(*dev[0])
         trk.event_timing(True)
-        for i in order[args.warmup:args.warmup + min(args.steps, 100)]:
+        for k, i in enumerate(order[:n_frames_ev]):
+            if begins_pass(order, k):
+                trk.init(*dev[0])
             trk.track(*dev[i])
         ev = trk.event_stats()
         trk.event_timing(False)
-        n_frames_ev = min(args.steps, 100)
         step_launches = max(ev["launches"] - ev["coarse_launches"], 1)
         step_us = (ev["total_us"] - ev["coarse_us"]) / step_launches
         achieved = ev["bytes"] / (ev["total_us"] * 1e-6) / 1e9 if ev["total_us"] > 0 else 0.0
@@ -316,8 +360,9 @@ def main():
         out = dict(metric="tracked frames/sec (1241x376, 4-level pyramid)", value=round(fps, 2), unit="frames/s",
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 4),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload="synthetic KITTI-shaped stereo sequence (configs[1]), 1241x376, 4 levels, "
-                                        "semi-dense, runner params, one sequence per GPU",
+                   config=dict(workload="synthetic KITTI-shaped stereo sequence (configs[1]: a forward drive, passes over "
+                                        "unique_frames frames, the tracker re-initialised on frame 0 at each pass), 1241x376, "
+                                        "4 levels, semi-dense, runner params, one sequence per GPU",
                                unique_frames=args.unique_frames, sequences_per_gpu=1,
                                overlap_depth=0 if args.no_overlap else args.overlap, gather_every=args.gather_every,
                                next_frame_pyramid_prefetch=not args.no_prefetch,
@@ -336,6 +381,8 @@ def main():
             trk2.init(*dev2[0])
             dmax = 0.0
             for j, i in enumerate(order[:n]):
+                if begins_pass(order, j):
+                    trk2.init(*dev2[0])
                 g = trk2.track(*dev2[i])
                 dmax = max(dmax, float(np.abs(g["pose_to_keyframe"].astype(np.float64) - cpu_poses[j]["pose_to_keyframe"]).max()))
             trk2.close()

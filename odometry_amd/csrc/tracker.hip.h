@@ -191,6 +191,13 @@ static void tracker_worker_main(odo_tracker* t) {
 extern "C" int odo_tracker_init(odo_tracker* t, const float* left, const float* right, const float abs_pose0[16]) {
   if (!t || !left || !right || !abs_pose0) return fail("odo_tracker_init: NULL arg");
   HIP_OK(hipSetDevice(t->ctx_a->device));
+  // Re-initialisation of a tracker that has been tracking: the tail of the last frame (its keyframe-candidate pyramid,
+  // a prefetched next pyramid, straggling LM launches) may still be running on stream A, and track() had moved the
+  // candidate image pyramid to that stream. Start from a quiet device and build everything on stream B again.
+  HIP_OK(hipStreamSynchronize(t->ctx_a->stream));
+  HIP_OK(hipStreamSynchronize(t->ctx_b->stream));
+  t->pre_img_on_a = 0;
+  t->pre_img->ctx = t->ctx_b;
   if (tracker_depth_and_pyramids(t, left, right)) return -1;   // :102, :130-131
   if (depth_finish(t->depth, true)) { fail("Init 0-th frame failed!"); return -1; }  // :103-106
   std::swap(t->kf_img, t->pre_img);                             // :141 first keyframe

@@ -121,9 +121,16 @@ def trajectory(n_frames, seed=0, fwd_range=(0.3, 0.6)):
         yaw = np.deg2rad(rng.uniform(-1.5, 1.5))
         if abs(yaw_total + yaw) > np.deg2rad(6.0):  # stay inside the corridor
             yaw = -yaw
-        yaw_total += yaw
         pitch = np.deg2rad(rng.uniform(-0.2, 0.2))
         roll = np.deg2rad(rng.uniform(-0.2, 0.2))
+        # long sequences: steer back towards the corridor axis once the camera has drifted (same random draws, so
+        # short sequences — which never drift this far — are unchanged)
+        cur = poses[-1]
+        if abs(cur[0, 3]) > 1.0 and np.sign(yaw) == np.sign(cur[0, 3]) and np.sign(cur[0, 2]) == np.sign(cur[0, 3]):
+            yaw = -yaw                                   # heading away from the axis: turn the other way
+        if abs(cur[1, 3]) > 0.3 and np.sign(cur[1, 2]) == np.sign(cur[1, 3]) and np.sign(-pitch) == np.sign(cur[1, 3]):
+            pitch = -pitch
+        yaw_total += yaw
         cy_, sy_ = np.cos(yaw), np.sin(yaw)
         cp, sp = np.cos(pitch), np.sin(pitch)
         cr, sr = np.cos(roll), np.sin(roll)

@@ -20,7 +20,9 @@ def run(n_seq, prio, steps=200):
         a, b = np.zeros(16, np.float32), np.zeros(16, np.float32)
         for i in order[:10]: trks[k].track_into(devs[k][i][0], devs[k][i][1], a, b)
         bar.wait()
-        for i in order[:steps]: trks[k].track_into(devs[k][i][0], devs[k][i][1], a, b)
+        for j, i in enumerate(order[10:10 + steps], start=10):
+            if bench.begins_pass(order, j): trks[k].init(*devs[k][0])
+            trks[k].track_into(devs[k][i][0], devs[k][i][1], a, b)
         bar.wait()
     th = [threading.Thread(target=work, args=(k,)) for k in range(n_seq)]
     [t.start() for t in th]

@@ -307,6 +307,13 @@ struct odo_lm {
   int use_list[ODO_MAX_LEVELS];
   unsigned long long kf_img_ver, kf_dep_ver;
   int* d_rowcnt; int* d_rowoff; int* d_npts; int* h_npts; int rows_cap;
+  // A second, identical set of list buffers for the keyframe CANDIDATE of the frame being tracked: the tracker fills it on
+  // its depth stream every frame (lm_build_candidate), off the Solve's critical path; when the candidate becomes the
+  // keyframe the two sets trade places (lm_adopt_candidate) instead of three launches + a read-back in front of the Solve.
+  PointList cand_pl[ODO_MAX_LEVELS];
+  size_t cand_pl_cap[ODO_MAX_LEVELS];
+  int* cand_d_rowcnt; int* cand_d_rowoff; int* cand_d_npts; int* cand_h_npts; int cand_rows_cap;
+  long cand_tag;   // caller's tag of the candidate (frame id), -1 = none
   // optional per-launch HIP-event timing of the evaluation kernels (bench.py roofline leg)
   int ev_on;
   std::vector<hipEvent_t>* ev_pool;
@@ -369,6 +376,9 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
   memset(m->h_prog, 0, sizeof(int) * 16);
   HIP_OK(hipMalloc((void**)&m->d_npts, sizeof(int) * ODO_MAX_LEVELS));
   HIP_OK(hipHostMalloc((void**)&m->h_npts, sizeof(int) * ODO_MAX_LEVELS, hipHostMallocDefault));
+  HIP_OK(hipMalloc((void**)&m->cand_d_npts, sizeof(int) * ODO_MAX_LEVELS));
+  HIP_OK(hipHostMalloc((void**)&m->cand_h_npts, sizeof(int) * ODO_MAX_LEVELS, hipHostMallocDefault));
+  m->cand_tag = -1;
   m->mode = getenv("ODO_LM_MODE") ? atoi(getenv("ODO_LM_MODE")) : 0;
   m->fused = getenv("ODO_LM_UNFUSED") ? 0 : 1;
   m->coarse = getenv("ODO_LM_NO_COARSE") ? 0 : 1;
@@ -385,13 +395,14 @@ extern "C" int odo_lm_destroy(odo_lm* m) {
   if (!m) return 0;
   (void)hipStreamSynchronize(m->ctx->stream);
   void* dv[] = {m->d_state, m->d_partials, m->d_init, m->d_out, m->d_trace, m->d_scale, m->d_res,
-                m->d_rowcnt, m->d_rowoff, m->d_npts};
+                m->d_rowcnt, m->d_rowoff, m->d_npts, m->cand_d_rowcnt, m->cand_d_rowoff, m->cand_d_npts};
   for (void* q : dv) if (q) (void)hipFree(q);
   for (int l = 0; l < ODO_MAX_LEVELS; l++) {
-    void* pv[] = {m->pl[l].a, m->pl[l].b, m->pl[l].c, m->pl[l].d};
+    void* pv[] = {m->pl[l].a, m->pl[l].b, m->pl[l].c, m->pl[l].d, m->cand_pl[l].a, m->cand_pl[l].b, m->cand_pl[l].c, m->cand_pl[l].d};
     for (void* q : pv) if (q) (void)hipFree(q);
   }
   (void)hipHostFree(m->h_npts);
+  (void)hipHostFree(m->cand_h_npts);
   if (m->ev_pool) { for (auto& e : *m->ev_pool) (void)hipEventDestroy(e); delete m->ev_pool; }
   (void)hipHostFree(m->h_out); (void)hipHostFree(m->h_trace); (void)hipHostFree(m->h_prog); (void)hipHostFree(m->h_res); (void)hipHostFree(m->h_done);
   delete m;
@@ -439,6 +450,68 @@ static int lm_ensure_res(odo_lm* m, size_t n) {
   return 0;
 }
 
+// Enqueues the three launches that compact the keyframe's valid-depth pixels of every level into point lists (and the
+// 32-byte read-back of the per-level counts) on `s`. img supplies I1, dep the inverse depths; both pyramids have the same
+// geometry. Buffers grow on demand (only the first keyframes of a run allocate).
+static int lm_enqueue_lists(odo_lm* m, PointList* pl, size_t* pl_cap, int*& d_rowcnt, int*& d_rowoff, int& rows_cap, int* d_npts,
+                            int* h_npts, const odo_pyr* img, const odo_pyr* dep, hipStream_t s, int* rows_total_out) {
+  KfLevels kl;
+  memset(&kl, 0, sizeof(kl));
+  kl.n_levels = m->n_levels;
+  int rows_total = 0;
+  for (int l = 0; l < m->n_levels; l++) {
+    kl.I1[l] = img->dev + img->off[l];
+    kl.D1[l] = dep->dev + dep->off[l];
+    kl.rows[l] = img->r[l]; kl.cols[l] = img->c[l];
+    kl.row_base[l] = rows_total;
+    const int ir = kl.rows[l] - 8, ic = kl.cols[l] - 8;
+    rows_total += (ir > 0 && ic > 0) ? ir : 0;
+    const size_t cap = (ir > 0 && ic > 0) ? (size_t)ir * ic : 0;
+    if (cap > pl_cap[l]) {
+      HIP_OK(hipStreamSynchronize(s));
+      void* pv[] = {pl[l].a, pl[l].b, pl[l].c, pl[l].d};
+      for (void* q : pv) if (q) HIP_OK(hipFree(q));
+      HIP_OK(hipMalloc((void**)&pl[l].a, sizeof(float4) * cap));
+      HIP_OK(hipMalloc((void**)&pl[l].b, sizeof(float4) * cap));
+      HIP_OK(hipMalloc((void**)&pl[l].c, sizeof(float4) * cap));
+      HIP_OK(hipMalloc((void**)&pl[l].d, sizeof(float) * cap));
+      pl_cap[l] = cap;
+    }
+  }
+  kl.row_base[m->n_levels] = rows_total;
+  for (int l = m->n_levels + 1; l <= ODO_MAX_LEVELS; l++) kl.row_base[l] = rows_total;
+  if (rows_total > rows_cap) {
+    HIP_OK(hipStreamSynchronize(s));
+    if (d_rowcnt) HIP_OK(hipFree(d_rowcnt));
+    if (d_rowoff) HIP_OK(hipFree(d_rowoff));
+    d_rowcnt = d_rowoff = nullptr;
+    HIP_OK(hipMalloc((void**)&d_rowcnt, sizeof(int) * rows_total));
+    HIP_OK(hipMalloc((void**)&d_rowoff, sizeof(int) * rows_total));
+    rows_cap = rows_total;
+  }
+  *rows_total_out = rows_total;
+  if (rows_total > 0) {
+    hipLaunchKernelGGL(kf_count_kernel, dim3(rows_total), dim3(256), 0, s, kl, d_rowcnt);
+    hipLaunchKernelGGL(kf_scan_kernel, dim3(1), dim3(1024), 0, s, kl, d_rowcnt, d_rowoff, d_npts);
+    hipLaunchKernelGGL(kf_fill_kernel, dim3(rows_total), dim3(256), 0, s, kl, m->K.f0, m->K.cx0, m->K.cy0, d_rowoff,
+                       pl[0], pl[1], pl[2], pl[3], pl[4], pl[5], pl[6], pl[7]);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(h_npts, d_npts, sizeof(int) * ODO_MAX_LEVELS, hipMemcpyDeviceToHost, s));
+  }
+  return 0;
+}
+
+// Per-level counts (host copy) -> which levels run on their list (auto: when at most half of the interior has depth).
+static void lm_take_counts(odo_lm* m, const int* h_npts, const odo_pyr* img, int rows_total) {
+  for (int l = 0; l < ODO_MAX_LEVELS; l++) { m->npts[l] = 0; m->use_list[l] = 0; }
+  if (rows_total <= 0) return;
+  for (int l = 0; l < m->n_levels; l++) {
+    m->npts[l] = h_npts[l];
+    const long interior = (long)(img->r[l] - 8) * (img->c[l] - 8);
+    m->use_list[l] = (m->mode == 2) || (interior > 0 && 2L * m->npts[l] <= interior);
+  }
+}
+
 // Builds (or reuses) the keyframe point lists for the pyramids of this Solve. Three launches over all levels +
 // a 32-byte read-back of the per-level counts; done once per keyframe (the cache is keyed on the pyramids' build
 // versions). Levels where more than half of the interior carries depth keep the dense scan.
@@ -446,56 +519,45 @@ static int lm_prepare_keyframe(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* 
   if (m->mode == 1) { for (int l = 0; l < m->n_levels; l++) m->use_list[l] = 0; return 0; }
   if (m->kf_img_ver == kf_img->version && m->kf_dep_ver == kf_dep->version) return 0;
   hipStream_t s = m->ctx->stream;
-  KfLevels kl;
-  memset(&kl, 0, sizeof(kl));
-  kl.n_levels = m->n_levels;
   int rows_total = 0;
-  for (int l = 0; l < m->n_levels; l++) {
-    kl.I1[l] = kf_img->dev + kf_img->off[l];
-    kl.D1[l] = kf_dep->dev + kf_dep->off[l];
-    kl.rows[l] = kf_img->r[l]; kl.cols[l] = kf_img->c[l];
-    kl.row_base[l] = rows_total;
-    const int ir = kl.rows[l] - 8, ic = kl.cols[l] - 8;
-    rows_total += (ir > 0 && ic > 0) ? ir : 0;
-    const size_t cap = (ir > 0 && ic > 0) ? (size_t)ir * ic : 0;
-    if (cap > m->pl_cap[l]) {
-      HIP_OK(hipStreamSynchronize(s));
-      void* pv[] = {m->pl[l].a, m->pl[l].b, m->pl[l].c, m->pl[l].d};
-      for (void* q : pv) if (q) HIP_OK(hipFree(q));
-      HIP_OK(hipMalloc((void**)&m->pl[l].a, sizeof(float4) * cap));
-      HIP_OK(hipMalloc((void**)&m->pl[l].b, sizeof(float4) * cap));
-      HIP_OK(hipMalloc((void**)&m->pl[l].c, sizeof(float4) * cap));
-      HIP_OK(hipMalloc((void**)&m->pl[l].d, sizeof(float) * cap));
-      m->pl_cap[l] = cap;
-    }
-  }
-  kl.row_base[m->n_levels] = rows_total;
-  for (int l = m->n_levels + 1; l <= ODO_MAX_LEVELS; l++) kl.row_base[l] = rows_total;
-  if (rows_total > m->rows_cap) {
-    HIP_OK(hipStreamSynchronize(s));
-    if (m->d_rowcnt) HIP_OK(hipFree(m->d_rowcnt));
-    if (m->d_rowoff) HIP_OK(hipFree(m->d_rowoff));
-    HIP_OK(hipMalloc((void**)&m->d_rowcnt, sizeof(int) * rows_total));
-    HIP_OK(hipMalloc((void**)&m->d_rowoff, sizeof(int) * rows_total));
-    m->rows_cap = rows_total;
-  }
-  for (int l = 0; l < ODO_MAX_LEVELS; l++) { m->npts[l] = 0; m->use_list[l] = 0; }
-  if (rows_total > 0) {
-    hipLaunchKernelGGL(kf_count_kernel, dim3(rows_total), dim3(256), 0, s, kl, m->d_rowcnt);
-    hipLaunchKernelGGL(kf_scan_kernel, dim3(1), dim3(1024), 0, s, kl, m->d_rowcnt, m->d_rowoff, m->d_npts);
-    hipLaunchKernelGGL(kf_fill_kernel, dim3(rows_total), dim3(256), 0, s, kl, m->K.f0, m->K.cx0, m->K.cy0, m->d_rowoff,
-                       m->pl[0], m->pl[1], m->pl[2], m->pl[3], m->pl[4], m->pl[5], m->pl[6], m->pl[7]);
-    HIP_OK(hipGetLastError());
-    HIP_OK(hipMemcpyAsync(m->h_npts, m->d_npts, sizeof(int) * ODO_MAX_LEVELS, hipMemcpyDeviceToHost, s));
-    HIP_OK(hipStreamSynchronize(s));
-    for (int l = 0; l < m->n_levels; l++) {
-      m->npts[l] = m->h_npts[l];
-      const long interior = (long)(kl.rows[l] - 8) * (kl.cols[l] - 8);
-      m->use_list[l] = (m->mode == 2) || (interior > 0 && 2L * m->npts[l] <= interior);
-    }
-  }
+  if (lm_enqueue_lists(m, m->pl, m->pl_cap, m->d_rowcnt, m->d_rowoff, m->rows_cap, m->d_npts, m->h_npts, kf_img, kf_dep, s,
+                       &rows_total)) return -1;
+  if (rows_total > 0) HIP_OK(hipStreamSynchronize(s));
+  lm_take_counts(m, m->h_npts, kf_img, rows_total);
   m->kf_img_ver = kf_img->version;
   m->kf_dep_ver = kf_dep->version;
+  return 0;
+}
+
+// Candidate lists (see odo_lm::cand_pl): enqueue on stream `s` (the tracker's depth stream); `img` holds the frame's image
+// pyramid, `dep` its freshly estimated depth pyramid. The counts are valid once `s` has drained past this point.
+static int lm_build_candidate(odo_lm* m, const odo_pyr* img, const odo_pyr* dep, hipStream_t s, long tag) {
+  m->cand_tag = -1;
+  if (m->mode == 1) return 0;
+  int rows_total = 0;
+  if (lm_enqueue_lists(m, m->cand_pl, m->cand_pl_cap, m->cand_d_rowcnt, m->cand_d_rowoff, m->cand_rows_cap, m->cand_d_npts,
+                       m->cand_h_npts, img, dep, s, &rows_total)) return -1;
+  if (rows_total > 0) m->cand_tag = tag;
+  return 0;
+}
+
+// The candidate tagged `tag` has become the keyframe (kf_img / kf_dep are its pyramids, the stream that built the lists
+// has drained): trade the two list sets. Returns 0 when adopted, 1 when there was no such candidate (the next Solve then
+// builds the lists itself).
+static int lm_adopt_candidate(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, long tag) {
+  if (m->mode == 1 || m->cand_tag < 0 || m->cand_tag != tag) return 1;
+  for (int l = 0; l < ODO_MAX_LEVELS; l++) { std::swap(m->pl[l], m->cand_pl[l]); std::swap(m->pl_cap[l], m->cand_pl_cap[l]); }
+  std::swap(m->d_rowcnt, m->cand_d_rowcnt); std::swap(m->d_rowoff, m->cand_d_rowoff); std::swap(m->rows_cap, m->cand_rows_cap);
+  std::swap(m->d_npts, m->cand_d_npts); std::swap(m->h_npts, m->cand_h_npts);
+  int rows_total = 0;
+  for (int l = 0; l < m->n_levels; l++) {
+    const int ir = kf_img->r[l] - 8, ic = kf_img->c[l] - 8;
+    rows_total += (ir > 0 && ic > 0) ? ir : 0;
+  }
+  lm_take_counts(m, m->h_npts, kf_img, rows_total);
+  m->kf_img_ver = kf_img->version;
+  m->kf_dep_ver = kf_dep->version;
+  m->cand_tag = -1;
   return 0;
 }
 

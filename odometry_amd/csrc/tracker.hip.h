@@ -19,11 +19,13 @@ struct odo_tracker {
   int n_keyframes, frame_id;
   int last_evals, last_depth_iters, last_valid;
   hipEvent_t ev_inputs;
+  hipEvent_t ev_cur_img;  // stream A: the current frame's image pyramid is complete (stream B reads it for the candidate lists)
   DepthJob job;
   int job_stage;  // 0 idle, 1 depth launches in flight, 2 depth tail enqueued (pyramids next), 3 all enqueued
   int job_err;
   double tm_solve_us, tm_depth_us, tm_frame_us, tm_wait_us; long tm_frames;  // host-clock averages (diagnostics)
   int pre_img_on_a;  // 1: the frame's second image pyramid (:251) is built on stream A after the Solve
+  int cand_lists;    // 1: keyframe-candidate point lists are built every frame on stream B (ODO_NO_CAND_LISTS=1 turns it off)
   // overlap_depth == 2: a helper host thread feeds stream B (ComputeDepth + candidate pyramids) while the calling
   // thread feeds stream A (pose LM). Host launch rate, not the GPU, bounds a latency-bound frame loop.
   std::thread worker;
@@ -74,6 +76,7 @@ extern "C" int odo_tracker_destroy(odo_tracker* t) {
   if (t->d_disp) (void)hipFree(t->d_disp);
   if (t->d_dep) (void)hipFree(t->d_dep);
   if (t->ev_inputs) (void)hipEventDestroy(t->ev_inputs);
+  if (t->ev_cur_img) (void)hipEventDestroy(t->ev_cur_img);
   odo_ctx_destroy(t->ctx_b);
   odo_ctx_destroy(t->ctx_a);
   delete t;
@@ -88,9 +91,10 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
   t->ctx_a = t->ctx_b = nullptr; t->lm = nullptr; t->depth = nullptr;
   t->kf_img = t->kf_dep = t->cur_img = t->pre_img = t->pre_dep = t->next_img = nullptr;
   t->hint_next = t->prefetched = nullptr;
-  t->d_val = nullptr; t->d_disp = t->d_dep = nullptr; t->ev_inputs = nullptr;
+  t->d_val = nullptr; t->d_disp = t->d_dep = nullptr; t->ev_inputs = nullptr; t->ev_cur_img = nullptr;
   t->n_keyframes = t->frame_id = t->last_evals = t->last_depth_iters = t->last_valid = 0;
   t->job_stage = t->job_err = 0; t->pre_img_on_a = 0;
+  t->cand_lists = getenv("ODO_NO_CAND_LISTS") ? 0 : 1;
   t->tm_solve_us = t->tm_depth_us = t->tm_frame_us = t->tm_wait_us = 0.0; t->tm_frames = 0;
   t->w_state.store(0); t->w_left = t->w_right = nullptr; t->w_rc = 0; t->w_err[0] = 0;
   t->p = *p;
@@ -119,6 +123,7 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
   ok = ok && hipMalloc((void**)&t->d_val, n) == hipSuccess && hipMalloc((void**)&t->d_disp, sizeof(float) * n) == hipSuccess &&
        hipMalloc((void**)&t->d_dep, sizeof(float) * n) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&t->ev_inputs, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&t->ev_cur_img, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     char keep[512];
     snprintf(keep, sizeof(keep), "%s", g_err);
@@ -150,6 +155,14 @@ static void tracker_job_pump(void* arg) {
     const odo_tracker_params& p = t->p;
     if (!t->pre_img_on_a && pyr_build(t->pre_img, t->job.left, p.smooth_image)) t->job_err = 1;  // :251
     if (pyr_build(t->pre_dep, t->d_dep, 0)) t->job_err = 1;                   // :252
+    // This frame may become the next keyframe (:258-265): compact its valid-depth pixels into point lists now, on this
+    // stream, beside the Solve — the image pyramid is the one stream A built for the frame (same image, same arithmetic
+    // as the :251 rebuild). If the frame is not promoted the lists are simply overwritten by the next frame's.
+    if (t->cand_lists) {
+      if (hipStreamWaitEvent(t->ctx_b->stream, t->ev_cur_img, 0) != hipSuccess ||
+          lm_build_candidate(t->lm, t->cur_img, t->pre_dep, t->ctx_b->stream, (long)t->frame_id))
+        t->lm->cand_tag = -1;
+    }
     if (depth_job_stats(t->depth, &t->job)) t->job_err = 1;  // completion word AFTER the pyramids: it covers them too
     t->job_stage = 3;
   }
@@ -198,7 +211,12 @@ extern "C" int odo_tracker_init(odo_tracker* t, const float* left, const float* 
   HIP_OK(hipStreamSynchronize(t->ctx_b->stream));
   t->pre_img_on_a = 0;
   t->pre_img->ctx = t->ctx_b;
-  if (tracker_depth_and_pyramids(t, left, right)) return -1;   // :102, :130-131
+  const int cand_keep = t->cand_lists;
+  t->cand_lists = 0;            // frame 0 has no stream-A pyramid: the first Solve builds the keyframe lists itself
+  t->lm->cand_tag = -1;
+  const int init_rc = tracker_depth_and_pyramids(t, left, right);   // :102, :130-131
+  t->cand_lists = cand_keep;
+  if (init_rc) return -1;
   if (depth_finish(t->depth, true)) { fail("Init 0-th frame failed!"); return -1; }  // :103-106
   std::swap(t->kf_img, t->pre_img);                             // :141 first keyframe
   std::swap(t->kf_dep, t->pre_dep);
@@ -257,17 +275,18 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
   HIP_OK(hipSetDevice(t->ctx_a->device));
   t->frame_id++;
   t->pre_img_on_a = p.overlap_depth != 0;
-  if (p.overlap_depth == 2) {
-    // helper thread: the whole stream-B job (ComputeDepth, candidate pyramids, final sync) runs beside this thread
-    t->w_left = left; t->w_right = right;
-    t->w_state.store(1, std::memory_order_release);
-  }
   if (t->prefetched == left) {
     std::swap(t->cur_img, t->next_img);  // :205 — this frame's pyramid was built on stream A at the end of the last call
   } else if (pyr_build(t->cur_img, left, p.smooth_image)) {                            // :205
     return -1;
   }
   t->prefetched = nullptr;
+  if (t->cand_lists) HIP_OK(hipEventRecord(t->ev_cur_img, t->ctx_a->stream));  // before the stream-B job can ask for it
+  if (p.overlap_depth == 2) {
+    // helper thread: the whole stream-B job (ComputeDepth, candidate pyramids, final sync) runs beside this thread
+    t->w_left = left; t->w_right = right;
+    t->w_state.store(1, std::memory_order_release);
+  }
   if (p.overlap_depth == 1) {
     // stream B: ComputeDepth + candidate pyramids, concurrent with the Solve on stream A. The front of the job is
     // enqueued now; its depth-LM launches are issued from the pose LM's wait loop (one host thread feeds both).
@@ -325,6 +344,7 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
     memcpy(t->kf_abs, cur, sizeof(cur));                                               // :260
     t->n_keyframes++;
     new_kf = 1;
+    if (t->cand_lists) lm_adopt_candidate(t->lm, t->kf_img, t->kf_dep, (long)t->frame_id);  // lists built beside the Solve
   }
   odo_lm_reset(t->lm, T, 0.01f);                                                       // :261 / :268 (both branches)
   if (pose_to_keyframe) memcpy(pose_to_keyframe, T, sizeof(T));

@@ -773,6 +773,48 @@ __global__ void __launch_bounds__(kUpdThreads) lm_update_kernel(LmState* __restr
   ODO_STAMP(7);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row-sharing block accumulation of the normal equations (fused LM kernels).
+// Instead of 29 fp64 products per thread followed by a 29 x T transpose through LDS, every thread publishes the ROW of
+// its point — J[6], fl32(J*w)[6], r, fl32(r*w): 14 floats — and 29 x S threads (S sub-lanes per quantity) each sum one
+// quantity over the rows of every S-th point: acc_q = sum_p fma(double(A[p]), double(B[p])), A/B two of the 14 row
+// entries. Same products as odo::accumulate_row (fp32 operands, exact in fp64), a fixed association order, a quarter of
+// the LDS traffic and 47 fewer instructions in the evaluation itself. A point that is skipped publishes a zero row.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRowFloats = 15;  // rows 0..5 J, 6..11 JW, 12 r, 13 rw, 14 valid (1 / 0: its square sums to the count)
+template <int T> struct RowBuf { static constexpr int W = T + 8; static constexpr int kBytes = kRowFloats * W * (int)sizeof(float); };
+
+__device__ __forceinline__ void rows_store(float* __restrict__ rows, int W, int t, const float J[6], float w, float r, bool valid) {
+#pragma unroll
+  for (int a = 0; a < 6; a++) {
+    rows[a * W + t] = valid ? J[a] : 0.0f;
+    rows[(6 + a) * W + t] = valid ? J[a] * w : 0.0f;
+  }
+  rows[12 * W + t] = valid ? r : 0.0f;
+  rows[13 * W + t] = valid ? r * w : 0.0f;
+  rows[14 * W + t] = valid ? 1.0f : 0.0f;
+}
+// Which two rows quantity q multiplies: q < 21: (JW[a], J[b]) for the upper triangle in row-major order;
+// 21..26: (JW[a], r); 27: (rw, r); 28: (valid, valid) = the number of residuals.
+__device__ __forceinline__ void rows_of_quantity(int q, int* rowA, int* rowB) {
+  int a = 0, k = q;
+  while (a < 5 && k >= 6 - a) { k -= 6 - a; a++; }   // q < 21: a = row of the upper triangle, k = b - a
+  if (q < 21) { *rowA = 6 + a; *rowB = a + k; }
+  else if (q < 27) { *rowA = 6 + (q - 21); *rowB = 12; }
+  else if (q == 27) { *rowA = 13; *rowB = 12; }
+  else { *rowA = 14; *rowB = 14; }
+}
+// One round: thread (q, s), t = q * S + s < 29 * S, adds the products of the points s, s + S, ... of the block.
+template <int T, int S>
+__device__ __forceinline__ double rows_accumulate(const float* __restrict__ rows, int rowA, int rowB, int s, double acc) {
+  constexpr int W = RowBuf<T>::W;
+  const float* A = rows + rowA * W + s;
+  const float* B = rows + rowB * W + s;
+#pragma unroll 8
+  for (int i = 0; i < T / S; i++) acc = fma((double)A[i * S], (double)B[i * S], acc);
+  return acc;
+}
+
 // =============================================================================================
 // Fused LM iteration: ONE launch per evaluation.
 // Every block first re-derives, redundantly and bit-identically, the LM step that the previous launch's partial
@@ -992,21 +1034,37 @@ __global__ void __launch_bounds__(kLmBlock) lm_step_kernel(StepArgs a) {
   const int lvl = run ? s_sh.level : 0;
   const StepLevel& L = a.lv[lvl];
   if (run && !publisher && (int)blockIdx.x < L.nblk) {
+    __shared__ float rows_sh[kRowFloats * RowBuf<kLmBlock>::W];  // the block's point rows (see rows_store)
+    constexpr int kS = 8;  // sub-lanes per quantity: 29 x 8 = 232 accumulating threads
+    const int my_q = threadIdx.x / kS, my_s = threadIdx.x % kS;
+    int rowA = 0, rowB = 0;
+    if (my_q < ODO_NACC) rows_of_quantity(my_q, &rowA, &rowB);
     float T[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) T[i] = s_sh.T[i];
-    double acc[ODO_NACC];
-#pragma unroll
-    for (int q = 0; q < ODO_NACC; q++) acc[q] = 0.0;
-    for (int idx = blockIdx.x * kLmBlock + threadIdx.x; idx < L.n; idx += L.nblk * kLmBlock) {
-      const PointK p = load_point(L.pl, idx);
-      int ui, vi;
-      if (!warp_point(p, T, L.k, L.rows, L.cols, &ui, &vi)) continue;
-      float r, J[6];
-      residual_jacobian(p, L.I2, L.rows, L.cols, ui, vi, &r, J);
-      accumulate_row(acc, r, robust_weight(r, a.robust, a.huber_delta, 1.0f), J);
+    double accq = 0.0;
+    const int first = blockIdx.x * kLmBlock;
+    for (int base = first; base < L.n; base += L.nblk * kLmBlock) {  // one round unless the level has > 160 x 256 points
+      const int idx = base + threadIdx.x;
+      float r = 0.0f, w = 0.0f, J[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      bool valid = false;
+      if (idx < L.n) {
+        const PointK p = load_point(L.pl, idx);
+        int ui, vi;
+        if (warp_point(p, T, L.k, L.rows, L.cols, &ui, &vi)) {
+          residual_jacobian(p, L.I2, L.rows, L.cols, ui, vi, &r, J);
+          w = robust_weight(r, a.robust, a.huber_delta, 1.0f);
+          valid = true;
+        }
+      }
+      if (base > first) __syncthreads();  // the previous round's rows have been consumed
+      rows_store(rows_sh, RowBuf<kLmBlock>::W, threadIdx.x, J, w, r, valid);
+      __syncthreads();
+      if (my_q < ODO_NACC) accq = rows_accumulate<kLmBlock, kS>(rows_sh, rowA, rowB, my_s, accq);
     }
-    block_reduce_acc(acc, a.part_out + (size_t)blockIdx.x * ODO_NACC);
+#pragma unroll
+    for (int o = kS / 2; o > 0; o >>= 1) accq += __shfl_xor(accq, o, kS);
+    if (my_q < ODO_NACC && my_s == 0) a.part_out[(size_t)blockIdx.x * ODO_NACC + my_q] = accq;
   }
   if (publisher) {
     if (threadIdx.x == 0 && run) { s_sh.pending = 1; s_sh.pending_nblk = L.nblk; }
@@ -1022,31 +1080,9 @@ __global__ void __launch_bounds__(kLmBlock) lm_step_kernel(StepArgs a) {
 // >= min_level: no launch, no global partials, no state reload between iterations. It hands over to the generic step
 // launches with the next level already begun.
 constexpr int kCoarseBlock = 512;
-constexpr int kCoarseLdsBytes = ODO_NACC * (kCoarseBlock + 8) * (int)sizeof(double);  // [29][512 + kRedPad] doubles
+constexpr int kCoarseLdsBytes = kRowFloats * (kCoarseBlock + 8) * (int)sizeof(float);  // [14][512 + 8] floats: point rows
 constexpr int kCoarseMaxPoints = 1024;  // levels with more points go to the multi-block step kernel (measured: a 512-thread
                                         // workgroup walking ~2000 points four per thread is no faster than seven blocks)
-
-// 29 sums of a 512-thread block into LDS (out) in one round through a 118 KB transpose buffer (dynamic LDS: gfx950
-// gives a workgroup up to 160 KB; two rounds through 62 KB took 5 100 cycles per iteration, this takes 3 400).
-__device__ __forceinline__ void block_reduce_acc_coarse(const double acc[ODO_NACC], double* red /* [29][520] */, double* out) {
-  constexpr int W = kCoarseBlock + kRedPad;
-  const int t = threadIdx.x;
-#pragma unroll
-  for (int q = 0; q < ODO_NACC; q++) red[q * W + t] = acc[q];
-  __syncthreads();
-  if (t < ODO_NACC * 16) {  // 16 lanes per quantity: 32 rows each, then a 16-wide butterfly
-    const int q = t >> 4, s = t & 15;
-    double v = 0.0;
-#pragma unroll 8
-    for (int i = 0; i < kCoarseBlock / 16; i++) v += red[q * W + i * 16 + s];
-    v += __shfl_xor(v, 8, 16);
-    v += __shfl_xor(v, 4, 16);
-    v += __shfl_xor(v, 2, 16);
-    v += __shfl_xor(v, 1, 16);
-    if (s == 0) out[q] = v;
-  }
-  __syncthreads();
-}
 
 __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int min_level) {
   // The pose LM is the latency-critical chain of a frame, while the depth stream floods the CUs with throughput work
@@ -1055,8 +1091,16 @@ __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int
   __shared__ LmState s_sh;
   extern __shared__ double red_sh[];  // kCoarseLdsBytes: reduction buffer; its head doubles as the fold scratch
   __shared__ double acc_sh[32];
+  // The level table moves to LDS (static-index copy): every later access indexes it with the level read from the state,
+  // and a dynamic index into the by-value kernel argument makes the compiler mirror all of `a` in scratch memory.
+  __shared__ StepLevel lv_sh[ODO_MAX_LEVELS_K];
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int l = 0; l < ODO_MAX_LEVELS_K; l++) lv_sh[l] = a.lv[l];
+  }
+  __syncthreads();
   // state in (or initialised), a pending evaluation of an earlier launch consumed, pyramid walk started
-  lm_fused_prologue(a.st_in, a.part_in, a.lv, a.n_levels, a.lambda0, a.precision, s_sh, red_sh, acc_sh, a.trace, a.cost_stat, true,
+  lm_fused_prologue(a.st_in, a.part_in, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, red_sh, acc_sh, a.trace, a.cost_stat, true,
                     a.first_of_solve ? a.init : nullptr);
   if (a.dbg && threadIdx.x == 0 && a.seq < 56) a.dbg[16 + 2 * a.seq] = wall_clock64();
   unsigned long long c_eval = 0, c_red = 0, c_sm = 0, c_it = 0, c_last = a.dbg ? __builtin_readcyclecounter() : 0;
@@ -1064,33 +1108,48 @@ __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int
   auto lap = [&](unsigned long long& sum) {
     if (a.dbg) { const unsigned long long now = __builtin_readcyclecounter(); sum += now - c_last; c_last = now; }
   };
+  float* rows_sh = (float*)red_sh;  // [14][512 + 8] floats
+  constexpr int kS = 16;            // sub-lanes per quantity: 29 x 16 = 464 accumulating threads
+  const int my_q = threadIdx.x / kS, my_s = threadIdx.x % kS;
+  int rowA = 0, rowB = 0;
+  if (my_q < ODO_NACC) rows_of_quantity(my_q, &rowA, &rowB);
   for (int guard = 0; guard < 4096; guard++) {
     const bool run = (s_sh.active != 0 && s_sh.status == 0 && s_sh.level >= min_level);  // block-uniform
     if (!run) break;
     c_it++;
-    const StepLevel& L = a.lv[s_sh.level];
+    const StepLevel& L = lv_sh[s_sh.level];
     float T[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) T[i] = s_sh.T[i];
-    double acc[ODO_NACC];
-#pragma unroll
-    for (int q = 0; q < ODO_NACC; q++) acc[q] = 0.0;
-    for (int idx = threadIdx.x; idx < L.n; idx += kCoarseBlock) {
-      const PointK p = load_point(L.pl, idx);
-      int ui, vi;
-      if (!warp_point(p, T, L.k, L.rows, L.cols, &ui, &vi)) continue;
-      float r, J[6];
-      residual_jacobian(p, L.I2, L.rows, L.cols, ui, vi, &r, J);
-      accumulate_row(acc, r, robust_weight(r, a.robust, a.huber_delta, 1.0f), J);
-    }
+    double accq = 0.0;
     // (Keeping each thread's points in registers across iterations and staging the 29 KB level image in LDS was
-    // measured: no faster. With 8 waves on one CU the evaluation is VALU-issue bound — ~300 instructions per point at two
-    // waves per SIMD, ~4 000 cycles — not latency bound.)
-    __syncthreads();  // everyone has read s_sh.T before the state machine rewrites it
-    lap(c_eval);
-    block_reduce_acc_coarse(acc, red_sh, acc_sh);
+    // measured: no faster. With 8 waves on one CU the evaluation is VALU-issue bound, not latency bound.)
+    for (int base = 0; base < L.n; base += kCoarseBlock) {  // one round per 512 points (kCoarseMaxPoints: two)
+      const int idx = base + threadIdx.x;
+      float r = 0.0f, w = 0.0f, J[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      bool valid = false;
+      if (idx < L.n) {
+        const PointK p = load_point(L.pl, idx);
+        int ui, vi;
+        if (warp_point(p, T, L.k, L.rows, L.cols, &ui, &vi)) {
+          residual_jacobian(p, L.I2, L.rows, L.cols, ui, vi, &r, J);
+          w = robust_weight(r, a.robust, a.huber_delta, 1.0f);
+          valid = true;
+        }
+      }
+      if (base > 0) __syncthreads();  // the previous round's rows have been consumed
+      rows_store(rows_sh, RowBuf<kCoarseBlock>::W, threadIdx.x, J, w, r, valid);
+      __syncthreads();  // rows visible (and, first round, everyone has read s_sh.T)
+      if (base == 0) lap(c_eval);
+      if (my_q < ODO_NACC) accq = rows_accumulate<kCoarseBlock, kS>(rows_sh, rowA, rowB, my_s, accq);
+    }
+    if (L.n <= 0) { __syncthreads(); lap(c_eval); }
+#pragma unroll
+    for (int o = kS / 2; o > 0; o >>= 1) accq += __shfl_xor(accq, o, kS);
+    if (my_q < ODO_NACC && my_s == 0) acc_sh[my_q] = accq;
+    __syncthreads();
     lap(c_red);
-    lm_state_machine(true, a.lv, a.n_levels, a.lambda0, a.precision, s_sh, acc_sh, a.trace, a.cost_stat, true);
+    lm_state_machine(true, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, acc_sh, a.trace, a.cost_stat, true);
     lap(c_sm);
   }
   lm_fused_publish(s_sh, a.st_out, a.host_prog, a.seq, a.token, a.cost_stat, a.out, a.done_flag);

@@ -200,7 +200,9 @@ typedef struct {
 
 int odo_tracker_default_params(odo_tracker_params* p); /* the runner's constants for KITTI 1241x376 */
 int odo_tracker_create(int device, const odo_tracker_params* p, odo_tracker** out);
-/* Frame 0 (ref: :95-145): ComputeDepth, pyramids, first keyframe with absolute pose abs_pose0. */
+/* Frame 0 (ref: :95-145): ComputeDepth, pyramids, first keyframe with absolute pose abs_pose0. May be called again at
+ * any time to start a new sequence on the same tracker: it drains both streams first and the tracker then behaves
+ * exactly like a freshly created one. */
 int odo_tracker_init(odo_tracker* t, const float* left_dev, const float* right_dev, const float abs_pose0_colmajor[16]);
 /* One iteration of the frame loop (ref: :198-271). Returns 0, or -1 when ComputeDepth failed (the runner
  * breaks out of its loop there, ref: :230-232). A failed Solve is NOT an error (the runner carries on with the

@@ -1251,8 +1251,8 @@ constexpr int kSelMaxElems = 4096;
 __global__ void __launch_bounds__(kSelThreads) depth_select_kernel(const float* __restrict__ L, int rows, int cols, int bnd,
                                                                     float grad_th, uint8_t* __restrict__ val,
                                                                     uint32_t* __restrict__ pts, int* __restrict__ cnt) {
-  __shared__ float key[kSelMaxElems];
   __shared__ float mag[kSelMaxElems];
+  __shared__ int bins[16][4];  // one 4-bin digit histogram per radix pass (all zeroed up front: one barrier per pass)
   __shared__ int wave_tot[kSelThreads / kWave];
   __shared__ int base_sh;
   const int t = threadIdx.x;
@@ -1264,34 +1264,64 @@ __global__ void __launch_bounds__(kSelThreads) depth_select_kernel(const float* 
     return;
   }
   const int sy = bnd + (b / 32) * bh, sx = bnd + (b % 32) * bw;
-  int np2 = 1;
-  while (np2 < bsz) np2 <<= 1;
-  for (int e = t; e < np2; e += kSelThreads) {
-    float m = __builtin_inff();
+  if (t < 16 * 4) (&bins[0][0])[t] = 0;
+  constexpr int kPer = kSelMaxElems / kSelThreads;  // keys per thread (1 at KITTI size: 38 x 23 = 874 per block)
+  unsigned keys[kPer];
+#pragma unroll
+  for (int u = 0; u < kPer; u++) {
+    const int e = t + u * kSelThreads;
+    keys[u] = 0xffffffffu;  // padding sorts last
     if (e < bsz) {
       const int y = sy + e / bw, x = sx + e % bw;
       const float gx = 0.5f * (L[(size_t)y * cols + x + 1] - L[(size_t)y * cols + x - 1]);
       const float gy = 0.5f * (L[(size_t)(y + 1) * cols + x] - L[(size_t)(y - 1) * cols + x]);
-      m = sqrtf(gx * gx + gy * gy);  // :321
+      const float m = sqrtf(gx * gx + gy * gy);  // :321
       mag[e] = m;
+      keys[u] = __float_as_uint(m);  // m >= +0: the bit pattern orders like the value
     }
-    key[e] = m;
   }
   __syncthreads();
-  for (int k = 2; k <= np2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = t; i < np2; i += kSelThreads) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const float a = key[i], c = key[ixj];
-          const bool up = ((i & k) == 0);
-          if ((a > c) == up) { key[i] = c; key[ixj] = a; }
+  // Block median = the element nth_element(size / 2) leaves at that position (:328) = the k-th smallest, k = bsz / 2:
+  // MSB-first radix select, 2 bits per pass. Each wave counts the four values of the current digit among the keys that
+  // still match the prefix with four ballots, four lanes add the wave's counts to the pass's bins, and after one barrier
+  // every thread reads the four bins and narrows (prefix, k) identically. With 32 waves resident per CU the selection is
+  // instruction-issue bound, so the digit is kept narrow: 16 passes x 4 ballots per wave (measured: a full bitonic sort
+  // of the 1024 keys, or 4-bit digits with 16 ballots per pass, both cost ~16 us of the kernel's 22).
+  unsigned prefix = 0u, pmask = 0u;
+  int kth = bsz / 2;
+  {
+    const int lane = t & 63;
+#pragma unroll
+    for (int pass = 0; pass < 16; pass++) {
+      const int shift = 30 - 2 * pass;
+      int mine = 0;  // lane d < 4 ends up with this wave's count of digit d
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        int c = 0;
+#pragma unroll
+        for (int u = 0; u < kPer; u++) {
+          if (u * kSelThreads >= bsz) break;  // block-uniform: no keys in this round
+          const bool hit = ((keys[u] & pmask) == prefix) && (((keys[u] >> shift) & 3u) == (unsigned)d);
+          c += __popcll(__ballot(hit));
         }
+        if (lane == d) mine = c;
       }
+      if (lane < 4 && mine) atomicAdd(&bins[pass][lane], mine);
       __syncthreads();
+      int d = 0, below = 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int c = bins[pass][q];
+        if (below + c <= kth && d == q) { below += c; d = q + 1; }
+      }
+      // d = first digit whose cumulative count exceeds kth (d < 4 because the matching keys number > kth)
+      kth -= below;
+      prefix |= (unsigned)d << shift;
+      pmask |= 3u << shift;
     }
   }
-  const float th = key[bsz / 2] + grad_th;  // :328-329 (nth_element at size/2)
+  const float median = __uint_as_float(prefix);
+  const float th = median + grad_th;  // :328-329
   if (t == 0) base_sh = 0;
   __syncthreads();
   const int lane = t & 63, wv = t >> 6;

@@ -232,6 +232,7 @@ def main():
     ap.add_argument("--distinct-sequences", action="store_true",
                     help="rank r tracks synthetic sequence r instead of every rank tracking sequence 0")
     args = ap.parse_args()
+    args.unique_frames = max(args.unique_frames, 2)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

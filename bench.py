@@ -217,8 +217,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--unique-frames", type=int, default=64,
-                    help="length of the synthetic forward drive; the steps are passes over it (frame 0 re-initialises)")
+    ap.add_argument("--unique-frames", type=int, default=200,
+                    help="length of the synthetic forward drive (configs[1]: the first 200 frames of a sequence); the steps "
+                         "are passes over it (frame 0 re-initialises the tracker)")
     ap.add_argument("--gather-every", type=int, default=8)
     ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-overlap", action="store_true", help="run ComputeDepth after Solve on one stream")
@@ -381,17 +382,26 @@ def main():
             dev2 = [(trk2.upload_frame(l), trk2.upload_frame(r)) for l, r in zip(seq["left"], seq["right"])]
             trk2.init(*dev2[0])
             dmax = 0.0
+            gpu_poses = []
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
             for j, i in enumerate(order[:n]):
                 if begins_pass(order, j):
                     trk2.init(*dev2[0])
-                g = trk2.track(*dev2[i])
-                dmax = max(dmax, float(np.abs(g["pose_to_keyframe"].astype(np.float64) - cpu_poses[j]["pose_to_keyframe"]).max()))
+                gpu_poses.append(trk2.track(*dev2[i])["pose_to_keyframe"])
+            torch.cuda.synchronize()
+            gpu_same_fps = n / (time.perf_counter() - tg)   # the GPU on exactly the frames the CPU sample covers
+            for j in range(n):
+                dmax = max(dmax, float(np.abs(gpu_poses[j].astype(np.float64) - cpu_poses[j]["pose_to_keyframe"]).max()))
             trk2.close()
             out["cpu_baseline"] = dict(value=round(cpu_fps, 3), unit="frames/s", cores=1, kind="port",
                                        sample=f"first {n} frames of the same sequence, oracle runner "
                                               f"(pyramids + Solve + ComputeDepth per frame), {cpu_dt:.1f} s")
             out["pose_max_abs_delta_vs_oracle"] = dmax
-            out["speedup_vs_cpu"] = round(fps / cpu_fps, 1)
+            # like for like: the start of a drive is its most expensive stretch (40-70 LM evaluations per frame against
+            # ~25 later), so the ratio is taken on the same frames, not against the whole-run rate
+            out["cpu_baseline"]["gpu_same_sample"] = dict(value=round(gpu_same_fps, 1), unit="frames/s")
+            out["speedup_vs_cpu"] = round(gpu_same_fps / cpu_fps, 1)
             # the same frames again with the LM pass in the reference's own shape (materialised N x 6 Jacobian, per-pixel
             # pow / GetCxLevel, separate fp32 product passes): timing only, fewer frames
             from oracle import oracle as _orc

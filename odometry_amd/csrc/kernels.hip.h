@@ -394,37 +394,10 @@ __global__ void __launch_bounds__(256) kf_count_kernel(KfLevels kl, int* __restr
   if (threadIdx.x == 0) rowcnt[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-// Pass 2: exclusive scan of the row counts inside each level (one block); npts[l] = points of level l.
-__global__ void __launch_bounds__(1024) kf_scan_kernel(KfLevels kl, const int* __restrict__ rowcnt, int* __restrict__ rowoff,
-                                                       int* __restrict__ npts) {
-  __shared__ int sh[1024];
-  const int t = threadIdx.x;
-  for (int l = 0; l < kl.n_levels; l++) {
-    const int r0 = kl.row_base[l], nr = kl.row_base[l + 1] - r0;
-    int carry = 0;
-    for (int c0 = 0; c0 < nr; c0 += 1024) {
-      const int i = c0 + t;
-      const int v = (i < nr) ? rowcnt[r0 + i] : 0;
-      sh[t] = v;
-      __syncthreads();
-      for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan
-        const int add = (t >= o) ? sh[t - o] : 0;
-        __syncthreads();
-        sh[t] += add;
-        __syncthreads();
-      }
-      if (i < nr) rowoff[r0 + i] = carry + sh[t] - v;
-      const int tot = sh[1023];
-      __syncthreads();
-      carry += tot;
-    }
-    if (t == 0) npts[l] = carry;
-  }
-}
-
-// Pass 3: one block per interior row: ordered compaction (ballot prefix) + the per-point constants.
+// Pass 2: one block per interior row: its offset from the row counts above it, ordered compaction (ballot prefix), the
+// per-point constants; the last row of a level writes the level's total.
 __global__ void __launch_bounds__(256) kf_fill_kernel(KfLevels kl, float f0, float cx0, float cy0,
-                                                      const int* __restrict__ rowoff, PointList pl0, PointList pl1,
+                                                      const int* __restrict__ rowcnt, int* __restrict__ npts, PointList pl0, PointList pl1,
                                                       PointList pl2, PointList pl3, PointList pl4, PointList pl5,
                                                       PointList pl6, PointList pl7) {
   __shared__ int wave_tot[4];
@@ -437,8 +410,17 @@ __global__ void __launch_bounds__(256) kf_fill_kernel(KfLevels kl, float f0, flo
   const float* D = kl.D1[l] + (size_t)y * cols;
   const float* I = kl.I1[l] + (size_t)y * cols;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  if (t == 0) base_sh = rowoff[blockIdx.x];
-  __syncthreads();
+  {  // this row's offset = number of points in the rows of the level above it (fixed order: exact integer sums)
+    const int r0 = kl.row_base[l], my = blockIdx.x - r0;
+    int part = 0;
+    for (int i = t; i < my; i += 256) part += rowcnt[r0 + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if (lane == 0) wave_tot[wv] = part;
+    __syncthreads();
+    if (t == 0) base_sh = (wave_tot[0] + wave_tot[1]) + (wave_tot[2] + wave_tot[3]);
+    __syncthreads();
+  }
   for (int x0 = 4; x0 < cols - 4; x0 += 256) {
     const int x = x0 + t;
     float d = 0.0f;
@@ -461,6 +443,8 @@ __global__ void __launch_bounds__(256) kf_fill_kernel(KfLevels kl, float f0, flo
     if (t == 0) base_sh += (wave_tot[0] + wave_tot[1]) + (wave_tot[2] + wave_tot[3]);
     __syncthreads();
   }
+  // the last row of a level knows the level's total
+  if (t == 0 && (int)blockIdx.x == kl.row_base[l + 1] - 1) npts[l] = base_sh;
 }
 
 __device__ __forceinline__ PointK load_point(const PointList& pl, int i) {

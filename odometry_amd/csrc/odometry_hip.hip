@@ -306,13 +306,13 @@ struct odo_lm {
   int npts[ODO_MAX_LEVELS];
   int use_list[ODO_MAX_LEVELS];
   unsigned long long kf_img_ver, kf_dep_ver;
-  int* d_rowcnt; int* d_rowoff; int* d_npts; int* h_npts; int rows_cap;
+  int* d_rowcnt; int* d_npts; int* h_npts; int rows_cap;
   // A second, identical set of list buffers for the keyframe CANDIDATE of the frame being tracked: the tracker fills it on
   // its depth stream every frame (lm_build_candidate), off the Solve's critical path; when the candidate becomes the
-  // keyframe the two sets trade places (lm_adopt_candidate) instead of three launches + a read-back in front of the Solve.
+  // keyframe the two sets trade places (lm_adopt_candidate) instead of list-building launches + a read-back in front of the Solve.
   PointList cand_pl[ODO_MAX_LEVELS];
   size_t cand_pl_cap[ODO_MAX_LEVELS];
-  int* cand_d_rowcnt; int* cand_d_rowoff; int* cand_d_npts; int* cand_h_npts; int cand_rows_cap;
+  int* cand_d_rowcnt; int* cand_d_npts; int* cand_h_npts; int cand_rows_cap;
   long cand_tag;   // caller's tag of the candidate (frame id), -1 = none
   // optional per-launch HIP-event timing of the evaluation kernels (bench.py roofline leg)
   int ev_on;
@@ -395,7 +395,7 @@ extern "C" int odo_lm_destroy(odo_lm* m) {
   if (!m) return 0;
   (void)hipStreamSynchronize(m->ctx->stream);
   void* dv[] = {m->d_state, m->d_partials, m->d_init, m->d_out, m->d_trace, m->d_scale, m->d_res,
-                m->d_rowcnt, m->d_rowoff, m->d_npts, m->cand_d_rowcnt, m->cand_d_rowoff, m->cand_d_npts};
+                m->d_rowcnt, m->d_npts, m->cand_d_rowcnt, m->cand_d_npts};
   for (void* q : dv) if (q) (void)hipFree(q);
   for (int l = 0; l < ODO_MAX_LEVELS; l++) {
     void* pv[] = {m->pl[l].a, m->pl[l].b, m->pl[l].c, m->pl[l].d, m->cand_pl[l].a, m->cand_pl[l].b, m->cand_pl[l].c, m->cand_pl[l].d};
@@ -450,10 +450,10 @@ static int lm_ensure_res(odo_lm* m, size_t n) {
   return 0;
 }
 
-// Enqueues the three launches that compact the keyframe's valid-depth pixels of every level into point lists (and the
+// Enqueues the two launches that compact the keyframe's valid-depth pixels of every level into point lists (and the
 // 32-byte read-back of the per-level counts) on `s`. img supplies I1, dep the inverse depths; both pyramids have the same
 // geometry. Buffers grow on demand (only the first keyframes of a run allocate).
-static int lm_enqueue_lists(odo_lm* m, PointList* pl, size_t* pl_cap, int*& d_rowcnt, int*& d_rowoff, int& rows_cap, int* d_npts,
+static int lm_enqueue_lists(odo_lm* m, PointList* pl, size_t* pl_cap, int*& d_rowcnt, int& rows_cap, int* d_npts,
                             int* h_npts, const odo_pyr* img, const odo_pyr* dep, hipStream_t s, int* rows_total_out) {
   KfLevels kl;
   memset(&kl, 0, sizeof(kl));
@@ -483,18 +483,16 @@ static int lm_enqueue_lists(odo_lm* m, PointList* pl, size_t* pl_cap, int*& d_ro
   if (rows_total > rows_cap) {
     HIP_OK(hipStreamSynchronize(s));
     if (d_rowcnt) HIP_OK(hipFree(d_rowcnt));
-    if (d_rowoff) HIP_OK(hipFree(d_rowoff));
-    d_rowcnt = d_rowoff = nullptr;
+    d_rowcnt = nullptr;
     HIP_OK(hipMalloc((void**)&d_rowcnt, sizeof(int) * rows_total));
-    HIP_OK(hipMalloc((void**)&d_rowoff, sizeof(int) * rows_total));
     rows_cap = rows_total;
   }
   *rows_total_out = rows_total;
   if (rows_total > 0) {
+    HIP_OK(hipMemsetAsync(d_npts, 0, sizeof(int) * ODO_MAX_LEVELS, s));  // levels without interior rows stay at 0
     hipLaunchKernelGGL(kf_count_kernel, dim3(rows_total), dim3(256), 0, s, kl, d_rowcnt);
-    hipLaunchKernelGGL(kf_scan_kernel, dim3(1), dim3(1024), 0, s, kl, d_rowcnt, d_rowoff, d_npts);
-    hipLaunchKernelGGL(kf_fill_kernel, dim3(rows_total), dim3(256), 0, s, kl, m->K.f0, m->K.cx0, m->K.cy0, d_rowoff,
-                       pl[0], pl[1], pl[2], pl[3], pl[4], pl[5], pl[6], pl[7]);
+    hipLaunchKernelGGL(kf_fill_kernel, dim3(rows_total), dim3(256), 0, s, kl, m->K.f0, m->K.cx0, m->K.cy0,
+                       (const int*)d_rowcnt, d_npts, pl[0], pl[1], pl[2], pl[3], pl[4], pl[5], pl[6], pl[7]);
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpyAsync(h_npts, d_npts, sizeof(int) * ODO_MAX_LEVELS, hipMemcpyDeviceToHost, s));
   }
@@ -512,7 +510,7 @@ static void lm_take_counts(odo_lm* m, const int* h_npts, const odo_pyr* img, int
   }
 }
 
-// Builds (or reuses) the keyframe point lists for the pyramids of this Solve. Three launches over all levels +
+// Builds (or reuses) the keyframe point lists for the pyramids of this Solve. Two launches over all levels +
 // a 32-byte read-back of the per-level counts; done once per keyframe (the cache is keyed on the pyramids' build
 // versions). Levels where more than half of the interior carries depth keep the dense scan.
 static int lm_prepare_keyframe(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep) {
@@ -520,7 +518,7 @@ static int lm_prepare_keyframe(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* 
   if (m->kf_img_ver == kf_img->version && m->kf_dep_ver == kf_dep->version) return 0;
   hipStream_t s = m->ctx->stream;
   int rows_total = 0;
-  if (lm_enqueue_lists(m, m->pl, m->pl_cap, m->d_rowcnt, m->d_rowoff, m->rows_cap, m->d_npts, m->h_npts, kf_img, kf_dep, s,
+  if (lm_enqueue_lists(m, m->pl, m->pl_cap, m->d_rowcnt, m->rows_cap, m->d_npts, m->h_npts, kf_img, kf_dep, s,
                        &rows_total)) return -1;
   if (rows_total > 0) HIP_OK(hipStreamSynchronize(s));
   lm_take_counts(m, m->h_npts, kf_img, rows_total);
@@ -535,7 +533,7 @@ static int lm_build_candidate(odo_lm* m, const odo_pyr* img, const odo_pyr* dep,
   m->cand_tag = -1;
   if (m->mode == 1) return 0;
   int rows_total = 0;
-  if (lm_enqueue_lists(m, m->cand_pl, m->cand_pl_cap, m->cand_d_rowcnt, m->cand_d_rowoff, m->cand_rows_cap, m->cand_d_npts,
+  if (lm_enqueue_lists(m, m->cand_pl, m->cand_pl_cap, m->cand_d_rowcnt, m->cand_rows_cap, m->cand_d_npts,
                        m->cand_h_npts, img, dep, s, &rows_total)) return -1;
   if (rows_total > 0) m->cand_tag = tag;
   return 0;
@@ -547,7 +545,7 @@ static int lm_build_candidate(odo_lm* m, const odo_pyr* img, const odo_pyr* dep,
 static int lm_adopt_candidate(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, long tag) {
   if (m->mode == 1 || m->cand_tag < 0 || m->cand_tag != tag) return 1;
   for (int l = 0; l < ODO_MAX_LEVELS; l++) { std::swap(m->pl[l], m->cand_pl[l]); std::swap(m->pl_cap[l], m->cand_pl_cap[l]); }
-  std::swap(m->d_rowcnt, m->cand_d_rowcnt); std::swap(m->d_rowoff, m->cand_d_rowoff); std::swap(m->rows_cap, m->cand_rows_cap);
+  std::swap(m->d_rowcnt, m->cand_d_rowcnt); std::swap(m->rows_cap, m->cand_rows_cap);
   std::swap(m->d_npts, m->cand_d_npts); std::swap(m->h_npts, m->cand_h_npts);
   int rows_total = 0;
   for (int l = 0; l < m->n_levels; l++) {

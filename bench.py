@@ -220,7 +220,7 @@ def main():
     ap.add_argument("--unique-frames", type=int, default=200,
                     help="length of the synthetic forward drive (configs[1]: the first 200 frames of a sequence); the steps "
                          "are passes over it (frame 0 re-initialises the tracker)")
-    ap.add_argument("--gather-every", type=int, default=8)
+    ap.add_argument("--gather-every", type=int, default=32, help="frames per RCCL pose all_gather (latency-insensitive: results only)")
     ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-overlap", action="store_true", help="run ComputeDepth after Solve on one stream")
     ap.add_argument("--no-prefetch", action="store_true", help="build each frame's image pyramid inside its own step")

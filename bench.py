@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """bench.py — tracked frames/s of the photometric-LM hot path on N MI355X (one process per GPU).
 
-Workload (BASELINE.json configs[1]): a synthetic KITTI-shaped stereo sequence, 1241x376, 4-level pyramid,
-semi-dense points, fp32, runner parameters (ref: run_odometry_kitti_offline.cpp:58-88). One "step" = one
+Workload (BASELINE.json configs[1]): a synthetic KITTI-shaped forward drive of --unique-frames (200) stereo pairs,
+1241x376, 4-level pyramid, semi-dense points, fp32, runner parameters (ref: run_odometry_kitti_offline.cpp:58-88),
+replayed pass after pass (the tracker is re-initialised on frame 0 at the start of each pass). One "step" = one
 iteration of the runner's frame loop (ref: :198-271) on one stereo pair that is already resident in HBM:
 ImagePyramid(cur) -> Solve against the keyframe -> pose chaining -> ComputeDepth -> rebuild the frame's
-pyramids -> keyframe test -> Reset. With N > 1 every rank tracks its own sequence (seed = rank; the path
-shards by sequence, no data-path collective) and the 6-DoF results are gathered over RCCL every
---gather-every frames; `value` = frames tracked by all ranks / max-over-ranks wall time.
+pyramids -> keyframe test -> Reset. With N > 1 every rank tracks its own copy of the sequence (the path shards by
+sequence, no data-path collective; --distinct-sequences gives rank r sequence r) and the 6-DoF results are gathered
+over RCCL every --gather-every frames, asynchronously; `value` = frames tracked by all ranks / max-over-ranks wall time.
 
 Prints ONE JSON line on rank 0.
 """

@@ -146,3 +146,38 @@ def test_pyramid_structural_identities_1080p(api):
     ip = api.ImagePyramid(4, const, True)
     for k in range(4):
         assert np.all(ip.GetPyramidImage(k) == 137.0)
+
+
+def test_candidate_lists_and_priority_stream_change_nothing(api):
+    """The keyframe-candidate point lists built on the depth stream (adopted on a keyframe switch) and the high-priority
+    LM stream are scheduling devices only: a tracker without them produces bit-identical poses and keyframe decisions over
+    a stretch of the forward drive that switches keyframes repeatedly."""
+    import os
+    import bench
+    seq = bench.render_sequence(40, 0, 8)
+    order = bench.frame_order(40, 39)
+
+    def run(env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            trk = api.Tracker(0)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        dev = [(trk.upload_frame(l), trk.upload_frame(r)) for l, r in zip(seq["left"], seq["right"])]
+        trk.init(*dev[0])
+        kf, ab, flags = np.zeros((39, 16), np.float32), np.zeros((39, 16), np.float32), []
+        for k, i in enumerate(order):
+            flags.append(trk.track_into(dev[i][0], dev[i][1], kf[k], ab[k]))
+        trk.close()
+        return kf, ab, flags
+
+    base = run({})
+    assert sum(base[2]) >= 5           # the stretch really promotes keyframes
+    for env in ({"ODO_NO_CAND_LISTS": "1"}, {"ODO_LM_PRIORITY": "0"}):
+        other = run(env)
+        assert np.array_equal(base[0], other[0]) and np.array_equal(base[1], other[1]) and base[2] == other[2]

@@ -395,7 +395,16 @@ def main():
             for j in range(n):
                 dmax = max(dmax, float(np.abs(gpu_poses[j].astype(np.float64) - cpu_poses[j]["pose_to_keyframe"]).max()))
             trk2.close()
+            cpu_model = ""
+            try:
+                for ln in open("/proc/cpuinfo"):
+                    if ln.startswith("model name"):
+                        cpu_model = ln.split(":", 1)[1].strip()
+                        break
+            except OSError:
+                pass
             out["cpu_baseline"] = dict(value=round(cpu_fps, 3), unit="frames/s", cores=1, kind="port",
+                                       host_cpu=cpu_model, host_logical_cpus=os.cpu_count(),
                                        sample=f"first {n} frames of the same sequence, oracle runner "
                                               f"(pyramids + Solve + ComputeDepth per frame), {cpu_dt:.1f} s")
             out["pose_max_abs_delta_vs_oracle"] = dmax

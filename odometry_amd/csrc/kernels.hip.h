@@ -352,6 +352,10 @@ __global__ void __launch_bounds__(kLmBlock) lm_residual_dense_kernel(LevelView v
   block_reduce_acc_2r(acc, partials + (size_t)blockIdx.x * ODO_NACC);
 }
 
+}  // namespace odo
+#include "dense.hip.h"
+namespace odo {
+
 // ---------------------------------------------------------------------------------------------
 // Semi-dense keyframe point lists. Everything of a residual that does not depend on the pose (back-projected
 // point, keyframe intensity, geometric Jacobian at the un-warped point; ref: src/lm_optimizer.cpp:193-234) is

@@ -64,29 +64,38 @@ struct PointK {
 
 ODO_HD bool depth_valid(float d) { return !(fabsf(d - 0.0f) < 0.01f); }  // ref: lm_optimizer.cpp:193
 
-ODO_HD PointK make_point(int x, int y, float inv_depth, float i1, const LevelK& k) {
-  PointK p;
+// make_point in two halves (the dense evaluation kernel runs them at different times): the back-projected point ...
+ODO_HD void point_xyz(int x, int y, float inv_depth, const LevelK& k, float* X, float* Y, float* Z) {
   const float z = 1.0f / inv_depth;                                   // :198
-  // The reference evaluates these three quotients in double (std::pow returns double) and rounds to float.
+  // The reference evaluates these quotients in double (std::pow returns double) and rounds to float.
   // Both operands are exactly representable in fp32 (fl = f0 / 2^level), and a correctly rounded fp64 quotient
   // of two fp32 values rounds to the correctly rounded fp32 quotient (53 >= 2*24 + 2), so the IEEE fp32 divide
   // below is bit-identical and four times cheaper on the device.
   const float flf = (float)k.fl;
-  p.X = (z * ((float)x - k.cx)) / flf;                                // h:35
-  p.Y = (z * ((float)y - k.cy)) / flf;                                // h:36
-  p.Z = z;
+  *X = (z * ((float)x - k.cx)) / flf;                                 // h:35
+  *Y = (z * ((float)y - k.cy)) / flf;                                 // h:36
+  *Z = z;
+}
+// ... and the geometric Jacobian at the un-warped point, from p->X, p->Y, p->Z.
+ODO_HD void point_jacobian(PointK* p, const LevelK& k) {
+  const float flf = (float)k.fl;
+  const float fx_z = flf / p->Z;                                      // :223
+  const float xy = p->X * p->Y, xx = p->X * p->X, yy = p->Y * p->Y, zz = p->Z * p->Z;
+  p->fx_z = fx_z;
+  p->jw02 = (-fx_z * p->X) / p->Z;                                    // :232
+  p->jw03 = (-fx_z * xy) / p->Z;
+  p->jw04 = (float)(k.fl * (1.0 + (double)(xx / zz)));
+  p->jw05 = -fx_z * p->Y;
+  p->jw12 = (-fx_z * p->Y) / p->Z;                                    // :233
+  p->jw13 = (float)(-k.fl * (1.0 + (double)(yy / zz)));
+  p->jw14 = -p->jw03;  // = (fx_z * xy) / Z (ref :233): IEEE negation commutes with multiply and divide, bit for bit
+  p->jw15 = fx_z * p->X;
+}
+ODO_HD PointK make_point(int x, int y, float inv_depth, float i1, const LevelK& k) {
+  PointK p;
+  point_xyz(x, y, inv_depth, k, &p.X, &p.Y, &p.Z);
   p.i1 = i1;
-  const float fx_z = flf / p.Z;                                       // :223
-  const float xy = p.X * p.Y, xx = p.X * p.X, yy = p.Y * p.Y, zz = p.Z * p.Z;
-  p.fx_z = fx_z;
-  p.jw02 = (-fx_z * p.X) / p.Z;                                       // :232
-  p.jw03 = (-fx_z * xy) / p.Z;
-  p.jw04 = (float)(k.fl * (1.0 + (double)(xx / zz)));
-  p.jw05 = -fx_z * p.Y;
-  p.jw12 = (-fx_z * p.Y) / p.Z;                                       // :233
-  p.jw13 = (float)(-k.fl * (1.0 + (double)(yy / zz)));
-  p.jw14 = -p.jw03;  // = (fx_z * xy) / Z (ref :233): IEEE negation commutes with multiply and divide, bit for bit
-  p.jw15 = fx_z * p.X;
+  point_jacobian(&p, k);
   return p;
 }
 
@@ -106,21 +115,25 @@ ODO_HD bool warp_point(const PointK& p, const float* T, const LevelK& k, int row
   return true;
 }
 
-// Residual + Jacobian row at the floor-sampled pixel (ref: lm_optimizer.cpp:215-234,
-// image_processing_global.h:62-69). I2: level image of the current frame, row-major.
-ODO_HD void residual_jacobian(const PointK& p, const float* I2, int rows, int cols, int ui, int vi, float* r, float J[6]) {
-  const int px = (ui - 1 >= 0) ? ui - 1 : 0, nx = (ui + 1 < cols) ? ui + 1 : cols - 1;
-  const int py = (vi - 1 >= 0) ? vi - 1 : 0, ny = (vi + 1 < rows) ? vi + 1 : rows - 1;
-  const float* row = I2 + (size_t)vi * cols;
-  const float gx = 0.5f * (row[nx] - row[px]);
-  const float gy = 0.5f * (I2[(size_t)ny * cols + ui] - I2[(size_t)py * cols + ui]);
-  *r = row[ui] - p.i1;
+// Residual + Jacobian row from the five I2 values around the floor-sampled pixel (centre, left, right, up, down; the
+// neighbours index-clamped to the image): ref lm_optimizer.cpp:215-234, image_processing_global.h:62-69.
+ODO_HD void residual_jacobian_taps(const PointK& p, float tc, float tl, float tr, float tu, float td, float* r, float J[6]) {
+  const float gx = 0.5f * (tr - tl);
+  const float gy = 0.5f * (td - tu);
+  *r = tc - p.i1;
   J[0] = gx * p.fx_z + gy * 0.0f;
   J[1] = gx * 0.0f + gy * p.fx_z;
   J[2] = gx * p.jw02 + gy * p.jw12;
   J[3] = gx * p.jw03 + gy * p.jw13;
   J[4] = gx * p.jw04 + gy * p.jw14;
   J[5] = gx * p.jw05 + gy * p.jw15;
+}
+// The same, reading the taps. I2: level image of the current frame, row-major.
+ODO_HD void residual_jacobian(const PointK& p, const float* I2, int rows, int cols, int ui, int vi, float* r, float J[6]) {
+  const int px = (ui - 1 >= 0) ? ui - 1 : 0, nx = (ui + 1 < cols) ? ui + 1 : cols - 1;
+  const int py = (vi - 1 >= 0) ? vi - 1 : 0, ny = (vi + 1 < rows) ? vi + 1 : rows - 1;
+  const float* row = I2 + (size_t)vi * cols;
+  residual_jacobian_taps(p, row[ui], row[px], row[nx], I2[(size_t)py * cols + ui], I2[(size_t)ny * cols + ui], r, J);
 }
 
 // Robust weight (ref: lm_optimizer.cpp:249-262). scale_sqr only used by mode 2.

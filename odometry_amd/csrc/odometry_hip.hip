@@ -325,6 +325,7 @@ struct odo_lm {
   int coarse;  // 1 = levels with <= kCoarseMaxPoints points run inside one workgroup (fused pipeline)
   int fused;  // 1 = one launch per evaluation (robust 0/1); 0 = separate residual / update kernels
   int mode;  // 0 auto (list when <= half of the interior has depth), 1 always dense scan, 2 always list
+  int dense_plain_div;  // 1 = dense levels use the plain IEEE divisions only (ODO_DENSE_PLAIN_DIV: A/B of the shared-reciprocal path)
   void (*idle_pump)(void*);  // called while the host waits for the device (the tracker feeds its depth stream here)
   void* idle_arg;
   // pinned host mirrors
@@ -380,6 +381,7 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
   HIP_OK(hipHostMalloc((void**)&m->cand_h_npts, sizeof(int) * ODO_MAX_LEVELS, hipHostMallocDefault));
   m->cand_tag = -1;
   m->mode = getenv("ODO_LM_MODE") ? atoi(getenv("ODO_LM_MODE")) : 0;
+  m->dense_plain_div = getenv("ODO_DENSE_PLAIN_DIV") ? 1 : 0;
   m->fused = getenv("ODO_LM_UNFUSED") ? 0 : 1;
   m->coarse = getenv("ODO_LM_NO_COARSE") ? 0 : 1;
   m->poll = getenv("ODO_NO_POLL") ? 0 : 1;
@@ -433,13 +435,23 @@ static int lm_check_pyrs(const odo_lm* m, const odo_pyr* a, const odo_pyr* d, co
   return 0;
 }
 
+// Dense levels: 256-thread blocks, register allocation held to four waves per SIMD (no spills), at most four blocks per CU.
+constexpr int kDenseBlock = 256, kDenseWaves = 4, kDenseGridCap = 1024;
+static inline DenseLevel lm_dense_level(const LevelView& v, const LevelK& k, int max_iters) {
+  DenseLevel L;
+  memset(&L, 0, sizeof(L));
+  L.I1 = v.I1; L.I2 = v.I2; L.D1 = v.D1; L.rows = v.rows; L.cols = v.cols; L.k = k;
+  L.fast_ok = dense_fast_ok(k.fl, k.cx, k.cy, v.rows, v.cols);
+  L.max_iters = max_iters;
+  dense_level_geometry(&L, kDenseBlock, kDenseGridCap);
+  return L;
+}
 static inline int lm_grid(int rows, int cols) {
-  const long n = (long)(rows - 8) * (cols - 8);
-  if (rows <= 8 || cols <= 8) return 1;
-  long g = (n + kLmBlock - 1) / kLmBlock;
-  if (g > kLmMaxBlocks) g = kLmMaxBlocks;
-  if (g < 1) g = 1;
-  return (int)g;
+  DenseLevel L;
+  memset(&L, 0, sizeof(L));
+  L.rows = rows; L.cols = cols;
+  dense_level_geometry(&L, kDenseBlock, kDenseGridCap);
+  return L.nblk;
 }
 
 static int lm_ensure_res(odo_lm* m, size_t n) {
@@ -580,9 +592,15 @@ static void lm_launch_eval(odo_lm* m, const LevelView& v, const LevelK& k, int l
                             v.I2, v.rows, v.cols, k, (const LmState*)m->d_state, level, m->robust, m->huber_delta,
                             (const float*)m->d_scale, m->d_partials);
     else
-      hipExtLaunchKernelGGL(lm_residual_dense_kernel, dim3(nblk), dim3(kLmBlock), 0, s, e0, e1, 0, v, k,
-                            (const LmState*)m->d_state, level, m->robust, m->huber_delta, (const float*)m->d_scale,
-                            m->d_partials);
+    {
+      const DenseLevel L = lm_dense_level(v, k, 0);
+      if (m->dense_plain_div)
+        hipExtLaunchKernelGGL((lm_dense_eval_kernel<kDenseBlock, 1, kDenseWaves>), dim3(L.nblk), dim3(kDenseBlock), 0, s, e0, e1, 0, L,
+                              (const LmState*)m->d_state, level, m->robust, m->huber_delta, (const float*)m->d_scale, m->d_partials);
+      else
+        hipExtLaunchKernelGGL((lm_dense_eval_kernel<kDenseBlock, 0, kDenseWaves>), dim3(L.nblk), dim3(kDenseBlock), 0, s, e0, e1, 0, L,
+                              (const LmState*)m->d_state, level, m->robust, m->huber_delta, (const float*)m->d_scale, m->d_partials);
+    }
     return;
   }
   if (m->use_list[level]) {
@@ -602,8 +620,13 @@ static void lm_launch_eval(odo_lm* m, const LevelView& v, const LevelK& k, int l
     hipLaunchKernelGGL(lm_tdist_scale_kernel, dim3(1), dim3(1024), 0, s, m->d_res, n > 0 ? n : 0, m->d_state, level,
                        m->d_scale);
   }
-  hipLaunchKernelGGL(lm_residual_dense_kernel, dim3(nblk), dim3(kLmBlock), 0, s, v, k, m->d_state, level, m->robust,
-                     m->huber_delta, m->d_scale, m->d_partials);
+  const DenseLevel L = lm_dense_level(v, k, 0);
+  if (m->dense_plain_div)
+    hipLaunchKernelGGL((lm_dense_eval_kernel<kDenseBlock, 1, kDenseWaves>), dim3(L.nblk), dim3(kDenseBlock), 0, s, L,
+                       (const LmState*)m->d_state, level, m->robust, m->huber_delta, (const float*)m->d_scale, m->d_partials);
+  else
+    hipLaunchKernelGGL((lm_dense_eval_kernel<kDenseBlock, 0, kDenseWaves>), dim3(L.nblk), dim3(kDenseBlock), 0, s, L,
+                       (const LmState*)m->d_state, level, m->robust, m->huber_delta, (const float*)m->d_scale, m->d_partials);
 }
 
 // Algorithmic bytes of one evaluation on `level`: dense scan 12 B per interior pixel,

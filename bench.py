@@ -66,53 +66,112 @@ def _render_pair(job):
     return L, R
 
 
-def load_traffic():
-    """Per-launch HBM traffic of the dominant kernel from the committed rocprofv3 --pmc summary, if present."""
+def load_traffic(key="lm_residual_bytes_per_launch"):
+    """Per-launch HBM traffic of a kernel from the committed rocprofv3 --pmc summary (profiles/pmc_traffic.json) and where
+    that number comes from: PMC counters cannot be collected from inside this process, so `traffic` is the value measured by the
+    separate --pmc passes of this same command, named in `traffic_source` — not a measurement of the run that prints it."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(p):
         try:
-            return json.load(open(p)).get("lm_residual_bytes_per_launch")
+            j = json.load(open(p))
+            return j.get(key), j.get("source", "profiles/pmc_traffic.json")
         except Exception:
-            return None
-    return None
+            return None, None
+    return None, None
 
 
-def cpu_baseline(seq, order, n_frames):
-    """The oracle (CPU restatement) stepping the same frames on one host core; a reported baseline, not the target."""
-    from oracle import runner as orunner
-    run = orunner.OracleRunner()
-    run.init(seq["left"][0], seq["right"][0])
-    poses = []
-    t0 = time.perf_counter()
-    for k, i in enumerate(order[:n_frames]):
-        if begins_pass(order, k):
-            run.init(seq["left"][0], seq["right"][0])
-        poses.append(run.track(seq["left"][i], seq["right"][i]))
-    dt = time.perf_counter() - t0
-    return n_frames / dt, poses, dt
+def cpu_baseline(seq, n_frames, n_reference_shape):
+    """The oracle (CPU restatement) stepping the first n_frames frames of the same sequence on ONE pinned host core, in a child
+    process, measured as BASELINE.md section 3 prescribes (oracle/cpu_baseline.py: -O3 -march=native build, 3 warm-up
+    frames, per-frame medians, Solve and ComputeDepth timed separately). A reported baseline, not the target."""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        path = os.path.join(td, "frames.npz")
+        np.savez(path, left=np.stack(seq["left"][:n_frames + 1]), right=np.stack(seq["right"][:n_frames + 1]))
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), path, str(n_frames),
+                            str(n_reference_shape)], capture_output=True, text=True, timeout=1200)
+    if p.returncode != 0:
+        raise RuntimeError("cpu baseline child failed: " + p.stderr[-2000:])
+    return json.loads(p.stdout.strip().splitlines()[-1])
 
 
-def dense_1080p_leg(api, synth):
-    """BASELINE.json configs[2]: 1920x1080, every pixel a residual — the HBM-bound shape of the evaluation kernel."""
+def dense_1080p_leg(api, synth, n_frames=5, passes=3):
+    """BASELINE.json configs[2]: a synthetic 1920x1080 stream with dense inverse depth (every pixel a residual on every
+    level), tracked the way the reference's test_optimizer.cpp does (ref: :86-105): per frame the image / depth pyramids of the
+    frame, Solve(frame k-1 -> k) with Huber weights, Reset to the identity. Frames are resident in HBM. Reports tracked frames/s
+    and, per pyramid level, the evaluation kernel's launch duration against the HBM roofline (12 B per interior pixel)."""
     K = (1100.0, 959.5, 539.5)
     scene = synth.Scene(1)
-    poses = synth.trajectory(2, 1)
-    L0, Z0 = scene.render(poses[0], 1080, 1920, *K)
-    L1, _ = scene.render(poses[1], 1080, 1920, *K)
-    inv = np.where(Z0 < 99.0, 1.0 / np.maximum(Z0, 1e-3), 0.0).astype(np.float32)
+    poses = synth.trajectory(n_frames, 1)
+    imgs, invs = [], []
+    for T in poses:
+        L, Z = scene.render(T, 1080, 1920, *K)
+        imgs.append(L)
+        invs.append(np.where(Z < 99.0, 1.0 / np.maximum(Z, 1e-3), 0.0).astype(np.float32))
     ctx = api.Context(0)
-    p0, d0, p1 = api.ImagePyramid(4, L0, True, ctx=ctx), api.DepthPyramid(4, inv, False, ctx=ctx), api.ImagePyramid(4, L1, True, ctx=ctx)
+    d_img = [ctx.upload(a) for a in imgs]
+    d_inv = [ctx.upload(a) for a in invs]
+    pimg = [api.ImagePyramid(4, None, False, ctx=ctx, device_ptr=d_img[0], shape=(1080, 1920)) for _ in range(2)]
+    pdep = [api.DepthPyramid(4, None, False, ctx=ctx, device_ptr=d_inv[0], shape=(1080, 1920)) for _ in range(2)]
     lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 1, 28.0, ctx=ctx, intrinsics=K)
-    T = np.linalg.inv(poses[1]) @ poses[0]
-    t = lm.time_eval(p0, d0, p1, 0, T, reps=50)
-    ach = t["bytes"] / (t["mean_us"] * 1e-6) / 1e9
+    eye = np.eye(4)
+
+    def one_pass(record=None):
+        pimg[0].rebuild_dev(d_img[0], False)
+        pdep[0].rebuild_dev(d_inv[0], False)
+        for k in range(1, n_frames):
+            cur, prev = k % 2, (k - 1) % 2
+            pimg[cur].rebuild_dev(d_img[k], False)      # the frame's pyramids (test_optimizer.cpp:53-54)
+            pdep[cur].rebuild_dev(d_inv[k], False)
+            T = lm.Solve(pimg[prev], pdep[prev], pimg[cur])   # :90
+            lm.Reset(eye, 0.01)                         # :104
+            if record is not None:
+                record.append((T, lm.launch_stats()[0]))
+    one_pass()   # warm-up
+    ctx.synchronize()
+    rec = []
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        one_pass(rec)
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    n_tracked = passes * (n_frames - 1)
+    # per-level roofline of the evaluation kernel at the last tracked pose (event-bracketed launches, no LM update)
+    k = n_frames - 1
+    T = rec[-1][0]
+    levels = []
+    for lvl in range(4):
+        t = lm.time_eval(pimg[(k - 1) % 2], pdep[(k - 1) % 2], pimg[k % 2], lvl, T, reps=50)
+        ach = t["bytes"] / (t["mean_us"] * 1e-6) / 1e9
+        levels.append(dict(level=lvl, residuals=t["n_points"], algorithmic_bytes=int(t["bytes"]),
+                           launch_us=round(t["mean_us"], 2), launch_min_us=round(t["min_us"], 2), achieved=round(ach, 1),
+                           frac=round(ach / HBM_PEAK_GBS, 4)))
+    # parity beside the timing: the first tracked pair against the oracle (one dense 1080p Solve on one host core)
+    from oracle import oracle as O
+    KD = dict(f0=K[0], cx0=K[1], cy0=K[2])
+    tc = time.perf_counter()
+    ref = O.lm_solve(O.image_pyramid(imgs[0], 4, False, flat=True), O.depth_pyramid(invs[0], 4, flat=True),
+                     O.image_pyramid(imgs[1], 4, False, flat=True), 1080, 1920, O.lm_params(robust=1, K=KD))
+    cpu_s = time.perf_counter() - tc
+    dmax = float(np.abs(rec[0][0].astype(np.float64) - ref["pose"]).max())
     lm.close()
-    for o in (p0, d0, p1):
+    for o in pimg + pdep:
         o.close()
+    for p in d_img + d_inv:
+        ctx.free(p)
     ctx.close()
-    return dict(kernel="lm_residual_dense_kernel(L0, 1920x1080, all pixels)", residuals=t["n_points"],
-                algorithmic_bytes=int(t["bytes"]), launch_us=round(t["mean_us"], 2), launch_min_us=round(t["min_us"], 2),
-                achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4))
+    l0 = levels[0]
+    return dict(workload="synthetic 1920x1080 stream, dense inverse depth, 4 levels, Huber, test_optimizer.cpp loop "
+                         "(pyramids + Solve + Reset per frame), frames resident in HBM",
+                frames_per_s=round(n_tracked / dt, 1), ms_per_frame=round(dt / n_tracked * 1e3, 3), frames_tracked=n_tracked,
+                lm_evals_per_frame=round(float(np.mean([r[1] for r in rec])), 1),
+                kernel="lm_dense_eval_kernel", bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s",
+                residuals=l0["residuals"], algorithmic_bytes=l0["algorithmic_bytes"], launch_us=l0["launch_us"],
+                launch_min_us=l0["launch_min_us"], achieved=l0["achieved"], frac=l0["frac"], per_level=levels,
+                cpu_oracle_solve_ms=round(cpu_s * 1e3, 1), pose_max_abs_delta_vs_oracle=dmax,
+                note="VALU-issue bound, not HBM bound: the parity arithmetic costs ~270 VALU instructions per pixel "
+                     "(28 fp64 FMAs, 23 fp32<->fp64 conversions, 3 + 1 reciprocals); see DESIGN.md section 5.1")
 
 
 def disparity_leg(api, seq, trk):
@@ -214,6 +273,9 @@ def multi_sequence_leg(api, seq, order, n_seq, steps):
 
 
 def main():
+    if os.environ.get("ODO_BENCH_FAULT_DUMP"):   # diagnostic: Python stacks of every thread on stderr after this many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["ODO_BENCH_FAULT_DUMP"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -222,7 +284,9 @@ def main():
                     help="length of the synthetic forward drive (configs[1]: the first 200 frames of a sequence); the steps "
                          "are passes over it (frame 0 re-initialises the tracker)")
     ap.add_argument("--gather-every", type=int, default=32, help="frames per RCCL pose all_gather (latency-insensitive: results only)")
-    ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=40,
+                    help="frames of the bounded CPU-baseline sample (0 = skip): the fused oracle tracks this many, the reference-shaped "
+                         "variant half of them (>= 20 each at the default)")
     ap.add_argument("--no-overlap", action="store_true", help="run ComputeDepth after Solve on one stream")
     ap.add_argument("--no-prefetch", action="store_true", help="build each frame's image pyramid inside its own step")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements")
@@ -233,6 +297,11 @@ def main():
     ap.add_argument("--overlap", type=int, default=2, help="1: one host thread feeds both streams, 2: helper thread")
     ap.add_argument("--distinct-sequences", action="store_true",
                     help="rank r tracks synthetic sequence r instead of every rank tracking sequence 0")
+    ap.add_argument("--sequences", type=int, default=0,
+                    help="BASELINE.json configs[3]: this many DISTINCT synthetic sequences (11 = KITTI seq 00-10) dealt round-robin "
+                         "over the ranks (dist.shard); every sequence is tracked for --steps frames, a rank tracks its sequences "
+                         "one after the other; value = sequences x steps / max-over-ranks wall time. 0 (default) = one sequence "
+                         "per rank, --steps frames each (weak scaling, the driver's contract)")
     args = ap.parse_args()
     args.unique_frames = max(args.unique_frames, 2)
 
@@ -240,10 +309,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # Weak scaling wants the same work on every GPU: per-frame cost depends on image content (20-50 LM evaluations), so by
-    # default every rank tracks its own copy of synthetic sequence 0; --distinct-sequences gives rank r sequence r.
-    # Rendered first, by a few worker processes, before this process touches the GPU.
-    seq = render_sequence(args.unique_frames, rank if args.distinct_sequences else 0,
-                          max(1, min(16, (os.cpu_count() or 1) // max(world, 1))))
+    # default every rank tracks its own copy of synthetic sequence 0; --distinct-sequences gives rank r sequence r and
+    # --sequences S deals S distinct sequences over the ranks. Rendered first, by a few worker processes, before this process
+    # touches the GPU.
+    from odometry_amd.dist import shard, frames_per_rank
+    n_sequences = args.sequences if args.sequences > 0 else world
+    my_seq_ids = shard(n_sequences, rank, world)          # sequences this rank tracks, in order
+    workers = max(1, min(16, (os.cpu_count() or 1) // max(world, 1)))
+    if args.sequences > 0:
+        seqs = [render_sequence(args.unique_frames, sid, workers) for sid in my_seq_ids]
+    else:
+        seqs = [render_sequence(args.unique_frames, rank if args.distinct_sequences else 0, workers)]
+    seq = seqs[0] if seqs else render_sequence(args.unique_frames, 0, workers)   # a rank without a sequence still takes part
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -267,7 +344,8 @@ def main():
     if not args.no_overlap and args.overlap == 2 and (os.cpu_count() or 1) < 2 * world + 2:
         args.overlap = 1
     trk = api.Tracker(local_rank, overlap_depth=0 if args.no_overlap else args.overlap)
-    dev = [(trk.upload_frame(l), trk.upload_frame(r)) for l, r in zip(seq["left"], seq["right"])]  # inputs resident in HBM
+    devs = [[(trk.upload_frame(l), trk.upload_frame(r)) for l, r in zip(q["left"], q["right"])] for q in (seqs or [seq])]
+    dev = devs[0]                                       # inputs resident in HBM
     trk.init(*dev[0])
     order = frame_order(args.unique_frames, args.warmup + args.steps)
 
@@ -278,25 +356,44 @@ def main():
         torch.cuda.synchronize()
 
     from odometry_amd.dist import PoseGatherer
-    gatherer = PoseGatherer(world, args.gather_every, device="cuda" if backend == "nccl" else None) if world > 1 else None
+    # frames each rank pushes in the timed region: the gather schedule is derived from these, identically on every rank
+    per_rank = frames_per_rank(n_sequences, args.steps, world)
+    gatherer = None
+    if world > 1:
+        gatherer = PoseGatherer(world, args.gather_every, device="cuda" if backend == "nccl" else None,
+                                n_local_frames=per_rank[rank], n_max_frames=max(per_rank))
     n_total = args.warmup + args.steps
-    poses_kf = np.zeros((n_total, 16), np.float32)    # pose_to_keyframe per step, column-major
-    poses_abs = np.zeros((n_total, 16), np.float32)
-    step_no = [0]
+    n_my = max(len(my_seq_ids), 1)
+    poses_kf = np.zeros((n_my, n_total, 16), np.float32)    # pose_to_keyframe per sequence and step, column-major
+    poses_abs = np.zeros((n_my, n_total, 16), np.float32)
 
-    def step(i):
-        k = step_no[0]
+    def step(j, k, dv, publish):
+        """Step k (frame order[k]) of this rank's j-th sequence, whose frames are dv."""
+        i = order[k]
         if begins_pass(order, k):
-            trk.init(*dev[0])   # a new pass over the sequence starts like the runner does: frame 0 becomes the keyframe
+            trk.init(*dv[0])   # a new pass over the sequence starts like the runner does: frame 0 becomes the keyframe
         if not args.no_prefetch and k + 1 < n_total:
-            trk.hint_next(dev[order[k + 1]][0])   # frames are resident: the next frame's pyramid overlaps this frame's tail
-        trk.track_into(dev[i][0], dev[i][1], poses_kf[k], poses_abs[k])
-        step_no[0] = k + 1
-        if gatherer is not None:
-            gatherer.push(poses_abs[k].reshape(4, 4).T)  # RCCL all_gather over xGMI every gather_every frames
+            trk.hint_next(dv[order[k + 1]][0])   # frames are resident: the next frame's pyramid overlaps this frame's tail
+        trk.track_into(dv[i][0], dv[i][1], poses_kf[j, k], poses_abs[j, k])
+        if publish and gatherer is not None:    # RCCL all_gather over xGMI every gather_every frames
+            gatherer.push(poses_abs[j, k].reshape(4, 4).T, seq_id=my_seq_ids[j] if my_seq_ids else 0, frame_id=i)
 
-    for i in order[:args.warmup]:
-        step(i)
+    def run_sequence(j, timed):
+        """Warm-up steps (untimed, first sequence only) or the timed steps of the j-th sequence of this rank."""
+        dv = devs[j]
+        if timed:
+            if j > 0 or args.sequences > 0:
+                trk.init(*dv[0])     # a new sequence starts on its own frame 0 (ref: run_odometry_kitti_offline.cpp:95-145)
+                for k in range(args.warmup):   # bring the sequence to the same point of its drive as the warmed-up one
+                    step(j, k, dv, False)
+            for k in range(args.warmup, n_total):
+                step(j, k, dv, True)
+        else:
+            for k in range(args.warmup):
+                step(j, k, dv, False)
+
+    if my_seq_ids and args.sequences == 0:
+        run_sequence(0, False)
     barrier()
     trk.timing()  # reset the host-clock diagnostics
     # The harness is Python: with torch imported a generation-2 garbage collection takes ~30 ms (140 frames' worth) and
@@ -304,19 +401,19 @@ def main():
     gc.collect()
     gc.disable()
     t0 = time.perf_counter()
-    if os.environ.get("ODO_BENCH_STEP_TIMES"):   # diagnostic: per-step wall times, the slowest ones on stderr
+    if os.environ.get("ODO_BENCH_STEP_TIMES") and args.sequences == 0:   # diagnostic: per-step wall times, the slowest ones on stderr
         st = []
-        for i in order[args.warmup:]:
+        for k in range(args.warmup, n_total):
             ta = time.perf_counter()
-            step(i)
+            step(0, k, devs[0], True)
             st.append(time.perf_counter() - ta)
         st = np.array(st) * 1e6
         top = np.argsort(st)[-8:][::-1]
         print("[step times] median %.1f mean %.1f us; slowest:" % (np.median(st), st.mean()),
               ", ".join("#%d %.0f" % (j, st[j]) for j in top), file=sys.stderr)
     else:
-        for i in order[args.warmup:]:
-            step(i)
+        for j in range(len(my_seq_ids)):
+            run_sequence(j, True)
     if gatherer is not None:
         gatherer.flush()
     barrier()
@@ -327,7 +424,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    fps = args.steps * world / elapsed
+    fps = args.steps * n_sequences / elapsed   # frames tracked by all ranks / max-over-ranks wall time
     host_timing = trk.timing()
     if rank == 0:
         # --- roofline of the dominant kernels (lm_coarse_kernel + lm_step_kernel: LM update + residual / normal-equation pass):
@@ -346,7 +443,7 @@ def main():
         achieved = ev["bytes"] / (ev["total_us"] * 1e-6) / 1e9 if ev["total_us"] > 0 else 0.0
         roof = dict(bound="hbm", kernel="LM evaluation kernels (lm_coarse_kernel + lm_step_kernel)",
                     achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 6),
-                    traffic=load_traffic(),
+                    traffic=load_traffic()[0], traffic_source=load_traffic()[1],
                     evaluations_per_frame=round(ev["active_launches"] / n_frames_ev, 2),
                     algorithmic_bytes_per_frame=round(ev["bytes"] / n_frames_ev, 1),
                     kernel_us_per_frame=round(ev["total_us"] / n_frames_ev, 2),
@@ -361,70 +458,69 @@ def main():
                                     algorithmic_bytes=int(tr0["bytes"]),
                                     achieved=round(tr0["bytes"] / (tr0["mean_us"] * 1e-6) / 1e9, 2))
         out = dict(metric="tracked frames/sec (1241x376, 4-level pyramid)", value=round(fps, 2), unit="frames/s",
-                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 4),
-                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=round(elapsed / (args.steps * max(max(per_rank) // max(args.steps, 1), 1)) * 1e3, 4),
+                   higher_is_better=True, scaling="strong" if args.sequences > 0 else "weak", vs_baseline=None, dtype="f32",
+                   data="synthetic",
                    config=dict(workload="synthetic KITTI-shaped stereo sequence (configs[1]: a forward drive, passes over "
                                         "unique_frames frames, the tracker re-initialised on frame 0 at each pass), 1241x376, "
                                         "4 levels, semi-dense, runner params, one sequence per GPU",
                                unique_frames=args.unique_frames, sequences_per_gpu=1,
+                               sequences=n_sequences, frames_per_rank=per_rank,
                                overlap_depth=0 if args.no_overlap else args.overlap, gather_every=args.gather_every,
                                next_frame_pyramid_prefetch=not args.no_prefetch,
-                               sequence_per_rank="distinct synthetic sequences" if args.distinct_sequences
+                               sequence_per_rank=("configs[3]: %d distinct synthetic sequences dealt round-robin over the ranks "
+                                                  "(rank r tracks sequences r, r + N, ... one after the other)" % n_sequences)
+                               if args.sequences > 0 else "distinct synthetic sequences" if args.distinct_sequences
                                else "every rank tracks its own copy of synthetic sequence 0 (equal work per GPU)"),
                    roofline=roof,
                    lm_evals_per_frame=round(float(np.mean(evals)), 2),
                    host_us_per_frame={k: round(v, 1) for k, v in host_timing.items()},
                    keyframes=trk.stats()["n_keyframes"])
+        if gatherer is not None:
+            # the exchange itself, checked: every rank's rows arrived on rank 0, and rank 0's own rows are the poses it tracked
+            got = [int(gatherer.rows(r).shape[0]) for r in range(world)]
+            out["pose_gather"] = dict(rows_per_rank=got, complete=(got == per_rank), collectives=gatherer.issued,
+                                      rows_per_collective=gatherer.every)
+            if my_seq_ids:
+                mine = gatherer.poses(0, seq_id=my_seq_ids[0])
+                want = poses_abs[0, args.warmup:].reshape(-1, 4, 4).transpose(0, 2, 1)[:, :3, :]
+                out["pose_gather"]["rank0_rows_match_tracked_poses"] = bool(np.array_equal(mine, want))
         if world == 1 and args.cpu_frames > 0:
-            n = min(args.cpu_frames, args.steps)
-            cpu_fps, cpu_poses, cpu_dt = cpu_baseline(seq, order, n)
+            n = min(args.cpu_frames, args.steps, args.unique_frames - 1)
+            cb = cpu_baseline(seq, n, max(min(n, 20), n // 2))   # >= 20 frames of each shape whenever the run has them
+            cpu_poses = [np.array(p) for p in cb.pop("poses")]
             # fresh GPU pass over the same frames from the same start: full-pipeline parity next to the timing
             trk2 = api.Tracker(local_rank, overlap_depth=0 if args.no_overlap else args.overlap)
-            dev2 = [(trk2.upload_frame(l), trk2.upload_frame(r)) for l, r in zip(seq["left"], seq["right"])]
+            dev2 = [(trk2.upload_frame(l), trk2.upload_frame(r)) for l, r in zip(seq["left"][:n + 1], seq["right"][:n + 1])]
             trk2.init(*dev2[0])
-            dmax = 0.0
             gpu_poses = []
             torch.cuda.synchronize()
             tg = time.perf_counter()
-            for j, i in enumerate(order[:n]):
-                if begins_pass(order, j):
-                    trk2.init(*dev2[0])
-                gpu_poses.append(trk2.track(*dev2[i])["pose_to_keyframe"])
+            for j in range(1, n + 1):
+                gpu_poses.append(trk2.track(*dev2[j])["pose_to_keyframe"])
             torch.cuda.synchronize()
             gpu_same_fps = n / (time.perf_counter() - tg)   # the GPU on exactly the frames the CPU sample covers
-            for j in range(n):
-                dmax = max(dmax, float(np.abs(gpu_poses[j].astype(np.float64) - cpu_poses[j]["pose_to_keyframe"]).max()))
+            dmax = max(float(np.abs(gpu_poses[j].astype(np.float64) - cpu_poses[j]).max()) for j in range(n))
             trk2.close()
-            cpu_model = ""
-            try:
-                for ln in open("/proc/cpuinfo"):
-                    if ln.startswith("model name"):
-                        cpu_model = ln.split(":", 1)[1].strip()
-                        break
-            except OSError:
-                pass
-            out["cpu_baseline"] = dict(value=round(cpu_fps, 3), unit="frames/s", cores=1, kind="port",
-                                       host_cpu=cpu_model, host_logical_cpus=os.cpu_count(),
-                                       sample=f"first {n} frames of the same sequence, oracle runner "
-                                              f"(pyramids + Solve + ComputeDepth per frame), {cpu_dt:.1f} s")
+            ref, fus = cb["reference_shape"], cb["fused"]
+            out["cpu_baseline"] = dict(
+                value=ref["frames_per_s"], unit="frames/s", cores=1, kind="port", host_cpu=cb["host_cpu"],
+                host_logical_cpus=cb["host_logical_cpus"], build=cb["build"], pinned_to_cpu=cb["pinned_to_cpu"],
+                sample=f"frames 1..{ref['frames']} of the same sequence after {cb['warmup_frames']} warm-up frames, one pinned core, "
+                       f"per-frame median; LM pass shaped like the reference (ComputeResidualJacobianNaive + OptimizeCameraPose: "
+                       f"materialised N x 6 Jacobian, per-pixel pow / GetCxLevel, separate fp32 product passes), {ref['total_s']} s",
+                solve_ms=ref["solve_ms_median"], compute_depth_ms=ref["compute_depth_ms_median"], frame_ms=ref["frame_ms_median"],
+                fused=dict(value=fus["frames_per_s"], unit="frames/s", cores=1, solve_ms=fus["solve_ms_median"],
+                           compute_depth_ms=fus["compute_depth_ms_median"], frame_ms=fus["frame_ms_median"],
+                           sample=f"frames 1..{fus['frames']}, the parity oracle itself (one residual / Jacobian pass, fp64 sums), "
+                                  f"{fus['total_s']} s"),
+                gpu_same_sample=dict(value=round(gpu_same_fps, 1), unit="frames/s"))
             out["pose_max_abs_delta_vs_oracle"] = dmax
             # like for like: the start of a drive is its most expensive stretch (40-70 LM evaluations per frame against
-            # ~25 later), so the ratio is taken on the same frames, not against the whole-run rate
-            out["cpu_baseline"]["gpu_same_sample"] = dict(value=round(gpu_same_fps, 1), unit="frames/s")
-            out["speedup_vs_cpu"] = round(gpu_same_fps / cpu_fps, 1)
-            # the same frames again with the LM pass in the reference's own shape (materialised N x 6 Jacobian, per-pixel
-            # pow / GetCxLevel, separate fp32 product passes): timing only, fewer frames
-            from oracle import oracle as _orc
-            n_ref = max(4, n // 4)
-            _orc.lib().orc_set_reference_shape(1)
-            try:
-                ref_fps, _, ref_dt = cpu_baseline(seq, order, n_ref)
-            finally:
-                _orc.lib().orc_set_reference_shape(0)
-            out["cpu_baseline"]["reference_shape"] = dict(
-                value=round(ref_fps, 3), unit="frames/s", cores=1,
-                sample=f"first {n_ref} frames, LM pass shaped like ComputeResidualJacobianNaive + OptimizeCameraPose "
-                       f"(fp32 sums; not bit-comparable), {ref_dt:.1f} s")
+            # ~25 later), so the ratios are taken on the same frames, not against the whole-run rate
+            out["speedup_vs_cpu"] = round(gpu_same_fps / ref["frames_per_s"], 1)
+            out["speedup_vs_cpu_fused"] = round(gpu_same_fps / fus["frames_per_s"], 1)
         if world == 1 and not args.no_extras:
             import contextlib
             with contextlib.redirect_stdout(sys.stderr):  # the mirrored classes print the reference's own messages

@@ -205,13 +205,17 @@ int odo_tracker_create(int device, const odo_tracker_params* p, odo_tracker** ou
  * exactly like a freshly created one. */
 int odo_tracker_init(odo_tracker* t, const float* left_dev, const float* right_dev, const float abs_pose0_colmajor[16]);
 /* One iteration of the frame loop (ref: :198-271). Returns 0, or -1 when ComputeDepth failed (the runner
- * breaks out of its loop there, ref: :230-232). A failed Solve is NOT an error (the runner carries on with the
- * pseudo-identity); solve_status reports it. */
+ * breaks out of its loop there, ref: :230-232); like the runner, which stores the frame's pose before it computes the depth
+ * (ref: :215-232), pose_to_keyframe / abs_pose / solve_status of that last frame are still written. A failed Solve is NOT an
+ * error (the runner carries on with the pseudo-identity); solve_status reports it, and abs_pose is then NaN (the inverse of
+ * the singular pseudo-identity, ref: :218), not zeros. */
 int odo_tracker_track(odo_tracker* t, const float* left_dev, const float* right_dev, float pose_to_keyframe[16],
                       float abs_pose[16], int* is_new_keyframe, float* motion_mag, int* solve_status);
 /* Optional pipelining for callers that already hold the next frame (offline runs): announce its left image before
  * tracking the current frame; its image pyramid (ref: :205 of the NEXT iteration) is then built at the end of this call
- * on the otherwise idle LM stream. Same work, earlier; results are unchanged. */
+ * on the otherwise idle LM stream. Same work, earlier; results are unchanged. The hinted buffer is identified by its device
+ * address: its contents must not change between the hint and the odo_tracker_track call that consumes it (a caller that
+ * recycles one buffer for every frame must not hint). odo_tracker_init drops a pending hint / prefetched pyramid. */
 int odo_tracker_hint_next(odo_tracker* t, const float* next_left_dev);
 /* Counters of the last tracked frame: LM evaluations, depth-LM iterations, valid depth points, keyframes so far. */
 int odo_tracker_stats(const odo_tracker* t, int* lm_evals, int* depth_iters, int* n_valid_depth, int* n_keyframes);

@@ -136,7 +136,9 @@ struct Huff {
     return -1;
   }
 };
-inline bool inflate(const uint8_t* in, size_t n, std::vector<uint8_t>& out) {
+// `max_out`: the decoded size the caller expects; decoding stops with an error as soon as the output would exceed it
+// (a few hundred bytes of IDAT can otherwise expand without limit).
+inline bool inflate(const uint8_t* in, size_t n, std::vector<uint8_t>& out, size_t max_out = (size_t)-1) {
   static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115,
                                      131, 163, 195, 227, 258};
   static const uint16_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -158,6 +160,7 @@ inline bool inflate(const uint8_t* in, size_t n, std::vector<uint8_t>& out) {
       const uint32_t len = br.p[br.pos] | (br.p[br.pos + 1] << 8), nlen = br.p[br.pos + 2] | (br.p[br.pos + 3] << 8);
       br.pos += 4;
       if ((len ^ 0xffffu) != nlen || br.pos + len > br.n) return false;
+      if (out.size() + len > max_out) return false;
       out.insert(out.end(), br.p + br.pos, br.p + br.pos + len);
       br.pos += len;
     } else if (type == 1 || type == 2) {
@@ -200,7 +203,7 @@ inline bool inflate(const uint8_t* in, size_t n, std::vector<uint8_t>& out) {
       for (;;) {
         const int sym = hl.decode(br);
         if (sym < 0 || !br.ok) return false;
-        if (sym < 256) out.push_back((uint8_t)sym);
+        if (sym < 256) { if (out.size() >= max_out) return false; out.push_back((uint8_t)sym); }
         else if (sym == 256) break;
         else {
           const int li = sym - 257;
@@ -209,7 +212,7 @@ inline bool inflate(const uint8_t* in, size_t n, std::vector<uint8_t>& out) {
           const int ds = hd.decode(br);
           if (ds < 0 || ds >= 30) return false;
           const size_t dist = dbase[ds] + br.bits(dext[ds]);
-          if (!br.ok || dist > out.size()) return false;
+          if (!br.ok || dist > out.size() || out.size() + (size_t)len > max_out) return false;
           const size_t from = out.size() - dist;
           for (int i = 0; i < len; i++) out.push_back(out[from + i]);
         }
@@ -257,15 +260,18 @@ inline bool read_png_gray8(const std::string& path, std::vector<uint8_t>& pixels
     }
     pos += 12 + (size_t)len;
   }
-  if (!have_ihdr || width <= 0 || height <= 0) return false;
+  // Sizes come from the file: bound them (65535 = the largest image the depth estimator takes) before any arithmetic or
+  // allocation is based on them, and do that arithmetic in size_t.
+  if (!have_ihdr || width <= 0 || height <= 0 || width > 65535 || height > 65535) return false;
+  const size_t raw_size = ((size_t)width + 1) * (size_t)height;
   std::vector<uint8_t> raw;
-  raw.reserve((size_t)(width + 1) * height);
-  if (!detail::inflate(idat.data(), idat.size(), raw)) return false;
-  if (raw.size() != (size_t)(width + 1) * height) return false;
+  raw.reserve(raw_size);
+  if (!detail::inflate(idat.data(), idat.size(), raw, raw_size)) return false;
+  if (raw.size() != raw_size) return false;
   pixels.assign((size_t)width * height, 0);
   for (int y = 0; y < height; y++) {
-    const uint8_t ft = raw[(size_t)y * (width + 1)];
-    const uint8_t* src = &raw[(size_t)y * (width + 1) + 1];
+    const uint8_t ft = raw[(size_t)y * ((size_t)width + 1)];
+    const uint8_t* src = &raw[(size_t)y * ((size_t)width + 1) + 1];
     uint8_t* cur = &pixels[(size_t)y * width];
     const uint8_t* up = y ? &pixels[(size_t)(y - 1) * width] : nullptr;
     for (int x = 0; x < width; x++) {

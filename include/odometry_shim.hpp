@@ -356,10 +356,16 @@ class LevenbergMarquardtOptimizer {  // ref: include/lm_optimizer.h:24-115
       std::cout << "Optimize failed! " << std::endl;  // ref: src/lm_optimizer.cpp:60-65 (out = pseudo-identity)
     return out;
   }
-  void ShowReport() {  // ref: src/lm_optimizer.cpp:364-371
+  // ref: src/lm_optimizer.cpp:364-371. The reference never writes iters_stat_ / cost_stat_ (no writer anywhere in
+  // lm_optimizer.cpp; ResetStatistics zeroes them), so its report is all zeros: that is what this prints. Compile with
+  // -DODOMETRY_SHIM_REAL_REPORT to print what the device actually counted (evaluations and first / last mean weighted
+  // error per level) — odo_lm_report() returns those either way.
+  void ShowReport() {
     int it[4] = {0, 0, 0, 0};
     float cost[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+#ifdef ODOMETRY_SHIM_REAL_REPORT
     odo_lm_report(lm_, it, cost);
+#endif
     std::cout << "Number of iterations performed per level: ";
     std::cout << it[0] << ", " << it[1] << ", " << it[2] << ", " << it[3] << std::endl;
     std::cout << "Costs before/after per level: " << std::endl;

@@ -194,8 +194,10 @@ class LevenbergMarquardtOptimizer:
         L.check(self.ctx.lib.odo_lm_report(self.h, iters, cost), "odo_lm_report")
         return list(iters), [[cost[2 * i], cost[2 * i + 1]] for i in range(4)]
 
-    def ShowReport(self):
-        iters, cost = self.report()
+    def ShowReport(self, real=False):
+        """ref: src/lm_optimizer.cpp:364-371 — the reference's statistics are never written, so it prints zeros; real=True
+        prints what the device counted (report())."""
+        iters, cost = self.report() if real else ([0, 0, 0, 0], [[0.0, 0.0]] * 4)
         print("Number of iterations performed per level: " + ", ".join(str(i) for i in iters))
         print("Costs before/after per level: ")
         for c in cost:

@@ -9,13 +9,14 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "odometry_hip.hip")
-DEPS = [SRC, os.path.join(_HERE, "csrc", "kernels.hip.h"), os.path.join(_HERE, "csrc", "odo_math.h"), os.path.join(_HERE, "csrc", "tracker.hip.h"), os.path.join(_HERE, "csrc", "camera.hip.h"),
+SRC_DENSE = os.path.join(_HERE, "csrc", "dense_kernels.hip")   # compiled with -fno-slp-vectorize (see dense.hip.h)
+DEPS = [SRC, SRC_DENSE, os.path.join(_HERE, "csrc", "kernels.hip.h"), os.path.join(_HERE, "csrc", "odo_math.h"), os.path.join(_HERE, "csrc", "tracker.hip.h"), os.path.join(_HERE, "csrc", "camera.hip.h"),
         os.path.join(_HERE, "csrc", "dense.hip.h"),
         os.path.join(os.path.dirname(_HERE), "include", "odometry_hip.h")]
 LIB = os.path.join(_HERE, "lib", "libodometry_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
-         "-fhip-fp32-correctly-rounded-divide-sqrt", "-shared", "-fPIC"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC"]
 
 
 def needs_build():
@@ -29,10 +30,23 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [HIPCC] + FLAGS + ["-o", LIB, SRC]
+    objdir = os.path.join(os.path.dirname(LIB), "obj")
+    os.makedirs(objdir, exist_ok=True)
+    o_main, o_dense = os.path.join(objdir, "odometry_hip.o"), os.path.join(objdir, "dense_kernels.o")
+    cmds = [[HIPCC] + FLAGS + ["-c", "-o", o_main, SRC],
+            [HIPCC] + FLAGS + ["-fno-slp-vectorize", "-c", "-o", o_dense, SRC_DENSE],
+            [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, o_main, o_dense]]
+    procs = []
+    for cmd in cmds[:2]:   # the two translation units compile side by side
+        if verbose:
+            print(" ".join(cmd))
+        procs.append(subprocess.Popen(cmd))
+    for pr, cmd in zip(procs, cmds[:2]):
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(cmds[2]))
+    subprocess.check_call(cmds[2])
     return LIB
 
 

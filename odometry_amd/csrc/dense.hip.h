@@ -9,9 +9,17 @@
 //     division" below): ~150 fewer VALU cycles per pixel-wave in a kernel that is VALU-issue bound;
 //   * the next unit's D1 / I1 loads are issued before the current unit is evaluated.
 #pragma once
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include "odo_math.h"
 
+// The kernels below are compiled in a translation unit of their own (dense_kernels.hip, -fno-slp-vectorize: hipcc's SLP
+// vectoriser turns pairs of fp32 operations into v_pk_mul_f32 / v_pk_fma_f32, measured at ~9.5 cycles per wave-instruction
+// against ~3.3 for a scalar fp32 operation — tools/microbench/valu_rates.hip); everything else sees only the level
+// description, its host-side helpers and the launcher declared at the end.
 namespace odo {
 
+#ifdef ODO_DENSE_KERNELS
 // ---------------------------------------------------------------------------------------------
 // Shared-reciprocal division.
 // hipcc -fhip-fp32-correctly-rounded-divide-sqrt expands a / b into
@@ -56,6 +64,8 @@ __device__ __forceinline__ double div_shared_d(double a, double b, double y) {
   return __builtin_fma(r0, y, q0);
 }
 
+#endif  // ODO_DENSE_KERNELS
+
 // Host-side part of the guard: intrinsics of a level for which the unscaled sequences are exact for every pixel whose
 // inverse depth passes the per-lane test |d| <= 4096 (|d| >= 0.01 holds for every evaluated pixel,
 // ref: src/lm_optimizer.cpp:193): focal length in [1, 65536], principal point within +-65536 and not closer than 2^-8 to
@@ -72,6 +82,7 @@ static inline int dense_fast_ok(double fl, float cx, float cy, int rows, int col
          rows <= 65535 && cols <= 65535;
 }
 
+#ifdef ODO_DENSE_KERNELS
 // odo::point_xyz / point_jacobian / make_point with the shared reciprocals: bit-identical for guarded operands.
 // yfl = rcp_refined((float)k.fl).
 __device__ __forceinline__ void point_xyz_shared(int x, int y, float inv_depth, const LevelK& k, float flf, float yfl, float* X,
@@ -124,6 +135,8 @@ __device__ __forceinline__ bool warp_point_shared(const PointK& p, const float* 
   return true;
 }
 
+#endif  // ODO_DENSE_KERNELS
+
 // ---------------------------------------------------------------------------------------------
 // Work decomposition of one dense level.
 // ---------------------------------------------------------------------------------------------
@@ -157,6 +170,8 @@ static inline void dense_level_geometry(DenseLevel* L, int block_threads, int ma
   L->nblk = (int)g;
 }
 
+#ifdef ODO_DENSE_KERNELS
+constexpr int kRedPad = 8;  // see kernels.hip.h
 // The units of block `b`: XCD group g = b % G owns the band of row groups [g n_rg / G, (g + 1) n_rg / G); inside the band
 // the units run strip by strip, top to bottom, and the group's blocks take consecutive runs of them.
 struct DenseRun { int strip, rg, rg0, rg1, count; };
@@ -472,5 +487,14 @@ __global__ void __launch_bounds__(kBlock, kWaves) lm_dense_eval_kernel(DenseLeve
   else dense_eval_block_pipelined<kBlock, kFlags>(L, blockIdx.x, T, robust, huber_delta, scale_sqr, acc);
   block_reduce_acc_w<kBlock>(acc, partials + (size_t)blockIdx.x * ODO_NACC);
 }
+
+#endif  // ODO_DENSE_KERNELS
+
+// Launcher (defined in dense_kernels.hip): one evaluation of level `L` at the pose in `st` on stream `s`; e0 / e1, when
+// given, are start / stop events bound to the dispatch. plain_div = 1 selects the plain IEEE divisions (A/B and parity
+// test of the shared-reciprocal path). Grid = L.nblk blocks of kDenseBlock threads.
+constexpr int kDenseBlock = 256, kDenseWaves = 4, kDenseGridCap = 1024;
+void launch_dense_eval(const DenseLevel& L, const LmState* st, int expect_level, int robust, float huber_delta,
+                       const float* scale_sqr_ptr, double* partials, hipStream_t s, hipEvent_t e0, hipEvent_t e1, int plain_div);
 
 }  // namespace odo

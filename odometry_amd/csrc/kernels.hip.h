@@ -260,7 +260,9 @@ struct LevelView {
 };
 
 constexpr int kLmBlock = 256;
+#ifndef ODO_DENSE_KERNELS
 constexpr int kRedPad = 8;  // sh[q][256+8] doubles: q-stride shifts 16 banks -> at most 2-way conflicts
+#endif
 
 // Deterministic block reduction of 29 fp64 accumulators per thread -> out[29].
 // Thread t < 232 owns quantity q = t>>3 and sums the 32 values sh[q][i*8 + (t&7)] in ascending i,

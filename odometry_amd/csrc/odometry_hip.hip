@@ -435,8 +435,8 @@ static int lm_check_pyrs(const odo_lm* m, const odo_pyr* a, const odo_pyr* d, co
   return 0;
 }
 
-// Dense levels: 256-thread blocks, register allocation held to four waves per SIMD (no spills), at most four blocks per CU.
-constexpr int kDenseBlock = 256, kDenseWaves = 4, kDenseGridCap = 1024;
+// Dense levels: 256-thread blocks, register allocation held to four waves per SIMD (no spills), at most four blocks per CU
+// (kDenseBlock / kDenseWaves / kDenseGridCap, dense.hip.h).
 static inline DenseLevel lm_dense_level(const LevelView& v, const LevelK& k, int max_iters) {
   DenseLevel L;
   memset(&L, 0, sizeof(L));
@@ -592,15 +592,8 @@ static void lm_launch_eval(odo_lm* m, const LevelView& v, const LevelK& k, int l
                             v.I2, v.rows, v.cols, k, (const LmState*)m->d_state, level, m->robust, m->huber_delta,
                             (const float*)m->d_scale, m->d_partials);
     else
-    {
-      const DenseLevel L = lm_dense_level(v, k, 0);
-      if (m->dense_plain_div)
-        hipExtLaunchKernelGGL((lm_dense_eval_kernel<kDenseBlock, 1, kDenseWaves>), dim3(L.nblk), dim3(kDenseBlock), 0, s, e0, e1, 0, L,
-                              (const LmState*)m->d_state, level, m->robust, m->huber_delta, (const float*)m->d_scale, m->d_partials);
-      else
-        hipExtLaunchKernelGGL((lm_dense_eval_kernel<kDenseBlock, 0, kDenseWaves>), dim3(L.nblk), dim3(kDenseBlock), 0, s, e0, e1, 0, L,
-                              (const LmState*)m->d_state, level, m->robust, m->huber_delta, (const float*)m->d_scale, m->d_partials);
-    }
+    launch_dense_eval(lm_dense_level(v, k, 0), m->d_state, level, m->robust, m->huber_delta, m->d_scale, m->d_partials, s, e0, e1,
+                      m->dense_plain_div);
     return;
   }
   if (m->use_list[level]) {
@@ -620,13 +613,8 @@ static void lm_launch_eval(odo_lm* m, const LevelView& v, const LevelK& k, int l
     hipLaunchKernelGGL(lm_tdist_scale_kernel, dim3(1), dim3(1024), 0, s, m->d_res, n > 0 ? n : 0, m->d_state, level,
                        m->d_scale);
   }
-  const DenseLevel L = lm_dense_level(v, k, 0);
-  if (m->dense_plain_div)
-    hipLaunchKernelGGL((lm_dense_eval_kernel<kDenseBlock, 1, kDenseWaves>), dim3(L.nblk), dim3(kDenseBlock), 0, s, L,
-                       (const LmState*)m->d_state, level, m->robust, m->huber_delta, (const float*)m->d_scale, m->d_partials);
-  else
-    hipLaunchKernelGGL((lm_dense_eval_kernel<kDenseBlock, 0, kDenseWaves>), dim3(L.nblk), dim3(kDenseBlock), 0, s, L,
-                       (const LmState*)m->d_state, level, m->robust, m->huber_delta, (const float*)m->d_scale, m->d_partials);
+  launch_dense_eval(lm_dense_level(v, k, 0), m->d_state, level, m->robust, m->huber_delta, m->d_scale, m->d_partials, s, nullptr,
+                    nullptr, m->dense_plain_div);
 }
 
 // Algorithmic bytes of one evaluation on `level`: dense scan 12 B per interior pixel,

@@ -29,7 +29,8 @@ struct odo_tracker {
   // overlap_depth == 2: a helper host thread feeds stream B (ComputeDepth + candidate pyramids) while the calling
   // thread feeds stream A (pose LM). Host launch rate, not the GPU, bounds a latency-bound frame loop.
   std::thread worker;
-  std::atomic<int> w_state;  // 0 idle, 1 job requested, 2 job done, 3 quit
+  std::atomic<int> w_state;  // 0 idle, 1 job requested, 2 job done
+  std::atomic<int> w_quit;   // 1: the worker leaves its loop once it is not running a job (never overwritten by the worker)
   const float *w_left, *w_right;
   int w_rc;
   char w_err[256];
@@ -63,7 +64,7 @@ extern "C" int odo_tracker_default_params(odo_tracker_params* p) {
 extern "C" int odo_tracker_destroy(odo_tracker* t) {
   if (!t) return 0;
   if (t->worker.joinable()) {
-    t->w_state.store(3, std::memory_order_release);
+    t->w_quit.store(1, std::memory_order_release);  // a job in flight finishes first; the flag is the worker's to read only
     t->worker.join();
   }
   if (t->ctx_a) (void)hipStreamSynchronize(t->ctx_a->stream);
@@ -96,7 +97,7 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
   t->job_stage = t->job_err = 0; t->pre_img_on_a = 0;
   t->cand_lists = getenv("ODO_NO_CAND_LISTS") ? 0 : 1;
   t->tm_solve_us = t->tm_depth_us = t->tm_frame_us = t->tm_wait_us = 0.0; t->tm_frames = 0;
-  t->w_state.store(0); t->w_left = t->w_right = nullptr; t->w_rc = 0; t->w_err[0] = 0;
+  t->w_state.store(0); t->w_quit.store(0); t->w_left = t->w_right = nullptr; t->w_rc = 0; t->w_err[0] = 0;
   t->p = *p;
   float eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   memcpy(t->pose_to_kf, eye, sizeof(eye));
@@ -183,8 +184,8 @@ static void tracker_worker_main(odo_tracker* t) {
   int idle_spins = 0;
   for (;;) {
     const int st = t->w_state.load(std::memory_order_acquire);
-    if (st == 3) return;
     if (st != 1) {
+      if (t->w_quit.load(std::memory_order_acquire)) return;
       // Spin while a sequence is being tracked (the next job arrives within a fraction of a millisecond and a
       // sleeping thread wakes ~100 us late); back off only after ~10 ms without work.
       if (++idle_spins > 20000000) std::this_thread::sleep_for(std::chrono::microseconds(200));
@@ -211,6 +212,7 @@ extern "C" int odo_tracker_init(odo_tracker* t, const float* left, const float* 
   HIP_OK(hipStreamSynchronize(t->ctx_b->stream));
   t->pre_img_on_a = 0;
   t->pre_img->ctx = t->ctx_b;
+  t->prefetched = t->hint_next = nullptr;  // a pyramid prefetched for the previous sequence is not this sequence's frame
   const int cand_keep = t->cand_lists;
   t->cand_lists = 0;            // frame 0 has no stream-A pyramid: the first Solve builds the keyframe lists itself
   t->lm->cand_tag = -1;
@@ -267,6 +269,22 @@ static void motion_angles(const float* T, float ang[3]) {
   ang[2] = atan2f(R[3] - R[1], R[0] + R[4]);
 }
 
+// Waits for the helper thread's job of this frame and takes its result. Bounded: the job is ~0.2 ms of launches plus the
+// depth LM; after 5 s the worker is presumed stuck behind a lost device and the frame fails (the tracker stays destroyable:
+// odo_tracker_destroy joins the worker whenever it comes back).
+static int tracker_wait_worker(odo_tracker* t) {
+  const auto q0 = std::chrono::steady_clock::now();
+  long spins = 0;
+  while (t->w_state.load(std::memory_order_acquire) != 2) {
+    if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - q0 > std::chrono::seconds(5))
+      return fail("    depth failed! (the depth stream's helper thread did not finish within 5 s)");
+  }
+  t->tm_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - q0).count();
+  t->w_state.store(0, std::memory_order_release);
+  if (t->w_rc) return fail("    depth failed! (%s)", t->w_err);                             // :230-232
+  return 0;
+}
+
 extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float* right, float pose_to_keyframe[16],
                                  float abs_pose[16], int* is_new_keyframe, float* motion_mag, int* solve_status) {
   if (!t || !left || !right) return fail("odo_tracker_track: NULL arg");
@@ -282,11 +300,19 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
   }
   t->prefetched = nullptr;
   if (t->cand_lists) HIP_OK(hipEventRecord(t->ev_cur_img, t->ctx_a->stream));  // before the stream-B job can ask for it
+  bool job_posted = false;
   if (p.overlap_depth == 2) {
     // helper thread: the whole stream-B job (ComputeDepth, candidate pyramids, final sync) runs beside this thread
     t->w_left = left; t->w_right = right;
     t->w_state.store(1, std::memory_order_release);
+    job_posted = true;
   }
+  // Every return below this point first collects the posted job: the worker must never be left with a finished job
+  // nobody takes (its "done" would sit in w_state for ever and the next frame would read a stale result).
+  struct JobGuard {
+    odo_tracker* t; bool* posted;
+    ~JobGuard() { if (*posted) { char keep[512]; snprintf(keep, sizeof(keep), "%s", g_err); (void)tracker_wait_worker(t); snprintf(g_err, sizeof(g_err), "%s", keep); } }
+  } job_guard{t, &job_posted};
   if (p.overlap_depth == 1) {
     // stream B: ComputeDepth + candidate pyramids, concurrent with the Solve on stream A. The front of the job is
     // enqueued now; its depth-LM launches are issued from the pose LM's wait loop (one host thread feeds both).
@@ -314,12 +340,21 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
     t->prefetched = t->hint_next;
     t->hint_next = nullptr;
   }
+  // :218 — the runner stores the frame's pose BEFORE it computes the depth (:215-232): a frame whose ComputeDepth fails
+  // still reports its pose (and the runner then leaves its loop).
+  memcpy(t->pose_to_kf, T, sizeof(T));
+  float inv[16], cur[16];
+  if (!invert4(T, inv))   // singular pose_to_keyframe (the failure pseudo-identity has (3,3) = 0): Eigen's inverse() of a
+    for (int i = 0; i < 16; i++) inv[i] = __builtin_nanf("");  // singular matrix is inf / NaN, not zeros
+  matmul4(t->kf_abs, inv, cur);                                                        // :218
+  if (pose_to_keyframe) memcpy(pose_to_keyframe, T, sizeof(T));
+  if (abs_pose) memcpy(abs_pose, cur, sizeof(cur));
+  if (solve_status) *solve_status = st;
+  if (is_new_keyframe) *is_new_keyframe = 0;
+  if (motion_mag) *motion_mag = 0.0f;
   if (p.overlap_depth == 2) {
-    const auto q0 = std::chrono::steady_clock::now();
-    while (t->w_state.load(std::memory_order_acquire) != 2) { /* spin: the job is ~0.2 ms */ }
-    t->tm_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - q0).count();
-    t->w_state.store(0, std::memory_order_release);
-    if (t->w_rc) { fail("    depth failed! (%s)", t->w_err); return -1; }                // :230-232
+    job_posted = false;   // collected here, not by the guard
+    if (tracker_wait_worker(t)) return -1;                                             // :230-232
   } else {
     if (p.overlap_depth == 1) {
       if (tracker_job_drain(t)) return -1;
@@ -328,10 +363,6 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
     }
     if (depth_finish(t->depth, false)) { fail("    depth failed!"); return -1; }       // :230-232
   }
-  memcpy(t->pose_to_kf, T, sizeof(T));
-  float inv[16], cur[16];
-  if (!invert4(T, inv)) memset(inv, 0, sizeof(inv));
-  matmul4(t->kf_abs, inv, cur);                                                        // :218
   float ang[3];
   motion_angles(T, ang);                                                               // :253
   const float mot[6] = {fabsf(ang[0]), fabsf(ang[1]), fabsf(ang[2]), fabsf(T[12]), fabsf(T[13]), fabsf(T[14])};

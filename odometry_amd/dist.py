@@ -3,10 +3,18 @@
 The path shards by SEQUENCE: tracking is sequential inside a sequence (each Solve starts from the previous pose and
 keyframe, ref: run_odometry_kitti_offline.cpp:215,258-268) and independent across sequences, so rank r owns the
 sequences r, r + world, ... and there is no data-path collective. The only exchange is the gather of the 6-DoF
-results: 12 floats (3x4) per tracked frame and rank, batched every `every` frames — latency-bound, a few hundred
-bytes per call.
+results: per tracked frame a row of 14 floats (sequence id, frame id, 3x4 pose), batched `every` rows per collective —
+latency-bound, a few hundred bytes per call.
+
+The exchange follows a schedule every rank derives from the same numbers, NOT from how many frames it tracked itself:
+with 11 sequences over 8 ranks (BASELINE.json configs[3]) ranks 0-2 track twice as many frames as ranks 3-7, and a
+collective per `every` LOCAL pushes would leave the ranks with different numbers of collectives (a hang at flush()).
+Here every rank issues exactly ceil(max_r frames_r / every) all_gathers of a fixed (every, 14) tensor; a rank that has
+run out of frames pads with rows whose sequence id is -1.
 """
 import numpy as np
+
+ROW = 14  # sequence id, frame id, 12 pose floats (row-major 3x4)
 
 
 def shard(n_items, rank, world):
@@ -14,29 +22,64 @@ def shard(n_items, rank, world):
     return list(range(rank, n_items, world))
 
 
-class PoseGatherer:
-    """Batches per-frame 3x4 poses and all-gathers them every `every` frames, off the tracking path: the collective is
-    issued asynchronously and its result is collected at a later push (or at flush()), so a rank never waits for the
-    exchange — nor, through it, for a slower rank — while it tracks."""
+def frames_per_rank(n_sequences, frames_per_sequence, world):
+    """Frames each rank will push when `n_sequences` sequences of `frames_per_sequence` tracked frames are dealt by shard()."""
+    return [len(shard(n_sequences, r, world)) * frames_per_sequence for r in range(world)]
 
-    def __init__(self, world, every=8, device=None):
-        self.world, self.every, self.device = world, every, device
+
+class PoseGatherer:
+    """Batches per-frame poses and all-gathers them `every` rows at a time, off the tracking path: a collective is issued
+    asynchronously and its result is collected at a later push (or at flush()), so a rank never waits for the exchange — nor,
+    through it, for a slower rank — while it tracks.
+
+    n_local_frames: how many rows THIS rank will push (its shard); n_max_frames: the largest such number over all ranks
+    (every rank computes both from the same sharding rule, e.g. frames_per_rank(); pass None to agree on it with one
+    all_reduce(MAX) here). The number and shape of the collectives depend on n_max_frames alone."""
+
+    def __init__(self, world, every=8, device=None, n_local_frames=None, n_max_frames=None):
+        self.world, self.every, self.device = world, max(int(every), 1), device
         self.pending = []
         self.inflight = []                           # (work handle or None, [tensor per rank]) in issue order
-        self.gathered = [[] for _ in range(world)]   # per rank: list of (every, 12) arrays
+        self.gathered = [[] for _ in range(world)]   # per rank: list of (every, ROW) arrays
+        self.n_local = n_local_frames
+        if n_max_frames is None and n_local_frames is not None and world > 1:
+            import torch
+            import torch.distributed as dist
+            t = torch.tensor([int(n_local_frames)], dtype=torch.int64)
+            if device is not None:
+                t = t.to(device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            n_max_frames = int(t.item())
+        if n_max_frames is None:
+            n_max_frames = n_local_frames
+        self.n_max = n_max_frames
+        # None = legacy mode: the caller guarantees that every rank pushes the same number of rows
+        self.n_collectives = None if n_max_frames is None else (int(n_max_frames) + self.every - 1) // self.every
+        self.issued = 0
+        self.pushed = 0
 
-    def push(self, pose4x4):
-        self.pending.append(np.asarray(pose4x4, np.float32)[:3, :].reshape(-1))
+    def push(self, pose4x4, seq_id=0, frame_id=None):
+        if self.n_local is not None and self.pushed >= self.n_local:
+            raise RuntimeError("PoseGatherer: more rows pushed than announced (n_local_frames)")
+        row = np.empty(ROW, np.float32)
+        row[0] = seq_id
+        row[1] = self.pushed if frame_id is None else frame_id
+        row[2:] = np.asarray(pose4x4, np.float32)[:3, :].reshape(-1)
+        self.pending.append(row)
+        self.pushed += 1
         if len(self.pending) == self.every:
             self._issue()
             self._drain(block=False)
 
     def _issue(self):
-        if not self.pending:
-            return
+        """One collective of exactly `every` rows (short batches are padded with sequence id -1)."""
         import torch
         import torch.distributed as dist
-        mine = torch.from_numpy(np.stack(self.pending))
+        rows = np.full((self.every, ROW), np.nan, np.float32)
+        rows[:, 0] = -1.0
+        if self.pending:
+            rows[:len(self.pending)] = np.stack(self.pending)
+        mine = torch.from_numpy(rows)
         if self.device is not None:
             mine = mine.to(self.device)
         if self.world > 1:
@@ -46,6 +89,7 @@ class PoseGatherer:
             out, work = [mine], None
         self.inflight.append((work, out))
         self.pending = []
+        self.issued += 1
 
     def _drain(self, block):
         while self.inflight:
@@ -59,10 +103,26 @@ class PoseGatherer:
             self.inflight.pop(0)
 
     def flush(self):
-        """Issue what is pending and wait for every outstanding exchange (end of a run)."""
-        self._issue()
+        """Issue what is pending, then the padded collectives this rank still owes the schedule, and wait for every
+        outstanding exchange (end of a run)."""
+        if self.pending:
+            self._issue()
+        if self.n_collectives is not None:
+            while self.issued < self.n_collectives:
+                self._issue()
         self._drain(block=True)
 
-    def poses(self, rank):
+    def rows(self, rank):
+        """Valid gathered rows of `rank`: (n, 14) = sequence id, frame id, 3x4 pose."""
         g = self.gathered[rank]
-        return np.concatenate(g).reshape(-1, 3, 4) if g else np.zeros((0, 3, 4), np.float32)
+        if not g:
+            return np.zeros((0, ROW), np.float32)
+        a = np.concatenate(g)
+        return a[a[:, 0] >= 0]
+
+    def poses(self, rank, seq_id=None):
+        """3x4 poses gathered from `rank` in push order (optionally of one sequence only)."""
+        a = self.rows(rank)
+        if seq_id is not None:
+            a = a[a[:, 0] == seq_id]
+        return a[:, 2:].reshape(-1, 3, 4)

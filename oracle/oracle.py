@@ -14,11 +14,27 @@ _SO = os.path.join(_HERE, "_build", "libodo_oracle.so")
 MAX_LEVELS = 8
 
 
+_SO_NATIVE = os.path.join(_HERE, "_build", "libodo_oracle_native.so")
+
+
 def build(force=False):
     src = os.path.join(_HERE, "odo_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "_build/libodo_oracle.so"], stdout=subprocess.DEVNULL)
     return _SO
+
+
+def build_native():
+    """The same source as the timing build of BASELINE.md section 3: -O3 -march=native (still -ffp-contract=off and no
+    fast-math, so every result is bit-identical to the portable build). Built on the machine that runs it — never shipped:
+    -march=native code of this container may not run on the GPU box's host. Falls back to the portable build."""
+    src = os.path.join(_HERE, "odo_oracle.c")
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "_build/libodo_oracle_native.so"], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL)
+        return _SO_NATIVE, "gcc -O3 -march=native -ffp-contract=off -fno-fast-math"
+    except (subprocess.CalledProcessError, OSError):
+        return build(), "gcc -O2 -ffp-contract=off -fno-fast-math (portable build: the native build failed)"
 
 
 class Intr(C.Structure):
@@ -60,7 +76,7 @@ _u8p = C.POINTER(C.c_uint8)
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(build())
+        _lib = C.CDLL(os.environ.get("ODO_ORACLE_SO") or build())   # ODO_ORACLE_SO: oracle/cpu_baseline.py's native build
         _lib.orc_pyramid_size.restype = C.c_long
         _lib.orc_level_offset.restype = C.c_long
         _lib.orc_sinf.restype = C.c_float

@@ -7,7 +7,7 @@ import numpy as np
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from odometry_amd.dist import PoseGatherer, shard
+from odometry_amd.dist import PoseGatherer, frames_per_rank, shard
 
 
 def fake_pose(rank, frame):
@@ -27,6 +27,23 @@ def _worker(rank, world, port, n_frames, every, q):
     g.flush()
     dist.barrier()
     q.put((rank, [g.poses(r) for r in range(world)]))
+    dist.destroy_process_group()
+
+
+def _worker_uneven(rank, world, port, n_sequences, frames, every, agree, q):
+    """BASELINE.json configs[3] in miniature: n_sequences sequences dealt over `world` ranks, so the ranks push different
+    numbers of rows; the collective schedule must not depend on that."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    per_rank = frames_per_rank(n_sequences, frames, world)
+    g = PoseGatherer(world, every, n_local_frames=per_rank[rank], n_max_frames=None if agree else max(per_rank))
+    for sid in shard(n_sequences, rank, world):
+        for f in range(frames):
+            g.push(fake_pose(sid, f), seq_id=sid, frame_id=f)
+    g.flush()
+    dist.barrier()
+    q.put((rank, g.issued, [g.rows(r) for r in range(world)]))
     dist.destroy_process_group()
 
 
@@ -60,3 +77,55 @@ def test_pose_gather_world2_gloo():
             assert got.shape == (n_frames, 3, 4)
             for f in range(n_frames):
                 assert np.array_equal(got[f], fake_pose(r, f)[:3, :])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_frames_per_rank_matches_shard():
+    assert frames_per_rank(11, 200, 8) == [400, 400, 400, 200, 200, 200, 200, 200]   # configs[3]
+    assert frames_per_rank(3, 7, 2) == [14, 7]
+    assert frames_per_rank(1, 5, 2) == [5, 0]                                      # a rank without a sequence
+
+
+import pytest
+
+
+@pytest.mark.parametrize("agree", [False, True])    # schedule from the sharding rule / agreed by one all_reduce(MAX)
+@pytest.mark.parametrize("n_sequences,frames,every", [(3, 7, 4), (1, 5, 8), (5, 6, 3)])
+def test_pose_gather_uneven_shards_world2_gloo(n_sequences, frames, every, agree):
+    """Ranks track different numbers of frames (3 sequences over 2 ranks: 14 vs 7 rows; one rank with nothing at all): every
+    rank issues the same number of fixed-size collectives, nothing hangs, every row arrives everywhere with its tags."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_uneven, args=(r, world, port, n_sequences, frames, every, agree, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, issued, rows = q.get(timeout=120)
+        res[rank] = (issued, rows)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    per_rank = frames_per_rank(n_sequences, frames, world)
+    n_coll = (max(per_rank) + every - 1) // every
+    for viewer in range(world):
+        issued, rows = res[viewer]
+        assert issued == n_coll                          # the schedule, not the local frame count
+        for r in range(world):
+            got = rows[r]
+            assert got.shape == (per_rank[r], 14)
+            k = 0
+            for sid in shard(n_sequences, r, world):
+                for f in range(frames):
+                    assert got[k, 0] == sid and got[k, 1] == f
+                    assert np.array_equal(got[k, 2:].reshape(3, 4), fake_pose(sid, f)[:3, :])
+                    k += 1

@@ -1,0 +1,46 @@
+"""bench.py's N > 1 path driven for real on a 1-GPU box: two ranks share device 0 (ODO_BENCH_SHARE_GPU) and exchange poses
+over gloo (ODO_BENCH_BACKEND) — the same sharding, schedule-based pose gather and max-over-ranks timing the 8-GPU RCCL run
+uses. Uneven shards on purpose: 3 sequences over 2 ranks (BASELINE.json configs[3] in miniature: 11 over 8)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_bench(extra, world=2, timeout=900):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, ODO_BENCH_SHARE_GPU="1", ODO_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--no-extras", "--cpu-frames", "0"] + extra
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]     # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_uneven_sequences():
+    out = _run_bench(["--sequences", "3", "--steps", "12", "--warmup", "3", "--unique-frames", "16", "--gather-every", "5"])
+    assert out["n_gpus"] == 2 and out["steps"] == 12 and out["scaling"] == "strong"
+    assert out["config"]["sequences"] == 3 and out["config"]["frames_per_rank"] == [24, 12]
+    g = out["pose_gather"]
+    assert g["complete"] and g["rows_per_rank"] == [24, 12]
+    assert g["collectives"] == 5                      # ceil(24 / 5) on EVERY rank, also the one that tracked 12 frames
+    assert g["rank0_rows_match_tracked_poses"]
+    assert out["value"] > 0 and abs(out["value"] - 36 / (out["ms_per_step"] * 1e-3 * 24)) < 1e-2 * out["value"]
+
+
+def test_bench_two_ranks_default_weak_scaling():
+    out = _run_bench(["--steps", "10", "--warmup", "2", "--unique-frames", "16", "--gather-every", "4"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["frames_per_rank"] == [10, 10]
+    assert out["pose_gather"]["complete"] and out["pose_gather"]["rank0_rows_match_tracked_poses"]

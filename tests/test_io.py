@@ -177,3 +177,38 @@ def test_stereo_calibration_file_of_the_reference(io):
     assert v[20] == 0.9999842188801975 and v[28] == 0.9999926905708509 and v[23] == -0.005183031408333682
     assert np.array_equal(v[29:32], [-0.060400809282521006, 0.00020747637203608188, 3.97878900435667e-05])
     assert np.array_equal(v[32:34], [640, 482])
+
+
+def _raw_png(path, w, h, payload):
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n")
+        f.write(chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)))
+        f.write(chunk(b"IDAT", payload))
+        f.write(chunk(b"IEND", b""))
+
+
+@pytest.mark.parametrize("w,h", [(0x7fffffff, 1), (70000, 4), (4, 70000), (0xffffffff, 0xffffffff)])
+def test_png_reader_rejects_absurd_header_sizes(io, tmp_path, w, h):
+    """IHDR sizes come from the file: they are bounded before any size arithmetic or allocation uses them."""
+    p = str(tmp_path / "huge.png")
+    _raw_png(p, w, h, zlib.compress(b"\x00" * 16))
+    out = np.zeros(64, np.uint8)
+    ww, hh = C.c_int(0), C.c_int(0)
+    assert io.io_read_png(p.encode(), out.ctypes.data_as(C.POINTER(C.c_ubyte)), out.size, C.byref(ww), C.byref(hh)) == -1
+
+
+def test_png_reader_stops_a_decompression_bomb(io, tmp_path):
+    """A small IDAT that inflates to far more than the header's width x height is refused while decoding (the inflater is
+    given the expected size), not after the output has grown without limit."""
+    p = str(tmp_path / "bomb.png")
+    bomb = zlib.compress(b"\x00" * (64 << 20), 9)       # 64 MiB of zeros in ~64 KiB
+    assert len(bomb) < (1 << 18)
+    _raw_png(p, 16, 16, bomb)
+    out = np.zeros(1024, np.uint8)
+    ww, hh = C.c_int(0), C.c_int(0)
+    import time
+    t0 = time.perf_counter()
+    assert io.io_read_png(p.encode(), out.ctypes.data_as(C.POINTER(C.c_ubyte)), out.size, C.byref(ww), C.byref(hh)) == -1
+    assert time.perf_counter() - t0 < 0.5

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#define ODO_DENSE_KERNELS 1
 #include "../../odometry_amd/csrc/kernels.hip.h"
 using namespace odo;
 

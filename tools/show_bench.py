@@ -1,8 +1,28 @@
-import sys, json
-for line in sys.stdin:
-    if '"metric"' not in line: continue
-    d = json.loads(line)
-    r = d['roofline']
-    print('fps', d['value'], 'ms', d['ms_per_step'], 'host', d['host_us_per_frame'])
-    print('step', r['lm_step_kernel'], 'coarse', r['lm_coarse_kernel'], 'evals', r['evaluations_per_frame'], 'kernel_us', r['kernel_us_per_frame'])
-    print('pose delta', d.get('pose_max_abs_delta_vs_oracle'), 'cpu', d.get('cpu_baseline', {}).get('value'))
+"""Prints the headline numbers of bench.py JSON lines: python tools/show_bench.py <file> [...]  (or JSON lines on stdin when
+no file is given AND stdin is not a terminal; never blocks on an interactive stdin)."""
+import json
+import sys
+
+
+def show(lines):
+    for line in lines:
+        if '"metric"' not in line:
+            continue
+        d = json.loads(line)
+        r = d['roofline']
+        print('fps', d['value'], 'ms', d['ms_per_step'], 'host', d['host_us_per_frame'])
+        print('step', r['lm_step_kernel'], 'coarse', r['lm_coarse_kernel'], 'evals', r['evaluations_per_frame'], 'kernel_us',
+              r['kernel_us_per_frame'])
+        print('pose delta', d.get('pose_max_abs_delta_vs_oracle'), 'cpu', d.get('cpu_baseline', {}).get('value'))
+        dn = d.get('roofline_dense_1080p')
+        if dn:
+            print('dense 1080p: fps', dn.get('frames_per_s'), 'L0 us', dn.get('launch_us'), 'frac', dn.get('frac'))
+
+
+if len(sys.argv) > 1:
+    for p in sys.argv[1:]:
+        show(open(p))
+elif not sys.stdin.isatty():
+    show(sys.stdin)
+else:
+    print(__doc__)

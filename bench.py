@@ -230,6 +230,98 @@ def single_pair_leg(api, seq):
     return out
 
 
+def shim_leg(api, seq, n_frames=100, passes=3):
+    """The drop-in surface, PCIe included. (1) shim_path: examples/run_odometry_synth.cpp — the reference runner's frame loop
+    written against include/odometry_shim.hpp (host-resident frames in page-locked stand-in Mats; device mirrors, lazy
+    downloads) — compiled with g++ and timed by its own clock over `passes` fresh runs of the first n_frames frames; its
+    pose_to_keyframe of every frame must equal the device-resident tracker's bit for bit. (2) pcie_inclusive: the same loop
+    through the host-buffer entry points of the C ABI (odo_pyramid_create / odo_depth_compute on pageable numpy arrays: every
+    input staged and uploaded at every use, every output downloaded at once) — what a build against real cv::Mat does."""
+    import re
+    import subprocess
+    import tempfile
+    out = {}
+    L, R = seq["left"][:n_frames], seq["right"][:n_frames]
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        exe = os.path.join(td, "run_odometry_synth")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "examples", "run_odometry_synth.cpp"), "-o", exe,
+                               "-L" + os.path.join(ROOT, "odometry_amd", "lib"), "-lodometry_hip",
+                               "-Wl,-rpath," + os.path.join(ROOT, "odometry_amd", "lib")])
+        frames = os.path.join(td, "frames.bin")
+        with open(frames, "wb") as f:
+            np.array([len(L), L[0].shape[0], L[0].shape[1]], np.int32).tofile(f)
+            for l, r in zip(L, R):
+                l.astype(np.float32).tofile(f)
+                r.astype(np.float32).tofile(f)
+        rel = os.path.join(td, "rel.bin")
+        p = subprocess.run([exe, frames, "--time", str(passes), "--rel-bin", rel], stdout=subprocess.DEVNULL,
+                           stderr=subprocess.PIPE, text=True, timeout=600)
+        m = re.search(r"SHIM_FPS ([\d.]+) FRAMES (\d+) PASSES (\d+)", p.stderr or "")
+        if p.returncode != 0 or not m:
+            raise RuntimeError("shim runner failed: " + (p.stderr or "")[-1500:])
+        shim_rel = np.fromfile(rel, np.float32).reshape(-1, 4, 4).transpose(0, 2, 1)
+    # the same frames through the device-resident tracker: bit-identical pose_to_keyframe
+    trk = api.Tracker(0)
+    dev = [(trk.upload_frame(l), trk.upload_frame(r)) for l, r in zip(L, R)]
+    trk.init(*dev[0])
+    same = True
+    for k in range(1, len(L)):
+        same = same and bool(np.array_equal(trk.track(*dev[k])["pose_to_keyframe"], shim_rel[k - 1]))
+    trk.close()
+    out["shim_path"] = dict(frames_per_s=float(m.group(1)), frames=int(m.group(2)), passes=int(m.group(3)),
+                            poses_bit_identical_to_tracker=same,
+                            what="examples/run_odometry_synth.cpp --time: runner loop over include/odometry_shim.hpp, host-resident "
+                                 "frames, set-up and PCIe inside the clock")
+    # (2) eager host-buffer path of the C ABI
+    ctx = api.Context(0)
+    de = api.DepthEstimator(8.0, 900.0, 15.0, 0.1, 30.0, 0.01, 28.0, 0.995, 50, 4, None, None,
+                            float(np.float32(386.1448) / np.float32(718.856)), 80000, ctx=ctx)
+    lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 1, 28.0, ctx=ctx, intrinsics=(718.856, 607.1928, 185.2157))
+    shp = L[0].shape
+    val, disp, dep = np.zeros(shp, np.uint8), np.zeros(shp, np.float32), np.zeros(shp, np.float32)
+
+    def run_pass():
+        poses = []
+        de.ComputeDepth(L[0], R[0], val, disp, dep)
+        kf_img, kf_dep = api.ImagePyramid(4, L[0], True, ctx=ctx), api.DepthPyramid(4, dep, False, ctx=ctx)
+        lm.Reset(np.eye(4), 0.01)
+        for k in range(1, len(L)):
+            cur = api.ImagePyramid(4, L[k], True, ctx=ctx)          # :205
+            T = lm.Solve(kf_img, kf_dep, cur)                       # :215
+            de.ComputeDepth(L[k], R[k], val, disp, dep)             # :229
+            pre_img, pre_dep = api.ImagePyramid(4, L[k], True, ctx=ctx), api.DepthPyramid(4, dep, False, ctx=ctx)   # :251-252
+            ang = np.abs([np.arctan2(T[2, 1] - T[1, 2], T[1, 1] + T[2, 2]), np.arctan2(T[0, 2] - T[2, 0], T[0, 0] + T[2, 2]),
+                          np.arctan2(T[1, 0] - T[0, 1], T[0, 0] + T[1, 1])])
+            mot = np.array([ang[0], ang[1], ang[2], abs(T[0, 3]), abs(T[1, 3]), abs(T[2, 3])], np.float32)   # :253-256
+            mag = float(np.dot(mot, np.array([0.1, 1.0, 0.1, 1.0, 0.1, 1.0], np.float32) / np.float32(3.3)))   # :257
+            if mag > 1.1:                                           # :258
+                kf_img.close(); kf_dep.close()
+                kf_img, kf_dep = pre_img, pre_dep
+            else:
+                pre_img.close(); pre_dep.close()
+            cur.close()
+            lm.Reset(T, 0.01)                                       # :261 / :268
+            poses.append(T)
+        kf_img.close(); kf_dep.close()
+        return poses
+    import contextlib
+    with contextlib.redirect_stdout(None):
+        run_pass()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            poses = run_pass()
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+    lm.close(); de.close(); ctx.close()
+    out["pcie_inclusive"] = dict(frames_per_s=round(passes * (len(L) - 1) / dt, 1), frames=passes * (len(L) - 1),
+                                 what="the runner's loop through the host-buffer C ABI entry points from Python (pageable numpy "
+                                      "inputs staged + uploaded at every use: 3 x left, right, depth per frame; val / disp / dep "
+                                      "downloaded at once)")
+    return out
+
+
 def multi_sequence_leg(api, seq, order, n_seq, steps):
     """Throughput with several independent sequences in flight on ONE GPU (each its own tracker: two HIP streams, two
     host threads). Not `value`: configs[1] is a single sequence, whose frames are inherently serial; this shows how
@@ -290,8 +382,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="run ComputeDepth after Solve on one stream")
     ap.add_argument("--no-prefetch", action="store_true", help="build each frame's image pyramid inside its own step")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements")
-    ap.add_argument("--extras", default="dense,disparity,single",
-                    help="side measurements to run: dense (configs[2]), disparity (configs[4]), single (configs[0]); "
+    ap.add_argument("--extras", default="dense,disparity,single,shim",
+                    help="side measurements to run: dense (configs[2]), disparity (configs[4]), single (configs[0]), shim (the "
+                         "drop-in C++ classes and the host-buffer C ABI, PCIe included); "
                          "multi (several trackers of one process on one GPU) is opt-in: it floods the device with concurrent "
                          "trackers, which is not what a profile of this command is meant to show")
     ap.add_argument("--overlap", type=int, default=2, help="1: one host thread feeds both streams, 2: helper thread")
@@ -531,6 +624,8 @@ def main():
                     out["disparity_1241x376"] = disparity_leg(api, seq, trk)
                 if "single" in legs:
                     out["single_pair_1241x376"] = single_pair_leg(api, seq)
+                if "shim" in legs:
+                    out.update(shim_leg(api, seq, n_frames=min(100, args.unique_frames)))
                 if "multi" in legs:   # last, with every other stream of this process gone (streams share hardware queues)
                     trk.close()
                     out["multi_sequence_1gpu"] = [multi_sequence_leg(api, seq, order, n, 200) for n in (2, 4, 8)]

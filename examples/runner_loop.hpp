@@ -36,8 +36,9 @@ inline io::Pose34 to_pose34(const Affine4f& T) {
 }
 
 // Returns the number of keyframes created after the first one, or -1 if frame 0 could not be initialised.
+// rel (optional): pose_to_keyframe of every frame (what Solve returned), for bit-exact comparisons.
 inline int track_sequence(const std::vector<Mat>& left, const std::vector<Mat>& right, const Affine4f& pose0,
-                          std::vector<io::Pose34>& pred, bool verbose = true) {
+                          std::vector<io::Pose34>& pred, bool verbose = true, std::vector<Affine4f>* rel = nullptr) {
   const unsigned num_frames = (unsigned)left.size();
   const unsigned num_pyramid = 4;
   const float baseline = 386.1448f / 718.856f;                          // :41
@@ -100,6 +101,7 @@ inline int track_sequence(const std::vector<Mat>& left, const std::vector<Mat>& 
     }
     pose_estimator.Reset(pose_to_keyframe, 0.01f);                    // :261 / :268
     pred[frame_id] = to_pose34(cur_pose);                             // :222
+    if (rel) rel->push_back(pose_to_keyframe);
     if (verbose)
       std::printf("frame %u kf %u motion %.4f  t = [% .5f % .5f % .5f]\n", frame_id, current_kf, motion_mag, cur_pose(0, 3),
                   cur_pose(1, 3), cur_pose(2, 3));

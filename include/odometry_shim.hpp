@@ -92,6 +92,87 @@ struct Scalar {  // cv::Scalar: only the first channel matters for single-channe
 inline double scalar0(const Scalar& s) { return s.val[0]; }
 // The subset of cv::Mat the runner and the estimators touch: rows, cols, type(), at<T>, ptr<T>, isContinuous,
 // copyTo / clone, ref-counted header copies.
+//
+// Unlike cv::Mat this stand-in knows about the device. Its pixel buffer is page-locked host memory (uploads from it are
+// plain asynchronous DMAs) and carries an optional DEVICE MIRROR with two validity flags:
+//   * the shim's classes read inputs through the mirror — a frame that goes to ImagePyramid (:205), ComputeDepth (:229)
+//     and ImagePyramid again (:251) crosses PCIe once, not three times;
+//   * ComputeDepth leaves val / disp / dep on the device and only marks the host side stale: the bytes come back when (if)
+//     host code looks at them. The runner only hands left_dep to DepthPyramid (:252), which takes the mirror.
+// Correctness does not rest on trust: every non-const access (ptr<T>() / at<T>() on a non-const Mat) brings the host copy
+// up to date and invalidates the mirror; every const access brings the host copy up to date. Header copies share buffer
+// and mirror, as cv::Mat headers share data.
+namespace detail {
+inline odo_ctx* context();
+struct MatBuf {
+  uint8_t* host = nullptr;
+  size_t bytes = 0;
+  bool pinned = false;
+  void* dev = nullptr;        // device mirror (allocated on first use by an estimator)
+  int dev_async = 0;
+  bool host_valid = true, dev_valid = false;
+  bool upload_pending = false;  // an asynchronous DMA may still be reading `host`
+  explicit MatBuf(size_t n);
+  ~MatBuf();
+  MatBuf(const MatBuf&) = delete;
+  MatBuf& operator=(const MatBuf&) = delete;
+  void sync_host() {  // host copy current (lazy download)
+    if (!host_valid && dev) { odo_dev_download(context(), host, dev, bytes); upload_pending = false; }
+    host_valid = true;
+  }
+  void touch() { sync_host(); dev_valid = false; }  // host code may write
+};
+// Page-locked blocks are expensive to create (hipHostMalloc): per-frame Mats recycle them through a small free list.
+struct PinnedPool {
+  std::vector<std::pair<size_t, void*>> free_;
+  ~PinnedPool() { for (auto& e : free_) odo_host_free(e.second); }
+  void* get(size_t n) {
+    for (size_t i = 0; i < free_.size(); i++)
+      if (free_[i].first == n) { void* p = free_[i].second; free_.erase(free_.begin() + (long)i); return p; }
+    return odo_host_alloc(n);
+  }
+  void put(size_t n, void* p) { if (free_.size() < 32) free_.emplace_back(n, p); else odo_host_free(p); }
+};
+inline PinnedPool& pinned_pool() { static thread_local PinnedPool pool; return pool; }
+// Mirrors that are pure caches (host copy current as well) are bounded: the runner keeps every frame of a sequence in
+// host memory (ref: run_odometry_kitti_offline.cpp:334-359 fills two vectors), and only the few it touched last need to
+// stay on the device. Least recently used first out; a mirror that holds the only current copy is never dropped.
+struct MirrorLru {
+  std::vector<std::weak_ptr<MatBuf>> order;  // most recent last
+  void use(const std::shared_ptr<MatBuf>& b, size_t keep = 16) {
+    for (size_t i = 0; i < order.size(); i++) {
+      auto q = order[i].lock();
+      if (!q || q.get() == b.get()) { order.erase(order.begin() + (long)i); i--; }
+    }
+    order.push_back(b);
+    size_t caches = 0;
+    for (auto& w : order) { auto q = w.lock(); if (q && q->dev && q->host_valid) caches++; }
+    for (size_t i = 0; i < order.size() && caches > keep; i++) {
+      auto q = order[i].lock();
+      if (q && q->dev && q->host_valid && q.get() != b.get()) {
+        odo_dev_free_async(context(), q->dev, q->dev_async);
+        q->dev = nullptr; q->dev_valid = false;
+        caches--;
+      }
+    }
+  }
+};
+inline MirrorLru& mirror_lru() { static thread_local MirrorLru lru; return lru; }
+inline MatBuf::MatBuf(size_t n) : bytes(n) {
+  if (n >= (64u << 10)) { host = static_cast<uint8_t*>(pinned_pool().get(n)); pinned = host != nullptr; }
+  if (!host) host = static_cast<uint8_t*>(std::malloc(n ? n : 1));
+}
+inline MatBuf::~MatBuf() {
+  if (dev) odo_dev_free_async(context(), dev, dev_async);
+  if (pinned) {
+    if (upload_pending) odo_ctx_synchronize(context());  // a DMA may still be reading the block
+    pinned_pool().put(bytes, host);
+  } else {
+    std::free(host);
+  }
+}
+}  // namespace detail
+
 class Mat {
  public:
   int rows = 0, cols = 0;
@@ -99,31 +180,55 @@ class Mat {
   Mat(int r, int c, int type) { create(r, c, type); }
   Mat(int r, int c, int type, double fill) {
     create(r, c, type);
-    if (type_ == CV_32F) for (size_t i = 0; i < (size_t)r * c; i++) reinterpret_cast<float*>(buf_->data())[i] = (float)fill;
-    else if (type_ == CV_64F) for (size_t i = 0; i < (size_t)r * c; i++) reinterpret_cast<double*>(buf_->data())[i] = fill;
-    else std::memset(buf_->data(), (int)fill, buf_->size());
+    if (type_ == CV_32F) for (size_t i = 0; i < (size_t)r * c; i++) reinterpret_cast<float*>(buf_->host)[i] = (float)fill;
+    else if (type_ == CV_64F) for (size_t i = 0; i < (size_t)r * c; i++) reinterpret_cast<double*>(buf_->host)[i] = fill;
+    else std::memset(buf_->host, (int)fill, buf_->bytes);
   }
   void create(int r, int c, int type) {
     rows = r; cols = c; type_ = type;
-    buf_ = std::make_shared<std::vector<uint8_t>>((size_t)r * c * elemSize());
+    buf_ = std::make_shared<detail::MatBuf>((size_t)r * c * elemSize());
   }
   int type() const { return type_; }
   int channels() const { return 1; }
   size_t elemSize() const { return type_ == CV_64F ? 8 : type_ == CV_32F ? 4 : 1; }
   bool isContinuous() const { return true; }
   bool empty() const { return !buf_ || rows == 0 || cols == 0; }
-  template <class T> T* ptr(int y = 0) { return reinterpret_cast<T*>(buf_->data() + (size_t)y * cols * elemSize()); }
-  template <class T> const T* ptr(int y = 0) const { return reinterpret_cast<const T*>(buf_->data() + (size_t)y * cols * elemSize()); }
+  template <class T> T* ptr(int y = 0) { buf_->touch(); return reinterpret_cast<T*>(buf_->host + (size_t)y * cols * elemSize()); }
+  template <class T> const T* ptr(int y = 0) const {
+    buf_->sync_host();
+    return reinterpret_cast<const T*>(buf_->host + (size_t)y * cols * elemSize());
+  }
   template <class T> T& at(int y, int x) { return ptr<T>(y)[x]; }
   template <class T> const T& at(int y, int x) const { return ptr<T>(y)[x]; }
   void copyTo(Mat& dst) const {
     dst.create(rows, cols, type_);
-    if (buf_) std::memcpy(dst.buf_->data(), buf_->data(), buf_->size());
+    if (buf_) { buf_->sync_host(); std::memcpy(dst.buf_->host, buf_->host, buf_->bytes); }
   }
   Mat clone() const { Mat m; copyTo(m); return m; }
+  // -- device side, for the shim's classes only --
+  // Device copy of the pixels for reading (uploads when the mirror is missing or stale). Null on failure.
+  const void* device_in() const {
+    detail::MatBuf& b = *buf_;
+    if (!b.dev && odo_dev_alloc_async(detail::context(), b.bytes, &b.dev, &b.dev_async) != 0) return nullptr;
+    detail::mirror_lru().use(buf_);
+    if (!b.dev_valid) {
+      if (odo_dev_upload_async(detail::context(), b.dev, b.host, b.bytes) != 0) return nullptr;
+      b.upload_pending = b.pinned;
+      b.dev_valid = true;
+    }
+    return b.dev;
+  }
+  // Device buffer a kernel is about to overwrite completely: afterwards the device holds the truth, the host copy is stale.
+  void* device_out() {
+    detail::MatBuf& b = *buf_;
+    if (!b.dev && odo_dev_alloc_async(detail::context(), b.bytes, &b.dev, &b.dev_async) != 0) return nullptr;
+    b.dev_valid = true;
+    b.host_valid = false;
+    return b.dev;
+  }
  private:
   int type_ = CV_32F;
-  std::shared_ptr<std::vector<uint8_t>> buf_;
+  std::shared_ptr<detail::MatBuf> buf_;
 };
 #endif
 
@@ -257,6 +362,40 @@ inline odo_ctx* context() {
   }
   return ctx;
 }
+// Device view of an input / output image for both Mat flavours. With the stand-in Mat the view borrows the Mat's mirror
+// (no copy when it is current); with cv::Mat there is nothing to hang a mirror on and nothing that reports writes, so every
+// input is staged and uploaded into a stream-ordered scratch block and every output is downloaded before the call returns.
+#ifdef ODOMETRY_SHIM_WITH_OPENCV
+struct DevIn {
+  void* dev = nullptr; int async_ = 0;
+  explicit DevIn(const Mat& m) {
+    const size_t n = m.total() * m.elemSize();
+    if (odo_dev_alloc_async(context(), n, &dev, &async_) == 0 && odo_dev_upload_async(context(), dev, m.data, n) != 0) {
+      odo_dev_free_async(context(), dev, async_); dev = nullptr;
+    }
+  }
+  ~DevIn() { if (dev) odo_dev_free_async(context(), dev, async_); }
+  const void* get() const { return dev; }
+};
+struct DevOut {
+  Mat& m; void* dev = nullptr; int async_ = 0;
+  explicit DevOut(Mat& mm) : m(mm) { odo_dev_alloc_async(context(), m.total() * m.elemSize(), &dev, &async_); }
+  ~DevOut() { if (dev) { odo_dev_download(context(), m.data, dev, m.total() * m.elemSize()); odo_dev_free_async(context(), dev, async_); } }
+  void* get() { return dev; }
+};
+#else
+struct DevIn {
+  const void* dev;
+  explicit DevIn(const Mat& m) : dev(m.device_in()) {}
+  const void* get() const { return dev; }
+};
+struct DevOut {
+  void* dev;
+  explicit DevOut(Mat& m) : dev(m.device_out()) {}
+  void* get() { return dev; }
+};
+#endif
+
 struct PyrHandle {
   odo_pyr* p = nullptr;
   std::vector<Mat> host;       // lazily downloaded levels for GetPyramidImage / GetPyramidDepth
@@ -277,8 +416,14 @@ inline std::shared_ptr<PyrHandle> make_pyr(int num_levels, const Mat& in, bool s
   auto h = std::make_shared<PyrHandle>();
   h->host.resize(num_levels > 0 ? num_levels : 0);
   h->have.assign(num_levels > 0 ? num_levels : 0, 0);
-  if (in.type() != PixelType || !in.isContinuous() ||
-      odo_pyramid_create(context(), in.ptr<float>(), in.rows, in.cols, 0, num_levels, smooth ? 1 : 0, kind, &h->p) != 0) {
+  bool ok = in.type() == PixelType && in.isContinuous();
+  if (ok) {
+    DevIn src(in);  // the frame on the device (already there when the same Mat was used a moment ago)
+    ok = src.get() != nullptr &&
+         odo_pyramid_create_dev(context(), static_cast<const float*>(src.get()), in.rows, in.cols, num_levels, smooth ? 1 : 0, kind,
+                                &h->p) == 0;
+  }
+  if (!ok) {
     std::cout << what << std::endl;  // ref: src/image_pyramid.cpp:16-18,34-36 (prints, object stays unusable)
     h->p = nullptr;
   }
@@ -425,8 +570,15 @@ class DepthEstimator {  // ref: include/depth_estimate.h:24-121
       return -1;
     }
     std::cout << "computing disparity ..." << std::endl;
-    const int st = odo_depth_compute(d_, left_img.ptr<float>(), right_img.ptr<float>(), left_img.rows, left_img.cols,
-                                     left_val.ptr<uint8_t>(), left_disp.ptr<float>(), left_dep.ptr<float>());
+    int st = -1;
+    {
+      detail::DevIn l(left_img), r(right_img);
+      detail::DevOut v(left_val), ds(left_disp), dp(left_dep);
+      if (l.get() && r.get() && v.get() && ds.get() && dp.get())
+        st = odo_depth_compute_dev(d_, static_cast<const float*>(l.get()), static_cast<const float*>(r.get()), left_img.rows,
+                                   left_img.cols, static_cast<uint8_t*>(v.get()), static_cast<float*>(ds.get()),
+                                   static_cast<float*>(dp.get()));
+    }
     int iters = 0, nsel = 0, nmatch = 0, nvalid = 0;
     float cost = 0;
     odo_depth_report(d_, &iters, &cost, &nsel, &nmatch, &nvalid);

@@ -39,11 +39,57 @@ extern "C" const char* odo_last_error(void) { return g_err; }
 extern "C" int odo_version(void) { return 100; }
 
 // ------------------------------------------------------------------------------------------------
+constexpr int kStageSlots = 4;
 struct odo_ctx {
   int device;
   hipStream_t stream;
   hipEvent_t ev0, ev1;
+  // pinned staging ring for uploads from pageable host memory: a slot is reused once the copy that read it has finished
+  void* stage[kStageSlots];
+  size_t stage_cap[kStageSlots];
+  hipEvent_t stage_ev[kStageSlots];
+  int stage_busy[kStageSlots];
+  int stage_next;
 };
+
+// ---- stream-ordered device memory ---------------------------------------------------------------------------------
+// Per-frame objects of the drop-in path (a pyramid per constructor call, ref: run_odometry_kitti_offline.cpp:205,251-252) are
+// allocated and freed in stream order from the device's memory pool (hipMallocAsync / hipFreeAsync): after the first
+// frames an allocation is a pool hit and a free neither synchronises the stream nor returns memory to the driver.
+static std::atomic<int> g_async_alloc{-1};  // -1 unknown, 0 unavailable (plain hipMalloc / hipFree), 1 in use
+static bool async_alloc_ready(int device) {
+  int v = g_async_alloc.load();
+  if (v >= 0) return v == 1;
+  v = 0;
+  if (!getenv("ODO_NO_ASYNC_ALLOC")) {
+    int supported = 0;
+    hipMemPool_t pool = nullptr;
+    if (hipDeviceGetAttribute(&supported, hipDeviceAttributeMemoryPoolsSupported, device) == hipSuccess && supported &&
+        hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
+      uint64_t keep = ~0ull;  // never trim the pool at synchronisation points
+      if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess) v = 1;
+    }
+    (void)hipGetLastError();
+  }
+  g_async_alloc.store(v);
+  return v == 1;
+}
+// *is_async tells dev_free_any how the block has to be returned.
+static int dev_alloc_any(odo_ctx* c, size_t bytes, void** out, bool* is_async) {
+  *is_async = false;
+  if (async_alloc_ready(c->device)) {
+    if (hipMallocAsync(out, bytes, c->stream) == hipSuccess) { *is_async = true; return 0; }
+    (void)hipGetLastError();
+  }
+  HIP_OK(hipMalloc(out, bytes));
+  return 0;
+}
+static void dev_free_any(odo_ctx* c, void* p, bool is_async) {
+  if (!p) return;
+  if (is_async && hipFreeAsync(p, c->stream) == hipSuccess) return;
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(p);
+}
 
 static int ctx_create(int device, int high_priority, odo_ctx** out);
 extern "C" int odo_ctx_create(int device, odo_ctx** out) { return ctx_create(device, 0, out); }
@@ -57,6 +103,7 @@ static int ctx_create(int device, int high_priority, odo_ctx** out) {
   HIP_OK(hipSetDevice(device));
   odo_ctx* c = new (std::nothrow) odo_ctx();
   if (!c) return fail("odo_ctx_create: out of memory");
+  memset(c, 0, sizeof(*c));
   c->device = device;
   if (high_priority) {
     int lo = 0, hi = 0;  // numerically lower = higher priority
@@ -67,6 +114,7 @@ static int ctx_create(int device, int high_priority, odo_ctx** out) {
   }
   HIP_OK(hipEventCreate(&c->ev0));
   HIP_OK(hipEventCreate(&c->ev1));
+  for (int i = 0; i < kStageSlots; i++) HIP_OK(hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming));
   *out = c;
   return 0;
 }
@@ -76,6 +124,10 @@ extern "C" int odo_ctx_destroy(odo_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
+  for (int i = 0; i < kStageSlots; i++) {
+    (void)hipEventDestroy(c->stage_ev[i]);
+    if (c->stage[i]) (void)hipHostFree(c->stage[i]);
+  }
   (void)hipStreamDestroy(c->stream);
   delete c;
   return 0;
@@ -109,16 +161,89 @@ extern "C" int odo_dev_free(odo_ctx* c, void* p) {
   HIP_OK(hipFree(p));
   return 0;
 }
+
+// ---- pinned host memory + uploads that do not stall -----------------------------------------------------------------
+// Host blocks handed out by odo_host_alloc are page-locked: an upload from one of them is a plain asynchronous DMA.
+// Uploads from any other host memory go through the context's pinned staging ring (one CPU copy, then the same DMA).
+// Either way the call returns as soon as the caller may reuse / release its buffer, without waiting for the device.
+#include <mutex>
+#include <map>
+static std::mutex g_pin_mu;
+static std::map<const char*, size_t> g_pinned;  // start -> bytes of every live odo_host_alloc block
+static bool host_is_pinned(const void* p, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  auto it = g_pinned.upper_bound((const char*)p);
+  if (it == g_pinned.begin()) return false;
+  --it;
+  return (const char*)p >= it->first && (const char*)p + bytes <= it->first + it->second;
+}
+extern "C" void* odo_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  g_pinned[(const char*)p] = bytes;
+  return p;
+}
+extern "C" void odo_host_free(void* p) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    g_pinned.erase((const char*)p);
+  }
+  (void)hipHostFree(p);
+}
+// dst (device, dense rows of row_bytes) <- src (host, pitch src_pitch), `rows` rows; asynchronous on the context's stream.
+static int upload_rows_async(odo_ctx* c, void* dst, const void* src, size_t src_pitch, size_t row_bytes, int rows) {
+  const size_t total = row_bytes * (size_t)rows;
+  const size_t span = src_pitch * (size_t)(rows - 1) + row_bytes;
+  if (host_is_pinned(src, span)) {
+    HIP_OK(hipMemcpy2DAsync(dst, row_bytes, src, src_pitch, row_bytes, rows, hipMemcpyHostToDevice, c->stream));
+    return 0;  // the block stays valid until odo_host_free, which the caller must not call before the stream has drained
+  }
+  const int slot = c->stage_next;
+  c->stage_next = (slot + 1) % kStageSlots;
+  if (c->stage_busy[slot]) { HIP_OK(hipEventSynchronize(c->stage_ev[slot])); c->stage_busy[slot] = 0; }
+  if (c->stage_cap[slot] < total) {
+    if (c->stage[slot]) HIP_OK(hipHostFree(c->stage[slot]));
+    c->stage[slot] = nullptr; c->stage_cap[slot] = 0;
+    HIP_OK(hipHostMalloc(&c->stage[slot], total, hipHostMallocDefault));
+    c->stage_cap[slot] = total;
+  }
+  if (src_pitch == row_bytes) memcpy(c->stage[slot], src, total);
+  else for (int y = 0; y < rows; y++) memcpy((char*)c->stage[slot] + (size_t)y * row_bytes, (const char*)src + (size_t)y * src_pitch, row_bytes);
+  HIP_OK(hipMemcpyAsync(dst, c->stage[slot], total, hipMemcpyHostToDevice, c->stream));
+  HIP_OK(hipEventRecord(c->stage_ev[slot], c->stream));
+  c->stage_busy[slot] = 1;
+  return 0;
+}
 extern "C" int odo_dev_upload(odo_ctx* c, void* dst, const void* src, size_t bytes) {
   if (!c) return fail("NULL ctx");
   HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
   HIP_OK(hipStreamSynchronize(c->stream));
   return 0;
 }
+extern "C" int odo_dev_upload_async(odo_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (!c || !dst || !src) return fail("NULL arg");
+  return upload_rows_async(c, dst, src, bytes, bytes, 1);
+}
 extern "C" int odo_dev_download(odo_ctx* c, void* dst, const void* src, size_t bytes) {
   if (!c) return fail("NULL ctx");
   HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_OK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+// Stream-ordered scratch for per-frame images of the drop-in path (see dev_alloc_any): free does not synchronise.
+extern "C" int odo_dev_alloc_async(odo_ctx* c, size_t bytes, void** out, int* is_async) {
+  if (!c || !out || !is_async) return fail("NULL arg");
+  HIP_OK(hipSetDevice(c->device));
+  bool a = false;
+  if (dev_alloc_any(c, bytes, out, &a)) return -1;
+  *is_async = a ? 1 : 0;
+  return 0;
+}
+extern "C" int odo_dev_free_async(odo_ctx* c, void* p, int is_async) {
+  if (!c) return fail("NULL ctx");
+  dev_free_any(c, p, is_async != 0);
   return 0;
 }
 
@@ -132,6 +257,7 @@ struct odo_pyr {
   int kind, levels, rows, cols;
   float* dev;      // all levels back to back
   float* staging;  // level-0-sized device copy of a host input (IMAGE kind: pyrDown reads the unsmoothed input)
+  bool dev_async, staging_async;  // how the two blocks were allocated (dev_alloc_any)
   size_t off[ODO_MAX_LEVELS];
   int r[ODO_MAX_LEVELS], c[ODO_MAX_LEVELS];
   unsigned long long version;  // bumped by every (re)build: keys the LM's keyframe point-list cache
@@ -181,7 +307,9 @@ static int pyr_build(odo_pyr* p, const float* img_dev, int smooth) {
   return 0;
 }
 
-static int pyr_alloc(odo_ctx* ctx, int rows, int cols, int levels, int kind, odo_pyr** out) {
+// pooled: stream-ordered allocation on ctx's stream (per-frame pyramids of the drop-in path, used on that stream only);
+// false: a plain allocation (the tracker's long-lived pyramids move between its two streams).
+static int pyr_alloc(odo_ctx* ctx, int rows, int cols, int levels, int kind, odo_pyr** out, bool pooled = true) {
   if (!ctx || !out) return fail("pyramid: NULL arg");
   *out = nullptr;
   if (levels < 1 || levels > ODO_MAX_LEVELS) return fail("pyramid: levels %d out of range", levels);
@@ -190,7 +318,7 @@ static int pyr_alloc(odo_ctx* ctx, int rows, int cols, int levels, int kind, odo
   odo_pyr* p = new (std::nothrow) odo_pyr();
   if (!p) return fail("out of memory");
   p->ctx = ctx; p->kind = kind; p->levels = levels; p->rows = rows; p->cols = cols;
-  p->dev = nullptr; p->staging = nullptr;
+  p->dev = nullptr; p->staging = nullptr; p->dev_async = p->staging_async = false;
   size_t tot = 0;
   int r = rows, c = cols;
   for (int l = 0; l < levels; l++) {
@@ -200,7 +328,12 @@ static int pyr_alloc(odo_ctx* ctx, int rows, int cols, int levels, int kind, odo
     if ((r < 1 || c < 1) && l + 1 < levels) { delete p; return fail("pyramid: image too small for %d levels", levels); }
   }
   HIP_OK(hipSetDevice(ctx->device));
-  HIP_OK(hipMalloc((void**)&p->dev, sizeof(float) * tot));
+  if (pooled) {
+    if (dev_alloc_any(ctx, sizeof(float) * tot, (void**)&p->dev, &p->dev_async)) { delete p; return -1; }
+  } else {
+    p->dev_async = false;
+    if (hipMalloc((void**)&p->dev, sizeof(float) * tot) != hipSuccess) { delete p; return fail("pyramid: hipMalloc failed"); }
+  }
   *out = p;
   return 0;
 }
@@ -212,17 +345,14 @@ extern "C" int odo_pyramid_create(odo_ctx* ctx, const float* img, int rows, int 
   if (stride_bytes < sizeof(float) * (size_t)cols) return fail("odo_pyramid_create: stride smaller than a row");
   odo_pyr* p = nullptr;
   if (pyr_alloc(ctx, rows, cols, levels, kind, &p)) return -1;
-  if (hipMalloc((void**)&p->staging, sizeof(float) * (size_t)rows * cols) != hipSuccess) {
+  if (dev_alloc_any(ctx, sizeof(float) * (size_t)rows * cols, (void**)&p->staging, &p->staging_async)) {
     odo_pyramid_destroy(p);
-    return fail("odo_pyramid_create: hipMalloc failed");
+    return fail("odo_pyramid_create: device allocation failed");
   }
-  hipError_t e = hipMemcpy2DAsync(p->staging, sizeof(float) * (size_t)cols, img, stride_bytes, sizeof(float) * (size_t)cols,
-                                  rows, hipMemcpyHostToDevice, ctx->stream);
-  if (e != hipSuccess) { odo_pyramid_destroy(p); return fail("odo_pyramid_create: upload failed: %s", hipGetErrorString(e)); }
-  // The caller may release `img` as soon as this returns (the reference's constructor copies synchronously):
-  // wait for the upload before handing control back. The pyramid kernels themselves stay asynchronous.
-  e = hipStreamSynchronize(ctx->stream);
-  if (e != hipSuccess) { odo_pyramid_destroy(p); return fail("odo_pyramid_create: upload failed: %s", hipGetErrorString(e)); }
+  // The caller may release `img` as soon as this returns (the reference's constructor copies synchronously): the image is
+  // copied into pinned staging memory on the spot (or, when it lives in an odo_host_alloc block, read by the DMA later —
+  // such a block must outlive the stream's pending work). Nothing here waits for the device.
+  if (upload_rows_async(ctx, p->staging, img, stride_bytes, sizeof(float) * (size_t)cols, rows)) { odo_pyramid_destroy(p); return -1; }
   if (pyr_build(p, p->staging, smooth)) { odo_pyramid_destroy(p); return -1; }
   *out = p;
   return 0;
@@ -265,9 +395,10 @@ extern "C" const float* odo_pyramid_level_dev(const odo_pyr* p, int level) {
 }
 extern "C" int odo_pyramid_destroy(odo_pyr* p) {
   if (!p) return 0;
-  (void)hipStreamSynchronize(p->ctx->stream);
-  if (p->dev) (void)hipFree(p->dev);
-  if (p->staging) (void)hipFree(p->staging);
+  // stream-ordered blocks go back to the pool behind whatever the stream still has queued on them; plain ones need the
+  // stream drained first
+  dev_free_any(p->ctx, p->dev, p->dev_async);
+  dev_free_any(p->ctx, p->staging, p->staging_async);
   delete p;
   return 0;
 }
@@ -1255,8 +1386,8 @@ static int depth_host(odo_depth* d, const float* left, const float* right, int r
   if (depth_ensure(d, rows, cols)) return -1;
   hipStream_t s = d->ctx->stream;
   const size_t n = (size_t)rows * cols;
-  HIP_OK(hipMemcpyAsync(d->d_left, left, sizeof(float) * n, hipMemcpyHostToDevice, s));
-  HIP_OK(hipMemcpyAsync(d->d_right, right, sizeof(float) * n, hipMemcpyHostToDevice, s));
+  if (upload_rows_async(d->ctx, d->d_left, left, sizeof(float) * (size_t)cols, sizeof(float) * (size_t)cols, rows)) return -1;
+  if (upload_rows_async(d->ctx, d->d_right, right, sizeof(float) * (size_t)cols, sizeof(float) * (size_t)cols, rows)) return -1;
   if (depth_run(d, d->d_left, d->d_right, rows, cols, d->d_val, d->d_disp, d->d_dep, stage)) return -1;
   HIP_OK(hipMemcpyAsync(val, d->d_val, n, hipMemcpyDeviceToHost, s));
   HIP_OK(hipMemcpyAsync(disp, d->d_disp, sizeof(float) * n, hipMemcpyDeviceToHost, s));
@@ -1279,7 +1410,9 @@ extern "C" int odo_depth_compute_dev(odo_depth* d, const float* left_dev, const 
   HIP_OK(hipSetDevice(d->ctx->device));
   if (depth_ensure(d, rows, cols)) return -1;
   if (depth_run(d, left_dev, right_dev, rows, cols, val_dev, disp_dev, dep_dev, 2)) return -1;
-  return depth_finish(d);
+  // outputs stay on the device: only the statistics are needed back, and they arrive through host-mapped memory behind the
+  // last launch of the job (no stream synchronisation)
+  return depth_finish(d, false);
 }
 
 extern "C" int odo_depth_report(const odo_depth* d, int* iters, float* cost, int* n_selected, int* n_matched, int* n_valid) {

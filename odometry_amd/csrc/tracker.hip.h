@@ -115,12 +115,12 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
   ok = ok && odo_depth_create(t->ctx_b, p->grad_th, p->ssd_th, p->photo_th, p->min_depth, p->max_depth, p->depth_lambda,
                               p->depth_huber_delta, p->depth_precision, p->depth_max_iters, p->boundary, &p->K, p->baseline,
                               p->max_residuals, p->max_disparity, p->any_size, &t->depth) == 0;
-  ok = ok && pyr_alloc(t->ctx_a, p->rows, p->cols, p->levels, ODO_PYR_IMAGE, &t->cur_img) == 0;
-  ok = ok && pyr_alloc(t->ctx_a, p->rows, p->cols, p->levels, ODO_PYR_IMAGE, &t->next_img) == 0;
-  ok = ok && pyr_alloc(t->ctx_b, p->rows, p->cols, p->levels, ODO_PYR_IMAGE, &t->kf_img) == 0;
-  ok = ok && pyr_alloc(t->ctx_b, p->rows, p->cols, p->levels, ODO_PYR_DEPTH, &t->kf_dep) == 0;
-  ok = ok && pyr_alloc(t->ctx_b, p->rows, p->cols, p->levels, ODO_PYR_IMAGE, &t->pre_img) == 0;
-  ok = ok && pyr_alloc(t->ctx_b, p->rows, p->cols, p->levels, ODO_PYR_DEPTH, &t->pre_dep) == 0;
+  ok = ok && pyr_alloc(t->ctx_a, p->rows, p->cols, p->levels, ODO_PYR_IMAGE, &t->cur_img, false) == 0;
+  ok = ok && pyr_alloc(t->ctx_a, p->rows, p->cols, p->levels, ODO_PYR_IMAGE, &t->next_img, false) == 0;
+  ok = ok && pyr_alloc(t->ctx_b, p->rows, p->cols, p->levels, ODO_PYR_IMAGE, &t->kf_img, false) == 0;
+  ok = ok && pyr_alloc(t->ctx_b, p->rows, p->cols, p->levels, ODO_PYR_DEPTH, &t->kf_dep, false) == 0;
+  ok = ok && pyr_alloc(t->ctx_b, p->rows, p->cols, p->levels, ODO_PYR_IMAGE, &t->pre_img, false) == 0;
+  ok = ok && pyr_alloc(t->ctx_b, p->rows, p->cols, p->levels, ODO_PYR_DEPTH, &t->pre_dep, false) == 0;
   ok = ok && hipMalloc((void**)&t->d_val, n) == hipSuccess && hipMalloc((void**)&t->d_disp, sizeof(float) * n) == hipSuccess &&
        hipMalloc((void**)&t->d_dep, sizeof(float) * n) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&t->ev_inputs, hipEventDisableTiming) == hipSuccess;

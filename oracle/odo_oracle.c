@@ -454,8 +454,27 @@ static float tdist_scale(const float* r, int n) {
  * separate fp32 passes (ref: :129,145-149). Same per-pixel arithmetic as pixel_row; the sums are fp32, so its
  * trajectory is not bit-comparable with the oracle proper — it exists only so that the CPU time of the reference's
  * shape can be reported next to the fused restatement. Selected with orc_set_reference_shape(1). */
-static int g_reference_shape = 0;
+static int g_reference_shape = 0;   /* 1: sequential fp32 sums; 2: eight strided fp32 partial sums + a pairwise combine (the
+                                      * association of an AVX2 reduction, which is what Eigen emits under -mavx2) */
 void orc_set_reference_shape(int on) { g_reference_shape = on; }
+static float dot_f32(const float* a, size_t sa, const float* b, size_t sb, const float* c, int n) {
+  /* sum_i a[i*sa] * b[i*sb] (* c[i] when c != NULL), fp32, association per g_reference_shape */
+  if (g_reference_shape != 2) {
+    float s = 0.0f;
+    for (int i = 0; i < n; i++) s += c ? a[(size_t)i * sa] * c[i] * b[(size_t)i * sb] : a[(size_t)i * sa] * b[(size_t)i * sb];
+    return s;
+  }
+  float lane[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int i = 0;
+  for (; i + 8 <= n; i += 8)
+    for (int k = 0; k < 8; k++) {
+      const float p = c ? a[(size_t)(i + k) * sa] * c[i + k] * b[(size_t)(i + k) * sb] : a[(size_t)(i + k) * sa] * b[(size_t)(i + k) * sb];
+      lane[k] += p;
+    }
+  float s = ((lane[0] + lane[4]) + (lane[2] + lane[6])) + ((lane[1] + lane[5]) + (lane[3] + lane[7]));
+  for (; i < n; i++) s += c ? a[(size_t)i * sa] * c[i] * b[(size_t)i * sb] : a[(size_t)i * sa] * b[(size_t)i * sb];
+  return s;
+}
 static volatile float g_two = 2.0f;  /* keeps the per-pixel pow() calls from being hoisted */
 
 static int lm_accumulate_reference_shape(const float* I1, const float* I2, const float* D1, int rows, int cols, int level,
@@ -496,8 +515,7 @@ static int lm_accumulate_reference_shape(const float* I1, const float* I2, const
     W[i] = w;
   }
   /* :129 err = r^T W r / N */
-  float err = 0.0f;
-  for (int i = 0; i < n; i++) err += r2[i] * W[i] * r2[i];
+  const float err = dot_f32(r2, 1, r2, 1, W, n);
   /* :145 JtW = J^T * W.asDiagonal(), a 6 x N temporary */
   float* JtW = (float*)malloc(sizeof(float) * (size_t)n * 6);
   for (int a = 0; a < 6; a++)
@@ -505,14 +523,8 @@ static int lm_accumulate_reference_shape(const float* I1, const float* I2, const
   /* :146 JtWJ = JtW * J (all 36 entries), :149 b = -JtW * r */
   float A[6][6], b[6];
   for (int a = 0; a < 6; a++) {
-    for (int c = 0; c < 6; c++) {
-      float sum = 0.0f;
-      for (int i = 0; i < n; i++) sum += JtW[(size_t)a * n + i] * J2[(size_t)i * 6 + c];
-      A[a][c] = sum;
-    }
-    float sb = 0.0f;
-    for (int i = 0; i < n; i++) sb += JtW[(size_t)a * n + i] * r2[i];
-    b[a] = sb;
+    for (int c = 0; c < 6; c++) A[a][c] = dot_f32(JtW + (size_t)a * n, 1, J2 + c, 6, NULL, n);
+    b[a] = dot_f32(JtW + (size_t)a * n, 1, r2, 1, NULL, n);
   }
   int k = 0;
   for (int a = 0; a < 6; a++)
@@ -605,7 +617,76 @@ static void solve_damped(const double acc[29], float lambda, float delta[6]) {
   }
   for (int c = 0; c < 6; c++) delta[c] = (float)xs[c];
 }
-void orc_solve_damped(const double acc[29], float lambda, float delta[6]) { solve_damped(acc, lambda, delta); }
+/* Sensitivity study only (oracle/sensitivity.py): the reference's own solver shape — fp32 system, fp32 column-pivoted
+ * Householder QR (Eigen's colPivHouseholderQr().solve(), ref: src/lm_optimizer.cpp:150-151; Eigen is not vendored: restated
+ * from the textbook algorithm — pivot on the largest remaining column norm, reflect, rank threshold eps * 6 * |max pivot|,
+ * back-substitute the leading rank x rank block, undo the permutation). Selected with orc_set_solver(1). */
+static int g_solver = 0;
+void orc_set_solver(int s) { g_solver = s; }
+static void solve_damped_qr_f32(const double acc[29], float lambda, float delta[6]) {
+  float A[6][6], b[6];
+  int k = 0;
+  for (int a = 0; a < 6; a++)
+    for (int c = a; c < 6; c++) { A[a][c] = (float)acc[k]; A[c][a] = (float)acc[k]; k++; }
+  for (int a = 0; a < 6; a++) { A[a][a] = A[a][a] + lambda * A[a][a]; b[a] = -(float)acc[21 + a]; }   /* :147-150 */
+  int perm[6] = {0, 1, 2, 3, 4, 5};
+  float maxpiv = 0.0f;
+  int rank = 6;
+  for (int c = 0; c < 6; c++) {
+    int best = c;
+    float bn = -1.0f;
+    for (int j = c; j < 6; j++) {
+      float nn = 0.0f;
+      for (int i = c; i < 6; i++) nn += A[i][j] * A[i][j];
+      if (nn > bn) { bn = nn; best = j; }
+    }
+    if (best != c) {
+      for (int i = 0; i < 6; i++) { const float t = A[i][c]; A[i][c] = A[i][best]; A[i][best] = t; }
+      const int t = perm[c]; perm[c] = perm[best]; perm[best] = t;
+    }
+    float tail = 0.0f;
+    for (int i = c + 1; i < 6; i++) tail += A[i][c] * A[i][c];
+    const float c0 = A[c][c];
+    float beta, tau;
+    if (tail == 0.0f) { beta = c0; tau = 0.0f; }
+    else {
+      beta = sqrtf(c0 * c0 + tail);
+      if (c0 >= 0.0f) beta = -beta;
+      for (int i = c + 1; i < 6; i++) A[i][c] = A[i][c] / (c0 - beta);   /* essential part of the reflector */
+      tau = (beta - c0) / beta;
+    }
+    /* apply H = I - tau v v^T (v = [1; essential]) to the trailing columns and to b */
+    if (tau != 0.0f) {
+      for (int j = c + 1; j < 6; j++) {
+        float d = A[c][j];
+        for (int i = c + 1; i < 6; i++) d += A[i][c] * A[i][j];
+        d *= tau;
+        A[c][j] -= d;
+        for (int i = c + 1; i < 6; i++) A[i][j] -= d * A[i][c];
+      }
+      float d = b[c];
+      for (int i = c + 1; i < 6; i++) d += A[i][c] * b[i];
+      d *= tau;
+      b[c] -= d;
+      for (int i = c + 1; i < 6; i++) b[i] -= d * A[i][c];
+    }
+    A[c][c] = beta;
+    if (fabsf(beta) > maxpiv) maxpiv = fabsf(beta);
+  }
+  const float thr = 1.1920929e-07f * 6.0f * maxpiv;
+  rank = 0;
+  for (int c = 0; c < 6; c++) if (fabsf(A[c][c]) > thr) rank++; else break;
+  float xs[6] = {0, 0, 0, 0, 0, 0};
+  for (int c = rank - 1; c >= 0; c--) {
+    float sum = b[c];
+    for (int j = c + 1; j < rank; j++) sum -= A[c][j] * xs[j];
+    xs[c] = sum / A[c][c];
+  }
+  for (int c = 0; c < 6; c++) delta[perm[c]] = xs[c];
+}
+void orc_solve_damped(const double acc[29], float lambda, float delta[6]) {
+  if (g_solver == 1) solve_damped_qr_f32(acc, lambda, delta); else solve_damped(acc, lambda, delta);
+}
 
 /* LevenbergMarquardtOptimizer::OptimizeCameraPose (ref: src/lm_optimizer.cpp:73-160).
  * img1/dep1 = keyframe pyramids, img2 = current pyramid, each stored level after level.
@@ -662,7 +743,7 @@ int orc_lm_solve(const float* img1, const float* dep1, const float* img2, int ro
       if (tr) { tr->accepted = accepted; tr->stop = stop; tr->lambda_after = lambda; }
       if (stop) break;
       float dv[6];
-      solve_damped(acc, lambda, dv);                                      /* :145-151 */
+      orc_solve_damped(acc, lambda, dv);                                  /* :145-151 */
       se3_exp(dv, &delta);                                                /* :152 */
       se3_left_update(&delta, &cur, &inc);                                /* :153 */
       if (tr) memcpy(tr->delta, dv, sizeof(dv));
@@ -690,6 +771,9 @@ static int cmp_float(const void* a, const void* b) {
 /* ComputeSsdPattern8Sse (ref: src/depth_estimate.cpp:435-453): AVX lane order and hadd tree
  * ((s0+s1)+(s2+s3)) + ((s4+s5)+(s6+s7)) with s0=(0,+2) s1=(-1,+1) s2=(+2,0) s3=(0,0) s4=(-2,0)
  * s5=(+1,-1) s6=(-1,-1) s7=(0,-2) as (dx,dy). L[8] holds the left taps in that lane order. */
+#if defined(__GNUC__) && !defined(__clang__)
+__attribute__((optimize("fp-contract=off")))  /* the reference's SSD is AVX intrinsics: no contraction there under any flag */
+#endif
 static float ssd8(const float L[8], const float* img, int cols, int x, int y) {
   const float* pp = img + (size_t)(y - 2) * cols;
   const float* p = img + (size_t)(y - 1) * cols;

@@ -39,6 +39,50 @@ def test_cpp_runner_over_shim(tmp_path, kitti_seq):
     assert "LM Optimizer failed! Invalid camera pointer!" in out.stdout   # the reference's null-camera warning
 
 
+def _build(tmp_path, src, name):
+    exe = str(tmp_path / name)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, src), "-o", exe,
+                           "-L" + os.path.join(ROOT, "odometry_amd", "lib"), "-lodometry_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "odometry_amd", "lib")])
+    return exe
+
+
+def test_shim_mat_device_mirror(tmp_path):
+    """The stand-in Mat's device mirror (uploads deduplicated, outputs downloaded lazily) never serves stale pixels: writes
+    through the Mat or a header copy invalidate it, device-side results are fetched on first host access."""
+    exe = _build(tmp_path, "tests/shim_mat_harness.cpp", "shim_mat_harness")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().splitlines()[-1].startswith("OK"), out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_shim_poses_bit_identical_to_tracker(tmp_path):
+    """The drop-in classes (host Mats, PCIe inside) and odo_tracker (device-resident frames) run the same kernels in the same
+    order: pose_to_keyframe of every frame is bit-identical, and the timed mode reproduces it pass after pass."""
+    from odometry_amd import api, synth
+    seq = synth.make_sequence(24, seed=2)
+    L, R = seq["left"], seq["right"]
+    exe = _build(tmp_path, "examples/run_odometry_synth.cpp", "run_odometry_synth")
+    frames = str(tmp_path / "frames.bin")
+    with open(frames, "wb") as f:
+        np.array([len(L), L[0].shape[0], L[0].shape[1]], np.int32).tofile(f)
+        for l, r in zip(L, R):
+            l.astype(np.float32).tofile(f)
+            r.astype(np.float32).tofile(f)
+    rel = str(tmp_path / "rel.bin")
+    out = subprocess.run([exe, frames, "--time", "2", "--rel-bin", rel], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    m = re.search(r"SHIM_FPS ([\d.]+) FRAMES (\d+) PASSES 2", out.stderr)
+    assert m and float(m.group(1)) > 0 and int(m.group(2)) == 2 * (len(L) - 1)
+    got = np.fromfile(rel, np.float32).reshape(-1, 4, 4).transpose(0, 2, 1)   # column-major on file
+    trk = api.Tracker(0)
+    dev = [(trk.upload_frame(l), trk.upload_frame(r)) for l, r in zip(L, R)]
+    trk.init(*dev[0])
+    for k in range(1, len(L)):
+        T = trk.track(*dev[k])["pose_to_keyframe"]
+        assert np.array_equal(T, got[k - 1]), f"frame {k}"
+    trk.close()
+
+
 def test_cpp_kitti_runner_with_png_ingest(tmp_path, kitti_seq):
     """examples/run_odometry_kitti.cpp: KITTI directory layout, PNG decoding, tracking, error evaluation, KITTI pose file."""
     from oracle import runner as orunner

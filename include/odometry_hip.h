@@ -138,6 +138,14 @@ int odo_lm_event_stats(const odo_lm* lm, double* total_us, long* launches, long*
                        double* algorithmic_bytes);
 /* Share of the above spent in the single-workgroup coarse-level kernel (one launch per Solve). */
 int odo_lm_event_stats2(const odo_lm* lm, double* coarse_us, long* coarse_launches);
+/* Sampling of the current image at the warped point. ODO_SAMPLE_FLOOR (default, parity mode) is what the reference does:
+ * I2 at floor(u), floor(v), central-difference gradient at that pixel (ref: src/lm_optimizer.cpp:208-217,
+ * include/image_processing_global.h:62-69). ODO_SAMPLE_BILINEAR is a NON-PARITY option (BASELINE.json north_star: "bilinear
+ * sample"): I2 interpolated in the 2x2 cell around (u, v), gradient = derivative of that interpolant, points whose cell
+ * leaves the image skipped; everything else (geometric Jacobian at the un-warped point, weights, LM schedule) unchanged. It
+ * has its own oracle mode (orc_set_sampling) and its own parity tests. */
+enum { ODO_SAMPLE_FLOOR = 0, ODO_SAMPLE_BILINEAR = 1 };
+int odo_lm_set_sampling(odo_lm* lm, int sampling);
 /* Iteration space of the residual kernel: 0 = automatic (per keyframe and level: a compacted point list when at most
  * half of the interior pixels carry depth, the dense scan of the reference otherwise), 1 = always the dense scan,
  * 2 = always the point list. All three evaluate the same per-point arithmetic. */

@@ -225,6 +225,10 @@ class LevenbergMarquardtOptimizer:
                                               C.byref(mean), C.byref(mn), C.byref(b), C.byref(n)), "odo_lm_time_eval")
         return dict(mean_us=mean.value, min_us=mn.value, bytes=b.value, n_points=n.value)
 
+    def set_sampling(self, bilinear):
+        """False = the reference's floor sampling (parity mode, default); True = bilinear sampling (non-parity option)."""
+        L.check(self.ctx.lib.odo_lm_set_sampling(self.h, 1 if bilinear else 0), "odo_lm_set_sampling")
+
     def set_mode(self, mode):
         L.check(self.ctx.lib.odo_lm_set_mode(self.h, mode), "odo_lm_set_mode")
 

@@ -119,22 +119,26 @@ __device__ __forceinline__ PointK make_point_shared(int x, int y, float inv_dept
 // odo::warp_point with one fp64 reciprocal for both image coordinates (ref: include/image_processing_global.h:42-59).
 // Exact whenever t0, t1 are finite and t2 is a finite positive float (every float is a normal double and no quotient of
 // two of them leaves the double range); the caller guards the pose.
-__device__ __forceinline__ bool warp_point_shared(const PointK& p, const float* T, const LevelK& k, int rows, int cols, int* ui, int* vi) {
+__device__ __forceinline__ bool warp_uv_shared(const PointK& p, const float* T, const LevelK& k, float* u, float* v) {
   const float t0 = ((T[0] * p.X + T[4] * p.Y) + T[8] * p.Z) + T[12];
   const float t1 = ((T[1] * p.X + T[5] * p.Y) + T[9] * p.Z) + T[13];
   const float t2 = ((T[2] * p.X + T[6] * p.Y) + T[10] * p.Z) + T[14];
   if (!(t2 > 0.0f)) return false;
   const double t2d = (double)t2;
   const double y = rcp_refined_d(t2d);
-  const float u = (float)(div_shared_d(k.fl * (double)t0, t2d, y) + (double)k.cx);
-  const float v = (float)(div_shared_d(k.fl * (double)t1, t2d, y) + (double)k.cy);
+  *u = (float)(div_shared_d(k.fl * (double)t0, t2d, y) + (double)k.cx);
+  *v = (float)(div_shared_d(k.fl * (double)t1, t2d, y) + (double)k.cy);
+  return true;
+}
+__device__ __forceinline__ bool warp_point_shared(const PointK& p, const float* T, const LevelK& k, int rows, int cols, int* ui, int* vi) {
+  float u, v;
+  if (!warp_uv_shared(p, T, k, &u, &v)) return false;
   const float fu = floorf(u), fv = floorf(v);
   if (!(fu < (float)cols) || !(fv < (float)rows) || !(fu >= 0.0f) || !(fv >= 0.0f)) return false;
   *ui = (int)fu;
   *vi = (int)fv;
   return true;
 }
-
 #endif  // ODO_DENSE_KERNELS
 
 // ---------------------------------------------------------------------------------------------
@@ -307,7 +311,9 @@ __device__ __forceinline__ void dense_eval_block(const DenseLevel& L, int b, con
 // ---------------------------------------------------------------------------------------------
 struct DensePix {
   float X, Y, Z, i1;
-  float tc, tl, tr, tu, td;  // I2 at the floor-sampled pixel and its index-clamped neighbours (ref: h:62-69)
+  float tc, tl, tr, tu, td;  // I2 at the floor-sampled pixel and its index-clamped neighbours (ref: h:62-69); in bilinear
+                             // mode the four cell corners: tc = (x0, y0), tr = (x0+1, y0), td = (x0, y0+1), tl = (x0+1, y0+1)
+  float fa, fb;              // bilinear mode: position inside the cell
   bool hit;                  // the pixel produces a residual
 };
 
@@ -323,24 +329,31 @@ __device__ __forceinline__ void dense_stage_a(int x, int y, float d, float i1, b
   p.X = 0.0f; p.Y = 0.0f; p.Z = 0.0f;
   int ui = 0, vi = 0;
   bool hit = false;
+  float fa = 0.0f, fb = 0.0f;
+  const bool bil = L.k.bilinear != 0;  // wave-uniform
   if (depth_valid(d)) {  // :193 (d == 0 stands for "outside the image" too)
-    if (fast) {
-      point_xyz_shared(x, y, d, L.k, flf, yfl, &p.X, &p.Y, &p.Z);
-      hit = warp_point_shared(p, T, L.k, L.rows, L.cols, &ui, &vi);
+    if (fast) point_xyz_shared(x, y, d, L.k, flf, yfl, &p.X, &p.Y, &p.Z);
+    else point_xyz(x, y, d, L.k, &p.X, &p.Y, &p.Z);
+    if (bil) {
+      float u, v;
+      hit = (fast ? warp_uv_shared(p, T, L.k, &u, &v) : warp_point_uv(p, T, L.k, &u, &v)) &&
+            bilinear_cell(u, v, L.rows, L.cols, &ui, &vi, &fa, &fb);
     } else {
-      point_xyz(x, y, d, L.k, &p.X, &p.Y, &p.Z);
-      hit = warp_point(p, T, L.k, L.rows, L.cols, &ui, &vi);
+      hit = fast ? warp_point_shared(p, T, L.k, L.rows, L.cols, &ui, &vi) : warp_point(p, T, L.k, L.rows, L.cols, &ui, &vi);
     }
   }
   if (!hit) { ui = 0; vi = 0; }  // the taps are issued unconditionally (no control flow around the loads): a pixel that
                                  // produces no residual reads pixel (0, 0) and ignores it
-  q->X = p.X; q->Y = p.Y; q->Z = p.Z; q->i1 = i1; q->hit = hit;
-  const int px = (ui - 1 >= 0) ? ui - 1 : 0, nx = (ui + 1 < L.cols) ? ui + 1 : L.cols - 1;
-  const int py = (vi - 1 >= 0) ? vi - 1 : 0, ny = (vi + 1 < L.rows) ? vi + 1 : L.rows - 1;
+  q->X = p.X; q->Y = p.Y; q->Z = p.Z; q->i1 = i1; q->hit = hit; q->fa = fa; q->fb = fb;
+  // floor mode: left / right / up / down neighbours, index-clamped; bilinear mode: the cell's other three corners (the cell
+  // is inside the image for a hit, and for a miss ui = vi = 0 keeps every index in range as long as the image is >= 2 x 2)
+  const int px = bil ? ((ui + 1 < L.cols && vi + 1 < L.rows) ? ui + 1 : ui) : ((ui - 1 >= 0) ? ui - 1 : 0);
+  const int nx = (ui + 1 < L.cols) ? ui + 1 : L.cols - 1;
+  const int py = bil ? vi : ((vi - 1 >= 0) ? vi - 1 : 0), ny = (vi + 1 < L.rows) ? vi + 1 : L.rows - 1;
   const unsigned cols = (unsigned)L.cols;
   const unsigned rowo = (unsigned)vi * cols;
   q->tc = ld_f32(L.I2, (rowo + (unsigned)ui) * 4u);
-  q->tl = ld_f32(L.I2, (rowo + (unsigned)px) * 4u);
+  q->tl = ld_f32(L.I2, ((bil ? (unsigned)ny * cols : rowo) + (unsigned)px) * 4u);
   q->tr = ld_f32(L.I2, (rowo + (unsigned)nx) * 4u);
   q->tu = ld_f32(L.I2, ((unsigned)py * cols + (unsigned)ui) * 4u);
   q->td = ld_f32(L.I2, ((unsigned)ny * cols + (unsigned)ui) * 4u);
@@ -355,7 +368,8 @@ __device__ __forceinline__ void dense_stage_b(const DensePix& q, bool fast, cons
   if (fast) point_jacobian_shared(&p, L.k, flf);
   else point_jacobian(&p, L.k);
   float r, J[6];
-  residual_jacobian_taps(p, q.tc, q.tl, q.tr, q.tu, q.td, &r, J);
+  if (L.k.bilinear) residual_jacobian_bilinear(p, q.tc, q.tr, q.td, q.tl, q.fa, q.fb, &r, J);
+  else residual_jacobian_taps(p, q.tc, q.tl, q.tr, q.tu, q.td, &r, J);
   const float w = robust_weight(r, robust, huber_delta, scale_sqr);
   if (kFlags & 2) {
     acc[27] += (double)(((((J[0] + J[1]) + J[2]) + J[3]) + J[4]) + J[5]) * (double)(r * w);

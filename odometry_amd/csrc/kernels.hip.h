@@ -480,10 +480,8 @@ __global__ void __launch_bounds__(kLmBlock) lm_residual_list_kernel(PointList pl
   for (int q = 0; q < ODO_NACC; q++) acc[q] = 0.0;
   for (int idx = blockIdx.x * kLmBlock + threadIdx.x; idx < n; idx += gridDim.x * kLmBlock) {
     const PointK p = load_point(pl, idx);
-    int ui, vi;
-    if (!warp_point(p, T, k, rows, cols, &ui, &vi)) continue;
     float r, J[6];
-    residual_jacobian(p, I2, rows, cols, ui, vi, &r, J);
+    if (!point_residual(p, T, k, I2, rows, cols, &r, J)) continue;
     const float w = robust_weight(r, robust, huber_delta, scale_sqr);
     accumulate_row(acc, r, w, J);
   }
@@ -501,9 +499,8 @@ __global__ void __launch_bounds__(kLmBlock) lm_residual_only_list_kernel(PointLi
   for (int i = 0; i < 16; i++) T[i] = st->T[i];
   for (int idx = blockIdx.x * kLmBlock + threadIdx.x; idx < n; idx += gridDim.x * kLmBlock) {
     const PointK p = load_point(pl, idx);
-    int ui, vi;
-    float r = __builtin_nanf("");
-    if (warp_point(p, T, k, rows, cols, &ui, &vi)) r = I2[(size_t)vi * cols + ui] - p.i1;
+    float r = __builtin_nanf(""), rr;
+    if (point_residual_only(p, T, k, I2, rows, cols, &rr)) r = rr;
     res[idx] = r;
   }
 }
@@ -525,8 +522,8 @@ __global__ void __launch_bounds__(kLmBlock) lm_residual_only_kernel(LevelView v,
     float r = __builtin_nanf("");
     if (depth_valid(d)) {
       const PointK p = make_point(x, y, d, v.I1[o], k);
-      int ui, vi;
-      if (warp_point(p, T, k, v.rows, v.cols, &ui, &vi)) r = v.I2[(size_t)vi * v.cols + ui] - p.i1;
+      float rr;
+      if (point_residual_only(p, T, k, v.I2, v.rows, v.cols, &rr)) r = rr;
     }
     res[idx] = r;
   }
@@ -1040,9 +1037,7 @@ __global__ void __launch_bounds__(kLmBlock) lm_step_kernel(StepArgs a) {
       bool valid = false;
       if (idx < L.n) {
         const PointK p = load_point(L.pl, idx);
-        int ui, vi;
-        if (warp_point(p, T, L.k, L.rows, L.cols, &ui, &vi)) {
-          residual_jacobian(p, L.I2, L.rows, L.cols, ui, vi, &r, J);
+        if (point_residual(p, T, L.k, L.I2, L.rows, L.cols, &r, J)) {
           w = robust_weight(r, a.robust, a.huber_delta, 1.0f);
           valid = true;
         }
@@ -1120,9 +1115,7 @@ __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int
       bool valid = false;
       if (idx < L.n) {
         const PointK p = load_point(L.pl, idx);
-        int ui, vi;
-        if (warp_point(p, T, L.k, L.rows, L.cols, &ui, &vi)) {
-          residual_jacobian(p, L.I2, L.rows, L.cols, ui, vi, &r, J);
+        if (point_residual(p, T, L.k, L.I2, L.rows, L.cols, &r, J)) {
           w = robust_weight(r, a.robust, a.huber_delta, 1.0f);
           valid = true;
         }

@@ -33,6 +33,7 @@ namespace odo {
 struct LevelK {
   double fl;   // f0 / 2^level
   float cx, cy;
+  int bilinear;  // 0 = the reference's floor sampling (parity mode); 1 = bilinear sampling (odo_lm_set_sampling, non-parity)
 };
 
 ODO_HD float cx_level(float c, int level) {
@@ -47,6 +48,7 @@ ODO_HD LevelK make_level_k(float f0, float cx0, float cy0, int level) {
   k.fl = (double)f0 / s;
   k.cx = cx_level(cx0, level);
   k.cy = cx_level(cy0, level);
+  k.bilinear = 0;
   return k;
 }
 
@@ -99,15 +101,21 @@ ODO_HD PointK make_point(int x, int y, float inv_depth, float i1, const LevelK& 
   return p;
 }
 
-// Warp by T (column-major 4x4), project, floor. Returns false when the point is skipped
-// (ref: image_processing_global.h:42-59). ui/vi = floor(u), floor(v).
-ODO_HD bool warp_point(const PointK& p, const float* T, const LevelK& k, int rows, int cols, int* ui, int* vi) {
+// Warp by T (column-major 4x4) and project (ref: image_processing_global.h:42-51). Returns false when the point lies
+// behind the camera (:43-46).
+ODO_HD bool warp_point_uv(const PointK& p, const float* T, const LevelK& k, float* u, float* v) {
   const float t0 = ((T[0] * p.X + T[4] * p.Y) + T[8] * p.Z) + T[12];
   const float t1 = ((T[1] * p.X + T[5] * p.Y) + T[9] * p.Z) + T[13];
   const float t2 = ((T[2] * p.X + T[6] * p.Y) + T[10] * p.Z) + T[14];
   if (!(t2 > 0.0f)) return false;
-  const float u = (float)(k.fl * (double)t0 / (double)t2 + (double)k.cx);
-  const float v = (float)(k.fl * (double)t1 / (double)t2 + (double)k.cy);
+  *u = (float)(k.fl * (double)t0 / (double)t2 + (double)k.cx);
+  *v = (float)(k.fl * (double)t1 / (double)t2 + (double)k.cy);
+  return true;
+}
+// ... then floor. Returns false when the point is skipped (ref: image_processing_global.h:54-59). ui/vi = floor(u), floor(v).
+ODO_HD bool warp_point(const PointK& p, const float* T, const LevelK& k, int rows, int cols, int* ui, int* vi) {
+  float u, v;
+  if (!warp_point_uv(p, T, k, &u, &v)) return false;
   const float fu = floorf(u), fv = floorf(v);
   if (!(fu < (float)cols) || !(fv < (float)rows) || !(fu >= 0.0f) || !(fv >= 0.0f)) return false;
   *ui = (int)fu;
@@ -134,6 +142,65 @@ ODO_HD void residual_jacobian(const PointK& p, const float* I2, int rows, int co
   const int py = (vi - 1 >= 0) ? vi - 1 : 0, ny = (vi + 1 < rows) ? vi + 1 : rows - 1;
   const float* row = I2 + (size_t)vi * cols;
   residual_jacobian_taps(p, row[ui], row[px], row[nx], I2[(size_t)py * cols + ui], I2[(size_t)ny * cols + ui], r, J);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bilinear sampling — a NON-PARITY option (BASELINE.json north_star names it; the reference samples at floor(u), floor(v),
+// ref: lm_optimizer.cpp:208-217, so the default stays floor). The warped point (u, v) lies in the cell of the four pixels
+// (x0, y0) .. (x0 + 1, y0 + 1), x0 = floor(u), y0 = floor(v), a = u - x0, b = v - y0; I2 is interpolated inside the cell and
+// the image gradient is the derivative of that interpolant (so the objective is continuous in the pose and the Jacobian is
+// its true derivative). The geometric Jacobian still comes from the un-warped point (:219-234), as in parity mode. A point
+// whose cell is not entirely inside the image is skipped. Fixed operation order, fp32, one rounding per operation.
+// ---------------------------------------------------------------------------------------------
+ODO_HD bool bilinear_cell(float u, float v, int rows, int cols, int* x0, int* y0, float* a, float* b) {
+  const float fu = floorf(u), fv = floorf(v);
+  if (!(fu >= 0.0f) || !(fv >= 0.0f) || !(fu + 1.0f < (float)cols) || !(fv + 1.0f < (float)rows)) return false;
+  *x0 = (int)fu; *y0 = (int)fv;
+  *a = u - fu; *b = v - fv;
+  return true;
+}
+ODO_HD void residual_jacobian_bilinear(const PointK& p, float i00, float i10, float i01, float i11, float a, float b, float* r,
+                                       float J[6]) {
+  const float dx0 = i10 - i00, dx1 = i11 - i01;      // horizontal differences on the upper / lower edge of the cell
+  const float top = i00 + a * dx0, bot = i01 + a * dx1;
+  const float val = top + b * (bot - top);
+  const float gx = dx0 + b * (dx1 - dx0);
+  const float dy0 = i01 - i00, dy1 = i11 - i10;      // vertical differences on the left / right edge
+  const float gy = dy0 + a * (dy1 - dy0);
+  *r = val - p.i1;
+  J[0] = gx * p.fx_z + gy * 0.0f;
+  J[1] = gx * 0.0f + gy * p.fx_z;
+  J[2] = gx * p.jw02 + gy * p.jw12;
+  J[3] = gx * p.jw03 + gy * p.jw13;
+  J[4] = gx * p.jw04 + gy * p.jw14;
+  J[5] = gx * p.jw05 + gy * p.jw15;
+}
+// Warp + sample + Jacobian row in the level's sampling mode. Returns false when the point produces no residual.
+ODO_HD bool point_residual(const PointK& p, const float* T, const LevelK& k, const float* I2, int rows, int cols, float* r,
+                           float J[6]) {
+  if (k.bilinear) {
+    float u, v, a, b;
+    int x0, y0;
+    if (!warp_point_uv(p, T, k, &u, &v) || !bilinear_cell(u, v, rows, cols, &x0, &y0, &a, &b)) return false;
+    const float* r0 = I2 + (size_t)y0 * cols + x0;
+    residual_jacobian_bilinear(p, r0[0], r0[1], r0[cols], r0[cols + 1], a, b, r, J);
+    return true;
+  }
+  int ui, vi;
+  if (!warp_point(p, T, k, rows, cols, &ui, &vi)) return false;
+  residual_jacobian(p, I2, rows, cols, ui, vi, r, J);
+  return true;
+}
+// The residual alone (t-distribution scale pass, ref: lm_optimizer.cpp:338-358).
+ODO_HD bool point_residual_only(const PointK& p, const float* T, const LevelK& k, const float* I2, int rows, int cols, float* r) {
+  if (k.bilinear) {
+    float J[6];
+    return point_residual(p, T, k, I2, rows, cols, r, J);
+  }
+  int ui, vi;
+  if (!warp_point(p, T, k, rows, cols, &ui, &vi)) return false;
+  *r = I2[(size_t)vi * cols + ui] - p.i1;
+  return true;
 }
 
 // Robust weight (ref: lm_optimizer.cpp:249-262). scale_sqr only used by mode 2.

@@ -406,6 +406,7 @@ extern "C" int odo_pyramid_destroy(odo_pyr* p) {
 // ------------------------------------------------------------------------------------------------
 // Pose LM
 // ------------------------------------------------------------------------------------------------
+static inline LevelK lm_level_k(const struct odo_lm* m, int level);
 static const odo_intrinsics kKitti00 = {718.856f, (float)607.1928, (float)185.2157};
 constexpr int kLmMaxBlocks = 1280;       // partial rows per buffer: dense scan = 5 blocks per CU
 
@@ -456,6 +457,7 @@ struct odo_lm {
   int coarse;  // 1 = levels with <= kCoarseMaxPoints points run inside one workgroup (fused pipeline)
   int fused;  // 1 = one launch per evaluation (robust 0/1); 0 = separate residual / update kernels
   int mode;  // 0 auto (list when <= half of the interior has depth), 1 always dense scan, 2 always list
+  int bilinear;  // odo_lm_set_sampling: 1 = bilinear sampling of the current image (non-parity option)
   int dense_plain_div;  // 1 = dense levels use the plain IEEE divisions only (ODO_DENSE_PLAIN_DIV: A/B of the shared-reciprocal path)
   void (*idle_pump)(void*);  // called while the host waits for the device (the tracker feeds its depth stream here)
   void* idle_arg;
@@ -469,6 +471,12 @@ struct odo_lm {
   int iters[ODO_MAX_LEVELS];
   int launches_level[ODO_MAX_LEVELS];
 };
+
+static inline LevelK lm_level_k(const odo_lm* m, int level) {
+  LevelK k = make_level_k(m->K.f0, m->K.cx0, m->K.cy0, level);
+  k.bilinear = m->bilinear;
+  return k;
+}
 
 extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const int* max_iters, int n_levels,
                              const float init_colmajor[16], int robust, float huber_delta, const odo_intrinsics* K,
@@ -801,7 +809,7 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
       L.rows = kf_img->r[l]; L.cols = kf_img->c[l];
       L.nblk = lm_grid_for(m, l, L.rows, L.cols);
       L.I2 = cur_img->dev + cur_img->off[l];
-      L.k = make_level_k(m->K.f0, m->K.cx0, m->K.cy0, l);
+      L.k = lm_level_k(m, l);
       L.max_iters = m->max_iters[l];
       if (L.nblk + 1 > grid) grid = L.nblk + 1;  // + the publisher block
       budget += m->max_iters[l] > 0 ? m->max_iters[l] : 0;
@@ -893,7 +901,7 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
       v.I2 = cur_img->dev + cur_img->off[l];
       v.D1 = kf_dep->dev + kf_dep->off[l];
       v.rows = kf_img->r[l]; v.cols = kf_img->c[l];
-      const LevelK k = make_level_k(m->K.f0, m->K.cx0, m->K.cy0, l);
+      const LevelK k = lm_level_k(m, l);
       const int nblk = lm_grid_for(m, l, v.rows, v.cols);
       if (m->robust == 2 && lm_ensure_res(m, (size_t)v.rows * v.cols)) return -1;
       bytes_per_level[l] = lm_level_bytes(m, l, v.rows, v.cols, nblk);
@@ -1005,6 +1013,11 @@ extern "C" int odo_lm_event_stats(const odo_lm* m, double* total_us, long* launc
   return 0;
 }
 
+extern "C" int odo_lm_set_sampling(odo_lm* m, int sampling) {
+  if (!m || (sampling != ODO_SAMPLE_FLOOR && sampling != ODO_SAMPLE_BILINEAR)) return fail("odo_lm_set_sampling: bad arg");
+  m->bilinear = sampling == ODO_SAMPLE_BILINEAR ? 1 : 0;
+  return 0;
+}
 extern "C" int odo_lm_set_mode(odo_lm* m, int mode) {
   if (!m || mode < 0 || mode > 2) return fail("odo_lm_set_mode: bad arg");
   m->mode = mode;
@@ -1089,7 +1102,7 @@ extern "C" int odo_lm_accumulate(odo_lm* m, const odo_pyr* kf_img, const odo_pyr
   v.I2 = cur_img->dev + cur_img->off[level];
   v.D1 = kf_dep->dev + kf_dep->off[level];
   v.rows = kf_img->r[level]; v.cols = kf_img->c[level];
-  const LevelK k = make_level_k(m->K.f0, m->K.cx0, m->K.cy0, level);
+  const LevelK k = lm_level_k(m, level);
   if (lm_prepare_keyframe(m, kf_img, kf_dep)) return -1;
   const int nblk = lm_grid_for(m, level, v.rows, v.cols);
   if (m->robust == 2 && lm_ensure_res(m, (size_t)v.rows * v.cols)) return -1;
@@ -1119,7 +1132,7 @@ extern "C" int odo_debug_update_stamps(odo_lm* m, const odo_pyr* kf_img, const o
   v.I2 = cur_img->dev + cur_img->off[level];
   v.D1 = kf_dep->dev + kf_dep->off[level];
   v.rows = kf_img->r[level]; v.cols = kf_img->c[level];
-  const LevelK k = make_level_k(m->K.f0, m->K.cx0, m->K.cy0, level);
+  const LevelK k = lm_level_k(m, level);
   if (lm_prepare_keyframe(m, kf_img, kf_dep)) return -1;
   const int nblk = lm_grid_for(m, level, v.rows, v.cols);
   unsigned long long* d_st = nullptr;

@@ -439,7 +439,7 @@ static int lm_time_eval(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep,
   v.I2 = cur_img->dev + cur_img->off[level];
   v.D1 = kf_dep->dev + kf_dep->off[level];
   v.rows = kf_img->r[level]; v.cols = kf_img->c[level];
-  const LevelK k = make_level_k(m->K.f0, m->K.cx0, m->K.cy0, level);
+  const LevelK k = lm_level_k(m, level);
   if (lm_prepare_keyframe(m, kf_img, kf_dep)) return -1;
   const int nblk = lm_grid_for(m, level, v.rows, v.cols);
   if (m->robust == 2 && lm_ensure_res(m, (size_t)v.rows * v.cols)) return -1;

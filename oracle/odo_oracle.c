@@ -376,6 +376,13 @@ float orc_cx_level(float c, int level) { return cx_level(c, level); }
  * pixel contributes, 0 when it is skipped. Mixed float/double promotions follow SURVEY appendix A10:
  * std::pow(2.0f, level) is double, so every expression it touches is evaluated in double and rounded
  * to float on assignment. */
+/* Sampling of the current image: 0 = floor (the reference, parity mode); 1 = bilinear — the oracle of the NON-PARITY option
+ * odo_lm_set_sampling(ODO_SAMPLE_BILINEAR) (BASELINE.json north_star names bilinear sampling; the reference has no such mode,
+ * so this definition — interpolate I2 in the 2x2 cell around (u, v), gradient = derivative of the interpolant, skip points whose
+ * cell leaves the image — is this repository's, shared op for op with odo_math.h:residual_jacobian_bilinear). */
+static int g_sampling = 0;
+void orc_set_sampling(int mode) { g_sampling = mode; }
+
 static int pixel_row(const float* I1, const float* I2, const float* D1, int rows, int cols, int x, int y,
                      const float T[16], double fl, float cxl, float cyl, float* r_out, float J[6]) {
   const float d = D1[(size_t)y * cols + x];
@@ -393,14 +400,30 @@ static int pixel_row(const float* I1, const float* I2, const float* D1, int rows
   const float u = (float)(fl * (double)t0 / (double)t2 + (double)cxl);    /* h:50 */
   const float v = (float)(fl * (double)t1 / (double)t2 + (double)cyl);    /* h:51 */
   const float fu = floorf(u), fv = floorf(v);
-  if (!(fu < (float)cols) || !(fv < (float)rows) || !(fu >= 0.0f) || !(fv >= 0.0f)) return 0; /* h:54-56 */
-  const int ui = (int)fu, vi = (int)fv;                                   /* :208-209 */
-  /* ComputePixelGradient h:62-69 (index clamping) */
-  const int px = (ui - 1 >= 0) ? ui - 1 : 0, nx = (ui + 1 < cols) ? ui + 1 : cols - 1;
-  const int py = (vi - 1 >= 0) ? vi - 1 : 0, ny = (vi + 1 < rows) ? vi + 1 : rows - 1;
-  const float gx = 0.5f * (I2[(size_t)vi * cols + nx] - I2[(size_t)vi * cols + px]);
-  const float gy = 0.5f * (I2[(size_t)ny * cols + ui] - I2[(size_t)py * cols + ui]);
-  *r_out = I2[(size_t)vi * cols + ui] - I1[(size_t)y * cols + x];         /* :217 */
+  float gx, gy;
+  if (g_sampling == 1) {
+    if (!(fu >= 0.0f) || !(fv >= 0.0f) || !(fu + 1.0f < (float)cols) || !(fv + 1.0f < (float)rows)) return 0;
+    const int x0 = (int)fu, y0 = (int)fv;
+    const float a = u - fu, b = v - fv;
+    const float* c0 = I2 + (size_t)y0 * cols + x0;
+    const float i00 = c0[0], i10 = c0[1], i01 = c0[cols], i11 = c0[cols + 1];
+    const float dx0 = i10 - i00, dx1 = i11 - i01;
+    const float top = i00 + a * dx0, bot = i01 + a * dx1;
+    const float val = top + b * (bot - top);
+    gx = dx0 + b * (dx1 - dx0);
+    const float dy0 = i01 - i00, dy1 = i11 - i10;
+    gy = dy0 + a * (dy1 - dy0);
+    *r_out = val - I1[(size_t)y * cols + x];
+  } else {
+    if (!(fu < (float)cols) || !(fv < (float)rows) || !(fu >= 0.0f) || !(fv >= 0.0f)) return 0; /* h:54-56 */
+    const int ui = (int)fu, vi = (int)fv;                                   /* :208-209 */
+    /* ComputePixelGradient h:62-69 (index clamping) */
+    const int px = (ui - 1 >= 0) ? ui - 1 : 0, nx = (ui + 1 < cols) ? ui + 1 : cols - 1;
+    const int py = (vi - 1 >= 0) ? vi - 1 : 0, ny = (vi + 1 < rows) ? vi + 1 : rows - 1;
+    gx = 0.5f * (I2[(size_t)vi * cols + nx] - I2[(size_t)vi * cols + px]);
+    gy = 0.5f * (I2[(size_t)ny * cols + ui] - I2[(size_t)py * cols + ui]);
+    *r_out = I2[(size_t)vi * cols + ui] - I1[(size_t)y * cols + x];         /* :217 */
+  }
   /* geometric Jacobian at the UN-warped point :223-233 */
   const float fx_z = (float)(fl / (double)Z);
   const float xy = X * Y, xx = X * X, yy = Y * Y, zz = Z * Z;

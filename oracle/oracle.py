@@ -94,6 +94,12 @@ def _f(a):
     return a, a.ctypes.data_as(_fp)
 
 
+def set_sampling(bilinear):
+    """Oracle of the non-parity bilinear-sampling option (odo_lm_set_sampling); False restores the reference's floor sampling.
+    Process-wide switch: callers reset it (try / finally)."""
+    lib().orc_set_sampling(1 if bilinear else 0)
+
+
 def lm_params(lam=0.01, precision=0.995, max_iters=(10, 20, 30, 30), robust=1, huber_delta=28.0, K=None):
     """Runner defaults (ref: run_odometry_kitti_offline.cpp:75-88)."""
     p = LmParams()

@@ -9,19 +9,21 @@ using namespace odo;
 
 extern "C" {
 
+static int g_emu_bilinear = 0;
+void emu_set_sampling(int bilinear) { g_emu_bilinear = bilinear; }   // the device's odo_lm_set_sampling
+
 int emu_lm_accumulate(const float* I1, const float* I2, const float* D1, int rows, int cols, int level, const float* T,
                       int robust, float huber_delta, float f0, float cx0, float cy0, double* acc) {
-  const LevelK k = make_level_k(f0, cx0, cy0, level);
+  LevelK k = make_level_k(f0, cx0, cy0, level);
+  k.bilinear = g_emu_bilinear;
   for (int i = 0; i < ODO_NACC; i++) acc[i] = 0.0;
   for (int y = 4; y < rows - 4; y++)
     for (int x = 4; x < cols - 4; x++) {
       const size_t o = (size_t)y * cols + x;
       if (!depth_valid(D1[o])) continue;
       const PointK p = make_point(x, y, D1[o], I1[o], k);
-      int ui, vi;
-      if (!warp_point(p, T, k, rows, cols, &ui, &vi)) continue;
       float r, J[6];
-      residual_jacobian(p, I2, rows, cols, ui, vi, &r, J);
+      if (!point_residual(p, T, k, I2, rows, cols, &r, J)) continue;
       accumulate_row(acc, r, robust_weight(r, robust, huber_delta, 1.0f), J);
     }
   return acc[28] > 0.0 ? 0 : -1;

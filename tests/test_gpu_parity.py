@@ -490,3 +490,39 @@ def test_tracker_next_frame_hint_changes_nothing(api, kitti_seq):
         out.append(np.stack(poses))
         trk.close()
     assert np.array_equal(out[0], out[1])
+
+
+def test_bilinear_sampling_option_matches_its_oracle(api, O, kitti_seq):
+    """odo_lm_set_sampling(ODO_SAMPLE_BILINEAR): a non-parity knob (the reference floors, ref: src/lm_optimizer.cpp:208-217)
+    with its own oracle mode. Accumulators of every level (point list, dense scan) and a whole Solve (fused list pipeline and
+    dense pipeline) against the oracle; the default stays floor sampling."""
+    L0, L1, inv, p0, d0, p1, *_ = _kitti_pyrs(api, O, kitti_seq)
+    T = np.eye(4, dtype=np.float32)
+    T[2, 3] = -0.35
+    T[0, 3] = 0.02
+    ref_floor = O.lm_solve(O.image_pyramid(L0, flat=True), O.depth_pyramid(inv, flat=True), O.image_pyramid(L1, flat=True),
+                           376, 1241, O.lm_params())
+    O.set_sampling(True)
+    try:
+        i0, i1, dd = O.image_pyramid(L0), O.image_pyramid(L1), O.depth_pyramid(inv)
+        for mode in (2, 1):   # keyframe point list, dense scan
+            lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 1, 28.0)
+            lm.set_sampling(True)
+            lm.set_mode(mode)
+            for level in range(4):
+                st, acc = lm.accumulate(p0, d0, p1, level, T)
+                ref = O.lm_accumulate(i0[level], i1[level], dd[level], level, T, robust=1)
+                assert st == 0 and acc[28] == ref["acc"][28] > 0
+                np.testing.assert_allclose(acc, ref["acc"], rtol=1e-11, atol=1e-7)
+            Tg = lm.Solve(p0, d0, p1)
+            ref = O.lm_solve(O.image_pyramid(L0, flat=True), O.depth_pyramid(inv, flat=True), O.image_pyramid(L1, flat=True),
+                             376, 1241, O.lm_params())
+            assert lm.last_status == 0 and ref["status"] == 0
+            assert se3_log_norm(ref["pose"], Tg) < 1e-5
+            assert lm.launch_stats()[0] == ref["n_evals"]
+            lm.close()
+    finally:
+        O.set_sampling(False)
+    # a fresh optimiser still floors
+    lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 1, 28.0)
+    assert se3_log_norm(ref_floor["pose"], lm.Solve(p0, d0, p1)) < 1e-5

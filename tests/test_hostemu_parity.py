@@ -126,3 +126,60 @@ def test_ssd_tree_bit_exact(emu):
         Rp = (rng.random(8) * 255).astype(np.float32)
         s = ((Lp - Rp) * (Lp - Rp)).astype(np.float32)
         assert emu.emu_ssd8(P(Lp), P(Rp)) == O.lib().orc_ssd8_tree(P(s))
+
+
+def test_bilinear_sampling_mode_bit_exact_and_continuous(emu, pyrs):
+    """The non-parity bilinear-sampling option (odo_lm_set_sampling): the device arithmetic (odo_math.h) against its oracle
+    mode bit for bit on every level and through a whole Solve; and the property that motivates it — the objective is
+    continuous in the pose, where floor sampling jumps."""
+    ip0, dp0, ip1 = pyrs
+    T = O.se3_exp(np.array([0.02, -0.01, -0.3, 0.002, 0.01, -0.003], np.float32))
+    Tc = np.ascontiguousarray(T.T)
+    O.set_sampling(True)
+    emu.emu_set_sampling(1)
+    try:
+        floor_ref = None
+        for lvl in range(4):
+            r, c = O.level_dims(376, 1241, lvl)
+            off = int(O.pyramid_size(376, 1241, lvl))
+            I1, I2, D1 = (a[off:off + r * c].reshape(r, c) for a in (ip0, ip1, dp0))
+            ref = O.lm_accumulate(I1, I2, D1, lvl, T, robust=1)
+            acc = np.zeros(29)
+            emu.emu_lm_accumulate(P(I1), P(I2), P(D1), r, c, lvl, P(Tc), 1, C.c_float(28.0), C.c_float(718.856),
+                                  C.c_float(607.1928), C.c_float(185.2157), acc.ctypes.data_as(C.POINTER(C.c_double)))
+            assert ref["status"] == 0 and np.array_equal(acc, ref["acc"])
+            if lvl == 0:
+                floor_ref = acc.copy()
+        ref = O.lm_solve(ip0, dp0, ip1, 376, 1241, O.lm_params())
+        out = np.zeros(16, np.float32)
+        ne = C.c_int(0)
+        mi = (C.c_int * 4)(10, 20, 30, 30)
+        init = np.eye(4, dtype=np.float32)
+        st = emu.emu_lm_solve(P(ip0), P(dp0), P(ip1), 376, 1241, 4, mi, C.c_float(0.01), C.c_float(0.995), 1,
+                              C.c_float(28.0), C.c_float(718.856), C.c_float(607.1928), C.c_float(185.2157), P(init), P(out),
+                              C.byref(ne))
+        assert st == ref["status"] == 0 and ne.value == ref["n_evals"]
+        assert np.array_equal(out.reshape(4, 4).T, ref["pose"])
+        bil_pose = ref["pose"]
+        # continuity: mean squared residual along a tiny translation sweep changes smoothly with bilinear sampling
+        r0, c0 = 376, 1241
+        I1, I2, D1 = (a[:r0 * c0].reshape(r0, c0) for a in (ip0, ip1, dp0))
+
+        def cost(tx):
+            Tt = T.copy()
+            Tt[0, 3] += tx
+            a = O.lm_accumulate(I1, I2, D1, 0, Tt, robust=0)["acc"]
+            return a[27] / a[28]
+        xs = np.linspace(0, 2e-3, 41)
+        cb = np.array([cost(x) for x in xs])
+    finally:
+        O.set_sampling(False)
+        emu.emu_set_sampling(0)
+    cf = np.array([O.lm_accumulate(I1, I2, D1, 0, np.block([[T[:3, :3], (T[:3, 3] + [x, 0, 0]).reshape(3, 1)], [0, 0, 0, 1]]).astype(np.float32),
+                                   robust=0)["acc"][27] / 1.0 for x in xs])
+    assert np.abs(np.diff(cb)).max() < 0.05 * abs(cb.mean())          # smooth
+    assert not np.array_equal(floor_ref, O.lm_accumulate(I1, I2, D1, 0, T, robust=1)["acc"])   # and a different objective
+    # the two sampling modes agree on the motion to well under a pixel's worth
+    floor_pose = O.lm_solve(ip0, dp0, ip1, 376, 1241, O.lm_params())["pose"]
+    assert np.abs(bil_pose - floor_pose).max() < 0.05
+    _ = cf

@@ -625,7 +625,7 @@ def main():
                 if "single" in legs:
                     out["single_pair_1241x376"] = single_pair_leg(api, seq)
                 if "shim" in legs:
-                    out.update(shim_leg(api, seq, n_frames=min(100, args.unique_frames)))
+                    out.update(shim_leg(api, seq, n_frames=min(200, args.unique_frames)))
                 if "multi" in legs:   # last, with every other stream of this process gone (streams share hardware queues)
                     trk.close()
                     out["multi_sequence_1gpu"] = [multi_sequence_leg(api, seq, order, n, 200) for n in (2, 4, 8)]

@@ -62,15 +62,16 @@ int odo_dev_upload(odo_ctx* ctx, void* dst_dev, const void* src_host, size_t byt
 int odo_dev_download(odo_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 /* The drop-in path (include/odometry_shim.hpp) without stalls: page-locked host blocks (an upload from one is a plain
  * asynchronous DMA; uploads from other host memory are copied once into the context's pinned staging ring), uploads that
- * return as soon as the caller may reuse its buffer instead of waiting for the device, and stream-ordered device blocks
- * whose release neither synchronises the stream nor returns memory to the driver (is_async, as returned by the allocation,
- * goes back into the matching free). A block from odo_host_alloc must not be freed while uploads from it may be pending
- * (odo_ctx_synchronize first). */
+ * return as soon as the caller may reuse its buffer instead of waiting for the device, and device blocks recycled through a
+ * free list of the context, whose release neither synchronises the stream nor calls the driver (is_async, as returned by
+ * the allocation, and the size go back into the matching free). Recycled blocks are for work on the context's own stream
+ * only: a block may be handed out again while work that used it is still queued on that stream. A block from
+ * odo_host_alloc must not be freed while uploads from it may be pending (odo_ctx_synchronize first). */
 void* odo_host_alloc(size_t bytes);
 void odo_host_free(void* host);
 int odo_dev_upload_async(odo_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int odo_dev_alloc_async(odo_ctx* ctx, size_t bytes, void** out_dev, int* is_async);
-int odo_dev_free_async(odo_ctx* ctx, void* dev, int is_async);
+int odo_dev_free_async(odo_ctx* ctx, void* dev, size_t bytes, int is_async);
 
 /* ---- pyramids ------------------------------------------------------------------------------
  * Replaces ImagePyramid::ImagePyramid / DepthPyramid::DepthPyramid

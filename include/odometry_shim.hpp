@@ -150,7 +150,7 @@ struct MirrorLru {
     for (size_t i = 0; i < order.size() && caches > keep; i++) {
       auto q = order[i].lock();
       if (q && q->dev && q->host_valid && q.get() != b.get()) {
-        odo_dev_free_async(context(), q->dev, q->dev_async);
+        odo_dev_free_async(context(), q->dev, q->bytes, q->dev_async);
         q->dev = nullptr; q->dev_valid = false;
         caches--;
       }
@@ -163,7 +163,7 @@ inline MatBuf::MatBuf(size_t n) : bytes(n) {
   if (!host) host = static_cast<uint8_t*>(std::malloc(n ? n : 1));
 }
 inline MatBuf::~MatBuf() {
-  if (dev) odo_dev_free_async(context(), dev, dev_async);
+  if (dev) odo_dev_free_async(context(), dev, bytes, dev_async);
   if (pinned) {
     if (upload_pending) odo_ctx_synchronize(context());  // a DMA may still be reading the block
     pinned_pool().put(bytes, host);
@@ -367,20 +367,19 @@ inline odo_ctx* context() {
 // input is staged and uploaded into a stream-ordered scratch block and every output is downloaded before the call returns.
 #ifdef ODOMETRY_SHIM_WITH_OPENCV
 struct DevIn {
-  void* dev = nullptr; int async_ = 0;
-  explicit DevIn(const Mat& m) {
-    const size_t n = m.total() * m.elemSize();
+  void* dev = nullptr; int async_ = 0; size_t n = 0;
+  explicit DevIn(const Mat& m) : n(m.total() * m.elemSize()) {
     if (odo_dev_alloc_async(context(), n, &dev, &async_) == 0 && odo_dev_upload_async(context(), dev, m.data, n) != 0) {
-      odo_dev_free_async(context(), dev, async_); dev = nullptr;
+      odo_dev_free_async(context(), dev, n, async_); dev = nullptr;
     }
   }
-  ~DevIn() { if (dev) odo_dev_free_async(context(), dev, async_); }
+  ~DevIn() { if (dev) odo_dev_free_async(context(), dev, n, async_); }
   const void* get() const { return dev; }
 };
 struct DevOut {
   Mat& m; void* dev = nullptr; int async_ = 0;
   explicit DevOut(Mat& mm) : m(mm) { odo_dev_alloc_async(context(), m.total() * m.elemSize(), &dev, &async_); }
-  ~DevOut() { if (dev) { odo_dev_download(context(), m.data, dev, m.total() * m.elemSize()); odo_dev_free_async(context(), dev, async_); } }
+  ~DevOut() { if (dev) { odo_dev_download(context(), m.data, dev, m.total() * m.elemSize()); odo_dev_free_async(context(), dev, m.total() * m.elemSize(), async_); } }
   void* get() { return dev; }
 };
 #else

@@ -160,7 +160,7 @@ struct DenseLevel {
 constexpr int kDenseMaxBlocks = 1280;  // five 256-thread blocks per CU
 
 // Fills the decomposition fields for `block_threads`-wide blocks. A block walks `units` (strip, row-group) pairs; the
-// grid is capped at max_blocks and shrinks for small levels so that every block has at least two units.
+// grid is capped at max_blocks; levels with fewer units than that get one block per unit.
 static inline void dense_level_geometry(DenseLevel* L, int block_threads, int max_blocks) {
   const int R = block_threads / 64;
   const int iw = L->cols - 8, ih = L->rows - 8;
@@ -168,7 +168,7 @@ static inline void dense_level_geometry(DenseLevel* L, int block_threads, int ma
   L->n_strips = (iw + 63) / 64;
   L->n_rg = (ih + R - 1) / R;
   const long units = (long)L->n_strips * L->n_rg;
-  long g = (units + 1) / 2;
+  long g = units;  // one unit per block while the grid fits (small levels are latency bound: the less serial work the better)
   if (g > max_blocks) g = max_blocks;
   if (g < 1) g = 1;
   L->nblk = (int)g;
@@ -180,15 +180,17 @@ constexpr int kRedPad = 8;  // see kernels.hip.h
 // the units run strip by strip, top to bottom, and the group's blocks take consecutive runs of them.
 struct DenseRun { int strip, rg, rg0, rg1, count; };
 __device__ __forceinline__ DenseRun dense_block_run(const DenseLevel& L, int b) {
+  // 32-bit arithmetic throughout (64-bit integer division costs several hundred cycles on the device): a band holds at most
+  // 1024 strips x 2048 row groups = 2^21 units (65535 x 65535 image), a group at most 128 blocks.
   DenseRun r;
-  const int G = L.nblk < 8 ? L.nblk : 8;
-  const int g = b % G, j = b / G;
-  const int nj = (L.nblk - g + G - 1) / G;  // blocks of this group
-  r.rg0 = (int)((long)g * L.n_rg / G);
-  r.rg1 = (int)((long)(g + 1) * L.n_rg / G);
-  const int nrg = r.rg1 - r.rg0;
-  const long U = (long)nrg * L.n_strips;
-  const long u0 = (long)j * U / nj, u1 = (long)(j + 1) * U / nj;
+  const unsigned G = L.nblk < 8 ? (unsigned)L.nblk : 8u;
+  const unsigned g = (unsigned)b % G, j = (unsigned)b / G;
+  const unsigned nj = ((unsigned)L.nblk - g + G - 1u) / G;  // blocks of this group
+  r.rg0 = (int)(g * (unsigned)L.n_rg / G);
+  r.rg1 = (int)((g + 1u) * (unsigned)L.n_rg / G);
+  const unsigned nrg = (unsigned)(r.rg1 - r.rg0);
+  const unsigned U = nrg * (unsigned)L.n_strips;
+  const unsigned u0 = j * U / nj, u1 = (j + 1u) * U / nj;  // (j + 1) * U <= 129 * 2^21 < 2^32
   r.count = (int)(u1 - u0);
   r.strip = nrg > 0 ? (int)(u0 / nrg) : 0;
   r.rg = nrg > 0 ? r.rg0 + (int)(u0 % nrg) : 0;

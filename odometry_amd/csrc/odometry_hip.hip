@@ -50,43 +50,35 @@ struct odo_ctx {
   hipEvent_t stage_ev[kStageSlots];
   int stage_busy[kStageSlots];
   int stage_next;
+  std::vector<struct PoolBlock>* pool;  // recycled device blocks (see dev_alloc_any)
 };
 
-// ---- stream-ordered device memory ---------------------------------------------------------------------------------
-// Per-frame objects of the drop-in path (a pyramid per constructor call, ref: run_odometry_kitti_offline.cpp:205,251-252) are
-// allocated and freed in stream order from the device's memory pool (hipMallocAsync / hipFreeAsync): after the first
-// frames an allocation is a pool hit and a free neither synchronises the stream nor returns memory to the driver.
-static std::atomic<int> g_async_alloc{-1};  // -1 unknown, 0 unavailable (plain hipMalloc / hipFree), 1 in use
-static bool async_alloc_ready(int device) {
-  int v = g_async_alloc.load();
-  if (v >= 0) return v == 1;
-  v = 0;
-  if (!getenv("ODO_NO_ASYNC_ALLOC")) {
-    int supported = 0;
-    hipMemPool_t pool = nullptr;
-    if (hipDeviceGetAttribute(&supported, hipDeviceAttributeMemoryPoolsSupported, device) == hipSuccess && supported &&
-        hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
-      uint64_t keep = ~0ull;  // never trim the pool at synchronisation points
-      if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess) v = 1;
-    }
-    (void)hipGetLastError();
-  }
-  g_async_alloc.store(v);
-  return v == 1;
-}
-// *is_async tells dev_free_any how the block has to be returned.
-static int dev_alloc_any(odo_ctx* c, size_t bytes, void** out, bool* is_async) {
-  *is_async = false;
-  if (async_alloc_ready(c->device)) {
-    if (hipMallocAsync(out, bytes, c->stream) == hipSuccess) { *is_async = true; return 0; }
-    (void)hipGetLastError();
+// ---- recycled device memory -------------------------------------------------------------------------------------------
+// Per-frame objects of the drop-in path (a pyramid per constructor call, ref: run_odometry_kitti_offline.cpp:205,251-252) take
+// their device blocks from a free list kept by the context and give them back to it: after the first frames an allocation
+// is a list hit and a release neither synchronises the stream nor calls the driver. A recycled block may be handed out
+// while work that used it is still queued — on the SAME stream, so the new owner's work is ordered behind it; that is why
+// the list belongs to the context (one stream) and why objects that move between streams (the tracker's pyramids) do not
+// use it. (hipMallocAsync / hipFreeAsync, the runtime's own stream-ordered allocator, was tried first: with blocks of
+// several sizes cycling through it the LM read stale images on ROCm 7.2 — tests/test_gpu_dense_1080p.py run in one process
+// — so the reuse rule is spelled out here instead.) ODO_NO_POOL=1 turns recycling off.
+struct PoolBlock { size_t bytes; void* p; };
+constexpr size_t kPoolMaxBlocks = 48;
+static bool pool_enabled() { static const bool on = getenv("ODO_NO_POOL") == nullptr; return on; }
+// *pooled tells dev_free_any how the block has to be returned.
+static int dev_alloc_any(odo_ctx* c, size_t bytes, void** out, bool* pooled) {
+  *pooled = pool_enabled();
+  if (*pooled && c->pool) {
+    auto& v = *c->pool;
+    for (size_t i = 0; i < v.size(); i++)
+      if (v[i].bytes == bytes) { *out = v[i].p; v.erase(v.begin() + (long)i); return 0; }
   }
   HIP_OK(hipMalloc(out, bytes));
   return 0;
 }
-static void dev_free_any(odo_ctx* c, void* p, bool is_async) {
+static void dev_free_any(odo_ctx* c, void* p, size_t bytes, bool pooled) {
   if (!p) return;
-  if (is_async && hipFreeAsync(p, c->stream) == hipSuccess) return;
+  if (pooled && c->pool && c->pool->size() < kPoolMaxBlocks) { c->pool->push_back(PoolBlock{bytes, p}); return; }
   (void)hipStreamSynchronize(c->stream);
   (void)hipFree(p);
 }
@@ -115,6 +107,7 @@ static int ctx_create(int device, int high_priority, odo_ctx** out) {
   HIP_OK(hipEventCreate(&c->ev0));
   HIP_OK(hipEventCreate(&c->ev1));
   for (int i = 0; i < kStageSlots; i++) HIP_OK(hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming));
+  c->pool = new std::vector<PoolBlock>();
   *out = c;
   return 0;
 }
@@ -128,6 +121,7 @@ extern "C" int odo_ctx_destroy(odo_ctx* c) {
     (void)hipEventDestroy(c->stage_ev[i]);
     if (c->stage[i]) (void)hipHostFree(c->stage[i]);
   }
+  if (c->pool) { for (auto& b : *c->pool) (void)hipFree(b.p); delete c->pool; }
   (void)hipStreamDestroy(c->stream);
   delete c;
   return 0;
@@ -232,7 +226,7 @@ extern "C" int odo_dev_download(odo_ctx* c, void* dst, const void* src, size_t b
   HIP_OK(hipStreamSynchronize(c->stream));
   return 0;
 }
-// Stream-ordered scratch for per-frame images of the drop-in path (see dev_alloc_any): free does not synchronise.
+// Recycled scratch for per-frame images of the drop-in path (see dev_alloc_any): the release does not synchronise.
 extern "C" int odo_dev_alloc_async(odo_ctx* c, size_t bytes, void** out, int* is_async) {
   if (!c || !out || !is_async) return fail("NULL arg");
   HIP_OK(hipSetDevice(c->device));
@@ -241,9 +235,9 @@ extern "C" int odo_dev_alloc_async(odo_ctx* c, size_t bytes, void** out, int* is
   *is_async = a ? 1 : 0;
   return 0;
 }
-extern "C" int odo_dev_free_async(odo_ctx* c, void* p, int is_async) {
+extern "C" int odo_dev_free_async(odo_ctx* c, void* p, size_t bytes, int is_async) {
   if (!c) return fail("NULL ctx");
-  dev_free_any(c, p, is_async != 0);
+  dev_free_any(c, p, bytes, is_async != 0);
   return 0;
 }
 
@@ -258,6 +252,7 @@ struct odo_pyr {
   float* dev;      // all levels back to back
   float* staging;  // level-0-sized device copy of a host input (IMAGE kind: pyrDown reads the unsmoothed input)
   bool dev_async, staging_async;  // how the two blocks were allocated (dev_alloc_any)
+  size_t dev_bytes, staging_bytes;
   size_t off[ODO_MAX_LEVELS];
   int r[ODO_MAX_LEVELS], c[ODO_MAX_LEVELS];
   unsigned long long version;  // bumped by every (re)build: keys the LM's keyframe point-list cache
@@ -318,7 +313,7 @@ static int pyr_alloc(odo_ctx* ctx, int rows, int cols, int levels, int kind, odo
   odo_pyr* p = new (std::nothrow) odo_pyr();
   if (!p) return fail("out of memory");
   p->ctx = ctx; p->kind = kind; p->levels = levels; p->rows = rows; p->cols = cols;
-  p->dev = nullptr; p->staging = nullptr; p->dev_async = p->staging_async = false;
+  p->dev = nullptr; p->staging = nullptr; p->dev_async = p->staging_async = false; p->dev_bytes = p->staging_bytes = 0;
   size_t tot = 0;
   int r = rows, c = cols;
   for (int l = 0; l < levels; l++) {
@@ -328,6 +323,7 @@ static int pyr_alloc(odo_ctx* ctx, int rows, int cols, int levels, int kind, odo
     if ((r < 1 || c < 1) && l + 1 < levels) { delete p; return fail("pyramid: image too small for %d levels", levels); }
   }
   HIP_OK(hipSetDevice(ctx->device));
+  p->dev_bytes = sizeof(float) * tot;
   if (pooled) {
     if (dev_alloc_any(ctx, sizeof(float) * tot, (void**)&p->dev, &p->dev_async)) { delete p; return -1; }
   } else {
@@ -345,7 +341,8 @@ extern "C" int odo_pyramid_create(odo_ctx* ctx, const float* img, int rows, int 
   if (stride_bytes < sizeof(float) * (size_t)cols) return fail("odo_pyramid_create: stride smaller than a row");
   odo_pyr* p = nullptr;
   if (pyr_alloc(ctx, rows, cols, levels, kind, &p)) return -1;
-  if (dev_alloc_any(ctx, sizeof(float) * (size_t)rows * cols, (void**)&p->staging, &p->staging_async)) {
+  p->staging_bytes = sizeof(float) * (size_t)rows * cols;
+  if (dev_alloc_any(ctx, p->staging_bytes, (void**)&p->staging, &p->staging_async)) {
     odo_pyramid_destroy(p);
     return fail("odo_pyramid_create: device allocation failed");
   }
@@ -397,8 +394,8 @@ extern "C" int odo_pyramid_destroy(odo_pyr* p) {
   if (!p) return 0;
   // stream-ordered blocks go back to the pool behind whatever the stream still has queued on them; plain ones need the
   // stream drained first
-  dev_free_any(p->ctx, p->dev, p->dev_async);
-  dev_free_any(p->ctx, p->staging, p->staging_async);
+  dev_free_any(p->ctx, p->dev, p->dev_bytes, p->dev_async);
+  dev_free_any(p->ctx, p->staging, p->staging_bytes, p->staging_async);
   delete p;
   return 0;
 }

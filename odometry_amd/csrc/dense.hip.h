@@ -175,7 +175,10 @@ static inline void dense_level_geometry(DenseLevel* L, int block_threads, int ma
 }
 
 #ifdef ODO_DENSE_KERNELS
+#ifndef ODO_KREDPAD
+#define ODO_KREDPAD 1
 constexpr int kRedPad = 8;  // see kernels.hip.h
+#endif
 // The units of block `b`: XCD group g = b % G owns the band of row groups [g n_rg / G, (g + 1) n_rg / G); inside the band
 // the units run strip by strip, top to bottom, and the group's blocks take consecutive runs of them.
 struct DenseRun { int strip, rg, rg0, rg1, count; };

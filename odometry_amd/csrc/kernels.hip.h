@@ -260,7 +260,8 @@ struct LevelView {
 };
 
 constexpr int kLmBlock = 256;
-#ifndef ODO_DENSE_KERNELS
+#ifndef ODO_KREDPAD
+#define ODO_KREDPAD 1
 constexpr int kRedPad = 8;  // sh[q][256+8] doubles: q-stride shifts 16 banks -> at most 2-way conflicts
 #endif
 

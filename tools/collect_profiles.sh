@@ -1,0 +1,25 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence kept under profiles/ (run on the GPU box through gpurun; raw output goes to gpurun_out/).
+#   bash tools/collect_profiles.sh <tag>
+# Passes (each its own run; counters never share a run with tracing beyond --kernel-trace):
+#   1. --kernel-trace --stats of the bench command (no child processes: the CPU-baseline and shim legs spawn programs)
+#   2. --pmc FETCH_SIZE   3. --pmc WRITE_SIZE   of the same command with fewer steps
+#   4. --pmc SQ_* of the dense-kernel microbenchmark (issue-bound evidence) + its plain output (A/B table)
+#   5. the VALU instruction-rate microbenchmark
+set -u
+TAG=${1:-r02}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $GRAFT_REPO_ROOT/bench.py --cpu-frames 0 --extras dense,disparity,single"
+timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH --steps 1000 --warmup 50 > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err < /dev/null
+timeout -k 5 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH --steps 199 --warmup 5 > /dev/null 2>&1 < /dev/null
+timeout -k 5 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH --steps 199 --warmup 5 > /dev/null 2>&1 < /dev/null
+F="-O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fhip-fp32-correctly-rounded-divide-sqrt"
+hipcc $F -o /tmp/dense_ablate $GRAFT_REPO_ROOT/tools/microbench/dense_ablate.hip 2> $OUT/build.log
+timeout -k 5 120 /tmp/dense_ablate > $OUT/dense_ablate.log 2>&1 < /dev/null
+timeout -k 5 120 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- /tmp/dense_ablate 1920 1080 "pipelined, shared reciprocals [1024" > /dev/null 2>&1 < /dev/null
+timeout -k 5 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_ablate -- /tmp/dense_ablate 1920 1080 "1024 x 256" > /dev/null 2>&1 < /dev/null
+hipcc -O3 --offload-arch=gfx950 -o /tmp/valu_rates $GRAFT_REPO_ROOT/tools/microbench/valu_rates.hip 2>> $OUT/build.log
+timeout -k 5 120 /tmp/valu_rates > $OUT/valu_rates.log 2>&1 < /dev/null
+ls -R $OUT | head -40

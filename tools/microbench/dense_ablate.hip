@@ -138,5 +138,8 @@ int main(int argc, char** argv) {
   RUN("pipelined, shared reciprocals", 512, 0, 512, 4);
   RUN("pipelined, shared reciprocals", 1024, 0, 256, 4);
   RUN("pipelined ablate: no normal-equation products", 256, 2, 1024, 4);
+  // FETCH_SIZE calibration for this access pattern (one dword per lane, coalesced rows): streams D1 and I1 of every interior
+  // pixel (2 x 4 B x interior = a known byte count) and almost nothing else (bogus geometry: the taps are skipped)
+  RUN("calibration: D1 + I1 streamed, no taps", 256, 62, 1024, 4);
   return 0;
 }

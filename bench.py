@@ -96,6 +96,35 @@ def cpu_baseline(seq, n_frames, n_reference_shape):
     return json.loads(p.stdout.strip().splitlines()[-1])
 
 
+def cpu_baseline_inprocess(seq, n_frames):
+    """Fallback when the pinned child process cannot run (no compiler for the native build, no fork): the portable oracle,
+    unpinned, in this process — same loop, per-frame totals only."""
+    from oracle import oracle as O
+    from oracle import runner as orunner
+    res = {}
+    for name, shape, nf in (("reference_shape", 1, max(4, n_frames // 2)), ("fused", 0, n_frames)):
+        O.lib().orc_set_reference_shape(shape)
+        try:
+            run = orunner.OracleRunner()
+            run.init(seq["left"][0], seq["right"][0])
+            ts, poses = [], []
+            for k in range(1, nf + 1):
+                t0 = time.perf_counter()
+                poses.append(run.track(seq["left"][k], seq["right"][k])["pose_to_keyframe"])
+                ts.append(time.perf_counter() - t0)
+        finally:
+            O.lib().orc_set_reference_shape(0)
+        ts = np.array(ts)
+        res[name] = dict(frames=int(nf), frames_per_s=round(float(1.0 / np.median(ts)), 3), solve_ms_median=None,
+                         compute_depth_ms_median=None, frame_ms_median=round(float(np.median(ts) * 1e3), 2),
+                         total_s=round(float(ts.sum()), 2))
+        if name == "fused":
+            res["poses"] = [p.astype(np.float64).tolist() for p in poses]
+    res.update(build="portable oracle build (-O2), in-process, unpinned: FALLBACK", pinned_to_cpu=None, warmup_frames=0,
+               host_cpu="", host_logical_cpus=os.cpu_count())
+    return res
+
+
 def dense_1080p_leg(api, synth, n_frames=5, passes=3):
     """BASELINE.json configs[2]: a synthetic 1920x1080 stream with dense inverse depth (every pixel a residual on every
     level), tracked the way the reference's test_optimizer.cpp does (ref: :86-105): per frame the image / depth pyramids of the
@@ -322,6 +351,36 @@ def shim_leg(api, seq, n_frames=100, passes=3):
     return out
 
 
+def multi_process_leg(counts=(1, 2, 4, 8), steps=200, warmup=20, unique_frames=64):
+    """Several sequences in flight on ONE GPU, one PROCESS per sequence (each process has its own hardware queues — unlike
+    several trackers inside one process, which share four): this very script launched as N ranks that all use device 0
+    (ODO_BENCH_SHARE_GPU, gloo for the pose gather). Not `value`: configs[1] is a single sequence; this shows how much of the
+    chip one latency-bound sequence leaves idle. Runs as child processes — call it before this process touches the GPU or
+    after it has released it."""
+    import socket
+    import subprocess
+    out = []
+    for n in counts:
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        env = dict(os.environ, ODO_BENCH_SHARE_GPU="1", ODO_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        base = [os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", str(steps), "--warmup", str(warmup), "--unique-frames",
+                str(unique_frames), "--no-extras", "--cpu-frames", "0"]
+        cmd = ([sys.executable] + base) if n == 1 else (
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+             "--master-port", str(port)] + base)
+        p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        line = next((ln for ln in p.stdout.splitlines() if ln.startswith("{")), None)
+        if p.returncode != 0 or line is None:
+            out.append(dict(processes=n, error=(p.stderr or "")[-400:]))
+            continue
+        d = json.loads(line)
+        out.append(dict(processes=n, frames_per_s=d["value"], ms_per_step=d["ms_per_step"]))
+    return out
+
+
 def multi_sequence_leg(api, seq, order, n_seq, steps):
     """Throughput with several independent sequences in flight on ONE GPU (each its own tracker: two HIP streams, two
     host threads). Not `value`: configs[1] is a single sequence, whose frames are inherently serial; this shows how
@@ -385,7 +444,7 @@ def main():
     ap.add_argument("--extras", default="dense,disparity,single,shim",
                     help="side measurements to run: dense (configs[2]), disparity (configs[4]), single (configs[0]), shim (the "
                          "drop-in C++ classes and the host-buffer C ABI, PCIe included); "
-                         "multi (several trackers of one process on one GPU) is opt-in: it floods the device with concurrent "
+                         "multi / multiproc (several trackers of one process / several processes on one GPU) are opt-in: it floods the device with concurrent "
                          "trackers, which is not what a profile of this command is meant to show")
     ap.add_argument("--overlap", type=int, default=2, help="1: one host thread feeds both streams, 2: helper thread")
     ap.add_argument("--distinct-sequences", action="store_true",
@@ -581,7 +640,11 @@ def main():
                 out["pose_gather"]["rank0_rows_match_tracked_poses"] = bool(np.array_equal(mine, want))
         if world == 1 and args.cpu_frames > 0:
             n = min(args.cpu_frames, args.steps, args.unique_frames - 1)
-            cb = cpu_baseline(seq, n, max(min(n, 20), n // 2))   # >= 20 frames of each shape whenever the run has them
+            try:
+                cb = cpu_baseline(seq, n, max(min(n, 20), n // 2))   # >= 20 frames of each shape whenever the run has them
+            except Exception as e:   # noqa: BLE001 — the headline line is printed regardless: fall back to this process
+                out["cpu_baseline_error"] = f"{type(e).__name__}: {e}"[:500]
+                cb = cpu_baseline_inprocess(seq, n)
             cpu_poses = [np.array(p) for p in cb.pop("poses")]
             # fresh GPU pass over the same frames from the same start: full-pipeline parity next to the timing
             trk2 = api.Tracker(local_rank, overlap_depth=0 if args.no_overlap else args.overlap)
@@ -618,17 +681,30 @@ def main():
             import contextlib
             with contextlib.redirect_stdout(sys.stderr):  # the mirrored classes print the reference's own messages
                 legs = set(args.extras.split(","))
+
+                def leg(key, fn):   # a side measurement that fails must not take the headline JSON line with it
+                    try:
+                        r = fn()
+                        if key is None:
+                            out.update(r)
+                        else:
+                            out[key] = r
+                    except Exception as e:   # noqa: BLE001
+                        out[(key or "shim_path") + "_error"] = f"{type(e).__name__}: {e}"[:500]
                 if "dense" in legs:
-                    out["roofline_dense_1080p"] = dense_1080p_leg(api, synth)
+                    leg("roofline_dense_1080p", lambda: dense_1080p_leg(api, synth))
                 if "disparity" in legs:
-                    out["disparity_1241x376"] = disparity_leg(api, seq, trk)
+                    leg("disparity_1241x376", lambda: disparity_leg(api, seq, trk))
                 if "single" in legs:
-                    out["single_pair_1241x376"] = single_pair_leg(api, seq)
+                    leg("single_pair_1241x376", lambda: single_pair_leg(api, seq))
                 if "shim" in legs:
-                    out.update(shim_leg(api, seq, n_frames=min(200, args.unique_frames)))
+                    leg(None, lambda: shim_leg(api, seq, n_frames=min(200, args.unique_frames)))
                 if "multi" in legs:   # last, with every other stream of this process gone (streams share hardware queues)
                     trk.close()
-                    out["multi_sequence_1gpu"] = [multi_sequence_leg(api, seq, order, n, 200) for n in (2, 4, 8)]
+                    leg("multi_sequence_1gpu", lambda: [multi_sequence_leg(api, seq, order, n, 200) for n in (2, 4, 8)])
+                if "multiproc" in legs:   # opt-in: child processes that share this GPU
+                    trk.close()
+                    leg("multi_process_1gpu", multi_process_leg)
         print(json.dumps(out))
     trk.close()
     if world > 1:

@@ -1065,7 +1065,13 @@ __global__ void __launch_bounds__(kLmBlock) lm_step_kernel(StepArgs a) {
 // sums. Here a single 512-thread workgroup loops evaluate -> reduce (LDS) -> state machine for every level
 // >= min_level: no launch, no global partials, no state reload between iterations. It hands over to the generic step
 // launches with the next level already begun.
-constexpr int kCoarseBlock = 512;
+#ifndef ODO_COARSE_BLOCK
+#define ODO_COARSE_BLOCK 512
+#endif
+// 512 threads, two rounds over a level of <= 1024 points. (1024 threads / one round / 32 sub-lanes per accumulated quantity was
+// measured in round 2: evaluation 4 100 -> 4 430 cycles, reduction 2 650 -> 3 960 per iteration: sixteen waves on one CU pay
+// more at the barriers than the second round costs.)
+constexpr int kCoarseBlock = ODO_COARSE_BLOCK;
 constexpr int kCoarseLdsBytes = kRowFloats * (kCoarseBlock + 8) * (int)sizeof(float);  // [14][512 + 8] floats: point rows
 constexpr int kCoarseMaxPoints = 1024;  // levels with more points go to the multi-block step kernel (measured: a 512-thread
                                         // workgroup walking ~2000 points four per thread is no faster than seven blocks)
@@ -1095,7 +1101,7 @@ __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int
     if (a.dbg) { const unsigned long long now = __builtin_readcyclecounter(); sum += now - c_last; c_last = now; }
   };
   float* rows_sh = (float*)red_sh;  // [14][512 + 8] floats
-  constexpr int kS = 16;            // sub-lanes per quantity: 29 x 16 = 464 accumulating threads
+  constexpr int kS = kCoarseBlock / 32;  // sub-lanes per quantity: 29 x 16 = 464 accumulating threads
   const int my_q = threadIdx.x / kS, my_s = threadIdx.x % kS;
   int rowA = 0, rowB = 0;
   if (my_q < ODO_NACC) rows_of_quantity(my_q, &rowA, &rowB);

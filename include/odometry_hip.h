@@ -105,6 +105,14 @@ int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const int* max_it
  * pseudo-identity whose (3,3) element is 0 (ref: src/lm_optimizer.cpp:48-52,60-65). */
 int odo_lm_solve(odo_lm* lm, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img,
                  float out_colmajor[16]);
+/* n independent Solves (n sequences, each with its own optimiser and pyramids) in the SAME launches: a single Solve is a
+ * serial chain of short launches that leaves most of the chip idle, n chains side by side take the time of the longest.
+ * Per-sequence arithmetic and launch order are those of odo_lm_solve: results are bit-identical to n separate calls. The
+ * optimisers must share one context. out_colmajor: n x 16 floats; status[i] = 0 / -1 per sequence (a failed sequence gets
+ * the pseudo-identity, like odo_lm_solve). Sequences that cannot take the fused point-list pipeline make the call fall back
+ * to one Solve after the other. */
+int odo_lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_img, const odo_pyr* const* kf_dep,
+                       const odo_pyr* const* cur_img, float* out_colmajor, int* status);
 /* Reset (ref: src/lm_optimizer.cpp:373-382): new initial pose and lambda, statistics cleared. */
 int odo_lm_reset(odo_lm* lm, const float init_colmajor[16], float lambda);
 /* ShowReport data (ref: src/lm_optimizer.cpp:364-371). The reference never writes its statistics, so

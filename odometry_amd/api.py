@@ -255,6 +255,19 @@ class LevenbergMarquardtOptimizer:
             pass
 
 
+def solve_batch(lms, kf_imgs, kf_deps, cur_imgs):
+    """odo_lm_solve_batch: the Solves of several independent sequences in the same launches. Returns (poses [n, 4, 4], status [n])."""
+    n = len(lms)
+    lib = lms[0].ctx.lib
+    arr = lambda objs: (C.c_void_p * n)(*[o.h for o in objs])   # noqa: E731
+    out = np.zeros((n, 16), np.float32)
+    st = (C.c_int * n)()
+    L.check(lib.odo_lm_solve_batch(n, arr(lms), arr(kf_imgs), arr(kf_deps), arr(cur_imgs), _fp(out), st), "odo_lm_solve_batch")
+    for m, v in zip(lms, st):
+        m.last_status = v
+    return np.stack([_from_colmajor(o) for o in out]), list(st)
+
+
 class DepthEstimator:
     """ref: include/depth_estimate.h:24-121"""
 

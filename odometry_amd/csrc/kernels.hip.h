@@ -841,6 +841,16 @@ struct StepArgs {
   float* out;           // host-mapped result (42 floats, see lm_write_result), written by the launch that finishes the Solve
   int* done_flag;       // host-mapped: set to `token` when `out` is complete
   int token;            // identifies this Solve in the progress and completion words
+  // batched Solves (one table entry per sequence, constant for the whole Solve; the launch number comes as a kernel argument):
+  LmState* st2[2];      // both state buffers: launch `seq` reads st2[seq & 1], writes st2[(seq + 1) & 1]
+  double* part2[2];     // idem for the partial sums
+  int min_level;        // lm_coarse_kernel: levels >= min_level run inside the workgroup (n_levels = none)
+};
+// What changes from launch to launch of one Solve.
+struct StepLaunch {
+  const LmState* st_in; LmState* st_out;
+  const double* part_in; double* part_out;
+  int seq, first_of_solve;
 };
 
 constexpr int kFoldChunk = 20;  // the 160 rows of a point-list grid in one round of loads per segment
@@ -1007,7 +1017,7 @@ __device__ __forceinline__ void lm_fused_publish(LmState& s_sh, LmState* __restr
 // One generic LM step. Which level it works on is decided on the device (the prologue walks the pyramid), so the host
 // issues identical launches until the device reports that the Solve is finished; the grid is sized for the largest
 // level and the blocks a coarser level does not need stop after the (redundant, parallel) prologue.
-__global__ void __launch_bounds__(kLmBlock) lm_step_kernel(StepArgs a) {
+__device__ __forceinline__ void lm_step_body(const StepArgs& a, const StepLaunch& q) {
   __builtin_amdgcn_s_setprio(3);  // see lm_coarse_kernel
   __shared__ LmState s_sh;
   __shared__ double fold_sh[8 * 32];
@@ -1015,9 +1025,9 @@ __global__ void __launch_bounds__(kLmBlock) lm_step_kernel(StepArgs a) {
   // The last block of the grid evaluates no points: it publishes the state, the trace row and the host progress word
   // (a system-scope release, ~0.5 us) while the other blocks are still evaluating.
   const bool publisher = (blockIdx.x == gridDim.x - 1);
-  if (a.dbg && publisher && threadIdx.x == 0 && a.seq < 56) a.dbg[16 + 2 * a.seq] = wall_clock64();  // diagnostic timeline
-  lm_fused_prologue(a.st_in, a.part_in, a.lv, a.n_levels, a.lambda0, a.precision, s_sh, fold_sh, acc_sh, a.trace, a.cost_stat,
-                    publisher, a.first_of_solve ? a.init : nullptr);
+  if (a.dbg && publisher && threadIdx.x == 0 && q.seq < 56) a.dbg[16 + 2 * q.seq] = wall_clock64();  // diagnostic timeline
+  lm_fused_prologue(q.st_in, q.part_in, a.lv, a.n_levels, a.lambda0, a.precision, s_sh, fold_sh, acc_sh, a.trace, a.cost_stat,
+                    publisher, q.first_of_solve ? a.init : nullptr);
   const bool run = (s_sh.active != 0 && s_sh.status == 0);  // block-uniform
   const int lvl = run ? s_sh.level : 0;
   const StepLevel& L = a.lv[lvl];
@@ -1050,14 +1060,27 @@ __global__ void __launch_bounds__(kLmBlock) lm_step_kernel(StepArgs a) {
     }
 #pragma unroll
     for (int o = kS / 2; o > 0; o >>= 1) accq += __shfl_xor(accq, o, kS);
-    if (my_q < ODO_NACC && my_s == 0) a.part_out[(size_t)blockIdx.x * ODO_NACC + my_q] = accq;
+    if (my_q < ODO_NACC && my_s == 0) q.part_out[(size_t)blockIdx.x * ODO_NACC + my_q] = accq;
   }
   if (publisher) {
     if (threadIdx.x == 0 && run) { s_sh.pending = 1; s_sh.pending_nblk = L.nblk; }
     __syncthreads();
-    lm_fused_publish(s_sh, a.st_out, a.host_prog, a.seq, a.token, a.cost_stat, a.out, a.done_flag);
-    if (a.dbg && threadIdx.x == 0 && a.seq < 56) a.dbg[16 + 2 * a.seq + 1] = wall_clock64();
+    lm_fused_publish(s_sh, q.st_out, a.host_prog, q.seq, a.token, a.cost_stat, a.out, a.done_flag);
+    if (a.dbg && threadIdx.x == 0 && q.seq < 56) a.dbg[16 + 2 * q.seq + 1] = wall_clock64();
   }
+}
+
+__global__ void __launch_bounds__(kLmBlock) lm_step_kernel(StepArgs a) {
+  const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve};
+  lm_step_body(a, q);
+}
+// Several independent Solves in the SAME launches: blockIdx.y picks the sequence's entry of a table in device memory that
+// stays constant for the whole Solve; every sequence runs its own state machine and finishes in its own time (the blocks of
+// a finished sequence return after the prologue). grid = (largest grid of any sequence, number of sequences).
+__global__ void __launch_bounds__(kLmBlock) lm_step_kernel_batch(const StepArgs* __restrict__ table, int seq, int first_of_solve) {
+  const StepArgs& a = table[blockIdx.y];
+  const StepLaunch q = {a.st2[seq & 1], a.st2[(seq + 1) & 1], a.part2[seq & 1], a.part2[(seq + 1) & 1], seq, first_of_solve};
+  lm_step_body(a, q);
 }
 
 // Coarse pyramid levels inside ONE workgroup. A level with a few thousand points does not fill more than a handful of
@@ -1076,7 +1099,7 @@ constexpr int kCoarseLdsBytes = kRowFloats * (kCoarseBlock + 8) * (int)sizeof(fl
 constexpr int kCoarseMaxPoints = 1024;  // levels with more points go to the multi-block step kernel (measured: a 512-thread
                                         // workgroup walking ~2000 points four per thread is no faster than seven blocks)
 
-__global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int min_level) {
+__device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaunch& q, int min_level) {
   // The pose LM is the latency-critical chain of a frame, while the depth stream floods the CUs with throughput work
   // (selection, SSD scan) at the same time: raise this workgroup's issue priority on the SIMDs it shares with them.
   __builtin_amdgcn_s_setprio(3);
@@ -1092,9 +1115,9 @@ __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int
   }
   __syncthreads();
   // state in (or initialised), a pending evaluation of an earlier launch consumed, pyramid walk started
-  lm_fused_prologue(a.st_in, a.part_in, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, red_sh, acc_sh, a.trace, a.cost_stat, true,
-                    a.first_of_solve ? a.init : nullptr);
-  if (a.dbg && threadIdx.x == 0 && a.seq < 56) a.dbg[16 + 2 * a.seq] = wall_clock64();
+  lm_fused_prologue(q.st_in, q.part_in, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, red_sh, acc_sh, a.trace, a.cost_stat, true,
+                    q.first_of_solve ? a.init : nullptr);
+  if (a.dbg && threadIdx.x == 0 && q.seq < 56) a.dbg[16 + 2 * q.seq] = wall_clock64();
   unsigned long long c_eval = 0, c_red = 0, c_sm = 0, c_it = 0, c_last = a.dbg ? __builtin_readcyclecounter() : 0;
   const unsigned long long c_begin = c_last;
   auto lap = [&](unsigned long long& sum) {
@@ -1142,12 +1165,24 @@ __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int
     lm_state_machine(true, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, acc_sh, a.trace, a.cost_stat, true);
     lap(c_sm);
   }
-  lm_fused_publish(s_sh, a.st_out, a.host_prog, a.seq, a.token, a.cost_stat, a.out, a.done_flag);
+  lm_fused_publish(s_sh, q.st_out, a.host_prog, q.seq, a.token, a.cost_stat, a.out, a.done_flag);
   if (a.dbg && threadIdx.x == 0) {
-    if (a.seq < 56) a.dbg[16 + 2 * a.seq + 1] = wall_clock64();
+    if (q.seq < 56) a.dbg[16 + 2 * q.seq + 1] = wall_clock64();
     a.dbg[0] += c_eval; a.dbg[1] += c_red; a.dbg[2] += c_sm; a.dbg[3] += c_it;
     a.dbg[4] += __builtin_readcyclecounter() - c_begin; a.dbg[5] += 1;
   }
+}
+
+__global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int min_level) {
+  const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve};
+  lm_coarse_body(a, q, min_level);
+}
+// Batched twin (see lm_step_kernel_batch): one workgroup per sequence, each with its own min_level (a sequence without a
+// coarse level only initialises its state, begins its first level and publishes).
+__global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel_batch(const StepArgs* __restrict__ table, int seq, int first_of_solve) {
+  const StepArgs& a = table[blockIdx.y];
+  const StepLaunch q = {a.st2[seq & 1], a.st2[(seq + 1) & 1], a.part2[seq & 1], a.part2[(seq + 1) & 1], seq, first_of_solve};
+  lm_coarse_body(a, q, a.min_level);
 }
 
 // End of a fused Solve when no step launch has reported it (no launch was issued at all, or the host is not polling):

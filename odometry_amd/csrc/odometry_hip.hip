@@ -982,6 +982,167 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Batched Solve: S independent optimisers (sequences) advance in the SAME launches (blockIdx.y = sequence). A single
+// sequence is a serial chain of ~8 us launches that leaves the chip idle; S chains side by side cost the time of the
+// longest one. Every optimiser keeps its own state, partial sums, point lists, trace, progress and result words — the
+// per-sequence arithmetic and launch order are exactly those of odo_lm_solve, so the results are bit-identical to S
+// separate Solves (tests/test_gpu_batch.py). All optimisers must share one context (stream). Falls back to one Solve after
+// the other when a sequence cannot take the fused point-list pipeline (dense levels, t-distribution weights).
+// ---------------------------------------------------------------------------------------------------------------
+struct LmBatchScratch {   // per context-less: owned by the first optimiser of a batch
+  StepArgs* h_table;      // pinned
+  StepArgs* d_table;
+  int cap;
+};
+static LmBatchScratch g_lm_batch = {nullptr, nullptr, 0};
+
+// Fills `a` for a fused Solve of `m` (everything that stays constant over the Solve's launches). Returns the grid the
+// step launches need, the launch budget of the step kernel and the first level the coarse kernel does not take.
+static void lm_fill_step_args(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* cur_img, int token, StepArgs* ap, int* grid_out,
+                              int* step_budget, int* min_level_out, double bytes_per_level[ODO_MAX_LEVELS]) {
+  StepArgs& a = *ap;
+  memset(&a, 0, sizeof(a));
+  a.n_levels = m->n_levels;
+  int grid = 1, budget = 0;
+  for (int l = 0; l < m->n_levels; l++) {
+    StepLevel& L = a.lv[l];
+    L.pl = m->pl[l]; L.n = m->npts[l];
+    L.rows = kf_img->r[l]; L.cols = kf_img->c[l];
+    L.nblk = lm_grid_for(m, l, L.rows, L.cols);
+    L.I2 = cur_img->dev + cur_img->off[l];
+    L.k = lm_level_k(m, l);
+    L.max_iters = m->max_iters[l];
+    if (L.nblk + 1 > grid) grid = L.nblk + 1;  // + the publisher block
+    budget += m->max_iters[l] > 0 ? m->max_iters[l] : 0;
+    bytes_per_level[l] = lm_level_bytes(m, l, L.rows, L.cols, L.nblk);
+  }
+  a.lambda0 = m->lambda; a.precision = m->precision; a.robust = m->robust; a.huber_delta = m->huber_delta;
+  a.trace = m->d_trace; a.cost_stat = m->d_cost; a.host_prog = m->d_prog;
+  a.out = m->d_res_map; a.done_flag = m->d_done; a.token = token;
+  memcpy(a.init, m->init, sizeof(a.init));
+  a.st2[0] = m->d_state; a.st2[1] = m->d_state + 1;
+  a.part2[0] = m->d_partials; a.part2[1] = m->d_partials + (size_t)kLmMaxBlocks * ODO_NACC;
+  int min_level = m->n_levels;
+  static const int coarse_max = getenv("ODO_COARSE_MAX") ? atoi(getenv("ODO_COARSE_MAX")) : kCoarseMaxPoints;
+  while (min_level > 0 && m->npts[min_level - 1] <= coarse_max) min_level--;
+  if (!m->coarse) min_level = m->n_levels;
+  a.min_level = min_level;
+  int coarse_budget = 0;
+  for (int l = min_level; l < m->n_levels; l++) coarse_budget += m->max_iters[l] > 0 ? m->max_iters[l] : 0;
+  *grid_out = grid;
+  *step_budget = budget - coarse_budget;
+  *min_level_out = min_level;
+}
+
+extern "C" int odo_lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_img, const odo_pyr* const* kf_dep,
+                                  const odo_pyr* const* cur_img, float* out_colmajor /* n x 16 */, int* status /* n */) {
+  if (n < 1 || !lms || !kf_img || !kf_dep || !cur_img || !out_colmajor || !status) return fail("odo_lm_solve_batch: bad arg");
+  bool batchable = n <= 64;
+  for (int i = 0; i < n && batchable; i++) {
+    if (!lms[i] || lms[i]->ctx != lms[0]->ctx) return fail("odo_lm_solve_batch: the optimisers must share one context");
+    for (int j = 0; j < i; j++) if (lms[j] == lms[i]) return fail("odo_lm_solve_batch: the same optimiser twice");
+    if (lm_check_pyrs(lms[i], kf_img[i], kf_dep[i], cur_img[i])) return -1;
+  }
+  hipStream_t s = lms[0]->ctx->stream;
+  HIP_OK(hipSetDevice(lms[0]->ctx->device));
+  for (int i = 0; i < n; i++) {
+    odo_lm* m = lms[i];
+    if (lm_prepare_keyframe(m, kf_img[i], kf_dep[i])) return -1;
+    bool fused = m->fused && m->robust != 2 && m->poll;
+    for (int l = 0; l < m->n_levels; l++) if (!m->use_list[l]) fused = false;
+    batchable = batchable && fused;
+  }
+  if (!batchable) {  // one after the other: same results, no batching
+    int rc = 0;
+    for (int i = 0; i < n; i++) { status[i] = odo_lm_solve(lms[i], kf_img[i], kf_dep[i], cur_img[i], out_colmajor + 16 * i); }
+    return rc;
+  }
+  if (g_lm_batch.cap < n) {
+    if (g_lm_batch.h_table) { HIP_OK(hipStreamSynchronize(s)); (void)hipHostFree(g_lm_batch.h_table); (void)hipFree(g_lm_batch.d_table); }
+    g_lm_batch.cap = 0;
+    HIP_OK(hipHostMalloc((void**)&g_lm_batch.h_table, sizeof(StepArgs) * (size_t)n, hipHostMallocDefault));
+    HIP_OK(hipMalloc((void**)&g_lm_batch.d_table, sizeof(StepArgs) * (size_t)n));
+    g_lm_batch.cap = n;
+  }
+  int grid = 1, budget = 0, any_coarse = 0;
+  std::vector<std::vector<double>> bytes(n, std::vector<double>(ODO_MAX_LEVELS, 0.0));
+  std::vector<int> tokens(n);
+  for (int i = 0; i < n; i++) {
+    odo_lm* m = lms[i];
+    m->token = (m->token % 0x3ffff) + 1;
+    tokens[i] = m->token;
+    int g = 1, b = 0, ml = 0;
+    lm_fill_step_args(m, kf_img[i], cur_img[i], tokens[i], &g_lm_batch.h_table[i], &g, &b, &ml, bytes[i].data());
+    if (g > grid) grid = g;
+    if (b > budget) budget = b;
+    if (ml < m->n_levels) any_coarse = 1;
+    m->last_coarse = (ml < m->n_levels) ? 1 : 0;
+  }
+  // the table of the previous batched Solve may still be read by its draining launches: order the upload behind them
+  HIP_OK(hipMemcpyAsync(g_lm_batch.d_table, g_lm_batch.h_table, sizeof(StepArgs) * (size_t)n, hipMemcpyHostToDevice, s));
+  auto progress = [&](int i) { const int v = ((volatile int*)lms[i]->h_prog)[0]; return ((v >> kProgSeqBits) == tokens[i]) ? (v & ((1 << kProgSeqBits) - 1)) : 0; };
+  auto finished = [&](int i) { return ((volatile int*)lms[i]->h_prog)[1] == tokens[i]; };
+  auto all_finished = [&]() { for (int i = 0; i < n; i++) if (!finished(i)) return false; return true; };
+  auto min_progress = [&]() { int p = 1 << 30; for (int i = 0; i < n; i++) { const int q = finished(i) ? (1 << 30) : progress(i); if (q < p) p = q; } return p; };
+  int seq = 0, launches = 0;
+  const int run_ahead = lms[0]->run_ahead;
+  if (any_coarse) {
+    hipLaunchKernelGGL(lm_coarse_kernel_batch, dim3(1, n), dim3(kCoarseBlock), kCoarseLdsBytes, s, (const StepArgs*)g_lm_batch.d_table, seq, 1);
+    seq++; launches++;
+  }
+  bool poll_ok = true;
+  for (int it = 0; it < budget + 1; it++) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (!all_finished() && seq - min_progress() > run_ahead) {
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { poll_ok = false; break; }  // never hang
+    }
+    if (all_finished()) break;
+    hipLaunchKernelGGL(lm_step_kernel_batch, dim3(grid, n), dim3(kLmBlock), 0, s, (const StepArgs*)g_lm_batch.d_table, seq,
+                       (seq == 0) ? 1 : 0);
+    seq++; launches++;
+    if (!poll_ok && it >= budget) break;
+  }
+  HIP_OK(hipGetLastError());
+  // results: each sequence's finishing launch wrote its own host-mapped block
+  int any_fail = 0;
+  for (int i = 0; i < n; i++) {
+    odo_lm* m = lms[i];
+    volatile int* done = m->h_done;
+    const auto t0 = std::chrono::steady_clock::now();
+    bool ok = true;
+    while (done[0] != tokens[i]) {
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { ok = false; break; }
+    }
+    if (!ok) {  // drain, then consume this sequence's last evaluation explicitly
+      HIP_OK(hipStreamSynchronize(s));
+      if (done[0] != tokens[i]) {
+        FinalizeArgs fa;
+        const StepArgs& a = g_lm_batch.h_table[i];
+        fa.st_in = a.st2[seq & 1]; fa.part_in = a.part2[seq & 1]; fa.precision = m->precision; fa.trace = m->d_trace;
+        fa.cost_stat = m->d_cost; fa.st_out = a.st2[0]; fa.out = m->d_res_map; fa.done_flag = m->d_done;
+        fa.token = tokens[i]; fa.first_of_solve = (seq == 0) ? 1 : 0;
+        memcpy(fa.init, m->init, sizeof(fa.init));
+        hipLaunchKernelGGL(lm_fused_finalize_kernel, dim3(1), dim3(kLmBlock), 0, s, fa);
+        HIP_OK(hipStreamSynchronize(s));
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    memcpy(m->h_out, m->h_res, sizeof(float) * 42);
+    m->trace_stale = 1;
+    float* o = out_colmajor + 16 * i;
+    memcpy(o, m->h_out, sizeof(float) * 16);
+    m->last_evals = (int)m->h_out[17];
+    m->last_launches = launches;
+    m->last_bytes = 0.0;
+    for (int l = 0; l < ODO_MAX_LEVELS; l++) { m->iters[l] = (int)m->h_out[18 + l]; m->last_bytes += bytes[i][l] * m->iters[l]; }
+    status[i] = (m->h_out[16] != 0.0f) ? -1 : 0;
+    if (status[i]) { any_fail = 1; }
+  }
+  if (any_fail) fail("Optimize failed! ");  // ref: src/lm_optimizer.cpp:60-61 (per-sequence status in `status`)
+  return 0;
+}
+
 // Per-launch HIP-event timing of the evaluation kernel (fused pipeline) on the stream it is launched on.
 // on = 1 starts (and clears) the accumulation, on = 0 stops it; odo_lm_event_stats reads the totals.
 extern "C" int odo_lm_event_timing(odo_lm* m, int on) {

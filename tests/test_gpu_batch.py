@@ -1,0 +1,87 @@
+"""Several sequences in the SAME launches (blockIdx.y = sequence): odo_lm_solve_batch must reproduce S separate odo_lm_solve
+calls BIT FOR BIT — same poses, same per-evaluation traces — whatever the mix of sequences (different keyframes, different
+initial poses, sequences that finish after very different numbers of evaluations)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    from odometry_amd import api
+    api.default_context()
+    return api
+
+
+def _trace_key(tr):
+    return [(t["level"], t["iter"], t["n_res"], t["accepted"], t["stop"], float(t["err"]), float(t["lambda_after"]),
+             tuple(float(v) for v in t["delta"])) for t in tr]
+
+
+@pytest.mark.parametrize("n_seq", [1, 3, 8])
+def test_batched_solve_is_bit_identical_to_separate_solves(api, kitti_seq, n_seq):
+    from odometry_amd import synth
+    L, Z = kitti_seq["left"], kitti_seq["depth"]
+    inv = [synth.semi_dense_inverse_depth(Z[k], L[k]) for k in range(3)]
+    pyr = [api.ImagePyramid(4, L[k], True) for k in range(3)]
+    dep = [api.DepthPyramid(4, inv[k], False) for k in range(3)]
+    # sequence i: keyframe kf[i], current frame cur[i], its own initial pose and robust mode
+    combos = [(0, 1), (1, 2), (0, 2), (1, 0), (2, 1), (0, 0), (2, 0), (1, 1)][:n_seq]
+    inits = []
+    for i in range(n_seq):
+        T = np.eye(4, dtype=np.float32)
+        T[2, 3] = -0.1 * i
+        T[0, 3] = 0.01 * (i % 3)
+        inits.append(T)
+
+    def make(i):
+        return api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], inits[i], None, i % 2, 28.0)
+    single, single_tr, single_ev = [], [], []
+    for i, (a, b) in enumerate(combos):
+        lm = make(i)
+        single.append(lm.Solve(pyr[a], dep[a], pyr[b]))
+        single_tr.append(_trace_key(lm.trace()))
+        single_ev.append(lm.launch_stats()[0])
+        lm.close()
+    lms = [make(i) for i in range(n_seq)]
+    poses, status = api.solve_batch(lms, [pyr[a] for a, _ in combos], [dep[a] for a, _ in combos], [pyr[b] for _, b in combos])
+    assert status == [0] * n_seq
+    assert len(set(single_ev)) > 1 or n_seq == 1      # the sequences really finish at different times
+    for i in range(n_seq):
+        assert np.array_equal(poses[i], single[i]), f"sequence {i}"
+        assert _trace_key(lms[i].trace()) == single_tr[i], f"sequence {i}"
+        assert lms[i].launch_stats()[0] == single_ev[i]
+    # a second batched Solve on the same optimisers (Reset in between, as the runner does) is again identical to single ones
+    for i in range(n_seq):
+        assert lms[i].Reset(poses[i], 0.01) == 0
+    poses2, status2 = api.solve_batch(lms, [pyr[a] for a, _ in combos], [dep[a] for a, _ in combos], [pyr[b] for _, b in combos])
+    for i, (a, b) in enumerate(combos):
+        lm = make(i)
+        lm.Reset(poses[i], 0.01)
+        assert np.array_equal(poses2[i], lm.Solve(pyr[a], dep[a], pyr[b])), f"sequence {i}, second Solve"
+        lm.close()
+    for lm in lms:
+        lm.close()
+
+
+def test_batched_solve_falls_back_for_dense_and_reports_failures(api, kitti_seq):
+    """A sequence that cannot take the fused point-list pipeline (dense scan forced) makes the call run the Solves one after
+    the other — same results; a sequence without any depth fails alone (status -1, pseudo-identity) and the others carry on."""
+    from odometry_amd import synth
+    L, Z = kitti_seq["left"], kitti_seq["depth"]
+    inv = synth.semi_dense_inverse_depth(Z[0], L[0])
+    p0, p1, d0 = api.ImagePyramid(4, L[0], True), api.ImagePyramid(4, L[1], True), api.DepthPyramid(4, inv, False)
+    dz = api.DepthPyramid(4, np.zeros_like(inv), False)
+    ref = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 1, 28.0)
+    want = ref.Solve(p0, d0, p1)
+    lms = [api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 1, 28.0) for _ in range(3)]
+    lms[1].set_mode(1)
+    poses, status = api.solve_batch(lms, [p0, p0, p0], [d0, d0, dz], [p1, p1, p1])
+    assert status == [0, 0, -1]
+    assert np.array_equal(poses[0], want)
+    assert np.abs(poses[1] - want).max() < 1e-5          # the dense scan sums in another order
+    assert poses[2][3, 3] == 0 and poses[2][0, 0] == 1   # ref: src/lm_optimizer.cpp:48-52
+    lms2 = [api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 1, 28.0) for _ in range(2)]
+    poses, status = api.solve_batch(lms2, [p0, p0], [d0, dz], [p1, p1])   # batched path, one failing sequence
+    assert status == [0, -1] and np.array_equal(poses[0], want) and poses[1][3, 3] == 0

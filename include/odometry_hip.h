@@ -259,6 +259,36 @@ int odo_tracker_time_residual(odo_tracker* t, int level, int reps, float* mean_u
 int odo_tracker_timing(odo_tracker* t, double out[4]);
 odo_lm* odo_tracker_lm(odo_tracker* t);
 odo_ctx* odo_tracker_ctx(odo_tracker* t);
+
+/* ---- S sequences in lock step on one GPU (the data-parallel axis of SURVEY section 8e inside one device) -----------------
+ * One odo_tracker tracks one sequence as a serial chain of ~70 short launches per frame, which leaves most of the chip
+ * idle. odo_tracker_batch runs the same frame loop (ref: run_odometry_kitti_offline.cpp:198-271) for n_sequences independent
+ * sequences with every launch carrying all of them (blockIdx.y / .z = sequence). Per-sequence arithmetic, reduction order and
+ * launch order are those of odo_tracker: poses, depth maps and keyframe decisions are bit-identical to n separate trackers.
+ * All sequences share rows / cols / parameters. Arrays are indexed by sequence; poses are n x 16 floats, column-major. */
+typedef struct odo_tracker_batch odo_tracker_batch;
+int odo_tracker_batch_create(int device, const odo_tracker_params* p, int n_sequences, odo_tracker_batch** out);
+int odo_tracker_batch_destroy(odo_tracker_batch* b);
+int odo_tracker_batch_size(const odo_tracker_batch* b);
+odo_ctx* odo_tracker_batch_ctx(odo_tracker_batch* b); /* for odo_dev_alloc / upload / download of its frames */
+/* Frame 0 of every sequence (ref: :95-145). abs_pose0: n x 16, or NULL for identity. Returns -1 if any sequence's
+ * ComputeDepth fails ("Init 0-th frame failed!", ref: :103-106). May be called again to start new sequences. */
+int odo_tracker_batch_init(odo_tracker_batch* b, const float* const* left_dev, const float* const* right_dev,
+                           const float* abs_pose0_colmajor);
+/* One iteration of the frame loop for every sequence. status[i]: 0 tracked; 1 the Solve failed (pseudo-identity, the runner
+ * carries on, ref: src/lm_optimizer.cpp:60-65); -1 ComputeDepth failed on this frame (its pose is still written and the
+ * sequence stops, ref: :230-232); -2 the sequence had stopped earlier (its outputs are untouched). Returns -1 only for
+ * argument / device errors. pose_to_keyframe, abs_pose, is_new_keyframe, motion_mag may be NULL. */
+int odo_tracker_batch_track(odo_tracker_batch* b, const float* const* left_dev, const float* const* right_dev,
+                            float* pose_to_keyframe, float* abs_pose, int* is_new_keyframe, float* motion_mag, int* status);
+/* Counters of the last tracked frame, one entry per sequence (any pointer may be NULL). */
+int odo_tracker_batch_stats(const odo_tracker_batch* b, int* lm_evals, int* depth_iters, int* n_valid_depth, int* n_keyframes);
+/* Diagnostics: host-clock averages per lock step since the last call, microseconds: {whole call, table + pyramid launches,
+ * batched Solve, wait for the depth chain after the Solve}. */
+int odo_tracker_batch_timing(odo_tracker_batch* b, double out[4]);
+/* Device pointers to sequence `seq`'s last outputs (rows x cols): validity mask (u8), disparity, inverse depth. */
+int odo_tracker_batch_outputs(const odo_tracker_batch* b, int seq, const uint8_t** val_dev, const float** disp_dev,
+                              const float** dep_dev);
 int odo_tracker_destroy(odo_tracker* t);
 
 /* ---- camera model: rectified intrinsics per level, undistort + rectify ---------------------------------

@@ -108,6 +108,15 @@ SIGNATURES = {
     "odo_tracker_lm": (_vp, [_vp]),
     "odo_tracker_ctx": (_vp, [_vp]),
     "odo_tracker_destroy": (C.c_int, [_vp]),
+    "odo_tracker_batch_create": (C.c_int, [C.c_int, C.POINTER(TrackerParams), C.c_int, C.POINTER(_vp)]),
+    "odo_tracker_batch_destroy": (C.c_int, [_vp]),
+    "odo_tracker_batch_size": (C.c_int, [_vp]),
+    "odo_tracker_batch_ctx": (_vp, [_vp]),
+    "odo_tracker_batch_init": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), _fp]),
+    "odo_tracker_batch_track": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), _fp, _fp, _ip, _fp, _ip]),
+    "odo_tracker_batch_timing": (C.c_int, [_vp, _dp]),
+    "odo_tracker_batch_stats": (C.c_int, [_vp, _ip, _ip, _ip, _ip]),
+    "odo_tracker_batch_outputs": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "odo_camera_create": (C.c_int, [_vp, C.c_int] + [C.c_double] * 11 + [C.c_int, C.c_int, C.POINTER(_vp)]),
     "odo_camera_configure": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_int]),
     "odo_camera_levels": (C.c_int, [_vp]),

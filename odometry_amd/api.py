@@ -569,3 +569,105 @@ class Tracker:
             self.close()
         except Exception:
             pass
+
+
+class TrackerBatch:
+    """n_sequences independent sequences tracked in lock step on one GPU (odo_tracker_batch_*): the frame loop of
+    ref: run_odometry_kitti_offline.cpp:198-271 once per sequence, every launch carrying all of them. Bit-identical to
+    n_sequences separate `Tracker` objects; frames are device-resident handles from `upload_frame`."""
+
+    def __init__(self, n_sequences, device=0, **overrides):
+        self.lib = L.load()
+        self.n = int(n_sequences)
+        self.params = L.TrackerParams()
+        L.check(self.lib.odo_tracker_default_params(C.byref(self.params)), "odo_tracker_default_params")
+        for k, v in overrides.items():
+            if k == "lm_max_iters":
+                for i, m in enumerate(v):
+                    self.params.lm_max_iters[i] = m
+            elif k == "K":
+                self.params.K = L.Intrinsics(*v)
+            else:
+                setattr(self.params, k, v)
+        h = C.c_void_p()
+        L.check(self.lib.odo_tracker_batch_create(device, C.byref(self.params), self.n, C.byref(h)), "odo_tracker_batch_create")
+        self.h = h
+        self._ctx = C.c_void_p(self.lib.odo_tracker_batch_ctx(h))
+        self._bufs = []
+        self._T = np.zeros(16 * self.n, np.float32)
+        self._A = np.zeros(16 * self.n, np.float32)
+        self._nk = (C.c_int * self.n)()
+        self._st = (C.c_int * self.n)()
+        self._mag = (C.c_float * self.n)()
+
+    def upload_frame(self, img):
+        img = _f32(img)
+        p = C.c_void_p()
+        L.check(self.lib.odo_dev_alloc(self._ctx, img.nbytes, C.byref(p)), "odo_dev_alloc")
+        L.check(self.lib.odo_dev_upload(self._ctx, p, img.ctypes.data_as(C.c_void_p), img.nbytes), "odo_dev_upload")
+        self._bufs.append(p)
+        return p
+
+    def _ptrs(self, handles):
+        if len(handles) != self.n:
+            raise ValueError(f"expected {self.n} frames, got {len(handles)}")
+        return (C.c_void_p * self.n)(*[h.value if isinstance(h, C.c_void_p) else h for h in handles])
+
+    def init(self, lefts, rights, abs_pose0=None):
+        pose = None
+        if abs_pose0 is not None:
+            pose = _fp(np.concatenate([_colmajor(P) for P in abs_pose0]).astype(np.float32))
+        L.check(self.lib.odo_tracker_batch_init(self.h, self._ptrs(lefts), self._ptrs(rights), pose), "odo_tracker_batch_init")
+
+    def track_raw(self, left_ptrs, right_ptrs):
+        """Lean variant for timing loops: takes prepared (c_void_p * n) arrays, returns the status array; poses stay in
+        self._T / self._A (n x 16, column-major)."""
+        st = self.lib.odo_tracker_batch_track(self.h, left_ptrs, right_ptrs, _fp(self._T), _fp(self._A), self._nk, self._mag,
+                                              self._st)
+        if st != 0:
+            raise L.OdoError("odo_tracker_batch_track: " + L.last_error())
+        return self._st
+
+    def track(self, lefts, rights):
+        self.track_raw(self._ptrs(lefts), self._ptrs(rights))
+        out = []
+        for i in range(self.n):
+            out.append(dict(pose_to_keyframe=_from_colmajor(self._T[16 * i:16 * i + 16].copy()),
+                            abs_pose=_from_colmajor(self._A[16 * i:16 * i + 16].copy()), new_keyframe=bool(self._nk[i]),
+                            motion=float(self._mag[i]), status=int(self._st[i])))
+        return out
+
+    def stats(self):
+        arr = [(C.c_int * self.n)() for _ in range(4)]
+        L.check(self.lib.odo_tracker_batch_stats(self.h, *arr), "odo_tracker_batch_stats")
+        return [dict(lm_evals=arr[0][i], depth_iters=arr[1][i], n_valid_depth=arr[2][i], n_keyframes=arr[3][i])
+                for i in range(self.n)]
+
+    def timing(self):
+        out = (C.c_double * 4)()
+        L.check(self.lib.odo_tracker_batch_timing(self.h, out), "odo_tracker_batch_timing")
+        return dict(step_us=out[0], head_us=out[1], solve_us=out[2], depth_wait_us=out[3])
+
+    def outputs(self, seq, rows, cols):
+        v, dsp, dep = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        L.check(self.lib.odo_tracker_batch_outputs(self.h, seq, C.byref(v), C.byref(dsp), C.byref(dep)), "odo_tracker_batch_outputs")
+        out = []
+        for ptr, dt in ((v, np.uint8), (dsp, np.float32), (dep, np.float32)):
+            a = np.empty((rows, cols), dt)
+            L.check(self.lib.odo_dev_download(self._ctx, a.ctypes.data_as(C.c_void_p), ptr, a.nbytes), "download")
+            out.append(a)
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            for p in self._bufs:
+                self.lib.odo_dev_free(self._ctx, p)
+            self._bufs = []
+            self.lib.odo_tracker_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -25,17 +25,17 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // grid.z selects one of up to two images (left/right blurred in one launch).
 // zero_u8 / zero_f0 / zero_f1 (optional): images of the same size cleared by the z == 0 slice — the depth estimator's
 // zero-filled outputs without three extra fill launches.
-__global__ void __launch_bounds__(256) blur3x3_kernel(const float* __restrict__ src0, float* __restrict__ dst0,
+__device__ __forceinline__ void blur3x3_kernel_body(int side, const float* __restrict__ src0, float* __restrict__ dst0,
                                                        const float* __restrict__ src1, float* __restrict__ dst1,
-                                                       int rows, int cols, uint8_t* __restrict__ zero_u8 = nullptr,
-                                                       float* __restrict__ zero_f0 = nullptr,
-                                                       float* __restrict__ zero_f1 = nullptr) {
-  const float* __restrict__ src = blockIdx.z ? src1 : src0;
-  float* __restrict__ dst = blockIdx.z ? dst1 : dst0;
+                                                       int rows, int cols, uint8_t* __restrict__ zero_u8,
+                                                       float* __restrict__ zero_f0,
+                                                       float* __restrict__ zero_f1) {
+  const float* __restrict__ src = side ? src1 : src0;
+  float* __restrict__ dst = side ? dst1 : dst0;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= cols || y >= rows) return;
-  if (blockIdx.z == 0 && zero_u8) {
+  if (side == 0 && zero_u8) {
     const size_t o = (size_t)y * cols + x;
     zero_u8[o] = 0; zero_f0[o] = 0.0f; zero_f1[o] = 0.0f;
   }
@@ -48,6 +48,13 @@ __global__ void __launch_bounds__(256) blur3x3_kernel(const float* __restrict__ 
     t[k] = r[x] * 0.5f + (r[xp] + r[xn]) * 0.25f;
   }
   dst[(size_t)y * cols + x] = t[1] * 0.5f + (t[0] + t[2]) * 0.25f;
+}
+__global__ void __launch_bounds__(256) blur3x3_kernel(const float* __restrict__ src0, float* __restrict__ dst0,
+                                                       const float* __restrict__ src1, float* __restrict__ dst1,
+                                                       int rows, int cols, uint8_t* __restrict__ zero_u8 = nullptr,
+                                                       float* __restrict__ zero_f0 = nullptr,
+                                                       float* __restrict__ zero_f1 = nullptr) {
+  blur3x3_kernel_body((int)blockIdx.z, src0, dst0, src1, dst1, rows, cols, zero_u8, zero_f0, zero_f1);
 }
 
 // 5x5 pyrDown [1,4,6,4,1]/16 per axis sampled at (2x,2y), reflect-101, dst = (rows/2, cols/2)
@@ -103,7 +110,7 @@ __device__ __forceinline__ float pd_v(float r0, float r1, float r2, float r3, fl
 }
 
 constexpr int kPyrThreads = 1024;  // the phases are short dependent LDS passes: more threads = fewer trips per thread
-__global__ void __launch_bounds__(kPyrThreads) image_pyramid_fused_kernel(const float* __restrict__ src, PyrOut o) {
+__device__ __forceinline__ void image_pyramid_fused_kernel_body(const float* __restrict__ src, PyrOut o) {
   __shared__ float in_t[kPIn * kPInS];
   __shared__ float h_t[kPIn * kPL1];   // horizontal pass (reused per level)
   __shared__ float l1_t[kPL1 * kPL1];
@@ -227,10 +234,13 @@ __global__ void __launch_bounds__(kPyrThreads) image_pyramid_fused_kernel(const 
     }
   }
 }
+__global__ void __launch_bounds__(kPyrThreads) image_pyramid_fused_kernel(const float* __restrict__ src, PyrOut o) {
+  image_pyramid_fused_kernel_body(src, o);
+}
 
 // Whole depth pyramid in one launch: L_k(Y,X) = L_0(2^k Y + 2^k - 1, 2^k X + 2^k - 1), the composition of the
 // reference's odd decimations (ref: src/image_processing_global.cpp:85-89,99-103). Thread <-> level-0 pixel.
-__global__ void __launch_bounds__(256) depth_pyramid_fused_kernel(const float* __restrict__ src, PyrOut o) {
+__device__ __forceinline__ void depth_pyramid_fused_kernel_body(const float* __restrict__ src, PyrOut o) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= o.cols[0] || y >= o.rows[0]) return;
@@ -246,6 +256,9 @@ __global__ void __launch_bounds__(256) depth_pyramid_fused_kernel(const float* _
       }
     }
   }
+}
+__global__ void __launch_bounds__(256) depth_pyramid_fused_kernel(const float* __restrict__ src, PyrOut o) {
+  depth_pyramid_fused_kernel_body(src, o);
 }
 
 // =============================================================================================
@@ -387,7 +400,10 @@ __device__ __forceinline__ int kf_find_level(const KfLevels& kl, int grow) {
 }
 
 // Pass 1: one block per interior row (all levels in one launch): number of valid depths in the row.
-__global__ void __launch_bounds__(256) kf_count_kernel(KfLevels kl, int* __restrict__ rowcnt) {
+// KL = KfLevels (a kernel argument, by value) or const KfLevels& (a table entry in global memory: dynamic level indexing
+// then stays plain loads instead of a private copy).
+template <class KL>
+__device__ __forceinline__ void kf_count_kernel_body(KL kl, int* __restrict__ rowcnt) {
   __shared__ int sh[4];
   const int l = kf_find_level(kl, blockIdx.x);
   const int y = 4 + (blockIdx.x - kl.row_base[l]);
@@ -400,17 +416,18 @@ __global__ void __launch_bounds__(256) kf_count_kernel(KfLevels kl, int* __restr
   __syncthreads();
   if (threadIdx.x == 0) rowcnt[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
+__global__ void __launch_bounds__(256) kf_count_kernel(KfLevels kl, int* __restrict__ rowcnt) {
+  kf_count_kernel_body<KfLevels>(kl, rowcnt);
+}
 
 // Pass 2: one block per interior row: its offset from the row counts above it, ordered compaction (ballot prefix), the
 // per-point constants; the last row of a level writes the level's total.
-__global__ void __launch_bounds__(256) kf_fill_kernel(KfLevels kl, float f0, float cx0, float cy0,
-                                                      const int* __restrict__ rowcnt, int* __restrict__ npts, PointList pl0, PointList pl1,
-                                                      PointList pl2, PointList pl3, PointList pl4, PointList pl5,
-                                                      PointList pl6, PointList pl7) {
+// l = the level of this block's row (kf_find_level), pl = that level's list.
+template <class KL>
+__device__ __forceinline__ void kf_fill_kernel_body(KL kl, int l, PointList pl, float f0, float cx0, float cy0,
+                                                      const int* __restrict__ rowcnt, int* __restrict__ npts) {
   __shared__ int wave_tot[4];
   __shared__ int base_sh;
-  const int l = kf_find_level(kl, blockIdx.x);
-  const PointList pl = l == 0 ? pl0 : l == 1 ? pl1 : l == 2 ? pl2 : l == 3 ? pl3 : l == 4 ? pl4 : l == 5 ? pl5 : l == 6 ? pl6 : pl7;
   const int y = 4 + (blockIdx.x - kl.row_base[l]);
   const int cols = kl.cols[l];
   const LevelK k = make_level_k(f0, cx0, cy0, l);
@@ -452,6 +469,14 @@ __global__ void __launch_bounds__(256) kf_fill_kernel(KfLevels kl, float f0, flo
   }
   // the last row of a level knows the level's total
   if (t == 0 && (int)blockIdx.x == kl.row_base[l + 1] - 1) npts[l] = base_sh;
+}
+__global__ void __launch_bounds__(256) kf_fill_kernel(KfLevels kl, float f0, float cx0, float cy0,
+                                                      const int* __restrict__ rowcnt, int* __restrict__ npts, PointList pl0, PointList pl1,
+                                                      PointList pl2, PointList pl3, PointList pl4, PointList pl5,
+                                                      PointList pl6, PointList pl7) {
+  const int l = kf_find_level(kl, blockIdx.x);
+  const PointList pl = l == 0 ? pl0 : l == 1 ? pl1 : l == 2 ? pl2 : l == 3 ? pl3 : l == 4 ? pl4 : l == 5 ? pl5 : l == 6 ? pl6 : pl7;
+  kf_fill_kernel_body<KfLevels>(kl, l, pl, f0, cx0, cy0, rowcnt, npts);
 }
 
 __device__ __forceinline__ PointK load_point(const PointList& pl, int i) {
@@ -1273,7 +1298,7 @@ constexpr int kSelMaxElems = 4096;
 // |grad| on the blurred left image, block median via an LDS bitonic sort, threshold = median + grad_th,
 // first <= 80 pixels in raster order above the threshold. Outputs the mask and a fixed-slot point list
 // pts[block*80 + k] = x | y<<16, cnt[block].
-__global__ void __launch_bounds__(kSelThreads) depth_select_kernel(const float* __restrict__ L, int rows, int cols, int bnd,
+__device__ __forceinline__ void depth_select_kernel_body(const float* __restrict__ L, int rows, int cols, int bnd,
                                                                     float grad_th, uint8_t* __restrict__ val,
                                                                     uint32_t* __restrict__ pts, int* __restrict__ cnt) {
   __shared__ float mag[kSelMaxElems];
@@ -1375,12 +1400,17 @@ __global__ void __launch_bounds__(kSelThreads) depth_select_kernel(const float* 
   }
   if (t == 0) cnt[b] = (base_sh < kSelCap) ? base_sh : kSelCap;
 }
+__global__ void __launch_bounds__(kSelThreads) depth_select_kernel(const float* __restrict__ L, int rows, int cols, int bnd,
+                                                                    float grad_th, uint8_t* __restrict__ val,
+                                                                    uint32_t* __restrict__ pts, int* __restrict__ cnt) {
+  depth_select_kernel_body(L, rows, cols, bnd, grad_th, val, pts, cnt);
+}
 
 // Epipolar line search (ref: src/depth_estimate.cpp:345-398): one wavefront per selected point, lanes scan
 // candidate columns right_x = lo + lane, lo + lane + 64, ... (coalesced reads of five right-image rows), each
 // lane keeps its first strict minimum, then a wave-wide (ssd, right_x) argmin where ties take the lowest
 // right_x — the sequential strict-< scan's answer. SSD uses the AVX hadd tree (ssd8_tree).
-__global__ void __launch_bounds__(256) depth_disparity_kernel(const float* __restrict__ L, const float* __restrict__ R,
+__device__ __forceinline__ void depth_disparity_kernel_body(const float* __restrict__ L, const float* __restrict__ R,
                                                                int rows, int cols, int bnd, int max_disp, float ssd_th,
                                                                float f0, float baseline, const uint32_t* __restrict__ pts,
                                                                const int* __restrict__ cnt, float* __restrict__ disp,
@@ -1431,6 +1461,14 @@ __global__ void __launch_bounds__(256) depth_disparity_kernel(const float* __res
     matched[slot] = hit ? 1 : 0;  // counted later by a reduction (a single-address atomic serialises at ~12 ns each)
   }
 }
+__global__ void __launch_bounds__(256) depth_disparity_kernel(const float* __restrict__ L, const float* __restrict__ R,
+                                                               int rows, int cols, int bnd, int max_disp, float ssd_th,
+                                                               float f0, float baseline, const uint32_t* __restrict__ pts,
+                                                               const int* __restrict__ cnt, float* __restrict__ disp,
+                                                               float* __restrict__ dep, float* __restrict__ d0,
+                                                               uint8_t* __restrict__ matched) {
+  depth_disparity_kernel_body(L, R, rows, cols, bnd, max_disp, ssd_th, f0, baseline, pts, cnt, disp, dep, d0, matched);
+}
 
 struct DepthLmStats {
   int iters;
@@ -1462,7 +1500,7 @@ __device__ __forceinline__ void dlm_report(int* host_prog, int k, int done) {
   __hip_atomic_store(host_prog, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__global__ void __launch_bounds__(kDlmBlock) depth_lm_step_kernel(
+__device__ __forceinline__ void depth_lm_step_kernel_body(
     int k, const float* __restrict__ left, const float* __restrict__ right, int cols, const uint32_t* __restrict__ pts,
     const int* __restrict__ cnt, const float* __restrict__ d0, float* __restrict__ scratch /* 6 x nslots */,
     DepthLmState* __restrict__ state /* [2] */, double* __restrict__ part_e /* [2][blocks] */,
@@ -1584,10 +1622,18 @@ __global__ void __launch_bounds__(kDlmBlock) depth_lm_step_kernel(
     if (blockIdx.x == 0) { state[(k + 1) & 1] = st; dlm_report(host_prog, k, 0); }
   }
 }
+__global__ void __launch_bounds__(kDlmBlock) depth_lm_step_kernel(
+    int k, const float* __restrict__ left, const float* __restrict__ right, int cols, const uint32_t* __restrict__ pts,
+    const int* __restrict__ cnt, const float* __restrict__ d0, float* __restrict__ scratch /* 6 x nslots */,
+    DepthLmState* __restrict__ state /* [2] */, double* __restrict__ part_e /* [2][blocks] */,
+    int* __restrict__ part_n /* [2][blocks] */, float tx, float fx, float huber_delta, float lambda0, float precision,
+    int max_iters, int* __restrict__ host_prog) {
+  depth_lm_step_kernel_body(k, left, right, cols, pts, cnt, d0, scratch, state, part_e, part_n, tx, fx, huber_delta, lambda0, precision, max_iters, host_prog);
+}
 
 // Write-back + filters (ref: src/depth_estimate.cpp:176-191) and per-block counts {valid, selected, matched}.
 // run_lm == 0: disparity-only entry (counts only, mask/depth untouched).
-__global__ void __launch_bounds__(kDlmBlock) depth_finalize_kernel(int run_lm, int cols, const uint32_t* __restrict__ pts,
+__device__ __forceinline__ void depth_finalize_kernel_body(int run_lm, int cols, const uint32_t* __restrict__ pts,
                                                                    const int* __restrict__ cnt,
                                                                    const uint8_t* __restrict__ matched,
                                                                    const float* __restrict__ scratch, float photo_th,
@@ -1621,8 +1667,17 @@ __global__ void __launch_bounds__(kDlmBlock) depth_finalize_kernel(int run_lm, i
   }
   if (t < 3) counts[blockIdx.x * 3 + t] = sh[t][0];
 }
+__global__ void __launch_bounds__(kDlmBlock) depth_finalize_kernel(int run_lm, int cols, const uint32_t* __restrict__ pts,
+                                                                   const int* __restrict__ cnt,
+                                                                   const uint8_t* __restrict__ matched,
+                                                                   const float* __restrict__ scratch, float photo_th,
+                                                                   float min_depth, float max_depth,
+                                                                   uint8_t* __restrict__ val, float* __restrict__ dep,
+                                                                   int* __restrict__ counts /* [blocks][3] */) {
+  depth_finalize_kernel_body(run_lm, cols, pts, cnt, matched, scratch, photo_th, min_depth, max_depth, val, dep, counts);
+}
 
-__global__ void __launch_bounds__(kDlmBlock) depth_stats_kernel(int run_lm, int n_launches, const int* __restrict__ counts,
+__device__ __forceinline__ void depth_stats_kernel_body(int run_lm, int n_launches, const int* __restrict__ counts,
                                                                 const DepthLmState* __restrict__ state,
                                                                 DepthLmStats* __restrict__ stats /* host-mapped */,
                                                                 int* __restrict__ done_flag, int token) {
@@ -1644,6 +1699,12 @@ __global__ void __launch_bounds__(kDlmBlock) depth_stats_kernel(int run_lm, int 
     stats->status = (run_lm && sh[0][0] < 500) ? -1 : 0;  // :192-197
     __hip_atomic_store(done_flag, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+}
+__global__ void __launch_bounds__(kDlmBlock) depth_stats_kernel(int run_lm, int n_launches, const int* __restrict__ counts,
+                                                                const DepthLmState* __restrict__ state,
+                                                                DepthLmStats* __restrict__ stats /* host-mapped */,
+                                                                int* __restrict__ done_flag, int token) {
+  depth_stats_kernel_body(run_lm, n_launches, counts, state, stats, done_flag, token);
 }
 
 }  // namespace odo

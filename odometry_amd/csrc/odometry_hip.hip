@@ -601,9 +601,10 @@ static int lm_ensure_res(odo_lm* m, size_t n) {
 // Enqueues the two launches that compact the keyframe's valid-depth pixels of every level into point lists (and the
 // 32-byte read-back of the per-level counts) on `s`. img supplies I1, dep the inverse depths; both pyramids have the same
 // geometry. Buffers grow on demand (only the first keyframes of a run allocate).
-static int lm_enqueue_lists(odo_lm* m, PointList* pl, size_t* pl_cap, int*& d_rowcnt, int& rows_cap, int* d_npts,
-                            int* h_npts, const odo_pyr* img, const odo_pyr* dep, hipStream_t s, int* rows_total_out) {
-  KfLevels kl;
+// Level geometry of a list build + the (grow-only) allocations it needs; no launches.
+static int lm_lists_layout(odo_lm* m, PointList* pl, size_t* pl_cap, int*& d_rowcnt, int& rows_cap, const odo_pyr* img,
+                           const odo_pyr* dep, hipStream_t s, KfLevels* kl_out, int* rows_total_out) {
+  KfLevels& kl = *kl_out;
   memset(&kl, 0, sizeof(kl));
   kl.n_levels = m->n_levels;
   int rows_total = 0;
@@ -635,6 +636,15 @@ static int lm_enqueue_lists(odo_lm* m, PointList* pl, size_t* pl_cap, int*& d_ro
     HIP_OK(hipMalloc((void**)&d_rowcnt, sizeof(int) * rows_total));
     rows_cap = rows_total;
   }
+  *rows_total_out = rows_total;
+  return 0;
+}
+
+static int lm_enqueue_lists(odo_lm* m, PointList* pl, size_t* pl_cap, int*& d_rowcnt, int& rows_cap, int* d_npts,
+                            int* h_npts, const odo_pyr* img, const odo_pyr* dep, hipStream_t s, int* rows_total_out) {
+  KfLevels kl;
+  int rows_total = 0;
+  if (lm_lists_layout(m, pl, pl_cap, d_rowcnt, rows_cap, img, dep, s, &kl, &rows_total)) return -1;
   *rows_total_out = rows_total;
   if (rows_total > 0) {
     HIP_OK(hipMemsetAsync(d_npts, 0, sizeof(int) * ODO_MAX_LEVELS, s));  // levels without interior rows stay at 0
@@ -1035,8 +1045,10 @@ static void lm_fill_step_args(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* c
   *min_level_out = min_level;
 }
 
-extern "C" int odo_lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_img, const odo_pyr* const* kf_dep,
-                                  const odo_pyr* const* cur_img, float* out_colmajor /* n x 16 */, int* status /* n */) {
+// idle / idle_arg: called from the wait loops (the batched tracker pumps its depth stream from there), may be NULL.
+static int lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_img, const odo_pyr* const* kf_dep,
+                          const odo_pyr* const* cur_img, float* out_colmajor /* n x 16 */, int* status /* n */,
+                          void (*idle)(void*), void* idle_arg) {
   if (n < 1 || !lms || !kf_img || !kf_dep || !cur_img || !out_colmajor || !status) return fail("odo_lm_solve_batch: bad arg");
   bool batchable = n <= 64;
   for (int i = 0; i < n && batchable; i++) {
@@ -1095,6 +1107,7 @@ extern "C" int odo_lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* cons
   for (int it = 0; it < budget + 1; it++) {
     const auto t0 = std::chrono::steady_clock::now();
     while (!all_finished() && seq - min_progress() > run_ahead) {
+      if (idle) idle(idle_arg);
       if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { poll_ok = false; break; }  // never hang
     }
     if (all_finished()) break;
@@ -1112,6 +1125,7 @@ extern "C" int odo_lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* cons
     const auto t0 = std::chrono::steady_clock::now();
     bool ok = true;
     while (done[0] != tokens[i]) {
+      if (idle) idle(idle_arg);
       if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { ok = false; break; }
     }
     if (!ok) {  // drain, then consume this sequence's last evaluation explicitly
@@ -1141,6 +1155,11 @@ extern "C" int odo_lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* cons
   }
   if (any_fail) fail("Optimize failed! ");  // ref: src/lm_optimizer.cpp:60-61 (per-sequence status in `status`)
   return 0;
+}
+
+extern "C" int odo_lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_img, const odo_pyr* const* kf_dep,
+                                  const odo_pyr* const* cur_img, float* out_colmajor /* n x 16 */, int* status /* n */) {
+  return lm_solve_batch(n, lms, kf_img, kf_dep, cur_img, out_colmajor, status, nullptr, nullptr);
 }
 
 // Per-launch HIP-event timing of the evaluation kernel (fused pipeline) on the stream it is launched on.
@@ -1597,4 +1616,5 @@ extern "C" int odo_depth_report(const odo_depth* d, int* iters, float* cost, int
 }
 
 #include "tracker.hip.h"
+#include "batch.hip.h"
 #include "camera.hip.h"

@@ -85,3 +85,84 @@ def test_batched_solve_falls_back_for_dense_and_reports_failures(api, kitti_seq)
     lms2 = [api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 1, 28.0) for _ in range(2)]
     poses, status = api.solve_batch(lms2, [p0, p0], [d0, dz], [p1, p1])   # batched path, one failing sequence
     assert status == [0, -1] and np.array_equal(poses[0], want) and poses[1][3, 3] == 0
+
+
+# ---- whole frame loop: S sequences in lock step (odo_tracker_batch_*) vs S separate trackers -------------------------------
+
+@pytest.fixture(scope="module")
+def drives():
+    """Three different 11-frame KITTI-shaped drives (the seed-0 drive switches keyframe at frame 9)."""
+    from odometry_amd import synth
+    return [synth.make_sequence(11, seed=s) for s in (0, 1, 2)]
+
+
+def _track_single(api, seq, n_frames):
+    trk = api.Tracker()
+    L = [trk.upload_frame(f) for f in seq["left"][:n_frames]]
+    R = [trk.upload_frame(f) for f in seq["right"][:n_frames]]
+    trk.init(L[0], R[0])
+    out = []
+    for k in range(1, n_frames):
+        r = trk.track(L[k], R[k])
+        r["stats"] = trk.stats()
+        out.append(r)
+    rows, cols = seq["left"][0].shape
+    maps = trk.outputs(rows, cols)
+    trk.close()
+    return out, maps
+
+
+@pytest.mark.parametrize("n_seq,overlap", [(1, 2), (3, 2), (3, 0)])
+def test_batched_tracker_is_bit_identical_to_separate_trackers(api, drives, n_seq, overlap):
+    n_frames = 11
+    seqs = drives[:n_seq]
+    singles = [_track_single(api, s, n_frames) for s in seqs]
+    assert any(r["new_keyframe"] for r in singles[0][0])          # the comparison covers a keyframe switch
+    tb = api.TrackerBatch(n_seq, overlap_depth=overlap)
+    L = [[tb.upload_frame(f) for f in s["left"][:n_frames]] for s in seqs]
+    R = [[tb.upload_frame(f) for f in s["right"][:n_frames]] for s in seqs]
+    tb.init([L[i][0] for i in range(n_seq)], [R[i][0] for i in range(n_seq)])
+    for k in range(1, n_frames):
+        res = tb.track([L[i][k] for i in range(n_seq)], [R[i][k] for i in range(n_seq)])
+        st = tb.stats()
+        for i in range(n_seq):
+            ref = singles[i][0][k - 1]
+            assert res[i]["status"] == 0
+            assert np.array_equal(res[i]["pose_to_keyframe"], ref["pose_to_keyframe"]), f"sequence {i} frame {k}"
+            assert np.array_equal(res[i]["abs_pose"], ref["abs_pose"]), f"sequence {i} frame {k}"
+            assert res[i]["new_keyframe"] == ref["new_keyframe"], f"sequence {i} frame {k}"
+            assert res[i]["motion"] == ref["motion"]
+            assert st[i] == ref["stats"], f"sequence {i} frame {k}"
+    rows, cols = seqs[0]["left"][0].shape
+    for i in range(n_seq):
+        for a, b in zip(tb.outputs(i, rows, cols), singles[i][1]):
+            assert np.array_equal(a, b)
+    tb.close()
+
+
+def test_batched_tracker_restart_and_stopped_sequence(api, drives):
+    """init() again starts new sequences on the same object; a sequence whose ComputeDepth fails stops (status -1, then -2)
+    while the others carry on with unchanged results."""
+    n_frames = 4
+    seqs = drives[:2]
+    ref = [_track_single(api, s, n_frames)[0] for s in seqs]
+    tb = api.TrackerBatch(2)
+    L = [[tb.upload_frame(f) for f in s["left"][:n_frames]] for s in seqs]
+    R = [[tb.upload_frame(f) for f in s["right"][:n_frames]] for s in seqs]
+    flat = tb.upload_frame(np.full_like(seqs[0]["left"][0], 90.0))   # no gradients: no selected points, ComputeDepth fails
+    for rep in range(2):
+        tb.init([L[0][0], L[1][0]], [R[0][0], R[1][0]])
+        for k in range(1, n_frames):
+            res = tb.track([L[0][k], L[1][k]], [R[0][k], R[1][k]])
+            for i in range(2):
+                assert np.array_equal(res[i]["pose_to_keyframe"], ref[i][k - 1]["pose_to_keyframe"]), (rep, i, k)
+    tb.init([L[0][0], L[1][0]], [R[0][0], R[1][0]])
+    res = tb.track([L[0][1], flat], [R[0][1], flat])
+    assert res[0]["status"] == 0 and res[1]["status"] == -1
+    assert np.array_equal(res[0]["pose_to_keyframe"], ref[0][0]["pose_to_keyframe"])
+    res = tb.track([L[0][2], L[1][2]], [R[0][2], R[1][2]])
+    assert res[0]["status"] == 0 and res[1]["status"] == -2
+    assert np.array_equal(res[0]["pose_to_keyframe"], ref[0][1]["pose_to_keyframe"])
+    with pytest.raises(api.L.OdoError):
+        tb.init([L[0][0], flat], [R[0][0], flat])      # "Init 0-th frame failed!"
+    tb.close()

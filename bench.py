@@ -423,6 +423,61 @@ def multi_sequence_leg(api, seq, order, n_seq, steps):
     return dict(sequences_in_flight=n_seq, frames_per_s=round(n_seq * steps / dt, 1), steps_each=steps)
 
 
+def batched_sequences_leg(api, seqs, counts=(1, 2, 4, 8), passes=3):
+    """Frames/s per GPU with S independent sequences tracked in lock step by ONE odo_tracker_batch (every launch carries all S
+    sequences: blockIdx.y / .z = sequence) — the data-parallel axis of configs[3] inside one device. Not `value` (configs[1] is
+    one sequence, whose frames are serial). Distinct synthetic drives (seeds 0..S-1), `passes` passes over their first frames,
+    each pass started like the runner starts a sequence; sequence 0's poses are checked bit for bit against the single tracker."""
+    n_frames = len(seqs[0]["left"])
+    trk = api.Tracker()
+    L = [trk.upload_frame(f) for f in seqs[0]["left"]]
+    R = [trk.upload_frame(f) for f in seqs[0]["right"]]
+    ref = np.zeros((n_frames, 16), np.float32)
+    scratch = np.zeros(16, np.float32)
+    for rep in range(passes + 1):
+        if rep == 1:
+            t0 = time.perf_counter()
+        trk.init(L[0], R[0])
+        for k in range(1, n_frames):
+            if k + 1 < n_frames:
+                trk.hint_next(L[k + 1])
+            trk.track_into(L[k], R[k], ref[k], scratch)
+    single_fps = passes * (n_frames - 1) / (time.perf_counter() - t0)
+    trk.close()
+    rows = []
+    for S in counts:
+        if S > len(seqs):
+            break
+        tb = api.TrackerBatch(S)
+        Ls = [[tb.upload_frame(f) for f in seqs[i]["left"]] for i in range(S)]
+        Rs = [[tb.upload_frame(f) for f in seqs[i]["right"]] for i in range(S)]
+        lp = [tb._ptrs([Ls[i][k] for i in range(S)]) for k in range(n_frames)]
+        rp = [tb._ptrs([Rs[i][k] for i in range(S)]) for k in range(n_frames)]
+        same, evals = True, []
+        for rep in range(passes + 1):
+            if rep == 1:
+                tb.timing()
+                t0 = time.perf_counter()
+            tb.init([Ls[i][0] for i in range(S)], [Rs[i][0] for i in range(S)])
+            for k in range(1, n_frames):
+                st = tb.track_raw(lp[k], rp[k])
+                if rep == 0:
+                    same = same and all(v == 0 for v in st) and bool(np.array_equal(tb._T[:16], ref[k]))
+                    evals.append([q["lm_evals"] for q in tb.stats()])
+        dt = time.perf_counter() - t0
+        tm = tb.timing()
+        tb.close()
+        ev = np.array(evals)
+        rows.append(dict(sequences=S, frames_per_s=round(S * passes * (n_frames - 1) / dt, 1),
+                         us_per_lock_step=round(dt / (passes * (n_frames - 1)) * 1e6, 1),
+                         lm_evals_per_frame_mean=round(float(ev.mean()), 1),
+                         lm_evals_per_lock_step=round(float(ev.max(axis=1).mean()), 1),
+                         solve_us=round(tm["solve_us"], 1), sequence0_bit_identical_to_single_tracker=same))
+    return dict(single_tracker_frames_per_s=round(single_fps, 1), frames_per_sequence=n_frames - 1, passes=passes, batched=rows,
+                note="a lock step costs the slowest sequence's evaluations (lm_evals_per_lock_step) plus the throughput-bound "
+                     "front end (pyramids, blur, selection, disparity scan) of all S frames")
+
+
 def main():
     if os.environ.get("ODO_BENCH_FAULT_DUMP"):   # diagnostic: Python stacks of every thread on stderr after this many seconds
         import faulthandler
@@ -441,9 +496,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="run ComputeDepth after Solve on one stream")
     ap.add_argument("--no-prefetch", action="store_true", help="build each frame's image pyramid inside its own step")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements")
-    ap.add_argument("--extras", default="dense,disparity,single,shim",
+    ap.add_argument("--extras", default="dense,disparity,single,shim,batched",
                     help="side measurements to run: dense (configs[2]), disparity (configs[4]), single (configs[0]), shim (the "
-                         "drop-in C++ classes and the host-buffer C ABI, PCIe included); "
+                         "drop-in C++ classes and the host-buffer C ABI, PCIe included), batched (S = 1/2/4/8 sequences in lock step on one GPU); "
                          "multi / multiproc (several trackers of one process / several processes on one GPU) are opt-in: it floods the device with concurrent "
                          "trackers, which is not what a profile of this command is meant to show")
     ap.add_argument("--overlap", type=int, default=2, help="1: one host thread feeds both streams, 2: helper thread")
@@ -454,6 +509,9 @@ def main():
                          "over the ranks (dist.shard); every sequence is tracked for --steps frames, a rank tracks its sequences "
                          "one after the other; value = sequences x steps / max-over-ranks wall time. 0 (default) = one sequence "
                          "per rank, --steps frames each (weak scaling, the driver's contract)")
+    ap.add_argument("--no-batch", action="store_true",
+                    help="--sequences: a rank that holds several sequences tracks them one after the other (one odo_tracker) instead "
+                         "of in lock step in the same launches (odo_tracker_batch)")
     args = ap.parse_args()
     args.unique_frames = max(args.unique_frames, 2)
 
@@ -473,6 +531,10 @@ def main():
     else:
         seqs = [render_sequence(args.unique_frames, rank if args.distinct_sequences else 0, workers)]
     seq = seqs[0] if seqs else render_sequence(args.unique_frames, 0, workers)   # a rank without a sequence still takes part
+    batch_seqs = None
+    if world == 1 and not args.no_extras and "batched" in args.extras.split(","):
+        nb = min(args.unique_frames, 40)   # eight distinct short drives for the batched leg (rendered before the GPU is touched)
+        batch_seqs = [dict(left=seq["left"][:nb], right=seq["right"][:nb])] + [render_sequence(nb, sid, workers) for sid in range(1, 8)]
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -544,6 +606,33 @@ def main():
             for k in range(args.warmup):
                 step(j, k, dv, False)
 
+    # configs[3] with more sequences than GPUs: the sequences of one rank advance in lock step, every launch carrying all of them
+    # (odo_tracker_batch: bit-identical to one tracker per sequence, tests/test_gpu_batch.py)
+    use_batch = args.sequences > 0 and len(my_seq_ids) > 1 and not args.no_batch
+    tb = None
+    if use_batch:
+        m = len(my_seq_ids)
+        tb = api.TrackerBatch(m, local_rank, overlap_depth=0 if args.no_overlap else args.overlap)
+        bdev = [[(tb.upload_frame(l), tb.upload_frame(r)) for l, r in zip(q["left"], q["right"])] for q in seqs]
+        blp = [tb._ptrs([bdev[j][i][0] for j in range(m)]) for i in range(args.unique_frames)]
+        brp = [tb._ptrs([bdev[j][i][1] for j in range(m)]) for i in range(args.unique_frames)]
+
+    def run_batched():
+        m = len(my_seq_ids)
+        tb.init([bdev[j][0][0] for j in range(m)], [bdev[j][0][1] for j in range(m)])
+        for k in range(n_total):
+            i = order[k]
+            if begins_pass(order, k):
+                tb.init([bdev[j][0][0] for j in range(m)], [bdev[j][0][1] for j in range(m)])
+            if not args.no_prefetch and k + 1 < n_total:
+                tb.hint_next(blp[order[k + 1]])
+            tb.track_raw(blp[i], brp[i])
+            poses_kf[:, k, :] = tb._T.reshape(m, 16)
+            poses_abs[:, k, :] = tb._A.reshape(m, 16)
+            if k >= args.warmup and gatherer is not None:
+                for j in range(m):
+                    gatherer.push(poses_abs[j, k].reshape(4, 4).T, seq_id=my_seq_ids[j], frame_id=i)
+
     if my_seq_ids and args.sequences == 0:
         run_sequence(0, False)
     barrier()
@@ -563,6 +652,8 @@ def main():
         top = np.argsort(st)[-8:][::-1]
         print("[step times] median %.1f mean %.1f us; slowest:" % (np.median(st), st.mean()),
               ", ".join("#%d %.0f" % (j, st[j]) for j in top), file=sys.stderr)
+    elif use_batch:
+        run_batched()
     else:
         for j in range(len(my_seq_ids)):
             run_sequence(j, True)
@@ -618,6 +709,7 @@ def main():
                                         "unique_frames frames, the tracker re-initialised on frame 0 at each pass), 1241x376, "
                                         "4 levels, semi-dense, runner params, one sequence per GPU",
                                unique_frames=args.unique_frames, sequences_per_gpu=1,
+                               sequences_in_lock_step_on_rank0=len(my_seq_ids) if use_batch else 0,
                                sequences=n_sequences, frames_per_rank=per_rank,
                                overlap_depth=0 if args.no_overlap else args.overlap, gather_every=args.gather_every,
                                next_frame_pyramid_prefetch=not args.no_prefetch,
@@ -697,6 +789,8 @@ def main():
                     leg("disparity_1241x376", lambda: disparity_leg(api, seq, trk))
                 if "single" in legs:
                     leg("single_pair_1241x376", lambda: single_pair_leg(api, seq))
+                if "batched" in legs and batch_seqs is not None:
+                    leg("batched_sequences", lambda: batched_sequences_leg(api, batch_seqs))
                 if "shim" in legs:
                     leg(None, lambda: shim_leg(api, seq, n_frames=min(200, args.unique_frames)))
                 if "multi" in legs:   # last, with every other stream of this process gone (streams share hardware queues)

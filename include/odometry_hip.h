@@ -271,16 +271,26 @@ int odo_tracker_batch_create(int device, const odo_tracker_params* p, int n_sequ
 int odo_tracker_batch_destroy(odo_tracker_batch* b);
 int odo_tracker_batch_size(const odo_tracker_batch* b);
 odo_ctx* odo_tracker_batch_ctx(odo_tracker_batch* b); /* for odo_dev_alloc / upload / download of its frames */
-/* Frame 0 of every sequence (ref: :95-145). abs_pose0: n x 16, or NULL for identity. Returns -1 if any sequence's
- * ComputeDepth fails ("Init 0-th frame failed!", ref: :103-106). May be called again to start new sequences. */
+/* Frame 0 (ref: :95-145) of every slot that is given a pair; a slot whose left_dev[i] / right_dev[i] are NULL stays empty.
+ * abs_pose0: n x 16, or NULL for identity. Returns -1 if any sequence's ComputeDepth fails ("Init 0-th frame failed!",
+ * ref: :103-106; the other slots are initialised all the same). May be called again to start new sequences. */
 int odo_tracker_batch_init(odo_tracker_batch* b, const float* const* left_dev, const float* const* right_dev,
                            const float* abs_pose0_colmajor);
-/* One iteration of the frame loop for every sequence. status[i]: 0 tracked; 1 the Solve failed (pseudo-identity, the runner
- * carries on, ref: src/lm_optimizer.cpp:60-65); -1 ComputeDepth failed on this frame (its pose is still written and the
- * sequence stops, ref: :230-232); -2 the sequence had stopped earlier (its outputs are untouched). Returns -1 only for
- * argument / device errors. pose_to_keyframe, abs_pose, is_new_keyframe, motion_mag may be NULL. */
+/* Starts a new sequence in ONE slot while the other slots keep theirs (sequences of different lengths: when one ends its
+ * slot takes the next sequence). Drains both streams first. abs_pose0: 16 floats or NULL for identity. */
+int odo_tracker_batch_init_one(odo_tracker_batch* b, int slot, const float* left_dev, const float* right_dev,
+                               const float abs_pose0_colmajor[16]);
+/* One iteration of the frame loop for every slot that is given a frame. status[i]: 0 tracked; 1 the Solve failed
+ * (pseudo-identity, the runner carries on, ref: src/lm_optimizer.cpp:60-65); -1 ComputeDepth failed on this frame (its pose is
+ * still written and the sequence stops, ref: :230-232); -2 the slot holds no running sequence (empty, or stopped earlier: its
+ * outputs are untouched); -3 no frame was given for the slot (left_dev[i] == NULL): it sits this step out, its state is kept,
+ * it costs nothing. Returns -1 only for argument / device errors. pose_to_keyframe, abs_pose, is_new_keyframe, motion_mag may
+ * be NULL. */
 int odo_tracker_batch_track(odo_tracker_batch* b, const float* const* left_dev, const float* const* right_dev,
                             float* pose_to_keyframe, float* abs_pose, int* is_new_keyframe, float* motion_mag, int* status);
+/* Optional pipelining, as odo_tracker_hint_next: the left images of the NEXT step (n pointers, NULL entries allowed), announced
+ * before odo_tracker_batch_track of the current one; their pyramids are built behind this step's Solve. Same work, earlier. */
+int odo_tracker_batch_hint_next(odo_tracker_batch* b, const float* const* next_left_dev);
 /* Counters of the last tracked frame, one entry per sequence (any pointer may be NULL). */
 int odo_tracker_batch_stats(const odo_tracker_batch* b, int* lm_evals, int* depth_iters, int* n_valid_depth, int* n_keyframes);
 /* Diagnostics: host-clock averages per lock step since the last call, microseconds: {whole call, table + pyramid launches,

@@ -619,6 +619,15 @@ class TrackerBatch:
             pose = _fp(np.concatenate([_colmajor(P) for P in abs_pose0]).astype(np.float32))
         L.check(self.lib.odo_tracker_batch_init(self.h, self._ptrs(lefts), self._ptrs(rights), pose), "odo_tracker_batch_init")
 
+    def init_one(self, slot, left, right, abs_pose0=None):
+        pose = None if abs_pose0 is None else _fp(_colmajor(abs_pose0))
+        L.check(self.lib.odo_tracker_batch_init_one(self.h, slot, left, right, pose), "odo_tracker_batch_init_one")
+
+    def hint_next(self, next_lefts):
+        """next_lefts: n handles (None allowed) or a prepared (c_void_p * n) array."""
+        arr = next_lefts if isinstance(next_lefts, C.Array) else self._ptrs(next_lefts)
+        L.check(self.lib.odo_tracker_batch_hint_next(self.h, arr), "odo_tracker_batch_hint_next")
+
     def track_raw(self, left_ptrs, right_ptrs):
         """Lean variant for timing loops: takes prepared (c_void_p * n) arrays, returns the status array; poses stay in
         self._T / self._A (n x 16, column-major)."""

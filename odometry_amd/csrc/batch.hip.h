@@ -97,24 +97,26 @@ __global__ void __launch_bounds__(kDlmBlock) depth_stats_batch_kernel(const Batc
 
 struct odo_tracker_batch {
   odo_tracker_params p;
-  int S;
+  int S;           // slots
   odo_ctx* ctx_a;  // image pyramids + pose LM
   odo_ctx* ctx_b;  // ComputeDepth, depth pyramids, candidate lists
   std::vector<odo_lm*> lm;
   std::vector<odo_depth*> depth;
-  std::vector<odo_pyr*> kf_img, kf_dep, cur_img, pre_dep;
+  std::vector<odo_pyr*> kf_img, kf_dep, cur_img, pre_dep, next_img;
   std::vector<uint8_t*> d_val;
   std::vector<float*> d_disp, d_dep;
   std::vector<float> kf_abs, pose_to_kf;  // S x 16
   std::vector<int> n_keyframes, alive, last_evals, last_depth_iters, last_valid;
-  int frame_id;
-  BatchSeq* h_tab;  // pinned
+  std::vector<long> frame_id;             // per slot: frames tracked since its init (tags the candidate lists)
+  std::vector<const float*> hint_next, prefetched;  // per slot: announced next left image / image whose pyramid sits in next_img
+  BatchSeq* h_tab;  // pinned, 2 S entries: [0, S) the lock step in flight, [S, 2S) the prefetch launch's pyramid-only entries
   BatchSeq* d_tab;
   int* h_cand_npts;  // host-mapped, S x ODO_MAX_LEVELS
   int* d_cand_npts;  // its device alias
   hipEvent_t ev_cur_img, ev_tab;
   int overlap;       // 1: the depth chain runs on stream B beside the pose LM on stream A (one host thread feeds both)
-  // depth chain state of the frame in flight
+  // the set of slots of the step in flight (table entry e <-> slot ids[e]) and its depth chain
+  std::vector<int> ids;
   int dk, dn_launches, dstage;  // dstage: 0 idle, 1 LM launches, 2 tail enqueued
   bool dpoll, dwaiting, with_lists;
   int derr;
@@ -136,7 +138,7 @@ extern "C" int odo_tracker_batch_destroy(odo_tracker_batch* b) {
   if (b->ctx_b) (void)hipStreamSynchronize(b->ctx_b->stream);
   for (odo_lm* m : b->lm) odo_lm_destroy(m);
   for (odo_depth* d : b->depth) odo_depth_destroy(d);
-  for (auto* v : {&b->kf_img, &b->kf_dep, &b->cur_img, &b->pre_dep})
+  for (auto* v : {&b->kf_img, &b->kf_dep, &b->cur_img, &b->pre_dep, &b->next_img})
     for (odo_pyr* q : *v) odo_pyramid_destroy(q);
   for (uint8_t* q : b->d_val) if (q) (void)hipFree(q);
   for (float* q : b->d_disp) if (q) (void)hipFree(q);
@@ -163,15 +165,17 @@ extern "C" int odo_tracker_batch_create(int device, const odo_tracker_params* p,
   b->p = *p; b->S = S;
   b->ctx_a = b->ctx_b = nullptr; b->h_tab = nullptr; b->d_tab = nullptr; b->h_cand_npts = b->d_cand_npts = nullptr;
   b->ev_cur_img = b->ev_tab = nullptr;
-  b->frame_id = 0; b->dstage = 0; b->derr = 0;
+  b->dstage = 0; b->derr = 0;
   b->tm_frame_us = b->tm_head_us = b->tm_solve_us = b->tm_depth_wait_us = 0.0; b->tm_frames = 0;
   b->overlap = (p->overlap_depth != 0) && !getenv("ODO_BATCH_NO_OVERLAP");
   b->lm.assign(S, nullptr); b->depth.assign(S, nullptr);
   b->kf_img.assign(S, nullptr); b->kf_dep.assign(S, nullptr); b->cur_img.assign(S, nullptr); b->pre_dep.assign(S, nullptr);
+  b->next_img.assign(S, nullptr);
   b->d_val.assign(S, nullptr); b->d_disp.assign(S, nullptr); b->d_dep.assign(S, nullptr);
   b->kf_abs.assign((size_t)S * 16, 0.0f); b->pose_to_kf.assign((size_t)S * 16, 0.0f);
   b->n_keyframes.assign(S, 0); b->alive.assign(S, 0); b->last_evals.assign(S, 0); b->last_depth_iters.assign(S, 0);
-  b->last_valid.assign(S, 0);
+  b->last_valid.assign(S, 0); b->frame_id.assign(S, 0);
+  b->hint_next.assign(S, nullptr); b->prefetched.assign(S, nullptr);
   const float eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   const size_t n = (size_t)p->rows * p->cols;
   const bool lm_prio = !(getenv("ODO_LM_PRIORITY") && atoi(getenv("ODO_LM_PRIORITY")) == 0);
@@ -185,14 +189,15 @@ extern "C" int odo_tracker_batch_create(int device, const odo_tracker_params* p,
                                 p->max_residuals, p->max_disparity, p->any_size, &b->depth[i]) == 0;
     ok = ok && depth_check_size(b->depth[i], p->rows, p->cols) == 0 && depth_ensure(b->depth[i], p->rows, p->cols) == 0;
     ok = ok && pyr_alloc(b->ctx_a, p->rows, p->cols, p->levels, ODO_PYR_IMAGE, &b->cur_img[i], false) == 0;
+    ok = ok && pyr_alloc(b->ctx_a, p->rows, p->cols, p->levels, ODO_PYR_IMAGE, &b->next_img[i], false) == 0;
     ok = ok && pyr_alloc(b->ctx_a, p->rows, p->cols, p->levels, ODO_PYR_IMAGE, &b->kf_img[i], false) == 0;
     ok = ok && pyr_alloc(b->ctx_b, p->rows, p->cols, p->levels, ODO_PYR_DEPTH, &b->kf_dep[i], false) == 0;
     ok = ok && pyr_alloc(b->ctx_b, p->rows, p->cols, p->levels, ODO_PYR_DEPTH, &b->pre_dep[i], false) == 0;
     ok = ok && hipMalloc((void**)&b->d_val[i], n) == hipSuccess && hipMalloc((void**)&b->d_disp[i], sizeof(float) * n) == hipSuccess &&
          hipMalloc((void**)&b->d_dep[i], sizeof(float) * n) == hipSuccess;
   }
-  ok = ok && hipHostMalloc((void**)&b->h_tab, sizeof(BatchSeq) * (size_t)S, hipHostMallocDefault) == hipSuccess;
-  ok = ok && hipMalloc((void**)&b->d_tab, sizeof(BatchSeq) * (size_t)S) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&b->h_tab, sizeof(BatchSeq) * 2 * (size_t)S, hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipMalloc((void**)&b->d_tab, sizeof(BatchSeq) * 2 * (size_t)S) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&b->h_cand_npts, sizeof(int) * ODO_MAX_LEVELS * (size_t)S,
                            hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
   ok = ok && hipHostGetDevicePointer((void**)&b->d_cand_npts, b->h_cand_npts, 0) == hipSuccess;
@@ -208,12 +213,14 @@ extern "C" int odo_tracker_batch_create(int device, const odo_tracker_params* p,
   return 0;
 }
 
-// Fills and uploads the frame's table (stream A; stream B waits for the upload through ev_tab). `first`: frame 0, whose
-// pyramids go straight into the keyframe slots.
+// Fills and uploads the step's table: entry e <-> slot b->ids[e] (stream A; stream B waits for the upload through ev_tab).
+// first: frame 0 of the listed slots, whose pyramids go straight into the keyframe buffers.
 static int batch_upload_table(odo_tracker_batch* b, const float* const* left, const float* const* right, bool first) {
   const odo_tracker_params& p = b->p;
-  for (int i = 0; i < b->S; i++) {
-    BatchSeq& q = b->h_tab[i];
+  const int n = (int)b->ids.size();
+  for (int e = 0; e < n; e++) {
+    const int i = b->ids[e];
+    BatchSeq& q = b->h_tab[e];
     odo_depth* d = b->depth[i];
     odo_lm* m = b->lm[i];
     odo_pyr* img = first ? b->kf_img[i] : b->cur_img[i];
@@ -222,7 +229,6 @@ static int batch_upload_table(odo_tracker_batch* b, const float* const* left, co
     q.left = left[i]; q.right = right[i];
     q.cur_img = batch_pyr_out(img, p.smooth_image);
     q.pre_dep = batch_pyr_out(dep, 0);
-    img->version = ++g_pyr_version;
     dep->version = ++g_pyr_version;
     q.bl = d->d_bl; q.br = d->d_br; q.disp = b->d_disp[i]; q.dep = b->d_dep[i]; q.d0 = d->d_d0; q.scratch = d->d_scratch;
     q.val = b->d_val[i]; q.matched = d->d_matched; q.pts = d->d_pts; q.cnt = d->d_cnt;
@@ -230,19 +236,19 @@ static int batch_upload_table(odo_tracker_batch* b, const float* const* left, co
     q.stats = d->d_stats_map; q.dprog = d->d_prog;
     d->token++;
     q.dtoken = d->token;
-    d->h_prog[0] = 0; d->h_prog[1] = 0;  // both streams are idle here (every frame ends on the completion words)
+    d->h_prog[0] = 0; d->h_prog[1] = 0;  // both streams are idle here (every step ends on the completion words)
     int rows_total = 0;
     m->cand_tag = -1;
     if (b->with_lists) {
       if (lm_lists_layout(m, m->cand_pl, m->cand_pl_cap, m->cand_d_rowcnt, m->cand_rows_cap, img, dep, b->ctx_b->stream, &q.kl,
                           &rows_total)) return -1;
-      if (rows_total > 0) m->cand_tag = (long)b->frame_id;
+      if (rows_total > 0) m->cand_tag = b->frame_id[i];
     }
     q.rowcnt = m->cand_d_rowcnt; q.npts = m->cand_d_npts; q.npts_host = b->d_cand_npts + (size_t)i * ODO_MAX_LEVELS;
     for (int l = 0; l < ODO_MAX_LEVELS; l++) q.pl[l] = m->cand_pl[l];
   }
   hipStream_t sa = b->ctx_a->stream;
-  HIP_OK(hipMemcpyAsync(b->d_tab, b->h_tab, sizeof(BatchSeq) * (size_t)b->S, hipMemcpyHostToDevice, sa));
+  HIP_OK(hipMemcpyAsync(b->d_tab, b->h_tab, sizeof(BatchSeq) * (size_t)n, hipMemcpyHostToDevice, sa));
   HIP_OK(hipEventRecord(b->ev_tab, sa));
   return 0;
 }
@@ -256,44 +262,48 @@ static int batch_rows_total(const odo_tracker_batch* b) {
   return rows_total;
 }
 
-// Front of the depth chain: blur, point selection, disparity scan for all sequences (3 launches).
+static inline dim3 batch_pyr_grid(const odo_tracker_batch* b, int n) {
+  return dim3((b->p.cols + kPT - 1) / kPT, (b->p.rows + kPT - 1) / kPT, n);
+}
+
+// Front of the depth chain: blur, point selection, disparity scan for the step's slots (3 launches).
 static int batch_depth_begin(odo_tracker_batch* b, hipStream_t s) {
   const odo_tracker_params& p = b->p;
   const odo_depth* d = b->depth[0];
-  const int S = b->S;
+  const int n = (int)b->ids.size();
   b->dk = 0; b->dn_launches = 0; b->dstage = 1; b->derr = 0; b->dpoll = d->poll != 0; b->dwaiting = false;
-  hipLaunchKernelGGL(blur3x3_batch_kernel, grid2d(p.cols, p.rows, 2 * S), dim3(256), 0, s, (const BatchSeq*)b->d_tab, p.rows, p.cols);
-  hipLaunchKernelGGL(depth_select_batch_kernel, dim3(kSelBlocks, S), dim3(kSelThreads), 0, s, (const BatchSeq*)b->d_tab, p.rows,
+  hipLaunchKernelGGL(blur3x3_batch_kernel, grid2d(p.cols, p.rows, 2 * n), dim3(256), 0, s, (const BatchSeq*)b->d_tab, p.rows, p.cols);
+  hipLaunchKernelGGL(depth_select_batch_kernel, dim3(kSelBlocks, n), dim3(kSelThreads), 0, s, (const BatchSeq*)b->d_tab, p.rows,
                      p.cols, d->boundary, d->grad_th);
-  hipLaunchKernelGGL(depth_disparity_batch_kernel, dim3(kSelBlocks * kSelCap / 4, S), dim3(256), 0, s, (const BatchSeq*)b->d_tab,
+  hipLaunchKernelGGL(depth_disparity_batch_kernel, dim3(kSelBlocks * kSelCap / 4, n), dim3(256), 0, s, (const BatchSeq*)b->d_tab,
                      p.rows, p.cols, d->boundary, d->max_disparity, d->ssd_th, d->K.f0, d->baseline);
   HIP_OK(hipGetLastError());
   return 0;
 }
 
-// Tail of the frame on the depth stream: filters, depth pyramids, candidate lists, statistics + completion words.
+// Tail of the step on the depth stream: filters, depth pyramids, candidate lists, statistics + completion words.
 static int batch_depth_tail(odo_tracker_batch* b, hipStream_t s) {
   const odo_tracker_params& p = b->p;
   const odo_depth* d = b->depth[0];
-  const int S = b->S;
+  const int n = (int)b->ids.size();
   const BatchSeq* tab = b->d_tab;
-  hipLaunchKernelGGL(depth_finalize_batch_kernel, dim3(kDlmBlocks, S), dim3(kDlmBlock), 0, s, tab, 1, p.cols, d->photo_th,
+  hipLaunchKernelGGL(depth_finalize_batch_kernel, dim3(kDlmBlocks, n), dim3(kDlmBlock), 0, s, tab, 1, p.cols, d->photo_th,
                      d->min_depth, d->max_depth);
-  hipLaunchKernelGGL(depth_pyramid_batch_kernel, grid2d(p.cols, p.rows, S), dim3(256), 0, s, tab);  // :252
+  hipLaunchKernelGGL(depth_pyramid_batch_kernel, grid2d(p.cols, p.rows, n), dim3(256), 0, s, tab);  // :252
   const int rows_total = batch_rows_total(b);
   const int with_lists = (b->with_lists && rows_total > 0) ? 1 : 0;
   if (with_lists) {
     if (s != b->ctx_a->stream) HIP_OK(hipStreamWaitEvent(s, b->ev_cur_img, 0));
-    hipLaunchKernelGGL(kf_count_batch_kernel, dim3(rows_total, S), dim3(256), 0, s, tab);
-    hipLaunchKernelGGL(kf_fill_batch_kernel, dim3(rows_total, S), dim3(256), 0, s, tab, p.K.f0, p.K.cx0, p.K.cy0);
+    hipLaunchKernelGGL(kf_count_batch_kernel, dim3(rows_total, n), dim3(256), 0, s, tab);
+    hipLaunchKernelGGL(kf_fill_batch_kernel, dim3(rows_total, n), dim3(256), 0, s, tab, p.K.f0, p.K.cx0, p.K.cy0);
   }
-  hipLaunchKernelGGL(depth_stats_batch_kernel, dim3(1, S), dim3(kDlmBlock), 0, s, tab, 1, b->dn_launches, with_lists);
+  hipLaunchKernelGGL(depth_stats_batch_kernel, dim3(1, n), dim3(kDlmBlock), 0, s, tab, 1, b->dn_launches, with_lists);
   HIP_OK(hipGetLastError());
   b->dstage = 2;
   return 0;
 }
 
-// Issues at most one depth-LM launch (all sequences) per call; enqueues the tail once every sequence's LM has stopped.
+// Issues at most one depth-LM launch (all slots of the step) per call; enqueues the tail once every slot's LM has stopped.
 static void batch_depth_pump(void* arg) {
   odo_tracker_batch* b = (odo_tracker_batch*)arg;
   if (b->dstage != 1) return;
@@ -302,7 +312,7 @@ static void batch_depth_pump(void* arg) {
   bool all_stopped = true;
   int min_prog = 1 << 30;
   if (b->dpoll) {
-    for (int i = 0; i < b->S; i++) {
+    for (int i : b->ids) {
       volatile int* prog = b->depth[i]->h_prog;
       if (!prog[1]) { all_stopped = false; if (prog[0] < min_prog) min_prog = prog[0]; }
     }
@@ -319,8 +329,9 @@ static void batch_depth_pump(void* arg) {
       return;
     }
     b->dwaiting = false;
-    hipLaunchKernelGGL(depth_lm_step_batch_kernel, dim3(kDlmBlocks, b->S), dim3(kDlmBlock), 0, s, (const BatchSeq*)b->d_tab, b->dk,
-                       b->p.cols, d0->baseline, d0->K.f0, d0->huber_delta, d0->lambda, d0->precision, d0->max_iters);
+    hipLaunchKernelGGL(depth_lm_step_batch_kernel, dim3(kDlmBlocks, (int)b->ids.size()), dim3(kDlmBlock), 0, s,
+                       (const BatchSeq*)b->d_tab, b->dk, b->p.cols, d0->baseline, d0->K.f0, d0->huber_delta, d0->lambda,
+                       d0->precision, d0->max_iters);
     b->dk++;
     b->dn_launches++;
     return;
@@ -328,11 +339,11 @@ static void batch_depth_pump(void* arg) {
   if (batch_depth_tail(b, s)) b->derr = 1;
 }
 
-// Waits for every sequence's completion word (bounded), takes the statistics. ok[i] = 0 when ComputeDepth failed for i.
+// Waits for every slot's completion word (bounded), takes the statistics. ok[e] = 0 when ComputeDepth failed for ids[e].
 static int batch_depth_finish(odo_tracker_batch* b, int* ok) {
   hipStream_t s = b->overlap ? b->ctx_b->stream : b->ctx_a->stream;
   const auto t0 = std::chrono::steady_clock::now();
-  for (int i = 0; i < b->S; i++) {
+  for (int i : b->ids) {
     odo_depth* d = b->depth[i];
     volatile int* done = d->h_prog + 4;
     while (done[0] != d->token) {
@@ -340,128 +351,210 @@ static int batch_depth_finish(odo_tracker_batch* b, int* ok) {
     }
   }
   std::atomic_thread_fence(std::memory_order_acquire);
-  for (int i = 0; i < b->S; i++) {
+  for (size_t e = 0; e < b->ids.size(); e++) {
+    const int i = b->ids[e];
     odo_depth* d = b->depth[i];
     d->last = *d->h_stats;
-    ok[i] = d->last.status == 0;
+    ok[e] = d->last.status == 0;
     b->last_valid[i] = d->last.n_valid;
     b->last_depth_iters[i] = d->last.iters;
   }
   return 0;
 }
 
-// The candidate lists built for sequence i this frame become its keyframe lists.
+// The candidate lists built for slot i this step become its keyframe lists.
 static void batch_adopt(odo_tracker_batch* b, int i) {
   odo_lm* m = b->lm[i];
   memcpy(m->cand_h_npts, b->h_cand_npts + (size_t)i * ODO_MAX_LEVELS, sizeof(int) * ODO_MAX_LEVELS);
-  (void)lm_adopt_candidate(m, b->kf_img[i], b->kf_dep[i], (long)b->frame_id);  // 1 = no candidate: the Solve builds the lists
+  (void)lm_adopt_candidate(m, b->kf_img[i], b->kf_dep[i], b->frame_id[i]);  // 1 = no candidate: the Solve builds the lists
 }
 
-extern "C" int odo_tracker_batch_init(odo_tracker_batch* b, const float* const* left_dev, const float* const* right_dev,
-                                      const float* abs_pose0 /* S x 16 column-major, or NULL for identity */) {
-  if (!b || !left_dev || !right_dev) return fail("odo_tracker_batch_init: NULL arg");
-  for (int i = 0; i < b->S; i++) if (!left_dev[i] || !right_dev[i]) return fail("odo_tracker_batch_init: NULL image %d", i);
+// Frame 0 of the slots in b->ids (ref: :95-145).
+static int batch_init_set(odo_tracker_batch* b, const float* const* left_dev, const float* const* right_dev,
+                          const float* abs_pose0) {
   HIP_OK(hipSetDevice(b->ctx_a->device));
+  // stragglers of the previous step (LM launches queued ahead) may still run on stream A; the keyframe buffers are rewritten now
   HIP_OK(hipStreamSynchronize(b->ctx_a->stream));
   HIP_OK(hipStreamSynchronize(b->ctx_b->stream));
   const odo_tracker_params& p = b->p;
-  b->frame_id = 0;
+  const int n = (int)b->ids.size();
+  if (n == 0) return 0;
   b->with_lists = !getenv("ODO_NO_CAND_LISTS");
+  for (int i : b->ids) {
+    b->frame_id[i] = 0; b->alive[i] = 0; b->hint_next[i] = b->prefetched[i] = nullptr;
+    b->kf_img[i]->version = ++g_pyr_version;
+  }
   if (batch_upload_table(b, left_dev, right_dev, true)) return -1;
   hipStream_t sa = b->ctx_a->stream;
   hipStream_t sb = b->overlap ? b->ctx_b->stream : sa;
-  hipLaunchKernelGGL(image_pyramid_batch_kernel, dim3((p.cols + kPT - 1) / kPT, (p.rows + kPT - 1) / kPT, b->S), dim3(kPyrThreads),
-                     0, sa, (const BatchSeq*)b->d_tab);                                    // :130
+  hipLaunchKernelGGL(image_pyramid_batch_kernel, batch_pyr_grid(b, n), dim3(kPyrThreads), 0, sa, (const BatchSeq*)b->d_tab);  // :130
   HIP_OK(hipEventRecord(b->ev_cur_img, sa));
   if (sb != sa) HIP_OK(hipStreamWaitEvent(sb, b->ev_tab, 0));
   if (batch_depth_begin(b, sb)) return -1;                                                // :102
   while (b->dstage == 1) batch_depth_pump(b);
-  if (b->derr) return -1;
-  std::vector<int> ok(b->S, 0);
+  if (b->derr) { b->dstage = 0; return -1; }
+  std::vector<int> ok(n, 0);
   if (batch_depth_finish(b, ok.data())) return -1;
   HIP_OK(hipStreamSynchronize(sa));
   b->dstage = 0;
   const float eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   int bad = -1;
-  for (int i = 0; i < b->S; i++) {
+  for (int e = 0; e < n; e++) {
+    const int i = b->ids[e];
     const float* a0 = abs_pose0 ? abs_pose0 + 16 * (size_t)i : eye;
     memcpy(&b->kf_abs[16 * (size_t)i], a0, sizeof(float) * 16);        // :143
     memcpy(&b->pose_to_kf[16 * (size_t)i], a0, sizeof(float) * 16);    // :98
     odo_lm_reset(b->lm[i], eye, p.lm_lambda);                          // :77-81
     b->lm[i]->kf_img_ver = b->lm[i]->kf_dep_ver = 0;
     b->n_keyframes[i] = 1;
-    b->alive[i] = ok[i];
-    if (!ok[i] && bad < 0) bad = i;
-    if (ok[i] && b->with_lists) batch_adopt(b, i);
+    b->alive[i] = ok[e];
+    if (!ok[e] && bad < 0) bad = i;
+    if (ok[e] && b->with_lists) batch_adopt(b, i);
   }
   if (bad >= 0) return fail("Init 0-th frame failed! (sequence %d: number of valid after optimization is too small: %d)", bad,
                             b->last_valid[bad]);                       // :103-106
   return 0;
 }
 
-// One iteration of the frame loop for every sequence. status[i]: 0 tracked; 1 the Solve failed (the runner carries on with
-// the pseudo-identity, ref: src/lm_optimizer.cpp:60-61); -1 ComputeDepth failed on this frame (pose still written, the
-// sequence stops: ref :230-232 breaks out of the loop); -2 the sequence had stopped earlier (outputs untouched).
+extern "C" int odo_tracker_batch_init(odo_tracker_batch* b, const float* const* left_dev, const float* const* right_dev,
+                                      const float* abs_pose0 /* S x 16 column-major, or NULL for identity */) {
+  if (!b || !left_dev || !right_dev) return fail("odo_tracker_batch_init: NULL arg");
+  b->ids.clear();
+  for (int i = 0; i < b->S; i++) {
+    if ((left_dev[i] == nullptr) != (right_dev[i] == nullptr)) return fail("odo_tracker_batch_init: slot %d has one image only", i);
+    if (left_dev[i]) b->ids.push_back(i);
+    else b->alive[i] = 0;   // an empty slot
+  }
+  return batch_init_set(b, left_dev, right_dev, abs_pose0);
+}
+
+extern "C" int odo_tracker_batch_init_one(odo_tracker_batch* b, int slot, const float* left_dev, const float* right_dev,
+                                          const float abs_pose0[16]) {
+  if (!b || !left_dev || !right_dev || slot < 0 || slot >= b->S) return fail("odo_tracker_batch_init_one: bad arg");
+  std::vector<const float*> l(b->S, nullptr), r(b->S, nullptr);
+  std::vector<float> a0;
+  l[slot] = left_dev; r[slot] = right_dev;
+  if (abs_pose0) { a0.assign((size_t)b->S * 16, 0.0f); memcpy(&a0[16 * (size_t)slot], abs_pose0, sizeof(float) * 16); }
+  b->ids.assign(1, slot);
+  return batch_init_set(b, l.data(), r.data(), abs_pose0 ? a0.data() : nullptr);
+}
+
+// Optional: the left images of the NEXT step (NULL entries allowed). Their pyramids are built at the end of the current step
+// on the pose-LM stream, which is idle while the depth stream finishes, instead of at the head of the next step.
+extern "C" int odo_tracker_batch_hint_next(odo_tracker_batch* b, const float* const* next_left_dev) {
+  if (!b) return fail("NULL batch tracker");
+  for (int i = 0; i < b->S; i++) b->hint_next[i] = next_left_dev ? next_left_dev[i] : nullptr;
+  return 0;
+}
+
+// One iteration of the frame loop for every slot that is given a frame. status[i]: 0 tracked; 1 the Solve failed (the runner
+// carries on with the pseudo-identity, ref: src/lm_optimizer.cpp:60-61); -1 ComputeDepth failed on this frame (pose still
+// written, the sequence stops: ref :230-232 breaks out of the loop); -2 the slot holds no running sequence (never initialised,
+// or stopped earlier: outputs untouched); -3 no frame given for the slot this step (left_dev[i] == NULL: it sits the step out).
 extern "C" int odo_tracker_batch_track(odo_tracker_batch* b, const float* const* left_dev, const float* const* right_dev,
                                        float* pose_to_keyframe /* S x 16 */, float* abs_pose /* S x 16 */,
                                        int* is_new_keyframe /* S */, float* motion_mag /* S */, int* status /* S */) {
   if (!b || !left_dev || !right_dev || !status) return fail("odo_tracker_batch_track: NULL arg");
   const int S = b->S;
-  for (int i = 0; i < S; i++) if (!left_dev[i] || !right_dev[i]) return fail("odo_tracker_batch_track: NULL image %d", i);
   const odo_tracker_params& p = b->p;
   const auto f0 = std::chrono::steady_clock::now();
   HIP_OK(hipSetDevice(b->ctx_a->device));
-  b->frame_id++;
+  b->ids.clear();
+  for (int i = 0; i < S; i++) {
+    if (is_new_keyframe) is_new_keyframe[i] = 0;
+    if (motion_mag) motion_mag[i] = 0.0f;
+    if ((left_dev[i] == nullptr) != (right_dev[i] == nullptr)) return fail("odo_tracker_batch_track: slot %d has one image only", i);
+    if (!left_dev[i]) { status[i] = -3; continue; }
+    if (!b->alive[i]) { status[i] = -2; continue; }
+    b->ids.push_back(i);
+  }
+  const int n = (int)b->ids.size();
+  if (n == 0) return 0;
   b->with_lists = !getenv("ODO_NO_CAND_LISTS");
+  // slots whose pyramid was prefetched at the end of the last step take it; the others get theirs built now
+  std::vector<int> build;
+  for (int i : b->ids) {
+    b->frame_id[i]++;
+    if (b->prefetched[i] && b->prefetched[i] == left_dev[i]) std::swap(b->cur_img[i], b->next_img[i]);
+    else { build.push_back(i); b->cur_img[i]->version = ++g_pyr_version; }
+    b->prefetched[i] = nullptr;
+  }
   if (batch_upload_table(b, left_dev, right_dev, false)) return -1;
   hipStream_t sa = b->ctx_a->stream;
   hipStream_t sb = b->overlap ? b->ctx_b->stream : sa;
-  hipLaunchKernelGGL(image_pyramid_batch_kernel, dim3((p.cols + kPT - 1) / kPT, (p.rows + kPT - 1) / kPT, S), dim3(kPyrThreads), 0,
-                     sa, (const BatchSeq*)b->d_tab);                                       // :205
+  if ((int)build.size() == n) {
+    hipLaunchKernelGGL(image_pyramid_batch_kernel, batch_pyr_grid(b, n), dim3(kPyrThreads), 0, sa, (const BatchSeq*)b->d_tab);  // :205
+  } else if (!build.empty()) {
+    // a mix (some slots were hinted, some not): the stragglers one launch each, through the step's own table entries
+    for (size_t e = 0; e < b->ids.size(); e++)
+      for (int i : build)
+        if (b->ids[e] == i)
+          hipLaunchKernelGGL(image_pyramid_batch_kernel, batch_pyr_grid(b, 1), dim3(kPyrThreads), 0, sa, (const BatchSeq*)b->d_tab + e);
+  }
   HIP_OK(hipEventRecord(b->ev_cur_img, sa));
   if (b->overlap) {
     HIP_OK(hipStreamWaitEvent(sb, b->ev_tab, 0));
     if (batch_depth_begin(b, sb)) return -1;                                              // :226 beside the Solve
   }
-  std::vector<float> T((size_t)S * 16);
-  std::vector<int> st(S, 0);
+  std::vector<float> T((size_t)n * 16);
+  std::vector<int> st(n, 0);
+  std::vector<odo_lm*> lms(n);
+  std::vector<const odo_pyr*> kfi(n), kfd(n), cur(n);
+  for (int e = 0; e < n; e++) { const int i = b->ids[e]; lms[e] = b->lm[i]; kfi[e] = b->kf_img[i]; kfd[e] = b->kf_dep[i]; cur[e] = b->cur_img[i]; }
   const auto f1 = std::chrono::steady_clock::now();
-  if (lm_solve_batch(S, b->lm.data(), b->kf_img.data(), b->kf_dep.data(), b->cur_img.data(), T.data(), st.data(),
+  if (lm_solve_batch(n, lms.data(), kfi.data(), kfd.data(), cur.data(), T.data(), st.data(),
                      b->overlap ? batch_depth_pump : nullptr, b) < 0) {                    // :215
-    if (b->dstage == 1) { while (b->dstage == 1) batch_depth_pump(b); }
-    std::vector<int> okd(S, 0);
+    while (b->dstage == 1) batch_depth_pump(b);
+    std::vector<int> okd(n, 0);
     if (b->dstage == 2) (void)batch_depth_finish(b, okd.data());
     b->dstage = 0;
     return -1;
   }
   const auto f2 = std::chrono::steady_clock::now();
+  // the next step's pyramids, on stream A behind the Solve (it is idle until the next step; the depth stream is still busy)
+  {
+    int m = 0;
+    for (int i = 0; i < S; i++) {
+      if (!b->hint_next[i]) continue;
+      BatchSeq& q = b->h_tab[S + m];
+      memset(&q, 0, sizeof(q));
+      q.left = b->hint_next[i];
+      q.cur_img = batch_pyr_out(b->next_img[i], p.smooth_image);
+      b->next_img[i]->version = ++g_pyr_version;
+      b->prefetched[i] = b->hint_next[i];
+      b->hint_next[i] = nullptr;
+      m++;
+    }
+    if (m > 0) {
+      HIP_OK(hipMemcpyAsync(b->d_tab + S, b->h_tab + S, sizeof(BatchSeq) * (size_t)m, hipMemcpyHostToDevice, sa));
+      hipLaunchKernelGGL(image_pyramid_batch_kernel, batch_pyr_grid(b, m), dim3(kPyrThreads), 0, sa, (const BatchSeq*)(b->d_tab + S));
+    }
+  }
   if (!b->overlap && batch_depth_begin(b, sb)) return -1;
   while (b->dstage == 1) batch_depth_pump(b);
-  std::vector<int> okd(S, 0);
   // :218 — poses are stored before the depth result is known
-  std::vector<float> cur((size_t)S * 16);
-  for (int i = 0; i < S; i++) {
-    if (!b->alive[i]) continue;
-    const float* Ti = &T[16 * (size_t)i];
+  std::vector<float> curp((size_t)n * 16);
+  for (int e = 0; e < n; e++) {
+    const int i = b->ids[e];
+    const float* Ti = &T[16 * (size_t)e];
     float inv[16];
     if (!invert4(Ti, inv)) for (int k = 0; k < 16; k++) inv[k] = __builtin_nanf("");
-    matmul4(&b->kf_abs[16 * (size_t)i], inv, &cur[16 * (size_t)i]);
+    matmul4(&b->kf_abs[16 * (size_t)i], inv, &curp[16 * (size_t)e]);
     memcpy(&b->pose_to_kf[16 * (size_t)i], Ti, sizeof(float) * 16);
     if (pose_to_keyframe) memcpy(pose_to_keyframe + 16 * (size_t)i, Ti, sizeof(float) * 16);
-    if (abs_pose) memcpy(abs_pose + 16 * (size_t)i, &cur[16 * (size_t)i], sizeof(float) * 16);
+    if (abs_pose) memcpy(abs_pose + 16 * (size_t)i, &curp[16 * (size_t)e], sizeof(float) * 16);
   }
   if (b->derr) { b->dstage = 0; return -1; }
+  std::vector<int> okd(n, 0);
   if (batch_depth_finish(b, okd.data())) return -1;
   const auto f3 = std::chrono::steady_clock::now();
   b->dstage = 0;
   int any_depth_fail = 0;
-  for (int i = 0; i < S; i++) {
-    if (is_new_keyframe) is_new_keyframe[i] = 0;
-    if (motion_mag) motion_mag[i] = 0.0f;
-    if (!b->alive[i]) { status[i] = -2; continue; }
+  for (int e = 0; e < n; e++) {
+    const int i = b->ids[e];
     b->last_evals[i] = b->lm[i]->last_evals;
-    if (!okd[i]) { status[i] = -1; b->alive[i] = 0; any_depth_fail = 1; continue; }        // :230-232
-    const float* Ti = &T[16 * (size_t)i];
+    if (!okd[e]) { status[i] = -1; b->alive[i] = 0; any_depth_fail = 1; continue; }        // :230-232
+    const float* Ti = &T[16 * (size_t)e];
     float ang[3];
     motion_angles(Ti, ang);                                                                // :253
     const float mot[6] = {fabsf(ang[0]), fabsf(ang[1]), fabsf(ang[2]), fabsf(Ti[12]), fabsf(Ti[13]), fabsf(Ti[14])};
@@ -470,14 +563,14 @@ extern "C" int odo_tracker_batch_track(odo_tracker_batch* b, const float* const*
     if (mag > p.keyframe_motion_th) {                                                      // :258
       std::swap(b->kf_img[i], b->cur_img[i]);                                              // :259 (the :251 rebuild has the same content)
       std::swap(b->kf_dep[i], b->pre_dep[i]);
-      memcpy(&b->kf_abs[16 * (size_t)i], &cur[16 * (size_t)i], sizeof(float) * 16);        // :260
+      memcpy(&b->kf_abs[16 * (size_t)i], &curp[16 * (size_t)e], sizeof(float) * 16);       // :260
       b->n_keyframes[i]++;
       if (is_new_keyframe) is_new_keyframe[i] = 1;
       if (b->with_lists) batch_adopt(b, i);
     }
     odo_lm_reset(b->lm[i], Ti, 0.01f);                                                     // :261 / :268
     if (motion_mag) motion_mag[i] = mag;
-    status[i] = st[i] ? 1 : 0;
+    status[i] = st[e] ? 1 : 0;
   }
   if (any_depth_fail) fail("    depth failed!");
   b->tm_frame_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - f0).count();

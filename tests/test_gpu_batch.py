@@ -166,3 +166,52 @@ def test_batched_tracker_restart_and_stopped_sequence(api, drives):
     with pytest.raises(api.L.OdoError):
         tb.init([L[0][0], flat], [R[0][0], flat])      # "Init 0-th frame failed!"
     tb.close()
+
+
+def test_batched_tracker_slots_of_different_lengths_and_hints(api, drives):
+    """Slots are independent: one sits steps out (no frame given), one is restarted on a new sequence while the others run
+    on (init_one), next-frame hints move the pyramid builds earlier — none of it changes any sequence's results."""
+    n_frames = 8
+    refs = [_track_single(api, s, n_frames)[0] for s in drives]
+    tb = api.TrackerBatch(3)
+    L = [[tb.upload_frame(f) for f in s["left"][:n_frames]] for s in drives]
+    R = [[tb.upload_frame(f) for f in s["right"][:n_frames]] for s in drives]
+    # slot 0: drive 0 frames 0..7 at steps 1..7; slot 1: empty at first, drive 1 started at step 3 (init_one);
+    # slot 2: drive 2, pauses at steps 2 and 5
+    tb.init([L[0][0], None, L[2][0]], [R[0][0], None, R[2][0]])
+    nxt = {0: 1, 1: None, 2: 1}                     # next frame index per slot (None: no running sequence)
+    got = {0: [], 1: [], 2: []}
+    for step in range(1, 12):
+        if step == 3:
+            tb.init_one(1, L[1][0], R[1][0])
+            nxt[1] = 1
+        frames = {}
+        for i in range(3):
+            k = nxt[i]
+            pause = (i == 2 and step in (2, 5))
+            frames[i] = k if (k is not None and k < n_frames and not pause) else None
+        lefts = [L[i][frames[i]] if frames[i] is not None else None for i in range(3)]
+        rights = [R[i][frames[i]] if frames[i] is not None else None for i in range(3)]
+        if step % 2 == 0:       # hints on every other step only; slot 2's hint is wrong on purpose at step 4 (ignored: pointer differs)
+            hint = []
+            for i in range(3):
+                k = frames[i]
+                hint.append(L[i][k + 1] if (k is not None and k + 1 < n_frames) else None)
+            if step == 4:
+                hint[2] = L[2][0]
+            tb.hint_next(hint)
+        res = tb.track(lefts, rights)
+        for i in range(3):
+            if frames[i] is None:
+                assert res[i]["status"] in (-3, -2)
+                continue
+            assert res[i]["status"] == 0
+            got[i].append(res[i])
+            nxt[i] = frames[i] + 1
+    for i in range(3):
+        assert len(got[i]) == n_frames - 1
+        for k, (a, r) in enumerate(zip(got[i], refs[i])):
+            assert np.array_equal(a["pose_to_keyframe"], r["pose_to_keyframe"]), (i, k)
+            assert np.array_equal(a["abs_pose"], r["abs_pose"]), (i, k)
+            assert a["new_keyframe"] == r["new_keyframe"]
+    tb.close()

@@ -36,7 +36,7 @@ def main():
     print(f"single tracker: {passes * (n_frames - 1) / dt:.1f} frames/s", flush=True)
     trk.close()
     for S in s_list:
-        for overlap in (2, 0):
+        for overlap, hint in ((2, True), (2, False), (0, False)):
             tb = api.TrackerBatch(S, overlap_depth=overlap)
             Ls = [[tb.upload_frame(f) for f in seqs[i]["left"]] for i in range(S)]
             Rs = [[tb.upload_frame(f) for f in seqs[i]["right"]] for i in range(S)]
@@ -49,13 +49,15 @@ def main():
                 from odometry_amd import _lib
                 _lib.check(tb.lib.odo_tracker_batch_init(tb.h, lp[0], rp[0], None), "init")
                 for k in range(1, n_frames):
+                    if hint and k + 1 < n_frames:
+                        tb.hint_next(lp[k + 1])
                     tb.track_raw(lp[k], rp[k])
                     if rep == 0:
                         evals.append([s["lm_evals"] for s in tb.stats()])
             dt = time.perf_counter() - t0
             tm = tb.timing()
             ev = np.array(evals)
-            print(f"batch S={S} overlap={overlap}: {S * passes * (n_frames - 1) / dt:.1f} frames/s  ({dt / (passes * (n_frames - 1)) * 1e6:.0f} us per "
+            print(f"batch S={S} overlap={overlap} hint={int(hint)}: {S * passes * (n_frames - 1) / dt:.1f} frames/s  ({dt / (passes * (n_frames - 1)) * 1e6:.0f} us per "
                   f"lock step; LM evaluations/frame mean {ev.mean():.1f}, max-over-sequences mean {ev.max(axis=1).mean():.1f}; host us: head {tm['head_us']:.0f} solve {tm['solve_us']:.0f} depth wait {tm['depth_wait_us']:.0f})", flush=True)
             tb.close()
 

@@ -586,8 +586,11 @@ def main():
         i = order[k]
         if begins_pass(order, k):
             trk.init(*dv[0])   # a new pass over the sequence starts like the runner does: frame 0 becomes the keyframe
-        if not args.no_prefetch and k + 1 < n_total:
-            trk.hint_next(dv[order[k + 1]][0])   # frames are resident: the next frame's pyramid overlaps this frame's tail
+        # Frames are resident: the next frame is announced, so its pyramid and the head of its Solve overlap this frame's tail
+        # (odo_tracker_hint_next). Not across the start of the clock: the last warm-up step announces nothing, so no work of
+        # the first timed step runs before t0.
+        if not args.no_prefetch and k + 1 < n_total and k + 1 != args.warmup:
+            trk.hint_next(dv[order[k + 1]][0])
         trk.track_into(dv[i][0], dv[i][1], poses_kf[j, k], poses_abs[j, k])
         if publish and gatherer is not None:    # RCCL all_gather over xGMI every gather_every frames
             gatherer.push(poses_abs[j, k].reshape(4, 4).T, seq_id=my_seq_ids[j] if my_seq_ids else 0, frame_id=i)
@@ -624,7 +627,7 @@ def main():
             i = order[k]
             if begins_pass(order, k):
                 tb.init([bdev[j][0][0] for j in range(m)], [bdev[j][0][1] for j in range(m)])
-            if not args.no_prefetch and k + 1 < n_total:
+            if not args.no_prefetch and k + 1 < n_total and k + 1 != args.warmup:
                 tb.hint_next(blp[order[k + 1]])
             tb.track_raw(blp[i], brp[i])
             poses_kf[:, k, :] = tb._T.reshape(m, 16)

@@ -105,6 +105,12 @@ int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const int* max_it
  * pseudo-identity whose (3,3) element is 0 (ref: src/lm_optimizer.cpp:48-52,60-65). */
 int odo_lm_solve(odo_lm* lm, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img,
                  float out_colmajor[16]);
+/* Optional: starts the Solve that the next odo_lm_solve(lm, kf_img, kf_dep, cur_img) with the SAME pyramids will collect, and
+ * returns without waiting (a caller that knows the inputs early — the next frame's pyramid, the initial pose set by Reset —
+ * overlaps the head of the Solve with its own bookkeeping). Same launches, earlier: results are unchanged. Reset, or a Solve on
+ * other pyramids, abandons it. Returns 0 started, 1 nothing started (this Solve does not use the fused pipeline), -1 error.
+ * While a started Solve is in flight the optimiser's trace / report of the previous Solve are being overwritten. */
+int odo_lm_solve_begin(odo_lm* lm, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img);
 /* n independent Solves (n sequences, each with its own optimiser and pyramids) in the SAME launches: a single Solve is a
  * serial chain of short launches that leaves most of the chip idle, n chains side by side take the time of the longest.
  * Per-sequence arithmetic and launch order are those of odo_lm_solve: results are bit-identical to n separate calls. The
@@ -240,8 +246,11 @@ int odo_tracker_init(odo_tracker* t, const float* left_dev, const float* right_d
 int odo_tracker_track(odo_tracker* t, const float* left_dev, const float* right_dev, float pose_to_keyframe[16],
                       float abs_pose[16], int* is_new_keyframe, float* motion_mag, int* solve_status);
 /* Optional pipelining for callers that already hold the next frame (offline runs): announce its left image before
- * tracking the current frame; its image pyramid (ref: :205 of the NEXT iteration) is then built at the end of this call
- * on the otherwise idle LM stream. Same work, earlier; results are unchanged. The hinted buffer is identified by its device
+ * tracking the current frame; its image pyramid (ref: :205 of the NEXT iteration) is then built during this call on a stream
+ * of its own, and the next frame's Solve is started (odo_lm_solve_begin: initial pose = this frame's result, ref: :261 / :268)
+ * as soon as this frame's Solve has returned, while the depth stream finishes this frame. Same work, earlier; results are
+ * unchanged (the LM's per-evaluation trace of the frame just tracked may already be overwritten when the call returns;
+ * ODO_NO_EARLY_SOLVE=1 keeps the pyramid prefetch only). The hinted buffer is identified by its device
  * address: its contents must not change between the hint and the odo_tracker_track call that consumes it (a caller that
  * recycles one buffer for every frame must not hint). odo_tracker_init drops a pending hint / prefetched pyramid. */
 int odo_tracker_hint_next(odo_tracker* t, const float* next_left_dev);

@@ -181,6 +181,13 @@ class LevenbergMarquardtOptimizer:
             print("Optimize failed! ")  # ref: src/lm_optimizer.cpp:61
         return _from_colmajor(out)
 
+    def SolveBegin(self, kImagePyr1, kDepthPyr1, kImagePyr2):
+        """odo_lm_solve_begin: start the Solve a following Solve() with the same pyramids collects. Returns 0 / 1 (not started)."""
+        st = self.ctx.lib.odo_lm_solve_begin(self.h, kImagePyr1.h, kDepthPyr1.h, kImagePyr2.h)
+        if st < 0:
+            raise L.OdoError("odo_lm_solve_begin: " + L.last_error())
+        return st
+
     def Reset(self, kRelativeInit, lam):
         init = _colmajor(kRelativeInit)
         st = self.ctx.lib.odo_lm_reset(self.h, _fp(init), lam)

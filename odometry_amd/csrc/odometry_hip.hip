@@ -407,6 +407,17 @@ static inline LevelK lm_level_k(const struct odo_lm* m, int level);
 static const odo_intrinsics kKitti00 = {718.856f, (float)607.1928, (float)185.2157};
 constexpr int kLmMaxBlocks = 1280;       // partial rows per buffer: dense scan = 5 blocks per CU
 
+// A fused Solve in flight (see lm_fused_begin / odo_lm_solve_begin).
+struct LmJob {
+  int active;
+  const odo_pyr *kf_img, *kf_dep, *cur_img;
+  unsigned long long kf_img_ver, kf_dep_ver, cur_ver;
+  StepArgs a;
+  int seq, launches, it, budget, grid, token, min_level;
+  bool poll, result_by_launch, issued_all;
+  double bytes_per_level[ODO_MAX_LEVELS];
+};
+
 struct odo_lm {
   odo_ctx* ctx;
   float lambda, precision, huber_delta;
@@ -467,6 +478,7 @@ struct odo_lm {
   double last_bytes;
   int iters[ODO_MAX_LEVELS];
   int launches_level[ODO_MAX_LEVELS];
+  LmJob job;
 };
 
 static inline LevelK lm_level_k(const odo_lm* m, int level) {
@@ -549,6 +561,7 @@ extern "C" int odo_lm_destroy(odo_lm* m) {
 
 extern "C" int odo_lm_reset(odo_lm* m, const float init_colmajor[16], float lambda) {
   if (!m || !init_colmajor) { fail("Reset optimizer failed!"); return -1; }
+  m->job.active = 0;                                // a Solve started early with the old initial pose is abandoned
   memcpy(m->init, init_colmajor, sizeof(m->init));  // SetInitialAffine, ref: src/lm_optimizer.cpp:385-389
   m->lambda = lambda;                               // SetLambda, ref: :391-395
   for (int i = 0; i < ODO_MAX_LEVELS; i++) m->iters[i] = 0;  // ResetStatistics, ref: :397-405
@@ -771,61 +784,62 @@ static inline double lm_level_bytes(const odo_lm* m, int level, int rows, int co
   return in + 8.0 * ODO_NACC * nblk;
 }
 
-extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img,
-                            float out_colmajor[16]) {
-  if (!out_colmajor) return fail("odo_lm_solve: NULL out");
-  // failure value first: pseudo-identity whose (3,3) is 0 (ref: src/lm_optimizer.cpp:48-52,60-65)
-  for (int i = 0; i < 16; i++) out_colmajor[i] = 0.0f;
-  out_colmajor[0] = out_colmajor[5] = out_colmajor[10] = 1.0f;
-  if (lm_check_pyrs(m, kf_img, kf_dep, cur_img)) return -1;
-  hipStream_t s = m->ctx->stream;
-  HIP_OK(hipSetDevice(m->ctx->device));
-  if (lm_prepare_keyframe(m, kf_img, kf_dep)) return -1;
-  int launches = 0;
-  double bytes_per_level[ODO_MAX_LEVELS] = {0};
-  // Early exit without a host sync: the device publishes its progress in host-mapped memory; the host stays at
-  // most `run_ahead` launches ahead of the device and stops issuing launches once the device reports that the Solve
-  // (fused pipeline) or the level (unfused pipeline) has ended. Stale launches are no-ops on the device either way.
-  volatile int* prog = m->h_prog;
-  bool poll = m->poll != 0;
-  bool fused = m->fused && m->robust != 2;
+// ---------------------------------------------------------------------------------------------------------------
+// A fused Solve as a resumable job: lm_fused_begin fills the launch arguments and enqueues the coarse launch,
+// lm_fused_pump issues the identical step launches (it never runs more than run_ahead launches ahead of the device) and
+// odo_lm_solve collects the result. odo_lm_solve_begin lets a caller that already knows the next Solve's inputs (the
+// tracker: next frame's pyramid, initial pose = this frame's result) start it before it is asked for: same launches,
+// earlier. A job is tied to its pyramids' build versions and to the optimiser's initial pose: Reset or a Solve on other
+// pyramids abandons it (its launches drain on the stream like the stragglers of any finished Solve: the next Solve starts
+// with first_of_solve = 1 and a new token).
+// ---------------------------------------------------------------------------------------------------------------
+static inline int lm_job_progress(const odo_lm* m) {
+  const int v = ((volatile int*)m->h_prog)[0];
+  return ((v >> kProgSeqBits) == m->job.token) ? (v & ((1 << kProgSeqBits) - 1)) : 0;
+}
+static inline bool lm_job_finished(const odo_lm* m) { return ((volatile int*)m->h_prog)[1] == m->job.token; }
+
+static bool lm_fused_eligible(const odo_lm* m) {
+  if (!(m->fused && m->robust != 2)) return false;
   for (int l = 0; l < m->n_levels; l++)
-    if (!m->use_list[l]) fused = false;  // dense levels are throughput bound: big grids + a separate update kernel
-  int seq = 0;
-  LmState* st[2] = {m->d_state, m->d_state + 1};
-  double* part[2] = {m->d_partials, m->d_partials + (size_t)kLmMaxBlocks * ODO_NACC};
+    if (!m->use_list[l]) return false;  // dense levels are throughput bound: big grids + a separate update kernel
+  return true;
+}
+
+// Keyframe lists must be current (lm_prepare_keyframe) and the Solve fused-eligible.
+static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img) {
+  hipStream_t s = m->ctx->stream;
+  LmJob& jb = m->job;
+  jb.kf_img = kf_img; jb.kf_dep = kf_dep; jb.cur_img = cur_img;
+  jb.kf_img_ver = kf_img->version; jb.kf_dep_ver = kf_dep->version; jb.cur_ver = cur_img->version;
+  jb.seq = 0; jb.launches = 0; jb.it = 0; jb.issued_all = false; jb.result_by_launch = false;
+  jb.poll = m->poll != 0;
+  for (int l = 0; l < ODO_MAX_LEVELS; l++) jb.bytes_per_level[l] = 0.0;
   // Every Solve has a token. The fused launches tag their progress words with it — launches of the previous Solve may
   // still be draining on the stream when this one starts (they are no-ops, but they do report) — and the launch that
   // finishes the Solve writes the result and the token into host-mapped memory itself.
   m->token = (m->token % 0x3ffff) + 1;
-  const int token = m->token;
-  auto fused_progress = [&]() { const int v = prog[0]; return ((v >> kProgSeqBits) == token) ? (v & ((1 << kProgSeqBits) - 1)) : 0; };
-  auto fused_finished = [&]() { return prog[1] == token; };
-  if (!fused)
-    for (int i = 0; i < 16; i++) m->h_prog[i] = 0;  // unfused Solves end with a stream sync: nothing is draining
-  bool result_by_launch = false;
-  if (fused) {
-    // ---- fused pipeline: identical generic step launches; the device walks the pyramid itself ----
-    StepArgs a;
-    memset(&a, 0, sizeof(a));
-    a.n_levels = m->n_levels;
-    int grid = 1, budget = 0;
-    for (int l = 0; l < m->n_levels; l++) {
-      StepLevel& L = a.lv[l];
-      L.pl = m->pl[l]; L.n = m->npts[l];
-      L.rows = kf_img->r[l]; L.cols = kf_img->c[l];
-      L.nblk = lm_grid_for(m, l, L.rows, L.cols);
-      L.I2 = cur_img->dev + cur_img->off[l];
-      L.k = lm_level_k(m, l);
-      L.max_iters = m->max_iters[l];
-      if (L.nblk + 1 > grid) grid = L.nblk + 1;  // + the publisher block
-      budget += m->max_iters[l] > 0 ? m->max_iters[l] : 0;
-      bytes_per_level[l] = lm_level_bytes(m, l, L.rows, L.cols, L.nblk);
-    }
-    a.lambda0 = m->lambda; a.precision = m->precision; a.robust = m->robust; a.huber_delta = m->huber_delta;
-    a.trace = m->d_trace; a.cost_stat = m->d_cost; a.host_prog = m->d_prog;
-    a.out = m->d_res_map; a.done_flag = m->d_done; a.token = token;
-    memcpy(a.init, m->init, sizeof(a.init));
+  jb.token = m->token;
+  StepArgs& a = jb.a;
+  memset(&a, 0, sizeof(a));
+  a.n_levels = m->n_levels;
+  int grid = 1, budget = 0;
+  for (int l = 0; l < m->n_levels; l++) {
+    StepLevel& L = a.lv[l];
+    L.pl = m->pl[l]; L.n = m->npts[l];
+    L.rows = kf_img->r[l]; L.cols = kf_img->c[l];
+    L.nblk = lm_grid_for(m, l, L.rows, L.cols);
+    L.I2 = cur_img->dev + cur_img->off[l];
+    L.k = lm_level_k(m, l);
+    L.max_iters = m->max_iters[l];
+    if (L.nblk + 1 > grid) grid = L.nblk + 1;  // + the publisher block
+    budget += m->max_iters[l] > 0 ? m->max_iters[l] : 0;
+    jb.bytes_per_level[l] = lm_level_bytes(m, l, L.rows, L.cols, L.nblk);
+  }
+  a.lambda0 = m->lambda; a.precision = m->precision; a.robust = m->robust; a.huber_delta = m->huber_delta;
+  a.trace = m->d_trace; a.cost_stat = m->d_cost; a.host_prog = m->d_prog;
+  a.out = m->d_res_map; a.done_flag = m->d_done; a.token = jb.token;
+  memcpy(a.init, m->init, sizeof(a.init));
     static unsigned long long* dbg_buf = [] {
       unsigned long long* p = nullptr;
       if (getenv("ODO_COARSE_STAMPS") && hipHostMalloc((void**)&p, 1024, hipHostMallocMapped) == hipSuccess) memset(p, 0, 1024);
@@ -851,53 +865,126 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
       fprintf(stderr, "[coarse stamps] per iteration: eval %.0f reduce %.0f state-machine %.0f cycles; iterations/launch %.2f, "
               "cycles/launch %.0f\n", (double)dbg_buf[0] / dbg_buf[3], (double)dbg_buf[1] / dbg_buf[3],
               (double)dbg_buf[2] / dbg_buf[3], (double)dbg_buf[3] / dbg_buf[5], (double)dbg_buf[4] / dbg_buf[5]);
-    // Coarse levels (few points) run inside one workgroup: one launch covers every level >= min_level.
-    int min_level = m->n_levels;
-    static const int coarse_max = getenv("ODO_COARSE_MAX") ? atoi(getenv("ODO_COARSE_MAX")) : kCoarseMaxPoints;
-    while (min_level > 0 && m->npts[min_level - 1] <= coarse_max) min_level--;
-    if (!m->coarse) min_level = m->n_levels;
-    m->last_coarse = (min_level < m->n_levels) ? 1 : 0;
-    if (min_level < m->n_levels) {
-      int coarse_budget = 0;
-      for (int l = min_level; l < m->n_levels; l++) coarse_budget += m->max_iters[l] > 0 ? m->max_iters[l] : 0;
-      budget -= coarse_budget;
-      a.st_in = st[seq & 1]; a.st_out = st[(seq + 1) & 1];
-      a.part_in = part[seq & 1]; a.part_out = part[(seq + 1) & 1];
-      a.seq = seq; a.first_of_solve = 1;
-      const bool ev = m->ev_on && m->ev_pool && m->ev_pool->size() >= 2;
-      if (ev)
-        hipExtLaunchKernelGGL(lm_coarse_kernel, dim3(1), dim3(kCoarseBlock), kCoarseLdsBytes, s, (*m->ev_pool)[0],
-                              (*m->ev_pool)[1], 0, a, min_level);
-      else
-        hipLaunchKernelGGL(lm_coarse_kernel, dim3(1), dim3(kCoarseBlock), kCoarseLdsBytes, s, a, min_level);
-      seq++;
-      launches++;
-    }
-    // `budget` launches evaluate at most `budget` times; while the host is polling, one more launch consumes the last
-    // evaluation and reports the result, so no separate finalize launch is needed.
-    for (int it = 0; it < budget + (poll ? 1 : 0); it++) {
-      if (poll) {
-        const auto t0 = std::chrono::steady_clock::now();
-        while (seq - fused_progress() > m->run_ahead && !fused_finished()) {
-          if (m->idle_pump) m->idle_pump(m->idle_arg);
-          if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { poll = false; break; }  // never hang
-        }
-        if (fused_finished()) { result_by_launch = true; break; }  // every level has finished on the device
-        if (!poll && it >= budget) break;
+  LmState* st[2] = {m->d_state, m->d_state + 1};
+  double* part[2] = {m->d_partials, m->d_partials + (size_t)kLmMaxBlocks * ODO_NACC};
+  // Coarse levels (few points) run inside one workgroup: one launch covers every level >= min_level.
+  int min_level = m->n_levels;
+  static const int coarse_max = getenv("ODO_COARSE_MAX") ? atoi(getenv("ODO_COARSE_MAX")) : kCoarseMaxPoints;
+  while (min_level > 0 && m->npts[min_level - 1] <= coarse_max) min_level--;
+  if (!m->coarse) min_level = m->n_levels;
+  m->last_coarse = (min_level < m->n_levels) ? 1 : 0;
+  if (min_level < m->n_levels) {
+    int coarse_budget = 0;
+    for (int l = min_level; l < m->n_levels; l++) coarse_budget += m->max_iters[l] > 0 ? m->max_iters[l] : 0;
+    budget -= coarse_budget;
+    a.st_in = st[jb.seq & 1]; a.st_out = st[(jb.seq + 1) & 1];
+    a.part_in = part[jb.seq & 1]; a.part_out = part[(jb.seq + 1) & 1];
+    a.seq = jb.seq; a.first_of_solve = 1;
+    const bool ev = m->ev_on && m->ev_pool && m->ev_pool->size() >= 2;
+    if (ev)
+      hipExtLaunchKernelGGL(lm_coarse_kernel, dim3(1), dim3(kCoarseBlock), kCoarseLdsBytes, s, (*m->ev_pool)[0],
+                            (*m->ev_pool)[1], 0, a, min_level);
+    else
+      hipLaunchKernelGGL(lm_coarse_kernel, dim3(1), dim3(kCoarseBlock), kCoarseLdsBytes, s, a, min_level);
+    jb.seq++;
+    jb.launches++;
+  }
+  jb.grid = grid; jb.budget = budget; jb.min_level = min_level;
+  jb.active = 1;
+  return 0;
+}
+
+// Issues step launches. block = false: returns as soon as the next launch would have to wait for the device.
+// `budget` launches evaluate at most `budget` times; while the host is polling, one more launch consumes the last
+// evaluation and reports the result, so no separate finalize launch is needed.
+static void lm_fused_pump(odo_lm* m, bool block) {
+  LmJob& jb = m->job;
+  if (!jb.active || jb.issued_all) return;
+  hipStream_t s = m->ctx->stream;
+  StepArgs& a = jb.a;
+  LmState* st[2] = {m->d_state, m->d_state + 1};
+  double* part[2] = {m->d_partials, m->d_partials + (size_t)kLmMaxBlocks * ODO_NACC};
+  while (jb.it < jb.budget + (jb.poll ? 1 : 0)) {
+    if (jb.poll) {
+      const auto t0 = std::chrono::steady_clock::now();
+      while (jb.seq - lm_job_progress(m) > m->run_ahead && !lm_job_finished(m)) {
+        if (!block) return;
+        if (m->idle_pump) m->idle_pump(m->idle_arg);
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { jb.poll = false; break; }  // never hang
       }
-      a.st_in = st[seq & 1]; a.st_out = st[(seq + 1) & 1];
-      a.part_in = part[seq & 1]; a.part_out = part[(seq + 1) & 1];
-      a.seq = seq; a.first_of_solve = (seq == 0) ? 1 : 0;
-      const bool ev = m->ev_on && m->ev_pool && (size_t)(2 * launches + 1) < m->ev_pool->size();
-      if (ev)  // timing pass: start / stop events bound to the dispatch itself (the kernel's own begin / end timestamps)
-        hipExtLaunchKernelGGL(lm_step_kernel, dim3(grid), dim3(kLmBlock), 0, s, (*m->ev_pool)[2 * launches],
-                              (*m->ev_pool)[2 * launches + 1], 0, a);
-      else
-        hipLaunchKernelGGL(lm_step_kernel, dim3(grid), dim3(kLmBlock), 0, s, a);
-      seq++;
-      launches++;
-      if (it == budget) result_by_launch = true;  // the extra launch consumes the last evaluation and reports
+      if (lm_job_finished(m)) { jb.result_by_launch = true; break; }  // every level has finished on the device
+      if (!jb.poll && jb.it >= jb.budget) break;
     }
+    a.st_in = st[jb.seq & 1]; a.st_out = st[(jb.seq + 1) & 1];
+    a.part_in = part[jb.seq & 1]; a.part_out = part[(jb.seq + 1) & 1];
+    a.seq = jb.seq; a.first_of_solve = (jb.seq == 0) ? 1 : 0;
+    const bool ev = m->ev_on && m->ev_pool && (size_t)(2 * jb.launches + 1) < m->ev_pool->size();
+    if (ev)  // timing pass: start / stop events bound to the dispatch itself (the kernel's own begin / end timestamps)
+      hipExtLaunchKernelGGL(lm_step_kernel, dim3(jb.grid), dim3(kLmBlock), 0, s, (*m->ev_pool)[2 * jb.launches],
+                            (*m->ev_pool)[2 * jb.launches + 1], 0, a);
+    else
+      hipLaunchKernelGGL(lm_step_kernel, dim3(jb.grid), dim3(kLmBlock), 0, s, a);
+    jb.seq++;
+    jb.launches++;
+    if (jb.it == jb.budget) jb.result_by_launch = true;  // the extra launch consumes the last evaluation and reports
+    jb.it++;
+  }
+  jb.issued_all = true;
+}
+
+static bool lm_job_matches(const odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img) {
+  const LmJob& jb = m->job;
+  return jb.active && jb.kf_img == kf_img && jb.kf_dep == kf_dep && jb.cur_img == cur_img && jb.kf_img_ver == kf_img->version &&
+         jb.kf_dep_ver == kf_dep->version && jb.cur_ver == cur_img->version;
+}
+
+// Starts the Solve that a following odo_lm_solve(lm, kf_img, kf_dep, cur_img) will collect. Returns 0 when started (or already
+// running), 1 when this Solve does not run on the fused pipeline (nothing started: odo_lm_solve does all of it), -1 on error.
+extern "C" int odo_lm_solve_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img) {
+  if (lm_check_pyrs(m, kf_img, kf_dep, cur_img)) return -1;
+  HIP_OK(hipSetDevice(m->ctx->device));
+  if (lm_job_matches(m, kf_img, kf_dep, cur_img)) return 0;
+  m->job.active = 0;
+  if (lm_prepare_keyframe(m, kf_img, kf_dep)) return -1;
+  if (!lm_fused_eligible(m)) return 1;
+  if (lm_fused_begin(m, kf_img, kf_dep, cur_img)) return -1;
+  lm_fused_pump(m, false);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img,
+                            float out_colmajor[16]) {
+  if (!out_colmajor) return fail("odo_lm_solve: NULL out");
+  // failure value first: pseudo-identity whose (3,3) is 0 (ref: src/lm_optimizer.cpp:48-52,60-65)
+  for (int i = 0; i < 16; i++) out_colmajor[i] = 0.0f;
+  out_colmajor[0] = out_colmajor[5] = out_colmajor[10] = 1.0f;
+  if (lm_check_pyrs(m, kf_img, kf_dep, cur_img)) return -1;
+  hipStream_t s = m->ctx->stream;
+  HIP_OK(hipSetDevice(m->ctx->device));
+  const bool resumed = lm_job_matches(m, kf_img, kf_dep, cur_img);   // started earlier by odo_lm_solve_begin
+  if (!resumed) {
+    m->job.active = 0;
+    if (lm_prepare_keyframe(m, kf_img, kf_dep)) return -1;
+  }
+  int launches = 0;
+  double bytes_per_level[ODO_MAX_LEVELS] = {0};
+  // Early exit without a host sync: the device publishes its progress in host-mapped memory; the host stays at
+  // most `run_ahead` launches ahead of the device and stops issuing launches once the device reports that the Solve
+  // (fused pipeline) or the level (unfused pipeline) has ended. Stale launches are no-ops on the device either way.
+  volatile int* prog = m->h_prog;
+  bool poll = m->poll != 0;
+  const bool fused = resumed || lm_fused_eligible(m);
+  int seq = 0;
+  if (!fused)
+    for (int i = 0; i < 16; i++) m->h_prog[i] = 0;  // unfused Solves end with a stream sync: nothing is draining
+  if (fused) {
+    // ---- fused pipeline: identical generic step launches; the device walks the pyramid itself ----
+    if (!resumed && lm_fused_begin(m, kf_img, kf_dep, cur_img)) return -1;
+    lm_fused_pump(m, true);
+    launches = m->job.launches;
+    seq = m->job.seq;
+    for (int l = 0; l < ODO_MAX_LEVELS; l++) bytes_per_level[l] = m->job.bytes_per_level[l];
   } else {
     // ---- unfused pipeline (t-distribution mode, dense levels): residual kernel(s) + update kernel per evaluation ----
     HIP_OK(hipMemcpyAsync(m->d_init, m->init, sizeof(float) * 16, hipMemcpyHostToDevice, s));
@@ -932,6 +1019,11 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
     }
   }
   if (fused) {
+    const int token = m->job.token;
+    const bool result_by_launch = m->job.result_by_launch;
+    LmState* st[2] = {m->d_state, m->d_state + 1};
+    double* part[2] = {m->d_partials, m->d_partials + (size_t)kLmMaxBlocks * ODO_NACC};
+    m->job.active = 0;
     // The result comes back through host-mapped memory: no copy operation and no stream-sync call on the critical
     // path; the host spins on the completion word (bounded; falls back to a stream sync).
     auto launch_finalize = [&]() {
@@ -1060,6 +1152,7 @@ static int lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
   HIP_OK(hipSetDevice(lms[0]->ctx->device));
   for (int i = 0; i < n; i++) {
     odo_lm* m = lms[i];
+    m->job.active = 0;
     if (lm_prepare_keyframe(m, kf_img[i], kf_dep[i])) return -1;
     bool fused = m->fused && m->robust != 2 && m->poll;
     for (int l = 0; l < m->n_levels; l++) if (!m->use_list[l]) fused = false;

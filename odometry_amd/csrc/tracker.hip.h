@@ -7,6 +7,7 @@ struct odo_tracker {
   odo_tracker_params p;
   odo_ctx* ctx_a;  // pyramids of the incoming frame + pose LM
   odo_ctx* ctx_b;  // ComputeDepth + the frame's keyframe-candidate pyramids
+  odo_ctx* ctx_c;  // the NEXT frame's image pyramid when the next Solve starts early (a stream of its own: it delays neither chain)
   odo_lm* lm;
   odo_depth* depth;
   odo_pyr *kf_img, *kf_dep, *cur_img, *pre_img, *pre_dep, *next_img;
@@ -34,6 +35,13 @@ struct odo_tracker {
   const float *w_left, *w_right;
   int w_rc;
   char w_err[256];
+  // Early start of the next Solve (overlap_depth != 0, next frame announced with odo_tracker_hint_next): the next frame's
+  // pyramid is built on a third stream at the start of the call, and as soon as this frame's Solve has returned — initial pose and
+  // keyframe decision are known then — the next Solve's launches go out on the LM stream while the depth stream finishes and
+  // the host does its bookkeeping (odo_lm_solve_begin). Same launches, earlier; ODO_NO_EARLY_SOLVE=1 turns it off.
+  int early_solve;
+  hipEvent_t ev_next;        // stream C: next_img is complete
+  int skip_pre_img;          // 1 while tracking: the :251 rebuild of the frame's image pyramid is the :205 pyramid itself
 };
 
 static void tracker_worker_main(odo_tracker* t);
@@ -69,6 +77,7 @@ extern "C" int odo_tracker_destroy(odo_tracker* t) {
   }
   if (t->ctx_a) (void)hipStreamSynchronize(t->ctx_a->stream);
   if (t->ctx_b) (void)hipStreamSynchronize(t->ctx_b->stream);
+  if (t->ctx_c) (void)hipStreamSynchronize(t->ctx_c->stream);
   odo_lm_destroy(t->lm);
   odo_depth_destroy(t->depth);
   odo_pyr* ps[] = {t->kf_img, t->kf_dep, t->cur_img, t->pre_img, t->pre_dep, t->next_img};
@@ -78,6 +87,8 @@ extern "C" int odo_tracker_destroy(odo_tracker* t) {
   if (t->d_dep) (void)hipFree(t->d_dep);
   if (t->ev_inputs) (void)hipEventDestroy(t->ev_inputs);
   if (t->ev_cur_img) (void)hipEventDestroy(t->ev_cur_img);
+  if (t->ev_next) (void)hipEventDestroy(t->ev_next);
+  odo_ctx_destroy(t->ctx_c);
   odo_ctx_destroy(t->ctx_b);
   odo_ctx_destroy(t->ctx_a);
   delete t;
@@ -89,7 +100,7 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
   *out = nullptr;
   odo_tracker* t = new (std::nothrow) odo_tracker();
   if (!t) return fail("out of memory");
-  t->ctx_a = t->ctx_b = nullptr; t->lm = nullptr; t->depth = nullptr;
+  t->ctx_a = t->ctx_b = t->ctx_c = nullptr; t->lm = nullptr; t->depth = nullptr;
   t->kf_img = t->kf_dep = t->cur_img = t->pre_img = t->pre_dep = t->next_img = nullptr;
   t->hint_next = t->prefetched = nullptr;
   t->d_val = nullptr; t->d_disp = t->d_dep = nullptr; t->ev_inputs = nullptr; t->ev_cur_img = nullptr;
@@ -98,6 +109,8 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
   t->cand_lists = getenv("ODO_NO_CAND_LISTS") ? 0 : 1;
   t->tm_solve_us = t->tm_depth_us = t->tm_frame_us = t->tm_wait_us = 0.0; t->tm_frames = 0;
   t->w_state.store(0); t->w_quit.store(0); t->w_left = t->w_right = nullptr; t->w_rc = 0; t->w_err[0] = 0;
+  t->ev_next = nullptr; t->skip_pre_img = 0;
+  t->early_solve = getenv("ODO_NO_EARLY_SOLVE") ? 0 : 1;
   t->p = *p;
   float eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   memcpy(t->pose_to_kf, eye, sizeof(eye));
@@ -109,7 +122,7 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
   // (read per tracker: several trackers in ONE process should not all draw from the small high-priority pool)
   const bool lm_prio = !(getenv("ODO_LM_PRIORITY") && atoi(getenv("ODO_LM_PRIORITY")) == 0);
   bool ok = (lm_prio ? odo_ctx_create_high_priority(device, &t->ctx_a) : odo_ctx_create(device, &t->ctx_a)) == 0 &&
-            odo_ctx_create(device, &t->ctx_b) == 0;
+            odo_ctx_create(device, &t->ctx_b) == 0 && odo_ctx_create(device, &t->ctx_c) == 0;
   ok = ok && odo_lm_create(t->ctx_a, p->lm_lambda, p->lm_precision, p->lm_max_iters, p->levels, eye, p->lm_robust,
                            p->lm_huber_delta, &p->K, &t->lm) == 0;
   ok = ok && odo_depth_create(t->ctx_b, p->grad_th, p->ssd_th, p->photo_th, p->min_depth, p->max_depth, p->depth_lambda,
@@ -125,6 +138,7 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
        hipMalloc((void**)&t->d_dep, sizeof(float) * n) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&t->ev_inputs, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&t->ev_cur_img, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&t->ev_next, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     char keep[512];
     snprintf(keep, sizeof(keep), "%s", g_err);
@@ -154,7 +168,7 @@ static void tracker_job_pump(void* arg) {
   if (r < 0) { t->job_err = 1; t->job_stage = 3; return; }
   if (r > 0) {
     const odo_tracker_params& p = t->p;
-    if (!t->pre_img_on_a && pyr_build(t->pre_img, t->job.left, p.smooth_image)) t->job_err = 1;  // :251
+    if (!t->skip_pre_img && !t->pre_img_on_a && pyr_build(t->pre_img, t->job.left, p.smooth_image)) t->job_err = 1;  // :251
     if (pyr_build(t->pre_dep, t->d_dep, 0)) t->job_err = 1;                   // :252
     // This frame may become the next keyframe (:258-265): compact its valid-depth pixels into point lists now, on this
     // stream, beside the Solve — the image pyramid is the one stream A built for the frame (same image, same arithmetic
@@ -167,6 +181,14 @@ static void tracker_job_pump(void* arg) {
     if (depth_job_stats(t->depth, &t->job)) t->job_err = 1;  // completion word AFTER the pyramids: it covers them too
     t->job_stage = 3;
   }
+}
+// The NEXT frame's image pyramid (ref: :205 of the next iteration) on a stream of its own, enqueued at the start of this
+// frame's call: complete long before this frame's Solve ends, so the next Solve can start the moment it does.
+static int tracker_next_pyramid(odo_tracker* t, const float* next_left) {
+  t->next_img->ctx = t->ctx_c;
+  if (pyr_build(t->next_img, next_left, t->p.smooth_image)) return -1;
+  HIP_OK(hipEventRecord(t->ev_next, t->ctx_c->stream));
+  return 0;
 }
 static int tracker_job_drain(odo_tracker* t) {
   while (t->job_stage == 1) tracker_job_pump(t);
@@ -210,7 +232,10 @@ extern "C" int odo_tracker_init(odo_tracker* t, const float* left, const float* 
   // candidate image pyramid to that stream. Start from a quiet device and build everything on stream B again.
   HIP_OK(hipStreamSynchronize(t->ctx_a->stream));
   HIP_OK(hipStreamSynchronize(t->ctx_b->stream));
+  HIP_OK(hipStreamSynchronize(t->ctx_c->stream));
   t->pre_img_on_a = 0;
+  t->skip_pre_img = 0;
+  t->lm->job.active = 0;                   // a Solve started early for the previous sequence's next frame is dropped
   t->pre_img->ctx = t->ctx_b;
   t->prefetched = t->hint_next = nullptr;  // a pyramid prefetched for the previous sequence is not this sequence's frame
   const int cand_keep = t->cand_lists;
@@ -292,14 +317,22 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
   const auto f0 = std::chrono::steady_clock::now();
   HIP_OK(hipSetDevice(t->ctx_a->device));
   t->frame_id++;
-  t->pre_img_on_a = p.overlap_depth != 0;
+  t->skip_pre_img = 1;     // :251 rebuilds the pyramid :205 built from the same image: bit-identical, so a promoted frame's
+  t->pre_img_on_a = 0;     // :205 pyramid becomes the keyframe pyramid (buffer swap below) and no second build is launched
   if (t->prefetched == left) {
-    std::swap(t->cur_img, t->next_img);  // :205 — this frame's pyramid was built on stream A at the end of the last call
-  } else if (pyr_build(t->cur_img, left, p.smooth_image)) {                            // :205
-    return -1;
+    std::swap(t->cur_img, t->next_img);  // :205 — this frame's pyramid was built during the last call
+  } else {
+    t->lm->job.active = 0;               // an early Solve (if any) was started on another image
+    t->cur_img->ctx = t->ctx_a;
+    if (pyr_build(t->cur_img, left, p.smooth_image)) return -1;                        // :205
   }
   t->prefetched = nullptr;
   if (t->cand_lists) HIP_OK(hipEventRecord(t->ev_cur_img, t->ctx_a->stream));  // before the stream-B job can ask for it
+  // The next frame's pyramid is enqueued on stream C right away when the next Solve may start early; otherwise it is built
+  // on stream A behind this frame's Solve (overlap_depth == 0, or ODO_NO_EARLY_SOLVE).
+  const float* next_left = t->hint_next;
+  t->hint_next = nullptr;
+  const bool early = t->early_solve && p.overlap_depth != 0 && next_left != nullptr;
   bool job_posted = false;
   if (p.overlap_depth == 2) {
     // helper thread: the whole stream-B job (ComputeDepth, candidate pyramids, final sync) runs beside this thread
@@ -320,26 +353,20 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
     t->lm->idle_pump = tracker_job_pump;
     t->lm->idle_arg = t;
   }
+  if (early && tracker_next_pyramid(t, next_left)) return -1;   // stream C, beside both chains
   float T[16];
   const auto s0 = std::chrono::steady_clock::now();
-  const int st = odo_lm_solve(t->lm, t->kf_img, t->kf_dep, t->cur_img, T);             // :215 (synchronises stream A)
+  const int st = odo_lm_solve(t->lm, t->kf_img, t->kf_dep, t->cur_img, T);             // :215 (collects an early start)
   const auto s1 = std::chrono::steady_clock::now();
   t->tm_solve_us += std::chrono::duration<double, std::micro>(s1 - s0).count();
   t->lm->idle_pump = nullptr;
-  if (t->pre_img_on_a) {
-    // :251 — the runner builds the frame's image pyramid a second time. It depends on the image only, so it goes to
-    // stream A, which is idle from here to the end of the frame while stream B finishes the depth. Ordered before
-    // the next frame's Solve by the stream itself.
-    t->pre_img->ctx = t->ctx_a;
-    if (pyr_build(t->pre_img, left, p.smooth_image)) return -1;
-  }
-  if (t->hint_next) {
+  if (next_left && !early) {
     // The caller told us which device image comes next (offline / batched runs know): its pyramid is built now, on
     // the idle stream A, instead of at the head of the next call where the Solve would wait for it.
-    if (pyr_build(t->next_img, t->hint_next, p.smooth_image)) return -1;
-    t->prefetched = t->hint_next;
-    t->hint_next = nullptr;
+    t->next_img->ctx = t->ctx_a;
+    if (pyr_build(t->next_img, next_left, p.smooth_image)) return -1;
   }
+  if (next_left) t->prefetched = next_left;
   // :218 — the runner stores the frame's pose BEFORE it computes the depth (:215-232): a frame whose ComputeDepth fails
   // still reports its pose (and the runner then leaves its loop).
   memcpy(t->pose_to_kf, T, sizeof(T));
@@ -352,32 +379,46 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
   if (solve_status) *solve_status = st;
   if (is_new_keyframe) *is_new_keyframe = 0;
   if (motion_mag) *motion_mag = 0.0f;
-  if (p.overlap_depth == 2) {
-    job_posted = false;   // collected here, not by the guard
-    if (tracker_wait_worker(t)) return -1;                                             // :230-232
-  } else {
-    if (p.overlap_depth == 1) {
-      if (tracker_job_drain(t)) return -1;
-    } else {
-      if (tracker_depth_and_pyramids(t, left, right)) return -1;                       // :226-252 in program order
-    }
-    if (depth_finish(t->depth, false)) { fail("    depth failed!"); return -1; }       // :230-232
-  }
   float ang[3];
   motion_angles(T, ang);                                                               // :253
   const float mot[6] = {fabsf(ang[0]), fabsf(ang[1]), fabsf(ang[2]), fabsf(T[12]), fabsf(T[13]), fabsf(T[14])};
   float mag = 0.0f;
   for (int i = 0; i < 6; i++) mag += mot[i] * p.keyframe_weight[i];                     // :257
+  const bool promote = mag > p.keyframe_motion_th;                                     // :258
+  // The next Solve's inputs: keyframe (unchanged unless this frame is promoted), next frame's pyramid (stream C, ev_next),
+  // initial pose = T (:261 / :268 Reset). Started here, it runs while stream B finishes this frame's depth.
+  auto start_next_solve = [&]() -> int {
+    if (hipStreamWaitEvent(t->ctx_a->stream, t->ev_next, 0) != hipSuccess) return 1;
+    return odo_lm_solve_begin(t->lm, t->kf_img, t->kf_dep, t->next_img) < 0 ? -1 : 0;
+  };
+  bool reset_done = false;
+  if (early && !promote) {
+    odo_lm_reset(t->lm, T, 0.01f);                                                     // :268
+    reset_done = true;
+    if (start_next_solve() < 0) return -1;
+  }
+  if (p.overlap_depth == 2) {
+    job_posted = false;   // collected here, not by the guard
+    if (tracker_wait_worker(t)) { t->lm->job.active = 0; return -1; }                  // :230-232
+  } else {
+    if (p.overlap_depth == 1) {
+      if (tracker_job_drain(t)) { t->lm->job.active = 0; return -1; }
+    } else {
+      if (tracker_depth_and_pyramids(t, left, right)) return -1;                       // :226-252 in program order
+    }
+    if (depth_finish(t->depth, false)) { t->lm->job.active = 0; fail("    depth failed!"); return -1; }  // :230-232
+  }
   int new_kf = 0;
-  if (mag > p.keyframe_motion_th) {                                                    // :258
-    std::swap(t->kf_img, t->pre_img);                                                  // :259
+  if (promote) {
+    std::swap(t->kf_img, t->cur_img);                                                  // :259 (the :251 rebuild == the :205 pyramid)
     std::swap(t->kf_dep, t->pre_dep);
     memcpy(t->kf_abs, cur, sizeof(cur));                                               // :260
     t->n_keyframes++;
     new_kf = 1;
     if (t->cand_lists) lm_adopt_candidate(t->lm, t->kf_img, t->kf_dep, (long)t->frame_id);  // lists built beside the Solve
   }
-  odo_lm_reset(t->lm, T, 0.01f);                                                       // :261 / :268 (both branches)
+  if (!reset_done) odo_lm_reset(t->lm, T, 0.01f);                                      // :261 / :268 (both branches)
+  if (early && promote && start_next_solve() < 0) return -1;   // against the new keyframe, as soon as its lists are adopted
   if (pose_to_keyframe) memcpy(pose_to_keyframe, T, sizeof(T));
   if (abs_pose) memcpy(abs_pose, cur, sizeof(cur));
   if (is_new_keyframe) *is_new_keyframe = new_kf;

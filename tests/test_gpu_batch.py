@@ -215,3 +215,84 @@ def test_batched_tracker_slots_of_different_lengths_and_hints(api, drives):
             assert np.array_equal(a["abs_pose"], r["abs_pose"]), (i, k)
             assert a["new_keyframe"] == r["new_keyframe"]
     tb.close()
+
+
+@pytest.mark.parametrize("overlap", [2, 1, 0])
+def test_early_start_of_the_next_solve_changes_nothing(api, drives, overlap):
+    """With the next frame announced (hint_next) the tracker builds its pyramid at the head of the depth stream's job and starts
+    the next Solve the moment the current one returns (odo_lm_solve_begin): same launches, earlier. Poses, keyframe decisions
+    and depth statistics must be those of the un-hinted run — across a keyframe switch, with a wrong hint, with a hint that is
+    followed by a re-initialisation, and with a frame that is not hinted at all."""
+    seq = drives[0]
+    n = 11
+
+    def run(hints):
+        trk = api.Tracker(0, overlap_depth=overlap)
+        dev = [(trk.upload_frame(l), trk.upload_frame(r)) for l, r in zip(seq["left"][:n], seq["right"][:n])]
+        out = []
+        for rep in range(2):
+            trk.init(*dev[0])
+            for k in range(1, n):
+                if hints:
+                    if k == 4:
+                        trk.hint_next(dev[0][0])            # wrong announcement: the next frame is 5
+                    elif k == 6:
+                        pass                                # no announcement
+                    elif k + 1 < n:
+                        trk.hint_next(dev[k + 1][0])
+                    else:
+                        trk.hint_next(dev[1][0])            # announced, but the sequence is re-initialised instead
+                r = trk.track(*dev[k])
+                r["stats"] = trk.stats()
+                out.append(r)
+        trk.close()
+        return out
+
+    plain, hinted = run(False), run(True)
+    assert any(r["new_keyframe"] for r in plain)
+    for k, (a, b) in enumerate(zip(plain, hinted)):
+        assert np.array_equal(a["pose_to_keyframe"], b["pose_to_keyframe"]), k
+        assert np.array_equal(a["abs_pose"], b["abs_pose"]), k
+        assert a["new_keyframe"] == b["new_keyframe"] and a["motion"] == b["motion"] and a["solve_status"] == b["solve_status"]
+        assert a["stats"] == b["stats"], k
+
+
+def test_solve_begin_then_solve_equals_solve(api, kitti_seq):
+    """odo_lm_solve_begin + odo_lm_solve == odo_lm_solve: same pose, same trace; a begin that is abandoned (Reset, or a Solve on
+    other pyramids) leaves no trace in the following Solve; dense / t-distribution Solves do not start early (returns 1)."""
+    from odometry_amd import synth
+    import time
+    L, Z = kitti_seq["left"], kitti_seq["depth"]
+    inv = [synth.semi_dense_inverse_depth(Z[k], L[k]) for k in range(2)]
+    pyr = [api.ImagePyramid(4, L[k], True) for k in range(3)]
+    dep = [api.DepthPyramid(4, inv[k], False) for k in range(2)]
+    init = np.eye(4, dtype=np.float32)
+    init[2, 3] = -0.2
+
+    def make(robust=1):
+        return api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], init, None, robust, 28.0)
+    ref = make()
+    T_ref = ref.Solve(pyr[0], dep[0], pyr[1])
+    tr_ref = _trace_key(ref.trace())
+    T_ref2 = ref.Solve(pyr[0], dep[0], pyr[2])          # second Solve from the same initial pose, other frame
+    tr_ref2 = _trace_key(ref.trace())
+    lm = make()
+    assert lm.SolveBegin(pyr[0], dep[0], pyr[1]) == 0
+    time.sleep(0.01)                                    # the device runs ahead as far as the launches issued so far allow
+    assert lm.SolveBegin(pyr[0], dep[0], pyr[1]) == 0   # already running
+    T = lm.Solve(pyr[0], dep[0], pyr[1])
+    assert np.array_equal(T, T_ref) and _trace_key(lm.trace()) == tr_ref
+    # abandoned by a Solve on another frame
+    assert lm.SolveBegin(pyr[0], dep[0], pyr[1]) == 0
+    T2 = lm.Solve(pyr[0], dep[0], pyr[2])
+    assert np.array_equal(T2, T_ref2) and _trace_key(lm.trace()) == tr_ref2
+    # abandoned by Reset (same pose: the Solve after it must still be the reference one)
+    assert lm.SolveBegin(pyr[0], dep[0], pyr[2]) == 0
+    assert lm.Reset(init, 0.01) == 0
+    T3 = lm.Solve(pyr[0], dep[0], pyr[1])
+    assert np.array_equal(T3, T_ref) and _trace_key(lm.trace()) == tr_ref
+    # t-distribution weights run the unfused pipeline: nothing to start early
+    lt = make(robust=2)
+    assert lt.SolveBegin(pyr[0], dep[0], pyr[1]) == 1
+    for o in (ref, lm, lt):
+        o.close()

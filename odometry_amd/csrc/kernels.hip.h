@@ -416,7 +416,10 @@ __device__ __forceinline__ void kf_count_kernel_body(KL kl, int* __restrict__ ro
   __syncthreads();
   if (threadIdx.x == 0) rowcnt[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
-__global__ void __launch_bounds__(256) kf_count_kernel(KfLevels kl, int* __restrict__ rowcnt) {
+// npts_zero: the per-level totals kf_fill_kernel writes (levels without interior rows stay at 0), cleared here so that no
+// memset operation is needed in front of the pair of launches.
+__global__ void __launch_bounds__(256) kf_count_kernel(KfLevels kl, int* __restrict__ rowcnt, int* __restrict__ npts_zero) {
+  if (npts_zero && blockIdx.x == 0 && threadIdx.x < ODO_MAX_LEVELS_K) npts_zero[threadIdx.x] = 0;
   kf_count_kernel_body<KfLevels>(kl, rowcnt);
 }
 

@@ -446,13 +446,13 @@ struct odo_lm {
   int npts[ODO_MAX_LEVELS];
   int use_list[ODO_MAX_LEVELS];
   unsigned long long kf_img_ver, kf_dep_ver;
-  int* d_rowcnt; int* d_npts; int* h_npts; int rows_cap;
+  int* d_rowcnt; int* d_npts; int* h_npts; int* hm_npts /* device alias of h_npts */; int rows_cap;
   // A second, identical set of list buffers for the keyframe CANDIDATE of the frame being tracked: the tracker fills it on
   // its depth stream every frame (lm_build_candidate), off the Solve's critical path; when the candidate becomes the
   // keyframe the two sets trade places (lm_adopt_candidate) instead of list-building launches + a read-back in front of the Solve.
   PointList cand_pl[ODO_MAX_LEVELS];
   size_t cand_pl_cap[ODO_MAX_LEVELS];
-  int* cand_d_rowcnt; int* cand_d_npts; int* cand_h_npts; int cand_rows_cap;
+  int* cand_d_rowcnt; int* cand_d_npts; int* cand_h_npts; int* cand_hm_npts; int cand_rows_cap;
   long cand_tag;   // caller's tag of the candidate (frame id), -1 = none
   // optional per-launch HIP-event timing of the evaluation kernels (bench.py roofline leg)
   int ev_on;
@@ -523,10 +523,14 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
   HIP_OK(hipHostMalloc((void**)&m->h_prog, sizeof(int) * 16, hipHostMallocMapped | hipHostMallocCoherent));
   HIP_OK(hipHostGetDevicePointer((void**)&m->d_prog, m->h_prog, 0));
   memset(m->h_prog, 0, sizeof(int) * 16);
+  // per-level point counts: written by kf_fill_kernel straight into host-mapped memory (no copy operation on the stream);
+  // d_npts / cand_d_npts are device arrays for the batched tracker, which forwards them from its last launch
   HIP_OK(hipMalloc((void**)&m->d_npts, sizeof(int) * ODO_MAX_LEVELS));
-  HIP_OK(hipHostMalloc((void**)&m->h_npts, sizeof(int) * ODO_MAX_LEVELS, hipHostMallocDefault));
+  HIP_OK(hipHostMalloc((void**)&m->h_npts, sizeof(int) * ODO_MAX_LEVELS, hipHostMallocMapped | hipHostMallocCoherent));
+  HIP_OK(hipHostGetDevicePointer((void**)&m->hm_npts, m->h_npts, 0));
   HIP_OK(hipMalloc((void**)&m->cand_d_npts, sizeof(int) * ODO_MAX_LEVELS));
-  HIP_OK(hipHostMalloc((void**)&m->cand_h_npts, sizeof(int) * ODO_MAX_LEVELS, hipHostMallocDefault));
+  HIP_OK(hipHostMalloc((void**)&m->cand_h_npts, sizeof(int) * ODO_MAX_LEVELS, hipHostMallocMapped | hipHostMallocCoherent));
+  HIP_OK(hipHostGetDevicePointer((void**)&m->cand_hm_npts, m->cand_h_npts, 0));
   m->cand_tag = -1;
   m->mode = getenv("ODO_LM_MODE") ? atoi(getenv("ODO_LM_MODE")) : 0;
   m->dense_plain_div = getenv("ODO_DENSE_PLAIN_DIV") ? 1 : 0;
@@ -653,19 +657,18 @@ static int lm_lists_layout(odo_lm* m, PointList* pl, size_t* pl_cap, int*& d_row
   return 0;
 }
 
-static int lm_enqueue_lists(odo_lm* m, PointList* pl, size_t* pl_cap, int*& d_rowcnt, int& rows_cap, int* d_npts,
-                            int* h_npts, const odo_pyr* img, const odo_pyr* dep, hipStream_t s, int* rows_total_out) {
+// hm_npts: device alias of the host-mapped per-level counts (the host reads them once the stream has passed the launches).
+static int lm_enqueue_lists(odo_lm* m, PointList* pl, size_t* pl_cap, int*& d_rowcnt, int& rows_cap, int* hm_npts,
+                            const odo_pyr* img, const odo_pyr* dep, hipStream_t s, int* rows_total_out) {
   KfLevels kl;
   int rows_total = 0;
   if (lm_lists_layout(m, pl, pl_cap, d_rowcnt, rows_cap, img, dep, s, &kl, &rows_total)) return -1;
   *rows_total_out = rows_total;
   if (rows_total > 0) {
-    HIP_OK(hipMemsetAsync(d_npts, 0, sizeof(int) * ODO_MAX_LEVELS, s));  // levels without interior rows stay at 0
-    hipLaunchKernelGGL(kf_count_kernel, dim3(rows_total), dim3(256), 0, s, kl, d_rowcnt);
+    hipLaunchKernelGGL(kf_count_kernel, dim3(rows_total), dim3(256), 0, s, kl, d_rowcnt, hm_npts);
     hipLaunchKernelGGL(kf_fill_kernel, dim3(rows_total), dim3(256), 0, s, kl, m->K.f0, m->K.cx0, m->K.cy0,
-                       (const int*)d_rowcnt, d_npts, pl[0], pl[1], pl[2], pl[3], pl[4], pl[5], pl[6], pl[7]);
+                       (const int*)d_rowcnt, hm_npts, pl[0], pl[1], pl[2], pl[3], pl[4], pl[5], pl[6], pl[7]);
     HIP_OK(hipGetLastError());
-    HIP_OK(hipMemcpyAsync(h_npts, d_npts, sizeof(int) * ODO_MAX_LEVELS, hipMemcpyDeviceToHost, s));
   }
   return 0;
 }
@@ -689,7 +692,7 @@ static int lm_prepare_keyframe(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* 
   if (m->kf_img_ver == kf_img->version && m->kf_dep_ver == kf_dep->version) return 0;
   hipStream_t s = m->ctx->stream;
   int rows_total = 0;
-  if (lm_enqueue_lists(m, m->pl, m->pl_cap, m->d_rowcnt, m->rows_cap, m->d_npts, m->h_npts, kf_img, kf_dep, s,
+  if (lm_enqueue_lists(m, m->pl, m->pl_cap, m->d_rowcnt, m->rows_cap, m->hm_npts, kf_img, kf_dep, s,
                        &rows_total)) return -1;
   if (rows_total > 0) HIP_OK(hipStreamSynchronize(s));
   lm_take_counts(m, m->h_npts, kf_img, rows_total);
@@ -704,8 +707,8 @@ static int lm_build_candidate(odo_lm* m, const odo_pyr* img, const odo_pyr* dep,
   m->cand_tag = -1;
   if (m->mode == 1) return 0;
   int rows_total = 0;
-  if (lm_enqueue_lists(m, m->cand_pl, m->cand_pl_cap, m->cand_d_rowcnt, m->cand_rows_cap, m->cand_d_npts,
-                       m->cand_h_npts, img, dep, s, &rows_total)) return -1;
+  if (lm_enqueue_lists(m, m->cand_pl, m->cand_pl_cap, m->cand_d_rowcnt, m->cand_rows_cap, m->cand_hm_npts, img, dep, s,
+                       &rows_total)) return -1;
   if (rows_total > 0) m->cand_tag = tag;
   return 0;
 }
@@ -717,7 +720,7 @@ static int lm_adopt_candidate(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* k
   if (m->mode == 1 || m->cand_tag < 0 || m->cand_tag != tag) return 1;
   for (int l = 0; l < ODO_MAX_LEVELS; l++) { std::swap(m->pl[l], m->cand_pl[l]); std::swap(m->pl_cap[l], m->cand_pl_cap[l]); }
   std::swap(m->d_rowcnt, m->cand_d_rowcnt); std::swap(m->rows_cap, m->cand_rows_cap);
-  std::swap(m->d_npts, m->cand_d_npts); std::swap(m->h_npts, m->cand_h_npts);
+  std::swap(m->d_npts, m->cand_d_npts); std::swap(m->h_npts, m->cand_h_npts); std::swap(m->hm_npts, m->cand_hm_npts);
   int rows_total = 0;
   for (int l = 0; l < m->n_levels; l++) {
     const int ir = kf_img->r[l] - 8, ic = kf_img->c[l] - 8;

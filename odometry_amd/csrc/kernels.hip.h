@@ -892,21 +892,27 @@ constexpr int kFoldChunk = 20;  // the 160 rows of a point-list grid in one roun
 // pending: acc_sh holds the 29 sums of an evaluation at s_sh.T that has not been consumed yet.
 __device__ __forceinline__ void lm_state_machine(bool pending, const StepLevel* lv, int n_levels, float lambda0,
                                                  float precision, LmState& s_sh, double* acc_sh, LmTraceRow* __restrict__ trace,
-                                                 float* __restrict__ cost_stat, bool publisher) {
+                                                 float* __restrict__ cost_stat, bool publisher,
+                                                 unsigned long long* smdbg = nullptr) {
   const int t = threadIdx.x;
   if (t < 64) {
+    unsigned long long c0 = smdbg ? __builtin_readcyclecounter() : 0, c1 = c0, c2 = c0, c3 = c0;
     LmState s = s_sh;
     const int iter0 = s.iter, lvl0 = s.level;
     const float err_last0 = s.err_last;
     bool need_step = false;
     if (pending) need_step = lm_decide(&s, acc_sh, precision);
+    if (smdbg) { c1 = __builtin_readcyclecounter(); c2 = c1; c3 = c1; }
     if (need_step) {
       float d[6];
       solve_damped_wave_regs(acc_sh, s.lambda, d);
 #pragma unroll
       for (int i = 0; i < 6; i++) s.delta[i] = d[i];
+      if (smdbg) { asm volatile("" ::"v"(d[0]), "v"(d[5])); c2 = __builtin_readcyclecounter(); }
       lm_apply_step(&s, s.max_iters);
+      if (smdbg) { asm volatile("" ::"v"(s.T[0]), "v"(s.T[14])); c3 = __builtin_readcyclecounter(); }
     }
+    if (smdbg && t == 0) { smdbg[0] += c1 - c0; smdbg[1] += c2 - c1; smdbg[2] += c3 - c2; smdbg[3] += 1; }
     if (pending) {
       if (publisher && t == 0) {
         const int ev = s.n_evals - 1;
@@ -1190,7 +1196,8 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
     if (my_q < ODO_NACC && my_s == 0) acc_sh[my_q] = accq;
     __syncthreads();
     lap(c_red);
-    lm_state_machine(true, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, acc_sh, a.trace, a.cost_stat, true);
+    lm_state_machine(true, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, acc_sh, a.trace, a.cost_stat, true,
+                     a.dbg ? a.dbg + 8 : nullptr);
     lap(c_sm);
   }
   lm_fused_publish(s_sh, q.st_out, a.host_prog, q.seq, a.token, a.cost_stat, a.out, a.done_flag);

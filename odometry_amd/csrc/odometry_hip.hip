@@ -868,6 +868,9 @@ static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_de
       fprintf(stderr, "[coarse stamps] per iteration: eval %.0f reduce %.0f state-machine %.0f cycles; iterations/launch %.2f, "
               "cycles/launch %.0f\n", (double)dbg_buf[0] / dbg_buf[3], (double)dbg_buf[1] / dbg_buf[3],
               (double)dbg_buf[2] / dbg_buf[3], (double)dbg_buf[3] / dbg_buf[5], (double)dbg_buf[4] / dbg_buf[5]);
+    if (dbg_buf && dbg_buf[5] > 0 && dbg_buf[5] % 100 == 0 && dbg_buf[11] > 0)
+      fprintf(stderr, "[state machine] decide %.0f solve %.0f exp/compose %.0f cycles per evaluation\n",
+              (double)dbg_buf[8] / dbg_buf[11], (double)dbg_buf[9] / dbg_buf[11], (double)dbg_buf[10] / dbg_buf[11]);
   LmState* st[2] = {m->d_state, m->d_state + 1};
   double* part[2] = {m->d_partials, m->d_partials + (size_t)kLmMaxBlocks * ODO_NACC};
   // Coarse levels (few points) run inside one workgroup: one launch covers every level >= min_level.

@@ -3,6 +3,7 @@
 #   bash tools/collect_profiles.sh <tag>
 # Passes (each its own run; counters never share a run with tracing beyond --kernel-trace):
 #   1. --kernel-trace --stats of the bench command (no child processes: the CPU-baseline and shim legs spawn programs)
+#   1b. the same of the driver's short run (--steps 20 --warmup 5)
 #   2. --pmc FETCH_SIZE   3. --pmc WRITE_SIZE   of the same command with fewer steps
 #   4. --pmc SQ_* of the dense-kernel microbenchmark (issue-bound evidence) + its plain output (A/B table)
 #   5. the VALU instruction-rate microbenchmark
@@ -11,8 +12,10 @@ TAG=${1:-r02}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $GRAFT_REPO_ROOT/bench.py --cpu-frames 0 --extras dense,disparity,single"
+BENCH="python3 $GRAFT_REPO_ROOT/bench.py --cpu-frames 0 --extras dense,disparity,single,batched"
 timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH --steps 1000 --warmup 50 > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err < /dev/null
+# 1b. the driver's own short run (python bench.py --steps 20 --warmup 5), side legs off: the averages bench.py's roofline line must agree with
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats20 -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-frames 0 --no-extras --steps 20 --warmup 5 > $OUT/bench_profiled_steps20.json 2> $OUT/bench_profiled_steps20.err < /dev/null
 timeout -k 5 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH --steps 199 --warmup 5 > /dev/null 2>&1 < /dev/null
 timeout -k 5 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH --steps 199 --warmup 5 > /dev/null 2>&1 < /dev/null
 F="-O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fhip-fp32-correctly-rounded-divide-sqrt"
@@ -22,4 +25,7 @@ timeout -k 5 120 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_
 timeout -k 5 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_ablate -- /tmp/dense_ablate 1920 1080 "1024 x 256" > /dev/null 2>&1 < /dev/null
 hipcc -O3 --offload-arch=gfx950 -o /tmp/valu_rates $GRAFT_REPO_ROOT/tools/microbench/valu_rates.hip 2>> $OUT/build.log
 timeout -k 5 120 /tmp/valu_rates > $OUT/valu_rates.log 2>&1 < /dev/null
-ls -R $OUT | head -40
+# keep the per-kernel stats and the counter collections (what the summaries are made from); drop the per-dispatch traces
+find $OUT -name "*_kernel_trace.csv" -delete
+find $OUT -name "*_agent_info.csv" -delete
+du -sh $OUT; ls -R $OUT | head -60

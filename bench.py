@@ -590,7 +590,7 @@ def main():
         # (odo_tracker_hint_next). Not across the start of the clock: the last warm-up step announces nothing, so no work of
         # the first timed step runs before t0.
         if not args.no_prefetch and k + 1 < n_total and k + 1 != args.warmup:
-            trk.hint_next(dv[order[k + 1]][0])
+            trk.hint_next(*dv[order[k + 1]])
         trk.track_into(dv[i][0], dv[i][1], poses_kf[j, k], poses_abs[j, k])
         if publish and gatherer is not None:    # RCCL all_gather over xGMI every gather_every frames
             gatherer.push(poses_abs[j, k].reshape(4, 4).T, seq_id=my_seq_ids[j] if my_seq_ids else 0, frame_id=i)

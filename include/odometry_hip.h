@@ -254,6 +254,12 @@ int odo_tracker_track(odo_tracker* t, const float* left_dev, const float* right_
  * address: its contents must not change between the hint and the odo_tracker_track call that consumes it (a caller that
  * recycles one buffer for every frame must not hint). odo_tracker_init drops a pending hint / prefetched pyramid. */
 int odo_tracker_hint_next(odo_tracker* t, const float* next_left_dev);
+/* The same with the next frame's right image as well: its ComputeDepth + candidate pyramids (ref: :226-252 of the NEXT
+ * iteration; they depend on the images only) are then enqueued on the depth stream a frame early too, behind this frame's, so
+ * the depth stream works a frame ahead of the pose LM and a short Solve no longer waits for it (overlap_depth == 2;
+ * ODO_NO_DEPTH_AHEAD=1 turns it off). Both buffers must stay unchanged until the odo_tracker_track call that consumes them.
+ * Results are unchanged. odo_tracker_outputs stays valid until the next odo_tracker_track call, as before. */
+int odo_tracker_hint_next_pair(odo_tracker* t, const float* next_left_dev, const float* next_right_dev);
 /* Counters of the last tracked frame: LM evaluations, depth-LM iterations, valid depth points, keyframes so far. */
 int odo_tracker_stats(const odo_tracker* t, int* lm_evals, int* depth_iters, int* n_valid_depth, int* n_keyframes);
 /* Device pointers to the last frame's outputs (rows x cols): validity mask (u8), disparity, inverse depth. */

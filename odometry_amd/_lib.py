@@ -102,6 +102,7 @@ SIGNATURES = {
     "odo_tracker_init": (C.c_int, [_vp, _vp, _vp, _fp]),
     "odo_tracker_track": (C.c_int, [_vp, _vp, _vp, _fp, _fp, _ip, _fp, _ip]),
     "odo_tracker_hint_next": (C.c_int, [_vp, _vp]),
+    "odo_tracker_hint_next_pair": (C.c_int, [_vp, _vp, _vp]),
     "odo_tracker_stats": (C.c_int, [_vp, _ip, _ip, _ip, _ip]),
     "odo_tracker_outputs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "odo_tracker_time_residual": (C.c_int, [_vp, C.c_int, C.c_int, _fp, _fp, _dp, _ip]),

@@ -510,8 +510,13 @@ class Tracker:
         return dict(pose_to_keyframe=_from_colmajor(T), abs_pose=_from_colmajor(A), new_keyframe=bool(nk.value),
                     motion=mag.value, solve_status=ss.value)
 
-    def hint_next(self, next_left_dev):
-        L.check(self.lib.odo_tracker_hint_next(self.h, next_left_dev), "odo_tracker_hint_next")
+    def hint_next(self, next_left_dev, next_right_dev=None):
+        """Announce the next frame: left image only (pyramid prefetch + early start of the next Solve) or the pair (the depth
+        stream then works a frame ahead as well)."""
+        if next_right_dev is None:
+            L.check(self.lib.odo_tracker_hint_next(self.h, next_left_dev), "odo_tracker_hint_next")
+        else:
+            L.check(self.lib.odo_tracker_hint_next_pair(self.h, next_left_dev, next_right_dev), "odo_tracker_hint_next_pair")
 
     def track_into(self, left_dev, right_dev, pose_to_kf, abs_pose):
         """Lean variant for timing loops: results land in caller-owned float32[16] column-major buffers."""

@@ -238,14 +238,14 @@ static int batch_upload_table(odo_tracker_batch* b, const float* const* left, co
     q.dtoken = d->token;
     d->h_prog[0] = 0; d->h_prog[1] = 0;  // both streams are idle here (every step ends on the completion words)
     int rows_total = 0;
-    m->cand_tag = -1;
+    m->cand[0].tag = -1;
     if (b->with_lists) {
-      if (lm_lists_layout(m, m->cand_pl, m->cand_pl_cap, m->cand_d_rowcnt, m->cand_rows_cap, img, dep, b->ctx_b->stream, &q.kl,
+      if (lm_lists_layout(m, m->cand[0].pl, m->cand[0].pl_cap, m->cand[0].d_rowcnt, m->cand[0].rows_cap, img, dep, b->ctx_b->stream, &q.kl,
                           &rows_total)) return -1;
-      if (rows_total > 0) m->cand_tag = b->frame_id[i];
+      if (rows_total > 0) m->cand[0].tag = b->frame_id[i];
     }
-    q.rowcnt = m->cand_d_rowcnt; q.npts = m->cand_d_npts; q.npts_host = b->d_cand_npts + (size_t)i * ODO_MAX_LEVELS;
-    for (int l = 0; l < ODO_MAX_LEVELS; l++) q.pl[l] = m->cand_pl[l];
+    q.rowcnt = m->cand[0].d_rowcnt; q.npts = m->cand[0].d_npts; q.npts_host = b->d_cand_npts + (size_t)i * ODO_MAX_LEVELS;
+    for (int l = 0; l < ODO_MAX_LEVELS; l++) q.pl[l] = m->cand[0].pl[l];
   }
   hipStream_t sa = b->ctx_a->stream;
   HIP_OK(hipMemcpyAsync(b->d_tab, b->h_tab, sizeof(BatchSeq) * (size_t)n, hipMemcpyHostToDevice, sa));
@@ -365,7 +365,7 @@ static int batch_depth_finish(odo_tracker_batch* b, int* ok) {
 // The candidate lists built for slot i this step become its keyframe lists.
 static void batch_adopt(odo_tracker_batch* b, int i) {
   odo_lm* m = b->lm[i];
-  memcpy(m->cand_h_npts, b->h_cand_npts + (size_t)i * ODO_MAX_LEVELS, sizeof(int) * ODO_MAX_LEVELS);
+  memcpy(m->cand[0].h_npts, b->h_cand_npts + (size_t)i * ODO_MAX_LEVELS, sizeof(int) * ODO_MAX_LEVELS);
   (void)lm_adopt_candidate(m, b->kf_img[i], b->kf_dep[i], b->frame_id[i]);  // 1 = no candidate: the Solve builds the lists
 }
 

@@ -407,6 +407,14 @@ static inline LevelK lm_level_k(const struct odo_lm* m, int level);
 static const odo_intrinsics kKitti00 = {718.856f, (float)607.1928, (float)185.2157};
 constexpr int kLmMaxBlocks = 1280;       // partial rows per buffer: dense scan = 5 blocks per CU
 
+// One set of keyframe-candidate point lists (see odo_lm::cand).
+struct LmCandSet {
+  PointList pl[ODO_MAX_LEVELS];
+  size_t pl_cap[ODO_MAX_LEVELS];
+  int* d_rowcnt; int* d_npts; int* h_npts; int* hm_npts; int rows_cap;
+  long tag;   // caller's tag of the candidate (frame id), -1 = none
+};
+
 // A fused Solve in flight (see lm_fused_begin / odo_lm_solve_begin).
 struct LmJob {
   int active;
@@ -450,10 +458,7 @@ struct odo_lm {
   // A second, identical set of list buffers for the keyframe CANDIDATE of the frame being tracked: the tracker fills it on
   // its depth stream every frame (lm_build_candidate), off the Solve's critical path; when the candidate becomes the
   // keyframe the two sets trade places (lm_adopt_candidate) instead of list-building launches + a read-back in front of the Solve.
-  PointList cand_pl[ODO_MAX_LEVELS];
-  size_t cand_pl_cap[ODO_MAX_LEVELS];
-  int* cand_d_rowcnt; int* cand_d_npts; int* cand_h_npts; int* cand_hm_npts; int cand_rows_cap;
-  long cand_tag;   // caller's tag of the candidate (frame id), -1 = none
+  LmCandSet cand[2];   // two of them: the tracker's depth stream may run a frame ahead of the pose LM (slot = job parity)
   // optional per-launch HIP-event timing of the evaluation kernels (bench.py roofline leg)
   int ev_on;
   std::vector<hipEvent_t>* ev_pool;
@@ -528,10 +533,12 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
   HIP_OK(hipMalloc((void**)&m->d_npts, sizeof(int) * ODO_MAX_LEVELS));
   HIP_OK(hipHostMalloc((void**)&m->h_npts, sizeof(int) * ODO_MAX_LEVELS, hipHostMallocMapped | hipHostMallocCoherent));
   HIP_OK(hipHostGetDevicePointer((void**)&m->hm_npts, m->h_npts, 0));
-  HIP_OK(hipMalloc((void**)&m->cand_d_npts, sizeof(int) * ODO_MAX_LEVELS));
-  HIP_OK(hipHostMalloc((void**)&m->cand_h_npts, sizeof(int) * ODO_MAX_LEVELS, hipHostMallocMapped | hipHostMallocCoherent));
-  HIP_OK(hipHostGetDevicePointer((void**)&m->cand_hm_npts, m->cand_h_npts, 0));
-  m->cand_tag = -1;
+  for (LmCandSet& cs : m->cand) {
+    HIP_OK(hipMalloc((void**)&cs.d_npts, sizeof(int) * ODO_MAX_LEVELS));
+    HIP_OK(hipHostMalloc((void**)&cs.h_npts, sizeof(int) * ODO_MAX_LEVELS, hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_OK(hipHostGetDevicePointer((void**)&cs.hm_npts, cs.h_npts, 0));
+    cs.tag = -1;
+  }
   m->mode = getenv("ODO_LM_MODE") ? atoi(getenv("ODO_LM_MODE")) : 0;
   m->dense_plain_div = getenv("ODO_DENSE_PLAIN_DIV") ? 1 : 0;
   m->fused = getenv("ODO_LM_UNFUSED") ? 0 : 1;
@@ -549,14 +556,16 @@ extern "C" int odo_lm_destroy(odo_lm* m) {
   if (!m) return 0;
   (void)hipStreamSynchronize(m->ctx->stream);
   void* dv[] = {m->d_state, m->d_partials, m->d_init, m->d_out, m->d_trace, m->d_scale, m->d_res,
-                m->d_rowcnt, m->d_npts, m->cand_d_rowcnt, m->cand_d_npts};
+                m->d_rowcnt, m->d_npts, m->cand[0].d_rowcnt, m->cand[0].d_npts, m->cand[1].d_rowcnt, m->cand[1].d_npts};
   for (void* q : dv) if (q) (void)hipFree(q);
   for (int l = 0; l < ODO_MAX_LEVELS; l++) {
-    void* pv[] = {m->pl[l].a, m->pl[l].b, m->pl[l].c, m->pl[l].d, m->cand_pl[l].a, m->cand_pl[l].b, m->cand_pl[l].c, m->cand_pl[l].d};
+    void* pv[] = {m->pl[l].a, m->pl[l].b, m->pl[l].c, m->pl[l].d, m->cand[0].pl[l].a, m->cand[0].pl[l].b, m->cand[0].pl[l].c, m->cand[0].pl[l].d,
+                  m->cand[1].pl[l].a, m->cand[1].pl[l].b, m->cand[1].pl[l].c, m->cand[1].pl[l].d};
     for (void* q : pv) if (q) (void)hipFree(q);
   }
   (void)hipHostFree(m->h_npts);
-  (void)hipHostFree(m->cand_h_npts);
+  (void)hipHostFree(m->cand[0].h_npts);
+  (void)hipHostFree(m->cand[1].h_npts);
   if (m->ev_pool) { for (auto& e : *m->ev_pool) (void)hipEventDestroy(e); delete m->ev_pool; }
   (void)hipHostFree(m->h_out); (void)hipHostFree(m->h_trace); (void)hipHostFree(m->h_prog); (void)hipHostFree(m->h_res); (void)hipHostFree(m->h_done);
   delete m;
@@ -703,24 +712,25 @@ static int lm_prepare_keyframe(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* 
 
 // Candidate lists (see odo_lm::cand_pl): enqueue on stream `s` (the tracker's depth stream); `img` holds the frame's image
 // pyramid, `dep` its freshly estimated depth pyramid. The counts are valid once `s` has drained past this point.
-static int lm_build_candidate(odo_lm* m, const odo_pyr* img, const odo_pyr* dep, hipStream_t s, long tag) {
-  m->cand_tag = -1;
+static int lm_build_candidate(odo_lm* m, const odo_pyr* img, const odo_pyr* dep, hipStream_t s, long tag, int slot = 0) {
+  LmCandSet& cs = m->cand[slot];
+  cs.tag = -1;
   if (m->mode == 1) return 0;
   int rows_total = 0;
-  if (lm_enqueue_lists(m, m->cand_pl, m->cand_pl_cap, m->cand_d_rowcnt, m->cand_rows_cap, m->cand_hm_npts, img, dep, s,
-                       &rows_total)) return -1;
-  if (rows_total > 0) m->cand_tag = tag;
+  if (lm_enqueue_lists(m, cs.pl, cs.pl_cap, cs.d_rowcnt, cs.rows_cap, cs.hm_npts, img, dep, s, &rows_total)) return -1;
+  if (rows_total > 0) cs.tag = tag;
   return 0;
 }
 
-// The candidate tagged `tag` has become the keyframe (kf_img / kf_dep are its pyramids, the stream that built the lists
-// has drained): trade the two list sets. Returns 0 when adopted, 1 when there was no such candidate (the next Solve then
-// builds the lists itself).
-static int lm_adopt_candidate(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, long tag) {
-  if (m->mode == 1 || m->cand_tag < 0 || m->cand_tag != tag) return 1;
-  for (int l = 0; l < ODO_MAX_LEVELS; l++) { std::swap(m->pl[l], m->cand_pl[l]); std::swap(m->pl_cap[l], m->cand_pl_cap[l]); }
-  std::swap(m->d_rowcnt, m->cand_d_rowcnt); std::swap(m->rows_cap, m->cand_rows_cap);
-  std::swap(m->d_npts, m->cand_d_npts); std::swap(m->h_npts, m->cand_h_npts); std::swap(m->hm_npts, m->cand_hm_npts);
+// The candidate tagged `tag` (in set `slot`) has become the keyframe (kf_img / kf_dep are its pyramids, the stream that built
+// the lists has drained): trade the two list sets. Returns 0 when adopted, 1 when there was no such candidate (the next
+// Solve then builds the lists itself).
+static int lm_adopt_candidate(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, long tag, int slot = 0) {
+  LmCandSet& cs = m->cand[slot];
+  if (m->mode == 1 || cs.tag < 0 || cs.tag != tag) return 1;
+  for (int l = 0; l < ODO_MAX_LEVELS; l++) { std::swap(m->pl[l], cs.pl[l]); std::swap(m->pl_cap[l], cs.pl_cap[l]); }
+  std::swap(m->d_rowcnt, cs.d_rowcnt); std::swap(m->rows_cap, cs.rows_cap);
+  std::swap(m->d_npts, cs.d_npts); std::swap(m->h_npts, cs.h_npts); std::swap(m->hm_npts, cs.hm_npts);
   int rows_total = 0;
   for (int l = 0; l < m->n_levels; l++) {
     const int ir = kf_img->r[l] - 8, ic = kf_img->c[l] - 8;
@@ -729,7 +739,7 @@ static int lm_adopt_candidate(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* k
   lm_take_counts(m, m->h_npts, kf_img, rows_total);
   m->kf_img_ver = kf_img->version;
   m->kf_dep_ver = kf_dep->version;
-  m->cand_tag = -1;
+  cs.tag = -1;
   return 0;
 }
 

@@ -3,6 +3,26 @@
 // Included by odometry_hip.hip after the pyramid / LM / depth objects are defined.
 #pragma once
 
+// One frame's stream-B work: ComputeDepth of the pair, the depth pyramid, the keyframe-candidate point lists. Two of them
+// exist (slot 0 / 1, each with its own outputs) so that the depth stream can work on the NEXT frame while the pose LM is
+// still on this one (odo_tracker_hint_next_pair).
+struct TrackerJob {
+  const float *left, *right;
+  odo_pyr* img;           // the frame's image pyramid (source of the candidate lists)
+  hipEvent_t img_ready;   // event after which `img` is complete (stream A: ev_cur_img, stream C: ev_next)
+  int slot;
+  long tag;               // frame id (tags the candidate lists)
+  int with_lists;
+  // progress (the thread that runs the job)
+  DepthJob dj;
+  int stage;              // 0 idle, 1 depth launches in flight, 3 all enqueued
+  int err;
+  // result
+  int rc;
+  char msg[256];
+  DepthLmStats stats;
+};
+
 struct odo_tracker {
   odo_tracker_params p;
   odo_ctx* ctx_a;  // pyramids of the incoming frame + pose LM
@@ -10,38 +30,39 @@ struct odo_tracker {
   odo_ctx* ctx_c;  // the NEXT frame's image pyramid when the next Solve starts early (a stream of its own: it delays neither chain)
   odo_lm* lm;
   odo_depth* depth;
-  odo_pyr *kf_img, *kf_dep, *cur_img, *pre_img, *pre_dep, *next_img;
+  odo_pyr *kf_img, *kf_dep, *cur_img, *pre_img, *next_img;
+  odo_pyr* pre_dep[2];         // per job slot
   const float* hint_next;      // device image the caller announced as the next frame (odo_tracker_hint_next)
+  const float* hint_next_right;  // its right image (odo_tracker_hint_next_pair), NULL: left only
   const float* prefetched;     // image whose pyramid already sits in next_img
-  uint8_t* d_val;
-  float *d_disp, *d_dep;
+  uint8_t* d_val[2];           // per job slot
+  float *d_disp[2], *d_dep[2];
+  int out_slot;                // slot that holds the last tracked frame's outputs
   float kf_abs[16];
   float pose_to_kf[16];
   int n_keyframes, frame_id;
   int last_evals, last_depth_iters, last_valid;
   hipEvent_t ev_inputs;
   hipEvent_t ev_cur_img;  // stream A: the current frame's image pyramid is complete (stream B reads it for the candidate lists)
-  DepthJob job;
-  int job_stage;  // 0 idle, 1 depth launches in flight, 2 depth tail enqueued (pyramids next), 3 all enqueued
-  int job_err;
+  TrackerJob jobs[2];
+  TrackerJob* cur_job;    // job the calling thread is pumping (overlap_depth 0 / 1)
   double tm_solve_us, tm_depth_us, tm_frame_us, tm_wait_us; long tm_frames;  // host-clock averages (diagnostics)
-  int pre_img_on_a;  // 1: the frame's second image pyramid (:251) is built on stream A after the Solve
   int cand_lists;    // 1: keyframe-candidate point lists are built every frame on stream B (ODO_NO_CAND_LISTS=1 turns it off)
   // overlap_depth == 2: a helper host thread feeds stream B (ComputeDepth + candidate pyramids) while the calling
   // thread feeds stream A (pose LM). Host launch rate, not the GPU, bounds a latency-bound frame loop.
+  // Jobs go through a two-entry ring: job n lives in jobs[n & 1]; the caller posts (w_posted++), the helper runs them in order
+  // (w_done++). At most two are outstanding: this frame's and, when the next pair was announced, the next frame's.
   std::thread worker;
-  std::atomic<int> w_state;  // 0 idle, 1 job requested, 2 job done
-  std::atomic<int> w_quit;   // 1: the worker leaves its loop once it is not running a job (never overwritten by the worker)
-  const float *w_left, *w_right;
-  int w_rc;
-  char w_err[256];
+  std::atomic<long> w_posted, w_done;
+  std::atomic<int> w_quit;   // 1: the worker leaves its loop once the ring is empty
+  long ahead_job;            // index of the job already posted for the NEXT frame, -1: none
   // Early start of the next Solve (overlap_depth != 0, next frame announced with odo_tracker_hint_next): the next frame's
   // pyramid is built on a third stream at the start of the call, and as soon as this frame's Solve has returned — initial pose and
   // keyframe decision are known then — the next Solve's launches go out on the LM stream while the depth stream finishes and
   // the host does its bookkeeping (odo_lm_solve_begin). Same launches, earlier; ODO_NO_EARLY_SOLVE=1 turns it off.
   int early_solve;
+  int depth_ahead;           // 1: with the next PAIR announced, the next frame's stream-B job is posted a frame early (ODO_NO_DEPTH_AHEAD=1: off)
   hipEvent_t ev_next;        // stream C: next_img is complete
-  int skip_pre_img;          // 1 while tracking: the :251 rebuild of the frame's image pyramid is the :205 pyramid itself
 };
 
 static void tracker_worker_main(odo_tracker* t);
@@ -80,11 +101,13 @@ extern "C" int odo_tracker_destroy(odo_tracker* t) {
   if (t->ctx_c) (void)hipStreamSynchronize(t->ctx_c->stream);
   odo_lm_destroy(t->lm);
   odo_depth_destroy(t->depth);
-  odo_pyr* ps[] = {t->kf_img, t->kf_dep, t->cur_img, t->pre_img, t->pre_dep, t->next_img};
+  odo_pyr* ps[] = {t->kf_img, t->kf_dep, t->cur_img, t->pre_img, t->pre_dep[0], t->pre_dep[1], t->next_img};
   for (odo_pyr* q : ps) odo_pyramid_destroy(q);
-  if (t->d_val) (void)hipFree(t->d_val);
-  if (t->d_disp) (void)hipFree(t->d_disp);
-  if (t->d_dep) (void)hipFree(t->d_dep);
+  for (int k = 0; k < 2; k++) {
+    if (t->d_val[k]) (void)hipFree(t->d_val[k]);
+    if (t->d_disp[k]) (void)hipFree(t->d_disp[k]);
+    if (t->d_dep[k]) (void)hipFree(t->d_dep[k]);
+  }
   if (t->ev_inputs) (void)hipEventDestroy(t->ev_inputs);
   if (t->ev_cur_img) (void)hipEventDestroy(t->ev_cur_img);
   if (t->ev_next) (void)hipEventDestroy(t->ev_next);
@@ -101,16 +124,22 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
   odo_tracker* t = new (std::nothrow) odo_tracker();
   if (!t) return fail("out of memory");
   t->ctx_a = t->ctx_b = t->ctx_c = nullptr; t->lm = nullptr; t->depth = nullptr;
-  t->kf_img = t->kf_dep = t->cur_img = t->pre_img = t->pre_dep = t->next_img = nullptr;
-  t->hint_next = t->prefetched = nullptr;
-  t->d_val = nullptr; t->d_disp = t->d_dep = nullptr; t->ev_inputs = nullptr; t->ev_cur_img = nullptr;
+  t->kf_img = t->kf_dep = t->cur_img = t->pre_img = t->next_img = nullptr;
+  t->hint_next = t->hint_next_right = t->prefetched = nullptr;
+  for (int k = 0; k < 2; k++) {
+    t->pre_dep[k] = nullptr; t->d_val[k] = nullptr; t->d_disp[k] = t->d_dep[k] = nullptr;
+    memset(&t->jobs[k], 0, sizeof(TrackerJob));
+    t->jobs[k].slot = k;
+  }
+  t->cur_job = nullptr; t->out_slot = 0; t->ahead_job = -1;
+  t->ev_inputs = nullptr; t->ev_cur_img = nullptr;
   t->n_keyframes = t->frame_id = t->last_evals = t->last_depth_iters = t->last_valid = 0;
-  t->job_stage = t->job_err = 0; t->pre_img_on_a = 0;
   t->cand_lists = getenv("ODO_NO_CAND_LISTS") ? 0 : 1;
   t->tm_solve_us = t->tm_depth_us = t->tm_frame_us = t->tm_wait_us = 0.0; t->tm_frames = 0;
-  t->w_state.store(0); t->w_quit.store(0); t->w_left = t->w_right = nullptr; t->w_rc = 0; t->w_err[0] = 0;
-  t->ev_next = nullptr; t->skip_pre_img = 0;
+  t->w_posted.store(0); t->w_done.store(0); t->w_quit.store(0);
+  t->ev_next = nullptr;
   t->early_solve = getenv("ODO_NO_EARLY_SOLVE") ? 0 : 1;
+  t->depth_ahead = getenv("ODO_NO_DEPTH_AHEAD") ? 0 : 1;
   t->p = *p;
   float eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   memcpy(t->pose_to_kf, eye, sizeof(eye));
@@ -133,9 +162,11 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
   ok = ok && pyr_alloc(t->ctx_b, p->rows, p->cols, p->levels, ODO_PYR_IMAGE, &t->kf_img, false) == 0;
   ok = ok && pyr_alloc(t->ctx_b, p->rows, p->cols, p->levels, ODO_PYR_DEPTH, &t->kf_dep, false) == 0;
   ok = ok && pyr_alloc(t->ctx_b, p->rows, p->cols, p->levels, ODO_PYR_IMAGE, &t->pre_img, false) == 0;
-  ok = ok && pyr_alloc(t->ctx_b, p->rows, p->cols, p->levels, ODO_PYR_DEPTH, &t->pre_dep, false) == 0;
-  ok = ok && hipMalloc((void**)&t->d_val, n) == hipSuccess && hipMalloc((void**)&t->d_disp, sizeof(float) * n) == hipSuccess &&
-       hipMalloc((void**)&t->d_dep, sizeof(float) * n) == hipSuccess;
+  for (int k = 0; k < 2; k++) {
+    ok = ok && pyr_alloc(t->ctx_b, p->rows, p->cols, p->levels, ODO_PYR_DEPTH, &t->pre_dep[k], false) == 0;
+    ok = ok && hipMalloc((void**)&t->d_val[k], n) == hipSuccess && hipMalloc((void**)&t->d_disp[k], sizeof(float) * n) == hipSuccess &&
+         hipMalloc((void**)&t->d_dep[k], sizeof(float) * n) == hipSuccess;
+  }
   ok = ok && hipEventCreateWithFlags(&t->ev_inputs, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&t->ev_cur_img, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&t->ev_next, hipEventDisableTiming) == hipSuccess;
@@ -152,35 +183,41 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
 
 // ComputeDepth of the pair and the frame's keyframe-candidate pyramids, all on stream B (ref: :226-252), as a
 // resumable job: begin enqueues the front, pump issues one more launch when the device is ready for it.
-static int tracker_job_begin(odo_tracker* t, const float* left, const float* right) {
+static int tracker_job_begin(odo_tracker* t, TrackerJob* j) {
   const odo_tracker_params& p = t->p;
-  t->job_err = 0;
+  j->err = 0;
   if (depth_check_size(t->depth, p.rows, p.cols)) return -1;
   if (depth_ensure(t->depth, p.rows, p.cols)) return -1;
-  if (depth_job_begin(t->depth, &t->job, left, right, p.rows, p.cols, t->d_val, t->d_disp, t->d_dep, 2)) return -1;
-  t->job_stage = 1;
+  if (depth_job_begin(t->depth, &j->dj, j->left, j->right, p.rows, p.cols, t->d_val[j->slot], t->d_disp[j->slot], t->d_dep[j->slot], 2))
+    return -1;
+  j->stage = 1;
   return 0;
+}
+static void tracker_job_pump_one(odo_tracker* t, TrackerJob* j) {
+  if (j->stage != 1) return;
+  const int r = depth_job_pump(t->depth, &j->dj);
+  if (r < 0) { j->err = 1; j->stage = 3; return; }
+  if (r > 0) {
+    const odo_tracker_params& p = t->p;
+    if (!j->img && pyr_build(t->pre_img, j->left, p.smooth_image)) j->err = 1;  // :130 (frame 0 only: see odo_tracker_track for :251)
+    if (pyr_build(t->pre_dep[j->slot], t->d_dep[j->slot], 0)) j->err = 1;                                  // :252
+    // This frame may become the next keyframe (:258-265): compact its valid-depth pixels into point lists now, on this
+    // stream, beside the Solve — the image pyramid is the one built for the frame's Solve (same image, same arithmetic
+    // as the :251 rebuild). If the frame is not promoted the lists are simply overwritten two frames later.
+    if (j->with_lists) {
+      if (hipStreamWaitEvent(t->ctx_b->stream, j->img_ready, 0) != hipSuccess ||
+          lm_build_candidate(t->lm, j->img, t->pre_dep[j->slot], t->ctx_b->stream, j->tag, j->slot))
+        t->lm->cand[j->slot].tag = -1;
+    } else {
+      t->lm->cand[j->slot].tag = -1;
+    }
+    if (depth_job_stats(t->depth, &j->dj)) j->err = 1;  // completion word AFTER the pyramids: it covers them too
+    j->stage = 3;
+  }
 }
 static void tracker_job_pump(void* arg) {
   odo_tracker* t = (odo_tracker*)arg;
-  if (t->job_stage != 1) return;
-  const int r = depth_job_pump(t->depth, &t->job);
-  if (r < 0) { t->job_err = 1; t->job_stage = 3; return; }
-  if (r > 0) {
-    const odo_tracker_params& p = t->p;
-    if (!t->skip_pre_img && !t->pre_img_on_a && pyr_build(t->pre_img, t->job.left, p.smooth_image)) t->job_err = 1;  // :251
-    if (pyr_build(t->pre_dep, t->d_dep, 0)) t->job_err = 1;                   // :252
-    // This frame may become the next keyframe (:258-265): compact its valid-depth pixels into point lists now, on this
-    // stream, beside the Solve — the image pyramid is the one stream A built for the frame (same image, same arithmetic
-    // as the :251 rebuild). If the frame is not promoted the lists are simply overwritten by the next frame's.
-    if (t->cand_lists) {
-      if (hipStreamWaitEvent(t->ctx_b->stream, t->ev_cur_img, 0) != hipSuccess ||
-          lm_build_candidate(t->lm, t->cur_img, t->pre_dep, t->ctx_b->stream, (long)t->frame_id))
-        t->lm->cand_tag = -1;
-    }
-    if (depth_job_stats(t->depth, &t->job)) t->job_err = 1;  // completion word AFTER the pyramids: it covers them too
-    t->job_stage = 3;
-  }
+  if (t->cur_job) tracker_job_pump_one(t, t->cur_job);
 }
 // The NEXT frame's image pyramid (ref: :205 of the next iteration) on a stream of its own, enqueued at the start of this
 // frame's call: complete long before this frame's Solve ends, so the next Solve can start the moment it does.
@@ -190,23 +227,34 @@ static int tracker_next_pyramid(odo_tracker* t, const float* next_left) {
   HIP_OK(hipEventRecord(t->ev_next, t->ctx_c->stream));
   return 0;
 }
-static int tracker_job_drain(odo_tracker* t) {
-  while (t->job_stage == 1) tracker_job_pump(t);
-  t->job_stage = 0;
-  return t->job_err ? -1 : 0;
+static int tracker_job_drain(odo_tracker* t, TrackerJob* j) {
+  while (j->stage == 1) tracker_job_pump_one(t, j);
+  j->stage = 0;
+  return j->err ? -1 : 0;
 }
-static int tracker_depth_and_pyramids(odo_tracker* t, const float* left, const float* right) {
-  if (tracker_job_begin(t, left, right)) return -1;
-  return tracker_job_drain(t);
+// Whole job on the calling thread: launches, then the wait for its completion word (or a full sync) and its statistics.
+static int tracker_job_run(odo_tracker* t, TrackerJob* j, bool full_sync) {
+  int rc = tracker_job_begin(t, j);
+  if (rc == 0) rc = tracker_job_drain(t, j);
+  if (rc == 0) rc = depth_finish(t->depth, full_sync);
+  j->stats = t->depth->last;
+  j->rc = rc;
+  if (rc) snprintf(j->msg, sizeof(j->msg), "%s", g_err);
+  return rc;
+}
+static void tracker_job_fill(odo_tracker* t, TrackerJob* j, const float* left, const float* right, odo_pyr* img, hipEvent_t img_ready,
+                             long tag, int with_lists) {
+  j->left = left; j->right = right; j->img = img; j->img_ready = img_ready; j->tag = tag; j->with_lists = with_lists;
+  j->stage = 0; j->err = 0; j->rc = 0; j->msg[0] = 0;
 }
 
-// Helper thread (overlap_depth == 2): runs the whole stream-B job of a frame, including its final stream sync.
+// Helper thread (overlap_depth == 2): runs the stream-B jobs of the ring in order, each up to its completion word.
 static void tracker_worker_main(odo_tracker* t) {
   (void)hipSetDevice(t->ctx_b->device);
   int idle_spins = 0;
   for (;;) {
-    const int st = t->w_state.load(std::memory_order_acquire);
-    if (st != 1) {
+    const long done = t->w_done.load(std::memory_order_relaxed);
+    if (t->w_posted.load(std::memory_order_acquire) <= done) {
       if (t->w_quit.load(std::memory_order_acquire)) return;
       // Spin while a sequence is being tracked (the next job arrives within a fraction of a millisecond and a
       // sleeping thread wakes ~100 us late); back off only after ~10 ms without work.
@@ -215,46 +263,63 @@ static void tracker_worker_main(odo_tracker* t) {
     }
     idle_spins = 0;
     const auto w0 = std::chrono::steady_clock::now();
-    int rc = tracker_depth_and_pyramids(t, t->w_left, t->w_right);
-    if (rc == 0) rc = depth_finish(t->depth, false);
+    (void)tracker_job_run(t, &t->jobs[done & 1], false);
     t->tm_depth_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
-    t->w_rc = rc;
-    if (rc) snprintf(t->w_err, sizeof(t->w_err), "%s", g_err);
-    t->w_state.store(2, std::memory_order_release);
+    t->w_done.store(done + 1, std::memory_order_release);
   }
+}
+
+// Waits until job `index` of the ring has been run. Bounded: a job is ~0.2 ms of launches plus the depth LM; after 5 s the
+// worker is presumed stuck behind a lost device (the tracker stays destroyable: odo_tracker_destroy joins the worker whenever
+// it comes back).
+static int tracker_wait_job(odo_tracker* t, long index) {
+  const auto q0 = std::chrono::steady_clock::now();
+  long spins = 0;
+  while (t->w_done.load(std::memory_order_acquire) <= index) {
+    if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - q0 > std::chrono::seconds(5))
+      return fail("    depth failed! (the depth stream's helper thread did not finish within 5 s)");
+  }
+  t->tm_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - q0).count();
+  return 0;
+}
+static int tracker_wait_idle(odo_tracker* t) {
+  const long posted = t->w_posted.load(std::memory_order_acquire);
+  return posted > 0 ? tracker_wait_job(t, posted - 1) : 0;
 }
 
 extern "C" int odo_tracker_init(odo_tracker* t, const float* left, const float* right, const float abs_pose0[16]) {
   if (!t || !left || !right || !abs_pose0) return fail("odo_tracker_init: NULL arg");
   HIP_OK(hipSetDevice(t->ctx_a->device));
-  // Re-initialisation of a tracker that has been tracking: the tail of the last frame (its keyframe-candidate pyramid,
-  // a prefetched next pyramid, straggling LM launches) may still be running on stream A, and track() had moved the
-  // candidate image pyramid to that stream. Start from a quiet device and build everything on stream B again.
+  // Re-initialisation of a tracker that has been tracking: a job posted ahead for the previous sequence's next frame, the
+  // tail of the last frame (a prefetched next pyramid, straggling LM launches, an early Solve) may still be running.
+  // Start from an idle helper thread and a quiet device and build everything on stream B again.
+  if (tracker_wait_idle(t)) return -1;
+  t->ahead_job = -1;
   HIP_OK(hipStreamSynchronize(t->ctx_a->stream));
   HIP_OK(hipStreamSynchronize(t->ctx_b->stream));
   HIP_OK(hipStreamSynchronize(t->ctx_c->stream));
-  t->pre_img_on_a = 0;
-  t->skip_pre_img = 0;
   t->lm->job.active = 0;                   // a Solve started early for the previous sequence's next frame is dropped
   t->pre_img->ctx = t->ctx_b;
-  t->prefetched = t->hint_next = nullptr;  // a pyramid prefetched for the previous sequence is not this sequence's frame
-  const int cand_keep = t->cand_lists;
-  t->cand_lists = 0;            // frame 0 has no stream-A pyramid: the first Solve builds the keyframe lists itself
-  t->lm->cand_tag = -1;
-  const int init_rc = tracker_depth_and_pyramids(t, left, right);   // :102, :130-131
-  t->cand_lists = cand_keep;
-  if (init_rc) return -1;
-  if (depth_finish(t->depth, true)) { fail("Init 0-th frame failed!"); return -1; }  // :103-106
+  t->prefetched = t->hint_next = t->hint_next_right = nullptr;  // announcements made for the previous sequence are void
+  t->lm->cand[0].tag = t->lm->cand[1].tag = -1;
+  TrackerJob* j = &t->jobs[0];
+  // frame 0 has no Solve pyramid: the first Solve builds the keyframe lists itself (with_lists = 0)
+  tracker_job_fill(t, j, left, right, nullptr, nullptr, 0, 0);
+  if (tracker_job_run(t, j, true)) {                            // :102, :130-131
+    if (t->depth->last.status != 0) fail("Init 0-th frame failed!");   // :103-106
+    return -1;
+  }
   std::swap(t->kf_img, t->pre_img);                             // :141 first keyframe
-  std::swap(t->kf_dep, t->pre_dep);
+  std::swap(t->kf_dep, t->pre_dep[0]);
+  t->out_slot = 0;
   memcpy(t->kf_abs, abs_pose0, sizeof(float) * 16);             // :143
   memcpy(t->pose_to_kf, abs_pose0, sizeof(float) * 16);         // :98 pose_to_keyframe = cur_pose
   float eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   odo_lm_reset(t->lm, eye, t->p.lm_lambda);                     // :77-81 init_relative_affine = I
   t->n_keyframes = 1;
   t->frame_id = 0;
-  t->last_valid = t->depth->last.n_valid;
-  t->last_depth_iters = t->depth->last.iters;
+  t->last_valid = j->stats.n_valid;
+  t->last_depth_iters = j->stats.iters;
   return 0;
 }
 
@@ -294,22 +359,6 @@ static void motion_angles(const float* T, float ang[3]) {
   ang[2] = atan2f(R[3] - R[1], R[0] + R[4]);
 }
 
-// Waits for the helper thread's job of this frame and takes its result. Bounded: the job is ~0.2 ms of launches plus the
-// depth LM; after 5 s the worker is presumed stuck behind a lost device and the frame fails (the tracker stays destroyable:
-// odo_tracker_destroy joins the worker whenever it comes back).
-static int tracker_wait_worker(odo_tracker* t) {
-  const auto q0 = std::chrono::steady_clock::now();
-  long spins = 0;
-  while (t->w_state.load(std::memory_order_acquire) != 2) {
-    if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - q0 > std::chrono::seconds(5))
-      return fail("    depth failed! (the depth stream's helper thread did not finish within 5 s)");
-  }
-  t->tm_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - q0).count();
-  t->w_state.store(0, std::memory_order_release);
-  if (t->w_rc) return fail("    depth failed! (%s)", t->w_err);                             // :230-232
-  return 0;
-}
-
 extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float* right, float pose_to_keyframe[16],
                                  float abs_pose[16], int* is_new_keyframe, float* motion_mag, int* solve_status) {
   if (!t || !left || !right) return fail("odo_tracker_track: NULL arg");
@@ -317,43 +366,65 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
   const auto f0 = std::chrono::steady_clock::now();
   HIP_OK(hipSetDevice(t->ctx_a->device));
   t->frame_id++;
-  t->skip_pre_img = 1;     // :251 rebuilds the pyramid :205 built from the same image: bit-identical, so a promoted frame's
-  t->pre_img_on_a = 0;     // :205 pyramid becomes the keyframe pyramid (buffer swap below) and no second build is launched
-  if (t->prefetched == left) {
+  // :251 rebuilds the pyramid :205 built from the same image: bit-identical, so a promoted frame's :205 pyramid becomes the
+  // keyframe pyramid (buffer swap below) and no second build is launched.
+  const bool had_prefetch = t->prefetched == left;
+  if (had_prefetch) {
     std::swap(t->cur_img, t->next_img);  // :205 — this frame's pyramid was built during the last call
   } else {
     t->lm->job.active = 0;               // an early Solve (if any) was started on another image
     t->cur_img->ctx = t->ctx_a;
     if (pyr_build(t->cur_img, left, p.smooth_image)) return -1;                        // :205
+    if (t->cand_lists) HIP_OK(hipEventRecord(t->ev_cur_img, t->ctx_a->stream));  // before the stream-B job can ask for it
   }
   t->prefetched = nullptr;
-  if (t->cand_lists) HIP_OK(hipEventRecord(t->ev_cur_img, t->ctx_a->stream));  // before the stream-B job can ask for it
-  // The next frame's pyramid is enqueued on stream C right away when the next Solve may start early; otherwise it is built
-  // on stream A behind this frame's Solve (overlap_depth == 0, or ODO_NO_EARLY_SOLVE).
   const float* next_left = t->hint_next;
-  t->hint_next = nullptr;
+  const float* next_right = t->hint_next_right;
+  t->hint_next = t->hint_next_right = nullptr;
   const bool early = t->early_solve && p.overlap_depth != 0 && next_left != nullptr;
-  bool job_posted = false;
+  const bool ahead = early && t->depth_ahead && p.overlap_depth == 2 && next_right != nullptr;
+  // ---- this frame's stream-B job: posted a frame ago (the pair was announced), or now
+  long my_job = -1;          // ring index (overlap_depth == 2)
+  TrackerJob* jk = nullptr;
   if (p.overlap_depth == 2) {
-    // helper thread: the whole stream-B job (ComputeDepth, candidate pyramids, final sync) runs beside this thread
-    t->w_left = left; t->w_right = right;
-    t->w_state.store(1, std::memory_order_release);
-    job_posted = true;
+    if (t->ahead_job >= 0) {
+      TrackerJob* ja = &t->jobs[t->ahead_job & 1];
+      if (had_prefetch && ja->left == left && ja->right == right) {
+        my_job = t->ahead_job;
+        jk = ja;
+      } else if (tracker_wait_idle(t)) {   // announced one pair, given another: let the stale job finish, its outputs are dropped
+        return -1;
+      }
+      t->ahead_job = -1;
+    }
+    if (my_job < 0) {
+      my_job = t->w_posted.load(std::memory_order_relaxed);
+      jk = &t->jobs[my_job & 1];
+      tracker_job_fill(t, jk, left, right, t->cur_img, had_prefetch ? t->ev_next : t->ev_cur_img, (long)t->frame_id, t->cand_lists);
+      t->w_posted.store(my_job + 1, std::memory_order_release);
+    }
+  } else {
+    jk = &t->jobs[0];
+    tracker_job_fill(t, jk, left, right, t->cur_img, had_prefetch ? t->ev_next : t->ev_cur_img, (long)t->frame_id, t->cand_lists);
   }
-  // Every return below this point first collects the posted job: the worker must never be left with a finished job
-  // nobody takes (its "done" would sit in w_state for ever and the next frame would read a stale result).
-  struct JobGuard {
-    odo_tracker* t; bool* posted;
-    ~JobGuard() { if (*posted) { char keep[512]; snprintf(keep, sizeof(keep), "%s", g_err); (void)tracker_wait_worker(t); snprintf(g_err, sizeof(g_err), "%s", keep); } }
-  } job_guard{t, &job_posted};
   if (p.overlap_depth == 1) {
     // stream B: ComputeDepth + candidate pyramids, concurrent with the Solve on stream A. The front of the job is
     // enqueued now; its depth-LM launches are issued from the pose LM's wait loop (one host thread feeds both).
-    if (tracker_job_begin(t, left, right)) return -1;
+    if (tracker_job_begin(t, jk)) return -1;
+    t->cur_job = jk;
     t->lm->idle_pump = tracker_job_pump;
     t->lm->idle_arg = t;
   }
-  if (early && tracker_next_pyramid(t, next_left)) return -1;   // stream C, beside both chains
+  // ---- the next frame: its pyramid on stream C right away; with the pair announced its stream-B job goes into the ring too
+  // (the helper runs it as soon as it is done with this frame's: the depth stream works a frame ahead of the pose LM)
+  if (early && tracker_next_pyramid(t, next_left)) return -1;
+  if (ahead) {
+    const long n = t->w_posted.load(std::memory_order_relaxed);
+    TrackerJob* ja = &t->jobs[n & 1];   // the other slot: this frame's job is n - 1 (or done long ago)
+    tracker_job_fill(t, ja, next_left, next_right, t->next_img, t->ev_next, (long)t->frame_id + 1, t->cand_lists);
+    t->w_posted.store(n + 1, std::memory_order_release);
+    t->ahead_job = n;
+  }
   float T[16];
   const auto s0 = std::chrono::steady_clock::now();
   const int st = odo_lm_solve(t->lm, t->kf_img, t->kf_dep, t->cur_img, T);             // :215 (collects an early start)
@@ -365,6 +436,7 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
     // the idle stream A, instead of at the head of the next call where the Solve would wait for it.
     t->next_img->ctx = t->ctx_a;
     if (pyr_build(t->next_img, next_left, p.smooth_image)) return -1;
+    HIP_OK(hipEventRecord(t->ev_next, t->ctx_a->stream));
   }
   if (next_left) t->prefetched = next_left;
   // :218 — the runner stores the frame's pose BEFORE it computes the depth (:215-232): a frame whose ComputeDepth fails
@@ -397,25 +469,33 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
     reset_done = true;
     if (start_next_solve() < 0) return -1;
   }
+  // ---- collect this frame's stream-B job
   if (p.overlap_depth == 2) {
-    job_posted = false;   // collected here, not by the guard
-    if (tracker_wait_worker(t)) { t->lm->job.active = 0; return -1; }                  // :230-232
+    if (tracker_wait_job(t, my_job)) { t->lm->job.active = 0; return -1; }
   } else {
     if (p.overlap_depth == 1) {
-      if (tracker_job_drain(t)) { t->lm->job.active = 0; return -1; }
+      int rc = tracker_job_drain(t, jk);
+      t->cur_job = nullptr;
+      if (rc == 0) rc = depth_finish(t->depth, false);
+      jk->stats = t->depth->last;
+      jk->rc = rc;
+      if (rc) snprintf(jk->msg, sizeof(jk->msg), "%s", g_err);
     } else {
-      if (tracker_depth_and_pyramids(t, left, right)) return -1;                       // :226-252 in program order
+      (void)tracker_job_run(t, jk, false);                                             // :226-252 in program order
     }
-    if (depth_finish(t->depth, false)) { t->lm->job.active = 0; fail("    depth failed!"); return -1; }  // :230-232
   }
+  t->out_slot = jk->slot;
+  t->last_depth_iters = jk->stats.iters;
+  t->last_valid = jk->stats.n_valid;
+  if (jk->rc) { t->lm->job.active = 0; return fail("    depth failed! (%s)", jk->msg); }   // :230-232
   int new_kf = 0;
   if (promote) {
     std::swap(t->kf_img, t->cur_img);                                                  // :259 (the :251 rebuild == the :205 pyramid)
-    std::swap(t->kf_dep, t->pre_dep);
+    std::swap(t->kf_dep, t->pre_dep[jk->slot]);
     memcpy(t->kf_abs, cur, sizeof(cur));                                               // :260
     t->n_keyframes++;
     new_kf = 1;
-    if (t->cand_lists) lm_adopt_candidate(t->lm, t->kf_img, t->kf_dep, (long)t->frame_id);  // lists built beside the Solve
+    if (t->cand_lists) lm_adopt_candidate(t->lm, t->kf_img, t->kf_dep, (long)t->frame_id, jk->slot);  // lists built beside the Solve
   }
   if (!reset_done) odo_lm_reset(t->lm, T, 0.01f);                                      // :261 / :268 (both branches)
   if (early && promote && start_next_solve() < 0) return -1;   // against the new keyframe, as soon as its lists are adopted
@@ -425,8 +505,6 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
   if (motion_mag) *motion_mag = mag;
   if (solve_status) *solve_status = st;
   t->last_evals = t->lm->last_evals;
-  t->last_depth_iters = t->depth->last.iters;
-  t->last_valid = t->depth->last.n_valid;
   t->tm_frame_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - f0).count();
   t->tm_frames++;
   return 0;
@@ -446,6 +524,15 @@ extern "C" int odo_tracker_timing(odo_tracker* t, double out[4]) {
 extern "C" int odo_tracker_hint_next(odo_tracker* t, const float* next_left_dev) {
   if (!t) return fail("NULL tracker");
   t->hint_next = next_left_dev;
+  t->hint_next_right = nullptr;
+  return 0;
+}
+// The same with the right image: the next frame's ComputeDepth + candidate pyramids are then enqueued a frame early as well
+// (the depth stream runs a frame ahead of the pose LM, so a short Solve no longer waits for it).
+extern "C" int odo_tracker_hint_next_pair(odo_tracker* t, const float* next_left_dev, const float* next_right_dev) {
+  if (!t) return fail("NULL tracker");
+  t->hint_next = next_left_dev;
+  t->hint_next_right = next_left_dev ? next_right_dev : nullptr;
   return 0;
 }
 
@@ -459,9 +546,9 @@ extern "C" int odo_tracker_stats(const odo_tracker* t, int* lm_evals, int* depth
 }
 extern "C" int odo_tracker_outputs(const odo_tracker* t, const uint8_t** val, const float** disp, const float** dep) {
   if (!t) return fail("NULL tracker");
-  if (val) *val = t->d_val;
-  if (disp) *disp = t->d_disp;
-  if (dep) *dep = t->d_dep;
+  if (val) *val = t->d_val[t->out_slot];
+  if (disp) *disp = t->d_disp[t->out_slot];
+  if (dep) *dep = t->d_dep[t->out_slot];
   return 0;
 }
 extern "C" odo_lm* odo_tracker_lm(odo_tracker* t) { return t ? t->lm : nullptr; }

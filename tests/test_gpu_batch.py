@@ -217,12 +217,13 @@ def test_batched_tracker_slots_of_different_lengths_and_hints(api, drives):
     tb.close()
 
 
-@pytest.mark.parametrize("overlap", [2, 1, 0])
-def test_early_start_of_the_next_solve_changes_nothing(api, drives, overlap):
-    """With the next frame announced (hint_next) the tracker builds its pyramid at the head of the depth stream's job and starts
-    the next Solve the moment the current one returns (odo_lm_solve_begin): same launches, earlier. Poses, keyframe decisions
-    and depth statistics must be those of the un-hinted run — across a keyframe switch, with a wrong hint, with a hint that is
-    followed by a re-initialisation, and with a frame that is not hinted at all."""
+@pytest.mark.parametrize("overlap,pair", [(2, True), (2, False), (1, False), (0, False), (1, True)])
+def test_early_start_of_the_next_solve_changes_nothing(api, drives, overlap, pair):
+    """With the next frame announced (hint_next) the tracker builds its pyramid on a third stream and starts the next Solve the
+    moment the current one returns (odo_lm_solve_begin); with the PAIR announced the depth stream also works a frame ahead
+    (two job slots). Same launches, earlier: poses, keyframe decisions, depth statistics and depth maps must be those of the
+    un-hinted run — across a keyframe switch, with a wrong hint, with a wrong right image, with a hint that is followed by a
+    re-initialisation, and with a frame that is not hinted at all."""
     seq = drives[0]
     n = 11
 
@@ -234,16 +235,23 @@ def test_early_start_of_the_next_solve_changes_nothing(api, drives, overlap):
             trk.init(*dev[0])
             for k in range(1, n):
                 if hints:
+                    def hint(i, right_of=None):
+                        j = i if right_of is None else right_of
+                        trk.hint_next(dev[i][0], dev[j][1]) if pair else trk.hint_next(dev[i][0])
                     if k == 4:
-                        trk.hint_next(dev[0][0])            # wrong announcement: the next frame is 5
+                        hint(0)                             # wrong announcement: the next frame is 5
                     elif k == 6:
                         pass                                # no announcement
+                    elif k == 8 and pair:
+                        hint(9, right_of=2)                 # right image of the announced pair is not the one that comes
                     elif k + 1 < n:
-                        trk.hint_next(dev[k + 1][0])
+                        hint(k + 1)
                     else:
-                        trk.hint_next(dev[1][0])            # announced, but the sequence is re-initialised instead
+                        hint(1)                             # announced, but the sequence is re-initialised instead
                 r = trk.track(*dev[k])
                 r["stats"] = trk.stats()
+                if k in (3, 9):
+                    r["maps"] = trk.outputs(*seq["left"][0].shape)
                 out.append(r)
         trk.close()
         return out
@@ -255,6 +263,9 @@ def test_early_start_of_the_next_solve_changes_nothing(api, drives, overlap):
         assert np.array_equal(a["abs_pose"], b["abs_pose"]), k
         assert a["new_keyframe"] == b["new_keyframe"] and a["motion"] == b["motion"] and a["solve_status"] == b["solve_status"]
         assert a["stats"] == b["stats"], k
+        if "maps" in a:
+            for ma, mb in zip(a["maps"], b["maps"]):
+                assert np.array_equal(ma, mb), k
 
 
 def test_solve_begin_then_solve_equals_solve(api, kitti_seq):

@@ -716,6 +716,9 @@ def main():
                                sequences=n_sequences, frames_per_rank=per_rank,
                                overlap_depth=0 if args.no_overlap else args.overlap, gather_every=args.gather_every,
                                next_frame_pyramid_prefetch=not args.no_prefetch,
+                               next_frame_announced=("stereo pair (odo_tracker_hint_next_pair: pyramid prefetch, early start of the next "
+                                                     "Solve, depth stream a frame ahead; never across the start of the clock)")
+                               if not args.no_prefetch else "no",
                                sequence_per_rank=("configs[3]: %d distinct synthetic sequences dealt round-robin over the ranks "
                                                   "(rank r tracks sequences r, r + N, ... one after the other)" % n_sequences)
                                if args.sequences > 0 else "distinct synthetic sequences" if args.distinct_sequences

@@ -1,5 +1,6 @@
 // tracker.hip.h — the runner's frame loop (run_odometry_kitti_offline.cpp:58-145, 198-271) as a C-ABI object.
-// Host logic only (keyframe policy, pose chaining); all image work is enqueued on two HIP streams.
+// Host logic only (keyframe policy, pose chaining); all image work is enqueued on three HIP streams (pose LM, depth, the
+// next frame's image pyramid).
 // Included by odometry_hip.hip after the pyramid / LM / depth objects are defined.
 #pragma once
 
@@ -42,7 +43,6 @@ struct odo_tracker {
   float pose_to_kf[16];
   int n_keyframes, frame_id;
   int last_evals, last_depth_iters, last_valid;
-  hipEvent_t ev_inputs;
   hipEvent_t ev_cur_img;  // stream A: the current frame's image pyramid is complete (stream B reads it for the candidate lists)
   TrackerJob jobs[2];
   TrackerJob* cur_job;    // job the calling thread is pumping (overlap_depth 0 / 1)
@@ -108,7 +108,6 @@ extern "C" int odo_tracker_destroy(odo_tracker* t) {
     if (t->d_disp[k]) (void)hipFree(t->d_disp[k]);
     if (t->d_dep[k]) (void)hipFree(t->d_dep[k]);
   }
-  if (t->ev_inputs) (void)hipEventDestroy(t->ev_inputs);
   if (t->ev_cur_img) (void)hipEventDestroy(t->ev_cur_img);
   if (t->ev_next) (void)hipEventDestroy(t->ev_next);
   odo_ctx_destroy(t->ctx_c);
@@ -132,7 +131,7 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
     t->jobs[k].slot = k;
   }
   t->cur_job = nullptr; t->out_slot = 0; t->ahead_job = -1;
-  t->ev_inputs = nullptr; t->ev_cur_img = nullptr;
+  t->ev_cur_img = nullptr;
   t->n_keyframes = t->frame_id = t->last_evals = t->last_depth_iters = t->last_valid = 0;
   t->cand_lists = getenv("ODO_NO_CAND_LISTS") ? 0 : 1;
   t->tm_solve_us = t->tm_depth_us = t->tm_frame_us = t->tm_wait_us = 0.0; t->tm_frames = 0;
@@ -167,7 +166,6 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
     ok = ok && hipMalloc((void**)&t->d_val[k], n) == hipSuccess && hipMalloc((void**)&t->d_disp[k], sizeof(float) * n) == hipSuccess &&
          hipMalloc((void**)&t->d_dep[k], sizeof(float) * n) == hipSuccess;
   }
-  ok = ok && hipEventCreateWithFlags(&t->ev_inputs, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&t->ev_cur_img, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&t->ev_next, hipEventDisableTiming) == hipSuccess;
   if (!ok) {

@@ -16,7 +16,7 @@ DEPS = [SRC, SRC_DENSE, os.path.join(_HERE, "csrc", "kernels.hip.h"), os.path.jo
 LIB = os.path.join(_HERE, "lib", "libodometry_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC"]
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC"] + os.environ.get("ODO_EXTRA_HIPCC_FLAGS", "").split()   # A/B builds
 
 
 def needs_build():

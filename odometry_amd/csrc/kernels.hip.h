@@ -680,6 +680,103 @@ __device__ __forceinline__ void solve_damped_wave(const double* acc, float lambd
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// exp() of the state machine with its four fp64 polynomial chains side by side. odo::sincos_f evaluates a sine and a cosine
+// polynomial (8 dependent multiply / add pairs each: contraction is off) one after the other, and se3_exp calls it twice
+// (theta / 2 for the quaternion, theta for the translation's V matrix): ~1 000 cycles of a 6 900-cycle state machine on a
+// wave whose 64 lanes all compute the same thing. Here lane group g = lane & 3 evaluates ONE of the four chains — g = 0: sin
+// of xa, 1: cos of xa, 2: sin of xb, 3: cos of xb — with its own argument and its own coefficients, and the four results are
+// read back with v_readlane. Every lane performs exactly the operations odo::sincos_f performs for its function, in its
+// order (x - K is x + (-K)): the results are bit-identical. Must be called by a full wavefront with wave-uniform arguments.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sincos_pair_lanes(float xa_f, float xb_f, float* sa, float* ca, float* sb, float* cb) {
+  const int g = threadIdx.x & 3;
+  const bool is_cos = (g & 1) != 0;
+  const double x = (double)((g & 2) ? xb_f : xa_f);
+  const double kf = floor(x * 6.36619772367581382433e-01 + 0.5);
+  const double r = (x - kf * 1.57079632673412561417e+00) - kf * 6.07710050650619224932e-11;
+  const double r2 = r * r;
+  // coefficients, highest power first; the eight Horner steps of both polynomials have the same shape p = p * r2 + k
+  double p = is_cos ? 1.0 / 6402373705728000.0 : 1.0 / 355687428096000.0;
+  p = p * r2 + (is_cos ? -(1.0 / 20922789888000.0) : -(1.0 / 1307674368000.0));
+  p = p * r2 + (is_cos ? 1.0 / 87178291200.0 : 1.0 / 6227020800.0);
+  p = p * r2 + (is_cos ? -(1.0 / 479001600.0) : -(1.0 / 39916800.0));
+  p = p * r2 + (is_cos ? 1.0 / 3628800.0 : 1.0 / 362880.0);
+  p = p * r2 + (is_cos ? -(1.0 / 40320.0) : -(1.0 / 5040.0));
+  p = p * r2 + (is_cos ? 1.0 / 720.0 : 1.0 / 120.0);
+  p = p * r2 + (is_cos ? -(1.0 / 24.0) : -(1.0 / 6.0));
+  p = p * r2 + (is_cos ? 1.0 / 2.0 : 1.0);
+  // sine: sr = ps * r; cosine: cr = 1 - pc * r2
+  const double tail = p * (is_cos ? r2 : r);
+  const double v = is_cos ? 1.0 - tail : tail;
+  const int q = (int)((long long)kf & 3);
+  const double sra = readlane_d(v, 0), cra = readlane_d(v, 1), srb = readlane_d(v, 2), crb = readlane_d(v, 3);
+  const int qa = __builtin_amdgcn_readlane(q, 0), qb = __builtin_amdgcn_readlane(q, 2);
+  {
+    double s_, c_;
+    if (qa == 0) { s_ = sra; c_ = cra; } else if (qa == 1) { s_ = cra; c_ = -sra; } else if (qa == 2) { s_ = -sra; c_ = -cra; } else { s_ = -cra; c_ = sra; }
+    *sa = (float)s_; *ca = (float)c_;
+  }
+  {
+    double s_, c_;
+    if (qb == 0) { s_ = srb; c_ = crb; } else if (qb == 1) { s_ = crb; c_ = -srb; } else if (qb == 2) { s_ = -srb; c_ = -crb; } else { s_ = -crb; c_ = srb; }
+    *sb = (float)s_; *cb = (float)c_;
+  }
+}
+
+// odo::se3_exp with the two sincos calls replaced by one sincos_pair_lanes (same operations otherwise, same order).
+__device__ __forceinline__ void se3_exp_wave(const float a[6], Se3* o) {
+  const float ox = a[3], oy = a[4], oz = a[5];
+  const float theta_sq = (ox * ox + oy * oy) + oz * oz;
+  const float theta = sqrtf(theta_sq);
+  const float half_theta = 0.5f * theta;
+  const bool small = theta < 1e-5f;   // wave-uniform
+  float sh = 0.0f, ch = 0.0f, st = 0.0f, ct = 0.0f;
+  if (!small) sincos_pair_lanes(half_theta, theta, &sh, &ch, &st, &ct);
+  float imag, real;
+  if (small) {
+    const float theta_po4 = theta_sq * theta_sq;
+    imag = (0.5f - (float)(1.0 / 48.0) * theta_sq) + (float)(1.0 / 3840.0) * theta_po4;
+    real = (1.0f - (float)(1.0 / 8.0) * theta_sq) + (float)(1.0 / 384.0) * theta_po4;
+  } else {
+    imag = sh / theta;
+    real = ch;
+  }
+  o->qw = real; o->qx = imag * ox; o->qy = imag * oy; o->qz = imag * oz;
+  const float Om[9] = {0.0f, -oz, oy, oz, 0.0f, -ox, -oy, ox, 0.0f};
+  float Om2[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+      Om2[i * 3 + j] = (Om[i * 3 + 0] * Om[0 * 3 + j] + Om[i * 3 + 1] * Om[1 * 3 + j]) + Om[i * 3 + 2] * Om[2 * 3 + j];
+  float V[9];
+  if (small) {
+    quat_to_rot(*o, V);
+  } else {
+    const float tsq = theta * theta;
+    const float ca = (1.0f - ct) / tsq;
+    const float cb = (theta - st) / (tsq * theta);
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const float id = (i == 0 || i == 4 || i == 8) ? 1.0f : 0.0f;
+      V[i] = (id + ca * Om[i]) + cb * Om2[i];
+    }
+  }
+  o->tx = (V[0] * a[0] + V[1] * a[1]) + V[2] * a[2];
+  o->ty = (V[3] * a[0] + V[4] * a[1]) + V[5] * a[2];
+  o->tz = (V[6] * a[0] + V[7] * a[1]) + V[8] * a[2];
+}
+// odo::lm_apply_step for a full wavefront (every lane carries the state): exp through se3_exp_wave.
+__device__ __forceinline__ void lm_apply_step_wave(LmState* s, int max_iters) {
+  Se3 d;
+  se3_exp_wave(s->delta, &d);                        // :152
+  se3_left_update(d, s->cur, &s->inc);               // :153
+  se3_to_colmajor(s->inc, s->T);
+  s->iter++;                                         // :154
+  if (!(max_iters > s->iter)) { s->active = 0; s->stop_reason = 3; }
+}
+
 // Sums the per-block partials in a fixed order and advances the LM state machine by one evaluation
 // (accept / reject, damped 6x6 solve, exp, left-compose; ref: src/lm_optimizer.cpp:129-154). One workgroup:
 // 256 threads fold the partials, wave 0 solves, lane 0 runs the scalar state machine.
@@ -909,7 +1006,11 @@ __device__ __forceinline__ void lm_state_machine(bool pending, const StepLevel* 
 #pragma unroll
       for (int i = 0; i < 6; i++) s.delta[i] = d[i];
       if (smdbg) { asm volatile("" ::"v"(d[0]), "v"(d[5])); c2 = __builtin_readcyclecounter(); }
+#ifdef ODO_NO_LANE_SINCOS
       lm_apply_step(&s, s.max_iters);
+#else
+      lm_apply_step_wave(&s, s.max_iters);
+#endif
       if (smdbg) { asm volatile("" ::"v"(s.T[0]), "v"(s.T[14])); c3 = __builtin_readcyclecounter(); }
     }
     if (smdbg && t == 0) { smdbg[0] += c1 - c0; smdbg[1] += c2 - c1; smdbg[2] += c3 - c2; smdbg[3] += 1; }

@@ -771,6 +771,14 @@ def main():
                                   f"{fus['total_s']} s"),
                 gpu_same_sample=dict(value=round(gpu_same_fps, 1), unit="frames/s"))
             out["pose_max_abs_delta_vs_oracle"] = dmax
+            # the timed run itself (next frame announced: pyramid prefetch, early Solve, depth stream a frame ahead) against this
+            # plain pass over the same frames: the first pass of the drive, before any re-initialisation
+            if args.sequences == 0:
+                m = min(n, n_total, args.unique_frames - 1)
+                timed = poses_kf[0, :m].reshape(m, 4, 4).transpose(0, 2, 1)
+                out["timed_run_poses_bit_identical_to_plain_pass"] = bool(
+                    all(np.array_equal(timed[j], gpu_poses[j]) for j in range(m)))
+                out["timed_run_frames_checked"] = m
             # like for like: the start of a drive is its most expensive stretch (40-70 LM evaluations per frame against
             # ~25 later), so the ratios are taken on the same frames, not against the whole-run rate
             out["speedup_vs_cpu"] = round(gpu_same_fps / ref["frames_per_s"], 1)

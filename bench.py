@@ -460,6 +460,8 @@ def batched_sequences_leg(api, seqs, counts=(1, 2, 4, 8), passes=3):
                 t0 = time.perf_counter()
             tb.init([Ls[i][0] for i in range(S)], [Rs[i][0] for i in range(S)])
             for k in range(1, n_frames):
+                if k + 1 < n_frames:
+                    tb.hint_next(lp[k + 1], rp[k + 1])
                 st = tb.track_raw(lp[k], rp[k])
                 if rep == 0:
                     same = same and all(v == 0 for v in st) and bool(np.array_equal(tb._T[:16], ref[k]))
@@ -628,7 +630,7 @@ def main():
             if begins_pass(order, k):
                 tb.init([bdev[j][0][0] for j in range(m)], [bdev[j][0][1] for j in range(m)])
             if not args.no_prefetch and k + 1 < n_total and k + 1 != args.warmup:
-                tb.hint_next(blp[order[k + 1]])
+                tb.hint_next(blp[order[k + 1]], brp[order[k + 1]])
             tb.track_raw(blp[i], brp[i])
             poses_kf[:, k, :] = tb._T.reshape(m, 16)
             poses_abs[:, k, :] = tb._A.reshape(m, 16)

@@ -306,6 +306,9 @@ int odo_tracker_batch_track(odo_tracker_batch* b, const float* const* left_dev, 
 /* Optional pipelining, as odo_tracker_hint_next: the left images of the NEXT step (n pointers, NULL entries allowed), announced
  * before odo_tracker_batch_track of the current one; their pyramids are built behind this step's Solve. Same work, earlier. */
 int odo_tracker_batch_hint_next(odo_tracker_batch* b, const float* const* next_left_dev);
+/* The same with the right images (odo_tracker_hint_next_pair for every slot): the next step's ComputeDepth, depth pyramids and
+ * candidate lists are enqueued a step early, so the depth stream works a step ahead of the pose LM. NULL entries allowed. */
+int odo_tracker_batch_hint_next_pair(odo_tracker_batch* b, const float* const* next_left_dev, const float* const* next_right_dev);
 /* Counters of the last tracked frame, one entry per sequence (any pointer may be NULL). */
 int odo_tracker_batch_stats(const odo_tracker_batch* b, int* lm_evals, int* depth_iters, int* n_valid_depth, int* n_keyframes);
 /* Diagnostics: host-clock averages per lock step since the last call, microseconds: {whole call, table + pyramid launches,

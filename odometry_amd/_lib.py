@@ -117,6 +117,7 @@ SIGNATURES = {
     "odo_tracker_batch_init": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), _fp]),
     "odo_tracker_batch_init_one": (C.c_int, [_vp, C.c_int, _vp, _vp, _fp]),
     "odo_tracker_batch_hint_next": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "odo_tracker_batch_hint_next_pair": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "odo_tracker_batch_track": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), _fp, _fp, _ip, _fp, _ip]),
     "odo_tracker_batch_timing": (C.c_int, [_vp, _dp]),
     "odo_tracker_batch_stats": (C.c_int, [_vp, _ip, _ip, _ip, _ip]),

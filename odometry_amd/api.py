@@ -635,10 +635,15 @@ class TrackerBatch:
         pose = None if abs_pose0 is None else _fp(_colmajor(abs_pose0))
         L.check(self.lib.odo_tracker_batch_init_one(self.h, slot, left, right, pose), "odo_tracker_batch_init_one")
 
-    def hint_next(self, next_lefts):
-        """next_lefts: n handles (None allowed) or a prepared (c_void_p * n) array."""
+    def hint_next(self, next_lefts, next_rights=None):
+        """next_lefts / next_rights: n handles (None allowed) or prepared (c_void_p * n) arrays. With the right images the depth
+        stream works a step ahead as well (odo_tracker_batch_hint_next_pair)."""
         arr = next_lefts if isinstance(next_lefts, C.Array) else self._ptrs(next_lefts)
-        L.check(self.lib.odo_tracker_batch_hint_next(self.h, arr), "odo_tracker_batch_hint_next")
+        if next_rights is None:
+            L.check(self.lib.odo_tracker_batch_hint_next(self.h, arr), "odo_tracker_batch_hint_next")
+        else:
+            arr_r = next_rights if isinstance(next_rights, C.Array) else self._ptrs(next_rights)
+            L.check(self.lib.odo_tracker_batch_hint_next_pair(self.h, arr, arr_r), "odo_tracker_batch_hint_next_pair")
 
     def track_raw(self, left_ptrs, right_ptrs):
         """Lean variant for timing loops: takes prepared (c_void_p * n) arrays, returns the status array; poses stay in

@@ -95,32 +95,66 @@ __global__ void __launch_bounds__(kDlmBlock) depth_stats_batch_kernel(const Batc
 
 }  // namespace odo
 
+// One batched stream-B job: ComputeDepth, depth pyramid and candidate lists of a set of slots (table entry e <-> slot ids[e]).
+// Two of them exist: `late` (slots whose frame of THIS step has no finished job yet) and `ahead` (the frames announced for the
+// NEXT step, odo_tracker_batch_hint_next_pair: the depth stream then works a step ahead of the pose LM).
+struct BatchChain {
+  std::vector<int> ids;
+  std::vector<int> par;      // output parity per entry (each slot has two output sets)
+  std::vector<long> tag;     // frame id per entry (tags the candidate lists)
+  std::vector<const float*> left, right;   // per SLOT: the pairs the job works on (copies: the job may outlive the caller's arrays)
+  std::vector<DepthLmStats> stats;         // per entry: the job's results, taken over by the calling thread (batch_chain_absorb)
+  bool img_is_next;          // the candidate lists read next_img (the announced frame's pyramid) instead of cur_img / kf_img
+  bool first;                // frame 0: the image pyramids are the keyframe buffers
+  int tag_add;               // 0 = the frame being tracked, 1 = the next one
+  BatchSeq* h_tab;           // pinned, S entries
+  BatchSeq* d_tab;
+  hipEvent_t img_ready;      // the image pyramids the candidate lists read are complete after this event
+  int k, n_launches, stage;  // stage: 0 idle, 1 depth-LM launches, 2 tail enqueued, 3 complete (results not absorbed yet)
+  std::atomic<int> complete; // 1: the job has been run (set by the thread that ran it, read by the tracker's owner)
+  bool poll, waiting, with_lists;
+  int err;
+  std::chrono::steady_clock::time_point wait_since;
+};
+
 struct odo_tracker_batch {
   odo_tracker_params p;
   int S;           // slots
   odo_ctx* ctx_a;  // image pyramids + pose LM
   odo_ctx* ctx_b;  // ComputeDepth, depth pyramids, candidate lists
+  odo_ctx* ctx_c;  // the next step's image pyramids
   std::vector<odo_lm*> lm;
   std::vector<odo_depth*> depth;
-  std::vector<odo_pyr*> kf_img, kf_dep, cur_img, pre_dep, next_img;
-  std::vector<uint8_t*> d_val;
-  std::vector<float*> d_disp, d_dep;
-  std::vector<float> kf_abs, pose_to_kf;  // S x 16
+  std::vector<odo_pyr*> kf_img, kf_dep, cur_img, next_img;
+  std::vector<odo_pyr*> pre_dep[2];        // per output parity
+  std::vector<uint8_t*> d_val[2];
+  std::vector<float*> d_disp[2], d_dep[2];
+  std::vector<int> next_par;               // parity the slot's next stream-B job writes
+  std::vector<int> res_par;                // parity that holds the slot's latest collected job
+  std::vector<int> res_ok;                 // that job's ComputeDepth status (1 = ok)
+  std::vector<int> out_par;                // parity that holds the outputs of the slot's last tracked frame
+  std::vector<const float*> res_left, res_right;  // the pair it was computed from (NULL: none)
+  std::vector<long> res_tag;               // frame id it was tagged with
+  std::vector<float> kf_abs, pose_to_kf;   // S x 16
   std::vector<int> n_keyframes, alive, last_evals, last_depth_iters, last_valid;
-  std::vector<long> frame_id;             // per slot: frames tracked since its init (tags the candidate lists)
-  std::vector<const float*> hint_next, prefetched;  // per slot: announced next left image / image whose pyramid sits in next_img
-  BatchSeq* h_tab;  // pinned, 2 S entries: [0, S) the lock step in flight, [S, 2S) the prefetch launch's pyramid-only entries
-  BatchSeq* d_tab;
-  int* h_cand_npts;  // host-mapped, S x ODO_MAX_LEVELS
+  std::vector<long> frame_id;              // per slot: frames tracked since its init (tags the candidate lists)
+  std::vector<const float*> hint_next, hint_next_right, prefetched;  // announced next pair / image whose pyramid sits in next_img
+  BatchSeq* h_pyr;  // pinned, 2 S entries: pyramid-only launches ([0, S) this step's on stream A, [S, 2S) the next step's on stream C)
+  BatchSeq* d_pyr;
+  int* h_cand_npts;  // host-mapped, S x 2 x ODO_MAX_LEVELS
   int* d_cand_npts;  // its device alias
-  hipEvent_t ev_cur_img, ev_tab;
+  hipEvent_t ev_cur_img, ev_next;
   int overlap;       // 1: the depth chain runs on stream B beside the pose LM on stream A (one host thread feeds both)
-  // the set of slots of the step in flight (table entry e <-> slot ids[e]) and its depth chain
-  std::vector<int> ids;
-  int dk, dn_launches, dstage;  // dstage: 0 idle, 1 LM launches, 2 tail enqueued
-  bool dpoll, dwaiting, with_lists;
-  int derr;
-  std::chrono::steady_clock::time_point dwait_since;
+  int depth_ahead;   // 1: announced pairs get their stream-B job a step early (ODO_NO_DEPTH_AHEAD=1: off)
+  BatchChain late, ahead;
+  // overlap: a helper host thread feeds stream B — it runs the posted chains one after the other, each up to its completion
+  // words (a slot's depth object serves one job at a time) — while the calling thread feeds the pose LM on stream A.
+  std::thread worker;
+  BatchChain* w_ring[2];
+  std::atomic<long> w_posted, w_done;
+  std::atomic<int> w_quit;
+  std::vector<int> ids;    // slots of the lock step in flight (pose LM)
+  bool with_lists;
   double tm_frame_us, tm_head_us, tm_solve_us, tm_depth_wait_us; long tm_frames;  // host-clock averages (diagnostics)
 };
 
@@ -134,25 +168,37 @@ static PyrOut batch_pyr_out(const odo_pyr* p, int smooth) {
 
 extern "C" int odo_tracker_batch_destroy(odo_tracker_batch* b) {
   if (!b) return 0;
-  if (b->ctx_a) (void)hipStreamSynchronize(b->ctx_a->stream);
-  if (b->ctx_b) (void)hipStreamSynchronize(b->ctx_b->stream);
+  if (b->worker.joinable()) {
+    b->w_quit.store(1, std::memory_order_release);  // chains already posted are run first
+    b->worker.join();
+  }
+  for (odo_ctx* c : {b->ctx_a, b->ctx_b, b->ctx_c}) if (c) (void)hipStreamSynchronize(c->stream);
   for (odo_lm* m : b->lm) odo_lm_destroy(m);
   for (odo_depth* d : b->depth) odo_depth_destroy(d);
-  for (auto* v : {&b->kf_img, &b->kf_dep, &b->cur_img, &b->pre_dep, &b->next_img})
+  for (auto* v : {&b->kf_img, &b->kf_dep, &b->cur_img, &b->next_img, &b->pre_dep[0], &b->pre_dep[1]})
     for (odo_pyr* q : *v) odo_pyramid_destroy(q);
-  for (uint8_t* q : b->d_val) if (q) (void)hipFree(q);
-  for (float* q : b->d_disp) if (q) (void)hipFree(q);
-  for (float* q : b->d_dep) if (q) (void)hipFree(q);
-  if (b->h_tab) (void)hipHostFree(b->h_tab);
-  if (b->d_tab) (void)hipFree(b->d_tab);
+  for (int k = 0; k < 2; k++) {
+    for (uint8_t* q : b->d_val[k]) if (q) (void)hipFree(q);
+    for (float* q : b->d_disp[k]) if (q) (void)hipFree(q);
+    for (float* q : b->d_dep[k]) if (q) (void)hipFree(q);
+  }
+  for (BatchChain* c : {&b->late, &b->ahead}) {
+    if (c->h_tab) (void)hipHostFree(c->h_tab);
+    if (c->d_tab) (void)hipFree(c->d_tab);
+  }
+  if (b->h_pyr) (void)hipHostFree(b->h_pyr);
+  if (b->d_pyr) (void)hipFree(b->d_pyr);
   if (b->h_cand_npts) (void)hipHostFree(b->h_cand_npts);
   if (b->ev_cur_img) (void)hipEventDestroy(b->ev_cur_img);
-  if (b->ev_tab) (void)hipEventDestroy(b->ev_tab);
+  if (b->ev_next) (void)hipEventDestroy(b->ev_next);
+  odo_ctx_destroy(b->ctx_c);
   odo_ctx_destroy(b->ctx_b);
   odo_ctx_destroy(b->ctx_a);
   delete b;
   return 0;
 }
+
+static void batch_worker_main(odo_tracker_batch* b);
 
 extern "C" int odo_tracker_batch_create(int device, const odo_tracker_params* p, int n_sequences, odo_tracker_batch** out) {
   if (!p || !out) return fail("odo_tracker_batch_create: NULL arg");
@@ -163,24 +209,29 @@ extern "C" int odo_tracker_batch_create(int device, const odo_tracker_params* p,
   if (!b) return fail("out of memory");
   const int S = n_sequences;
   b->p = *p; b->S = S;
-  b->ctx_a = b->ctx_b = nullptr; b->h_tab = nullptr; b->d_tab = nullptr; b->h_cand_npts = b->d_cand_npts = nullptr;
-  b->ev_cur_img = b->ev_tab = nullptr;
-  b->dstage = 0; b->derr = 0;
+  b->ctx_a = b->ctx_b = b->ctx_c = nullptr; b->h_pyr = b->d_pyr = nullptr; b->h_cand_npts = b->d_cand_npts = nullptr;
+  b->ev_cur_img = b->ev_next = nullptr;
+  for (BatchChain* c : {&b->late, &b->ahead}) { c->h_tab = c->d_tab = nullptr; c->stage = 0; c->err = 0; c->img_ready = nullptr; c->complete.store(0); }
+  b->w_ring[0] = b->w_ring[1] = nullptr; b->w_posted.store(0); b->w_done.store(0); b->w_quit.store(0);
   b->tm_frame_us = b->tm_head_us = b->tm_solve_us = b->tm_depth_wait_us = 0.0; b->tm_frames = 0;
   b->overlap = (p->overlap_depth != 0) && !getenv("ODO_BATCH_NO_OVERLAP");
+  b->depth_ahead = b->overlap && !getenv("ODO_NO_DEPTH_AHEAD");
   b->lm.assign(S, nullptr); b->depth.assign(S, nullptr);
-  b->kf_img.assign(S, nullptr); b->kf_dep.assign(S, nullptr); b->cur_img.assign(S, nullptr); b->pre_dep.assign(S, nullptr);
-  b->next_img.assign(S, nullptr);
-  b->d_val.assign(S, nullptr); b->d_disp.assign(S, nullptr); b->d_dep.assign(S, nullptr);
+  b->kf_img.assign(S, nullptr); b->kf_dep.assign(S, nullptr); b->cur_img.assign(S, nullptr); b->next_img.assign(S, nullptr);
+  for (int k = 0; k < 2; k++) {
+    b->pre_dep[k].assign(S, nullptr); b->d_val[k].assign(S, nullptr); b->d_disp[k].assign(S, nullptr); b->d_dep[k].assign(S, nullptr);
+  }
+  b->next_par.assign(S, 0); b->res_par.assign(S, 0); b->res_ok.assign(S, 0); b->out_par.assign(S, 0);
+  b->res_left.assign(S, nullptr); b->res_right.assign(S, nullptr); b->res_tag.assign(S, -1);
   b->kf_abs.assign((size_t)S * 16, 0.0f); b->pose_to_kf.assign((size_t)S * 16, 0.0f);
   b->n_keyframes.assign(S, 0); b->alive.assign(S, 0); b->last_evals.assign(S, 0); b->last_depth_iters.assign(S, 0);
   b->last_valid.assign(S, 0); b->frame_id.assign(S, 0);
-  b->hint_next.assign(S, nullptr); b->prefetched.assign(S, nullptr);
+  b->hint_next.assign(S, nullptr); b->hint_next_right.assign(S, nullptr); b->prefetched.assign(S, nullptr);
   const float eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   const size_t n = (size_t)p->rows * p->cols;
   const bool lm_prio = !(getenv("ODO_LM_PRIORITY") && atoi(getenv("ODO_LM_PRIORITY")) == 0);
   bool ok = (lm_prio ? odo_ctx_create_high_priority(device, &b->ctx_a) : odo_ctx_create(device, &b->ctx_a)) == 0 &&
-            odo_ctx_create(device, &b->ctx_b) == 0;
+            odo_ctx_create(device, &b->ctx_b) == 0 && odo_ctx_create(device, &b->ctx_c) == 0;
   for (int i = 0; i < S && ok; i++) {
     ok = ok && odo_lm_create(b->ctx_a, p->lm_lambda, p->lm_precision, p->lm_max_iters, p->levels, eye, p->lm_robust,
                              p->lm_huber_delta, &p->K, &b->lm[i]) == 0;
@@ -192,64 +243,31 @@ extern "C" int odo_tracker_batch_create(int device, const odo_tracker_params* p,
     ok = ok && pyr_alloc(b->ctx_a, p->rows, p->cols, p->levels, ODO_PYR_IMAGE, &b->next_img[i], false) == 0;
     ok = ok && pyr_alloc(b->ctx_a, p->rows, p->cols, p->levels, ODO_PYR_IMAGE, &b->kf_img[i], false) == 0;
     ok = ok && pyr_alloc(b->ctx_b, p->rows, p->cols, p->levels, ODO_PYR_DEPTH, &b->kf_dep[i], false) == 0;
-    ok = ok && pyr_alloc(b->ctx_b, p->rows, p->cols, p->levels, ODO_PYR_DEPTH, &b->pre_dep[i], false) == 0;
-    ok = ok && hipMalloc((void**)&b->d_val[i], n) == hipSuccess && hipMalloc((void**)&b->d_disp[i], sizeof(float) * n) == hipSuccess &&
-         hipMalloc((void**)&b->d_dep[i], sizeof(float) * n) == hipSuccess;
+    for (int k = 0; k < 2 && ok; k++) {
+      ok = ok && pyr_alloc(b->ctx_b, p->rows, p->cols, p->levels, ODO_PYR_DEPTH, &b->pre_dep[k][i], false) == 0;
+      ok = ok && hipMalloc((void**)&b->d_val[k][i], n) == hipSuccess && hipMalloc((void**)&b->d_disp[k][i], sizeof(float) * n) == hipSuccess &&
+           hipMalloc((void**)&b->d_dep[k][i], sizeof(float) * n) == hipSuccess;
+    }
   }
-  ok = ok && hipHostMalloc((void**)&b->h_tab, sizeof(BatchSeq) * 2 * (size_t)S, hipHostMallocDefault) == hipSuccess;
-  ok = ok && hipMalloc((void**)&b->d_tab, sizeof(BatchSeq) * 2 * (size_t)S) == hipSuccess;
-  ok = ok && hipHostMalloc((void**)&b->h_cand_npts, sizeof(int) * ODO_MAX_LEVELS * (size_t)S,
+  for (BatchChain* c : {&b->late, &b->ahead}) {
+    ok = ok && hipHostMalloc((void**)&c->h_tab, sizeof(BatchSeq) * (size_t)S, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_tab, sizeof(BatchSeq) * (size_t)S) == hipSuccess;
+  }
+  ok = ok && hipHostMalloc((void**)&b->h_pyr, sizeof(BatchSeq) * 2 * (size_t)S, hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipMalloc((void**)&b->d_pyr, sizeof(BatchSeq) * 2 * (size_t)S) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&b->h_cand_npts, sizeof(int) * 2 * ODO_MAX_LEVELS * (size_t)S,
                            hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
   ok = ok && hipHostGetDevicePointer((void**)&b->d_cand_npts, b->h_cand_npts, 0) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&b->ev_cur_img, hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&b->ev_tab, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&b->ev_next, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     char keep[512];
     snprintf(keep, sizeof(keep), "%s", g_err);
     odo_tracker_batch_destroy(b);
     return fail("odo_tracker_batch_create failed: %s", keep);
   }
+  if (b->overlap) b->worker = std::thread(batch_worker_main, b);
   *out = b;
-  return 0;
-}
-
-// Fills and uploads the step's table: entry e <-> slot b->ids[e] (stream A; stream B waits for the upload through ev_tab).
-// first: frame 0 of the listed slots, whose pyramids go straight into the keyframe buffers.
-static int batch_upload_table(odo_tracker_batch* b, const float* const* left, const float* const* right, bool first) {
-  const odo_tracker_params& p = b->p;
-  const int n = (int)b->ids.size();
-  for (int e = 0; e < n; e++) {
-    const int i = b->ids[e];
-    BatchSeq& q = b->h_tab[e];
-    odo_depth* d = b->depth[i];
-    odo_lm* m = b->lm[i];
-    odo_pyr* img = first ? b->kf_img[i] : b->cur_img[i];
-    odo_pyr* dep = first ? b->kf_dep[i] : b->pre_dep[i];
-    memset(&q, 0, sizeof(q));
-    q.left = left[i]; q.right = right[i];
-    q.cur_img = batch_pyr_out(img, p.smooth_image);
-    q.pre_dep = batch_pyr_out(dep, 0);
-    dep->version = ++g_pyr_version;
-    q.bl = d->d_bl; q.br = d->d_br; q.disp = b->d_disp[i]; q.dep = b->d_dep[i]; q.d0 = d->d_d0; q.scratch = d->d_scratch;
-    q.val = b->d_val[i]; q.matched = d->d_matched; q.pts = d->d_pts; q.cnt = d->d_cnt;
-    q.dstate = d->d_lmstate; q.part_e = d->d_part_e; q.part_n = d->d_part_n; q.counts = d->d_counts;
-    q.stats = d->d_stats_map; q.dprog = d->d_prog;
-    d->token++;
-    q.dtoken = d->token;
-    d->h_prog[0] = 0; d->h_prog[1] = 0;  // both streams are idle here (every step ends on the completion words)
-    int rows_total = 0;
-    m->cand[0].tag = -1;
-    if (b->with_lists) {
-      if (lm_lists_layout(m, m->cand[0].pl, m->cand[0].pl_cap, m->cand[0].d_rowcnt, m->cand[0].rows_cap, img, dep, b->ctx_b->stream, &q.kl,
-                          &rows_total)) return -1;
-      if (rows_total > 0) m->cand[0].tag = b->frame_id[i];
-    }
-    q.rowcnt = m->cand[0].d_rowcnt; q.npts = m->cand[0].d_npts; q.npts_host = b->d_cand_npts + (size_t)i * ODO_MAX_LEVELS;
-    for (int l = 0; l < ODO_MAX_LEVELS; l++) q.pl[l] = m->cand[0].pl[l];
-  }
-  hipStream_t sa = b->ctx_a->stream;
-  HIP_OK(hipMemcpyAsync(b->d_tab, b->h_tab, sizeof(BatchSeq) * (size_t)n, hipMemcpyHostToDevice, sa));
-  HIP_OK(hipEventRecord(b->ev_tab, sa));
   return 0;
 }
 
@@ -266,53 +284,112 @@ static inline dim3 batch_pyr_grid(const odo_tracker_batch* b, int n) {
   return dim3((b->p.cols + kPT - 1) / kPT, (b->p.rows + kPT - 1) / kPT, n);
 }
 
-// Front of the depth chain: blur, point selection, disparity scan for the step's slots (3 launches).
-static int batch_depth_begin(odo_tracker_batch* b, hipStream_t s) {
-  const odo_tracker_params& p = b->p;
-  const odo_depth* d = b->depth[0];
-  const int n = (int)b->ids.size();
-  b->dk = 0; b->dn_launches = 0; b->dstage = 1; b->derr = 0; b->dpoll = d->poll != 0; b->dwaiting = false;
-  hipLaunchKernelGGL(blur3x3_batch_kernel, grid2d(p.cols, p.rows, 2 * n), dim3(256), 0, s, (const BatchSeq*)b->d_tab, p.rows, p.cols);
-  hipLaunchKernelGGL(depth_select_batch_kernel, dim3(kSelBlocks, n), dim3(kSelThreads), 0, s, (const BatchSeq*)b->d_tab, p.rows,
-                     p.cols, d->boundary, d->grad_th);
-  hipLaunchKernelGGL(depth_disparity_batch_kernel, dim3(kSelBlocks * kSelCap / 4, n), dim3(256), 0, s, (const BatchSeq*)b->d_tab,
-                     p.rows, p.cols, d->boundary, d->max_disparity, d->ssd_th, d->K.f0, d->baseline);
+// One pyramid-only launch: the image pyramids `dst[i]` of `src[i]` for the listed slots, on stream s, through table rows
+// [row0, row0 + n) of the pyramid table.
+static int batch_build_pyramids(odo_tracker_batch* b, const std::vector<int>& slots, const std::vector<const float*>& src,
+                                const std::vector<odo_pyr*>& dst, int row0, hipStream_t s) {
+  const int n = (int)slots.size();
+  if (n == 0) return 0;
+  for (int e = 0; e < n; e++) {
+    const int i = slots[e];
+    BatchSeq& q = b->h_pyr[row0 + e];
+    memset(&q, 0, sizeof(q));
+    q.left = src[i];
+    q.cur_img = batch_pyr_out(dst[i], b->p.smooth_image);
+    dst[i]->version = ++g_pyr_version;
+  }
+  HIP_OK(hipMemcpyAsync(b->d_pyr + row0, b->h_pyr + row0, sizeof(BatchSeq) * (size_t)n, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(image_pyramid_batch_kernel, batch_pyr_grid(b, n), dim3(kPyrThreads), 0, s, (const BatchSeq*)(b->d_pyr + row0));
   HIP_OK(hipGetLastError());
   return 0;
 }
 
-// Tail of the step on the depth stream: filters, depth pyramids, candidate lists, statistics + completion words.
-static int batch_depth_tail(odo_tracker_batch* b, hipStream_t s) {
+// Fills and uploads a chain's table and enqueues the front of its depth job (blur, point selection, disparity scan) on stream s.
+// The chain describes the job: ids, the pairs (left / right per slot), which image pyramid the candidate lists read, the
+// frame tag. Entry e writes the slot's next output parity.
+static int batch_chain_begin(odo_tracker_batch* b, BatchChain* c, hipStream_t s) {
+  const odo_tracker_params& p = b->p;
+  const int n = (int)c->ids.size();
+  c->par.assign(n, 0); c->tag.assign(n, -1); c->stats.assign(n, DepthLmStats());
+  c->stage = 0; c->err = 0; c->k = 0; c->n_launches = 0; c->waiting = false;
+  if (n == 0) { c->stage = 3; return 0; }
+  for (int e = 0; e < n; e++) {
+    const int i = c->ids[e];
+    const int par = b->next_par[i];
+    b->next_par[i] ^= 1;
+    c->par[e] = par;
+    c->tag[e] = b->frame_id[i] + c->tag_add;
+    BatchSeq& q = c->h_tab[e];
+    odo_depth* d = b->depth[i];
+    odo_lm* m = b->lm[i];
+    odo_pyr* img = c->first ? b->kf_img[i] : c->img_is_next ? b->next_img[i] : b->cur_img[i];
+    odo_pyr* dep = b->pre_dep[par][i];
+    memset(&q, 0, sizeof(q));
+    q.left = c->left[i]; q.right = c->right[i];
+    q.cur_img = batch_pyr_out(img, p.smooth_image);
+    q.pre_dep = batch_pyr_out(dep, 0);
+    dep->version = ++g_pyr_version;
+    q.bl = d->d_bl; q.br = d->d_br; q.disp = b->d_disp[par][i]; q.dep = b->d_dep[par][i]; q.d0 = d->d_d0; q.scratch = d->d_scratch;
+    q.val = b->d_val[par][i]; q.matched = d->d_matched; q.pts = d->d_pts; q.cnt = d->d_cnt;
+    q.dstate = d->d_lmstate; q.part_e = d->d_part_e; q.part_n = d->d_part_n; q.counts = d->d_counts;
+    q.stats = d->d_stats_map; q.dprog = d->d_prog;
+    d->token++;
+    q.dtoken = d->token;
+    d->h_prog[0] = 0; d->h_prog[1] = 0;  // the slot's previous job is complete: nobody is polling these
+    int rows_total = 0;
+    LmCandSet& cs = m->cand[par];
+    cs.tag = -1;
+    if (c->with_lists) {
+      if (lm_lists_layout(m, cs.pl, cs.pl_cap, cs.d_rowcnt, cs.rows_cap, img, dep, s, &q.kl, &rows_total)) return -1;
+      if (rows_total > 0) cs.tag = c->tag[e];
+    }
+    q.rowcnt = cs.d_rowcnt; q.npts = cs.d_npts; q.npts_host = b->d_cand_npts + ((size_t)i * 2 + par) * ODO_MAX_LEVELS;
+    for (int l = 0; l < ODO_MAX_LEVELS; l++) q.pl[l] = cs.pl[l];
+  }
+  HIP_OK(hipMemcpyAsync(c->d_tab, c->h_tab, sizeof(BatchSeq) * (size_t)n, hipMemcpyHostToDevice, s));
+  const odo_depth* d = b->depth[0];
+  c->poll = d->poll != 0;
+  const BatchSeq* tab = c->d_tab;
+  hipLaunchKernelGGL(blur3x3_batch_kernel, grid2d(p.cols, p.rows, 2 * n), dim3(256), 0, s, tab, p.rows, p.cols);
+  hipLaunchKernelGGL(depth_select_batch_kernel, dim3(kSelBlocks, n), dim3(kSelThreads), 0, s, tab, p.rows, p.cols, d->boundary,
+                     d->grad_th);
+  hipLaunchKernelGGL(depth_disparity_batch_kernel, dim3(kSelBlocks * kSelCap / 4, n), dim3(256), 0, s, tab, p.rows, p.cols,
+                     d->boundary, d->max_disparity, d->ssd_th, d->K.f0, d->baseline);
+  HIP_OK(hipGetLastError());
+  c->stage = 1;
+  return 0;
+}
+
+// Tail of a chain: filters, depth pyramids, candidate lists, statistics + completion words.
+static int batch_chain_tail(odo_tracker_batch* b, BatchChain* c, hipStream_t s) {
   const odo_tracker_params& p = b->p;
   const odo_depth* d = b->depth[0];
-  const int n = (int)b->ids.size();
-  const BatchSeq* tab = b->d_tab;
+  const int n = (int)c->ids.size();
+  const BatchSeq* tab = c->d_tab;
   hipLaunchKernelGGL(depth_finalize_batch_kernel, dim3(kDlmBlocks, n), dim3(kDlmBlock), 0, s, tab, 1, p.cols, d->photo_th,
                      d->min_depth, d->max_depth);
   hipLaunchKernelGGL(depth_pyramid_batch_kernel, grid2d(p.cols, p.rows, n), dim3(256), 0, s, tab);  // :252
   const int rows_total = batch_rows_total(b);
-  const int with_lists = (b->with_lists && rows_total > 0) ? 1 : 0;
+  const int with_lists = (c->with_lists && rows_total > 0) ? 1 : 0;
   if (with_lists) {
-    if (s != b->ctx_a->stream) HIP_OK(hipStreamWaitEvent(s, b->ev_cur_img, 0));
+    if (c->img_ready) HIP_OK(hipStreamWaitEvent(s, c->img_ready, 0));
     hipLaunchKernelGGL(kf_count_batch_kernel, dim3(rows_total, n), dim3(256), 0, s, tab);
     hipLaunchKernelGGL(kf_fill_batch_kernel, dim3(rows_total, n), dim3(256), 0, s, tab, p.K.f0, p.K.cx0, p.K.cy0);
   }
-  hipLaunchKernelGGL(depth_stats_batch_kernel, dim3(1, n), dim3(kDlmBlock), 0, s, tab, 1, b->dn_launches, with_lists);
+  hipLaunchKernelGGL(depth_stats_batch_kernel, dim3(1, n), dim3(kDlmBlock), 0, s, tab, 1, c->n_launches, with_lists);
   HIP_OK(hipGetLastError());
-  b->dstage = 2;
+  c->stage = 2;
   return 0;
 }
 
-// Issues at most one depth-LM launch (all slots of the step) per call; enqueues the tail once every slot's LM has stopped.
-static void batch_depth_pump(void* arg) {
-  odo_tracker_batch* b = (odo_tracker_batch*)arg;
-  if (b->dstage != 1) return;
+// Issues at most one depth-LM launch (all slots of the chain) per call; enqueues the tail once every slot's LM has stopped.
+static void batch_chain_pump(odo_tracker_batch* b, BatchChain* c, hipStream_t s) {
+  if (c->stage != 1) return;
   const odo_depth* d0 = b->depth[0];
-  hipStream_t s = b->overlap ? b->ctx_b->stream : b->ctx_a->stream;
   bool all_stopped = true;
   int min_prog = 1 << 30;
-  if (b->dpoll) {
-    for (int i : b->ids) {
+  if (c->poll) {
+    for (int i : c->ids) {
       volatile int* prog = b->depth[i]->h_prog;
       if (!prog[1]) { all_stopped = false; if (prog[0] < min_prog) min_prog = prog[0]; }
     }
@@ -320,96 +397,165 @@ static void batch_depth_pump(void* arg) {
     all_stopped = false;
   }
   // launch k decides on evaluation k-1 and runs evaluation k: max_iters evaluations need max_iters + 1 launches
-  const bool lm_over = (b->dk > d0->max_iters) || (b->dpoll && all_stopped);
+  const bool lm_over = (c->k > d0->max_iters) || (c->poll && all_stopped);
   if (!lm_over) {
-    if (b->dpoll && b->dk - min_prog > d0->run_ahead) {
+    if (c->poll && c->k - min_prog > d0->run_ahead) {
       const auto now = std::chrono::steady_clock::now();
-      if (!b->dwaiting) { b->dwaiting = true; b->dwait_since = now; }
-      else if (now - b->dwait_since > std::chrono::seconds(2)) b->dpoll = false;  // never hang on a lost progress word
+      if (!c->waiting) { c->waiting = true; c->wait_since = now; }
+      else if (now - c->wait_since > std::chrono::seconds(2)) c->poll = false;  // never hang on a lost progress word
       return;
     }
-    b->dwaiting = false;
-    hipLaunchKernelGGL(depth_lm_step_batch_kernel, dim3(kDlmBlocks, (int)b->ids.size()), dim3(kDlmBlock), 0, s,
-                       (const BatchSeq*)b->d_tab, b->dk, b->p.cols, d0->baseline, d0->K.f0, d0->huber_delta, d0->lambda,
+    c->waiting = false;
+    hipLaunchKernelGGL(depth_lm_step_batch_kernel, dim3(kDlmBlocks, (int)c->ids.size()), dim3(kDlmBlock), 0, s,
+                       (const BatchSeq*)c->d_tab, c->k, b->p.cols, d0->baseline, d0->K.f0, d0->huber_delta, d0->lambda,
                        d0->precision, d0->max_iters);
-    b->dk++;
-    b->dn_launches++;
+    c->k++;
+    c->n_launches++;
     return;
   }
-  if (batch_depth_tail(b, s)) b->derr = 1;
+  if (batch_chain_tail(b, c, s)) { c->err = 1; c->stage = 0; }
 }
 
-// Waits for every slot's completion word (bounded), takes the statistics. ok[e] = 0 when ComputeDepth failed for ids[e].
-static int batch_depth_finish(odo_tracker_batch* b, int* ok) {
+// A whole chain on the calling thread: front, depth-LM launches, tail, then the wait for every slot's completion word (bounded)
+// and a copy of the statistics. The results stay in the chain until batch_chain_absorb.
+static int batch_chain_run(odo_tracker_batch* b, BatchChain* c) {
   hipStream_t s = b->overlap ? b->ctx_b->stream : b->ctx_a->stream;
+  if (batch_chain_begin(b, c, s)) { c->err = 1; c->stage = 3; c->complete.store(1, std::memory_order_release); return -1; }
+  while (c->stage == 1) batch_chain_pump(b, c, s);
+  if (c->stage != 2) { c->stage = 3; c->complete.store(1, std::memory_order_release); return c->err ? -1 : 0; }
   const auto t0 = std::chrono::steady_clock::now();
-  for (int i : b->ids) {
+  for (int i : c->ids) {
     odo_depth* d = b->depth[i];
     volatile int* done = d->h_prog + 4;
     while (done[0] != d->token) {
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) { HIP_OK(hipStreamSynchronize(s)); break; }
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) { (void)hipStreamSynchronize(s); break; }
     }
   }
   std::atomic_thread_fence(std::memory_order_acquire);
-  for (size_t e = 0; e < b->ids.size(); e++) {
-    const int i = b->ids[e];
-    odo_depth* d = b->depth[i];
-    d->last = *d->h_stats;
-    ok[e] = d->last.status == 0;
-    b->last_valid[i] = d->last.n_valid;
-    b->last_depth_iters[i] = d->last.iters;
+  for (size_t e = 0; e < c->ids.size(); e++) c->stats[e] = *b->depth[c->ids[e]]->h_stats;
+  c->stage = 3;
+  c->complete.store(1, std::memory_order_release);
+  return 0;
+}
+
+// Helper thread: runs the posted chains in order.
+static void batch_worker_main(odo_tracker_batch* b) {
+  (void)hipSetDevice(b->ctx_b->device);
+  int idle_spins = 0;
+  for (;;) {
+    const long done = b->w_done.load(std::memory_order_relaxed);
+    if (b->w_posted.load(std::memory_order_acquire) <= done) {
+      if (b->w_quit.load(std::memory_order_acquire)) return;
+      if (++idle_spins > 20000000) std::this_thread::sleep_for(std::chrono::microseconds(200));
+      continue;
+    }
+    idle_spins = 0;
+    (void)batch_chain_run(b, b->w_ring[done & 1]);
+    b->w_done.store(done + 1, std::memory_order_release);
+  }
+}
+// Hands a chain to the helper thread (or runs it right here when there is none). At most two may be outstanding.
+static void batch_chain_post(odo_tracker_batch* b, BatchChain* c) {
+  c->complete.store(0, std::memory_order_relaxed);
+  if (!b->worker.joinable()) { (void)batch_chain_run(b, c); return; }
+  const long n = b->w_posted.load(std::memory_order_relaxed);
+  b->w_ring[n & 1] = c;
+  b->w_posted.store(n + 1, std::memory_order_release);
+}
+// Waits until the helper thread has run everything posted so far (bounded).
+static int batch_wait_chains(odo_tracker_batch* b) {
+  if (!b->worker.joinable()) return 0;
+  const long posted = b->w_posted.load(std::memory_order_acquire);
+  const auto q0 = std::chrono::steady_clock::now();
+  long spins = 0;
+  while (b->w_done.load(std::memory_order_acquire) < posted) {
+    if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - q0 > std::chrono::seconds(10))
+      return fail("    depth failed! (the depth stream's helper thread did not finish within 10 s)");
   }
   return 0;
 }
 
-// The candidate lists built for slot i this step become its keyframe lists.
-static void batch_adopt(odo_tracker_batch* b, int i) {
-  odo_lm* m = b->lm[i];
-  memcpy(m->cand[0].h_npts, b->h_cand_npts + (size_t)i * ODO_MAX_LEVELS, sizeof(int) * ODO_MAX_LEVELS);
-  (void)lm_adopt_candidate(m, b->kf_img[i], b->kf_dep[i], b->frame_id[i]);  // 1 = no candidate: the Solve builds the lists
+// Takes a complete chain's results over: per slot the parity, status, statistics, the pair the job was computed from, the
+// candidate lists' per-level counts. Called by the thread that owns the tracker state, never by the helper.
+static int batch_chain_absorb(odo_tracker_batch* b, BatchChain* c) {
+  if (c->stage != 3) return 0;
+  c->stage = 0;
+  if (c->err) return -1;
+  for (size_t e = 0; e < c->ids.size(); e++) {
+    const int i = c->ids[e];
+    b->depth[i]->last = c->stats[e];
+    b->res_par[i] = c->par[e];
+    b->res_ok[i] = c->stats[e].status == 0;
+    b->res_left[i] = c->left[i]; b->res_right[i] = c->right[i];
+    b->res_tag[i] = c->tag[e];
+    memcpy(b->lm[i]->cand[c->par[e]].h_npts, b->h_cand_npts + ((size_t)i * 2 + c->par[e]) * ODO_MAX_LEVELS, sizeof(int) * ODO_MAX_LEVELS);
+  }
+  return 0;
+}
+
+// Sets a chain up for the listed slots (the job itself is described by the caller through the fields set here).
+static void batch_chain_fill(odo_tracker_batch* b, BatchChain* c, const std::vector<int>& ids, const float* const* left,
+                             const float* const* right, bool first, bool img_is_next, int tag_add, hipEvent_t img_ready) {
+  c->ids = ids;
+  c->left.assign(b->S, nullptr); c->right.assign(b->S, nullptr);
+  for (int i : ids) { c->left[i] = left[i]; c->right[i] = right[i]; }
+  c->first = first; c->img_is_next = img_is_next; c->tag_add = tag_add; c->img_ready = img_ready;
+  c->with_lists = b->with_lists;
+  c->err = 0;
+}
+
+// Everything the helper thread has been given is run to completion and taken over (a chain posted ahead keeps its results
+// with its slots), and the device is quiet afterwards.
+static int batch_quiesce(odo_tracker_batch* b) {
+  if (batch_wait_chains(b)) return -1;
+  (void)batch_chain_absorb(b, &b->late);
+  (void)batch_chain_absorb(b, &b->ahead);
+  for (odo_ctx* c : {b->ctx_a, b->ctx_b, b->ctx_c}) HIP_OK(hipStreamSynchronize(c->stream));
+  return 0;
 }
 
 // Frame 0 of the slots in b->ids (ref: :95-145).
 static int batch_init_set(odo_tracker_batch* b, const float* const* left_dev, const float* const* right_dev,
                           const float* abs_pose0) {
   HIP_OK(hipSetDevice(b->ctx_a->device));
-  // stragglers of the previous step (LM launches queued ahead) may still run on stream A; the keyframe buffers are rewritten now
-  HIP_OK(hipStreamSynchronize(b->ctx_a->stream));
-  HIP_OK(hipStreamSynchronize(b->ctx_b->stream));
+  if (batch_quiesce(b)) return -1;
   const odo_tracker_params& p = b->p;
   const int n = (int)b->ids.size();
   if (n == 0) return 0;
   b->with_lists = !getenv("ODO_NO_CAND_LISTS");
   for (int i : b->ids) {
-    b->frame_id[i] = 0; b->alive[i] = 0; b->hint_next[i] = b->prefetched[i] = nullptr;
-    b->kf_img[i]->version = ++g_pyr_version;
+    b->frame_id[i] = 0; b->alive[i] = 0; b->hint_next[i] = b->hint_next_right[i] = b->prefetched[i] = nullptr;
+    b->res_left[i] = b->res_right[i] = nullptr;
   }
-  if (batch_upload_table(b, left_dev, right_dev, true)) return -1;
   hipStream_t sa = b->ctx_a->stream;
-  hipStream_t sb = b->overlap ? b->ctx_b->stream : sa;
-  hipLaunchKernelGGL(image_pyramid_batch_kernel, batch_pyr_grid(b, n), dim3(kPyrThreads), 0, sa, (const BatchSeq*)b->d_tab);  // :130
+  std::vector<const float*> src(left_dev, left_dev + b->S);
+  if (batch_build_pyramids(b, b->ids, src, b->kf_img, 0, sa)) return -1;                  // :130
   HIP_OK(hipEventRecord(b->ev_cur_img, sa));
-  if (sb != sa) HIP_OK(hipStreamWaitEvent(sb, b->ev_tab, 0));
-  if (batch_depth_begin(b, sb)) return -1;                                                // :102
-  while (b->dstage == 1) batch_depth_pump(b);
-  if (b->derr) { b->dstage = 0; return -1; }
-  std::vector<int> ok(n, 0);
-  if (batch_depth_finish(b, ok.data())) return -1;
+  BatchChain* c = &b->late;
+  batch_chain_fill(b, c, b->ids, left_dev, right_dev, true, false, 0, b->ev_cur_img);
+  if (batch_chain_run(b, c)) return -1;                                                  // :102 (on this thread: nothing to overlap)
+  if (batch_chain_absorb(b, c)) return -1;
   HIP_OK(hipStreamSynchronize(sa));
-  b->dstage = 0;
   const float eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   int bad = -1;
-  for (int e = 0; e < n; e++) {
-    const int i = b->ids[e];
+  for (int i : b->ids) {
     const float* a0 = abs_pose0 ? abs_pose0 + 16 * (size_t)i : eye;
     memcpy(&b->kf_abs[16 * (size_t)i], a0, sizeof(float) * 16);        // :143
     memcpy(&b->pose_to_kf[16 * (size_t)i], a0, sizeof(float) * 16);    // :98
     odo_lm_reset(b->lm[i], eye, p.lm_lambda);                          // :77-81
     b->lm[i]->kf_img_ver = b->lm[i]->kf_dep_ver = 0;
     b->n_keyframes[i] = 1;
-    b->alive[i] = ok[e];
-    if (!ok[e] && bad < 0) bad = i;
-    if (ok[e] && b->with_lists) batch_adopt(b, i);
+    b->alive[i] = b->res_ok[i];
+    b->last_valid[i] = b->depth[i]->last.n_valid;
+    b->last_depth_iters[i] = b->depth[i]->last.iters;
+    if (!b->res_ok[i] && bad < 0) bad = i;
+    b->out_par[i] = b->res_par[i];
+    if (b->res_ok[i]) {
+      const int par = b->res_par[i];
+      std::swap(b->kf_dep[i], b->pre_dep[par][i]);                     // :141: the frame's depth pyramid is the keyframe's
+      if (b->with_lists) (void)lm_adopt_candidate(b->lm[i], b->kf_img[i], b->kf_dep[i], 0, par);
+    }
+    b->res_left[i] = b->res_right[i] = nullptr;
   }
   if (bad >= 0) return fail("Init 0-th frame failed! (sequence %d: number of valid after optimization is too small: %d)", bad,
                             b->last_valid[bad]);                       // :103-106
@@ -439,11 +585,22 @@ extern "C" int odo_tracker_batch_init_one(odo_tracker_batch* b, int slot, const 
   return batch_init_set(b, l.data(), r.data(), abs_pose0 ? a0.data() : nullptr);
 }
 
-// Optional: the left images of the NEXT step (NULL entries allowed). Their pyramids are built at the end of the current step
-// on the pose-LM stream, which is idle while the depth stream finishes, instead of at the head of the next step.
+// Optional: the left images of the NEXT step (NULL entries allowed). Their pyramids are built during the current step on a
+// stream of their own instead of at the head of the next step.
 extern "C" int odo_tracker_batch_hint_next(odo_tracker_batch* b, const float* const* next_left_dev) {
   if (!b) return fail("NULL batch tracker");
-  for (int i = 0; i < b->S; i++) b->hint_next[i] = next_left_dev ? next_left_dev[i] : nullptr;
+  for (int i = 0; i < b->S; i++) { b->hint_next[i] = next_left_dev ? next_left_dev[i] : nullptr; b->hint_next_right[i] = nullptr; }
+  return 0;
+}
+// The same with the right images: the next step's ComputeDepth + depth pyramids + candidate lists (they depend on the images
+// only) are enqueued a step early as well, so the depth stream works a step ahead of the pose LM.
+extern "C" int odo_tracker_batch_hint_next_pair(odo_tracker_batch* b, const float* const* next_left_dev,
+                                                const float* const* next_right_dev) {
+  if (!b) return fail("NULL batch tracker");
+  for (int i = 0; i < b->S; i++) {
+    b->hint_next[i] = next_left_dev ? next_left_dev[i] : nullptr;
+    b->hint_next_right[i] = (b->hint_next[i] && next_right_dev) ? next_right_dev[i] : nullptr;
+  }
   return 0;
 }
 
@@ -469,69 +626,69 @@ extern "C" int odo_tracker_batch_track(odo_tracker_batch* b, const float* const*
     b->ids.push_back(i);
   }
   const int n = (int)b->ids.size();
-  if (n == 0) return 0;
   b->with_lists = !getenv("ODO_NO_CAND_LISTS");
-  // slots whose pyramid was prefetched at the end of the last step take it; the others get theirs built now
-  std::vector<int> build;
-  for (int i : b->ids) {
-    b->frame_id[i]++;
-    if (b->prefetched[i] && b->prefetched[i] == left_dev[i]) std::swap(b->cur_img[i], b->next_img[i]);
-    else { build.push_back(i); b->cur_img[i]->version = ++g_pyr_version; }
-    b->prefetched[i] = nullptr;
-  }
-  if (batch_upload_table(b, left_dev, right_dev, false)) return -1;
   hipStream_t sa = b->ctx_a->stream;
   hipStream_t sb = b->overlap ? b->ctx_b->stream : sa;
-  if ((int)build.size() == n) {
-    hipLaunchKernelGGL(image_pyramid_batch_kernel, batch_pyr_grid(b, n), dim3(kPyrThreads), 0, sa, (const BatchSeq*)b->d_tab);  // :205
-  } else if (!build.empty()) {
-    // a mix (some slots were hinted, some not): the stragglers one launch each, through the step's own table entries
-    for (size_t e = 0; e < b->ids.size(); e++)
-      for (int i : build)
-        if (b->ids[e] == i)
-          hipLaunchKernelGGL(image_pyramid_batch_kernel, batch_pyr_grid(b, 1), dim3(kPyrThreads), 0, sa, (const BatchSeq*)b->d_tab + e);
+  hipStream_t sc = b->ctx_c->stream;
+  // ---- the chain posted a step ago for the frames announced then: normally complete long ago (it had the whole previous
+  // step). Its results stay with their slots whether or not the announced pair is the one that came.
+  if (batch_wait_chains(b)) return -1;
+  (void)batch_chain_absorb(b, &b->late);
+  if (batch_chain_absorb(b, &b->ahead)) return -1;
+  if (n == 0) return 0;
+  // ---- image pyramids of this step: prefetched during the last step (stream C), or built now (stream A)
+  std::vector<int> build;
+  bool any_prefetched = false;
+  for (int i : b->ids) {
+    b->frame_id[i]++;
+    if (b->prefetched[i] && b->prefetched[i] == left_dev[i]) { std::swap(b->cur_img[i], b->next_img[i]); any_prefetched = true; }
+    else build.push_back(i);
+    b->prefetched[i] = nullptr;
+  }
+  if (any_prefetched) HIP_OK(hipStreamWaitEvent(sa, b->ev_next, 0));
+  {
+    std::vector<const float*> src(left_dev, left_dev + S);
+    if (batch_build_pyramids(b, build, src, b->cur_img, 0, sa)) return -1;               // :205
   }
   HIP_OK(hipEventRecord(b->ev_cur_img, sa));
-  if (b->overlap) {
-    HIP_OK(hipStreamWaitEvent(sb, b->ev_tab, 0));
-    if (batch_depth_begin(b, sb)) return -1;                                              // :226 beside the Solve
+  // ---- stream B, this step's frames: slots whose collected job is not for this pair get one now (beside the Solve, :226)
+  BatchChain* late = &b->late;
+  {
+    std::vector<int> need;
+    for (int i : b->ids)
+      if (!(b->res_left[i] == left_dev[i] && b->res_right[i] == right_dev[i] && b->res_tag[i] == b->frame_id[i])) need.push_back(i);
+    batch_chain_fill(b, late, need, left_dev, right_dev, false, false, 0, b->ev_cur_img);
   }
+  const bool late_now = b->overlap != 0;
+  if (late_now && !late->ids.empty()) batch_chain_post(b, late);
+  // ---- the next step: pyramids on stream C; announced pairs get their stream-B job now, behind this step's (the helper runs
+  // the chains one after the other: a slot's depth object serves one job at a time)
+  std::vector<int> nxt, nxt_pair;
+  for (int i = 0; i < S; i++) {
+    if (!b->hint_next[i] || !b->alive[i]) continue;
+    nxt.push_back(i);
+    if (b->hint_next_right[i] && b->depth_ahead) nxt_pair.push_back(i);
+  }
+  if (!nxt.empty()) {
+    if (batch_build_pyramids(b, nxt, b->hint_next, b->next_img, S, sc)) return -1;
+    HIP_OK(hipEventRecord(b->ev_next, sc));
+    for (int i : nxt) b->prefetched[i] = b->hint_next[i];
+  }
+  BatchChain* ahead = &b->ahead;
+  batch_chain_fill(b, ahead, nxt_pair, b->hint_next.data(), b->hint_next_right.data(), false, true, 1, b->ev_next);
+  if (!ahead->ids.empty()) batch_chain_post(b, ahead);
+  for (int i = 0; i < S; i++) b->hint_next[i] = b->hint_next_right[i] = nullptr;
+  // ---- pose LM of this step (stream A), the chains' launches pumped from its wait loops
   std::vector<float> T((size_t)n * 16);
   std::vector<int> st(n, 0);
   std::vector<odo_lm*> lms(n);
   std::vector<const odo_pyr*> kfi(n), kfd(n), cur(n);
   for (int e = 0; e < n; e++) { const int i = b->ids[e]; lms[e] = b->lm[i]; kfi[e] = b->kf_img[i]; kfd[e] = b->kf_dep[i]; cur[e] = b->cur_img[i]; }
   const auto f1 = std::chrono::steady_clock::now();
-  if (lm_solve_batch(n, lms.data(), kfi.data(), kfd.data(), cur.data(), T.data(), st.data(),
-                     b->overlap ? batch_depth_pump : nullptr, b) < 0) {                    // :215
-    while (b->dstage == 1) batch_depth_pump(b);
-    std::vector<int> okd(n, 0);
-    if (b->dstage == 2) (void)batch_depth_finish(b, okd.data());
-    b->dstage = 0;
-    return -1;
-  }
+  const int lm_rc = lm_solve_batch(n, lms.data(), kfi.data(), kfd.data(), cur.data(), T.data(), st.data(), nullptr, nullptr);  // :215
   const auto f2 = std::chrono::steady_clock::now();
-  // the next step's pyramids, on stream A behind the Solve (it is idle until the next step; the depth stream is still busy)
-  {
-    int m = 0;
-    for (int i = 0; i < S; i++) {
-      if (!b->hint_next[i]) continue;
-      BatchSeq& q = b->h_tab[S + m];
-      memset(&q, 0, sizeof(q));
-      q.left = b->hint_next[i];
-      q.cur_img = batch_pyr_out(b->next_img[i], p.smooth_image);
-      b->next_img[i]->version = ++g_pyr_version;
-      b->prefetched[i] = b->hint_next[i];
-      b->hint_next[i] = nullptr;
-      m++;
-    }
-    if (m > 0) {
-      HIP_OK(hipMemcpyAsync(b->d_tab + S, b->h_tab + S, sizeof(BatchSeq) * (size_t)m, hipMemcpyHostToDevice, sa));
-      hipLaunchKernelGGL(image_pyramid_batch_kernel, batch_pyr_grid(b, m), dim3(kPyrThreads), 0, sa, (const BatchSeq*)(b->d_tab + S));
-    }
-  }
-  if (!b->overlap && batch_depth_begin(b, sb)) return -1;
-  while (b->dstage == 1) batch_depth_pump(b);
+  if (!late_now && !late->ids.empty()) batch_chain_post(b, late);   // program order: runs right here
+  if (lm_rc < 0) return -1;
   // :218 — poses are stored before the depth result is known
   std::vector<float> curp((size_t)n * 16);
   for (int e = 0; e < n; e++) {
@@ -544,16 +701,28 @@ extern "C" int odo_tracker_batch_track(odo_tracker_batch* b, const float* const*
     if (pose_to_keyframe) memcpy(pose_to_keyframe + 16 * (size_t)i, Ti, sizeof(float) * 16);
     if (abs_pose) memcpy(abs_pose + 16 * (size_t)i, &curp[16 * (size_t)e], sizeof(float) * 16);
   }
-  if (b->derr) { b->dstage = 0; return -1; }
-  std::vector<int> okd(n, 0);
-  if (batch_depth_finish(b, okd.data())) return -1;
+  // this step's depth results: the late chain is in front of the ahead chain in the helper's queue
+  if (!late->ids.empty()) {
+    if (b->worker.joinable()) {
+      const auto q0 = std::chrono::steady_clock::now();
+      long spins = 0;
+      while (!late->complete.load(std::memory_order_acquire)) {
+        if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - q0 > std::chrono::seconds(10))
+          return fail("    depth failed! (the depth stream's helper thread did not finish within 10 s)");
+      }
+    }
+    if (batch_chain_absorb(b, late)) return -1;
+  }
   const auto f3 = std::chrono::steady_clock::now();
-  b->dstage = 0;
   int any_depth_fail = 0;
   for (int e = 0; e < n; e++) {
     const int i = b->ids[e];
+    const int par = b->res_par[i];
+    b->out_par[i] = par;
     b->last_evals[i] = b->lm[i]->last_evals;
-    if (!okd[e]) { status[i] = -1; b->alive[i] = 0; any_depth_fail = 1; continue; }        // :230-232
+    b->last_valid[i] = b->depth[i]->last.n_valid;   // NB: of the slot's latest collected job (this frame's)
+    b->last_depth_iters[i] = b->depth[i]->last.iters;
+    if (!b->res_ok[i]) { status[i] = -1; b->alive[i] = 0; any_depth_fail = 1; continue; }  // :230-232
     const float* Ti = &T[16 * (size_t)e];
     float ang[3];
     motion_angles(Ti, ang);                                                                // :253
@@ -562,11 +731,11 @@ extern "C" int odo_tracker_batch_track(odo_tracker_batch* b, const float* const*
     for (int k = 0; k < 6; k++) mag += mot[k] * p.keyframe_weight[k];                       // :257
     if (mag > p.keyframe_motion_th) {                                                      // :258
       std::swap(b->kf_img[i], b->cur_img[i]);                                              // :259 (the :251 rebuild has the same content)
-      std::swap(b->kf_dep[i], b->pre_dep[i]);
+      std::swap(b->kf_dep[i], b->pre_dep[par][i]);
       memcpy(&b->kf_abs[16 * (size_t)i], &curp[16 * (size_t)e], sizeof(float) * 16);       // :260
       b->n_keyframes[i]++;
       if (is_new_keyframe) is_new_keyframe[i] = 1;
-      if (b->with_lists) batch_adopt(b, i);
+      if (b->with_lists) (void)lm_adopt_candidate(b->lm[i], b->kf_img[i], b->kf_dep[i], b->frame_id[i], par);
     }
     odo_lm_reset(b->lm[i], Ti, 0.01f);                                                     // :261 / :268
     if (motion_mag) motion_mag[i] = mag;
@@ -581,8 +750,8 @@ extern "C" int odo_tracker_batch_track(odo_tracker_batch* b, const float* const*
   return 0;
 }
 
-// Host-clock averages per lock step since the last call (microseconds): whole call, head (table + pyramid launches), the
-// batched Solve (depth launches are pumped from its wait loops), the wait for the depth chain after the Solve.
+// Host-clock averages per lock step since the last call (microseconds): whole call, head (tables + pyramid + chain fronts), the
+// batched Solve (depth launches are pumped from its wait loops), the wait for this step's depth chain after the Solve.
 extern "C" int odo_tracker_batch_timing(odo_tracker_batch* b, double out[4]) {
   if (!b || !out) return fail("NULL arg");
   const double n = b->tm_frames > 0 ? (double)b->tm_frames : 1.0;
@@ -604,9 +773,10 @@ extern "C" int odo_tracker_batch_stats(const odo_tracker_batch* b, int* lm_evals
 extern "C" int odo_tracker_batch_outputs(const odo_tracker_batch* b, int seq, const uint8_t** val, const float** disp,
                                          const float** dep) {
   if (!b || seq < 0 || seq >= b->S) return fail("odo_tracker_batch_outputs: bad arg");
-  if (val) *val = b->d_val[seq];
-  if (disp) *disp = b->d_disp[seq];
-  if (dep) *dep = b->d_dep[seq];
+  const int par = b->out_par[seq];
+  if (val) *val = b->d_val[par][seq];
+  if (disp) *disp = b->d_disp[par][seq];
+  if (dep) *dep = b->d_dep[par][seq];
   return 0;
 }
 extern "C" int odo_tracker_batch_size(const odo_tracker_batch* b) { return b ? b->S : 0; }

@@ -112,8 +112,8 @@ def _track_single(api, seq, n_frames):
     return out, maps
 
 
-@pytest.mark.parametrize("n_seq,overlap", [(1, 2), (3, 2), (3, 0)])
-def test_batched_tracker_is_bit_identical_to_separate_trackers(api, drives, n_seq, overlap):
+@pytest.mark.parametrize("n_seq,overlap,pairs", [(1, 2, False), (3, 2, False), (3, 0, False), (3, 2, True), (1, 2, True), (3, 0, True)])
+def test_batched_tracker_is_bit_identical_to_separate_trackers(api, drives, n_seq, overlap, pairs):
     n_frames = 11
     seqs = drives[:n_seq]
     singles = [_track_single(api, s, n_frames) for s in seqs]
@@ -123,6 +123,8 @@ def test_batched_tracker_is_bit_identical_to_separate_trackers(api, drives, n_se
     R = [[tb.upload_frame(f) for f in s["right"][:n_frames]] for s in seqs]
     tb.init([L[i][0] for i in range(n_seq)], [R[i][0] for i in range(n_seq)])
     for k in range(1, n_frames):
+        if pairs and k + 1 < n_frames:   # the next pair announced: pyramids prefetched, the depth stream a step ahead
+            tb.hint_next([L[i][k + 1] for i in range(n_seq)], [R[i][k + 1] for i in range(n_seq)])
         res = tb.track([L[i][k] for i in range(n_seq)], [R[i][k] for i in range(n_seq)])
         st = tb.stats()
         for i in range(n_seq):
@@ -168,7 +170,8 @@ def test_batched_tracker_restart_and_stopped_sequence(api, drives):
     tb.close()
 
 
-def test_batched_tracker_slots_of_different_lengths_and_hints(api, drives):
+@pytest.mark.parametrize("pairs", [False, True])
+def test_batched_tracker_slots_of_different_lengths_and_hints(api, drives, pairs):
     """Slots are independent: one sits steps out (no frame given), one is restarted on a new sequence while the others run
     on (init_one), next-frame hints move the pyramid builds earlier — none of it changes any sequence's results."""
     n_frames = 8
@@ -192,14 +195,25 @@ def test_batched_tracker_slots_of_different_lengths_and_hints(api, drives):
             frames[i] = k if (k is not None and k < n_frames and not pause) else None
         lefts = [L[i][frames[i]] if frames[i] is not None else None for i in range(3)]
         rights = [R[i][frames[i]] if frames[i] is not None else None for i in range(3)]
-        if step % 2 == 0:       # hints on every other step only; slot 2's hint is wrong on purpose at step 4 (ignored: pointer differs)
+        if step % 2 == 0 or (pairs and step >= 7):       # hints on every other step, later on every step; slot 2's hint is wrong on purpose at step 4 (ignored: pointer differs)
             hint = []
             for i in range(3):
                 k = frames[i]
                 hint.append(L[i][k + 1] if (k is not None and k + 1 < n_frames) else None)
             if step == 4:
                 hint[2] = L[2][0]
-            tb.hint_next(hint)
+            if pairs:       # the depth stream a step ahead; slot 0's right image is wrong on purpose at step 6
+                hr = []
+                for i in range(3):
+                    k = frames[i]
+                    hr.append(R[i][k + 1] if (k is not None and k + 1 < n_frames) else None)
+                if step == 4:
+                    hr[2] = R[2][0]
+                if step == 6 and hr[0] is not None:
+                    hr[0] = R[0][0]
+                tb.hint_next(hint, hr)
+            else:
+                tb.hint_next(hint)
         res = tb.track(lefts, rights)
         for i in range(3):
             if frames[i] is None:

@@ -50,7 +50,7 @@ def main():
                 _lib.check(tb.lib.odo_tracker_batch_init(tb.h, lp[0], rp[0], None), "init")
                 for k in range(1, n_frames):
                     if hint and k + 1 < n_frames:
-                        tb.hint_next(lp[k + 1])
+                        tb.hint_next(lp[k + 1], rp[k + 1])
                     tb.track_raw(lp[k], rp[k])
                     if rep == 0:
                         evals.append([s["lm_evals"] for s in tb.stats()])

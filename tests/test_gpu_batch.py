@@ -321,3 +321,60 @@ def test_solve_begin_then_solve_equals_solve(api, kitti_seq):
     assert lt.SolveBegin(pyr[0], dep[0], pyr[1]) == 1
     for o in (ref, lm, lt):
         o.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_batched_tracker_random_schedule(api, drives, seed):
+    """Property: whatever the schedule — slots pausing at random, announcements (left only / pair) that are right, wrong or
+    missing, a slot restarted in the middle (init_one) — every sequence's poses and keyframe decisions are those of its own
+    single tracker."""
+    rng = np.random.default_rng(seed)
+    n_frames = 9
+    refs = [_track_single(api, s, n_frames)[0] for s in drives]
+    tb = api.TrackerBatch(3)
+    L = [[tb.upload_frame(f) for f in s["left"][:n_frames]] for s in drives]
+    R = [[tb.upload_frame(f) for f in s["right"][:n_frames]] for s in drives]
+    tb.init([L[i][0] for i in range(3)], [R[i][0] for i in range(3)])
+    nxt = [1, 1, 1]
+    got = [[], [], []]
+    restarted = False
+    for step in range(60):
+        if all(k >= n_frames for k in nxt):
+            break
+        if not restarted and step == 5:          # slot 1 starts its sequence over
+            tb.init_one(1, L[1][0], R[1][0])
+            nxt[1], got[1], restarted = 1, [], True
+        go = [nxt[i] < n_frames and rng.random() < 0.75 for i in range(3)]
+        if not any(go):
+            continue
+        lefts = [L[i][nxt[i]] if go[i] else None for i in range(3)]
+        rights = [R[i][nxt[i]] if go[i] else None for i in range(3)]
+        mode = rng.integers(0, 4)                # 0 none, 1 left only, 2 pair, 3 pair with errors
+        if mode:
+            hl, hr = [], []
+            for i in range(3):
+                k = nxt[i] + (1 if go[i] else 0)  # the frame the slot tracks next time
+                ok = k < n_frames
+                hl.append(L[i][k] if ok else None)
+                hr.append(R[i][k] if ok else None)
+                if mode == 3 and ok and rng.random() < 0.5:
+                    if rng.random() < 0.5:
+                        hl[i] = L[i][0]
+                    else:
+                        hr[i] = R[i][0]
+            tb.hint_next(hl, hr if mode >= 2 else None)
+        res = tb.track(lefts, rights)
+        for i in range(3):
+            if go[i]:
+                assert res[i]["status"] == 0, (step, i)
+                got[i].append(res[i])
+                nxt[i] += 1
+            else:
+                assert res[i]["status"] == -3
+    for i in range(3):
+        assert len(got[i]) == n_frames - 1
+        for k, (a, r) in enumerate(zip(got[i], refs[i])):
+            assert np.array_equal(a["pose_to_keyframe"], r["pose_to_keyframe"]), (i, k)
+            assert np.array_equal(a["abs_pose"], r["abs_pose"]), (i, k)
+            assert a["new_keyframe"] == r["new_keyframe"], (i, k)
+    tb.close()

@@ -378,3 +378,41 @@ def test_batched_tracker_random_schedule(api, drives, seed):
             assert np.array_equal(a["abs_pose"], r["abs_pose"]), (i, k)
             assert a["new_keyframe"] == r["new_keyframe"], (i, k)
     tb.close()
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_tracker_random_announcements(api, drives, seed):
+    """Property for the single tracker: random announcements (none / left / pair, right or wrong) and a re-initialisation at a
+    random frame never change poses, keyframe decisions, depth statistics or depth maps."""
+    rng = np.random.default_rng(seed)
+    seq = drives[seed % 3]
+    n = 11
+    plain, _ = _track_single(api, seq, n)
+    trk = api.Tracker(0)
+    dev = [(trk.upload_frame(l), trk.upload_frame(r)) for l, r in zip(seq["left"][:n], seq["right"][:n])]
+    reinit_at = int(rng.integers(3, 8))
+    for rep in range(2):
+        trk.init(*dev[0])
+        for k in range(1, n):
+            mode = rng.integers(0, 5)        # 0 none, 1 left, 2 pair, 3 wrong left, 4 wrong right
+            j = min(k + 1, n - 1)
+            if mode == 1:
+                trk.hint_next(dev[j][0])
+            elif mode == 2:
+                trk.hint_next(dev[j][0], dev[j][1])
+            elif mode == 3:
+                trk.hint_next(dev[0][0], dev[j][1])
+            elif mode == 4:
+                trk.hint_next(dev[j][0], dev[0][1])
+            r = trk.track(*dev[k])
+            ref = plain[k - 1]
+            assert np.array_equal(r["pose_to_keyframe"], ref["pose_to_keyframe"]), (rep, k)
+            assert np.array_equal(r["abs_pose"], ref["abs_pose"]), (rep, k)
+            assert r["new_keyframe"] == ref["new_keyframe"] and trk.stats() == ref["stats"], (rep, k)
+            if rep == 0 and k == reinit_at:
+                break                        # the sequence is started over in the middle of the announcements
+    maps = trk.outputs(*seq["left"][0].shape)
+    trk.close()
+    ref_maps = _track_single(api, seq, n)[1]
+    for a, b in zip(maps, ref_maps):
+        assert np.array_equal(a, b)

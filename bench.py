@@ -729,6 +729,12 @@ def main():
                    lm_evals_per_frame=round(float(np.mean(evals)), 2),
                    host_us_per_frame={k: round(v, 1) for k, v in host_timing.items()},
                    keyframes=trk.stats()["n_keyframes"])
+        if args.sequences == 0 and n_total > args.unique_frames - 1:
+            # determinism of the timed run: every later pass over the drive (re-initialised on frame 0) repeats the first one
+            per = args.unique_frames - 1
+            same = all(np.array_equal(poses_kf[0, k], poses_kf[0, k % per]) and np.array_equal(poses_abs[0, k], poses_abs[0, k % per])
+                       for k in range(per, n_total))
+            out["timed_run_passes_repeat_bit_for_bit"] = bool(same)
         if gatherer is not None:
             # the exchange itself, checked: every rank's rows arrived on rank 0, and rank 0's own rows are the poses it tracked
             got = [int(gatherer.rows(r).shape[0]) for r in range(world)]

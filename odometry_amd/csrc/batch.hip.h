@@ -38,9 +38,13 @@ struct BatchSeq {
   PointList pl[ODO_MAX_LEVELS_K];
 };
 
-__global__ void __launch_bounds__(kPyrThreads) image_pyramid_batch_kernel(const BatchSeq* __restrict__ tab) {
+#ifndef ODO_BATCH_PYR_THREADS
+#define ODO_BATCH_PYR_THREADS 256
+#endif
+constexpr int kBatchPyrThreads = ODO_BATCH_PYR_THREADS;
+__global__ void __launch_bounds__(kBatchPyrThreads) image_pyramid_batch_kernel(const BatchSeq* __restrict__ tab) {
   const BatchSeq& q = tab[blockIdx.z];
-  image_pyramid_fused_kernel_body(q.left, q.cur_img);
+  image_pyramid_fused_kernel_body<kBatchPyrThreads>(q.left, q.cur_img);
 }
 __global__ void __launch_bounds__(256) depth_pyramid_batch_kernel(const BatchSeq* __restrict__ tab) {
   const BatchSeq& q = tab[blockIdx.z];
@@ -299,7 +303,7 @@ static int batch_build_pyramids(odo_tracker_batch* b, const std::vector<int>& sl
     dst[i]->version = ++g_pyr_version;
   }
   HIP_OK(hipMemcpyAsync(b->d_pyr + row0, b->h_pyr + row0, sizeof(BatchSeq) * (size_t)n, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(image_pyramid_batch_kernel, batch_pyr_grid(b, n), dim3(kPyrThreads), 0, s, (const BatchSeq*)(b->d_pyr + row0));
+  hipLaunchKernelGGL(image_pyramid_batch_kernel, batch_pyr_grid(b, n), dim3(kBatchPyrThreads), 0, s, (const BatchSeq*)(b->d_pyr + row0));
   HIP_OK(hipGetLastError());
   return 0;
 }

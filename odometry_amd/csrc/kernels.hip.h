@@ -110,6 +110,9 @@ __device__ __forceinline__ float pd_v(float r0, float r1, float r2, float r3, fl
 }
 
 constexpr int kPyrThreads = 1024;  // the phases are short dependent LDS passes: more threads = fewer trips per thread
+// kThreads: 1 024 for one frame (short dependent LDS passes: more threads = fewer trips per thread, lowest latency); the batched
+// tracker, whose launches carry many frames, uses fewer threads per tile so that more tiles are resident per CU (throughput).
+template <int kThreads>
 __device__ __forceinline__ void image_pyramid_fused_kernel_body(const float* __restrict__ src, PyrOut o) {
   __shared__ float in_t[kPIn * kPInS];
   __shared__ float h_t[kPIn * kPL1];   // horizontal pass (reused per level)
@@ -119,13 +122,13 @@ __device__ __forceinline__ void image_pyramid_fused_kernel_body(const float* __r
   const int ty = blockIdx.y, tx = blockIdx.x;
   const int R0 = o.rows[0], C0 = o.cols[0];
   const int iy0 = kPT * ty - 14, ix0 = kPT * tx - 14;  // input halo origin (level-0 coordinates, may be negative)
-  for (int e = t; e < kPIn * kPIn; e += kPyrThreads) {
+  for (int e = t; e < kPIn * kPIn; e += kThreads) {
     const int i = e / kPIn, j = e % kPIn;
     in_t[i * kPInS + j] = src[(size_t)reflect101(iy0 + i, R0) * C0 + reflect101(ix0 + j, C0)];
   }
   __syncthreads();
   // ---- level 0: blur (or copy) of the owned 32x32 ----
-  for (int e = t; e < kPT * kPT; e += kPyrThreads) {
+  for (int e = t; e < kPT * kPT; e += kThreads) {
     const int y = kPT * ty + e / kPT, x = kPT * tx + e % kPT;
     if (y < R0 && x < C0) {
       const int i = y - iy0, j = x - ix0;
@@ -151,7 +154,7 @@ __device__ __forceinline__ void image_pyramid_fused_kernel_body(const float* __r
   const int y1hi = min(16 * ty + 18, R1 - 1), x1hi = min(16 * tx + 18, C1 - 1);
   const int n1y = y1hi - y1lo + 1, n1x = x1hi - x1lo + 1;
   // horizontal pass over every input row of the halo, for the needed L1 columns
-  for (int e = t; e < kPIn * kPL1; e += kPyrThreads) {
+  for (int e = t; e < kPIn * kPL1; e += kThreads) {
     const int i = e / kPL1, jx = e % kPL1;
     if (jx < n1x) {
       const int x1 = x1lo + jx;
@@ -163,7 +166,7 @@ __device__ __forceinline__ void image_pyramid_fused_kernel_body(const float* __r
     }
   }
   __syncthreads();
-  for (int e = t; e < kPL1 * kPL1; e += kPyrThreads) {
+  for (int e = t; e < kPL1 * kPL1; e += kThreads) {
     const int iy = e / kPL1, jx = e % kPL1;
     if (iy < n1y && jx < n1x) {
       const int y1 = y1lo + iy;
@@ -183,7 +186,7 @@ __device__ __forceinline__ void image_pyramid_fused_kernel_body(const float* __r
   const int y2lo = max(8 * ty - 2, 0), x2lo = max(8 * tx - 2, 0);
   const int y2hi = min(8 * ty + 8, R2 - 1), x2hi = min(8 * tx + 8, C2 - 1);
   const int n2y = y2hi - y2lo + 1, n2x = x2hi - x2lo + 1;
-  for (int e = t; e < kPL1 * kPL2; e += kPyrThreads) {  // horizontal pass over L1 halo rows
+  for (int e = t; e < kPL1 * kPL2; e += kThreads) {  // horizontal pass over L1 halo rows
     const int i = e / kPL2, jx = e % kPL2;
     if (i < n1y && jx < n2x) {
       const int x2 = x2lo + jx;
@@ -195,7 +198,7 @@ __device__ __forceinline__ void image_pyramid_fused_kernel_body(const float* __r
     }
   }
   __syncthreads();
-  for (int e = t; e < kPL2 * kPL2; e += kPyrThreads) {
+  for (int e = t; e < kPL2 * kPL2; e += kThreads) {
     const int iy = e / kPL2, jx = e % kPL2;
     if (iy < n2y && jx < n2x) {
       const int y2 = y2lo + iy;
@@ -212,7 +215,7 @@ __device__ __forceinline__ void image_pyramid_fused_kernel_body(const float* __r
   __syncthreads();
   // ---- level 3: the owned 4x4 ----
   const int R3 = o.rows[3], C3 = o.cols[3];
-  for (int e = t; e < kPL2 * 4; e += kPyrThreads) {  // horizontal pass over L2 halo rows for the 4 owned columns
+  for (int e = t; e < kPL2 * 4; e += kThreads) {  // horizontal pass over L2 halo rows for the 4 owned columns
     const int i = e / 4, jx = e % 4;
     const int x3 = 4 * tx + jx;
     if (i < n2y && x3 < C3) {
@@ -235,7 +238,7 @@ __device__ __forceinline__ void image_pyramid_fused_kernel_body(const float* __r
   }
 }
 __global__ void __launch_bounds__(kPyrThreads) image_pyramid_fused_kernel(const float* __restrict__ src, PyrOut o) {
-  image_pyramid_fused_kernel_body(src, o);
+  image_pyramid_fused_kernel_body<kPyrThreads>(src, o);
 }
 
 // Whole depth pyramid in one launch: L_k(Y,X) = L_0(2^k Y + 2^k - 1, 2^k X + 2^k - 1), the composition of the

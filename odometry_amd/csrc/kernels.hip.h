@@ -780,115 +780,6 @@ __device__ __forceinline__ void lm_apply_step_wave(LmState* s, int max_iters) {
   if (!(max_iters > s->iter)) { s->active = 0; s->stop_reason = 3; }
 }
 
-// Sums the per-block partials in a fixed order and advances the LM state machine by one evaluation
-// (accept / reject, damped 6x6 solve, exp, left-compose; ref: src/lm_optimizer.cpp:129-154). One workgroup:
-// 256 threads fold the partials, wave 0 solves, lane 0 runs the scalar state machine.
-// STAMP builds (diagnostic entry odo_debug_update_stamps only) record s_memtime at phase boundaries into `stamps`.
-constexpr int kUpdThreads = 1024;
-#define ODO_STAMP(i) do { if (STAMP && threadIdx.x == 0) stamps[i] = __builtin_readcyclecounter(); } while (0)
-template <bool STAMP>
-__global__ void __launch_bounds__(kUpdThreads) lm_update_kernel(LmState* __restrict__ st, const double* __restrict__ partials,
-                                                         int nblk, int expect_level, float precision, int max_iters,
-                                                         LmTraceRow* __restrict__ trace, float* __restrict__ cost_stat,
-                                                         int* __restrict__ host_prog, int seq,
-                                                         unsigned long long* __restrict__ stamps) {
-  ODO_STAMP(0);
-  if (!(st->active != 0 && st->level == expect_level)) {
-    // stale launch (the level's loop already stopped): only report progress to the polling host
-    if (host_prog && threadIdx.x == 0) __hip_atomic_store(host_prog, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    return;
-  }
-  __shared__ double sh[32][32];
-  __shared__ double acc_sh[32];
-  __shared__ LmState s_sh;  // LDS copy: dynamic indexing (iters_level[level]) stays out of scratch memory
-  __shared__ float delta_sh[6];
-  __shared__ int need_step_sh, iter_before_sh;
-  __shared__ float err_last_before_sh;
-  const int t = threadIdx.x;
-  const int q = t & 31, seg = t >> 5;
-  // fold the per-block partials: 32 segments x 29 quantities, every load of a thread in flight at once (<= 5 for the
-  // 160-block point-list grids), then a fixed-order combine — the association order depends only on nblk, so
-  // results are run-to-run identical.
-  double v = 0.0;
-  if (q < ODO_NACC) {
-    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
-    int b = seg;
-    for (; b + 96 < nblk; b += 128) {
-      v0 += partials[(size_t)b * ODO_NACC + q];
-      v1 += partials[(size_t)(b + 32) * ODO_NACC + q];
-      v2 += partials[(size_t)(b + 64) * ODO_NACC + q];
-      v3 += partials[(size_t)(b + 96) * ODO_NACC + q];
-    }
-    for (; b < nblk; b += 32) v0 += partials[(size_t)b * ODO_NACC + q];
-    v = (v0 + v1) + (v2 + v3);
-  }
-  ODO_STAMP(1);
-  sh[seg][q] = v;
-  if (t < (int)(sizeof(LmState) / sizeof(int))) ((int*)&s_sh)[t] = ((const int*)st)[t];  // cooperative state copy
-  __syncthreads();
-  if (t >= 64) return;  // wave 0 carries on alone
-  if (t < ODO_NACC) {
-    double a = 0.0;
-#pragma unroll
-    for (int g = 0; g < 32; g++) a += sh[g][t];
-    acc_sh[t] = a;
-  }
-  __builtin_amdgcn_s_waitcnt(0xc07f);
-  __builtin_amdgcn_wave_barrier();
-  ODO_STAMP(2);
-  if (t == 0) {
-    iter_before_sh = s_sh.iter;
-    err_last_before_sh = s_sh.err_last;
-    need_step_sh = lm_decide(&s_sh, acc_sh, precision) ? 1 : 0;
-  }
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): lane 0's LDS writes before the wave reads them
-  __builtin_amdgcn_wave_barrier();
-  ODO_STAMP(3);
-  const bool need_step = need_step_sh != 0;
-  if (need_step) {
-    solve_damped_wave(acc_sh, s_sh.lambda, delta_sh);
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-  }
-  ODO_STAMP(4);
-  if (t == 0) {
-    LmState& s = s_sh;
-    if (need_step) {
-      for (int i = 0; i < 6; i++) s.delta[i] = delta_sh[i];
-      lm_apply_step(&s, max_iters);
-    }
-    ODO_STAMP(5);
-    const int ev = s.n_evals - 1;
-    if (ev < kTraceCap) {
-      LmTraceRow& r = trace[ev];
-      r.level = expect_level;
-      r.iter = iter_before_sh;
-      r.n_res = (int)acc_sh[28];
-      r.err = s.err_now;
-      r.accepted = (s.status == 0 && !(s.err_now > err_last_before_sh)) ? 1 : 0;
-      r.stop = (s.stop_reason == 3 || s.active) ? 0 : s.stop_reason;
-      r.lambda_after = s.lambda;
-      for (int i = 0; i < 6; i++) r.delta[i] = (s.active || s.stop_reason == 3) ? s.delta[i] : 0.0f;
-    }
-    if (iter_before_sh == 0 && s.iters_level[expect_level & 7] == 1) cost_stat[expect_level * 2 + 0] = s.err_now;
-    cost_stat[expect_level * 2 + 1] = s.err_now;
-  }
-  __builtin_amdgcn_s_waitcnt(0xc07f);
-  __builtin_amdgcn_wave_barrier();
-  ODO_STAMP(6);
-  if (t < (int)(sizeof(LmState) / sizeof(int))) ((int*)st)[t] = ((const int*)&s_sh)[t];  // cooperative write-back
-  if (t == 0) {
-    const LmState& s = s_sh;
-    if (host_prog) {
-      // host-mapped progress words: [2 + level] = 1 once the level's loop has stopped (the host then skips the
-      // launches it has not issued yet), [0] = sequence number of the last update launch that has run.
-      if (!s.active) __hip_atomic_store(host_prog + 2 + expect_level, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(host_prog, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-  ODO_STAMP(7);
-}
-
 // ---------------------------------------------------------------------------------------------
 // Row-sharing block accumulation of the normal equations (fused LM kernels).
 // Instead of 29 fp64 products per thread followed by a 29 x T transpose through LDS, every thread publishes the ROW of
@@ -1052,6 +943,75 @@ __device__ __forceinline__ void lm_state_machine(bool pending, const StepLevel* 
     if (t == 0) s_sh = s;
   }
   __syncthreads();
+}
+
+// Sums the per-block partials in a fixed order and advances the LM state machine by one evaluation
+// (accept / reject, damped 6x6 solve, exp, left-compose; ref: src/lm_optimizer.cpp:129-154). One workgroup:
+// all threads fold the partials, wave 0 runs lm_state_machine.
+// STAMP builds (diagnostic entry odo_debug_update_stamps only) record s_memtime at phase boundaries into `stamps`.
+constexpr int kUpdThreads = 1024;
+#define ODO_STAMP(i) do { if (STAMP && threadIdx.x == 0) stamps[i] = __builtin_readcyclecounter(); } while (0)
+template <bool STAMP>
+__global__ void __launch_bounds__(kUpdThreads) lm_update_kernel(LmState* __restrict__ st, const double* __restrict__ partials,
+                                                         int nblk, int expect_level, float precision, int max_iters,
+                                                         LmTraceRow* __restrict__ trace, float* __restrict__ cost_stat,
+                                                         int* __restrict__ host_prog, int seq,
+                                                         unsigned long long* __restrict__ stamps) {
+  ODO_STAMP(0);
+  if (!(st->active != 0 && st->level == expect_level)) {
+    // stale launch (the level's loop already stopped): only report progress to the polling host
+    if (host_prog && threadIdx.x == 0) __hip_atomic_store(host_prog, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
+  __shared__ double sh[32][32];
+  __shared__ double acc_sh[32];
+  __shared__ LmState s_sh;  // LDS copy: dynamic indexing (iters_level[level]) stays out of scratch memory
+  const int t = threadIdx.x;
+  const int q = t & 31, seg = t >> 5;
+  // fold the per-block partials: 32 segments x 29 quantities, every load of a thread in flight at once (<= 5 for the
+  // 160-block point-list grids), then a fixed-order combine — the association order depends only on nblk, so
+  // results are run-to-run identical.
+  double v = 0.0;
+  if (q < ODO_NACC) {
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+    int b = seg;
+    for (; b + 96 < nblk; b += 128) {
+      v0 += partials[(size_t)b * ODO_NACC + q];
+      v1 += partials[(size_t)(b + 32) * ODO_NACC + q];
+      v2 += partials[(size_t)(b + 64) * ODO_NACC + q];
+      v3 += partials[(size_t)(b + 96) * ODO_NACC + q];
+    }
+    for (; b < nblk; b += 32) v0 += partials[(size_t)b * ODO_NACC + q];
+    v = (v0 + v1) + (v2 + v3);
+  }
+  ODO_STAMP(1);
+  sh[seg][q] = v;
+  if (t < (int)(sizeof(LmState) / sizeof(int))) ((int*)&s_sh)[t] = ((const int*)st)[t];  // cooperative state copy
+  __syncthreads();
+  if (t < ODO_NACC) {
+    double a = 0.0;
+#pragma unroll
+    for (int g = 0; g < 32; g++) a += sh[g][t];
+    acc_sh[t] = a;
+  }
+  if (t == 0) s_sh.max_iters = max_iters;   // (what lm_begin_level stored: the argument is the same number)
+  __syncthreads();
+  ODO_STAMP(2);
+  // wave 0: accept / reject, the 6x6 solve across the wavefront, exp / compose, trace row, cost statistics — the state
+  // machine of the fused kernels (every lane carries the state; the four sin / cos chains in four lane groups)
+  lm_state_machine(true, nullptr, 0, 0.0f, precision, s_sh, acc_sh, trace, cost_stat, true);
+  ODO_STAMP(3); ODO_STAMP(4); ODO_STAMP(5); ODO_STAMP(6);
+  if (t < (int)(sizeof(LmState) / sizeof(int))) ((int*)st)[t] = ((const int*)&s_sh)[t];  // cooperative write-back
+  if (t == 0) {
+    const LmState& s = s_sh;
+    if (host_prog) {
+      // host-mapped progress words: [2 + level] = 1 once the level's loop has stopped (the host then skips the
+      // launches it has not issued yet), [0] = sequence number of the last update launch that has run.
+      if (!s.active) __hip_atomic_store(host_prog + 2 + expect_level, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(host_prog, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  ODO_STAMP(7);
 }
 
 // Prologue shared by the step kernel and the finalize kernel: leaves the advanced state in s_sh.

@@ -352,6 +352,33 @@ int odo_camera_undistort_rectify_dev(odo_camera* cam, const float* src_dev, int 
                                      float border_value);
 int odo_camera_destroy(odo_camera* cam);
 
+/* ---- the pose exchange of the multi-GPU path for hosts that are not Python ---------------------------
+ * Tracking shards by sequence (rank r owns sequences r, r + N, ...; ref: run_odometry_kitti_offline.cpp:198-271 is sequential
+ * inside a sequence and independent across sequences): there is no data-path collective. The one exchange is an all-gather of
+ * the results over RCCL: per tracked frame a row of ODO_GATHER_ROW floats (sequence id, frame id, the 3x4 absolute pose,
+ * row-major), `every` rows per ncclAllGather, on a stream of its own, never waited for while tracking. The schedule is fixed up
+ * front: EVERY rank issues ceil(n_max_frames / every) collectives of a fixed block and pads with rows whose sequence id is -1
+ * (uneven shards — 11 sequences over 8 GPUs — cannot leave ranks with different numbers of collectives). RCCL is dlopen'ed
+ * (librccl.so.1, or ODO_RCCL_SO): no link-time dependency. bench.py uses the same schedule through torch.distributed
+ * (odometry_amd/dist.py); this entry is exercised at world size 1 on the GPU box only (RCCL refuses two ranks on one device). */
+#define ODO_GATHER_ID_BYTES 128
+#define ODO_GATHER_ROW 14
+typedef struct odo_gather odo_gather;
+/* Rank 0: an ncclUniqueId; hand its bytes to every rank by the host's own means (MPI, a file, a socket). */
+int odo_gather_unique_id(unsigned char id[ODO_GATHER_ID_BYTES]);
+/* Collective over all ranks (ncclCommInitRank). n_local_frames: rows THIS rank will push; n_max_frames: the largest such number
+ * over the ranks (every rank derives both from the same sharding rule). */
+int odo_gather_create(int device, int world, int rank, const unsigned char id[ODO_GATHER_ID_BYTES], int every,
+                      int n_local_frames, int n_max_frames, odo_gather** out);
+/* One tracked frame's result; every `every`-th push issues a collective and returns at once. */
+int odo_gather_push(odo_gather* g, int seq_id, int frame_id, const float abs_pose_colmajor[16]);
+/* Issues what is left of the schedule (padded) and waits for every collective. */
+int odo_gather_flush(odo_gather* g);
+/* After flush: the valid rows received from `rank` (ODO_GATHER_ROW floats each, in push order). */
+int odo_gather_rows(odo_gather* g, int rank, const float** rows, int* n_rows);
+int odo_gather_issued(const odo_gather* g);   /* collectives issued so far */
+int odo_gather_destroy(odo_gather* g);
+
 #ifdef __cplusplus
 }
 #endif

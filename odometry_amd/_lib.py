@@ -110,6 +110,13 @@ SIGNATURES = {
     "odo_tracker_lm": (_vp, [_vp]),
     "odo_tracker_ctx": (_vp, [_vp]),
     "odo_tracker_destroy": (C.c_int, [_vp]),
+    "odo_gather_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
+    "odo_gather_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "odo_gather_push": (C.c_int, [_vp, C.c_int, C.c_int, _fp]),
+    "odo_gather_flush": (C.c_int, [_vp]),
+    "odo_gather_rows": (C.c_int, [_vp, C.c_int, C.POINTER(_fp), _ip]),
+    "odo_gather_issued": (C.c_int, [_vp]),
+    "odo_gather_destroy": (C.c_int, [_vp]),
     "odo_tracker_batch_create": (C.c_int, [C.c_int, C.POINTER(TrackerParams), C.c_int, C.POINTER(_vp)]),
     "odo_tracker_batch_destroy": (C.c_int, [_vp]),
     "odo_tracker_batch_size": (C.c_int, [_vp]),

@@ -1726,4 +1726,5 @@ extern "C" int odo_depth_report(const odo_depth* d, int* iters, float* cost, int
 
 #include "tracker.hip.h"
 #include "batch.hip.h"
+#include "gather.hip.h"
 #include "camera.hip.h"

@@ -682,7 +682,7 @@ extern "C" int odo_tracker_batch_track(odo_tracker_batch* b, const float* const*
   batch_chain_fill(b, ahead, nxt_pair, b->hint_next.data(), b->hint_next_right.data(), false, true, 1, b->ev_next);
   if (!ahead->ids.empty()) batch_chain_post(b, ahead);
   for (int i = 0; i < S; i++) b->hint_next[i] = b->hint_next_right[i] = nullptr;
-  // ---- pose LM of this step (stream A), the chains' launches pumped from its wait loops
+  // ---- pose LM of this step (stream A); the helper thread feeds stream B meanwhile
   std::vector<float> T((size_t)n * 16);
   std::vector<int> st(n, 0);
   std::vector<odo_lm*> lms(n);

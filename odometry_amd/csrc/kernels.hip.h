@@ -864,6 +864,10 @@ struct StepArgs {
   LmState* st2[2];      // both state buffers: launch `seq` reads st2[seq & 1], writes st2[(seq + 1) & 1]
   double* part2[2];     // idem for the partial sums
   int min_level;        // lm_coarse_kernel: levels >= min_level run inside the workgroup (n_levels = none)
+  // hand-over to the unfused pipeline (dense fine levels): the device stops walking the pyramid below stop_level, reports the
+  // Solve "finished" there and leaves its state in final_state, from which the host carries on level by level
+  int stop_level;       // 0: the fused pipeline covers every level
+  LmState* final_state; // where the finishing launch copies the state (NULL: nowhere)
 };
 // What changes from launch to launch of one Solve.
 struct StepLaunch {
@@ -884,7 +888,7 @@ constexpr int kFoldChunk = 20;  // the 160 rows of a point-list grid in one roun
 __device__ __forceinline__ void lm_state_machine(bool pending, const StepLevel* lv, int n_levels, float lambda0,
                                                  float precision, LmState& s_sh, double* acc_sh, LmTraceRow* __restrict__ trace,
                                                  float* __restrict__ cost_stat, bool publisher,
-                                                 unsigned long long* smdbg = nullptr) {
+                                                 unsigned long long* smdbg = nullptr, int stop_level = 0) {
   const int t = threadIdx.x;
   if (t < 64) {
     unsigned long long c0 = smdbg ? __builtin_readcyclecounter() : 0, c1 = c0, c2 = c0, c3 = c0;
@@ -934,7 +938,7 @@ __device__ __forceinline__ void lm_state_machine(bool pending, const StepLevel* 
     if (lv) {
       while (!s.active && s.status == 0 && !s.finished) {
         const int next = (s.level < 0) ? n_levels - 1 : s.level - 1;
-        if (next < 0) { s.finished = 1; break; }
+        if (next < stop_level) { s.finished = 1; break; }   // stop_level > 0: the levels below are the host's (unfused pipeline)
         s.stop_reason = 0;
         lm_begin_level(&s, next, lambda0, lv[next].max_iters);  // ref: src/lm_optimizer.cpp:110-115
       }
@@ -1022,7 +1026,7 @@ __device__ __forceinline__ void lm_fused_prologue(const LmState* __restrict__ st
                                                   const StepLevel* lv, int n_levels, float lambda0, float precision,
                                                   LmState& s_sh, double* fold_sh, double* acc_sh,
                                                   LmTraceRow* __restrict__ trace, float* __restrict__ cost_stat, bool publisher,
-                                                  const float* init /* non-null: first launch of a Solve */) {
+                                                  const float* init /* non-null: first launch of a Solve */, int stop_level = 0) {
   const int t = threadIdx.x;
   if (init) {
     if (t == 0) {
@@ -1068,7 +1072,7 @@ __device__ __forceinline__ void lm_fused_prologue(const LmState* __restrict__ st
     }
     __syncthreads();
   }
-  lm_state_machine(pending, lv, n_levels, lambda0, precision, s_sh, acc_sh, trace, cost_stat, publisher);
+  lm_state_machine(pending, lv, n_levels, lambda0, precision, s_sh, acc_sh, trace, cost_stat, publisher, nullptr, stop_level);
 }
 
 // End of a Solve: affine_ = current_estimate.matrix() (ref: src/lm_optimizer.cpp:158) or the pseudo-identity on failure
@@ -1095,10 +1099,11 @@ constexpr int kProgSeqBits = 12;  // progress word = (token << 12) | launches fi
                                   // that drain after the host has moved on cannot be mistaken for this Solve's progress
 __device__ __forceinline__ void lm_fused_publish(LmState& s_sh, LmState* __restrict__ st_out, int* __restrict__ host_prog,
                                                  int seq, int token, const float* cost_stat, float* __restrict__ out,
-                                                 int* __restrict__ done_flag) {
+                                                 int* __restrict__ done_flag, LmState* __restrict__ final_state = nullptr) {
   const int t = threadIdx.x;
   if (t < 64) {
     if (t < (int)(sizeof(LmState) / sizeof(int))) ((int*)st_out)[t] = ((const int*)&s_sh)[t];
+    if (final_state && s_sh.finished && t < (int)(sizeof(LmState) / sizeof(int))) ((int*)final_state)[t] = ((const int*)&s_sh)[t];
     if (t == 0) {
       // the launch that learns that every level is done hands the result to the host itself (no finalize launch)
       if (s_sh.finished && out) lm_write_result(s_sh, cost_stat, out, done_flag, token);
@@ -1125,7 +1130,7 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const StepLaunch
   const bool publisher = (blockIdx.x == gridDim.x - 1);
   if (a.dbg && publisher && threadIdx.x == 0 && q.seq < 56) a.dbg[16 + 2 * q.seq] = wall_clock64();  // diagnostic timeline
   lm_fused_prologue(q.st_in, q.part_in, a.lv, a.n_levels, a.lambda0, a.precision, s_sh, fold_sh, acc_sh, a.trace, a.cost_stat,
-                    publisher, q.first_of_solve ? a.init : nullptr);
+                    publisher, q.first_of_solve ? a.init : nullptr, a.stop_level);
   const bool run = (s_sh.active != 0 && s_sh.status == 0);  // block-uniform
   const int lvl = run ? s_sh.level : 0;
   const StepLevel& L = a.lv[lvl];
@@ -1163,7 +1168,7 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const StepLaunch
   if (publisher) {
     if (threadIdx.x == 0 && run) { s_sh.pending = 1; s_sh.pending_nblk = L.nblk; }
     __syncthreads();
-    lm_fused_publish(s_sh, q.st_out, a.host_prog, q.seq, a.token, a.cost_stat, a.out, a.done_flag);
+    lm_fused_publish(s_sh, q.st_out, a.host_prog, q.seq, a.token, a.cost_stat, a.out, a.done_flag, a.final_state);
     if (a.dbg && threadIdx.x == 0 && q.seq < 56) a.dbg[16 + 2 * q.seq + 1] = wall_clock64();
   }
 }
@@ -1214,7 +1219,7 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
   __syncthreads();
   // state in (or initialised), a pending evaluation of an earlier launch consumed, pyramid walk started
   lm_fused_prologue(q.st_in, q.part_in, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, red_sh, acc_sh, a.trace, a.cost_stat, true,
-                    q.first_of_solve ? a.init : nullptr);
+                    q.first_of_solve ? a.init : nullptr, a.stop_level);
   if (a.dbg && threadIdx.x == 0 && q.seq < 56) a.dbg[16 + 2 * q.seq] = wall_clock64();
   unsigned long long c_eval = 0, c_red = 0, c_sm = 0, c_it = 0, c_last = a.dbg ? __builtin_readcyclecounter() : 0;
   const unsigned long long c_begin = c_last;
@@ -1261,10 +1266,10 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
     __syncthreads();
     lap(c_red);
     lm_state_machine(true, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, acc_sh, a.trace, a.cost_stat, true,
-                     a.dbg ? a.dbg + 8 : nullptr);
+                     a.dbg ? a.dbg + 8 : nullptr, a.stop_level);
     lap(c_sm);
   }
-  lm_fused_publish(s_sh, q.st_out, a.host_prog, q.seq, a.token, a.cost_stat, a.out, a.done_flag);
+  lm_fused_publish(s_sh, q.st_out, a.host_prog, q.seq, a.token, a.cost_stat, a.out, a.done_flag, a.final_state);
   if (a.dbg && threadIdx.x == 0) {
     if (q.seq < 56) a.dbg[16 + 2 * q.seq + 1] = wall_clock64();
     a.dbg[0] += c_eval; a.dbg[1] += c_red; a.dbg[2] += c_sm; a.dbg[3] += c_it;

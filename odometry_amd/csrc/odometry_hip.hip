@@ -421,7 +421,7 @@ struct LmJob {
   const odo_pyr *kf_img, *kf_dep, *cur_img;
   unsigned long long kf_img_ver, kf_dep_ver, cur_ver;
   StepArgs a;
-  int seq, launches, it, budget, grid, token, min_level;
+  int seq, launches, it, budget, grid, token, min_level, stop_level;
   bool poll, result_by_launch, issued_all;
   double bytes_per_level[ODO_MAX_LEVELS];
 };
@@ -434,7 +434,10 @@ struct odo_lm {
   odo_intrinsics K;
   float init[16];
   // device
-  LmState* d_state;
+  LmState* d_state;   // [0], [1]: the fused pipeline's double buffer ([0]: a whole unfused Solve); [2]: unfused continuation of a fused Solve
+  LmState* ust;       // the state the unfused kernels work on (d_state, or d_state + 2 during a continuation)
+  int upo;            // offset of the unfused pipeline's host-mapped progress words (0, or 16 during a continuation)
+  int fuse_dense_max; // dense levels with at most this many points run on their point list through the fused pipeline (0: never)
   double* d_partials;
   float* d_init;
   float* d_out;  // 26 floats
@@ -510,7 +513,9 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
   HIP_OK(hipSetDevice(ctx->device));
   // the single-workgroup coarse kernel reduces through 118 KB of LDS (gfx950: up to 160 KB per workgroup)
   HIP_OK(hipFuncSetAttribute((const void*)lm_coarse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kCoarseLdsBytes));
-  HIP_OK(hipMalloc((void**)&m->d_state, sizeof(LmState) * 2));                          // double-buffered (fused pipeline)
+  HIP_OK(hipMalloc((void**)&m->d_state, sizeof(LmState) * 3));                          // double-buffered (fused pipeline) + continuation
+  m->ust = m->d_state; m->upo = 0;
+  m->fuse_dense_max = getenv("ODO_FUSE_DENSE_MAX") ? atoi(getenv("ODO_FUSE_DENSE_MAX")) : 131072;
   HIP_OK(hipMalloc((void**)&m->d_partials, sizeof(double) * 2 * kLmMaxBlocks * ODO_NACC)); // idem
   HIP_OK(hipMalloc((void**)&m->d_init, sizeof(float) * 16));
   HIP_OK(hipMalloc((void**)&m->d_out, sizeof(float) * 48));  // 26 result floats + 16 cost statistics: one read-back
@@ -525,9 +530,9 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
   HIP_OK(hipHostMalloc((void**)&m->h_done, sizeof(int) * 4, hipHostMallocMapped | hipHostMallocCoherent));
   HIP_OK(hipHostGetDevicePointer((void**)&m->d_done, m->h_done, 0));
   m->h_done[0] = 0;
-  HIP_OK(hipHostMalloc((void**)&m->h_prog, sizeof(int) * 16, hipHostMallocMapped | hipHostMallocCoherent));
+  HIP_OK(hipHostMalloc((void**)&m->h_prog, sizeof(int) * 32, hipHostMallocMapped | hipHostMallocCoherent));
   HIP_OK(hipHostGetDevicePointer((void**)&m->d_prog, m->h_prog, 0));
-  memset(m->h_prog, 0, sizeof(int) * 16);
+  memset(m->h_prog, 0, sizeof(int) * 32);
   // per-level point counts: written by kf_fill_kernel straight into host-mapped memory (no copy operation on the stream);
   // d_npts / cand_d_npts are device arrays for the batched tracker, which forwards them from its last launch
   HIP_OK(hipMalloc((void**)&m->d_npts, sizeof(int) * ODO_MAX_LEVELS));
@@ -689,7 +694,10 @@ static void lm_take_counts(odo_lm* m, const int* h_npts, const odo_pyr* img, int
   for (int l = 0; l < m->n_levels; l++) {
     m->npts[l] = h_npts[l];
     const long interior = (long)(img->r[l] - 8) * (img->c[l] - 8);
-    m->use_list[l] = (m->mode == 2) || (interior > 0 && 2L * m->npts[l] <= interior);
+    // sparse levels always; small dense levels too (a few launches of the fused pipeline instead of an evaluation + an update
+    // launch per LM iteration: the hand-over to the dense pipeline happens at the first level that is neither)
+    m->use_list[l] = (m->mode == 2) || (interior > 0 && 2L * m->npts[l] <= interior) ||
+                     (m->mode == 0 && m->npts[l] > 0 && m->npts[l] <= m->fuse_dense_max);
   }
 }
 
@@ -761,10 +769,10 @@ static void lm_launch_eval(odo_lm* m, const LevelView& v, const LevelK& k, int l
   if (e0 && e1 && m->robust != 2) {  // timing legs: dispatch-bound start / stop events
     if (m->use_list[level])
       hipExtLaunchKernelGGL(lm_residual_list_kernel, dim3(nblk), dim3(kLmBlock), 0, s, e0, e1, 0, m->pl[level], m->npts[level],
-                            v.I2, v.rows, v.cols, k, (const LmState*)m->d_state, level, m->robust, m->huber_delta,
+                            v.I2, v.rows, v.cols, k, (const LmState*)m->ust, level, m->robust, m->huber_delta,
                             (const float*)m->d_scale, m->d_partials);
     else
-    launch_dense_eval(lm_dense_level(v, k, 0), m->d_state, level, m->robust, m->huber_delta, m->d_scale, m->d_partials, s, e0, e1,
+    launch_dense_eval(lm_dense_level(v, k, 0), m->ust, level, m->robust, m->huber_delta, m->d_scale, m->d_partials, s, e0, e1,
                       m->dense_plain_div);
     return;
   }
@@ -772,20 +780,20 @@ static void lm_launch_eval(odo_lm* m, const LevelView& v, const LevelK& k, int l
     const int n = m->npts[level];
     if (m->robust == 2) {
       hipLaunchKernelGGL(lm_residual_only_list_kernel, dim3(nblk), dim3(kLmBlock), 0, s, m->pl[level], n, v.I2, v.rows,
-                         v.cols, k, m->d_state, level, m->d_res);
-      hipLaunchKernelGGL(lm_tdist_scale_kernel, dim3(1), dim3(1024), 0, s, m->d_res, n, m->d_state, level, m->d_scale);
+                         v.cols, k, m->ust, level, m->d_res);
+      hipLaunchKernelGGL(lm_tdist_scale_kernel, dim3(1), dim3(1024), 0, s, m->d_res, n, m->ust, level, m->d_scale);
     }
     hipLaunchKernelGGL(lm_residual_list_kernel, dim3(nblk), dim3(kLmBlock), 0, s, m->pl[level], n, v.I2, v.rows, v.cols, k,
-                       m->d_state, level, m->robust, m->huber_delta, m->d_scale, m->d_partials);
+                       m->ust, level, m->robust, m->huber_delta, m->d_scale, m->d_partials);
     return;
   }
   if (m->robust == 2) {
     const int n = (v.rows - 8) * (v.cols - 8);
-    hipLaunchKernelGGL(lm_residual_only_kernel, dim3(nblk), dim3(kLmBlock), 0, s, v, k, m->d_state, level, m->d_res);
-    hipLaunchKernelGGL(lm_tdist_scale_kernel, dim3(1), dim3(1024), 0, s, m->d_res, n > 0 ? n : 0, m->d_state, level,
+    hipLaunchKernelGGL(lm_residual_only_kernel, dim3(nblk), dim3(kLmBlock), 0, s, v, k, m->ust, level, m->d_res);
+    hipLaunchKernelGGL(lm_tdist_scale_kernel, dim3(1), dim3(1024), 0, s, m->d_res, n > 0 ? n : 0, m->ust, level,
                        m->d_scale);
   }
-  launch_dense_eval(lm_dense_level(v, k, 0), m->d_state, level, m->robust, m->huber_delta, m->d_scale, m->d_partials, s, nullptr,
+  launch_dense_eval(lm_dense_level(v, k, 0), m->ust, level, m->robust, m->huber_delta, m->d_scale, m->d_partials, s, nullptr,
                     nullptr, m->dense_plain_div);
 }
 
@@ -812,12 +820,15 @@ static inline int lm_job_progress(const odo_lm* m) {
 }
 static inline bool lm_job_finished(const odo_lm* m) { return ((volatile int*)m->h_prog)[1] == m->job.token; }
 
-static bool lm_fused_eligible(const odo_lm* m) {
-  if (!(m->fused && m->robust != 2)) return false;
-  for (int l = 0; l < m->n_levels; l++)
-    if (!m->use_list[l]) return false;  // dense levels are throughput bound: big grids + a separate update kernel
-  return true;
+// Lowest level of the coarse-to-fine run of point-list levels the fused pipeline can take (it starts at the coarsest level):
+// 0 = the whole Solve, n_levels = nothing (the Solve runs on the unfused pipeline from the start).
+static int lm_fused_stop_level(const odo_lm* m) {
+  if (!(m->fused && m->robust != 2)) return m->n_levels;
+  int stop = m->n_levels;
+  while (stop > 0 && m->use_list[stop - 1]) stop--;
+  return stop;
 }
+static bool lm_fused_eligible(const odo_lm* m) { return lm_fused_stop_level(m) < m->n_levels; }
 
 // Keyframe lists must be current (lm_prepare_keyframe) and the Solve fused-eligible.
 static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img) {
@@ -836,8 +847,10 @@ static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_de
   StepArgs& a = jb.a;
   memset(&a, 0, sizeof(a));
   a.n_levels = m->n_levels;
+  const int stop = lm_fused_stop_level(m);   // levels below it are handed over to the unfused pipeline
+  jb.stop_level = stop;
   int grid = 1, budget = 0;
-  for (int l = 0; l < m->n_levels; l++) {
+  for (int l = stop; l < m->n_levels; l++) {
     StepLevel& L = a.lv[l];
     L.pl = m->pl[l]; L.n = m->npts[l];
     L.rows = kf_img->r[l]; L.cols = kf_img->c[l];
@@ -852,6 +865,8 @@ static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_de
   a.lambda0 = m->lambda; a.precision = m->precision; a.robust = m->robust; a.huber_delta = m->huber_delta;
   a.trace = m->d_trace; a.cost_stat = m->d_cost; a.host_prog = m->d_prog;
   a.out = m->d_res_map; a.done_flag = m->d_done; a.token = jb.token;
+  a.stop_level = stop;
+  a.final_state = stop > 0 ? m->d_state + 2 : nullptr;
   memcpy(a.init, m->init, sizeof(a.init));
     static unsigned long long* dbg_buf = [] {
       unsigned long long* p = nullptr;
@@ -886,7 +901,7 @@ static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_de
   // Coarse levels (few points) run inside one workgroup: one launch covers every level >= min_level.
   int min_level = m->n_levels;
   static const int coarse_max = getenv("ODO_COARSE_MAX") ? atoi(getenv("ODO_COARSE_MAX")) : kCoarseMaxPoints;
-  while (min_level > 0 && m->npts[min_level - 1] <= coarse_max) min_level--;
+  while (min_level > stop && m->npts[min_level - 1] <= coarse_max) min_level--;
   if (!m->coarse) min_level = m->n_levels;
   m->last_coarse = (min_level < m->n_levels) ? 1 : 0;
   if (min_level < m->n_levels) {
@@ -948,6 +963,48 @@ static void lm_fused_pump(odo_lm* m, bool block) {
   jb.issued_all = true;
 }
 
+// Levels l_hi .. 0 of the unfused pipeline (one evaluation launch + one lm_update_kernel launch per LM iteration, the host at
+// most run_ahead iterations ahead, early exit through the host-mapped progress words) on the state m->ust; the progress words
+// are h_prog[m->upo ...]. Used for a whole Solve (t-distribution weights, dense levels from the top) and for the fine dense
+// levels below the fused pipeline's hand-over.
+static int lm_unfused_levels(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img, int l_hi,
+                             int* launches_io, double bytes_per_level[ODO_MAX_LEVELS]) {
+  hipStream_t s = m->ctx->stream;
+  volatile int* prog = m->h_prog + m->upo;
+  for (int i = 0; i < 16; i++) m->h_prog[m->upo + i] = 0;  // nothing of the unfused pipeline is draining: its Solves end with a stream sync
+  bool poll = m->poll != 0;
+  int seq = 0;
+  for (int l = l_hi; l >= 0; l--) {  // ref: src/lm_optimizer.cpp:92
+    LevelView v;
+    v.I1 = kf_img->dev + kf_img->off[l];
+    v.I2 = cur_img->dev + cur_img->off[l];
+    v.D1 = kf_dep->dev + kf_dep->off[l];
+    v.rows = kf_img->r[l]; v.cols = kf_img->c[l];
+    const LevelK k = lm_level_k(m, l);
+    const int nblk = lm_grid_for(m, l, v.rows, v.cols);
+    if (m->robust == 2 && lm_ensure_res(m, (size_t)v.rows * v.cols)) return -1;
+    bytes_per_level[l] = lm_level_bytes(m, l, v.rows, v.cols, nblk);
+    hipLaunchKernelGGL(lm_begin_level_kernel, dim3(1), dim3(64), 0, s, m->ust, l, m->lambda, m->max_iters[l]);
+    for (int it = 0; it < m->max_iters[l]; it++) {  // ref: :117
+      if (poll) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (seq - prog[0] > m->run_ahead && !prog[2 + l]) {
+          if (m->idle_pump) m->idle_pump(m->idle_arg);
+          if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { poll = false; break; }  // never hang
+        }
+        if (prog[2 + l]) break;  // the level's loop has stopped on the device
+      }
+      seq++;
+      lm_launch_eval(m, v, k, l, nblk);
+      hipLaunchKernelGGL(lm_update_kernel<false>, dim3(1), dim3(kUpdThreads), 0, s, m->ust, m->d_partials, nblk, l,
+                         m->precision, m->max_iters[l], m->d_trace, m->d_cost, m->d_prog + m->upo, seq,
+                         (unsigned long long*)nullptr);
+      (*launches_io)++;
+    }
+  }
+  return 0;
+}
+
 static bool lm_job_matches(const odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img) {
   const LmJob& jb = m->job;
   return jb.active && jb.kf_img == kf_img && jb.kf_dep == kf_dep && jb.cur_img == cur_img && jb.kf_img_ver == kf_img->version &&
@@ -988,12 +1045,8 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
   // Early exit without a host sync: the device publishes its progress in host-mapped memory; the host stays at
   // most `run_ahead` launches ahead of the device and stops issuing launches once the device reports that the Solve
   // (fused pipeline) or the level (unfused pipeline) has ended. Stale launches are no-ops on the device either way.
-  volatile int* prog = m->h_prog;
-  bool poll = m->poll != 0;
   const bool fused = resumed || lm_fused_eligible(m);
   int seq = 0;
-  if (!fused)
-    for (int i = 0; i < 16; i++) m->h_prog[i] = 0;  // unfused Solves end with a stream sync: nothing is draining
   if (fused) {
     // ---- fused pipeline: identical generic step launches; the device walks the pyramid itself ----
     if (!resumed && lm_fused_begin(m, kf_img, kf_dep, cur_img)) return -1;
@@ -1005,34 +1058,8 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
     // ---- unfused pipeline (t-distribution mode, dense levels): residual kernel(s) + update kernel per evaluation ----
     HIP_OK(hipMemcpyAsync(m->d_init, m->init, sizeof(float) * 16, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(lm_begin_solve_kernel, dim3(1), dim3(64), 0, s, m->d_state, m->d_init, m->d_cost);
-    for (int l = m->n_levels - 1; l >= 0; l--) {  // ref: src/lm_optimizer.cpp:92
-      LevelView v;
-      v.I1 = kf_img->dev + kf_img->off[l];
-      v.I2 = cur_img->dev + cur_img->off[l];
-      v.D1 = kf_dep->dev + kf_dep->off[l];
-      v.rows = kf_img->r[l]; v.cols = kf_img->c[l];
-      const LevelK k = lm_level_k(m, l);
-      const int nblk = lm_grid_for(m, l, v.rows, v.cols);
-      if (m->robust == 2 && lm_ensure_res(m, (size_t)v.rows * v.cols)) return -1;
-      bytes_per_level[l] = lm_level_bytes(m, l, v.rows, v.cols, nblk);
-      hipLaunchKernelGGL(lm_begin_level_kernel, dim3(1), dim3(64), 0, s, m->d_state, l, m->lambda, m->max_iters[l]);
-      for (int it = 0; it < m->max_iters[l]; it++) {  // ref: :117
-        if (poll) {
-          const auto t0 = std::chrono::steady_clock::now();
-          while (seq - prog[0] > m->run_ahead && !prog[2 + l]) {
-            if (m->idle_pump) m->idle_pump(m->idle_arg);
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { poll = false; break; }  // never hang
-          }
-          if (prog[2 + l]) break;  // the level's loop has stopped on the device
-        }
-        seq++;
-        lm_launch_eval(m, v, k, l, nblk);
-        hipLaunchKernelGGL(lm_update_kernel<false>, dim3(1), dim3(kUpdThreads), 0, s, m->d_state, m->d_partials, nblk, l,
-                           m->precision, m->max_iters[l], m->d_trace, m->d_cost, m->d_prog, seq,
-                           (unsigned long long*)nullptr);
-        launches++;
-      }
-    }
+    m->ust = m->d_state; m->upo = 0;
+    if (lm_unfused_levels(m, kf_img, kf_dep, cur_img, m->n_levels - 1, &launches, bytes_per_level)) return -1;
   }
   if (fused) {
     const int token = m->job.token;
@@ -1069,6 +1096,24 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     memcpy(m->h_out, m->h_res, sizeof(float) * 42);
+    const int stop = m->job.stop_level;
+    if (stop > 0 && m->h_out[16] == 0.0f) {
+      // ---- hand-over: the fine levels are dense. The finishing launch left the state in d_state[2] (ordered before anything
+      // enqueued from here on; the launches the host had queued ahead are no-ops that touch d_state[0 / 1] only); the unfused
+      // pipeline carries on from it with its own progress words, then reports like an unfused Solve.
+      if (!result_by_launch || !ok)   // the explicit finalize wrote st[0]: bring it over
+        HIP_OK(hipMemcpyAsync(m->d_state + 2, st[0], sizeof(LmState), hipMemcpyDeviceToDevice, s));
+      m->ust = m->d_state + 2; m->upo = 16;
+      const int rc = lm_unfused_levels(m, kf_img, kf_dep, cur_img, stop - 1, &launches, bytes_per_level);
+      if (rc == 0) {
+        hipLaunchKernelGGL(lm_finalize_kernel, dim3(1), dim3(64), 0, s, (const LmState*)m->ust, m->d_out);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipMemcpyAsync(m->h_out, m->d_out, sizeof(float) * 42, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+      }
+      m->ust = m->d_state; m->upo = 0;
+      if (rc) return -1;
+    }
   } else {
     hipLaunchKernelGGL(lm_finalize_kernel, dim3(1), dim3(64), 0, s, m->d_state, m->d_out);
     HIP_OK(hipGetLastError());

@@ -49,15 +49,19 @@ def _pyrs(api, scene, k0, k1):
             api.ImagePyramid(4, scene["left"][k1], False))
 
 
-@pytest.mark.parametrize("robust", [1, 0])
-def test_dense_1080p_solve_matches_oracle(api, O, scene, robust):
+@pytest.mark.parametrize("robust,handover", [(1, True), (0, True), (1, False)])
+def test_dense_1080p_solve_matches_oracle(api, O, scene, robust, handover, monkeypatch):
     """Full dense Solve on a 1080p pair, the test_optimizer.cpp call pattern (unsmoothed pyramids, identity start,
     ref: test_optimizer.cpp:53-54,90): identical evaluation trace (level, iteration, residual count, accept / stop) and pose
-    within 1e-5 on the SE(3) log-map norm."""
+    within 1e-5 on the SE(3) log-map norm. handover: the two coarse levels (27 k and 108 k pixels, all with depth) run on their
+    point lists through the fused pipeline, which hands the Solve over to the dense pipeline at level 1; without it
+    (ODO_FUSE_DENSE_MAX=0) every level runs the dense scan."""
+    if not handover:
+        monkeypatch.setenv("ODO_FUSE_DENSE_MAX", "0")
     p0, d0, p1 = _pyrs(api, scene, 0, 1)
     lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, robust, 28.0, intrinsics=K)
     T = lm.Solve(p0, d0, p1)
-    assert lm.points()[1][:4] == [0, 0, 0, 0]   # every level ran the dense scan (all pixels carry depth)
+    assert lm.points()[1][:4] == ([0, 0, 1, 1] if handover else [0, 0, 0, 0])   # which levels ran on their point list
     ref = O.lm_solve(O.image_pyramid(scene["left"][0], 4, False, flat=True), O.depth_pyramid(scene["inv"][0], 4, flat=True),
                      O.image_pyramid(scene["left"][1], 4, False, flat=True), ROWS, COLS, O.lm_params(robust=robust, K=KD))
     assert lm.last_status == 0 and ref["status"] == 0

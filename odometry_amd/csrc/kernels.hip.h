@@ -431,9 +431,28 @@ __global__ void __launch_bounds__(256) kf_count_kernel(KfLevels kl, int* __restr
 // l = the level of this block's row (kf_find_level), pl = that level's list.
 template <class KL>
 __device__ __forceinline__ void kf_fill_kernel_body(KL kl, int l, PointList pl, float f0, float cx0, float cy0,
-                                                      const int* __restrict__ rowcnt, int* __restrict__ npts) {
+                                                      const int* __restrict__ rowcnt, int* __restrict__ npts, int dense_above = 0) {
   __shared__ int wave_tot[4];
   __shared__ int base_sh;
+  if (dense_above > 0) {
+    // A level that will run the dense scan anyway — more than dense_above points AND more than half of its interior with
+    // depth (the host's rule, lm_take_counts) — needs its COUNT only: skip the 52 B per point its list would take (130 MB per
+    // keyframe on a dense 1080p pyramid). Every block of the level reaches the same verdict from the same row counts.
+    const int r0 = kl.row_base[l], r1 = kl.row_base[l + 1];
+    int part = 0;
+    for (int i = r0 + (int)threadIdx.x; i < r1; i += 256) part += rowcnt[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = part;
+    __syncthreads();
+    const int total = (wave_tot[0] + wave_tot[1]) + (wave_tot[2] + wave_tot[3]);
+    __syncthreads();
+    const long interior = (long)(kl.rows[l] - 8) * (kl.cols[l] - 8);
+    if (total > dense_above && 2L * total > interior) {
+      if (threadIdx.x == 0 && (int)blockIdx.x == r1 - 1) npts[l] = total;
+      return;
+    }
+  }
   const int y = 4 + (blockIdx.x - kl.row_base[l]);
   const int cols = kl.cols[l];
   const LevelK k = make_level_k(f0, cx0, cy0, l);
@@ -479,10 +498,10 @@ __device__ __forceinline__ void kf_fill_kernel_body(KL kl, int l, PointList pl, 
 __global__ void __launch_bounds__(256) kf_fill_kernel(KfLevels kl, float f0, float cx0, float cy0,
                                                       const int* __restrict__ rowcnt, int* __restrict__ npts, PointList pl0, PointList pl1,
                                                       PointList pl2, PointList pl3, PointList pl4, PointList pl5,
-                                                      PointList pl6, PointList pl7) {
+                                                      PointList pl6, PointList pl7, int dense_above) {
   const int l = kf_find_level(kl, blockIdx.x);
   const PointList pl = l == 0 ? pl0 : l == 1 ? pl1 : l == 2 ? pl2 : l == 3 ? pl3 : l == 4 ? pl4 : l == 5 ? pl5 : l == 6 ? pl6 : pl7;
-  kf_fill_kernel_body<KfLevels>(kl, l, pl, f0, cx0, cy0, rowcnt, npts);
+  kf_fill_kernel_body<KfLevels>(kl, l, pl, f0, cx0, cy0, rowcnt, npts, dense_above);
 }
 
 __device__ __forceinline__ PointK load_point(const PointList& pl, int i) {

@@ -681,7 +681,8 @@ static int lm_enqueue_lists(odo_lm* m, PointList* pl, size_t* pl_cap, int*& d_ro
   if (rows_total > 0) {
     hipLaunchKernelGGL(kf_count_kernel, dim3(rows_total), dim3(256), 0, s, kl, d_rowcnt, hm_npts);
     hipLaunchKernelGGL(kf_fill_kernel, dim3(rows_total), dim3(256), 0, s, kl, m->K.f0, m->K.cx0, m->K.cy0,
-                       (const int*)d_rowcnt, hm_npts, pl[0], pl[1], pl[2], pl[3], pl[4], pl[5], pl[6], pl[7]);
+                       (const int*)d_rowcnt, hm_npts, pl[0], pl[1], pl[2], pl[3], pl[4], pl[5], pl[6], pl[7],
+                       m->mode == 0 ? m->fuse_dense_max : 0);
     HIP_OK(hipGetLastError());
   }
   return 0;

@@ -240,6 +240,11 @@ __device__ __forceinline__ void image_pyramid_fused_kernel_body(const float* __r
 __global__ void __launch_bounds__(kPyrThreads) image_pyramid_fused_kernel(const float* __restrict__ src, PyrOut o) {
   image_pyramid_fused_kernel_body<kPyrThreads>(src, o);
 }
+// Large images (many more tiles than CUs): 256 threads per tile, eight tiles resident per CU instead of two.
+constexpr int kPyrThreadsWide = 256;
+__global__ void __launch_bounds__(kPyrThreadsWide) image_pyramid_fused_wide_kernel(const float* __restrict__ src, PyrOut o) {
+  image_pyramid_fused_kernel_body<kPyrThreadsWide>(src, o);
+}
 
 // Whole depth pyramid in one launch: L_k(Y,X) = L_0(2^k Y + 2^k - 1, 2^k X + 2^k - 1), the composition of the
 // reference's odd decimations (ref: src/image_processing_global.cpp:85-89,99-103). Thread <-> level-0 pixel.

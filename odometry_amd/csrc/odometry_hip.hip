@@ -271,9 +271,14 @@ static int pyr_build(odo_pyr* p, const float* img_dev, int smooth) {
     memset(&o, 0, sizeof(o));
     o.n_levels = p->levels; o.smooth = smooth ? 1 : 0;
     for (int l = 0; l < p->levels; l++) { o.lvl[l] = p->dev + p->off[l]; o.rows[l] = p->r[l]; o.cols[l] = p->c[l]; }
-    if (p->kind == ODO_PYR_IMAGE)
-      hipLaunchKernelGGL(image_pyramid_fused_kernel, dim3((cols + kPT - 1) / kPT, (rows + kPT - 1) / kPT), dim3(kPyrThreads), 0, s,
-                         img_dev, o);
+    if (p->kind == ODO_PYR_IMAGE) {
+      const dim3 tiles((cols + kPT - 1) / kPT, (rows + kPT - 1) / kPT);
+      static const int wide_from = getenv("ODO_PYR_WIDE_FROM") ? atoi(getenv("ODO_PYR_WIDE_FROM")) : 1024;   // tiles
+      if ((int)(tiles.x * tiles.y) >= wide_from)
+        hipLaunchKernelGGL(image_pyramid_fused_wide_kernel, tiles, dim3(kPyrThreadsWide), 0, s, img_dev, o);
+      else
+        hipLaunchKernelGGL(image_pyramid_fused_kernel, tiles, dim3(kPyrThreads), 0, s, img_dev, o);
+    }
     else
       hipLaunchKernelGGL(depth_pyramid_fused_kernel, grid2d(cols, rows), dim3(256), 0, s, img_dev, o);
     HIP_OK(hipGetLastError());

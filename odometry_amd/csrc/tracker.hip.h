@@ -396,6 +396,9 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
       t->ahead_job = -1;
     }
     if (my_job < 0) {
+      // nothing may be left in the ring (a call that returned early after posting its job leaves one there): at most two jobs —
+      // this frame's and the next frame's — are ever outstanding
+      if (tracker_wait_idle(t)) return -1;
       my_job = t->w_posted.load(std::memory_order_relaxed);
       jk = &t->jobs[my_job & 1];
       tracker_job_fill(t, jk, left, right, t->cur_img, had_prefetch ? t->ev_next : t->ev_cur_img, (long)t->frame_id, t->cand_lists);

@@ -51,6 +51,11 @@ struct odo_ctx {
   int stage_busy[kStageSlots];
   int stage_next;
   std::vector<struct PoolBlock>* pool;  // recycled device blocks (see dev_alloc_any)
+  // per-sequence argument table of the batched Solves issued on this stream (odo_lm_solve_batch): per context, because the
+  // launches a finished Solve still has queued read it, and only the stream orders the next upload behind them
+  void* lm_batch_h;   // pinned
+  void* lm_batch_d;
+  int lm_batch_cap;   // entries
 };
 
 // ---- recycled device memory -------------------------------------------------------------------------------------------
@@ -122,6 +127,8 @@ extern "C" int odo_ctx_destroy(odo_ctx* c) {
     if (c->stage[i]) (void)hipHostFree(c->stage[i]);
   }
   if (c->pool) { for (auto& b : *c->pool) (void)hipFree(b.p); delete c->pool; }
+  if (c->lm_batch_h) (void)hipHostFree(c->lm_batch_h);
+  if (c->lm_batch_d) (void)hipFree(c->lm_batch_d);
   (void)hipStreamDestroy(c->stream);
   delete c;
   return 0;
@@ -1159,13 +1166,6 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
 // separate Solves (tests/test_gpu_batch.py). All optimisers must share one context (stream). Falls back to one Solve after
 // the other when a sequence cannot take the fused point-list pipeline (dense levels, t-distribution weights).
 // ---------------------------------------------------------------------------------------------------------------
-struct LmBatchScratch {   // per context-less: owned by the first optimiser of a batch
-  StepArgs* h_table;      // pinned
-  StepArgs* d_table;
-  int cap;
-};
-static LmBatchScratch g_lm_batch = {nullptr, nullptr, 0};
-
 // Fills `a` for a fused Solve of `m` (everything that stays constant over the Solve's launches). Returns the grid the
 // step launches need, the launch budget of the step kernel and the first level the coarse kernel does not take.
 static void lm_fill_step_args(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* cur_img, int token, StepArgs* ap, int* grid_out,
@@ -1230,13 +1230,16 @@ static int lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
     for (int i = 0; i < n; i++) { status[i] = odo_lm_solve(lms[i], kf_img[i], kf_dep[i], cur_img[i], out_colmajor + 16 * i); }
     return rc;
   }
-  if (g_lm_batch.cap < n) {
-    if (g_lm_batch.h_table) { HIP_OK(hipStreamSynchronize(s)); (void)hipHostFree(g_lm_batch.h_table); (void)hipFree(g_lm_batch.d_table); }
-    g_lm_batch.cap = 0;
-    HIP_OK(hipHostMalloc((void**)&g_lm_batch.h_table, sizeof(StepArgs) * (size_t)n, hipHostMallocDefault));
-    HIP_OK(hipMalloc((void**)&g_lm_batch.d_table, sizeof(StepArgs) * (size_t)n));
-    g_lm_batch.cap = n;
+  odo_ctx* cx = lms[0]->ctx;
+  if (cx->lm_batch_cap < n) {
+    if (cx->lm_batch_h) { HIP_OK(hipStreamSynchronize(s)); (void)hipHostFree(cx->lm_batch_h); (void)hipFree(cx->lm_batch_d); }
+    cx->lm_batch_cap = 0; cx->lm_batch_h = cx->lm_batch_d = nullptr;
+    HIP_OK(hipHostMalloc(&cx->lm_batch_h, sizeof(StepArgs) * (size_t)n, hipHostMallocDefault));
+    HIP_OK(hipMalloc(&cx->lm_batch_d, sizeof(StepArgs) * (size_t)n));
+    cx->lm_batch_cap = n;
   }
+  StepArgs* const h_table = (StepArgs*)cx->lm_batch_h;
+  StepArgs* const d_table = (StepArgs*)cx->lm_batch_d;
   int grid = 1, budget = 0, any_coarse = 0;
   std::vector<std::vector<double>> bytes(n, std::vector<double>(ODO_MAX_LEVELS, 0.0));
   std::vector<int> tokens(n);
@@ -1245,14 +1248,14 @@ static int lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
     m->token = (m->token % 0x3ffff) + 1;
     tokens[i] = m->token;
     int g = 1, b = 0, ml = 0;
-    lm_fill_step_args(m, kf_img[i], cur_img[i], tokens[i], &g_lm_batch.h_table[i], &g, &b, &ml, bytes[i].data());
+    lm_fill_step_args(m, kf_img[i], cur_img[i], tokens[i], &h_table[i], &g, &b, &ml, bytes[i].data());
     if (g > grid) grid = g;
     if (b > budget) budget = b;
     if (ml < m->n_levels) any_coarse = 1;
     m->last_coarse = (ml < m->n_levels) ? 1 : 0;
   }
   // the table of the previous batched Solve may still be read by its draining launches: order the upload behind them
-  HIP_OK(hipMemcpyAsync(g_lm_batch.d_table, g_lm_batch.h_table, sizeof(StepArgs) * (size_t)n, hipMemcpyHostToDevice, s));
+  HIP_OK(hipMemcpyAsync(d_table, h_table, sizeof(StepArgs) * (size_t)n, hipMemcpyHostToDevice, s));
   auto progress = [&](int i) { const int v = ((volatile int*)lms[i]->h_prog)[0]; return ((v >> kProgSeqBits) == tokens[i]) ? (v & ((1 << kProgSeqBits) - 1)) : 0; };
   auto finished = [&](int i) { return ((volatile int*)lms[i]->h_prog)[1] == tokens[i]; };
   auto all_finished = [&]() { for (int i = 0; i < n; i++) if (!finished(i)) return false; return true; };
@@ -1260,7 +1263,7 @@ static int lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
   int seq = 0, launches = 0;
   const int run_ahead = lms[0]->run_ahead;
   if (any_coarse) {
-    hipLaunchKernelGGL(lm_coarse_kernel_batch, dim3(1, n), dim3(kCoarseBlock), kCoarseLdsBytes, s, (const StepArgs*)g_lm_batch.d_table, seq, 1);
+    hipLaunchKernelGGL(lm_coarse_kernel_batch, dim3(1, n), dim3(kCoarseBlock), kCoarseLdsBytes, s, (const StepArgs*)d_table, seq, 1);
     seq++; launches++;
   }
   bool poll_ok = true;
@@ -1271,7 +1274,7 @@ static int lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
       if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { poll_ok = false; break; }  // never hang
     }
     if (all_finished()) break;
-    hipLaunchKernelGGL(lm_step_kernel_batch, dim3(grid, n), dim3(kLmBlock), 0, s, (const StepArgs*)g_lm_batch.d_table, seq,
+    hipLaunchKernelGGL(lm_step_kernel_batch, dim3(grid, n), dim3(kLmBlock), 0, s, (const StepArgs*)d_table, seq,
                        (seq == 0) ? 1 : 0);
     seq++; launches++;
     if (!poll_ok && it >= budget) break;
@@ -1292,7 +1295,7 @@ static int lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
       HIP_OK(hipStreamSynchronize(s));
       if (done[0] != tokens[i]) {
         FinalizeArgs fa;
-        const StepArgs& a = g_lm_batch.h_table[i];
+        const StepArgs& a = h_table[i];
         fa.st_in = a.st2[seq & 1]; fa.part_in = a.part2[seq & 1]; fa.precision = m->precision; fa.trace = m->d_trace;
         fa.cost_stat = m->d_cost; fa.st_out = a.st2[0]; fa.out = m->d_res_map; fa.done_flag = m->d_done;
         fa.token = tokens[i]; fa.first_of_solve = (seq == 0) ? 1 : 0;

@@ -416,3 +416,28 @@ def test_tracker_random_announcements(api, drives, seed):
     ref_maps = _track_single(api, seq, n)[1]
     for a, b in zip(maps, ref_maps):
         assert np.array_equal(a, b)
+
+
+def test_two_batched_trackers_interleaved(api, drives):
+    """Two batched trackers of one process stepped alternately (each on its own streams, with announcements): the launches a
+    finished batched Solve still has queued must never see the other tracker's argument table."""
+    n_frames = 8
+    refs = [_track_single(api, s, n_frames)[0] for s in drives]
+    tbs = [api.TrackerBatch(2), api.TrackerBatch(2)]
+    sel = [(0, 1), (2, 0)]                      # which drives each tracker's two slots run
+    L = [[[tb.upload_frame(f) for f in drives[d]["left"][:n_frames]] for d in ds] for tb, ds in zip(tbs, sel)]
+    R = [[[tb.upload_frame(f) for f in drives[d]["right"][:n_frames]] for d in ds] for tb, ds in zip(tbs, sel)]
+    for t, tb in enumerate(tbs):
+        tb.init([L[t][i][0] for i in range(2)], [R[t][i][0] for i in range(2)])
+    for k in range(1, n_frames):
+        for t, tb in enumerate(tbs):
+            if k + 1 < n_frames:
+                tb.hint_next([L[t][i][k + 1] for i in range(2)], [R[t][i][k + 1] for i in range(2)])
+            res = tb.track([L[t][i][k] for i in range(2)], [R[t][i][k] for i in range(2)])
+            for i in range(2):
+                ref = refs[sel[t][i]][k - 1]
+                assert res[i]["status"] == 0
+                assert np.array_equal(res[i]["pose_to_keyframe"], ref["pose_to_keyframe"]), (t, i, k)
+                assert res[i]["new_keyframe"] == ref["new_keyframe"]
+    for tb in tbs:
+        tb.close()

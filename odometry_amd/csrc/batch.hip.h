@@ -150,6 +150,7 @@ struct odo_tracker_batch {
   hipEvent_t ev_cur_img, ev_next;
   int overlap;       // 1: the depth chain runs on stream B beside the pose LM on stream A (one host thread feeds both)
   int depth_ahead;   // 1: announced pairs get their stream-B job a step early (ODO_NO_DEPTH_AHEAD=1: off)
+  int early_solve;   // 1: the next lock step's Solve is started as soon as this step's decisions are taken (ODO_NO_EARLY_SOLVE=1: off)
   BatchChain late, ahead;
   // overlap: a helper host thread feeds stream B — it runs the posted chains one after the other, each up to its completion
   // words (a slot's depth object serves one job at a time) — while the calling thread feeds the pose LM on stream A.
@@ -220,6 +221,7 @@ extern "C" int odo_tracker_batch_create(int device, const odo_tracker_params* p,
   b->tm_frame_us = b->tm_head_us = b->tm_solve_us = b->tm_depth_wait_us = 0.0; b->tm_frames = 0;
   b->overlap = (p->overlap_depth != 0) && !getenv("ODO_BATCH_NO_OVERLAP");
   b->depth_ahead = b->overlap && !getenv("ODO_NO_DEPTH_AHEAD");
+  b->early_solve = b->overlap && !getenv("ODO_NO_EARLY_SOLVE");
   b->lm.assign(S, nullptr); b->depth.assign(S, nullptr);
   b->kf_img.assign(S, nullptr); b->kf_dep.assign(S, nullptr); b->cur_img.assign(S, nullptr); b->next_img.assign(S, nullptr);
   for (int k = 0; k < 2; k++) {
@@ -744,6 +746,20 @@ extern "C" int odo_tracker_batch_track(odo_tracker_batch* b, const float* const*
     odo_lm_reset(b->lm[i], Ti, 0.01f);                                                     // :261 / :268
     if (motion_mag) motion_mag[i] = mag;
     status[i] = st[e] ? 1 : 0;
+  }
+  // ---- the next lock step's Solve: its inputs are all known now — the keyframes (promotions taken), the announced frames'
+  // pyramids (stream C, ev_next), the initial poses (:261 / :268 Reset above). Its coarse launch and first step launches go out
+  // here and run while the caller gets its results and comes back (lm_solve_batch collects the job if the next call brings
+  // exactly the announced frames, else it is abandoned like any finished Solve's queued launches).
+  if (b->early_solve && !nxt.empty()) {
+    std::vector<odo_lm*> l2;
+    std::vector<const odo_pyr*> ki, kd, cu;
+    for (int i : nxt)
+      if (b->alive[i]) { l2.push_back(b->lm[i]); ki.push_back(b->kf_img[i]); kd.push_back(b->kf_dep[i]); cu.push_back(b->next_img[i]); }
+    if (!l2.empty()) {
+      HIP_OK(hipStreamWaitEvent(sa, b->ev_next, 0));
+      if (lm_batch_begin((int)l2.size(), l2.data(), ki.data(), kd.data(), cu.data()) < 0) return -1;
+    }
   }
   if (any_depth_fail) fail("    depth failed!");
   b->tm_frame_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - f0).count();

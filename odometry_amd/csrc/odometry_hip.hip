@@ -56,6 +56,7 @@ struct odo_ctx {
   void* lm_batch_h;   // pinned
   void* lm_batch_d;
   int lm_batch_cap;   // entries
+  struct LmBatchJob* lm_batch_job;   // the batched Solve in flight on this stream, if any
 };
 
 // ---- recycled device memory -------------------------------------------------------------------------------------------
@@ -116,6 +117,7 @@ static int ctx_create(int device, int high_priority, odo_ctx** out) {
   *out = c;
   return 0;
 }
+static void lm_batch_job_free(odo_ctx* c);
 extern "C" int odo_ctx_destroy(odo_ctx* c) {
   if (!c) return 0;
   (void)hipSetDevice(c->device);
@@ -127,6 +129,7 @@ extern "C" int odo_ctx_destroy(odo_ctx* c) {
     if (c->stage[i]) (void)hipHostFree(c->stage[i]);
   }
   if (c->pool) { for (auto& b : *c->pool) (void)hipFree(b.p); delete c->pool; }
+  lm_batch_job_free(c);
   if (c->lm_batch_h) (void)hipHostFree(c->lm_batch_h);
   if (c->lm_batch_d) (void)hipFree(c->lm_batch_d);
   (void)hipStreamDestroy(c->stream);
@@ -481,6 +484,7 @@ struct odo_lm {
   long ev_launches, ev_active, ev_coarse_launches;
   int last_coarse;  // 1 if the last Solve started with the single-workgroup coarse kernel
   int trace_stale;
+  unsigned reset_gen;   // bumped by odo_lm_reset: a batched Solve started early is tied to it
   float* h_res; float* d_res_map; int* h_done; int* d_done; int token;  // host-mapped result + completion word
   int coarse;  // 1 = levels with <= kCoarseMaxPoints points run inside one workgroup (fused pipeline)
   int fused;  // 1 = one launch per evaluation (robust 0/1); 0 = separate residual / update kernels
@@ -592,6 +596,7 @@ extern "C" int odo_lm_destroy(odo_lm* m) {
 extern "C" int odo_lm_reset(odo_lm* m, const float init_colmajor[16], float lambda) {
   if (!m || !init_colmajor) { fail("Reset optimizer failed!"); return -1; }
   m->job.active = 0;                                // a Solve started early with the old initial pose is abandoned
+  m->reset_gen++;
   memcpy(m->init, init_colmajor, sizeof(m->init));  // SetInitialAffine, ref: src/lm_optimizer.cpp:385-389
   m->lambda = lambda;                               // SetLambda, ref: :391-395
   for (int i = 0; i < ODO_MAX_LEVELS; i++) m->iters[i] = 0;  // ResetStatistics, ref: :397-405
@@ -1204,19 +1209,69 @@ static void lm_fill_step_args(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* c
   *min_level_out = min_level;
 }
 
-// idle / idle_arg: called from the wait loops (the batched tracker pumps its depth stream from there), may be NULL.
-static int lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_img, const odo_pyr* const* kf_dep,
-                          const odo_pyr* const* cur_img, float* out_colmajor /* n x 16 */, int* status /* n */,
-                          void (*idle)(void*), void* idle_arg) {
-  if (n < 1 || !lms || !kf_img || !kf_dep || !cur_img || !out_colmajor || !status) return fail("odo_lm_solve_batch: bad arg");
-  bool batchable = n <= 64;
-  for (int i = 0; i < n && batchable; i++) {
-    if (!lms[i] || lms[i]->ctx != lms[0]->ctx) return fail("odo_lm_solve_batch: the optimisers must share one context");
-    for (int j = 0; j < i; j++) if (lms[j] == lms[i]) return fail("odo_lm_solve_batch: the same optimiser twice");
-    if (lm_check_pyrs(lms[i], kf_img[i], kf_dep[i], cur_img[i])) return -1;
+// A batched Solve as a resumable job (one per context): lm_batch_begin fills and uploads the argument table and enqueues the
+// coarse launch and as many step launches as the run-ahead allows; lm_solve_batch collects a job that matches its arguments
+// (same optimisers, same pyramids by build version, no Reset since) or starts one. The batched tracker begins the NEXT lock
+// step's Solve as soon as this step's decisions are taken.
+struct LmBatchJob {
+  int active, n;
+  std::vector<odo_lm*> lms;
+  std::vector<const odo_pyr*> kf_img, kf_dep, cur_img;
+  std::vector<unsigned long long> kf_img_ver, kf_dep_ver, cur_ver;
+  std::vector<unsigned> reset_gen;
+  std::vector<int> tokens;
+  std::vector<std::vector<double>> bytes;
+  int grid, budget, seq, launches, it;
+  bool poll_ok, issued_all;
+};
+static void lm_batch_job_free(odo_ctx* c) { delete c->lm_batch_job; c->lm_batch_job = nullptr; }
+
+static bool lm_batch_all_finished(const LmBatchJob& jb) {
+  for (int i = 0; i < jb.n; i++) if (((volatile int*)jb.lms[i]->h_prog)[1] != jb.tokens[i]) return false;
+  return true;
+}
+static int lm_batch_min_progress(const LmBatchJob& jb) {
+  int p = 1 << 30;
+  for (int i = 0; i < jb.n; i++) {
+    if (((volatile int*)jb.lms[i]->h_prog)[1] == jb.tokens[i]) continue;
+    const int v = ((volatile int*)jb.lms[i]->h_prog)[0];
+    const int q = ((v >> kProgSeqBits) == jb.tokens[i]) ? (v & ((1 << kProgSeqBits) - 1)) : 0;
+    if (q < p) p = q;
   }
-  hipStream_t s = lms[0]->ctx->stream;
-  HIP_OK(hipSetDevice(lms[0]->ctx->device));
+  return p;
+}
+// Issues step launches; block = false: returns as soon as the next launch would have to wait for the device.
+static void lm_batch_pump(odo_ctx* cx, bool block, void (*idle)(void*), void* idle_arg) {
+  LmBatchJob& jb = *cx->lm_batch_job;
+  if (!jb.active || jb.issued_all) return;
+  hipStream_t s = cx->stream;
+  const int run_ahead = jb.lms[0]->run_ahead;
+  while (jb.it < jb.budget + 1) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (!lm_batch_all_finished(jb) && jb.seq - lm_batch_min_progress(jb) > run_ahead) {
+      if (!block) return;
+      if (idle) idle(idle_arg);
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { jb.poll_ok = false; break; }  // never hang
+    }
+    if (lm_batch_all_finished(jb)) break;
+    hipLaunchKernelGGL(lm_step_kernel_batch, dim3(jb.grid, jb.n), dim3(kLmBlock), 0, s, (const StepArgs*)cx->lm_batch_d, jb.seq,
+                       (jb.seq == 0) ? 1 : 0);
+    jb.seq++; jb.launches++;
+    if (!jb.poll_ok && jb.it >= jb.budget) break;
+    jb.it++;
+  }
+  jb.issued_all = true;
+}
+
+// Returns 0 started, 1 not batchable (nothing started), -1 error. The keyframe lists must be current for every optimiser.
+static int lm_batch_begin(int n, odo_lm* const* lms, const odo_pyr* const* kf_img, const odo_pyr* const* kf_dep,
+                          const odo_pyr* const* cur_img) {
+  odo_ctx* cx = lms[0]->ctx;
+  hipStream_t s = cx->stream;
+  if (!cx->lm_batch_job) cx->lm_batch_job = new LmBatchJob();
+  LmBatchJob& jb = *cx->lm_batch_job;
+  jb.active = 0;
+  bool batchable = n <= 64;
   for (int i = 0; i < n; i++) {
     odo_lm* m = lms[i];
     m->job.active = 0;
@@ -1225,12 +1280,7 @@ static int lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
     for (int l = 0; l < m->n_levels; l++) if (!m->use_list[l]) fused = false;
     batchable = batchable && fused;
   }
-  if (!batchable) {  // one after the other: same results, no batching
-    int rc = 0;
-    for (int i = 0; i < n; i++) { status[i] = odo_lm_solve(lms[i], kf_img[i], kf_dep[i], cur_img[i], out_colmajor + 16 * i); }
-    return rc;
-  }
-  odo_ctx* cx = lms[0]->ctx;
+  if (!batchable) return 1;
   if (cx->lm_batch_cap < n) {
     if (cx->lm_batch_h) { HIP_OK(hipStreamSynchronize(s)); (void)hipHostFree(cx->lm_batch_h); (void)hipFree(cx->lm_batch_d); }
     cx->lm_batch_cap = 0; cx->lm_batch_h = cx->lm_batch_d = nullptr;
@@ -1240,15 +1290,19 @@ static int lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
   }
   StepArgs* const h_table = (StepArgs*)cx->lm_batch_h;
   StepArgs* const d_table = (StepArgs*)cx->lm_batch_d;
+  jb.n = n;
+  jb.lms.assign(lms, lms + n); jb.kf_img.assign(kf_img, kf_img + n); jb.kf_dep.assign(kf_dep, kf_dep + n); jb.cur_img.assign(cur_img, cur_img + n);
+  jb.kf_img_ver.resize(n); jb.kf_dep_ver.resize(n); jb.cur_ver.resize(n); jb.reset_gen.resize(n); jb.tokens.resize(n);
+  jb.bytes.assign(n, std::vector<double>(ODO_MAX_LEVELS, 0.0));
   int grid = 1, budget = 0, any_coarse = 0;
-  std::vector<std::vector<double>> bytes(n, std::vector<double>(ODO_MAX_LEVELS, 0.0));
-  std::vector<int> tokens(n);
   for (int i = 0; i < n; i++) {
     odo_lm* m = lms[i];
+    jb.kf_img_ver[i] = kf_img[i]->version; jb.kf_dep_ver[i] = kf_dep[i]->version; jb.cur_ver[i] = cur_img[i]->version;
+    jb.reset_gen[i] = m->reset_gen;
     m->token = (m->token % 0x3ffff) + 1;
-    tokens[i] = m->token;
+    jb.tokens[i] = m->token;
     int g = 1, b = 0, ml = 0;
-    lm_fill_step_args(m, kf_img[i], cur_img[i], tokens[i], &h_table[i], &g, &b, &ml, bytes[i].data());
+    lm_fill_step_args(m, kf_img[i], cur_img[i], jb.tokens[i], &h_table[i], &g, &b, &ml, jb.bytes[i].data());
     if (g > grid) grid = g;
     if (b > budget) budget = b;
     if (ml < m->n_levels) any_coarse = 1;
@@ -1256,30 +1310,56 @@ static int lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
   }
   // the table of the previous batched Solve may still be read by its draining launches: order the upload behind them
   HIP_OK(hipMemcpyAsync(d_table, h_table, sizeof(StepArgs) * (size_t)n, hipMemcpyHostToDevice, s));
-  auto progress = [&](int i) { const int v = ((volatile int*)lms[i]->h_prog)[0]; return ((v >> kProgSeqBits) == tokens[i]) ? (v & ((1 << kProgSeqBits) - 1)) : 0; };
-  auto finished = [&](int i) { return ((volatile int*)lms[i]->h_prog)[1] == tokens[i]; };
-  auto all_finished = [&]() { for (int i = 0; i < n; i++) if (!finished(i)) return false; return true; };
-  auto min_progress = [&]() { int p = 1 << 30; for (int i = 0; i < n; i++) { const int q = finished(i) ? (1 << 30) : progress(i); if (q < p) p = q; } return p; };
-  int seq = 0, launches = 0;
-  const int run_ahead = lms[0]->run_ahead;
+  jb.grid = grid; jb.budget = budget; jb.seq = 0; jb.launches = 0; jb.it = 0; jb.poll_ok = true; jb.issued_all = false;
   if (any_coarse) {
-    hipLaunchKernelGGL(lm_coarse_kernel_batch, dim3(1, n), dim3(kCoarseBlock), kCoarseLdsBytes, s, (const StepArgs*)d_table, seq, 1);
-    seq++; launches++;
+    hipLaunchKernelGGL(lm_coarse_kernel_batch, dim3(1, n), dim3(kCoarseBlock), kCoarseLdsBytes, s, (const StepArgs*)d_table, jb.seq, 1);
+    jb.seq++; jb.launches++;
   }
-  bool poll_ok = true;
-  for (int it = 0; it < budget + 1; it++) {
-    const auto t0 = std::chrono::steady_clock::now();
-    while (!all_finished() && seq - min_progress() > run_ahead) {
-      if (idle) idle(idle_arg);
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { poll_ok = false; break; }  // never hang
-    }
-    if (all_finished()) break;
-    hipLaunchKernelGGL(lm_step_kernel_batch, dim3(grid, n), dim3(kLmBlock), 0, s, (const StepArgs*)d_table, seq,
-                       (seq == 0) ? 1 : 0);
-    seq++; launches++;
-    if (!poll_ok && it >= budget) break;
-  }
+  jb.active = 1;
+  lm_batch_pump(cx, false, nullptr, nullptr);
   HIP_OK(hipGetLastError());
+  return 0;
+}
+
+static bool lm_batch_matches(const odo_ctx* cx, int n, odo_lm* const* lms, const odo_pyr* const* kf_img,
+                             const odo_pyr* const* kf_dep, const odo_pyr* const* cur_img) {
+  const LmBatchJob* jb = cx->lm_batch_job;
+  if (!jb || !jb->active || jb->n != n) return false;
+  for (int i = 0; i < n; i++)
+    if (jb->lms[i] != lms[i] || jb->kf_img[i] != kf_img[i] || jb->kf_dep[i] != kf_dep[i] || jb->cur_img[i] != cur_img[i] ||
+        jb->kf_img_ver[i] != kf_img[i]->version || jb->kf_dep_ver[i] != kf_dep[i]->version || jb->cur_ver[i] != cur_img[i]->version ||
+        jb->reset_gen[i] != lms[i]->reset_gen) return false;
+  return true;
+}
+
+// idle / idle_arg: called from the wait loops, may be NULL.
+static int lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_img, const odo_pyr* const* kf_dep,
+                          const odo_pyr* const* cur_img, float* out_colmajor /* n x 16 */, int* status /* n */,
+                          void (*idle)(void*), void* idle_arg) {
+  if (n < 1 || !lms || !kf_img || !kf_dep || !cur_img || !out_colmajor || !status) return fail("odo_lm_solve_batch: bad arg");
+  for (int i = 0; i < n; i++) {
+    if (!lms[i] || lms[i]->ctx != lms[0]->ctx) return fail("odo_lm_solve_batch: the optimisers must share one context");
+    for (int j = 0; j < i; j++) if (lms[j] == lms[i]) return fail("odo_lm_solve_batch: the same optimiser twice");
+    if (lm_check_pyrs(lms[i], kf_img[i], kf_dep[i], cur_img[i])) return -1;
+  }
+  odo_ctx* cx = lms[0]->ctx;
+  hipStream_t s = cx->stream;
+  HIP_OK(hipSetDevice(cx->device));
+  if (!lm_batch_matches(cx, n, lms, kf_img, kf_dep, cur_img)) {
+    if (cx->lm_batch_job) cx->lm_batch_job->active = 0;   // a job started on other inputs is abandoned: its launches drain
+    const int rc = lm_batch_begin(n, lms, kf_img, kf_dep, cur_img);
+    if (rc < 0) return -1;
+    if (rc == 1) {  // one after the other: same results, no batching
+      for (int i = 0; i < n; i++) { status[i] = odo_lm_solve(lms[i], kf_img[i], kf_dep[i], cur_img[i], out_colmajor + 16 * i); }
+      return 0;
+    }
+  }
+  LmBatchJob& jb = *cx->lm_batch_job;
+  lm_batch_pump(cx, true, idle, idle_arg);
+  HIP_OK(hipGetLastError());
+  jb.active = 0;
+  const StepArgs* h_table = (const StepArgs*)cx->lm_batch_h;
+  const int seq = jb.seq, launches = jb.launches;
   // results: each sequence's finishing launch wrote its own host-mapped block
   int any_fail = 0;
   for (int i = 0; i < n; i++) {
@@ -1287,18 +1367,18 @@ static int lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
     volatile int* done = m->h_done;
     const auto t0 = std::chrono::steady_clock::now();
     bool ok = true;
-    while (done[0] != tokens[i]) {
+    while (done[0] != jb.tokens[i]) {
       if (idle) idle(idle_arg);
       if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { ok = false; break; }
     }
     if (!ok) {  // drain, then consume this sequence's last evaluation explicitly
       HIP_OK(hipStreamSynchronize(s));
-      if (done[0] != tokens[i]) {
+      if (done[0] != jb.tokens[i]) {
         FinalizeArgs fa;
         const StepArgs& a = h_table[i];
         fa.st_in = a.st2[seq & 1]; fa.part_in = a.part2[seq & 1]; fa.precision = m->precision; fa.trace = m->d_trace;
         fa.cost_stat = m->d_cost; fa.st_out = a.st2[0]; fa.out = m->d_res_map; fa.done_flag = m->d_done;
-        fa.token = tokens[i]; fa.first_of_solve = (seq == 0) ? 1 : 0;
+        fa.token = jb.tokens[i]; fa.first_of_solve = (seq == 0) ? 1 : 0;
         memcpy(fa.init, m->init, sizeof(fa.init));
         hipLaunchKernelGGL(lm_fused_finalize_kernel, dim3(1), dim3(kLmBlock), 0, s, fa);
         HIP_OK(hipStreamSynchronize(s));
@@ -1312,7 +1392,7 @@ static int lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
     m->last_evals = (int)m->h_out[17];
     m->last_launches = launches;
     m->last_bytes = 0.0;
-    for (int l = 0; l < ODO_MAX_LEVELS; l++) { m->iters[l] = (int)m->h_out[18 + l]; m->last_bytes += bytes[i][l] * m->iters[l]; }
+    for (int l = 0; l < ODO_MAX_LEVELS; l++) { m->iters[l] = (int)m->h_out[18 + l]; m->last_bytes += jb.bytes[i][l] * m->iters[l]; }
     status[i] = (m->h_out[16] != 0.0f) ? -1 : 0;
     if (status[i]) { any_fail = 1; }
   }

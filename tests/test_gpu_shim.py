@@ -163,3 +163,36 @@ def test_cpp_camera_pyramid_over_shim(tmp_path):
             np.testing.assert_allclose(vals[4], intr[l, 0] / (640 / 5.76), rtol=1e-8)   # f_meters, ref: include/camera.h:85
     assert "camera raw image is not 480x640!" in out.stdout
     assert "stereo configuration done!" in out.stdout
+
+
+def test_c_example_over_the_tracker_abi(tmp_path):
+    """examples/track_resident.c — plain C over odo_tracker_*, frames resident on the device, the next pair announced before
+    every frame: the same pose_to_keyframe as the C++ runner over the drop-in classes, bit for bit, with and without the
+    announcements, pass after pass."""
+    from odometry_amd import synth
+    seq = synth.make_sequence(14, seed=0)     # long enough for the first keyframe switch (frame 9)
+    L, R = seq["left"], seq["right"]
+    frames = str(tmp_path / "frames.bin")
+    with open(frames, "wb") as f:
+        np.array([len(L), L[0].shape[0], L[0].shape[1]], np.int32).tofile(f)
+        for l, r in zip(L, R):
+            l.astype(np.float32).tofile(f)
+            r.astype(np.float32).tofile(f)
+    shim = _build(tmp_path, "examples/run_odometry_synth.cpp", "run_odometry_synth")
+    rel_shim = str(tmp_path / "rel_shim.bin")
+    out = subprocess.run([shim, frames, "--rel-bin", rel_shim], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    want = np.fromfile(rel_shim, np.float32)
+    exe = str(tmp_path / "track_resident")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "track_resident.c"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "odometry_amd", "lib"), "-lodometry_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "odometry_amd", "lib"), "-lm"])
+    for extra in ([], ["--no-announce"]):
+        rel = str(tmp_path / "rel_c.bin")
+        out = subprocess.run([exe, frames, "--passes", "2", "--rel-bin", rel] + extra, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        assert re.search(r"TRACK_FPS ([\d.]+) FRAMES 26 PASSES 2", out.stderr), out.stderr[-500:]
+        assert "Total keyframes: 1" in out.stdout or "Total keyframes:" in out.stdout
+        got = np.fromfile(rel, np.float32)
+        assert got.shape == want.shape and np.array_equal(got, want), extra

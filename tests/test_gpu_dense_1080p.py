@@ -150,3 +150,29 @@ def test_compute_depth_1080p_any_size_matches_oracle(api, O, scene):
     # the guard itself still stands without the knob
     de2 = api.DepthEstimator(8.0, 900.0, 15.0, 0.1, 30.0, 0.01, 28.0, 0.995, 50, 4, None, None, 0.5, 80000, intrinsics=K)
     assert de2.ComputeDepth(L, R, val, disp, dep) == -1
+
+
+@pytest.mark.parametrize("robust", [1, 0])
+def test_kitti_size_dense_solve_hands_over_at_level_0(api, O, kitti_seq, robust):
+    """376x1241 with dense ground-truth depth: levels 3..1 (7 k / 28 k / 113 k pixels, all with depth) run on their point lists
+    through the fused pipeline, level 0 (454 k) on the dense scan — the hand-over happens between levels 1 and 0. Trace and
+    pose against the oracle; the tracker's early start (odo_lm_solve_begin) works on such a Solve too."""
+    L, Z = kitti_seq["left"], kitti_seq["depth"]
+    inv = np.where(Z[0] < 99.0, 1.0 / np.maximum(Z[0], 1e-3), 0.0).astype(np.float32)
+    p0, d0, p1 = api.ImagePyramid(4, L[0], True), api.DepthPyramid(4, inv, False), api.ImagePyramid(4, L[1], True)
+    ref = O.lm_solve(O.image_pyramid(L[0], 4, True, flat=True), O.depth_pyramid(inv, 4, flat=True),
+                     O.image_pyramid(L[1], 4, True, flat=True), 376, 1241, O.lm_params(robust=robust))
+    for begin_early in (False, True):
+        lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, robust, 28.0)
+        if begin_early:
+            assert lm.SolveBegin(p0, d0, p1) == 0
+        T = lm.Solve(p0, d0, p1)
+        assert lm.points()[1][:4] == [0, 1, 1, 1]
+        assert lm.last_status == 0 and ref["status"] == 0
+        tr = lm.trace()
+        assert len(tr) == ref["n_evals"]
+        for a, b in zip(tr, ref["trace"]):
+            assert (a["level"], a["iter"], a["n_res"], a["accepted"], a["stop"]) == \
+                   (b["level"], b["iter"], b["n_res"], b["accepted"], b["stop"])
+        assert se3_log_norm(ref["pose"], T) < 1e-5
+        lm.close()

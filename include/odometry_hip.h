@@ -132,8 +132,10 @@ int odo_lm_destroy(odo_lm* lm);
  * acc[28] N. Parity-test entry for the dominant kernel. */
 int odo_lm_accumulate(odo_lm* lm, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img, int level,
                       const float T_colmajor[16], double acc[ODO_NACC]);
-/* Per-evaluation trace of the last Solve: rows of 12 floats
- * {level, iter, N, err, lambda_after, accepted, stop, delta[0..5] (first 5)...}; see DESIGN.md. */
+/* Per-evaluation trace of the last Solve (level, iteration, residual count, accept / stop decision, error, lambda, step; see
+ * DESIGN.md). Optimisers created with odo_lm_create record it (and the per-level cost statistics of odo_lm_report); the
+ * optimisers inside odo_tracker / odo_tracker_batch do not — nobody reads them, and the row costs ~600 cycles per evaluation on
+ * the critical wave — unless ODO_LM_TRACE=1 is set when the tracker is created; odo_lm_trace then returns -1. */
 typedef struct {
   int level, iter, n_res, accepted, stop;
   float err, lambda_after;

@@ -266,6 +266,7 @@ extern "C" int odo_tracker_batch_create(int device, const odo_tracker_params* p,
   ok = ok && hipHostGetDevicePointer((void**)&b->d_cand_npts, b->h_cand_npts, 0) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&b->ev_cur_img, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&b->ev_next, hipEventDisableTiming) == hipSuccess;
+  if (ok && !getenv("ODO_LM_TRACE")) for (odo_lm* m : b->lm) m->record = 0;
   if (!ok) {
     char keep[512];
     snprintf(keep, sizeof(keep), "%s", g_err);

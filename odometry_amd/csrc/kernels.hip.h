@@ -937,7 +937,9 @@ __device__ __forceinline__ void lm_state_machine(bool pending, const StepLevel* 
     }
     if (smdbg && t == 0) { smdbg[0] += c1 - c0; smdbg[1] += c2 - c1; smdbg[2] += c3 - c2; smdbg[3] += 1; }
     if (pending) {
-      if (publisher && t == 0) {
+      // trace == NULL: an optimiser whose per-evaluation rows and per-level cost statistics nobody reads (the trackers' own):
+      // the ~80 instructions of the row are then not on the critical wave (~600 cycles per evaluation of the coarse kernel)
+      if (publisher && t == 0 && trace) {
         const int ev = s.n_evals - 1;
         if (ev < kTraceCap) {
           LmTraceRow& r = trace[ev];
@@ -1060,7 +1062,7 @@ __device__ __forceinline__ void lm_fused_prologue(const LmState* __restrict__ st
       s_sh.level = -1; s_sh.iter = 0; s_sh.lambda = 0.0f; s_sh.err_last = 1e+10f;
       for (int i = 0; i < 16; i++) s_sh.T[i] = m[i];
     }
-    if (publisher && t < 16) cost_stat[t] = 0.0f;
+    if (publisher && t < 16 && cost_stat) cost_stat[t] = 0.0f;
   } else if (t < (int)(sizeof(LmState) / sizeof(int))) {
     ((int*)&s_sh)[t] = ((const int*)st_in)[t];
   }
@@ -1115,7 +1117,7 @@ __device__ __forceinline__ void lm_write_result(const LmState& s, const float* c
   out[16] = (float)s.status;
   out[17] = (float)s.n_evals;
   for (int i = 0; i < 8; i++) out[18 + i] = (float)s.iters_level[i];
-  for (int i = 0; i < 16; i++) out[26 + i] = cost_stat[i];
+  for (int i = 0; i < 16; i++) out[26 + i] = cost_stat ? cost_stat[i] : 0.0f;
   __hip_atomic_store(done_flag, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 

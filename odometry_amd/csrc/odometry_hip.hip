@@ -484,6 +484,8 @@ struct odo_lm {
   long ev_launches, ev_active, ev_coarse_launches;
   int last_coarse;  // 1 if the last Solve started with the single-workgroup coarse kernel
   int trace_stale;
+  int record;      // 1: per-evaluation trace rows and per-level cost statistics are written (odo_lm_trace / odo_lm_report);
+                   // the trackers switch it off for their own optimisers (ODO_LM_TRACE=1 keeps it)
   unsigned reset_gen;   // bumped by odo_lm_reset: a batched Solve started early is tied to it
   float* h_res; float* d_res_map; int* h_done; int* d_done; int token;  // host-mapped result + completion word
   int coarse;  // 1 = levels with <= kCoarseMaxPoints points run inside one workgroup (fused pipeline)
@@ -560,6 +562,7 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
     HIP_OK(hipHostGetDevicePointer((void**)&cs.hm_npts, cs.h_npts, 0));
     cs.tag = -1;
   }
+  m->record = 1;
   m->mode = getenv("ODO_LM_MODE") ? atoi(getenv("ODO_LM_MODE")) : 0;
   m->dense_plain_div = getenv("ODO_DENSE_PLAIN_DIV") ? 1 : 0;
   m->fused = getenv("ODO_LM_UNFUSED") ? 0 : 1;
@@ -881,7 +884,7 @@ static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_de
     jb.bytes_per_level[l] = lm_level_bytes(m, l, L.rows, L.cols, L.nblk);
   }
   a.lambda0 = m->lambda; a.precision = m->precision; a.robust = m->robust; a.huber_delta = m->huber_delta;
-  a.trace = m->d_trace; a.cost_stat = m->d_cost; a.host_prog = m->d_prog;
+  a.trace = m->record ? m->d_trace : nullptr; a.cost_stat = m->record ? m->d_cost : nullptr; a.host_prog = m->d_prog;
   a.out = m->d_res_map; a.done_flag = m->d_done; a.token = jb.token;
   a.stop_level = stop;
   a.final_state = stop > 0 ? m->d_state + 2 : nullptr;
@@ -1015,7 +1018,7 @@ static int lm_unfused_levels(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf
       seq++;
       lm_launch_eval(m, v, k, l, nblk);
       hipLaunchKernelGGL(lm_update_kernel<false>, dim3(1), dim3(kUpdThreads), 0, s, m->ust, m->d_partials, nblk, l,
-                         m->precision, m->max_iters[l], m->d_trace, m->d_cost, m->d_prog + m->upo, seq,
+                         m->precision, m->max_iters[l], m->record ? m->d_trace : nullptr, m->d_cost, m->d_prog + m->upo, seq,
                          (unsigned long long*)nullptr);
       (*launches_io)++;
     }
@@ -1089,8 +1092,8 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
     // path; the host spins on the completion word (bounded; falls back to a stream sync).
     auto launch_finalize = [&]() {
       FinalizeArgs fa;
-      fa.st_in = st[seq & 1]; fa.part_in = part[seq & 1]; fa.precision = m->precision; fa.trace = m->d_trace;
-      fa.cost_stat = m->d_cost; fa.st_out = st[0]; fa.out = m->d_res_map; fa.done_flag = m->d_done;
+      fa.st_in = st[seq & 1]; fa.part_in = part[seq & 1]; fa.precision = m->precision; fa.trace = m->record ? m->d_trace : nullptr;
+      fa.cost_stat = m->record ? m->d_cost : nullptr; fa.st_out = st[0]; fa.out = m->d_res_map; fa.done_flag = m->d_done;
       fa.token = token; fa.first_of_solve = (seq == 0) ? 1 : 0;
       memcpy(fa.init, m->init, sizeof(fa.init));
       hipLaunchKernelGGL(lm_fused_finalize_kernel, dim3(1), dim3(kLmBlock), 0, s, fa);
@@ -1192,7 +1195,7 @@ static void lm_fill_step_args(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* c
     bytes_per_level[l] = lm_level_bytes(m, l, L.rows, L.cols, L.nblk);
   }
   a.lambda0 = m->lambda; a.precision = m->precision; a.robust = m->robust; a.huber_delta = m->huber_delta;
-  a.trace = m->d_trace; a.cost_stat = m->d_cost; a.host_prog = m->d_prog;
+  a.trace = m->record ? m->d_trace : nullptr; a.cost_stat = m->record ? m->d_cost : nullptr; a.host_prog = m->d_prog;
   a.out = m->d_res_map; a.done_flag = m->d_done; a.token = token;
   memcpy(a.init, m->init, sizeof(a.init));
   a.st2[0] = m->d_state; a.st2[1] = m->d_state + 1;
@@ -1376,8 +1379,8 @@ static int lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
       if (done[0] != jb.tokens[i]) {
         FinalizeArgs fa;
         const StepArgs& a = h_table[i];
-        fa.st_in = a.st2[seq & 1]; fa.part_in = a.part2[seq & 1]; fa.precision = m->precision; fa.trace = m->d_trace;
-        fa.cost_stat = m->d_cost; fa.st_out = a.st2[0]; fa.out = m->d_res_map; fa.done_flag = m->d_done;
+        fa.st_in = a.st2[seq & 1]; fa.part_in = a.part2[seq & 1]; fa.precision = m->precision; fa.trace = m->record ? m->d_trace : nullptr;
+        fa.cost_stat = m->record ? m->d_cost : nullptr; fa.st_out = a.st2[0]; fa.out = m->d_res_map; fa.done_flag = m->d_done;
         fa.token = jb.tokens[i]; fa.first_of_solve = (seq == 0) ? 1 : 0;
         memcpy(fa.init, m->init, sizeof(fa.init));
         hipLaunchKernelGGL(lm_fused_finalize_kernel, dim3(1), dim3(kLmBlock), 0, s, fa);
@@ -1465,6 +1468,7 @@ extern "C" int odo_lm_report(const odo_lm* m, int iters[4], float cost[4][2]) {
 extern "C" int odo_lm_trace(const odo_lm* mc, odo_lm_trace_row* rows, int cap, int* n_rows) {
   odo_lm* m = const_cast<odo_lm*>(mc);
   if (!m || !n_rows) return fail("NULL arg");
+  if (!m->record) return fail("odo_lm_trace: this optimiser does not record its trace (a tracker's own; ODO_LM_TRACE=1 keeps it)");
   if (m->trace_stale) {
     HIP_OK(hipMemcpyAsync(m->h_trace, m->d_trace, sizeof(LmTraceRow) * kTraceCap, hipMemcpyDeviceToHost, m->ctx->stream));
     HIP_OK(hipStreamSynchronize(m->ctx->stream));

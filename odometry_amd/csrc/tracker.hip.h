@@ -168,6 +168,7 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
   }
   ok = ok && hipEventCreateWithFlags(&t->ev_cur_img, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&t->ev_next, hipEventDisableTiming) == hipSuccess;
+  if (ok && !getenv("ODO_LM_TRACE")) t->lm->record = 0;   // nobody reads the per-evaluation rows / cost statistics of a tracker's Solves
   if (!ok) {
     char keep[512];
     snprintf(keep, sizeof(keep), "%s", g_err);

@@ -1407,7 +1407,6 @@ __device__ __forceinline__ void depth_select_kernel_body(const float* __restrict
                                                                     float grad_th, uint8_t* __restrict__ val,
                                                                     uint32_t* __restrict__ pts, int* __restrict__ cnt) {
   __shared__ float mag[kSelMaxElems];
-  __shared__ int bins[16][4];  // one 4-bin digit histogram per radix pass (all zeroed up front: one barrier per pass)
   __shared__ int wave_tot[kSelThreads / kWave];
   __shared__ int base_sh;
   const int t = threadIdx.x;
@@ -1419,7 +1418,6 @@ __device__ __forceinline__ void depth_select_kernel_body(const float* __restrict
     return;
   }
   const int sy = bnd + (b / 32) * bh, sx = bnd + (b % 32) * bw;
-  if (t < 16 * 4) (&bins[0][0])[t] = 0;
   constexpr int kPer = kSelMaxElems / kSelThreads;  // keys per thread (1 at KITTI size: 38 x 23 = 874 per block)
   unsigned keys[kPer];
 #pragma unroll
@@ -1437,42 +1435,56 @@ __device__ __forceinline__ void depth_select_kernel_body(const float* __restrict
   }
   __syncthreads();
   // Block median = the element nth_element(size / 2) leaves at that position (:328) = the k-th smallest, k = bsz / 2:
-  // MSB-first radix select, 2 bits per pass. Each wave counts the four values of the current digit among the keys that
-  // still match the prefix with four ballots, four lanes add the wave's counts to the pass's bins, and after one barrier
-  // every thread reads the four bins and narrows (prefix, k) identically. With 32 waves resident per CU the selection is
-  // instruction-issue bound, so the digit is kept narrow: 16 passes x 4 ballots per wave (measured: a full bitonic sort
-  // of the 1024 keys, or 4-bit digits with 16 ballots per pass, both cost ~16 us of the kernel's 22).
+  // MSB-first radix select, 8 bits per pass. The keys that still match the prefix are counted into a 256-bin LDS histogram
+  // (one ds_add per key), wave 0 finds the bin that holds the k-th key with a prefix scan (four bins per lane), and every
+  // thread narrows (prefix, k) identically. Four passes of ~20 instructions per wave — the 2-bit / four-ballot variant this
+  // replaces spent ~1 000 instructions per wave (16 passes), and with 32 waves resident per CU the selection is
+  // instruction-issue bound (13 us -> see DESIGN 5.2).
+  __shared__ int hist[256];
+  __shared__ int sel_sh[2];
   unsigned prefix = 0u, pmask = 0u;
   int kth = bsz / 2;
   {
     const int lane = t & 63;
 #pragma unroll
-    for (int pass = 0; pass < 16; pass++) {
-      const int shift = 30 - 2 * pass;
-      int mine = 0;  // lane d < 4 ends up with this wave's count of digit d
-#pragma unroll
-      for (int d = 0; d < 4; d++) {
-        int c = 0;
-#pragma unroll
-        for (int u = 0; u < kPer; u++) {
-          if (u * kSelThreads >= bsz) break;  // block-uniform: no keys in this round
-          const bool hit = ((keys[u] & pmask) == prefix) && (((keys[u] >> shift) & 3u) == (unsigned)d);
-          c += __popcll(__ballot(hit));
-        }
-        if (lane == d) mine = c;
-      }
-      if (lane < 4 && mine) atomicAdd(&bins[pass][lane], mine);
+    for (int pass = 0; pass < 4; pass++) {
+      const int shift = 24 - 8 * pass;
+      if (t < 256) hist[t] = 0;
       __syncthreads();
-      int d = 0, below = 0;
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int c = bins[pass][q];
-        if (below + c <= kth && d == q) { below += c; d = q + 1; }
+      for (int u = 0; u < kPer; u++) {
+        if (u * kSelThreads >= bsz) break;  // block-uniform: no keys in this round
+        const int e = t + u * kSelThreads;
+        if (e < bsz && (keys[u] & pmask) == prefix) atomicAdd(&hist[(keys[u] >> shift) & 255u], 1);
       }
-      // d = first digit whose cumulative count exceeds kth (d < 4 because the matching keys number > kth)
-      kth -= below;
-      prefix |= (unsigned)d << shift;
-      pmask |= 3u << shift;
+      __syncthreads();
+      if (t < 64) {
+        const int c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+        const int sum = (c0 + c1) + (c2 + c3);
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int v = __shfl_up(incl, o, 64);
+          if (lane >= o) incl += v;
+        }
+        const int excl = incl - sum;
+        if (excl <= kth && kth < incl) {   // exactly one lane: the matching keys number more than kth
+          int below = excl, d = 4 * lane;
+          if (kth >= below + c0) {
+            below += c0; d++;
+            if (kth >= below + c1) {
+              below += c1; d++;
+              if (kth >= below + c2) { below += c2; d++; }
+            }
+          }
+          sel_sh[0] = d;
+          sel_sh[1] = below;
+        }
+      }
+      __syncthreads();
+      kth -= sel_sh[1];
+      prefix |= (unsigned)sel_sh[0] << shift;
+      pmask |= 255u << shift;
     }
   }
   const float median = __uint_as_float(prefix);

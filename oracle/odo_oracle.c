@@ -5,7 +5,10 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as the
  * checker (or as the timed CPU baseline), never as the thing shipped or measured as the GPU path.
  *
- * PARITY UNPINNED.  The reference (WangYuTum/odometry) cannot be built here (no Eigen, no OpenCV,
+ * PARITY UNPINNED, except the disparity scan.  orc_disparity_scan / ssd8 / cx_level below are checked bit for bit against
+ * the reference's own lines (src/depth_estimate.cpp:380-395,435-453; include/image_processing_global.h:22-28), compiled from
+ * /root/reference by oracle/make_ref_fixtures.py: tests/golden/ssd_ref.npz, cx_level_ref.npz, tests/test_ref_pin.py.
+ * For everything else: the reference (WangYuTum/odometry) cannot be built here (no Eigen, no OpenCV,
  * empty nanogui submodule, std::sqrtf) and none of its tests pins a numeric result, so this file is a
  * from-scratch restatement that follows the cited reference lines op for op.  Where the reference
  * delegates to OpenCV / Eigen (blur, pyrDown, dense products, the 6x6 solve, quaternion<->matrix) the
@@ -809,6 +812,44 @@ static float ssd8(const float L[8], const float* img, int cols, int x, int y) {
   return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 float orc_ssd8_tree(const float s[8]) { return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7])); }
+/* one candidate: left taps in lane order against the right image at (x, y) — tests/test_ref_pin.py */
+float orc_ssd8_at(const float L[8], const float* img, int cols, int x, int y) { return ssd8(L, img, cols, x, y); }
+
+/* The epipolar scan of DisparityDepthEstimate on its own (ref: src/depth_estimate.cpp:345-398): for every marked pixel of the
+ * BLURRED pair the 8-tap SSD of every candidate column, first strict minimum, threshold, disparity and inverse depth. Optional
+ * outputs best / match (smallest SSD and its column per marked pixel) exist for tests/test_ref_pin.py, which compares this
+ * function with the reference's own lines compiled by oracle/make_ref_fixtures.py. */
+void orc_disparity_scan(const float* L, const float* R, const uint8_t* val, int rows, int cols, int bnd, float ssd_th, float fx,
+                        float baseline, int max_disparity, float* disp, float* dep, float* best_out, int* match_out,
+                        int* n_sel_out, int* n_match_out) {
+  int n_sel = 0, n_match = 0;
+  for (int y = bnd; y < rows - bnd; y++)                                  /* :346 */
+    for (int x = bnd; x < cols - bnd; x++) {                              /* :352 */
+      if (val[(size_t)y * cols + x] == 0) continue;
+      n_sel++;
+      const float* pp = L + (size_t)(y - 2) * cols; const float* pr = L + (size_t)(y - 1) * cols;
+      const float* cr = L + (size_t)y * cols; const float* nr = L + (size_t)(y + 1) * cols;
+      const float* nn = L + (size_t)(y + 2) * cols;
+      const float Lp[8] = {nn[x], nr[x - 1], cr[x + 2], cr[x], cr[x - 2], pr[x + 1], pr[x - 1], pp[x]}; /* :380-381 */
+      float best = 1e+10f;
+      int match = -1;
+      int lo = bnd;
+      if (max_disparity > 0 && x - max_disparity > lo) lo = x - max_disparity;
+      for (int rx = lo; rx < x; rx++) {                                   /* :382 */
+        const float s = ssd8(Lp, R, cols, rx, y);
+        if (s < best) { best = s; match = rx; }                           /* :385-386 strict < */
+      }
+      if (best_out) best_out[(size_t)y * cols + x] = best;
+      if (match_out) match_out[(size_t)y * cols + x] = match;
+      if (best > ssd_th) continue;                                        /* :388 */
+      const float dsp = (float)abs(x - match);                            /* :391 */
+      disp[(size_t)y * cols + x] = dsp;
+      dep[(size_t)y * cols + x] = dsp / (fx * baseline);                  /* :394 */
+      n_match++;
+    }
+  if (n_sel_out) *n_sel_out = n_sel;
+  if (n_match_out) *n_match_out = n_match;
+}
 
 /* DisparityDepthEstimate (ref: src/depth_estimate.cpp:244-401). val must be zeroed by the caller;
  * disp/dep are zero-filled here. bl/br receive the blurred images if non-NULL. */
@@ -846,29 +887,8 @@ static int disparity_depth(const float* left, const float* right, int rows, int 
         if (grad[(size_t)y * cols + x] > th) { val[(size_t)y * cols + x] = 1; vc++; }
       }
   }
-  const float fx = p->f0;
-  for (int y = bnd; y < rows - bnd; y++)                                  /* :346 */
-    for (int x = bnd; x < cols - bnd; x++) {                              /* :352 */
-      if (val[(size_t)y * cols + x] == 0) continue;
-      n_sel++;
-      const float* pp = L + (size_t)(y - 2) * cols; const float* pr = L + (size_t)(y - 1) * cols;
-      const float* cr = L + (size_t)y * cols; const float* nr = L + (size_t)(y + 1) * cols;
-      const float* nn = L + (size_t)(y + 2) * cols;
-      const float Lp[8] = {nn[x], nr[x - 1], cr[x + 2], cr[x], cr[x - 2], pr[x + 1], pr[x - 1], pp[x]}; /* :380-381 */
-      float best = 1e+10f;
-      int match = -1;
-      int lo = bnd;
-      if (p->max_disparity > 0 && x - p->max_disparity > lo) lo = x - p->max_disparity;
-      for (int rx = lo; rx < x; rx++) {                                   /* :382 */
-        const float s = ssd8(Lp, R, cols, rx, y);
-        if (s < best) { best = s; match = rx; }                           /* :385-386 strict < */
-      }
-      if (best > p->ssd_th) continue;                                     /* :388 */
-      const float dsp = (float)abs(x - match);                            /* :391 */
-      disp[(size_t)y * cols + x] = dsp;
-      dep[(size_t)y * cols + x] = dsp / (fx * p->baseline);               /* :394 */
-      n_match++;
-    }
+  orc_disparity_scan(L, R, val, rows, cols, bnd, p->ssd_th, p->f0, p->baseline, p->max_disparity, disp, dep, NULL, NULL,
+                     &n_sel, &n_match);
   if (st) { st->n_selected = n_sel; st->n_matched = n_match; }
   free(L); free(R); free(grad); free(bg);
   return 0;

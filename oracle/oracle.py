@@ -86,6 +86,8 @@ def lib():
         _lib.orc_cx_level.restype = C.c_float
         _lib.orc_cx_level.argtypes = [C.c_float, C.c_int]
         _lib.orc_ssd8_tree.restype = C.c_float
+        _lib.orc_ssd8_at.restype = C.c_float
+        _lib.orc_disparity_scan.restype = None
     return _lib
 
 
@@ -249,6 +251,27 @@ def compute_depth(left, right, params, stage=2):
                                      disp.ctypes.data_as(_fp), dep.ctypes.data_as(_fp), C.byref(st))
     return dict(status=status, val=val, disp=disp, dep=dep, n_selected=st.n_selected, n_matched=st.n_matched,
                 n_valid=st.n_valid, iters=st.iters, cost=st.cost)
+
+
+def disparity_scan(left_blur, right_blur, val, boundary=4, ssd_th=900.0, f0=718.856, baseline=KITTI_BASELINE, max_disparity=0):
+    """The epipolar scan alone on an already blurred pair and a given mask (ref: src/depth_estimate.cpp:345-398)."""
+    lb, pl = _f(left_blur)
+    rb, pr = _f(right_blur)
+    val = np.ascontiguousarray(val, np.uint8)
+    rows, cols = lb.shape
+    disp, dep, best = (np.zeros((rows, cols), np.float32) for _ in range(3))
+    col = np.full((rows, cols), -1, np.int32)
+    ns, nm = C.c_int(0), C.c_int(0)
+    lib().orc_disparity_scan(pl, pr, val.ctypes.data_as(_u8p), rows, cols, boundary, C.c_float(ssd_th), C.c_float(f0),
+                             C.c_float(baseline), max_disparity, disp.ctypes.data_as(_fp), dep.ctypes.data_as(_fp),
+                             best.ctypes.data_as(_fp), col.ctypes.data_as(C.POINTER(C.c_int)), C.byref(ns), C.byref(nm))
+    return dict(disp=disp, dep=dep, best_ssd=best, best_col=col, n_selected=ns.value, n_matched=nm.value)
+
+
+def ssd8_at(left_lane_order, img, x, y):
+    L, pL = _f(left_lane_order)
+    im, pi = _f(img)
+    return lib().orc_ssd8_at(pL, pi, im.shape[1], int(x), int(y))
 
 
 def track_frame(kf_img_flat, kf_dep_flat, cur_left, cur_right, lm_p, depth_p, init):

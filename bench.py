@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """bench.py — tracked frames/s of the photometric-LM hot path on N MI355X (one process per GPU).
 
-Workload (BASELINE.json configs[1]): a synthetic KITTI-shaped forward drive of --unique-frames (200) stereo pairs,
+`python bench.py --gpus N` works both ways: launched by torch.distributed.run (WORLD_SIZE set: this process is one rank), or
+plainly — then this process starts the N ranks itself (a child `python -m torch.distributed.run ... bench.py`, before anything here
+touches the GPU), relays rank 0's one JSON line and exits non-zero if any rank failed. It never prints n_gpus != --gpus.
+
+Workload (BASELINE.json configs[1]): a synthetic KITTI-shaped forward drive of --unique-frames (200) stereo pairs (--drive natural:
+textures with the 1/f amplitude spectrum of natural images, on which the reference's keyframe policy keeps track; the white-ish
+"corridor" drive of rounds 1-2, on which it loses track at every keyframe switch, is reported beside it as stress_drive),
 1241x376, 4-level pyramid, semi-dense points, fp32, runner parameters (ref: run_odometry_kitti_offline.cpp:58-88),
 replayed pass after pass (the tracker is re-initialised on frame 0 at the start of each pass). One "step" = one
 iteration of the runner's frame loop (ref: :198-271) on one stereo pair that is already resident in HBM:
@@ -16,6 +22,8 @@ import argparse
 import gc
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,6 +33,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector peak (256 CUs x 128 lanes x 2 flop x 2.4 GHz), non-packed FMA rate
+L1_PEAK_GBS = 256 * 64 * 2.4  # 64 B / clk / CU vector L1 x 256 CUs x 2.4 GHz = 39.3 TB/s
+DRIVE = "natural"             # set from --drive in main(); the render workers read it
 
 
 def frame_order(n_unique, n_steps):
@@ -40,15 +51,16 @@ def begins_pass(order, k):
     return k > 0 and order[k] == 1
 
 
-def render_sequence(n_frames, seed, workers):
+def render_sequence(n_frames, seed, workers, drive=None):
     """The synthetic stereo sequence, rendered by a small process pool (called before anything touches the GPU)."""
     from odometry_amd import synth
+    drive = drive or DRIVE
     if workers <= 1 or n_frames <= 8:
-        return synth.make_sequence(n_frames, seed=seed)
+        return synth.make_sequence(n_frames, seed=seed, drive=drive)
     import concurrent.futures as cf
-    poses = synth.trajectory(n_frames, seed)
+    poses = synth.drive_trajectory(drive, n_frames, seed)
     with cf.ProcessPoolExecutor(max_workers=workers) as ex:
-        frames = list(ex.map(_render_pair, [(seed, poses[i]) for i in range(n_frames)], chunksize=max(1, n_frames // (4 * workers))))
+        frames = list(ex.map(_render_pair, [(seed, poses[i], drive) for i in range(n_frames)], chunksize=max(1, n_frames // (4 * workers))))
     return dict(left=[f[0] for f in frames], right=[f[1] for f in frames], poses=poses, depth=[])
 
 
@@ -57,10 +69,10 @@ _scene_cache = {}
 
 def _render_pair(job):
     from odometry_amd import synth
-    seed, T = job
-    if seed not in _scene_cache:
-        _scene_cache[seed] = synth.Scene(seed)
-    sc = _scene_cache[seed]
+    seed, T, drive = job
+    if (seed, drive) not in _scene_cache:
+        _scene_cache[(seed, drive)] = synth.drive_scene(drive, seed)
+    sc = _scene_cache[(seed, drive)]
     L, _ = sc.render(T, synth.KITTI_ROWS, synth.KITTI_COLS, synth.KITTI_F, synth.KITTI_CX, synth.KITTI_CY, 0.0)
     R, _ = sc.render(T, synth.KITTI_ROWS, synth.KITTI_COLS, synth.KITTI_F, synth.KITTI_CX, synth.KITTI_CY, synth.KITTI_BASELINE)
     return L, R
@@ -212,9 +224,16 @@ def disparity_leg(api, seq, trk):
         de = api.DepthEstimator(8.0, 900.0, 15.0, 0.1, 30.0, 0.01, 28.0, 0.995, 50, 4, None, None,
                                 float(np.float32(386.1448) / np.float32(718.856)), 80000, ctx=ctx, max_disparity=md)
         t = de.time_stages(l_dev, r_dev, 376, 1241, reps=20)
+        scan_s = t["scan_us"] * 1e-6
+        tf = t["candidates"] * 24.0 / scan_s / 1e12          # ~24 flop per candidate (8 sub, 8 mul, 7 add, 1 compare)
+        l1 = t["candidates"] * 8 * 4.0 / scan_s / 1e9        # eight 4-byte taps per candidate, served by the vector L1
         out[name] = dict(scan_us=round(t["scan_us"], 2), select_us=round(t["select_us"], 2), blur_us=round(t["blur_us"], 2),
                          selected_points=t["n_selected"], ssd_candidates=int(t["candidates"]),
-                         gcandidates_per_s=round(t["candidates"] / (t["scan_us"] * 1e-6) / 1e9, 2))
+                         gcandidates_per_s=round(t["candidates"] / scan_s / 1e9, 2),
+                         roofline=dict(kernel="depth_disparity_kernel", bound="valu/l1", flop_per_candidate=24,
+                                       achieved=round(tf, 2), peak=VALU_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tf / VALU_F32_PEAK_TFLOPS, 4),
+                                       l1_achieved_gbs=round(l1, 1), l1_peak_gbs=round(L1_PEAK_GBS, 1), l1_frac=round(l1 / L1_PEAK_GBS, 4),
+                                       hbm_new_bytes="~0: both blurred images (3.7 MB) are L2 / Infinity-Cache resident"))
         de.close()
     ctx.free(l_dev)
     ctx.free(r_dev)
@@ -485,6 +504,176 @@ def batched_sequences_leg(api, seqs, counts=(1, 2, 4, 8), passes=3):
                      "front end (pyramids, blur, selection, disparity scan) of all S frames")
 
 
+def tracking_error(poses_abs_colmajor, gt_c2w, frame_ids):
+    """Translation error of tracked absolute poses (n x 16, column-major, camera-to-world with frame 0 = identity) against the
+    synthetic ground truth (ref: run_odometry_kitti_offline.cpp:361-372 evaluates exactly this: mean translation error)."""
+    est = np.asarray(poses_abs_colmajor, np.float64).reshape(-1, 4, 4).transpose(0, 2, 1)[:, :3, 3]
+    gt = np.array([gt_c2w[i][:3, 3] for i in frame_ids], np.float64)
+    e = np.linalg.norm(est - gt, axis=1)
+    return e
+
+
+def drive_leg(api, seq, warmup, steps, local_rank=0):
+    """One pass of the runner's loop over a resident sequence with the next pair announced (the timed run's configuration), on a
+    tracker of its own: frames/s over `steps` frames after `warmup`, LM evaluations per frame, tracking error vs ground truth."""
+    n = len(seq["left"])
+    steps = max(1, min(steps, n - 1 - warmup))
+    trk = api.Tracker(local_rank)
+    dev = [(trk.upload_frame(l), trk.upload_frame(r)) for l, r in zip(seq["left"][:warmup + steps + 1], seq["right"][:warmup + steps + 1])]
+    pk, pa = np.zeros((warmup + steps, 16), np.float32), np.zeros((warmup + steps, 16), np.float32)
+    trk.init(*dev[0])
+    evals, kfs = [], 0
+    t0 = None
+    for k in range(warmup + steps):
+        if k == warmup:
+            trk._sync()
+            t0 = time.perf_counter()
+        if k + 2 <= warmup + steps and k + 1 != warmup:
+            trk.hint_next(*dev[k + 2])
+        kfs += trk.track_into(dev[k + 1][0], dev[k + 1][1], pk[k], pa[k])
+        evals.append(trk.stats()["lm_evals"])
+    trk._sync()
+    dt = time.perf_counter() - t0
+    err = tracking_error(pa, seq["poses"], list(range(1, warmup + steps + 1)))
+    trk.close()
+    return dict(frames_per_s=round(steps / dt, 1), frames=steps, warmup=warmup, lm_evals_per_frame=round(float(np.mean(evals[warmup:])), 2),
+                keyframes=kfs + 1,
+                tracking_error_vs_ground_truth_m=dict(mean=round(float(err.mean()), 4), median=round(float(np.median(err)), 4),
+                                                      max=round(float(err.max()), 4), frames_within_5cm=int((err < 0.05).sum()),
+                                                      frames=int(err.size)))
+
+
+def configs3_leg(api, seqs, my_ids, n_sequences, world, rank, local_rank, backend, steps, warmup, gather_every):
+    """BASELINE.json configs[3] proper, run by ALL ranks after the headline region of an N > 1 run: n_sequences (11 = KITTI 00-10)
+    distinct drives dealt round-robin over the ranks (dist.shard), a rank's sequences tracked in lock step in the same launches
+    (odo_tracker_batch), poses gathered over the same backend with the schedule-based exchange. Strong scaling: value = all frames
+    / max-over-ranks wall time. Returns the leg's dict on rank 0, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    from odometry_amd.dist import PoseGatherer, frames_per_rank
+    m = len(my_ids)
+    per_rank = frames_per_rank(n_sequences, steps, world)
+    gath = PoseGatherer(world, gather_every, device="cuda" if backend == "nccl" else None, n_local_frames=per_rank[rank],
+                        n_max_frames=max(per_rank)) if world > 1 else None
+    tb = None
+    if m > 0:
+        tb = api.TrackerBatch(m, local_rank)
+        dv = [[(tb.upload_frame(l), tb.upload_frame(r)) for l, r in zip(q["left"], q["right"])] for q in seqs]
+        n_fr = len(seqs[0]["left"])
+        lp = [tb._ptrs([dv[j][i][0] for j in range(m)]) for i in range(n_fr)]
+        rp = [tb._ptrs([dv[j][i][1] for j in range(m)]) for i in range(n_fr)]
+        tb.init([dv[j][0][0] for j in range(m)], [dv[j][0][1] for j in range(m)])
+        for k in range(warmup):
+            if k + 1 < warmup:
+                tb.hint_next(lp[k + 2], rp[k + 2])
+            tb.track_raw(lp[k + 1], rp[k + 1])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    errs = []
+    if m > 0:
+        for k in range(warmup, warmup + steps):
+            if k + 1 < warmup + steps:
+                tb.hint_next(lp[k + 2], rp[k + 2])
+            tb.track_raw(lp[k + 1], rp[k + 1])
+            A = tb._A.reshape(m, 16)
+            for j in range(m):
+                if gath is not None:
+                    gath.push(A[j].reshape(4, 4).T, seq_id=my_ids[j], frame_id=k + 1)
+                errs.append(float(np.linalg.norm(A[j].reshape(4, 4).T[:3, 3].astype(np.float64) - seqs[j]["poses"][k + 1][:3, 3])))
+        tb.lib.odo_tracker_batch_quiesce(tb.h)
+    if gath is not None:
+        gath.flush()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    secs = [dt]
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        al = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(al, tt)
+        secs = [float(t.item()) for t in al]
+    if tb is not None:
+        tb.close()
+    if rank != 0:
+        return None
+    got = [int(gath.rows(r).shape[0]) for r in range(world)] if gath is not None else per_rank
+    return dict(sequences=n_sequences, steps_per_sequence=steps, warmup=warmup, frames_per_rank=per_rank,
+                frames_per_s=round(n_sequences * steps / max(secs), 1), seconds_per_rank=[round(t, 4) for t in secs],
+                scaling="strong", sequences_in_lock_step_on_rank0=m,
+                pose_gather=dict(rows_per_rank=got, complete=(got == per_rank), collectives=gath.issued if gath is not None else 0),
+                rank0_frames_within_5cm_of_ground_truth=[int(sum(e < 0.05 for e in errs)), len(errs)],
+                what="configs[3]: %d distinct synthetic sequences dealt round-robin over %d ranks, a rank's sequences in lock step "
+                     "(odo_tracker_batch), schedule-based pose gather" % (n_sequences, world))
+
+
+def launch_ranks(n, argv, timeout=3600):
+    """`bench.py --gpus N` started plainly (no WORLD_SIZE): start the N ranks as a child torch.distributed.run — one process per
+    GPU, rendezvous on 127.0.0.1 — BEFORE this process has touched the GPU (it never does), relay rank 0's JSON line, and return
+    the exit code: non-zero when any rank failed, when no line came back, or when the line's n_gpus is not N."""
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)   # stderr passes through
+    try:
+        out, _ = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        p.communicate()
+        print(f"bench.py: the {n} ranks did not finish within {timeout} s", file=sys.stderr)
+        return 124
+    line = None
+    for ln in out.splitlines():
+        if ln.startswith("{"):
+            try:
+                d = json.loads(ln)
+            except ValueError:
+                continue
+            if "metric" in d:
+                line = (ln, d)
+        else:
+            print(ln, file=sys.stderr)
+    if p.returncode != 0:
+        print(f"bench.py: torch.distributed.run exited with {p.returncode}: a rank failed, no result printed", file=sys.stderr)
+        return p.returncode or 1
+    if line is None:
+        print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
+        return 1
+    if line[1].get("n_gpus") != n:
+        print(f"bench.py: the ranks report n_gpus = {line[1].get('n_gpus')}, asked for {n}: refusing to print it", file=sys.stderr)
+        return 1
+    print(line[0], flush=True)
+    return 0
+
+
+def launch_probe(args, world, rank):
+    """Test hook (--launch-probe, CPU only): what a rank does up to the point where it would touch the GPU — join the process group
+    (gloo), prove every rank is there with one all_reduce — then rank 0 prints a line in the bench format. `fail` makes rank 1 exit
+    non-zero so the launcher's error path can be tested. tests/test_bench_launcher.py."""
+    import torch
+    import torch.distributed as dist
+    if args.launch_probe == "fail" and rank == world - 1:
+        raise SystemExit(3)
+    seen = 1
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        dist.destroy_process_group()
+    if rank == 0:
+        n_gpus = world + 1 if args.launch_probe == "lie" else world
+        print(json.dumps(dict(metric="launch-probe", value=0.0, unit="frames/s", n_gpus=n_gpus, ranks_seen=seen, steps=args.steps,
+                              warmup=args.warmup)))
+
+
 def main():
     if os.environ.get("ODO_BENCH_FAULT_DUMP"):   # diagnostic: Python stacks of every thread on stderr after this many seconds
         import faulthandler
@@ -516,15 +705,34 @@ def main():
                          "over the ranks (dist.shard); every sequence is tracked for --steps frames, a rank tracks its sequences "
                          "one after the other; value = sequences x steps / max-over-ranks wall time. 0 (default) = one sequence "
                          "per rank, --steps frames each (weak scaling, the driver's contract)")
+    ap.add_argument("--drive", default="natural",
+                    help="synthetic drive (odometry_amd/synth.py DRIVES): natural (default: 1/f-spectrum textures, the tracker "
+                         "keeps track) or corridor (rounds 1-2: the reference's keyframe policy loses track at every switch)")
+    ap.add_argument("--no-stress", action="store_true", help="skip the stress_drive leg (the corridor drive beside the headline)")
+    ap.add_argument("--event-sample", type=int, default=8,
+                    help="roofline: every N-th LM launch of the TIMED run carries HIP start / stop events (0 = none)")
+    ap.add_argument("--configs3", type=int, default=11,
+                    help="N > 1 runs: after the headline region, BASELINE.json configs[3] as an extra key of the same line — this "
+                         "many distinct sequences (11 = KITTI 00-10) dealt over the ranks, batched ranks (0 = skip)")
+    ap.add_argument("--launch-probe", default="", help=argparse.SUPPRESS)
     ap.add_argument("--no-batch", action="store_true",
                     help="--sequences: a rank that holds several sequences tracks them one after the other (one odo_tracker) instead "
                          "of in lock step in the same launches (odo_tracker_batch)")
     args = ap.parse_args()
     args.unique_frames = max(args.unique_frames, 2)
+    global DRIVE
+    DRIVE = args.drive
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started plainly with --gpus N: this process becomes the launcher (nothing above has touched the GPU)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {world}: refusing to run (n_gpus must be what was asked for)")
+    if args.launch_probe:
+        return launch_probe(args, world, rank)
     # Weak scaling wants the same work on every GPU: per-frame cost depends on image content (20-50 LM evaluations), so by
     # default every rank tracks its own copy of synthetic sequence 0; --distinct-sequences gives rank r sequence r and
     # --sequences S deals S distinct sequences over the ranks. Rendered first, by a few worker processes, before this process
@@ -538,6 +746,15 @@ def main():
     else:
         seqs = [render_sequence(args.unique_frames, rank if args.distinct_sequences else 0, workers)]
     seq = seqs[0] if seqs else render_sequence(args.unique_frames, 0, workers)   # a rank without a sequence still takes part
+    c3_ids, c3_seqs, c3_steps, c3_warm = [], [], 0, 0
+    if world > 1 and args.sequences == 0 and args.configs3 > 0 and not args.no_extras:
+        c3_warm = min(args.warmup, 5)
+        c3_steps = max(1, min(args.steps, 40))
+        c3_ids = shard(args.configs3, rank, world)
+        c3_seqs = [render_sequence(c3_warm + c3_steps + 1, sid, workers) for sid in c3_ids]
+    stress_seq = None
+    if world == 1 and not args.no_extras and not args.no_stress and args.drive != "corridor":
+        stress_seq = render_sequence(min(args.unique_frames, 200), 0, workers, drive="corridor")
     batch_seqs = None
     if world == 1 and not args.no_extras and "batched" in args.extras.split(","):
         nb = min(args.unique_frames, 40)   # eight distinct short drives for the batched leg (rendered before the GPU is touched)
@@ -551,13 +768,26 @@ def main():
     backend = os.environ.get("ODO_BENCH_BACKEND", "nccl")
     if os.environ.get("ODO_BENCH_SHARE_GPU"):
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank}, this node has {torch.cuda.device_count()} (one rank per GPU)")
     torch.cuda.set_device(local_rank)
+    exchange = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+        # Evidence that the exchange really spans `world` ranks on distinct devices: one all_reduce of ones over the very backend
+        # the pose gather uses (nccl = RCCL over xGMI), and an all_gather of every rank's device identity.
+        dev = "cuda" if backend == "nccl" else "cpu"
+        ones = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(ones)
+        props = torch.cuda.get_device_properties(local_rank)
+        ident = f"{socket.gethostname()}:{local_rank}:{getattr(props, 'uuid', '')}:{getattr(props, 'pci_bus_id', '')}:{getattr(props, 'pci_device_id', '')}"
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        exchange = dict(backend=dist.get_backend(), ranks_seen=int(ones.item()), distinct_devices=len(set(idents)))
 
     from odometry_amd import api, synth
     # Each rank keeps two host threads busy (the caller polls the LM stream, the helper feeds the depth stream). On a host
@@ -647,6 +877,12 @@ def main():
         run_sequence(0, False)
     barrier()
     trk.timing()  # reset the host-clock diagnostics
+    step_s = np.zeros(args.steps, np.float64)   # wall time of every timed step of this rank's first sequence (spread diagnostics)
+    # roofline of the dominant kernels, measured IN the timed run: every --event-sample-th LM launch carries start / stop events
+    # bound to its dispatch (a sample keeps the perturbation of the timed region below a percent; bracketing every launch costs 3-5 %)
+    ev_in_timed = args.event_sample > 0 and args.sequences == 0
+    if ev_in_timed:
+        trk.event_timing(args.event_sample)
     # The harness is Python: with torch imported a generation-2 garbage collection takes ~30 ms (140 frames' worth) and
     # would land somewhere inside the timed loop. The loop itself allocates next to nothing, so the collector is parked.
     gc.collect()
@@ -664,6 +900,13 @@ def main():
               ", ".join("#%d %.0f" % (j, st[j]) for j in top), file=sys.stderr)
     elif use_batch:
         run_batched()
+    elif args.sequences == 0 and my_seq_ids:
+        tp = time.perf_counter()
+        for k in range(args.warmup, n_total):    # run_sequence(0, True) with the clock read between steps
+            step(0, k, devs[0], True)
+            tn = time.perf_counter()
+            step_s[k - args.warmup] = tn - tp
+            tp = tn
     else:
         for j in range(len(my_seq_ids)):
             run_sequence(j, True)
@@ -672,39 +915,72 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    ev_timed = trk.event_stats_ex() if ev_in_timed else None
+    if ev_in_timed:
+        trk.event_timing(0)
+    my_elapsed = elapsed
+    rank_elapsed = [elapsed]
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        all_t = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(all_t, tt)
+        rank_elapsed = [float(t.item()) for t in all_t]
+        elapsed = max(rank_elapsed)
 
     fps = args.steps * n_sequences / elapsed   # frames tracked by all ranks / max-over-ranks wall time
     host_timing = trk.timing()
+    c3 = None
+    if c3_steps > 0:
+        try:
+            c3 = configs3_leg(api, c3_seqs, c3_ids, args.configs3, world, rank, local_rank, backend, c3_steps, c3_warm, args.gather_every)
+        except Exception as e:   # noqa: BLE001 — a collective leg: a failing rank fails the run (the launcher reports it)
+            print(f"[rank {rank}] configs3 leg failed: {type(e).__name__}: {e}", file=sys.stderr)
+            raise
     if rank == 0:
-        # --- roofline of the dominant kernels (lm_coarse_kernel + lm_step_kernel: LM update + residual / normal-equation pass):
-        # a second pass over the same frames with every launch bracketed by HIP events on the kernel's own stream.
-        n_frames_ev = min(args.steps, 100)
-        trk.init(*dev[0])
-        trk.event_timing(True)
-        for k, i in enumerate(order[:n_frames_ev]):
-            if begins_pass(order, k):
-                trk.init(*dev[0])
-            trk.track(*dev[i])
-        ev = trk.event_stats()
-        trk.event_timing(False)
-        step_launches = max(ev["launches"] - ev["coarse_launches"], 1)
-        step_us = (ev["total_us"] - ev["coarse_us"]) / step_launches
-        achieved = ev["bytes"] / (ev["total_us"] * 1e-6) / 1e9 if ev["total_us"] > 0 else 0.0
+        # --- roofline of the dominant kernels (lm_coarse_kernel + lm_step_kernel: LM update + residual / normal-equation pass)
+        if ev_timed is not None and ev_timed["step_sampled"] > 0:
+            # from the TIMED run itself: sampled launches carry dispatch-bound start / stop events; counts are exact
+            n_frames_ev = args.steps
+            step_launches = max(ev_timed["launches"] - ev_timed["coarse_launches"], 1)
+            step_us = ev_timed["step_us"] / ev_timed["step_sampled"]
+            coarse_us = ev_timed["coarse_us"] / max(ev_timed["coarse_sampled"], 1)
+            total_us = step_us * step_launches + coarse_us * ev_timed["coarse_launches"]
+            ev = dict(bytes=ev_timed["bytes"], active_launches=ev_timed["evaluations"], coarse_launches=ev_timed["coarse_launches"])
+            how = (f"HIP events on every {args.event_sample}th LM launch of the timed run itself ({ev_timed['step_sampled']} step + "
+                   f"{ev_timed['coarse_sampled']} coarse launches sampled of {ev_timed['launches']}); launch counts exact")
+        else:
+            # --sequences / --event-sample 0: a second pass over the same frames with every launch bracketed (inflates durations 3-5 %)
+            n_frames_ev = min(args.steps, 100)
+            trk.init(*dev[0])
+            trk.event_timing(1)
+            for k, i in enumerate(order[:n_frames_ev]):
+                if begins_pass(order, k):
+                    trk.init(*dev[0])
+                trk.track(*dev[i])
+            e1 = trk.event_stats()
+            trk.event_timing(0)
+            step_launches = max(e1["launches"] - e1["coarse_launches"], 1)
+            step_us = (e1["total_us"] - e1["coarse_us"]) / step_launches
+            coarse_us = e1["coarse_us"] / max(e1["coarse_launches"], 1)
+            total_us = e1["total_us"]
+            ev = dict(bytes=e1["bytes"], active_launches=e1["active_launches"], coarse_launches=e1["coarse_launches"])
+            how = "a separate pass over the same frames with HIP events on every LM launch (not the timed run)"
+        achieved = ev["bytes"] / (total_us * 1e-6) / 1e9 if total_us > 0 else 0.0
+        kernel_us_per_frame = total_us / n_frames_ev
         roof = dict(bound="hbm", kernel="LM evaluation kernels (lm_coarse_kernel + lm_step_kernel)",
                     achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 6),
-                    traffic=load_traffic()[0], traffic_source=load_traffic()[1],
+                    traffic=load_traffic()[0], traffic_source=load_traffic()[1], measured=how,
                     evaluations_per_frame=round(ev["active_launches"] / n_frames_ev, 2),
                     algorithmic_bytes_per_frame=round(ev["bytes"] / n_frames_ev, 1),
-                    kernel_us_per_frame=round(ev["total_us"] / n_frames_ev, 2),
-                    lm_step_kernel=dict(launches_per_frame=round(step_launches / n_frames_ev, 2), launch_us=round(step_us, 3)),
+                    kernel_us_per_frame=round(kernel_us_per_frame, 2),
+                    kernel_time_fits_in_step=bool(kernel_us_per_frame <= elapsed / args.steps * 1e6) if ev_timed is not None else None,
+                    lm_step_kernel=dict(launches_per_frame=round(step_launches / n_frames_ev, 2), launch_us=round(step_us, 3),
+                                        algorithmic_bytes_per_launch=round((ev["bytes"]) / max(ev["active_launches"], 1), 1),
+                                        achieved=round(ev["bytes"] / max(ev["active_launches"], 1) / (step_us * 1e-6) / 1e9, 2) if step_us > 0 else None),
                     lm_coarse_kernel=dict(launches_per_frame=round(ev["coarse_launches"] / n_frames_ev, 2),
-                                          launch_us=round(ev["coarse_us"] / max(ev["coarse_launches"], 1), 2)),
+                                          launch_us=round(coarse_us, 2)),
                     note="single 1241x376 frame: the working set is cache resident and every evaluation is a serial chain "
-                         "(solve, exp, ~30k points); see roofline_dense_1080p for the HBM-bound shape")
+                         "(solve, exp, 13-30k points); see roofline_dense_1080p for the HBM-bound shape")
         evals = [ev["active_launches"] / n_frames_ev]
         tr0 = trk.time_residual(0, reps=100)   # evaluation-only kernel on level 0 (no LM update), for reference
         roof["eval_only_L0"] = dict(launch_us=round(tr0["mean_us"], 3), residuals=tr0["n_points"],
@@ -717,7 +993,8 @@ def main():
                    data="synthetic",
                    config=dict(workload="synthetic KITTI-shaped stereo sequence (configs[1]: a forward drive, passes over "
                                         "unique_frames frames, the tracker re-initialised on frame 0 at each pass), 1241x376, "
-                                        "4 levels, semi-dense, runner params, one sequence per GPU",
+                                        "4 levels, semi-dense, runner params, one sequence per GPU; drive '%s' (odometry_amd/synth.py)" % args.drive,
+                               drive=args.drive,
                                unique_frames=args.unique_frames, sequences_per_gpu=1,
                                sequences_in_lock_step_on_rank0=len(my_seq_ids) if use_batch else 0,
                                sequences=n_sequences, frames_per_rank=per_rank,
@@ -734,6 +1011,27 @@ def main():
                    lm_evals_per_frame=round(float(np.mean(evals)), 2),
                    host_us_per_frame={k: round(v, 1) for k, v in host_timing.items()},
                    keyframes=trk.stats()["n_keyframes"])
+        if args.sequences == 0 and my_seq_ids:
+            # spread of the timed steps (host clock per step; their sum is the timed region): noise vs regression for a reader
+            us = step_s * 1e6
+            out["step_us"] = dict(median=round(float(np.median(us)), 1), p10=round(float(np.percentile(us, 10)), 1),
+                                  p90=round(float(np.percentile(us, 90)), 1), min=round(float(us.min()), 1), max=round(float(us.max()), 1))
+            # does the tracker track? absolute poses of the first pass over the drive against the synthetic ground truth
+            # (ref: run_odometry_kitti_offline.cpp:361-372 prints this mean translation error)
+            m = min(n_total, args.unique_frames - 1)
+            err = tracking_error(poses_abs[0, :m], seq["poses"], order[:m])
+            rel_ok = int((err < 0.05).sum())
+            out["tracking_error_vs_ground_truth_m"] = dict(
+                frames=m, mean=round(float(err.mean()), 4), median=round(float(np.median(err)), 4), max=round(float(err.max()), 4),
+                final=round(float(err[-1]), 4), frames_within_5cm=rel_ok,
+                note="absolute translation error over the first pass of the drive; a keyframe switch whose first Solve misses (the "
+                     "reference resets to the pose relative to the OLD keyframe) bakes metres into every later absolute pose")
+        if c3 is not None:
+            out["configs3_sequences_%d" % args.configs3] = c3
+        if world > 1:
+            fr = [per_rank[r] / t if t > 0 else 0.0 for r, t in enumerate(rank_elapsed)]
+            out["per_rank"] = dict(frames=per_rank, seconds=[round(t, 4) for t in rank_elapsed], frames_per_s=[round(f, 1) for f in fr],
+                                   slowest_over_fastest_seconds=round(max(rank_elapsed) / max(min(rank_elapsed), 1e-9), 3))
         if args.sequences == 0 and n_total > args.unique_frames - 1:
             # determinism of the timed run: every later pass over the drive (re-initialised on frame 0) repeats the first one
             per = args.unique_frames - 1
@@ -744,7 +1042,9 @@ def main():
             # the exchange itself, checked: every rank's rows arrived on rank 0, and rank 0's own rows are the poses it tracked
             got = [int(gatherer.rows(r).shape[0]) for r in range(world)]
             out["pose_gather"] = dict(rows_per_rank=got, complete=(got == per_rank), collectives=gatherer.issued,
-                                      rows_per_collective=gatherer.every)
+                                      rows_per_collective=gatherer.every, backend=exchange["backend"],
+                                      rccl_ranks_seen=exchange["ranks_seen"] if exchange["backend"] == "nccl" else None,
+                                      ranks_seen=exchange["ranks_seen"], distinct_devices=exchange["distinct_devices"])
             if my_seq_ids:
                 mine = gatherer.poses(0, seq_id=my_seq_ids[0])
                 want = poses_abs[0, args.warmup:].reshape(-1, 4, 4).transpose(0, 2, 1)[:, :3, :]
@@ -810,6 +1110,14 @@ def main():
                             out[key] = r
                     except Exception as e:   # noqa: BLE001
                         out[(key or "shim_path") + "_error"] = f"{type(e).__name__}: {e}"[:500]
+                if stress_seq is not None:
+                    def stress():
+                        r = drive_leg(api, stress_seq, args.warmup, args.steps, local_rank)
+                        r["what"] = ("the 'corridor' drive of rounds 1-2 (value noise + hard-edged tiles): the reference's keyframe policy "
+                                     "loses track at its first keyframe switch there and re-promotes a keyframe on most frames; same "
+                                     "steps / warm-up as the headline, own tracker")
+                        return r
+                    leg("stress_drive", stress)
                 if "dense" in legs:
                     leg("roofline_dense_1080p", lambda: dense_1080p_leg(api, synth))
                 if "disparity" in legs:

@@ -44,7 +44,11 @@ enum { ODO_MAX_LEVELS = 8, ODO_NACC = 29 };
 const char* odo_last_error(void);
 int odo_version(void);
 
-/* ---- context ------------------------------------------------------------------------------ */
+/* ---- context ------------------------------------------------------------------------------
+ * One HIP stream + its bookkeeping. A context is meant for one host thread (the reference is single-threaded, ref:
+ * run_odometry_kitti_offline.cpp:3): launches of two threads on the same context would interleave on its stream. Its device-block
+ * free list, pinned staging ring and upload tickets are mutex-guarded, so allocation / upload / release from a second thread
+ * (e.g. a Mat destroyed elsewhere) is safe. */
 int odo_ctx_create(int device, odo_ctx** out);
 /* Same, on a high-priority HIP stream (its hardware queue comes from a pool of its own): for a latency-critical chain of
  * dependent launches that must not queue behind other streams' work. Used by odo_tracker for the LM stream. */
@@ -70,6 +74,12 @@ int odo_dev_download(odo_ctx* ctx, void* dst_host, const void* src_dev, size_t b
 void* odo_host_alloc(size_t bytes);
 void odo_host_free(void* host);
 int odo_dev_upload_async(odo_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+/* Upload tickets: odo_dev_upload_async from a page-locked block (odo_host_alloc) is a DMA that reads the block in place after
+ * the call has returned. odo_ctx_upload_ticket returns the ticket of the most recent such upload (monotonic, 0 = none);
+ * odo_ctx_upload_wait(ticket) returns once that upload and all earlier ones no longer read host memory — the moment the block
+ * may be rewritten or released. Waiting for a retired ticket costs nothing. */
+unsigned long odo_ctx_upload_ticket(odo_ctx* ctx);
+int odo_ctx_upload_wait(odo_ctx* ctx, unsigned long ticket);
 int odo_dev_alloc_async(odo_ctx* ctx, size_t bytes, void** out_dev, int* is_async);
 int odo_dev_free_async(odo_ctx* ctx, void* dev, size_t bytes, int is_async);
 
@@ -147,14 +157,18 @@ int odo_lm_trace(const odo_lm* lm, odo_lm_trace_row* rows, int cap, int* n_rows)
 int odo_lm_time_eval(odo_lm* lm, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img, int level,
                      const float T_colmajor[16], int reps, float* mean_us, float* min_us, double* algorithmic_bytes,
                      int* n_points);
-/* Roofline leg of bench.py: while on, every evaluation-kernel launch of Solve is bracketed by HIP events on the
- * context's stream; the stats are the summed launch durations, the number of launches, how many of them evaluated
- * points, and the algorithmic bytes they touched. */
+/* Roofline leg of bench.py: HIP-event timing of the evaluation-kernel launches of Solve, start / stop events bound to the
+ * dispatch on the context's stream. on = 0: off; 1: every launch; N > 1: every N-th launch of a Solve (rotating residue: cheap
+ * enough to stay on inside a timed region). The stats are the summed launch durations, the number of launches, how many of them
+ * evaluated points, and the algorithmic bytes they touched. */
 int odo_lm_event_timing(odo_lm* lm, int on);
 int odo_lm_event_stats(const odo_lm* lm, double* total_us, long* launches, long* active_launches,
                        double* algorithmic_bytes);
 /* Share of the above spent in the single-workgroup coarse-level kernel (one launch per Solve). */
 int odo_lm_event_stats2(const odo_lm* lm, double* coarse_us, long* coarse_launches);
+/* out[0] sampled step-kernel time (us), [1] sampled step launches, [2] sampled coarse-kernel time (us), [3] sampled coarse
+ * launches, [4] all launches issued, [5] all coarse launches, [6] evaluations, [7] algorithmic bytes. */
+int odo_lm_event_stats_ex(const odo_lm* lm, double out[8]);
 /* Sampling of the current image at the warped point. ODO_SAMPLE_FLOOR (default, parity mode) is what the reference does:
  * I2 at floor(u), floor(v), central-difference gradient at that pixel (ref: src/lm_optimizer.cpp:208-217,
  * include/image_processing_global.h:62-69). ODO_SAMPLE_BILINEAR is a NON-PARITY option (BASELINE.json north_star: "bilinear
@@ -262,6 +276,11 @@ int odo_tracker_hint_next(odo_tracker* t, const float* next_left_dev);
  * ODO_NO_DEPTH_AHEAD=1 turns it off). Both buffers must stay unchanged until the odo_tracker_track call that consumes them.
  * Results are unchanged. odo_tracker_outputs stays valid until the next odo_tracker_track call, as before. */
 int odo_tracker_hint_next_pair(odo_tracker* t, const float* next_left_dev, const float* next_right_dev);
+/* Runs to completion (or drops) everything still in flight on behalf of frames the caller handed over — the stream-B job of an
+ * announced pair, the prefetched pyramid of an announced image, an early-started Solve — and leaves all streams idle. After it
+ * returns nothing, queued or yet to be issued by the helper thread, reads a caller-owned frame buffer: call it before freeing or
+ * overwriting frames that were announced but never tracked (odo_tracker_destroy / odo_tracker_init do it themselves). */
+int odo_tracker_quiesce(odo_tracker* t);
 /* Counters of the last tracked frame: LM evaluations, depth-LM iterations, valid depth points, keyframes so far. */
 int odo_tracker_stats(const odo_tracker* t, int* lm_evals, int* depth_iters, int* n_valid_depth, int* n_keyframes);
 /* Device pointers to the last frame's outputs (rows x cols): validity mask (u8), disparity, inverse depth. */
@@ -313,6 +332,9 @@ int odo_tracker_batch_hint_next(odo_tracker_batch* b, const float* const* next_l
 int odo_tracker_batch_hint_next_pair(odo_tracker_batch* b, const float* const* next_left_dev, const float* const* next_right_dev);
 /* Counters of the last tracked frame, one entry per sequence (any pointer may be NULL). */
 int odo_tracker_batch_stats(const odo_tracker_batch* b, int* lm_evals, int* depth_iters, int* n_valid_depth, int* n_keyframes);
+/* The batched twin of odo_tracker_quiesce: posted chains run to completion, the early-started next Solve is dropped,
+ * announcements are void, all streams idle; afterwards nothing reads a caller-owned frame buffer. */
+int odo_tracker_batch_quiesce(odo_tracker_batch* b);
 /* Diagnostics: host-clock averages per lock step since the last call, microseconds: {whole call, table + pyramid launches,
  * batched Solve, wait for the depth chain after the Solve}. */
 int odo_tracker_batch_timing(odo_tracker_batch* b, double out[4]);
@@ -357,12 +379,13 @@ int odo_camera_destroy(odo_camera* cam);
 /* ---- the pose exchange of the multi-GPU path for hosts that are not Python ---------------------------
  * Tracking shards by sequence (rank r owns sequences r, r + N, ...; ref: run_odometry_kitti_offline.cpp:198-271 is sequential
  * inside a sequence and independent across sequences): there is no data-path collective. The one exchange is an all-gather of
- * the results over RCCL: per tracked frame a row of ODO_GATHER_ROW floats (sequence id, frame id, the 3x4 absolute pose,
- * row-major), `every` rows per ncclAllGather, on a stream of its own, never waited for while tracking. The schedule is fixed up
+ * the results over RCCL: per tracked frame a row of ODO_GATHER_ROW four-byte words (int32 sequence id, int32 frame id — bit
+ * patterns in the float row, exact for any id — then the 3x4 absolute pose as floats, row-major), `every` rows per ncclAllGather, on a stream of its own, never waited for while tracking. The schedule is fixed up
  * front: EVERY rank issues ceil(n_max_frames / every) collectives of a fixed block and pads with rows whose sequence id is -1
  * (uneven shards — 11 sequences over 8 GPUs — cannot leave ranks with different numbers of collectives). RCCL is dlopen'ed
  * (librccl.so.1, or ODO_RCCL_SO): no link-time dependency. bench.py uses the same schedule through torch.distributed
- * (odometry_amd/dist.py); this entry is exercised at world size 1 on the GPU box only (RCCL refuses two ranks on one device). */
+ * (odometry_amd/dist.py); on a one-GPU box this entry runs at world size 1 only (RCCL refuses two ranks on one device),
+ * tests/test_gpu_gather.py::test_two_ranks_* runs it at world size 2 wherever two devices are visible. */
 #define ODO_GATHER_ID_BYTES 128
 #define ODO_GATHER_ROW 14
 typedef struct odo_gather odo_gather;
@@ -376,9 +399,11 @@ int odo_gather_create(int device, int world, int rank, const unsigned char id[OD
 int odo_gather_push(odo_gather* g, int seq_id, int frame_id, const float abs_pose_colmajor[16]);
 /* Issues what is left of the schedule (padded) and waits for every collective. */
 int odo_gather_flush(odo_gather* g);
-/* After flush: the valid rows received from `rank` (ODO_GATHER_ROW floats each, in push order). */
+/* After flush: the valid rows received from `rank` (ODO_GATHER_ROW words each, in push order; words 0 and 1 are int32 bit
+ * patterns: memcpy them into ints). */
 int odo_gather_rows(odo_gather* g, int rank, const float** rows, int* n_rows);
 int odo_gather_issued(const odo_gather* g);   /* collectives issued so far */
+int odo_gather_ranks(const odo_gather* g);    /* ranks in the communicator, from ncclCommCount; -1 on error */
 int odo_gather_destroy(odo_gather* g);
 
 #ifdef __cplusplus

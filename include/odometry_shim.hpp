@@ -99,9 +99,12 @@ inline double scalar0(const Scalar& s) { return s.val[0]; }
 //     and ImagePyramid again (:251) crosses PCIe once, not three times;
 //   * ComputeDepth leaves val / disp / dep on the device and only marks the host side stale: the bytes come back when (if)
 //     host code looks at them. The runner only hands left_dep to DepthPyramid (:252), which takes the mirror.
-// Correctness does not rest on trust: every non-const access (ptr<T>() / at<T>() on a non-const Mat) brings the host copy
-// up to date and invalidates the mirror; every const access brings the host copy up to date. Header copies share buffer
-// and mirror, as cv::Mat headers share data.
+// Correctness does not rest on trust: every non-const access (ptr<T>() / at<T>() on a non-const Mat) waits for a pending
+// upload out of the buffer, brings the host copy up to date and invalidates the mirror; every const access brings the host
+// copy up to date. Header copies share buffer and mirror, as cv::Mat headers share data.
+// ONE RULE for callers: a pointer obtained from non-const ptr<T>() must not be kept across a call into a shim class and
+// written through afterwards — the shim cannot see such a write (the mirror would go stale). Fetch the pointer again after
+// the call, as the reference's own code does (it calls ptr<T>() / at<T>() per row / per pixel).
 namespace detail {
 inline odo_ctx* context();
 struct MatBuf {
@@ -111,16 +114,21 @@ struct MatBuf {
   void* dev = nullptr;        // device mirror (allocated on first use by an estimator)
   int dev_async = 0;
   bool host_valid = true, dev_valid = false;
-  bool upload_pending = false;  // an asynchronous DMA may still be reading `host`
+  unsigned long upload_ticket = 0;  // != 0: an asynchronous DMA issued with this ticket may still be reading `host`
   explicit MatBuf(size_t n);
   ~MatBuf();
   MatBuf(const MatBuf&) = delete;
   MatBuf& operator=(const MatBuf&) = delete;
+  void wait_upload() {  // the DMA out of `host` (if any) has finished: the block may be rewritten / recycled
+    if (upload_ticket) { odo_ctx_upload_wait(context(), upload_ticket); upload_ticket = 0; }
+  }
   void sync_host() {  // host copy current (lazy download)
-    if (!host_valid && dev) { odo_dev_download(context(), host, dev, bytes); upload_pending = false; }
+    if (!host_valid && dev) { odo_dev_download(context(), host, dev, bytes); upload_ticket = 0; }
     host_valid = true;
   }
-  void touch() { sync_host(); dev_valid = false; }  // host code may write
+  // Host code may write: the pending upload out of the block is waited for first (cv::Mat semantics let the caller refill a
+  // Mat the moment a constructor it was passed to has returned), the host copy is brought up to date, the mirror is void.
+  void touch() { wait_upload(); sync_host(); dev_valid = false; }
 };
 // Page-locked blocks are expensive to create (hipHostMalloc): per-frame Mats recycle them through a small free list.
 struct PinnedPool {
@@ -165,7 +173,7 @@ inline MatBuf::MatBuf(size_t n) : bytes(n) {
 inline MatBuf::~MatBuf() {
   if (dev) odo_dev_free_async(context(), dev, bytes, dev_async);
   if (pinned) {
-    if (upload_pending) odo_ctx_synchronize(context());  // a DMA may still be reading the block
+    wait_upload();  // a DMA may still be reading the block (a retired ticket costs nothing)
     pinned_pool().put(bytes, host);
   } else {
     std::free(host);
@@ -213,7 +221,7 @@ class Mat {
     detail::mirror_lru().use(buf_);
     if (!b.dev_valid) {
       if (odo_dev_upload_async(detail::context(), b.dev, b.host, b.bytes) != 0) return nullptr;
-      b.upload_pending = b.pinned;
+      b.upload_ticket = b.pinned ? odo_ctx_upload_ticket(detail::context()) : 0;
       b.dev_valid = true;
     }
     return b.dev;

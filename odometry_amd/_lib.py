@@ -81,6 +81,7 @@ SIGNATURES = {
     "odo_lm_event_timing": (C.c_int, [_vp, C.c_int]),
     "odo_lm_event_stats": (C.c_int, [_vp, _dp, C.POINTER(C.c_long), C.POINTER(C.c_long), _dp]),
     "odo_lm_event_stats2": (C.c_int, [_vp, _dp, C.POINTER(C.c_long)]),
+    "odo_lm_event_stats_ex": (C.c_int, [_vp, _dp]),
     "odo_lm_solve_begin": (C.c_int, [_vp, _vp, _vp, _vp]),
     "odo_lm_solve_batch": (C.c_int, [C.c_int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _fp, C.POINTER(C.c_int)]),
     "odo_lm_set_sampling": (C.c_int, [_vp, C.c_int]),
@@ -110,15 +111,20 @@ SIGNATURES = {
     "odo_tracker_lm": (_vp, [_vp]),
     "odo_tracker_ctx": (_vp, [_vp]),
     "odo_tracker_destroy": (C.c_int, [_vp]),
+    "odo_ctx_upload_ticket": (C.c_ulong, [_vp]),
+    "odo_ctx_upload_wait": (C.c_int, [_vp, C.c_ulong]),
+    "odo_tracker_quiesce": (C.c_int, [_vp]),
     "odo_gather_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "odo_gather_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "odo_gather_push": (C.c_int, [_vp, C.c_int, C.c_int, _fp]),
     "odo_gather_flush": (C.c_int, [_vp]),
     "odo_gather_rows": (C.c_int, [_vp, C.c_int, C.POINTER(_fp), _ip]),
     "odo_gather_issued": (C.c_int, [_vp]),
+    "odo_gather_ranks": (C.c_int, [_vp]),
     "odo_gather_destroy": (C.c_int, [_vp]),
     "odo_tracker_batch_create": (C.c_int, [C.c_int, C.POINTER(TrackerParams), C.c_int, C.POINTER(_vp)]),
     "odo_tracker_batch_destroy": (C.c_int, [_vp]),
+    "odo_tracker_batch_quiesce": (C.c_int, [_vp]),
     "odo_tracker_batch_size": (C.c_int, [_vp]),
     "odo_tracker_batch_ctx": (_vp, [_vp]),
     "odo_tracker_batch_init": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), _fp]),

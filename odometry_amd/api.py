@@ -557,6 +557,18 @@ class Tracker:
         return dict(total_us=us.value, launches=n.value, active_launches=a.value, bytes=b.value,
                     coarse_us=cu.value, coarse_launches=cn.value)
 
+    def _sync(self):
+        """All three streams of the tracker idle (end of a timed region)."""
+        L.check(self.lib.odo_tracker_quiesce(self.h), "odo_tracker_quiesce")
+
+    def event_stats_ex(self):
+        """Sampled event timing (event_timing(N)): mean launch durations of the two LM kernels + launch / evaluation counts."""
+        lm = C.c_void_p(self.lib.odo_tracker_lm(self.h))
+        o = (C.c_double * 8)()
+        L.check(self.lib.odo_lm_event_stats_ex(lm, o), "odo_lm_event_stats_ex")
+        return dict(step_us=o[0], step_sampled=int(o[1]), coarse_us=o[2], coarse_sampled=int(o[3]), launches=int(o[4]),
+                    coarse_launches=int(o[5]), evaluations=int(o[6]), bytes=o[7])
+
     def timing(self):
         out = (C.c_double * 4)()
         L.check(self.lib.odo_tracker_timing(self.h, out), "odo_tracker_timing")
@@ -570,6 +582,10 @@ class Tracker:
 
     def close(self):
         if getattr(self, "h", None):
+            # frames announced with hint_next may still be read by launches the helper thread has yet to issue (the job posted
+            # ahead, the prefetched pyramid, an early Solve): quiesce first, free the frames, then destroy (the buffers come
+            # from the tracker's own context, so they cannot outlive it)
+            self.lib.odo_tracker_quiesce(self.h)
             for p in self._bufs:
                 self.lib.odo_dev_free(self._ctx, p)
             self._bufs = []
@@ -686,6 +702,7 @@ class TrackerBatch:
 
     def close(self):
         if getattr(self, "h", None):
+            self.lib.odo_tracker_batch_quiesce(self.h)   # see Tracker.close
             for p in self._bufs:
                 self.lib.odo_dev_free(self._ctx, p)
             self._bufs = []

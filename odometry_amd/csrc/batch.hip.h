@@ -521,6 +521,19 @@ static int batch_quiesce(odo_tracker_batch* b) {
   return 0;
 }
 
+// The batched twin of odo_tracker_quiesce: chains posted ahead are run to completion, the early-started Solve of the next lock
+// step is dropped, announcements are void, all streams idle. Afterwards nothing reads a caller-owned frame buffer.
+extern "C" int odo_tracker_batch_quiesce(odo_tracker_batch* b) {
+  if (!b) return fail("NULL batch tracker");
+  HIP_OK(hipSetDevice(b->ctx_a->device));
+  if (batch_quiesce(b)) return -1;
+  for (int i = 0; i < b->S; i++) {
+    b->lm[i]->job.active = 0;
+    b->hint_next[i] = b->hint_next_right[i] = b->prefetched[i] = nullptr;
+  }
+  return 0;
+}
+
 // Frame 0 of the slots in b->ids (ref: :95-145).
 static int batch_init_set(odo_tracker_batch* b, const float* const* left_dev, const float* const* right_dev,
                           const float* abs_pose0) {

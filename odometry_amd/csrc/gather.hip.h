@@ -1,7 +1,7 @@
 // gather.hip.h — the one exchange step of the multi-GPU path behind the C ABI: an all-gather of the tracked
 // poses over RCCL, for hosts that are not Python (bench.py reaches RCCL through torch.distributed: odometry_amd/dist.py is the
 // same schedule). Tracking shards by sequence (rank r owns sequences r, r + N, ...): there is no data-path collective; per
-// tracked frame a rank contributes one row of 14 floats (sequence id, frame id, 3x4 pose, row-major), `every` rows per
+// tracked frame a rank contributes one row of 14 four-byte words (int32 sequence id, int32 frame id, 3x4 float pose, row-major), `every` rows per
 // collective.
 //
 // The schedule is agreed up front, never derived from a rank's own frame count: with 11 sequences over 8 ranks some ranks push
@@ -22,6 +22,7 @@ typedef int (*GetUniqueIdFn)(UniqueId*);
 typedef int (*CommInitRankFn)(Comm*, int, UniqueId, int);
 typedef int (*AllGatherFn)(const void*, void*, size_t, int, Comm, hipStream_t);
 typedef int (*CommDestroyFn)(Comm);
+typedef int (*CommCountFn)(Comm, int*);
 typedef const char* (*GetErrorStringFn)(int);
 struct Api {
   void* so;
@@ -29,10 +30,11 @@ struct Api {
   CommInitRankFn comm_init_rank;
   AllGatherFn all_gather;
   CommDestroyFn comm_destroy;
+  CommCountFn comm_count;
   GetErrorStringFn error_string;
 };
 static Api* api() {
-  static Api a = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  static Api a = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   static bool tried = false;
   if (!tried) {
     tried = true;
@@ -47,6 +49,7 @@ static Api* api() {
       a.comm_init_rank = (CommInitRankFn)dlsym(a.so, "ncclCommInitRank");
       a.all_gather = (AllGatherFn)dlsym(a.so, "ncclAllGather");
       a.comm_destroy = (CommDestroyFn)dlsym(a.so, "ncclCommDestroy");
+      a.comm_count = (CommCountFn)dlsym(a.so, "ncclCommCount");
       a.error_string = (GetErrorStringFn)dlsym(a.so, "ncclGetErrorString");
       if (!a.get_unique_id || !a.comm_init_rank || !a.all_gather || !a.comm_destroy) { dlclose(a.so); a.so = nullptr; }
     }
@@ -133,7 +136,7 @@ extern "C" int odo_gather_create(int device, int world, int rank, const unsigned
   if (!ok) { odo_gather_destroy(g); return fail("odo_gather_create: device allocation failed"); }
   for (size_t i = 0; i < n_send; i++) g->h_send[i] = __builtin_nanf("");
   for (int c = 0; c < (g->n_coll > 0 ? g->n_coll : 1); c++)
-    for (int r = 0; r < every; r++) g->h_send[((size_t)c * every + r) * kGatherRow] = -1.0f;   // padding rows: sequence id -1
+    for (int r = 0; r < every; r++) { const int neg = -1; memcpy(&g->h_send[((size_t)c * every + r) * kGatherRow], &neg, sizeof(int)); }   // padding rows: sequence id -1
   odo_rccl::UniqueId u;
   memcpy(u.internal, id, ODO_GATHER_ID_BYTES);
   const int rc = a->comm_init_rank(&g->comm, world, u, rank);
@@ -165,8 +168,8 @@ extern "C" int odo_gather_push(odo_gather* g, int seq_id, int frame_id, const fl
   if (g->flushed) return fail("odo_gather_push: after odo_gather_flush");
   if (g->pushed >= g->n_local) return fail("odo_gather_push: more rows pushed than announced (n_local_frames = %d)", g->n_local);
   float* row = g->h_send + (size_t)g->pushed * kGatherRow;   // blocks are contiguous: row p lives in block p / every
-  row[0] = (float)seq_id;
-  row[1] = (float)frame_id;
+  memcpy(&row[0], &seq_id, sizeof(int));     // ids travel as int32 bit patterns in the float row: exact for any id
+  memcpy(&row[1], &frame_id, sizeof(int));
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 4; j++) row[2 + i * 4 + j] = abs_pose_colmajor[j * 4 + i];
   g->pushed++;
@@ -185,9 +188,12 @@ extern "C" int odo_gather_flush(odo_gather* g) {
   for (int c = 0; c < g->n_coll; c++)
     for (int r = 0; r < g->world; r++) {
       const float* src = g->h_recv + ((size_t)c * g->world + r) * blk;
-      for (int k = 0; k < g->every; k++)
-        if (src[(size_t)k * kGatherRow] >= 0.0f)
+      for (int k = 0; k < g->every; k++) {
+        int sid;
+        memcpy(&sid, &src[(size_t)k * kGatherRow], sizeof(int));
+        if (sid >= 0)
           (*g->rows)[r].insert((*g->rows)[r].end(), src + (size_t)k * kGatherRow, src + (size_t)(k + 1) * kGatherRow);
+      }
     }
   g->flushed = true;
   return 0;
@@ -202,3 +208,12 @@ extern "C" int odo_gather_rows(odo_gather* g, int rank, const float** rows, int*
 }
 
 extern "C" int odo_gather_issued(const odo_gather* g) { return g ? g->issued : 0; }
+// Number of ranks in the RCCL communicator, asked of the communicator itself (ncclCommCount), not echoed from `world`.
+extern "C" int odo_gather_ranks(const odo_gather* g) {
+  if (!g || !g->comm) return fail("odo_gather_ranks: no communicator");
+  odo_rccl::Api* a = odo_rccl::api();
+  if (!a || !a->comm_count) return fail("odo_gather_ranks: ncclCommCount not available");
+  int n = 0;
+  RCCL_OK(a->comm_count(g->comm, &n));
+  return n;
+}

@@ -40,6 +40,7 @@ extern "C" int odo_version(void) { return 100; }
 
 // ------------------------------------------------------------------------------------------------
 constexpr int kStageSlots = 4;
+#include <mutex>
 struct odo_ctx {
   int device;
   hipStream_t stream;
@@ -51,6 +52,11 @@ struct odo_ctx {
   int stage_busy[kStageSlots];
   int stage_next;
   std::vector<struct PoolBlock>* pool;  // recycled device blocks (see dev_alloc_any)
+  std::mutex* mu;                       // guards pool + staging ring + upload tickets (a context may be shared by host threads)
+  // upload tickets (odo_ctx_upload_ticket / odo_ctx_upload_wait): ticket t is retired once up_ev[t % kUpRing] — recorded behind
+  // the t-th asynchronous upload, or behind a later one that reused the ring entry — has passed
+  hipEvent_t up_ev[16];
+  unsigned long up_issued, up_retired;
   // per-sequence argument table of the batched Solves issued on this stream (odo_lm_solve_batch): per context, because the
   // launches a finished Solve still has queued read it, and only the stream orders the next upload behind them
   void* lm_batch_h;   // pinned
@@ -68,23 +74,44 @@ struct odo_ctx {
 // use it. (hipMallocAsync / hipFreeAsync, the runtime's own stream-ordered allocator, was tried first: with blocks of
 // several sizes cycling through it the LM read stale images on ROCm 7.2 — tests/test_gpu_dense_1080p.py run in one process
 // — so the reuse rule is spelled out here instead.) ODO_NO_POOL=1 turns recycling off.
-struct PoolBlock { size_t bytes; void* p; };
+struct PoolBlock { size_t bytes; void* p; hipEvent_t ev; };   // ev: recorded on the stream when the block was released
 constexpr size_t kPoolMaxBlocks = 48;
 static bool pool_enabled() { static const bool on = getenv("ODO_NO_POOL") == nullptr; return on; }
 // *pooled tells dev_free_any how the block has to be returned.
 static int dev_alloc_any(odo_ctx* c, size_t bytes, void** out, bool* pooled) {
   *pooled = pool_enabled();
   if (*pooled && c->pool) {
+    std::lock_guard<std::mutex> lk(*c->mu);
     auto& v = *c->pool;
-    for (size_t i = 0; i < v.size(); i++)
-      if (v[i].bytes == bytes) { *out = v[i].p; v.erase(v.begin() + (long)i); return 0; }
+    for (size_t i = v.size(); i-- > 0;)   // most recently released first
+      if (v[i].bytes == bytes) { *out = v[i].p; if (v[i].ev) (void)hipEventDestroy(v[i].ev); v.erase(v.begin() + (long)i); return 0; }
   }
   HIP_OK(hipMalloc(out, bytes));
   return 0;
 }
 static void dev_free_any(odo_ctx* c, void* p, size_t bytes, bool pooled) {
   if (!p) return;
-  if (pooled && c->pool && c->pool->size() < kPoolMaxBlocks) { c->pool->push_back(PoolBlock{bytes, p}); return; }
+  if (pooled && c->pool) {
+    // The list never refuses a block: when it is full, the OLDEST entry (a size nobody has asked for since it was released —
+    // hits are taken from the young end) is evicted. Its release event has long passed in a running frame loop, so the
+    // eviction waits for nothing; the caller's stream is never synchronised.
+    PoolBlock old{0, nullptr, nullptr};
+    {
+      std::lock_guard<std::mutex> lk(*c->mu);
+      auto& v = *c->pool;
+      if (v.size() >= kPoolMaxBlocks) { old = v.front(); v.erase(v.begin()); }
+      PoolBlock nb{bytes, p, nullptr};
+      if (hipEventCreateWithFlags(&nb.ev, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(nb.ev, c->stream);
+      else nb.ev = nullptr;
+      v.push_back(nb);
+    }
+    if (old.p) {
+      if (old.ev) { (void)hipEventSynchronize(old.ev); (void)hipEventDestroy(old.ev); }
+      else (void)hipStreamSynchronize(c->stream);
+      (void)hipFree(old.p);
+    }
+    return;
+  }
   (void)hipStreamSynchronize(c->stream);
   (void)hipFree(p);
 }
@@ -114,6 +141,8 @@ static int ctx_create(int device, int high_priority, odo_ctx** out) {
   HIP_OK(hipEventCreate(&c->ev1));
   for (int i = 0; i < kStageSlots; i++) HIP_OK(hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming));
   c->pool = new std::vector<PoolBlock>();
+  c->mu = new std::mutex();
+  for (auto& e : c->up_ev) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   *out = c;
   return 0;
 }
@@ -128,7 +157,9 @@ extern "C" int odo_ctx_destroy(odo_ctx* c) {
     (void)hipEventDestroy(c->stage_ev[i]);
     if (c->stage[i]) (void)hipHostFree(c->stage[i]);
   }
-  if (c->pool) { for (auto& b : *c->pool) (void)hipFree(b.p); delete c->pool; }
+  if (c->pool) { for (auto& b : *c->pool) { if (b.ev) (void)hipEventDestroy(b.ev); (void)hipFree(b.p); } delete c->pool; }
+  for (auto& e : c->up_ev) if (e) (void)hipEventDestroy(e);
+  delete c->mu;
   lm_batch_job_free(c);
   if (c->lm_batch_h) (void)hipHostFree(c->lm_batch_h);
   if (c->lm_batch_d) (void)hipFree(c->lm_batch_d);
@@ -170,7 +201,6 @@ extern "C" int odo_dev_free(odo_ctx* c, void* p) {
 // Host blocks handed out by odo_host_alloc are page-locked: an upload from one of them is a plain asynchronous DMA.
 // Uploads from any other host memory go through the context's pinned staging ring (one CPU copy, then the same DMA).
 // Either way the call returns as soon as the caller may reuse / release its buffer, without waiting for the device.
-#include <mutex>
 #include <map>
 static std::mutex g_pin_mu;
 static std::map<const char*, size_t> g_pinned;  // start -> bytes of every live odo_host_alloc block
@@ -200,9 +230,13 @@ extern "C" void odo_host_free(void* p) {
 static int upload_rows_async(odo_ctx* c, void* dst, const void* src, size_t src_pitch, size_t row_bytes, int rows) {
   const size_t total = row_bytes * (size_t)rows;
   const size_t span = src_pitch * (size_t)(rows - 1) + row_bytes;
+  std::lock_guard<std::mutex> lk(*c->mu);
   if (host_is_pinned(src, span)) {
     HIP_OK(hipMemcpy2DAsync(dst, row_bytes, src, src_pitch, row_bytes, rows, hipMemcpyHostToDevice, c->stream));
-    return 0;  // the block stays valid until odo_host_free, which the caller must not call before the stream has drained
+    // the DMA reads the caller's block in place: it may be rewritten / released once this upload's ticket has retired
+    c->up_issued++;
+    HIP_OK(hipEventRecord(c->up_ev[c->up_issued % 16], c->stream));
+    return 0;
   }
   const int slot = c->stage_next;
   c->stage_next = (slot + 1) % kStageSlots;
@@ -218,6 +252,27 @@ static int upload_rows_async(odo_ctx* c, void* dst, const void* src, size_t src_
   HIP_OK(hipMemcpyAsync(dst, c->stage[slot], total, hipMemcpyHostToDevice, c->stream));
   HIP_OK(hipEventRecord(c->stage_ev[slot], c->stream));
   c->stage_busy[slot] = 1;
+  return 0;
+}
+// Ticket of the most recent in-place (page-locked source) asynchronous upload of this context; 0 = none yet.
+extern "C" unsigned long odo_ctx_upload_ticket(odo_ctx* c) {
+  if (!c) return 0;
+  std::lock_guard<std::mutex> lk(*c->mu);
+  return c->up_issued;
+}
+// Returns once the upload with that ticket — and every earlier one — no longer reads its host block.
+extern "C" int odo_ctx_upload_wait(odo_ctx* c, unsigned long ticket) {
+  if (!c) return fail("NULL ctx");
+  hipEvent_t ev;
+  {
+    std::lock_guard<std::mutex> lk(*c->mu);
+    if (ticket == 0 || ticket <= c->up_retired) return 0;
+    if (ticket > c->up_issued) return fail("odo_ctx_upload_wait: ticket %lu was never issued", ticket);
+    ev = c->up_ev[ticket % 16];   // this upload's event, or that of a LATER upload that reused the entry: both imply it
+  }
+  HIP_OK(hipEventSynchronize(ev));
+  std::lock_guard<std::mutex> lk(*c->mu);
+  if (ticket > c->up_retired) c->up_retired = ticket;
   return 0;
 }
 extern "C" int odo_dev_upload(odo_ctx* c, void* dst, const void* src, size_t bytes) {
@@ -478,10 +533,13 @@ struct odo_lm {
   // keyframe the two sets trade places (lm_adopt_candidate) instead of list-building launches + a read-back in front of the Solve.
   LmCandSet cand[2];   // two of them: the tracker's depth stream may run a frame ahead of the pose LM (slot = job parity)
   // optional per-launch HIP-event timing of the evaluation kernels (bench.py roofline leg)
-  int ev_on;
+  int ev_on;            // 0 off; N >= 1: every N-th launch of a Solve carries start / stop events (1 = every launch)
+  int ev_phase;         // which residue of the launch index is sampled in the Solve in flight (rotates Solve by Solve)
+  long ev_solves;
   std::vector<hipEvent_t>* ev_pool;
   double ev_total_us, ev_bytes, ev_coarse_us;
-  long ev_launches, ev_active, ev_coarse_launches;
+  long ev_launches, ev_active, ev_coarse_launches;   // launches issued / evaluations / SAMPLED coarse launches
+  long ev_sampled, ev_coarse_all;                    // sampled launches (step + coarse) / all coarse launches
   int last_coarse;  // 1 if the last Solve started with the single-workgroup coarse kernel
   int trace_stale;
   int record;      // 1: per-evaluation trace rows and per-level cost statistics are written (odo_lm_trace / odo_lm_report);
@@ -835,6 +893,10 @@ static inline double lm_level_bytes(const odo_lm* m, int level, int rows, int co
 // pyramids abandons it (its launches drain on the stream like the stragglers of any finished Solve: the next Solve starts
 // with first_of_solve = 1 and a new token).
 // ---------------------------------------------------------------------------------------------------------------
+// Event timing: is launch `i` of the Solve in flight one of the sampled ones?
+static inline bool lm_ev_sampled(const odo_lm* m, int i) {
+  return m->ev_on > 0 && m->ev_pool && (size_t)(2 * i + 1) < m->ev_pool->size() && ((i + m->ev_phase) % m->ev_on) == 0;
+}
 static inline int lm_job_progress(const odo_lm* m) {
   const int v = ((volatile int*)m->h_prog)[0];
   return ((v >> kProgSeqBits) == m->job.token) ? (v & ((1 << kProgSeqBits) - 1)) : 0;
@@ -865,6 +927,7 @@ static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_de
   // finishes the Solve writes the result and the token into host-mapped memory itself.
   m->token = (m->token % 0x3ffff) + 1;
   jb.token = m->token;
+  if (m->ev_on > 0) m->ev_phase = (int)(m->ev_solves++ % m->ev_on);
   StepArgs& a = jb.a;
   memset(&a, 0, sizeof(a));
   a.n_levels = m->n_levels;
@@ -932,7 +995,7 @@ static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_de
     a.st_in = st[jb.seq & 1]; a.st_out = st[(jb.seq + 1) & 1];
     a.part_in = part[jb.seq & 1]; a.part_out = part[(jb.seq + 1) & 1];
     a.seq = jb.seq; a.first_of_solve = 1;
-    const bool ev = m->ev_on && m->ev_pool && m->ev_pool->size() >= 2;
+    const bool ev = lm_ev_sampled(m, 0);
     if (ev)
       hipExtLaunchKernelGGL(lm_coarse_kernel, dim3(1), dim3(kCoarseBlock), kCoarseLdsBytes, s, (*m->ev_pool)[0],
                             (*m->ev_pool)[1], 0, a, min_level);
@@ -970,8 +1033,8 @@ static void lm_fused_pump(odo_lm* m, bool block) {
     a.st_in = st[jb.seq & 1]; a.st_out = st[(jb.seq + 1) & 1];
     a.part_in = part[jb.seq & 1]; a.part_out = part[(jb.seq + 1) & 1];
     a.seq = jb.seq; a.first_of_solve = (jb.seq == 0) ? 1 : 0;
-    const bool ev = m->ev_on && m->ev_pool && (size_t)(2 * jb.launches + 1) < m->ev_pool->size();
-    if (ev)  // timing pass: start / stop events bound to the dispatch itself (the kernel's own begin / end timestamps)
+    const bool ev = lm_ev_sampled(m, jb.launches);
+    if (ev)  // timing: start / stop events bound to the dispatch itself (the kernel's own begin / end timestamps)
       hipExtLaunchKernelGGL(lm_step_kernel, dim3(jb.grid), dim3(kLmBlock), 0, s, (*m->ev_pool)[2 * jb.launches],
                             (*m->ev_pool)[2 * jb.launches + 1], 0, a);
     else
@@ -1151,14 +1214,17 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
     m->last_bytes += bytes_per_level[l] * m->iters[l];
   }
   if (m->ev_on && m->ev_pool && fused) {
-    for (int i = 0; i < launches && (size_t)(2 * i + 1) < m->ev_pool->size(); i++) {
+    for (int i = 0; i < launches; i++) {
+      if (!lm_ev_sampled(m, i)) continue;
       float ms = 0.0f;
       if (hipEventElapsedTime(&ms, (*m->ev_pool)[2 * i], (*m->ev_pool)[2 * i + 1]) == hipSuccess) {
         m->ev_total_us += ms * 1000.0;
+        m->ev_sampled++;
         if (i == 0 && m->last_coarse) { m->ev_coarse_us += ms * 1000.0; m->ev_coarse_launches++; }
       }
     }
     m->ev_launches += launches;
+    m->ev_coarse_all += m->last_coarse;
     m->ev_active += m->last_evals;
     m->ev_bytes += m->last_bytes;
   }
@@ -1408,16 +1474,32 @@ extern "C" int odo_lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* cons
   return lm_solve_batch(n, lms, kf_img, kf_dep, cur_img, out_colmajor, status, nullptr, nullptr);
 }
 
-// Per-launch HIP-event timing of the evaluation kernel (fused pipeline) on the stream it is launched on.
-// on = 1 starts (and clears) the accumulation, on = 0 stops it; odo_lm_event_stats reads the totals.
+// HIP-event timing of the evaluation kernels (fused pipeline) on the stream they are launched on: start / stop events bound
+// to the dispatch. on = 0 stops; on = 1 brackets every launch; on = N > 1 brackets every N-th launch of a Solve (the sampled
+// residue rotates from Solve to Solve, so the coarse launch — index 0 — is sampled every N-th Solve): cheap enough to leave on
+// inside a timed region. Turning it on clears the accumulators.
 extern "C" int odo_lm_event_timing(odo_lm* m, int on) {
   if (!m) return fail("NULL lm");
+  if (on < 0) return fail("odo_lm_event_timing: on must be >= 0");
   if (on && !m->ev_pool) {
     m->ev_pool = new std::vector<hipEvent_t>(2 * 128);
     for (auto& e : *m->ev_pool) HIP_OK(hipEventCreate(&e));
   }
-  if (on) { m->ev_total_us = m->ev_bytes = m->ev_coarse_us = 0.0; m->ev_launches = m->ev_active = m->ev_coarse_launches = 0; }
-  m->ev_on = on ? 1 : 0;
+  if (on) {
+    m->ev_total_us = m->ev_bytes = m->ev_coarse_us = 0.0;
+    m->ev_launches = m->ev_active = m->ev_coarse_launches = m->ev_sampled = m->ev_coarse_all = 0;
+    m->ev_solves = 0; m->ev_phase = 0;
+  }
+  m->ev_on = on;
+  return 0;
+}
+// out[0] sampled step-kernel time (us), out[1] sampled step launches, out[2] sampled coarse-kernel time (us), out[3] sampled
+// coarse launches, out[4] all launches issued, out[5] all coarse launches, out[6] evaluations, out[7] algorithmic bytes.
+extern "C" int odo_lm_event_stats_ex(const odo_lm* m, double out[8]) {
+  if (!m || !out) return fail("NULL arg");
+  out[0] = m->ev_total_us - m->ev_coarse_us; out[1] = (double)(m->ev_sampled - m->ev_coarse_launches);
+  out[2] = m->ev_coarse_us; out[3] = (double)m->ev_coarse_launches;
+  out[4] = (double)m->ev_launches; out[5] = (double)m->ev_coarse_all; out[6] = (double)m->ev_active; out[7] = m->ev_bytes;
   return 0;
 }
 extern "C" int odo_lm_event_stats2(const odo_lm* m, double* coarse_us, long* coarse_launches) {

@@ -286,20 +286,31 @@ static int tracker_wait_idle(odo_tracker* t) {
   return posted > 0 ? tracker_wait_job(t, posted - 1) : 0;
 }
 
+// Everything the tracker still has in flight on behalf of frames the caller handed it — the job posted ahead for an announced
+// pair, the prefetched pyramid of an announced image, an early-started Solve, straggling LM launches — is run to completion or
+// dropped, and all three streams are idle afterwards. After this call no launch, queued or yet to be issued by the helper thread,
+// reads a caller-owned frame buffer: the caller may free or overwrite its frames (announcements are void).
+extern "C" int odo_tracker_quiesce(odo_tracker* t) {
+  if (!t) return fail("NULL tracker");
+  HIP_OK(hipSetDevice(t->ctx_a->device));
+  if (tracker_wait_idle(t)) return -1;
+  t->ahead_job = -1;
+  HIP_OK(hipStreamSynchronize(t->ctx_a->stream));
+  HIP_OK(hipStreamSynchronize(t->ctx_b->stream));
+  HIP_OK(hipStreamSynchronize(t->ctx_c->stream));
+  t->lm->job.active = 0;                   // a Solve started early for an announced frame is dropped
+  t->prefetched = t->hint_next = t->hint_next_right = nullptr;  // announcements are void
+  return 0;
+}
+
 extern "C" int odo_tracker_init(odo_tracker* t, const float* left, const float* right, const float abs_pose0[16]) {
   if (!t || !left || !right || !abs_pose0) return fail("odo_tracker_init: NULL arg");
   HIP_OK(hipSetDevice(t->ctx_a->device));
   // Re-initialisation of a tracker that has been tracking: a job posted ahead for the previous sequence's next frame, the
   // tail of the last frame (a prefetched next pyramid, straggling LM launches, an early Solve) may still be running.
   // Start from an idle helper thread and a quiet device and build everything on stream B again.
-  if (tracker_wait_idle(t)) return -1;
-  t->ahead_job = -1;
-  HIP_OK(hipStreamSynchronize(t->ctx_a->stream));
-  HIP_OK(hipStreamSynchronize(t->ctx_b->stream));
-  HIP_OK(hipStreamSynchronize(t->ctx_c->stream));
-  t->lm->job.active = 0;                   // a Solve started early for the previous sequence's next frame is dropped
+  if (odo_tracker_quiesce(t)) return -1;
   t->pre_img->ctx = t->ctx_b;
-  t->prefetched = t->hint_next = t->hint_next_right = nullptr;  // announcements made for the previous sequence are void
   t->lm->cand[0].tag = t->lm->cand[1].tag = -1;
   TrackerJob* j = &t->jobs[0];
   // frame 0 has no Solve pyramid: the first Solve builds the keyframe lists itself (with_lists = 0)

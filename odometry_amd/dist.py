@@ -3,7 +3,7 @@
 The path shards by SEQUENCE: tracking is sequential inside a sequence (each Solve starts from the previous pose and
 keyframe, ref: run_odometry_kitti_offline.cpp:215,258-268) and independent across sequences, so rank r owns the
 sequences r, r + world, ... and there is no data-path collective. The only exchange is the gather of the 6-DoF
-results: per tracked frame a row of 14 floats (sequence id, frame id, 3x4 pose), batched `every` rows per collective —
+results: per tracked frame a row of 14 four-byte words (int32 sequence id, int32 frame id, 3x4 float32 pose), batched `every` rows per collective —
 latency-bound, a few hundred bytes per call.
 
 The exchange follows a schedule every rank derives from the same numbers, NOT from how many frames it tracked itself:
@@ -32,9 +32,14 @@ class PoseGatherer:
     asynchronously and its result is collected at a later push (or at flush()), so a rank never waits for the exchange — nor,
     through it, for a slower rank — while it tracks.
 
-    n_local_frames: how many rows THIS rank will push (its shard); n_max_frames: the largest such number over all ranks
-    (every rank computes both from the same sharding rule, e.g. frames_per_rank(); pass None to agree on it with one
-    all_reduce(MAX) here). The number and shape of the collectives depend on n_max_frames alone."""
+    n_local_frames: how many rows THIS rank will push (its shard) — required when world > 1; n_max_frames: the largest such
+    number over all ranks (every rank computes both from the same sharding rule, e.g. frames_per_rank()). The number and shape of
+    the collectives depend on the agreed maximum alone. With world > 1 the constructor ALWAYS runs one all_reduce(MAX) over
+    (n_local_frames, n_max_frames or -1) — on every rank, whatever it was given, so ranks cannot disagree about whether a
+    collective happens here — and raises if a rank's n_max_frames contradicts the agreed value.
+
+    Rows travel as 14 four-byte words: int32 sequence id, int32 frame id (bit-cast into the float32 row, exact for any id),
+    twelve float32 pose entries. Padding rows carry sequence id -1."""
 
     def __init__(self, world, every=8, device=None, n_local_frames=None, n_max_frames=None):
         self.world, self.every, self.device = world, max(int(every), 1), device
@@ -42,18 +47,24 @@ class PoseGatherer:
         self.inflight = []                           # (work handle or None, [tensor per rank]) in issue order
         self.gathered = [[] for _ in range(world)]   # per rank: list of (every, ROW) arrays
         self.n_local = n_local_frames
-        if n_max_frames is None and n_local_frames is not None and world > 1:
+        if world > 1:
+            if n_local_frames is None:
+                raise ValueError("PoseGatherer: n_local_frames is required when world > 1 (the collective schedule is derived "
+                                 "from the shard sizes, never from how many rows a rank happens to push)")
             import torch
             import torch.distributed as dist
-            t = torch.tensor([int(n_local_frames)], dtype=torch.int64)
+            t = torch.tensor([int(n_local_frames), -1 if n_max_frames is None else int(n_max_frames)], dtype=torch.int64)
             if device is not None:
                 t = t.to(device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            n_max_frames = int(t.item())
-        if n_max_frames is None:
+            agreed = int(max(t[0].item(), t[1].item()))
+            if n_max_frames is not None and int(n_max_frames) != agreed:
+                raise ValueError(f"PoseGatherer: n_max_frames = {n_max_frames} on this rank, but the ranks agree on {agreed}")
+            n_max_frames = agreed
+        elif n_max_frames is None:
             n_max_frames = n_local_frames
         self.n_max = n_max_frames
-        # None = legacy mode: the caller guarantees that every rank pushes the same number of rows
+        # None (single process only): no schedule, flush() issues what is pending
         self.n_collectives = None if n_max_frames is None else (int(n_max_frames) + self.every - 1) // self.every
         self.issued = 0
         self.pushed = 0
@@ -62,8 +73,7 @@ class PoseGatherer:
         if self.n_local is not None and self.pushed >= self.n_local:
             raise RuntimeError("PoseGatherer: more rows pushed than announced (n_local_frames)")
         row = np.empty(ROW, np.float32)
-        row[0] = seq_id
-        row[1] = self.pushed if frame_id is None else frame_id
+        row[:2] = np.array([seq_id, self.pushed if frame_id is None else frame_id], np.int32).view(np.float32)
         row[2:] = np.asarray(pose4x4, np.float32)[:3, :].reshape(-1)
         self.pending.append(row)
         self.pushed += 1
@@ -76,7 +86,7 @@ class PoseGatherer:
         import torch
         import torch.distributed as dist
         rows = np.full((self.every, ROW), np.nan, np.float32)
-        rows[:, 0] = -1.0
+        rows[:, :2] = np.array([-1, -1], np.int32).view(np.float32)
         if self.pending:
             rows[:len(self.pending)] = np.stack(self.pending)
         mine = torch.from_numpy(rows)
@@ -113,16 +123,20 @@ class PoseGatherer:
         self._drain(block=True)
 
     def rows(self, rank):
-        """Valid gathered rows of `rank`: (n, 14) = sequence id, frame id, 3x4 pose."""
+        """Valid gathered rows of `rank`: (n, 14) float32 words = int32 sequence id, int32 frame id (see ids()), 3x4 pose."""
         g = self.gathered[rank]
         if not g:
             return np.zeros((0, ROW), np.float32)
-        a = np.concatenate(g)
-        return a[a[:, 0] >= 0]
+        a = np.ascontiguousarray(np.concatenate(g))
+        return a[a[:, 0].view(np.int32) >= 0]
+
+    def ids(self, rank):
+        """(n, 2) int32: sequence id and frame id of every valid row gathered from `rank`."""
+        return np.ascontiguousarray(self.rows(rank)[:, :2]).view(np.int32)
 
     def poses(self, rank, seq_id=None):
         """3x4 poses gathered from `rank` in push order (optionally of one sequence only)."""
         a = self.rows(rank)
         if seq_id is not None:
-            a = a[a[:, 0] == seq_id]
+            a = a[np.ascontiguousarray(a[:, 0]).view(np.int32) == seq_id]
         return a[:, 2:].reshape(-1, 3, 4)

@@ -44,10 +44,32 @@ class Scene:
     """Corridor of textured planes. texels_per_m controls texture scale."""
 
     def __init__(self, seed=0, half_width=(4.0, 5.0), cam_height=1.65, ceil_height=3.0, end_z=600.0,
-                 tex_size=1024, texels_per_m=60.0, tile_texels=(11, 29, 67)):
+                 tex_size=1024, texels_per_m=60.0, tile_texels=(11, 29, 67), contrast=(1.0, 1.0, 1.0, 1.0, 1.0),
+                 spectrum=None, sigma=40.0, tile_amp=0.0, ribs=None):
         rng = np.random.default_rng(0x0D0E77E7 + 1000 * seed)
         self.tex = []
-        for _ in range(5):  # smooth value noise + random-brightness tiles (sparse strong edges, like real scenes)
+        for _ in range(5 if spectrum is not None else 0):
+            # natural-image statistics: amplitude spectrum ~ 1 / f^spectrum (random phases, tileable by construction), so
+            # that coarse pyramid levels carry most of the contrast — what makes coarse-to-fine alignment of real images work
+            fy = np.fft.fftfreq(tex_size)[:, None]
+            fx = np.fft.rfftfreq(tex_size)[None, :]
+            f = np.sqrt(fx * fx + fy * fy)
+            f[0, 0] = 1.0
+            amp = 1.0 / f ** spectrum
+            amp[0, 0] = 0.0
+            ph = rng.uniform(0.0, 2.0 * np.pi, amp.shape)
+            t = np.fft.irfft2(amp * np.exp(1j * ph), s=(tex_size, tex_size))
+            t = (t - t.mean()) / t.std()
+            tiles = np.zeros_like(t)
+            if tile_amp > 0.0:
+                ii = np.arange(tex_size)
+                for s_ in tile_texels:
+                    nc = tex_size // s_ + 1
+                    cells = rng.uniform(-1.0, 1.0, (nc, nc))
+                    tiles += cells[np.ix_(ii // s_, ii // s_)]
+                tiles /= np.sqrt(len(tile_texels))
+            self.tex.append(np.clip(128.0 + sigma * t + tile_amp * tiles, 0.0, 255.0))
+        for _ in range(5 if spectrum is None else 0):  # smooth value noise + random-brightness tiles (sparse strong edges)
             t = _value_noise(rng, tex_size, 6, 128)
             t = (t - t.mean()) / t.std()
             tiles = np.zeros_like(t)
@@ -59,6 +81,12 @@ class Scene:
             tiles /= np.sqrt(len(tile_texels))
             self.tex.append(np.clip(128.0 + 22.0 * t + 50.0 * tiles, 0.0, 255.0))
         self.tpm = texels_per_m
+        # ribs = (spacing, half_opening, opening_height): fronto-parallel frames across the corridor every `spacing` metres (z = k *
+        # spacing), each with a doorway |x| < half_opening below `opening_height` above the ground that the camera drives through —
+        # tunnel ribs / gantries: textured structure AHEAD of the camera at every depth, near the focus of expansion
+        self.ribs = ribs
+        self.cam_height = cam_height
+        self.contrast = contrast   # per plane (ground, left wall, right wall, ceiling / sky, end wall): grey = 128 + c * (tex - 128)
         # planes: (normal n, offset h) with n . X = h; texture axes (a, b) index world coords
         self.planes = [
             (np.array([0.0, 1.0, 0.0]), cam_height, (0, 2)),        # ground  y = +h
@@ -105,28 +133,62 @@ class Scene:
             if not hit.any():
                 continue
             P = t[None, :] + dirs[hit] * s[hit][:, None]
-            img[hit] = self._sample(k, P[:, a], P[:, b])
+            img[hit] = 128.0 + self.contrast[k] * (self._sample(k, P[:, a], P[:, b]) - 128.0)
             best[hit] = s[hit]
+        if self.ribs is not None:
+            spacing, half_open, open_h = self.ribs
+            k0 = int(np.floor(t[2] / spacing)) + 1
+            dz = dirs[..., 2]
+            for k in range(k0, k0 + 14):                      # nearest first; farther ribs only where nothing nearer was hit
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    sk = np.where(dz > 1e-9, (k * spacing - t[2]) / dz, np.inf)
+                cand = (sk > 1e-3) & (sk < best)
+                if not cand.any():
+                    continue
+                P = t[None, :] + dirs[cand] * sk[cand][:, None]
+                solid = (np.abs(P[:, 0]) > half_open) | (P[:, 1] < self.cam_height - open_h)     # y is down: above the doorway
+                idx = np.flatnonzero(cand.ravel())[solid]
+                if idx.size == 0:
+                    continue
+                Ps = P[solid]
+                val = 128.0 + self.contrast[4] * (self._sample(4, Ps[:, 0] + 3.7 * k, Ps[:, 1] + 1.3 * k) - 128.0)
+                img.ravel()[idx] = val
+                best.ravel()[idx] = sk.ravel()[idx]
         img = np.clip(np.rint(img), 0, 255).astype(np.float32)
         return img, best
 
 
-def trajectory(n_frames, seed=0, fwd_range=(0.3, 0.6)):
+# Named drives: scene + motion. "corridor" is the drive of rounds 1-2 (everything within 5-30 m of the camera, 0.3-0.6 m per
+# frame): on it the reference's keyframe policy loses track at every keyframe switch. The others are
+# candidates evaluated with tools/drive_search.py.
+DRIVES = {
+    "corridor": dict(scene={}, fwd_range=(0.3, 0.6), max_offset=1.0),
+    # bench.py's workload since round 3. Same corridor and motion; the textures have the amplitude spectrum of natural images
+    # (~ 1 / f^1.55, sigma 80 grey levels before clipping) instead of white-ish value noise + hard-edged tiles. Coarse pyramid levels
+    # then carry most of the contrast, the basin of the level-3 alignment is wide enough for the first Solve after a keyframe switch
+    # (which starts ~3.6 m off: the reference resets to the pose relative to the OLD keyframe, ref: run_odometry_kitti_offline.cpp:
+    # 261-262) to converge in 21 of 25 switches over 200 frames; the tracker stays within centimetres of the ground truth on 195 of
+    # 199 frames (tools/drive_search.py natural 200). Found by scanning spectrum x contrast x speed x corridor width with the oracle.
+    "natural": dict(scene=dict(spectrum=1.55, sigma=80.0), fwd_range=(0.3, 0.6), max_offset=1.0),
+}
+
+
+def trajectory(n_frames, seed=0, fwd_range=(0.3, 0.6), max_offset=1.0, yaw_deg=1.5, yaw_total_deg=6.0):
     """Camera-to-world poses: forward fwd_range m/frame, yaw <= 1.5 deg, pitch/roll <= 0.2 deg per frame."""
     rng = np.random.default_rng(0x0D0E77E7 + 1000 * seed + 17)
     poses = [np.eye(4)]
     yaw_total = 0.0
     for _ in range(1, n_frames):
         fwd = rng.uniform(*fwd_range)
-        yaw = np.deg2rad(rng.uniform(-1.5, 1.5))
-        if abs(yaw_total + yaw) > np.deg2rad(6.0):  # stay inside the corridor
+        yaw = np.deg2rad(rng.uniform(-yaw_deg, yaw_deg))
+        if abs(yaw_total + yaw) > np.deg2rad(yaw_total_deg):  # stay inside the corridor
             yaw = -yaw
         pitch = np.deg2rad(rng.uniform(-0.2, 0.2))
         roll = np.deg2rad(rng.uniform(-0.2, 0.2))
         # long sequences: steer back towards the corridor axis once the camera has drifted (same random draws, so
         # short sequences — which never drift this far — are unchanged)
         cur = poses[-1]
-        if abs(cur[0, 3]) > 1.0 and np.sign(yaw) == np.sign(cur[0, 3]) and np.sign(cur[0, 2]) == np.sign(cur[0, 3]):
+        if abs(cur[0, 3]) > max_offset and np.sign(yaw) == np.sign(cur[0, 3]) and np.sign(cur[0, 2]) == np.sign(cur[0, 3]):
             yaw = -yaw                                   # heading away from the axis: turn the other way
         if abs(cur[1, 3]) > 0.3 and np.sign(cur[1, 2]) == np.sign(cur[1, 3]) and np.sign(-pitch) == np.sign(cur[1, 3]):
             pitch = -pitch
@@ -144,11 +206,19 @@ def trajectory(n_frames, seed=0, fwd_range=(0.3, 0.6)):
     return poses
 
 
+def drive_scene(drive, seed):
+    return Scene(seed, **DRIVES[drive]["scene"])
+
+
+def drive_trajectory(drive, n_frames, seed):
+    return trajectory(n_frames, seed, **{k: v for k, v in DRIVES[drive].items() if k != "scene"})
+
+
 def make_sequence(n_frames, seed=0, rows=KITTI_ROWS, cols=KITTI_COLS, f=KITTI_F, cx=KITTI_CX, cy=KITTI_CY,
-                  baseline=KITTI_BASELINE, with_depth=False):
+                  baseline=KITTI_BASELINE, with_depth=False, drive="corridor"):
     """Returns dict(left=[...], right=[...], poses=[c2w...], depth=[...] optional)."""
-    scene = Scene(seed)
-    poses = trajectory(n_frames, seed)
+    scene = drive_scene(drive, seed)
+    poses = drive_trajectory(drive, n_frames, seed)
     out = dict(left=[], right=[], poses=poses, depth=[])
     for T in poses:
         L, Z = scene.render(T, rows, cols, f, cx, cy, 0.0)

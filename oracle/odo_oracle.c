@@ -475,8 +475,8 @@ static float tdist_scale(const float* r, int n) {
 /* ---- timing-only variant in the reference's own shape (SURVEY 8d "faithful restatement") ----
  * ComputeResidualJacobianNaive materialises J (N x 6), the weights and the residuals for the whole frame
  * (ref: src/lm_optimizer.cpp:187-188 resize to rows*cols, :242-243 conservativeResize copy), re-evaluates
- * std::pow(2.0f, level) and GetCxLevel for every pixel (ref: include/image_processing_global.h:22-28,35-36,50-51;
- * src/lm_optimizer.cpp:223-233), and OptimizeCameraPose then forms JtW (6 x N temporary), JtW*J, JtW*r and r^T W r as
+ * std::pow(2.0f, level) and GetCxLevel at every use site for every pixel WITH VALID DEPTH (ref: :193-196 skips the others first;
+ * include/image_processing_global.h:22-28,35-36,50-51; src/lm_optimizer.cpp:223-233), and OptimizeCameraPose then forms JtW (6 x N temporary), JtW*J, JtW*r and r^T W r as
  * separate fp32 passes (ref: :129,145-149). Same per-pixel arithmetic as pixel_row; the sums are fp32, so its
  * trajectory is not bit-comparable with the oracle proper — it exists only so that the CPU time of the reference's
  * shape can be reported next to the fused restatement. Selected with orc_set_reference_shape(1). */
@@ -501,7 +501,60 @@ static float dot_f32(const float* a, size_t sa, const float* b, size_t sb, const
   for (; i < n; i++) s += c ? a[(size_t)i * sa] * c[i] * b[(size_t)i * sb] : a[(size_t)i * sa] * b[(size_t)i * sb];
   return s;
 }
-static volatile float g_two = 2.0f;  /* keeps the per-pixel pow() calls from being hoisted */
+/* The reference evaluates std::pow(2.0f, level) and GetCxLevel at every use site, for every pixel that PASSES the depth test
+ * (ref: src/lm_optimizer.cpp:193-196 `continue`s before any of them): ReprojectToCameraFrame 2 pow + 2 GetCxLevel
+ * (include/image_processing_global.h:35-36), WarpPixel 2 + 2 after its Z' > 0 test (h:45,50-51), the Jacobian 4 pow once the warp
+ * succeeded (src/lm_optimizer.cpp:223-224,232-233). Does a reference build really call pow there? Yes: GCC 11 -O3 -march=haswell
+ * -mavx2 (ref: CMakeLists.txt:19) keeps `call pow@PLT` inside the pixel loop for exactly this pattern (pow may set errno under the
+ * default -fmath-errno, so it is neither hoisted nor merged) — checked with a stand-alone loop of the same shape. The volatile
+ * base below only stops THIS file's compiler from folding pow(2.0, level) because `level` is visible as a small constant range
+ * after inlining; it adds no call the reference does not make. */
+static volatile float g_two = 2.0f;
+#define REF_FL() ((double)K->f0 / pow((double)g_two, (double)level))
+
+/* pixel_row with the reference's call pattern: same arithmetic, same results bit for bit (fl, cxl, cyl are the same values
+ * wherever they are recomputed), the reference's amount of work per pixel. Floor sampling only. */
+static int pixel_row_reference_shape(const float* I1, const float* I2, const float* D1, int rows, int cols, int x, int y,
+                                     const float T[16], const orc_intr* K, int level, float* r_out, float J[6]) {
+  const float d = D1[(size_t)y * cols + x];
+  if (fabsf(d - 0.0f) < 0.01f) return 0;                                  /* :193-196: nothing below runs for invalid depth */
+  const float z = 1.0f / d;                                               /* :198 */
+  const float X = (float)((double)(z * ((float)x - cx_level(K->cx0, level))) / REF_FL());   /* h:35 */
+  const float Y = (float)((double)(z * ((float)y - cx_level(K->cy0, level))) / REF_FL());   /* h:36 */
+  const float Z = z;
+  const float t0 = ((T[0] * X + T[4] * Y) + T[8] * Z) + T[12] * 1.0f;     /* h:43 */
+  const float t1 = ((T[1] * X + T[5] * Y) + T[9] * Z) + T[13] * 1.0f;
+  const float t2 = ((T[2] * X + T[6] * Y) + T[10] * Z) + T[14] * 1.0f;
+  if (!(t2 > 0.0f)) return 0;                                             /* h:45 */
+  const float u = (float)(REF_FL() * (double)t0 / (double)t2 + (double)cx_level(K->cx0, level));   /* h:50 */
+  const float v = (float)(REF_FL() * (double)t1 / (double)t2 + (double)cx_level(K->cy0, level));   /* h:51 */
+  const float fu = floorf(u), fv = floorf(v);
+  if (!(fu < (float)cols) || !(fv < (float)rows) || !(fu >= 0.0f) || !(fv >= 0.0f)) return 0;      /* h:54-56 */
+  const int ui = (int)fu, vi = (int)fv;                                   /* :208-209 */
+  const int px = (ui - 1 >= 0) ? ui - 1 : 0, nx = (ui + 1 < cols) ? ui + 1 : cols - 1;             /* h:62-69 */
+  const int py = (vi - 1 >= 0) ? vi - 1 : 0, ny = (vi + 1 < rows) ? vi + 1 : rows - 1;
+  const float gx = 0.5f * (I2[(size_t)vi * cols + nx] - I2[(size_t)vi * cols + px]);
+  const float gy = 0.5f * (I2[(size_t)ny * cols + ui] - I2[(size_t)py * cols + ui]);
+  *r_out = I2[(size_t)vi * cols + ui] - I1[(size_t)y * cols + x];         /* :217 */
+  const float fx_z = (float)(REF_FL() / (double)Z);                       /* :223 */
+  const float fy_z = (float)(REF_FL() / (double)Z);                       /* :224 (fy = fx: the same value, evaluated again) */
+  const float xy = X * Y, xx = X * X, yy = Y * Y, zz = Z * Z;
+  const float jw02 = (-fx_z * X) / Z;
+  const float jw03 = (-fx_z * xy) / Z;
+  const float jw04 = (float)(REF_FL() * (1.0 + (double)(xx / zz)));       /* :232 */
+  const float jw05 = -fx_z * Y;
+  const float jw12 = (-fy_z * Y) / Z;
+  const float jw13 = (float)(-REF_FL() * (1.0 + (double)(yy / zz)));      /* :233 */
+  const float jw14 = (fy_z * xy) / Z;
+  const float jw15 = fy_z * X;
+  J[0] = gx * fx_z + gy * 0.0f;                                           /* :234 */
+  J[1] = gx * 0.0f + gy * fy_z;
+  J[2] = gx * jw02 + gy * jw12;
+  J[3] = gx * jw03 + gy * jw13;
+  J[4] = gx * jw04 + gy * jw14;
+  J[5] = gx * jw05 + gy * jw15;
+  return 1;
+}
 
 static int lm_accumulate_reference_shape(const float* I1, const float* I2, const float* D1, int rows, int cols, int level,
                                          const float T[16], int robust, float huber_delta, const orc_intr* K,
@@ -513,15 +566,8 @@ static int lm_accumulate_reference_shape(const float* I1, const float* I2, const
   if (!J || !W || !r) { free(J); free(W); free(r); return -1; }
   int n = 0;
   for (int y = 4; y < rows - 4; y++)
-    for (int x = 4; x < cols - 4; x++) {
-      /* the reference calls pow(2.0f, level) in ReprojectToCameraFrame (x2), WarpPixel (x2) and the Jacobian (x4), and
-       * GetCxLevel (a loop over the levels) four times, for every pixel */
-      double fl = 0.0;
-      for (int k = 0; k < 8; k++) fl = (double)K->f0 / pow((double)g_two, (double)level);
-      float cxl = 0.0f, cyl = 0.0f;
-      for (int k = 0; k < 2; k++) { cxl = cx_level(K->cx0, level); cyl = cx_level(K->cy0, level); }
-      if (pixel_row(I1, I2, D1, rows, cols, x, y, T, fl, cxl, cyl, &r[n], &J[(size_t)n * 6])) n++;
-    }
+    for (int x = 4; x < cols - 4; x++)
+      if (pixel_row_reference_shape(I1, I2, D1, rows, cols, x, y, T, K, level, &r[n], &J[(size_t)n * 6])) n++;
   for (int i = 0; i < 29; i++) acc[i] = 0.0;
   if (n == 0) { free(J); free(W); free(r); return -1; }
   /* :242-243 conservativeResize(n, 6): Eigen reallocates and copies */

@@ -21,7 +21,7 @@ def _worker(rank, world, port, n_frames, every, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    g = PoseGatherer(world, every)
+    g = PoseGatherer(world, every, n_local_frames=n_frames)
     for f in range(n_frames):
         g.push(fake_pose(rank, f))
     g.flush()
@@ -44,6 +44,27 @@ def _worker_uneven(rank, world, port, n_sequences, frames, every, agree, q):
     g.flush()
     dist.barrier()
     q.put((rank, g.issued, [g.rows(r) for r in range(world)]))
+    dist.destroy_process_group()
+
+
+def _worker_mixed(rank, world, port, q):
+    """One rank passes n_max_frames, the other leaves it to the constructor: the agreement collective runs on BOTH (it used to run
+    only on ranks without n_max_frames and hang). Ids beyond 2^24 survive the float32 row."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_local = [5, 3][rank]
+    g = PoseGatherer(world, 4, n_local_frames=n_local, n_max_frames=5 if rank == 0 else None)
+    for f in range(n_local):
+        g.push(fake_pose(rank, f), seq_id=(1 << 24) + 1 + rank, frame_id=(1 << 30) + f)
+    g.flush()
+    dist.barrier()
+    err = None
+    try:
+        PoseGatherer(world, 4)          # legacy mode is refused when world > 1
+    except ValueError as e:
+        err = str(e)
+    q.put((rank, g.n_max, [g.ids(r) for r in range(world)], err))
     dist.destroy_process_group()
 
 
@@ -126,6 +147,30 @@ def test_pose_gather_uneven_shards_world2_gloo(n_sequences, frames, every, agree
             k = 0
             for sid in shard(n_sequences, r, world):
                 for f in range(frames):
-                    assert got[k, 0] == sid and got[k, 1] == f
+                    assert tuple(got[k, :2].view(np.int32)) == (sid, f)     # ids travel as int32 bit patterns
                     assert np.array_equal(got[k, 2:].reshape(3, 4), fake_pose(sid, f)[:3, :])
                     k += 1
+
+
+def test_pose_gather_mixed_n_max_and_large_ids_world2_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_mixed, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, n_max, ids, err = q.get(timeout=120)
+        res[rank] = (n_max, ids, err)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for viewer in range(world):
+        n_max, ids, err = res[viewer]
+        assert n_max == 5 and err and "n_local_frames is required" in err
+        for r, n_local in enumerate([5, 3]):
+            assert ids[r].shape == (n_local, 2)
+            assert ids[r][:, 0].tolist() == [(1 << 24) + 1 + r] * n_local            # not representable in float32
+            assert ids[r][:, 1].tolist() == [(1 << 30) + f for f in range(n_local)]

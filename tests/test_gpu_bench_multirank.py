@@ -13,14 +13,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_bench(extra, world=2, timeout=900):
+def _run_bench(extra, world=2, timeout=900, no_extras=True):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, ODO_BENCH_SHARE_GPU="1", ODO_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--no-extras", "--cpu-frames", "0"] + extra
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--cpu-frames", "0"] + (["--no-extras"] if no_extras else []) + extra
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -44,3 +44,16 @@ def test_bench_two_ranks_default_weak_scaling():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak"
     assert out["config"]["frames_per_rank"] == [10, 10]
     assert out["pose_gather"]["complete"] and out["pose_gather"]["rank0_rows_match_tracked_poses"]
+
+
+def test_bench_two_ranks_carries_configs3_and_exchange_evidence():
+    """The default N > 1 line: per-rank rates, the exchange's own evidence (ranks seen by a collective of the gather's backend,
+    distinct devices), and configs[3] in miniature (3 sequences over the 2 ranks, batched rank 0) as an extra key."""
+    out = _run_bench(["--steps", "8", "--warmup", "2", "--unique-frames", "12", "--gather-every", "4", "--configs3", "3"], no_extras=False)
+    assert out["n_gpus"] == 2 and out["pose_gather"]["complete"]
+    assert out["pose_gather"]["ranks_seen"] == 2 and out["pose_gather"]["backend"] == "gloo"
+    assert out["pose_gather"]["distinct_devices"] == 1           # this test shares ONE device between the ranks on purpose
+    assert len(out["per_rank"]["frames_per_s"]) == 2 and out["per_rank"]["slowest_over_fastest_seconds"] >= 1.0
+    c3 = out["configs3_sequences_3"]
+    assert c3["frames_per_rank"] == [16, 8] and c3["pose_gather"]["complete"] and c3["sequences_in_lock_step_on_rank0"] == 2
+    assert c3["frames_per_s"] > 0

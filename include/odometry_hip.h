@@ -157,18 +157,19 @@ int odo_lm_trace(const odo_lm* lm, odo_lm_trace_row* rows, int cap, int* n_rows)
 int odo_lm_time_eval(odo_lm* lm, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img, int level,
                      const float T_colmajor[16], int reps, float* mean_us, float* min_us, double* algorithmic_bytes,
                      int* n_points);
-/* Roofline leg of bench.py: HIP-event timing of the evaluation-kernel launches of Solve, start / stop events bound to the
- * dispatch on the context's stream. on = 0: off; 1: every launch; N > 1: every N-th launch of a Solve (rotating residue: cheap
- * enough to stay on inside a timed region). The stats are the summed launch durations, the number of launches, how many of them
- * evaluated points, and the algorithmic bytes they touched. */
+/* Roofline leg of bench.py: execution spans of the LM kernels' launches (lm_coarse_kernel, lm_step_kernel and their batched
+ * twins). A sampled launch records the device wall clock (100 MHz) at the entry of its earliest block and at the exit of its latest
+ * one — the kernel's own execution time, free of queueing and dispatch effects — into a slot of device memory; the statistics
+ * calls drain the stream and read the slots. on = 0: off; 1: every launch; N > 1: every N-th launch of a Solve (rotating residue:
+ * cheap enough to stay on inside a timed region). For a batched Solve the statistics live with the first optimiser. */
 int odo_lm_event_timing(odo_lm* lm, int on);
-int odo_lm_event_stats(const odo_lm* lm, double* total_us, long* launches, long* active_launches,
+int odo_lm_event_stats(odo_lm* lm, double* total_us, long* launches, long* active_launches,
                        double* algorithmic_bytes);
 /* Share of the above spent in the single-workgroup coarse-level kernel (one launch per Solve). */
-int odo_lm_event_stats2(const odo_lm* lm, double* coarse_us, long* coarse_launches);
+int odo_lm_event_stats2(odo_lm* lm, double* coarse_us, long* coarse_launches);
 /* out[0] sampled step-kernel time (us), [1] sampled step launches, [2] sampled coarse-kernel time (us), [3] sampled coarse
  * launches, [4] all launches issued, [5] all coarse launches, [6] evaluations, [7] algorithmic bytes. */
-int odo_lm_event_stats_ex(const odo_lm* lm, double out[8]);
+int odo_lm_event_stats_ex(odo_lm* lm, double out[8]);
 /* Sampling of the current image at the warped point. ODO_SAMPLE_FLOOR (default, parity mode) is what the reference does:
  * I2 at floor(u), floor(v), central-difference gradient at that pixel (ref: src/lm_optimizer.cpp:208-217,
  * include/image_processing_global.h:62-69). ODO_SAMPLE_BILINEAR is a NON-PARITY option (BASELINE.json north_star: "bilinear
@@ -306,6 +307,8 @@ typedef struct odo_tracker_batch odo_tracker_batch;
 int odo_tracker_batch_create(int device, const odo_tracker_params* p, int n_sequences, odo_tracker_batch** out);
 int odo_tracker_batch_destroy(odo_tracker_batch* b);
 int odo_tracker_batch_size(const odo_tracker_batch* b);
+/* The pose optimiser of one slot (launch statistics of the batched Solves live with the first slot's: odo_lm_event_timing). */
+odo_lm* odo_tracker_batch_lm(odo_tracker_batch* b, int slot);
 odo_ctx* odo_tracker_batch_ctx(odo_tracker_batch* b); /* for odo_dev_alloc / upload / download of its frames */
 /* Frame 0 (ref: :95-145) of every slot that is given a pair; a slot whose left_dev[i] / right_dev[i] are NULL stays empty.
  * abs_pose0: n x 16, or NULL for identity. Returns -1 if any sequence's ComputeDepth fails ("Init 0-th frame failed!",

@@ -690,6 +690,16 @@ class TrackerBatch:
         L.check(self.lib.odo_tracker_batch_timing(self.h, out), "odo_tracker_batch_timing")
         return dict(step_us=out[0], head_us=out[1], solve_us=out[2], depth_wait_us=out[3])
 
+    def event_timing(self, on):
+        """Execution-span sampling of the batched LM launches (every `on`-th; 0 = off); statistics live with slot 0's optimiser."""
+        L.check(self.lib.odo_lm_event_timing(C.c_void_p(self.lib.odo_tracker_batch_lm(self.h, 0)), int(on)), "odo_lm_event_timing")
+
+    def event_stats_ex(self):
+        o = (C.c_double * 8)()
+        L.check(self.lib.odo_lm_event_stats_ex(C.c_void_p(self.lib.odo_tracker_batch_lm(self.h, 0)), o), "odo_lm_event_stats_ex")
+        return dict(step_us=o[0], step_sampled=int(o[1]), coarse_us=o[2], coarse_sampled=int(o[3]), launches=int(o[4]),
+                    coarse_launches=int(o[5]), evaluations=int(o[6]), bytes=o[7])
+
     def outputs(self, seq, rows, cols):
         v, dsp, dep = C.c_void_p(), C.c_void_p(), C.c_void_p()
         L.check(self.lib.odo_tracker_batch_outputs(self.h, seq, C.byref(v), C.byref(dsp), C.byref(dep)), "odo_tracker_batch_outputs")

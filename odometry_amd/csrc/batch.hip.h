@@ -814,4 +814,5 @@ extern "C" int odo_tracker_batch_outputs(const odo_tracker_batch* b, int seq, co
   return 0;
 }
 extern "C" int odo_tracker_batch_size(const odo_tracker_batch* b) { return b ? b->S : 0; }
+extern "C" odo_lm* odo_tracker_batch_lm(odo_tracker_batch* b, int slot) { return (b && slot >= 0 && slot < b->S) ? b->lm[slot] : nullptr; }
 extern "C" odo_ctx* odo_tracker_batch_ctx(odo_tracker_batch* b) { return b ? b->ctx_a : nullptr; }

@@ -892,13 +892,23 @@ struct StepArgs {
   // Solve "finished" there and leaves its state in final_state, from which the host carries on level by level
   int stop_level;       // 0: the fused pipeline covers every level
   LmState* final_state; // where the finishing launch copies the state (NULL: nowhere)
+  // bench.py roofline: a sampled launch records its own execution span — span[0] = min over blocks of the device wall clock
+  // (100 MHz) at entry, span[1] = max at exit; NULL: not sampled (two fire-and-forget device-scope atomics per block when on)
+  unsigned long long* span;
 };
 // What changes from launch to launch of one Solve.
 struct StepLaunch {
   const LmState* st_in; LmState* st_out;
   const double* part_in; double* part_out;
   int seq, first_of_solve;
+  unsigned long long* span;
 };
+__device__ __forceinline__ void lm_span_begin(unsigned long long* span) {
+  if (span && threadIdx.x == 0) atomicMin(span, (unsigned long long)wall_clock64());
+}
+__device__ __forceinline__ void lm_span_end(unsigned long long* span) {
+  if (span && threadIdx.x == 0) atomicMax(span + 1, (unsigned long long)wall_clock64());
+}
 
 constexpr int kFoldChunk = 20;  // the 160 rows of a point-list grid in one round of loads per segment
 
@@ -1148,6 +1158,7 @@ __device__ __forceinline__ void lm_fused_publish(LmState& s_sh, LmState* __restr
 // level and the blocks a coarser level does not need stop after the (redundant, parallel) prologue.
 __device__ __forceinline__ void lm_step_body(const StepArgs& a, const StepLaunch& q) {
   __builtin_amdgcn_s_setprio(3);  // see lm_coarse_kernel
+  lm_span_begin(q.span);
   __shared__ LmState s_sh;
   __shared__ double fold_sh[8 * 32];
   __shared__ double acc_sh[32];
@@ -1197,18 +1208,20 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const StepLaunch
     lm_fused_publish(s_sh, q.st_out, a.host_prog, q.seq, a.token, a.cost_stat, a.out, a.done_flag, a.final_state);
     if (a.dbg && threadIdx.x == 0 && q.seq < 56) a.dbg[16 + 2 * q.seq + 1] = wall_clock64();
   }
+  lm_span_end(q.span);
 }
 
 __global__ void __launch_bounds__(kLmBlock) lm_step_kernel(StepArgs a) {
-  const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve};
+  const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve, a.span};
   lm_step_body(a, q);
 }
 // Several independent Solves in the SAME launches: blockIdx.y picks the sequence's entry of a table in device memory that
 // stays constant for the whole Solve; every sequence runs its own state machine and finishes in its own time (the blocks of
 // a finished sequence return after the prologue). grid = (largest grid of any sequence, number of sequences).
-__global__ void __launch_bounds__(kLmBlock) lm_step_kernel_batch(const StepArgs* __restrict__ table, int seq, int first_of_solve) {
+__global__ void __launch_bounds__(kLmBlock) lm_step_kernel_batch(const StepArgs* __restrict__ table, int seq, int first_of_solve,
+                                                                 unsigned long long* span) {
   const StepArgs& a = table[blockIdx.y];
-  const StepLaunch q = {a.st2[seq & 1], a.st2[(seq + 1) & 1], a.part2[seq & 1], a.part2[(seq + 1) & 1], seq, first_of_solve};
+  const StepLaunch q = {a.st2[seq & 1], a.st2[(seq + 1) & 1], a.part2[seq & 1], a.part2[(seq + 1) & 1], seq, first_of_solve, span};
   lm_step_body(a, q);
 }
 
@@ -1232,6 +1245,7 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
   // The pose LM is the latency-critical chain of a frame, while the depth stream floods the CUs with throughput work
   // (selection, SSD scan) at the same time: raise this workgroup's issue priority on the SIMDs it shares with them.
   __builtin_amdgcn_s_setprio(3);
+  lm_span_begin(q.span);
   __shared__ LmState s_sh;
   extern __shared__ double red_sh[];  // kCoarseLdsBytes: reduction buffer; its head doubles as the fold scratch
   __shared__ double acc_sh[32];
@@ -1301,17 +1315,19 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
     a.dbg[0] += c_eval; a.dbg[1] += c_red; a.dbg[2] += c_sm; a.dbg[3] += c_it;
     a.dbg[4] += __builtin_readcyclecounter() - c_begin; a.dbg[5] += 1;
   }
+  lm_span_end(q.span);
 }
 
 __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int min_level) {
-  const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve};
+  const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve, a.span};
   lm_coarse_body(a, q, min_level);
 }
 // Batched twin (see lm_step_kernel_batch): one workgroup per sequence, each with its own min_level (a sequence without a
 // coarse level only initialises its state, begins its first level and publishes).
-__global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel_batch(const StepArgs* __restrict__ table, int seq, int first_of_solve) {
+__global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel_batch(const StepArgs* __restrict__ table, int seq, int first_of_solve,
+                                                                       unsigned long long* span) {
   const StepArgs& a = table[blockIdx.y];
-  const StepLaunch q = {a.st2[seq & 1], a.st2[(seq + 1) & 1], a.part2[seq & 1], a.part2[(seq + 1) & 1], seq, first_of_solve};
+  const StepLaunch q = {a.st2[seq & 1], a.st2[(seq + 1) & 1], a.part2[seq & 1], a.part2[(seq + 1) & 1], seq, first_of_solve, span};
   lm_coarse_body(a, q, a.min_level);
 }
 

@@ -540,7 +540,13 @@ struct odo_lm {
   double ev_total_us, ev_bytes, ev_coarse_us;
   long ev_launches, ev_active, ev_coarse_launches;   // launches issued / evaluations / SAMPLED coarse launches
   long ev_sampled, ev_coarse_all;                    // sampled launches (step + coarse) / all coarse launches
+  // execution spans of the sampled launches (StepArgs::span): a ring of {min start, max end} device wall-clock pairs, one slot
+  // per sampled launch, collected (stream sync + one copy) when the statistics are read
+  unsigned long long* d_span;
+  int span_used;
+  std::vector<unsigned char>* span_kind;             // per assigned slot: 1 = coarse launch, 0 = step launch
   int last_coarse;  // 1 if the last Solve started with the single-workgroup coarse kernel
+  int last_coarse_batch;  // (lms[0] of a batched Solve) 1 if the batch began with a coarse launch
   int trace_stale;
   int record;      // 1: per-evaluation trace rows and per-level cost statistics are written (odo_lm_trace / odo_lm_report);
                    // the trackers switch it off for their own optimisers (ODO_LM_TRACE=1 keeps it)
@@ -649,6 +655,8 @@ extern "C" int odo_lm_destroy(odo_lm* m) {
   (void)hipHostFree(m->cand[0].h_npts);
   (void)hipHostFree(m->cand[1].h_npts);
   if (m->ev_pool) { for (auto& e : *m->ev_pool) (void)hipEventDestroy(e); delete m->ev_pool; }
+  if (m->d_span) (void)hipFree(m->d_span);
+  delete m->span_kind;
   (void)hipHostFree(m->h_out); (void)hipHostFree(m->h_trace); (void)hipHostFree(m->h_prog); (void)hipHostFree(m->h_res); (void)hipHostFree(m->h_done);
   delete m;
   return 0;
@@ -893,9 +901,33 @@ static inline double lm_level_bytes(const odo_lm* m, int level, int rows, int co
 // pyramids abandons it (its launches drain on the stream like the stragglers of any finished Solve: the next Solve starts
 // with first_of_solve = 1 and a new token).
 // ---------------------------------------------------------------------------------------------------------------
-// Event timing: is launch `i` of the Solve in flight one of the sampled ones?
-static inline bool lm_ev_sampled(const odo_lm* m, int i) {
-  return m->ev_on > 0 && m->ev_pool && (size_t)(2 * i + 1) < m->ev_pool->size() && ((i + m->ev_phase) % m->ev_on) == 0;
+// Launch timing: is launch `i` of the Solve in flight one of the sampled ones? If so it gets the next free span slot.
+constexpr int kSpanSlots = 16384;
+static inline unsigned long long* lm_span_slot(odo_lm* m, int i, bool coarse) {
+  if (!(m->ev_on > 0 && m->d_span && ((i + m->ev_phase) % m->ev_on) == 0) || m->span_used >= kSpanSlots) return nullptr;
+  m->span_kind->push_back(coarse ? 1 : 0);
+  return m->d_span + 2 * (size_t)(m->span_used++);
+}
+// Reads the spans of every sampled launch so far into the accumulators and frees the slots (drains the stream first).
+static int lm_span_collect(odo_lm* m) {
+  if (!m->d_span || m->span_used == 0) return 0;
+  HIP_OK(hipSetDevice(m->ctx->device));
+  HIP_OK(hipStreamSynchronize(m->ctx->stream));
+  std::vector<unsigned long long> h(2 * (size_t)m->span_used);
+  HIP_OK(hipMemcpy(h.data(), m->d_span, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+  for (int i = 0; i < m->span_used; i++) {
+    const unsigned long long t0 = h[2 * i], t1 = h[2 * i + 1];
+    if (t0 == ~0ull || t1 == 0 || t1 < t0) continue;   // a launch that never ran (dropped with its Solve)
+    const double us = (double)(t1 - t0) * 0.01;          // wall_clock64: 100 MHz
+    m->ev_total_us += us;
+    m->ev_sampled++;
+    if ((*m->span_kind)[i]) { m->ev_coarse_us += us; m->ev_coarse_launches++; }
+  }
+  for (int i = 0; i < m->span_used; i++) { h[2 * i] = ~0ull; h[2 * i + 1] = 0; }
+  HIP_OK(hipMemcpy(m->d_span, h.data(), sizeof(unsigned long long) * h.size(), hipMemcpyHostToDevice));
+  m->span_used = 0;
+  m->span_kind->clear();
+  return 0;
 }
 static inline int lm_job_progress(const odo_lm* m) {
   const int v = ((volatile int*)m->h_prog)[0];
@@ -995,12 +1027,8 @@ static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_de
     a.st_in = st[jb.seq & 1]; a.st_out = st[(jb.seq + 1) & 1];
     a.part_in = part[jb.seq & 1]; a.part_out = part[(jb.seq + 1) & 1];
     a.seq = jb.seq; a.first_of_solve = 1;
-    const bool ev = lm_ev_sampled(m, 0);
-    if (ev)
-      hipExtLaunchKernelGGL(lm_coarse_kernel, dim3(1), dim3(kCoarseBlock), kCoarseLdsBytes, s, (*m->ev_pool)[0],
-                            (*m->ev_pool)[1], 0, a, min_level);
-    else
-      hipLaunchKernelGGL(lm_coarse_kernel, dim3(1), dim3(kCoarseBlock), kCoarseLdsBytes, s, a, min_level);
+    a.span = lm_span_slot(m, 0, true);
+    hipLaunchKernelGGL(lm_coarse_kernel, dim3(1), dim3(kCoarseBlock), kCoarseLdsBytes, s, a, min_level);
     jb.seq++;
     jb.launches++;
   }
@@ -1033,12 +1061,8 @@ static void lm_fused_pump(odo_lm* m, bool block) {
     a.st_in = st[jb.seq & 1]; a.st_out = st[(jb.seq + 1) & 1];
     a.part_in = part[jb.seq & 1]; a.part_out = part[(jb.seq + 1) & 1];
     a.seq = jb.seq; a.first_of_solve = (jb.seq == 0) ? 1 : 0;
-    const bool ev = lm_ev_sampled(m, jb.launches);
-    if (ev)  // timing: start / stop events bound to the dispatch itself (the kernel's own begin / end timestamps)
-      hipExtLaunchKernelGGL(lm_step_kernel, dim3(jb.grid), dim3(kLmBlock), 0, s, (*m->ev_pool)[2 * jb.launches],
-                            (*m->ev_pool)[2 * jb.launches + 1], 0, a);
-    else
-      hipLaunchKernelGGL(lm_step_kernel, dim3(jb.grid), dim3(kLmBlock), 0, s, a);
+    a.span = lm_span_slot(m, jb.launches, false);   // sampled launches record their own execution span (bench.py roofline)
+    hipLaunchKernelGGL(lm_step_kernel, dim3(jb.grid), dim3(kLmBlock), 0, s, a);
     jb.seq++;
     jb.launches++;
     if (jb.it == jb.budget) jb.result_by_launch = true;  // the extra launch consumes the last evaluation and reports
@@ -1213,16 +1237,7 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
     m->iters[l] = (int)m->h_out[18 + l];
     m->last_bytes += bytes_per_level[l] * m->iters[l];
   }
-  if (m->ev_on && m->ev_pool && fused) {
-    for (int i = 0; i < launches; i++) {
-      if (!lm_ev_sampled(m, i)) continue;
-      float ms = 0.0f;
-      if (hipEventElapsedTime(&ms, (*m->ev_pool)[2 * i], (*m->ev_pool)[2 * i + 1]) == hipSuccess) {
-        m->ev_total_us += ms * 1000.0;
-        m->ev_sampled++;
-        if (i == 0 && m->last_coarse) { m->ev_coarse_us += ms * 1000.0; m->ev_coarse_launches++; }
-      }
-    }
+  if (m->ev_on && fused) {
     m->ev_launches += launches;
     m->ev_coarse_all += m->last_coarse;
     m->ev_active += m->last_evals;
@@ -1324,7 +1339,7 @@ static void lm_batch_pump(odo_ctx* cx, bool block, void (*idle)(void*), void* id
     }
     if (lm_batch_all_finished(jb)) break;
     hipLaunchKernelGGL(lm_step_kernel_batch, dim3(jb.grid, jb.n), dim3(kLmBlock), 0, s, (const StepArgs*)cx->lm_batch_d, jb.seq,
-                       (jb.seq == 0) ? 1 : 0);
+                       (jb.seq == 0) ? 1 : 0, lm_span_slot(jb.lms[0], jb.launches, false));
     jb.seq++; jb.launches++;
     if (!jb.poll_ok && jb.it >= jb.budget) break;
     jb.it++;
@@ -1380,8 +1395,11 @@ static int lm_batch_begin(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
   // the table of the previous batched Solve may still be read by its draining launches: order the upload behind them
   HIP_OK(hipMemcpyAsync(d_table, h_table, sizeof(StepArgs) * (size_t)n, hipMemcpyHostToDevice, s));
   jb.grid = grid; jb.budget = budget; jb.seq = 0; jb.launches = 0; jb.it = 0; jb.poll_ok = true; jb.issued_all = false;
+  if (lms[0]->ev_on > 0) lms[0]->ev_phase = (int)(lms[0]->ev_solves++ % lms[0]->ev_on);
+  lms[0]->last_coarse_batch = any_coarse;
   if (any_coarse) {
-    hipLaunchKernelGGL(lm_coarse_kernel_batch, dim3(1, n), dim3(kCoarseBlock), kCoarseLdsBytes, s, (const StepArgs*)d_table, jb.seq, 1);
+    hipLaunchKernelGGL(lm_coarse_kernel_batch, dim3(1, n), dim3(kCoarseBlock), kCoarseLdsBytes, s, (const StepArgs*)d_table, jb.seq, 1,
+                       lm_span_slot(lms[0], 0, true));
     jb.seq++; jb.launches++;
   }
   jb.active = 1;
@@ -1465,6 +1483,12 @@ static int lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
     status[i] = (m->h_out[16] != 0.0f) ? -1 : 0;
     if (status[i]) { any_fail = 1; }
   }
+  if (lms[0]->ev_on) {   // launch statistics of the batched Solve, kept with the first optimiser (odo_lm_event_stats_ex)
+    odo_lm* m0 = lms[0];
+    m0->ev_launches += launches;
+    m0->ev_coarse_all += m0->last_coarse_batch;
+    for (int i = 0; i < n; i++) { m0->ev_active += lms[i]->last_evals; m0->ev_bytes += lms[i]->last_bytes; }
+  }
   if (any_fail) fail("Optimize failed! ");  // ref: src/lm_optimizer.cpp:60-61 (per-sequence status in `status`)
   return 0;
 }
@@ -1481,36 +1505,47 @@ extern "C" int odo_lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* cons
 extern "C" int odo_lm_event_timing(odo_lm* m, int on) {
   if (!m) return fail("NULL lm");
   if (on < 0) return fail("odo_lm_event_timing: on must be >= 0");
-  if (on && !m->ev_pool) {
-    m->ev_pool = new std::vector<hipEvent_t>(2 * 128);
-    for (auto& e : *m->ev_pool) HIP_OK(hipEventCreate(&e));
+  if (on && !m->d_span) {
+    HIP_OK(hipSetDevice(m->ctx->device));
+    HIP_OK(hipMalloc((void**)&m->d_span, sizeof(unsigned long long) * 2 * kSpanSlots));
+    std::vector<unsigned long long> h(2 * (size_t)kSpanSlots);
+    for (int i = 0; i < kSpanSlots; i++) { h[2 * i] = ~0ull; h[2 * i + 1] = 0; }
+    HIP_OK(hipMemcpy(m->d_span, h.data(), sizeof(unsigned long long) * h.size(), hipMemcpyHostToDevice));
+    m->span_kind = new std::vector<unsigned char>();
+    m->span_used = 0;
   }
   if (on) {
+    if (lm_span_collect(m)) return -1;   // slots of an earlier period
     m->ev_total_us = m->ev_bytes = m->ev_coarse_us = 0.0;
     m->ev_launches = m->ev_active = m->ev_coarse_launches = m->ev_sampled = m->ev_coarse_all = 0;
     m->ev_solves = 0; m->ev_phase = 0;
+  } else if (m->ev_on) {
+    if (lm_span_collect(m)) return -1;
   }
   m->ev_on = on;
   return 0;
 }
 // out[0] sampled step-kernel time (us), out[1] sampled step launches, out[2] sampled coarse-kernel time (us), out[3] sampled
 // coarse launches, out[4] all launches issued, out[5] all coarse launches, out[6] evaluations, out[7] algorithmic bytes.
-extern "C" int odo_lm_event_stats_ex(const odo_lm* m, double out[8]) {
+extern "C" int odo_lm_event_stats_ex(odo_lm* m, double out[8]) {
   if (!m || !out) return fail("NULL arg");
+  if (lm_span_collect(m)) return -1;
   out[0] = m->ev_total_us - m->ev_coarse_us; out[1] = (double)(m->ev_sampled - m->ev_coarse_launches);
   out[2] = m->ev_coarse_us; out[3] = (double)m->ev_coarse_launches;
   out[4] = (double)m->ev_launches; out[5] = (double)m->ev_coarse_all; out[6] = (double)m->ev_active; out[7] = m->ev_bytes;
   return 0;
 }
-extern "C" int odo_lm_event_stats2(const odo_lm* m, double* coarse_us, long* coarse_launches) {
+extern "C" int odo_lm_event_stats2(odo_lm* m, double* coarse_us, long* coarse_launches) {
   if (!m) return fail("NULL lm");
+  if (lm_span_collect(m)) return -1;
   if (coarse_us) *coarse_us = m->ev_coarse_us;
   if (coarse_launches) *coarse_launches = m->ev_coarse_launches;
   return 0;
 }
-extern "C" int odo_lm_event_stats(const odo_lm* m, double* total_us, long* launches, long* active_launches,
+extern "C" int odo_lm_event_stats(odo_lm* m, double* total_us, long* launches, long* active_launches,
                                   double* algorithmic_bytes) {
   if (!m) return fail("NULL lm");
+  if (lm_span_collect(m)) return -1;
   if (total_us) *total_us = m->ev_total_us;
   if (launches) *launches = m->ev_launches;
   if (active_launches) *active_launches = m->ev_active;

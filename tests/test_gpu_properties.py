@@ -154,7 +154,7 @@ def test_candidate_lists_and_priority_stream_change_nothing(api):
     a stretch of the forward drive that switches keyframes repeatedly."""
     import os
     import bench
-    seq = bench.render_sequence(40, 0, 8)
+    seq = bench.render_sequence(40, 0, 8, drive="corridor")   # the drive on which the policy re-promotes keyframes all the time
     order = bench.frame_order(40, 39)
 
     def run(env):

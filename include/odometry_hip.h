@@ -157,6 +157,11 @@ int odo_lm_trace(const odo_lm* lm, odo_lm_trace_row* rows, int cap, int* n_rows)
 int odo_lm_time_eval(odo_lm* lm, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img, int level,
                      const float T_colmajor[16], int reps, float* mean_us, float* min_us, double* algorithmic_bytes,
                      int* n_points);
+/* The same for n optimisers of one context in ONE launch (blockIdx.y = stream): the batched dense evaluation of odo_lm_solve_batch.
+ * `level` must be dense (not a point-list level) for every optimiser; algorithmic_bytes / n_points_total are totals over the streams. */
+int odo_lm_time_eval_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_img, const odo_pyr* const* kf_dep,
+                           const odo_pyr* const* cur_img, int level, const float T_colmajor[16], int reps, float* mean_us,
+                           float* min_us, double* algorithmic_bytes, int* n_points_total);
 /* Roofline leg of bench.py: execution spans of the LM kernels' launches (lm_coarse_kernel, lm_step_kernel and their batched
  * twins). A sampled launch records the device wall clock (100 MHz) at the entry of its earliest block and at the exit of its latest
  * one — the kernel's own execution time, free of queueing and dispatch effects — into a slot of device memory; the statistics

@@ -275,6 +275,17 @@ def solve_batch(lms, kf_imgs, kf_deps, cur_imgs):
     return np.stack([_from_colmajor(o) for o in out]), list(st)
 
 
+def time_eval_batch(lms, kf_imgs, kf_deps, cur_imgs, level, T, reps=50):
+    """odo_lm_time_eval_batch: `reps` event-timed launches of the batched dense evaluation (blockIdx.y = stream) of `level`."""
+    n = len(lms)
+    lib = lms[0].ctx.lib
+    arr = lambda objs: (C.c_void_p * n)(*[o.h for o in objs])   # noqa: E731
+    mean, mn, b, npts = C.c_float(0), C.c_float(0), C.c_double(0), C.c_int(0)
+    L.check(lib.odo_lm_time_eval_batch(n, arr(lms), arr(kf_imgs), arr(kf_deps), arr(cur_imgs), level, _fp(_colmajor(T)), reps,
+                                       C.byref(mean), C.byref(mn), C.byref(b), C.byref(npts)), "odo_lm_time_eval_batch")
+    return dict(mean_us=mean.value, min_us=mn.value, bytes=b.value, n_points=npts.value)
+
+
 class DepthEstimator:
     """ref: include/depth_estimate.h:24-121"""
 

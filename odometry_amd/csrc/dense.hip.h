@@ -159,6 +159,17 @@ struct DenseLevel {
 
 constexpr int kDenseMaxBlocks = 1280;  // five 256-thread blocks per CU
 
+// One stream's entry of the table a batched evaluation launch reads (lm_dense_eval_batch_kernel).
+struct DenseBatchItem {
+  DenseLevel L;
+  const LmState* st;
+  const float* scale_sqr;
+  double* partials;
+  int expect_level, robust;
+  float huber_delta;
+  int pad_;
+};
+
 // Fills the decomposition fields for `block_threads`-wide blocks. A block walks `units` (strip, row-group) pairs; the
 // grid is capped at max_blocks; levels with fewer units than that get one block per unit.
 static inline void dense_level_geometry(DenseLevel* L, int block_threads, int max_blocks) {
@@ -507,6 +518,28 @@ __global__ void __launch_bounds__(kBlock, kWaves) lm_dense_eval_kernel(DenseLeve
   block_reduce_acc_w<kBlock>(acc, partials + (size_t)blockIdx.x * ODO_NACC);
 }
 
+// Several independent streams (optimisers) in ONE launch: blockIdx.y picks the stream's entry of a table in device memory, block
+// (x, y) does exactly what block x of the stream's own launch does (same units, same reduction order: bit-identical results).
+// One 1080p level is too small to fill the chip for long (2 M pixels: ~18 us, of which launch ramp and tail are a large part);
+// S levels side by side are S times the bytes in one ramp. grid = (largest nblk of any stream, rounded up to a multiple of 8 so
+// that blockIdx.x % 8 stays the XCD label of every row of the grid; S).
+template <int kBlock, int kFlags, int kWaves>
+__global__ void __launch_bounds__(kBlock, kWaves) lm_dense_eval_batch_kernel(const DenseBatchItem* __restrict__ items) {
+  const DenseBatchItem& it = items[blockIdx.y];
+  if ((int)blockIdx.x >= it.L.nblk) return;
+  if (!(it.st->active != 0 && it.st->level == it.expect_level)) return;
+  float T[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) T[i] = it.st->T[i];
+  const float scale_sqr = (it.robust == 2) ? *it.scale_sqr : 1.0f;
+  double acc[ODO_NACC];
+#pragma unroll
+  for (int q = 0; q < ODO_NACC; q++) acc[q] = 0.0;
+  const DenseLevel L = it.L;   // wave-uniform: scalar loads
+  dense_eval_block_pipelined<kBlock, kFlags>(L, blockIdx.x, T, it.robust, it.huber_delta, scale_sqr, acc);
+  block_reduce_acc_w<kBlock>(acc, it.partials + (size_t)blockIdx.x * ODO_NACC);
+}
+
 #endif  // ODO_DENSE_KERNELS
 
 // Launcher (defined in dense_kernels.hip): one evaluation of level `L` at the pose in `st` on stream `s`; e0 / e1, when
@@ -515,5 +548,7 @@ __global__ void __launch_bounds__(kBlock, kWaves) lm_dense_eval_kernel(DenseLeve
 constexpr int kDenseBlock = 256, kDenseWaves = 4, kDenseGridCap = 1024;
 void launch_dense_eval(const DenseLevel& L, const LmState* st, int expect_level, int robust, float huber_delta,
                        const float* scale_sqr_ptr, double* partials, hipStream_t s, hipEvent_t e0, hipEvent_t e1, int plain_div);
+// The batched twin: n streams, d_items = device table of n DenseBatchItem, max_nblk = largest L.nblk among them.
+void launch_dense_eval_batch(const DenseBatchItem* d_items, int n, int max_nblk, hipStream_t s, hipEvent_t e0, hipEvent_t e1, int plain_div);
 
 }  // namespace odo

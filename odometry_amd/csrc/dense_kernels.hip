@@ -27,4 +27,15 @@ void launch_dense_eval(const DenseLevel& L, const LmState* st, int expect_level,
   }
 }
 
+void launch_dense_eval_batch(const DenseBatchItem* d_items, int n, int max_nblk, hipStream_t s, hipEvent_t e0, hipEvent_t e1, int plain_div) {
+  const dim3 grid((max_nblk + 7) / 8 * 8, n), block(kDenseBlock);
+  if (plain_div) {
+    if (e0 && e1) hipExtLaunchKernelGGL((lm_dense_eval_batch_kernel<kDenseBlock, 1, kDenseWaves>), grid, block, 0, s, e0, e1, 0, d_items);
+    else hipLaunchKernelGGL((lm_dense_eval_batch_kernel<kDenseBlock, 1, kDenseWaves>), grid, block, 0, s, d_items);
+  } else {
+    if (e0 && e1) hipExtLaunchKernelGGL((lm_dense_eval_batch_kernel<kDenseBlock, 0, kDenseWaves>), grid, block, 0, s, e0, e1, 0, d_items);
+    else hipLaunchKernelGGL((lm_dense_eval_batch_kernel<kDenseBlock, 0, kDenseWaves>), grid, block, 0, s, d_items);
+  }
+}
+
 }  // namespace odo

@@ -992,11 +992,11 @@ __device__ __forceinline__ void lm_state_machine(bool pending, const StepLevel* 
 constexpr int kUpdThreads = 1024;
 #define ODO_STAMP(i) do { if (STAMP && threadIdx.x == 0) stamps[i] = __builtin_readcyclecounter(); } while (0)
 template <bool STAMP>
-__global__ void __launch_bounds__(kUpdThreads) lm_update_kernel(LmState* __restrict__ st, const double* __restrict__ partials,
-                                                         int nblk, int expect_level, float precision, int max_iters,
-                                                         LmTraceRow* __restrict__ trace, float* __restrict__ cost_stat,
-                                                         int* __restrict__ host_prog, int seq,
-                                                         unsigned long long* __restrict__ stamps) {
+__device__ __forceinline__ void lm_update_body(LmState* __restrict__ st, const double* __restrict__ partials,
+                                               int nblk, int expect_level, float precision, int max_iters,
+                                               LmTraceRow* __restrict__ trace, float* __restrict__ cost_stat,
+                                               int* __restrict__ host_prog, int seq,
+                                               unsigned long long* __restrict__ stamps) {
   ODO_STAMP(0);
   if (!(st->active != 0 && st->level == expect_level)) {
     // stale launch (the level's loop already stopped): only report progress to the polling host
@@ -1052,6 +1052,34 @@ __global__ void __launch_bounds__(kUpdThreads) lm_update_kernel(LmState* __restr
     }
   }
   ODO_STAMP(7);
+}
+template <bool STAMP>
+__global__ void __launch_bounds__(kUpdThreads) lm_update_kernel(LmState* __restrict__ st, const double* __restrict__ partials,
+                                                         int nblk, int expect_level, float precision, int max_iters,
+                                                         LmTraceRow* __restrict__ trace, float* __restrict__ cost_stat,
+                                                         int* __restrict__ host_prog, int seq,
+                                                         unsigned long long* __restrict__ stamps) {
+  lm_update_body<STAMP>(st, partials, nblk, expect_level, precision, max_iters, trace, cost_stat, host_prog, seq, stamps);
+}
+// The unfused pipeline for several streams at once (dense levels of a batched Solve): one table entry per stream, constant for
+// a pyramid level; blockIdx.x = stream. Each block is the stream's own single-stream launch.
+struct UpdItem {
+  LmState* st;
+  const double* partials;
+  int nblk, expect_level;
+  float precision;
+  int max_iters;
+  LmTraceRow* trace;
+  float* cost_stat;
+  int* host_prog;
+  float lambda0;
+  const float* init;   // lm_begin_solve_batch_kernel: affine_init_, column-major, device memory
+  float* out;          // lm_finalize_batch_kernel: 26 result floats, device memory
+};
+__global__ void __launch_bounds__(kUpdThreads) lm_update_batch_kernel(const UpdItem* __restrict__ items, int seq) {
+  const UpdItem& q = items[blockIdx.x];
+  lm_update_body<false>(q.st, q.partials, q.nblk, q.expect_level, q.precision, q.max_iters, q.trace, q.cost_stat, q.host_prog, seq,
+                        nullptr);
 }
 
 // Prologue shared by the step kernel and the finalize kernel: leaves the advanced state in s_sh.
@@ -1391,7 +1419,32 @@ __global__ void lm_begin_level_kernel(LmState* __restrict__ st, int level, float
 
 // affine_ = current_estimate.matrix() (ref: src/lm_optimizer.cpp:158), or the pseudo-identity whose (3,3)
 // is 0 on failure (ref: :48-52,60-65). out[16] = pose, out[16] = status as float.
-__global__ void lm_finalize_kernel(const LmState* __restrict__ st, float* __restrict__ out) {
+__device__ __forceinline__ void lm_finalize_body(const LmState* __restrict__ st, float* __restrict__ out);
+__global__ void lm_finalize_kernel(const LmState* __restrict__ st, float* __restrict__ out) { lm_finalize_body(st, out); }
+__global__ void lm_finalize_batch_kernel(const UpdItem* __restrict__ items) { lm_finalize_body(items[blockIdx.x].st, items[blockIdx.x].out); }
+__global__ void lm_begin_solve_batch_kernel(const UpdItem* __restrict__ items) {
+  if (threadIdx.x == 0) {
+    const UpdItem& q = items[blockIdx.x];
+    LmState s;
+    float m[16];
+    for (int i = 0; i < 16; i++) m[i] = q.init[i];
+    lm_begin_solve(&s, m);
+    s.level = -1; s.iter = 0; s.lambda = 0.0f; s.err_last = 1e+10f;
+    for (int i = 0; i < 16; i++) s.T[i] = m[i];
+    *q.st = s;
+    for (int i = 0; i < 16; i++) q.cost_stat[i] = 0.0f;
+  }
+}
+__global__ void lm_begin_level_batch_kernel(const UpdItem* __restrict__ items) {
+  if (threadIdx.x == 0) {
+    const UpdItem& q = items[blockIdx.x];
+    LmState s = *q.st;
+    s.stop_reason = 0;
+    lm_begin_level(&s, q.expect_level, q.lambda0, q.max_iters);
+    *q.st = s;
+  }
+}
+__device__ __forceinline__ void lm_finalize_body(const LmState* __restrict__ st, float* __restrict__ out) {
   if (threadIdx.x == 0) {
     float m[16];
     if (st->status == 0) {

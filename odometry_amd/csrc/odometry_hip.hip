@@ -62,6 +62,9 @@ struct odo_ctx {
   void* lm_batch_h;   // pinned
   void* lm_batch_d;
   int lm_batch_cap;   // entries
+  // tables of the batched UNFUSED pipeline (dense levels of a batched Solve): per pyramid level a row of n entries
+  void *dense_h, *dense_d, *upd_h, *upd_d;   // DenseBatchItem / UpdItem [ODO_MAX_LEVELS][dense_cap]
+  int dense_cap;
   struct LmBatchJob* lm_batch_job;   // the batched Solve in flight on this stream, if any
 };
 
@@ -163,6 +166,10 @@ extern "C" int odo_ctx_destroy(odo_ctx* c) {
   lm_batch_job_free(c);
   if (c->lm_batch_h) (void)hipHostFree(c->lm_batch_h);
   if (c->lm_batch_d) (void)hipFree(c->lm_batch_d);
+  if (c->dense_h) (void)hipHostFree(c->dense_h);
+  if (c->upd_h) (void)hipHostFree(c->upd_h);
+  if (c->dense_d) (void)hipFree(c->dense_d);
+  if (c->upd_d) (void)hipFree(c->upd_d);
   (void)hipStreamDestroy(c->stream);
   delete c;
   return 0;
@@ -1262,8 +1269,9 @@ static void lm_fill_step_args(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* c
   StepArgs& a = *ap;
   memset(&a, 0, sizeof(a));
   a.n_levels = m->n_levels;
+  const int stop = lm_fused_stop_level(m);   // > 0: the levels below are dense and handed over to the unfused pipeline
   int grid = 1, budget = 0;
-  for (int l = 0; l < m->n_levels; l++) {
+  for (int l = stop; l < m->n_levels; l++) {
     StepLevel& L = a.lv[l];
     L.pl = m->pl[l]; L.n = m->npts[l];
     L.rows = kf_img->r[l]; L.cols = kf_img->c[l];
@@ -1278,12 +1286,14 @@ static void lm_fill_step_args(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* c
   a.lambda0 = m->lambda; a.precision = m->precision; a.robust = m->robust; a.huber_delta = m->huber_delta;
   a.trace = m->record ? m->d_trace : nullptr; a.cost_stat = m->record ? m->d_cost : nullptr; a.host_prog = m->d_prog;
   a.out = m->d_res_map; a.done_flag = m->d_done; a.token = token;
+  a.stop_level = stop;
+  a.final_state = stop > 0 ? m->d_state + 2 : nullptr;
   memcpy(a.init, m->init, sizeof(a.init));
   a.st2[0] = m->d_state; a.st2[1] = m->d_state + 1;
   a.part2[0] = m->d_partials; a.part2[1] = m->d_partials + (size_t)kLmMaxBlocks * ODO_NACC;
   int min_level = m->n_levels;
   static const int coarse_max = getenv("ODO_COARSE_MAX") ? atoi(getenv("ODO_COARSE_MAX")) : kCoarseMaxPoints;
-  while (min_level > 0 && m->npts[min_level - 1] <= coarse_max) min_level--;
+  while (min_level > stop && m->npts[min_level - 1] <= coarse_max) min_level--;
   if (!m->coarse) min_level = m->n_levels;
   a.min_level = min_level;
   int coarse_budget = 0;
@@ -1360,9 +1370,13 @@ static int lm_batch_begin(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
     odo_lm* m = lms[i];
     m->job.active = 0;
     if (lm_prepare_keyframe(m, kf_img[i], kf_dep[i])) return -1;
-    bool fused = m->fused && m->robust != 2 && m->poll;
-    for (int l = 0; l < m->n_levels; l++) if (!m->use_list[l]) fused = false;
-    batchable = batchable && fused;
+    // the fused point-list pipeline must cover the top of the pyramid; what lies below its hand-over level (dense levels) is
+    // batched too (lm_unfused_levels_batch) provided every stream hands over at the same level and those levels are all dense
+    bool ok = m->fused && m->robust != 2 && m->poll && lm_fused_eligible(m) && lm_fused_stop_level(m) == lm_fused_stop_level(lms[0]) &&
+              m->n_levels == lms[0]->n_levels;
+    for (int l = 0; l < lm_fused_stop_level(m); l++)
+      if (m->use_list[l] || kf_img[i]->r[l] != kf_img[0]->r[l] || kf_img[i]->c[l] != kf_img[0]->c[l]) ok = false;
+    batchable = batchable && ok;
   }
   if (!batchable) return 1;
   if (cx->lm_batch_cap < n) {
@@ -1419,6 +1433,97 @@ static bool lm_batch_matches(const odo_ctx* cx, int n, odo_lm* const* lms, const
   return true;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The unfused pipeline for several streams in the SAME launches: levels l_hi .. 0 (all dense) of the optimisers lms[0 .. nc),
+// each on its own state m->ust with its own progress words h_prog[m->upo ...]. Per LM iteration ONE evaluation launch
+// (lm_dense_eval_batch_kernel, blockIdx.y = stream) and ONE update launch (lm_update_batch_kernel, blockIdx.x = stream): every
+// stream's blocks do exactly what its own launches would do, so the results are bit-identical to lm_unfused_levels stream by
+// stream. A level is issued until EVERY stream's loop has stopped on it (a stopped stream's blocks return at once).
+// ---------------------------------------------------------------------------------------------------------------
+static int lm_unfused_levels_batch(int nc, odo_lm* const* lms, const odo_pyr* const* kf_img, const odo_pyr* const* kf_dep,
+                                   const odo_pyr* const* cur_img, int l_hi, int* launches_io, std::vector<std::vector<double>>& bytes,
+                                   void (*idle)(void*), void* idle_arg) {
+  odo_ctx* cx = lms[0]->ctx;
+  hipStream_t s = cx->stream;
+  if (cx->dense_cap < nc) {
+    if (cx->dense_h) {
+      HIP_OK(hipStreamSynchronize(s));
+      (void)hipHostFree(cx->dense_h); (void)hipHostFree(cx->upd_h); (void)hipFree(cx->dense_d); (void)hipFree(cx->upd_d);
+    }
+    cx->dense_h = cx->dense_d = cx->upd_h = cx->upd_d = nullptr; cx->dense_cap = 0;
+    HIP_OK(hipHostMalloc(&cx->dense_h, sizeof(DenseBatchItem) * ODO_MAX_LEVELS * (size_t)nc, hipHostMallocDefault));
+    HIP_OK(hipHostMalloc(&cx->upd_h, sizeof(UpdItem) * ODO_MAX_LEVELS * (size_t)nc, hipHostMallocDefault));
+    HIP_OK(hipMalloc(&cx->dense_d, sizeof(DenseBatchItem) * ODO_MAX_LEVELS * (size_t)nc));
+    HIP_OK(hipMalloc(&cx->upd_d, sizeof(UpdItem) * ODO_MAX_LEVELS * (size_t)nc));
+    cx->dense_cap = nc;
+  }
+  const int cap = cx->dense_cap;
+  for (int i = 0; i < nc; i++)
+    for (int k = 0; k < 16; k++) lms[i]->h_prog[lms[i]->upo + k] = 0;   // nothing of the unfused pipeline is draining (see lm_unfused_levels)
+  bool poll = true;
+  int seq = 0;
+  const int run_ahead = lms[0]->run_ahead;
+  for (int l = l_hi; l >= 0; l--) {  // ref: src/lm_optimizer.cpp:92
+    // one table row per level: a row is rewritten only by the next Solve, long after the launches that read it
+    DenseBatchItem* dh = (DenseBatchItem*)cx->dense_h + (size_t)l * cap;
+    DenseBatchItem* dd = (DenseBatchItem*)cx->dense_d + (size_t)l * cap;
+    UpdItem* uh = (UpdItem*)cx->upd_h + (size_t)l * cap;
+    UpdItem* ud = (UpdItem*)cx->upd_d + (size_t)l * cap;
+    int max_nblk = 1, max_it = 0;
+    for (int i = 0; i < nc; i++) {
+      odo_lm* m = lms[i];
+      LevelView v;
+      v.I1 = kf_img[i]->dev + kf_img[i]->off[l];
+      v.I2 = cur_img[i]->dev + cur_img[i]->off[l];
+      v.D1 = kf_dep[i]->dev + kf_dep[i]->off[l];
+      v.rows = kf_img[i]->r[l]; v.cols = kf_img[i]->c[l];
+      const DenseLevel L = lm_dense_level(v, lm_level_k(m, l), m->max_iters[l]);
+      memset(&dh[i], 0, sizeof(dh[i]));
+      dh[i].L = L; dh[i].st = m->ust; dh[i].scale_sqr = m->d_scale; dh[i].partials = m->d_partials;
+      dh[i].expect_level = l; dh[i].robust = m->robust; dh[i].huber_delta = m->huber_delta;
+      memset(&uh[i], 0, sizeof(uh[i]));
+      uh[i].st = m->ust; uh[i].partials = m->d_partials; uh[i].nblk = L.nblk; uh[i].expect_level = l; uh[i].precision = m->precision;
+      uh[i].max_iters = m->max_iters[l]; uh[i].trace = m->record ? m->d_trace : nullptr; uh[i].cost_stat = m->d_cost;
+      uh[i].host_prog = m->d_prog + m->upo; uh[i].lambda0 = m->lambda; uh[i].init = m->d_init; uh[i].out = m->d_out;
+      bytes[i][l] = lm_level_bytes(m, l, v.rows, v.cols, L.nblk);
+      if (L.nblk > max_nblk) max_nblk = L.nblk;
+      if (m->max_iters[l] > max_it) max_it = m->max_iters[l];
+    }
+    HIP_OK(hipMemcpyAsync(dd, dh, sizeof(DenseBatchItem) * (size_t)nc, hipMemcpyHostToDevice, s));
+    HIP_OK(hipMemcpyAsync(ud, uh, sizeof(UpdItem) * (size_t)nc, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(lm_begin_level_batch_kernel, dim3(nc), dim3(64), 0, s, (const UpdItem*)ud);
+    for (int it = 0; it < max_it; it++) {  // ref: :117
+      if (poll) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+          bool all_stopped = true;
+          int min_prog = 1 << 30;
+          for (int i = 0; i < nc; i++) {
+            volatile int* prog = lms[i]->h_prog + lms[i]->upo;
+            if (!prog[2 + l]) all_stopped = false;
+            if (prog[0] < min_prog) min_prog = prog[0];
+          }
+          if (all_stopped) { it = max_it; break; }
+          if (seq - min_prog <= run_ahead) break;
+          if (idle) idle(idle_arg);
+          if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { poll = false; break; }  // never hang
+        }
+        if (it >= max_it) break;  // every stream's loop on this level has stopped on the device
+      }
+      seq++;
+      launch_dense_eval_batch(dd, nc, max_nblk, s, nullptr, nullptr, lms[0]->dense_plain_div);
+      hipLaunchKernelGGL(lm_update_batch_kernel, dim3(nc), dim3(kUpdThreads), 0, s, (const UpdItem*)ud, seq);
+      (*launches_io)++;
+    }
+  }
+  // affine_ = current_estimate.matrix() of every stream, then one read-back each behind the same sync
+  hipLaunchKernelGGL(lm_finalize_batch_kernel, dim3(nc), dim3(64), 0, s, (const UpdItem*)((UpdItem*)cx->upd_d));   // row of level 0
+  HIP_OK(hipGetLastError());
+  for (int i = 0; i < nc; i++) HIP_OK(hipMemcpyAsync(lms[i]->h_out, lms[i]->d_out, sizeof(float) * 42, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  return 0;
+}
+
 // idle / idle_arg: called from the wait loops, may be NULL.
 static int lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_img, const odo_pyr* const* kf_dep,
                           const odo_pyr* const* cur_img, float* out_colmajor /* n x 16 */, int* status /* n */,
@@ -1432,11 +1537,47 @@ static int lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
   odo_ctx* cx = lms[0]->ctx;
   hipStream_t s = cx->stream;
   HIP_OK(hipSetDevice(cx->device));
+  int launches = 0;
+  std::vector<std::vector<double>> bytes(n, std::vector<double>(ODO_MAX_LEVELS, 0.0));
+  int any_fail = 0;
+  // per-stream bookkeeping once m->h_out holds the stream's final result
+  auto take_result = [&](int i) {
+    odo_lm* m = lms[i];
+    m->trace_stale = 1;
+    memcpy(out_colmajor + 16 * i, m->h_out, sizeof(float) * 16);
+    m->last_evals = (int)m->h_out[17];
+    m->last_launches = launches;
+    m->last_bytes = 0.0;
+    for (int l = 0; l < ODO_MAX_LEVELS; l++) { m->iters[l] = (int)m->h_out[18 + l]; m->last_bytes += bytes[i][l] * m->iters[l]; }
+    status[i] = (m->h_out[16] != 0.0f) ? -1 : 0;
+  };
   if (!lm_batch_matches(cx, n, lms, kf_img, kf_dep, cur_img)) {
     if (cx->lm_batch_job) cx->lm_batch_job->active = 0;   // a job started on other inputs is abandoned: its launches drain
     const int rc = lm_batch_begin(n, lms, kf_img, kf_dep, cur_img);
     if (rc < 0) return -1;
-    if (rc == 1) {  // one after the other: same results, no batching
+    if (rc == 1) {
+      // No fused part to batch. Pyramids that are dense on EVERY level (no point-list level at the top) still batch: the whole
+      // Solve is the unfused pipeline, all streams in the same launches.
+      bool dense_only = n <= 64;
+      for (int i = 0; i < n && dense_only; i++) {
+        odo_lm* m = lms[i];
+        dense_only = m->fused && m->robust != 2 && m->poll && m->n_levels == lms[0]->n_levels && lm_fused_stop_level(m) == m->n_levels;
+        for (int l = 0; l < m->n_levels && dense_only; l++)
+          if (m->use_list[l] || kf_img[i]->r[l] != kf_img[0]->r[l] || kf_img[i]->c[l] != kf_img[0]->c[l]) dense_only = false;
+      }
+      if (dense_only) {
+        for (int i = 0; i < n; i++) {
+          odo_lm* m = lms[i];
+          HIP_OK(hipMemcpyAsync(m->d_init, m->init, sizeof(float) * 16, hipMemcpyHostToDevice, s));
+          hipLaunchKernelGGL(lm_begin_solve_kernel, dim3(1), dim3(64), 0, s, m->d_state, m->d_init, m->d_cost);
+          m->ust = m->d_state; m->upo = 0;
+        }
+        if (lm_unfused_levels_batch(n, lms, kf_img, kf_dep, cur_img, lms[0]->n_levels - 1, &launches, bytes, idle, idle_arg)) return -1;
+        for (int i = 0; i < n; i++) { take_result(i); if (status[i]) any_fail = 1; }
+        if (any_fail) fail("Optimize failed! ");
+        return 0;
+      }
+      // one after the other: same results, no batching (t-distribution weights, mixed list / dense structures)
       for (int i = 0; i < n; i++) { status[i] = odo_lm_solve(lms[i], kf_img[i], kf_dep[i], cur_img[i], out_colmajor + 16 * i); }
       return 0;
     }
@@ -1446,9 +1587,11 @@ static int lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
   HIP_OK(hipGetLastError());
   jb.active = 0;
   const StepArgs* h_table = (const StepArgs*)cx->lm_batch_h;
-  const int seq = jb.seq, launches = jb.launches;
+  const int seq = jb.seq;
+  launches = jb.launches;
+  for (int i = 0; i < n; i++) bytes[i] = jb.bytes[i];
+  const int stop = lm_fused_stop_level(lms[0]);   // the same for every stream of a batch
   // results: each sequence's finishing launch wrote its own host-mapped block
-  int any_fail = 0;
   for (int i = 0; i < n; i++) {
     odo_lm* m = lms[i];
     volatile int* done = m->h_done;
@@ -1468,21 +1611,38 @@ static int lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
         fa.token = jb.tokens[i]; fa.first_of_solve = (seq == 0) ? 1 : 0;
         memcpy(fa.init, m->init, sizeof(fa.init));
         hipLaunchKernelGGL(lm_fused_finalize_kernel, dim3(1), dim3(kLmBlock), 0, s, fa);
+        if (stop > 0) HIP_OK(hipMemcpyAsync(m->d_state + 2, a.st2[0], sizeof(LmState), hipMemcpyDeviceToDevice, s));   // the hand-over state
         HIP_OK(hipStreamSynchronize(s));
       }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     memcpy(m->h_out, m->h_res, sizeof(float) * 42);
-    m->trace_stale = 1;
-    float* o = out_colmajor + 16 * i;
-    memcpy(o, m->h_out, sizeof(float) * 16);
-    m->last_evals = (int)m->h_out[17];
-    m->last_launches = launches;
-    m->last_bytes = 0.0;
-    for (int l = 0; l < ODO_MAX_LEVELS; l++) { m->iters[l] = (int)m->h_out[18 + l]; m->last_bytes += jb.bytes[i][l] * m->iters[l]; }
-    status[i] = (m->h_out[16] != 0.0f) ? -1 : 0;
-    if (status[i]) { any_fail = 1; }
   }
+  if (stop > 0) {
+    // ---- hand-over: the levels below `stop` are dense. Every stream whose fused part succeeded left its state in d_state[2];
+    // the unfused pipeline carries them on together (one evaluation + one update launch per iteration for all of them).
+    std::vector<int> c;
+    for (int i = 0; i < n; i++) if (lms[i]->h_out[16] == 0.0f) c.push_back(i);
+    if (!c.empty()) {
+      const int nc = (int)c.size();
+      std::vector<odo_lm*> l2(nc);
+      std::vector<const odo_pyr*> ki(nc), kd(nc), cu(nc);
+      std::vector<std::vector<double>> b2(nc, std::vector<double>(ODO_MAX_LEVELS, 0.0));
+      for (int e = 0; e < nc; e++) {
+        const int i = c[e];
+        l2[e] = lms[i]; ki[e] = kf_img[i]; kd[e] = kf_dep[i]; cu[e] = cur_img[i];
+        lms[i]->ust = lms[i]->d_state + 2; lms[i]->upo = 16;
+      }
+      const int rc = lm_unfused_levels_batch(nc, l2.data(), ki.data(), kd.data(), cu.data(), stop - 1, &launches, b2, idle, idle_arg);
+      for (int e = 0; e < nc; e++) {
+        const int i = c[e];
+        lms[i]->ust = lms[i]->d_state; lms[i]->upo = 0;
+        for (int l = 0; l < stop; l++) bytes[i][l] = b2[e][l];
+      }
+      if (rc) return -1;
+    }
+  }
+  for (int i = 0; i < n; i++) { take_result(i); if (status[i]) any_fail = 1; }
   if (lms[0]->ev_on) {   // launch statistics of the batched Solve, kept with the first optimiser (odo_lm_event_stats_ex)
     odo_lm* m0 = lms[0];
     m0->ev_launches += launches;

@@ -620,6 +620,77 @@ extern "C" int odo_lm_time_eval(odo_lm* m, const odo_pyr* kf_img, const odo_pyr*
   return lm_time_eval(m, kf_img, kf_dep, cur_img, level, T_colmajor, reps, mean_us, min_us, algorithmic_bytes, n_points);
 }
 
+// The same for n streams in ONE launch (lm_dense_eval_batch_kernel): `level` must be dense for every optimiser. Times `reps`
+// event-bracketed batched launches; algorithmic_bytes is the total over the streams (12 B per interior pixel each).
+extern "C" int odo_lm_time_eval_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_img, const odo_pyr* const* kf_dep,
+                                      const odo_pyr* const* cur_img, int level, const float T_colmajor[16], int reps,
+                                      float* mean_us, float* min_us, double* algorithmic_bytes, int* n_points_total) {
+  if (n < 1 || n > 64 || !lms || !kf_img || !kf_dep || !cur_img || !T_colmajor || reps < 1) return fail("odo_lm_time_eval_batch: bad arg");
+  for (int i = 0; i < n; i++) {
+    if (!lms[i] || lms[i]->ctx != lms[0]->ctx) return fail("odo_lm_time_eval_batch: the optimisers must share one context");
+    if (lm_check_pyrs(lms[i], kf_img[i], kf_dep[i], cur_img[i])) return -1;
+    if (level < 0 || level >= lms[i]->n_levels) return fail("odo_lm_time_eval_batch: bad level");
+    if (lm_prepare_keyframe(lms[i], kf_img[i], kf_dep[i])) return -1;
+    if (lms[i]->use_list[level] || lms[i]->robust == 2) return fail("odo_lm_time_eval_batch: level %d of stream %d is not a dense Huber / L2 level", level, i);
+  }
+  odo_ctx* cx = lms[0]->ctx;
+  hipStream_t s = cx->stream;
+  HIP_OK(hipSetDevice(cx->device));
+  DenseBatchItem* h = nullptr;
+  DenseBatchItem* d = nullptr;
+  HIP_OK(hipHostMalloc((void**)&h, sizeof(DenseBatchItem) * (size_t)n, hipHostMallocDefault));
+  HIP_OK(hipMalloc((void**)&d, sizeof(DenseBatchItem) * (size_t)n));
+  int max_nblk = 1;
+  double bytes = 0.0;
+  for (int i = 0; i < n; i++) {
+    odo_lm* m = lms[i];
+    LevelView v;
+    v.I1 = kf_img[i]->dev + kf_img[i]->off[level];
+    v.I2 = cur_img[i]->dev + cur_img[i]->off[level];
+    v.D1 = kf_dep[i]->dev + kf_dep[i]->off[level];
+    v.rows = kf_img[i]->r[level]; v.cols = kf_img[i]->c[level];
+    const DenseLevel L = lm_dense_level(v, lm_level_k(m, level), 0);
+    memset(&h[i], 0, sizeof(h[i]));
+    h[i].L = L; h[i].st = m->d_state; h[i].scale_sqr = m->d_scale; h[i].partials = m->d_partials;
+    h[i].expect_level = level; h[i].robust = m->robust; h[i].huber_delta = m->huber_delta;
+    if (L.nblk > max_nblk) max_nblk = L.nblk;
+    bytes += lm_level_bytes(m, level, v.rows, v.cols, L.nblk);
+    HIP_OK(hipMemcpyAsync(m->d_init, T_colmajor, sizeof(float) * 16, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(lm_force_state_kernel, dim3(1), dim3(64), 0, s, m->d_state, m->d_init, level);
+  }
+  HIP_OK(hipMemcpyAsync(d, h, sizeof(DenseBatchItem) * (size_t)n, hipMemcpyHostToDevice, s));
+  std::vector<hipEvent_t> ev(2 * (size_t)reps);
+  for (auto& e : ev) HIP_OK(hipEventCreate(&e));
+  for (int w = 0; w < 3; w++) launch_dense_eval_batch(d, n, max_nblk, s, nullptr, nullptr, lms[0]->dense_plain_div);
+  for (int i = 0; i < reps; i++) launch_dense_eval_batch(d, n, max_nblk, s, ev[2 * i], ev[2 * i + 1], lms[0]->dense_plain_div);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipStreamSynchronize(s));
+  double sum = 0.0, mn = 1e30;
+  for (int i = 0; i < reps; i++) {
+    float ms = 0.0f;
+    HIP_OK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+    sum += ms; if (ms < mn) mn = ms;
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  // residual counts: fold each stream's partial rows (column 28)
+  int npts = 0;
+  double* d_acc = nullptr;
+  HIP_OK(hipMalloc((void**)&d_acc, sizeof(double) * ODO_NACC));
+  for (int i = 0; i < n; i++) {
+    hipLaunchKernelGGL(lm_sum_partials_kernel, dim3(1), dim3(256), 0, s, lms[i]->d_partials, h[i].L.nblk, d_acc);
+    double acc[ODO_NACC];
+    HIP_OK(hipMemcpyAsync(acc, d_acc, sizeof(acc), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    npts += (int)acc[28];
+  }
+  (void)hipFree(d_acc); (void)hipFree(d); (void)hipHostFree(h);
+  if (mean_us) *mean_us = (float)(sum / reps * 1000.0);
+  if (min_us) *min_us = (float)(mn * 1000.0);
+  if (algorithmic_bytes) *algorithmic_bytes = bytes;
+  if (n_points_total) *n_points_total = npts;
+  return 0;
+}
+
 extern "C" int odo_tracker_time_residual(odo_tracker* t, int level, int reps, float* mean_us, float* min_us,
                                          double* algorithmic_bytes, int* n_points) {
   if (!t || reps < 1 || level < 0 || level >= t->p.levels) return fail("odo_tracker_time_residual: bad arg");

@@ -176,3 +176,60 @@ def test_kitti_size_dense_solve_hands_over_at_level_0(api, O, kitti_seq, robust)
                    (b["level"], b["iter"], b["n_res"], b["accepted"], b["stop"])
         assert se3_log_norm(ref["pose"], T) < 1e-5
         lm.close()
+
+
+# ---- several dense streams in the same launches (odo_lm_solve_batch over dense pyramids) -------------------------------------
+
+@pytest.mark.parametrize("handover", [True, False])
+def test_batched_dense_1080p_solves_equal_separate_solves(api, scene, handover, monkeypatch):
+    """Three 1080p dense Solves (frame 0 -> 1, 1 -> 2, and 0 -> 2: different images, different iteration counts) in ONE batched
+    call — fused point-list levels in the batched step launches, the dense levels below the hand-over in the batched
+    evaluation + update launches — against the same three Solves one after the other: poses, evaluation counts and the per-
+    level iteration counts bit for bit. handover = False (ODO_FUSE_DENSE_MAX=0): every level dense, the whole Solve unfused."""
+    if not handover:
+        monkeypatch.setenv("ODO_FUSE_DENSE_MAX", "0")
+    pairs = [(0, 1), (1, 2), (0, 2)]
+    pyrs = [_pyrs(api, scene, a, b) for a, b in pairs]
+    want = []
+    for p0, d0, p1 in pyrs:
+        lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 1, 28.0, intrinsics=K)
+        T = lm.Solve(p0, d0, p1)
+        want.append((T, lm.launch_stats()[0], lm.report()[0]))
+        lm.close()
+    lms = [api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 1, 28.0, intrinsics=K) for _ in pairs]
+    poses, status = api.solve_batch(lms, [p[0] for p in pyrs], [p[1] for p in pyrs], [p[2] for p in pyrs])
+    assert status == [0, 0, 0]
+    assert len({w[1] for w in want}) > 1          # the streams really differ in length
+    for i, lm in enumerate(lms):
+        assert np.array_equal(poses[i], want[i][0]), f"stream {i}"
+        assert lm.launch_stats()[0] == want[i][1] and lm.report()[0] == want[i][2]
+    # again on the same optimisers after a Reset (tables, progress words and states are reused)
+    for lm in lms:
+        lm.Reset(np.eye(4), 0.01)
+    poses2, _ = api.solve_batch(lms, [p[0] for p in pyrs], [p[1] for p in pyrs], [p[2] for p in pyrs])
+    assert np.array_equal(poses2, poses)
+
+
+def test_batched_dense_failing_stream_fails_alone(api, scene):
+    """A stream whose keyframe has no depth at all fails (pseudo-identity, ref: src/lm_optimizer.cpp:48-52) without disturbing the
+    dense streams batched with it."""
+    p0, d0, p1 = _pyrs(api, scene, 0, 1)
+    dz = api.DepthPyramid(4, np.zeros_like(scene["inv"][0]), False)
+    ref = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 1, 28.0, intrinsics=K)
+    want = ref.Solve(p0, d0, p1)
+    lms = [api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 1, 28.0, intrinsics=K) for _ in range(2)]
+    poses, status = api.solve_batch(lms, [p0, p0], [d0, dz], [p1, p1])
+    assert status[0] == 0 and np.array_equal(poses[0], want)
+    assert status[1] == -1 and poses[1][3, 3] == 0 and poses[1][0, 0] == 1
+
+
+@pytest.mark.parametrize("level", [0, 1])
+def test_batched_dense_evaluation_counts_every_stream(api, scene, level):
+    """odo_lm_time_eval_batch (bench.py's batched roofline leg): S streams in one launch produce S times the residuals."""
+    p0, d0, p1 = _pyrs(api, scene, 0, 1)
+    T = (np.linalg.inv(scene["poses"][1]) @ scene["poses"][0]).astype(np.float32)
+    lms = [api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 1, 28.0, intrinsics=K) for _ in range(3)]
+    one = lms[0].time_eval(p0, d0, p1, level, T, reps=3)
+    t = api.time_eval_batch(lms, [p0] * 3, [d0] * 3, [p1] * 3, level, T, reps=3)
+    assert t["n_points"] == 3 * one["n_points"] and abs(t["bytes"] - 3 * one["bytes"]) < 1.0
+    assert t["mean_us"] > 0

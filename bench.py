@@ -196,6 +196,60 @@ def dense_1080p_leg(api, synth, n_frames=5, passes=3):
                      O.image_pyramid(imgs[1], 4, False, flat=True), 1080, 1920, O.lm_params(robust=1, K=KD))
     cpu_s = time.perf_counter() - tc
     dmax = float(np.abs(rec[0][0].astype(np.float64) - ref["pose"]).max())
+    # ---- S streams in flight (odo_lm_solve_batch over dense pyramids): every evaluation / update launch carries all S of them
+    # (blockIdx = stream). One 1080p level is too small to keep the chip busy for long (launch ramp + tail are a large part of
+    # 18 us); S levels side by side move S times the bytes in one ramp. Per-level roofline of the batched evaluation kernel and the
+    # tracked-stream rate (S independent streams, the same frames in rotated order, the test_optimizer.cpp loop per stream).
+    batched = []
+    for S in (2, 4, 8):
+        lms = [api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 1, 28.0, ctx=ctx, intrinsics=K)
+               for _ in range(S)]
+        pi = [[api.ImagePyramid(4, None, False, ctx=ctx, device_ptr=d_img[0], shape=(1080, 1920)) for _ in range(2)] for _ in range(S)]
+        pd = [[api.DepthPyramid(4, None, False, ctx=ctx, device_ptr=d_inv[0], shape=(1080, 1920)) for _ in range(2)] for _ in range(S)]
+        nf = n_frames - 1
+
+        def stream_pass(check=None):
+            for j in range(S):
+                pi[j][0].rebuild_dev(d_img[j % n_frames], False)
+                pd[j][0].rebuild_dev(d_inv[j % n_frames], False)
+            for k in range(1, nf + 1):
+                cur, prev = k % 2, (k - 1) % 2
+                for j in range(S):
+                    pi[j][cur].rebuild_dev(d_img[(j + k) % n_frames], False)
+                    pd[j][cur].rebuild_dev(d_inv[(j + k) % n_frames], False)
+                poses, st = api.solve_batch(lms, [pi[j][prev] for j in range(S)], [pd[j][prev] for j in range(S)],
+                                            [pi[j][cur] for j in range(S)])
+                for m in lms:
+                    m.Reset(eye, 0.01)
+                if check is not None:
+                    check.append(poses)
+        first = []
+        stream_pass(first)   # warm-up; stream 0 of this pass is the single stream's first pass
+        same0 = all(np.array_equal(first[k][0], rec[k][0]) for k in range(nf))
+        ctx.synchronize()
+        tb0 = time.perf_counter()
+        for _ in range(passes):
+            stream_pass()
+        ctx.synchronize()
+        dtb = time.perf_counter() - tb0
+        per_level = []
+        kk = n_frames - 1
+        for lvl in range(4):
+            try:
+                tt = api.time_eval_batch(lms, [pi[j][(kk - 1) % 2] for j in range(S)], [pd[j][(kk - 1) % 2] for j in range(S)],
+                                         [pi[j][kk % 2] for j in range(S)], lvl, T, reps=30)
+            except Exception:   # noqa: BLE001 — a level that runs on its point list (fused pipeline), not the dense scan
+                continue
+            ach = tt["bytes"] / (tt["mean_us"] * 1e-6) / 1e9
+            per_level.append(dict(level=lvl, residuals=tt["n_points"], algorithmic_bytes=int(tt["bytes"]), launch_us=round(tt["mean_us"], 2),
+                                  launch_min_us=round(tt["min_us"], 2), achieved=round(ach, 1), frac=round(ach / HBM_PEAK_GBS, 4)))
+        batched.append(dict(streams=S, frames_per_s=round(S * passes * nf / dtb, 1), ms_per_lock_step=round(dtb / (passes * nf) * 1e3, 3),
+                            stream0_bit_identical_to_single_stream=bool(same0), per_level=per_level))
+        for m in lms:
+            m.close()
+        for row in pi + pd:
+            for o in row:
+                o.close()
     lm.close()
     for o in pimg + pdep:
         o.close()
@@ -210,7 +264,7 @@ def dense_1080p_leg(api, synth, n_frames=5, passes=3):
                 kernel="lm_dense_eval_kernel", bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s",
                 residuals=l0["residuals"], algorithmic_bytes=l0["algorithmic_bytes"], launch_us=l0["launch_us"],
                 launch_min_us=l0["launch_min_us"], achieved=l0["achieved"], frac=l0["frac"], per_level=levels,
-                cpu_oracle_solve_ms=round(cpu_s * 1e3, 1), pose_max_abs_delta_vs_oracle=dmax,
+                cpu_oracle_solve_ms=round(cpu_s * 1e3, 1), pose_max_abs_delta_vs_oracle=dmax, batched=batched,
                 note="VALU-issue bound, not HBM bound: the parity arithmetic costs ~270 VALU instructions per pixel "
                      "(28 fp64 FMAs, 23 fp32<->fp64 conversions, 3 + 1 reciprocals); see DESIGN.md section 5.1")
 
@@ -514,7 +568,8 @@ def batched_sequences_leg(api, seqs, counts=(1, 2, 4, 8), passes=3):
                          us_per_lock_step=round(dt / (passes * (n_frames - 1)) * 1e6, 1),
                          lm_evals_per_frame_mean=round(float(ev.mean()), 1),
                          lm_evals_per_lock_step=round(float(ev.max(axis=1).mean()), 1),
-                         solve_us=round(tm["solve_us"], 1), sequence0_bit_identical_to_single_tracker=same,
+                         solve_us=round(tm["solve_us"], 1), head_us=round(tm["head_us"], 1), depth_wait_us=round(tm["depth_wait_us"], 1),
+                         call_us=round(tm["step_us"], 1), sequence0_bit_identical_to_single_tracker=same,
                          every_pass_repeats_the_first_bit_for_bit=repeat))
     return dict(single_tracker_frames_per_s=round(single_fps, 1), frames_per_sequence=n_frames - 1, passes=passes, batched=rows,
                 note="a lock step costs the slowest sequence's evaluations (lm_evals_per_lock_step) plus the throughput-bound "

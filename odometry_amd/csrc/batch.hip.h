@@ -160,6 +160,8 @@ struct odo_tracker_batch {
   std::atomic<int> w_quit;
   std::vector<int> ids;    // slots of the lock step in flight (pose LM)
   bool with_lists;
+  hipEvent_t ev_a;         // a point on stream A (the rebuild of next_img on stream C goes behind an abandoned early Solve)
+  int dead;                // 1: a wait timed out with work in flight — every later call fails fast
   double tm_frame_us, tm_head_us, tm_solve_us, tm_depth_wait_us; long tm_frames;  // host-clock averages (diagnostics)
 };
 
@@ -196,6 +198,7 @@ extern "C" int odo_tracker_batch_destroy(odo_tracker_batch* b) {
   if (b->h_cand_npts) (void)hipHostFree(b->h_cand_npts);
   if (b->ev_cur_img) (void)hipEventDestroy(b->ev_cur_img);
   if (b->ev_next) (void)hipEventDestroy(b->ev_next);
+  if (b->ev_a) (void)hipEventDestroy(b->ev_a);
   odo_ctx_destroy(b->ctx_c);
   odo_ctx_destroy(b->ctx_b);
   odo_ctx_destroy(b->ctx_a);
@@ -215,7 +218,7 @@ extern "C" int odo_tracker_batch_create(int device, const odo_tracker_params* p,
   const int S = n_sequences;
   b->p = *p; b->S = S;
   b->ctx_a = b->ctx_b = b->ctx_c = nullptr; b->h_pyr = b->d_pyr = nullptr; b->h_cand_npts = b->d_cand_npts = nullptr;
-  b->ev_cur_img = b->ev_next = nullptr;
+  b->ev_cur_img = b->ev_next = b->ev_a = nullptr; b->dead = 0;
   for (BatchChain* c : {&b->late, &b->ahead}) { c->h_tab = c->d_tab = nullptr; c->stage = 0; c->err = 0; c->img_ready = nullptr; c->complete.store(0); }
   b->w_ring[0] = b->w_ring[1] = nullptr; b->w_posted.store(0); b->w_done.store(0); b->w_quit.store(0);
   b->tm_frame_us = b->tm_head_us = b->tm_solve_us = b->tm_depth_wait_us = 0.0; b->tm_frames = 0;
@@ -266,6 +269,7 @@ extern "C" int odo_tracker_batch_create(int device, const odo_tracker_params* p,
   ok = ok && hipHostGetDevicePointer((void**)&b->d_cand_npts, b->h_cand_npts, 0) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&b->ev_cur_img, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&b->ev_next, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&b->ev_a, hipEventDisableTiming) == hipSuccess;
   if (ok && !getenv("ODO_LM_TRACE")) for (odo_lm* m : b->lm) m->record = 0;
   if (!ok) {
     char keep[512];
@@ -476,8 +480,10 @@ static int batch_wait_chains(odo_tracker_batch* b) {
   const auto q0 = std::chrono::steady_clock::now();
   long spins = 0;
   while (b->w_done.load(std::memory_order_acquire) < posted) {
-    if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - q0 > std::chrono::seconds(10))
+    if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - q0 > std::chrono::seconds(10)) {
+      b->dead = 1;   // the helper still owns its chains: every later call fails fast instead of refilling them under it
       return fail("    depth failed! (the depth stream's helper thread did not finish within 10 s)");
+    }
   }
   return 0;
 }
@@ -632,6 +638,7 @@ extern "C" int odo_tracker_batch_track(odo_tracker_batch* b, const float* const*
                                        float* pose_to_keyframe /* S x 16 */, float* abs_pose /* S x 16 */,
                                        int* is_new_keyframe /* S */, float* motion_mag /* S */, int* status /* S */) {
   if (!b || !left_dev || !right_dev || !status) return fail("odo_tracker_batch_track: NULL arg");
+  if (b->dead) return fail("odo_tracker_batch_track: this tracker timed out with work in flight earlier and is dead: destroy it");
   const int S = b->S;
   const odo_tracker_params& p = b->p;
   const auto f0 = std::chrono::steady_clock::now();
@@ -658,11 +665,11 @@ extern "C" int odo_tracker_batch_track(odo_tracker_batch* b, const float* const*
   if (n == 0) return 0;
   // ---- image pyramids of this step: prefetched during the last step (stream C), or built now (stream A)
   std::vector<int> build;
-  bool any_prefetched = false;
+  bool any_prefetched = false, wrong_hint = false;
   for (int i : b->ids) {
     b->frame_id[i]++;
     if (b->prefetched[i] && b->prefetched[i] == left_dev[i]) { std::swap(b->cur_img[i], b->next_img[i]); any_prefetched = true; }
-    else build.push_back(i);
+    else { build.push_back(i); if (b->prefetched[i]) wrong_hint = true; }
     b->prefetched[i] = nullptr;
   }
   if (any_prefetched) HIP_OK(hipStreamWaitEvent(sa, b->ev_next, 0));
@@ -690,6 +697,12 @@ extern "C" int odo_tracker_batch_track(odo_tracker_batch* b, const float* const*
     if (b->hint_next_right[i] && b->depth_ahead) nxt_pair.push_back(i);
   }
   if (!nxt.empty()) {
+    if (wrong_hint) {
+      // A frame other than the announced one came: the Solve started early for the announced frame is abandoned, but its
+      // launches on stream A may still be reading next_img — the rebuild on stream C goes behind them.
+      HIP_OK(hipEventRecord(b->ev_a, sa));
+      HIP_OK(hipStreamWaitEvent(sc, b->ev_a, 0));
+    }
     if (batch_build_pyramids(b, nxt, b->hint_next, b->next_img, S, sc)) return -1;
     HIP_OK(hipEventRecord(b->ev_next, sc));
     for (int i : nxt) b->prefetched[i] = b->hint_next[i];
@@ -727,8 +740,10 @@ extern "C" int odo_tracker_batch_track(odo_tracker_batch* b, const float* const*
       const auto q0 = std::chrono::steady_clock::now();
       long spins = 0;
       while (!late->complete.load(std::memory_order_acquire)) {
-        if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - q0 > std::chrono::seconds(10))
+        if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - q0 > std::chrono::seconds(10)) {
+          b->dead = 1;   // the helper still owns the chain: nothing of this tracker may be reused
           return fail("    depth failed! (the depth stream's helper thread did not finish within 10 s)");
+        }
       }
     }
     if (batch_chain_absorb(b, late)) return -1;

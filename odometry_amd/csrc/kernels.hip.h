@@ -1623,7 +1623,28 @@ __device__ __forceinline__ void depth_disparity_kernel_body(const float* __restr
   if (max_disp > 0 && x - max_disp > lo) lo = x - max_disp;
   float best = 1e+10f;  // :367
   int match = 0x7fffffff;
-  for (int rx = lo + lane; rx < x; rx += kWave) {  // :382
+#ifndef ODO_SCAN_UNROLL
+#define ODO_SCAN_UNROLL 2
+#endif
+  // :382 — lanes = consecutive candidate columns. ODO_SCAN_UNROLL candidates per lane and trip, all their taps loaded before any is
+  // used: the scan is latency bound on the right-image rows (58 % of wave cycles in s_waitcnt), so more loads in flight per wave
+  // is what moves it. Candidates are compared in ascending column order, so the strict < keeps the first minimum (:385-386).
+  int rx = lo + lane;
+  for (; rx + (ODO_SCAN_UNROLL - 1) * kWave < x; rx += ODO_SCAN_UNROLL * kWave) {
+    float Rq[ODO_SCAN_UNROLL][8];
+#pragma unroll
+    for (int u = 0; u < ODO_SCAN_UNROLL; u++) {
+      const int c = rx + u * kWave;
+      Rq[u][0] = rnn[c]; Rq[u][1] = rn[c - 1]; Rq[u][2] = rc[c + 2]; Rq[u][3] = rc[c]; Rq[u][4] = rc[c - 2];
+      Rq[u][5] = rp[c + 1]; Rq[u][6] = rp[c - 1]; Rq[u][7] = rpp[c];
+    }
+#pragma unroll
+    for (int u = 0; u < ODO_SCAN_UNROLL; u++) {
+      const float s = ssd8_tree(Lp, Rq[u]);
+      if (s < best) { best = s; match = rx + u * kWave; }
+    }
+  }
+  for (; rx < x; rx += kWave) {
     const float Rp[8] = {rnn[rx], rn[rx - 1], rc[rx + 2], rc[rx], rc[rx - 2], rp[rx + 1], rp[rx - 1], rpp[rx]};
     const float s = ssd8_tree(Lp, Rp);
     if (s < best) { best = s; match = rx; }  // :385-386

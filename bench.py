@@ -552,8 +552,8 @@ def batched_sequences_leg(api, seqs, counts=(1, 2, 4, 8), passes=3):
         ev = np.array(evals)
         roof = None
         if es["step_sampled"] > 0:
-            step_us = es["step_us"] / es["step_sampled"]
-            coarse_us = es["coarse_us"] / max(es["coarse_sampled"], 1)
+            step_us = es["step_period_us"] / es["step_periods"] if es["step_periods"] > 0 else es["step_us"] / es["step_sampled"]
+            coarse_us = es["coarse_period_us"] / es["coarse_periods"] if es["coarse_periods"] > 0 else es["coarse_us"] / max(es["coarse_sampled"], 1)
             n_step = max(es["launches"] - es["coarse_launches"], 1)
             total_us = step_us * n_step + coarse_us * es["coarse_launches"]
             ach = es["bytes"] / (total_us * 1e-6) / 1e9
@@ -562,8 +562,9 @@ def batched_sequences_leg(api, seqs, counts=(1, 2, 4, 8), passes=3):
                         step_launch_us=round(step_us, 2), coarse_launch_us=round(coarse_us, 1),
                         step_launches_per_lock_step=round(n_step / (passes * (n_frames - 1)), 2),
                         algorithmic_bytes_per_lock_step=round(es["bytes"] / (passes * (n_frames - 1)), 1),
-                        measured="execution spans of every 8th batched launch of the timed passes (%d step + %d coarse sampled)"
-                                 % (es["step_sampled"], es["coarse_sampled"]))
+                        step_exec_span_us=round(es["step_us"] / es["step_sampled"], 2),
+                        measured="start-to-start periods of every 8th batched launch and its successor in the timed passes (%d step + "
+                                 "%d coarse pairs)" % (es["step_periods"], es["coarse_periods"]))
         rows.append(dict(sequences=S, frames_per_s=round(S * passes * (n_frames - 1) / dt, 1), roofline=roof,
                          us_per_lock_step=round(dt / (passes * (n_frames - 1)) * 1e6, 1),
                          lm_evals_per_frame_mean=round(float(ev.mean()), 1),
@@ -1033,13 +1034,18 @@ def main():
             # from the TIMED run itself: sampled launches record their own execution span; counts are exact
             n_frames_ev = args.steps
             step_launches = max(ev_timed["launches"] - ev_timed["coarse_launches"], 1)
-            step_us = ev_timed["step_us"] / ev_timed["step_sampled"]
-            coarse_us = ev_timed["coarse_us"] / max(ev_timed["coarse_sampled"], 1)
+            # launch_us = start-to-start PERIOD of consecutive launches (execution + the dependent-kernel boundary: what one
+            # evaluation costs the chain; rocprofv3's per-dispatch duration lies between it and the bare execution span)
+            step_span = ev_timed["step_us"] / ev_timed["step_sampled"]
+            coarse_span = ev_timed["coarse_us"] / max(ev_timed["coarse_sampled"], 1)
+            step_us = ev_timed["step_period_us"] / ev_timed["step_periods"] if ev_timed["step_periods"] > 0 else step_span
+            coarse_us = ev_timed["coarse_period_us"] / ev_timed["coarse_periods"] if ev_timed["coarse_periods"] > 0 else coarse_span
             total_us = step_us * step_launches + coarse_us * ev_timed["coarse_launches"]
             ev = dict(bytes=ev_timed["bytes"], active_launches=ev_timed["evaluations"], coarse_launches=ev_timed["coarse_launches"])
-            how = (f"execution spans (device wall clock at the entry of the first block and the exit of the last) of every "
-                   f"{args.event_sample}th LM launch of the timed run itself ({ev_timed['step_sampled']} step + "
-                   f"{ev_timed['coarse_sampled']} coarse launches sampled of {ev_timed['launches']}); launch counts exact")
+            how = (f"device wall clock inside the kernels of every {args.event_sample}th LM launch AND its successor in the timed run "
+                   f"itself: launch_us = start-to-start period of the pair ({ev_timed['step_periods']} step + {ev_timed['coarse_periods']} "
+                   f"coarse pairs), exec_span_us = entry of the first block to exit of the last ({ev_timed['step_sampled']} + "
+                   f"{ev_timed['coarse_sampled']} launches of {ev_timed['launches']}); launch counts exact")
         else:
             # --sequences / --event-sample 0: a second pass over the same frames with every launch sampled
             n_frames_ev = min(args.steps, 100)
@@ -1052,8 +1058,8 @@ def main():
             e1 = trk.event_stats()
             trk.event_timing(0)
             step_launches = max(e1["launches"] - e1["coarse_launches"], 1)
-            step_us = (e1["total_us"] - e1["coarse_us"]) / step_launches
-            coarse_us = e1["coarse_us"] / max(e1["coarse_launches"], 1)
+            step_us = step_span = (e1["total_us"] - e1["coarse_us"]) / step_launches
+            coarse_us = coarse_span = e1["coarse_us"] / max(e1["coarse_launches"], 1)
             total_us = e1["total_us"]
             ev = dict(bytes=e1["bytes"], active_launches=e1["active_launches"], coarse_launches=e1["coarse_launches"])
             how = "a separate pass over the same frames with the execution span of every LM launch recorded (not the timed run)"
@@ -1067,10 +1073,11 @@ def main():
                     kernel_us_per_frame=round(kernel_us_per_frame, 2),
                     kernel_time_fits_in_step=bool(kernel_us_per_frame <= elapsed / args.steps * 1e6) if ev_timed is not None else None,
                     lm_step_kernel=dict(launches_per_frame=round(step_launches / n_frames_ev, 2), launch_us=round(step_us, 3),
+                                        exec_span_us=round(step_span, 3),
                                         algorithmic_bytes_per_launch=round((ev["bytes"]) / max(ev["active_launches"], 1), 1),
                                         achieved=round(ev["bytes"] / max(ev["active_launches"], 1) / (step_us * 1e-6) / 1e9, 2) if step_us > 0 else None),
                     lm_coarse_kernel=dict(launches_per_frame=round(ev["coarse_launches"] / n_frames_ev, 2),
-                                          launch_us=round(coarse_us, 2)),
+                                          launch_us=round(coarse_us, 2), exec_span_us=round(coarse_span, 2)),
                     note="single 1241x376 frame: the working set is cache resident and every evaluation is a serial chain "
                          "(solve, exp, 13-30k points); see roofline_dense_1080p for the HBM-bound shape")
         evals = [ev["active_launches"] / n_frames_ev]

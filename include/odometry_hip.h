@@ -173,8 +173,10 @@ int odo_lm_event_stats(odo_lm* lm, double* total_us, long* launches, long* activ
 /* Share of the above spent in the single-workgroup coarse-level kernel (one launch per Solve). */
 int odo_lm_event_stats2(odo_lm* lm, double* coarse_us, long* coarse_launches);
 /* out[0] sampled step-kernel time (us), [1] sampled step launches, [2] sampled coarse-kernel time (us), [3] sampled coarse
- * launches, [4] all launches issued, [5] all coarse launches, [6] evaluations, [7] algorithmic bytes. */
-int odo_lm_event_stats_ex(odo_lm* lm, double out[8]);
+ * launches, [4] all launches issued, [5] all coarse launches, [6] evaluations, [7] algorithmic bytes, [8] / [9] summed
+ * start-to-start periods of consecutive sampled step launches (us) and their number — execution plus the dependent-kernel
+ * boundary: what an evaluation costs the serial chain —, [10] / [11] the same from a coarse launch to the step launch behind it. */
+int odo_lm_event_stats_ex(odo_lm* lm, double out[12]);
 /* Sampling of the current image at the warped point. ODO_SAMPLE_FLOOR (default, parity mode) is what the reference does:
  * I2 at floor(u), floor(v), central-difference gradient at that pixel (ref: src/lm_optimizer.cpp:208-217,
  * include/image_processing_global.h:62-69). ODO_SAMPLE_BILINEAR is a NON-PARITY option (BASELINE.json north_star: "bilinear

@@ -575,10 +575,11 @@ class Tracker:
     def event_stats_ex(self):
         """Sampled event timing (event_timing(N)): mean launch durations of the two LM kernels + launch / evaluation counts."""
         lm = C.c_void_p(self.lib.odo_tracker_lm(self.h))
-        o = (C.c_double * 8)()
+        o = (C.c_double * 12)()
         L.check(self.lib.odo_lm_event_stats_ex(lm, o), "odo_lm_event_stats_ex")
         return dict(step_us=o[0], step_sampled=int(o[1]), coarse_us=o[2], coarse_sampled=int(o[3]), launches=int(o[4]),
-                    coarse_launches=int(o[5]), evaluations=int(o[6]), bytes=o[7])
+                    coarse_launches=int(o[5]), evaluations=int(o[6]), bytes=o[7], step_period_us=o[8], step_periods=int(o[9]),
+                    coarse_period_us=o[10], coarse_periods=int(o[11]))
 
     def timing(self):
         out = (C.c_double * 4)()
@@ -706,10 +707,11 @@ class TrackerBatch:
         L.check(self.lib.odo_lm_event_timing(C.c_void_p(self.lib.odo_tracker_batch_lm(self.h, 0)), int(on)), "odo_lm_event_timing")
 
     def event_stats_ex(self):
-        o = (C.c_double * 8)()
+        o = (C.c_double * 12)()
         L.check(self.lib.odo_lm_event_stats_ex(C.c_void_p(self.lib.odo_tracker_batch_lm(self.h, 0)), o), "odo_lm_event_stats_ex")
         return dict(step_us=o[0], step_sampled=int(o[1]), coarse_us=o[2], coarse_sampled=int(o[3]), launches=int(o[4]),
-                    coarse_launches=int(o[5]), evaluations=int(o[6]), bytes=o[7])
+                    coarse_launches=int(o[5]), evaluations=int(o[6]), bytes=o[7], step_period_us=o[8], step_periods=int(o[9]),
+                    coarse_period_us=o[10], coarse_periods=int(o[11]))
 
     def outputs(self, seq, rows, cols):
         v, dsp, dep = C.c_void_p(), C.c_void_p(), C.c_void_p()

@@ -506,9 +506,9 @@ __global__ void __launch_bounds__(kBlock, kWaves) lm_dense_eval_kernel(DenseLeve
                                                                 const float* __restrict__ scale_sqr_ptr,
                                                                 double* __restrict__ partials) {
   if (!(st->active != 0 && st->level == expect_level)) return;
-  float T[16];
+  float T[16];   // the pose is wave-uniform: pinned to scalar registers (16 vector registers less in a kernel held to 128 of them)
 #pragma unroll
-  for (int i = 0; i < 16; i++) T[i] = st->T[i];
+  for (int i = 0; i < 16; i++) T[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(st->T[i])));
   const float scale_sqr = (robust == 2) ? *scale_sqr_ptr : 1.0f;
   double acc[ODO_NACC];
 #pragma unroll
@@ -523,6 +523,14 @@ __global__ void __launch_bounds__(kBlock, kWaves) lm_dense_eval_kernel(DenseLeve
 // One 1080p level is too small to fill the chip for long (2 M pixels: ~18 us, of which launch ramp and tail are a large part);
 // S levels side by side are S times the bytes in one ramp. grid = (largest nblk of any stream, rounded up to a multiple of 8 so
 // that blockIdx.x % 8 stays the XCD label of every row of the grid; S).
+__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffu)), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return (const float*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double uniform_f64(double d) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(d)), __builtin_amdgcn_readfirstlane(__double2loint(d)));
+}
 template <int kBlock, int kFlags, int kWaves>
 __global__ void __launch_bounds__(kBlock, kWaves) lm_dense_eval_batch_kernel(const DenseBatchItem* __restrict__ items) {
   const DenseBatchItem& it = items[blockIdx.y];
@@ -530,13 +538,27 @@ __global__ void __launch_bounds__(kBlock, kWaves) lm_dense_eval_batch_kernel(con
   if (!(it.st->active != 0 && it.st->level == it.expect_level)) return;
   float T[16];
 #pragma unroll
-  for (int i = 0; i < 16; i++) T[i] = it.st->T[i];
+  for (int i = 0; i < 16; i++) T[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(it.st->T[i])));
   const float scale_sqr = (it.robust == 2) ? *it.scale_sqr : 1.0f;
   double acc[ODO_NACC];
 #pragma unroll
   for (int q = 0; q < ODO_NACC; q++) acc[q] = 0.0;
-  const DenseLevel L = it.L;   // wave-uniform: scalar loads
-  dense_eval_block_pipelined<kBlock, kFlags>(L, blockIdx.x, T, it.robust, it.huber_delta, scale_sqr, acc);
+  // The level description is wave-uniform but comes from memory: pin every field to scalar registers (in the single-stream kernel it
+  // is a kernel argument and lives there anyway; left to itself the compiler keeps part of it in vector registers here — 128 VGPRs
+  // + 20 B of scratch per lane against 116 and none).
+  DenseLevel L;
+  L.I1 = uniform_ptr(it.L.I1); L.I2 = uniform_ptr(it.L.I2); L.D1 = uniform_ptr(it.L.D1);
+  L.rows = __builtin_amdgcn_readfirstlane(it.L.rows); L.cols = __builtin_amdgcn_readfirstlane(it.L.cols);
+  L.k.fl = uniform_f64(it.L.k.fl);
+  L.k.cx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(it.L.k.cx)));
+  L.k.cy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(it.L.k.cy)));
+  L.k.bilinear = __builtin_amdgcn_readfirstlane(it.L.k.bilinear);
+  L.nblk = __builtin_amdgcn_readfirstlane(it.L.nblk); L.n_strips = __builtin_amdgcn_readfirstlane(it.L.n_strips);
+  L.n_rg = __builtin_amdgcn_readfirstlane(it.L.n_rg); L.fast_ok = __builtin_amdgcn_readfirstlane(it.L.fast_ok);
+  L.max_iters = __builtin_amdgcn_readfirstlane(it.L.max_iters);
+  const int robust = __builtin_amdgcn_readfirstlane(it.robust);
+  const float huber_delta = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(it.huber_delta)));
+  dense_eval_block_pipelined<kBlock, kFlags>(L, blockIdx.x, T, robust, huber_delta, scale_sqr, acc);
   block_reduce_acc_w<kBlock>(acc, it.partials + (size_t)blockIdx.x * ODO_NACC);
 }
 

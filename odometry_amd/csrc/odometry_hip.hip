@@ -551,7 +551,10 @@ struct odo_lm {
   // per sampled launch, collected (stream sync + one copy) when the statistics are read
   unsigned long long* d_span;
   int span_used;
-  std::vector<unsigned char>* span_kind;             // per assigned slot: 1 = coarse launch, 0 = step launch
+  struct SpanTag { unsigned char coarse; long solve; int idx; };
+  std::vector<SpanTag>* span_kind;                   // per assigned slot: which launch (coarse / step, Solve number, launch index)
+  double ev_period_us, ev_cperiod_us;                // start-to-start distance of two CONSECUTIVE sampled launches (step / coarse first)
+  long ev_period_n, ev_cperiod_n;
   int last_coarse;  // 1 if the last Solve started with the single-workgroup coarse kernel
   int last_coarse_batch;  // (lms[0] of a batched Solve) 1 if the batch began with a coarse launch
   int trace_stale;
@@ -911,8 +914,11 @@ static inline double lm_level_bytes(const odo_lm* m, int level, int rows, int co
 // Launch timing: is launch `i` of the Solve in flight one of the sampled ones? If so it gets the next free span slot.
 constexpr int kSpanSlots = 16384;
 static inline unsigned long long* lm_span_slot(odo_lm* m, int i, bool coarse) {
-  if (!(m->ev_on > 0 && m->d_span && ((i + m->ev_phase) % m->ev_on) == 0) || m->span_used >= kSpanSlots) return nullptr;
-  m->span_kind->push_back(coarse ? 1 : 0);
+  // launch i and its successor i + 1 are sampled together: the distance of their starts is the launch PERIOD — execution plus
+  // the dependent-kernel boundary, what an evaluation costs the serial chain — next to the execution span of each
+  const bool hit = m->ev_on > 0 && m->d_span && (((i + m->ev_phase) % m->ev_on) == 0 || (i > 0 && ((i - 1 + m->ev_phase) % m->ev_on) == 0));
+  if (!hit || m->span_used >= kSpanSlots) return nullptr;
+  m->span_kind->push_back(odo_lm::SpanTag{(unsigned char)(coarse ? 1 : 0), m->ev_solves, i});
   return m->d_span + 2 * (size_t)(m->span_used++);
 }
 // Reads the spans of every sampled launch so far into the accumulators and frees the slots (drains the stream first).
@@ -926,9 +932,18 @@ static int lm_span_collect(odo_lm* m) {
     const unsigned long long t0 = h[2 * i], t1 = h[2 * i + 1];
     if (t0 == ~0ull || t1 == 0 || t1 < t0) continue;   // a launch that never ran (dropped with its Solve)
     const double us = (double)(t1 - t0) * 0.01;          // wall_clock64: 100 MHz
+    const odo_lm::SpanTag& tg = (*m->span_kind)[i];
     m->ev_total_us += us;
     m->ev_sampled++;
-    if ((*m->span_kind)[i]) { m->ev_coarse_us += us; m->ev_coarse_launches++; }
+    if (tg.coarse) { m->ev_coarse_us += us; m->ev_coarse_launches++; }
+    if (i + 1 < m->span_used) {   // its successor was sampled too: start-to-start period
+      const odo_lm::SpanTag& nx = (*m->span_kind)[i + 1];
+      const unsigned long long n0 = h[2 * (i + 1)];
+      if (nx.solve == tg.solve && nx.idx == tg.idx + 1 && n0 != ~0ull && n0 > t0) {
+        const double per = (double)(n0 - t0) * 0.01;
+        if (tg.coarse) { m->ev_cperiod_us += per; m->ev_cperiod_n++; } else { m->ev_period_us += per; m->ev_period_n++; }
+      }
+    }
   }
   for (int i = 0; i < m->span_used; i++) { h[2 * i] = ~0ull; h[2 * i + 1] = 0; }
   HIP_OK(hipMemcpy(m->d_span, h.data(), sizeof(unsigned long long) * h.size(), hipMemcpyHostToDevice));
@@ -1671,13 +1686,14 @@ extern "C" int odo_lm_event_timing(odo_lm* m, int on) {
     std::vector<unsigned long long> h(2 * (size_t)kSpanSlots);
     for (int i = 0; i < kSpanSlots; i++) { h[2 * i] = ~0ull; h[2 * i + 1] = 0; }
     HIP_OK(hipMemcpy(m->d_span, h.data(), sizeof(unsigned long long) * h.size(), hipMemcpyHostToDevice));
-    m->span_kind = new std::vector<unsigned char>();
+    m->span_kind = new std::vector<odo_lm::SpanTag>();
     m->span_used = 0;
   }
   if (on) {
     if (lm_span_collect(m)) return -1;   // slots of an earlier period
     m->ev_total_us = m->ev_bytes = m->ev_coarse_us = 0.0;
     m->ev_launches = m->ev_active = m->ev_coarse_launches = m->ev_sampled = m->ev_coarse_all = 0;
+    m->ev_period_us = m->ev_cperiod_us = 0.0; m->ev_period_n = m->ev_cperiod_n = 0;
     m->ev_solves = 0; m->ev_phase = 0;
   } else if (m->ev_on) {
     if (lm_span_collect(m)) return -1;
@@ -1686,10 +1702,13 @@ extern "C" int odo_lm_event_timing(odo_lm* m, int on) {
   return 0;
 }
 // out[0] sampled step-kernel time (us), out[1] sampled step launches, out[2] sampled coarse-kernel time (us), out[3] sampled
-// coarse launches, out[4] all launches issued, out[5] all coarse launches, out[6] evaluations, out[7] algorithmic bytes.
-extern "C" int odo_lm_event_stats_ex(odo_lm* m, double out[8]) {
+// coarse launches, out[4] all launches issued, out[5] all coarse launches, out[6] evaluations, out[7] algorithmic bytes,
+// out[8] / out[9] summed start-to-start periods of consecutive sampled step launches (us) and their number, out[10] / out[11]
+// the same from a coarse launch to the step launch behind it.
+extern "C" int odo_lm_event_stats_ex(odo_lm* m, double out[12]) {
   if (!m || !out) return fail("NULL arg");
   if (lm_span_collect(m)) return -1;
+  out[8] = m->ev_period_us; out[9] = (double)m->ev_period_n; out[10] = m->ev_cperiod_us; out[11] = (double)m->ev_cperiod_n;
   out[0] = m->ev_total_us - m->ev_coarse_us; out[1] = (double)(m->ev_sampled - m->ev_coarse_launches);
   out[2] = m->ev_coarse_us; out[3] = (double)m->ev_coarse_launches;
   out[4] = (double)m->ev_launches; out[5] = (double)m->ev_coarse_all; out[6] = (double)m->ev_active; out[7] = m->ev_bytes;

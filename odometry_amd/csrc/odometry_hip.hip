@@ -911,6 +911,14 @@ static inline double lm_level_bytes(const odo_lm* m, int level, int rows, int co
 // pyramids abandons it (its launches drain on the stream like the stragglers of any finished Solve: the next Solve starts
 // with first_of_solve = 1 and a new token).
 // ---------------------------------------------------------------------------------------------------------------
+// Which residue of the launch index is sampled in the next Solve: a hash of the Solve counter, NOT the counter modulo N — the
+// tracker promotes a keyframe every ~8 frames on bench.py's drive and the Solve after a switch is the long one, so "every 8th
+// Solve" aliased with the keyframe rhythm (coarse launch sampled at 193 or 220 us depending on the warm-up length, population
+// mean 203).
+static inline int lm_ev_next_phase(odo_lm* m) {
+  const unsigned long long h = (unsigned long long)(m->ev_solves++) * 0x9E3779B97F4A7C15ull;
+  return (int)((h >> 40) % (unsigned long long)m->ev_on);
+}
 // Launch timing: is launch `i` of the Solve in flight one of the sampled ones? If so it gets the next free span slot.
 constexpr int kSpanSlots = 16384;
 static inline unsigned long long* lm_span_slot(odo_lm* m, int i, bool coarse) {
@@ -981,7 +989,7 @@ static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_de
   // finishes the Solve writes the result and the token into host-mapped memory itself.
   m->token = (m->token % 0x3ffff) + 1;
   jb.token = m->token;
-  if (m->ev_on > 0) m->ev_phase = (int)(m->ev_solves++ % m->ev_on);
+  if (m->ev_on > 0) m->ev_phase = lm_ev_next_phase(m);
   StepArgs& a = jb.a;
   memset(&a, 0, sizeof(a));
   a.n_levels = m->n_levels;
@@ -1424,7 +1432,7 @@ static int lm_batch_begin(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
   // the table of the previous batched Solve may still be read by its draining launches: order the upload behind them
   HIP_OK(hipMemcpyAsync(d_table, h_table, sizeof(StepArgs) * (size_t)n, hipMemcpyHostToDevice, s));
   jb.grid = grid; jb.budget = budget; jb.seq = 0; jb.launches = 0; jb.it = 0; jb.poll_ok = true; jb.issued_all = false;
-  if (lms[0]->ev_on > 0) lms[0]->ev_phase = (int)(lms[0]->ev_solves++ % lms[0]->ev_on);
+  if (lms[0]->ev_on > 0) lms[0]->ev_phase = lm_ev_next_phase(lms[0]);
   lms[0]->last_coarse_batch = any_coarse;
   if (any_coarse) {
     hipLaunchKernelGGL(lm_coarse_kernel_batch, dim3(1, n), dim3(kCoarseBlock), kCoarseLdsBytes, s, (const StepArgs*)d_table, jb.seq, 1,

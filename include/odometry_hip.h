@@ -88,7 +88,8 @@ int odo_dev_free_async(odo_ctx* ctx, void* dev, size_t bytes, int is_async);
  * (ref: include/image_pyramid.h:24,51; src/image_pyramid.cpp:13-19,30-37;
  *  src/image_processing_global.cpp:12-56,58-113).
  * kind IMAGE: L0 = 3x3 Gaussian blur if smooth else copy; L1 = pyrDown(input); Lk = pyrDown(L(k-1)).
- * kind DEPTH: L0 = copy, Lk(y,x) = L(k-1)(2y+1,2x+1); smooth must be 0 (no reference caller passes 1).
+ * kind DEPTH: L0 = copy, or cv::medianBlur 3x3 (replicated border) if smooth (ref: src/image_processing_global.cpp:76-80; no
+ * reference caller passes 1); Lk(y,x) = L(k-1)(2y+1,2x+1).
  * `img` is a host pointer with row pitch stride_bytes (0 = cols*4). */
 int odo_pyramid_create(odo_ctx* ctx, const float* img, int rows, int cols, size_t stride_bytes, int levels,
                        int smooth, int kind, odo_pyr** out);

@@ -78,6 +78,25 @@ __global__ void __launch_bounds__(256) pyrdown_kernel(const float* __restrict__ 
 }
 
 // Depth decimation L_k(y,x) = L_{k-1}(2y+1, 2x+1) (ref: src/image_processing_global.cpp:85-89,99-103).
+// cv::medianBlur(src, dst, 3) on fp32 (ref: src/image_processing_global.cpp:77, DepthPyramid with smooth = true): median of the
+// 3x3 neighbourhood, replicated border, by the 19-exchange sorting network for nine values (a selection: bit-exact by definition).
+__device__ __forceinline__ void med_cx(float& a, float& b) { const float lo = fminf(a, b), hi = fmaxf(a, b); a = lo; b = hi; }
+__global__ void __launch_bounds__(256) median3x3_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= cols || y >= rows) return;
+  const int xm = x > 0 ? x - 1 : 0, xp = x + 1 < cols ? x + 1 : cols - 1;
+  const int ym = y > 0 ? y - 1 : 0, yp = y + 1 < rows ? y + 1 : rows - 1;
+  const float* r0 = src + (size_t)ym * cols;
+  const float* r1 = src + (size_t)y * cols;
+  const float* r2 = src + (size_t)yp * cols;
+  float p0 = r0[xm], p1 = r0[x], p2 = r0[xp], p3 = r1[xm], p4 = r1[x], p5 = r1[xp], p6 = r2[xm], p7 = r2[x], p8 = r2[xp];
+  med_cx(p1, p2); med_cx(p4, p5); med_cx(p7, p8); med_cx(p0, p1); med_cx(p3, p4); med_cx(p6, p7);
+  med_cx(p1, p2); med_cx(p4, p5); med_cx(p7, p8); med_cx(p0, p3); med_cx(p5, p8); med_cx(p4, p7);
+  med_cx(p3, p6); med_cx(p1, p4); med_cx(p2, p5); med_cx(p4, p7); med_cx(p4, p2); med_cx(p6, p4);
+  med_cx(p4, p2);
+  dst[(size_t)y * cols + x] = p4;
+}
+
 __global__ void __launch_bounds__(256) decimate_odd_kernel(const float* __restrict__ src, int cols,
                                                             float* __restrict__ dst, int dr, int dc) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -248,12 +267,12 @@ __global__ void __launch_bounds__(kPyrThreadsWide) image_pyramid_fused_wide_kern
 
 // Whole depth pyramid in one launch: L_k(Y,X) = L_0(2^k Y + 2^k - 1, 2^k X + 2^k - 1), the composition of the
 // reference's odd decimations (ref: src/image_processing_global.cpp:85-89,99-103). Thread <-> level-0 pixel.
-__device__ __forceinline__ void depth_pyramid_fused_kernel_body(const float* __restrict__ src, PyrOut o) {
+__device__ __forceinline__ void depth_pyramid_fused_kernel_body(const float* src, PyrOut o) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= o.cols[0] || y >= o.rows[0]) return;
   const float v = src[(size_t)y * o.cols[0] + x];
-  o.lvl[0][(size_t)y * o.cols[0] + x] = v;
+  if (src != o.lvl[0]) o.lvl[0][(size_t)y * o.cols[0] + x] = v;   // in place when level 0 was filled by the median filter
 #pragma unroll
   for (int l = 1; l < 4; l++) {
     if (l < o.n_levels) {
@@ -265,7 +284,7 @@ __device__ __forceinline__ void depth_pyramid_fused_kernel_body(const float* __r
     }
   }
 }
-__global__ void __launch_bounds__(256) depth_pyramid_fused_kernel(const float* __restrict__ src, PyrOut o) {
+__global__ void __launch_bounds__(256) depth_pyramid_fused_kernel(const float* src, PyrOut o) {
   depth_pyramid_fused_kernel_body(src, o);
 }
 

@@ -335,8 +335,13 @@ static int pyr_build(odo_pyr* p, const float* img_dev, int smooth) {
   hipStream_t s = p->ctx->stream;
   p->version = ++g_pyr_version;
   const int rows = p->rows, cols = p->cols;
-  if (p->kind == ODO_PYR_DEPTH && smooth)
-    return fail("depth pyramid smoothing (cv::medianBlur) is not implemented: no reference caller uses it");
+  if (p->kind == ODO_PYR_DEPTH && smooth) {
+    // cv::medianBlur(in, L0, 3) (ref: src/image_processing_global.cpp:76-80; no caller of the reference passes smooth = true): the
+    // median goes into level 0 and the levels below are decimated from it (the fused kernel's level-0 copy is then in place)
+    hipLaunchKernelGGL(median3x3_kernel, grid2d(cols, rows), dim3(256), 0, s, img_dev, p->dev, rows, cols);
+    img_dev = p->dev;
+    smooth = 0;
+  }
   static const bool unfused = getenv("ODO_PYR_UNFUSED") != nullptr;
   if (p->levels <= 4 && !unfused) {  // whole pyramid in one launch
     PyrOut o;
@@ -370,7 +375,7 @@ static int pyr_build(odo_pyr* p, const float* img_dev, int smooth) {
       prev = p->dev + p->off[l];
     }
   } else {
-    HIP_OK(hipMemcpyAsync(p->dev, img_dev, sizeof(float) * (size_t)rows * cols, hipMemcpyDeviceToDevice, s));
+    if (img_dev != p->dev) HIP_OK(hipMemcpyAsync(p->dev, img_dev, sizeof(float) * (size_t)rows * cols, hipMemcpyDeviceToDevice, s));
     for (int l = 1; l < p->levels; l++)
       hipLaunchKernelGGL(decimate_odd_kernel, grid2d(p->c[l], p->r[l]), dim3(256), 0, s, p->dev + p->off[l - 1],
                          p->c[l - 1], p->dev + p->off[l], p->r[l], p->c[l]);

@@ -219,11 +219,43 @@ int orc_image_pyramid(const float* img, int rows, int cols, int n_levels, int sm
   return 0;
 }
 
-/* MedianDepthPyramidNaive with smooth=false (ref: src/image_processing_global.cpp:58-113):
- * L0 = copy, Lk(y,x) = L(k-1)(2y+1, 2x+1). (smooth=true needs cv::medianBlur; no caller uses it.) */
+/* cv::medianBlur(src, dst, 3) on CV_32F (ref: src/image_processing_global.cpp:77; OpenCV is not vendored: restated from its
+ * documented definition — the median of the 3x3 neighbourhood, BORDER_REPLICATE). A median is a selection, not arithmetic: any
+ * correct implementation returns the same bits (inputs without NaN). */
+int orc_median3x3(const float* src, int rows, int cols, float* dst) {
+  if (rows < 1 || cols < 1) return -1;
+  for (int y = 0; y < rows; y++)
+    for (int x = 0; x < cols; x++) {
+      float v[9];
+      int k = 0;
+      for (int dy = -1; dy <= 1; dy++)
+        for (int dx = -1; dx <= 1; dx++) {
+          int yy = y + dy, xx = x + dx;
+          yy = yy < 0 ? 0 : (yy >= rows ? rows - 1 : yy);
+          xx = xx < 0 ? 0 : (xx >= cols ? cols - 1 : xx);
+          v[k++] = src[(size_t)yy * cols + xx];
+        }
+      for (int i = 1; i < 9; i++) {   /* insertion sort of nine */
+        const float t = v[i];
+        int j = i - 1;
+        while (j >= 0 && v[j] > t) { v[j + 1] = v[j]; j--; }
+        v[j + 1] = t;
+      }
+      dst[(size_t)y * cols + x] = v[4];
+    }
+  return 0;
+}
+
+/* MedianDepthPyramidNaive (ref: src/image_processing_global.cpp:58-113): L0 = copy, or the 3x3 median when `smooth`
+ * (:76-80; no caller of the reference passes true), Lk(y,x) = L(k-1)(2y+1, 2x+1). */
+int orc_depth_pyramid_ex(const float* dep, int rows, int cols, int n_levels, int smooth, float* out);
 int orc_depth_pyramid(const float* dep, int rows, int cols, int n_levels, float* out) {
+  return orc_depth_pyramid_ex(dep, rows, cols, n_levels, 0, out);
+}
+int orc_depth_pyramid_ex(const float* dep, int rows, int cols, int n_levels, int smooth, float* out) {
   if (n_levels < 1 || n_levels > ORC_MAX_LEVELS) return -1;
-  memcpy(out, dep, sizeof(float) * (size_t)rows * cols);
+  if (smooth) { if (orc_median3x3(dep, rows, cols, out)) return -1; }
+  else memcpy(out, dep, sizeof(float) * (size_t)rows * cols);
   const float* prev = out;
   int pr = rows, pc = cols;
   float* dst = out + (size_t)rows * cols;

@@ -163,11 +163,18 @@ def image_pyramid(img, n_levels=4, smooth=True, flat=False):
     return out if flat else split_levels(out, rows, cols, n_levels)
 
 
-def depth_pyramid(dep, n_levels=4, flat=False):
+def median3x3(img):
+    img, p = _f(img)
+    out = np.empty_like(img)
+    assert lib().orc_median3x3(p, img.shape[0], img.shape[1], out.ctypes.data_as(_fp)) == 0
+    return out
+
+
+def depth_pyramid(dep, n_levels=4, flat=False, smooth=False):
     dep, p = _f(dep)
     rows, cols = dep.shape
     out = np.empty(int(pyramid_size(rows, cols, n_levels)), np.float32)
-    assert lib().orc_depth_pyramid(p, rows, cols, n_levels, out.ctypes.data_as(_fp)) == 0
+    assert lib().orc_depth_pyramid_ex(p, rows, cols, n_levels, int(smooth), out.ctypes.data_as(_fp)) == 0
     return out if flat else split_levels(out, rows, cols, n_levels)
 
 

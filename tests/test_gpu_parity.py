@@ -54,6 +54,20 @@ def test_depth_pyramid_bit_exact(api, O):
         assert np.array_equal(pyr.GetPyramidDepth(l), ref[l])
 
 
+@pytest.mark.parametrize("levels,shape", [(4, (376, 1241)), (4, (61, 83)), (6, (200, 264))])
+def test_depth_pyramid_median_smoothing_bit_exact(api, O, levels, shape):
+    """DepthPyramid(.., smooth = true): cv::medianBlur 3x3 into level 0, the levels below decimated from it (ref:
+    src/image_processing_global.cpp:76-80,85-106) — the one-launch pyramid (<= 4 levels) and the level-by-level path (> 4)."""
+    rng = np.random.default_rng(11)
+    dep = rng.random(shape).astype(np.float32)
+    dep[rng.random(dep.shape) < 0.6] = 0
+    ref = O.depth_pyramid(dep, levels, smooth=True)
+    pyr = api.DepthPyramid(levels, dep, True)
+    for l in range(levels):
+        assert np.array_equal(pyr.GetPyramidDepth(l), ref[l]), f"level {l}"
+    assert not np.array_equal(ref[0], dep)     # the filter did something
+
+
 def test_pyramid_bad_level(api):
     pyr = api.ImagePyramid(4, np.zeros((64, 64), np.float32), True)
     with pytest.raises(IndexError):

@@ -14,8 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 fp = C.POINTER(C.c_float)
 
 
-@pytest.fixture(scope="module")
-def emu():
+def load_emu():
+    """Builds (if stale) and loads tests/hostemu.cpp: odometry_amd/csrc/odo_math.h compiled for the host."""
     so = os.path.join(ROOT, "tests", "_build_hostemu.so")
     src = os.path.join(ROOT, "tests", "hostemu.cpp")
     hdr = os.path.join(ROOT, "odometry_amd", "csrc", "odo_math.h")
@@ -27,6 +27,11 @@ def emu():
     lib.emu_cx_level.restype = C.c_float
     lib.emu_cx_level.argtypes = [C.c_float, C.c_int]
     return lib
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return load_emu()
 
 
 def P(a):

@@ -90,3 +90,23 @@ def test_principal_point_rule():
     cy = [O.lib().orc_cx_level(185.2157, l) for l in range(4)]
     np.testing.assert_allclose(cx, [607.1928, 304.3464, 152.9232, 77.2116], rtol=2e-7)
     np.testing.assert_allclose(cy, [185.2157, 93.35785, 47.428925, 24.4644625], rtol=2e-7)
+
+
+def test_median3x3_and_smoothed_depth_pyramid():
+    """DepthPyramid(smooth = true): cv::medianBlur(.., 3) (ref: src/image_processing_global.cpp:76-80) restated as the median of
+    the 3x3 neighbourhood with a replicated border, against scipy's; the levels below are decimated from the filtered level 0."""
+    from scipy import ndimage
+    rng = np.random.default_rng(5)
+    for shape in ((7, 9), (48, 64), (33, 41)):
+        a = rng.random(shape, np.float32)
+        a[rng.random(shape) < 0.3] = 0.0          # invalid depth holes
+        got = O.median3x3(a)
+        assert np.array_equal(got, ndimage.median_filter(a, size=3, mode="nearest"))
+    a = rng.random((48, 64), np.float32)
+    lv = O.depth_pyramid(a, 4, smooth=True)
+    m = O.median3x3(a)
+    assert np.array_equal(lv[0], m)
+    for k in range(1, 4):
+        s = 2 ** k
+        assert np.array_equal(lv[k], m[s - 1::s, s - 1::s][:lv[k].shape[0], :lv[k].shape[1]])
+    assert np.array_equal(O.depth_pyramid(a, 4)[0], a)      # smooth = false: a plain copy, as before

@@ -105,8 +105,8 @@ def test_hip_disparity_matches_reference_code(ssd, key):
 def test_shared_device_arithmetic_matches_reference_code(ssd):
     """odometry_amd/csrc/odo_math.h — the header the HIP kernels compile — built for the host: its cx_level and ssd8_tree against
     the reference's GetCxLevel and ComputeSsdPattern8Sse outputs."""
-    from tests.test_hostemu_parity import emu as _emu_fixture
-    lib = _emu_fixture.__wrapped__()
+    from test_hostemu_parity import load_emu
+    lib = load_emu()
     g = np.load(os.path.join(GOLD, "cx_level_ref.npz"))
     for i, c in enumerate(g["c"]):
         for j, l in enumerate(g["levels"]):

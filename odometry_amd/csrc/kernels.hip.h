@@ -922,11 +922,16 @@ struct StepLaunch {
   int seq, first_of_solve;
   unsigned long long* span;
 };
+// In a batched launch (gridDim.y sequences) one block in eight takes part, a different residue per sequence: several hundred
+// atomics on one address serialise in the L2 (~10 ns each: ~4 us for the 424 blocks of an S = 8 step launch, on a 16 us kernel).
+__device__ __forceinline__ bool lm_span_block() {
+  return threadIdx.x == 0 && (gridDim.y == 1 || ((blockIdx.x ^ blockIdx.y) & 7u) == 0u);
+}
 __device__ __forceinline__ void lm_span_begin(unsigned long long* span) {
-  if (span && threadIdx.x == 0) atomicMin(span, (unsigned long long)wall_clock64());
+  if (span && lm_span_block()) atomicMin(span, (unsigned long long)wall_clock64());
 }
 __device__ __forceinline__ void lm_span_end(unsigned long long* span) {
-  if (span && threadIdx.x == 0) atomicMax(span + 1, (unsigned long long)wall_clock64());
+  if (span && lm_span_block()) atomicMax(span + 1, (unsigned long long)wall_clock64());
 }
 
 constexpr int kFoldChunk = 20;  // the 160 rows of a point-list grid in one round of loads per segment

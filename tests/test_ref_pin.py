@@ -2,7 +2,7 @@
 
 tests/golden/ssd_ref.npz and cx_level_ref.npz are written by oracle/make_ref_fixtures.py, which compiles
 src/depth_estimate.cpp:435-453 (ComputeSsdPattern8Sse), :380-395 (template taps, candidate loop, strict-< first minimum,
-threshold, disparity, inverse depth) and include/image_processing_global.h:22-28 (GetCxLevel) straight out of /root/reference
+threshold, disparity, inverse depth) and include/image_processing_global.h:22-28 (GetCxLevel) and src/camera.cpp:61-65 (the camera pyramid's intrinsic rule) straight out of /root/reference
 with the reference's build flags. These are the only fixtures in this repository that do not come from the restatement itself;
 they pin D3's arithmetic and the principal-point rule. Everything else stays "parity unpinned" (DESIGN.md section 2)."""
 import ctypes as C
@@ -28,6 +28,34 @@ def test_cx_level_matches_reference_code():
             assert np.float32(O.lib().orc_cx_level(float(c), int(l))) == g["out"][i, j]
     # the two constants of the hot path (ref: include/image_processing_global.h:35-36), levels 0-3 as SURVEY section 8 lists them
     assert np.allclose(g["out"][0, :4], [607.1928, 304.3464, 152.9232, 77.2116], rtol=0, atol=1e-4)
+
+
+def test_camera_intrinsic_pyramid_matches_reference_code():
+    """CameraPyramid::ConfigureCamera's per-level rule (ref: src/camera.cpp:61-65, the five update statements compiled as they
+    stand): the oracle's orc_camera_intrinsics bit for bit, 32 cameras x 6 levels, in double."""
+    g = np.load(os.path.join(GOLD, "cx_level_ref.npz"))
+    for cin, want in zip(g["cam_in"], g["cam_out"]):
+        P = np.zeros((3, 4))
+        P[0, 0], P[1, 1], P[0, 1], P[0, 2], P[1, 2], P[2, 2] = cin[0], cin[1], cin[2], cin[3], cin[4], 1.0
+        got = O.camera_intrinsics(P, 6)
+        assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_hip_camera_intrinsics_match_reference_code():
+    """odo_camera_configure / odo_camera_intrinsics through the C ABI against the same fixture (KITTI-00 and the reference's own
+    calibration-file camera)."""
+    from odometry_amd import api
+    g = np.load(os.path.join(GOLD, "cx_level_ref.npz"))
+    for cin, want in zip(g["cam_in"][:4], g["cam_out"][:4]):
+        cam = api.CameraPyramid(4, cin[0], cin[1], cin[2], cin[3], cin[4], 0.0, 0.0, 0.0, 0.0, 6.4, 4.8, 128, 96)
+        P = np.zeros((3, 4))
+        P[0, 0], P[1, 1], P[0, 1], P[0, 2], P[1, 2], P[2, 2] = cin[0], cin[1], cin[2], cin[3], cin[4], 1.0
+        cam.ConfigureCamera(np.eye(3), P, (128, 96))
+        for l in range(4):
+            got = [cam.fx_double(l), cam.fy_double(l), cam.f_theta_double(l), cam.cx_double(l), cam.cy_double(l)]
+            assert got == list(want[l]), (l, got, list(want[l]))
+        cam.close()
 
 
 def test_ssd_tree_kats_match_reference_code(ssd):
@@ -83,6 +111,11 @@ def test_oracle_scan_matches_live_reference_build_on_fresh_inputs():
     for c in (607.1928, 185.2157, 0.0, 1e6):
         for l in range(8):
             assert O.lib().orc_cx_level(C.c_float(c), l) == L.ref_cx_level(C.c_float(c), l)
+    out = np.zeros((5, 5))
+    L.ref_camera_pyramid(1100.0, 1090.5, 0.25, 959.5, 539.5, 5, out.ctypes.data_as(C.POINTER(C.c_double)))
+    P = np.zeros((3, 4))
+    P[0, 0], P[1, 1], P[0, 1], P[0, 2], P[1, 2], P[2, 2] = 1100.0, 1090.5, 0.25, 959.5, 539.5, 1.0
+    assert np.array_equal(O.camera_intrinsics(P, 5), out)
 
 
 @pytest.mark.gpu

@@ -13,6 +13,8 @@ however, need nothing but <immintrin.h> and <cmath>, because they work on plain 
   src/depth_estimate.cpp:345,367,380-395     the scan itself: template taps, candidate loop [begin_x, x), strict-< first
                                              minimum, ssd_th test, disparity and inverse depth
   src/camera.cpp:61-65                       CameraPyramid::ConfigureCamera's per-level update of fx, fy, f_theta, cx, cy
+  src/lm_optimizer.cpp:110-115,117,131-143,  the LM driver of one pyramid level: locals, loop test, accept / reject, the lambda rule,
+                       154-155               both stop tests, which estimate is current afterwards — with the estimates as plain tags
 
 This script reads exactly those line ranges out of /root/reference AT RUN TIME (nothing of the reference is stored in this
 repository: the generated translation unit lives in oracle/_ref/, which is git-ignored), checks their SHA-256 so that a
@@ -49,10 +51,18 @@ RANGES = {
     "reset_ssd": ("src/depth_estimate.cpp", 367, 367),
     "scan": ("src/depth_estimate.cpp", 380, 395),
     "cam_pyr": ("src/camera.cpp", 61, 65),
+    "lm_locals": ("src/lm_optimizer.cpp", 110, 115),
+    "lm_while": ("src/lm_optimizer.cpp", 117, 117),
+    "lm_rule": ("src/lm_optimizer.cpp", 131, 143),
+    "lm_iter": ("src/lm_optimizer.cpp", 154, 155),
 }
 # sha256 of each extracted range (`--print-hashes`), checked on every run: a reference checkout whose lines have moved must
 # not produce fixtures
 HASHES = {
+    "lm_locals": "b0c30a5ffa74aa3ec49270f0690ebea04781a6a89cb567b1a503637ae5c02600",
+    "lm_while": "c05b8e308b0ab360155b95d827128cd767be49419b82d6d196c27224771eee21",
+    "lm_rule": "8fde3401e2e200e7331efe4a20961c1214c186ae18ce3ede7aecb676fcc567b9",
+    "lm_iter": "588f49474923e44a4cadddf7edea6e9e2edd25f171fb1275e371d331754284a9",
     "cx_level": "087fce328d582035762e689b56cc811230d452a88400840256b747a46f032d7f",
     "ssd_sse": "af9ffdb4bbc07135532d04bc189c7b2965fda0ad33426abeeec6ce9b9f5dc392",
     "locals_a": "e9c92b0d42195c090da847700430614441951e0df747dc31bc206ea1efc89c22",
@@ -86,11 +96,47 @@ def harness_source():
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <algorithm>
 // ---- include/image_processing_global.h:22-28
 {t['cx_level']}
 // ---- src/depth_estimate.cpp:435-453 (qualifier `DepthEstimator::` removed)
 {ssd}
 extern "C" float ref_cx_level(float cx, int level) {{ return GetCxLevel(cx, level); }}
+// The LM driver of one level (ref: src/lm_optimizer.cpp:110-155) replayed on a GIVEN sequence of errors: what the evaluation at
+// :121-129 would have produced is errs[k]; the estimates are tags (0 = the level's starting pose, k + 1 = the pose solved after
+// evaluation k, :153). rec: 5 ints per evaluation = {{current_lambda bits, err_last bits, current_estimate, last_estimate, 1 if the
+// loop broke at this evaluation}}. Returns the number of evaluations consumed; *final_current = current_estimate at :158.
+extern "C" int ref_lm_schedule(const float* errs, int n_errs, float lambda_, float precision_, int max_iters_l, int* rec,
+                               int* final_current) {{
+  int current_estimate = 0, last_estimate = 0, inc_estimate = 0;
+  float current_lambda = 0.0f;
+  const int max_iterations_[1] = {{max_iters_l}};
+  const int l = 0;
+  int k = 0;
+  // ---- src/lm_optimizer.cpp:110-115
+{t['lm_locals']}
+  // ---- :117
+{t['lm_while']}
+    if (k >= n_errs) break;
+    err_now = errs[k];                       // :121-129
+    bool broke = true;
+    do {{   // the reference's `break`s (:134, :140) leave this one-trip loop with broke still set
+      // ---- :131-143
+{t['lm_rule']}
+      broke = false;
+    }} while (0);
+    union {{ float f; int i; }} ul, ue;
+    ul.f = current_lambda; ue.f = err_last;
+    rec[5 * k + 0] = ul.i; rec[5 * k + 1] = ue.i; rec[5 * k + 2] = current_estimate; rec[5 * k + 3] = last_estimate; rec[5 * k + 4] = broke ? 1 : 0;
+    k++;
+    if (broke) break;
+    inc_estimate = k;                        // :145-153: the pose solved after this evaluation
+    // ---- :154-155
+{t['lm_iter']}
+  (void)err_diff;
+  *final_current = current_estimate;
+  return k;
+}}
 // out[l] = fx, fy, f_theta, cx, cy of level l: the loop of src/camera.cpp:49-66 around its five update statements
 extern "C" void ref_camera_pyramid(double fx, double fy, double f_theta, double cx, double cy, int levels_, double* out) {{
   for (int l = 0; l < levels_; l++) {{
@@ -167,6 +213,8 @@ def load(lib=None):
     L.ref_cx_level.argtypes = [C.c_float, C.c_int]
     L.ref_ssd8.restype = None
     L.ref_ssd8.argtypes = [fp, fp, fp, fp, fp, fp, C.c_int, fp]
+    L.ref_lm_schedule.restype = C.c_int
+    L.ref_lm_schedule.argtypes = [fp, C.c_int, C.c_float, C.c_float, C.c_int, ip, ip]
     L.ref_camera_pyramid.restype = None
     L.ref_camera_pyramid.argtypes = [C.c_double] * 5 + [C.c_int, C.POINTER(C.c_double)]
     L.ref_scan.restype = C.c_int
@@ -192,6 +240,39 @@ def ref_ssd8(L, left8, rows5, x):
     r = [np.ascontiguousarray(rows5[i], np.float32) for i in range(5)]
     L.ref_ssd8(_f(np.ascontiguousarray(left8, np.float32)), _f(r[0]), _f(r[1]), _f(r[2]), _f(r[3]), _f(r[4]), int(x), _f(out))
     return out[0]
+
+
+def lm_error_sequences(seed=3, n=240):
+    """Error sequences that walk the LM driver through all of its branches: slowly converging ones (precision stop), noisy ones
+    (accept / reject mixes), diverging ones (eleven rejects in a row: the lambda stop), short budgets (loop test)."""
+    rng = np.random.default_rng(seed)
+    seqs = []
+    for i in range(n):
+        kind = i % 4
+        m = int(rng.integers(3, 40))
+        e = np.empty(m, np.float32)
+        v = float(rng.uniform(50, 900))
+        for k in range(m):
+            if kind == 0:
+                v *= float(rng.uniform(0.80, 0.999))
+            elif kind == 1:
+                v *= float(rng.uniform(0.90, 1.06))
+            elif kind == 2:
+                v *= float(rng.uniform(1.0005, 1.2)) if k > 2 else 0.9
+            else:
+                v *= float(rng.uniform(0.97, 1.01))
+            e[k] = v
+        seqs.append((e, float(rng.choice([0.01, 0.01, 0.5, 2000.0])), float(rng.choice([0.995, 0.995, 0.9, 0.9999])),
+                     int(rng.choice([10, 20, 30, 30, 3]))))
+    return seqs
+
+
+def ref_lm_schedule(L, errs, lam, precision, max_iters):
+    errs = np.ascontiguousarray(errs, np.float32)
+    rec = np.zeros((len(errs), 5), np.int32)
+    fin = C.c_int(0)
+    n = L.ref_lm_schedule(_f(errs), len(errs), lam, precision, max_iters, rec.ctypes.data_as(C.POINTER(C.c_int)), C.byref(fin))
+    return rec[:n].copy(), fin.value
 
 
 def scenes():
@@ -279,6 +360,24 @@ def main():
     for i, c in enumerate(cams):
         L.ref_camera_pyramid(*[float(v) for v in c], 6, cam_out[i].ctypes.data_as(C.POINTER(C.c_double)))
     np.savez_compressed(os.path.join(GOLD, "cx_level_ref.npz"), c=cs, levels=lv, out=tab, cam_in=cams, cam_out=cam_out)
+    # the LM driver's schedule on given error sequences
+    sq = lm_error_sequences()
+    maxlen = max(len(e) for e, _, _, _ in sq)
+    errs = np.zeros((len(sq), maxlen), np.float32)
+    meta = np.zeros((len(sq), 4), np.float64)           # length, lambda, precision, max_iters
+    recs = np.full((len(sq), maxlen, 5), -1, np.int32)
+    outs = np.zeros((len(sq), 2), np.int32)             # evaluations consumed, final current estimate
+    n_break = n_rej = 0
+    for i, (e, lam, prec, mi) in enumerate(sq):
+        rec, fin = ref_lm_schedule(L, e, lam, prec, mi)
+        errs[i, :len(e)] = e
+        meta[i] = (len(e), lam, prec, mi)
+        recs[i, :len(rec)] = rec
+        outs[i] = (len(rec), fin)
+        n_break += int(rec[-1, 4]) if len(rec) else 0
+        n_rej += int((rec[1:, 2] == rec[:-1, 3]).sum()) if len(rec) > 1 else 0
+    np.savez_compressed(os.path.join(GOLD, "lm_schedule_ref.npz"), errs=errs, meta=meta, recs=recs, outs=outs)
+    print(f"wrote lm_schedule_ref.npz ({len(sq)} sequences, {n_break} ending in a break)")
     n_a = int(sc["a"][4].sum())
     n_b = int(sc["b"][4].sum())
     print(f"wrote tests/golden/ssd_ref.npz ({n_a} + {n_b} scanned points, {K} tree KATs of which {n_diff} separate the tree "

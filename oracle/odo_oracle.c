@@ -796,6 +796,47 @@ void orc_solve_damped(const double acc[29], float lambda, float delta[6]) {
  * img1/dep1 = keyframe pyramids, img2 = current pyramid, each stored level after level.
  * init / out: column-major 4x4. trace may be NULL. Returns 0, or -1 (then out = pseudo-identity whose
  * (3,3) is 0, ref :48-52,60-65). */
+/* The accept / reject / lambda / stop rule of one evaluation of the LM loop (ref: src/lm_optimizer.cpp:131-143). Returns the
+ * stop code (0 carry on, 1 precision break :140, 2 lambda break :134); *accepted tells which branch ran. Pinned to the reference's
+ * own lines by tests/test_ref_pin.py (oracle/make_ref_fixtures.py compiles :110-115,117,131-143,154-155 as they stand). */
+static int lm_rule(float err_now, float* err_last, float* lambda, float precision, int* accepted) {
+  if (err_now > *err_last) {                                              /* :131 */
+    *accepted = 0;
+    *lambda = *lambda * 5.0f;                                             /* :133 */
+    return (*lambda > 1e+5f) ? 2 : 0;                                     /* :134 */
+  }
+  *accepted = 1;
+  const float err_diff = err_now / *err_last;                             /* :139 */
+  if (err_diff > precision) return 1;                                     /* :140 */
+  *err_last = err_now;                                                    /* :141 */
+  *lambda = fmaxf(*lambda / 5.0f, 1e-5f);                                 /* :142 */
+  return 0;
+}
+/* The LM driver of one level replayed on a given sequence of errors, estimates as tags (0 = the level's starting pose, k + 1 = the
+ * pose solved after evaluation k): rec = 5 ints per evaluation {lambda bits, err_last bits, current tag, last tag, broke}. Same
+ * loop as orc_lm_solve's (ref: :110-155); the twin of ref_lm_schedule in oracle/make_ref_fixtures.py. */
+int orc_lm_schedule(const float* errs, int n_errs, float lambda0, float precision, int max_iters, int* rec, int* final_current) {
+  int cur = 0, last = 0, inc = 0, iter = 0, k = 0;
+  float err_last = 1e+10f, lambda = lambda0;
+  inc = cur;
+  while (max_iters > iter) {
+    if (k >= n_errs) break;
+    int accepted;
+    const int stop = lm_rule(errs[k], &err_last, &lambda, precision, &accepted);
+    if (accepted) { cur = inc; last = cur; }
+    else if (!stop) cur = last;
+    memcpy(&rec[5 * k + 0], &lambda, sizeof(int));
+    memcpy(&rec[5 * k + 1], &err_last, sizeof(int));
+    rec[5 * k + 2] = cur; rec[5 * k + 3] = last; rec[5 * k + 4] = stop ? 1 : 0;
+    k++;
+    if (stop) break;
+    inc = k;
+    iter++;
+  }
+  *final_current = cur;
+  return k;
+}
+
 int orc_lm_solve(const float* img1, const float* dep1, const float* img2, int rows, int cols,
                  const orc_lm_params* p, const float init[16], float out[16], orc_lm_trace* trace,
                  int trace_cap, int* n_trace) {
@@ -827,23 +868,10 @@ int orc_lm_solve(const float* img1, const float* dep1, const float* img2, int ro
         memcpy(tr->pose, T, sizeof(T));
       }
       nt++;
-      int stop = 0, accepted;
-      if (err_now > err_last) {                                           /* :131 */
-        accepted = 0;
-        lambda = lambda * 5.0f;
-        if (lambda > 1e+5f) stop = 2;
-        else cur = last;
-      } else {
-        accepted = 1;
-        cur = inc;
-        last = cur;
-        const float err_diff = err_now / err_last;
-        if (err_diff > p->precision) stop = 1;
-        else {
-          err_last = err_now;
-          lambda = fmaxf(lambda / 5.0f, 1e-5f);
-        }
-      }
+      int accepted;
+      const int stop = lm_rule(err_now, &err_last, &lambda, p->precision, &accepted);   /* :131-143 */
+      if (accepted) { cur = inc; last = cur; }                            /* :137-138 (before the precision break of :140) */
+      else if (!stop) cur = last;                                         /* :135 (after the lambda break of :134) */
       if (tr) { tr->accepted = accepted; tr->stop = stop; tr->lambda_after = lambda; }
       if (stop) break;
       float dv[6];

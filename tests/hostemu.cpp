@@ -69,4 +69,29 @@ void emu_solve_damped(const double* acc, float lambda, float* delta) { solve_dam
 void emu_sincos(float x, float* s, float* c) { sincos_f(x, s, c); }
 float emu_ssd8(const float* L, const float* R) { return ssd8_tree(L, R); }
 float emu_cx_level(float c, int level) { return cx_level(c, level); }
+// The device's LM state machine (lm_begin_level / lm_consume: what lm_step_kernel and lm_coarse_kernel run) replayed on a given
+// sequence of errors, the poses tagged through their x translation: the twin of orc_lm_schedule / ref_lm_schedule.
+int emu_lm_schedule(const float* errs, int n_errs, float lambda0, float precision, int max_iters, int* rec, int* final_current) {
+  LmState s;
+  const float eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  lm_begin_solve(&s, eye);
+  lm_begin_level(&s, 0, lambda0, max_iters);
+  int k = 0;
+  while (s.active && k < n_errs) {
+    double acc[ODO_NACC];
+    for (int i = 0; i < ODO_NACC; i++) acc[i] = 0.0;
+    acc[27] = (double)errs[k]; acc[28] = 1.0;          // err_now = float(acc[27] / acc[28]) = errs[k]; a zero system: zero step
+    lm_consume(&s, acc, precision, max_iters);
+    memcpy(&rec[5 * k + 0], &s.lambda, sizeof(int));
+    memcpy(&rec[5 * k + 1], &s.err_last, sizeof(int));
+    rec[5 * k + 2] = (int)s.cur.tx; rec[5 * k + 3] = (int)s.last.tx;
+    const int broke = (!s.active && (s.stop_reason == 1 || s.stop_reason == 2)) ? 1 : 0;
+    rec[5 * k + 4] = broke;
+    k++;
+    if (broke) break;
+    s.inc.tx = (float)k;                               // the pose solved after this evaluation
+  }
+  *final_current = (int)s.cur.tx;
+  return k;
+}
 }

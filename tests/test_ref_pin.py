@@ -58,6 +58,37 @@ def test_hip_camera_intrinsics_match_reference_code():
         cam.close()
 
 
+def _schedule(fn, errs, lam, prec, mi):
+    errs = np.ascontiguousarray(errs, np.float32)
+    rec = np.zeros((len(errs), 5), np.int32)
+    fin = C.c_int(0)
+    n = fn(errs.ctypes.data_as(C.POINTER(C.c_float)), len(errs), C.c_float(lam), C.c_float(prec), int(mi),
+           rec.ctypes.data_as(C.POINTER(C.c_int)), C.byref(fin))
+    return rec[:n], n, fin.value
+
+
+def test_lm_driver_schedule_matches_reference_code():
+    """The LM loop of one pyramid level (ref: src/lm_optimizer.cpp:110-115,117,131-143,154-155 compiled as they stand, estimates as
+    tags) replayed on 240 error sequences — accept / reject, lambda x5 and /5 with its floor, the precision and lambda breaks, the
+    iteration budget, which estimate is current afterwards: the oracle's loop AND the device's state machine (odo_math.h
+    lm_consume, host-compiled) reproduce every recorded word."""
+    from test_hostemu_parity import load_emu
+    g = np.load(os.path.join(GOLD, "lm_schedule_ref.npz"))
+    emu = load_emu()
+    n_break = n_budget = n_reject = 0
+    for errs, meta, recs, outs in zip(g["errs"], g["meta"], g["recs"], g["outs"]):
+        m, lam, prec, mi = int(meta[0]), float(meta[1]), float(meta[2]), int(meta[3])
+        want = recs[:outs[0]]
+        for fn in (O.lib().orc_lm_schedule, emu.emu_lm_schedule):
+            rec, n, fin = _schedule(fn, errs[:m], lam, prec, mi)
+            assert n == outs[0] and fin == outs[1]
+            assert np.array_equal(rec, want)
+        n_break += int(want[-1, 4])
+        n_budget += int(outs[0] == mi and not want[-1, 4])
+        n_reject += int(sum(1 for k in range(1, len(want)) if want[k, 2] == want[k - 1, 3] and want[k, 0] != want[k - 1, 0]))
+    assert n_break > 50 and n_budget > 20 and n_reject > 200     # the fixture walks every branch
+
+
 def test_ssd_tree_kats_match_reference_code(ssd):
     # left8 is in _mm256_set_ps ARGUMENT order (ref: src/depth_estimate.cpp:380-381); the oracle holds lanes low -> high
     for l8, r5, x, want in zip(ssd["kat_left8"], ssd["kat_rows5"], ssd["kat_x"], ssd["kat_ssd"]):
@@ -111,6 +142,12 @@ def test_oracle_scan_matches_live_reference_build_on_fresh_inputs():
     for c in (607.1928, 185.2157, 0.0, 1e6):
         for l in range(8):
             assert O.lib().orc_cx_level(C.c_float(c), l) == L.ref_cx_level(C.c_float(c), l)
+    rng2 = np.random.default_rng(123)
+    for trial in range(50):   # fresh error sequences through the reference's LM loop lines and the oracle's
+        errs = (rng2.uniform(100, 500) * np.cumprod(rng2.uniform(0.9, 1.08, int(rng2.integers(3, 40))))).astype(np.float32)
+        want, fin = M.ref_lm_schedule(L, errs, 0.01, 0.995, 30)
+        rec, n, f2 = _schedule(O.lib().orc_lm_schedule, errs, 0.01, 0.995, 30)
+        assert n == len(want) and f2 == fin and np.array_equal(rec, want)
     out = np.zeros((5, 5))
     L.ref_camera_pyramid(1100.0, 1090.5, 0.25, 959.5, 539.5, 5, out.ctypes.data_as(C.POINTER(C.c_double)))
     P = np.zeros((3, 4))

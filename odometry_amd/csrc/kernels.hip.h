@@ -1715,11 +1715,7 @@ struct DepthLmStats {
 // k-1 is re-derived at the top of launch k by EVERY block from the per-block partial sums of launch k-1 (fixed
 // summation order -> all blocks agree bit for bit), so no grid barrier and no host round trip is needed.
 // State and partials are double-buffered by launch parity. Uses the UNBLURRED images (:67).
-struct DepthLmState {
-  float lambda, err_last, err_now;
-  int iter;
-  int done;
-};
+// DepthLmState, depth_lm_begin / depth_lm_decide / depth_lm_advance: odo_math.h (shared with the host build the tests pin)
 constexpr int kDlmBlock = 256;
 constexpr int kDlmBlocks = kSelBlocks * kSelCap / kDlmBlock;  // 160
 
@@ -1762,8 +1758,7 @@ __device__ __forceinline__ void depth_lm_step_kernel_body(
     pf_left = left[(size_t)(pf_pk >> 16) * cols + (pf_pk & 0xffffu)];
   }
   if (k == 0) {
-    st.lambda = lambda0; st.err_last = 1e+10f; st.err_now = 0.0f; st.iter = 0;
-    st.done = (max_iters > 0) ? 0 : 1;
+    depth_lm_begin(&st, lambda0, max_iters);
     const float v = ok ? d0[s] : 0.0f;
     cur[s] = v; pre[s] = 0.0f; tmp[s] = v; res[s] = 0.0f; jt[s] = 1.0f; bb[s] = 0.0f;
     my_tmp = v;
@@ -1789,16 +1784,7 @@ __device__ __forceinline__ void depth_lm_step_kernel_body(
       for (int o = 32; o > 0; o >>= 1) { fe += __shfl_xor(fe, o, 64); fn += __shfl_xor(fn, o, 64); }
     }
     const float err_now = (1.0f / (float)fn) * (float)fe;  // :239
-    st.err_now = err_now;
-    int mode;  // 0 reject+continue, 1 accept+continue, 2 reject+break, 3 accept+break
-    if (err_now > st.err_last) {  // :150
-      st.lambda = st.lambda * 10.0f;
-      mode = (st.lambda > 1e+5f) ? 2 : 0;
-    } else {
-      const float err_diff = err_now / st.err_last;
-      if (err_diff > precision) mode = 3;
-      else { mode = 1; st.err_last = err_now; st.lambda = fmaxf(st.lambda / 10.0f, 1e-7f); }
-    }
+    const int mode = depth_lm_decide(&st, err_now, precision);  // 0 reject+continue, 1 accept+continue, 2 reject+break, 3 accept+break
     my_tmp = 0.0f;
     if (mode != 2 && ok) {
       float c;
@@ -1813,11 +1799,7 @@ __device__ __forceinline__ void depth_lm_step_kernel_body(
         tmp[s] = my_tmp;
       }
     }
-    if (mode == 2 || mode == 3) st.done = 1;
-    else {
-      st.iter++;                              // :167
-      if (!(max_iters > st.iter)) st.done = 1;  // :141
-    }
+    depth_lm_advance(&st, mode, max_iters);   // :167, :141
     if (st.done) { if (blockIdx.x == 0 && t == 0) { state[(k + 1) & 1] = st; dlm_report(host_prog, k, 1); } return; }
   }
   // ---- evaluation k at tmp (ComputeResidualJacobian :200-242) ----

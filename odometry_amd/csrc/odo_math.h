@@ -536,6 +536,44 @@ ODO_HD void lm_consume(LmState* s, const double acc[ODO_NACC], float precision, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// The inverse-depth LM's driver (ref: src/depth_estimate.cpp:92-96,141,150-161,167): the state every block of
+// depth_lm_step_kernel carries from launch to launch, and the rule one evaluation's error is judged by. Pinned to the
+// reference's own lines through the host build (tests/test_ref_pin.py, emu_depth_lm_schedule).
+// ---------------------------------------------------------------------------------------------
+struct DepthLmState {
+  float lambda, err_last, err_now;
+  int iter;
+  int done;
+};
+ODO_HD void depth_lm_begin(DepthLmState* st, float lambda0, int max_iters) {
+  st->lambda = lambda0;                              // :92
+  st->err_last = 1e+10f;                             // :94
+  st->err_now = 0.0f;                                // :95
+  st->iter = 0;                                      // :93
+  st->done = (max_iters > 0) ? 0 : 1;                // :141
+}
+// Returns the mode: 0 reject + carry on (current = pre, :153), 1 accept + carry on (current = tmp, pre = current, :155-156),
+// 2 reject + break (:152), 3 accept + break (:158). Lambda and err_last are updated as the reference's lines do.
+ODO_HD int depth_lm_decide(DepthLmState* st, float err_now, float precision) {
+  st->err_now = err_now;
+  if (err_now > st->err_last) {                      // :150
+    st->lambda = st->lambda * 10.0f;                 // :151
+    return (st->lambda > 1e+5f) ? 2 : 0;             // :152
+  }
+  const float err_diff = err_now / st->err_last;     // :157
+  if (err_diff > precision) return 3;                // :158
+  st->err_last = err_now;                            // :159
+  st->lambda = fmaxf(st->lambda / 10.0f, 1e-7f);     // :160
+  return 1;
+}
+// iter_count++ (:167) and the loop test (:141) after a step that carries on; a break ends the loop as it stands
+ODO_HD void depth_lm_advance(DepthLmState* st, int mode, int max_iters) {
+  if (mode == 2 || mode == 3) { st->done = 1; return; }
+  st->iter++;
+  if (!(max_iters > st->iter)) st->done = 1;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Depth estimator pieces (ref: src/depth_estimate.cpp).
 // ---------------------------------------------------------------------------------------------
 // 8-tap SSD with the AVX hadd tree of ComputeSsdPattern8Sse (depth_estimate.cpp:435-453).

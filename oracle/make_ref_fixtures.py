@@ -55,6 +55,10 @@ RANGES = {
     "lm_while": ("src/lm_optimizer.cpp", 117, 117),
     "lm_rule": ("src/lm_optimizer.cpp", 131, 143),
     "lm_iter": ("src/lm_optimizer.cpp", 154, 155),
+    "dlm_locals": ("src/depth_estimate.cpp", 92, 96),
+    "dlm_while": ("src/depth_estimate.cpp", 141, 141),
+    "dlm_rule": ("src/depth_estimate.cpp", 150, 161),
+    "dlm_iter": ("src/depth_estimate.cpp", 167, 168),
 }
 # sha256 of each extracted range (`--print-hashes`), checked on every run: a reference checkout whose lines have moved must
 # not produce fixtures
@@ -63,6 +67,10 @@ HASHES = {
     "lm_while": "c05b8e308b0ab360155b95d827128cd767be49419b82d6d196c27224771eee21",
     "lm_rule": "8fde3401e2e200e7331efe4a20961c1214c186ae18ce3ede7aecb676fcc567b9",
     "lm_iter": "588f49474923e44a4cadddf7edea6e9e2edd25f171fb1275e371d331754284a9",
+    "dlm_locals": "d7bada3232045425592b50a58d6e7715e97b04c42ccfb00835308c3f7cd492d3",
+    "dlm_while": "6d748a04b4a5173d7576127a10382b302c7c960b82f9ae140bd5542d18657bc2",
+    "dlm_rule": "5eac4ac163be63494711529fbfcf85d01b4d79a83f0bf8bdc1675ada219e7504",
+    "dlm_iter": "e3e1949081947b3d8345adebf3f0aa25ae97d745dc5f8e638469c4fd656c618c",
     "cx_level": "087fce328d582035762e689b56cc811230d452a88400840256b747a46f032d7f",
     "ssd_sse": "af9ffdb4bbc07135532d04bc189c7b2965fda0ad33426abeeec6ce9b9f5dc392",
     "locals_a": "e9c92b0d42195c090da847700430614441951e0df747dc31bc206ea1efc89c22",
@@ -135,6 +143,39 @@ extern "C" int ref_lm_schedule(const float* errs, int n_errs, float lambda_, flo
 {t['lm_iter']}
   (void)err_diff;
   *final_current = current_estimate;
+  return k;
+}}
+// The inverse-depth LM driver (ref: src/depth_estimate.cpp:92-168) replayed the same way: errs[k] is what ComputeResidualJacobian
+// (:144) would have returned in err_now; the depth vectors are tags (0 = init_depth :121,:137, -1 = the zero vector pre_depth starts
+// as :123, k + 1 = the vector solved after evaluation k :166). rec: 5 ints per evaluation = {{current_lambda bits, err_last bits,
+// current_depth, pre_depth, 1 if the loop broke here}}. Returns the evaluations consumed; *iters = iter_count at :171.
+extern "C" int ref_depth_lm_schedule(const float* errs, int n_errs, float lambda_, float precision_, int max_iters_, int* rec,
+                                     int* final_current, int* iters) {{
+  int current_depth = 0, pre_depth = -1, tmp_depth = 0;
+  int k = 0;
+  // ---- src/depth_estimate.cpp:92-96
+{t['dlm_locals']}
+  // ---- :141
+{t['dlm_while']}
+    if (k >= n_errs) break;
+    err_now = errs[k];                       // :144
+    bool broke = true;
+    do {{   // the reference's `break`s (:152, :158) leave this one-trip loop with broke still set
+      // ---- :150-161
+{t['dlm_rule']}
+      broke = false;
+    }} while (0);
+    union {{ float f; int i; }} ul, ue;
+    ul.f = current_lambda; ue.f = err_last;
+    rec[5 * k + 0] = ul.i; rec[5 * k + 1] = ue.i; rec[5 * k + 2] = current_depth; rec[5 * k + 3] = pre_depth; rec[5 * k + 4] = broke ? 1 : 0;
+    k++;
+    if (broke) break;
+    tmp_depth = k;                           // :164-166: the vector solved after this evaluation
+    // ---- :167-168
+{t['dlm_iter']}
+  (void)err_diff;
+  *final_current = current_depth;
+  *iters = iter_count;
   return k;
 }}
 // out[l] = fx, fy, f_theta, cx, cy of level l: the loop of src/camera.cpp:49-66 around its five update statements
@@ -215,6 +256,8 @@ def load(lib=None):
     L.ref_ssd8.argtypes = [fp, fp, fp, fp, fp, fp, C.c_int, fp]
     L.ref_lm_schedule.restype = C.c_int
     L.ref_lm_schedule.argtypes = [fp, C.c_int, C.c_float, C.c_float, C.c_int, ip, ip]
+    L.ref_depth_lm_schedule.restype = C.c_int
+    L.ref_depth_lm_schedule.argtypes = [fp, C.c_int, C.c_float, C.c_float, C.c_int, ip, ip, ip]
     L.ref_camera_pyramid.restype = None
     L.ref_camera_pyramid.argtypes = [C.c_double] * 5 + [C.c_int, C.POINTER(C.c_double)]
     L.ref_scan.restype = C.c_int
@@ -273,6 +316,39 @@ def ref_lm_schedule(L, errs, lam, precision, max_iters):
     fin = C.c_int(0)
     n = L.ref_lm_schedule(_f(errs), len(errs), lam, precision, max_iters, rec.ctypes.data_as(C.POINTER(C.c_int)), C.byref(fin))
     return rec[:n].copy(), fin.value
+
+
+def depth_lm_error_sequences(seed=5, n=240):
+    """The same four kinds of sequence for the inverse-depth LM (x10 / /10, floor 1e-7, stop at 1e5: six rejects from 0.01)."""
+    rng = np.random.default_rng(seed)
+    seqs = []
+    for i in range(n):
+        kind = i % 4
+        m = int(rng.integers(3, 60))
+        e = np.empty(m, np.float32)
+        v = float(rng.uniform(20, 400))
+        for k in range(m):
+            if kind == 0:
+                v *= float(rng.uniform(0.80, 0.999))
+            elif kind == 1:
+                v *= float(rng.uniform(0.90, 1.06))
+            elif kind == 2:
+                v *= float(rng.uniform(1.0005, 1.2)) if k > 2 else 0.9
+            else:
+                v *= float(rng.uniform(0.97, 1.01))
+            e[k] = v
+        seqs.append((e, float(rng.choice([0.01, 0.01, 1e-6, 3000.0])), float(rng.choice([0.995, 0.995, 0.9, 0.9999])),
+                     int(rng.choice([50, 50, 20, 5, 0]))))
+    return seqs
+
+
+def ref_depth_lm_schedule(L, errs, lam, precision, max_iters):
+    errs = np.ascontiguousarray(errs, np.float32)
+    rec = np.zeros((len(errs), 5), np.int32)
+    fin, it = C.c_int(0), C.c_int(0)
+    n = L.ref_depth_lm_schedule(_f(errs), len(errs), lam, precision, max_iters, rec.ctypes.data_as(C.POINTER(C.c_int)),
+                                C.byref(fin), C.byref(it))
+    return rec[:n].copy(), fin.value, it.value
 
 
 def scenes():
@@ -378,6 +454,23 @@ def main():
         n_rej += int((rec[1:, 2] == rec[:-1, 3]).sum()) if len(rec) > 1 else 0
     np.savez_compressed(os.path.join(GOLD, "lm_schedule_ref.npz"), errs=errs, meta=meta, recs=recs, outs=outs)
     print(f"wrote lm_schedule_ref.npz ({len(sq)} sequences, {n_break} ending in a break)")
+    # the inverse-depth LM driver's schedule
+    sq = depth_lm_error_sequences()
+    maxlen = max(len(e) for e, _, _, _ in sq)
+    errs = np.zeros((len(sq), maxlen), np.float32)
+    meta = np.zeros((len(sq), 4), np.float64)
+    recs = np.full((len(sq), maxlen, 5), -9, np.int32)
+    outs = np.zeros((len(sq), 3), np.int32)             # evaluations consumed, final current depth tag, iter_count
+    n_break = 0
+    for i, (e, lam, prec, mi) in enumerate(sq):
+        rec, fin, it = ref_depth_lm_schedule(L, e, lam, prec, mi)
+        errs[i, :len(e)] = e
+        meta[i] = (len(e), lam, prec, mi)
+        recs[i, :len(rec)] = rec
+        outs[i] = (len(rec), fin, it)
+        n_break += int(rec[-1, 4]) if len(rec) else 0
+    np.savez_compressed(os.path.join(GOLD, "depth_lm_schedule_ref.npz"), errs=errs, meta=meta, recs=recs, outs=outs)
+    print(f"wrote depth_lm_schedule_ref.npz ({len(sq)} sequences, {n_break} ending in a break)")
     n_a = int(sc["a"][4].sum())
     n_b = int(sc["b"][4].sum())
     print(f"wrote tests/golden/ssd_ref.npz ({n_a} + {n_b} scanned points, {K} tree KATs of which {n_diff} separate the tree "

@@ -1000,6 +1000,49 @@ static int disparity_depth(const float* left, const float* right, int rows, int 
   return 0;
 }
 
+/* The accept / reject / lambda / stop rule of one evaluation of the inverse-depth LM (ref: src/depth_estimate.cpp:150-161). Returns
+ * the stop code (0 carry on, 1 precision break :158, 2 lambda break :152); *accepted tells which branch ran. Pinned to the
+ * reference's own lines by tests/test_ref_pin.py (oracle/make_ref_fixtures.py compiles :92-96,141,150-161,167 as they stand). */
+static int depth_lm_rule(float err_now, float* err_last, float* lambda, float precision, int* accepted) {
+  if (err_now > *err_last) {                                              /* :150 */
+    *accepted = 0;
+    *lambda = *lambda * 10.0f;                                            /* :151 */
+    return (*lambda > 1e+5f) ? 2 : 0;                                     /* :152 */
+  }
+  *accepted = 1;
+  const float err_diff = err_now / *err_last;                             /* :157 */
+  if (err_diff > precision) return 1;                                     /* :158 */
+  *err_last = err_now;                                                    /* :159 */
+  *lambda = fmaxf(*lambda / 10.0f, 1e-7f);                                /* :160 */
+  return 0;
+}
+/* The inverse-depth LM driver replayed on a given sequence of errors, depth vectors as tags (0 = the scan's depths, k + 1 = the
+ * vector solved after evaluation k, -1 = the zero vector pre_depth starts as): rec = 5 ints per evaluation {lambda bits, err_last
+ * bits, current tag, pre tag, broke}; *iters = iter_count at :171. Same loop as depth_optimization's below; the twin of
+ * ref_depth_lm_schedule in oracle/make_ref_fixtures.py. */
+int orc_depth_lm_schedule(const float* errs, int n_errs, float lambda0, float precision, int max_iters, int* rec, int* final_current,
+                          int* iters) {
+  int cur = 0, pre = -1, tmp = 0, iter = 0, k = 0;
+  float err_last = 1e+10f, lambda = lambda0;
+  while (max_iters > iter) {
+    if (k >= n_errs) break;
+    int accepted;
+    const int stop = depth_lm_rule(errs[k], &err_last, &lambda, precision, &accepted);
+    if (accepted) { cur = tmp; pre = cur; }
+    else if (!stop) cur = pre;
+    memcpy(&rec[5 * k + 0], &lambda, sizeof(int));
+    memcpy(&rec[5 * k + 1], &err_last, sizeof(int));
+    rec[5 * k + 2] = cur; rec[5 * k + 3] = pre; rec[5 * k + 4] = stop ? 1 : 0;
+    k++;
+    if (stop) break;
+    tmp = k;
+    iter++;
+  }
+  *final_current = cur;
+  *iters = iter;
+  return k;
+}
+
 /* DepthOptimization + ComputeResidualJacobian (ref: src/depth_estimate.cpp:80-198, 200-242).
  * Uses the UNBLURRED images (:67). err sums are accumulated in fp64 and rounded to fp32. */
 static int depth_optimization(const float* left, const float* right, int rows, int cols, const orc_depth_params* p,
@@ -1040,18 +1083,13 @@ static int depth_optimization(const float* left, const float* right, int rows, i
       bb[i] = -r_diff * w_i * r_i;                                        /* :235 */
     }
     err_now = (1.0f / (float)n_act) * (float)esum;                        /* :239 */
-    if (err_now > err_last) {                                             /* :150 */
-      lambda = lambda * 10.0f;
-      if (lambda > 1e+5f) break;
-      memcpy(cur, pre, sizeof(float) * (size_t)n);
-    } else {
-      memcpy(cur, tmp, sizeof(float) * (size_t)n);
-      memcpy(pre, cur, sizeof(float) * (size_t)n);
-      const float err_diff = err_now / err_last;
-      if (err_diff > p->precision) break;
-      err_last = err_now;
-      lambda = fmaxf(lambda / 10.0f, 1e-7f);
-    }
+    int accepted;
+    const int stop = depth_lm_rule(err_now, &err_last, &lambda, p->precision, &accepted);   /* :150-161 */
+    if (accepted) {
+      memcpy(cur, tmp, sizeof(float) * (size_t)n);                        /* :155 */
+      memcpy(pre, cur, sizeof(float) * (size_t)n);                        /* :156 */
+    } else if (!stop) memcpy(cur, pre, sizeof(float) * (size_t)n);        /* :153 */
+    if (stop) break;
     for (int i = 0; i < n; i++) {                                         /* :164-166 */
       const float A = jtwj[i] + lambda * jtwj[i];
       const float dd = (1.0f / A) * bb[i];

@@ -94,4 +94,29 @@ int emu_lm_schedule(const float* errs, int n_errs, float lambda0, float precisio
   *final_current = (int)s.cur.tx;
   return k;
 }
+// The device's inverse-depth LM driver (depth_lm_begin / depth_lm_decide / depth_lm_advance: what every block of
+// depth_lm_step_kernel runs) replayed on a given sequence of errors, the depth vectors as tags (0 = the scan's depths, k + 1 = the
+// vector solved after evaluation k; pre starts as the zero vector, tag -1): the twin of orc_depth_lm_schedule /
+// ref_depth_lm_schedule. rec = 5 ints per evaluation {lambda bits, err_last bits, current tag, pre tag, broke}.
+int emu_depth_lm_schedule(const float* errs, int n_errs, float lambda0, float precision, int max_iters, int* rec, int* final_current,
+                          int* iters) {
+  DepthLmState st;
+  depth_lm_begin(&st, lambda0, max_iters);
+  int cur = 0, pre = -1, tmp = 0, k = 0;
+  while (!st.done && k < n_errs) {
+    const int mode = depth_lm_decide(&st, errs[k], precision);
+    if (mode == 0) cur = pre;                            // the kernel's `c = pf_pre`
+    else if (mode == 1 || mode == 3) { cur = tmp; pre = cur; }
+    memcpy(&rec[5 * k + 0], &st.lambda, sizeof(int));
+    memcpy(&rec[5 * k + 1], &st.err_last, sizeof(int));
+    rec[5 * k + 2] = cur; rec[5 * k + 3] = pre; rec[5 * k + 4] = (mode >= 2) ? 1 : 0;
+    k++;
+    depth_lm_advance(&st, mode, max_iters);
+    if (mode >= 2) break;
+    tmp = k;
+  }
+  *final_current = cur;
+  *iters = st.iter;
+  return k;
+}
 }

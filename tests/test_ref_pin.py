@@ -89,6 +89,38 @@ def test_lm_driver_schedule_matches_reference_code():
     assert n_break > 50 and n_budget > 20 and n_reject > 200     # the fixture walks every branch
 
 
+def _depth_schedule(fn, errs, lam, prec, mi):
+    errs = np.ascontiguousarray(errs, np.float32)
+    rec = np.zeros((max(len(errs), 1), 5), np.int32)
+    fin, it = C.c_int(0), C.c_int(0)
+    n = fn(errs.ctypes.data_as(C.POINTER(C.c_float)), len(errs), C.c_float(lam), C.c_float(prec), int(mi),
+           rec.ctypes.data_as(C.POINTER(C.c_int)), C.byref(fin), C.byref(it))
+    return rec[:n], n, fin.value, it.value
+
+
+def test_depth_lm_driver_schedule_matches_reference_code():
+    """The inverse-depth LM loop (ref: src/depth_estimate.cpp:92-96,141,150-161,167-168 compiled as they stand, depth vectors as
+    tags) replayed on 240 error sequences — lambda x10 and /10 with its 1e-7 floor, the 1e5 and precision breaks, the iteration
+    budget (0 included), which vector is current and which is `pre` afterwards, iter_count: the oracle's loop AND the rule every
+    block of depth_lm_step_kernel runs (odo_math.h depth_lm_begin / depth_lm_decide / depth_lm_advance, host-compiled) reproduce
+    every recorded word."""
+    from test_hostemu_parity import load_emu
+    g = np.load(os.path.join(GOLD, "depth_lm_schedule_ref.npz"))
+    emu = load_emu()
+    n_break = n_budget = n_zero = 0
+    for errs, meta, recs, outs in zip(g["errs"], g["meta"], g["recs"], g["outs"]):
+        m, lam, prec, mi = int(meta[0]), float(meta[1]), float(meta[2]), int(meta[3])
+        want = recs[:outs[0]]
+        for fn in (O.lib().orc_depth_lm_schedule, emu.emu_depth_lm_schedule):
+            rec, n, fin, it = _depth_schedule(fn, errs[:m], lam, prec, mi)
+            assert n == outs[0] and fin == outs[1] and it == outs[2]
+            assert np.array_equal(rec, want)
+        n_zero += int(outs[0] == 0)
+        n_break += int(want[-1, 4]) if len(want) else 0
+        n_budget += int(len(want) > 0 and outs[0] == mi and not want[-1, 4])
+    assert n_break > 50 and n_budget > 20 and n_zero > 10
+
+
 def test_ssd_tree_kats_match_reference_code(ssd):
     # left8 is in _mm256_set_ps ARGUMENT order (ref: src/depth_estimate.cpp:380-381); the oracle holds lanes low -> high
     for l8, r5, x, want in zip(ssd["kat_left8"], ssd["kat_rows5"], ssd["kat_x"], ssd["kat_ssd"]):
@@ -148,6 +180,11 @@ def test_oracle_scan_matches_live_reference_build_on_fresh_inputs():
         want, fin = M.ref_lm_schedule(L, errs, 0.01, 0.995, 30)
         rec, n, f2 = _schedule(O.lib().orc_lm_schedule, errs, 0.01, 0.995, 30)
         assert n == len(want) and f2 == fin and np.array_equal(rec, want)
+    for trial in range(50):   # and through the inverse-depth LM's
+        errs = (rng2.uniform(20, 300) * np.cumprod(rng2.uniform(0.9, 1.08, int(rng2.integers(3, 60))))).astype(np.float32)
+        want, fin, it = M.ref_depth_lm_schedule(L, errs, 0.01, 0.995, 50)
+        rec, n, f2, i2 = _depth_schedule(O.lib().orc_depth_lm_schedule, errs, 0.01, 0.995, 50)
+        assert n == len(want) and f2 == fin and i2 == it and np.array_equal(rec, want)
     out = np.zeros((5, 5))
     L.ref_camera_pyramid(1100.0, 1090.5, 0.25, 959.5, 539.5, 5, out.ctypes.data_as(C.POINTER(C.c_double)))
     P = np.zeros((3, 4))

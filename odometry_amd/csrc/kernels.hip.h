@@ -1616,10 +1616,42 @@ __global__ void __launch_bounds__(kSelThreads) depth_select_kernel(const float* 
   depth_select_kernel_body(L, rows, cols, bnd, grad_th, val, pts, cnt);
 }
 
-// Epipolar line search (ref: src/depth_estimate.cpp:345-398): one wavefront per selected point, lanes scan
-// candidate columns right_x = lo + lane, lo + lane + 64, ... (coalesced reads of five right-image rows), each
-// lane keeps its first strict minimum, then a wave-wide (ssd, right_x) argmin where ties take the lowest
-// right_x — the sequential strict-< scan's answer. SSD uses the AVX hadd tree (ssd8_tree).
+// Epipolar line search (ref: src/depth_estimate.cpp:345-398): one wavefront per selected point. Each lane keeps its first strict
+// minimum over ascending candidate columns, then a wave-wide (ssd, right_x) argmin where ties take the lowest right_x — the
+// sequential strict-< scan's answer (:385-386). SSD uses the AVX hadd tree (ssd8_tree).
+//
+// Main loop: a lane owns FOUR consecutive candidates c0 .. c0 + 3 (c0 = base + 4 * lane) and fetches the 26 right-image values
+// their 32 taps touch with seven vector loads (row y: 8 values, y - 1: 6, y + 1 / y + 2 / y - 2: 4 each) — 6.5 dwords per
+// candidate instead of 8, 7 requests per 4 candidates instead of 32, and a wave's 1 KB request straddles one extra cache line
+// where every 256-B request of the one-candidate-per-lane form straddles one too. The scan is bound by the vector L1's line
+// rate (the blurred pair is L2 resident; 18 k points each streaming five rows leave nothing to reuse in a 32 KB L1), so lines per
+// candidate are what it costs: 23.4 -> 20.2 us for the reference's full range. Fewer than 256 candidates left: lanes =
+// consecutive candidates, stride 64. The slot header (count, packed coordinates, eight left taps) comes through the scalar
+// cache: the wave's index is uniform, so none of it occupies the vector memory path.
+//
+// Measured and not kept (round 3, all bit-identical; tools/scan_probe.py): a persistent grid (256 .. 2048
+// blocks walking the slots: 53 .. 22 us — static striding balances worse than the dispatcher); groups of 2 .. 16 slots per wave
+// with their headers fetched together (23.3 .. 50.9 us — the points of a group then scan one after the other); the points of a
+// group walked in lock step, 32 taps in flight per wave (21.9 .. 24.6 us; best for +-128 px: 10.1 against 11.9 us); right-image
+// rows of a (tile, 256-column chunk) staged in LDS by 512-thread workgroups with a 64-bit atomic-min merge and a resolve kernel
+// (35.1 + 3.9 us: per (point, chunk) bookkeeping outweighs the cheaper taps). With ONE candidate per point the kernel still
+// takes 8 .. 11 us in every shape: the floor is the per-point chain of dependent trips to L2, not the scan.
+struct __attribute__((packed, aligned(4))) ScanF4 { float v[4]; };
+struct __attribute__((packed, aligned(4))) ScanF2 { float v[2]; };
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+// (best, match) <- the lexicographic minimum with the lane the DPP pattern pairs this one with (every pattern used is a
+// permutation inside a row of 16 lanes, so every lane has a source)
+template <int CTRL> __device__ __forceinline__ void scan_min_step(float& best, int& match) {
+  const float ob = dpp_f<CTRL>(best);
+  const int om = dpp_i<CTRL>(match);
+  const bool take = ob < best || (ob == best && om < match);
+  best = take ? ob : best;
+  match = take ? om : match;
+}
 __device__ __forceinline__ void depth_disparity_kernel_body(const float* __restrict__ L, const float* __restrict__ R,
                                                                int rows, int cols, int bnd, int max_disp, float ssd_th,
                                                                float f0, float baseline, const uint32_t* __restrict__ pts,
@@ -1627,10 +1659,11 @@ __device__ __forceinline__ void depth_disparity_kernel_body(const float* __restr
                                                                float* __restrict__ dep, float* __restrict__ d0,
                                                                uint8_t* __restrict__ matched) {
   const int lane = threadIdx.x & 63;
-  const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));  // wave-uniform
   const int b = slot / kSelCap, k = slot % kSelCap;
-  if (b >= kSelBlocks || k >= cnt[b]) return;  // wave-uniform
-  const uint32_t pk = pts[slot];
+  if (b >= kSelBlocks) return;
+  const uint32_t pk = pts[slot];  // requested with the count, not after it (an unused slot's word is never looked at)
+  if (k >= cnt[b]) return;
   const int x = (int)(pk & 0xffffu), y = (int)(pk >> 16);
   const float* lpp = L + (size_t)(y - 2) * cols;
   const float* lp = L + (size_t)(y - 1) * cols;
@@ -1647,13 +1680,31 @@ __device__ __forceinline__ void depth_disparity_kernel_body(const float* __restr
   if (max_disp > 0 && x - max_disp > lo) lo = x - max_disp;
   float best = 1e+10f;  // :367
   int match = 0x7fffffff;
+  int base = lo;
+  // :382 — four consecutive candidates per lane while a whole 256-candidate trip fits below x
+  for (; base + 4 * kWave <= x; base += 4 * kWave) {
+    const int c0 = base + 4 * lane;
+    const ScanF4 C0 = *(const ScanF4*)(rc + c0 - 2), C1 = *(const ScanF4*)(rc + c0 + 2);
+    const ScanF4 P0 = *(const ScanF4*)(rp + c0 - 1);
+    const ScanF2 P1 = *(const ScanF2*)(rp + c0 + 3);
+    const ScanF4 N0 = *(const ScanF4*)(rn + c0 - 1);
+    const ScanF4 NN = *(const ScanF4*)(rnn + c0);
+    const ScanF4 PP = *(const ScanF4*)(rpp + c0);
+    const float C[8] = {C0.v[0], C0.v[1], C0.v[2], C0.v[3], C1.v[0], C1.v[1], C1.v[2], C1.v[3]};  // rc[c0 - 2 + i]
+    const float P[6] = {P0.v[0], P0.v[1], P0.v[2], P0.v[3], P1.v[0], P1.v[1]};                      // rp[c0 - 1 + i]
+#pragma unroll
+    for (int u = 0; u < 4; u++) {  // ascending columns: the strict < keeps the first minimum
+      const float Rq[8] = {NN.v[u], N0.v[u], C[u + 4], C[u + 2], C[u], P[u + 2], P[u], PP.v[u]};
+      const float s = ssd8_tree(Lp, Rq);
+      if (s < best) { best = s; match = c0 + u; }
+    }
+  }
 #ifndef ODO_SCAN_UNROLL
 #define ODO_SCAN_UNROLL 2
 #endif
-  // :382 — lanes = consecutive candidate columns. ODO_SCAN_UNROLL candidates per lane and trip, all their taps loaded before any is
-  // used: the scan is latency bound on the right-image rows (58 % of wave cycles in s_waitcnt), so more loads in flight per wave
-  // is what moves it. Candidates are compared in ascending column order, so the strict < keeps the first minimum (:385-386).
-  int rx = lo + lane;
+  // the rest: lanes = consecutive candidate columns. ODO_SCAN_UNROLL candidates per lane and trip, all their taps loaded before
+  // any is used (more loads in flight per wave)
+  int rx = base + lane;
   for (; rx + (ODO_SCAN_UNROLL - 1) * kWave < x; rx += ODO_SCAN_UNROLL * kWave) {
     float Rq[ODO_SCAN_UNROLL][8];
 #pragma unroll
@@ -1673,17 +1724,27 @@ __device__ __forceinline__ void depth_disparity_kernel_body(const float* __restr
     const float s = ssd8_tree(Lp, Rp);
     if (s < best) { best = s; match = rx; }  // :385-386
   }
+  // argmin over the wave without a trip through LDS: inside each row of 16 lanes by DPP (xor 1, xor 2, mirror of 8, mirror of 16),
+  // then the four row results through scalar registers
+  scan_min_step<0xB1>(best, match);   // quad_perm [1, 0, 3, 2]
+  scan_min_step<0x4E>(best, match);   // quad_perm [2, 3, 0, 1]
+  scan_min_step<0x141>(best, match);  // row_half_mirror
+  scan_min_step<0x140>(best, match);  // row_mirror
+  float wb = lane_f(best, 0);
+  int wm = __builtin_amdgcn_readlane(match, 0);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ob = __shfl_xor(best, o, kWave);
-    const int om = __shfl_xor(match, o, kWave);
-    if (ob < best || (ob == best && om < match)) { best = ob; match = om; }
+  for (int r = 1; r < 4; r++) {
+    const float ob = lane_f(best, 16 * r);
+    const int om = __builtin_amdgcn_readlane(match, 16 * r);
+    const bool take = ob < wb || (ob == wb && om < wm);
+    wb = take ? ob : wb;
+    wm = take ? om : wm;
   }
   if (lane == 0) {
     float dd = 0.0f;
-    const bool hit = !(best > ssd_th);  // :388
+    const bool hit = !(wb > ssd_th);  // :388
     if (hit) {
-      const float dsp = (float)(x - match);  // :391
+      const float dsp = (float)(x - wm);     // :391
       dd = dsp / (f0 * baseline);            // :394
       disp[(size_t)y * cols + x] = dsp;
       dep[(size_t)y * cols + x] = dd;

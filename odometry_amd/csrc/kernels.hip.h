@@ -1383,6 +1383,235 @@ __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel_batch(const Ste
   lm_coarse_body(a, q, a.min_level);
 }
 
+// =============================================================================================
+// The fine levels in ONE launch: a persistent kernel whose K workgroups exchange their partial sums through L2.
+//
+// A step launch per evaluation costs a kernel boundary (1.5-1.8 us), a reload of state and partial rows (two dependent trips to
+// L2) and the keyframe point's record (another) every time. Here K workgroups stay resident for all evaluations of the levels the
+// coarse kernel does not take. Per evaluation every workgroup (a) evaluates its virtual blocks — virtual block vb is exactly the
+// step kernel's block vb: points vb * 256 + t (+ rounds), the same row publication and the same 29 x 8 accumulation, so the 232-B
+// partial row of a virtual block is bit for bit the step kernel's — (b) publishes each row as 58 data-tagged 8-byte granules
+// {32 bits of payload, 32-bit tag = Solve token and evaluation number} with agent-scope (write-through) stores, (c) gathers ALL
+// rows by polling the granules themselves with agent-scope loads — no flag, no fence, one trip through L2 (MI355X guide,
+// handoff-1to1: 0.8-1.0 us; tools/microbench/xcd_allgather.hip: 0.8-1.3 us for 4-16 workgroups) — in the fold's own access
+// pattern (thread (q, seg) reads rows seg, seg + 8, ... of quantity q and adds them in that order: lm_fused_prologue's fold),
+// then (d) runs the state machine redundantly, as every block of a step launch does. Nothing but the rows crosses workgroups.
+// Rows are double-buffered by evaluation parity: a workgroup can be at most one evaluation ahead of the slowest (it cannot
+// finish gathering evaluation e before every workgroup has published e).
+//
+// Placement: blocks are dealt round-robin over the 8 XCDs, so the launch has 8 x K blocks of which every eighth takes part
+// (they share an XCD and its L2; the others return at once). That is for speed only: the workgroups tell each other their XCC id
+// first, and only if all agree do the rows go out as plain stores (they stay in that L2); otherwise as agent-scope stores, which
+// are coherent at any placement. Every poll is bounded: a workgroup that waits longer than kFineSpinLimit polls gives up and the Solve reports
+// failure instead of hanging the device.
+// =============================================================================================
+constexpr int kFineGran = 2 * ODO_NACC;          // granules per partial row
+constexpr int kFineRowsMax = 160;                // = kLmListMaxBlocks (host): partial rows of the largest point-list level
+constexpr int kFineChunk = 8;                    // rows a folding thread keeps in flight
+constexpr int kFineSpinLimit = 1 << 17;          // polls of one chunk before giving up (~0.1 s, not microseconds)
+constexpr int kFineThreads = 2 * kLmBlock;       // a workgroup works on TWO virtual blocks at a time, one per half
+constexpr int kFineKMax = 32;                     // workgroups of one launch: they wait for each other, so each needs a CU of the XCD (32) to itself
+constexpr int kFineXbufWords = 2 * kFineRowsMax * kFineGran + kFineKMax;  // two row buffers + one placement word per workgroup
+typedef unsigned FineG2 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) FineG2 FineG2Global;   // global_load (not flat_load) for the coherent gather loads
+// One partial sum -> two granules {upper 32 bits | tag}, {lower 32 bits | tag}, each ONE 8-byte store. local: every workgroup of the
+// launch sits on the same XCD (checked at run time) — plain stores then leave the line in that XCD's L2, where the L1-bypassing
+// gather loads find it (MI355X guide: an agent-scope store drops the line and the reader pays the trip to the fabric);
+// otherwise agent-scope write-through stores, correct at any placement.
+__device__ __forceinline__ void fine_publish(unsigned long long* __restrict__ buf, int vb, int q, double acc, unsigned tag, bool local) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(acc);
+  unsigned long long* g = buf + (size_t)vb * kFineGran + 2 * q;
+  const unsigned long long g0 = ((bits >> 32) << 32) | tag, g1 = (bits << 32) | tag;
+  if (local) {
+    g[0] = g0;
+    g[1] = g1;
+  } else {
+    __hip_atomic_store(g, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(g + 1, g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__device__ __forceinline__ int fine_xcc_id() {
+  int v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 0xf;
+}
+__device__ __forceinline__ void lm_fine_body(const StepArgs& a, int K, int w, unsigned long long* __restrict__ xbuf, int fault) {
+  __builtin_amdgcn_s_setprio(3);  // see lm_coarse_kernel
+  const int t = threadIdx.x, tl = t & (kLmBlock - 1), half = t >> 8;
+  const bool publisher = (w == 0);
+  if (publisher && t == 0 && a.span) atomicMin(a.span, (unsigned long long)wall_clock64());
+  __shared__ LmState s_sh;
+  __shared__ double fold_sh[8 * 32];
+  __shared__ double acc_sh[32];
+  __shared__ StepLevel lv_sh[ODO_MAX_LEVELS_K];  // dynamic level index: keep the by-value argument out of scratch memory
+  __shared__ float rows_sh2[2][kRowFloats * RowBuf<kLmBlock>::W];
+  __shared__ int bail_sh, local_sh;
+  float* rows_sh = rows_sh2[half];
+  const unsigned tag_base = (unsigned)a.token << 8;
+  unsigned long long* place = xbuf + 2 * kFineRowsMax * kFineGran;  // [K] {xcc id, token} words
+  if (t == 0) {
+#pragma unroll
+    for (int l = 0; l < ODO_MAX_LEVELS_K; l++) lv_sh[l] = a.lv[l];
+    bail_sh = 0;
+    local_sh = 0;
+    // where am I? (agent-scope store: this exchange must work at any placement)
+    __hip_atomic_store(place + w, ((unsigned long long)(unsigned)fine_xcc_id() << 32) | tag_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  // state in (left by the coarse launch, or initialised), a pending evaluation of an earlier launch consumed, pyramid walk started
+  lm_fused_prologue(a.st_in, a.part_in, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, fold_sh, acc_sh, a.trace, a.cost_stat,
+                    publisher, a.first_of_solve ? a.init : nullptr, a.stop_level);
+  // does every workgroup of this launch share my XCD? (wave 0, lane i asks about workgroup i; the answer is the same everywhere)
+  if (t < 64) {
+    bool same = true, got = false;
+    if (t < K) {
+      unsigned long long pw = 0;
+      for (int spin = 0; !got && spin < kFineSpinLimit; spin++) {
+        pw = __hip_atomic_load(place + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        got = ((unsigned)pw == tag_base);
+      }
+      same = got && ((int)(pw >> 32) == fine_xcc_id());
+    } else {
+      got = true;
+    }
+    const bool all_got = __all(got), all_same = __all(same);
+    if (t == 0) { local_sh = (all_got && all_same) ? 1 : 0; if (!all_got) bail_sh = 1; }
+  }
+  __syncthreads();
+  const bool local = local_sh != 0;
+  constexpr int kS = 8;  // sub-lanes per quantity: 29 x 8 = 232 accumulating threads per half (the step kernel's)
+  const int my_q = tl / kS, my_s = tl % kS;
+  int rowA = 0, rowB = 0;
+  if (my_q < ODO_NACC) rows_of_quantity(my_q, &rowA, &rowB);
+  const int fq = t & 31, fseg = t >> 5;  // the fold's thread map (segments 0..7 fold: the first half of the workgroup)
+  PointK pt;
+  bool pt_ok = false;
+  int pt_level = -1;
+  unsigned long long c_eval = 0, c_xchg = 0, c_sm = 0, c_it = 0, c_last = a.dbg ? __builtin_readcyclecounter() : 0;
+  auto lap = [&](unsigned long long& sum) {
+    if (a.dbg) { const unsigned long long now = __builtin_readcyclecounter(); sum += now - c_last; c_last = now; }
+  };
+  for (int ev = 0; ev < 4096; ev++) {
+    const bool run = (s_sh.active != 0 && s_sh.status == 0 && !s_sh.finished && !bail_sh);  // block-uniform
+    if (!run) break;
+    c_it++;
+    const StepLevel& L = lv_sh[s_sh.level];
+    const int nblk = L.nblk;
+    const unsigned tag = tag_base + 1u + (unsigned)(ev % 255);   // never tag_base itself: that is the placement word's
+    unsigned long long* buf = xbuf + (size_t)(ev & 1) * kFineRowsMax * kFineGran;
+    float T[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) T[i] = s_sh.T[i];
+    // ---- (a) + (b): my virtual blocks, two at a time (half h of the workgroup works on virtual block vb0 + h * K) ----
+    const bool resident = (nblk <= 2 * K) && (L.n <= nblk * kLmBlock);  // one point per thread covers my share of the level
+    if (resident) {
+      // The keyframe point stays in registers for the whole level: one trip to L2 per level instead of one per evaluation.
+      const int vb = w + half * K;
+      if (s_sh.level != pt_level) {
+        pt_level = s_sh.level;
+        const int idx = vb * kLmBlock + tl;
+        pt_ok = vb < nblk && idx < L.n;
+        if (pt_ok) pt = load_point(L.pl, idx);
+      }
+      float r = 0.0f, wgt = 0.0f, J[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      bool valid = false;
+      if (pt_ok && point_residual(pt, T, L.k, L.I2, L.rows, L.cols, &r, J)) {
+        wgt = robust_weight(r, a.robust, a.huber_delta, 1.0f);
+        valid = true;
+      }
+      rows_store(rows_sh, RowBuf<kLmBlock>::W, tl, J, wgt, r, valid);   // (the state machine's closing barrier separates this
+      __syncthreads();                                                  //  from the previous evaluation's row sums)
+      if (vb < nblk) {
+        double accq = 0.0;
+        if (my_q < ODO_NACC) accq = rows_accumulate<kLmBlock, kS>(rows_sh, rowA, rowB, my_s, accq);
+#pragma unroll
+        for (int o = kS / 2; o > 0; o >>= 1) accq += __shfl_xor(accq, o, kS);
+        if (my_q < ODO_NACC && my_s == 0 && !(fault && w == K - 1)) fine_publish(buf, vb, my_q, accq, tag, local);
+      }
+    } else {
+      const int rounds = (L.n + nblk * kLmBlock - 1) / (nblk * kLmBlock);  // > 1 only beyond 160 x 256 points (a round without
+      for (int vb0 = w; vb0 < nblk; vb0 += 2 * K) {                        //  points adds zero rows: the sums do not change)
+        const int vb = vb0 + half * K;
+        double accq = 0.0;
+        for (int rd = 0; rd < rounds; rd++) {
+          const int idx = (vb + rd * nblk) * kLmBlock + tl;
+          float r = 0.0f, wgt = 0.0f, J[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+          bool valid = false;
+          if (vb < nblk && idx < L.n) {
+            const PointK p = load_point(L.pl, idx);
+            if (point_residual(p, T, L.k, L.I2, L.rows, L.cols, &r, J)) {
+              wgt = robust_weight(r, a.robust, a.huber_delta, 1.0f);
+              valid = true;
+            }
+          }
+          __syncthreads();  // the previous round's rows have been consumed
+          rows_store(rows_sh, RowBuf<kLmBlock>::W, tl, J, wgt, r, valid);
+          __syncthreads();
+          if (my_q < ODO_NACC) accq = rows_accumulate<kLmBlock, kS>(rows_sh, rowA, rowB, my_s, accq);
+        }
+#pragma unroll
+        for (int o = kS / 2; o > 0; o >>= 1) accq += __shfl_xor(accq, o, kS);
+        if (vb < nblk && my_q < ODO_NACC && my_s == 0) fine_publish(buf, vb, my_q, accq, tag, local);
+      }
+    }
+    lap(c_eval);
+    // ---- (c): gather every row in the fold's order (lm_fused_prologue: segment seg adds rows seg, seg + 8, ... ascending) ----
+    double v = 0.0;
+    if (fq < ODO_NACC && fseg < 8) {
+      for (int b0 = fseg; b0 < nblk; b0 += 8 * kFineChunk) {
+        FineG2 g2[kFineChunk];   // {hi granule, lo granule} of one double: one 16-byte load that bypasses L1
+        bool all = false;
+        for (int spin = 0; !all && spin < kFineSpinLimit; spin++) {
+          all = true;
+#pragma unroll
+          for (int u = 0; u < kFineChunk; u++) {
+            const int b = b0 + 8 * u;
+            if (b < nblk) g2[u] = *(const volatile FineG2Global*)(buf + (size_t)b * kFineGran + 2 * fq);  // re-read every pass, sc0 sc1
+          }
+#pragma unroll
+          for (int u = 0; u < kFineChunk; u++) {
+            const int b = b0 + 8 * u;
+            if (b < nblk) all = all && (g2[u].x == tag) && (g2[u].z == tag);
+          }
+        }
+        if (!all) bail_sh = 1;  // a workgroup of this Solve never published: report failure, do not hang
+#pragma unroll
+        for (int u = 0; u < kFineChunk; u++) {
+          const int b = b0 + 8 * u;
+          if (b < nblk) v += __longlong_as_double((long long)(((unsigned long long)g2[u].y << 32) | (unsigned long long)g2[u].w));
+        }
+      }
+    }
+    if (fseg < 8) fold_sh[fseg * 32 + fq] = v;
+    __syncthreads();
+    if (t < ODO_NACC) {
+      double acc = 0.0;
+#pragma unroll
+      for (int g = 0; g < 8; g++) acc += fold_sh[g * 32 + t];
+      acc_sh[t] = acc;
+    }
+    __syncthreads();
+    lap(c_xchg);
+    if (bail_sh) break;
+    // ---- (d): the state machine, every workgroup for itself ----
+    lm_state_machine(true, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, acc_sh, a.trace, a.cost_stat, publisher, nullptr,
+                     a.stop_level);
+    lap(c_sm);
+  }
+  if (bail_sh && t == 0) { s_sh.status = -2; s_sh.active = 0; s_sh.finished = 1; }   // -2: gave up waiting (the host redoes the Solve)
+  __syncthreads();
+  if (publisher) {
+    lm_fused_publish(s_sh, a.st_out, a.host_prog, a.seq, a.token, a.cost_stat, a.out, a.done_flag, a.final_state);
+    if (a.dbg && t == 0) { a.dbg[128] += c_eval; a.dbg[129] += c_xchg; a.dbg[130] += c_sm; a.dbg[131] += c_it; a.dbg[132] += 1; a.dbg[133] += local ? 1 : 0; }
+    if (t == 0 && a.span) atomicMax(a.span + 1, (unsigned long long)wall_clock64());
+  }
+}
+// grid = 8 * K blocks: every eighth block takes part (one XCD), the others return at once
+__global__ void __launch_bounds__(kFineThreads) lm_fine_kernel(StepArgs a, int K, unsigned long long* __restrict__ xbuf, int fault) {
+  if ((blockIdx.x & 7u) != 0u) return;
+  lm_fine_body(a, K, (int)(blockIdx.x >> 3), xbuf, fault);
+}
+
 // End of a fused Solve when no step launch has reported it (no launch was issued at all, or the host is not polling):
 // consume the last pending evaluation, then hand the result over like lm_fused_publish does.
 struct FinalizeArgs {

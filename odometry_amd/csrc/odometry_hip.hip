@@ -568,6 +568,12 @@ struct odo_lm {
   unsigned reset_gen;   // bumped by odo_lm_reset: a batched Solve started early is tied to it
   float* h_res; float* d_res_map; int* h_done; int* d_done; int token;  // host-mapped result + completion word
   int coarse;  // 1 = levels with <= kCoarseMaxPoints points run inside one workgroup (fused pipeline)
+  // Fine point-list levels in ONE persistent launch (lm_fine_kernel) instead of a step launch per evaluation: fine_k workgroups
+  // on one XCD exchange their partial rows through d_xbuf. 0 = off (ODO_LM_NO_FINE: the step launches, kept for the batched Solve).
+  int fine_k;
+  int fine_bails;   // Solves whose persistent launch gave up and that were redone on the step launches
+  int fine_fault;   // test hook (ODO_LM_FINE_FAULT): the last workgroup of the persistent launch never publishes
+  unsigned long long* d_xbuf;
   int fused;  // 1 = one launch per evaluation (robust 0/1); 0 = separate residual / update kernels
   int mode;  // 0 auto (list when <= half of the interior has depth), 1 always dense scan, 2 always list
   int bilinear;  // odo_lm_set_sampling: 1 = bilinear sampling of the current image (non-parity option)
@@ -646,6 +652,11 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
   m->dense_plain_div = getenv("ODO_DENSE_PLAIN_DIV") ? 1 : 0;
   m->fused = getenv("ODO_LM_UNFUSED") ? 0 : 1;
   m->coarse = getenv("ODO_LM_NO_COARSE") ? 0 : 1;
+  m->fine_k = getenv("ODO_LM_NO_FINE") ? 0 : (getenv("ODO_LM_FINE_K") ? atoi(getenv("ODO_LM_FINE_K")) : 32);
+  if (m->fine_k < 0 || m->fine_k > kFineKMax) m->fine_k = 32;
+  m->fine_fault = getenv("ODO_LM_FINE_FAULT") ? 1 : 0;
+  HIP_OK(hipMalloc((void**)&m->d_xbuf, sizeof(unsigned long long) * kFineXbufWords));
+  HIP_OK(hipMemset(m->d_xbuf, 0, sizeof(unsigned long long) * kFineXbufWords));   // tag 0: no Solve has token 0
   m->poll = getenv("ODO_NO_POLL") ? 0 : 1;
   m->run_ahead = getenv("ODO_RUN_AHEAD") ? atoi(getenv("ODO_RUN_AHEAD")) : 2;
   HIP_OK(hipMemsetAsync(m->d_trace, 0, sizeof(LmTraceRow) * kTraceCap, ctx->stream));
@@ -658,7 +669,7 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
 extern "C" int odo_lm_destroy(odo_lm* m) {
   if (!m) return 0;
   (void)hipStreamSynchronize(m->ctx->stream);
-  void* dv[] = {m->d_state, m->d_partials, m->d_init, m->d_out, m->d_trace, m->d_scale, m->d_res,
+  void* dv[] = {m->d_state, m->d_partials, m->d_xbuf, m->d_init, m->d_out, m->d_trace, m->d_scale, m->d_res,
                 m->d_rowcnt, m->d_npts, m->cand[0].d_rowcnt, m->cand[0].d_npts, m->cand[1].d_rowcnt, m->cand[1].d_npts};
   for (void* q : dv) if (q) (void)hipFree(q);
   for (int l = 0; l < ODO_MAX_LEVELS; l++) {
@@ -1021,7 +1032,7 @@ static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_de
   memcpy(a.init, m->init, sizeof(a.init));
     static unsigned long long* dbg_buf = [] {
       unsigned long long* p = nullptr;
-      if (getenv("ODO_COARSE_STAMPS") && hipHostMalloc((void**)&p, 1024, hipHostMallocMapped) == hipSuccess) memset(p, 0, 1024);
+      if (getenv("ODO_COARSE_STAMPS") && hipHostMalloc((void**)&p, 2048, hipHostMallocMapped) == hipSuccess) memset(p, 0, 2048);
       return p;
     }();
     a.dbg = dbg_buf;
@@ -1044,6 +1055,10 @@ static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_de
       fprintf(stderr, "[coarse stamps] per iteration: eval %.0f reduce %.0f state-machine %.0f cycles; iterations/launch %.2f, "
               "cycles/launch %.0f\n", (double)dbg_buf[0] / dbg_buf[3], (double)dbg_buf[1] / dbg_buf[3],
               (double)dbg_buf[2] / dbg_buf[3], (double)dbg_buf[3] / dbg_buf[5], (double)dbg_buf[4] / dbg_buf[5]);
+    if (dbg_buf && dbg_buf[132] > 0 && dbg_buf[132] % 100 == 0)
+      fprintf(stderr, "[fine stamps] per evaluation: eval + publish %.0f gather + fold %.0f state-machine %.0f cycles; evaluations/launch "
+              "%.2f, same-XCD launches %.0f %%\n", (double)dbg_buf[128] / dbg_buf[131], (double)dbg_buf[129] / dbg_buf[131],
+              (double)dbg_buf[130] / dbg_buf[131], (double)dbg_buf[131] / dbg_buf[132], 100.0 * (double)dbg_buf[133] / dbg_buf[132]);
     if (dbg_buf && dbg_buf[5] > 0 && dbg_buf[5] % 100 == 0 && dbg_buf[11] > 0)
       fprintf(stderr, "[state machine] decide %.0f solve %.0f exp/compose %.0f cycles per evaluation\n",
               (double)dbg_buf[8] / dbg_buf[11], (double)dbg_buf[9] / dbg_buf[11], (double)dbg_buf[10] / dbg_buf[11]);
@@ -1069,6 +1084,18 @@ static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_de
   }
   jb.grid = grid; jb.budget = budget; jb.min_level = min_level;
   jb.active = 1;
+  if (m->fine_k > 0 && budget > 0) {
+    // every level the coarse launch leaves in ONE persistent launch; it reports the result itself (nothing to pump)
+    a.st_in = st[jb.seq & 1]; a.st_out = st[(jb.seq + 1) & 1];
+    a.part_in = part[jb.seq & 1]; a.part_out = part[(jb.seq + 1) & 1];
+    a.seq = jb.seq; a.first_of_solve = (jb.seq == 0) ? 1 : 0;
+    a.span = lm_span_slot(m, jb.launches, false);
+    hipLaunchKernelGGL(lm_fine_kernel, dim3(8 * m->fine_k), dim3(kFineThreads), 0, s, a, m->fine_k, m->d_xbuf, m->fine_fault);
+    jb.seq++;
+    jb.launches++;
+    jb.issued_all = true;
+    jb.result_by_launch = true;
+  }
   return 0;
 }
 
@@ -1190,9 +1217,14 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
   // (fused pipeline) or the level (unfused pipeline) has ended. Stale launches are no-ops on the device either way.
   const bool fused = resumed || lm_fused_eligible(m);
   int seq = 0;
+  bool started = resumed;
+  const int fine_k_asked = m->fine_k;
+fused_again:
   if (fused) {
-    // ---- fused pipeline: identical generic step launches; the device walks the pyramid itself ----
-    if (!resumed && lm_fused_begin(m, kf_img, kf_dep, cur_img)) return -1;
+    // ---- fused pipeline: the coarse launch + one persistent launch (or identical generic step launches); the device walks
+    // the pyramid itself ----
+    if (!started && lm_fused_begin(m, kf_img, kf_dep, cur_img)) return -1;
+    started = true;
     lm_fused_pump(m, true);
     launches = m->job.launches;
     seq = m->job.seq;
@@ -1239,6 +1271,19 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     memcpy(m->h_out, m->h_res, sizeof(float) * 42);
+    if (m->h_out[16] == -2.0f && m->fine_k > 0) {
+      // The persistent launch gave up: one of its workgroups never showed up within the spin limit (they wait for each other,
+      // so all of them must be resident at once: another client of this GPU can hold the CUs they need). Nothing is lost but
+      // time: the same Solve again on the step launches, which need no co-residency; after three such Solves the optimiser
+      // stays on them.
+      m->fine_bails++;
+      m->fine_k = 0;
+      started = false;
+      launches = 0;
+      HIP_OK(hipStreamSynchronize(s));
+      goto fused_again;
+    }
+    if (fine_k_asked > 0 && m->fine_k == 0 && m->fine_bails < 3) m->fine_k = fine_k_asked;
     const int stop = m->job.stop_level;
     if (stop > 0 && m->h_out[16] == 0.0f) {
       // ---- hand-over: the fine levels are dense. The finishing launch left the state in d_state[2] (ordered before anything

@@ -1067,7 +1067,10 @@ def main():
             how = "a separate pass over the same frames with the execution span of every LM launch recorded (not the timed run)"
         achieved = ev["bytes"] / (total_us * 1e-6) / 1e9 if total_us > 0 else 0.0
         kernel_us_per_frame = total_us / n_frames_ev
-        roof = dict(bound="hbm", kernel="LM evaluation kernels (lm_coarse_kernel + lm_step_kernel)",
+        # one persistent launch per Solve (lm_fine_kernel) instead of a step launch per evaluation: as many as coarse launches
+        fine = step_launches <= 1.05 * max(ev["coarse_launches"], 1)
+        fine_key = "lm_fine_kernel" if fine else "lm_step_kernel"
+        roof = dict(bound="hbm", kernel="LM evaluation kernels (lm_coarse_kernel + %s)" % fine_key,
                     achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 6),
                     traffic=load_traffic()[0], traffic_source=load_traffic()[1], measured=how,
                     evaluations_per_frame=round(ev["active_launches"] / n_frames_ev, 2),
@@ -1076,14 +1079,22 @@ def main():
                     # the LM chain IS the frame (everything else overlaps it): the ratio sits at ~1, sampling noise of a few percent
                     kernel_time_over_step_time=round(kernel_us_per_frame / (elapsed / args.steps * 1e6), 3) if ev_timed is not None else None,
                     kernel_time_fits_in_step=bool(kernel_us_per_frame <= 1.03 * elapsed / args.steps * 1e6) if ev_timed is not None else None,
-                    lm_step_kernel=dict(launches_per_frame=round(step_launches / n_frames_ev, 2), launch_us=round(step_us, 3),
-                                        exec_span_us=round(step_span, 3),
-                                        algorithmic_bytes_per_launch=round((ev["bytes"]) / max(ev["active_launches"], 1), 1),
-                                        achieved=round(ev["bytes"] / max(ev["active_launches"], 1) / (step_us * 1e-6) / 1e9, 2) if step_us > 0 else None),
                     lm_coarse_kernel=dict(launches_per_frame=round(ev["coarse_launches"] / n_frames_ev, 2),
                                           launch_us=round(coarse_us, 2), exec_span_us=round(coarse_span, 2)),
                     note="single 1241x376 frame: the working set is cache resident and every evaluation is a serial chain "
                          "(solve, exp, 13-30k points); see roofline_dense_1080p for the HBM-bound shape")
+        if fine:
+            roof[fine_key] = dict(launches_per_frame=round(step_launches / n_frames_ev, 2), launch_us=round(step_span, 2),
+                                  exec_span_us=round(step_span, 2),
+                                  what="every evaluation of the levels the coarse launch leaves, in one persistent launch: 32 workgroups "
+                                       "of one XCD exchange their partial rows through L2 (DESIGN.md section 5.1); us per evaluation = "
+                                       "(coarse + fine) exec spans / evaluations_per_frame",
+                                  us_per_evaluation_both_kernels=round(kernel_us_per_frame / max(ev["active_launches"] / n_frames_ev, 1e-9), 2))
+        else:
+            roof[fine_key] = dict(launches_per_frame=round(step_launches / n_frames_ev, 2), launch_us=round(step_us, 3),
+                                  exec_span_us=round(step_span, 3),
+                                  algorithmic_bytes_per_launch=round((ev["bytes"]) / max(ev["active_launches"], 1), 1),
+                                  achieved=round(ev["bytes"] / max(ev["active_launches"], 1) / (step_us * 1e-6) / 1e9, 2) if step_us > 0 else None)
         evals = [ev["active_launches"] / n_frames_ev]
         tr0 = trk.time_residual(0, reps=100)   # evaluation-only kernel on level 0 (no LM update), for reference
         roof["eval_only_L0"] = dict(launch_us=round(tr0["mean_us"], 3), residuals=tr0["n_points"],

@@ -196,6 +196,11 @@ int odo_lm_points(const odo_lm* lm, int npts[ODO_MAX_LEVELS], int use_list[ODO_M
  * work, and the algorithmic bytes they touched (dense scan 12 B per interior
  * pixel, point list 32 B per point, plus the fp64 partials written). */
 int odo_lm_launch_stats(const odo_lm* lm, int* n_active_launches, int* n_total_launches, double* algorithmic_bytes);
+/* The persistent launch of the fine levels (lm_fine_kernel: every evaluation the coarse launch leaves in ONE launch whose
+ * workgroups exchange partial sums through L2): *workgroups = how many cooperate (0: off — this optimiser
+ * issues a step launch per evaluation, by choice (ODO_LM_NO_FINE) or after three fall-backs), *fallbacks = Solves whose persistent
+ * launch gave up waiting for one of its workgroups and that were redone on the step launches (results unaffected). */
+int odo_lm_persistent_stats(const odo_lm* lm, int* workgroups, int* fallbacks);
 
 /* Diagnostic: cycle-counter stamps at the phase boundaries of one LM update launch ("update kernel"). */
 int odo_debug_update_stamps(odo_lm* lm, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img, int level,

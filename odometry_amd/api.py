@@ -250,6 +250,12 @@ class LevenbergMarquardtOptimizer:
         L.check(self.ctx.lib.odo_lm_launch_stats(self.h, C.byref(a), C.byref(t), C.byref(b)), "odo_lm_launch_stats")
         return a.value, t.value, b.value
 
+    def persistent_stats(self):
+        """(workgroups of the persistent fine-level launch — 0: step launches —, Solves redone on the step launches)"""
+        k, f = C.c_int(0), C.c_int(0)
+        L.check(self.ctx.lib.odo_lm_persistent_stats(self.h, C.byref(k), C.byref(f)), "odo_lm_persistent_stats")
+        return k.value, f.value
+
     def close(self):
         if getattr(self, "h", None):
             self.ctx.lib.odo_lm_destroy(self.h)

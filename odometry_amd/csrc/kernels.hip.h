@@ -1526,7 +1526,7 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, int K, int w, un
         if (my_q < ODO_NACC) accq = rows_accumulate<kLmBlock, kS>(rows_sh, rowA, rowB, my_s, accq);
 #pragma unroll
         for (int o = kS / 2; o > 0; o >>= 1) accq += __shfl_xor(accq, o, kS);
-        if (my_q < ODO_NACC && my_s == 0 && !(fault && w == K - 1)) fine_publish(buf, vb, my_q, accq, tag, local);
+        if (my_q < ODO_NACC && my_s == 0 && !(fault && vb == 0)) fine_publish(buf, vb, my_q, accq, tag, local);   // fault: row 0 never appears
       }
     } else {
       const int rounds = (L.n + nblk * kLmBlock - 1) / (nblk * kLmBlock);  // > 1 only beyond 160 x 256 points (a round without

@@ -572,7 +572,7 @@ struct odo_lm {
   // on one XCD exchange their partial rows through d_xbuf. 0 = off (ODO_LM_NO_FINE: the step launches, kept for the batched Solve).
   int fine_k;
   int fine_bails;   // Solves whose persistent launch gave up and that were redone on the step launches
-  int fine_fault;   // test hook (ODO_LM_FINE_FAULT): the last workgroup of the persistent launch never publishes
+  int fine_fault;   // test hook (ODO_LM_FINE_FAULT): the first partial row of the persistent launch is never published
   unsigned long long* d_xbuf;
   int fused;  // 1 = one launch per evaluation (robust 0/1); 0 = separate residual / update kernels
   int mode;  // 0 auto (list when <= half of the interior has depth), 1 always dense scan, 2 always list
@@ -1836,6 +1836,12 @@ extern "C" int odo_lm_trace(const odo_lm* mc, odo_lm_trace_row* rows, int cap, i
   return 0;
 }
 
+extern "C" int odo_lm_persistent_stats(const odo_lm* m, int* workgroups, int* fallbacks) {
+  if (!m) return fail("odo_lm_persistent_stats: NULL lm");
+  if (workgroups) *workgroups = m->fine_k;
+  if (fallbacks) *fallbacks = m->fine_bails;
+  return 0;
+}
 extern "C" int odo_lm_launch_stats(const odo_lm* m, int* n_active, int* n_total, double* bytes) {
   if (!m) return fail("NULL lm");
   if (n_active) *n_active = m->last_evals;

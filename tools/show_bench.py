@@ -11,7 +11,8 @@ def show(lines):
         d = json.loads(line)
         r = d['roofline']
         print('fps', d['value'], 'ms', d['ms_per_step'], 'host', d['host_us_per_frame'])
-        print('step', r['lm_step_kernel'], 'coarse', r['lm_coarse_kernel'], 'evals', r['evaluations_per_frame'], 'kernel_us',
+        fk = 'lm_fine_kernel' if 'lm_fine_kernel' in r else 'lm_step_kernel'
+        print(fk, r[fk], 'coarse', r['lm_coarse_kernel'], 'evals', r['evaluations_per_frame'], 'kernel_us',
               r['kernel_us_per_frame'])
         print('pose delta', d.get('pose_max_abs_delta_vs_oracle'), 'cpu', d.get('cpu_baseline', {}).get('value'))
         dn = d.get('roofline_dense_1080p')

@@ -1289,7 +1289,7 @@ __global__ void __launch_bounds__(kLmBlock) lm_step_kernel_batch(const StepArgs*
 // measured in round 2: evaluation 4 100 -> 4 430 cycles, reduction 2 650 -> 3 960 per iteration: sixteen waves on one CU pay
 // more at the barriers than the second round costs.)
 constexpr int kCoarseBlock = ODO_COARSE_BLOCK;
-constexpr int kCoarseLdsBytes = kRowFloats * (kCoarseBlock + 8) * (int)sizeof(float);  // [14][512 + 8] floats: point rows
+constexpr int kCoarseLdsBytes = 2 * kRowFloats * (kLmBlock + 8) * (int)sizeof(float);  // [2][15][256 + 8] floats: point rows of two virtual blocks
 constexpr int kCoarseMaxPoints = 1024;  // levels with more points go to the multi-block step kernel (measured: a 512-thread
                                         // workgroup walking ~2000 points four per thread is no faster than seven blocks)
 
@@ -1318,9 +1318,17 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
   auto lap = [&](unsigned long long& sum) {
     if (a.dbg) { const unsigned long long now = __builtin_readcyclecounter(); sum += now - c_last; c_last = now; }
   };
-  float* rows_sh = (float*)red_sh;  // [14][512 + 8] floats
-  constexpr int kS = kCoarseBlock / 32;  // sub-lanes per quantity: 29 x 16 = 464 accumulating threads
-  const int my_q = threadIdx.x / kS, my_s = threadIdx.x % kS;
+  // Accumulation order = the step / fine kernels': virtual blocks of 256 points (29 x 8 sub-lane chains over every eighth row, an
+  // 8-lane butterfly), their 232-B partial rows folded segment by segment (lm_fused_prologue's order). A level therefore gives the
+  // same sums bit for bit whichever kernel evaluates it — the single tracker sends a 830-point level to the persistent launch,
+  // the batched one keeps it here. The two halves of the workgroup work on two virtual blocks at a time.
+  static_assert(kCoarseBlock == 2 * kLmBlock, "two 256-point virtual blocks per round");
+  constexpr int kS = 8;
+  constexpr int kVbMax = (kCoarseMaxPoints + kLmBlock - 1) / kLmBlock;
+  __shared__ double part_sh[kVbMax][32];
+  const int tl = threadIdx.x & (kLmBlock - 1), half = threadIdx.x >> 8;
+  float* rows_sh = (float*)red_sh + half * (kRowFloats * RowBuf<kLmBlock>::W);  // [2][15][256 + 8] floats
+  const int my_q = tl / kS, my_s = tl % kS;
   int rowA = 0, rowB = 0;
   if (my_q < ODO_NACC) rows_of_quantity(my_q, &rowA, &rowB);
   for (int guard = 0; guard < 4096; guard++) {
@@ -1331,31 +1339,50 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
     float T[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) T[i] = s_sh.T[i];
-    double accq = 0.0;
+    const int nvb = L.nblk;  // = ceil(n / 256), at least 1 (lm_grid_for)
     // (Keeping each thread's points in registers across iterations and staging the 29 KB level image in LDS was
     // measured: no faster. With 8 waves on one CU the evaluation is VALU-issue bound, not latency bound.)
-    for (int base = 0; base < L.n; base += kCoarseBlock) {  // one round per 512 points (kCoarseMaxPoints: two)
-      const int idx = base + threadIdx.x;
+    for (int vb0 = 0; vb0 < nvb; vb0 += 2) {  // one round per 512 points (kCoarseMaxPoints: two)
+      const int vb = vb0 + half;
+      const int idx = vb * kLmBlock + tl;
       float r = 0.0f, w = 0.0f, J[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
       bool valid = false;
-      if (idx < L.n) {
+      if (vb < nvb && idx < L.n) {
         const PointK p = load_point(L.pl, idx);
         if (point_residual(p, T, L.k, L.I2, L.rows, L.cols, &r, J)) {
           w = robust_weight(r, a.robust, a.huber_delta, 1.0f);
           valid = true;
         }
       }
-      if (base > 0) __syncthreads();  // the previous round's rows have been consumed
-      rows_store(rows_sh, RowBuf<kCoarseBlock>::W, threadIdx.x, J, w, r, valid);
+      if (vb0 > 0) __syncthreads();  // the previous round's rows have been consumed
+      rows_store(rows_sh, RowBuf<kLmBlock>::W, tl, J, w, r, valid);
       __syncthreads();  // rows visible (and, first round, everyone has read s_sh.T)
-      if (base == 0) lap(c_eval);
-      if (my_q < ODO_NACC) accq = rows_accumulate<kCoarseBlock, kS>(rows_sh, rowA, rowB, my_s, accq);
-    }
-    if (L.n <= 0) { __syncthreads(); lap(c_eval); }
+      if (vb0 == 0) lap(c_eval);
+      double accq = 0.0;
+      if (my_q < ODO_NACC) accq = rows_accumulate<kLmBlock, kS>(rows_sh, rowA, rowB, my_s, accq);
 #pragma unroll
-    for (int o = kS / 2; o > 0; o >>= 1) accq += __shfl_xor(accq, o, kS);
-    if (my_q < ODO_NACC && my_s == 0) acc_sh[my_q] = accq;
+      for (int o = kS / 2; o > 0; o >>= 1) accq += __shfl_xor(accq, o, kS);
+      if (vb < nvb && my_q < ODO_NACC && my_s == 0) part_sh[vb][my_q] = accq;
+    }
     __syncthreads();
+    {  // the fold of lm_fused_prologue: segment seg adds rows seg, seg + 8, ... in ascending order, then the segments in order
+      const int fq = threadIdx.x & 31, fseg = threadIdx.x >> 5;
+      double* fold_sh = red_sh;  // the rows have been consumed (barrier above)
+      if (fseg < 8) {
+        double v = 0.0;
+        if (fq < ODO_NACC)
+          for (int b = fseg; b < nvb; b += 8) v += part_sh[b][fq];
+        fold_sh[fseg * 32 + fq] = v;
+      }
+      __syncthreads();
+      if (threadIdx.x < ODO_NACC) {
+        double acc = 0.0;
+#pragma unroll
+        for (int g = 0; g < 8; g++) acc += fold_sh[g * 32 + threadIdx.x];
+        acc_sh[threadIdx.x] = acc;
+      }
+      __syncthreads();
+    }
     lap(c_red);
     lm_state_machine(true, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, acc_sh, a.trace, a.cost_stat, true,
                      a.dbg ? a.dbg + 8 : nullptr, a.stop_level);

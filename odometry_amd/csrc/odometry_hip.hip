@@ -1066,7 +1066,12 @@ static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_de
   double* part[2] = {m->d_partials, m->d_partials + (size_t)kLmMaxBlocks * ODO_NACC};
   // Coarse levels (few points) run inside one workgroup: one launch covers every level >= min_level.
   int min_level = m->n_levels;
-  static const int coarse_max = getenv("ODO_COARSE_MAX") ? atoi(getenv("ODO_COARSE_MAX")) : kCoarseMaxPoints;
+  // With the persistent launch behind it the coarse launch keeps only the levels that fit ONE round of its workgroup (512 points):
+  // a level of two rounds costs less as four virtual blocks on four CUs. Every kernel sums a level in the same order, so where a
+  // level runs does not show in the result.
+  static const int coarse_env = getenv("ODO_COARSE_MAX") ? atoi(getenv("ODO_COARSE_MAX")) : -1;
+  const int coarse_max = coarse_env >= 0 ? (coarse_env < kCoarseMaxPoints ? coarse_env : kCoarseMaxPoints)
+                                         : (m->fine_k > 0 ? kCoarseBlock : kCoarseMaxPoints);
   while (min_level > stop && m->npts[min_level - 1] <= coarse_max) min_level--;
   if (!m->coarse) min_level = m->n_levels;
   m->last_coarse = (min_level < m->n_levels) ? 1 : 0;

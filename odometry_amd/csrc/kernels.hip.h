@@ -1584,11 +1584,17 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, int K, int w, un
     lap(c_eval);
     // ---- (c): gather every row in the fold's order (lm_fused_prologue: segment seg adds rows seg, seg + 8, ... ascending) ----
     double v = 0.0;
+#ifndef ODO_FINE_RUDE_POLL
+    __builtin_amdgcn_s_setprio(0);  // waiting is not urgent: the depth stream's waves on this CU go first while we poll
+#endif
     if (fq < ODO_NACC && fseg < 8) {
       for (int b0 = fseg; b0 < nblk; b0 += 8 * kFineChunk) {
         FineG2 g2[kFineChunk];   // {hi granule, lo granule} of one double: one 16-byte load that bypasses L1
         bool all = false;
         for (int spin = 0; !all && spin < kFineSpinLimit; spin++) {
+#ifndef ODO_FINE_RUDE_POLL
+          if (spin > 0) __builtin_amdgcn_s_sleep(1);
+#endif
           all = true;
 #pragma unroll
           for (int u = 0; u < kFineChunk; u++) {
@@ -1609,6 +1615,7 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, int K, int w, un
         }
       }
     }
+    __builtin_amdgcn_s_setprio(3);
     if (fseg < 8) fold_sh[fseg * 32 + fq] = v;
     __syncthreads();
     if (t < ODO_NACC) {

@@ -1069,11 +1069,21 @@ static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_de
   // With the persistent launch behind it the coarse launch keeps only the levels that fit ONE round of its workgroup (512 points):
   // a level of two rounds costs less as four virtual blocks on four CUs. Every kernel sums a level in the same order, so where a
   // level runs does not show in the result.
+  // The persistent launch pays when its workgroups can hold a level's points in registers (<= 2 virtual blocks each); a level of
+  // more blocks (the point-list levels of a 1080p stream: 115 and 160) is better spread over 160 CUs by the step launches.
   static const int coarse_env = getenv("ODO_COARSE_MAX") ? atoi(getenv("ODO_COARSE_MAX")) : -1;
-  const int coarse_max = coarse_env >= 0 ? (coarse_env < kCoarseMaxPoints ? coarse_env : kCoarseMaxPoints)
-                                         : (m->fine_k > 0 ? kCoarseBlock : kCoarseMaxPoints);
-  while (min_level > stop && m->npts[min_level - 1] <= coarse_max) min_level--;
-  if (!m->coarse) min_level = m->n_levels;
+  bool fine_fits = m->fine_k > 0;
+  for (int pass = 0; pass < 2; pass++) {
+    const int coarse_max = coarse_env >= 0 ? (coarse_env < kCoarseMaxPoints ? coarse_env : kCoarseMaxPoints)
+                                           : (fine_fits ? kCoarseBlock : kCoarseMaxPoints);
+    min_level = m->n_levels;
+    while (min_level > stop && m->npts[min_level - 1] <= coarse_max) min_level--;
+    if (!m->coarse) min_level = m->n_levels;
+    if (!fine_fits) break;
+    for (int l = stop; l < min_level; l++)
+      if (a.lv[l].nblk > 2 * m->fine_k || a.lv[l].n > a.lv[l].nblk * kLmBlock) fine_fits = false;
+    if (fine_fits) break;   // else once more with the coarse launch's full reach
+  }
   m->last_coarse = (min_level < m->n_levels) ? 1 : 0;
   if (min_level < m->n_levels) {
     int coarse_budget = 0;
@@ -1089,7 +1099,7 @@ static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_de
   }
   jb.grid = grid; jb.budget = budget; jb.min_level = min_level;
   jb.active = 1;
-  if (m->fine_k > 0 && budget > 0) {
+  if (fine_fits && budget > 0) {
     // every level the coarse launch leaves in ONE persistent launch; it reports the result itself (nothing to pump)
     a.st_in = st[jb.seq & 1]; a.st_out = st[(jb.seq + 1) & 1];
     a.part_in = part[jb.seq & 1]; a.part_out = part[(jb.seq + 1) & 1];

@@ -1462,7 +1462,7 @@ __device__ __forceinline__ int fine_xcc_id() {
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
   return v & 0xf;
 }
-__device__ __forceinline__ void lm_fine_body(const StepArgs& a, int K, int w, unsigned long long* __restrict__ xbuf, int fault) {
+__device__ __forceinline__ void lm_fine_body(const StepArgs& a, int K, int w, unsigned long long* __restrict__ xbuf, int fault, int lo_level) {
   __builtin_amdgcn_s_setprio(3);  // see lm_coarse_kernel
   const int t = threadIdx.x, tl = t & (kLmBlock - 1), half = t >> 8;
   const bool publisher = (w == 0);
@@ -1519,8 +1519,8 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, int K, int w, un
     if (a.dbg) { const unsigned long long now = __builtin_readcyclecounter(); sum += now - c_last; c_last = now; }
   };
   for (int ev = 0; ev < 4096; ev++) {
-    const bool run = (s_sh.active != 0 && s_sh.status == 0 && !s_sh.finished && !bail_sh);  // block-uniform
-    if (!run) break;
+    const bool run = (s_sh.active != 0 && s_sh.status == 0 && !s_sh.finished && !bail_sh && s_sh.level >= lo_level);  // block-uniform
+    if (!run) break;   // (a level below lo_level has begun: the step launches behind this one carry on from the state it leaves)
     c_it++;
     const StepLevel& L = lv_sh[s_sh.level];
     const int nblk = L.nblk;
@@ -1641,9 +1641,10 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, int K, int w, un
   }
 }
 // grid = 8 * K blocks: every eighth block takes part (one XCD), the others return at once
-__global__ void __launch_bounds__(kFineThreads) lm_fine_kernel(StepArgs a, int K, unsigned long long* __restrict__ xbuf, int fault) {
+__global__ void __launch_bounds__(kFineThreads) lm_fine_kernel(StepArgs a, int K, unsigned long long* __restrict__ xbuf, int fault,
+                                                               int lo_level) {
   if ((blockIdx.x & 7u) != 0u) return;
-  lm_fine_body(a, K, (int)(blockIdx.x >> 3), xbuf, fault);
+  lm_fine_body(a, K, (int)(blockIdx.x >> 3), xbuf, fault, lo_level);
 }
 
 // End of a fused Solve when no step launch has reported it (no launch was issued at all, or the host is not polling):

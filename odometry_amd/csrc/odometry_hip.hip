@@ -1072,17 +1072,22 @@ static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_de
   // The persistent launch pays when its workgroups can hold a level's points in registers (<= 2 virtual blocks each); a level of
   // more blocks (the point-list levels of a 1080p stream: 115 and 160) is better spread over 160 CUs by the step launches.
   static const int coarse_env = getenv("ODO_COARSE_MAX") ? atoi(getenv("ODO_COARSE_MAX")) : -1;
-  bool fine_fits = m->fine_k > 0;
+  // fine_lo: the persistent launch takes levels [fine_lo, min_level) — the coarse-to-fine run of levels that fit below the
+  // coarse launch's; the levels under it (if any) follow on step launches, which read the state it leaves like they read the
+  // coarse launch's.
+  auto fits = [&](int l) { return a.lv[l].nblk <= 2 * m->fine_k && a.lv[l].n <= a.lv[l].nblk * kLmBlock; };
+  int fine_lo = m->n_levels;
   for (int pass = 0; pass < 2; pass++) {
+    const bool want_fine = m->fine_k > 0 && pass == 0;
     const int coarse_max = coarse_env >= 0 ? (coarse_env < kCoarseMaxPoints ? coarse_env : kCoarseMaxPoints)
-                                           : (fine_fits ? kCoarseBlock : kCoarseMaxPoints);
+                                           : (want_fine ? kCoarseBlock : kCoarseMaxPoints);
     min_level = m->n_levels;
     while (min_level > stop && m->npts[min_level - 1] <= coarse_max) min_level--;
     if (!m->coarse) min_level = m->n_levels;
-    if (!fine_fits) break;
-    for (int l = stop; l < min_level; l++)
-      if (a.lv[l].nblk > 2 * m->fine_k || a.lv[l].n > a.lv[l].nblk * kLmBlock) fine_fits = false;
-    if (fine_fits) break;   // else once more with the coarse launch's full reach
+    fine_lo = min_level;
+    if (!want_fine) break;
+    while (fine_lo > stop && fits(fine_lo - 1)) fine_lo--;
+    if (fine_lo < min_level) break;   // it takes at least the level under the coarse launch's; else the coarse launch's full reach
   }
   m->last_coarse = (min_level < m->n_levels) ? 1 : 0;
   if (min_level < m->n_levels) {
@@ -1097,20 +1102,25 @@ static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_de
     jb.seq++;
     jb.launches++;
   }
-  jb.grid = grid; jb.budget = budget; jb.min_level = min_level;
-  jb.active = 1;
-  if (fine_fits && budget > 0) {
-    // every level the coarse launch leaves in ONE persistent launch; it reports the result itself (nothing to pump)
+  int fine_budget = 0;
+  for (int l = fine_lo; l < min_level; l++) fine_budget += m->max_iters[l] > 0 ? m->max_iters[l] : 0;
+  if (fine_lo < min_level && fine_budget > 0) {
+    // levels [fine_lo, min_level) in ONE persistent launch; if they are the rest of the Solve it reports the result itself
+    budget -= fine_budget;
     a.st_in = st[jb.seq & 1]; a.st_out = st[(jb.seq + 1) & 1];
     a.part_in = part[jb.seq & 1]; a.part_out = part[(jb.seq + 1) & 1];
     a.seq = jb.seq; a.first_of_solve = (jb.seq == 0) ? 1 : 0;
     a.span = lm_span_slot(m, jb.launches, false);
-    hipLaunchKernelGGL(lm_fine_kernel, dim3(8 * m->fine_k), dim3(kFineThreads), 0, s, a, m->fine_k, m->d_xbuf, m->fine_fault);
+    hipLaunchKernelGGL(lm_fine_kernel, dim3(8 * m->fine_k), dim3(kFineThreads), 0, s, a, m->fine_k, m->d_xbuf, m->fine_fault, fine_lo);
     jb.seq++;
     jb.launches++;
-    jb.issued_all = true;
-    jb.result_by_launch = true;
+    if (fine_lo <= stop) {   // nothing left for step launches
+      jb.issued_all = true;
+      jb.result_by_launch = true;
+    }
   }
+  jb.grid = grid; jb.budget = budget; jb.min_level = min_level;
+  jb.active = 1;
   return 0;
 }
 

@@ -57,3 +57,40 @@ def test_product_does_not_import_the_oracle():
                 src = open(os.path.join(dp, fn)).read()
                 assert "oracle" not in src.replace("the oracle", "").replace("against the oracle", "") or fn == "odo_math.h", \
                     f"{fn} mentions the oracle"
+
+
+def test_kernel_register_budgets():
+    """Register budgets that are part of how the kernels share the chip (read from the built code object's metadata; no GPU needed).
+    lm_fine_kernel's 32 workgroups hold one CU each of an XCD for a whole Solve while the depth stream's kernels run on the same CUs:
+    at <= 208 VGPRs (two waves per SIMD = 416 of 512) the depth stream's 256-thread blocks still fit beside a workgroup; a build that
+    drifted to 247 had nothing left and the depth job of the next frame slowed from ~200 to ~400 us, past the frame time
+    (DESIGN.md section 5.1). No kernel may spill."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    from odometry_amd import _lib
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        pytest.skip("no ROCm LLVM tools here")
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        so = os.path.join(td, "lib.so")
+        shutil.copy(_lib.LIB_PATH, so)
+        subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", so], cwd=td, check=True, capture_output=True)
+        notes = ""
+        for f in sorted(os.listdir(td)):
+            if "gfx950" in f:
+                notes += subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", os.path.join(td, f)], check=True,
+                                        capture_output=True, text=True).stdout
+    kernels = {}
+    for blk in notes.split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk)
+        vg = re.search(r"\.vgpr_count:\s+(\d+)", blk)
+        sp = re.search(r"\.vgpr_spill_count:\s+(\d+)", blk)
+        if name and vg and sp:
+            kernels[name.group(1)] = (int(vg.group(1)), int(sp.group(1)))
+    assert len(kernels) > 40
+    spilling = {k: v for k, v in kernels.items() if v[1] > 0}
+    assert not spilling, spilling
+    fine = [v for k, v in kernels.items() if "lm_fine_kernel" in k]
+    assert len(fine) == 1 and fine[0][0] <= 208, fine

@@ -1072,7 +1072,8 @@ def main():
         fine_key = "lm_fine_kernel" if fine else "lm_step_kernel"
         roof = dict(bound="hbm", kernel="LM evaluation kernels (lm_coarse_kernel + %s)" % fine_key,
                     achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 6),
-                    traffic=load_traffic()[0], traffic_source=load_traffic()[1], measured=how,
+                    traffic=load_traffic("lm_fine_bytes_per_launch" if fine else "lm_residual_bytes_per_launch")[0],
+                    traffic_source=load_traffic()[1], measured=how,
                     evaluations_per_frame=round(ev["active_launches"] / n_frames_ev, 2),
                     algorithmic_bytes_per_frame=round(ev["bytes"] / n_frames_ev, 1),
                     kernel_us_per_frame=round(kernel_us_per_frame, 2),

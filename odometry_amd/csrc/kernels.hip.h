@@ -1753,7 +1753,13 @@ __device__ __forceinline__ void lm_finalize_body(const LmState* __restrict__ st,
 // =============================================================================================
 constexpr int kSelCap = 80;      // ref: src/depth_estimate.cpp:334
 constexpr int kSelBlocks = 512;  // 16 x 32 blocks, ref: :302
-constexpr int kSelThreads = 1024;
+// 512 threads (two keys per thread at KITTI's 874-pixel tiles): a 1024-thread block does not fit beside a workgroup of the
+// persistent LM launch on its CUs (4 waves per SIMD x 32 VGPRs against the 96 it leaves), so an eighth of the grid waited for the
+// Solve to end and the depth job ran 230 us instead of 205; alone the kernel takes 9.7 us either way (256 threads: 10.9).
+#ifndef ODO_SEL_THREADS
+#define ODO_SEL_THREADS 512
+#endif
+constexpr int kSelThreads = ODO_SEL_THREADS;
 constexpr int kSelMaxElems = 4096;
 
 // Point selection (ref: src/depth_estimate.cpp:300-342): one workgroup per 16x32 grid block.

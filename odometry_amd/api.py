@@ -587,6 +587,13 @@ class Tracker:
                     coarse_launches=int(o[5]), evaluations=int(o[6]), bytes=o[7], step_period_us=o[8], step_periods=int(o[9]),
                     coarse_period_us=o[10], coarse_periods=int(o[11]))
 
+    def persistent_stats(self):
+        """(workgroups of the pose LM's persistent fine-level launch — 0: step launches —, Solves redone on the step launches)"""
+        lm = C.c_void_p(self.lib.odo_tracker_lm(self.h))
+        k, f = C.c_int(0), C.c_int(0)
+        L.check(self.lib.odo_lm_persistent_stats(lm, C.byref(k), C.byref(f)), "odo_lm_persistent_stats")
+        return k.value, f.value
+
     def timing(self):
         out = (C.c_double * 4)()
         L.check(self.lib.odo_tracker_timing(self.h, out), "odo_tracker_timing")

@@ -5,9 +5,13 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as the
  * checker (or as the timed CPU baseline), never as the thing shipped or measured as the GPU path.
  *
- * PARITY UNPINNED, except the disparity scan.  orc_disparity_scan / ssd8 / cx_level below are checked bit for bit against
- * the reference's own lines (src/depth_estimate.cpp:380-395,435-453; include/image_processing_global.h:22-28), compiled from
- * /root/reference by oracle/make_ref_fixtures.py: tests/golden/ssd_ref.npz, cx_level_ref.npz, tests/test_ref_pin.py.
+ * PARITY UNPINNED, except: the disparity scan, its SSD tree and GetCxLevel (orc_disparity_scan / ssd8 / cx_level), the camera
+ * pyramid's intrinsic rule, and the accept / reject / lambda / stop schedules of both LM loops (lm_rule / orc_lm_schedule,
+ * depth_lm_rule / orc_depth_lm_schedule) are checked bit for bit against the reference's own lines
+ * (src/depth_estimate.cpp:92-96,141,150-161,167-168,380-395,435-453; include/image_processing_global.h:22-28;
+ * src/camera.cpp:61-65; src/lm_optimizer.cpp:110-115,117,131-143,154-155), compiled from /root/reference by
+ * oracle/make_ref_fixtures.py: tests/golden/ssd_ref.npz, cx_level_ref.npz, lm_schedule_ref.npz, depth_lm_schedule_ref.npz,
+ * tests/test_ref_pin.py.
  * For everything else: the reference (WangYuTum/odometry) cannot be built here (no Eigen, no OpenCV,
  * empty nanogui submodule, std::sqrtf) and none of its tests pins a numeric result, so this file is a
  * from-scratch restatement that follows the cited reference lines op for op.  Where the reference

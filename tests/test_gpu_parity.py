@@ -574,3 +574,33 @@ def test_persistent_launch_and_its_fallback_give_the_same_pose(monkeypatch):
     assert st == (0, 3)                        # three Solves were redone, the fourth went to the step launches directly
     for T in bad:
         assert np.array_equal(T, ref[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("keep,iters", [(1.0, [10, 20, 30, 30]), (0.45, [10, 20, 30, 30]), (0.12, [10, 20, 30, 30, 30]),
+                                        (0.45, [10, 20]), (0.03, [10, 20, 30, 30]), (1.0, [0, 20, 0, 30])])
+def test_lm_solve_across_keyframe_densities_and_pyramid_depths(api, O, kitti_seq, keep, iters):
+    """Which kernel runs which level depends on the keyframe's point counts (coarse launch: levels of one round of its workgroup;
+    persistent launch: the run of levels of <= 64 virtual blocks under it; step launches: what is left) — dense keyframes, sparse
+    ones, two to five pyramid levels, zero budgets: the evaluation trace and the pose match the oracle in every split, and the
+    persistent launch never falls back."""
+    from odometry_amd import synth
+    n = len(iters)
+    L0, L1 = kitti_seq["left"][0], kitti_seq["left"][1]
+    inv = synth.semi_dense_inverse_depth(kitti_seq["depth"][0], L0, stride_keep=keep, seed=3)
+    p0, d0, p1 = api.ImagePyramid(n, L0, True), api.DepthPyramid(n, inv, False), api.ImagePyramid(n, L1, True)
+    lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, iters, np.eye(4), None, 1, 28.0)
+    T = lm.Solve(p0, d0, p1)
+    ref = O.lm_solve(O.image_pyramid(L0, n, flat=True), O.depth_pyramid(inv, n, flat=True), O.image_pyramid(L1, n, flat=True),
+                     376, 1241, O.lm_params(max_iters=tuple(iters)))
+    assert lm.last_status == ref["status"] == 0
+    assert se3_log_norm(ref["pose"], T) < 1e-5
+    tr = lm.trace()
+    assert len(tr) == ref["n_evals"]
+    for a, b in zip(tr, ref["trace"]):
+        assert (a["level"], a["iter"], a["n_res"], a["accepted"], a["stop"]) == \
+               (b["level"], b["iter"], b["n_res"], b["accepted"], b["stop"])
+    npts, _ = lm.points()
+    st = lm.persistent_stats()
+    assert st[0] > 0 and st[1] == 0, (npts, st)
+    lm.close()

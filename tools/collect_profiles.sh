@@ -10,7 +10,8 @@
 set -u
 TAG=${1:-r02}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
-mkdir -p $OUT
+rm -rf $OUT   # (gpurun MERGES what a call writes into the caller's gpurun_out/: use a fresh tag per collection there, or delete
+mkdir -p $OUT  #  the local copy first — rocprofv3 names its files by PID, and PIDs repeat from box to box)
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $GRAFT_REPO_ROOT/bench.py --cpu-frames 0 --extras dense,disparity,single,batched"
 timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH --steps 1000 --warmup 50 > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err < /dev/null

@@ -907,6 +907,8 @@ struct StepArgs {
   LmState* st2[2];      // both state buffers: launch `seq` reads st2[seq & 1], writes st2[(seq + 1) & 1]
   double* part2[2];     // idem for the partial sums
   int min_level;        // lm_coarse_kernel: levels >= min_level run inside the workgroup (n_levels = none)
+  int fine_lo;          // lm_fine_kernel_batch: the persistent launch takes levels [fine_lo, min_level) (>= min_level: none)
+  unsigned long long* xbuf;  // ... and exchanges this sequence's partial rows through this buffer (kFineXbufWords words)
   // hand-over to the unfused pipeline (dense fine levels): the device stops walking the pyramid below stop_level, reports the
   // Solve "finished" there and leaves its state in final_state, from which the host carries on level by level
   int stop_level;       // 0: the fused pipeline covers every level
@@ -1462,11 +1464,12 @@ __device__ __forceinline__ int fine_xcc_id() {
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
   return v & 0xf;
 }
-__device__ __forceinline__ void lm_fine_body(const StepArgs& a, int K, int w, unsigned long long* __restrict__ xbuf, int fault, int lo_level) {
+__device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch& q, int K, int w, unsigned long long* __restrict__ xbuf,
+                                             int fault, int lo_level) {
   __builtin_amdgcn_s_setprio(3);  // see lm_coarse_kernel
   const int t = threadIdx.x, tl = t & (kLmBlock - 1), half = t >> 8;
   const bool publisher = (w == 0);
-  if (publisher && t == 0 && a.span) atomicMin(a.span, (unsigned long long)wall_clock64());
+  if (publisher && t == 0 && q.span) atomicMin(q.span, (unsigned long long)wall_clock64());
   __shared__ LmState s_sh;
   __shared__ double fold_sh[8 * 32];
   __shared__ double acc_sh[32];
@@ -1486,8 +1489,8 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, int K, int w, un
   }
   __syncthreads();
   // state in (left by the coarse launch, or initialised), a pending evaluation of an earlier launch consumed, pyramid walk started
-  lm_fused_prologue(a.st_in, a.part_in, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, fold_sh, acc_sh, a.trace, a.cost_stat,
-                    publisher, a.first_of_solve ? a.init : nullptr, a.stop_level);
+  lm_fused_prologue(q.st_in, q.part_in, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, fold_sh, acc_sh, a.trace, a.cost_stat,
+                    publisher, q.first_of_solve ? a.init : nullptr, a.stop_level);
   // does every workgroup of this launch share my XCD? (wave 0, lane i asks about workgroup i; the answer is the same everywhere)
   if (t < 64) {
     bool same = true, got = false;
@@ -1635,16 +1638,37 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, int K, int w, un
   if (bail_sh && t == 0) { s_sh.status = -2; s_sh.active = 0; s_sh.finished = 1; }   // -2: gave up waiting (the host redoes the Solve)
   __syncthreads();
   if (publisher) {
-    lm_fused_publish(s_sh, a.st_out, a.host_prog, a.seq, a.token, a.cost_stat, a.out, a.done_flag, a.final_state);
+    lm_fused_publish(s_sh, q.st_out, a.host_prog, q.seq, a.token, a.cost_stat, a.out, a.done_flag, a.final_state);
     if (a.dbg && t == 0) { a.dbg[128] += c_eval; a.dbg[129] += c_xchg; a.dbg[130] += c_sm; a.dbg[131] += c_it; a.dbg[132] += 1; a.dbg[133] += local ? 1 : 0; }
-    if (t == 0 && a.span) atomicMax(a.span + 1, (unsigned long long)wall_clock64());
+    if (t == 0 && q.span) atomicMax(q.span + 1, (unsigned long long)wall_clock64());
   }
 }
 // grid = 8 * K blocks: every eighth block takes part (one XCD), the others return at once
 __global__ void __launch_bounds__(kFineThreads) lm_fine_kernel(StepArgs a, int K, unsigned long long* __restrict__ xbuf, int fault,
                                                                int lo_level) {
   if ((blockIdx.x & 7u) != 0u) return;
-  lm_fine_body(a, K, (int)(blockIdx.x >> 3), xbuf, fault, lo_level);
+  const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve, a.span};
+  lm_fine_body(a, q, K, (int)(blockIdx.x >> 3), xbuf, fault, lo_level);
+}
+// Batched twin: the sequences of a batched Solve each get an XCD (sequence i: the blocks with blockIdx.x % 8 == i % 8; beyond
+// eight sequences two or more share an XCD, K workgroups each). grid = 8 * K * ceil(n / 8). A sequence whose levels do not
+// fit (fine_lo >= min_level) takes no part: its blocks return at once and its levels follow on the batched step launches.
+__global__ void __launch_bounds__(kFineThreads) lm_fine_kernel_batch(const StepArgs* __restrict__ table, int n, int K, int seq,
+                                                                     int first_of_solve, unsigned long long* span) {
+  const int r = (int)(blockIdx.x & 7u), wa = (int)(blockIdx.x >> 3);
+  const int i = (wa / K) * 8 + r, w = wa % K;
+  if (i >= n) return;
+  const StepArgs& a = table[i];
+  const StepLaunch q = {a.st2[seq & 1], a.st2[(seq + 1) & 1], a.part2[seq & 1], a.part2[(seq + 1) & 1], seq, first_of_solve,
+                        (i == 0) ? span : nullptr};
+  if (a.fine_lo >= a.min_level) {
+    // nothing to evaluate here, but the launch number is the whole batch's: one workgroup carries the sequence's state from this
+    // launch's input buffer to its output buffer (prologue + publish, no level at or above lo_level = none), as a step launch of a
+    // finished sequence does
+    if (w == 0) lm_fine_body(a, q, 1, 0, a.xbuf, 0, ODO_MAX_LEVELS_K + 1);
+    return;
+  }
+  lm_fine_body(a, q, K, w, a.xbuf, 0, a.fine_lo);
 }
 
 // End of a fused Solve when no step launch has reported it (no launch was issued at all, or the host is not polling):

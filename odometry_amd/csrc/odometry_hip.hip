@@ -66,6 +66,7 @@ struct odo_ctx {
   void *dense_h, *dense_d, *upd_h, *upd_d;   // DenseBatchItem / UpdItem [ODO_MAX_LEVELS][dense_cap]
   int dense_cap;
   struct LmBatchJob* lm_batch_job;   // the batched Solve in flight on this stream, if any
+  int batch_fine_bails;              // batched Solves whose persistent launch gave up (redone on the step launches; 3: stays off)
 };
 
 // ---- recycled device memory -------------------------------------------------------------------------------------------
@@ -1363,7 +1364,8 @@ fused_again:
 // Fills `a` for a fused Solve of `m` (everything that stays constant over the Solve's launches). Returns the grid the
 // step launches need, the launch budget of the step kernel and the first level the coarse kernel does not take.
 static void lm_fill_step_args(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* cur_img, int token, StepArgs* ap, int* grid_out,
-                              int* step_budget, int* min_level_out, double bytes_per_level[ODO_MAX_LEVELS]) {
+                              int* step_budget, int* min_level_out, double bytes_per_level[ODO_MAX_LEVELS], int fine_k = 0,
+                              int* fine_lo_out = nullptr) {
   StepArgs& a = *ap;
   memset(&a, 0, sizeof(a));
   a.n_levels = m->n_levels;
@@ -1389,16 +1391,31 @@ static void lm_fill_step_args(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* c
   memcpy(a.init, m->init, sizeof(a.init));
   a.st2[0] = m->d_state; a.st2[1] = m->d_state + 1;
   a.part2[0] = m->d_partials; a.part2[1] = m->d_partials + (size_t)kLmMaxBlocks * ODO_NACC;
-  int min_level = m->n_levels;
-  static const int coarse_max = getenv("ODO_COARSE_MAX") ? atoi(getenv("ODO_COARSE_MAX")) : kCoarseMaxPoints;
-  while (min_level > stop && m->npts[min_level - 1] <= coarse_max) min_level--;
-  if (!m->coarse) min_level = m->n_levels;
+  // which kernel takes which level: as in lm_fused_begin (fine_k workgroups per sequence in the batched persistent launch; 0: none)
+  static const int coarse_env = getenv("ODO_COARSE_MAX") ? atoi(getenv("ODO_COARSE_MAX")) : -1;
+  auto fits = [&](int l) { return a.lv[l].nblk <= 2 * fine_k && a.lv[l].n <= a.lv[l].nblk * kLmBlock; };
+  int min_level = m->n_levels, fine_lo = m->n_levels;
+  for (int pass = 0; pass < 2; pass++) {
+    const bool want_fine = fine_k > 0 && pass == 0;
+    const int coarse_max = coarse_env >= 0 ? (coarse_env < kCoarseMaxPoints ? coarse_env : kCoarseMaxPoints)
+                                           : (want_fine ? kCoarseBlock : kCoarseMaxPoints);
+    min_level = m->n_levels;
+    while (min_level > stop && m->npts[min_level - 1] <= coarse_max) min_level--;
+    if (!m->coarse) min_level = m->n_levels;
+    fine_lo = min_level;
+    if (!want_fine) break;
+    while (fine_lo > stop && fits(fine_lo - 1)) fine_lo--;
+    if (fine_lo < min_level) break;
+  }
   a.min_level = min_level;
-  int coarse_budget = 0;
-  for (int l = min_level; l < m->n_levels; l++) coarse_budget += m->max_iters[l] > 0 ? m->max_iters[l] : 0;
+  a.fine_lo = fine_lo;
+  a.xbuf = m->d_xbuf;
+  int above = 0;   // evaluations the coarse and the persistent launch can take
+  for (int l = fine_lo; l < m->n_levels; l++) above += m->max_iters[l] > 0 ? m->max_iters[l] : 0;
   *grid_out = grid;
-  *step_budget = budget - coarse_budget;
+  *step_budget = budget - above;
   *min_level_out = min_level;
+  if (fine_lo_out) *fine_lo_out = fine_lo;
 }
 
 // A batched Solve as a resumable job (one per context): lm_batch_begin fills and uploads the argument table and enqueues the
@@ -1415,6 +1432,8 @@ struct LmBatchJob {
   std::vector<std::vector<double>> bytes;
   int grid, budget, seq, launches, it;
   bool poll_ok, issued_all;
+  bool fine_used;   // this job has a batched persistent launch (lm_fine_kernel_batch)
+  bool fine_off_once = false;   // the next lm_batch_begin must not use it (redo after a launch that gave up)
 };
 static void lm_batch_job_free(odo_ctx* c) { delete c->lm_batch_job; c->lm_batch_job = nullptr; }
 
@@ -1490,18 +1509,28 @@ static int lm_batch_begin(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
   jb.lms.assign(lms, lms + n); jb.kf_img.assign(kf_img, kf_img + n); jb.kf_dep.assign(kf_dep, kf_dep + n); jb.cur_img.assign(cur_img, cur_img + n);
   jb.kf_img_ver.resize(n); jb.kf_dep_ver.resize(n); jb.cur_ver.resize(n); jb.reset_gen.resize(n); jb.tokens.resize(n);
   jb.bytes.assign(n, std::vector<double>(ODO_MAX_LEVELS, 0.0));
-  int grid = 1, budget = 0, any_coarse = 0;
+  // The batched persistent launch: every sequence on its own XCD (beyond eight, several per XCD with fewer workgroups each).
+  // ODO_LM_BATCH_FINE_K: workgroups per sequence (0 = off); default: what an XCD's 32 CUs allow, at most 16 from five sequences
+  // on — the depth front end of S >= 5 frames needs the other half of the chip while the workgroups wait for each other.
+  static const int fine_env = getenv("ODO_LM_BATCH_FINE_K") ? atoi(getenv("ODO_LM_BATCH_FINE_K")) : -1;
+  const int per_xcd = (n + 7) / 8;
+  int fine_k = (fine_env >= 0) ? fine_env : ((n <= 4) ? kFineKMax : kFineKMax / 2);
+  if (fine_k * per_xcd > kFineKMax) fine_k = kFineKMax / per_xcd;
+  if (cx->batch_fine_bails >= 3 || lms[0]->fine_k <= 0 || getenv("ODO_LM_NO_FINE")) fine_k = 0;
+  if (jb.fine_off_once) { fine_k = 0; jb.fine_off_once = false; }
+  int grid = 1, budget = 0, any_coarse = 0, any_fine = 0;
   for (int i = 0; i < n; i++) {
     odo_lm* m = lms[i];
     jb.kf_img_ver[i] = kf_img[i]->version; jb.kf_dep_ver[i] = kf_dep[i]->version; jb.cur_ver[i] = cur_img[i]->version;
     jb.reset_gen[i] = m->reset_gen;
     m->token = (m->token % 0x3ffff) + 1;
     jb.tokens[i] = m->token;
-    int g = 1, b = 0, ml = 0;
-    lm_fill_step_args(m, kf_img[i], cur_img[i], jb.tokens[i], &h_table[i], &g, &b, &ml, jb.bytes[i].data());
+    int g = 1, b = 0, ml = 0, fl = 0;
+    lm_fill_step_args(m, kf_img[i], cur_img[i], jb.tokens[i], &h_table[i], &g, &b, &ml, jb.bytes[i].data(), fine_k, &fl);
     if (g > grid) grid = g;
     if (b > budget) budget = b;
     if (ml < m->n_levels) any_coarse = 1;
+    if (fl < ml) any_fine = 1;
     m->last_coarse = (ml < m->n_levels) ? 1 : 0;
   }
   // the table of the previous batched Solve may still be read by its draining launches: order the upload behind them
@@ -1512,6 +1541,12 @@ static int lm_batch_begin(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
   if (any_coarse) {
     hipLaunchKernelGGL(lm_coarse_kernel_batch, dim3(1, n), dim3(kCoarseBlock), kCoarseLdsBytes, s, (const StepArgs*)d_table, jb.seq, 1,
                        lm_span_slot(lms[0], 0, true));
+    jb.seq++; jb.launches++;
+  }
+  jb.fine_used = any_fine != 0;
+  if (any_fine) {
+    hipLaunchKernelGGL(lm_fine_kernel_batch, dim3(8 * fine_k * per_xcd), dim3(kFineThreads), 0, s, (const StepArgs*)d_table, n, fine_k,
+                       jb.seq, (jb.seq == 0) ? 1 : 0, lm_span_slot(lms[0], jb.launches, false));
     jb.seq++; jb.launches++;
   }
   jb.active = 1;
@@ -1680,6 +1715,8 @@ static int lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
       return 0;
     }
   }
+  int redone = 0;
+collect_again:
   LmBatchJob& jb = *cx->lm_batch_job;
   lm_batch_pump(cx, true, idle, idle_arg);
   HIP_OK(hipGetLastError());
@@ -1715,6 +1752,20 @@ static int lm_solve_batch(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     memcpy(m->h_out, m->h_res, sizeof(float) * 42);
+  }
+  if (!redone && jb.fine_used) {
+    // a sequence's persistent workgroups gave up waiting for each other (status -2: they could not all be resident): the whole
+    // batched Solve again on the step launches — same results; after three such Solves this context stays on them
+    bool gave_up = false;
+    for (int i = 0; i < n; i++) gave_up = gave_up || lms[i]->h_out[16] == -2.0f;
+    if (gave_up) {
+      cx->batch_fine_bails++;
+      HIP_OK(hipStreamSynchronize(s));
+      jb.fine_off_once = true;
+      if (lm_batch_begin(n, lms, kf_img, kf_dep, cur_img) != 0) return fail("odo_lm_solve_batch: redo after a persistent launch gave up failed");
+      redone = 1;
+      goto collect_again;
+    }
   }
   if (stop > 0) {
     // ---- hand-over: the levels below `stop` are dense. Every stream whose fused part succeeded left its state in d_state[2];

@@ -1510,11 +1510,13 @@ static int lm_batch_begin(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
   jb.kf_img_ver.resize(n); jb.kf_dep_ver.resize(n); jb.cur_ver.resize(n); jb.reset_gen.resize(n); jb.tokens.resize(n);
   jb.bytes.assign(n, std::vector<double>(ODO_MAX_LEVELS, 0.0));
   // The batched persistent launch: every sequence on its own XCD (beyond eight, several per XCD with fewer workgroups each).
-  // ODO_LM_BATCH_FINE_K: workgroups per sequence (0 = off); default: what an XCD's 32 CUs allow, at most 16 from five sequences
-  // on — the depth front end of S >= 5 frames needs the other half of the chip while the workgroups wait for each other.
+  // ODO_LM_BATCH_FINE_K: workgroups per sequence (0 = off); default 32 (an XCD's CUs) up to four sequences, 16 up to eight, 8
+  // beyond — the depth front end of that many frames needs most of the chip while the workgroups wait for each other
+  // (measured, frames/s at S = 4 / 8 / 11: 32 workgroups 8 850 / 12 130 / —, 16: 8 100 / 12 580 / 10 100, 8: 8 140 / 12 780 / 13 230,
+  // none: 7 930 / 12 320 / 12 830).
   static const int fine_env = getenv("ODO_LM_BATCH_FINE_K") ? atoi(getenv("ODO_LM_BATCH_FINE_K")) : -1;
   const int per_xcd = (n + 7) / 8;
-  int fine_k = (fine_env >= 0) ? fine_env : ((n <= 4) ? kFineKMax : kFineKMax / 2);
+  int fine_k = (fine_env >= 0) ? fine_env : ((n <= 4) ? kFineKMax : (n <= 8) ? kFineKMax / 2 : kFineKMax / 4);
   if (fine_k * per_xcd > kFineKMax) fine_k = kFineKMax / per_xcd;
   if (cx->batch_fine_bails >= 3 || lms[0]->fine_k <= 0 || getenv("ODO_LM_NO_FINE")) fine_k = 0;
   if (jb.fine_off_once) { fine_k = 0; jb.fine_off_once = false; }

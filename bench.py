@@ -557,7 +557,9 @@ def batched_sequences_leg(api, seqs, counts=(1, 2, 4, 8), passes=3):
             n_step = max(es["launches"] - es["coarse_launches"], 1)
             total_us = step_us * n_step + coarse_us * es["coarse_launches"]
             ach = es["bytes"] / (total_us * 1e-6) / 1e9
-            roof = dict(kernel="lm_step_kernel_batch (+ lm_coarse_kernel_batch)", bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS,
+            roof = dict(kernel="lm_coarse_kernel_batch + lm_fine_kernel_batch (every sequence's persistent launch on its own XCD) + what "
+                               "is left of lm_step_kernel_batch; 'step' below = every launch that is not the coarse one", bound="hbm",
+                        unit="GB/s", peak=HBM_PEAK_GBS,
                         achieved=round(ach, 2), frac=round(ach / HBM_PEAK_GBS, 5),
                         step_launch_us=round(step_us, 2), coarse_launch_us=round(coarse_us, 1),
                         step_launches_per_lock_step=round(n_step / (passes * (n_frames - 1)), 2),

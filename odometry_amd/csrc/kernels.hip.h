@@ -909,6 +909,7 @@ struct StepArgs {
   int min_level;        // lm_coarse_kernel: levels >= min_level run inside the workgroup (n_levels = none)
   int fine_lo;          // lm_fine_kernel_batch: the persistent launch takes levels [fine_lo, min_level) (>= min_level: none)
   unsigned long long* xbuf;  // ... and exchanges this sequence's partial rows through this buffer (kFineXbufWords words)
+  unsigned fine_epoch;       // tags of the exchange: (fine_epoch << 8) + evaluation; the host never repeats an epoch on a buffer it has not cleared
   // hand-over to the unfused pipeline (dense fine levels): the device stops walking the pyramid below stop_level, reports the
   // Solve "finished" there and leaves its state in final_state, from which the host carries on level by level
   int stop_level;       // 0: the fused pipeline covers every level
@@ -1477,7 +1478,7 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
   __shared__ float rows_sh2[2][kRowFloats * RowBuf<kLmBlock>::W];
   __shared__ int bail_sh, local_sh;
   float* rows_sh = rows_sh2[half];
-  const unsigned tag_base = (unsigned)a.token << 8;
+  const unsigned tag_base = a.fine_epoch << 8;   // unique per launch on this buffer (lm_fine_next_epoch): a stale granule cannot pass for a new one
   unsigned long long* place = xbuf + 2 * kFineRowsMax * kFineGran;  // [K] {xcc id, token} words
   if (t == 0) {
 #pragma unroll

@@ -573,6 +573,7 @@ struct odo_lm {
   // on one XCD exchange their partial rows through d_xbuf. 0 = off (ODO_LM_NO_FINE: the step launches, kept for the batched Solve).
   int fine_k;
   int fine_bails;   // Solves whose persistent launch gave up and that were redone on the step launches
+  unsigned fine_epoch;  // tag epoch of the exchange buffer (lm_fine_next_epoch)
   int fine_fault;   // test hook (ODO_LM_FINE_FAULT): the first partial row of the persistent launch is never published
   unsigned long long* d_xbuf;
   int fused;  // 1 = one launch per evaluation (robust 0/1); 0 = separate residual / update kernels
@@ -982,6 +983,17 @@ static inline int lm_job_progress(const odo_lm* m) {
 }
 static inline bool lm_job_finished(const odo_lm* m) { return ((volatile int*)m->h_prog)[1] == m->job.token; }
 
+// The exchange buffer's tags are (epoch << 8) + evaluation. An epoch is used for one launch; when the 24 bits are exhausted the
+// buffer is cleared on the stream (tag 0 = never valid) before they start over, so a granule left by an old launch — a row beyond
+// the levels of every Solve since — can never carry the tag a new launch waits for.
+static unsigned lm_fine_next_epoch(odo_lm* m) {
+  if (++m->fine_epoch >= (1u << 24)) {
+    (void)hipMemsetAsync(m->d_xbuf, 0, sizeof(unsigned long long) * kFineXbufWords, m->ctx->stream);
+    m->fine_epoch = 1;
+  }
+  return m->fine_epoch;
+}
+
 // Lowest level of the coarse-to-fine run of point-list levels the fused pipeline can take (it starts at the coarsest level):
 // 0 = the whole Solve, n_levels = nothing (the Solve runs on the unfused pipeline from the start).
 static int lm_fused_stop_level(const odo_lm* m) {
@@ -1112,6 +1124,7 @@ static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_de
     a.part_in = part[jb.seq & 1]; a.part_out = part[(jb.seq + 1) & 1];
     a.seq = jb.seq; a.first_of_solve = (jb.seq == 0) ? 1 : 0;
     a.span = lm_span_slot(m, jb.launches, false);
+    a.fine_epoch = lm_fine_next_epoch(m);
     hipLaunchKernelGGL(lm_fine_kernel, dim3(8 * m->fine_k), dim3(kFineThreads), 0, s, a, m->fine_k, m->d_xbuf, m->fine_fault, fine_lo);
     jb.seq++;
     jb.launches++;
@@ -1410,6 +1423,7 @@ static void lm_fill_step_args(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* c
   a.min_level = min_level;
   a.fine_lo = fine_lo;
   a.xbuf = m->d_xbuf;
+  a.fine_epoch = (fine_lo < min_level) ? lm_fine_next_epoch(m) : 0u;   // (a sequence that only carries its state exchanges nothing)
   int above = 0;   // evaluations the coarse and the persistent launch can take
   for (int l = fine_lo; l < m->n_levels; l++) above += m->max_iters[l] > 0 ? m->max_iters[l] : 0;
   *grid_out = grid;

@@ -1421,7 +1421,7 @@ __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel_batch(const Ste
 // coarse kernel does not take. Per evaluation every workgroup (a) evaluates its virtual blocks — virtual block vb is exactly the
 // step kernel's block vb: points vb * 256 + t (+ rounds), the same row publication and the same 29 x 8 accumulation, so the 232-B
 // partial row of a virtual block is bit for bit the step kernel's — (b) publishes each row as 58 data-tagged 8-byte granules
-// {32 bits of payload, 32-bit tag = Solve token and evaluation number} with agent-scope (write-through) stores, (c) gathers ALL
+// {32 bits of payload, 32-bit tag = launch epoch of the buffer and evaluation number} with plain (or agent-scope) stores, (c) gathers ALL
 // rows by polling the granules themselves with agent-scope loads — no flag, no fence, one trip through L2 (MI355X guide,
 // handoff-1to1: 0.8-1.0 us; tools/microbench/xcd_allgather.hip: 0.8-1.3 us for 4-16 workgroups) — in the fold's own access
 // pattern (thread (q, seg) reads rows seg, seg + 8, ... of quantity q and adds them in that order: lm_fused_prologue's fold),
@@ -1479,7 +1479,7 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
   __shared__ int bail_sh, local_sh;
   float* rows_sh = rows_sh2[half];
   const unsigned tag_base = a.fine_epoch << 8;   // unique per launch on this buffer (lm_fine_next_epoch): a stale granule cannot pass for a new one
-  unsigned long long* place = xbuf + 2 * kFineRowsMax * kFineGran;  // [K] {xcc id, token} words
+  unsigned long long* place = xbuf + 2 * kFineRowsMax * kFineGran;  // [K] {xcc id, launch epoch} words
   if (t == 0) {
 #pragma unroll
     for (int l = 0; l < ODO_MAX_LEVELS_K; l++) lv_sh[l] = a.lv[l];

@@ -199,7 +199,8 @@ int odo_lm_launch_stats(const odo_lm* lm, int* n_active_launches, int* n_total_l
 /* The persistent launch of the fine levels (lm_fine_kernel: every evaluation the coarse launch leaves in ONE launch whose
  * workgroups exchange partial sums through L2): *workgroups = how many cooperate (0: off — this optimiser
  * issues a step launch per evaluation, by choice (ODO_LM_NO_FINE) or after three fall-backs), *fallbacks = Solves whose persistent
- * launch gave up waiting for one of its workgroups and that were redone on the step launches (results unaffected). */
+ * launch gave up waiting for one of its workgroups and that were redone on the step launches (results unaffected): this
+ * optimiser's own Solves plus the batched Solves (odo_lm_solve_batch, odo_tracker_batch) of its context. */
 int odo_lm_persistent_stats(const odo_lm* lm, int* workgroups, int* fallbacks);
 
 /* Diagnostic: cycle-counter stamps at the phase boundaries of one LM update launch ("update kernel"). */

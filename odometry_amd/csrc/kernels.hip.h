@@ -1655,7 +1655,7 @@ __global__ void __launch_bounds__(kFineThreads) lm_fine_kernel(StepArgs a, int K
 // eight sequences two or more share an XCD, K workgroups each). grid = 8 * K * ceil(n / 8). A sequence whose levels do not
 // fit (fine_lo >= min_level) takes no part: its blocks return at once and its levels follow on the batched step launches.
 __global__ void __launch_bounds__(kFineThreads) lm_fine_kernel_batch(const StepArgs* __restrict__ table, int n, int K, int seq,
-                                                                     int first_of_solve, unsigned long long* span) {
+                                                                     int first_of_solve, unsigned long long* span, int fault) {
   const int r = (int)(blockIdx.x & 7u), wa = (int)(blockIdx.x >> 3);
   const int i = (wa / K) * 8 + r, w = wa % K;
   if (i >= n) return;
@@ -1669,7 +1669,7 @@ __global__ void __launch_bounds__(kFineThreads) lm_fine_kernel_batch(const StepA
     if (w == 0) lm_fine_body(a, q, 1, 0, a.xbuf, 0, ODO_MAX_LEVELS_K + 1);
     return;
   }
-  lm_fine_body(a, q, K, w, a.xbuf, 0, a.fine_lo);
+  lm_fine_body(a, q, K, w, a.xbuf, fault, a.fine_lo);
 }
 
 // End of a fused Solve when no step launch has reported it (no launch was issued at all, or the host is not polling):

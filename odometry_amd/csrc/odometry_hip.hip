@@ -1562,7 +1562,7 @@ static int lm_batch_begin(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
   jb.fine_used = any_fine != 0;
   if (any_fine) {
     hipLaunchKernelGGL(lm_fine_kernel_batch, dim3(8 * fine_k * per_xcd), dim3(kFineThreads), 0, s, (const StepArgs*)d_table, n, fine_k,
-                       jb.seq, (jb.seq == 0) ? 1 : 0, lm_span_slot(lms[0], jb.launches, false));
+                       jb.seq, (jb.seq == 0) ? 1 : 0, lm_span_slot(lms[0], jb.launches, false), lms[0]->fine_fault);
     jb.seq++; jb.launches++;
   }
   jb.active = 1;
@@ -1931,7 +1931,7 @@ extern "C" int odo_lm_trace(const odo_lm* mc, odo_lm_trace_row* rows, int cap, i
 extern "C" int odo_lm_persistent_stats(const odo_lm* m, int* workgroups, int* fallbacks) {
   if (!m) return fail("odo_lm_persistent_stats: NULL lm");
   if (workgroups) *workgroups = m->fine_k;
-  if (fallbacks) *fallbacks = m->fine_bails;
+  if (fallbacks) *fallbacks = m->fine_bails + m->ctx->batch_fine_bails;   // its own Solves + its context's batched Solves
   return 0;
 }
 extern "C" int odo_lm_launch_stats(const odo_lm* m, int* n_active, int* n_total, double* bytes) {

@@ -441,3 +441,41 @@ def test_two_batched_trackers_interleaved(api, drives):
                 assert res[i]["new_keyframe"] == ref["new_keyframe"]
     for tb in tbs:
         tb.close()
+
+
+def test_batched_persistent_launch_falls_back_without_changing_a_pose(api, kitti_seq, monkeypatch):
+    """The batched Solve runs every sequence's fine levels in one persistent launch (a sequence per XCD). With a partial row that
+    never appears (ODO_LM_FINE_FAULT) the sequences' workgroups give up within their spin limit, the whole batched Solve is run
+    again on the step launches, and after three such Solves the context stays on them — poses equal the undisturbed ones bit for
+    bit every time."""
+    from odometry_amd import synth
+    L, Z = kitti_seq["left"], kitti_seq["depth"]
+    inv = synth.semi_dense_inverse_depth(Z[0], L[0], stride_keep=0.4, seed=1)
+    p0, d0 = api.ImagePyramid(4, L[0], True), api.DepthPyramid(4, inv, False)
+    curs = [api.ImagePyramid(4, L[k], True) for k in (1, 2)]
+
+    def run(n_calls):
+        ctx = api.Context(0)
+        lms = [api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 1, 28.0, ctx=ctx) for _ in range(2)]
+        kf = [api.ImagePyramid(4, L[0], True, ctx=ctx)] * 2
+        kd = [api.DepthPyramid(4, inv, False, ctx=ctx)] * 2
+        cu = [api.ImagePyramid(4, L[k], True, ctx=ctx) for k in (1, 2)]
+        out = []
+        for _ in range(n_calls):
+            poses, status = api.solve_batch(lms, kf, kd, cu)
+            assert status == [0, 0]
+            out.append([p.copy() for p in poses])
+        st = lms[0].persistent_stats()
+        for o in lms:
+            o.close()
+        return out, st
+
+    ref, st = run(1)
+    assert st[1] == 0
+    monkeypatch.setenv("ODO_LM_FINE_FAULT", "1")
+    got, st = run(5)
+    assert st[1] == 3                      # three batched Solves were redone, then the context stayed on the step launches
+    for poses in got:
+        for a, b in zip(poses, ref[0]):
+            assert np.array_equal(a, b)
+    del p0, d0, curs

@@ -570,7 +570,7 @@ struct odo_lm {
   float* h_res; float* d_res_map; int* h_done; int* d_done; int token;  // host-mapped result + completion word
   int coarse;  // 1 = levels with <= kCoarseMaxPoints points run inside one workgroup (fused pipeline)
   // Fine point-list levels in ONE persistent launch (lm_fine_kernel) instead of a step launch per evaluation: fine_k workgroups
-  // on one XCD exchange their partial rows through d_xbuf. 0 = off (ODO_LM_NO_FINE: the step launches, kept for the batched Solve).
+  // on one XCD exchange their partial rows through d_xbuf. 0 = off (ODO_LM_NO_FINE: step launches; also the fall-back). The batched Solve has its own launch (lm_fine_kernel_batch).
   int fine_k;
   int fine_bails;   // Solves whose persistent launch gave up and that were redone on the step launches
   unsigned fine_epoch;  // tag epoch of the exchange buffer (lm_fine_next_epoch)

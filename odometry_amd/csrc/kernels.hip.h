@@ -832,17 +832,26 @@ __device__ __forceinline__ void lm_apply_step_wave(LmState* s, int max_iters) {
 // the LDS traffic and 47 fewer instructions in the evaluation itself. A point that is skipped publishes a zero row.
 // ---------------------------------------------------------------------------------------------
 constexpr int kRowFloats = 15;  // rows 0..5 J, 6..11 JW, 12 r, 13 rw, 14 valid (1 / 0: its square sums to the count)
-template <int T> struct RowBuf { static constexpr int W = T + 8; static constexpr int kBytes = kRowFloats * W * (int)sizeof(float); };
+// Layout of one row: the value of point t sits at (t % S) * (T / S + 4) + t / S — the T / S values a sub-lane s sums (points s, s + S,
+// ...) are contiguous and 16-byte aligned, so its chain reads them as T / S / 4 ds_read_b128 instead of T / S ds_read_b32 per
+// operand; the stride T / S + 4 = 36 keeps the stores of a wave (64 consecutive points) on distinct banks two by two.
+constexpr int kRowSub = 8;      // S: sub-lanes per quantity in every kernel (one accumulation order everywhere)
+template <int T> struct RowBuf {
+  static constexpr int kStride = T / kRowSub + 4;
+  static constexpr int W = kRowSub * kStride;
+  static constexpr int kBytes = kRowFloats * W * (int)sizeof(float);
+};
 
 __device__ __forceinline__ void rows_store(float* __restrict__ rows, int W, int t, const float J[6], float w, float r, bool valid) {
+  const int p = (t % kRowSub) * (W / kRowSub) + t / kRowSub;
 #pragma unroll
   for (int a = 0; a < 6; a++) {
-    rows[a * W + t] = valid ? J[a] : 0.0f;
-    rows[(6 + a) * W + t] = valid ? J[a] * w : 0.0f;
+    rows[a * W + p] = valid ? J[a] : 0.0f;
+    rows[(6 + a) * W + p] = valid ? J[a] * w : 0.0f;
   }
-  rows[12 * W + t] = valid ? r : 0.0f;
-  rows[13 * W + t] = valid ? r * w : 0.0f;
-  rows[14 * W + t] = valid ? 1.0f : 0.0f;
+  rows[12 * W + p] = valid ? r : 0.0f;
+  rows[13 * W + p] = valid ? r * w : 0.0f;
+  rows[14 * W + p] = valid ? 1.0f : 0.0f;
 }
 // Which two rows quantity q multiplies: q < 21: (JW[a], J[b]) for the upper triangle in row-major order;
 // 21..26: (JW[a], r); 27: (rw, r); 28: (valid, valid) = the number of residuals.
@@ -854,14 +863,21 @@ __device__ __forceinline__ void rows_of_quantity(int q, int* rowA, int* rowB) {
   else if (q == 27) { *rowA = 13; *rowB = 12; }
   else { *rowA = 14; *rowB = 14; }
 }
-// One round: thread (q, s), t = q * S + s < 29 * S, adds the products of the points s, s + S, ... of the block.
+// One round: thread (q, s), t = q * S + s < 29 * S, adds the products of the points s, s + S, ... of the block, in that order.
 template <int T, int S>
 __device__ __forceinline__ double rows_accumulate(const float* __restrict__ rows, int rowA, int rowB, int s, double acc) {
+  static_assert(S == kRowSub && (T / S) % 4 == 0, "the row layout is built for S sub-lanes");
   constexpr int W = RowBuf<T>::W;
-  const float* A = rows + rowA * W + s;
-  const float* B = rows + rowB * W + s;
-#pragma unroll 8
-  for (int i = 0; i < T / S; i++) acc = fma((double)A[i * S], (double)B[i * S], acc);
+  const float4* A = (const float4*)(rows + rowA * W + s * RowBuf<T>::kStride);
+  const float4* B = (const float4*)(rows + rowB * W + s * RowBuf<T>::kStride);
+#pragma unroll
+  for (int i = 0; i < T / S / 4; i++) {
+    const float4 a = A[i], b = B[i];
+    acc = fma((double)a.x, (double)b.x, acc);
+    acc = fma((double)a.y, (double)b.y, acc);
+    acc = fma((double)a.z, (double)b.z, acc);
+    acc = fma((double)a.w, (double)b.w, acc);
+  }
   return acc;
 }
 
@@ -1292,7 +1308,7 @@ __global__ void __launch_bounds__(kLmBlock) lm_step_kernel_batch(const StepArgs*
 // measured in round 2: evaluation 4 100 -> 4 430 cycles, reduction 2 650 -> 3 960 per iteration: sixteen waves on one CU pay
 // more at the barriers than the second round costs.)
 constexpr int kCoarseBlock = ODO_COARSE_BLOCK;
-constexpr int kCoarseLdsBytes = 2 * kRowFloats * (kLmBlock + 8) * (int)sizeof(float);  // [2][15][256 + 8] floats: point rows of two virtual blocks
+constexpr int kCoarseLdsBytes = 2 * RowBuf<kLmBlock>::kBytes;  // [2][15][288] floats: point rows of two virtual blocks
 constexpr int kCoarseMaxPoints = 1024;  // levels with more points go to the multi-block step kernel (measured: a 512-thread
                                         // workgroup walking ~2000 points four per thread is no faster than seven blocks)
 

@@ -1576,6 +1576,8 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
         if (my_q < ODO_NACC && my_s == 0 && !(fault && vb == 0)) fine_publish(buf, vb, my_q, accq, tag, local);   // fault: row 0 never appears
       }
     } else {
+      // (Not reached today: the host sends only levels that fit, lm_fused_begin / lm_fill_step_args fits(). Kept as the general form
+      //  — and because without it the register allocator gives this kernel 245 VGPRs instead of 203, see test_kernel_register_budgets.)
       const int rounds = (L.n + nblk * kLmBlock - 1) / (nblk * kLmBlock);  // > 1 only beyond 160 x 256 points (a round without
       for (int vb0 = w; vb0 < nblk; vb0 += 2 * K) {                        //  points adds zero rows: the sums do not change)
         const int vb = vb0 + half * K;
@@ -1604,17 +1606,13 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
     lap(c_eval);
     // ---- (c): gather every row in the fold's order (lm_fused_prologue: segment seg adds rows seg, seg + 8, ... ascending) ----
     double v = 0.0;
-#ifndef ODO_FINE_RUDE_POLL
     __builtin_amdgcn_s_setprio(0);  // waiting is not urgent: the depth stream's waves on this CU go first while we poll
-#endif
     if (fq < ODO_NACC && fseg < 8) {
       for (int b0 = fseg; b0 < nblk; b0 += 8 * kFineChunk) {
         FineG2 g2[kFineChunk];   // {hi granule, lo granule} of one double: one 16-byte load that bypasses L1
         bool all = false;
         for (int spin = 0; !all && spin < kFineSpinLimit; spin++) {
-#ifndef ODO_FINE_RUDE_POLL
           if (spin > 0) __builtin_amdgcn_s_sleep(1);
-#endif
           all = true;
 #pragma unroll
           for (int u = 0; u < kFineChunk; u++) {

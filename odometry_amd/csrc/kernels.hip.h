@@ -863,6 +863,21 @@ __device__ __forceinline__ void rows_of_quantity(int q, int* rowA, int* rowB) {
   else if (q == 27) { *rowA = 13; *rowB = 12; }
   else { *rowA = 14; *rowB = 14; }
 }
+// The butterfly over the eight sub-lanes of a quantity (xor 4, then 2, then 1 — the order is part of the sums' bits) on DPP instead
+// of ds_bpermute: quad_perm for xor 1 and xor 2; xor 4 = row_shl:4 for the lanes whose bit 2 is clear, row_shr:4 for the others
+// (both sources lie inside the lane's row of 16). Three dependent ~110-cycle trips through the LDS crossbar become ~15 VALU moves.
+template <int CTRL> __device__ __forceinline__ double dpp_d(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double rows_butterfly8(double acc) {
+  const double up = dpp_d<0x104>(acc), dn = dpp_d<0x114>(acc);   // row_shl:4: lane i <- i + 4; row_shr:4: lane i <- i - 4
+  acc += (threadIdx.x & 4) ? dn : up;                            // xor 4
+  acc += dpp_d<0x4E>(acc);                                       // quad_perm [2, 3, 0, 1]: xor 2
+  acc += dpp_d<0xB1>(acc);                                       // quad_perm [1, 0, 3, 2]: xor 1
+  return acc;
+}
 // One round: thread (q, s), t = q * S + s < 29 * S, adds the products of the points s, s + S, ... of the block, in that order.
 template <int T, int S>
 __device__ __forceinline__ double rows_accumulate(const float* __restrict__ rows, int rowA, int rowB, int s, double acc) {
@@ -1269,8 +1284,7 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const StepLaunch
       __syncthreads();
       if (my_q < ODO_NACC) accq = rows_accumulate<kLmBlock, kS>(rows_sh, rowA, rowB, my_s, accq);
     }
-#pragma unroll
-    for (int o = kS / 2; o > 0; o >>= 1) accq += __shfl_xor(accq, o, kS);
+    accq = rows_butterfly8(accq);
     if (my_q < ODO_NACC && my_s == 0) q.part_out[(size_t)blockIdx.x * ODO_NACC + my_q] = accq;
   }
   if (publisher) {
@@ -1379,8 +1393,7 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
       if (vb0 == 0) lap(c_eval);
       double accq = 0.0;
       if (my_q < ODO_NACC) accq = rows_accumulate<kLmBlock, kS>(rows_sh, rowA, rowB, my_s, accq);
-#pragma unroll
-      for (int o = kS / 2; o > 0; o >>= 1) accq += __shfl_xor(accq, o, kS);
+      accq = rows_butterfly8(accq);
       if (vb < nvb && my_q < ODO_NACC && my_s == 0) part_sh[vb][my_q] = accq;
     }
     __syncthreads();
@@ -1571,8 +1584,7 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
       if (vb < nblk) {
         double accq = 0.0;
         if (my_q < ODO_NACC) accq = rows_accumulate<kLmBlock, kS>(rows_sh, rowA, rowB, my_s, accq);
-#pragma unroll
-        for (int o = kS / 2; o > 0; o >>= 1) accq += __shfl_xor(accq, o, kS);
+        accq = rows_butterfly8(accq);
         if (my_q < ODO_NACC && my_s == 0 && !(fault && vb == 0)) fine_publish(buf, vb, my_q, accq, tag, local);   // fault: row 0 never appears
       }
     } else {
@@ -1598,8 +1610,7 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
           __syncthreads();
           if (my_q < ODO_NACC) accq = rows_accumulate<kLmBlock, kS>(rows_sh, rowA, rowB, my_s, accq);
         }
-#pragma unroll
-        for (int o = kS / 2; o > 0; o >>= 1) accq += __shfl_xor(accq, o, kS);
+        accq = rows_butterfly8(accq);
         if (vb < nblk && my_q < ODO_NACC && my_s == 0) fine_publish(buf, vb, my_q, accq, tag, local);
       }
     }

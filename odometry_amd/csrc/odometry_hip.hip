@@ -66,7 +66,8 @@ struct odo_ctx {
   void *dense_h, *dense_d, *upd_h, *upd_d;   // DenseBatchItem / UpdItem [ODO_MAX_LEVELS][dense_cap]
   int dense_cap;
   struct LmBatchJob* lm_batch_job;   // the batched Solve in flight on this stream, if any
-  int batch_fine_bails;              // batched Solves whose persistent launch gave up (redone on the step launches; 3: stays off)
+  int batch_fine_bails;              // batched Solves whose persistent launch gave up and were redone on the step launches (lifetime)
+  int batch_fine_strikes, batch_fine_clean;   // as odo_lm::fine_strikes / fine_clean, for the batched launch of this context
 };
 
 // ---- recycled device memory -------------------------------------------------------------------------------------------
@@ -572,7 +573,10 @@ struct odo_lm {
   // Fine point-list levels in ONE persistent launch (lm_fine_kernel) instead of a step launch per evaluation: fine_k workgroups
   // on one XCD exchange their partial rows through d_xbuf. 0 = off (ODO_LM_NO_FINE: step launches; also the fall-back). The batched Solve has its own launch (lm_fine_kernel_batch).
   int fine_k;
-  int fine_bails;   // Solves whose persistent launch gave up and that were redone on the step launches
+  int fine_bails;   // Solves whose persistent launch gave up and that were redone on the step launches (lifetime count)
+  int fine_k_cfg;   // the configured number of workgroups (fine_k is 0 while the launch is switched off after three strikes)
+  int fine_strikes; // give-ups that count towards switching off; a long run of clean Solves forgives them
+  int fine_clean;   // Solves since the last give-up (persistent launch on) / since it was switched off (off)
   unsigned fine_epoch;  // tag epoch of the exchange buffer (lm_fine_next_epoch)
   int fine_fault;   // test hook (ODO_LM_FINE_FAULT): the first partial row of the persistent launch is never published
   unsigned long long* d_xbuf;
@@ -656,6 +660,7 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
   m->coarse = getenv("ODO_LM_NO_COARSE") ? 0 : 1;
   m->fine_k = getenv("ODO_LM_NO_FINE") ? 0 : (getenv("ODO_LM_FINE_K") ? atoi(getenv("ODO_LM_FINE_K")) : 32);
   if (m->fine_k < 0 || m->fine_k > kFineKMax) m->fine_k = 32;
+  m->fine_k_cfg = m->fine_k;
   m->fine_fault = getenv("ODO_LM_FINE_FAULT") ? 1 : 0;
   HIP_OK(hipMalloc((void**)&m->d_xbuf, sizeof(unsigned long long) * kFineXbufWords));
   HIP_OK(hipMemset(m->d_xbuf, 0, sizeof(unsigned long long) * kFineXbufWords));   // tag 0: no Solve has token 0
@@ -1316,13 +1321,22 @@ fused_again:
       // time: the same Solve again on the step launches, which need no co-residency; after three such Solves the optimiser
       // stays on them.
       m->fine_bails++;
+      m->fine_strikes++;
+      m->fine_clean = 0;
       m->fine_k = 0;
       started = false;
       launches = 0;
       HIP_OK(hipStreamSynchronize(s));
       goto fused_again;
     }
-    if (fine_k_asked > 0 && m->fine_k == 0 && m->fine_bails < 3) m->fine_k = fine_k_asked;
+    if (fine_k_asked > 0 && m->fine_k == 0 && m->fine_strikes < 3) m->fine_k = fine_k_asked;
+    // A disturbance that has passed must not cost the persistent launch for good: 1 024 clean Solves forgive the strikes, and an
+    // optimiser that was switched off tries again after 4 096 Solves on the step launches (one more give-up switches it off again).
+    if (m->fine_k_cfg > 0) {
+      m->fine_clean++;
+      if (m->fine_k > 0 && m->fine_clean >= 1024) { m->fine_strikes = 0; m->fine_clean = 0; }
+      if (m->fine_k == 0 && m->fine_strikes >= 3 && m->fine_clean >= 4096) { m->fine_k = m->fine_k_cfg; m->fine_strikes = 2; m->fine_clean = 0; }
+    }
     const int stop = m->job.stop_level;
     if (stop > 0 && m->h_out[16] == 0.0f) {
       // ---- hand-over: the fine levels are dense. The finishing launch left the state in d_state[2] (ordered before anything
@@ -1532,7 +1546,7 @@ static int lm_batch_begin(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
   const int per_xcd = (n + 7) / 8;
   int fine_k = (fine_env >= 0) ? fine_env : ((n <= 4) ? kFineKMax : (n <= 8) ? kFineKMax / 2 : kFineKMax / 4);
   if (fine_k * per_xcd > kFineKMax) fine_k = kFineKMax / per_xcd;
-  if (cx->batch_fine_bails >= 3 || lms[0]->fine_k <= 0 || getenv("ODO_LM_NO_FINE")) fine_k = 0;
+  if (cx->batch_fine_strikes >= 3 || lms[0]->fine_k_cfg <= 0 || getenv("ODO_LM_NO_FINE")) fine_k = 0;
   if (jb.fine_off_once) { fine_k = 0; jb.fine_off_once = false; }
   int grid = 1, budget = 0, any_coarse = 0, any_fine = 0;
   for (int i = 0; i < n; i++) {
@@ -1776,6 +1790,8 @@ collect_again:
     for (int i = 0; i < n; i++) gave_up = gave_up || lms[i]->h_out[16] == -2.0f;
     if (gave_up) {
       cx->batch_fine_bails++;
+      cx->batch_fine_strikes++;
+      cx->batch_fine_clean = 0;
       HIP_OK(hipStreamSynchronize(s));
       jb.fine_off_once = true;
       if (lm_batch_begin(n, lms, kf_img, kf_dep, cur_img) != 0) return fail("odo_lm_solve_batch: redo after a persistent launch gave up failed");
@@ -1808,6 +1824,10 @@ collect_again:
     }
   }
   for (int i = 0; i < n; i++) { take_result(i); if (status[i]) any_fail = 1; }
+  // (forgiveness as in odo_lm_solve: 1 024 clean batched Solves clear the strikes; switched off, it tries again after 4 096)
+  cx->batch_fine_clean++;
+  if (cx->batch_fine_strikes < 3 && cx->batch_fine_clean >= 1024) { cx->batch_fine_strikes = 0; cx->batch_fine_clean = 0; }
+  if (cx->batch_fine_strikes >= 3 && cx->batch_fine_clean >= 4096) { cx->batch_fine_strikes = 2; cx->batch_fine_clean = 0; }
   if (lms[0]->ev_on) {   // launch statistics of the batched Solve, kept with the first optimiser (odo_lm_event_stats_ex)
     odo_lm* m0 = lms[0];
     m0->ev_launches += launches;

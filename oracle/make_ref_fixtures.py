@@ -17,9 +17,9 @@ however, need nothing but <immintrin.h> and <cmath>, because they work on plain 
                        154-155               both stop tests, which estimate is current afterwards — with the estimates as plain tags
 
 This script reads exactly those line ranges out of /root/reference AT RUN TIME (nothing of the reference is stored in this
-repository: the generated translation unit lives in oracle/_ref/, which is git-ignored), checks their SHA-256 so that a
-shifted line range cannot go unnoticed, and compiles them with the reference's own flags (ref: CMakeLists.txt:19) into
-oracle/_ref/libref_scan.so. The only edit to the extracted text is the removal of the `DepthEstimator::` qualifier (the class
+repository or written into its tree: the generated translation unit and the library live in a temporary directory outside
+/root/repo), checks their SHA-256 on EVERY path that compiles them so that a shifted line range cannot go unnoticed, and
+compiles them with the reference's own flags (ref: CMakeLists.txt:19) into libref_scan.so there. The only edit to the extracted text is the removal of the `DepthEstimator::` qualifier (the class
 declaration lives in a header that includes Eigen and OpenCV). What the harness around them supplies is what cv::Mat supplied:
 row pointers (`ptr<float>(y)` = base + y * cols), the y / x loops of :346,:352 and the three members the lines read
 (boundary_, ssd_th_, baseline_) as plain variables. Blur and point selection are NOT reference code here (cv::GaussianBlur,
@@ -37,7 +37,6 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 REF = os.environ.get("ODO_REFERENCE_DIR", "/root/reference")
-OUT = os.path.join(HERE, "_ref")
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 # name: (file, first line, last line)
@@ -83,11 +82,23 @@ HASHES = {
 }
 
 
+class ReferencePinError(RuntimeError):
+    """The reference checkout is absent, or one of the pinned line ranges no longer holds the text the hashes were taken from."""
+
+
 def extract(name):
+    """The text of one pinned line range — returned only if its SHA-256 is the recorded one, so that NO path (fixtures, build(),
+    the live-build test) can compile text that is not the text this file was written against."""
     rel, a, b = RANGES[name]
-    with open(os.path.join(REF, rel)) as f:
-        lines = f.readlines()
-    return "".join(lines[a - 1:b])
+    try:
+        with open(os.path.join(REF, rel)) as f:
+            lines = f.readlines()
+    except OSError as e:
+        raise ReferencePinError(f"{REF}/{rel} not readable: {e}")
+    text = "".join(lines[a - 1:b])
+    if "--print-hashes" not in sys.argv and HASHES.get(name) != sha(text):
+        raise ReferencePinError(f"line range {name} ({rel}:{a}-{b}) changed: sha256 {sha(text)}")
+    return text
 
 
 def sha(text):
@@ -97,7 +108,7 @@ def sha(text):
 def harness_source():
     t = {k: extract(k) for k in RANGES}
     ssd = t["ssd_sse"].replace("DepthEstimator::", "")
-    return f"""// GENERATED by oracle/make_ref_fixtures.py from line ranges of {REF} — never committed (oracle/_ref/ is git-ignored).
+    return f"""// GENERATED by oracle/make_ref_fixtures.py from line ranges of {REF} — lives outside the repository, deleted after the compile.
 #include <immintrin.h>
 #include <pmmintrin.h>
 #include <xmmintrin.h>
@@ -235,20 +246,33 @@ extern "C" int ref_scan(const float* left_rect, const float* right_rect, const u
 """
 
 
-def build():
-    os.makedirs(OUT, exist_ok=True)
-    src = os.path.join(OUT, "ref_scan_harness.cpp")
+def build(out_dir=None):
+    """Compiles the pinned lines into libref_scan.so inside `out_dir` (default: a fresh temporary directory OUTSIDE the repository)
+    and returns the library's path. Nothing of the reference — neither the generated translation unit nor the library — is ever
+    written under /root/repo, so nothing of it can travel with the tree. Every range is hash-checked by
+    extract() before it is compiled."""
+    import tempfile
+    if out_dir is None:
+        out_dir = tempfile.mkdtemp(prefix="odo_ref_")
+    out_dir = os.path.abspath(out_dir)
+    if os.path.commonpath([out_dir, ROOT]) == ROOT:
+        raise ReferencePinError(f"refusing to build reference lines inside the repository ({out_dir})")
+    os.makedirs(out_dir, exist_ok=True)
+    src = os.path.join(out_dir, "ref_scan_harness.cpp")
     with open(src, "w") as f:
         f.write(harness_source())
-    lib = os.path.join(OUT, "libref_scan.so")
+    lib = os.path.join(out_dir, "libref_scan.so")
     # the reference's flags (ref: CMakeLists.txt:19); -Wno-unused for the locals of :282-297 the scan lines do not touch
-    subprocess.check_call(["g++", "-std=c++14", "-O3", "-mtune=haswell", "-march=haswell", "-m64", "-msse", "-msse2", "-msse3",
-                           "-msse4.1", "-msse4.2", "-mavx2", "-mavx", "-Wno-unused", "-shared", "-fPIC", "-o", lib, src])
+    try:
+        subprocess.check_call(["g++", "-std=c++14", "-O3", "-mtune=haswell", "-march=haswell", "-m64", "-msse", "-msse2", "-msse3",
+                               "-msse4.1", "-msse4.2", "-mavx2", "-mavx", "-Wno-unused", "-shared", "-fPIC", "-o", lib, src])
+    finally:
+        os.unlink(src)
     return lib
 
 
-def load(lib=None):
-    L = C.CDLL(lib or os.path.join(OUT, "libref_scan.so"))
+def load(lib):
+    L = C.CDLL(lib)
     fp, ip, bp = C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_uint8)
     L.ref_cx_level.restype = C.c_float
     L.ref_cx_level.argtypes = [C.c_float, C.c_int]
@@ -388,11 +412,10 @@ def main():
         for k in RANGES:
             print(f'    "{k}": "{sha(extract(k))}",')
         return
-    for k in RANGES:
-        got = sha(extract(k))
-        if HASHES.get(k) != got:
-            raise SystemExit(f"line range {k} ({RANGES[k][0]}:{RANGES[k][1]}-{RANGES[k][2]}) changed: sha256 {got}")
-    L = load(build())
+    try:
+        L = load(build())   # every range hash-checked in extract()
+    except ReferencePinError as e:
+        raise SystemExit(str(e))
     boundary, ssd_th = 4, 900.0
     baseline = float(np.float32(386.1448) / np.float32(718.856))
     sc = scenes()

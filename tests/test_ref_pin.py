@@ -14,6 +14,7 @@ import pytest
 from oracle import oracle as O
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -154,11 +155,12 @@ def test_fixture_inputs_are_what_the_oracle_front_end_produces(ssd, key):
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference checkout exists in the build container only")
-def test_oracle_scan_matches_live_reference_build_on_fresh_inputs():
-    """In the build container the reference lines are compiled again (oracle/_ref/, git-ignored) and run on inputs the fixture
-    does not hold: 20 random pairs, random masks, full-mantissa values."""
+def test_oracle_scan_matches_live_reference_build_on_fresh_inputs(tmp_path_factory):
+    """In the build container the reference lines are compiled again — hash-checked, into a temporary directory OUTSIDE the
+    repository, so nothing of the reference ever lies in the tree that travels — and run on inputs the fixture does not hold:
+    20 random pairs, random masks, full-mantissa values."""
     from oracle import make_ref_fixtures as M
-    L = M.load(M.build())
+    L = M.load(M.build(str(tmp_path_factory.mktemp("odo_ref"))))
     rng = np.random.default_rng(99)
     for trial in range(20):
         rows, cols = int(rng.integers(12, 40)), int(rng.integers(24, 160))
@@ -190,6 +192,23 @@ def test_oracle_scan_matches_live_reference_build_on_fresh_inputs():
     P = np.zeros((3, 4))
     P[0, 0], P[1, 1], P[0, 1], P[0, 2], P[1, 2], P[2, 2] = 1100.0, 1090.5, 0.25, 959.5, 539.5, 1.0
     assert np.array_equal(O.camera_intrinsics(P, 5), out)
+
+
+def test_reference_lines_are_never_built_inside_the_repository():
+    """make_ref_fixtures.build() refuses a target directory under the repository root, and a line range whose text is not the
+    recorded one is refused before anything is compiled (every path goes through extract())."""
+    from oracle import make_ref_fixtures as M
+    with pytest.raises(M.ReferencePinError):
+        M.build(os.path.join(ROOT, "oracle", "_ref"))
+    assert not os.path.exists(os.path.join(ROOT, "oracle", "_ref"))
+    if os.path.isdir(M.REF):
+        old = M.HASHES["scan"]
+        M.HASHES["scan"] = "0" * 64
+        try:
+            with pytest.raises(M.ReferencePinError):
+                M.extract("scan")
+        finally:
+            M.HASHES["scan"] = old
 
 
 @pytest.mark.gpu

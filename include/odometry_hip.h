@@ -202,6 +202,12 @@ int odo_lm_launch_stats(const odo_lm* lm, int* n_active_launches, int* n_total_l
  * launch gave up waiting for one of its workgroups and that were redone on the step launches (results unaffected): this
  * optimiser's own Solves plus the batched Solves (odo_lm_solve_batch, odo_tracker_batch) of its context. */
 int odo_lm_persistent_stats(const odo_lm* lm, int* workgroups, int* fallbacks);
+/* Its give-up policy. A wait inside the launch is bounded by the device wall clock (4 ms; ODO_LM_FINE_WAIT_US), so a give-up costs
+ * that + one redo of the Solve on the step launches. Three give-ups switch the launch off; it is tried again after *retry_after
+ * Solves — 4 096, doubling with every further switch-off up to 2^20 — and 1 024 clean Solves with the launch on forget all of it.
+ * *strikes = give-ups that count at the moment (3: switched off), *solves_until_retry = Solves left on the step launches before the
+ * next try (0 while the launch is on). */
+int odo_lm_persistent_backoff(const odo_lm* lm, int* strikes, int* retry_after, int* solves_until_retry);
 
 /* Diagnostic: cycle-counter stamps at the phase boundaries of one LM update launch ("update kernel"). */
 int odo_debug_update_stamps(odo_lm* lm, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img, int level,

@@ -256,6 +256,12 @@ class LevenbergMarquardtOptimizer:
         L.check(self.ctx.lib.odo_lm_persistent_stats(self.h, C.byref(k), C.byref(f)), "odo_lm_persistent_stats")
         return k.value, f.value
 
+    def persistent_backoff(self):
+        """(give-ups that count — 3: switched off —, Solves a switched-off launch waits before its next try, Solves left until then)"""
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        L.check(self.ctx.lib.odo_lm_persistent_backoff(self.h, C.byref(a), C.byref(b), C.byref(c)), "odo_lm_persistent_backoff")
+        return a.value, b.value, c.value
+
     def close(self):
         if getattr(self, "h", None):
             self.ctx.lib.odo_lm_destroy(self.h)

@@ -941,6 +941,7 @@ struct StepArgs {
   int fine_lo;          // lm_fine_kernel_batch: the persistent launch takes levels [fine_lo, min_level) (>= min_level: none)
   unsigned long long* xbuf;  // ... and exchanges this sequence's partial rows through this buffer (kFineXbufWords words)
   unsigned fine_epoch;       // tags of the exchange: (fine_epoch << 8) + evaluation; the host never repeats an epoch on a buffer it has not cleared
+  unsigned fine_wait;        // bound of one wait of the persistent launch in wall-clock ticks (0: kFineWaitTicks)
   // hand-over to the unfused pipeline (dense fine levels): the device stops walking the pyramid below stop_level, reports the
   // Solve "finished" there and leaves its state in final_state, from which the host carries on level by level
   int stop_level;       // 0: the fused pipeline covers every level
@@ -1461,13 +1462,23 @@ __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel_batch(const Ste
 // Placement: blocks are dealt round-robin over the 8 XCDs, so the launch has 8 x K blocks of which every eighth takes part
 // (they share an XCD and its L2; the others return at once). That is for speed only: the workgroups tell each other their XCC id
 // first, and only if all agree do the rows go out as plain stores (they stay in that L2); otherwise as agent-scope stores, which
-// are coherent at any placement. Every poll is bounded: a workgroup that waits longer than kFineSpinLimit polls gives up and the Solve reports
-// failure instead of hanging the device.
+// are coherent at any placement. Every wait is bounded by the device wall clock (kFineWaitTicks: 4 ms): a workgroup that waits longer gives up
+// and the Solve reports status -2 (the host redoes it on the step launches) instead of hanging the device.
 // =============================================================================================
 constexpr int kFineGran = 2 * ODO_NACC;          // granules per partial row
 constexpr int kFineRowsMax = 160;                // = kLmListMaxBlocks (host): partial rows of the largest point-list level
 constexpr int kFineChunk = 8;                    // rows a folding thread keeps in flight
-constexpr int kFineSpinLimit = 1 << 17;          // polls of one chunk before giving up (~0.1 s, not microseconds)
+constexpr unsigned kFineWaitTicks = 400000u;     // default bound of one wait, in ticks of the 100 MHz wall clock: 4 ms — three orders of
+                                                 // magnitude above a normal exchange (~1 us), short enough that a give-up is a hiccup of one
+                                                 // frame, not a stall (StepArgs::fine_wait overrides: ODO_LM_FINE_WAIT_US)
+// A bounded wait: the clock is looked at every 32nd poll only (s_memrealtime is a scalar memory operation of ~100 cycles).
+struct FineDeadline {
+  unsigned long long t0;
+  unsigned limit;
+  __device__ __forceinline__ bool expired(int spin) const {
+    return (spin & 31) == 31 && (unsigned long long)wall_clock64() - t0 > (unsigned long long)limit;
+  }
+};
 constexpr int kFineThreads = 2 * kLmBlock;       // a workgroup works on TWO virtual blocks at a time, one per half
 constexpr int kFineKMax = 32;                     // workgroups of one launch: they wait for each other, so each needs a CU of the XCD (32) to itself
 constexpr int kFineXbufWords = 2 * kFineRowsMax * kFineGran + kFineKMax;  // two row buffers + one placement word per workgroup
@@ -1509,6 +1520,7 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
   float* rows_sh = rows_sh2[half];
   const unsigned tag_base = a.fine_epoch << 8;   // unique per launch on this buffer (lm_fine_next_epoch): a stale granule cannot pass for a new one
   unsigned long long* place = xbuf + 2 * kFineRowsMax * kFineGran;  // [K] {xcc id, launch epoch} words
+  const unsigned wait_limit = a.fine_wait ? a.fine_wait : kFineWaitTicks;
   if (t == 0) {
 #pragma unroll
     for (int l = 0; l < ODO_MAX_LEVELS_K; l++) lv_sh[l] = a.lv[l];
@@ -1526,9 +1538,11 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
     bool same = true, got = false;
     if (t < K) {
       unsigned long long pw = 0;
-      for (int spin = 0; !got && spin < kFineSpinLimit; spin++) {
+      const FineDeadline dl = {(unsigned long long)wall_clock64(), wait_limit};
+      for (int spin = 0; !got; spin++) {
         pw = __hip_atomic_load(place + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         got = ((unsigned)pw == tag_base);
+        if (!got && dl.expired(spin)) break;
       }
       same = got && ((int)(pw >> 32) == fine_xcc_id());
     } else {
@@ -1622,8 +1636,10 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
       for (int b0 = fseg; b0 < nblk; b0 += 8 * kFineChunk) {
         FineG2 g2[kFineChunk];   // {hi granule, lo granule} of one double: one 16-byte load that bypasses L1
         bool all = false;
-        for (int spin = 0; !all && spin < kFineSpinLimit; spin++) {
-          if (spin > 0) __builtin_amdgcn_s_sleep(1);
+        FineDeadline dl = {0ull, wait_limit};
+        for (int spin = 0; !all; spin++) {
+          if (spin == 1) dl.t0 = (unsigned long long)wall_clock64();   // the first pass succeeds three times in four: no clock read then
+          if (spin > 0) { if (dl.expired(spin)) break; __builtin_amdgcn_s_sleep(1); }
           all = true;
 #pragma unroll
           for (int u = 0; u < kFineChunk; u++) {

@@ -68,6 +68,7 @@ struct odo_ctx {
   struct LmBatchJob* lm_batch_job;   // the batched Solve in flight on this stream, if any
   int batch_fine_bails;              // batched Solves whose persistent launch gave up and were redone on the step launches (lifetime)
   int batch_fine_strikes, batch_fine_clean;   // as odo_lm::fine_strikes / fine_clean, for the batched launch of this context
+  int batch_fine_offs;                        // as odo_lm::fine_offs
 };
 
 // ---- recycled device memory -------------------------------------------------------------------------------------------
@@ -577,6 +578,8 @@ struct odo_lm {
   int fine_k_cfg;   // the configured number of workgroups (fine_k is 0 while the launch is switched off after three strikes)
   int fine_strikes; // give-ups that count towards switching off; a long run of clean Solves forgives them
   int fine_clean;   // Solves since the last give-up (persistent launch on) / since it was switched off (off)
+  int fine_offs;    // times the launch has been switched off since the last forgiveness: the retry interval doubles with each (fine_retry_after)
+  unsigned fine_wait;   // bound of one wait inside the launch, wall-clock ticks (ODO_LM_FINE_WAIT_US; 0: the kernel's default, 4 ms)
   unsigned fine_epoch;  // tag epoch of the exchange buffer (lm_fine_next_epoch)
   int fine_fault;   // test hook (ODO_LM_FINE_FAULT): the first partial row of the persistent launch is never published
   unsigned long long* d_xbuf;
@@ -662,6 +665,7 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
   if (m->fine_k < 0 || m->fine_k > kFineKMax) m->fine_k = 32;
   m->fine_k_cfg = m->fine_k;
   m->fine_fault = getenv("ODO_LM_FINE_FAULT") ? 1 : 0;
+  m->fine_wait = getenv("ODO_LM_FINE_WAIT_US") ? (unsigned)(100L * atol(getenv("ODO_LM_FINE_WAIT_US"))) : 0u;
   HIP_OK(hipMalloc((void**)&m->d_xbuf, sizeof(unsigned long long) * kFineXbufWords));
   HIP_OK(hipMemset(m->d_xbuf, 0, sizeof(unsigned long long) * kFineXbufWords));   // tag 0: no Solve has token 0
   m->poll = getenv("ODO_NO_POLL") ? 0 : 1;
@@ -1009,6 +1013,32 @@ static int lm_fused_stop_level(const odo_lm* m) {
 }
 static bool lm_fused_eligible(const odo_lm* m) { return lm_fused_stop_level(m) < m->n_levels; }
 
+// Give-up policy of the persistent launches (single and batched). A give-up costs one bounded wait (4 ms) + a redo of the Solve on
+// the step launches. Three give-ups switch the launch off; it is tried again after kFineRetryFirst Solves, and every further
+// switch-off doubles that interval (up to kFineRetryCap): on a GPU that is shared for good the hiccup becomes rarer and rarer
+// instead of recurring every second. kFineForgive clean Solves with the launch on forget everything.
+constexpr int kFineRetryFirst = 4096, kFineRetryCap = 1 << 20, kFineForgive = 1024;
+static inline int fine_retry_after(int offs) {
+  long v = kFineRetryFirst;
+  for (int i = 1; i < offs && v < kFineRetryCap; i++) v *= 2;
+  return (int)(v < kFineRetryCap ? v : kFineRetryCap);
+}
+// One give-up: returns true when the launch is (now) switched off.
+static inline bool fine_note_giveup(int* strikes, int* clean, int* offs) {
+  (*strikes)++;
+  *clean = 0;
+  if (*strikes >= 3) { (*offs)++; return true; }
+  return false;
+}
+// One Solve that did not give up. on: the launch was used. Returns true when a switched-off launch is due for another try
+// (the caller switches it on; one more give-up switches it off again with a doubled interval).
+static inline bool fine_note_clean(bool on, int* strikes, int* clean, int* offs) {
+  (*clean)++;
+  if (on && *strikes < 3 && *clean >= kFineForgive) { *strikes = 0; *clean = 0; *offs = 0; }
+  if (*strikes >= 3 && *clean >= fine_retry_after(*offs)) { *strikes = 2; *clean = 0; return true; }
+  return false;
+}
+
 // Keyframe lists must be current (lm_prepare_keyframe) and the Solve fused-eligible.
 static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img) {
   hipStream_t s = m->ctx->stream;
@@ -1130,6 +1160,7 @@ static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_de
     a.seq = jb.seq; a.first_of_solve = (jb.seq == 0) ? 1 : 0;
     a.span = lm_span_slot(m, jb.launches, false);
     a.fine_epoch = lm_fine_next_epoch(m);
+    a.fine_wait = m->fine_wait;
     hipLaunchKernelGGL(lm_fine_kernel, dim3(8 * m->fine_k), dim3(kFineThreads), 0, s, a, m->fine_k, m->d_xbuf, m->fine_fault, fine_lo);
     jb.seq++;
     jb.launches++;
@@ -1316,13 +1347,12 @@ fused_again:
     std::atomic_thread_fence(std::memory_order_acquire);
     memcpy(m->h_out, m->h_res, sizeof(float) * 42);
     if (m->h_out[16] == -2.0f && m->fine_k > 0) {
-      // The persistent launch gave up: one of its workgroups never showed up within the spin limit (they wait for each other,
+      // The persistent launch gave up: one of its workgroups never showed up within the wait bound (they wait for each other,
       // so all of them must be resident at once: another client of this GPU can hold the CUs they need). Nothing is lost but
       // time: the same Solve again on the step launches, which need no co-residency; after three such Solves the optimiser
-      // stays on them.
+      // stays on them (fine_note_giveup: for a while that doubles each time).
       m->fine_bails++;
-      m->fine_strikes++;
-      m->fine_clean = 0;
+      (void)fine_note_giveup(&m->fine_strikes, &m->fine_clean, &m->fine_offs);
       m->fine_k = 0;
       started = false;
       launches = 0;
@@ -1331,12 +1361,9 @@ fused_again:
     }
     if (fine_k_asked > 0 && m->fine_k == 0 && m->fine_strikes < 3) m->fine_k = fine_k_asked;
     // A disturbance that has passed must not cost the persistent launch for good: 1 024 clean Solves forgive the strikes, and an
-    // optimiser that was switched off tries again after 4 096 Solves on the step launches (one more give-up switches it off again).
-    if (m->fine_k_cfg > 0) {
-      m->fine_clean++;
-      if (m->fine_k > 0 && m->fine_clean >= 1024) { m->fine_strikes = 0; m->fine_clean = 0; }
-      if (m->fine_k == 0 && m->fine_strikes >= 3 && m->fine_clean >= 4096) { m->fine_k = m->fine_k_cfg; m->fine_strikes = 2; m->fine_clean = 0; }
-    }
+    // optimiser that was switched off tries again after 4 096 Solves on the step launches — 8 192 after the next switch-off, and
+    // so on (one more give-up switches it off again).
+    if (m->fine_k_cfg > 0 && fine_note_clean(m->fine_k > 0, &m->fine_strikes, &m->fine_clean, &m->fine_offs)) m->fine_k = m->fine_k_cfg;
     const int stop = m->job.stop_level;
     if (stop > 0 && m->h_out[16] == 0.0f) {
       // ---- hand-over: the fine levels are dense. The finishing launch left the state in d_state[2] (ordered before anything
@@ -1438,6 +1465,7 @@ static void lm_fill_step_args(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* c
   a.fine_lo = fine_lo;
   a.xbuf = m->d_xbuf;
   a.fine_epoch = (fine_lo < min_level) ? lm_fine_next_epoch(m) : 0u;   // (a sequence that only carries its state exchanges nothing)
+  a.fine_wait = m->fine_wait;
   int above = 0;   // evaluations the coarse and the persistent launch can take
   for (int l = fine_lo; l < m->n_levels; l++) above += m->max_iters[l] > 0 ? m->max_iters[l] : 0;
   *grid_out = grid;
@@ -1790,8 +1818,7 @@ collect_again:
     for (int i = 0; i < n; i++) gave_up = gave_up || lms[i]->h_out[16] == -2.0f;
     if (gave_up) {
       cx->batch_fine_bails++;
-      cx->batch_fine_strikes++;
-      cx->batch_fine_clean = 0;
+      (void)fine_note_giveup(&cx->batch_fine_strikes, &cx->batch_fine_clean, &cx->batch_fine_offs);
       HIP_OK(hipStreamSynchronize(s));
       jb.fine_off_once = true;
       if (lm_batch_begin(n, lms, kf_img, kf_dep, cur_img) != 0) return fail("odo_lm_solve_batch: redo after a persistent launch gave up failed");
@@ -1824,10 +1851,8 @@ collect_again:
     }
   }
   for (int i = 0; i < n; i++) { take_result(i); if (status[i]) any_fail = 1; }
-  // (forgiveness as in odo_lm_solve: 1 024 clean batched Solves clear the strikes; switched off, it tries again after 4 096)
-  cx->batch_fine_clean++;
-  if (cx->batch_fine_strikes < 3 && cx->batch_fine_clean >= 1024) { cx->batch_fine_strikes = 0; cx->batch_fine_clean = 0; }
-  if (cx->batch_fine_strikes >= 3 && cx->batch_fine_clean >= 4096) { cx->batch_fine_strikes = 2; cx->batch_fine_clean = 0; }
+  // (forgiveness and retry as in odo_lm_solve: lm_batch_begin uses the launch whenever batch_fine_strikes < 3)
+  (void)fine_note_clean(jb.fine_used && !redone, &cx->batch_fine_strikes, &cx->batch_fine_clean, &cx->batch_fine_offs);
   if (lms[0]->ev_on) {   // launch statistics of the batched Solve, kept with the first optimiser (odo_lm_event_stats_ex)
     odo_lm* m0 = lms[0];
     m0->ev_launches += launches;
@@ -1952,6 +1977,16 @@ extern "C" int odo_lm_persistent_stats(const odo_lm* m, int* workgroups, int* fa
   if (!m) return fail("odo_lm_persistent_stats: NULL lm");
   if (workgroups) *workgroups = m->fine_k;
   if (fallbacks) *fallbacks = m->fine_bails + m->ctx->batch_fine_bails;   // its own Solves + its context's batched Solves
+  return 0;
+}
+// Back-off state of the persistent launch: give-ups that count (3 = switched off), the interval after which a switched-off launch
+// is tried again (doubles with every switch-off), and the Solves left until then (0 while the launch is on).
+extern "C" int odo_lm_persistent_backoff(const odo_lm* m, int* strikes, int* retry_after, int* solves_until_retry) {
+  if (!m) return fail("odo_lm_persistent_backoff: NULL lm");
+  const int ra = fine_retry_after(m->fine_offs);
+  if (strikes) *strikes = m->fine_strikes;
+  if (retry_after) *retry_after = ra;
+  if (solves_until_retry) *solves_until_retry = (m->fine_k_cfg > 0 && m->fine_k == 0 && m->fine_strikes >= 3) ? (ra - m->fine_clean > 0 ? ra - m->fine_clean : 0) : 0;
   return 0;
 }
 extern "C" int odo_lm_launch_stats(const odo_lm* m, int* n_active, int* n_total, double* bytes) {

@@ -545,9 +545,9 @@ def test_bilinear_sampling_option_matches_its_oracle(api, O, kitti_seq):
 @pytest.mark.gpu
 def test_persistent_launch_and_its_fallback_give_the_same_pose(monkeypatch):
     """The fine levels run in ONE persistent launch whose workgroups wait for each other (lm_fine_kernel). With a workgroup that
-    never publishes (ODO_LM_FINE_FAULT) the launch gives up within its spin limit instead of hanging, the host redoes the Solve on
-    the step launches, and after three such Solves the optimiser stays on them: same pose bit for bit, as with the persistent
-    launch switched off altogether."""
+    never publishes (ODO_LM_FINE_FAULT) the launch gives up within its wall-clock wait bound (4 ms) instead of hanging, the host
+    redoes the Solve on the step launches, and after three such Solves the optimiser stays on them — for 4 096 Solves, then it tries
+    once more (odo_lm_persistent_backoff): same pose bit for bit, as with the persistent launch switched off altogether."""
     from odometry_amd import api, synth
     seq = synth.make_sequence(2, seed=5, with_depth=True)
     L0, L1 = seq["left"][0], seq["left"][1]
@@ -559,19 +559,25 @@ def test_persistent_launch_and_its_fallback_give_the_same_pose(monkeypatch):
         lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 1, 28.0, intrinsics=K)
         out = [lm.Solve(p0, d0, p1).copy() for _ in range(n)]
         st = lm.persistent_stats()
+        solve.backoff = lm.persistent_backoff()
         assert lm.last_status == 0
         lm.close()
         return out, st
 
     ref, st = solve()
     assert st[0] > 0 and st[1] == 0            # persistent launch on, never fell back
+    assert solve.backoff == (0, 4096, 0)
     monkeypatch.setenv("ODO_LM_NO_FINE", "1")
     off, st = solve()
     assert st == (0, 0) and np.array_equal(off[0], ref[0])
     monkeypatch.delenv("ODO_LM_NO_FINE")
     monkeypatch.setenv("ODO_LM_FINE_FAULT", "1")
+    import time
+    t0 = time.perf_counter()
     bad, st = solve(4)
     assert st == (0, 3)                        # three Solves were redone, the fourth went to the step launches directly
+    assert solve.backoff == (3, 4096, 4095)    # switched off; one Solve of the 4 096 on the step launches done
+    assert time.perf_counter() - t0 < 2.0      # a give-up is a bounded wait of milliseconds (it was ~0.2 s each)
     for T in bad:
         assert np.array_equal(T, ref[0])
 

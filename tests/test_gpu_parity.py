@@ -576,7 +576,7 @@ def test_persistent_launch_and_its_fallback_give_the_same_pose(monkeypatch):
     t0 = time.perf_counter()
     bad, st = solve(4)
     assert st == (0, 3)                        # three Solves were redone, the fourth went to the step launches directly
-    assert solve.backoff == (3, 4096, 4095)    # switched off; one Solve of the 4 096 on the step launches done
+    assert solve.backoff == (3, 4096, 4094)    # switched off; two Solves (the third redo + the fourth) of the 4 096 done
     assert time.perf_counter() - t0 < 2.0      # a give-up is a bounded wait of milliseconds (it was ~0.2 s each)
     for T in bad:
         assert np.array_equal(T, ref[0])

@@ -485,11 +485,19 @@ static int pixel_row(const float* I1, const float* I2, const float* D1, int rows
 }
 
 /* ComputeScaleNaive (ref: src/lm_optimizer.cpp:338-358); the per-pass sum is accumulated in fp64. */
+static long g_tdist_passes = 0, g_tdist_calls = 0;   /* diagnostic: passes over the residuals / calls (orc_tdist_counters) */
+void orc_tdist_counters(long* passes, long* calls, int reset) {
+  if (passes) *passes = g_tdist_passes;
+  if (calls) *calls = g_tdist_calls;
+  if (reset) g_tdist_passes = g_tdist_calls = 0;
+}
 static float tdist_scale(const float* r, int n) {
   float init_sigma = 5.0f, cur = 5.0f;
   const float vee = 200.0f;
   int guard = 0;
+  g_tdist_calls++;
   do {
+    g_tdist_passes++;
     init_sigma = cur;
     const float sigma_sqr = cur * cur;
     double sum = 0.0;

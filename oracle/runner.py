@@ -16,6 +16,15 @@ def motion_angles(T):
                      np.arctan2(f(R[1, 0] - R[0, 1]), f(R[0, 0] + R[1, 1]))], np.float32)
 
 
+def matmul4_f32(A, B):
+    """4x4 fp32 product, every operation rounded once, k ascending: ((a0 b0 + a1 b1) + a2 b2) + a3 b3 — the association of the
+    plain triple loop (ref: run_odometry_kitti_offline.cpp:218, Eigen's 4x4 float product is unpinned: this is the stated order)."""
+    A = np.asarray(A, np.float32)
+    B = np.asarray(B, np.float32)
+    t = [(A[:, k:k + 1] * B[k:k + 1, :]).astype(np.float32) for k in range(4)]   # outer products: one rounding per entry
+    return (((t[0] + t[1]).astype(np.float32) + t[2]).astype(np.float32) + t[3]).astype(np.float32)
+
+
 class OracleRunner:
     def __init__(self, lm_params=None, depth_params=None, motion_th=1.1):
         self.lp = lm_params or O.lm_params()
@@ -39,7 +48,8 @@ class OracleRunner:
             raise RuntimeError("    depth failed!")
         T = r["pose"]
         inv = np.linalg.inv(T.astype(np.float64)).astype(np.float32)
-        cur = (self.kf_abs @ inv).astype(np.float32)
+        cur = matmul4_f32(self.kf_abs, inv)   # (numpy's own float32 `@` leaves the association to BLAS: a chain of ~25 keyframes
+        #                                        then drifts by ulps of a 100 m translation, more than the pose tolerance)
         mot = np.concatenate([np.abs(motion_angles(T)), np.abs(T[:3, 3])]).astype(np.float32)
         mag = np.float32(0)
         for m, w in zip(mot, KEYFRAME_WEIGHT):

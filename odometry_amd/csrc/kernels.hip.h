@@ -604,52 +604,6 @@ __global__ void __launch_bounds__(kLmBlock) lm_residual_only_kernel(LevelView v,
   }
 }
 
-// Fixed-point iteration for the t-distribution scale over the stored residuals; one workgroup, sums in fp64
-// with a fixed association order (ref: src/lm_optimizer.cpp:338-358). Writes sigma^2.
-__global__ void __launch_bounds__(1024) lm_tdist_scale_kernel(const float* __restrict__ res, int n,
-                                                               const LmState* __restrict__ st, int expect_level,
-                                                               float* __restrict__ scale_sqr_out) {
-  if (!(st->active != 0 && st->level == expect_level)) return;
-  __shared__ double shs[1024];
-  __shared__ int shn[1024];
-  __shared__ float sh_sigma;
-  __shared__ int sh_done;
-  const int t = threadIdx.x;
-  float cur = 5.0f;
-  for (int guard = 0; guard < 1000; guard++) {
-    const float init_sigma = cur;
-    const float sigma_sqr = cur * cur;
-    double s = 0.0;
-    int cnt = 0;
-    for (int i = t; i < n; i += 1024) {
-      const float r = res[i];
-      if (r == r) {
-        const float e2 = r * r;
-        s += (double)(e2 * (1.0f + 200.0f) / (200.0f + e2 / sigma_sqr));
-        cnt++;
-      }
-    }
-    shs[t] = s;
-    shn[t] = cnt;
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-      if (t < o) { shs[t] += shs[t + o]; shn[t] += shn[t + o]; }
-      __syncthreads();
-    }
-    if (t == 0) {
-      const float nxt = (shn[0] > 0) ? sqrtf((float)(shs[0] / (double)shn[0])) : cur;
-      sh_sigma = nxt;
-      sh_done = (shn[0] == 0) || !(fabsf(nxt - init_sigma) >= 1e-3f);
-    }
-    __syncthreads();
-    cur = sh_sigma;
-    const int done = sh_done;
-    __syncthreads();
-    if (done) break;
-  }
-  if (t == 0) *scale_sqr_out = cur * cur;
-}
-
 static_assert(sizeof(LmState) <= 64 * sizeof(int), "LmState must fit one wavefront-wide copy");
 static_assert(sizeof(LmState) == 64 * sizeof(int), "LmState is exactly 64 dwords");
 
@@ -894,6 +848,118 @@ __device__ __forceinline__ double rows_accumulate(const float* __restrict__ rows
     acc = fma((double)a.w, (double)b.w, acc);
   }
   return acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// t-distribution weights inside the fused kernels (robust == 2: ComputeScaleNaive, ref: src/lm_optimizer.cpp:257-261,338-358).
+// The scale is a fixed-point iteration sigma <- sqrt(mean_i f(r_i, sigma)): every pass is one more sum over ALL residuals of the
+// evaluation, so it is one more reduction through whatever joins the evaluation's points — a wave, the workgroup's LDS (coarse
+// kernel), the L2 exchange (persistent kernel). One summation order everywhere, defined on the point list alone:
+//   partial[c] = wave_sum64 of the terms of points 64 c .. 64 c + 63 (a skipped point's term is +0);
+//   total      = wave_sum64 over lanes l of (partial[l] + partial[l + 64] + ... ascending)
+// with wave_sum64 the butterfly below (xor 1, xor 2, mirror of 8, mirror of 16 on DPP; the four row sums as (r0 + r1) + (r2 + r3)).
+// Terms are fp32 values >= +0 summed in fp64, so chunks without points (+0) change nothing: the coarse kernel, the persistent
+// kernel and lm_tdist_scale_kernel (the unfused pipeline, point-list levels) give the same sigma bit for bit.
+// Must be called by a full wavefront.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum64(double v) {
+  v += dpp_d<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+  v += dpp_d<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+  v += dpp_d<0x141>(v);   // row_half_mirror: lane i <- 7 - i (the other quad of the eight)
+  v += dpp_d<0x140>(v);   // row_mirror: lane i <- 15 - i (the other eight of the row)
+  const double r0 = readlane_d(v, 0), r1 = readlane_d(v, 16), r2 = readlane_d(v, 32), r3 = readlane_d(v, 48);
+  return (r0 + r1) + (r2 + r3);
+}
+// One residual's term of a scale pass (ref: src/lm_optimizer.cpp:350-351), nu = 200.
+__device__ __forceinline__ float tdist_term(float e2, float sigma_sqr) { return e2 * (1.0f + 200.0f) / (200.0f + e2 / sigma_sqr); }
+// sigma of the next pass from the pass's total and the number of residuals (ref: :353), and the loop test (:354).
+__device__ __forceinline__ float tdist_next_sigma(double total, int n) { return sqrtf((float)(total / (double)n)); }
+__device__ __forceinline__ bool tdist_converged(float nxt, float cur) { return !(fabsf(nxt - cur) >= 1e-3f); }
+constexpr int kTdistMaxPasses = 1000;   // the restatement's guard (a scale iteration that does not settle)
+
+// Fixed-point iteration for the t-distribution scale over the stored residuals (unfused pipeline); one workgroup, sums in fp64
+// with a fixed association order (ref: src/lm_optimizer.cpp:338-358). Writes sigma^2. res[i] = NaN: point i gave no residual.
+// list_order (point-list levels, n <= 64 * kTdistChunksMax): the summation order of the fused kernels (see wave_sum64) — the same
+// sigma bit for bit whichever pipeline evaluates the level. Otherwise (dense levels: up to millions of residuals) a strided
+// per-thread sum and a tree.
+constexpr int kTdistChunksMax = 640;   // 64-point chunks of the largest point-list level (160 virtual blocks)
+__global__ void __launch_bounds__(1024) lm_tdist_scale_kernel(const float* __restrict__ res, int n,
+                                                               const LmState* __restrict__ st, int expect_level,
+                                                               float* __restrict__ scale_sqr_out, int list_order) {
+  if (!(st->active != 0 && st->level == expect_level)) return;
+  __shared__ double shs[1024];
+  __shared__ int shn[1024];
+  __shared__ float sh_sigma;
+  __shared__ int sh_done;
+  const int t = threadIdx.x;
+  float cur = 5.0f;
+  if (list_order) {
+    double* part = shs;                 // [kTdistChunksMax] chunk sums of the pass (kTdistChunksMax <= 1024)
+    const int lane = t & 63, wv = t >> 6;
+    const int nchunk = (n + 63) / 64;
+    int n_valid = 0;
+    for (int pass = 0; pass < kTdistMaxPasses; pass++) {
+      const float sigma_sqr = cur * cur;
+      int cnt = 0;
+      for (int c = wv; c < nchunk; c += 16) {
+        const int i = 64 * c + lane;
+        const float r = (i < n) ? res[i] : __builtin_nanf("");
+        const bool ok = (r == r);
+        const double ws = wave_sum64(ok ? (double)tdist_term(r * r, sigma_sqr) : 0.0);
+        if (lane == 0) part[c] = ws;
+        cnt += __popcll(__ballot(ok));
+      }
+      if (pass == 0 && lane == 0) shn[wv] = cnt;
+      __syncthreads();
+      if (pass == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) tot += shn[w];
+        n_valid = tot;
+      }
+      double a = 0.0;
+      for (int c = lane; c < nchunk; c += 64) a += part[c];
+      const double total = wave_sum64(a);   // every wave for itself: nothing to broadcast
+      const float nxt = (n_valid > 0) ? tdist_next_sigma(total, n_valid) : cur;
+      const bool done = (n_valid == 0) || tdist_converged(nxt, cur);
+      cur = nxt;
+      if (done) break;
+      __syncthreads();   // the chunk sums have been read: the next pass may overwrite them
+    }
+    if (t == 0) *scale_sqr_out = cur * cur;
+    return;
+  }
+  for (int guard = 0; guard < kTdistMaxPasses; guard++) {
+    const float init_sigma = cur;
+    const float sigma_sqr = cur * cur;
+    double s = 0.0;
+    int cnt = 0;
+    for (int i = t; i < n; i += 1024) {
+      const float r = res[i];
+      if (r == r) {
+        s += (double)tdist_term(r * r, sigma_sqr);
+        cnt++;
+      }
+    }
+    shs[t] = s;
+    shn[t] = cnt;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+      if (t < o) { shs[t] += shs[t + o]; shn[t] += shn[t + o]; }
+      __syncthreads();
+    }
+    if (t == 0) {
+      const float nxt = (shn[0] > 0) ? tdist_next_sigma(shs[0], shn[0]) : cur;
+      sh_sigma = nxt;
+      sh_done = (shn[0] == 0) || tdist_converged(nxt, init_sigma);
+    }
+    __syncthreads();
+    cur = sh_sigma;
+    const int done = sh_done;
+    __syncthreads();
+    if (done) break;
+  }
+  if (t == 0) *scale_sqr_out = cur * cur;
 }
 
 // =============================================================================================
@@ -1327,6 +1393,32 @@ constexpr int kCoarseLdsBytes = 2 * RowBuf<kLmBlock>::kBytes;  // [2][15][288] f
 constexpr int kCoarseMaxPoints = 1024;  // levels with more points go to the multi-block step kernel (measured: a 512-thread
                                         // workgroup walking ~2000 points four per thread is no faster than seven blocks)
 
+// ComputeScaleNaive inside one workgroup (ref: src/lm_optimizer.cpp:338-358): every thread of the workgroup calls it with its
+// point's squared residual (valid = false: no residual). part: [2][waves] doubles, cnt: [waves] ints of LDS.
+__device__ __forceinline__ float coarse_tdist_sigma(double (*part)[kCoarseBlock / kWave], int* cnt, float e2, bool valid) {
+  constexpr int kW = kCoarseBlock / kWave;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int my_cnt = __popcll(__ballot(valid));
+  float sigma = 5.0f;
+  int n_total = 0;
+  for (int pass = 0; pass < kTdistMaxPasses; pass++) {
+    const double ws = wave_sum64(valid ? (double)tdist_term(e2, sigma * sigma) : 0.0);
+    if (lane == 0) { part[pass & 1][wv] = ws; if (pass == 0) cnt[wv] = my_cnt; }
+    __syncthreads();   // (the other parity is still being read by nobody: a wave passes this barrier only after its reads of pass - 1)
+    if (pass == 0) {
+      int tot = 0;
+#pragma unroll
+      for (int i = 0; i < kW; i++) tot += cnt[i];
+      n_total = tot;
+    }
+    const double total = wave_sum64(lane < kW ? part[pass & 1][lane] : 0.0);
+    const float nxt = (n_total > 0) ? tdist_next_sigma(total, n_total) : sigma;
+    const bool done = (n_total == 0) || tdist_converged(nxt, sigma);
+    sigma = nxt;
+    if (done) break;   // workgroup-uniform: every wave folds the same values in the same order
+  }
+  return sigma;
+}
 __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaunch& q, int min_level) {
   // The pose LM is the latency-critical chain of a frame, while the depth stream floods the CUs with throughput work
   // (selection, SSD scan) at the same time: raise this workgroup's issue priority on the SIMDs it shares with them.
@@ -1360,6 +1452,8 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
   constexpr int kS = 8;
   constexpr int kVbMax = (kCoarseMaxPoints + kLmBlock - 1) / kLmBlock;
   __shared__ double part_sh[kVbMax][32];
+  __shared__ double sc_part[2][kCoarseBlock / kWave];   // t-distribution scale passes: the waves' chunk sums, by pass parity
+  __shared__ int sc_cnt[kCoarseBlock / kWave];
   const int tl = threadIdx.x & (kLmBlock - 1), half = threadIdx.x >> 8;
   float* rows_sh = (float*)red_sh + half * (kRowFloats * RowBuf<kLmBlock>::W);  // [2][15][256 + 8] floats
   const int my_q = tl / kS, my_s = tl % kS;
@@ -1387,6 +1481,13 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
           w = robust_weight(r, a.robust, a.huber_delta, 1.0f);
           valid = true;
         }
+      }
+      if (a.robust == 2) {
+        // t-distribution weights (ref: src/lm_optimizer.cpp:257-261,338-358): the scale iteration over the level's residuals, one
+        // workgroup barrier per pass; chunk = wave (the host sends this kernel only levels of ONE round in this mode: nvb <= 2),
+        // summed in the one order (wave_sum64: the chunks of waves without points are +0)
+        const float sg = coarse_tdist_sigma(sc_part, sc_cnt, r * r, valid);
+        if (valid) w = robust_weight(r, 2, a.huber_delta, sg * sg);
       }
       if (vb0 > 0) __syncthreads();  // the previous round's rows have been consumed
       rows_store(rows_sh, RowBuf<kLmBlock>::W, tl, J, w, r, valid);
@@ -1481,7 +1582,14 @@ struct FineDeadline {
 };
 constexpr int kFineThreads = 2 * kLmBlock;       // a workgroup works on TWO virtual blocks at a time, one per half
 constexpr int kFineKMax = 32;                     // workgroups of one launch: they wait for each other, so each needs a CU of the XCD (32) to itself
-constexpr int kFineXbufWords = 2 * kFineRowsMax * kFineGran + kFineKMax;  // two row buffers + one placement word per workgroup
+// t-distribution scale passes (robust == 2): one fp64 sum per 64-point chunk (wave) and pass, double-buffered by pass parity,
+// as a 16-byte granule pair {upper 32 bits | tag, lower 32 bits | tag}; the chunk's residual count as {count | tag} (pass 0 only).
+constexpr int kScaleChunks = 4 * 2 * kFineKMax;  // 256: four waves per virtual block, <= 2 * kFineKMax virtual blocks per level
+constexpr int kScaleWords = 2 * kScaleChunks * 2 + kScaleChunks;
+constexpr int kFineScaleOff = 2 * kFineRowsMax * kFineGran + kFineKMax;   // (a multiple of 2 words: the pairs are 16-byte aligned)
+static_assert(kFineScaleOff % 2 == 0, "scale granule pairs must be 16-byte aligned");
+constexpr int kFineXbufWords = kFineScaleOff + kScaleWords;  // two row buffers + one placement word per workgroup + the scale area
+constexpr int kTdistMaxEvals = 1023;             // evaluations of one launch the scale tags can tell apart (10 bits)
 typedef unsigned FineG2 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) FineG2 FineG2Global;   // global_load (not flat_load) for the coherent gather loads
 // One partial sum -> two granules {upper 32 bits | tag}, {lower 32 bits | tag}, each ONE 8-byte store. local: every workgroup of the
@@ -1505,6 +1613,85 @@ __device__ __forceinline__ int fine_xcc_id() {
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
   return v & 0xf;
 }
+// ComputeScaleNaive across the workgroups of the persistent launch (ref: src/lm_optimizer.cpp:338-358): called by every wave whose
+// virtual block belongs to the level (vb < nblk; a full wavefront, wave-uniform arguments except e2 / valid), each for itself — no
+// workgroup barrier, no LDS: per pass the wave's chunk sum goes out as one tagged granule pair and all chunk sums of the level come
+// back with L1-bypassing 16-byte loads (lane l: chunks l, l + 64, ...), folded in the one order (wave_sum64). A wave can be at most
+// one pass ahead of the slowest (it cannot finish gathering pass p before every wave has published p), hence the two parities.
+// tag_ev = (launch epoch & 0xfff) << 20 | evaluation << 10; the pass number + 1 fills the low 10 bits (never 0: a cleared buffer
+// matches nothing). Returns sigma; sets *bail when a wait ran out (the Solve then reports -2 like the row exchange does).
+__device__ __forceinline__ float fine_tdist_sigma(unsigned long long* __restrict__ sbuf, int chunk, int nchunk, unsigned tag_ev,
+                                                  float e2, bool valid, bool local, unsigned wait_limit, int* bail) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long* cnts = sbuf + 2 * kScaleChunks * 2;
+  const int my_cnt = __popcll(__ballot(valid));
+  float sigma = 5.0f;
+  int n_total = 0;
+  for (int pass = 0; pass < kTdistMaxPasses; pass++) {
+    const unsigned tag = tag_ev | (unsigned)(pass + 1);
+    const double ws = wave_sum64(valid ? (double)tdist_term(e2, sigma * sigma) : 0.0);
+    unsigned long long* sums = sbuf + (size_t)(pass & 1) * kScaleChunks * 2;
+    if (lane == 0) {
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(ws);
+      const unsigned long long g0 = ((bits >> 32) << 32) | tag, g1 = (bits << 32) | tag;
+      const unsigned long long gc = ((unsigned long long)(unsigned)my_cnt << 32) | tag;
+      if (local) {
+        sums[2 * chunk] = g0; sums[2 * chunk + 1] = g1;
+        if (pass == 0) cnts[chunk] = gc;
+      } else {
+        __hip_atomic_store(sums + 2 * chunk, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sums + 2 * chunk + 1, g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (pass == 0) __hip_atomic_store(cnts + chunk, gc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    FineG2 g[kScaleChunks / 64];
+    unsigned long long gc[kScaleChunks / 64];
+    bool all = false;
+    FineDeadline dl = {0ull, wait_limit};
+    __builtin_amdgcn_s_setprio(0);
+    for (int spin = 0; !all; spin++) {
+      if (spin == 1) dl.t0 = (unsigned long long)wall_clock64();
+      if (spin > 0) { if (dl.expired(spin)) break; __builtin_amdgcn_s_sleep(1); }
+      bool mine = true;
+#pragma unroll
+      for (int u = 0; u < kScaleChunks / 64; u++) {
+        const int c = lane + 64 * u;
+        if (c < nchunk) {
+          g[u] = *(const volatile FineG2Global*)(sums + 2 * c);
+          if (pass == 0) gc[u] = __hip_atomic_load(cnts + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kScaleChunks / 64; u++) {
+        const int c = lane + 64 * u;
+        if (c < nchunk) mine = mine && (g[u].x == tag) && (g[u].z == tag) && (pass != 0 || (unsigned)gc[u] == tag);
+      }
+      all = __all(mine);
+    }
+    __builtin_amdgcn_s_setprio(3);
+    if (!all) { if (lane == 0) *bail = 1; break; }
+    double part = 0.0, cnt = 0.0;
+#pragma unroll
+    for (int u = 0; u < kScaleChunks / 64; u++) {
+      const int c = lane + 64 * u;
+      if (c < nchunk) {
+        part += __longlong_as_double((long long)(((unsigned long long)g[u].y << 32) | (unsigned long long)g[u].w));
+        if (pass == 0) cnt += (double)(unsigned)(gc[u] >> 32);
+      }
+    }
+    const double total = wave_sum64(part);
+    if (pass == 0) n_total = (int)wave_sum64(cnt);   // integers: exact in any order
+    const float nxt = (n_total > 0) ? tdist_next_sigma(total, n_total) : sigma;
+    const bool done = (n_total == 0) || tdist_converged(nxt, sigma);
+    sigma = nxt;
+    if (done) break;
+  }
+  return sigma;
+}
+// kTdist: the t-distribution build (robust == 2: the scale passes of fine_tdist_sigma in front of the weights). A template
+// parameter, not a branch: the Huber / L2 kernel's register count is part of how it shares its CUs with the depth stream
+// (tests/test_abi.py::test_kernel_register_budgets), and the scale loop's gather registers would cost it 27 VGPRs.
+template <bool kTdist>
 __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch& q, int K, int w, unsigned long long* __restrict__ xbuf,
                                              int fault, int lo_level) {
   __builtin_amdgcn_s_setprio(3);  // see lm_coarse_kernel
@@ -1593,8 +1780,15 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
         wgt = robust_weight(r, a.robust, a.huber_delta, 1.0f);
         valid = true;
       }
+      if (kTdist && vb < nblk) {
+        // t-distribution weights need the scale of ALL residuals of this evaluation first (ref: src/lm_optimizer.cpp:257-261)
+        const float sg = fine_tdist_sigma(xbuf + kFineScaleOff, vb * 4 + (tl >> 6), 4 * nblk,
+                                          ((a.fine_epoch & 0xfffu) << 20) | (((unsigned)ev & 0x3ffu) << 10), r * r, valid, local, wait_limit, &bail_sh);
+        if (valid) wgt = robust_weight(r, 2, a.huber_delta, sg * sg);
+      }
       rows_store(rows_sh, RowBuf<kLmBlock>::W, tl, J, wgt, r, valid);   // (the state machine's closing barrier separates this
       __syncthreads();                                                  //  from the previous evaluation's row sums)
+      if (bail_sh) break;   // (block-uniform behind the barrier) a scale pass ran out of time
       if (vb < nblk) {
         double accq = 0.0;
         if (my_q < ODO_NACC) accq = rows_accumulate<kLmBlock, kS>(rows_sh, rowA, rowB, my_s, accq);
@@ -1690,7 +1884,14 @@ __global__ void __launch_bounds__(kFineThreads) lm_fine_kernel(StepArgs a, int K
                                                                int lo_level) {
   if ((blockIdx.x & 7u) != 0u) return;
   const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve, a.span};
-  lm_fine_body(a, q, K, (int)(blockIdx.x >> 3), xbuf, fault, lo_level);
+  lm_fine_body<false>(a, q, K, (int)(blockIdx.x >> 3), xbuf, fault, lo_level);
+}
+// The same with t-distribution weights (a.robust == 2).
+__global__ void __launch_bounds__(kFineThreads) lm_fine_tdist_kernel(StepArgs a, int K, unsigned long long* __restrict__ xbuf, int fault,
+                                                                     int lo_level) {
+  if ((blockIdx.x & 7u) != 0u) return;
+  const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve, a.span};
+  lm_fine_body<true>(a, q, K, (int)(blockIdx.x >> 3), xbuf, fault, lo_level);
 }
 // Batched twin: the sequences of a batched Solve each get an XCD (sequence i: the blocks with blockIdx.x % 8 == i % 8; beyond
 // eight sequences two or more share an XCD, K workgroups each). grid = 8 * K * ceil(n / 8). A sequence whose levels do not
@@ -1707,10 +1908,10 @@ __global__ void __launch_bounds__(kFineThreads) lm_fine_kernel_batch(const StepA
     // nothing to evaluate here, but the launch number is the whole batch's: one workgroup carries the sequence's state from this
     // launch's input buffer to its output buffer (prologue + publish, no level at or above lo_level = none), as a step launch of a
     // finished sequence does
-    if (w == 0) lm_fine_body(a, q, 1, 0, a.xbuf, 0, ODO_MAX_LEVELS_K + 1);
+    if (w == 0) lm_fine_body<false>(a, q, 1, 0, a.xbuf, 0, ODO_MAX_LEVELS_K + 1);
     return;
   }
-  lm_fine_body(a, q, K, w, a.xbuf, fault, a.fine_lo);
+  lm_fine_body<false>(a, q, K, w, a.xbuf, fault, a.fine_lo);   // (a batched Solve never carries t-distribution weights: lm_batch_begin)
 }
 
 // End of a fused Solve when no step launch has reported it (no launch was issued at all, or the host is not polling):

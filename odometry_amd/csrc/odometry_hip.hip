@@ -875,14 +875,9 @@ static int lm_adopt_candidate(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* k
   return 0;
 }
 
-constexpr int kLmListMaxBlocks = 160;
+static inline int lm_list_blocks(int npts);
 static inline int lm_grid_for(const odo_lm* m, int level, int rows, int cols) {
-  if (m->use_list[level]) {
-    long g = ((long)m->npts[level] + kLmBlock - 1) / kLmBlock;
-    if (g > kLmListMaxBlocks) g = kLmListMaxBlocks;
-    if (g < 1) g = 1;
-    return (int)g;
-  }
+  if (m->use_list[level]) return lm_list_blocks(m->npts[level]);
   return lm_grid(rows, cols);
 }
 
@@ -905,7 +900,8 @@ static void lm_launch_eval(odo_lm* m, const LevelView& v, const LevelK& k, int l
     if (m->robust == 2) {
       hipLaunchKernelGGL(lm_residual_only_list_kernel, dim3(nblk), dim3(kLmBlock), 0, s, m->pl[level], n, v.I2, v.rows,
                          v.cols, k, m->ust, level, m->d_res);
-      hipLaunchKernelGGL(lm_tdist_scale_kernel, dim3(1), dim3(1024), 0, s, m->d_res, n, m->ust, level, m->d_scale);
+      hipLaunchKernelGGL(lm_tdist_scale_kernel, dim3(1), dim3(1024), 0, s, m->d_res, n, m->ust, level, m->d_scale,
+                         n <= 64 * kTdistChunksMax ? 1 : 0);   // point-list levels: the fused kernels' summation order
     }
     hipLaunchKernelGGL(lm_residual_list_kernel, dim3(nblk), dim3(kLmBlock), 0, s, m->pl[level], n, v.I2, v.rows, v.cols, k,
                        m->ust, level, m->robust, m->huber_delta, m->d_scale, m->d_partials);
@@ -915,7 +911,7 @@ static void lm_launch_eval(odo_lm* m, const LevelView& v, const LevelK& k, int l
     const int n = (v.rows - 8) * (v.cols - 8);
     hipLaunchKernelGGL(lm_residual_only_kernel, dim3(nblk), dim3(kLmBlock), 0, s, v, k, m->ust, level, m->d_res);
     hipLaunchKernelGGL(lm_tdist_scale_kernel, dim3(1), dim3(1024), 0, s, m->d_res, n > 0 ? n : 0, m->ust, level,
-                       m->d_scale);
+                       m->d_scale, 0);
   }
   launch_dense_eval(lm_dense_level(v, k, 0), m->ust, level, m->robust, m->huber_delta, m->d_scale, m->d_partials, s, nullptr,
                     nullptr, m->dense_plain_div);
@@ -1000,17 +996,72 @@ static unsigned lm_fine_next_epoch(odo_lm* m) {
     (void)hipMemsetAsync(m->d_xbuf, 0, sizeof(unsigned long long) * kFineXbufWords, m->ctx->stream);
     m->fine_epoch = 1;
   }
+  // the scale area's tags (t-distribution passes) carry the low 12 bits of the epoch next to the evaluation and pass numbers:
+  // cleared whenever those start over
+  if ((m->fine_epoch & 0xfffu) == 0u)
+    (void)hipMemsetAsync(m->d_xbuf + kFineScaleOff, 0, sizeof(unsigned long long) * kScaleWords, m->ctx->stream);
   return m->fine_epoch;
 }
 
+constexpr int kLmListMaxBlocks = 160;
+static inline int lm_list_blocks(int npts) {
+  long g = ((long)npts + kLmBlock - 1) / kLmBlock;
+  if (g > kLmListMaxBlocks) g = kLmListMaxBlocks;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+// Which kernel takes which point-list level of a fused Solve (levels stop .. n_levels - 1, coarse to fine):
+//   levels >= *min_level          the coarse launch (one workgroup: few points),
+//   levels [*fine_lo, *min_level) the persistent launch (fine_k workgroups; 0: there is none),
+//   levels [stop, *fine_lo)       a step launch per evaluation.
+// With the persistent launch behind it the coarse launch keeps only the levels that fit ONE round of its workgroup (512 points):
+// a level of two rounds costs less as four virtual blocks on four CUs. Every kernel sums a level in the same order, so where a
+// level runs does not show in the result. The persistent launch pays when its workgroups can hold a level's points in registers
+// (<= 2 virtual blocks each); a level of more blocks (the point-list levels of a 1080p stream: 115 and 160) is better spread over
+// 160 CUs by the step launches. t-distribution weights (robust == 2): the coarse launch always stays at one round.
+static void lm_plan_levels(const odo_lm* m, int stop, int fine_k, int* min_level_out, int* fine_lo_out) {
+  static const int coarse_env = getenv("ODO_COARSE_MAX") ? atoi(getenv("ODO_COARSE_MAX")) : -1;
+  auto fits = [&](int l) { const int nblk = lm_list_blocks(m->npts[l]); return nblk <= 2 * fine_k && m->npts[l] <= nblk * kLmBlock; };
+  int min_level = m->n_levels, fine_lo = m->n_levels;
+  for (int pass = 0; pass < 2; pass++) {
+    const bool want_fine = fine_k > 0 && pass == 0;
+    int coarse_max = coarse_env >= 0 ? (coarse_env < kCoarseMaxPoints ? coarse_env : kCoarseMaxPoints)
+                                     : (want_fine ? kCoarseBlock : kCoarseMaxPoints);
+    if (m->robust == 2 && coarse_max > kCoarseBlock) coarse_max = kCoarseBlock;
+    min_level = m->n_levels;
+    while (min_level > stop && m->npts[min_level - 1] <= coarse_max) min_level--;
+    if (!m->coarse) min_level = m->n_levels;
+    fine_lo = min_level;
+    if (!want_fine) break;
+    while (fine_lo > stop && fits(fine_lo - 1)) fine_lo--;
+    if (fine_lo < min_level) break;   // it takes at least the level under the coarse launch's; else the coarse launch's full reach
+  }
+  *min_level_out = min_level;
+  *fine_lo_out = fine_lo;
+}
+
 // Lowest level of the coarse-to-fine run of point-list levels the fused pipeline can take (it starts at the coarsest level):
-// 0 = the whole Solve, n_levels = nothing (the Solve runs on the unfused pipeline from the start).
-static int lm_fused_stop_level(const odo_lm* m) {
-  if (!(m->fused && m->robust != 2)) return m->n_levels;
+// 0 = the whole Solve, n_levels = nothing (the Solve runs on the unfused pipeline from the start). fine_k: workgroups of the
+// persistent launch this Solve may use.
+// t-distribution weights: every evaluation needs the scale of ALL its residuals before any weight — a fixed-point iteration, one
+// reduction over the level per pass (ref: src/lm_optimizer.cpp:257-261,338-358). The coarse launch (LDS) and the persistent launch
+// (L2 exchange) iterate it in place; a step launch per evaluation cannot (no grid-wide reduction inside a launch), so the fused part
+// of such a Solve ends above the first level neither of the two takes and the unfused pipeline carries on from there.
+static int lm_fused_stop_level(const odo_lm* m, int fine_k) {
+  if (!m->fused) return m->n_levels;
   int stop = m->n_levels;
   while (stop > 0 && m->use_list[stop - 1]) stop--;
+  if (m->robust == 2) {
+    int min_level = 0, fine_lo = 0;
+    lm_plan_levels(m, stop, fine_k, &min_level, &fine_lo);
+    stop = fine_lo;
+    long budget = 0;
+    for (int l = stop; l < m->n_levels; l++) budget += m->max_iters[l] > 0 ? m->max_iters[l] : 0;
+    if (budget > kTdistMaxEvals) stop = m->n_levels;   // (the scale tags count evaluations in 10 bits)
+  }
   return stop;
 }
+static int lm_fused_stop_level(const odo_lm* m) { return lm_fused_stop_level(m, m->fine_k); }
 static bool lm_fused_eligible(const odo_lm* m) { return lm_fused_stop_level(m) < m->n_levels; }
 
 // Give-up policy of the persistent launches (single and batched). A give-up costs one bounded wait (4 ms) + a redo of the Solve on
@@ -1112,31 +1163,10 @@ static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_de
               (double)dbg_buf[8] / dbg_buf[11], (double)dbg_buf[9] / dbg_buf[11], (double)dbg_buf[10] / dbg_buf[11]);
   LmState* st[2] = {m->d_state, m->d_state + 1};
   double* part[2] = {m->d_partials, m->d_partials + (size_t)kLmMaxBlocks * ODO_NACC};
-  // Coarse levels (few points) run inside one workgroup: one launch covers every level >= min_level.
-  int min_level = m->n_levels;
-  // With the persistent launch behind it the coarse launch keeps only the levels that fit ONE round of its workgroup (512 points):
-  // a level of two rounds costs less as four virtual blocks on four CUs. Every kernel sums a level in the same order, so where a
-  // level runs does not show in the result.
-  // The persistent launch pays when its workgroups can hold a level's points in registers (<= 2 virtual blocks each); a level of
-  // more blocks (the point-list levels of a 1080p stream: 115 and 160) is better spread over 160 CUs by the step launches.
-  static const int coarse_env = getenv("ODO_COARSE_MAX") ? atoi(getenv("ODO_COARSE_MAX")) : -1;
-  // fine_lo: the persistent launch takes levels [fine_lo, min_level) — the coarse-to-fine run of levels that fit below the
-  // coarse launch's; the levels under it (if any) follow on step launches, which read the state it leaves like they read the
-  // coarse launch's.
-  auto fits = [&](int l) { return a.lv[l].nblk <= 2 * m->fine_k && a.lv[l].n <= a.lv[l].nblk * kLmBlock; };
-  int fine_lo = m->n_levels;
-  for (int pass = 0; pass < 2; pass++) {
-    const bool want_fine = m->fine_k > 0 && pass == 0;
-    const int coarse_max = coarse_env >= 0 ? (coarse_env < kCoarseMaxPoints ? coarse_env : kCoarseMaxPoints)
-                                           : (want_fine ? kCoarseBlock : kCoarseMaxPoints);
-    min_level = m->n_levels;
-    while (min_level > stop && m->npts[min_level - 1] <= coarse_max) min_level--;
-    if (!m->coarse) min_level = m->n_levels;
-    fine_lo = min_level;
-    if (!want_fine) break;
-    while (fine_lo > stop && fits(fine_lo - 1)) fine_lo--;
-    if (fine_lo < min_level) break;   // it takes at least the level under the coarse launch's; else the coarse launch's full reach
-  }
+  // which kernel takes which level (lm_plan_levels): the coarse launch levels >= min_level, the persistent launch
+  // [fine_lo, min_level), step launches what is left above `stop` (t-distribution weights: nothing — stop == fine_lo)
+  int min_level = m->n_levels, fine_lo = m->n_levels;
+  lm_plan_levels(m, stop, m->fine_k, &min_level, &fine_lo);
   m->last_coarse = (min_level < m->n_levels) ? 1 : 0;
   if (min_level < m->n_levels) {
     int coarse_budget = 0;
@@ -1161,13 +1191,20 @@ static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_de
     a.span = lm_span_slot(m, jb.launches, false);
     a.fine_epoch = lm_fine_next_epoch(m);
     a.fine_wait = m->fine_wait;
-    hipLaunchKernelGGL(lm_fine_kernel, dim3(8 * m->fine_k), dim3(kFineThreads), 0, s, a, m->fine_k, m->d_xbuf, m->fine_fault, fine_lo);
+    if (m->robust == 2)
+      hipLaunchKernelGGL(lm_fine_tdist_kernel, dim3(8 * m->fine_k), dim3(kFineThreads), 0, s, a, m->fine_k, m->d_xbuf, m->fine_fault, fine_lo);
+    else
+      hipLaunchKernelGGL(lm_fine_kernel, dim3(8 * m->fine_k), dim3(kFineThreads), 0, s, a, m->fine_k, m->d_xbuf, m->fine_fault, fine_lo);
     jb.seq++;
     jb.launches++;
     if (fine_lo <= stop) {   // nothing left for step launches
       jb.issued_all = true;
       jb.result_by_launch = true;
     }
+  }
+  if (min_level <= stop && min_level < m->n_levels) {   // the coarse launch covers the whole fused part: it reports the result itself
+    jb.issued_all = true;
+    jb.result_by_launch = true;
   }
   jb.grid = grid; jb.budget = budget; jb.min_level = min_level;
   jb.active = 1;
@@ -1290,7 +1327,7 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
   // Early exit without a host sync: the device publishes its progress in host-mapped memory; the host stays at
   // most `run_ahead` launches ahead of the device and stops issuing launches once the device reports that the Solve
   // (fused pipeline) or the level (unfused pipeline) has ended. Stale launches are no-ops on the device either way.
-  const bool fused = resumed || lm_fused_eligible(m);
+  bool fused = resumed || lm_fused_eligible(m);
   int seq = 0;
   bool started = resumed;
   const int fine_k_asked = m->fine_k;
@@ -1357,6 +1394,7 @@ fused_again:
       started = false;
       launches = 0;
       HIP_OK(hipStreamSynchronize(s));
+      fused = lm_fused_eligible(m);   // (t-distribution weights: without the persistent launch the fused part may be empty)
       goto fused_again;
     }
     if (fine_k_asked > 0 && m->fine_k == 0 && m->fine_strikes < 3) m->fine_k = fine_k_asked;
@@ -1446,21 +1484,8 @@ static void lm_fill_step_args(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* c
   a.st2[0] = m->d_state; a.st2[1] = m->d_state + 1;
   a.part2[0] = m->d_partials; a.part2[1] = m->d_partials + (size_t)kLmMaxBlocks * ODO_NACC;
   // which kernel takes which level: as in lm_fused_begin (fine_k workgroups per sequence in the batched persistent launch; 0: none)
-  static const int coarse_env = getenv("ODO_COARSE_MAX") ? atoi(getenv("ODO_COARSE_MAX")) : -1;
-  auto fits = [&](int l) { return a.lv[l].nblk <= 2 * fine_k && a.lv[l].n <= a.lv[l].nblk * kLmBlock; };
   int min_level = m->n_levels, fine_lo = m->n_levels;
-  for (int pass = 0; pass < 2; pass++) {
-    const bool want_fine = fine_k > 0 && pass == 0;
-    const int coarse_max = coarse_env >= 0 ? (coarse_env < kCoarseMaxPoints ? coarse_env : kCoarseMaxPoints)
-                                           : (want_fine ? kCoarseBlock : kCoarseMaxPoints);
-    min_level = m->n_levels;
-    while (min_level > stop && m->npts[min_level - 1] <= coarse_max) min_level--;
-    if (!m->coarse) min_level = m->n_levels;
-    fine_lo = min_level;
-    if (!want_fine) break;
-    while (fine_lo > stop && fits(fine_lo - 1)) fine_lo--;
-    if (fine_lo < min_level) break;
-  }
+  lm_plan_levels(m, stop, fine_k, &min_level, &fine_lo);
   a.min_level = min_level;
   a.fine_lo = fine_lo;
   a.xbuf = m->d_xbuf;

@@ -583,22 +583,76 @@ def test_persistent_launch_and_its_fallback_give_the_same_pose(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_tdistribution_weights_same_pose_on_every_pipeline(O, monkeypatch):
+    """configs[0]'s own parameter set (ref: test_optimizer.cpp:53-54,59-67: unsmoothed pyramids, identity start, robust_estimator = 2)
+    through (a) the coarse + persistent launches with the scale iteration inside them, (b) the coarse launch + the unfused pipeline
+    below it (ODO_LM_NO_FINE), (c) the unfused pipeline alone (ODO_LM_UNFUSED), (d) a persistent launch that gives up
+    (ODO_LM_FINE_FAULT: redone on (b)): the same pose and the same evaluation trace bit for bit — one summation order for the scale
+    passes everywhere — and the oracle's trace."""
+    from odometry_amd import api, synth
+    seq = synth.make_sequence(2, seed=5, with_depth=True)
+    L0, L1 = seq["left"][0], seq["left"][1]
+    inv = synth.semi_dense_inverse_depth(seq["depth"][0], L0, stride_keep=0.1, seed=3)   # ~12 k points on level 0: every level fits
+    p0, d0, p1 = api.ImagePyramid(4, L0, False), api.DepthPyramid(4, inv, False), api.ImagePyramid(4, L1, False)
+    ref = O.lm_solve(O.image_pyramid(L0, 4, False, flat=True), O.depth_pyramid(inv, 4, flat=True), O.image_pyramid(L1, 4, False, flat=True),
+                     376, 1241, O.lm_params(robust=2))
+
+    def solve(n=1):
+        lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 2, 28.0)
+        out = []
+        for _ in range(n):
+            T = lm.Solve(p0, d0, p1).copy()
+            assert lm.last_status == 0
+            out.append((T, [(a["level"], a["iter"], a["n_res"], a["accepted"], a["stop"], a["err"], a["lambda_after"]) + tuple(a["delta"])
+                            for a in lm.trace()], lm.launch_stats()[1]))
+            lm.Reset(np.eye(4), 0.01)                      # ref: test_optimizer.cpp:104
+        st = lm.persistent_stats()
+        lm.close()
+        return out, st
+
+    fused, st = solve(2)
+    assert st[0] > 0 and st[1] == 0
+    assert fused[0][2] <= 3, f"{fused[0][2]} launches: the t-distribution Solve did not stay inside the coarse + persistent launches"
+    assert se3_log_norm(ref["pose"], fused[0][0]) < 1e-5 and len(fused[0][1]) == ref["n_evals"]
+    for a, b in zip(fused[0][1], ref["trace"]):
+        assert a[:5] == (b["level"], b["iter"], b["n_res"], b["accepted"], b["stop"])
+        assert abs(a[5] - b["err"]) <= 1e-6 * abs(b["err"])
+    assert np.array_equal(fused[0][0], fused[1][0]) and fused[0][1] == fused[1][1]
+    for env in ("ODO_LM_NO_FINE", "ODO_LM_UNFUSED", "ODO_LM_FINE_FAULT"):
+        monkeypatch.setenv(env, "1")
+        other, st = solve(2 if env == "ODO_LM_FINE_FAULT" else 1)
+        monkeypatch.delenv(env)
+        if env == "ODO_LM_FINE_FAULT":
+            assert st[1] == 2                              # both Solves gave up and were redone
+        else:
+            assert st == (0, 0) or env == "ODO_LM_UNFUSED"
+        for T, tr, _ in other:
+            assert np.array_equal(T, fused[0][0]), env
+            assert tr == fused[0][1], env
+    for o in (p0, d0, p1):
+        o.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("robust", [1, 2])
 @pytest.mark.parametrize("keep,iters", [(1.0, [10, 20, 30, 30]), (0.45, [10, 20, 30, 30]), (0.12, [10, 20, 30, 30, 30]),
                                         (0.45, [10, 20]), (0.03, [10, 20, 30, 30]), (1.0, [0, 20, 0, 30])])
-def test_lm_solve_across_keyframe_densities_and_pyramid_depths(api, O, kitti_seq, keep, iters):
+def test_lm_solve_across_keyframe_densities_and_pyramid_depths(api, O, kitti_seq, keep, iters, robust):
     """Which kernel runs which level depends on the keyframe's point counts (coarse launch: levels of one round of its workgroup;
     persistent launch: the run of levels of <= 64 virtual blocks under it; step launches: what is left) — dense keyframes, sparse
     ones, two to five pyramid levels, zero budgets: the evaluation trace and the pose match the oracle in every split, and the
-    persistent launch never falls back."""
+    persistent launch never falls back. robust = 2 (t-distribution weights, ref: src/lm_optimizer.cpp:257-261,338-358;
+    test_optimizer.cpp:65): the scale iteration runs inside the coarse and the persistent launch, and what neither takes goes to
+    the unfused pipeline below the hand-over level."""
     from odometry_amd import synth
     n = len(iters)
     L0, L1 = kitti_seq["left"][0], kitti_seq["left"][1]
     inv = synth.semi_dense_inverse_depth(kitti_seq["depth"][0], L0, stride_keep=keep, seed=3)
     p0, d0, p1 = api.ImagePyramid(n, L0, True), api.DepthPyramid(n, inv, False), api.ImagePyramid(n, L1, True)
-    lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, iters, np.eye(4), None, 1, 28.0)
+    lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, iters, np.eye(4), None, robust, 28.0)
     T = lm.Solve(p0, d0, p1)
     ref = O.lm_solve(O.image_pyramid(L0, n, flat=True), O.depth_pyramid(inv, n, flat=True), O.image_pyramid(L1, n, flat=True),
-                     376, 1241, O.lm_params(max_iters=tuple(iters)))
+                     376, 1241, O.lm_params(max_iters=tuple(iters), robust=robust))
     assert lm.last_status == ref["status"] == 0
     assert se3_log_norm(ref["pose"], T) < 1e-5
     tr = lm.trace()
@@ -606,6 +660,7 @@ def test_lm_solve_across_keyframe_densities_and_pyramid_depths(api, O, kitti_seq
     for a, b in zip(tr, ref["trace"]):
         assert (a["level"], a["iter"], a["n_res"], a["accepted"], a["stop"]) == \
                (b["level"], b["iter"], b["n_res"], b["accepted"], b["stop"])
+        assert abs(a["err"] - b["err"]) <= 1e-6 * abs(b["err"])
     npts, _ = lm.points()
     st = lm.persistent_stats()
     assert st[0] > 0 and st[1] == 0, (npts, st)

@@ -241,6 +241,12 @@ int odo_depth_time_stages(odo_depth* d, const float* left_dev, const float* righ
                           float us[3], double* candidates, int* n_selected);
 /* ReportStatus data (ref: src/depth_estimate.cpp:465-468) + counts printed by ComputeDepth (:62,74). */
 int odo_depth_report(const odo_depth* d, int* iters, float* cost, int* n_selected, int* n_matched, int* n_valid);
+/* DepthOptimization (ref: src/depth_estimate.cpp:141-191) runs as ONE persistent launch (depth_lm_persistent_kernel: 32 workgroups
+ * of one XCD, every point's state in registers, one tagged 16-byte pair per 256 points and iteration through L2) instead of a launch
+ * per iteration; the step launches are its fall-back, bit-identical. *on = 1 while the persistent launch is in use (0: off, by
+ * choice — ODO_DEPTH_NO_PERSIST — or after three give-ups, with the pose LM's back-off: odo_lm_persistent_backoff), *fallbacks =
+ * ComputeDepth calls whose launch gave up waiting for one of its workgroups and that were run again on the step launches. */
+int odo_depth_persistent_stats(const odo_depth* d, int* on, int* fallbacks);
 int odo_depth_destroy(odo_depth* d);
 
 /* ---- tracker: the runner's frame loop ---------------------------------------------------------------

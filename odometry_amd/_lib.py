@@ -100,6 +100,7 @@ SIGNATURES = {
     "odo_depth_disparity": (C.c_int, [_vp, _fp, _fp, C.c_int, C.c_int, _u8p, _fp, _fp]),
     "odo_depth_time_stages": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _fp, _dp, _ip]),
     "odo_depth_report": (C.c_int, [_vp, _ip, _fp, _ip, _ip, _ip]),
+    "odo_depth_persistent_stats": (C.c_int, [_vp, _ip, _ip]),
     "odo_depth_destroy": (C.c_int, [_vp]),
     "odo_tracker_default_params": (C.c_int, [C.POINTER(TrackerParams)]),
     "odo_tracker_create": (C.c_int, [C.c_int, C.POINTER(TrackerParams), C.POINTER(_vp)]),

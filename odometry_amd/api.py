@@ -356,6 +356,12 @@ class DepthEstimator:
                                               C.byref(nv)), "odo_depth_report")
         return dict(iters=it.value, cost=cost.value, n_selected=ns.value, n_matched=nm.value, n_valid=nv.value)
 
+    def persistent_stats(self):
+        """(1 while DepthOptimization runs as one persistent launch — 0: a launch per iteration —, calls redone on the step launches)"""
+        a, b = C.c_int(0), C.c_int(0)
+        L.check(self.ctx.lib.odo_depth_persistent_stats(self.h, C.byref(a), C.byref(b)), "odo_depth_persistent_stats")
+        return a.value, b.value
+
     def ReportStatus(self):
         r = self.report()
         print(f"    Number of iters performed: {r['iters']}(max allowed: {self.max_iters_})")

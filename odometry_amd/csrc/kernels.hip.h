@@ -2373,13 +2373,14 @@ __device__ __forceinline__ void depth_lm_step_kernel_body(
     int fn = 0;
     {
       const int lane = t & 63;
+      double fnd = 0.0;
 #pragma unroll
       for (int j = 0; j < (kDlmBlocks + 63) / 64; j++) {
         const int b = lane + 64 * j;
-        if (b < kDlmBlocks) { fe += pe[b]; fn += pn[b]; }
+        if (b < kDlmBlocks) { fe += pe[b]; fnd += (double)pn[b]; }
       }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { fe += __shfl_xor(fe, o, 64); fn += __shfl_xor(fn, o, 64); }
+      fe = wave_sum64(fe);                 // (the order of depth_lm_persistent_kernel's fold: both give the same bits)
+      fn = (int)wave_sum64(fnd);           // integers: exact
     }
     const float err_now = (1.0f / (float)fn) * (float)fe;  // :239
     const int mode = depth_lm_decide(&st, err_now, precision);  // 0 reject+continue, 1 accept+continue, 2 reject+break, 3 accept+break
@@ -2422,9 +2423,9 @@ __device__ __forceinline__ void depth_lm_step_kernel_body(
       bb[s] = -r_diff * w_i * r_i;                                                       // :235
     }
   }
-  // block sum: butterfly inside each wave, then the four wave sums in a fixed order (one barrier)
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { esum += __shfl_xor(esum, o, 64); nact += __shfl_xor(nact, o, 64); }
+  // block sum: wave_sum64 inside each wave, then the four wave sums in a fixed order (one barrier)
+  esum = wave_sum64(esum);
+  nact = __popcll(__ballot(nact != 0));
   if ((t & 63) == 0) { shs[t >> 6] = esum; shn[t >> 6] = nact; }
   __syncthreads();
   if (t == 0) {
@@ -2440,6 +2441,249 @@ __global__ void __launch_bounds__(kDlmBlock) depth_lm_step_kernel(
     int* __restrict__ part_n /* [2][blocks] */, float tx, float fx, float huber_delta, float lambda0, float precision,
     int max_iters, int* __restrict__ host_prog) {
   depth_lm_step_kernel_body(k, left, right, cols, pts, cnt, d0, scratch, state, part_e, part_n, tx, fx, huber_delta, lambda0, precision, max_iters, host_prog);
+}
+
+// =============================================================================================
+// DepthOptimization in ONE launch (round 4): the whole iteration of ref: src/depth_estimate.cpp:141-168 plus the write-back and
+// filters of :176-191 inside a persistent kernel, instead of a launch per iteration (~27 dependent launches of 4.8 us per frame).
+// K = 32 workgroups of 256 threads on one XCD; workgroup g owns the 256-slot virtual blocks 5 g .. 5 g + 4 — exactly the blocks of
+// depth_lm_step_kernel — and thread t of it the slots (5 g + j) * 256 + t, whose whole state (current / previous / trial inverse
+// depth, diagonal of JtWJ, -JtWr, last residual, the left pixel) stays in registers for all iterations. Per iteration only the
+// global error crosses workgroups (:150, the one accept / reject decision all points share): every virtual block's {sum w r^2, N}
+// goes out as ONE tagged 16-byte granule pair and every wave gathers the 160 pairs itself with L1-bypassing loads (no flag, no
+// fence, no hand-over through LDS: profiles/r04_scalar_exchange.txt) and folds them in depth_lm_step_kernel's order, so both give
+// the same bits: the step launches stay as the fall-back (a launch that cannot get its workgroups resident gives up within the
+// wait bound, reports it through the statistics, and the host runs the job again on them) and as the batched tracker's path.
+// A granule = {32 bits of payload | 16 bits of extra payload | 16-bit tag}; tag = (launch epoch & 0xff) << 8 | iteration + 1 (the
+// host clears the buffer whenever the epoch's low byte starts over, so a stale granule cannot pass for a new one); the pairs are
+// double-buffered by iteration parity (a wave cannot be two iterations ahead of the slowest: it needs everybody's pair of k - 1).
+// =============================================================================================
+constexpr int kDpK = 32;                         // workgroups (they wait for each other: all must be resident at once)
+constexpr int kDpVb = kDlmBlocks / kDpK;         // virtual blocks per workgroup = slots per thread: 5
+constexpr int kDpMaxIters = 250;                 // the 8-bit iteration field of the tags
+constexpr int kDpXbufWords = 2 * kDlmBlocks * 2 + kDpK;   // two parities of 160 pairs + one placement word per workgroup
+static_assert(kDlmBlocks % kDpK == 0, "every workgroup owns the same number of virtual blocks");
+struct DepthPersistArgs {
+  const float *left, *right;
+  int cols;
+  const uint32_t* pts;
+  const int* cnt;
+  const float* d0;
+  const uint8_t* matched;
+  DepthLmState* state_out;      // final driver state (iterations, last error) for depth_stats_kernel
+  float tx, fx, huber_delta, lambda0, precision;
+  int max_iters;
+  float photo_th, min_depth, max_depth;
+  uint8_t* val;
+  float* dep;
+  int* counts;                  // [kDlmBlocks][3] {valid, selected, matched} per virtual block
+  unsigned long long* xbuf;     // kDpXbufWords
+  unsigned epoch;
+  unsigned wait_ticks;          // bound of one wait (100 MHz wall clock); 0: kFineWaitTicks
+  int* gave_up;                 // device word: set to 1 by a workgroup whose wait ran out (depth_stats_kernel reads and clears it)
+  int fault;                    // test hook (ODO_DEPTH_PERSIST_FAULT): virtual block 0's pair is never published
+  unsigned long long* dbg;      // diagnostic (ODO_DEPTH_STAMPS): cycle sums of workgroup 0's phases, else null
+};
+__global__ void __launch_bounds__(kDlmBlock) depth_lm_persistent_kernel(DepthPersistArgs a) {
+  if ((blockIdx.x & 7u) != 4u) return;            // every eighth block: one XCD (not the one the pose LM's persistent launch sits on)
+  const int g = (int)(blockIdx.x >> 3), t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  __shared__ double sh_e[kDpVb][kDlmBlock / 64];
+  __shared__ int sh_n[kDpVb][kDlmBlock / 64];
+  __shared__ int sh_c[kDpVb][kDlmBlock / 64][3];
+  __shared__ int local_sh, bail_sh;
+  const unsigned wait_limit = a.wait_ticks ? a.wait_ticks : kFineWaitTicks;
+  unsigned long long* place = a.xbuf + 2 * kDlmBlocks * 2;
+  const unsigned ep = (a.epoch & 0xffu) << 8;
+  if (t == 0) {
+    local_sh = 0; bail_sh = 0;
+    __hip_atomic_store(place + g, ((unsigned long long)(unsigned)fine_xcc_id() << 32) | (a.epoch + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  // ---- my slots: everything an iteration needs, in registers ----
+  bool ok[kDpVb];
+  uint32_t pk[kDpVb];
+  float lft[kDpVb], cur[kDpVb], pre[kDpVb], tmp[kDpVb], res[kDpVb], jt[kDpVb], bb[kDpVb];
+#pragma unroll
+  for (int j = 0; j < kDpVb; j++) {
+    const int s = (g * kDpVb + j) * kDlmBlock + t;
+    ok[j] = (s % kSelCap) < a.cnt[s / kSelCap];
+    pk[j] = ok[j] ? a.pts[s] : 0u;
+    lft[j] = ok[j] ? a.left[(size_t)(pk[j] >> 16) * a.cols + (pk[j] & 0xffffu)] : 0.0f;
+    const float v = ok[j] ? a.d0[s] : 0.0f;
+    cur[j] = v; pre[j] = 0.0f; tmp[j] = v; res[j] = 0.0f; jt[j] = 1.0f; bb[j] = 0.0f;   // :121-137
+  }
+  // does every workgroup of this launch share my XCD? (then plain stores stay in its L2, where the gather loads find them)
+  if (t < 64) {
+    bool same = true, got = (t >= kDpK);
+    if (t < kDpK) {
+      unsigned long long pw = 0;
+      const FineDeadline dl = {(unsigned long long)wall_clock64(), wait_limit};
+      for (int spin = 0; !got; spin++) {
+        pw = __hip_atomic_load(place + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        got = ((unsigned)pw == a.epoch + 1u);
+        if (!got && dl.expired(spin)) break;
+      }
+      same = got && ((int)(pw >> 32) == fine_xcc_id());
+    }
+    const bool all_got = __all(got), all_same = __all(same);
+    if (t == 0) { local_sh = (all_got && all_same) ? 1 : 0; if (!all_got) bail_sh = 1; }
+  }
+  __syncthreads();
+  const bool local = local_sh != 0;
+  DepthLmState st;
+  depth_lm_begin(&st, a.lambda0, a.max_iters);      // :92-96
+  const bool placed = bail_sh == 0;   // (workgroup-uniform: read behind the barrier above)
+  unsigned long long c_gather = 0, c_decide = 0, c_eval = 0, c_sum = 0, c_it = 0, c_last = a.dbg ? __builtin_readcyclecounter() : 0;
+  const unsigned long long c_begin = c_last;
+  auto lap = [&](unsigned long long& sum) {
+    if (a.dbg) { const unsigned long long now = __builtin_readcyclecounter(); sum += now - c_last; c_last = now; }
+  };
+  for (int k = 0; placed && !st.done; k++) {   // (st: every wave derives the same state)
+    FineG2 q[(kDlmBlocks + 63) / 64];
+    c_it++;
+    if (k > 0) {
+      // ---- gather the pairs of evaluation k - 1 (every wave for itself) ----
+      const unsigned tag = ep | (unsigned)k;         // evaluation k - 1 was published with iteration field k
+      const unsigned long long* buf = a.xbuf + (size_t)((k - 1) & 1) * kDlmBlocks * 2;
+      bool all = false;
+      FineDeadline dl = {0ull, wait_limit};
+      for (int spin = 0; !all; spin++) {
+        if (spin == 1) dl.t0 = (unsigned long long)wall_clock64();
+        if (spin > 0 && dl.expired(spin)) break;
+        bool mine = true;
+#pragma unroll
+        for (int u = 0; u < (kDlmBlocks + 63) / 64; u++) {
+          const int b = lane + 64 * u;
+          if (b < kDlmBlocks) q[u] = *(const volatile FineG2Global*)(buf + 2 * b);
+        }
+#pragma unroll
+        for (int u = 0; u < (kDlmBlocks + 63) / 64; u++) {
+          const int b = lane + 64 * u;
+          if (b < kDlmBlocks) mine = mine && ((q[u].x & 0xffffu) == tag) && ((q[u].z & 0xffffu) == tag);
+        }
+        all = __all(mine);
+      }
+      if (!all && lane == 0) bail_sh = 1;
+      __syncthreads();      // a wait that ran out in ANY wave ends the loop for the whole workgroup at the same point
+      lap(c_gather);
+      if (bail_sh) break;
+      // ---- decision for evaluation k - 1 (identical arithmetic in every wave: depth_lm_step_kernel's fold) ----
+      double fe = 0.0, fnd = 0.0;
+#pragma unroll
+      for (int u = 0; u < (kDlmBlocks + 63) / 64; u++) {
+        const int b = lane + 64 * u;
+        if (b < kDlmBlocks) {
+          fe += __longlong_as_double((long long)(((unsigned long long)q[u].y << 32) | (unsigned long long)q[u].w));
+          fnd += (double)(q[u].x >> 16);
+        }
+      }
+      fe = wave_sum64(fe);
+      const int fn = (int)wave_sum64(fnd);
+      const float err_now = (1.0f / (float)fn) * (float)fe;           // :239
+      const int mode = depth_lm_decide(&st, err_now, a.precision);    // :150-161
+#pragma unroll
+      for (int j = 0; j < kDpVb; j++) {
+        if (mode != 2 && ok[j]) {
+          float c;
+          if (mode == 0) c = pre[j];                  // :153
+          else { c = tmp[j]; pre[j] = c; }            // :155-156
+          cur[j] = c;
+          if (mode != 3) {
+            const float jj = jt[j];
+            const float A = jj + st.lambda * jj;      // :164
+            const float dd = (1.0f / A) * bb[j];      // :165
+            tmp[j] = dd + c;                          // :166
+          }
+        }
+      }
+      depth_lm_advance(&st, mode, a.max_iters);       // :167, :141
+      if (a.dbg) asm volatile("" ::"v"(tmp[0]), "v"(tmp[kDpVb - 1]));
+      lap(c_decide);
+      if (st.done) break;
+    }
+    // ---- evaluation k at tmp (ComputeResidualJacobian :200-242) ----
+    double esum[kDpVb];
+    int nact[kDpVb];
+#pragma unroll
+    for (int j = 0; j < kDpVb; j++) {
+      esum[j] = 0.0; nact[j] = 0;
+      if (ok[j]) {
+        const int x = (int)(pk[j] & 0xffffu), y = (int)(pk[j] >> 16);
+        const float wf = floorf((float)x - a.tx * a.fx * tmp[j]);       // :217
+        if (!(wf >= 2.0f) || !(wf <= (float)(a.cols - 2))) {            // :219-223
+          jt[j] = 0.0f; bb[j] = 0.0f; res[j] = -1000.0f;
+        } else {
+          const int wx = (int)wf;
+          const float* Rr = a.right + (size_t)y * a.cols;
+          const float r_i = lft[j] - Rr[wx];                                                       // :226
+          const float w_i = (fabsf(r_i) <= a.huber_delta) ? 1.0f : a.huber_delta / fabsf(r_i);     // :228
+          const float r_diff = a.tx * a.fx * 0.5f * (Rr[wx + 1] - Rr[wx - 1]);                     // :229
+          res[j] = fabsf(r_i);
+          nact[j] = 1;
+          esum[j] = (double)(r_i * r_i * w_i);                                                     // :233
+          jt[j] = r_diff * r_diff * w_i;                                                           // :234
+          bb[j] = -r_diff * w_i * r_i;                                                             // :235
+        }
+      }
+    }
+    if (a.dbg) asm volatile("" ::"v"(esum[0]), "v"(esum[kDpVb - 1]));
+    lap(c_eval);
+#pragma unroll
+    for (int j = 0; j < kDpVb; j++) {
+      const double ws = wave_sum64(esum[j]);
+      const int wn = __popcll(__ballot(nact[j] != 0));
+      if (lane == 0) { sh_e[j][wv] = ws; sh_n[j][wv] = wn; }
+    }
+    __syncthreads();
+    lap(c_sum);
+    if (t < kDpVb) {
+      const int vb = g * kDpVb + t;
+      const double e = (sh_e[t][0] + sh_e[t][1]) + (sh_e[t][2] + sh_e[t][3]);     // depth_lm_step_kernel's block sum
+      const int n = (sh_n[t][0] + sh_n[t][1]) + (sh_n[t][2] + sh_n[t][3]);
+      const unsigned tag = ep | (unsigned)(k + 1);
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(e);
+      const unsigned long long g0 = ((bits >> 32) << 32) | ((unsigned long long)(unsigned)n << 16) | tag, g1 = (bits << 32) | tag;
+      unsigned long long* dst = a.xbuf + (size_t)(k & 1) * kDlmBlocks * 2 + 2 * vb;
+      if (!(a.fault && vb == 0)) {
+        if (local) { dst[0] = g0; dst[1] = g1; }
+        else {
+          __hip_atomic_store(dst, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(dst + 1, g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    // (no second barrier: sh_e / sh_n are rewritten only after the next gather, which needs this workgroup's own pairs — published
+    //  by the threads that read them)
+  }
+  __syncthreads();
+  const bool bailed = bail_sh != 0;   // (workgroup-uniform behind the barrier)
+  if (bailed && t == 0) __hip_atomic_store(a.gave_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // ---- write-back + filters (:176-191) and the per-block counts of depth_finalize_kernel ----
+#pragma unroll
+  for (int j = 0; j < kDpVb; j++) {
+    const int s = (g * kDpVb + j) * kDlmBlock + t;
+    bool good = false;
+    if (ok[j] && !bailed) {
+      const size_t o = (size_t)(pk[j] >> 16) * a.cols + (pk[j] & 0xffffu);
+      const float c = cur[j], rs = res[j];
+      good = !(rs > a.photo_th || rs == -1000.0f);
+      if (good && (1.0f / c > a.max_depth || 1.0f / c < a.min_depth)) good = false;
+      a.val[o] = good ? 1 : 0;
+      a.dep[o] = good ? c : 0.0f;
+    }
+    const int c0 = __popcll(__ballot(good)), c1 = __popcll(__ballot(ok[j])), c2 = __popcll(__ballot(ok[j] && a.matched[s] != 0));
+    if (lane == 0) { sh_c[j][wv][0] = c0; sh_c[j][wv][1] = c1; sh_c[j][wv][2] = c2; }
+  }
+  __syncthreads();
+  if (t < kDpVb * 3) {
+    const int j = t / 3, qn = t % 3;
+    a.counts[(g * kDpVb + j) * 3 + qn] = (sh_c[j][0][qn] + sh_c[j][1][qn]) + (sh_c[j][2][qn] + sh_c[j][3][qn]);
+  }
+  if (g == 0 && t == 0) *a.state_out = st;
+  if (a.dbg && g == 0 && t == 0) {
+    a.dbg[0] += c_gather; a.dbg[1] += c_decide; a.dbg[2] += c_eval; a.dbg[3] += c_sum; a.dbg[4] += c_it; a.dbg[5] += 1;
+    a.dbg[6] += local ? 1 : 0; a.dbg[7] += __builtin_readcyclecounter() - c_begin;
+  }
 }
 
 // Write-back + filters (ref: src/depth_estimate.cpp:176-191) and per-block counts {valid, selected, matched}.
@@ -2488,10 +2732,12 @@ __global__ void __launch_bounds__(kDlmBlock) depth_finalize_kernel(int run_lm, i
   depth_finalize_kernel_body(run_lm, cols, pts, cnt, matched, scratch, photo_th, min_depth, max_depth, val, dep, counts);
 }
 
+// gave_up (optional): device word a persistent depth-LM launch sets when one of its waits ran out — the statistics then carry
+// status -2 (the host runs the job again on the step launches) and the word is cleared for the next job.
 __device__ __forceinline__ void depth_stats_kernel_body(int run_lm, int n_launches, const int* __restrict__ counts,
                                                                 const DepthLmState* __restrict__ state,
                                                                 DepthLmStats* __restrict__ stats /* host-mapped */,
-                                                                int* __restrict__ done_flag, int token) {
+                                                                int* __restrict__ done_flag, int token, int* __restrict__ gave_up = nullptr) {
   __shared__ int sh[3][kDlmBlock];
   const int t = threadIdx.x;
   for (int q = 0; q < 3; q++) sh[q][t] = (t < kDlmBlocks) ? counts[t * 3 + q] : 0;
@@ -2508,14 +2754,15 @@ __device__ __forceinline__ void depth_stats_kernel_body(int run_lm, int n_launch
     stats->n_selected = sh[1][0];
     stats->n_matched = sh[2][0];
     stats->status = (run_lm && sh[0][0] < 500) ? -1 : 0;  // :192-197
+    if (gave_up && *gave_up) { stats->status = -2; *gave_up = 0; }
     __hip_atomic_store(done_flag, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 __global__ void __launch_bounds__(kDlmBlock) depth_stats_kernel(int run_lm, int n_launches, const int* __restrict__ counts,
                                                                 const DepthLmState* __restrict__ state,
                                                                 DepthLmStats* __restrict__ stats /* host-mapped */,
-                                                                int* __restrict__ done_flag, int token) {
-  depth_stats_kernel_body(run_lm, n_launches, counts, state, stats, done_flag, token);
+                                                                int* __restrict__ done_flag, int token, int* __restrict__ gave_up) {
+  depth_stats_kernel_body(run_lm, n_launches, counts, state, stats, done_flag, token, gave_up);
 }
 
 }  // namespace odo

@@ -2150,6 +2150,15 @@ struct odo_depth {
   DepthLmStats* d_stats_map;  // device alias of the host-mapped h_stats
   int token;
   DepthLmStats last;
+  // DepthOptimization in ONE persistent launch (depth_lm_persistent_kernel) instead of a launch per iteration; the step launches
+  // are its fall-back (give-up policy as the pose LM's persistent launch: fine_note_giveup / fine_note_clean)
+  int persist, persist_cfg;       // 1: on (ODO_DEPTH_NO_PERSIST=1 / three give-ups: off)
+  int persist_off_once;           // the job being run again after a give-up goes to the step launches
+  int persist_bails, persist_strikes, persist_clean, persist_offs;
+  int persist_fault;              // test hook (ODO_DEPTH_PERSIST_FAULT)
+  unsigned persist_epoch, persist_wait;
+  unsigned long long* d_xbuf;     // kDpXbufWords
+  int* d_gave_up;
 };
 
 extern "C" int odo_depth_create(odo_ctx* ctx, float grad_th, float ssd_th, float photo_th, float min_depth, float max_depth,
@@ -2184,6 +2193,13 @@ extern "C" int odo_depth_create(odo_ctx* ctx, float grad_th, float ssd_th, float
   memset(d->h_prog, 0, sizeof(int) * 8);
   d->poll = getenv("ODO_NO_POLL") ? 0 : 1;
   d->run_ahead = getenv("ODO_RUN_AHEAD") ? atoi(getenv("ODO_RUN_AHEAD")) : 3;
+  d->persist = d->persist_cfg = getenv("ODO_DEPTH_NO_PERSIST") ? 0 : 1;
+  d->persist_fault = getenv("ODO_DEPTH_PERSIST_FAULT") ? 1 : 0;
+  d->persist_wait = getenv("ODO_LM_FINE_WAIT_US") ? (unsigned)(100L * atol(getenv("ODO_LM_FINE_WAIT_US"))) : 0u;
+  HIP_OK(hipMalloc((void**)&d->d_xbuf, sizeof(unsigned long long) * kDpXbufWords));
+  HIP_OK(hipMemset(d->d_xbuf, 0, sizeof(unsigned long long) * kDpXbufWords));
+  HIP_OK(hipMalloc((void**)&d->d_gave_up, sizeof(int)));
+  HIP_OK(hipMemset(d->d_gave_up, 0, sizeof(int)));
   *out = d;
   return 0;
 }
@@ -2200,7 +2216,8 @@ extern "C" int odo_depth_destroy(odo_depth* d) {
   if (!d) return 0;
   (void)hipStreamSynchronize(d->ctx->stream);
   depth_free_images(d);
-  void* dv[] = {d->d_pts, d->d_cnt, d->d_d0, d->d_scratch, d->d_matched, d->d_lmstate, d->d_part_e, d->d_part_n, d->d_counts};
+  void* dv[] = {d->d_pts, d->d_cnt, d->d_d0, d->d_scratch, d->d_matched, d->d_lmstate, d->d_part_e, d->d_part_n, d->d_counts, d->d_xbuf,
+                d->d_gave_up};
   for (void* q : dv) if (q) (void)hipFree(q);
   (void)hipHostFree(d->h_stats); (void)hipHostFree(d->h_prog);
   delete d;
@@ -2246,6 +2263,7 @@ struct DepthJob {
   int k;          // next depth-LM launch index
   int n_launches;
   bool poll, tail_done;
+  bool persistent;   // the depth LM + write-back of this job went out as ONE persistent launch
   std::chrono::steady_clock::time_point wait_since;
   bool waiting;
 };
@@ -2256,7 +2274,7 @@ static int depth_job_begin(odo_depth* d, DepthJob* j, const float* left, const f
   const size_t n = (size_t)rows * cols;
   j->left = left; j->right = right; j->val = val; j->disp = disp; j->dep = dep;
   j->rows = rows; j->cols = cols; j->stage = stage;
-  j->k = 0; j->n_launches = 0; j->poll = d->poll != 0; j->tail_done = false; j->waiting = false;
+  j->k = 0; j->n_launches = 0; j->poll = d->poll != 0; j->tail_done = false; j->waiting = false; j->persistent = false;
   // progress words may only be reset while this stream is idle: every ComputeDepth ends with depth_finish()'s sync
   d->h_prog[0] = 0; d->h_prog[1] = 0;
   (void)n;
@@ -2288,14 +2306,48 @@ static int depth_job_stats(odo_depth* d, DepthJob* j) {
   const int run_lm = j->stage != 1 ? 1 : 0;
   d->token++;
   hipLaunchKernelGGL(depth_stats_kernel, dim3(1), dim3(kDlmBlock), 0, d->ctx->stream, run_lm, j->n_launches, d->d_counts,
-                     d->d_lmstate, d->d_stats_map, d->d_prog + 4, d->token);
+                     d->d_lmstate, d->d_stats_map, d->d_prog + 4, d->token, j->persistent ? d->d_gave_up : (int*)nullptr);
   HIP_OK(hipGetLastError());
   return 0;
 }
 
 // Returns 1 when the whole job has been enqueued, 0 when there is more to do (call again), -1 on error.
+// DepthOptimization + write-back in one persistent launch (depth_lm_persistent_kernel); depth_job_stats follows as for the step launches.
+static int depth_job_persistent(odo_depth* d, DepthJob* j) {
+  hipStream_t s = d->ctx->stream;
+  if ((++d->persist_epoch & 0xffu) == 0u)   // the pairs' tags carry the low byte of the epoch: cleared whenever it starts over
+    HIP_OK(hipMemsetAsync(d->d_xbuf, 0, sizeof(unsigned long long) * 2 * kDlmBlocks * 2, s));
+  DepthPersistArgs a;
+  memset(&a, 0, sizeof(a));
+  a.left = j->left; a.right = j->right; a.cols = j->cols; a.pts = d->d_pts; a.cnt = d->d_cnt; a.d0 = d->d_d0; a.matched = d->d_matched;
+  a.state_out = d->d_lmstate;   // [0]: depth_job_stats reads state[n_launches & 1] with n_launches = 0
+  a.tx = d->baseline; a.fx = d->K.f0; a.huber_delta = d->huber_delta; a.lambda0 = d->lambda; a.precision = d->precision;
+  a.max_iters = d->max_iters; a.photo_th = d->photo_th; a.min_depth = d->min_depth; a.max_depth = d->max_depth;
+  a.val = j->val; a.dep = j->dep; a.counts = d->d_counts; a.xbuf = d->d_xbuf; a.epoch = d->persist_epoch; a.wait_ticks = d->persist_wait;
+  a.gave_up = d->d_gave_up; a.fault = d->persist_fault;
+  static unsigned long long* dbg_buf = [] {
+    unsigned long long* p = nullptr;
+    if (getenv("ODO_DEPTH_STAMPS") && hipHostMalloc((void**)&p, 256, hipHostMallocMapped) == hipSuccess) memset(p, 0, 256);
+    return p;
+  }();
+  a.dbg = dbg_buf;
+  if (dbg_buf && dbg_buf[5] > 0 && dbg_buf[5] % 100 == 0)
+    fprintf(stderr, "[depth stamps] per iteration: gather %.0f decide + update %.0f evaluate %.0f sums + publish %.0f cycles; iterations/launch "
+            "%.2f, loop cycles/launch %.0f, same-XCD launches %.0f %%\n", (double)dbg_buf[0] / dbg_buf[4], (double)dbg_buf[1] / dbg_buf[4],
+            (double)dbg_buf[2] / dbg_buf[4], (double)dbg_buf[3] / dbg_buf[4], (double)dbg_buf[4] / dbg_buf[5], (double)dbg_buf[7] / dbg_buf[5],
+            100.0 * (double)dbg_buf[6] / dbg_buf[5]);
+  hipLaunchKernelGGL(depth_lm_persistent_kernel, dim3(8 * kDpK), dim3(kDlmBlock), 0, s, a);
+  HIP_OK(hipGetLastError());
+  j->persistent = true;
+  j->n_launches = 0;
+  j->tail_done = true;
+  return 0;
+}
+
 static int depth_job_pump(odo_depth* d, DepthJob* j) {
   if (j->tail_done) return 1;
+  if (j->stage != 1 && j->k == 0 && d->persist && !d->persist_off_once && d->max_iters <= kDpMaxIters)
+    return depth_job_persistent(d, j) ? -1 : 1;
   volatile int* prog = d->h_prog;
   // launch k decides on evaluation k-1 and runs evaluation k: max_iters evaluations need max_iters + 1 launches
   bool lm_over = (j->stage == 1) || (j->k > d->max_iters) || (j->poll && prog[1]);
@@ -2343,6 +2395,19 @@ static int depth_finish(odo_depth* d, bool full_sync = true) {
     std::atomic_thread_fence(std::memory_order_acquire);
   }
   d->last = *d->h_stats;
+  if (d->last.status == -2) {
+    // the persistent depth-LM launch gave up (its workgroups could not all be resident within the wait bound): the caller runs the
+    // job again — on the step launches, which need no co-residency (depth_run_checked / tracker_job_run)
+    d->persist_bails++;
+    if (fine_note_giveup(&d->persist_strikes, &d->persist_clean, &d->persist_offs)) d->persist = 0;
+    d->persist_off_once = 1;
+    return 2;
+  }
+  if (d->persist_cfg) {
+    const bool used = d->persist && !d->persist_off_once;
+    d->persist_off_once = 0;
+    if (fine_note_clean(used, &d->persist_strikes, &d->persist_clean, &d->persist_offs)) d->persist = 1;
+  }
   if (d->last.status != 0) return fail("number of valid after optimization is too small: %d", d->last.n_valid);
   return 0;
 }
@@ -2361,7 +2426,15 @@ static int depth_host(odo_depth* d, const float* left, const float* right, int r
   HIP_OK(hipMemcpyAsync(val, d->d_val, n, hipMemcpyDeviceToHost, s));
   HIP_OK(hipMemcpyAsync(disp, d->d_disp, sizeof(float) * n, hipMemcpyDeviceToHost, s));
   HIP_OK(hipMemcpyAsync(dep, d->d_dep, sizeof(float) * n, hipMemcpyDeviceToHost, s));
-  return depth_finish(d);
+  int rc = depth_finish(d);
+  if (rc == 2) {   // the persistent launch gave up: the same job again on the step launches, outputs copied again
+    if (depth_run(d, d->d_left, d->d_right, rows, cols, d->d_val, d->d_disp, d->d_dep, stage)) return -1;
+    HIP_OK(hipMemcpyAsync(val, d->d_val, n, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipMemcpyAsync(disp, d->d_disp, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipMemcpyAsync(dep, d->d_dep, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+    rc = depth_finish(d);
+  }
+  return rc == 0 ? 0 : -1;
 }
 
 extern "C" int odo_depth_compute(odo_depth* d, const float* left, const float* right, int rows, int cols, uint8_t* val,
@@ -2381,9 +2454,20 @@ extern "C" int odo_depth_compute_dev(odo_depth* d, const float* left_dev, const 
   if (depth_run(d, left_dev, right_dev, rows, cols, val_dev, disp_dev, dep_dev, 2)) return -1;
   // outputs stay on the device: only the statistics are needed back, and they arrive through host-mapped memory behind the
   // last launch of the job (no stream synchronisation)
-  return depth_finish(d, false);
+  int rc = depth_finish(d, false);
+  if (rc == 2) {   // the persistent launch gave up: the same job again on the step launches
+    if (depth_run(d, left_dev, right_dev, rows, cols, val_dev, disp_dev, dep_dev, 2)) return -1;
+    rc = depth_finish(d, false);
+  }
+  return rc == 0 ? 0 : -1;
 }
 
+extern "C" int odo_depth_persistent_stats(const odo_depth* d, int* on, int* fallbacks) {
+  if (!d) return fail("NULL depth estimator");
+  if (on) *on = (d->persist && d->max_iters <= kDpMaxIters) ? 1 : 0;
+  if (fallbacks) *fallbacks = d->persist_bails;
+  return 0;
+}
 extern "C" int odo_depth_report(const odo_depth* d, int* iters, float* cost, int* n_selected, int* n_matched, int* n_valid) {
   if (!d) return fail("NULL depth estimator");
   if (iters) *iters = d->last.iters;

@@ -236,6 +236,12 @@ static int tracker_job_run(odo_tracker* t, TrackerJob* j, bool full_sync) {
   int rc = tracker_job_begin(t, j);
   if (rc == 0) rc = tracker_job_drain(t, j);
   if (rc == 0) rc = depth_finish(t->depth, full_sync);
+  if (rc == 2) {   // the persistent depth-LM launch gave up: the whole job again (depth_finish has switched this run to the step launches)
+    rc = tracker_job_begin(t, j);
+    if (rc == 0) rc = tracker_job_drain(t, j);
+    if (rc == 0) rc = depth_finish(t->depth, full_sync);
+    if (rc == 2) rc = -1;
+  }
   j->stats = t->depth->last;
   j->rc = rc;
   if (rc) snprintf(j->msg, sizeof(j->msg), "%s", g_err);
@@ -490,6 +496,7 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
       int rc = tracker_job_drain(t, jk);
       t->cur_job = nullptr;
       if (rc == 0) rc = depth_finish(t->depth, false);
+      if (rc == 2) rc = tracker_job_run(t, jk, false);   // persistent depth-LM launch gave up: the job again, on the step launches
       jk->stats = t->depth->last;
       jk->rc = rc;
       if (rc) snprintf(jk->msg, sizeof(jk->msg), "%s", g_err);

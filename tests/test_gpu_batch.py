@@ -284,7 +284,8 @@ def test_early_start_of_the_next_solve_changes_nothing(api, drives, overlap, pai
 
 def test_solve_begin_then_solve_equals_solve(api, kitti_seq):
     """odo_lm_solve_begin + odo_lm_solve == odo_lm_solve: same pose, same trace; a begin that is abandoned (Reset, or a Solve on
-    other pyramids) leaves no trace in the following Solve; dense / t-distribution Solves do not start early (returns 1)."""
+    other pyramids) leaves no trace in the following Solve; t-distribution Solves start early too since the scale iteration runs
+    inside the fused launches (round 4); a Solve that is dense from the top (unfused pipeline) does not (returns 1)."""
     from odometry_amd import synth
     import time
     L, Z = kitti_seq["left"], kitti_seq["depth"]
@@ -316,10 +317,19 @@ def test_solve_begin_then_solve_equals_solve(api, kitti_seq):
     assert lm.Reset(init, 0.01) == 0
     T3 = lm.Solve(pyr[0], dep[0], pyr[1])
     assert np.array_equal(T3, T_ref) and _trace_key(lm.trace()) == tr_ref
-    # t-distribution weights run the unfused pipeline: nothing to start early
+    # t-distribution weights: the levels the coarse + persistent launches take start early as well, same result
+    rt = make(robust=2)
+    T_t = rt.Solve(pyr[0], dep[0], pyr[1])
+    tr_t = _trace_key(rt.trace())
     lt = make(robust=2)
-    assert lt.SolveBegin(pyr[0], dep[0], pyr[1]) == 1
-    for o in (ref, lm, lt):
+    assert lt.SolveBegin(pyr[0], dep[0], pyr[1]) == 0
+    T4 = lt.Solve(pyr[0], dep[0], pyr[1])
+    assert np.array_equal(T4, T_t) and _trace_key(lt.trace()) == tr_t
+    # the dense scan from the top runs the unfused pipeline: nothing to start early
+    ld = make()
+    ld.set_mode(1)
+    assert ld.SolveBegin(pyr[0], dep[0], pyr[1]) == 1
+    for o in (ref, lm, lt, rt, ld):
         o.close()
 
 

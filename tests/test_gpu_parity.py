@@ -287,6 +287,50 @@ def test_compute_depth_matches_oracle(api, O, kitti_seq):
         assert rep["n_valid"] == ref["n_valid"] == int(val.sum())
 
 
+def test_depth_lm_persistent_launch_and_its_fallback_give_the_same_depths(O, kitti_seq, monkeypatch):
+    """DepthOptimization (ref: src/depth_estimate.cpp:141-191) runs as ONE persistent launch whose 32 workgroups wait for each
+    other (depth_lm_persistent_kernel); a launch per iteration (depth_lm_step_kernel) is its fall-back. Same mask, disparities,
+    inverse depths, iteration count and cost bit for bit: with the persistent launch, with it switched off (ODO_DEPTH_NO_PERSIST),
+    and when a workgroup never publishes (ODO_DEPTH_PERSIST_FAULT: the launch gives up within its wait bound, the job is run again
+    on the step launches, and after three such calls the estimator stays on them). Different iteration budgets, incl. 0 and 1."""
+    from odometry_amd import api
+    L, R = kitti_seq["left"][1], kitti_seq["right"][1]
+    base = float(np.float32(386.1448) / np.float32(718.856))
+
+    def run(max_iters, n=1):
+        de = api.DepthEstimator(8.0, 900.0, 15.0, 0.1, 30.0, 0.01, 28.0, 0.995, max_iters, 4, None, None, base, 80000)
+        outs = []
+        for _ in range(n):
+            val, disp, dep = _bufs(L.shape)
+            st = de.ComputeDepth(L, R, val, disp, dep)
+            rep = de.report()
+            outs.append((st, val, disp, dep, rep["iters"], rep["cost"], rep["n_valid"]))
+        ps = de.persistent_stats()
+        de.close()
+        return outs, ps
+
+    def same(a, b):
+        return a[0] == b[0] and all(np.array_equal(x, y) for x, y in zip(a[1:4], b[1:4])) and a[4:] == b[4:]
+
+    for max_iters in (50, 7, 1, 0):
+        ref = O.compute_depth(L, R, O.depth_params(max_iters=max_iters), stage=2)
+        on, ps = run(max_iters)
+        assert ps == (1, 0)
+        assert on[0][0] == ref["status"] and on[0][4] == ref["iters"] and np.array_equal(on[0][1], ref["val"])
+        np.testing.assert_allclose(on[0][3], ref["dep"], rtol=0, atol=1e-7)
+        monkeypatch.setenv("ODO_DEPTH_NO_PERSIST", "1")
+        off, ps = run(max_iters)
+        monkeypatch.delenv("ODO_DEPTH_NO_PERSIST")
+        assert ps == (0, 0) and same(on[0], off[0]), f"max_iters {max_iters}"
+    monkeypatch.setenv("ODO_DEPTH_PERSIST_FAULT", "1")
+    bad, ps = run(50, n=4)
+    monkeypatch.delenv("ODO_DEPTH_PERSIST_FAULT")
+    assert ps == (0, 3)                        # three calls were run again, the fourth went to the step launches directly
+    on, _ = run(50)
+    for b in bad:
+        assert same(b, on[0])
+
+
 def test_compute_depth_size_guard(api):
     de = _depth_est(api)
     val, disp, dep = _bufs((480, 640))

@@ -2446,23 +2446,28 @@ __global__ void __launch_bounds__(kDlmBlock) depth_lm_step_kernel(
 // =============================================================================================
 // DepthOptimization in ONE launch (round 4): the whole iteration of ref: src/depth_estimate.cpp:141-168 plus the write-back and
 // filters of :176-191 inside a persistent kernel, instead of a launch per iteration (~27 dependent launches of 4.8 us per frame).
-// K = 32 workgroups of 256 threads on one XCD; workgroup g owns the 256-slot virtual blocks 5 g .. 5 g + 4 — exactly the blocks of
-// depth_lm_step_kernel — and thread t of it the slots (5 g + j) * 256 + t, whose whole state (current / previous / trial inverse
-// depth, diagonal of JtWJ, -JtWr, last residual, the left pixel) stays in registers for all iterations. Per iteration only the
-// global error crosses workgroups (:150, the one accept / reject decision all points share): every virtual block's {sum w r^2, N}
-// goes out as ONE tagged 16-byte granule pair and every wave gathers the 160 pairs itself with L1-bypassing loads (no flag, no
-// fence, no hand-over through LDS: profiles/r04_scalar_exchange.txt) and folds them in depth_lm_step_kernel's order, so both give
-// the same bits: the step launches stay as the fall-back (a launch that cannot get its workgroups resident gives up within the
-// wait bound, reports it through the statistics, and the host runs the job again on them) and as the batched tracker's path.
+// K = 80 workgroups of 512 threads on one XCD; workgroup g owns the two 256-slot virtual blocks 2 g, 2 g + 1 — exactly blocks
+// of depth_lm_step_kernel, wave w of it the 64 slots the step kernel's wave (w & 3) of block 2 g + (w >> 2) has — and every thread
+// ONE slot, whose whole state (current / previous / trial inverse depth, diagonal of JtWJ, -JtWr, last residual, the left pixel)
+// stays in registers for all iterations. Per iteration only the global error crosses workgroups (:150, the one accept / reject
+// decision all points share): every virtual block's {sum w r^2, N} goes out as ONE tagged 16-byte granule pair, wave 0 of every
+// workgroup gathers the 160 pairs with L1-bypassing loads (no flag, no fence) and folds them in depth_lm_step_kernel's order, so
+// both kernels give the same bits: the step launches stay as the fall-back (a launch that cannot get its workgroups resident
+// gives up within the wait bound, reports it through the statistics, and the host runs the job again on them) and as the batched
+// tracker's path. An iteration is two trips through the XCD's L2 (the pairs; the three right-image taps) and two workgroup barriers.
+// (First shape, measured: 32 workgroups x 256 threads x FIVE slots per thread, every wave gathering: 7.4 k cycles per iteration —
+// gather 2.8 k, decide + update 1.3 k, evaluation 1.9 k, five wave sums + publish 1.4 k — no faster than the launches it replaced.)
 // A granule = {32 bits of payload | 16 bits of extra payload | 16-bit tag}; tag = (launch epoch & 0xff) << 8 | iteration + 1 (the
 // host clears the buffer whenever the epoch's low byte starts over, so a stale granule cannot pass for a new one); the pairs are
-// double-buffered by iteration parity (a wave cannot be two iterations ahead of the slowest: it needs everybody's pair of k - 1).
+// double-buffered by iteration parity (wave 0 cannot be two iterations ahead of the slowest: it needs everybody's pair of k - 1).
 // =============================================================================================
-constexpr int kDpK = 32;                         // workgroups (they wait for each other: all must be resident at once)
-constexpr int kDpVb = kDlmBlocks / kDpK;         // virtual blocks per workgroup = slots per thread: 5
+constexpr int kDpThreads = 512;
+constexpr int kDpVb = kDpThreads / kDlmBlock;    // virtual blocks per workgroup: 2
+constexpr int kDpK = kDlmBlocks / kDpVb;         // workgroups: 80 (they wait for each other: all must be resident at once — three fit a CU.
+                                                 // 40 x 1 024 threads would need <= 64 VGPRs to fit two per CU: 13 spills)
 constexpr int kDpMaxIters = 250;                 // the 8-bit iteration field of the tags
 constexpr int kDpXbufWords = 2 * kDlmBlocks * 2 + kDpK;   // two parities of 160 pairs + one placement word per workgroup
-static_assert(kDlmBlocks % kDpK == 0, "every workgroup owns the same number of virtual blocks");
+static_assert(kDlmBlocks % kDpVb == 0 && kDpK <= kDpThreads, "every workgroup owns the same number of virtual blocks; one thread per workgroup");
 struct DepthPersistArgs {
   const float *left, *right;
   int cols;
@@ -2484,49 +2489,42 @@ struct DepthPersistArgs {
   int fault;                    // test hook (ODO_DEPTH_PERSIST_FAULT): virtual block 0's pair is never published
   unsigned long long* dbg;      // diagnostic (ODO_DEPTH_STAMPS): cycle sums of workgroup 0's phases, else null
 };
-__global__ void __launch_bounds__(kDlmBlock) depth_lm_persistent_kernel(DepthPersistArgs a) {
+__global__ void __launch_bounds__(kDpThreads) depth_lm_persistent_kernel(DepthPersistArgs a) {
   if ((blockIdx.x & 7u) != 4u) return;            // every eighth block: one XCD (not the one the pose LM's persistent launch sits on)
   const int g = (int)(blockIdx.x >> 3), t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  __shared__ double sh_e[kDpVb][kDlmBlock / 64];
-  __shared__ int sh_n[kDpVb][kDlmBlock / 64];
-  __shared__ int sh_c[kDpVb][kDlmBlock / 64][3];
-  __shared__ int local_sh, bail_sh;
+  __shared__ double sh_e[kDpThreads / 64];
+  __shared__ int sh_n[kDpThreads / 64];
+  __shared__ int sh_c[kDpThreads / 64][3];
+  __shared__ double fold_e;
+  __shared__ int fold_n, local_sh, bail_sh;
   const unsigned wait_limit = a.wait_ticks ? a.wait_ticks : kFineWaitTicks;
   unsigned long long* place = a.xbuf + 2 * kDlmBlocks * 2;
   const unsigned ep = (a.epoch & 0xffu) << 8;
   if (t == 0) {
-    local_sh = 0; bail_sh = 0;
+    local_sh = 1; bail_sh = 0;
     __hip_atomic_store(place + g, ((unsigned long long)(unsigned)fine_xcc_id() << 32) | (a.epoch + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  // ---- my slot: everything an iteration needs, in registers ----
+  const int s = g * kDpThreads + t;               // = (2 g + (wv >> 2)) * 256 + (t & 255): the step kernel's slot of the same wave
+  const bool ok = (s % kSelCap) < a.cnt[s / kSelCap];
+  const uint32_t pk = ok ? a.pts[s] : 0u;
+  const int px = (int)(pk & 0xffffu), py = (int)(pk >> 16);
+  const float lft = ok ? a.left[(size_t)py * a.cols + px] : 0.0f;
+  const float* Rr = a.right + (size_t)py * a.cols;
+  float cur = ok ? a.d0[s] : 0.0f, pre = 0.0f, tmp = cur, res = 0.0f, jt = 1.0f, bb = 0.0f;   // :121-137
   __syncthreads();
-  // ---- my slots: everything an iteration needs, in registers ----
-  bool ok[kDpVb];
-  uint32_t pk[kDpVb];
-  float lft[kDpVb], cur[kDpVb], pre[kDpVb], tmp[kDpVb], res[kDpVb], jt[kDpVb], bb[kDpVb];
-#pragma unroll
-  for (int j = 0; j < kDpVb; j++) {
-    const int s = (g * kDpVb + j) * kDlmBlock + t;
-    ok[j] = (s % kSelCap) < a.cnt[s / kSelCap];
-    pk[j] = ok[j] ? a.pts[s] : 0u;
-    lft[j] = ok[j] ? a.left[(size_t)(pk[j] >> 16) * a.cols + (pk[j] & 0xffffu)] : 0.0f;
-    const float v = ok[j] ? a.d0[s] : 0.0f;
-    cur[j] = v; pre[j] = 0.0f; tmp[j] = v; res[j] = 0.0f; jt[j] = 1.0f; bb[j] = 0.0f;   // :121-137
-  }
   // does every workgroup of this launch share my XCD? (then plain stores stay in its L2, where the gather loads find them)
-  if (t < 64) {
-    bool same = true, got = (t >= kDpK);
-    if (t < kDpK) {
-      unsigned long long pw = 0;
-      const FineDeadline dl = {(unsigned long long)wall_clock64(), wait_limit};
-      for (int spin = 0; !got; spin++) {
-        pw = __hip_atomic_load(place + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        got = ((unsigned)pw == a.epoch + 1u);
-        if (!got && dl.expired(spin)) break;
-      }
-      same = got && ((int)(pw >> 32) == fine_xcc_id());
+  if (t < kDpK) {   // thread i asks about workgroup i
+    unsigned long long pw = 0;
+    bool got = false;
+    const FineDeadline dl = {(unsigned long long)wall_clock64(), wait_limit};
+    for (int spin = 0; !got; spin++) {
+      pw = __hip_atomic_load(place + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      got = ((unsigned)pw == a.epoch + 1u);
+      if (!got && dl.expired(spin)) break;
     }
-    const bool all_got = __all(got), all_same = __all(same);
-    if (t == 0) { local_sh = (all_got && all_same) ? 1 : 0; if (!all_got) bail_sh = 1; }
+    if (!got) bail_sh = 1;
+    else if ((int)(pw >> 32) != fine_xcc_id()) local_sh = 0;
   }
   __syncthreads();
   const bool local = local_sh != 0;
@@ -2538,108 +2536,98 @@ __global__ void __launch_bounds__(kDlmBlock) depth_lm_persistent_kernel(DepthPer
   auto lap = [&](unsigned long long& sum) {
     if (a.dbg) { const unsigned long long now = __builtin_readcyclecounter(); sum += now - c_last; c_last = now; }
   };
-  for (int k = 0; placed && !st.done; k++) {   // (st: every wave derives the same state)
-    FineG2 q[(kDlmBlocks + 63) / 64];
+  for (int k = 0; placed && !st.done; k++) {   // (st: every thread derives the same state)
     c_it++;
     if (k > 0) {
-      // ---- gather the pairs of evaluation k - 1 (every wave for itself) ----
-      const unsigned tag = ep | (unsigned)k;         // evaluation k - 1 was published with iteration field k
-      const unsigned long long* buf = a.xbuf + (size_t)((k - 1) & 1) * kDlmBlocks * 2;
-      bool all = false;
-      FineDeadline dl = {0ull, wait_limit};
-      for (int spin = 0; !all; spin++) {
-        if (spin == 1) dl.t0 = (unsigned long long)wall_clock64();
-        if (spin > 0 && dl.expired(spin)) break;
-        bool mine = true;
+      if (t < 64) {
+        // ---- wave 0: gather the pairs of evaluation k - 1, fold them in depth_lm_step_kernel's order ----
+        const unsigned tag = ep | (unsigned)k;         // evaluation k - 1 was published with iteration field k
+        const unsigned long long* buf = a.xbuf + (size_t)((k - 1) & 1) * kDlmBlocks * 2;
+        FineG2 q[(kDlmBlocks + 63) / 64];
+        bool all = false;
+        FineDeadline dl = {0ull, wait_limit};
+        for (int spin = 0; !all; spin++) {
+          if (spin == 1) dl.t0 = (unsigned long long)wall_clock64();
+          if (spin > 0 && dl.expired(spin)) break;
+          bool mine = true;
+#pragma unroll
+          for (int u = 0; u < (kDlmBlocks + 63) / 64; u++) {
+            const int b = lane + 64 * u;
+            if (b < kDlmBlocks) q[u] = *(const volatile FineG2Global*)(buf + 2 * b);
+          }
+#pragma unroll
+          for (int u = 0; u < (kDlmBlocks + 63) / 64; u++) {
+            const int b = lane + 64 * u;
+            if (b < kDlmBlocks) mine = mine && ((q[u].x & 0xffffu) == tag) && ((q[u].z & 0xffffu) == tag);
+          }
+          all = __all(mine);
+        }
+        double fe = 0.0, fnd = 0.0;
 #pragma unroll
         for (int u = 0; u < (kDlmBlocks + 63) / 64; u++) {
           const int b = lane + 64 * u;
-          if (b < kDlmBlocks) q[u] = *(const volatile FineG2Global*)(buf + 2 * b);
+          if (b < kDlmBlocks) {
+            fe += __longlong_as_double((long long)(((unsigned long long)q[u].y << 32) | (unsigned long long)q[u].w));
+            fnd += (double)(q[u].x >> 16);
+          }
         }
-#pragma unroll
-        for (int u = 0; u < (kDlmBlocks + 63) / 64; u++) {
-          const int b = lane + 64 * u;
-          if (b < kDlmBlocks) mine = mine && ((q[u].x & 0xffffu) == tag) && ((q[u].z & 0xffffu) == tag);
-        }
-        all = __all(mine);
+        fe = wave_sum64(fe);
+        const int fn = (int)wave_sum64(fnd);
+        if (lane == 0) { fold_e = fe; fold_n = fn; if (!all) bail_sh = 1; }
       }
-      if (!all && lane == 0) bail_sh = 1;
-      __syncthreads();      // a wait that ran out in ANY wave ends the loop for the whole workgroup at the same point
+      __syncthreads();      // the error of evaluation k - 1 is in LDS — or a wait ran out, for the whole workgroup at the same point
       lap(c_gather);
       if (bail_sh) break;
-      // ---- decision for evaluation k - 1 (identical arithmetic in every wave: depth_lm_step_kernel's fold) ----
-      double fe = 0.0, fnd = 0.0;
-#pragma unroll
-      for (int u = 0; u < (kDlmBlocks + 63) / 64; u++) {
-        const int b = lane + 64 * u;
-        if (b < kDlmBlocks) {
-          fe += __longlong_as_double((long long)(((unsigned long long)q[u].y << 32) | (unsigned long long)q[u].w));
-          fnd += (double)(q[u].x >> 16);
-        }
-      }
-      fe = wave_sum64(fe);
-      const int fn = (int)wave_sum64(fnd);
-      const float err_now = (1.0f / (float)fn) * (float)fe;           // :239
+      // ---- decision for evaluation k - 1 (identical arithmetic in every thread) ----
+      const float err_now = (1.0f / (float)fold_n) * (float)fold_e;   // :239
       const int mode = depth_lm_decide(&st, err_now, a.precision);    // :150-161
-#pragma unroll
-      for (int j = 0; j < kDpVb; j++) {
-        if (mode != 2 && ok[j]) {
-          float c;
-          if (mode == 0) c = pre[j];                  // :153
-          else { c = tmp[j]; pre[j] = c; }            // :155-156
-          cur[j] = c;
-          if (mode != 3) {
-            const float jj = jt[j];
-            const float A = jj + st.lambda * jj;      // :164
-            const float dd = (1.0f / A) * bb[j];      // :165
-            tmp[j] = dd + c;                          // :166
-          }
+      if (mode != 2 && ok) {
+        float c;
+        if (mode == 0) c = pre;                       // :153
+        else { c = tmp; pre = c; }                    // :155-156
+        cur = c;
+        if (mode != 3) {
+          const float A = jt + st.lambda * jt;        // :164
+          const float dd = (1.0f / A) * bb;           // :165
+          tmp = dd + c;                               // :166
         }
       }
       depth_lm_advance(&st, mode, a.max_iters);       // :167, :141
-      if (a.dbg) asm volatile("" ::"v"(tmp[0]), "v"(tmp[kDpVb - 1]));
+      if (a.dbg) asm volatile("" ::"v"(tmp));
       lap(c_decide);
       if (st.done) break;
     }
     // ---- evaluation k at tmp (ComputeResidualJacobian :200-242) ----
-    double esum[kDpVb];
-    int nact[kDpVb];
-#pragma unroll
-    for (int j = 0; j < kDpVb; j++) {
-      esum[j] = 0.0; nact[j] = 0;
-      if (ok[j]) {
-        const int x = (int)(pk[j] & 0xffffu), y = (int)(pk[j] >> 16);
-        const float wf = floorf((float)x - a.tx * a.fx * tmp[j]);       // :217
-        if (!(wf >= 2.0f) || !(wf <= (float)(a.cols - 2))) {            // :219-223
-          jt[j] = 0.0f; bb[j] = 0.0f; res[j] = -1000.0f;
-        } else {
-          const int wx = (int)wf;
-          const float* Rr = a.right + (size_t)y * a.cols;
-          const float r_i = lft[j] - Rr[wx];                                                       // :226
-          const float w_i = (fabsf(r_i) <= a.huber_delta) ? 1.0f : a.huber_delta / fabsf(r_i);     // :228
-          const float r_diff = a.tx * a.fx * 0.5f * (Rr[wx + 1] - Rr[wx - 1]);                     // :229
-          res[j] = fabsf(r_i);
-          nact[j] = 1;
-          esum[j] = (double)(r_i * r_i * w_i);                                                     // :233
-          jt[j] = r_diff * r_diff * w_i;                                                           // :234
-          bb[j] = -r_diff * w_i * r_i;                                                             // :235
-        }
+    double esum = 0.0;
+    bool act = false;
+    if (ok) {
+      const float wf = floorf((float)px - a.tx * a.fx * tmp);           // :217
+      if (!(wf >= 2.0f) || !(wf <= (float)(a.cols - 2))) {              // :219-223
+        jt = 0.0f; bb = 0.0f; res = -1000.0f;
+      } else {
+        const int wx = (int)wf;
+        const float r_i = lft - Rr[wx];                                                          // :226
+        const float w_i = (fabsf(r_i) <= a.huber_delta) ? 1.0f : a.huber_delta / fabsf(r_i);     // :228
+        const float r_diff = a.tx * a.fx * 0.5f * (Rr[wx + 1] - Rr[wx - 1]);                     // :229
+        res = fabsf(r_i);
+        act = true;
+        esum = (double)(r_i * r_i * w_i);                                                        // :233
+        jt = r_diff * r_diff * w_i;                                                              // :234
+        bb = -r_diff * w_i * r_i;                                                                // :235
       }
     }
-    if (a.dbg) asm volatile("" ::"v"(esum[0]), "v"(esum[kDpVb - 1]));
+    if (a.dbg) asm volatile("" ::"v"(esum));
     lap(c_eval);
-#pragma unroll
-    for (int j = 0; j < kDpVb; j++) {
-      const double ws = wave_sum64(esum[j]);
-      const int wn = __popcll(__ballot(nact[j] != 0));
-      if (lane == 0) { sh_e[j][wv] = ws; sh_n[j][wv] = wn; }
+    {
+      const double ws = wave_sum64(esum);
+      const int wn = __popcll(__ballot(act));
+      if (lane == 0) { sh_e[wv] = ws; sh_n[wv] = wn; }
     }
     __syncthreads();
-    lap(c_sum);
     if (t < kDpVb) {
       const int vb = g * kDpVb + t;
-      const double e = (sh_e[t][0] + sh_e[t][1]) + (sh_e[t][2] + sh_e[t][3]);     // depth_lm_step_kernel's block sum
-      const int n = (sh_n[t][0] + sh_n[t][1]) + (sh_n[t][2] + sh_n[t][3]);
+      const double e = (sh_e[4 * t] + sh_e[4 * t + 1]) + (sh_e[4 * t + 2] + sh_e[4 * t + 3]);     // depth_lm_step_kernel's block sum
+      const int n = (sh_n[4 * t] + sh_n[4 * t + 1]) + (sh_n[4 * t + 2] + sh_n[4 * t + 3]);
       const unsigned tag = ep | (unsigned)(k + 1);
       const unsigned long long bits = (unsigned long long)__double_as_longlong(e);
       const unsigned long long g0 = ((bits >> 32) << 32) | ((unsigned long long)(unsigned)n << 16) | tag, g1 = (bits << 32) | tag;
@@ -2652,32 +2640,29 @@ __global__ void __launch_bounds__(kDlmBlock) depth_lm_persistent_kernel(DepthPer
         }
       }
     }
-    // (no second barrier: sh_e / sh_n are rewritten only after the next gather, which needs this workgroup's own pairs — published
-    //  by the threads that read them)
+    lap(c_sum);
+    // (sh_e / sh_n are rewritten only behind the next iteration's first barrier, which wave 0 — their reader — reaches after this)
   }
   __syncthreads();
   const bool bailed = bail_sh != 0;   // (workgroup-uniform behind the barrier)
   if (bailed && t == 0) __hip_atomic_store(a.gave_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // ---- write-back + filters (:176-191) and the per-block counts of depth_finalize_kernel ----
-#pragma unroll
-  for (int j = 0; j < kDpVb; j++) {
-    const int s = (g * kDpVb + j) * kDlmBlock + t;
-    bool good = false;
-    if (ok[j] && !bailed) {
-      const size_t o = (size_t)(pk[j] >> 16) * a.cols + (pk[j] & 0xffffu);
-      const float c = cur[j], rs = res[j];
-      good = !(rs > a.photo_th || rs == -1000.0f);
-      if (good && (1.0f / c > a.max_depth || 1.0f / c < a.min_depth)) good = false;
-      a.val[o] = good ? 1 : 0;
-      a.dep[o] = good ? c : 0.0f;
-    }
-    const int c0 = __popcll(__ballot(good)), c1 = __popcll(__ballot(ok[j])), c2 = __popcll(__ballot(ok[j] && a.matched[s] != 0));
-    if (lane == 0) { sh_c[j][wv][0] = c0; sh_c[j][wv][1] = c1; sh_c[j][wv][2] = c2; }
+  bool good = false;
+  if (ok && !bailed) {
+    const size_t o = (size_t)py * a.cols + px;
+    good = !(res > a.photo_th || res == -1000.0f);
+    if (good && (1.0f / cur > a.max_depth || 1.0f / cur < a.min_depth)) good = false;
+    a.val[o] = good ? 1 : 0;
+    a.dep[o] = good ? cur : 0.0f;
+  }
+  {
+    const int c0 = __popcll(__ballot(good)), c1 = __popcll(__ballot(ok)), c2 = __popcll(__ballot(ok && a.matched[s] != 0));
+    if (lane == 0) { sh_c[wv][0] = c0; sh_c[wv][1] = c1; sh_c[wv][2] = c2; }
   }
   __syncthreads();
   if (t < kDpVb * 3) {
     const int j = t / 3, qn = t % 3;
-    a.counts[(g * kDpVb + j) * 3 + qn] = (sh_c[j][0][qn] + sh_c[j][1][qn]) + (sh_c[j][2][qn] + sh_c[j][3][qn]);
+    a.counts[(g * kDpVb + j) * 3 + qn] = (sh_c[4 * j][qn] + sh_c[4 * j + 1][qn]) + (sh_c[4 * j + 2][qn] + sh_c[4 * j + 3][qn]);
   }
   if (g == 0 && t == 0) *a.state_out = st;
   if (a.dbg && g == 0 && t == 0) {

@@ -2336,7 +2336,7 @@ static int depth_job_persistent(odo_depth* d, DepthJob* j) {
             "%.2f, loop cycles/launch %.0f, same-XCD launches %.0f %%\n", (double)dbg_buf[0] / dbg_buf[4], (double)dbg_buf[1] / dbg_buf[4],
             (double)dbg_buf[2] / dbg_buf[4], (double)dbg_buf[3] / dbg_buf[4], (double)dbg_buf[4] / dbg_buf[5], (double)dbg_buf[7] / dbg_buf[5],
             100.0 * (double)dbg_buf[6] / dbg_buf[5]);
-  hipLaunchKernelGGL(depth_lm_persistent_kernel, dim3(8 * kDpK), dim3(kDlmBlock), 0, s, a);
+  hipLaunchKernelGGL(depth_lm_persistent_kernel, dim3(8 * kDpK), dim3(kDpThreads), 0, s, a);
   HIP_OK(hipGetLastError());
   j->persistent = true;
   j->n_launches = 0;

@@ -80,6 +80,14 @@ int odo_dev_upload_async(odo_ctx* ctx, void* dst_dev, const void* src_host, size
  * may be rewritten or released. Waiting for a retired ticket costs nothing. */
 unsigned long odo_ctx_upload_ticket(odo_ctx* ctx);
 int odo_ctx_upload_wait(odo_ctx* ctx, unsigned long ticket);
+/* Orders `waiter`'s stream behind everything queued on `signaller`'s stream so far (an event, no host wait): two contexts of one
+ * host thread — the drop-in classes keep a second one for work that need not wait for the pose LM (an upload started early). */
+int odo_ctx_stream_wait(odo_ctx* waiter, odo_ctx* signaller);
+/* The same in two halves: odo_ctx_mark names the point `ctx`'s stream has been filled up to (returns a non-zero mark), and
+ * odo_ctx_stream_wait_mark orders `waiter` behind that point — not behind what was queued on `signaller` since (a mark older
+ * than the last eight falls back to "everything queued so far"). */
+unsigned long odo_ctx_mark(odo_ctx* ctx);
+int odo_ctx_stream_wait_mark(odo_ctx* waiter, odo_ctx* signaller, unsigned long mark);
 int odo_dev_alloc_async(odo_ctx* ctx, size_t bytes, void** out_dev, int* is_async);
 int odo_dev_free_async(odo_ctx* ctx, void* dev, size_t bytes, int is_async);
 
@@ -232,6 +240,20 @@ int odo_depth_compute(odo_depth* d, const float* left, const float* right, int r
 /* Same with device-resident inputs and outputs (no PCIe in the timed region). */
 int odo_depth_compute_dev(odo_depth* d, const float* left_dev, const float* right_dev, int rows, int cols,
                           uint8_t* val_dev, float* disp_dev, float* dep_dev);
+/* The front half of ComputeDepth that needs the LEFT image only — its 3x3 blur and the block-median point selection (ref:
+ * src/depth_estimate.cpp:255-256,300-342) — enqueued ahead of the call, on `side`'s stream, so that it runs beside whatever the
+ * estimator's own stream is busy with (the drop-in classes issue it from ImagePyramid's constructor, ref:
+ * run_odometry_kitti_offline.cpp:205: the pose LM's Solve of :215 then hides it). `stamp` (non-zero) names the image's content:
+ * odo_depth_compute_dev_stamped(.., the same left_dev, the same stamp) picks the prepared half up (same launches, earlier: results
+ * identical); any other call drops it. Work queued on the estimator's stream before this call is ordered in front of it. */
+int odo_depth_prepare_left_dev(odo_depth* d, odo_ctx* side, const float* left_dev, int rows, int cols, unsigned long long stamp);
+/* ... ordered behind `mark` of the estimator's stream (odo_ctx_mark, taken once left_dev was complete) instead of behind everything
+ * queued there by now — for a caller that has meanwhile queued work the prepared half is meant to run BESIDE (the pose LM's Solve).
+ * The estimator's previous ComputeDepth must have returned before the mark was taken. */
+int odo_depth_prepare_left_dev_marked(odo_depth* d, odo_ctx* side, const float* left_dev, int rows, int cols, unsigned long long stamp,
+                                      unsigned long mark);
+int odo_depth_compute_dev_stamped(odo_depth* d, const float* left_dev, const float* right_dev, int rows, int cols,
+                                  uint8_t* val_dev, float* disp_dev, float* dep_dev, unsigned long long left_stamp);
 /* Disparity stage only (DisparityDepthEstimate, ref: src/depth_estimate.cpp:244-401). */
 int odo_depth_disparity(odo_depth* d, const float* left, const float* right, int rows, int cols, uint8_t* val,
                         float* disp, float* dep);

@@ -107,7 +107,9 @@ inline double scalar0(const Scalar& s) { return s.val[0]; }
 // the call, as the reference's own code does (it calls ptr<T>() / at<T>() per row / per pixel).
 namespace detail {
 inline odo_ctx* context();
-struct MatBuf {
+inline odo_ctx* side_context();
+inline unsigned long long next_stamp() { static thread_local unsigned long long s = 0; return ++s; }
+struct MatBuf : std::enable_shared_from_this<MatBuf> {
   uint8_t* host = nullptr;
   size_t bytes = 0;
   bool pinned = false;
@@ -115,21 +117,44 @@ struct MatBuf {
   int dev_async = 0;
   bool host_valid = true, dev_valid = false;
   unsigned long upload_ticket = 0;  // != 0: an asynchronous DMA issued with this ticket may still be reading `host`
+  bool upload_on_side = false;      // ... on the side context's stream (a stereo partner uploaded ahead of its first use)
+  void free_mirror() {              // stream-ordered release to the main context's free list: behind what either stream has queued on the block
+    if (!dev) return;
+    if (side_pending) odo_ctx_stream_wait(context(), side_context());
+    odo_dev_free_async(context(), dev, bytes, dev_async);
+    dev = nullptr; dev_valid = false; side_pending = false;
+  }
+  bool side_pending = false;        // the main stream has not been ordered behind that upload yet
+  unsigned long long stamp;         // names the CONTENT: renewed whenever host code may have written or a kernel has (keys the
+                                    // pyramid cache and the prepared front half of ComputeDepth)
+  MatBuf *prev = nullptr, *next = nullptr;   // live buffers of this thread in creation order (stereo-partner guess)
+  bool fill_pending = false;                 // Mat(rows, cols, type, value): the fill is done on the first host access
+  double fill_value = 0.0;
+  int fill_type = 0;
+  void materialize_fill() {
+    if (!fill_pending) return;
+    fill_pending = false;
+    if (fill_type == 5 /* CV_32F */) for (size_t i = 0; i < bytes / 4; i++) reinterpret_cast<float*>(host)[i] = (float)fill_value;
+    else if (fill_type == 6 /* CV_64F */) for (size_t i = 0; i < bytes / 8; i++) reinterpret_cast<double*>(host)[i] = fill_value;
+    else std::memset(host, (int)fill_value, bytes);
+  }
   explicit MatBuf(size_t n);
   ~MatBuf();
   MatBuf(const MatBuf&) = delete;
   MatBuf& operator=(const MatBuf&) = delete;
   void wait_upload() {  // the DMA out of `host` (if any) has finished: the block may be rewritten / recycled
-    if (upload_ticket) { odo_ctx_upload_wait(context(), upload_ticket); upload_ticket = 0; }
+    if (upload_ticket) { odo_ctx_upload_wait(upload_on_side ? side_context() : context(), upload_ticket); upload_ticket = 0; }
   }
-  void sync_host() {  // host copy current (lazy download)
-    if (!host_valid && dev) { odo_dev_download(context(), host, dev, bytes); upload_ticket = 0; }
+  void sync_host() {  // host copy current (lazy download; a pending fill is void once a kernel has overwritten the image)
+    if (!host_valid && dev) { odo_dev_download(context(), host, dev, bytes); upload_ticket = 0; fill_pending = false; }
+    else materialize_fill();
     host_valid = true;
   }
   // Host code may write: the pending upload out of the block is waited for first (cv::Mat semantics let the caller refill a
   // Mat the moment a constructor it was passed to has returned), the host copy is brought up to date, the mirror is void.
-  void touch() { wait_upload(); sync_host(); dev_valid = false; }
+  void touch() { wait_upload(); sync_host(); dev_valid = false; side_pending = false; stamp = next_stamp(); }
 };
+inline MatBuf*& matbuf_tail() { static thread_local MatBuf* t = nullptr; return t; }
 // Page-locked blocks are expensive to create (hipHostMalloc): per-frame Mats recycle them through a small free list.
 struct PinnedPool {
   std::vector<std::pair<size_t, void*>> free_;
@@ -158,20 +183,47 @@ struct MirrorLru {
     for (size_t i = 0; i < order.size() && caches > keep; i++) {
       auto q = order[i].lock();
       if (q && q->dev && q->host_valid && q.get() != b.get()) {
-        odo_dev_free_async(context(), q->dev, q->bytes, q->dev_async);
-        q->dev = nullptr; q->dev_valid = false;
+        q->free_mirror();
         caches--;
       }
     }
   }
 };
 inline MirrorLru& mirror_lru() { static thread_local MirrorLru lru; return lru; }
-inline MatBuf::MatBuf(size_t n) : bytes(n) {
+// The upload of a buffer started EARLY, on the side context's stream, for an image the next call is expected to ask for (the right
+// image of the pair whose left image just went to ImagePyramid): it then crosses PCIe while the pose LM runs instead of in front
+// of ComputeDepth. Only page-locked, current, not yet mirrored buffers; a wrong guess costs one idle-time copy. Mat::device_in
+// orders the main stream behind the copy when the image is used; a host write in between waits for it and voids it (touch()).
+inline bool prefetch_eligible(const MatBuf& b) { return b.pinned && b.host_valid && !b.dev_valid && !b.upload_ticket && !b.fill_pending; }
+// First half, BEFORE the main stream's fill level is marked: the mirror block (a recycled block's earlier use is queued on the main
+// stream in front of that mark, and the side stream goes behind the mark).
+inline void prefetch_reserve(const std::shared_ptr<MatBuf>& sp) {
+  MatBuf& b = *sp;
+  if (!prefetch_eligible(b)) return;
+  if (!b.dev && odo_dev_alloc_async(context(), b.bytes, &b.dev, &b.dev_async) != 0) { b.dev = nullptr; return; }
+  mirror_lru().use(sp);
+}
+// Second half: the copy, on the side stream (already ordered behind the mark).
+inline void prefetch_to_device(const std::shared_ptr<MatBuf>& sp) {
+  MatBuf& b = *sp;
+  if (!prefetch_eligible(b) || !b.dev) return;
+  if (odo_dev_upload_async(side_context(), b.dev, b.host, b.bytes) != 0) return;
+  b.upload_ticket = odo_ctx_upload_ticket(side_context());
+  b.upload_on_side = true;
+  b.side_pending = true;
+  b.dev_valid = true;
+}
+inline MatBuf::MatBuf(size_t n) : bytes(n), stamp(next_stamp()) {
   if (n >= (64u << 10)) { host = static_cast<uint8_t*>(pinned_pool().get(n)); pinned = host != nullptr; }
   if (!host) host = static_cast<uint8_t*>(std::malloc(n ? n : 1));
+  prev = matbuf_tail();
+  if (prev) prev->next = this;
+  matbuf_tail() = this;
 }
 inline MatBuf::~MatBuf() {
-  if (dev) odo_dev_free_async(context(), dev, bytes, dev_async);
+  if (prev) prev->next = next;
+  if (next) next->prev = prev; else matbuf_tail() = prev;
+  free_mirror();
   if (pinned) {
     wait_upload();  // a DMA may still be reading the block (a retired ticket costs nothing)
     pinned_pool().put(bytes, host);
@@ -188,9 +240,9 @@ class Mat {
   Mat(int r, int c, int type) { create(r, c, type); }
   Mat(int r, int c, int type, double fill) {
     create(r, c, type);
-    if (type_ == CV_32F) for (size_t i = 0; i < (size_t)r * c; i++) reinterpret_cast<float*>(buf_->host)[i] = (float)fill;
-    else if (type_ == CV_64F) for (size_t i = 0; i < (size_t)r * c; i++) reinterpret_cast<double*>(buf_->host)[i] = fill;
-    else std::memset(buf_->host, (int)fill, buf_->bytes);
+    // filled when (if) somebody looks: the runner's per-frame output Mats (ref: run_odometry_kitti_offline.cpp:226) go straight to
+    // ComputeDepth, which overwrites them on the device — 466 KB of memset per frame that nobody reads
+    buf_->fill_pending = true; buf_->fill_value = fill; buf_->fill_type = type_;
   }
   void create(int r, int c, int type) {
     rows = r; cols = c; type_ = type;
@@ -220,20 +272,31 @@ class Mat {
     if (!b.dev && odo_dev_alloc_async(detail::context(), b.bytes, &b.dev, &b.dev_async) != 0) return nullptr;
     detail::mirror_lru().use(buf_);
     if (!b.dev_valid) {
+      b.materialize_fill();
       if (odo_dev_upload_async(detail::context(), b.dev, b.host, b.bytes) != 0) return nullptr;
       b.upload_ticket = b.pinned ? odo_ctx_upload_ticket(detail::context()) : 0;
+      b.upload_on_side = false;
       b.dev_valid = true;
+    } else if (b.side_pending) {   // uploaded ahead on the side stream: the main stream's work goes behind that copy
+      if (odo_ctx_stream_wait(detail::context(), detail::side_context()) != 0) return nullptr;
+      b.side_pending = false;
     }
     return b.dev;
   }
+  unsigned long long content_stamp() const { return buf_ ? buf_->stamp : 0; }
   // Device buffer a kernel is about to overwrite completely: afterwards the device holds the truth, the host copy is stale.
   void* device_out() {
     detail::MatBuf& b = *buf_;
+    b.wait_upload();
+    if (b.side_pending) { odo_ctx_stream_wait(detail::context(), detail::side_context()); b.side_pending = false; }
     if (!b.dev && odo_dev_alloc_async(detail::context(), b.bytes, &b.dev, &b.dev_async) != 0) return nullptr;
     b.dev_valid = true;
     b.host_valid = false;
+    b.fill_pending = false;
+    b.stamp = detail::next_stamp();
     return b.dev;
   }
+  const std::shared_ptr<detail::MatBuf>& buffer() const { return buf_; }
  private:
   int type_ = CV_32F;
   std::shared_ptr<detail::MatBuf> buf_;
@@ -241,7 +304,7 @@ class Mat {
 #endif
 
 // ------------------------------------------------------------------------------------------------
-namespace detail { inline odo_ctx* context(); }
+namespace detail { inline odo_ctx* context(); inline odo_ctx* side_context(); }
 
 // ref: include/camera.h:16-119. Raw calibration, the rectified intrinsic pyramid and the undistort + rectify remap, on
 // the device. The runner passes nullptr for its cameras (ref: run_odometry_kitti_offline.cpp:51-52) and the
@@ -370,6 +433,19 @@ inline odo_ctx* context() {
   }
   return ctx;
 }
+// A second context (stream) of the same thread for work that need not queue behind the pose LM: the upload of the stereo
+// partner and the left half of ComputeDepth's front end, both started from ImagePyramid's constructor.
+inline odo_ctx* side_context() {
+  static thread_local odo_ctx* ctx = nullptr;
+  if (!ctx) {
+    const char* dev = std::getenv("ODOMETRY_HIP_DEVICE");
+    if (odo_ctx_create(dev ? std::atoi(dev) : 0, &ctx) != 0) {
+      std::cout << "odometry_hip: " << odo_last_error() << std::endl;
+      std::exit(1);
+    }
+  }
+  return ctx;
+}
 // Device view of an input / output image for both Mat flavours. With the stand-in Mat the view borrows the Mat's mirror
 // (no copy when it is current); with cv::Mat there is nothing to hang a mirror on and nothing that reports writes, so every
 // input is staged and uploaded into a stream-ordered scratch block and every output is downloaded before the call returns.
@@ -419,7 +495,56 @@ inline const Mat& pyr_level(const std::shared_ptr<PyrHandle>& h, int level) {
   }
   return h->host[level];
 }
+#ifndef ODOMETRY_SHIM_WITH_OPENCV
+// What the drop-in classes do AHEAD of the call that needs it (same launches and copies, earlier; ODOMETRY_SHIM_NO_LOOKAHEAD=1 in
+// the environment switches all of it off). The runner's frame is strictly serial — ImagePyramid(left) :205, Solve :215,
+// ComputeDepth(left, right) :229, ImagePyramid(left) again :251 — so whatever does not depend on the Solve's result is started
+// from ImagePyramid's constructor and runs beside the Solve:
+//   * the right image's upload (the partner guess: the Mat ComputeDepth was given with this left Mat last time — the runner
+//     refills the same two Mats every frame, ref: :200,334-359 — else the same-sized Mat created right after it);
+//   * the left image's blur + point selection of ComputeDepth (odo_depth_prepare_left_dev) for the estimator of this thread;
+//   * and the :251 pyramid is the :205 pyramid (same content stamp, levels and smoothing: the device pyramid is shared).
+struct Lookahead {
+  bool on = std::getenv("ODOMETRY_SHIM_NO_LOOKAHEAD") == nullptr;
+  std::weak_ptr<MatBuf> last_left, last_right;   // the pair of the last ComputeDepth
+  odo_depth* estimator = nullptr;                // the DepthEstimator of this thread (the last one constructed)
+  int est_rows = 0, est_cols = 0;                // the frame size it was last used with
+  struct Entry { unsigned long long stamp; int levels, smooth, kind; std::weak_ptr<struct PyrHandle> h; };
+  Entry cache[4];
+  int cache_next = 0;
+  std::weak_ptr<MatBuf> pending_left;            // the left image ImagePyramid was just built from: its lookahead is still to be issued
+  std::weak_ptr<MatBuf> pending_partner;         // ... and the guessed right image (mirror block reserved)
+  int pending_rows = 0, pending_cols = 0;
+  unsigned long pending_mark = 0;                // the main stream's fill level then (odo_ctx_mark): the side stream goes behind THAT
+};
+inline Lookahead& lookahead() { static thread_local Lookahead l; return l; }
+// Issues the recorded lookahead. Called by Solve right AFTER its own launches have gone out (the Solve is the critical path: ~15 us
+// of host work must not sit in front of it), else by the next ComputeDepth.
+inline void run_lookahead() {
+  Lookahead& la = lookahead();
+  std::shared_ptr<MatBuf> lb = la.pending_left.lock(), guess = la.pending_partner.lock();
+  la.pending_left.reset(); la.pending_partner.reset();
+  if (!la.on || !lb || !la.pending_mark) return;
+  if (odo_ctx_stream_wait_mark(side_context(), context(), la.pending_mark) != 0) return;
+  // the stereo partner's upload, on the side stream
+  if (guess && guess.get() != lb.get()) prefetch_to_device(guess);
+  // ComputeDepth's left half, on the side stream (frames of the size the estimator has seen), behind the left image's upload —
+  // the mark — not behind the Solve queued since
+  if (la.estimator && la.pending_rows == la.est_rows && la.pending_cols == la.est_cols && lb->dev && lb->dev_valid &&
+      !lb->side_pending)
+    (void)odo_depth_prepare_left_dev_marked(la.estimator, side_context(), static_cast<const float*>(lb->dev), la.pending_rows,
+                                            la.pending_cols, lb->stamp, la.pending_mark);
+}
+#endif
 inline std::shared_ptr<PyrHandle> make_pyr(int num_levels, const Mat& in, bool smooth, int kind, const char* what) {
+#ifndef ODOMETRY_SHIM_WITH_OPENCV
+  Lookahead& la = lookahead();
+  const unsigned long long stamp = in.content_stamp();
+  if (la.on && stamp)
+    for (auto& e : la.cache)
+      if (e.stamp == stamp && e.levels == num_levels && e.smooth == (smooth ? 1 : 0) && e.kind == kind)
+        if (auto hit = e.h.lock()) return hit;   // :251 after :205: the same image, the same arithmetic — the same device pyramid
+#endif
   auto h = std::make_shared<PyrHandle>();
   h->host.resize(num_levels > 0 ? num_levels : 0);
   h->have.assign(num_levels > 0 ? num_levels : 0, 0);
@@ -434,6 +559,23 @@ inline std::shared_ptr<PyrHandle> make_pyr(int num_levels, const Mat& in, bool s
     std::cout << what << std::endl;  // ref: src/image_pyramid.cpp:16-18,34-36 (prints, object stays unusable)
     h->p = nullptr;
   }
+#ifndef ODOMETRY_SHIM_WITH_OPENCV
+  if (ok && la.on) {
+    Lookahead::Entry& e = la.cache[la.cache_next++ % 4];
+    e.stamp = in.content_stamp(); e.levels = num_levels; e.smooth = smooth ? 1 : 0; e.kind = kind; e.h = h;
+    if (kind == ODO_PYR_IMAGE && in.buffer()) {
+      const std::shared_ptr<MatBuf>& lb = in.buffer();
+      la.pending_left = lb; la.pending_rows = in.rows; la.pending_cols = in.cols;
+      // the partner guess: the Mat ComputeDepth was given with this one last time, else the same-sized Mat created right after it
+      std::shared_ptr<MatBuf> guess;
+      if (la.last_left.lock().get() == lb.get()) guess = la.last_right.lock();
+      else if (lb->next && lb->next->bytes == lb->bytes) guess = lb->next->shared_from_this();
+      if (guess && guess.get() != lb.get()) prefetch_reserve(guess);
+      la.pending_partner = guess;
+      la.pending_mark = odo_ctx_mark(context());
+    }
+  }
+#endif
   return h;
 }
 }  // namespace detail
@@ -504,6 +646,12 @@ class LevenbergMarquardtOptimizer {  // ref: include/lm_optimizer.h:24-115
 
   Affine4f Solve(const ImagePyramid& kImagePyr1, const DepthPyramid& kDepthPyr1, const ImagePyramid& kImagePyr2) {
     Affine4f out;
+#ifndef ODOMETRY_SHIM_WITH_OPENCV
+    // the Solve's launches first (odo_lm_solve_begin returns once they are queued), then what can run beside them
+    if (kImagePyr1.handle() && kDepthPyr1.handle() && kImagePyr2.handle())
+      (void)odo_lm_solve_begin(lm_, kImagePyr1.handle(), kDepthPyr1.handle(), kImagePyr2.handle());
+    detail::run_lookahead();
+#endif
     if (odo_lm_solve(lm_, kImagePyr1.handle(), kDepthPyr1.handle(), kImagePyr2.handle(), affine_data(out)) != 0)
       std::cout << "Optimize failed! " << std::endl;  // ref: src/lm_optimizer.cpp:60-65 (out = pseudo-identity)
     return out;
@@ -557,8 +705,16 @@ class DepthEstimator {  // ref: include/depth_estimate.h:24-121
     if (odo_depth_create(detail::context(), grad_th, ssd_th, photo_th, min_depth, max_depth, lambda, huber_delta, precision,
                          max_iters, boundary, Kp, baseline, max_residuals, 0, 0, &d_) != 0)
       std::cout << "odometry_hip: " << odo_last_error() << std::endl;
+#ifndef ODOMETRY_SHIM_WITH_OPENCV
+    else detail::lookahead().estimator = d_;
+#endif
   }
-  ~DepthEstimator() { odo_depth_destroy(d_); }
+  ~DepthEstimator() {
+#ifndef ODOMETRY_SHIM_WITH_OPENCV
+    if (detail::lookahead().estimator == d_) detail::lookahead().estimator = nullptr;
+#endif
+    odo_depth_destroy(d_);
+  }
   DepthEstimator(const DepthEstimator&) = delete;
   DepthEstimator& operator=(const DepthEstimator&) = delete;
 
@@ -579,12 +735,26 @@ class DepthEstimator {  // ref: include/depth_estimate.h:24-121
     std::cout << "computing disparity ..." << std::endl;
     int st = -1;
     {
+#ifndef ODOMETRY_SHIM_WITH_OPENCV
+      detail::lookahead().pending_left.reset();   // (a lookahead nobody issued: too late for it now)
+#endif
       detail::DevIn l(left_img), r(right_img);
       detail::DevOut v(left_val), ds(left_disp), dp(left_dep);
-      if (l.get() && r.get() && v.get() && ds.get() && dp.get())
+      if (l.get() && r.get() && v.get() && ds.get() && dp.get()) {
+#ifdef ODOMETRY_SHIM_WITH_OPENCV
         st = odo_depth_compute_dev(d_, static_cast<const float*>(l.get()), static_cast<const float*>(r.get()), left_img.rows,
                                    left_img.cols, static_cast<uint8_t*>(v.get()), static_cast<float*>(ds.get()),
                                    static_cast<float*>(dp.get()));
+#else
+        // (the left image's content stamp lets the estimator pick up the half prepared from ImagePyramid's constructor)
+        st = odo_depth_compute_dev_stamped(d_, static_cast<const float*>(l.get()), static_cast<const float*>(r.get()), left_img.rows,
+                                           left_img.cols, static_cast<uint8_t*>(v.get()), static_cast<float*>(ds.get()),
+                                           static_cast<float*>(dp.get()), left_img.content_stamp());
+        detail::Lookahead& la = detail::lookahead();
+        la.last_left = left_img.buffer(); la.last_right = right_img.buffer();
+        la.est_rows = left_img.rows; la.est_cols = left_img.cols;
+#endif
+      }
     }
     int iters = 0, nsel = 0, nmatch = 0, nvalid = 0;
     float cost = 0;

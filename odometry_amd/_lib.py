@@ -97,6 +97,9 @@ SIGNATURES = {
                                                           C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "odo_depth_compute": (C.c_int, [_vp, _fp, _fp, C.c_int, C.c_int, _u8p, _fp, _fp]),
     "odo_depth_compute_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "odo_depth_prepare_left_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_ulonglong]),
+    "odo_depth_prepare_left_dev_marked": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_ulonglong, C.c_ulong]),
+    "odo_depth_compute_dev_stamped": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_ulonglong]),
     "odo_depth_disparity": (C.c_int, [_vp, _fp, _fp, C.c_int, C.c_int, _u8p, _fp, _fp]),
     "odo_depth_time_stages": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _fp, _dp, _ip]),
     "odo_depth_report": (C.c_int, [_vp, _ip, _fp, _ip, _ip, _ip]),
@@ -118,6 +121,9 @@ SIGNATURES = {
     "odo_tracker_destroy": (C.c_int, [_vp]),
     "odo_ctx_upload_ticket": (C.c_ulong, [_vp]),
     "odo_ctx_upload_wait": (C.c_int, [_vp, C.c_ulong]),
+    "odo_ctx_stream_wait": (C.c_int, [_vp, _vp]),
+    "odo_ctx_mark": (C.c_ulong, [_vp]),
+    "odo_ctx_stream_wait_mark": (C.c_int, [_vp, _vp, C.c_ulong]),
     "odo_tracker_quiesce": (C.c_int, [_vp]),
     "odo_gather_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "odo_gather_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),

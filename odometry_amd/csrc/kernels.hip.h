@@ -2134,7 +2134,7 @@ __device__ __forceinline__ void depth_select_kernel_body(const float* __restrict
     const int rank = off + pre;
     if (f && rank < kSelCap) {
       const int y = sy + e / bw, x = sx + e % bw;
-      val[(size_t)y * cols + x] = 1;  // :336
+      if (val) val[(size_t)y * cols + x] = 1;  // :336 (NULL: a selection prepared ahead of ComputeDepth, odo_depth_prepare_left_dev)
       pts[b * kSelCap + rank] = (uint32_t)x | ((uint32_t)y << 16);
     }
     __syncthreads();

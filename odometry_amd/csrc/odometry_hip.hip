@@ -52,11 +52,14 @@ struct odo_ctx {
   int stage_busy[kStageSlots];
   int stage_next;
   std::vector<struct PoolBlock>* pool;  // recycled device blocks (see dev_alloc_any)
+  std::vector<hipEvent_t>* pool_events; // release events not in use (creating / destroying one per block and frame costs ~3 us of host time each)
   std::mutex* mu;                       // guards pool + staging ring + upload tickets (a context may be shared by host threads)
   // upload tickets (odo_ctx_upload_ticket / odo_ctx_upload_wait): ticket t is retired once up_ev[t % kUpRing] — recorded behind
   // the t-th asynchronous upload, or behind a later one that reused the ring entry — has passed
   hipEvent_t up_ev[16];
   unsigned long up_issued, up_retired;
+  hipEvent_t sw_ev[8];   // odo_ctx_stream_wait: events recorded on this stream for other streams to wait on (ring)
+  unsigned long sw_next;
   // per-sequence argument table of the batched Solves issued on this stream (odo_lm_solve_batch): per context, because the
   // launches a finished Solve still has queued read it, and only the stream orders the next upload behind them
   void* lm_batch_h;   // pinned
@@ -90,7 +93,7 @@ static int dev_alloc_any(odo_ctx* c, size_t bytes, void** out, bool* pooled) {
     std::lock_guard<std::mutex> lk(*c->mu);
     auto& v = *c->pool;
     for (size_t i = v.size(); i-- > 0;)   // most recently released first
-      if (v[i].bytes == bytes) { *out = v[i].p; if (v[i].ev) (void)hipEventDestroy(v[i].ev); v.erase(v.begin() + (long)i); return 0; }
+      if (v[i].bytes == bytes) { *out = v[i].p; if (v[i].ev) c->pool_events->push_back(v[i].ev); v.erase(v.begin() + (long)i); return 0; }
   }
   HIP_OK(hipMalloc(out, bytes));
   return 0;
@@ -107,8 +110,9 @@ static void dev_free_any(odo_ctx* c, void* p, size_t bytes, bool pooled) {
       auto& v = *c->pool;
       if (v.size() >= kPoolMaxBlocks) { old = v.front(); v.erase(v.begin()); }
       PoolBlock nb{bytes, p, nullptr};
-      if (hipEventCreateWithFlags(&nb.ev, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(nb.ev, c->stream);
-      else nb.ev = nullptr;
+      if (!c->pool_events->empty()) { nb.ev = c->pool_events->back(); c->pool_events->pop_back(); }
+      else if (hipEventCreateWithFlags(&nb.ev, hipEventDisableTiming) != hipSuccess) nb.ev = nullptr;
+      if (nb.ev) (void)hipEventRecord(nb.ev, c->stream);
       v.push_back(nb);
     }
     if (old.p) {
@@ -147,8 +151,10 @@ static int ctx_create(int device, int high_priority, odo_ctx** out) {
   HIP_OK(hipEventCreate(&c->ev1));
   for (int i = 0; i < kStageSlots; i++) HIP_OK(hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming));
   c->pool = new std::vector<PoolBlock>();
+  c->pool_events = new std::vector<hipEvent_t>();
   c->mu = new std::mutex();
   for (auto& e : c->up_ev) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto& e : c->sw_ev) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   *out = c;
   return 0;
 }
@@ -164,7 +170,9 @@ extern "C" int odo_ctx_destroy(odo_ctx* c) {
     if (c->stage[i]) (void)hipHostFree(c->stage[i]);
   }
   if (c->pool) { for (auto& b : *c->pool) { if (b.ev) (void)hipEventDestroy(b.ev); (void)hipFree(b.p); } delete c->pool; }
+  if (c->pool_events) { for (auto& e : *c->pool_events) (void)hipEventDestroy(e); delete c->pool_events; }
   for (auto& e : c->up_ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : c->sw_ev) if (e) (void)hipEventDestroy(e);
   delete c->mu;
   lm_batch_job_free(c);
   if (c->lm_batch_h) (void)hipHostFree(c->lm_batch_h);
@@ -283,6 +291,38 @@ extern "C" int odo_ctx_upload_wait(odo_ctx* c, unsigned long ticket) {
   HIP_OK(hipEventSynchronize(ev));
   std::lock_guard<std::mutex> lk(*c->mu);
   if (ticket > c->up_retired) c->up_retired = ticket;
+  return 0;
+}
+extern "C" unsigned long odo_ctx_mark(odo_ctx* c) {
+  if (!c) return 0;
+  std::lock_guard<std::mutex> lk(*c->mu);
+  const unsigned long mark = ++c->sw_next;             // marks count from 1; ring entry = mark % 8
+  if (hipEventRecord(c->sw_ev[mark % 8], c->stream) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return mark;
+}
+extern "C" int odo_ctx_stream_wait_mark(odo_ctx* waiter, odo_ctx* signaller, unsigned long mark) {
+  if (!waiter || !signaller) return fail("odo_ctx_stream_wait_mark: NULL ctx");
+  if (waiter == signaller) return 0;
+  hipEvent_t ev = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(*signaller->mu);
+    if (mark != 0 && mark <= signaller->sw_next && signaller->sw_next - mark < 8) ev = signaller->sw_ev[mark % 8];
+  }
+  if (!ev) return odo_ctx_stream_wait(waiter, signaller);   // unknown or overwritten mark: behind everything queued so far
+  HIP_OK(hipStreamWaitEvent(waiter->stream, ev, 0));
+  return 0;
+}
+extern "C" int odo_ctx_stream_wait(odo_ctx* waiter, odo_ctx* signaller) {
+  if (!waiter || !signaller) return fail("odo_ctx_stream_wait: NULL ctx");
+  if (waiter == signaller) return 0;
+  const unsigned long mark = odo_ctx_mark(signaller);
+  if (mark == 0) return fail("odo_ctx_stream_wait: hipEventRecord failed");
+  hipEvent_t ev;
+  {
+    std::lock_guard<std::mutex> lk(*signaller->mu);
+    ev = signaller->sw_ev[mark % 8];   // (a ring entry is re-recorded 8 marks later: a stream that was told to wait for it has
+  }                                    //  captured the earlier record by then — hipStreamWaitEvent snapshots the event's state)
+  HIP_OK(hipStreamWaitEvent(waiter->stream, ev, 0));
   return 0;
 }
 extern "C" int odo_dev_upload(odo_ctx* c, void* dst, const void* src, size_t bytes) {
@@ -2159,6 +2199,11 @@ struct odo_depth {
   unsigned persist_epoch, persist_wait;
   unsigned long long* d_xbuf;     // kDpXbufWords
   int* d_gave_up;
+  // odo_depth_prepare_left_dev: blur(left) + selection enqueued ahead of the call on another stream
+  const float* prep_left;         // NULL: nothing prepared
+  unsigned long long prep_stamp;
+  int prep_rows, prep_cols;
+  hipEvent_t prep_ev;             // recorded behind the prepared launches
 };
 
 extern "C" int odo_depth_create(odo_ctx* ctx, float grad_th, float ssd_th, float photo_th, float min_depth, float max_depth,
@@ -2200,6 +2245,7 @@ extern "C" int odo_depth_create(odo_ctx* ctx, float grad_th, float ssd_th, float
   HIP_OK(hipMemset(d->d_xbuf, 0, sizeof(unsigned long long) * kDpXbufWords));
   HIP_OK(hipMalloc((void**)&d->d_gave_up, sizeof(int)));
   HIP_OK(hipMemset(d->d_gave_up, 0, sizeof(int)));
+  HIP_OK(hipEventCreateWithFlags(&d->prep_ev, hipEventDisableTiming));
   *out = d;
   return 0;
 }
@@ -2220,12 +2266,14 @@ extern "C" int odo_depth_destroy(odo_depth* d) {
                 d->d_gave_up};
   for (void* q : dv) if (q) (void)hipFree(q);
   (void)hipHostFree(d->h_stats); (void)hipHostFree(d->h_prog);
+  if (d->prep_ev) { (void)hipEventSynchronize(d->prep_ev); (void)hipEventDestroy(d->prep_ev); }
   delete d;
   return 0;
 }
 
 static int depth_ensure(odo_depth* d, int rows, int cols) {
   if (d->rows == rows && d->cols == cols) return 0;
+  if (d->prep_left) { HIP_OK(hipEventSynchronize(d->prep_ev)); d->prep_left = nullptr; }   // a prepared half on the old buffers is dropped
   HIP_OK(hipStreamSynchronize(d->ctx->stream));
   depth_free_images(d);
   const size_t n = (size_t)rows * cols;
@@ -2269,8 +2317,17 @@ struct DepthJob {
 };
 
 static int depth_job_begin(odo_depth* d, DepthJob* j, const float* left, const float* right, int rows, int cols,
-                           uint8_t* val, float* disp, float* dep, int stage) {
+                           uint8_t* val, float* disp, float* dep, int stage, unsigned long long left_stamp = 0) {
   hipStream_t s = d->ctx->stream;
+  // a front half prepared ahead (odo_depth_prepare_left_dev): either it is this call's — the blurred left image and the selected
+  // points are (or will be) there, behind prep_ev — or it is dropped; in both cases this stream goes on behind it (it writes the
+  // estimator's buffers)
+  bool prepared = false;
+  if (d->prep_left) {
+    HIP_OK(hipStreamWaitEvent(s, d->prep_ev, 0));
+    prepared = stage == 2 && left_stamp != 0 && d->prep_left == left && d->prep_stamp == left_stamp && d->prep_rows == rows && d->prep_cols == cols;
+    d->prep_left = nullptr;
+  }
   const size_t n = (size_t)rows * cols;
   j->left = left; j->right = right; j->val = val; j->disp = disp; j->dep = dep;
   j->rows = rows; j->cols = cols; j->stage = stage;
@@ -2278,11 +2335,17 @@ static int depth_job_begin(odo_depth* d, DepthJob* j, const float* left, const f
   // progress words may only be reset while this stream is idle: every ComputeDepth ends with depth_finish()'s sync
   d->h_prog[0] = 0; d->h_prog[1] = 0;
   (void)n;
-  // blur both images; the same launch zero-fills val / disp / dep
-  hipLaunchKernelGGL(blur3x3_kernel, grid2d(cols, rows, 2), dim3(256), 0, s, left, d->d_bl, right, d->d_br, rows, cols, val,
-                     disp, dep);
-  hipLaunchKernelGGL(depth_select_kernel, dim3(kSelBlocks), dim3(kSelThreads), 0, s, d->d_bl, rows, cols, d->boundary,
-                     d->grad_th, val, d->d_pts, d->d_cnt);
+  if (prepared) {
+    // the right image's blur alone (as slice 0 of the launch: it carries the zero-fill of val / disp / dep); the selection has run
+    // (without marking val: DepthOptimization's write-back sets every selected pixel's flag anyway, ref: :176-191)
+    hipLaunchKernelGGL(blur3x3_kernel, grid2d(cols, rows, 1), dim3(256), 0, s, right, d->d_br, right, d->d_br, rows, cols, val, disp, dep);
+  } else {
+    // blur both images; the same launch zero-fills val / disp / dep
+    hipLaunchKernelGGL(blur3x3_kernel, grid2d(cols, rows, 2), dim3(256), 0, s, left, d->d_bl, right, d->d_br, rows, cols, val,
+                       disp, dep);
+    hipLaunchKernelGGL(depth_select_kernel, dim3(kSelBlocks), dim3(kSelThreads), 0, s, d->d_bl, rows, cols, d->boundary,
+                       d->grad_th, val, d->d_pts, d->d_cnt);
+  }
   hipLaunchKernelGGL(depth_disparity_kernel, dim3(kSelBlocks * kSelCap / 4), dim3(256), 0, s, d->d_bl, d->d_br, rows, cols,
                      d->boundary, d->max_disparity, d->ssd_th, d->K.f0, d->baseline, d->d_pts, d->d_cnt, disp, dep,
                      d->d_d0, d->d_matched);
@@ -2371,9 +2434,9 @@ static int depth_job_pump(odo_depth* d, DepthJob* j) {
 
 // Enqueues the whole ComputeDepth (stage 2) or only the disparity stage (stage 1) on device pointers.
 static int depth_run(odo_depth* d, const float* left, const float* right, int rows, int cols, uint8_t* val, float* disp,
-                     float* dep, int stage) {
+                     float* dep, int stage, unsigned long long left_stamp = 0) {
   DepthJob j;
-  if (depth_job_begin(d, &j, left, right, rows, cols, val, disp, dep, stage)) return -1;
+  if (depth_job_begin(d, &j, left, right, rows, cols, val, disp, dep, stage, left_stamp)) return -1;
   for (;;) {
     const int r = depth_job_pump(d, &j);
     if (r < 0) return -1;
@@ -2444,6 +2507,42 @@ extern "C" int odo_depth_compute(odo_depth* d, const float* left, const float* r
 extern "C" int odo_depth_disparity(odo_depth* d, const float* left, const float* right, int rows, int cols, uint8_t* val,
                                    float* disp, float* dep) {
   return depth_host(d, left, right, rows, cols, val, disp, dep, 1);
+}
+extern "C" int odo_depth_prepare_left_dev(odo_depth* d, odo_ctx* side, const float* left_dev, int rows, int cols, unsigned long long stamp) {
+  return odo_depth_prepare_left_dev_marked(d, side, left_dev, rows, cols, stamp, 0);
+}
+extern "C" int odo_depth_prepare_left_dev_marked(odo_depth* d, odo_ctx* side, const float* left_dev, int rows, int cols,
+                                                 unsigned long long stamp, unsigned long mark) {
+  if (!d || !side || !left_dev || stamp == 0) return fail("odo_depth_prepare_left_dev: bad arg");
+  if (side->device != d->ctx->device) return fail("odo_depth_prepare_left_dev: the two contexts must be on one device");
+  if (depth_check_size(d, rows, cols)) return -1;
+  HIP_OK(hipSetDevice(d->ctx->device));
+  if (d->prep_left) HIP_OK(hipStreamWaitEvent(side->stream, d->prep_ev, 0));   // (a prepared half nobody picked up: one at a time)
+  if (depth_ensure(d, rows, cols)) return -1;
+  // what produced left_dev (an upload), and the estimator's previous call, come first
+  if (mark ? odo_ctx_stream_wait_mark(side, d->ctx, mark) : odo_ctx_stream_wait(side, d->ctx)) return -1;
+  hipLaunchKernelGGL(blur3x3_kernel, grid2d(cols, rows, 1), dim3(256), 0, side->stream, left_dev, d->d_bl, left_dev, d->d_bl, rows, cols,
+                     (uint8_t*)nullptr, (float*)nullptr, (float*)nullptr);
+  hipLaunchKernelGGL(depth_select_kernel, dim3(kSelBlocks), dim3(kSelThreads), 0, side->stream, (const float*)d->d_bl, rows, cols, d->boundary,
+                     d->grad_th, (uint8_t*)nullptr, d->d_pts, d->d_cnt);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipEventRecord(d->prep_ev, side->stream));
+  d->prep_left = left_dev; d->prep_stamp = stamp; d->prep_rows = rows; d->prep_cols = cols;
+  return 0;
+}
+extern "C" int odo_depth_compute_dev_stamped(odo_depth* d, const float* left_dev, const float* right_dev, int rows, int cols,
+                                             uint8_t* val_dev, float* disp_dev, float* dep_dev, unsigned long long left_stamp) {
+  if (!d || !left_dev || !right_dev || !val_dev || !disp_dev || !dep_dev) return fail("depth: NULL arg");
+  if (depth_check_size(d, rows, cols)) return -1;
+  HIP_OK(hipSetDevice(d->ctx->device));
+  if (depth_ensure(d, rows, cols)) return -1;
+  if (depth_run(d, left_dev, right_dev, rows, cols, val_dev, disp_dev, dep_dev, 2, left_stamp)) return -1;
+  int rc = depth_finish(d, false);
+  if (rc == 2) {   // the persistent launch gave up: the same job again on the step launches
+    if (depth_run(d, left_dev, right_dev, rows, cols, val_dev, disp_dev, dep_dev, 2)) return -1;
+    rc = depth_finish(d, false);
+  }
+  return rc == 0 ? 0 : -1;
 }
 extern "C" int odo_depth_compute_dev(odo_depth* d, const float* left_dev, const float* right_dev, int rows, int cols,
                                      uint8_t* val_dev, float* disp_dev, float* dep_dev) {

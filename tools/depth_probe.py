@@ -14,7 +14,7 @@ from odometry_amd import api, synth  # noqa: E402
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-    seq = synth.make_sequence(3, seed=0, drive="natural")
+    seq = synth.make_sequence(int(sys.argv[2]) if len(sys.argv) > 2 else 3, seed=0, drive="natural")
     ctx = api.Context(0)
     frames = [(ctx.upload(l), ctx.upload(r)) for l, r in zip(seq["left"], seq["right"])]
     rows, cols = seq["left"][0].shape

@@ -52,8 +52,9 @@ inline int track_sequence(const std::vector<Mat>& left, const std::vector<Mat>& 
 
   Affine4f cur_pose = pose0, pose_to_keyframe = cur_pose;  // :96-98
   pred.assign(num_frames, to_pose34(cur_pose));
-  Mat pre_left_val(left[0].rows, left[0].cols, CV_8U, 0), pre_left_disp(left[0].rows, left[0].cols, PixelType, 0),
-      pre_left_dep(left[0].rows, left[0].cols, PixelType, 0);
+  const Scalar init_val(0);                                             // :99-101
+  Mat pre_left_val(left[0].rows, left[0].cols, CV_8U, init_val), pre_left_disp(left[0].rows, left[0].cols, PixelType, init_val),
+      pre_left_dep(left[0].rows, left[0].cols, PixelType, init_val);
   if (depth_estimator.ComputeDepth(left[0], right[0], pre_left_val, pre_left_disp, pre_left_dep) == -1) {  // :102
     std::cout << "Init 0-th frame failed!" << std::endl;
     return -1;
@@ -75,7 +76,7 @@ inline int track_sequence(const std::vector<Mat>& left, const std::vector<Mat>& 
                                             cur_img_pyramid);          // :215
     cur_pose = mul(keyframe_poses_abs[current_kf], rigid_inverse(pose_to_keyframe));  // :218
 
-    Mat cur_left_val(left[0].rows, left[0].cols, CV_8U, 0), cur_left_disp(left[0].rows, left[0].cols, PixelType),
+    Mat cur_left_val(left[0].rows, left[0].cols, CV_8U, init_val), cur_left_disp(left[0].rows, left[0].cols, PixelType),
         cur_left_dep(left[0].rows, left[0].cols, PixelType);
     if (depth_estimator.ComputeDepth(left[frame_id], right[frame_id], cur_left_val, cur_left_disp, cur_left_dep) == -1) {
       std::cout << "    depth failed!" << std::endl;                   // :230-232

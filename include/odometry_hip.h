@@ -74,6 +74,9 @@ int odo_dev_download(odo_ctx* ctx, void* dst_host, const void* src_dev, size_t b
 void* odo_host_alloc(size_t bytes);
 void odo_host_free(void* host);
 int odo_dev_upload_async(odo_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+/* The same for an image whose rows lie src_pitch bytes apart on the host (a cv::Mat view: step > cols * elemSize): `rows` rows of
+ * row_bytes bytes land densely packed at dst_dev. */
+int odo_dev_upload_2d_async(odo_ctx* ctx, void* dst_dev, const void* src_host, size_t src_pitch, size_t row_bytes, int rows);
 /* Upload tickets: odo_dev_upload_async from a page-locked block (odo_host_alloc) is a DMA that reads the block in place after
  * the call has returned. odo_ctx_upload_ticket returns the ticket of the most recent such upload (monotonic, 0 = none);
  * odo_ctx_upload_wait(ticket) returns once that upload and all earlier ones no longer read host memory — the moment the block

@@ -238,6 +238,7 @@ class Mat {
   int rows = 0, cols = 0;
   Mat() {}
   Mat(int r, int c, int type) { create(r, c, type); }
+  Mat(int r, int c, int type, const Scalar& s) : Mat(r, c, type, s.val[0]) {}   // cv::Mat(rows, cols, type, cv::Scalar)
   Mat(int r, int c, int type, double fill) {
     create(r, c, type);
     // filled when (if) somebody looks: the runner's per-frame output Mats (ref: run_odometry_kitti_offline.cpp:226) go straight to
@@ -450,20 +451,31 @@ inline odo_ctx* side_context() {
 // (no copy when it is current); with cv::Mat there is nothing to hang a mirror on and nothing that reports writes, so every
 // input is staged and uploaded into a stream-ordered scratch block and every output is downloaded before the call returns.
 #ifdef ODOMETRY_SHIM_WITH_OPENCV
+// (a cv::Mat may be a view: its rows lie m.step bytes apart. Inputs are uploaded row by row into a dense device image; outputs
+// must be continuous — the callers check, with the reference's own message, ref: src/depth_estimate.cpp:259-263 — and a view handed
+// in as an output yields no device buffer instead of bytes in the wrong place.)
 struct DevIn {
   void* dev = nullptr; int async_ = 0; size_t n = 0;
   explicit DevIn(const Mat& m) : n(m.total() * m.elemSize()) {
-    if (odo_dev_alloc_async(context(), n, &dev, &async_) == 0 && odo_dev_upload_async(context(), dev, m.data, n) != 0) {
-      odo_dev_free_async(context(), dev, n, async_); dev = nullptr;
-    }
+    if (m.empty() || odo_dev_alloc_async(context(), n, &dev, &async_) != 0) { dev = nullptr; return; }
+    const size_t row_bytes = (size_t)m.cols * m.elemSize();
+    const int rc = m.isContinuous() ? odo_dev_upload_async(context(), dev, m.data, n)
+                                    : odo_dev_upload_2d_async(context(), dev, m.data, (size_t)m.step, row_bytes, m.rows);
+    if (rc != 0) { odo_dev_free_async(context(), dev, n, async_); dev = nullptr; }
   }
   ~DevIn() { if (dev) odo_dev_free_async(context(), dev, n, async_); }
+  DevIn(const DevIn&) = delete;
+  DevIn& operator=(const DevIn&) = delete;
   const void* get() const { return dev; }
 };
 struct DevOut {
   Mat& m; void* dev = nullptr; int async_ = 0;
-  explicit DevOut(Mat& mm) : m(mm) { odo_dev_alloc_async(context(), m.total() * m.elemSize(), &dev, &async_); }
+  explicit DevOut(Mat& mm) : m(mm) {
+    if (!m.empty() && m.isContinuous()) odo_dev_alloc_async(context(), m.total() * m.elemSize(), &dev, &async_);
+  }
   ~DevOut() { if (dev) { odo_dev_download(context(), m.data, dev, m.total() * m.elemSize()); odo_dev_free_async(context(), dev, m.total() * m.elemSize(), async_); } }
+  DevOut(const DevOut&) = delete;
+  DevOut& operator=(const DevOut&) = delete;
   void* get() { return dev; }
 };
 #else
@@ -548,7 +560,7 @@ inline std::shared_ptr<PyrHandle> make_pyr(int num_levels, const Mat& in, bool s
   auto h = std::make_shared<PyrHandle>();
   h->host.resize(num_levels > 0 ? num_levels : 0);
   h->have.assign(num_levels > 0 ? num_levels : 0, 0);
-  bool ok = in.type() == PixelType && in.isContinuous();
+  bool ok = in.type() == PixelType && !in.empty();   // (a cv::Mat view is fine: DevIn uploads it row by row, like cv::GaussianBlur reads it)
   if (ok) {
     DevIn src(in);  // the frame on the device (already there when the same Mat was used a moment ago)
     ok = src.get() != nullptr &&

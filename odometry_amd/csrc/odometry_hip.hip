@@ -335,6 +335,10 @@ extern "C" int odo_dev_upload_async(odo_ctx* c, void* dst, const void* src, size
   if (!c || !dst || !src) return fail("NULL arg");
   return upload_rows_async(c, dst, src, bytes, bytes, 1);
 }
+extern "C" int odo_dev_upload_2d_async(odo_ctx* c, void* dst, const void* src, size_t src_pitch, size_t row_bytes, int rows) {
+  if (!c || !dst || !src || rows < 1 || src_pitch < row_bytes) return fail("odo_dev_upload_2d_async: bad arg");
+  return upload_rows_async(c, dst, src, src_pitch, row_bytes, rows);
+}
 extern "C" int odo_dev_download(odo_ctx* c, void* dst, const void* src, size_t bytes) {
   if (!c) return fail("NULL ctx");
   HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));

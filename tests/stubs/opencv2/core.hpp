@@ -1,0 +1,132 @@
+// tests/stubs/opencv2/core.hpp — TEST SCAFFOLDING ONLY: a minimal stand-in for <opencv2/core.hpp>, written from OpenCV's documented
+// public API (cv::Mat: rows, cols, data, step, type(), total(), elemSize(), isContinuous(), ptr / at, create / clone / copyTo,
+// reference-counted header copies, ROI views, user-data headers with a row step; cv::Scalar, cv::Size, cv::Rect and the constants the
+// drop-in classes name). This image has no OpenCV; the stub exists so that the -DODOMETRY_SHIM_WITH_OPENCV branch of
+// include/odometry_shim.hpp — the one a maintainer of the reference would build — goes through a compiler and a GPU run
+// (tests/test_gpu_shim.py). It is not part of the product and implements no image processing.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <cstdlib>
+
+#define CV_8U 0
+#define CV_32F 5
+#define CV_64F 6
+#define CV_8UC1 0
+#define CV_32FC1 5
+#define CV_64FC1 6
+
+namespace cv {
+typedef unsigned char uchar;
+
+template <class T> struct Scalar_ {
+  T val[4];
+  Scalar_() { val[0] = val[1] = val[2] = val[3] = 0; }
+  Scalar_(T v0) { val[0] = v0; val[1] = val[2] = val[3] = 0; }
+  Scalar_(T v0, T v1, T v2 = 0, T v3 = 0) { val[0] = v0; val[1] = v1; val[2] = v2; val[3] = v3; }
+  T& operator[](int i) { return val[i]; }
+  const T& operator[](int i) const { return val[i]; }
+};
+typedef Scalar_<double> Scalar;
+
+struct Size {
+  int width, height;
+  Size() : width(0), height(0) {}
+  Size(int w, int h) : width(w), height(h) {}
+};
+struct Rect {
+  int x, y, width, height;
+  Rect() : x(0), y(0), width(0), height(0) {}
+  Rect(int x_, int y_, int w, int h) : x(x_), y(y_), width(w), height(h) {}
+};
+enum InterpolationFlags { INTER_NEAREST = 0, INTER_LINEAR = 1 };
+enum BorderTypes { BORDER_CONSTANT = 0, BORDER_REPLICATE = 1, BORDER_REFLECT_101 = 4 };
+
+struct MatStep {
+  size_t p[2];
+  MatStep() { p[0] = p[1] = 0; }
+  operator size_t() const { return p[0]; }
+  size_t operator[](int i) const { return p[i]; }
+};
+
+class Mat {
+ public:
+  enum { AUTO_STEP = 0 };
+  int flags, dims, rows, cols;
+  uchar* data;
+  MatStep step;
+
+  Mat() : flags(0), dims(0), rows(0), cols(0), data(nullptr), type_(0), base_(nullptr), refcount_(nullptr) {}
+  Mat(int r, int c, int type) : Mat() { create(r, c, type); }
+  Mat(int r, int c, int type, const Scalar& s) : Mat() { create(r, c, type); setTo(s); }
+  // header over user data: no copy, no ownership; `step_bytes` = distance between rows (AUTO_STEP: no padding)
+  Mat(int r, int c, int type, void* user, size_t step_bytes = AUTO_STEP) : Mat() {
+    rows = r; cols = c; type_ = type; dims = 2; data = static_cast<uchar*>(user);
+    step.p[1] = elemSize(); step.p[0] = step_bytes == AUTO_STEP ? (size_t)c * elemSize() : step_bytes;
+  }
+  Mat(const Mat& m) : flags(m.flags), dims(m.dims), rows(m.rows), cols(m.cols), data(m.data), step(m.step), type_(m.type_), base_(m.base_),
+                      refcount_(m.refcount_) { if (refcount_) ++*refcount_; }
+  Mat(const Mat& m, const Rect& roi) : Mat(m) {   // a view: shares the pixels, keeps the parent's row step
+    rows = roi.height; cols = roi.width;
+    data = m.data + (size_t)roi.y * m.step.p[0] + (size_t)roi.x * m.elemSize();
+  }
+  Mat& operator=(const Mat& m) {
+    if (this != &m) {
+      if (m.refcount_) ++*m.refcount_;
+      release();
+      flags = m.flags; dims = m.dims; rows = m.rows; cols = m.cols; data = m.data; step = m.step; type_ = m.type_; base_ = m.base_;
+      refcount_ = m.refcount_;
+    }
+    return *this;
+  }
+  ~Mat() { release(); }
+  Mat operator()(const Rect& roi) const { return Mat(*this, roi); }
+
+  void create(int r, int c, int type) {
+    if (data && rows == r && cols == c && type_ == type && isContinuous() && refcount_) return;   // cv::Mat::create keeps a fitting buffer
+    release();
+    rows = r; cols = c; type_ = type; dims = 2;
+    step.p[1] = elemSize(); step.p[0] = (size_t)c * elemSize();
+    const size_t n = (size_t)r * step.p[0];
+    base_ = static_cast<uchar*>(std::malloc(n ? n : 1));
+    data = base_;
+    refcount_ = new int(1);
+  }
+  void release() {
+    if (refcount_ && --*refcount_ == 0) { std::free(base_); delete refcount_; }
+    base_ = nullptr; refcount_ = nullptr; data = nullptr; rows = cols = 0;
+  }
+  Mat clone() const { Mat m; copyTo(m); return m; }
+  void copyTo(Mat& dst) const {
+    dst.create(rows, cols, type_);
+    for (int y = 0; y < rows; y++) std::memcpy(dst.data + (size_t)y * dst.step.p[0], data + (size_t)y * step.p[0], (size_t)cols * elemSize());
+  }
+  Mat& setTo(const Scalar& s) {
+    for (int y = 0; y < rows; y++)
+      for (int x = 0; x < cols; x++) {
+        uchar* p = data + (size_t)y * step.p[0] + (size_t)x * elemSize();
+        if (type_ == CV_32F) *reinterpret_cast<float*>(p) = (float)s[0];
+        else if (type_ == CV_64F) *reinterpret_cast<double*>(p) = s[0];
+        else *p = (uchar)s[0];
+      }
+    return *this;
+  }
+  int type() const { return type_; }
+  int depth() const { return type_; }
+  int channels() const { return 1; }
+  size_t elemSize() const { return type_ == CV_64F ? 8 : type_ == CV_32F ? 4 : 1; }
+  size_t total() const { return (size_t)rows * cols; }
+  bool isContinuous() const { return rows <= 1 || step.p[0] == (size_t)cols * elemSize(); }
+  bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
+  template <class T> T* ptr(int y = 0) { return reinterpret_cast<T*>(data + (size_t)y * step.p[0]); }
+  template <class T> const T* ptr(int y = 0) const { return reinterpret_cast<const T*>(data + (size_t)y * step.p[0]); }
+  template <class T> T& at(int y, int x) { return ptr<T>(y)[x]; }
+  template <class T> const T& at(int y, int x) const { return ptr<T>(y)[x]; }
+
+ private:
+  int type_;
+  uchar* base_;
+  int* refcount_;
+};
+}  // namespace cv

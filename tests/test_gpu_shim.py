@@ -83,6 +83,51 @@ def test_shim_poses_bit_identical_to_tracker(tmp_path):
     trk.close()
 
 
+_CV_FLAGS = ["-DODOMETRY_SHIM_WITH_OPENCV", "-DODOMETRY_SHIM_WITH_EIGEN", "-I" + os.path.join(ROOT, "tests", "stubs")]
+
+
+def _build_cv(tmp_path, src, name):
+    """The cv::Mat / Eigen branch of the shim — the one a maintainer of the reference builds — against tests/stubs (this image has
+    neither library: the stubs are written from the documented APIs, test scaffolding only)."""
+    exe = str(tmp_path / name)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Werror"] + _CV_FLAGS +
+                          ["-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, src), "-o", exe,
+                           "-L" + os.path.join(ROOT, "odometry_amd", "lib"), "-lodometry_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "odometry_amd", "lib")])
+    return exe
+
+
+def test_opencv_eigen_branch_tracks_bit_identically_to_the_stand_in_build(tmp_path):
+    """examples/run_odometry_synth.cpp built twice — with the stand-in Mat / Affine4f and with -DODOMETRY_SHIM_WITH_OPENCV
+    -DODOMETRY_SHIM_WITH_EIGEN (cv::Mat inputs staged and uploaded at every use, outputs downloaded at once, Eigen poses): the same
+    pose_to_keyframe for every frame, bit for bit."""
+    from odometry_amd import synth
+    seq = synth.make_sequence(12, seed=2)
+    L, R = seq["left"], seq["right"]
+    frames = str(tmp_path / "frames.bin")
+    with open(frames, "wb") as f:
+        np.array([len(L), L[0].shape[0], L[0].shape[1]], np.int32).tofile(f)
+        for l, r in zip(L, R):
+            l.astype(np.float32).tofile(f)
+            r.astype(np.float32).tofile(f)
+    rels = []
+    for exe in (_build(tmp_path, "examples/run_odometry_synth.cpp", "synth_standin"),
+                _build_cv(tmp_path, "examples/run_odometry_synth.cpp", "synth_opencv")):
+        rel = exe + ".rel"
+        out = subprocess.run([exe, frames, "--rel-bin", rel], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        rels.append(np.fromfile(rel, np.float32).reshape(-1, 16))
+    assert rels[0].shape == (len(L) - 1, 16) and np.array_equal(rels[0], rels[1])
+
+
+def test_opencv_branch_honours_step_and_rejects_views_like_the_reference(tmp_path):
+    """cv::Mat views (rows `step` bytes apart) through the drop-in classes: pyramids of a view equal those of its continuous clone;
+    ComputeDepth refuses non-continuous inputs and outputs with the reference's message (ref: src/depth_estimate.cpp:259-263)."""
+    exe = _build_cv(tmp_path, "tests/shim_opencv_harness.cpp", "shim_opencv_harness")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().splitlines()[-1].startswith("OK"), out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_cpp_kitti_runner_with_png_ingest(tmp_path, kitti_seq):
     """examples/run_odometry_kitti.cpp: KITTI directory layout, PNG decoding, tracking, error evaluation, KITTI pose file."""
     from oracle import runner as orunner

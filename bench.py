@@ -609,9 +609,10 @@ def tracking_summary(e_abs, e_rel):
     return d
 
 
-def drive_leg(api, seq, warmup, steps, local_rank=0):
+def drive_leg(api, seq, warmup, steps, local_rank=0, details=None):
     """One pass of the runner's loop over a resident sequence with the next pair announced (the timed run's configuration), on a
-    tracker of its own: frames/s over `steps` frames after `warmup`, LM evaluations per frame, tracking error vs ground truth."""
+    tracker of its own: frames/s over `steps` frames after `warmup`, LM evaluations per frame, tracking error vs ground truth.
+    details (a dict, optional): filled with the poses, the keyframes' level-0 point counts, launches per Solve, persistent-launch stats."""
     n = len(seq["left"])
     steps = max(1, min(steps, n - 1 - warmup))
     trk = api.Tracker(local_rank)
@@ -628,12 +629,43 @@ def drive_leg(api, seq, warmup, steps, local_rank=0):
             trk.hint_next(*dev[k + 2])
         flags.append(trk.track_into(dev[k + 1][0], dev[k + 1][1], pk[k], pa[k]))
         evals.append(trk.stats()["lm_evals"])
+        if details is not None:
+            pts, launches = trk.lm_points()
+            details.setdefault("level0_points", []).append(pts[0])
+            details.setdefault("launches", []).append(launches)
     trk._sync()
     dt = time.perf_counter() - t0
     e_abs, e_rel = tracking_error(pa, seq["poses"], list(range(1, warmup + steps + 1)), pk, flags)
+    if details is not None:
+        details["poses"] = pk.copy()
+        details["persistent"] = trk.persistent_stats()
     trk.close()
     return dict(frames_per_s=round(steps / dt, 1), frames=steps, warmup=warmup, lm_evals_per_frame=round(float(np.mean(evals[warmup:])), 2),
                 keyframes=int(sum(flags)) + 1, tracking_error_vs_ground_truth_m=tracking_summary(e_abs, e_rel))
+
+
+def saturated_leg(api, seq, warmup, steps, local_rank=0):
+    """A keyframe at the reference's point cap (ref: src/depth_estimate.cpp:300-304,333-339: up to 80 points in each of 512 blocks):
+    the 'dense' drive selects ~39 800 of the 40 960 slots and keeps ~28 000 inverse depths on level 0 — 110+ virtual blocks, more
+    than the persistent launch's 32 workgroups hold in registers (64), so level 0 runs on a step launch per evaluation behind the
+    persistent launch (levels 3 - 1). Reported: frames/s as the headline measures it, launches per Solve, Solves redone (none: the
+    persistent launch never gives up), and the same drive with the persistent launch off (ODO_LM_NO_FINE): bit-identical poses."""
+    d_on, d_off = {}, {}
+    r = drive_leg(api, seq, warmup, steps, local_rank, details=d_on)
+    os.environ["ODO_LM_NO_FINE"] = "1"
+    try:
+        r_off = drive_leg(api, seq, warmup, steps, local_rank, details=d_off)
+    finally:
+        del os.environ["ODO_LM_NO_FINE"]
+    r["level0_points_mean"] = int(np.mean(d_on["level0_points"]))
+    r["level0_points_max"] = int(np.max(d_on["level0_points"]))
+    r["launches_per_solve"] = round(float(np.mean(d_on["launches"][warmup:])), 2)
+    r["persistent_launch"] = dict(workgroups=d_on["persistent"][0], solves_redone_on_step_launches=d_on["persistent"][1])
+    r["step_launches_only"] = dict(frames_per_s=r_off["frames_per_s"], launches_per_solve=round(float(np.mean(d_off["launches"][warmup:])), 2))
+    r["poses_bit_identical_to_step_launches_only"] = bool(np.array_equal(d_on["poses"], d_off["poses"]))
+    r["what"] = ("odometry_amd/synth.py drive 'dense' (1 / f^1.2 textures: the point selection hits its cap of 80 per block); same steps / "
+                 "warm-up as the headline, own tracker; level 0 (> 64 virtual blocks) on step launches behind the persistent launch")
+    return r
 
 
 def configs3_leg(api, seqs, my_ids, n_sequences, world, rank, local_rank, backend, steps, warmup, gather_every):
@@ -785,7 +817,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="run ComputeDepth after Solve on one stream")
     ap.add_argument("--no-prefetch", action="store_true", help="build each frame's image pyramid inside its own step")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements")
-    ap.add_argument("--extras", default="dense,disparity,single,shim,batched",
+    ap.add_argument("--extras", default="dense,disparity,single,shim,batched,saturated",
                     help="side measurements to run: dense (configs[2]), disparity (configs[4]), single (configs[0]), shim (the "
                          "drop-in C++ classes and the host-buffer C ABI, PCIe included), batched (S = 1/2/4/8 sequences in lock step on one GPU); "
                          "multi / multiproc (several trackers of one process / several processes on one GPU) are opt-in: it floods the device with concurrent "
@@ -848,6 +880,9 @@ def main():
     stress_seq = None
     if world == 1 and not args.no_extras and not args.no_stress and args.drive != "corridor":
         stress_seq = render_sequence(min(args.unique_frames, 200), 0, workers, drive="corridor")
+    saturated_seq = None
+    if world == 1 and not args.no_extras and "saturated" in args.extras.split(","):
+        saturated_seq = render_sequence(min(args.unique_frames, args.warmup + args.steps + 2, 200), 0, workers, drive="dense")
     batch_seqs = None
     if world == 1 and not args.no_extras and "batched" in args.extras.split(","):
         nb = min(args.unique_frames, 40)   # eight distinct short drives for the batched leg (rendered before the GPU is touched)
@@ -1238,6 +1273,8 @@ def main():
                                      "steps / warm-up as the headline, own tracker")
                         return r
                     leg("stress_drive", stress)
+                if saturated_seq is not None:
+                    leg("saturated_keyframe", lambda: saturated_leg(api, saturated_seq, args.warmup, args.steps, local_rank))
                 if "dense" in legs:
                     leg("roofline_dense_1080p", lambda: dense_1080p_leg(api, synth))
                 if "disparity" in legs:

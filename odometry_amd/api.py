@@ -606,6 +606,16 @@ class Tracker:
         L.check(self.lib.odo_lm_persistent_stats(lm, C.byref(k), C.byref(f)), "odo_lm_persistent_stats")
         return k.value, f.value
 
+    def lm_points(self):
+        """Points per pyramid level of the current keyframe's lists (level 0 first) and the launches of the last Solve."""
+        lm = C.c_void_p(self.lib.odo_tracker_lm(self.h))
+        n = (C.c_int * L.MAX_LEVELS)()
+        u = (C.c_int * L.MAX_LEVELS)()
+        L.check(self.lib.odo_lm_points(lm, n, u), "odo_lm_points")
+        a, t, b = C.c_int(0), C.c_int(0), C.c_double(0)
+        L.check(self.lib.odo_lm_launch_stats(lm, C.byref(a), C.byref(t), C.byref(b)), "odo_lm_launch_stats")
+        return list(n)[:self.params.levels], t.value
+
     def timing(self):
         out = (C.c_double * 4)()
         L.check(self.lib.odo_tracker_timing(self.h, out), "odo_tracker_timing")

@@ -170,6 +170,11 @@ DRIVES = {
     # 261-262) to converge in 21 of 25 switches over 200 frames; the tracker stays within centimetres of the ground truth on 195 of
     # 199 frames (tools/drive_search.py natural 200). Found by scanning spectrum x contrast x speed x corridor width with the oracle.
     "natural": dict(scene=dict(spectrum=1.55, sigma=80.0), fwd_range=(0.3, 0.6), max_offset=1.0),
+    # bench.py's saturated_keyframe leg (round 4): a flatter spectrum (~ 1 / f^1.2) puts enough fine texture into every 38 x 23 block
+    # for the point selection to hit its cap of 80 per block (ref: src/depth_estimate.cpp:300-304,333-339): 39 805 of 40 960 slots
+    # selected, ~28 700 valid inverse depths on level 0 of a keyframe (the natural drive: 18 037 / 13 643) — what a richly textured
+    # real frame does to the pose LM's finest level.
+    "dense": dict(scene=dict(spectrum=1.2, sigma=80.0), fwd_range=(0.3, 0.6), max_offset=1.0),
 }
 
 

@@ -1122,8 +1122,10 @@ def main():
                     note="single 1241x376 frame: the working set is cache resident and every evaluation is a serial chain "
                          "(solve, exp, 13-30k points); see roofline_dense_1080p for the HBM-bound shape")
         pk, pf = trk.persistent_stats()
+        dk, df = trk.depth_persistent_stats()
         roof["persistent_launch"] = dict(workgroups=pk, solves_redone_on_step_launches=pf,
-                                         note="lm_fine_kernel: 0 workgroups = off (by choice or after three fall-backs)")
+                                         depth_lm_persistent=dk, depth_jobs_redone_on_step_launches=df,
+                                         note="lm_fine_kernel: 0 workgroups = off (by choice or after three fall-backs); depth_lm_persistent_kernel likewise")
         if fine:
             roof[fine_key] = dict(launches_per_frame=round(step_launches / n_frames_ev, 2), launch_us=round(step_span, 2),
                                   exec_span_us=round(step_span, 2),

@@ -346,6 +346,7 @@ int odo_tracker_time_residual(odo_tracker* t, int level, int reps, float* mean_u
  * {track() call, Solve on stream A, stream-B job on the helper thread, wait for the helper}. */
 int odo_tracker_timing(odo_tracker* t, double out[4]);
 odo_lm* odo_tracker_lm(odo_tracker* t);
+odo_depth* odo_tracker_depth(odo_tracker* t);   /* its depth estimator (odo_depth_persistent_stats, odo_depth_report) */
 odo_ctx* odo_tracker_ctx(odo_tracker* t);
 
 /* ---- S sequences in lock step on one GPU (the data-parallel axis of SURVEY section 8e inside one device) -----------------

@@ -606,6 +606,13 @@ class Tracker:
         L.check(self.lib.odo_lm_persistent_stats(lm, C.byref(k), C.byref(f)), "odo_lm_persistent_stats")
         return k.value, f.value
 
+    def depth_persistent_stats(self):
+        """(1 while the depth LM runs as one persistent launch, ComputeDepth jobs run again on the step launches)"""
+        d = C.c_void_p(self.lib.odo_tracker_depth(self.h))
+        a, b = C.c_int(0), C.c_int(0)
+        L.check(self.lib.odo_depth_persistent_stats(d, C.byref(a), C.byref(b)), "odo_depth_persistent_stats")
+        return a.value, b.value
+
     def lm_points(self):
         """Points per pyramid level of the current keyframe's lists (level 0 first) and the launches of the last Solve."""
         lm = C.c_void_p(self.lib.odo_tracker_lm(self.h))

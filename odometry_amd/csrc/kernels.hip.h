@@ -1008,6 +1008,7 @@ struct StepArgs {
   unsigned long long* xbuf;  // ... and exchanges this sequence's partial rows through this buffer (kFineXbufWords words)
   unsigned fine_epoch;       // tags of the exchange: (fine_epoch << 8) + evaluation; the host never repeats an epoch on a buffer it has not cleared
   unsigned fine_wait;        // bound of one wait of the persistent launch in wall-clock ticks (0: kFineWaitTicks)
+  int fine_home;             // the XCC id of the XCD this optimiser's persistent launch runs on (fine_on_home; < 0: class 0 wherever it lands)
   // hand-over to the unfused pipeline (dense fine levels): the device stops walking the pyramid below stop_level, reports the
   // Solve "finished" there and leaves its state in final_state, from which the host carries on level by level
   int stop_level;       // 0: the fused pipeline covers every level
@@ -1494,12 +1495,29 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
       __syncthreads();  // rows visible (and, first round, everyone has read s_sh.T)
       if (vb0 == 0) lap(c_eval);
       double accq = 0.0;
-      if (my_q < ODO_NACC) accq = rows_accumulate<kLmBlock, kS>(rows_sh, rowA, rowB, my_s, accq);
-      accq = rows_butterfly8(accq);
-      if (vb < nvb && my_q < ODO_NACC && my_s == 0) part_sh[vb][my_q] = accq;
+      if (vb < nvb) {   // (uniform over the four waves of a half)
+        if (my_q < ODO_NACC) accq = rows_accumulate<kLmBlock, kS>(rows_sh, rowA, rowB, my_s, accq);
+        accq = rows_butterfly8(accq);
+      }
+      if (nvb == 1) {
+        // One virtual block (<= 256 points: the usual coarsest level): its partial row IS the level's sums — the fold below would add
+        // it to zeros, segment 0 first, then the seven empty segments; the same additions here, by the thread that holds the value,
+        // without the two trips through LDS and the two barriers around them.
+        if (half == 0 && my_q < ODO_NACC && my_s == 0) {
+          double v = 0.0;
+          v += accq;              // segment 0: rows 0, 8, ... = row 0
+          double acc = 0.0;
+          acc += v;
+#pragma unroll
+          for (int g = 1; g < 8; g++) acc += 0.0;   // segments 1 .. 7 are empty (IEEE: kept as written, -0 + 0 = +0)
+          acc_sh[my_q] = acc;
+        }
+      } else if (vb < nvb && my_q < ODO_NACC && my_s == 0) {
+        part_sh[vb][my_q] = accq;
+      }
     }
     __syncthreads();
-    {  // the fold of lm_fused_prologue: segment seg adds rows seg, seg + 8, ... in ascending order, then the segments in order
+    if (nvb > 1) {  // the fold of lm_fused_prologue: segment seg adds rows seg, seg + 8, ... in ascending order, then the segments in order
       const int fq = threadIdx.x & 31, fseg = threadIdx.x >> 5;
       double* fold_sh = red_sh;  // the rows have been consumed (barrier above)
       if (fseg < 8) {
@@ -1613,6 +1631,22 @@ __device__ __forceinline__ int fine_xcc_id() {
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
   return v & 0xf;
 }
+// WHICH XCD a persistent launch sits on. The blocks of a launch are dealt round-robin over the 8 XCDs, so its eight block classes
+// (blockIdx.x & 7) sit on eight XCDs — but on which one a given class lands changes from launch to launch (the dispatcher carries
+// on where the previous dispatch stopped). Two persistent launches of one process that end up on the SAME XCD — the pose LM's and
+// the depth LM's, which run side by side — cannot both get their workgroups resident (a pose-LM workgroup takes a CU's registers
+// whole): each holds some CUs and waits for the rest until the wait bound ends one of them (measured: a depth job in ~40 redone,
+// 4 ms each time). So every persistent user has a HOME XCD — a hardware XCC id the host read with xcc_probe_kernel and hands out
+// per device: an odo_lm the first, its estimator the second, the next tracker the third and fourth ... — and the blocks that find
+// themselves there take part: no block waits for another one to decide this (a class that sits behind the OTHER persistent launch
+// may not even start before that one ends). home < 0 (the probe did not see eight distinct ids): class 0, wherever it lands.
+__device__ __forceinline__ bool fine_on_home(int home) {
+  return home >= 0 ? fine_xcc_id() == home : (blockIdx.x & 7u) == 0u;
+}
+__global__ void xcc_probe_kernel(int* __restrict__ out) {
+  if (threadIdx.x == 0) out[blockIdx.x] = fine_xcc_id();
+}
+struct XccIds { int id[8]; };   // the eight XCC ids of the device (id[0] < 0: unknown)
 // ComputeScaleNaive across the workgroups of the persistent launch (ref: src/lm_optimizer.cpp:338-358): called by every wave whose
 // virtual block belongs to the level (vb < nblk; a full wavefront, wave-uniform arguments except e2 / valid), each for itself — no
 // workgroup barrier, no LDS: per pass the wave's chunk sum goes out as one tagged granule pair and all chunk sums of the level come
@@ -1879,26 +1913,35 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
     if (t == 0 && q.span) atomicMax(q.span + 1, (unsigned long long)wall_clock64());
   }
 }
-// grid = 8 * K blocks: every eighth block takes part (one XCD), the others return at once
+// grid = 8 * K blocks: the class (blockIdx.x & 7) that sits on the optimiser's home XCD takes part, the others return at once
+template <bool kTdist>
+__device__ __forceinline__ void lm_fine_entry(const StepArgs& a, int K, unsigned long long* __restrict__ xbuf, int fault, int lo_level) {
+  if (!fine_on_home(a.fine_home)) return;
+  const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve, a.span};
+  lm_fine_body<kTdist>(a, q, K, (int)(blockIdx.x >> 3), xbuf, fault, lo_level);
+}
 __global__ void __launch_bounds__(kFineThreads) lm_fine_kernel(StepArgs a, int K, unsigned long long* __restrict__ xbuf, int fault,
                                                                int lo_level) {
-  if ((blockIdx.x & 7u) != 0u) return;
-  const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve, a.span};
-  lm_fine_body<false>(a, q, K, (int)(blockIdx.x >> 3), xbuf, fault, lo_level);
+  lm_fine_entry<false>(a, K, xbuf, fault, lo_level);
 }
 // The same with t-distribution weights (a.robust == 2).
 __global__ void __launch_bounds__(kFineThreads) lm_fine_tdist_kernel(StepArgs a, int K, unsigned long long* __restrict__ xbuf, int fault,
                                                                      int lo_level) {
-  if ((blockIdx.x & 7u) != 0u) return;
-  const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve, a.span};
-  lm_fine_body<true>(a, q, K, (int)(blockIdx.x >> 3), xbuf, fault, lo_level);
+  lm_fine_entry<true>(a, K, xbuf, fault, lo_level);
 }
 // Batched twin: the sequences of a batched Solve each get an XCD (sequence i: the blocks with blockIdx.x % 8 == i % 8; beyond
 // eight sequences two or more share an XCD, K workgroups each). grid = 8 * K * ceil(n / 8). A sequence whose levels do not
 // fit (fine_lo >= min_level) takes no part: its blocks return at once and its levels follow on the batched step launches.
 __global__ void __launch_bounds__(kFineThreads) lm_fine_kernel_batch(const StepArgs* __restrict__ table, int n, int K, int seq,
-                                                                     int first_of_solve, unsigned long long* span, int fault) {
-  const int r = (int)(blockIdx.x & 7u), wa = (int)(blockIdx.x >> 3);
+                                                                     int first_of_solve, unsigned long long* span, int fault, XccIds xcc) {
+  // sequence i on the i-th XCD of the device, whichever block class sits there in this launch (XCC ids unknown: on class i % 8, as dealt)
+  int r = (int)(blockIdx.x & 7u);
+  if (xcc.id[0] >= 0) {
+    const int mine = fine_xcc_id();
+#pragma unroll
+    for (int c = 0; c < 8; c++) if (xcc.id[c] == mine) r = c;
+  }
+  const int wa = (int)(blockIdx.x >> 3);
   const int i = (wa / K) * 8 + r, w = wa % K;
   if (i >= n) return;
   const StepArgs& a = table[i];
@@ -2488,16 +2531,17 @@ struct DepthPersistArgs {
   int* gave_up;                 // device word: set to 1 by a workgroup whose wait ran out (depth_stats_kernel reads and clears it)
   int fault;                    // test hook (ODO_DEPTH_PERSIST_FAULT): virtual block 0's pair is never published
   unsigned long long* dbg;      // diagnostic (ODO_DEPTH_STAMPS): cycle sums of workgroup 0's phases, else null
+  int home;                     // the XCC id of the XCD this estimator's persistent launch runs on (fine_on_home)
 };
 __global__ void __launch_bounds__(kDpThreads) depth_lm_persistent_kernel(DepthPersistArgs a) {
-  if ((blockIdx.x & 7u) != 4u) return;            // every eighth block: one XCD (not the one the pose LM's persistent launch sits on)
+  const unsigned wait_limit = a.wait_ticks ? a.wait_ticks : kFineWaitTicks;
+  if (!fine_on_home(a.home)) return;   // the block class on the estimator's home XCD — never the pose LM's — takes part
   const int g = (int)(blockIdx.x >> 3), t = threadIdx.x, lane = t & 63, wv = t >> 6;
   __shared__ double sh_e[kDpThreads / 64];
   __shared__ int sh_n[kDpThreads / 64];
   __shared__ int sh_c[kDpThreads / 64][3];
   __shared__ double fold_e;
   __shared__ int fold_n, local_sh, bail_sh;
-  const unsigned wait_limit = a.wait_ticks ? a.wait_ticks : kFineWaitTicks;
   unsigned long long* place = a.xbuf + 2 * kDlmBlocks * 2;
   const unsigned ep = (a.epoch & 0xffu) << 8;
   if (t == 0) {

@@ -10,6 +10,7 @@
 #include <chrono>
 
 #include <atomic>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <utility>
@@ -37,6 +38,47 @@ static int fail(const char* fmt, ...) {
 
 extern "C" const char* odo_last_error(void) { return g_err; }
 extern "C" int odo_version(void) { return 100; }
+
+// Home XCDs of the persistent launches (kernels.hip.h, fine_read_classes): every user of one — a pose optimiser, a depth estimator —
+// takes the next XCD of its device when it is created, so that the launches that run side by side (a tracker's pose LM and its depth
+// LM; up to four trackers of one process) never sit on the same XCD.
+// The XCC ids themselves are read from the device once (eight blocks of one launch, one per XCD); if they are not eight distinct
+// ids (a partitioned device), homes are off (-1) and the launches use their block class 0 wherever it lands, as before round 4.
+static std::atomic<unsigned> g_next_home_xcd[16];
+static std::mutex g_xcc_mu;
+static int g_xcc_state[16];      // 0 unknown, 1 eight distinct ids, -1 not usable
+static XccIds g_xcc_ids[16];
+static const XccIds& device_xcc_ids(int device) {
+  std::lock_guard<std::mutex> lk(g_xcc_mu);
+  const int dv = device & 15;
+  if (g_xcc_state[dv] == 0) {
+    g_xcc_state[dv] = -1;
+    for (int& v : g_xcc_ids[dv].id) v = -1;
+    int* d = nullptr;
+    int h[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    if (!getenv("ODO_NO_HOME_XCD") && hipMalloc((void**)&d, sizeof(h)) == hipSuccess) {
+      hipLaunchKernelGGL(xcc_probe_kernel, dim3(8), dim3(64), 0, 0, d);
+      if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+        unsigned seen = 0u;
+        for (int v : h) if (v >= 0 && v < 16) seen |= 1u << v;
+        if (__builtin_popcount(seen) == 8) { for (int i = 0; i < 8; i++) g_xcc_ids[dv].id[i] = h[i]; g_xcc_state[dv] = 1; }
+      }
+      (void)hipFree(d);
+    }
+    (void)hipGetLastError();
+  }
+  return g_xcc_ids[dv];
+}
+// Measured (round 4, tools/persist_conflict_probe.py): with homes 3 288 frames/s, with the launches left where the dispatcher puts them
+// 3 341 — and the occasional give-up of a depth launch did not go away (it is not the two launches meeting on one XCD). Homes are
+// therefore OFF unless ODO_HOME_XCD=1 asks for them (several trackers in one process).
+static int next_home_xcd(int device) {
+  static const bool on = getenv("ODO_HOME_XCD") != nullptr;
+  if (!on) return -1;
+  const XccIds& x = device_xcc_ids(device);
+  const unsigned k = g_next_home_xcd[device & 15].fetch_add(1u);
+  return x.id[0] >= 0 ? x.id[k & 7u] : -1;
+}
 
 // ------------------------------------------------------------------------------------------------
 constexpr int kStageSlots = 4;
@@ -626,6 +668,7 @@ struct odo_lm {
   unsigned fine_wait;   // bound of one wait inside the launch, wall-clock ticks (ODO_LM_FINE_WAIT_US; 0: the kernel's default, 4 ms)
   unsigned fine_epoch;  // tag epoch of the exchange buffer (lm_fine_next_epoch)
   int fine_fault;   // test hook (ODO_LM_FINE_FAULT): the first partial row of the persistent launch is never published
+  int fine_home;    // the XCD its persistent launch runs on (next_home_xcd)
   unsigned long long* d_xbuf;
   int fused;  // 1 = one launch per evaluation (robust 0/1); 0 = separate residual / update kernels
   int mode;  // 0 auto (list when <= half of the interior has depth), 1 always dense scan, 2 always list
@@ -709,6 +752,7 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
   if (m->fine_k < 0 || m->fine_k > kFineKMax) m->fine_k = 32;
   m->fine_k_cfg = m->fine_k;
   m->fine_fault = getenv("ODO_LM_FINE_FAULT") ? 1 : 0;
+  m->fine_home = next_home_xcd(ctx->device);
   m->fine_wait = getenv("ODO_LM_FINE_WAIT_US") ? (unsigned)(100L * atol(getenv("ODO_LM_FINE_WAIT_US"))) : 0u;
   HIP_OK(hipMalloc((void**)&m->d_xbuf, sizeof(unsigned long long) * kFineXbufWords));
   HIP_OK(hipMemset(m->d_xbuf, 0, sizeof(unsigned long long) * kFineXbufWords));   // tag 0: no Solve has token 0
@@ -1235,6 +1279,7 @@ static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_de
     a.span = lm_span_slot(m, jb.launches, false);
     a.fine_epoch = lm_fine_next_epoch(m);
     a.fine_wait = m->fine_wait;
+    a.fine_home = m->fine_home;
     if (m->robust == 2)
       hipLaunchKernelGGL(lm_fine_tdist_kernel, dim3(8 * m->fine_k), dim3(kFineThreads), 0, s, a, m->fine_k, m->d_xbuf, m->fine_fault, fine_lo);
     else
@@ -1535,6 +1580,7 @@ static void lm_fill_step_args(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* c
   a.xbuf = m->d_xbuf;
   a.fine_epoch = (fine_lo < min_level) ? lm_fine_next_epoch(m) : 0u;   // (a sequence that only carries its state exchanges nothing)
   a.fine_wait = m->fine_wait;
+  a.fine_home = m->fine_home;
   int above = 0;   // evaluations the coarse and the persistent launch can take
   for (int l = fine_lo; l < m->n_levels; l++) above += m->max_iters[l] > 0 ? m->max_iters[l] : 0;
   *grid_out = grid;
@@ -1673,7 +1719,8 @@ static int lm_batch_begin(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
   jb.fine_used = any_fine != 0;
   if (any_fine) {
     hipLaunchKernelGGL(lm_fine_kernel_batch, dim3(8 * fine_k * per_xcd), dim3(kFineThreads), 0, s, (const StepArgs*)d_table, n, fine_k,
-                       jb.seq, (jb.seq == 0) ? 1 : 0, lm_span_slot(lms[0], jb.launches, false), lms[0]->fine_fault);
+                       jb.seq, (jb.seq == 0) ? 1 : 0, lm_span_slot(lms[0], jb.launches, false), lms[0]->fine_fault,
+                       lms[0]->fine_home >= 0 ? device_xcc_ids(cx->device) : XccIds{{-1, -1, -1, -1, -1, -1, -1, -1}});
     jb.seq++; jb.launches++;
   }
   jb.active = 1;
@@ -2201,6 +2248,7 @@ struct odo_depth {
   int persist_bails, persist_strikes, persist_clean, persist_offs;
   int persist_fault;              // test hook (ODO_DEPTH_PERSIST_FAULT)
   unsigned persist_epoch, persist_wait;
+  int persist_home;               // the XCD its persistent launch runs on (next_home_xcd)
   unsigned long long* d_xbuf;     // kDpXbufWords
   int* d_gave_up;
   // odo_depth_prepare_left_dev: blur(left) + selection enqueued ahead of the call on another stream
@@ -2244,6 +2292,7 @@ extern "C" int odo_depth_create(odo_ctx* ctx, float grad_th, float ssd_th, float
   d->run_ahead = getenv("ODO_RUN_AHEAD") ? atoi(getenv("ODO_RUN_AHEAD")) : 3;
   d->persist = d->persist_cfg = getenv("ODO_DEPTH_NO_PERSIST") ? 0 : 1;
   d->persist_fault = getenv("ODO_DEPTH_PERSIST_FAULT") ? 1 : 0;
+  d->persist_home = next_home_xcd(ctx->device);
   d->persist_wait = getenv("ODO_LM_FINE_WAIT_US") ? (unsigned)(100L * atol(getenv("ODO_LM_FINE_WAIT_US"))) : 0u;
   HIP_OK(hipMalloc((void**)&d->d_xbuf, sizeof(unsigned long long) * kDpXbufWords));
   HIP_OK(hipMemset(d->d_xbuf, 0, sizeof(unsigned long long) * kDpXbufWords));
@@ -2391,7 +2440,7 @@ static int depth_job_persistent(odo_depth* d, DepthJob* j) {
   a.tx = d->baseline; a.fx = d->K.f0; a.huber_delta = d->huber_delta; a.lambda0 = d->lambda; a.precision = d->precision;
   a.max_iters = d->max_iters; a.photo_th = d->photo_th; a.min_depth = d->min_depth; a.max_depth = d->max_depth;
   a.val = j->val; a.dep = j->dep; a.counts = d->d_counts; a.xbuf = d->d_xbuf; a.epoch = d->persist_epoch; a.wait_ticks = d->persist_wait;
-  a.gave_up = d->d_gave_up; a.fault = d->persist_fault;
+  a.gave_up = d->d_gave_up; a.fault = d->persist_fault; a.home = d->persist_home;
   static unsigned long long* dbg_buf = [] {
     unsigned long long* p = nullptr;
     if (getenv("ODO_DEPTH_STAMPS") && hipHostMalloc((void**)&p, 256, hipHostMallocMapped) == hipSuccess) memset(p, 0, 256);
@@ -2466,6 +2515,7 @@ static int depth_finish(odo_depth* d, bool full_sync = true) {
     // the persistent depth-LM launch gave up (its workgroups could not all be resident within the wait bound): the caller runs the
     // job again — on the step launches, which need no co-residency (depth_run_checked / tracker_job_run)
     d->persist_bails++;
+    if (getenv("ODO_LOG_GIVEUPS")) fprintf(stderr, "[odometry_hip] depth-LM persistent launch gave up (launch epoch %u, %d clean jobs before)\n", d->persist_epoch, d->persist_clean);
     if (fine_note_giveup(&d->persist_strikes, &d->persist_clean, &d->persist_offs)) d->persist = 0;
     d->persist_off_once = 1;
     return 2;

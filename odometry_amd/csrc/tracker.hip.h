@@ -572,6 +572,7 @@ extern "C" int odo_tracker_outputs(const odo_tracker* t, const uint8_t** val, co
   return 0;
 }
 extern "C" odo_lm* odo_tracker_lm(odo_tracker* t) { return t ? t->lm : nullptr; }
+extern "C" odo_depth* odo_tracker_depth(odo_tracker* t) { return t ? t->depth : nullptr; }
 extern "C" odo_ctx* odo_tracker_ctx(odo_tracker* t) { return t ? t->ctx_a : nullptr; }
 
 // bench.py roofline leg: `reps` launches of the evaluation kernel (residual / normal-equation pass, without the LM

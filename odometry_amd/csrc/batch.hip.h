@@ -533,6 +533,7 @@ extern "C" int odo_tracker_batch_quiesce(odo_tracker_batch* b) {
   if (!b) return fail("NULL batch tracker");
   HIP_OK(hipSetDevice(b->ctx_a->device));
   if (batch_quiesce(b)) return -1;
+  if (b->ctx_a->lm_batch_job) b->ctx_a->lm_batch_job->active = 0;   // the batched Solve started early for the next lock step is dropped
   for (int i = 0; i < b->S; i++) {
     b->lm[i]->job.active = 0;
     b->hint_next[i] = b->hint_next_right[i] = b->prefetched[i] = nullptr;

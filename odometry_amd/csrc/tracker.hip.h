@@ -646,6 +646,17 @@ extern "C" int odo_lm_time_eval_batch(int n, odo_lm* const* lms, const odo_pyr* 
   HIP_OK(hipSetDevice(cx->device));
   DenseBatchItem* h = nullptr;
   DenseBatchItem* d = nullptr;
+  std::vector<hipEvent_t> ev;
+  double* d_acc = nullptr;
+  struct Cleanup {   // every early return below (HIP_OK) gives the tables and the events back
+    DenseBatchItem*& h; DenseBatchItem*& d; std::vector<hipEvent_t>& ev; double*& d_acc;
+    ~Cleanup() {
+      for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+      if (d_acc) (void)hipFree(d_acc);
+      if (d) (void)hipFree(d);
+      if (h) (void)hipHostFree(h);
+    }
+  } cleanup{h, d, ev, d_acc};
   HIP_OK(hipHostMalloc((void**)&h, sizeof(DenseBatchItem) * (size_t)n, hipHostMallocDefault));
   HIP_OK(hipMalloc((void**)&d, sizeof(DenseBatchItem) * (size_t)n));
   int max_nblk = 1;
@@ -667,7 +678,7 @@ extern "C" int odo_lm_time_eval_batch(int n, odo_lm* const* lms, const odo_pyr* 
     hipLaunchKernelGGL(lm_force_state_kernel, dim3(1), dim3(64), 0, s, m->d_state, m->d_init, level);
   }
   HIP_OK(hipMemcpyAsync(d, h, sizeof(DenseBatchItem) * (size_t)n, hipMemcpyHostToDevice, s));
-  std::vector<hipEvent_t> ev(2 * (size_t)reps);
+  ev.assign(2 * (size_t)reps, nullptr);
   for (auto& e : ev) HIP_OK(hipEventCreate(&e));
   for (int w = 0; w < 3; w++) launch_dense_eval_batch(d, n, max_nblk, s, nullptr, nullptr, lms[0]->dense_plain_div);
   for (int i = 0; i < reps; i++) launch_dense_eval_batch(d, n, max_nblk, s, ev[2 * i], ev[2 * i + 1], lms[0]->dense_plain_div);
@@ -679,10 +690,8 @@ extern "C" int odo_lm_time_eval_batch(int n, odo_lm* const* lms, const odo_pyr* 
     HIP_OK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
     sum += ms; if (ms < mn) mn = ms;
   }
-  for (auto& e : ev) (void)hipEventDestroy(e);
   // residual counts: fold each stream's partial rows (column 28)
   int npts = 0;
-  double* d_acc = nullptr;
   HIP_OK(hipMalloc((void**)&d_acc, sizeof(double) * ODO_NACC));
   for (int i = 0; i < n; i++) {
     hipLaunchKernelGGL(lm_sum_partials_kernel, dim3(1), dim3(256), 0, s, lms[i]->d_partials, h[i].L.nblk, d_acc);
@@ -691,7 +700,6 @@ extern "C" int odo_lm_time_eval_batch(int n, odo_lm* const* lms, const odo_pyr* 
     HIP_OK(hipStreamSynchronize(s));
     npts += (int)acc[28];
   }
-  (void)hipFree(d_acc); (void)hipFree(d); (void)hipHostFree(h);
   if (mean_us) *mean_us = (float)(sum / reps * 1000.0);
   if (min_us) *min_us = (float)(mn * 1000.0);
   if (algorithmic_bytes) *algorithmic_bytes = bytes;

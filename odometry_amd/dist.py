@@ -53,13 +53,20 @@ class PoseGatherer:
                                  "from the shard sizes, never from how many rows a rank happens to push)")
             import torch
             import torch.distributed as dist
-            t = torch.tensor([int(n_local_frames), -1 if n_max_frames is None else int(n_max_frames)], dtype=torch.int64)
+            # one all_reduce(MAX) carries the agreement AND its check: [local frames, stated maximum, -stated maximum] — the second
+            # and third entries come back as max and -min of what the ranks stated (a rank that states nothing contributes the
+            # neutral -2^62), so EVERY rank sees a disagreement and every rank raises: none is left waiting in the next collective
+            none = -(1 << 62)
+            stated = none if n_max_frames is None else int(n_max_frames)
+            t = torch.tensor([int(n_local_frames), stated, none if n_max_frames is None else -int(n_max_frames)], dtype=torch.int64)
             if device is not None:
                 t = t.to(device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            agreed = int(max(t[0].item(), t[1].item()))
-            if n_max_frames is not None and int(n_max_frames) != agreed:
-                raise ValueError(f"PoseGatherer: n_max_frames = {n_max_frames} on this rank, but the ranks agree on {agreed}")
+            hi, lo = int(t[1].item()), -int(t[2].item())
+            agreed = int(max(t[0].item(), hi))
+            if hi != none and (hi != lo or hi < int(t[0].item())):
+                raise ValueError(f"PoseGatherer: the ranks state different n_max_frames ({lo} .. {hi}; largest shard {int(t[0].item())}; "
+                                 f"this rank: {n_max_frames})")
             n_max_frames = agreed
         elif n_max_frames is None:
             n_max_frames = n_local_frames

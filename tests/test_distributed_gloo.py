@@ -174,3 +174,43 @@ def test_pose_gather_mixed_n_max_and_large_ids_world2_gloo():
             assert ids[r].shape == (n_local, 2)
             assert ids[r][:, 0].tolist() == [(1 << 24) + 1 + r] * n_local            # not representable in float32
             assert ids[r][:, 1].tolist() == [(1 << 30) + f for f in range(n_local)]
+
+
+def _worker_disagree(rank, world, port, q):
+    """The ranks state DIFFERENT n_max_frames: every rank must raise — none may carry on into a collective the other never joins."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    err = None
+    try:
+        PoseGatherer(world, 4, n_local_frames=3, n_max_frames=[5, 7][rank])
+    except ValueError as e:
+        err = str(e)
+    err2 = None
+    try:
+        PoseGatherer(world, 4, n_local_frames=[9, 3][rank], n_max_frames=5)   # smaller than the largest shard: an error everywhere too
+    except ValueError as e:
+        err2 = str(e)
+    dist.barrier()        # both ranks are still in step
+    q.put((rank, err, err2))
+    dist.destroy_process_group()
+
+
+def test_disagreeing_n_max_frames_raises_on_every_rank():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_disagree, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, err, err2 = q.get(timeout=120)
+        res[rank] = (err, err2)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert res[r][0] and "different n_max_frames" in res[r][0]
+        assert res[r][1] and "different n_max_frames" in res[r][1]

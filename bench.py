@@ -1148,6 +1148,15 @@ def main():
                    ms_per_step=round(elapsed / (args.steps * max(max(per_rank) // max(args.steps, 1), 1)) * 1e3, 4),
                    higher_is_better=True, scaling="strong" if args.sequences > 0 else "weak", vs_baseline=None, dtype="f32",
                    data="synthetic",
+                   drive=args.drive, event_sample=args.event_sample if ev_in_timed else 0,
+                   note=("workload since round 3: drive 'natural' (1 / f^1.55 textures, on which the reference's keyframe policy keeps "
+                         "track) — NOT comparable with BENCH_r01 / r02, which ran the 'corridor' drive (reported beside this line as "
+                         "stress_drive); span sampling of every %dth LM launch (two device atomics per sampled block) is ON inside the "
+                         "timed region (--event-sample 0 switches it off: within 1 %%). Parity: pose / mask / disparity delta = 0 against "
+                         "oracle/odo_oracle.c, a line-cited restatement of the reference; pinned to the reference's own code: the SSD tree "
+                         "+ epipolar scan, GetCxLevel, the camera pyramid's intrinsic rule, both LM drivers' schedules; everything else "
+                         "is parity-unpinned (no Eigen / OpenCV in this image); expected distance to a real reference binary 1e-5 ... 5e-3 "
+                         "on the SE(3) log-norm (profiles/r02_oracle_sensitivity*.json)" % args.event_sample),
                    config=dict(workload="synthetic KITTI-shaped stereo sequence (configs[1]: a forward drive, passes over "
                                         "unique_frames frames, the tracker re-initialised on frame 0 at each pass), 1241x376, "
                                         "4 levels, semi-dense, runner params, one sequence per GPU; drive '%s' (odometry_amd/synth.py)" % args.drive,

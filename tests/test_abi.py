@@ -96,3 +96,10 @@ def test_kernel_register_budgets():
     assert len(fine) == 2, fine      # the single tracker's and the batched tracker's
     for k, v in fine.items():
         assert v[0] <= (224 if "batch" in k else 208), (k, v)
+    # depth_lm_persistent_kernel: its 80 workgroups of 512 threads wait for each other, so ALL must be resident on the 32 CUs of one
+    # XCD at once: 640 waves / 128 SIMDs = 5 waves per SIMD -> at most 512 / 5 = 102 -> 96 VGPRs (allocation granule 8)
+    dp = [v for k, v in kernels.items() if "depth_lm_persistent_kernel" in k]
+    assert len(dp) == 1 and dp[0][0] <= 96, dp
+    # lm_fine_tdist_kernel (t-distribution weights, configs[0]'s parameter set) is a build of its own so that the scale loop's
+    # registers do not count against lm_fine_kernel's budget
+    assert any("lm_fine_tdist_kernel" in k for k in kernels)

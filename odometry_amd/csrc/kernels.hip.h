@@ -1394,25 +1394,35 @@ constexpr int kCoarseLdsBytes = 2 * RowBuf<kLmBlock>::kBytes;  // [2][15][288] f
 constexpr int kCoarseMaxPoints = 1024;  // levels with more points go to the multi-block step kernel (measured: a 512-thread
                                         // workgroup walking ~2000 points four per thread is no faster than seven blocks)
 
-// ComputeScaleNaive inside one workgroup (ref: src/lm_optimizer.cpp:338-358): every thread of the workgroup calls it with its
-// point's squared residual (valid = false: no residual). part: [2][waves] doubles, cnt: [waves] ints of LDS.
-__device__ __forceinline__ float coarse_tdist_sigma(double (*part)[kCoarseBlock / kWave], int* cnt, float e2, bool valid) {
+// ComputeScaleNaive inside one workgroup (ref: src/lm_optimizer.cpp:338-358): every thread of the workgroup calls it with the squared
+// residuals of its points — one per round of the level (nr = 1 or 2 rounds of 512 points; valid = false: no residual). Chunk = 64
+// consecutive points = one wave of one round: chunk (2 rd + half) * 4 + (wave & 3) = rd * 8 + wave, summed in the one order
+// (wave_sum64: chunks without points are +0). part: [2][16] doubles, cnt: [16] ints of LDS. One workgroup barrier per pass.
+constexpr int kCoarseRounds = kCoarseMaxPoints / kCoarseBlock;   // 2
+constexpr int kCoarseChunks = kCoarseRounds * (kCoarseBlock / kWave);   // 16
+__device__ __forceinline__ float coarse_tdist_sigma(double (*part)[kCoarseChunks], int* cnt, const float e2[kCoarseRounds],
+                                                    const bool valid[kCoarseRounds], int nr) {
   constexpr int kW = kCoarseBlock / kWave;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int my_cnt = __popcll(__ballot(valid));
+  int my_cnt[kCoarseRounds];
+#pragma unroll
+  for (int rd = 0; rd < kCoarseRounds; rd++) my_cnt[rd] = __popcll(__ballot(rd < nr && valid[rd]));
   float sigma = 5.0f;
   int n_total = 0;
   for (int pass = 0; pass < kTdistMaxPasses; pass++) {
-    const double ws = wave_sum64(valid ? (double)tdist_term(e2, sigma * sigma) : 0.0);
-    if (lane == 0) { part[pass & 1][wv] = ws; if (pass == 0) cnt[wv] = my_cnt; }
+#pragma unroll
+    for (int rd = 0; rd < kCoarseRounds; rd++) {
+      const double ws = wave_sum64((rd < nr && valid[rd]) ? (double)tdist_term(e2[rd], sigma * sigma) : 0.0);
+      if (lane == 0) { part[pass & 1][rd * kW + wv] = ws; if (pass == 0) cnt[rd * kW + wv] = my_cnt[rd]; }
+    }
     __syncthreads();   // (the other parity is still being read by nobody: a wave passes this barrier only after its reads of pass - 1)
     if (pass == 0) {
       int tot = 0;
 #pragma unroll
-      for (int i = 0; i < kW; i++) tot += cnt[i];
+      for (int i = 0; i < kCoarseChunks; i++) tot += cnt[i];
       n_total = tot;
     }
-    const double total = wave_sum64(lane < kW ? part[pass & 1][lane] : 0.0);
+    const double total = wave_sum64(lane < kCoarseChunks ? part[pass & 1][lane] : 0.0);
     const float nxt = (n_total > 0) ? tdist_next_sigma(total, n_total) : sigma;
     const bool done = (n_total == 0) || tdist_converged(nxt, sigma);
     sigma = nxt;
@@ -1453,8 +1463,8 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
   constexpr int kS = 8;
   constexpr int kVbMax = (kCoarseMaxPoints + kLmBlock - 1) / kLmBlock;
   __shared__ double part_sh[kVbMax][32];
-  __shared__ double sc_part[2][kCoarseBlock / kWave];   // t-distribution scale passes: the waves' chunk sums, by pass parity
-  __shared__ int sc_cnt[kCoarseBlock / kWave];
+  __shared__ double sc_part[2][kCoarseChunks];   // t-distribution scale passes: the chunk sums (wave x round), by pass parity
+  __shared__ int sc_cnt[kCoarseChunks];
   const int tl = threadIdx.x & (kLmBlock - 1), half = threadIdx.x >> 8;
   float* rows_sh = (float*)red_sh + half * (kRowFloats * RowBuf<kLmBlock>::W);  // [2][15][256 + 8] floats
   const int my_q = tl / kS, my_s = tl % kS;
@@ -1471,24 +1481,44 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
     const int nvb = L.nblk;  // = ceil(n / 256), at least 1 (lm_grid_for)
     // (Keeping each thread's points in registers across iterations and staging the 29 KB level image in LDS was
     // measured: no faster. With 8 waves on one CU the evaluation is VALU-issue bound, not latency bound.)
-    for (int vb0 = 0; vb0 < nvb; vb0 += 2) {  // one round per 512 points (kCoarseMaxPoints: two)
+    // t-distribution weights (ref: src/lm_optimizer.cpp:257-261,338-358) need the scale of ALL residuals of the evaluation before any
+    // weight: the residuals of every round are evaluated first and kept (with their Jacobian rows) in registers, then the scale
+    // iteration runs over them (coarse_tdist_sigma), then the rounds go through the row sums as usual
+    float td_r[kCoarseRounds] = {0.0f, 0.0f}, td_J[kCoarseRounds][6] = {{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}};
+    bool td_valid[kCoarseRounds] = {false, false};
+    float td_scale_sqr = 1.0f;
+    if (a.robust == 2) {
+      float e2[kCoarseRounds];
+#pragma unroll
+      for (int rd = 0; rd < kCoarseRounds; rd++) {
+        const int vb = 2 * rd + half, idx = vb * kLmBlock + tl;
+        if (vb < nvb && idx < L.n) {
+          const PointK p = load_point(L.pl, idx);
+          td_valid[rd] = point_residual(p, T, L.k, L.I2, L.rows, L.cols, &td_r[rd], td_J[rd]);
+        }
+        e2[rd] = td_r[rd] * td_r[rd];
+      }
+      const float sg = coarse_tdist_sigma(sc_part, sc_cnt, e2, td_valid, (nvb + 1) / 2);
+      td_scale_sqr = sg * sg;
+    }
+#pragma unroll
+    for (int vb0 = 0; vb0 < 2 * kCoarseRounds; vb0 += 2) {  // one round per 512 points (kCoarseMaxPoints: two)
+      if (vb0 >= nvb) break;
       const int vb = vb0 + half;
       const int idx = vb * kLmBlock + tl;
       float r = 0.0f, w = 0.0f, J[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
       bool valid = false;
-      if (vb < nvb && idx < L.n) {
+      if (a.robust == 2) {
+        r = td_r[vb0 / 2]; valid = td_valid[vb0 / 2];
+#pragma unroll
+        for (int i = 0; i < 6; i++) J[i] = td_J[vb0 / 2][i];
+        if (valid) w = robust_weight(r, 2, a.huber_delta, td_scale_sqr);
+      } else if (vb < nvb && idx < L.n) {
         const PointK p = load_point(L.pl, idx);
         if (point_residual(p, T, L.k, L.I2, L.rows, L.cols, &r, J)) {
           w = robust_weight(r, a.robust, a.huber_delta, 1.0f);
           valid = true;
         }
-      }
-      if (a.robust == 2) {
-        // t-distribution weights (ref: src/lm_optimizer.cpp:257-261,338-358): the scale iteration over the level's residuals, one
-        // workgroup barrier per pass; chunk = wave (the host sends this kernel only levels of ONE round in this mode: nvb <= 2),
-        // summed in the one order (wave_sum64: the chunks of waves without points are +0)
-        const float sg = coarse_tdist_sigma(sc_part, sc_cnt, r * r, valid);
-        if (valid) w = robust_weight(r, 2, a.huber_delta, sg * sg);
       }
       if (vb0 > 0) __syncthreads();  // the previous round's rows have been consumed
       rows_store(rows_sh, RowBuf<kLmBlock>::W, tl, J, w, r, valid);

@@ -1106,7 +1106,7 @@ static inline int lm_list_blocks(int npts) {
 // a level of two rounds costs less as four virtual blocks on four CUs. Every kernel sums a level in the same order, so where a
 // level runs does not show in the result. The persistent launch pays when its workgroups can hold a level's points in registers
 // (<= 2 virtual blocks each); a level of more blocks (the point-list levels of a 1080p stream: 115 and 160) is better spread over
-// 160 CUs by the step launches. t-distribution weights (robust == 2): the coarse launch always stays at one round.
+// 160 CUs by the step launches. t-distribution weights (robust == 2): the coarse launch takes every level it can hold (1 024 points).
 static void lm_plan_levels(const odo_lm* m, int stop, int fine_k, int* min_level_out, int* fine_lo_out) {
   static const int coarse_env = getenv("ODO_COARSE_MAX") ? atoi(getenv("ODO_COARSE_MAX")) : -1;
   auto fits = [&](int l) { const int nblk = lm_list_blocks(m->npts[l]); return nblk <= 2 * fine_k && m->npts[l] <= nblk * kLmBlock; };
@@ -1115,7 +1115,9 @@ static void lm_plan_levels(const odo_lm* m, int stop, int fine_k, int* min_level
     const bool want_fine = fine_k > 0 && pass == 0;
     int coarse_max = coarse_env >= 0 ? (coarse_env < kCoarseMaxPoints ? coarse_env : kCoarseMaxPoints)
                                      : (want_fine ? kCoarseBlock : kCoarseMaxPoints);
-    if (m->robust == 2 && coarse_max > kCoarseBlock) coarse_max = kCoarseBlock;
+    // (t-distribution weights: every scale pass is a reduction over the level — one barrier inside the coarse launch's workgroup,
+    //  a trip through L2 between the persistent launch's: the coarse launch takes what it can hold, both of its rounds)
+    if (m->robust == 2 && coarse_env < 0) coarse_max = kCoarseMaxPoints;
     min_level = m->n_levels;
     while (min_level > stop && m->npts[min_level - 1] <= coarse_max) min_level--;
     if (!m->coarse) min_level = m->n_levels;

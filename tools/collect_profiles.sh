@@ -13,7 +13,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 rm -rf $OUT   # (gpurun MERGES what a call writes into the caller's gpurun_out/: use a fresh tag per collection there, or delete
 mkdir -p $OUT  #  the local copy first — rocprofv3 names its files by PID, and PIDs repeat from box to box)
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $GRAFT_REPO_ROOT/bench.py --cpu-frames 0 --extras dense,disparity,single,batched"
+BENCH="python3 $GRAFT_REPO_ROOT/bench.py --cpu-frames 0 --extras dense,disparity,single,batched,saturated"
 timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH --steps 1000 --warmup 50 > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err < /dev/null
 # 1b. the driver's own short run (python bench.py --steps 20 --warmup 5), side legs off: the averages bench.py's roofline line must agree with
 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats20 -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-frames 0 --no-extras --steps 20 --warmup 5 > $OUT/bench_profiled_steps20.json 2> $OUT/bench_profiled_steps20.err < /dev/null

@@ -345,6 +345,13 @@ int odo_tracker_time_residual(odo_tracker* t, int level, int reps, float* mean_u
 /* Diagnostics: host-clock averages per tracked frame since the last call, microseconds:
  * {track() call, Solve on stream A, stream-B job on the helper thread, wait for the helper}. */
 int odo_tracker_timing(odo_tracker* t, double out[4]);
+/* Chained Solves: with the next frame announced, its Solve is queued BEHIND this frame's before this frame's result exists —
+ * same keyframe, initial pose = this Solve's result taken on the device (what Reset hands it, ref: run_odometry_kitti_offline.cpp:
+ * 261,268), guarded on the device by the runner's keyframe test (ref: :253-258: a promoted or failed frame makes every launch of
+ * the chained Solve return at once). The host's own test decides what counts; results are those of the unchained order.
+ * Opt-in (ODO_CHAIN_SOLVE=1): it closes the GPU's idle gap between two Solves and does not change the frame rate. *adopted = chained Solves that became the next Solve, *wasted = chained Solves that ran for
+ * nothing because the two keyframe tests disagreed (an ulp of atan2f: expected never). */
+int odo_tracker_chain_stats(const odo_tracker* t, long* adopted, long* wasted);
 odo_lm* odo_tracker_lm(odo_tracker* t);
 odo_depth* odo_tracker_depth(odo_tracker* t);   /* its depth estimator (odo_depth_persistent_stats, odo_depth_report) */
 odo_ctx* odo_tracker_ctx(odo_tracker* t);

@@ -606,6 +606,12 @@ class Tracker:
         L.check(self.lib.odo_lm_persistent_stats(lm, C.byref(k), C.byref(f)), "odo_lm_persistent_stats")
         return k.value, f.value
 
+    def chain_stats(self):
+        """(Solves that started on the device behind the Solve before them, chained Solves that ran for nothing)"""
+        a, b = C.c_long(0), C.c_long(0)
+        L.check(self.lib.odo_tracker_chain_stats(self.h, C.byref(a), C.byref(b)), "odo_tracker_chain_stats")
+        return a.value, b.value
+
     def depth_persistent_stats(self):
         """(1 while the depth LM runs as one persistent launch, ComputeDepth jobs run again on the step launches)"""
         d = C.c_void_p(self.lib.odo_tracker_depth(self.h))

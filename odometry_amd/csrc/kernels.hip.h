@@ -1009,6 +1009,15 @@ struct StepArgs {
   unsigned fine_epoch;       // tags of the exchange: (fine_epoch << 8) + evaluation; the host never repeats an epoch on a buffer it has not cleared
   unsigned fine_wait;        // bound of one wait of the persistent launch in wall-clock ticks (0: kFineWaitTicks)
   int fine_home;             // the XCC id of the XCD this optimiser's persistent launch runs on (fine_on_home; < 0: class 0 wherever it lands)
+  // Chained Solves (the tracker's next Solve queued BEHIND the one in flight, before its result exists: lm_chain_begin). The launch
+  // that finishes a Solve leaves its pose and a guard word in device memory; a chained Solve starts from that pose — what Reset
+  // would have handed it (ref: run_odometry_kitti_offline.cpp:261,268) — provided the guard says the Solve it follows succeeded and
+  // the runner's keyframe test (ref: :253-258) keeps the keyframe; otherwise every launch of it returns at once.
+  float* chain_pose;         // [16] column-major pose of the last finished Solve (device memory)
+  int* chain_guard;          // (token << 2) | 2 (promote) | 1 (succeeded) of the last finished Solve
+  int chain_in_token;        // != 0: this Solve is chained behind the Solve with that token
+  int chain_out;             // 1: the finishing launch writes chain_pose / chain_guard (kf_rule: six weights + the threshold)
+  float kf_rule[7];
   // hand-over to the unfused pipeline (dense fine levels): the device stops walking the pyramid below stop_level, reports the
   // Solve "finished" there and leaves its state in final_state, from which the host carries on level by level
   int stop_level;       // 0: the fused pipeline covers every level
@@ -1216,12 +1225,14 @@ __device__ __forceinline__ void lm_fused_prologue(const LmState* __restrict__ st
                                                   const StepLevel* lv, int n_levels, float lambda0, float precision,
                                                   LmState& s_sh, double* fold_sh, double* acc_sh,
                                                   LmTraceRow* __restrict__ trace, float* __restrict__ cost_stat, bool publisher,
-                                                  const float* init /* non-null: first launch of a Solve */, int stop_level = 0) {
+                                                  const float* init /* non-null: first launch of a Solve */, int stop_level = 0,
+                                                  const float* __restrict__ init_dev = nullptr /* a chained Solve: the pose the Solve before it left in device memory */) {
   const int t = threadIdx.x;
   if (init) {
     if (t == 0) {
       float m[16];
-      for (int i = 0; i < 16; i++) m[i] = init[i];
+      if (init_dev) { for (int i = 0; i < 16; i++) m[i] = init_dev[i]; }
+      else { for (int i = 0; i < 16; i++) m[i] = init[i]; }
       lm_begin_solve(&s_sh, m);
       s_sh.level = -1; s_sh.iter = 0; s_sh.lambda = 0.0f; s_sh.err_last = 1e+10f;
       for (int i = 0; i < 16; i++) s_sh.T[i] = m[i];
@@ -1268,8 +1279,16 @@ __device__ __forceinline__ void lm_fused_prologue(const LmState* __restrict__ st
 // End of a Solve: affine_ = current_estimate.matrix() (ref: src/lm_optimizer.cpp:158) or the pseudo-identity on failure
 // (ref: :48-52,60-65), status, counters and cost statistics into host-mapped memory, then the completion word.
 // One thread. out: 16 pose (column-major), status, n_evals, 8 evaluations per level, 16 cost statistics.
+// chain (optional): the arguments of the Solve, for the hand-over to a chained Solve (chain_out); word 43 of the result block then
+// tells the host what the guard says: (token << 2) | 1 = a Solve chained behind this one runs, | 2 = its launches return at once
+// (failure, or the keyframe test fires).
+struct ChainOut { float* pose; int* guard; int on; float w0, w1, w2, w3, w4, w5, th; };
+__device__ __forceinline__ ChainOut chain_out_of(const StepArgs& a) {   // (by value, field by field: the address of a by-value kernel
+  return ChainOut{a.chain_pose, a.chain_guard, a.chain_out, a.kf_rule[0], a.kf_rule[1], a.kf_rule[2], a.kf_rule[3], a.kf_rule[4],   // argument would mirror all of it in scratch memory)
+                  a.kf_rule[5], a.kf_rule[6]};
+}
 __device__ __forceinline__ void lm_write_result(const LmState& s, const float* cost_stat, float* __restrict__ out,
-                                                int* __restrict__ done_flag, int token) {
+                                                int* __restrict__ done_flag, int token, const ChainOut chain = ChainOut{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0}) {
   float m[16];
   if (s.status == 0) {
     se3_to_colmajor(s.cur, m);
@@ -1282,21 +1301,38 @@ __device__ __forceinline__ void lm_write_result(const LmState& s, const float* c
   out[17] = (float)s.n_evals;
   for (int i = 0; i < 8; i++) out[18 + i] = (float)s.iters_level[i];
   for (int i = 0; i < 16; i++) out[26 + i] = cost_stat ? cost_stat[i] : 0.0f;
-  __hip_atomic_store(done_flag, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(done_flag, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // the host has the result from here on
+  if (chain.on) {
+    // ... and the Solve queued behind this launch gets its start: pose, then the guard (the launch ends behind these stores). The
+    // verdict goes to the host as well, tagged with the token (word 43 of the result block, written last).
+    for (int i = 0; i < 16; i++) chain.pose[i] = m[i];
+    const float w[6] = {chain.w0, chain.w1, chain.w2, chain.w3, chain.w4, chain.w5};
+    // (a bound, not the test itself — the host's motion_magnitude decides, ref: :258: within ODO_MOTION_SLACK of the threshold the
+    //  chained Solve is told to return, and the host starts the next Solve the ordinary way if its own test keeps the keyframe)
+    const bool promote = (s.status != 0) || !(motion_magnitude_approx(m, w) < chain.th - ODO_MOTION_SLACK);
+    __hip_atomic_store(chain.guard, (token << 2) | (promote ? 2 : 0) | 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((int*)out + 43, (token << 2) | (promote ? 2 : 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+// A chained Solve's launches look at the guard first (every thread; the word is final: the Solve it belongs to has ended).
+__device__ __forceinline__ bool lm_chain_skip(const StepArgs& a) {
+  if (a.chain_in_token == 0) return false;
+  return __hip_atomic_load(a.chain_guard, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ((a.chain_in_token << 2) | 1);
 }
 
 constexpr int kProgSeqBits = 12;  // progress word = (token << 12) | launches finished: stale launches of an earlier Solve
                                   // that drain after the host has moved on cannot be mistaken for this Solve's progress
 __device__ __forceinline__ void lm_fused_publish(LmState& s_sh, LmState* __restrict__ st_out, int* __restrict__ host_prog,
                                                  int seq, int token, const float* cost_stat, float* __restrict__ out,
-                                                 int* __restrict__ done_flag, LmState* __restrict__ final_state = nullptr) {
+                                                 int* __restrict__ done_flag, LmState* __restrict__ final_state = nullptr,
+                                                 const ChainOut chain = ChainOut{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0}) {
   const int t = threadIdx.x;
   if (t < 64) {
     if (t < (int)(sizeof(LmState) / sizeof(int))) ((int*)st_out)[t] = ((const int*)&s_sh)[t];
     if (final_state && s_sh.finished && t < (int)(sizeof(LmState) / sizeof(int))) ((int*)final_state)[t] = ((const int*)&s_sh)[t];
     if (t == 0) {
       // the launch that learns that every level is done hands the result to the host itself (no finalize launch)
-      if (s_sh.finished && out) lm_write_result(s_sh, cost_stat, out, done_flag, token);
+      if (s_sh.finished && out) lm_write_result(s_sh, cost_stat, out, done_flag, token, chain);
       if (host_prog) {
         // host-mapped progress: [1] = token once every level is done (the host stops issuing launches),
         // [0] = number of launches of this Solve that have finished
@@ -1311,6 +1347,7 @@ __device__ __forceinline__ void lm_fused_publish(LmState& s_sh, LmState* __restr
 // issues identical launches until the device reports that the Solve is finished; the grid is sized for the largest
 // level and the blocks a coarser level does not need stop after the (redundant, parallel) prologue.
 __device__ __forceinline__ void lm_step_body(const StepArgs& a, const StepLaunch& q) {
+  if (lm_chain_skip(a)) return;
   __builtin_amdgcn_s_setprio(3);  // see lm_coarse_kernel
   lm_span_begin(q.span);
   __shared__ LmState s_sh;
@@ -1321,7 +1358,7 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const StepLaunch
   const bool publisher = (blockIdx.x == gridDim.x - 1);
   if (a.dbg && publisher && threadIdx.x == 0 && q.seq < 56) a.dbg[16 + 2 * q.seq] = wall_clock64();  // diagnostic timeline
   lm_fused_prologue(q.st_in, q.part_in, a.lv, a.n_levels, a.lambda0, a.precision, s_sh, fold_sh, acc_sh, a.trace, a.cost_stat,
-                    publisher, q.first_of_solve ? a.init : nullptr, a.stop_level);
+                    publisher, q.first_of_solve ? a.init : nullptr, a.stop_level, a.chain_in_token ? a.chain_pose : nullptr);
   const bool run = (s_sh.active != 0 && s_sh.status == 0);  // block-uniform
   const int lvl = run ? s_sh.level : 0;
   const StepLevel& L = a.lv[lvl];
@@ -1358,7 +1395,7 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const StepLaunch
   if (publisher) {
     if (threadIdx.x == 0 && run) { s_sh.pending = 1; s_sh.pending_nblk = L.nblk; }
     __syncthreads();
-    lm_fused_publish(s_sh, q.st_out, a.host_prog, q.seq, a.token, a.cost_stat, a.out, a.done_flag, a.final_state);
+    lm_fused_publish(s_sh, q.st_out, a.host_prog, q.seq, a.token, a.cost_stat, a.out, a.done_flag, a.final_state, chain_out_of(a));
     if (a.dbg && threadIdx.x == 0 && q.seq < 56) a.dbg[16 + 2 * q.seq + 1] = wall_clock64();
   }
   lm_span_end(q.span);
@@ -1431,6 +1468,7 @@ __device__ __forceinline__ float coarse_tdist_sigma(double (*part)[kCoarseChunks
   return sigma;
 }
 __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaunch& q, int min_level) {
+  if (lm_chain_skip(a)) return;
   // The pose LM is the latency-critical chain of a frame, while the depth stream floods the CUs with throughput work
   // (selection, SSD scan) at the same time: raise this workgroup's issue priority on the SIMDs it shares with them.
   __builtin_amdgcn_s_setprio(3);
@@ -1448,7 +1486,7 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
   __syncthreads();
   // state in (or initialised), a pending evaluation of an earlier launch consumed, pyramid walk started
   lm_fused_prologue(q.st_in, q.part_in, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, red_sh, acc_sh, a.trace, a.cost_stat, true,
-                    q.first_of_solve ? a.init : nullptr, a.stop_level);
+                    q.first_of_solve ? a.init : nullptr, a.stop_level, a.chain_in_token ? a.chain_pose : nullptr);
   if (a.dbg && threadIdx.x == 0 && q.seq < 56) a.dbg[16 + 2 * q.seq] = wall_clock64();
   unsigned long long c_eval = 0, c_red = 0, c_sm = 0, c_it = 0, c_last = a.dbg ? __builtin_readcyclecounter() : 0;
   const unsigned long long c_begin = c_last;
@@ -1570,7 +1608,7 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
                      a.dbg ? a.dbg + 8 : nullptr, a.stop_level);
     lap(c_sm);
   }
-  lm_fused_publish(s_sh, q.st_out, a.host_prog, q.seq, a.token, a.cost_stat, a.out, a.done_flag, a.final_state);
+  lm_fused_publish(s_sh, q.st_out, a.host_prog, q.seq, a.token, a.cost_stat, a.out, a.done_flag, a.final_state, chain_out_of(a));
   if (a.dbg && threadIdx.x == 0) {
     if (q.seq < 56) a.dbg[16 + 2 * q.seq + 1] = wall_clock64();
     a.dbg[0] += c_eval; a.dbg[1] += c_red; a.dbg[2] += c_sm; a.dbg[3] += c_it;
@@ -1783,7 +1821,7 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
   __syncthreads();
   // state in (left by the coarse launch, or initialised), a pending evaluation of an earlier launch consumed, pyramid walk started
   lm_fused_prologue(q.st_in, q.part_in, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, fold_sh, acc_sh, a.trace, a.cost_stat,
-                    publisher, q.first_of_solve ? a.init : nullptr, a.stop_level);
+                    publisher, q.first_of_solve ? a.init : nullptr, a.stop_level, a.chain_in_token ? a.chain_pose : nullptr);
   // does every workgroup of this launch share my XCD? (wave 0, lane i asks about workgroup i; the answer is the same everywhere)
   if (t < 64) {
     bool same = true, got = false;
@@ -1938,7 +1976,7 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
   if (bail_sh && t == 0) { s_sh.status = -2; s_sh.active = 0; s_sh.finished = 1; }   // -2: gave up waiting (the host redoes the Solve)
   __syncthreads();
   if (publisher) {
-    lm_fused_publish(s_sh, q.st_out, a.host_prog, q.seq, a.token, a.cost_stat, a.out, a.done_flag, a.final_state);
+    lm_fused_publish(s_sh, q.st_out, a.host_prog, q.seq, a.token, a.cost_stat, a.out, a.done_flag, a.final_state, chain_out_of(a));
     if (a.dbg && t == 0) { a.dbg[128] += c_eval; a.dbg[129] += c_xchg; a.dbg[130] += c_sm; a.dbg[131] += c_it; a.dbg[132] += 1; a.dbg[133] += local ? 1 : 0; }
     if (t == 0 && q.span) atomicMax(q.span + 1, (unsigned long long)wall_clock64());
   }
@@ -1946,7 +1984,7 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
 // grid = 8 * K blocks: the class (blockIdx.x & 7) that sits on the optimiser's home XCD takes part, the others return at once
 template <bool kTdist>
 __device__ __forceinline__ void lm_fine_entry(const StepArgs& a, int K, unsigned long long* __restrict__ xbuf, int fault, int lo_level) {
-  if (!fine_on_home(a.fine_home)) return;
+  if (!fine_on_home(a.fine_home) || lm_chain_skip(a)) return;
   const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve, a.span};
   lm_fine_body<kTdist>(a, q, K, (int)(blockIdx.x >> 3), xbuf, fault, lo_level);
 }

@@ -536,6 +536,52 @@ ODO_HD void lm_consume(LmState* s, const double acc[ODO_NACC], float precision, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// The runner's keyframe test on a pose_to_keyframe (ref: run_odometry_kitti_offline.cpp:144-145,253-258): Sophus SO3::angleX/Y/Z of
+// the R -> q -> R round trip (third_party/Sophus/sophus/so3.hpp:127-154), |angles| and |translation| weighted and summed in order.
+// One source for the trackers' host code and for the device-side guard of a chained Solve (the two atan2f may differ in the last
+// bit; the guard is only a hint — the host's decision counts, see lm_chain_begin).
+// ---------------------------------------------------------------------------------------------
+ODO_HD void motion_angles3(const float* T, float ang[3]) {
+  Se3 s;
+  se3_from_colmajor(T, &s);
+  float R[9];
+  quat_to_rot(s, R);
+  ang[0] = atan2f(R[7] - R[5], R[4] + R[8]);
+  ang[1] = atan2f(R[2] - R[6], R[0] + R[8]);
+  ang[2] = atan2f(R[3] - R[1], R[0] + R[4]);
+}
+ODO_HD float motion_magnitude(const float* T, const float w[6]) {
+  float ang[3];
+  motion_angles3(T, ang);                                                              // :253
+  const float mot[6] = {fabsf(ang[0]), fabsf(ang[1]), fabsf(ang[2]), fabsf(T[12]), fabsf(T[13]), fabsf(T[14])};
+  float mag = 0.0f;
+  for (int i = 0; i < 6; i++) mag += mot[i] * w[i];                                     // :257
+  return mag;
+}
+
+// A CHEAP bound on the same quantity for the device-side guard of a chained Solve — a hint, not the decision (the host's
+// motion_magnitude decides): angles from the pose's own rotation block (no R -> q -> R round trip: 1e-7) through a polynomial
+// arctangent (|error| < 2.1e-4 rad: 2e-4 of magnitude at the runner's weights). The guard lets the chained Solve run only if the bound stays below the threshold by kMotionSlack.
+ODO_HD float atan2_approx(float y, float x) {
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  const float a = (mx > 0.0f) ? mn / mx : 0.0f;
+  const float s2 = a * a;
+  float r = ((-0.0464964749f * s2 + 0.15931422f) * s2 - 0.327622764f) * s2 * a + a;   // atan(a), a in [0, 1]: max error 2.1e-4
+  if (ay > ax) r = 1.57079637f - r;
+  if (x < 0.0f) r = 3.14159274f - r;
+  return (y < 0.0f) ? -r : r;
+}
+ODO_HD float motion_magnitude_approx(const float* T, const float w[6]) {
+  // T column-major: R[i][j] = T[j * 4 + i]; angleX = atan2(R21 - R12, R11 + R22), ... as motion_angles3
+  const float ax = atan2_approx(T[1 * 4 + 2] - T[2 * 4 + 1], T[1 * 4 + 1] + T[2 * 4 + 2]);
+  const float ay = atan2_approx(T[2 * 4 + 0] - T[0 * 4 + 2], T[0 * 4 + 0] + T[2 * 4 + 2]);
+  const float az = atan2_approx(T[0 * 4 + 1] - T[1 * 4 + 0], T[0 * 4 + 0] + T[1 * 4 + 1]);
+  return fabsf(ax) * w[0] + fabsf(ay) * w[1] + fabsf(az) * w[2] + fabsf(T[12]) * w[3] + fabsf(T[13]) * w[4] + fabsf(T[14]) * w[5];
+}
+#define ODO_MOTION_SLACK 1e-3f
+
+// ---------------------------------------------------------------------------------------------
 // The inverse-depth LM's driver (ref: src/depth_estimate.cpp:92-96,141,150-161,167): the state every block of
 // depth_lm_step_kernel carries from launch to launch, and the rule one evaluation's error is judged by. Pinned to the
 // reference's own lines through the host build (tests/test_ref_pin.py, emu_depth_lm_schedule).

@@ -593,6 +593,7 @@ struct LmJob {
   unsigned long long kf_img_ver, kf_dep_ver, cur_ver;
   StepArgs a;
   int seq, launches, it, budget, grid, token, min_level, stop_level;
+  int slot;   // which of the two host-mapped result blocks its finishing launch writes (a chained Solve takes the other one)
   bool poll, result_by_launch, issued_all;
   double bytes_per_level[ODO_MAX_LEVELS];
 };
@@ -686,6 +687,15 @@ struct odo_lm {
   int iters[ODO_MAX_LEVELS];
   int launches_level[ODO_MAX_LEVELS];
   LmJob job;
+  // A Solve queued BEHIND the one in flight before its result exists (lm_chain_begin: the trackers' next Solve): it starts from the
+  // pose the finishing launch of `job` leaves in d_chain_pose, if the guard in d_chain_guard lets it (success, keyframe kept).
+  LmJob chained;
+  float* d_chain_pose;     // [16]
+  int* d_chain_guard;
+  float kf_rule[7];        // the runner's keyframe test (six weights, threshold): lm_set_chain_rule
+  int kf_on;
+  int slot_next;
+  int last_token, last_slot;   // of the Solve odo_lm_solve collected last (lm_chain_verdict)
 };
 
 static inline LevelK lm_level_k(const odo_lm* m, int level) {
@@ -724,11 +734,15 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
   HIP_OK(hipHostMalloc((void**)&m->h_out, sizeof(float) * 48, hipHostMallocDefault));
   HIP_OK(hipHostMalloc((void**)&m->h_trace, sizeof(LmTraceRow) * kTraceCap, hipHostMallocDefault));
   m->h_cost = m->h_out + 26;
-  HIP_OK(hipHostMalloc((void**)&m->h_res, sizeof(float) * 48, hipHostMallocMapped | hipHostMallocCoherent));
+  HIP_OK(hipHostMalloc((void**)&m->h_res, sizeof(float) * 48 * 2, hipHostMallocMapped | hipHostMallocCoherent));   // two result blocks (LmJob::slot)
+  memset(m->h_res, 0, sizeof(float) * 48 * 2);
+  HIP_OK(hipMalloc((void**)&m->d_chain_pose, sizeof(float) * 32));   // pose [0 .. 15] and guard [16] in one cache line
+  HIP_OK(hipMemset(m->d_chain_pose, 0, sizeof(float) * 32));
+  m->d_chain_guard = (int*)(m->d_chain_pose + 16);
   HIP_OK(hipHostGetDevicePointer((void**)&m->d_res_map, m->h_res, 0));
   HIP_OK(hipHostMalloc((void**)&m->h_done, sizeof(int) * 4, hipHostMallocMapped | hipHostMallocCoherent));
   HIP_OK(hipHostGetDevicePointer((void**)&m->d_done, m->h_done, 0));
-  m->h_done[0] = 0;
+  m->h_done[0] = 0; m->h_done[1] = 0;
   HIP_OK(hipHostMalloc((void**)&m->h_prog, sizeof(int) * 32, hipHostMallocMapped | hipHostMallocCoherent));
   HIP_OK(hipHostGetDevicePointer((void**)&m->d_prog, m->h_prog, 0));
   memset(m->h_prog, 0, sizeof(int) * 32);
@@ -768,7 +782,7 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
 extern "C" int odo_lm_destroy(odo_lm* m) {
   if (!m) return 0;
   (void)hipStreamSynchronize(m->ctx->stream);
-  void* dv[] = {m->d_state, m->d_partials, m->d_xbuf, m->d_init, m->d_out, m->d_trace, m->d_scale, m->d_res,
+  void* dv[] = {m->d_state, m->d_partials, m->d_xbuf, m->d_init, m->d_out, m->d_trace, m->d_scale, m->d_res, m->d_chain_pose,
                 m->d_rowcnt, m->d_npts, m->cand[0].d_rowcnt, m->cand[0].d_npts, m->cand[1].d_rowcnt, m->cand[1].d_npts};
   for (void* q : dv) if (q) (void)hipFree(q);
   for (int l = 0; l < ODO_MAX_LEVELS; l++) {
@@ -790,6 +804,7 @@ extern "C" int odo_lm_destroy(odo_lm* m) {
 extern "C" int odo_lm_reset(odo_lm* m, const float init_colmajor[16], float lambda) {
   if (!m || !init_colmajor) { fail("Reset optimizer failed!"); return -1; }
   m->job.active = 0;                                // a Solve started early with the old initial pose is abandoned
+  m->chained.active = 0;                            // (lm_chain_adopt re-activates a chained Solve that started from exactly this pose)
   m->reset_gen++;
   memcpy(m->init, init_colmajor, sizeof(m->init));  // SetInitialAffine, ref: src/lm_optimizer.cpp:385-389
   m->lambda = lambda;                               // SetLambda, ref: :391-395
@@ -1181,9 +1196,23 @@ static inline bool fine_note_clean(bool on, int* strikes, int* clean, int* offs)
 }
 
 // Keyframe lists must be current (lm_prepare_keyframe) and the Solve fused-eligible.
+// chain_in_token != 0: a chained Solve (lm_chain_begin) behind the Solve with that token: only if the coarse + persistent launches
+// cover all of it (returns 1 without launching anything otherwise), lambda0 = chain_lambda (what Reset will set).
+static int lm_fused_begin_job(odo_lm* m, LmJob& jb, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img,
+                              int chain_in_token, float chain_lambda);
 static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img) {
+  m->chained.active = 0;   // (a chained Solve belongs to the job it was queued behind)
+  return lm_fused_begin_job(m, m->job, kf_img, kf_dep, cur_img, 0, 0.0f);
+}
+static int lm_fused_begin_job(odo_lm* m, LmJob& jb, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img,
+                              int chain_in_token, float chain_lambda) {
   hipStream_t s = m->ctx->stream;
-  LmJob& jb = m->job;
+  if (chain_in_token) {   // feasibility first: nothing is launched for a Solve that would need step launches or the unfused pipeline
+    const int stop0 = lm_fused_stop_level(m);
+    int ml = 0, fl = 0;
+    lm_plan_levels(m, stop0, m->fine_k, &ml, &fl);
+    if (stop0 != 0 || !((fl <= stop0 && fl < ml) || (ml <= stop0 && ml < m->n_levels))) return 1;
+  }
   jb.kf_img = kf_img; jb.kf_dep = kf_dep; jb.cur_img = cur_img;
   jb.kf_img_ver = kf_img->version; jb.kf_dep_ver = kf_dep->version; jb.cur_ver = cur_img->version;
   jb.seq = 0; jb.launches = 0; jb.it = 0; jb.issued_all = false; jb.result_by_launch = false;
@@ -1194,7 +1223,8 @@ static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_de
   // finishes the Solve writes the result and the token into host-mapped memory itself.
   m->token = (m->token % 0x3ffff) + 1;
   jb.token = m->token;
-  if (m->ev_on > 0) m->ev_phase = lm_ev_next_phase(m);
+  jb.slot = (m->slot_next++) & 1;
+  if (m->ev_on > 0 && !chain_in_token) m->ev_phase = lm_ev_next_phase(m);
   StepArgs& a = jb.a;
   memset(&a, 0, sizeof(a));
   a.n_levels = m->n_levels;
@@ -1213,12 +1243,16 @@ static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_de
     budget += m->max_iters[l] > 0 ? m->max_iters[l] : 0;
     jb.bytes_per_level[l] = lm_level_bytes(m, l, L.rows, L.cols, L.nblk);
   }
-  a.lambda0 = m->lambda; a.precision = m->precision; a.robust = m->robust; a.huber_delta = m->huber_delta;
+  a.lambda0 = chain_in_token ? chain_lambda : m->lambda; a.precision = m->precision; a.robust = m->robust; a.huber_delta = m->huber_delta;
   a.trace = m->record ? m->d_trace : nullptr; a.cost_stat = m->record ? m->d_cost : nullptr; a.host_prog = m->d_prog;
-  a.out = m->d_res_map; a.done_flag = m->d_done; a.token = jb.token;
+  a.out = m->d_res_map + 48 * jb.slot; a.done_flag = m->d_done + jb.slot; a.token = jb.token;
   a.stop_level = stop;
   a.final_state = stop > 0 ? m->d_state + 2 : nullptr;
   memcpy(a.init, m->init, sizeof(a.init));
+  a.chain_pose = m->d_chain_pose; a.chain_guard = m->d_chain_guard;
+  a.chain_in_token = chain_in_token;
+  a.chain_out = m->kf_on;
+  memcpy(a.kf_rule, m->kf_rule, sizeof(a.kf_rule));
     static unsigned long long* dbg_buf = [] {
       unsigned long long* p = nullptr;
       if (getenv("ODO_COARSE_STAMPS") && hipHostMalloc((void**)&p, 2048, hipHostMallocMapped) == hipSuccess) memset(p, 0, 2048);
@@ -1399,6 +1433,46 @@ extern "C" int odo_lm_solve_begin(odo_lm* m, const odo_pyr* kf_img, const odo_py
   return 0;
 }
 
+// ---- chained Solves (used by the trackers) -----------------------------------------------------------------------------
+// The keyframe test the guard of a chained Solve applies (ref: run_odometry_kitti_offline.cpp:144-145,257-258).
+static void lm_set_chain_rule(odo_lm* m, const float w[6], float th) {
+  for (int i = 0; i < 6; i++) m->kf_rule[i] = w[i];
+  m->kf_rule[6] = th;
+  m->kf_on = 1;
+}
+// Queues the Solve of `next_img` against the SAME keyframe behind the Solve in flight (m->job, all of whose launches must be out),
+// starting from the pose that Solve will leave — what the runner's Reset(pose_to_keyframe, lambda) hands the next Solve (ref: :261,
+// :268) — before that pose exists: the GPU goes from one Solve into the next without the host in between (15-18 us per frame on
+// bench.py's drive). The caller orders the stream behind next_img's construction first. Returns 0 queued, 1 not possible.
+static int lm_chain_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* next_img, float lambda) {
+  m->chained.active = 0;
+  if (!m->kf_on || !m->fused || !m->job.active || !m->job.issued_all || !m->job.result_by_launch) return 1;
+  if (m->job.kf_img != kf_img || m->job.kf_dep != kf_dep || m->job.kf_img_ver != kf_img->version || m->job.kf_dep_ver != kf_dep->version) return 1;
+  if (lm_check_pyrs(m, kf_img, kf_dep, next_img)) return 1;
+  if (!lm_fused_eligible(m)) return 1;
+  const int rc = lm_fused_begin_job(m, m->chained, kf_img, kf_dep, next_img, m->job.token, lambda);
+  if (rc != 0) { m->chained.active = 0; return 1; }
+  return 0;
+}
+// After the Solve in flight has been collected: what its guard told the chained Solve — 1 it runs, 2 its launches return at once,
+// 0 there is none / unknown (treated as "returns at once" by the caller after a stream sync).
+static int lm_chain_verdict(odo_lm* m, int token_of_collected, int slot_of_collected) {
+  if (!m->chained.active || m->chained.a.chain_in_token != token_of_collected) return 0;
+  volatile int* w = (volatile int*)(m->h_res + 48 * slot_of_collected) + 43;
+  const auto t0 = std::chrono::steady_clock::now();
+  while ((w[0] >> 2) != token_of_collected) {
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) return 0;
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return w[0] & 3;
+}
+// The chained Solve becomes the job in flight (call after odo_lm_reset with the pose it started from).
+static void lm_chain_adopt(odo_lm* m) {
+  m->job = m->chained;
+  m->job.active = 1;
+  m->chained.active = 0;
+}
+
 extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img,
                             float out_colmajor[16]) {
   if (!out_colmajor) return fail("odo_lm_solve: NULL out");
@@ -1411,6 +1485,7 @@ extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_
   const bool resumed = lm_job_matches(m, kf_img, kf_dep, cur_img);   // started earlier by odo_lm_solve_begin
   if (!resumed) {
     m->job.active = 0;
+    m->chained.active = 0;
     if (lm_prepare_keyframe(m, kf_img, kf_dep)) return -1;
   }
   int launches = 0;
@@ -1440,7 +1515,7 @@ fused_again:
     if (lm_unfused_levels(m, kf_img, kf_dep, cur_img, m->n_levels - 1, &launches, bytes_per_level)) return -1;
   }
   if (fused) {
-    const int token = m->job.token;
+    const int token = m->job.token, slot = m->job.slot;
     const bool result_by_launch = m->job.result_by_launch;
     LmState* st[2] = {m->d_state, m->d_state + 1};
     double* part[2] = {m->d_partials, m->d_partials + (size_t)kLmMaxBlocks * ODO_NACC};
@@ -1450,7 +1525,7 @@ fused_again:
     auto launch_finalize = [&]() {
       FinalizeArgs fa;
       fa.st_in = st[seq & 1]; fa.part_in = part[seq & 1]; fa.precision = m->precision; fa.trace = m->record ? m->d_trace : nullptr;
-      fa.cost_stat = m->record ? m->d_cost : nullptr; fa.st_out = st[0]; fa.out = m->d_res_map; fa.done_flag = m->d_done;
+      fa.cost_stat = m->record ? m->d_cost : nullptr; fa.st_out = st[0]; fa.out = m->d_res_map + 48 * slot; fa.done_flag = m->d_done + slot;
       fa.token = token; fa.first_of_solve = (seq == 0) ? 1 : 0;
       memcpy(fa.init, m->init, sizeof(fa.init));
       hipLaunchKernelGGL(lm_fused_finalize_kernel, dim3(1), dim3(kLmBlock), 0, s, fa);
@@ -1458,7 +1533,7 @@ fused_again:
     // Not polling (or nothing launched): a finalize launch consumes the last evaluation and reports.
     if (!result_by_launch) launch_finalize();
     HIP_OK(hipGetLastError());
-    volatile int* done = m->h_done;
+    volatile int* done = m->h_done + slot;
     const auto t0 = std::chrono::steady_clock::now();
     bool ok = true;
     while (done[0] != token) {
@@ -1473,7 +1548,7 @@ fused_again:
       }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
-    memcpy(m->h_out, m->h_res, sizeof(float) * 42);
+    memcpy(m->h_out, m->h_res + 48 * slot, sizeof(float) * 42);
     if (m->h_out[16] == -2.0f && m->fine_k > 0) {
       // The persistent launch gave up: one of its workgroups never showed up within the wait bound (they wait for each other,
       // so all of them must be resident at once: another client of this GPU can hold the CUs they need). Nothing is lost but
@@ -1484,6 +1559,7 @@ fused_again:
       m->fine_k = 0;
       started = false;
       launches = 0;
+      m->chained.active = 0;   // (a Solve chained behind this one sees a guard without its token and returns at once)
       HIP_OK(hipStreamSynchronize(s));
       fused = lm_fused_eligible(m);   // (t-distribution weights: without the persistent launch the fused part may be empty)
       goto fused_again;
@@ -1519,6 +1595,8 @@ fused_again:
   }
   m->trace_stale = 1;  // the per-evaluation trace stays on the device until odo_lm_trace() asks for it
   memcpy(out_colmajor, m->h_out, sizeof(float) * 16);
+  m->last_token = fused ? m->job.token : 0;
+  m->last_slot = fused ? m->job.slot : 0;
   m->last_evals = (int)m->h_out[17];
   m->last_launches = launches;
   m->last_bytes = 0.0;

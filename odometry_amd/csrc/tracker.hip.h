@@ -61,6 +61,9 @@ struct odo_tracker {
   // keyframe decision are known then — the next Solve's launches go out on the LM stream while the depth stream finishes and
   // the host does its bookkeeping (odo_lm_solve_begin). Same launches, earlier; ODO_NO_EARLY_SOLVE=1 turns it off.
   int early_solve;
+  int chain_solve;           // 1: ... and queued BEHIND this frame's Solve before its result exists (lm_chain_begin; ODO_NO_CHAIN_SOLVE=1: off)
+  long chain_used, chain_wasted;   // chained Solves adopted / that ran for nothing (the host's keyframe test disagreed with the guard)
+  double dbg_pre_us, dbg_spin_us, dbg_chain_us, dbg_verdict_us, dbg_post_us; long dbg_n;   // ODO_TRACK_DEBUG: host time per call, by phase
   int depth_ahead;           // 1: with the next PAIR announced, the next frame's stream-B job is posted a frame early (ODO_NO_DEPTH_AHEAD=1: off)
   hipEvent_t ev_next;        // stream C: next_img is complete
 };
@@ -138,6 +141,12 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
   t->w_posted.store(0); t->w_done.store(0); t->w_quit.store(0);
   t->ev_next = nullptr;
   t->early_solve = getenv("ODO_NO_EARLY_SOLVE") ? 0 : 1;
+  // Chained Solves are OFF unless ODO_CHAIN_SOLVE=1: measured (round 4) they close the 14 us the GPU idles between
+  // two Solves (rocprofv3: fine -> next coarse gap 14.2 -> 0.0 us) and the frame rate does not move (3 250 both ways): the LM
+  // kernels' own wall time grows by what the gap gave (same cycle counts: the clock, not the work).
+  t->chain_solve = (t->early_solve && getenv("ODO_CHAIN_SOLVE") && !getenv("ODO_NO_CHAIN_SOLVE")) ? 1 : 0;
+  t->chain_used = t->chain_wasted = 0;
+  t->dbg_pre_us = t->dbg_spin_us = t->dbg_chain_us = t->dbg_verdict_us = t->dbg_post_us = 0.0; t->dbg_n = 0;
   t->depth_ahead = getenv("ODO_NO_DEPTH_AHEAD") ? 0 : 1;
   t->p = *p;
   float eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
@@ -169,6 +178,7 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
   ok = ok && hipEventCreateWithFlags(&t->ev_cur_img, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&t->ev_next, hipEventDisableTiming) == hipSuccess;
   if (ok && !getenv("ODO_LM_TRACE")) t->lm->record = 0;   // nobody reads the per-evaluation rows / cost statistics of a tracker's Solves
+  if (ok) lm_set_chain_rule(t->lm, p->keyframe_weight, p->keyframe_motion_th);
   if (!ok) {
     char keep[512];
     snprintf(keep, sizeof(keep), "%s", g_err);
@@ -305,6 +315,7 @@ extern "C" int odo_tracker_quiesce(odo_tracker* t) {
   HIP_OK(hipStreamSynchronize(t->ctx_b->stream));
   HIP_OK(hipStreamSynchronize(t->ctx_c->stream));
   t->lm->job.active = 0;                   // a Solve started early for an announced frame is dropped
+  t->lm->chained.active = 0;
   t->prefetched = t->hint_next = t->hint_next_right = nullptr;  // announcements are void
   return 0;
 }
@@ -444,9 +455,39 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
     t->w_posted.store(n + 1, std::memory_order_release);
     t->ahead_job = n;
   }
+  // ---- the next frame's Solve, queued behind this frame's before its result exists: same keyframe, initial pose = this Solve's
+  // result taken on the device, guarded by the runner's keyframe test on the device (lm_chain_begin). This frame's Solve must be in
+  // flight for that: started early in the last call (or chained then), else started here.
+  bool chained = false;
+  const auto d0 = std::chrono::steady_clock::now();
+  auto d1 = d0, d2 = d0;
+  if (early && t->chain_solve) {
+    if (!lm_job_matches(t->lm, t->kf_img, t->kf_dep, t->cur_img)) {
+      if (had_prefetch && hipStreamWaitEvent(t->ctx_a->stream, t->ev_next, 0) != hipSuccess) return fail("hipStreamWaitEvent failed");
+      if (odo_lm_solve_begin(t->lm, t->kf_img, t->kf_dep, t->cur_img) < 0) return -1;
+    }
+    // (ev_next is re-recorded by tracker_next_pyramid above: the next frame's pyramid on stream C — ~15 us of work enqueued a moment
+    //  ago, while this frame's Solve has a few hundred us to go: wait for it HERE, on the host, so that no wait packet sits between
+    //  this Solve's last launch and the chained Solve's first; after 100 us the stream waits for it instead)
+    bool ready = false;
+    d1 = std::chrono::steady_clock::now();
+    for (const auto w0 = std::chrono::steady_clock::now(); !ready;) {
+      ready = hipEventQuery(t->ev_next) == hipSuccess;
+      if (!ready && std::chrono::steady_clock::now() - w0 > std::chrono::microseconds(100)) break;
+    }
+    (void)hipGetLastError();   // (hipErrorNotReady is not an error)
+    d2 = std::chrono::steady_clock::now();
+    if (ready || hipStreamWaitEvent(t->ctx_a->stream, t->ev_next, 0) == hipSuccess)
+      chained = lm_chain_begin(t->lm, t->kf_img, t->kf_dep, t->next_img, 0.01f) == 0;
+  }
+  const auto d3 = std::chrono::steady_clock::now();
+  t->dbg_pre_us += std::chrono::duration<double, std::micro>(d0 - f0).count();
+  t->dbg_spin_us += std::chrono::duration<double, std::micro>(d2 - d1).count();
+  t->dbg_chain_us += std::chrono::duration<double, std::micro>(d3 - d2).count();
   float T[16];
   const auto s0 = std::chrono::steady_clock::now();
   const int st = odo_lm_solve(t->lm, t->kf_img, t->kf_dep, t->cur_img, T);             // :215 (collects an early start)
+  const int solved_token = t->lm->last_token, solved_slot = t->lm->last_slot;
   const auto s1 = std::chrono::steady_clock::now();
   t->tm_solve_us += std::chrono::duration<double, std::micro>(s1 - s0).count();
   t->lm->idle_pump = nullptr;
@@ -470,11 +511,7 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
   if (solve_status) *solve_status = st;
   if (is_new_keyframe) *is_new_keyframe = 0;
   if (motion_mag) *motion_mag = 0.0f;
-  float ang[3];
-  motion_angles(T, ang);                                                               // :253
-  const float mot[6] = {fabsf(ang[0]), fabsf(ang[1]), fabsf(ang[2]), fabsf(T[12]), fabsf(T[13]), fabsf(T[14])};
-  float mag = 0.0f;
-  for (int i = 0; i < 6; i++) mag += mot[i] * p.keyframe_weight[i];                     // :257
+  const float mag = motion_magnitude(T, p.keyframe_weight);                            // :253-257 (odo_math.h: the guard's own function)
   const bool promote = mag > p.keyframe_motion_th;                                     // :258
   // The next Solve's inputs: keyframe (unchanged unless this frame is promoted), next frame's pyramid (stream C, ev_next),
   // initial pose = T (:261 / :268 Reset). Started here, it runs while stream B finishes this frame's depth.
@@ -483,7 +520,27 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
     return odo_lm_solve_begin(t->lm, t->kf_img, t->kf_dep, t->next_img) < 0 ? -1 : 0;
   };
   bool reset_done = false;
-  if (early && !promote) {
+  const auto v0 = std::chrono::steady_clock::now();
+  if (chained) {
+    // what did the guard tell the chained Solve? It runs (1) exactly when the device's keyframe test kept the keyframe and the Solve
+    // succeeded; the host's own test decides what counts: agreement and "keep" -> the chained Solve IS the next Solve.
+    int verdict = lm_chain_verdict(t->lm, solved_token, solved_slot);
+    if (verdict == 0) {   // no word (a redone Solve, a finalize launch): its launches saw a guard without their token and returned
+      verdict = 2;
+    }
+    if (verdict == 1 && !promote && st == 0) {
+      odo_lm_reset(t->lm, T, 0.01f);                                                   // :268 (the pose and lambda it started from)
+      lm_chain_adopt(t->lm);
+      reset_done = true;
+      t->chain_used++;
+    } else {
+      t->lm->chained.active = 0;
+      if (verdict == 1) t->chain_wasted++;   // it runs for nothing: the Solve started below queues behind it
+      chained = false;
+    }
+  }
+  t->dbg_verdict_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - v0).count();
+  if (early && !promote && !reset_done) {
     odo_lm_reset(t->lm, T, 0.01f);                                                     // :268
     reset_done = true;
     if (start_next_solve() < 0) return -1;
@@ -527,6 +584,11 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
   t->last_evals = t->lm->last_evals;
   t->tm_frame_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - f0).count();
   t->tm_frames++;
+  t->dbg_post_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - s1).count();
+  if (++t->dbg_n % 500 == 0 && getenv("ODO_TRACK_DEBUG"))
+    fprintf(stderr, "[track] per call: before the chain %.1f us, waiting for the next pyramid %.1f, chain launches %.1f, guard verdict %.1f, "
+            "after the Solve returned %.1f\n", t->dbg_pre_us / t->dbg_n, t->dbg_spin_us / t->dbg_n, t->dbg_chain_us / t->dbg_n,
+            t->dbg_verdict_us / t->dbg_n, t->dbg_post_us / t->dbg_n);
   return 0;
 }
 
@@ -569,6 +631,12 @@ extern "C" int odo_tracker_outputs(const odo_tracker* t, const uint8_t** val, co
   if (val) *val = t->d_val[t->out_slot];
   if (disp) *disp = t->d_disp[t->out_slot];
   if (dep) *dep = t->d_dep[t->out_slot];
+  return 0;
+}
+extern "C" int odo_tracker_chain_stats(const odo_tracker* t, long* adopted, long* wasted) {
+  if (!t) return fail("NULL tracker");
+  if (adopted) *adopted = t->chain_used;
+  if (wasted) *wasted = t->chain_wasted;
   return 0;
 }
 extern "C" odo_lm* odo_tracker_lm(odo_tracker* t) { return t ? t->lm : nullptr; }

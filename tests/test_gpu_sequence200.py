@@ -110,3 +110,24 @@ def test_batched_tracker_all_200_frames_two_drives_match_their_oracle_runners(dr
     tb.close()
     for s in range(S):
         assert st[s]["n_keyframes"] == oracle_runs[s]["n_keyframes"]
+
+
+def test_chained_solves_give_the_unchained_poses(drives, oracle_runs, monkeypatch):
+    """ODO_CHAIN_SOLVE=1: the next frame's Solve is queued behind this frame's before its result exists — initial pose taken on the
+    device, guarded by a bound on the runner's keyframe test (odo_tracker_chain_stats). Same poses, keyframe decisions and depth
+    counts as the oracle runner over the first 80 frames; most Solves are adopted, none runs for nothing."""
+    from odometry_amd import api
+    monkeypatch.setenv("ODO_CHAIN_SOLVE", "1")
+    seq, ref = drives[0], oracle_runs[0]
+    trk = api.Tracker(0)
+    n = 80
+    dev = [(trk.upload_frame(l), trk.upload_frame(r)) for l, r in zip(seq["left"][:n], seq["right"][:n])]
+    trk.init(*dev[0])
+    for k in range(1, n):
+        if k + 1 < n:
+            trk.hint_next(*dev[k + 1])
+        g = trk.track(*dev[k])
+        _check_frame(k, g, ref["rows"][k - 1], trk.stats()["n_valid_depth"])
+    adopted, wasted = trk.chain_stats()
+    trk.close()
+    assert adopted >= 50 and wasted == 0, (adopted, wasted)

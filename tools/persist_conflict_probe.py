@@ -35,7 +35,7 @@ def main():
     trk._sync()
     dt = time.perf_counter() - t0
     print(f"{n} frames: {n / dt:.0f} frames/s, calls over 2 ms: {slow}, pose LM (workgroups, Solves redone) {trk.persistent_stats()}, "
-          f"depth LM (on, jobs redone) {trk.depth_persistent_stats()}, env "
+          f"depth LM (on, jobs redone) {trk.depth_persistent_stats()}, chained Solves (adopted, wasted) {trk.chain_stats()}, env "
           f"{ {k: v for k, v in os.environ.items() if k.startswith('ODO_')} }", flush=True)
     trk.close()
 

@@ -257,6 +257,22 @@ int odo_depth_prepare_left_dev_marked(odo_depth* d, odo_ctx* side, const float* 
                                       unsigned long mark);
 int odo_depth_compute_dev_stamped(odo_depth* d, const float* left_dev, const float* right_dev, int rows, int cols,
                                   uint8_t* val_dev, float* disp_dev, float* dep_dev, unsigned long long left_stamp);
+/* The WHOLE of ComputeDepth(left, right) (ref: src/depth_estimate.cpp:31-78) started ahead of the call: every launch of it goes to
+ * `side`'s stream — behind `mark` of the estimator's stream (0: behind everything queued there), i.e. behind whatever produced the
+ * two images and recycled the three output blocks — and the function returns without waiting. ComputeDepth does not depend on the
+ * pose: the drop-in classes start it once the Solve of :215 has been queued, and the runner's ComputeDepth of :229 only collects it.
+ * Returns 0: started; 1: not started (the inverse-depth LM would need host-paced step launches: its persistent launch is off or
+ * switched off) — nothing was queued; -1: error. Stamps (non-zero) name the two images' contents.
+ * odo_depth_compute_end_dev: ComputeDepth proper with both stamps. The job started ahead with exactly these arguments is waited for
+ * (bounded spin on its completion word; the estimator's stream is ordered behind it), a job started ahead with other arguments is
+ * waited for and dropped, and without a matching job everything is computed now: the same launches either way, results identical.
+ * Every other entry point of the estimator drops a job started ahead the same way. odo_depth_early_pending: 1 while one is out. */
+int odo_depth_compute_begin_dev(odo_depth* d, odo_ctx* side, const float* left_dev, const float* right_dev, int rows, int cols,
+                                uint8_t* val_dev, float* disp_dev, float* dep_dev, unsigned long long left_stamp,
+                                unsigned long long right_stamp, unsigned long mark);
+int odo_depth_compute_end_dev(odo_depth* d, const float* left_dev, const float* right_dev, int rows, int cols, uint8_t* val_dev,
+                              float* disp_dev, float* dep_dev, unsigned long long left_stamp, unsigned long long right_stamp);
+int odo_depth_early_pending(const odo_depth* d);
 /* Disparity stage only (DisparityDepthEstimate, ref: src/depth_estimate.cpp:244-401). */
 int odo_depth_disparity(odo_depth* d, const float* left, const float* right, int rows, int cols, uint8_t* val,
                         float* disp, float* dep);

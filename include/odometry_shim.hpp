@@ -297,6 +297,17 @@ class Mat {
     b.stamp = detail::next_stamp();
     return b.dev;
   }
+  // A device block a kernel has (or will have, in stream order) written completely becomes this Mat's mirror: as device_out(),
+  // without allocating (ComputeDepth started ahead writes into blocks reserved for its outputs before their Mats exist).
+  void adopt_device(void* block, int async_flag) {
+    detail::MatBuf& b = *buf_;
+    b.wait_upload();
+    b.free_mirror();
+    b.dev = block; b.dev_async = async_flag;
+    b.dev_valid = true; b.host_valid = false; b.fill_pending = false; b.side_pending = false;
+    b.stamp = detail::next_stamp();
+  }
+  size_t device_bytes() const { return buf_ ? buf_->bytes : 0; }
   const std::shared_ptr<detail::MatBuf>& buffer() const { return buf_; }
  private:
   int type_ = CV_32F;
@@ -514,9 +525,24 @@ inline const Mat& pyr_level(const std::shared_ptr<PyrHandle>& h, int level) {
 // from ImagePyramid's constructor and runs beside the Solve:
 //   * the right image's upload (the partner guess: the Mat ComputeDepth was given with this left Mat last time — the runner
 //     refills the same two Mats every frame, ref: :200,334-359 — else the same-sized Mat created right after it);
-//   * the left image's blur + point selection of ComputeDepth (odo_depth_prepare_left_dev) for the estimator of this thread;
+//   * ComputeDepth(left, right) itself — it does not depend on the pose — into three blocks reserved for its outputs
+//     (odo_depth_compute_begin_dev, for the estimator of this thread); the ComputeDepth call of :229 then finds the job under the
+//     content stamps of its two images, makes the blocks the mirrors of its output Mats and only waits (a wrong guess, a refilled
+//     Mat, another size: the job is dropped and ComputeDepth computes as if nothing had been started);
+//     where the whole job cannot be started (no partner known, the depth LM on host-paced step launches) its left half is:
+//     blur + point selection of the left image (odo_depth_prepare_left_dev);
 //   * and the :251 pyramid is the :205 pyramid (same content stamp, levels and smoothing: the device pyramid is shared).
 struct Lookahead {
+  struct Early {                                 // ComputeDepth started ahead
+    void* blk[3] = {nullptr, nullptr, nullptr};  // val (u8), disp, dep (f32): reserved from the main context's free list
+    int async_[3] = {0, 0, 0};
+    size_t bytes[3] = {0, 0, 0};
+    bool reserved = false, started = false;
+    odo_depth* est = nullptr;
+    const void *left_dev = nullptr, *right_dev = nullptr;
+    unsigned long long left_stamp = 0, right_stamp = 0;
+    int rows = 0, cols = 0;
+  } early;
   bool on = std::getenv("ODOMETRY_SHIM_NO_LOOKAHEAD") == nullptr;
   std::weak_ptr<MatBuf> last_left, last_right;   // the pair of the last ComputeDepth
   odo_depth* estimator = nullptr;                // the DepthEstimator of this thread (the last one constructed)
@@ -530,6 +556,28 @@ struct Lookahead {
   unsigned long pending_mark = 0;                // the main stream's fill level then (odo_ctx_mark): the side stream goes behind THAT
 };
 inline Lookahead& lookahead() { static thread_local Lookahead l; return l; }
+// The three output blocks of a ComputeDepth started ahead go back to the free list: behind the job (side stream) when it was started.
+inline void early_release() {
+  Lookahead::Early& e = lookahead().early;
+  if (!e.reserved) return;
+  if (e.started) odo_ctx_stream_wait(context(), side_context());
+  for (int i = 0; i < 3; i++)
+    if (e.blk[i]) { odo_dev_free_async(context(), e.blk[i], e.bytes[i], e.async_[i]); e.blk[i] = nullptr; }
+  e.reserved = e.started = false;
+}
+inline void early_reserve(int rows, int cols) {
+  early_release();
+  Lookahead::Early& e = lookahead().early;
+  const size_t n = (size_t)rows * cols;
+  e.bytes[0] = n; e.bytes[1] = e.bytes[2] = n * sizeof(float);
+  for (int i = 0; i < 3; i++)
+    if (odo_dev_alloc_async(context(), e.bytes[i], &e.blk[i], &e.async_[i]) != 0) {
+      e.blk[i] = nullptr;
+      for (int k = 0; k < i; k++) { odo_dev_free_async(context(), e.blk[k], e.bytes[k], e.async_[k]); e.blk[k] = nullptr; }
+      return;
+    }
+  e.reserved = true; e.started = false; e.rows = rows; e.cols = cols;
+}
 // Issues the recorded lookahead. Called by Solve right AFTER its own launches have gone out (the Solve is the critical path: ~15 us
 // of host work must not sit in front of it), else by the next ComputeDepth.
 inline void run_lookahead() {
@@ -540,12 +588,25 @@ inline void run_lookahead() {
   if (odo_ctx_stream_wait_mark(side_context(), context(), la.pending_mark) != 0) return;
   // the stereo partner's upload, on the side stream
   if (guess && guess.get() != lb.get()) prefetch_to_device(guess);
-  // ComputeDepth's left half, on the side stream (frames of the size the estimator has seen), behind the left image's upload —
-  // the mark — not behind the Solve queued since
+  // ComputeDepth on the side stream (frames of the size the estimator has seen), behind the left image's upload — the mark — not
+  // behind the Solve queued since: all of it when the partner is on the device (or on its way there on the side stream), else
+  // its left half
   if (la.estimator && la.pending_rows == la.est_rows && la.pending_cols == la.est_cols && lb->dev && lb->dev_valid &&
-      !lb->side_pending)
+      !lb->side_pending) {
+    Lookahead::Early& e = la.early;
+    if (e.reserved && !e.started && e.rows == la.pending_rows && e.cols == la.pending_cols && guess && guess.get() != lb.get() &&
+        guess->dev && guess->dev_valid && guess->bytes == lb->bytes &&
+        odo_depth_compute_begin_dev(la.estimator, side_context(), static_cast<const float*>(lb->dev),
+                                    static_cast<const float*>(guess->dev), e.rows, e.cols, static_cast<uint8_t*>(e.blk[0]),
+                                    static_cast<float*>(e.blk[1]), static_cast<float*>(e.blk[2]), lb->stamp, guess->stamp,
+                                    la.pending_mark) == 0) {
+      e.started = true; e.est = la.estimator;
+      e.left_dev = lb->dev; e.right_dev = guess->dev; e.left_stamp = lb->stamp; e.right_stamp = guess->stamp;
+      return;
+    }
     (void)odo_depth_prepare_left_dev_marked(la.estimator, side_context(), static_cast<const float*>(lb->dev), la.pending_rows,
                                             la.pending_cols, lb->stamp, la.pending_mark);
+  }
 }
 #endif
 inline std::shared_ptr<PyrHandle> make_pyr(int num_levels, const Mat& in, bool smooth, int kind, const char* what) {
@@ -584,6 +645,9 @@ inline std::shared_ptr<PyrHandle> make_pyr(int num_levels, const Mat& in, bool s
       else if (lb->next && lb->next->bytes == lb->bytes) guess = lb->next->shared_from_this();
       if (guess && guess.get() != lb.get()) prefetch_reserve(guess);
       la.pending_partner = guess;
+      // ... and the three output blocks of a ComputeDepth started ahead (recycled blocks: their earlier use is in front of the mark)
+      if (la.estimator && in.rows == la.est_rows && in.cols == la.est_cols && guess && guess.get() != lb.get()) early_reserve(in.rows, in.cols);
+      else early_release();
       la.pending_mark = odo_ctx_mark(context());
     }
   }
@@ -723,7 +787,7 @@ class DepthEstimator {  // ref: include/depth_estimate.h:24-121
   }
   ~DepthEstimator() {
 #ifndef ODOMETRY_SHIM_WITH_OPENCV
-    if (detail::lookahead().estimator == d_) detail::lookahead().estimator = nullptr;
+    if (detail::lookahead().estimator == d_) { detail::early_release(); detail::lookahead().estimator = nullptr; }
 #endif
     odo_depth_destroy(d_);
   }
@@ -746,10 +810,33 @@ class DepthEstimator {  // ref: include/depth_estimate.h:24-121
     }
     std::cout << "computing disparity ..." << std::endl;
     int st = -1;
-    {
+    bool collected = false;
 #ifndef ODOMETRY_SHIM_WITH_OPENCV
-      detail::lookahead().pending_left.reset();   // (a lookahead nobody issued: too late for it now)
+    {
+      detail::Lookahead& la = detail::lookahead();
+      la.pending_left.reset();   // (a lookahead nobody issued: too late for it now)
+      // the job started ahead from ImagePyramid's constructor / Solve, if it was started for exactly these two images
+      detail::Lookahead::Early& e = la.early;
+      const detail::MatBuf *lb = left_img.buffer().get(), *rb = right_img.buffer().get();
+      if (e.started && e.est == d_ && lb && rb && lb->dev == e.left_dev && lb->dev_valid && lb->stamp == e.left_stamp &&
+          rb->dev == e.right_dev && rb->dev_valid && rb->stamp == e.right_stamp && left_img.rows == e.rows && left_img.cols == e.cols &&
+          left_val.device_bytes() == e.bytes[0] && left_disp.device_bytes() == e.bytes[1] && left_dep.device_bytes() == e.bytes[2]) {
+        left_val.adopt_device(e.blk[0], e.async_[0]);
+        left_disp.adopt_device(e.blk[1], e.async_[1]);
+        left_dep.adopt_device(e.blk[2], e.async_[2]);
+        st = odo_depth_compute_end_dev(d_, static_cast<const float*>(e.left_dev), static_cast<const float*>(e.right_dev), e.rows, e.cols,
+                                       static_cast<uint8_t*>(e.blk[0]), static_cast<float*>(e.blk[1]), static_cast<float*>(e.blk[2]),
+                                       e.left_stamp, e.right_stamp);
+        e.blk[0] = e.blk[1] = e.blk[2] = nullptr;   // (the Mats own them now)
+        e.reserved = e.started = false;
+        collected = true;
+        la.last_left = left_img.buffer(); la.last_right = right_img.buffer();
+      } else {
+        detail::early_release();   // (the library drops the job itself at its next call)
+      }
+    }
 #endif
+    if (!collected) {
       detail::DevIn l(left_img), r(right_img);
       detail::DevOut v(left_val), ds(left_disp), dp(left_dep);
       if (l.get() && r.get() && v.get() && ds.get() && dp.get()) {

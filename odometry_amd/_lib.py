@@ -101,6 +101,9 @@ SIGNATURES = {
     "odo_depth_prepare_left_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_ulonglong]),
     "odo_depth_prepare_left_dev_marked": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_ulonglong, C.c_ulong]),
     "odo_depth_compute_dev_stamped": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_ulonglong]),
+    "odo_depth_compute_begin_dev": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_ulonglong, C.c_ulonglong, C.c_ulong]),
+    "odo_depth_compute_end_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_ulonglong, C.c_ulonglong]),
+    "odo_depth_early_pending": (C.c_int, [_vp]),
     "odo_depth_disparity": (C.c_int, [_vp, _fp, _fp, C.c_int, C.c_int, _u8p, _fp, _fp]),
     "odo_depth_time_stages": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _fp, _dp, _ip]),
     "odo_depth_report": (C.c_int, [_vp, _ip, _fp, _ip, _ip, _ip]),

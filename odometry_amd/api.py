@@ -342,6 +342,18 @@ class DepthEstimator:
     def compute_dev(self, left_dev, right_dev, rows, cols, val_dev, disp_dev, dep_dev):
         return self.ctx.lib.odo_depth_compute_dev(self.h, left_dev, right_dev, rows, cols, val_dev, disp_dev, dep_dev)
 
+    def compute_begin_dev(self, side_ctx, left_dev, right_dev, rows, cols, val_dev, disp_dev, dep_dev, left_stamp, right_stamp, mark=0):
+        """ComputeDepth started ahead on side_ctx's stream (returns at once): 0 started, 1 not started, -1 error."""
+        return self.ctx.lib.odo_depth_compute_begin_dev(self.h, side_ctx.h, left_dev, right_dev, rows, cols, val_dev, disp_dev,
+                                                        dep_dev, left_stamp, right_stamp, mark)
+
+    def compute_end_dev(self, left_dev, right_dev, rows, cols, val_dev, disp_dev, dep_dev, left_stamp, right_stamp):
+        return self.ctx.lib.odo_depth_compute_end_dev(self.h, left_dev, right_dev, rows, cols, val_dev, disp_dev, dep_dev,
+                                                      left_stamp, right_stamp)
+
+    def early_pending(self):
+        return bool(self.ctx.lib.odo_depth_early_pending(self.h))
+
     def time_stages(self, left_dev, right_dev, rows, cols, reps=20):
         us = (C.c_float * 3)()
         cand, nsel = C.c_double(0), C.c_int(0)

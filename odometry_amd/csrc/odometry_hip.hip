@@ -2336,7 +2336,17 @@ struct odo_depth {
   unsigned long long prep_stamp;
   int prep_rows, prep_cols;
   hipEvent_t prep_ev;             // recorded behind the prepared launches
+  // odo_depth_compute_begin_dev: a WHOLE ComputeDepth enqueued ahead of the call on another stream (same event)
+  hipStream_t job_stream;         // stream the depth_job_* functions enqueue on; NULL: the estimator's own (ctx->stream)
+  struct Early {
+    int active;
+    const float *left, *right;
+    unsigned long long left_stamp, right_stamp;
+    int rows, cols;
+    uint8_t* val; float *disp, *dep;
+  } early;
 };
+static inline hipStream_t depth_stream(const odo_depth* d) { return d->job_stream ? d->job_stream : d->ctx->stream; }
 
 extern "C" int odo_depth_create(odo_ctx* ctx, float grad_th, float ssd_th, float photo_th, float min_depth, float max_depth,
                                 float lambda, float huber_delta, float precision, int max_iters, int boundary,
@@ -2393,13 +2403,15 @@ static void depth_free_images(odo_depth* d) {
 
 extern "C" int odo_depth_destroy(odo_depth* d) {
   if (!d) return 0;
+  if (d->early.active) { d->early.active = 0; (void)hipEventSynchronize(d->prep_ev); }
   (void)hipStreamSynchronize(d->ctx->stream);
+  if (d->prep_ev) (void)hipEventSynchronize(d->prep_ev);   // a half / a whole job started ahead on another stream writes these buffers
   depth_free_images(d);
   void* dv[] = {d->d_pts, d->d_cnt, d->d_d0, d->d_scratch, d->d_matched, d->d_lmstate, d->d_part_e, d->d_part_n, d->d_counts, d->d_xbuf,
                 d->d_gave_up};
   for (void* q : dv) if (q) (void)hipFree(q);
   (void)hipHostFree(d->h_stats); (void)hipHostFree(d->h_prog);
-  if (d->prep_ev) { (void)hipEventSynchronize(d->prep_ev); (void)hipEventDestroy(d->prep_ev); }
+  if (d->prep_ev) (void)hipEventDestroy(d->prep_ev);
   delete d;
   return 0;
 }
@@ -2407,6 +2419,7 @@ extern "C" int odo_depth_destroy(odo_depth* d) {
 static int depth_ensure(odo_depth* d, int rows, int cols) {
   if (d->rows == rows && d->cols == cols) return 0;
   if (d->prep_left) { HIP_OK(hipEventSynchronize(d->prep_ev)); d->prep_left = nullptr; }   // a prepared half on the old buffers is dropped
+  // (a whole job started ahead has been settled by every caller before it gets here: depth_early_settle)
   HIP_OK(hipStreamSynchronize(d->ctx->stream));
   depth_free_images(d);
   const size_t n = (size_t)rows * cols;
@@ -2451,7 +2464,7 @@ struct DepthJob {
 
 static int depth_job_begin(odo_depth* d, DepthJob* j, const float* left, const float* right, int rows, int cols,
                            uint8_t* val, float* disp, float* dep, int stage, unsigned long long left_stamp = 0) {
-  hipStream_t s = d->ctx->stream;
+  hipStream_t s = depth_stream(d);
   // a front half prepared ahead (odo_depth_prepare_left_dev): either it is this call's — the blurred left image and the selected
   // points are (or will be) there, behind prep_ev — or it is dropped; in both cases this stream goes on behind it (it writes the
   // estimator's buffers)
@@ -2490,7 +2503,7 @@ static int depth_job_begin(odo_depth* d, DepthJob* j, const float* left, const f
 // the completion word; a caller may enqueue more work of its own between the two (the tracker's pyramids), so that
 // "completion word set" implies that work is done too.
 static int depth_job_tail(odo_depth* d, DepthJob* j) {
-  hipStream_t s = d->ctx->stream;
+  hipStream_t s = depth_stream(d);
   const int run_lm = j->stage != 1 ? 1 : 0;
   hipLaunchKernelGGL(depth_finalize_kernel, dim3(kDlmBlocks), dim3(kDlmBlock), 0, s, run_lm, j->cols, d->d_pts, d->d_cnt,
                      d->d_matched, d->d_scratch, d->photo_th, d->min_depth, d->max_depth, j->val, j->dep, d->d_counts);
@@ -2501,7 +2514,7 @@ static int depth_job_tail(odo_depth* d, DepthJob* j) {
 static int depth_job_stats(odo_depth* d, DepthJob* j) {
   const int run_lm = j->stage != 1 ? 1 : 0;
   d->token++;
-  hipLaunchKernelGGL(depth_stats_kernel, dim3(1), dim3(kDlmBlock), 0, d->ctx->stream, run_lm, j->n_launches, d->d_counts,
+  hipLaunchKernelGGL(depth_stats_kernel, dim3(1), dim3(kDlmBlock), 0, depth_stream(d), run_lm, j->n_launches, d->d_counts,
                      d->d_lmstate, d->d_stats_map, d->d_prog + 4, d->token, j->persistent ? d->d_gave_up : (int*)nullptr);
   HIP_OK(hipGetLastError());
   return 0;
@@ -2510,7 +2523,7 @@ static int depth_job_stats(odo_depth* d, DepthJob* j) {
 // Returns 1 when the whole job has been enqueued, 0 when there is more to do (call again), -1 on error.
 // DepthOptimization + write-back in one persistent launch (depth_lm_persistent_kernel); depth_job_stats follows as for the step launches.
 static int depth_job_persistent(odo_depth* d, DepthJob* j) {
-  hipStream_t s = d->ctx->stream;
+  hipStream_t s = depth_stream(d);
   if ((++d->persist_epoch & 0xffu) == 0u)   // the pairs' tags carry the low byte of the epoch: cleared whenever it starts over
     HIP_OK(hipMemsetAsync(d->d_xbuf, 0, sizeof(unsigned long long) * 2 * kDlmBlocks * 2, s));
   DepthPersistArgs a;
@@ -2555,7 +2568,7 @@ static int depth_job_pump(odo_depth* d, DepthJob* j) {
       return 0;
     }
     j->waiting = false;
-    hipLaunchKernelGGL(depth_lm_step_kernel, dim3(kDlmBlocks), dim3(kDlmBlock), 0, d->ctx->stream, j->k, j->left, j->right,
+    hipLaunchKernelGGL(depth_lm_step_kernel, dim3(kDlmBlocks), dim3(kDlmBlock), 0, depth_stream(d), j->k, j->left, j->right,
                        j->cols, d->d_pts, d->d_cnt, d->d_d0, d->d_scratch, d->d_lmstate, d->d_part_e, d->d_part_n,
                        d->baseline, d->K.f0, d->huber_delta, d->lambda, d->precision, d->max_iters, d->d_prog);
     j->k++;
@@ -2609,11 +2622,22 @@ static int depth_finish(odo_depth* d, bool full_sync = true) {
   return 0;
 }
 
+// A whole job started ahead (odo_depth_compute_begin_dev) that nobody picked up: it is waited for — it owns the estimator's buffers
+// and its progress words — and its result dropped.
+static int depth_early_settle(odo_depth* d) {
+  if (!d->early.active) return 0;
+  d->early.active = 0;
+  HIP_OK(hipStreamWaitEvent(d->ctx->stream, d->prep_ev, 0));
+  (void)depth_finish(d, false);
+  return 0;
+}
+
 static int depth_host(odo_depth* d, const float* left, const float* right, int rows, int cols, uint8_t* val, float* disp,
                       float* dep, int stage) {
   if (!d || !left || !right || !val || !disp || !dep) return fail("depth: NULL arg");
   if (depth_check_size(d, rows, cols)) return -1;
   HIP_OK(hipSetDevice(d->ctx->device));
+  if (depth_early_settle(d)) return -1;
   if (depth_ensure(d, rows, cols)) return -1;
   hipStream_t s = d->ctx->stream;
   const size_t n = (size_t)rows * cols;
@@ -2651,6 +2675,7 @@ extern "C" int odo_depth_prepare_left_dev_marked(odo_depth* d, odo_ctx* side, co
   if (side->device != d->ctx->device) return fail("odo_depth_prepare_left_dev: the two contexts must be on one device");
   if (depth_check_size(d, rows, cols)) return -1;
   HIP_OK(hipSetDevice(d->ctx->device));
+  if (depth_early_settle(d)) return -1;
   if (d->prep_left) HIP_OK(hipStreamWaitEvent(side->stream, d->prep_ev, 0));   // (a prepared half nobody picked up: one at a time)
   if (depth_ensure(d, rows, cols)) return -1;
   // what produced left_dev (an upload), and the estimator's previous call, come first
@@ -2669,6 +2694,7 @@ extern "C" int odo_depth_compute_dev_stamped(odo_depth* d, const float* left_dev
   if (!d || !left_dev || !right_dev || !val_dev || !disp_dev || !dep_dev) return fail("depth: NULL arg");
   if (depth_check_size(d, rows, cols)) return -1;
   HIP_OK(hipSetDevice(d->ctx->device));
+  if (depth_early_settle(d)) return -1;
   if (depth_ensure(d, rows, cols)) return -1;
   if (depth_run(d, left_dev, right_dev, rows, cols, val_dev, disp_dev, dep_dev, 2, left_stamp)) return -1;
   int rc = depth_finish(d, false);
@@ -2678,11 +2704,62 @@ extern "C" int odo_depth_compute_dev_stamped(odo_depth* d, const float* left_dev
   }
   return rc == 0 ? 0 : -1;
 }
+// The whole of ComputeDepth(left, right) enqueued on `side`'s stream, without waiting: the call returns once the launches are out.
+// Returns 0: started; 1: not started (the depth LM would need host-paced step launches: persistent launch off / switched off);
+// -1: error. odo_depth_compute_end_dev with the same arguments collects it.
+extern "C" int odo_depth_compute_begin_dev(odo_depth* d, odo_ctx* side, const float* left_dev, const float* right_dev, int rows, int cols,
+                                           uint8_t* val_dev, float* disp_dev, float* dep_dev, unsigned long long left_stamp,
+                                           unsigned long long right_stamp, unsigned long mark) {
+  if (!d || !side || !left_dev || !right_dev || !val_dev || !disp_dev || !dep_dev || !left_stamp || !right_stamp)
+    return fail("odo_depth_compute_begin_dev: bad arg");
+  if (side->device != d->ctx->device) return fail("odo_depth_compute_begin_dev: the two contexts must be on one device");
+  if (depth_check_size(d, rows, cols)) return -1;
+  HIP_OK(hipSetDevice(d->ctx->device));
+  if (depth_early_settle(d)) return -1;
+  if (!(d->persist && !d->persist_off_once && d->max_iters <= kDpMaxIters)) return 1;
+  if (d->prep_left) { HIP_OK(hipStreamWaitEvent(side->stream, d->prep_ev, 0)); d->prep_left = nullptr; }
+  if (depth_ensure(d, rows, cols)) return -1;
+  // what produced the two images and the three blocks, and the estimator's previous call, come first
+  if (mark ? odo_ctx_stream_wait_mark(side, d->ctx, mark) : odo_ctx_stream_wait(side, d->ctx)) return -1;
+  d->job_stream = side->stream;
+  const int rc = depth_run(d, left_dev, right_dev, rows, cols, val_dev, disp_dev, dep_dev, 2);
+  d->job_stream = nullptr;
+  if (rc) return -1;
+  HIP_OK(hipEventRecord(d->prep_ev, side->stream));
+  d->early.active = 1;
+  d->early.left = left_dev; d->early.right = right_dev; d->early.left_stamp = left_stamp; d->early.right_stamp = right_stamp;
+  d->early.rows = rows; d->early.cols = cols; d->early.val = val_dev; d->early.disp = disp_dev; d->early.dep = dep_dev;
+  return 0;
+}
+// ComputeDepth on device pointers with both images' content stamps: the job started ahead with exactly these arguments is waited for
+// (the estimator's stream is ordered behind it); anything else — nothing started, other images, other blocks — is computed now.
+// Same results either way (same launches, earlier).
+extern "C" int odo_depth_compute_end_dev(odo_depth* d, const float* left_dev, const float* right_dev, int rows, int cols,
+                                         uint8_t* val_dev, float* disp_dev, float* dep_dev, unsigned long long left_stamp,
+                                         unsigned long long right_stamp) {
+  if (!d || !left_dev || !right_dev || !val_dev || !disp_dev || !dep_dev) return fail("depth: NULL arg");
+  const odo_depth::Early& e = d->early;
+  if (!(e.active && left_stamp && right_stamp && e.left == left_dev && e.right == right_dev && e.left_stamp == left_stamp &&
+        e.right_stamp == right_stamp && e.rows == rows && e.cols == cols && e.val == val_dev && e.disp == disp_dev && e.dep == dep_dev))
+    return odo_depth_compute_dev_stamped(d, left_dev, right_dev, rows, cols, val_dev, disp_dev, dep_dev, left_stamp);
+  HIP_OK(hipSetDevice(d->ctx->device));
+  d->early.active = 0;
+  HIP_OK(hipStreamWaitEvent(d->ctx->stream, d->prep_ev, 0));
+  int rc = depth_finish(d, false);
+  if (rc == 2) {   // the persistent launch gave up: the same job again on the step launches, on the estimator's own stream
+    if (depth_run(d, left_dev, right_dev, rows, cols, val_dev, disp_dev, dep_dev, 2)) return -1;
+    rc = depth_finish(d, false);
+  }
+  return rc == 0 ? 0 : -1;
+}
+// 1 while a job started by odo_depth_compute_begin_dev has not been collected.
+extern "C" int odo_depth_early_pending(const odo_depth* d) { return d && d->early.active ? 1 : 0; }
 extern "C" int odo_depth_compute_dev(odo_depth* d, const float* left_dev, const float* right_dev, int rows, int cols,
                                      uint8_t* val_dev, float* disp_dev, float* dep_dev) {
   if (!d || !left_dev || !right_dev || !val_dev || !disp_dev || !dep_dev) return fail("depth: NULL arg");
   if (depth_check_size(d, rows, cols)) return -1;
   HIP_OK(hipSetDevice(d->ctx->device));
+  if (depth_early_settle(d)) return -1;
   if (depth_ensure(d, rows, cols)) return -1;
   if (depth_run(d, left_dev, right_dev, rows, cols, val_dev, disp_dev, dep_dev, 2)) return -1;
   // outputs stay on the device: only the statistics are needed back, and they arrive through host-mapped memory behind the

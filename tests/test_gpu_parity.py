@@ -331,6 +331,85 @@ def test_depth_lm_persistent_launch_and_its_fallback_give_the_same_depths(O, kit
         assert same(b, on[0])
 
 
+def test_compute_depth_started_ahead_on_another_stream_gives_the_same_outputs(kitti_seq, monkeypatch):
+    """odo_depth_compute_begin_dev / _end_dev (what the drop-in classes do beside the Solve): the whole ComputeDepth enqueued on a second
+    context's stream and collected later is bit-identical to odo_depth_compute_dev; a job collected with other stamps, or never
+    collected (the next plain call), is dropped and recomputed; with the persistent depth-LM launch off nothing is started; a
+    persistent launch that gives up inside a job started ahead is run again by the collecting call."""
+    from odometry_amd import api
+    ctx, side = api.default_context(), api.Context(0)
+    base = float(np.float32(386.1448) / np.float32(718.856))
+    rows, cols = kitti_seq["left"][0].shape
+    n = rows * cols
+
+    def outs():
+        return ctx.alloc(n), ctx.alloc(4 * n), ctx.alloc(4 * n)
+
+    def get(o):
+        return (ctx.download(o[0], (rows, cols), np.uint8), ctx.download(o[1], (rows, cols), np.float32),
+                ctx.download(o[2], (rows, cols), np.float32))
+
+    def make():
+        return api.DepthEstimator(8.0, 900.0, 15.0, 0.1, 30.0, 0.01, 28.0, 0.995, 50, 4, None, None, base, 80000)
+
+    de = make()
+    frames = [(ctx.upload(kitti_seq["left"][k]), ctx.upload(kitti_seq["right"][k])) for k in (1, 2)]
+    ref = []
+    for l, r in frames:
+        o = outs()
+        assert de.compute_dev(l, r, rows, cols, *o) == 0
+        ref.append((get(o), de.report()))
+    ctx.synchronize()
+
+    def check(o, k):
+        got = get(o)
+        assert all(np.array_equal(a, b) for a, b in zip(got, ref[k][0])) and de.report() == ref[k][1]
+
+    # started ahead, collected with the same arguments
+    for k, (l, r) in enumerate(frames):
+        o = outs()
+        assert de.compute_begin_dev(side, l, r, rows, cols, *o, 11 + k, 21 + k) == 0 and de.early_pending()
+        assert de.compute_end_dev(l, r, rows, cols, *o, 11 + k, 21 + k) == 0 and not de.early_pending()
+        check(o, k)
+    # started for frame 0, collected for frame 1 (other images): dropped, frame 1 computed now
+    o0, o1 = outs(), outs()
+    assert de.compute_begin_dev(side, *frames[0], rows, cols, *o0, 31, 32) == 0
+    assert de.compute_end_dev(*frames[1], rows, cols, *o1, 33, 34) == 0 and not de.early_pending()
+    check(o1, 1)
+    # the same images under another stamp (the Mat was refilled in between): dropped as well
+    o2 = outs()
+    assert de.compute_begin_dev(side, *frames[0], rows, cols, *o0, 41, 42) == 0
+    assert de.compute_end_dev(*frames[0], rows, cols, *o2, 41, 43) == 0
+    check(o2, 0)
+    # never collected: the next plain call drops it
+    assert de.compute_begin_dev(side, *frames[1], rows, cols, *o0, 51, 52) == 0
+    assert de.compute_dev(*frames[0], rows, cols, *o2) == 0 and not de.early_pending()
+    check(o2, 0)
+    ps = de.persistent_stats()
+    de.close()
+    assert ps == (1, 0)
+    # persistent depth-LM launch off: nothing is started (the step launches are paced by the host)
+    monkeypatch.setenv("ODO_DEPTH_NO_PERSIST", "1")
+    de = make()
+    o = outs()
+    assert de.compute_begin_dev(side, *frames[0], rows, cols, *o, 61, 62) == 1 and not de.early_pending()
+    assert de.compute_end_dev(*frames[0], rows, cols, *o, 61, 62) == 0
+    check(o, 0)
+    de.close()
+    monkeypatch.delenv("ODO_DEPTH_NO_PERSIST")
+    # a launch that gives up inside the job started ahead: the collecting call runs the job again on the step launches
+    monkeypatch.setenv("ODO_DEPTH_PERSIST_FAULT", "1")
+    de = make()
+    o = outs()
+    assert de.compute_begin_dev(side, *frames[1], rows, cols, *o, 71, 72) == 0
+    assert de.compute_end_dev(*frames[1], rows, cols, *o, 71, 72) == 0
+    check(o, 1)
+    assert de.persistent_stats()[1] == 1
+    de.close()
+    monkeypatch.delenv("ODO_DEPTH_PERSIST_FAULT")
+    side.close()
+
+
 def test_compute_depth_size_guard(api):
     de = _depth_est(api)
     val, disp, dep = _bufs((480, 640))

@@ -81,6 +81,13 @@ def test_shim_poses_bit_identical_to_tracker(tmp_path):
         T = trk.track(*dev[k])["pose_to_keyframe"]
         assert np.array_equal(T, got[k - 1]), f"frame {k}"
     trk.close()
+    # what the classes start ahead of the call that needs it (the partner's upload, ComputeDepth beside the Solve, the shared
+    # :205 / :251 pyramid) changes nothing: the same poses with all of it switched off
+    rel_off = str(tmp_path / "rel_off.bin")
+    out = subprocess.run([exe, frames, "--time", "1", "--rel-bin", rel_off], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, ODOMETRY_SHIM_NO_LOOKAHEAD="1"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert np.array_equal(np.fromfile(rel_off, np.float32), np.fromfile(rel, np.float32))
 
 
 _CV_FLAGS = ["-DODOMETRY_SHIM_WITH_OPENCV", "-DODOMETRY_SHIM_WITH_EIGEN", "-I" + os.path.join(ROOT, "tests", "stubs")]

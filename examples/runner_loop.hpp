@@ -2,6 +2,7 @@
 // include/odometry_shim.hpp: same classes, constructor arguments and call order. Shared by the synthetic-data example
 // and the KITTI example. Fills `pred` with the absolute 3x4 pose of every frame (row-major, frame 0 = `pose0`).
 #pragma once
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <tuple>
@@ -41,6 +42,7 @@ inline int track_sequence(const std::vector<Mat>& left, const std::vector<Mat>& 
                           std::vector<io::Pose34>& pred, bool verbose = true, std::vector<Affine4f>* rel = nullptr) {
   const unsigned num_frames = (unsigned)left.size();
   const unsigned num_pyramid = 4;
+  const auto t_setup = std::chrono::steady_clock::now();
   const float baseline = 386.1448f / 718.856f;                          // :41
   std::shared_ptr<CameraPyramid> left_cam_ptr = nullptr, right_cam_ptr = nullptr;  // :51-52
 
@@ -70,22 +72,40 @@ inline int track_sequence(const std::vector<Mat>& left, const std::vector<Mat>& 
   keyframe_poses_abs.emplace_back(cur_pose);
   const float w[6] = {0.1f / 3.3f, 1.0f / 3.3f, 0.1f / 3.3f, 1.0f / 3.3f, 0.1f / 3.3f, 1.0f / 3.3f};  // :144-145
 
+  // ODO_RUNNER_PHASES=1: host time per phase of the frame loop, mean over the frames, on stderr (diagnostic)
+  const bool phases = std::getenv("ODO_RUNNER_PHASES") != nullptr;
+  const double setup_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_setup).count();
+  double ph[7] = {0, 0, 0, 0, 0, 0, 0};
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto lap = [&](std::chrono::steady_clock::time_point& t0, int i) {
+    if (!phases) return;
+    const auto t1 = now();
+    ph[i] += std::chrono::duration<double, std::micro>(t1 - t0).count();
+    t0 = t1;
+  };
   for (unsigned frame_id = 1; frame_id < num_frames; frame_id++) {     // :198
+    auto tp = now();
+    {
     ImagePyramid cur_img_pyramid(num_pyramid, left[frame_id], true);   // :205
+    lap(tp, 0);
     pose_to_keyframe = pose_estimator.Solve(std::get<0>(keyframes[current_kf]), std::get<1>(keyframes[current_kf]),
                                             cur_img_pyramid);          // :215
+    lap(tp, 1);
     cur_pose = mul(keyframe_poses_abs[current_kf], rigid_inverse(pose_to_keyframe));  // :218
 
     Mat cur_left_val(left[0].rows, left[0].cols, CV_8U, init_val), cur_left_disp(left[0].rows, left[0].cols, PixelType),
         cur_left_dep(left[0].rows, left[0].cols, PixelType);
+    lap(tp, 2);
     if (depth_estimator.ComputeDepth(left[frame_id], right[frame_id], cur_left_val, cur_left_disp, cur_left_dep) == -1) {
       std::cout << "    depth failed!" << std::endl;                   // :230-232
       break;
     }
+    lap(tp, 3);
     delete pre_img_pyramid_ptr;
     delete pre_dep_pyramid_ptr;
     pre_img_pyramid_ptr = new ImagePyramid(num_pyramid, left[frame_id], true);       // :251
     pre_dep_pyramid_ptr = new DepthPyramid(num_pyramid, cur_left_dep, false);        // :252
+    lap(tp, 4);
 
     // :253-257 weighted motion; angles as Sophus SO3::angleX/Y/Z reduce to for a rotation matrix
     const Affine4f& T = pose_to_keyframe;
@@ -106,6 +126,14 @@ inline int track_sequence(const std::vector<Mat>& left, const std::vector<Mat>& 
     if (verbose)
       std::printf("frame %u kf %u motion %.4f  t = [% .5f % .5f % .5f]\n", frame_id, current_kf, motion_mag, cur_pose(0, 3),
                   cur_pose(1, 3), cur_pose(2, 3));
+    lap(tp, 5);
+    }
+    lap(tp, 6);
+  }
+  if (phases && num_frames > 1) {
+    const double n = num_frames - 1;
+    std::fprintf(stderr, "[runner phases] ImagePyramid :205 %.1f  Solve :215 %.1f  pose + output Mats %.1f  ComputeDepth :229 %.1f  "
+                 "pyramids :251-252 %.1f  keyframe test + Reset %.1f  end of the frame's scope %.1f us per frame; constructors + frame 0: %.0f us once\n", ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ph[5] / n, ph[6] / n, setup_us);
   }
   delete pre_img_pyramid_ptr;
   delete pre_dep_pyramid_ptr;

@@ -547,11 +547,16 @@ struct Lookahead {
   std::weak_ptr<MatBuf> last_left, last_right;   // the pair of the last ComputeDepth
   odo_depth* estimator = nullptr;                // the DepthEstimator of this thread (the last one constructed)
   int est_rows = 0, est_cols = 0;                // the frame size it was last used with
-  struct Entry { unsigned long long stamp; int levels, smooth, kind; std::weak_ptr<struct PyrHandle> h; };
-  Entry cache[4];
+  struct Entry { unsigned long long stamp; int levels, smooth, kind; std::weak_ptr<struct PyrHandle> h; bool on_side; };
+  Entry cache[4] = {};
+  std::shared_ptr<struct PyrHandle> ahead_pyr;   // the next frame's image pyramid, built ahead on the side stream
+  unsigned long long recorded_stamp = 0;         // the image content the pending lookahead was recorded for
+  int pending_levels = 0, pending_smooth = 0;
   int cache_next = 0;
   std::weak_ptr<MatBuf> pending_left;            // the left image ImagePyramid was just built from: its lookahead is still to be issued
   std::weak_ptr<MatBuf> pending_partner;         // ... and the guessed right image (mirror block reserved)
+  std::weak_ptr<MatBuf> pending_next;            // ... and the guessed NEXT left image (the same-sized Mat created right after the partner)
+  const MatBuf* next_guess_was = nullptr;        // what the previous frame's guess named (compared, never dereferenced)
   int pending_rows = 0, pending_cols = 0;
   unsigned long pending_mark = 0;                // the main stream's fill level then (odo_ctx_mark): the side stream goes behind THAT
 };
@@ -582,8 +587,8 @@ inline void early_reserve(int rows, int cols) {
 // of host work must not sit in front of it), else by the next ComputeDepth.
 inline void run_lookahead() {
   Lookahead& la = lookahead();
-  std::shared_ptr<MatBuf> lb = la.pending_left.lock(), guess = la.pending_partner.lock();
-  la.pending_left.reset(); la.pending_partner.reset();
+  std::shared_ptr<MatBuf> lb = la.pending_left.lock(), guess = la.pending_partner.lock(), nxt = la.pending_next.lock();
+  la.pending_left.reset(); la.pending_partner.reset(); la.pending_next.reset();
   if (!la.on || !lb || !la.pending_mark) return;
   if (odo_ctx_stream_wait_mark(side_context(), context(), la.pending_mark) != 0) return;
   // the stereo partner's upload, on the side stream
@@ -602,11 +607,59 @@ inline void run_lookahead() {
                                     la.pending_mark) == 0) {
       e.started = true; e.est = la.estimator;
       e.left_dev = lb->dev; e.right_dev = guess->dev; e.left_stamp = lb->stamp; e.right_stamp = guess->stamp;
-      return;
+    } else {
+      (void)odo_depth_prepare_left_dev_marked(la.estimator, side_context(), static_cast<const float*>(lb->dev), la.pending_rows,
+                                              la.pending_cols, lb->stamp, la.pending_mark);
     }
-    (void)odo_depth_prepare_left_dev_marked(la.estimator, side_context(), static_cast<const float*>(lb->dev), la.pending_rows,
-                                            la.pending_cols, lb->stamp, la.pending_mark);
   }
+  // the NEXT frame's left image follows on the side stream, behind this frame's ComputeDepth: it crosses PCIe while the Solve still
+  // runs instead of in front of the next ImagePyramid — and its pyramid is built there too (the next ImagePyramid of the same
+  // content, levels and smoothing finds it in the cache)
+  if (nxt && nxt.get() != lb.get() && nxt.get() != guess.get()) {
+    prefetch_to_device(nxt);
+    static const bool ahead_pyr_on = std::getenv("ODOMETRY_SHIM_NO_AHEAD_PYRAMID") == nullptr;
+    if (ahead_pyr_on && nxt->dev && nxt->dev_valid && nxt->side_pending && la.pending_levels > 0) {
+      auto h = std::make_shared<PyrHandle>();
+      h->host.resize(la.pending_levels);
+      h->have.assign(la.pending_levels, 0);
+      if (odo_pyramid_create_dev(side_context(), static_cast<const float*>(nxt->dev), la.pending_rows, la.pending_cols, la.pending_levels,
+                                 la.pending_smooth, ODO_PYR_IMAGE, &h->p) == 0) {
+        Lookahead::Entry& ce = la.cache[la.cache_next++ % 4];
+        ce.stamp = nxt->stamp; ce.levels = la.pending_levels; ce.smooth = la.pending_smooth; ce.kind = ODO_PYR_IMAGE; ce.h = h;
+        ce.on_side = true;
+        la.ahead_pyr = h;   // (kept alive until the next ImagePyramid has had its chance)
+      }
+    }
+  }
+}
+// What ImagePyramid's constructor records for the Solve that follows (run_lookahead issues it): once per image content.
+inline void record_lookahead(const Mat& in, int num_levels, bool smooth) {
+  Lookahead& la = lookahead();
+  const std::shared_ptr<MatBuf>& lb = in.buffer();
+  if (!lb || la.recorded_stamp == lb->stamp) return;   // (:251 builds the pyramid of the :205 image again)
+  la.recorded_stamp = lb->stamp;
+  la.pending_left = lb; la.pending_rows = in.rows; la.pending_cols = in.cols;
+  la.pending_levels = num_levels; la.pending_smooth = smooth ? 1 : 0;
+  // the partner guess: the Mat ComputeDepth was given with this one last time, else the same-sized Mat created right after it
+  std::shared_ptr<MatBuf> guess;
+  if (la.last_left.lock().get() == lb.get()) guess = la.last_right.lock();
+  else if (lb->next && lb->next->bytes == lb->bytes) guess = lb->next->shared_from_this();
+  if (guess && guess.get() != lb.get()) prefetch_reserve(guess);
+  la.pending_partner = guess;
+  // the next frame's left image: a sequence read into Mats pair by pair (ref: :334-359) has it right behind the partner
+  std::shared_ptr<MatBuf> nxt;
+  if (guess && guess.get() != lb.get() && guess->next && guess->next != lb.get() && guess->next->bytes == lb->bytes)
+    nxt = guess->next->shared_from_this();
+  // ... but only once the guess has proved right: this left image IS what the previous frame's guess named (a runner that
+  // refills two Mats per frame, ref: :200, never gets there — the same-sized Mat behind its partner is something else)
+  const bool proven = la.next_guess_was == lb.get();
+  la.next_guess_was = nxt.get();
+  if (nxt && proven) prefetch_reserve(nxt); else nxt.reset();
+  la.pending_next = nxt;
+  // ... and the three output blocks of a ComputeDepth started ahead (recycled blocks: their earlier use is in front of the mark)
+  if (la.estimator && in.rows == la.est_rows && in.cols == la.est_cols && guess && guess.get() != lb.get()) early_reserve(in.rows, in.cols);
+  else early_release();
+  la.pending_mark = odo_ctx_mark(context());
 }
 #endif
 inline std::shared_ptr<PyrHandle> make_pyr(int num_levels, const Mat& in, bool smooth, int kind, const char* what) {
@@ -616,7 +669,19 @@ inline std::shared_ptr<PyrHandle> make_pyr(int num_levels, const Mat& in, bool s
   if (la.on && stamp)
     for (auto& e : la.cache)
       if (e.stamp == stamp && e.levels == num_levels && e.smooth == (smooth ? 1 : 0) && e.kind == kind)
-        if (auto hit = e.h.lock()) return hit;   // :251 after :205: the same image, the same arithmetic — the same device pyramid
+        if (auto hit = e.h.lock()) {
+          // :251 after :205: the same image, the same arithmetic — the same device pyramid; or the pyramid built ahead on the side
+          // stream during the previous frame's Solve (the main stream goes behind it: the image's upload and the pyramid kernel)
+          if (e.on_side) {
+            odo_ctx_stream_wait(context(), side_context());
+            e.on_side = false;
+            if (in.buffer()) in.buffer()->side_pending = false;
+          }
+          if (la.ahead_pyr.get() == hit.get()) la.ahead_pyr.reset();
+          if (kind == ODO_PYR_IMAGE) record_lookahead(in, num_levels, smooth);
+          return hit;
+        }
+  if (kind == ODO_PYR_IMAGE) la.ahead_pyr.reset();   // (a pyramid built ahead for an image that did not come)
 #endif
   auto h = std::make_shared<PyrHandle>();
   h->host.resize(num_levels > 0 ? num_levels : 0);
@@ -635,21 +700,8 @@ inline std::shared_ptr<PyrHandle> make_pyr(int num_levels, const Mat& in, bool s
 #ifndef ODOMETRY_SHIM_WITH_OPENCV
   if (ok && la.on) {
     Lookahead::Entry& e = la.cache[la.cache_next++ % 4];
-    e.stamp = in.content_stamp(); e.levels = num_levels; e.smooth = smooth ? 1 : 0; e.kind = kind; e.h = h;
-    if (kind == ODO_PYR_IMAGE && in.buffer()) {
-      const std::shared_ptr<MatBuf>& lb = in.buffer();
-      la.pending_left = lb; la.pending_rows = in.rows; la.pending_cols = in.cols;
-      // the partner guess: the Mat ComputeDepth was given with this one last time, else the same-sized Mat created right after it
-      std::shared_ptr<MatBuf> guess;
-      if (la.last_left.lock().get() == lb.get()) guess = la.last_right.lock();
-      else if (lb->next && lb->next->bytes == lb->bytes) guess = lb->next->shared_from_this();
-      if (guess && guess.get() != lb.get()) prefetch_reserve(guess);
-      la.pending_partner = guess;
-      // ... and the three output blocks of a ComputeDepth started ahead (recycled blocks: their earlier use is in front of the mark)
-      if (la.estimator && in.rows == la.est_rows && in.cols == la.est_cols && guess && guess.get() != lb.get()) early_reserve(in.rows, in.cols);
-      else early_release();
-      la.pending_mark = odo_ctx_mark(context());
-    }
+    e.stamp = in.content_stamp(); e.levels = num_levels; e.smooth = smooth ? 1 : 0; e.kind = kind; e.h = h; e.on_side = false;
+    if (kind == ODO_PYR_IMAGE) record_lookahead(in, num_levels, smooth);
   }
 #endif
   return h;

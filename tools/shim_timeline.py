@@ -23,11 +23,14 @@ def main():
     starts = []
     for i in coarse:
         j = i
-        while j > 0 and not (ops[j][2].startswith("PCIe") and "image_pyramid" in ops[j + 1][2]):
+        while j > 0 and "image_pyramid" not in ops[j][2]:
+            j -= 1
+        # (the left image's upload sits right in front of the pyramid on the same stream unless it was sent ahead on the side stream)
+        if j > 0 and ops[j - 1][2].startswith("PCIe") and ops[j - 1][3] == ops[j][3]:
             j -= 1
         starts.append(j)
     frames = [ops[a:b] for a, b in zip(starts[:-1], starts[1:])]
-    main_stream = frames[0][0][3]
+    main_stream = ops[coarse[0]][3]
     agg = defaultdict(lambda: [0.0, 0.0, 0, ""])
     period = idle = 0.0
     for fr, nxt in zip(frames, starts[1:]):

@@ -1231,7 +1231,10 @@ __device__ __forceinline__ void lm_fused_prologue(const LmState* __restrict__ st
   if (init) {
     if (t == 0) {
       float m[16];
-      if (init_dev) { for (int i = 0; i < 16; i++) m[i] = init_dev[i]; }
+      // (the device-side pose through atomic loads: plain loads would let the compiler fold the two sources into ONE pointer —
+      //  kernel-argument address or global — and a by-value kernel argument whose address is taken that way is mirrored in scratch
+      //  memory: 1 032 B per lane in lm_step_kernel, launches 7.8 -> 18 us)
+      if (init_dev) { for (int i = 0; i < 16; i++) m[i] = __hip_atomic_load(init_dev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
       else { for (int i = 0; i < 16; i++) m[i] = init[i]; }
       lm_begin_solve(&s_sh, m);
       s_sh.level = -1; s_sh.iter = 0; s_sh.lambda = 0.0f; s_sh.err_last = 1e+10f;
@@ -1358,7 +1361,7 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const StepLaunch
   const bool publisher = (blockIdx.x == gridDim.x - 1);
   if (a.dbg && publisher && threadIdx.x == 0 && q.seq < 56) a.dbg[16 + 2 * q.seq] = wall_clock64();  // diagnostic timeline
   lm_fused_prologue(q.st_in, q.part_in, a.lv, a.n_levels, a.lambda0, a.precision, s_sh, fold_sh, acc_sh, a.trace, a.cost_stat,
-                    publisher, q.first_of_solve ? a.init : nullptr, a.stop_level, a.chain_in_token ? a.chain_pose : nullptr);
+                    publisher, q.first_of_solve ? a.init : nullptr, a.stop_level);   // (a chained Solve has no step launches: lm_chain_begin)
   const bool run = (s_sh.active != 0 && s_sh.status == 0);  // block-uniform
   const int lvl = run ? s_sh.level : 0;
   const StepLevel& L = a.lv[lvl];

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Per-frame timeline of the drop-in path from a rocprofv3 kernel trace + memory-copy trace of examples/run_odometry_synth.
 
-A frame of the runner's loop (ref: run_odometry_kitti_offline.cpp:198-271) is cut at its pose-LM coarse launch; the frames of the
-LAST pass (the timed one) are averaged: for every operation of a frame its mean start offset from the frame's first operation (the
-left image's upload), its mean duration and its stream (operations on different streams overlap), then the gaps on the main
-stream — device idle while the host turns around — and the frame period."""
+A frame of the runner's loop (ref: run_odometry_kitti_offline.cpp:198-271) is cut at the START of its pose-LM coarse launch; the
+frames of the LAST pass (the timed one) are averaged: for every operation of a cycle its mean start offset from that point, its mean
+duration and its stream (operations on different streams overlap; what the classes start ahead for the NEXT frame shows up at the
+end of the cycle), then the gaps on the main stream — device idle while the host turns around — and the frame period."""
 import csv
 import sys
 from collections import defaultdict
@@ -19,16 +19,9 @@ def main():
         ops.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "PCIe upload (1.9 MB)", r.get("Stream_Id", "")))
     ops.sort()
     coarse = [i for i, o in enumerate(ops) if o[2] == "lm_coarse_kernel"][-(n - 1):]
-    # a frame starts with the upload in front of its image pyramid: walk back from the coarse launch to that copy
-    starts = []
-    for i in coarse:
-        j = i
-        while j > 0 and "image_pyramid" not in ops[j][2]:
-            j -= 1
-        # (the left image's upload sits right in front of the pyramid on the same stream unless it was sent ahead on the side stream)
-        if j > 0 and ops[j - 1][2].startswith("PCIe") and ops[j - 1][3] == ops[j][3]:
-            j -= 1
-        starts.append(j)
+    # the cycle is cut at the start of each Solve's coarse launch (the main stream's first operation of a frame that cannot move:
+    # uploads and pyramids may run ahead on the side stream, i.e. at the END of the previous cycle)
+    starts = list(coarse)
     frames = [ops[a:b] for a, b in zip(starts[:-1], starts[1:])]
     main_stream = ops[coarse[0]][3]
     agg = defaultdict(lambda: [0.0, 0.0, 0, ""])

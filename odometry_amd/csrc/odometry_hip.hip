@@ -2383,7 +2383,11 @@ extern "C" int odo_depth_create(odo_ctx* ctx, float grad_th, float ssd_th, float
   d->persist = d->persist_cfg = getenv("ODO_DEPTH_NO_PERSIST") ? 0 : 1;
   d->persist_fault = getenv("ODO_DEPTH_PERSIST_FAULT") ? 1 : 0;
   d->persist_home = next_home_xcd(ctx->device);
-  d->persist_wait = getenv("ODO_LM_FINE_WAIT_US") ? (unsigned)(100L * atol(getenv("ODO_LM_FINE_WAIT_US"))) : 0u;
+  // Wait bound of the persistent depth launch: 0.5 ms of the 100 MHz device clock (a whole depth LM is 70-100 us). Deliberately
+  // SHORTER than the pose LM's (4 ms): the two persistent kernels cannot share a CU (416 + 160 VGPRs per SIMD), so when both are
+  // partially resident on one XCD each holds CUs the other is waiting for — seen ~ once in 4 000 frames of a 100 000-frame soak —
+  // and the one that is NOT the frame's critical chain must be the one that yields, quickly.
+  d->persist_wait = getenv("ODO_DEPTH_WAIT_US") ? (unsigned)(100L * atol(getenv("ODO_DEPTH_WAIT_US"))) : 50000u;
   HIP_OK(hipMalloc((void**)&d->d_xbuf, sizeof(unsigned long long) * kDpXbufWords));
   HIP_OK(hipMemset(d->d_xbuf, 0, sizeof(unsigned long long) * kDpXbufWords));
   HIP_OK(hipMalloc((void**)&d->d_gave_up, sizeof(int)));

@@ -90,6 +90,40 @@ def test_shim_poses_bit_identical_to_tracker(tmp_path):
     assert np.array_equal(np.fromfile(rel_off, np.float32), np.fromfile(rel, np.float32))
 
 
+def test_lookahead_survives_refilled_swapped_and_poked_mats(tmp_path):
+    """What the drop-in classes start ahead (the partner's upload, the whole ComputeDepth, the next frame's upload and pyramid) is keyed
+    by content stamps: two Mats refilled per frame like the reference's load_data, the two Mats swapping roles every frame, and a right
+    image modified between Solve and ComputeDepth all give the poses and depth outputs of a run with the look-ahead switched off,
+    bit for bit — and the refilled runs give those of the run with every frame in its own Mat."""
+    from odometry_amd import synth
+    seq = synth.make_sequence(10, seed=3)
+    L, R = seq["left"], seq["right"]
+    frames = str(tmp_path / "frames.bin")
+    with open(frames, "wb") as f:
+        np.array([len(L), L[0].shape[0], L[0].shape[1]], np.int32).tofile(f)
+        for l, r in zip(L, R):
+            l.astype(np.float32).tofile(f)
+            r.astype(np.float32).tofile(f)
+    exe = _build(tmp_path, "tests/shim_lookahead_harness.cpp", "shim_lookahead_harness")
+
+    def run(mode, off):
+        env = dict(os.environ)
+        if off:
+            env["ODOMETRY_SHIM_NO_LOOKAHEAD"] = "1"
+        out = subprocess.run([exe, frames, mode], capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        lines = out.stdout.strip().splitlines()
+        assert len(lines) == len(L) and all(ln.split()[1] == "0" for ln in lines), out.stdout[-2000:]
+        return lines
+
+    base = run("vector", True)
+    for mode in ("vector", "refill", "swap"):
+        assert run(mode, False) == base, mode
+    assert run("refill", True) == base and run("swap", True) == base
+    poked = run("poke", True)
+    assert poked != base and run("poke", False) == poked
+
+
 _CV_FLAGS = ["-DODOMETRY_SHIM_WITH_OPENCV", "-DODOMETRY_SHIM_WITH_EIGEN", "-I" + os.path.join(ROOT, "tests", "stubs")]
 
 

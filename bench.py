@@ -196,6 +196,24 @@ def dense_1080p_leg(api, synth, n_frames=5, passes=3):
                      O.image_pyramid(imgs[1], 4, False, flat=True), 1080, 1920, O.lm_params(robust=1, K=KD))
     cpu_s = time.perf_counter() - tc
     dmax = float(np.abs(rec[0][0].astype(np.float64) - ref["pose"]).max())
+    # ---- the same pair with t-distribution weights (test_optimizer.cpp's own robust_estimator = 2): the scale of ALL residuals per
+    # evaluation, a fixed-point iteration over up to 2 M residuals (lm_tdist_scale_multi_kernel: <= 128 workgroups meet once per pass)
+    lm_t = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 2, 28.0, ctx=ctx, intrinsics=K)
+    pimg[0].rebuild_dev(d_img[0], False); pdep[0].rebuild_dev(d_inv[0], False); pimg[1].rebuild_dev(d_img[1], False)
+    tdist_ms = []
+    for _ in range(4):
+        lm_t.Reset(eye, 0.01)
+        ctx.synchronize()
+        tq = time.perf_counter()
+        T_t = lm_t.Solve(pimg[0], pdep[0], pimg[1])
+        tdist_ms.append((time.perf_counter() - tq) * 1e3)
+    tdist_evals = lm_t.launch_stats()[0]
+    tc = time.perf_counter()
+    ref_t = O.lm_solve(O.image_pyramid(imgs[0], 4, False, flat=True), O.depth_pyramid(invs[0], 4, flat=True),
+                       O.image_pyramid(imgs[1], 4, False, flat=True), 1080, 1920, O.lm_params(robust=2, K=KD))
+    tdist = dict(gpu_solve_ms=round(min(tdist_ms[1:]), 3), evaluations=int(tdist_evals), cpu_oracle_solve_ms=round((time.perf_counter() - tc) * 1e3, 1),
+                 pose_max_abs_delta_vs_oracle=float(np.abs(T_t.astype(np.float64) - ref_t["pose"]).max()))
+    lm_t.close()
     # ---- S streams in flight (odo_lm_solve_batch over dense pyramids): every evaluation / update launch carries all S of them
     # (blockIdx = stream). One 1080p level is too small to keep the chip busy for long (launch ramp + tail are a large part of
     # 18 us); S levels side by side move S times the bytes in one ramp. Per-level roofline of the batched evaluation kernel and the
@@ -265,6 +283,7 @@ def dense_1080p_leg(api, synth, n_frames=5, passes=3):
                 residuals=l0["residuals"], algorithmic_bytes=l0["algorithmic_bytes"], launch_us=l0["launch_us"],
                 launch_min_us=l0["launch_min_us"], achieved=l0["achieved"], frac=l0["frac"], per_level=levels,
                 cpu_oracle_solve_ms=round(cpu_s * 1e3, 1), pose_max_abs_delta_vs_oracle=dmax, batched=batched,
+                t_distribution_single_pair=tdist,
                 note="VALU-issue bound, not HBM bound: the parity arithmetic costs ~270 VALU instructions per pixel "
                      "(28 fp64 FMAs, 23 fp32<->fp64 conversions, 3 + 1 reciprocals); see DESIGN.md section 5.1")
 

@@ -885,8 +885,15 @@ constexpr int kTdistMaxPasses = 1000;   // the restatement's guard (a scale iter
 constexpr int kTdistChunksMax = 640;   // 64-point chunks of the largest point-list level (160 virtual blocks)
 __global__ void __launch_bounds__(1024) lm_tdist_scale_kernel(const float* __restrict__ res, int n,
                                                                const LmState* __restrict__ st, int expect_level,
-                                                               float* __restrict__ scale_sqr_out, int list_order) {
+                                                               float* __restrict__ scale_sqr_out, int list_order,
+                                                               int* __restrict__ only_if = nullptr) {
   if (!(st->active != 0 && st->level == expect_level)) return;
+  // only_if: the fall-back of lm_tdist_scale_multi_kernel — runs only when that launch gave up, and clears the flag
+  if (only_if) {
+    if (__hip_atomic_load(only_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+    __syncthreads();   // (every thread has read the flag)
+    if (threadIdx.x == 0) __hip_atomic_store(only_if, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   __shared__ double shs[1024];
   __shared__ int shn[1024];
   __shared__ float sh_sigma;
@@ -1669,6 +1676,103 @@ struct FineDeadline {
     return (spin & 31) == 31 && (unsigned long long)wall_clock64() - t0 > (unsigned long long)limit;
   }
 };
+// ComputeScaleNaive over a DENSE level (ref: src/lm_optimizer.cpp:338-358; up to 2 M residuals): the fixed-point iteration of
+// lm_tdist_scale_kernel spread over G <= 128 workgroups that keep their residuals in registers (<= 32 per thread) and meet once per
+// pass: every workgroup publishes the fp64 sum of its terms as tagged 8-byte granules (agent scope: the workgroups sit on all XCDs),
+// wave 0 of every workgroup gathers the G sums, folds them in a fixed order and hands sigma to its workgroup — every workgroup
+// computes the same sigma and the same convergence decision. One pass is one trip through the fabric (~3 us) instead of one
+// workgroup walking every residual (70-140 us at 1080p). Sums: per thread in ascending index, wave_sum64, the eight waves of a
+// workgroup in order, the workgroups g = lane, lane + 64 in order per lane, wave_sum64 — fixed for a given n (G depends on n only).
+// Every wait is bounded (wait_ticks of the 100 MHz clock): a launch whose workgroups cannot all be resident sets *gave_up and the
+// single-workgroup kernel, queued behind it with only_if = gave_up, does the level.
+constexpr int kTsThreads = 512, kTsPerThread = 32, kTsMaxWg = 128;
+constexpr int kTsXbufWords = 2 * kTsMaxWg * 4;   // [pass parity][workgroup]{sum hi | tag, sum lo | tag, count | tag, -}
+__global__ void __launch_bounds__(kTsThreads) lm_tdist_scale_multi_kernel(const float* __restrict__ res, int n,
+                                                                          const LmState* __restrict__ st, int expect_level,
+                                                                          float* __restrict__ scale_sqr_out,
+                                                                          unsigned long long* __restrict__ xbuf, unsigned epoch,
+                                                                          unsigned wait_ticks, int* __restrict__ gave_up, int fault) {
+  if (!(st->active != 0 && st->level == expect_level)) return;   // (the state does not change while this launch runs: grid-uniform)
+  const int G = gridDim.x, g = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const size_t stride = (size_t)G * kTsThreads;
+  float e2[kTsPerThread];
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < kTsPerThread; k++) {
+    const size_t i = (size_t)g * kTsThreads + t + (size_t)k * stride;
+    const float r = (i < (size_t)n) ? res[i] : __builtin_nanf("");
+    const bool ok = (r == r);
+    e2[k] = ok ? r * r : -1.0f;   // (a squared residual is never negative: < 0 marks "no residual")
+    cnt += ok ? 1 : 0;
+  }
+  __shared__ double wsum[kTsThreads / 64];
+  __shared__ double wcnt[kTsThreads / 64];
+  __shared__ float sh_sigma;
+  __shared__ int sh_done, sh_bail;
+  const unsigned wait_limit = wait_ticks ? wait_ticks : 400000u;
+  float cur = 5.0f;
+  double n_valid = 0.0;
+  for (int pass = 0; pass < kTdistMaxPasses; pass++) {
+    const float sigma_sqr = cur * cur;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < kTsPerThread; k++)
+      if (e2[k] >= 0.0f) s += (double)tdist_term(e2[k], sigma_sqr);
+    const double ws = wave_sum64(s);
+    if (pass == 0) {
+      const double wc = wave_sum64((double)cnt);
+      if (lane == 0) wcnt[wv] = wc;
+    }
+    if (lane == 0) wsum[wv] = ws;
+    __syncthreads();
+    if (t < 64) {
+      double P = 0.0, C = 0.0;
+#pragma unroll
+      for (int w = 0; w < kTsThreads / 64; w++) { P += wsum[w]; if (pass == 0) C += wcnt[w]; }
+      const unsigned tag = (epoch << 10) | (unsigned)(pass + 1);
+      unsigned long long* mine = xbuf + ((size_t)(pass & 1) * kTsMaxWg + g) * 4;
+      if (lane == 0 && !(fault && g == 1)) {   // (fault: test hook — workgroup 1 never publishes)
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(P);
+        __hip_atomic_store(mine + 0, ((bits >> 32) << 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 1, ((bits & 0xffffffffull) << 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 2, ((unsigned long long)(unsigned)(int)C << 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      double a = 0.0, c = 0.0;
+      bool all = true;
+      const FineDeadline dl = {(unsigned long long)wall_clock64(), wait_limit};
+      for (int gg = lane; gg < G; gg += 64) {
+        const unsigned long long* theirs = xbuf + ((size_t)(pass & 1) * kTsMaxWg + gg) * 4;
+        unsigned long long w0 = 0, w1 = 0, w2 = 0;
+        bool got = false;
+        for (int spin = 0; !got; spin++) {
+          w0 = __hip_atomic_load(theirs + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          w1 = __hip_atomic_load(theirs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          w2 = __hip_atomic_load(theirs + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          got = ((unsigned)w0 == tag) && ((unsigned)w1 == tag) && ((unsigned)w2 == tag);
+          if (!got && dl.expired(spin)) break;
+        }
+        all = all && got;
+        a += __longlong_as_double((long long)(((w0 >> 32) << 32) | (w1 >> 32)));
+        c += (double)(int)(unsigned)(w2 >> 32);
+      }
+      const bool everyone = __all(all);
+      const double total = wave_sum64(a);
+      if (pass == 0) n_valid = wave_sum64(c);
+      const float nxt = (n_valid > 0.0) ? tdist_next_sigma(total, (int)n_valid) : cur;
+      const bool done = !(n_valid > 0.0) || tdist_converged(nxt, cur);
+      if (lane == 0) { sh_sigma = nxt; sh_done = done ? 1 : 0; sh_bail = everyone ? 0 : 1; }
+    }
+    __syncthreads();
+    if (sh_bail) {   // a workgroup of this launch never published: the single-workgroup kernel behind this launch does the level
+      if (t == 0) __hip_atomic_store(gave_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    cur = sh_sigma;
+    if (sh_done) break;   // workgroup- and grid-uniform
+  }
+  if (g == 0 && t == 0) *scale_sqr_out = cur * cur;
+}
+
 constexpr int kFineThreads = 2 * kLmBlock;       // a workgroup works on TWO virtual blocks at a time, one per half
 constexpr int kFineKMax = 32;                     // workgroups of one launch: they wait for each other, so each needs a CU of the XCD (32) to itself
 // t-distribution scale passes (robust == 2): one fp64 sum per 64-point chunk (wave) and pass, double-buffered by pass parity,

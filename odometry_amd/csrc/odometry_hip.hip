@@ -618,6 +618,12 @@ struct odo_lm {
   float* d_res;   // t-dist residual buffer (lazy)
   size_t res_cap;
   float* d_scale;
+  unsigned long long* d_ts_xbuf;   // lm_tdist_scale_multi_kernel: exchange buffer (kTsXbufWords), launch epoch, give-up flag
+  int* d_ts_gave_up;
+  unsigned ts_epoch;
+  int ts_multi;                    // 0: ODO_TDIST_SINGLE=1 (the single-workgroup scale kernel for every level)
+  int ts_fault;                    // test hook (ODO_TDIST_MULTI_FAULT): a workgroup never publishes
+  unsigned ts_wait;                // wait bound in ticks of the 100 MHz clock (ODO_LM_FINE_WAIT_US), 0: 4 ms
   // host-mapped progress words the update kernel writes (early-exit polling)
   int* h_prog;
   int* d_prog;
@@ -731,6 +737,14 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
   HIP_OK(hipMalloc((void**)&m->d_trace, sizeof(LmTraceRow) * kTraceCap));
   m->d_cost = m->d_out + 26;
   HIP_OK(hipMalloc((void**)&m->d_scale, sizeof(float)));
+  HIP_OK(hipMalloc((void**)&m->d_ts_xbuf, sizeof(unsigned long long) * kTsXbufWords));
+  HIP_OK(hipMemset(m->d_ts_xbuf, 0, sizeof(unsigned long long) * kTsXbufWords));
+  HIP_OK(hipMalloc((void**)&m->d_ts_gave_up, sizeof(int)));
+  HIP_OK(hipMemset(m->d_ts_gave_up, 0, sizeof(int)));
+  m->ts_epoch = 0;
+  m->ts_multi = getenv("ODO_TDIST_SINGLE") ? 0 : 1;
+  m->ts_fault = getenv("ODO_TDIST_MULTI_FAULT") ? 1 : 0;
+  m->ts_wait = getenv("ODO_LM_FINE_WAIT_US") ? (unsigned)(100L * atol(getenv("ODO_LM_FINE_WAIT_US"))) : 0u;
   HIP_OK(hipHostMalloc((void**)&m->h_out, sizeof(float) * 48, hipHostMallocDefault));
   HIP_OK(hipHostMalloc((void**)&m->h_trace, sizeof(LmTraceRow) * kTraceCap, hipHostMallocDefault));
   m->h_cost = m->h_out + 26;
@@ -782,7 +796,7 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
 extern "C" int odo_lm_destroy(odo_lm* m) {
   if (!m) return 0;
   (void)hipStreamSynchronize(m->ctx->stream);
-  void* dv[] = {m->d_state, m->d_partials, m->d_xbuf, m->d_init, m->d_out, m->d_trace, m->d_scale, m->d_res, m->d_chain_pose,
+  void* dv[] = {m->d_state, m->d_partials, m->d_xbuf, m->d_init, m->d_out, m->d_trace, m->d_scale, m->d_res, m->d_chain_pose, m->d_ts_xbuf, m->d_ts_gave_up,
                 m->d_rowcnt, m->d_npts, m->cand[0].d_rowcnt, m->cand[0].d_npts, m->cand[1].d_rowcnt, m->cand[1].d_npts};
   for (void* q : dv) if (q) (void)hipFree(q);
   for (int l = 0; l < ODO_MAX_LEVELS; l++) {
@@ -984,6 +998,35 @@ static inline int lm_grid_for(const odo_lm* m, int level, int rows, int cols) {
   return lm_grid(rows, cols);
 }
 
+// ComputeScaleNaive over the n residuals in m->d_res (ref: src/lm_optimizer.cpp:338-358). Point-list levels of <= 64 *
+// kTdistChunksMax points: one workgroup in the fused kernels' summation order (the same sigma bit for bit on every pipeline).
+// Larger levels (dense: up to 2 M residuals): lm_tdist_scale_multi_kernel on up to 128 workgroups, with the single-workgroup
+// kernel queued behind it as its fall-back (a no-op unless the launch gave up).
+static void lm_launch_scale(odo_lm* m, int n, int level) {
+  hipStream_t s = m->ctx->stream;
+  if (n <= 64 * kTdistChunksMax) {
+    hipLaunchKernelGGL(lm_tdist_scale_kernel, dim3(1), dim3(1024), 0, s, m->d_res, n, m->ust, level, m->d_scale, 1, (int*)nullptr);
+    return;
+  }
+  const long per_wg = (long)kTsThreads * 8;   // eight residuals per thread until the grid is full
+  long G = (n + per_wg - 1) / per_wg;
+  if (G > kTsMaxWg) G = kTsMaxWg;
+  if (G < 2) G = 2;
+  const bool fits = (long)n <= G * kTsThreads * (long)kTsPerThread;
+  if (!m->ts_multi || !fits) {
+    hipLaunchKernelGGL(lm_tdist_scale_kernel, dim3(1), dim3(1024), 0, s, m->d_res, n, m->ust, level, m->d_scale, 0, (int*)nullptr);
+    return;
+  }
+  m->ts_epoch = (m->ts_epoch + 1) & 0x3fffffu;   // 22 bits beside the 10-bit pass number: cleared when it starts over
+  if (m->ts_epoch == 0) {
+    (void)hipMemsetAsync(m->d_ts_xbuf, 0, sizeof(unsigned long long) * kTsXbufWords, s);
+    m->ts_epoch = 1;
+  }
+  hipLaunchKernelGGL(lm_tdist_scale_multi_kernel, dim3((unsigned)G), dim3(kTsThreads), 0, s, m->d_res, n, m->ust, level, m->d_scale,
+                     m->d_ts_xbuf, m->ts_epoch, m->ts_wait, m->d_ts_gave_up, m->ts_fault);
+  hipLaunchKernelGGL(lm_tdist_scale_kernel, dim3(1), dim3(1024), 0, s, m->d_res, n, m->ust, level, m->d_scale, 0, m->d_ts_gave_up);
+}
+
 // One evaluation of the hot loop at the pose held in the device state.
 static void lm_launch_eval(odo_lm* m, const LevelView& v, const LevelK& k, int level, int nblk, hipEvent_t e0 = nullptr,
                            hipEvent_t e1 = nullptr) {
@@ -1003,8 +1046,7 @@ static void lm_launch_eval(odo_lm* m, const LevelView& v, const LevelK& k, int l
     if (m->robust == 2) {
       hipLaunchKernelGGL(lm_residual_only_list_kernel, dim3(nblk), dim3(kLmBlock), 0, s, m->pl[level], n, v.I2, v.rows,
                          v.cols, k, m->ust, level, m->d_res);
-      hipLaunchKernelGGL(lm_tdist_scale_kernel, dim3(1), dim3(1024), 0, s, m->d_res, n, m->ust, level, m->d_scale,
-                         n <= 64 * kTdistChunksMax ? 1 : 0);   // point-list levels: the fused kernels' summation order
+      lm_launch_scale(m, n, level);
     }
     hipLaunchKernelGGL(lm_residual_list_kernel, dim3(nblk), dim3(kLmBlock), 0, s, m->pl[level], n, v.I2, v.rows, v.cols, k,
                        m->ust, level, m->robust, m->huber_delta, m->d_scale, m->d_partials);
@@ -1013,8 +1055,7 @@ static void lm_launch_eval(odo_lm* m, const LevelView& v, const LevelK& k, int l
   if (m->robust == 2) {
     const int n = (v.rows - 8) * (v.cols - 8);
     hipLaunchKernelGGL(lm_residual_only_kernel, dim3(nblk), dim3(kLmBlock), 0, s, v, k, m->ust, level, m->d_res);
-    hipLaunchKernelGGL(lm_tdist_scale_kernel, dim3(1), dim3(1024), 0, s, m->d_res, n > 0 ? n : 0, m->ust, level,
-                       m->d_scale, 0);
+    lm_launch_scale(m, n > 0 ? n : 0, level);
   }
   launch_dense_eval(lm_dense_level(v, k, 0), m->ust, level, m->robust, m->huber_delta, m->d_scale, m->d_partials, s, nullptr,
                     nullptr, m->dense_plain_div);

@@ -78,6 +78,34 @@ def test_dense_1080p_solve_matches_oracle(api, O, scene, robust, handover, monke
     assert abs(T[2, 3] - gt[2, 3]) < 0.05
 
 
+@pytest.mark.parametrize("variant", ["multi", "single", "fault"])
+def test_dense_1080p_tdistribution_solve_matches_oracle(api, O, scene, variant, monkeypatch):
+    """t-distribution weights on dense levels (ref: src/lm_optimizer.cpp:257-261,338-358 at 2 M residuals): the scale iteration runs on
+    up to 128 workgroups that meet once per pass (lm_tdist_scale_multi_kernel), on one workgroup (ODO_TDIST_SINGLE=1: the fall-back),
+    and through that fall-back after a workgroup of the multi launch never published (ODO_TDIST_MULTI_FAULT=1): the oracle's trace
+    and pose every time."""
+    if variant == "single":
+        monkeypatch.setenv("ODO_TDIST_SINGLE", "1")
+    if variant == "fault":
+        monkeypatch.setenv("ODO_TDIST_MULTI_FAULT", "1")
+        monkeypatch.setenv("ODO_LM_FINE_WAIT_US", "300")
+    p0, d0, p1 = _pyrs(api, scene, 0, 1)
+    lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 2, 28.0, intrinsics=K)
+    T = lm.Solve(p0, d0, p1)
+    ref = O.lm_solve(O.image_pyramid(scene["left"][0], 4, False, flat=True), O.depth_pyramid(scene["inv"][0], 4, flat=True),
+                     O.image_pyramid(scene["left"][1], 4, False, flat=True), ROWS, COLS, O.lm_params(robust=2, K=KD))
+    assert lm.last_status == 0 and ref["status"] == 0
+    tr = lm.trace()
+    assert len(tr) == ref["n_evals"]
+    for a, b in zip(tr, ref["trace"]):
+        assert (a["level"], a["iter"], a["n_res"], a["accepted"], a["stop"]) == \
+               (b["level"], b["iter"], b["n_res"], b["accepted"], b["stop"])
+        assert abs(a["err"] - b["err"]) <= 1e-6 * abs(b["err"])
+    assert tr[-1]["level"] == 0 and max(t["n_res"] for t in tr) > 1.5e6
+    d = se3_log_norm(ref["pose"], T)
+    assert d < 1e-5, f"pose delta {d} vs oracle"
+
+
 def test_dense_1080p_stream_matches_oracle(api, O, scene):
     """Two consecutive frames tracked the way test_optimizer.cpp does (ref: :86-105): Solve(frame k-1 -> k), Reset to the
     identity; both poses against the oracle."""

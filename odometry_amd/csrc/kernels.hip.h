@@ -905,16 +905,27 @@ __global__ void __launch_bounds__(1024) lm_tdist_scale_kernel(const float* __res
     const int lane = t & 63, wv = t >> 6;
     const int nchunk = (n + 63) / 64;
     int n_valid = 0;
+    // the wave's residuals (chunks wv, wv + 16, ...) stay in registers for every pass: one trip to memory per launch, not per pass
+    constexpr int kPer = kTdistChunksMax / 16;
+    float e2[kPer];
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < kPer; u++) {
+      const int c = wv + 16 * u, i = 64 * c + lane;
+      const float r = (c < nchunk && i < n) ? res[i] : __builtin_nanf("");
+      const bool ok = (r == r);
+      e2[u] = ok ? r * r : -1.0f;   // (< 0: no residual)
+      cnt += __popcll(__ballot(ok));
+    }
     for (int pass = 0; pass < kTdistMaxPasses; pass++) {
       const float sigma_sqr = cur * cur;
-      int cnt = 0;
-      for (int c = wv; c < nchunk; c += 16) {
-        const int i = 64 * c + lane;
-        const float r = (i < n) ? res[i] : __builtin_nanf("");
-        const bool ok = (r == r);
-        const double ws = wave_sum64(ok ? (double)tdist_term(r * r, sigma_sqr) : 0.0);
-        if (lane == 0) part[c] = ws;
-        cnt += __popcll(__ballot(ok));
+#pragma unroll
+      for (int u = 0; u < kPer; u++) {
+        const int c = wv + 16 * u;
+        if (c < nchunk) {   // wave-uniform
+          const double ws = wave_sum64(e2[u] >= 0.0f ? (double)tdist_term(e2[u], sigma_sqr) : 0.0);
+          if (lane == 0) part[c] = ws;
+        }
       }
       if (pass == 0 && lane == 0) shn[wv] = cnt;
       __syncthreads();

@@ -998,13 +998,14 @@ static inline int lm_grid_for(const odo_lm* m, int level, int rows, int cols) {
   return lm_grid(rows, cols);
 }
 
-// ComputeScaleNaive over the n residuals in m->d_res (ref: src/lm_optimizer.cpp:338-358). Point-list levels of <= 64 *
-// kTdistChunksMax points: one workgroup in the fused kernels' summation order (the same sigma bit for bit on every pipeline).
-// Larger levels (dense: up to 2 M residuals): lm_tdist_scale_multi_kernel on up to 128 workgroups, with the single-workgroup
-// kernel queued behind it as its fall-back (a no-op unless the launch gave up).
+// ComputeScaleNaive over the n residuals in m->d_res (ref: src/lm_optimizer.cpp:338-358). Levels a fused kernel could also take
+// (<= 2 * kFineKMax virtual blocks = 16 384 points): one workgroup in the fused kernels' summation order — the same sigma bit for
+// bit on every pipeline. Larger levels only ever run here (27 k-point lists of a dense pyramid's coarse levels, dense levels of up
+// to 2 M residuals): lm_tdist_scale_multi_kernel on up to 128 workgroups, with the single-workgroup kernel queued behind it as its
+// fall-back (a no-op unless the launch gave up).
 static void lm_launch_scale(odo_lm* m, int n, int level) {
   hipStream_t s = m->ctx->stream;
-  if (n <= 64 * kTdistChunksMax) {
+  if (n <= 2 * kFineKMax * kLmBlock) {
     hipLaunchKernelGGL(lm_tdist_scale_kernel, dim3(1), dim3(1024), 0, s, m->d_res, n, m->ust, level, m->d_scale, 1, (int*)nullptr);
     return;
   }
@@ -1013,8 +1014,9 @@ static void lm_launch_scale(odo_lm* m, int n, int level) {
   if (G > kTsMaxWg) G = kTsMaxWg;
   if (G < 2) G = 2;
   const bool fits = (long)n <= G * kTsThreads * (long)kTsPerThread;
+  const int single_order = (n <= 64 * kTdistChunksMax) ? 1 : 0;   // (what the single-workgroup kernel can hold in registers)
   if (!m->ts_multi || !fits) {
-    hipLaunchKernelGGL(lm_tdist_scale_kernel, dim3(1), dim3(1024), 0, s, m->d_res, n, m->ust, level, m->d_scale, 0, (int*)nullptr);
+    hipLaunchKernelGGL(lm_tdist_scale_kernel, dim3(1), dim3(1024), 0, s, m->d_res, n, m->ust, level, m->d_scale, single_order, (int*)nullptr);
     return;
   }
   m->ts_epoch = (m->ts_epoch + 1) & 0x3fffffu;   // 22 bits beside the 10-bit pass number: cleared when it starts over
@@ -1024,7 +1026,7 @@ static void lm_launch_scale(odo_lm* m, int n, int level) {
   }
   hipLaunchKernelGGL(lm_tdist_scale_multi_kernel, dim3((unsigned)G), dim3(kTsThreads), 0, s, m->d_res, n, m->ust, level, m->d_scale,
                      m->d_ts_xbuf, m->ts_epoch, m->ts_wait, m->d_ts_gave_up, m->ts_fault);
-  hipLaunchKernelGGL(lm_tdist_scale_kernel, dim3(1), dim3(1024), 0, s, m->d_res, n, m->ust, level, m->d_scale, 0, m->d_ts_gave_up);
+  hipLaunchKernelGGL(lm_tdist_scale_kernel, dim3(1), dim3(1024), 0, s, m->d_res, n, m->ust, level, m->d_scale, single_order, m->d_ts_gave_up);
 }
 
 // One evaluation of the hot loop at the pose held in the device state.

@@ -1622,7 +1622,8 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
         for (int g = 0; g < 8; g++) acc += fold_sh[g * 32 + threadIdx.x];
         acc_sh[threadIdx.x] = acc;
       }
-      __syncthreads();
+      // (no workgroup barrier here: the 29 sums are written by lanes of wave 0 and read by wave 0 alone — lm_state_machine — and
+      //  a wave's LDS accesses stay in order; the other waves wait at the state machine's closing barrier)
     }
     lap(c_red);
     lm_state_machine(true, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, acc_sh, a.trace, a.cost_stat, true,
@@ -2083,7 +2084,7 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
       for (int g = 0; g < 8; g++) acc += fold_sh[g * 32 + t];
       acc_sh[t] = acc;
     }
-    __syncthreads();
+    // (no second barrier: written and read by wave 0 only, see lm_coarse_body; bail_sh was set in front of the barrier above)
     lap(c_xchg);
     if (bail_sh) break;
     // ---- (d): the state machine, every workgroup for itself ----

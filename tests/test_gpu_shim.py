@@ -90,7 +90,7 @@ def test_shim_poses_bit_identical_to_tracker(tmp_path):
     assert np.array_equal(np.fromfile(rel_off, np.float32), np.fromfile(rel, np.float32))
 
 
-def test_lookahead_survives_refilled_swapped_and_poked_mats(tmp_path):
+def test_lookahead_survives_refilled_swapped_and_poked_mats(tmp_path, monkeypatch):
     """What the drop-in classes start ahead (the partner's upload, the whole ComputeDepth, the next frame's upload and pyramid) is keyed
     by content stamps: two Mats refilled per frame like the reference's load_data, the two Mats swapping roles every frame, and a right
     image modified between Solve and ComputeDepth all give the poses and depth outputs of a run with the look-ahead switched off,
@@ -122,6 +122,9 @@ def test_lookahead_survives_refilled_swapped_and_poked_mats(tmp_path):
     assert run("refill", True) == base and run("swap", True) == base
     poked = run("poke", True)
     assert poked != base and run("poke", False) == poked
+    # a persistent depth launch that gives up inside the job started ahead: ComputeDepth runs the job again
+    monkeypatch.setenv("ODO_DEPTH_PERSIST_FAULT", "1")
+    assert run("vector", False) == base and run("refill", False) == base
 
 
 _CV_FLAGS = ["-DODOMETRY_SHIM_WITH_OPENCV", "-DODOMETRY_SHIM_WITH_EIGEN", "-I" + os.path.join(ROOT, "tests", "stubs")]

@@ -556,6 +556,7 @@ struct Lookahead {
   std::weak_ptr<MatBuf> pending_left;            // the left image ImagePyramid was just built from: its lookahead is still to be issued
   std::weak_ptr<MatBuf> pending_partner;         // ... and the guessed right image (mirror block reserved)
   std::weak_ptr<MatBuf> pending_next;            // ... and the guessed NEXT left image (the same-sized Mat created right after the partner)
+  std::weak_ptr<MatBuf> pending_next_r;          // ... and ITS partner (the one after that): the next frame's ComputeDepth can then start at once
   const MatBuf* next_guess_was = nullptr;        // what the previous frame's guess named (compared, never dereferenced)
   int pending_rows = 0, pending_cols = 0;
   unsigned long pending_mark = 0;                // the main stream's fill level then (odo_ctx_mark): the side stream goes behind THAT
@@ -587,8 +588,9 @@ inline void early_reserve(int rows, int cols) {
 // of host work must not sit in front of it), else by the next ComputeDepth.
 inline void run_lookahead() {
   Lookahead& la = lookahead();
-  std::shared_ptr<MatBuf> lb = la.pending_left.lock(), guess = la.pending_partner.lock(), nxt = la.pending_next.lock();
-  la.pending_left.reset(); la.pending_partner.reset(); la.pending_next.reset();
+  std::shared_ptr<MatBuf> lb = la.pending_left.lock(), guess = la.pending_partner.lock(), nxt = la.pending_next.lock(),
+                          nxt_r = la.pending_next_r.lock();
+  la.pending_left.reset(); la.pending_partner.reset(); la.pending_next.reset(); la.pending_next_r.reset();
   if (!la.on || !lb || !la.pending_mark) return;
   if (odo_ctx_stream_wait_mark(side_context(), context(), la.pending_mark) != 0) return;
   // the stereo partner's upload, on the side stream
@@ -630,6 +632,9 @@ inline void run_lookahead() {
         la.ahead_pyr = h;   // (kept alive until the next ImagePyramid has had its chance)
       }
     }
+    // ... and the next frame's RIGHT image behind that: the next frame's ComputeDepth then starts the moment its Solve has been
+    // queued instead of behind a 39-us upload, and this stream's chain ends inside the Solve
+    if (nxt_r && nxt_r.get() != lb.get() && nxt_r.get() != guess.get() && nxt_r.get() != nxt.get()) prefetch_to_device(nxt_r);
   }
 }
 // What ImagePyramid's constructor records for the Solve that follows (run_lookahead issues it): once per image content.
@@ -656,6 +661,10 @@ inline void record_lookahead(const Mat& in, int num_levels, bool smooth) {
   la.next_guess_was = nxt.get();
   if (nxt && proven) prefetch_reserve(nxt); else nxt.reset();
   la.pending_next = nxt;
+  std::shared_ptr<MatBuf> nxt_r;
+  if (nxt && nxt->next && nxt->next != lb.get() && nxt->next != guess.get() && nxt->next->bytes == lb->bytes) nxt_r = nxt->next->shared_from_this();
+  if (nxt_r) prefetch_reserve(nxt_r);
+  la.pending_next_r = nxt_r;
   // ... and the three output blocks of a ComputeDepth started ahead (recycled blocks: their earlier use is in front of the mark)
   if (la.estimator && in.rows == la.est_rows && in.cols == la.est_cols && guess && guess.get() != lb.get()) early_reserve(in.rows, in.cols);
   else early_release();

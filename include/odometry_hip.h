@@ -133,6 +133,14 @@ int odo_lm_solve(odo_lm* lm, const odo_pyr* kf_img, const odo_pyr* kf_dep, const
  * other pyramids, abandons it. Returns 0 started, 1 nothing started (this Solve does not use the fused pipeline), -1 error.
  * While a started Solve is in flight the optimiser's trace / report of the previous Solve are being overwritten. */
 int odo_lm_solve_begin(odo_lm* lm, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img);
+/* Keyframe-candidate point lists built ahead of the Solve that may need them (the point lists are what the validity test of
+ * ComputeResidualJacobianNaive selects, ref: src/lm_optimizer.cpp:190-198; the runner promotes a frame to keyframe AFTER its Solve,
+ * run_odometry_kitti_offline.cpp:258-260, so the first Solve against a new keyframe would build them in front of its first launch):
+ * img / dep are the pyramids of a frame that may become the keyframe. The launches go to `side`'s stream behind `mark` of the
+ * optimiser's stream (odo_ctx_mark; 0: behind everything queued there); the call returns at once. A later Solve on exactly these
+ * pyramids adopts the lists by a buffer swap; any other Solve ignores them. One candidate at a time. Not for an optimiser owned
+ * by a tracker. */
+int odo_lm_candidate_begin(odo_lm* lm, odo_ctx* side, const odo_pyr* img, const odo_pyr* dep, unsigned long mark);
 /* n independent Solves (n sequences, each with its own optimiser and pyramids) in the SAME launches: a single Solve is a
  * serial chain of short launches that leaves most of the chip idle, n chains side by side take the time of the longest.
  * Per-sequence arithmetic and launch order are those of odo_lm_solve: results are bit-identical to n separate calls. The

@@ -547,8 +547,11 @@ struct Lookahead {
   std::weak_ptr<MatBuf> last_left, last_right;   // the pair of the last ComputeDepth
   odo_depth* estimator = nullptr;                // the DepthEstimator of this thread (the last one constructed)
   int est_rows = 0, est_cols = 0;                // the frame size it was last used with
-  struct Entry { unsigned long long stamp; int levels, smooth, kind; std::weak_ptr<struct PyrHandle> h; bool on_side; };
-  Entry cache[4] = {};
+  struct Entry { unsigned long long stamp; int levels, smooth, kind; std::weak_ptr<struct PyrHandle> h; bool on_side; unsigned long side_mark; };
+  Entry cache[8] = {};
+  std::shared_ptr<struct PyrHandle> early_dep_pyr;   // the depth pyramid of the ComputeDepth started ahead (:252, built beside the Solve)
+  int dp_levels = 0, dp_smooth = 0;                  // what the last DepthPyramid was constructed with
+  unsigned long early_dep_mark = 0;                  // the side stream's position right behind that pyramid's launch
   std::shared_ptr<struct PyrHandle> ahead_pyr;   // the next frame's image pyramid, built ahead on the side stream
   unsigned long long recorded_stamp = 0;         // the image content the pending lookahead was recorded for
   int pending_levels = 0, pending_smooth = 0;
@@ -586,7 +589,7 @@ inline void early_reserve(int rows, int cols) {
 }
 // Issues the recorded lookahead. Called by Solve right AFTER its own launches have gone out (the Solve is the critical path: ~15 us
 // of host work must not sit in front of it), else by the next ComputeDepth.
-inline void run_lookahead() {
+inline void run_lookahead(odo_lm* lm = nullptr, const odo_pyr* cur_img = nullptr) {
   Lookahead& la = lookahead();
   std::shared_ptr<MatBuf> lb = la.pending_left.lock(), guess = la.pending_partner.lock(), nxt = la.pending_next.lock(),
                           nxt_r = la.pending_next_r.lock();
@@ -609,6 +612,21 @@ inline void run_lookahead() {
                                     la.pending_mark) == 0) {
       e.started = true; e.est = la.estimator;
       e.left_dev = lb->dev; e.right_dev = guess->dev; e.left_stamp = lb->stamp; e.right_stamp = guess->stamp;
+      // ... and behind it, still beside the Solve: the frame's depth pyramid (:252, with what the last DepthPyramid was built with)
+      // and the keyframe-candidate point lists of (this image pyramid, that depth pyramid) — if the runner promotes this frame
+      // (:258-260), the next Solve finds its lists built (odo_lm_candidate_begin) instead of building them in front of its launches
+      la.early_dep_pyr.reset();
+      if (la.dp_levels > 0) {
+        auto hp = std::make_shared<PyrHandle>();
+        hp->host.resize(la.dp_levels);
+        hp->have.assign(la.dp_levels, 0);
+        if (odo_pyramid_create_dev(side_context(), static_cast<const float*>(e.blk[2]), e.rows, e.cols, la.dp_levels, la.dp_smooth,
+                                   ODO_PYR_DEPTH, &hp->p) == 0) {
+          la.early_dep_pyr = hp;
+          la.early_dep_mark = odo_ctx_mark(side_context());
+          if (lm && cur_img) (void)odo_lm_candidate_begin(lm, side_context(), cur_img, hp->p, la.pending_mark);
+        }
+      }
     } else {
       (void)odo_depth_prepare_left_dev_marked(la.estimator, side_context(), static_cast<const float*>(lb->dev), la.pending_rows,
                                               la.pending_cols, lb->stamp, la.pending_mark);
@@ -626,9 +644,10 @@ inline void run_lookahead() {
       h->have.assign(la.pending_levels, 0);
       if (odo_pyramid_create_dev(side_context(), static_cast<const float*>(nxt->dev), la.pending_rows, la.pending_cols, la.pending_levels,
                                  la.pending_smooth, ODO_PYR_IMAGE, &h->p) == 0) {
-        Lookahead::Entry& ce = la.cache[la.cache_next++ % 4];
+        Lookahead::Entry& ce = la.cache[la.cache_next++ % 8];
         ce.stamp = nxt->stamp; ce.levels = la.pending_levels; ce.smooth = la.pending_smooth; ce.kind = ODO_PYR_IMAGE; ce.h = h;
         ce.on_side = true;
+        ce.side_mark = odo_ctx_mark(side_context());   // (the consumer waits for THIS point of the side stream, not for what follows)
         la.ahead_pyr = h;   // (kept alive until the next ImagePyramid has had its chance)
       }
     }
@@ -682,12 +701,14 @@ inline std::shared_ptr<PyrHandle> make_pyr(int num_levels, const Mat& in, bool s
           // :251 after :205: the same image, the same arithmetic — the same device pyramid; or the pyramid built ahead on the side
           // stream during the previous frame's Solve (the main stream goes behind it: the image's upload and the pyramid kernel)
           if (e.on_side) {
-            odo_ctx_stream_wait(context(), side_context());
+            odo_ctx_stream_wait_mark(context(), side_context(), e.side_mark);   // (an overwritten mark: behind everything queued there)
             e.on_side = false;
             if (in.buffer()) in.buffer()->side_pending = false;
           }
           if (la.ahead_pyr.get() == hit.get()) la.ahead_pyr.reset();
+          if (la.early_dep_pyr.get() == hit.get()) la.early_dep_pyr.reset();
           if (kind == ODO_PYR_IMAGE) record_lookahead(in, num_levels, smooth);
+          else { la.dp_levels = num_levels; la.dp_smooth = smooth ? 1 : 0; }
           return hit;
         }
   if (kind == ODO_PYR_IMAGE) la.ahead_pyr.reset();   // (a pyramid built ahead for an image that did not come)
@@ -708,9 +729,10 @@ inline std::shared_ptr<PyrHandle> make_pyr(int num_levels, const Mat& in, bool s
   }
 #ifndef ODOMETRY_SHIM_WITH_OPENCV
   if (ok && la.on) {
-    Lookahead::Entry& e = la.cache[la.cache_next++ % 4];
-    e.stamp = in.content_stamp(); e.levels = num_levels; e.smooth = smooth ? 1 : 0; e.kind = kind; e.h = h; e.on_side = false;
+    Lookahead::Entry& e = la.cache[la.cache_next++ % 8];
+    e.stamp = in.content_stamp(); e.levels = num_levels; e.smooth = smooth ? 1 : 0; e.kind = kind; e.h = h; e.on_side = false; e.side_mark = 0;
     if (kind == ODO_PYR_IMAGE) record_lookahead(in, num_levels, smooth);
+    else { la.dp_levels = num_levels; la.dp_smooth = smooth ? 1 : 0; }
   }
 #endif
   return h;
@@ -787,7 +809,7 @@ class LevenbergMarquardtOptimizer {  // ref: include/lm_optimizer.h:24-115
     // the Solve's launches first (odo_lm_solve_begin returns once they are queued), then what can run beside them
     if (kImagePyr1.handle() && kDepthPyr1.handle() && kImagePyr2.handle())
       (void)odo_lm_solve_begin(lm_, kImagePyr1.handle(), kDepthPyr1.handle(), kImagePyr2.handle());
-    detail::run_lookahead();
+    detail::run_lookahead(lm_, kImagePyr2.handle());
 #endif
     if (odo_lm_solve(lm_, kImagePyr1.handle(), kDepthPyr1.handle(), kImagePyr2.handle(), affine_data(out)) != 0)
       std::cout << "Optimize failed! " << std::endl;  // ref: src/lm_optimizer.cpp:60-65 (out = pseudo-identity)
@@ -885,15 +907,28 @@ class DepthEstimator {  // ref: include/depth_estimate.h:24-121
         left_val.adopt_device(e.blk[0], e.async_[0]);
         left_disp.adopt_device(e.blk[1], e.async_[1]);
         left_dep.adopt_device(e.blk[2], e.async_[2]);
+        int persist_on = 0, redone_before = 0, redone_after = 0;
+        odo_depth_persistent_stats(d_, &persist_on, &redone_before);
         st = odo_depth_compute_end_dev(d_, static_cast<const float*>(e.left_dev), static_cast<const float*>(e.right_dev), e.rows, e.cols,
                                        static_cast<uint8_t*>(e.blk[0]), static_cast<float*>(e.blk[1]), static_cast<float*>(e.blk[2]),
                                        e.left_stamp, e.right_stamp);
         e.blk[0] = e.blk[1] = e.blk[2] = nullptr;   // (the Mats own them now)
         e.reserved = e.started = false;
         collected = true;
+        odo_depth_persistent_stats(d_, &persist_on, &redone_after);
+        // the :252 pyramid was built from this block beside the Solve: DepthPyramid finds it — unless the job had to be run again
+        // (its persistent launch gave up: the block was rewritten after the pyramid had been built from it)
+        if (la.early_dep_pyr && st == 0 && redone_after == redone_before) {
+          detail::Lookahead::Entry& ce = la.cache[la.cache_next++ % 8];
+          ce.stamp = left_dep.content_stamp(); ce.levels = la.dp_levels; ce.smooth = la.dp_smooth; ce.kind = ODO_PYR_DEPTH;
+          ce.h = la.early_dep_pyr; ce.on_side = true; ce.side_mark = la.early_dep_mark;
+        } else {
+          la.early_dep_pyr.reset();
+        }
         la.last_left = left_img.buffer(); la.last_right = right_img.buffer();
       } else {
         detail::early_release();   // (the library drops the job itself at its next call)
+        la.early_dep_pyr.reset();
       }
     }
 #endif

@@ -85,6 +85,7 @@ SIGNATURES = {
     "odo_lm_event_stats2": (C.c_int, [_vp, _dp, C.POINTER(C.c_long)]),
     "odo_lm_event_stats_ex": (C.c_int, [_vp, _dp]),
     "odo_lm_solve_begin": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "odo_lm_candidate_begin": (C.c_int, [_vp, _vp, _vp, _vp, C.c_ulong]),
     "odo_lm_solve_batch": (C.c_int, [C.c_int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _fp, C.POINTER(C.c_int)]),
     "odo_lm_set_sampling": (C.c_int, [_vp, C.c_int]),
     "odo_lm_set_mode": (C.c_int, [_vp, C.c_int]),

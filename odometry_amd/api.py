@@ -188,6 +188,10 @@ class LevenbergMarquardtOptimizer:
             raise L.OdoError("odo_lm_solve_begin: " + L.last_error())
         return st
 
+    def CandidateBegin(self, side_ctx, kImagePyr, kDepthPyr, mark=0):
+        """Keyframe-candidate point lists of (kImagePyr, kDepthPyr) built ahead on side_ctx's stream (odo_lm_candidate_begin)."""
+        return self.ctx.lib.odo_lm_candidate_begin(self.h, side_ctx.h, kImagePyr.h, kDepthPyr.h, mark)
+
     def Reset(self, kRelativeInit, lam):
         init = _colmajor(kRelativeInit)
         st = self.ctx.lib.odo_lm_reset(self.h, _fp(init), lam)

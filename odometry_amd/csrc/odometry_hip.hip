@@ -100,7 +100,7 @@ struct odo_ctx {
   // the t-th asynchronous upload, or behind a later one that reused the ring entry — has passed
   hipEvent_t up_ev[16];
   unsigned long up_issued, up_retired;
-  hipEvent_t sw_ev[8];   // odo_ctx_stream_wait: events recorded on this stream for other streams to wait on (ring)
+  hipEvent_t sw_ev[32];  // odo_ctx_stream_wait / odo_ctx_mark: events recorded on this stream for other streams to wait on (ring)
   unsigned long sw_next;
   // per-sequence argument table of the batched Solves issued on this stream (odo_lm_solve_batch): per context, because the
   // launches a finished Solve still has queued read it, and only the stream orders the next upload behind them
@@ -338,8 +338,8 @@ extern "C" int odo_ctx_upload_wait(odo_ctx* c, unsigned long ticket) {
 extern "C" unsigned long odo_ctx_mark(odo_ctx* c) {
   if (!c) return 0;
   std::lock_guard<std::mutex> lk(*c->mu);
-  const unsigned long mark = ++c->sw_next;             // marks count from 1; ring entry = mark % 8
-  if (hipEventRecord(c->sw_ev[mark % 8], c->stream) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  const unsigned long mark = ++c->sw_next;             // marks count from 1; ring entry = mark % 32
+  if (hipEventRecord(c->sw_ev[mark % 32], c->stream) != hipSuccess) { (void)hipGetLastError(); return 0; }
   return mark;
 }
 extern "C" int odo_ctx_stream_wait_mark(odo_ctx* waiter, odo_ctx* signaller, unsigned long mark) {
@@ -348,7 +348,7 @@ extern "C" int odo_ctx_stream_wait_mark(odo_ctx* waiter, odo_ctx* signaller, uns
   hipEvent_t ev = nullptr;
   {
     std::lock_guard<std::mutex> lk(*signaller->mu);
-    if (mark != 0 && mark <= signaller->sw_next && signaller->sw_next - mark < 8) ev = signaller->sw_ev[mark % 8];
+    if (mark != 0 && mark <= signaller->sw_next && signaller->sw_next - mark < 32) ev = signaller->sw_ev[mark % 32];
   }
   if (!ev) return odo_ctx_stream_wait(waiter, signaller);   // unknown or overwritten mark: behind everything queued so far
   HIP_OK(hipStreamWaitEvent(waiter->stream, ev, 0));
@@ -362,7 +362,7 @@ extern "C" int odo_ctx_stream_wait(odo_ctx* waiter, odo_ctx* signaller) {
   hipEvent_t ev;
   {
     std::lock_guard<std::mutex> lk(*signaller->mu);
-    ev = signaller->sw_ev[mark % 8];   // (a ring entry is re-recorded 8 marks later: a stream that was told to wait for it has
+    ev = signaller->sw_ev[mark % 32];  // (a ring entry is re-recorded 32 marks later: a stream that was told to wait for it has
   }                                    //  captured the earlier record by then — hipStreamWaitEvent snapshots the event's state)
   HIP_OK(hipStreamWaitEvent(waiter->stream, ev, 0));
   return 0;
@@ -640,6 +640,9 @@ struct odo_lm {
   // its depth stream every frame (lm_build_candidate), off the Solve's critical path; when the candidate becomes the
   // keyframe the two sets trade places (lm_adopt_candidate) instead of list-building launches + a read-back in front of the Solve.
   LmCandSet cand[2];   // two of them: the tracker's depth stream may run a frame ahead of the pose LM (slot = job parity)
+  // odo_lm_candidate_begin (an optimiser that is NOT a tracker's): the lists of a frame that may become the keyframe, built ahead
+  // on another stream into cand[1]; lm_prepare_keyframe adopts them when a Solve names exactly those pyramids
+  struct Ahead { int active; unsigned long long img_ver, dep_ver; hipEvent_t ev; } ahead;
   // optional per-launch HIP-event timing of the evaluation kernels (bench.py roofline leg)
   int ev_on;            // 0 off; N >= 1: every N-th launch of a Solve carries start / stop events (1 = every launch)
   int ev_phase;         // which residue of the launch index is sampled in the Solve in flight (rotates Solve by Solve)
@@ -771,6 +774,8 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
     HIP_OK(hipHostGetDevicePointer((void**)&cs.hm_npts, cs.h_npts, 0));
     cs.tag = -1;
   }
+  m->ahead.active = 0;
+  HIP_OK(hipEventCreateWithFlags(&m->ahead.ev, hipEventDisableTiming));
   m->record = 1;
   m->mode = getenv("ODO_LM_MODE") ? atoi(getenv("ODO_LM_MODE")) : 0;
   m->dense_plain_div = getenv("ODO_DENSE_PLAIN_DIV") ? 1 : 0;
@@ -795,6 +800,7 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
 
 extern "C" int odo_lm_destroy(odo_lm* m) {
   if (!m) return 0;
+  if (m->ahead.ev) { (void)hipEventSynchronize(m->ahead.ev); (void)hipEventDestroy(m->ahead.ev); }   // lists being built ahead on another stream
   (void)hipStreamSynchronize(m->ctx->stream);
   void* dv[] = {m->d_state, m->d_partials, m->d_xbuf, m->d_init, m->d_out, m->d_trace, m->d_scale, m->d_res, m->d_chain_pose, m->d_ts_xbuf, m->d_ts_gave_up,
                 m->d_rowcnt, m->d_npts, m->cand[0].d_rowcnt, m->cand[0].d_npts, m->cand[1].d_rowcnt, m->cand[1].d_npts};
@@ -945,9 +951,17 @@ static void lm_take_counts(odo_lm* m, const int* h_npts, const odo_pyr* img, int
 // Builds (or reuses) the keyframe point lists for the pyramids of this Solve. Two launches over all levels +
 // a 32-byte read-back of the per-level counts; done once per keyframe (the cache is keyed on the pyramids' build
 // versions). Levels where more than half of the interior carries depth keep the dense scan.
+static int lm_adopt_candidate(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, long tag, int slot);
 static int lm_prepare_keyframe(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep) {
   if (m->mode == 1) { for (int l = 0; l < m->n_levels; l++) m->use_list[l] = 0; return 0; }
   if (m->kf_img_ver == kf_img->version && m->kf_dep_ver == kf_dep->version) return 0;
+  if (m->ahead.active && m->ahead.img_ver == kf_img->version && m->ahead.dep_ver == kf_dep->version) {
+    // built ahead for exactly these pyramids (odo_lm_candidate_begin): the launches have long finished — the event makes sure —
+    // and the two list sets trade places: no launch and no read-back in front of this Solve
+    m->ahead.active = 0;
+    HIP_OK(hipEventSynchronize(m->ahead.ev));
+    if (lm_adopt_candidate(m, kf_img, kf_dep, 1, 1) == 0) return 0;
+  }
   hipStream_t s = m->ctx->stream;
   int rows_total = 0;
   if (lm_enqueue_lists(m, m->pl, m->pl_cap, m->d_rowcnt, m->rows_cap, m->hm_npts, kf_img, kf_dep, s,
@@ -974,7 +988,7 @@ static int lm_build_candidate(odo_lm* m, const odo_pyr* img, const odo_pyr* dep,
 // The candidate tagged `tag` (in set `slot`) has become the keyframe (kf_img / kf_dep are its pyramids, the stream that built
 // the lists has drained): trade the two list sets. Returns 0 when adopted, 1 when there was no such candidate (the next
 // Solve then builds the lists itself).
-static int lm_adopt_candidate(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, long tag, int slot = 0) {
+static int lm_adopt_candidate(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, long tag, int slot) {
   LmCandSet& cs = m->cand[slot];
   if (m->mode == 1 || cs.tag < 0 || cs.tag != tag) return 1;
   for (int l = 0; l < ODO_MAX_LEVELS; l++) { std::swap(m->pl[l], cs.pl[l]); std::swap(m->pl_cap[l], cs.pl_cap[l]); }
@@ -1473,6 +1487,28 @@ extern "C" int odo_lm_solve_begin(odo_lm* m, const odo_pyr* kf_img, const odo_py
   if (lm_fused_begin(m, kf_img, kf_dep, cur_img)) return -1;
   lm_fused_pump(m, false);
   HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// Keyframe-candidate point lists built AHEAD (the lists are what ComputeResidualJacobianNaive's validity test selects, ref:
+// src/lm_optimizer.cpp:190-198): `img` / `dep` are the pyramids of a frame that may become the keyframe of later Solves. The two
+// list-building launches go to `side`'s stream, behind `mark` of the optimiser's stream (0: behind everything queued there), and
+// the call returns at once. A later Solve whose keyframe pyramids are exactly these (same builds) adopts the lists by a buffer swap
+// instead of building them, with a read-back of the counts, in front of its first launch; any other Solve ignores them. One
+// candidate at a time (a new call replaces the previous one); `side` must be the same context for every call on this optimiser.
+// Not for an optimiser owned by odo_tracker / odo_tracker_batch (they keep their own candidates).
+extern "C" int odo_lm_candidate_begin(odo_lm* m, odo_ctx* side, const odo_pyr* img, const odo_pyr* dep, unsigned long mark) {
+  if (!m || !side || !img || !dep) return fail("odo_lm_candidate_begin: NULL arg");
+  if (side->device != m->ctx->device) return fail("odo_lm_candidate_begin: the two contexts must be on one device");
+  if (img->levels != dep->levels || img->levels < m->n_levels) return fail("odo_lm_candidate_begin: pyramids do not fit the optimiser");
+  HIP_OK(hipSetDevice(m->ctx->device));
+  m->ahead.active = 0;
+  if (mark ? odo_ctx_stream_wait_mark(side, m->ctx, mark) : odo_ctx_stream_wait(side, m->ctx)) return -1;
+  if (lm_build_candidate(m, img, dep, side->stream, 1, 1)) return -1;
+  if (m->cand[1].tag != 1) return 0;   // (dense-scan mode, or nothing to list)
+  HIP_OK(hipEventRecord(m->ahead.ev, side->stream));
+  m->ahead.img_ver = img->version; m->ahead.dep_ver = dep->version;
+  m->ahead.active = 1;
   return 0;
 }
 

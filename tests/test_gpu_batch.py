@@ -282,6 +282,44 @@ def test_early_start_of_the_next_solve_changes_nothing(api, drives, overlap, pai
                 assert np.array_equal(ma, mb), k
 
 
+def test_candidate_lists_built_ahead_give_the_same_solve(api, kitti_seq):
+    """odo_lm_candidate_begin: the point lists of a frame that may become the keyframe, built on another stream while the optimiser
+    solves against the current keyframe. A Solve against exactly those pyramids adopts them (same pose and trace as an optimiser that
+    builds its lists in front of the Solve); a Solve against other pyramids ignores them; a candidate that is replaced before it is
+    used leaves no trace."""
+    from odometry_amd import synth
+    L, Z = kitti_seq["left"], kitti_seq["depth"]
+    inv = [synth.semi_dense_inverse_depth(Z[k], L[k]) for k in range(3)]
+    pyr = [api.ImagePyramid(4, L[k], True) for k in range(3)]
+    dep = [api.DepthPyramid(4, inv[k], False) for k in range(3)]
+    side = api.Context(0)
+
+    def make():
+        return api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4, dtype=np.float32), None, 1, 28.0)
+    ref = make()
+    want = {}
+    for kf, cur in ((0, 1), (1, 2), (2, 0)):
+        T = ref.Solve(pyr[kf], dep[kf], pyr[cur])
+        want[(kf, cur)] = (T, _trace_key(ref.trace()), ref.points())
+        ref.Reset(np.eye(4, dtype=np.float32), 0.01)
+    lm = make()
+    T = lm.Solve(pyr[0], dep[0], pyr[1])                         # keyframe 0
+    assert np.array_equal(T, want[(0, 1)][0])
+    assert lm.CandidateBegin(side, pyr[1], dep[1]) == 0          # frame 1 may become the keyframe
+    lm.Reset(np.eye(4, dtype=np.float32), 0.01)
+    T = lm.Solve(pyr[1], dep[1], pyr[2])                         # ... and does: lists adopted
+    assert np.array_equal(T, want[(1, 2)][0]) and _trace_key(lm.trace()) == want[(1, 2)][1] and lm.points() == want[(1, 2)][2]
+    assert lm.CandidateBegin(side, pyr[1], dep[1]) == 0          # a candidate nobody uses ...
+    assert lm.CandidateBegin(side, pyr[0], dep[0]) == 0          # ... replaced by another one nobody uses
+    lm.Reset(np.eye(4, dtype=np.float32), 0.01)
+    T = lm.Solve(pyr[2], dep[2], pyr[0])                         # other pyramids: built in front of the Solve as always
+    assert np.array_equal(T, want[(2, 0)][0]) and _trace_key(lm.trace()) == want[(2, 0)][1] and lm.points() == want[(2, 0)][2]
+    lm.Reset(np.eye(4, dtype=np.float32), 0.01)
+    T = lm.Solve(pyr[0], dep[0], pyr[1])                         # the pending candidate (0) is adopted now
+    assert np.array_equal(T, want[(0, 1)][0]) and _trace_key(lm.trace()) == want[(0, 1)][1]
+    lm.close(); ref.close(); side.close()
+
+
 def test_solve_begin_then_solve_equals_solve(api, kitti_seq):
     """odo_lm_solve_begin + odo_lm_solve == odo_lm_solve: same pose, same trace; a begin that is abandoned (Reset, or a Solve on
     other pyramids) leaves no trace in the following Solve; t-distribution Solves start early too since the scale iteration runs

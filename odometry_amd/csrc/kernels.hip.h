@@ -935,8 +935,12 @@ __global__ void __launch_bounds__(1024) lm_tdist_scale_kernel(const float* __res
         for (int w = 0; w < 16; w++) tot += shn[w];
         n_valid = tot;
       }
-      double a = 0.0;
-      for (int c = lane; c < nchunk; c += 64) a += part[c];
+      double a = 0.0;   // (the one order: a virtual block's four chunk sums first, then the virtual blocks lane-strided, then across lanes)
+      for (int v = lane; 4 * v < nchunk; v += 64) {
+        const int c = 4 * v;
+        const double p1 = (c + 1 < nchunk) ? part[c + 1] : 0.0, p2 = (c + 2 < nchunk) ? part[c + 2] : 0.0, p3 = (c + 3 < nchunk) ? part[c + 3] : 0.0;
+        a += ((part[c] + p1) + p2) + p3;
+      }
       const double total = wave_sum64(a);   // every wave for itself: nothing to broadcast
       const float nxt = (n_valid > 0) ? tdist_next_sigma(total, n_valid) : cur;
       const bool done = (n_valid == 0) || tdist_converged(nxt, cur);
@@ -1455,7 +1459,7 @@ constexpr int kCoarseMaxPoints = 1024;  // levels with more points go to the mul
 // ComputeScaleNaive inside one workgroup (ref: src/lm_optimizer.cpp:338-358): every thread of the workgroup calls it with the squared
 // residuals of its points — one per round of the level (nr = 1 or 2 rounds of 512 points; valid = false: no residual). Chunk = 64
 // consecutive points = one wave of one round: chunk (2 rd + half) * 4 + (wave & 3) = rd * 8 + wave, summed in the one order
-// (wave_sum64: chunks without points are +0). part: [2][16] doubles, cnt: [16] ints of LDS. One workgroup barrier per pass.
+// (wave_sum64 per chunk — chunks without points are +0 —, a virtual block's four chunks, then the virtual blocks: see fine_tdist_sigma). part: [2][16] doubles, cnt: [16] ints of LDS. One workgroup barrier per pass.
 constexpr int kCoarseRounds = kCoarseMaxPoints / kCoarseBlock;   // 2
 constexpr int kCoarseChunks = kCoarseRounds * (kCoarseBlock / kWave);   // 16
 __device__ __forceinline__ float coarse_tdist_sigma(double (*part)[kCoarseChunks], int* cnt, const float e2[kCoarseRounds],
@@ -1480,7 +1484,14 @@ __device__ __forceinline__ float coarse_tdist_sigma(double (*part)[kCoarseChunks
       for (int i = 0; i < kCoarseChunks; i++) tot += cnt[i];
       n_total = tot;
     }
-    const double total = wave_sum64(lane < kCoarseChunks ? part[pass & 1][lane] : 0.0);
+    // (the one order: a virtual block's four chunk sums first — G = ((c0 + c1) + c2) + c3, virtual block v = 2 * round + half —, then
+    //  the virtual blocks across lanes)
+    double G = 0.0;
+    if (lane < kCoarseChunks / 4) {
+      const double* pv = &part[pass & 1][(lane >> 1) * kW + 4 * (lane & 1)];
+      G = ((pv[0] + pv[1]) + pv[2]) + pv[3];
+    }
+    const double total = wave_sum64(G);
     const float nxt = (n_total > 0) ? tdist_next_sigma(total, n_total) : sigma;
     const bool done = (n_total == 0) || tdist_converged(nxt, sigma);
     sigma = nxt;
@@ -1834,16 +1845,23 @@ __global__ void xcc_probe_kernel(int* __restrict__ out) {
   if (threadIdx.x == 0) out[blockIdx.x] = fine_xcc_id();
 }
 struct XccIds { int id[8]; };   // the eight XCC ids of the device (id[0] < 0: unknown)
-// ComputeScaleNaive across the workgroups of the persistent launch (ref: src/lm_optimizer.cpp:338-358): called by every wave whose
-// virtual block belongs to the level (vb < nblk; a full wavefront, wave-uniform arguments except e2 / valid), each for itself — no
-// workgroup barrier, no LDS: per pass the wave's chunk sum goes out as one tagged granule pair and all chunk sums of the level come
-// back with L1-bypassing 16-byte loads (lane l: chunks l, l + 64, ...), folded in the one order (wave_sum64). A wave can be at most
-// one pass ahead of the slowest (it cannot finish gathering pass p before every wave has published p), hence the two parities.
-// tag_ev = (launch epoch & 0xfff) << 20 | evaluation << 10; the pass number + 1 fills the low 10 bits (never 0: a cleared buffer
-// matches nothing). Returns sigma; sets *bail when a wait ran out (the Solve then reports -2 like the row exchange does).
+// ComputeScaleNaive across the workgroups of the persistent launch (ref: src/lm_optimizer.cpp:338-358): called by every thread of a
+// workgroup that holds a virtual block of the level (workgroup barriers inside; a half without a virtual block contributes zeros).
+// Per pass every wave sums its 64 terms (wave_sum64), the four waves of a half add their chunk sums up through LDS — G = ((c0 + c1) +
+// c2) + c3 — and ONE tagged granule pair per virtual block goes out; every wave gathers all of them with L1-bypassing 16-byte loads
+// (lane v: virtual block v) and folds them with wave_sum64: every wave of every workgroup computes the same sigma and the same
+// convergence decision, nothing is broadcast. <= 64 publishers and one load per gathering lane where one sum per WAVE (<= 256
+// publishers, four loads per lane) cost 2.8 k cycles per pass: 2.3 k (configs[0]: 0.885 -> 0.81 ms). The same association — chunk,
+// virtual block, lanes — in coarse_tdist_sigma and lm_tdist_scale_kernel: one sigma bit for bit on every pipeline.
+// A workgroup can be at most one pass ahead of the slowest (it cannot finish gathering pass p before every one has published p),
+// hence the two parities. tag_ev = (launch epoch & 0xfff) << 20 | evaluation << 10; the pass number + 1 fills the low 10 bits (never
+// 0: a cleared buffer matches nothing). Returns sigma; sets *bail when a wait ran out (the Solve then reports -2 like the row
+// exchange does). td_ws: [2][8] doubles, td_cnt: [8] ints of LDS.
 __device__ __forceinline__ float fine_tdist_sigma(unsigned long long* __restrict__ sbuf, int chunk, int nchunk, unsigned tag_ev,
-                                                  float e2, bool valid, bool local, unsigned wait_limit, int* bail) {
-  const int lane = threadIdx.x & 63;
+                                                          float e2, bool valid, bool local, unsigned wait_limit, int* bail,
+                                                          double (*td_ws)[8], int* td_cnt) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int vb = chunk >> 2, nvb = nchunk >> 2;
   unsigned long long* cnts = sbuf + 2 * kScaleChunks * 2;
   const int my_cnt = __popcll(__ballot(valid));
   float sigma = 5.0f;
@@ -1851,22 +1869,26 @@ __device__ __forceinline__ float fine_tdist_sigma(unsigned long long* __restrict
   for (int pass = 0; pass < kTdistMaxPasses; pass++) {
     const unsigned tag = tag_ev | (unsigned)(pass + 1);
     const double ws = wave_sum64(valid ? (double)tdist_term(e2, sigma * sigma) : 0.0);
+    if (lane == 0) { td_ws[pass & 1][wv] = ws; if (pass == 0) td_cnt[wv] = my_cnt; }
+    __syncthreads();
     unsigned long long* sums = sbuf + (size_t)(pass & 1) * kScaleChunks * 2;
-    if (lane == 0) {
-      const unsigned long long bits = (unsigned long long)__double_as_longlong(ws);
+    if ((wv & 3) == 0 && lane == 0) {
+      const double G = ((td_ws[pass & 1][wv] + td_ws[pass & 1][wv + 1]) + td_ws[pass & 1][wv + 2]) + td_ws[pass & 1][wv + 3];
+      const int C = td_cnt[wv] + td_cnt[wv + 1] + td_cnt[wv + 2] + td_cnt[wv + 3];
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(G);
       const unsigned long long g0 = ((bits >> 32) << 32) | tag, g1 = (bits << 32) | tag;
-      const unsigned long long gc = ((unsigned long long)(unsigned)my_cnt << 32) | tag;
+      const unsigned long long gc = ((unsigned long long)(unsigned)C << 32) | tag;
       if (local) {
-        sums[2 * chunk] = g0; sums[2 * chunk + 1] = g1;
-        if (pass == 0) cnts[chunk] = gc;
+        sums[2 * vb] = g0; sums[2 * vb + 1] = g1;
+        if (pass == 0) cnts[vb] = gc;
       } else {
-        __hip_atomic_store(sums + 2 * chunk, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(sums + 2 * chunk + 1, g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (pass == 0) __hip_atomic_store(cnts + chunk, gc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sums + 2 * vb, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sums + 2 * vb + 1, g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (pass == 0) __hip_atomic_store(cnts + vb, gc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    FineG2 g[kScaleChunks / 64];
-    unsigned long long gc[kScaleChunks / 64];
+    FineG2 g = {0, 0, 0, 0};
+    unsigned long long gc = 0;
     bool all = false;
     FineDeadline dl = {0ull, wait_limit};
     __builtin_amdgcn_s_setprio(0);
@@ -1874,34 +1896,22 @@ __device__ __forceinline__ float fine_tdist_sigma(unsigned long long* __restrict
       if (spin == 1) dl.t0 = (unsigned long long)wall_clock64();
       if (spin > 0) { if (dl.expired(spin)) break; __builtin_amdgcn_s_sleep(1); }
       bool mine = true;
-#pragma unroll
-      for (int u = 0; u < kScaleChunks / 64; u++) {
-        const int c = lane + 64 * u;
-        if (c < nchunk) {
-          g[u] = *(const volatile FineG2Global*)(sums + 2 * c);
-          if (pass == 0) gc[u] = __hip_atomic_load(cnts + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < kScaleChunks / 64; u++) {
-        const int c = lane + 64 * u;
-        if (c < nchunk) mine = mine && (g[u].x == tag) && (g[u].z == tag) && (pass != 0 || (unsigned)gc[u] == tag);
+      if (lane < nvb) {
+        g = *(const volatile FineG2Global*)(sums + 2 * lane);
+        if (pass == 0) gc = __hip_atomic_load(cnts + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mine = (g.x == tag) && (g.z == tag) && (pass != 0 || (unsigned)gc == tag);
       }
       all = __all(mine);
     }
     __builtin_amdgcn_s_setprio(3);
     if (!all) { if (lane == 0) *bail = 1; break; }
     double part = 0.0, cnt = 0.0;
-#pragma unroll
-    for (int u = 0; u < kScaleChunks / 64; u++) {
-      const int c = lane + 64 * u;
-      if (c < nchunk) {
-        part += __longlong_as_double((long long)(((unsigned long long)g[u].y << 32) | (unsigned long long)g[u].w));
-        if (pass == 0) cnt += (double)(unsigned)(gc[u] >> 32);
-      }
+    if (lane < nvb) {
+      part = __longlong_as_double((long long)(((unsigned long long)g.y << 32) | (unsigned long long)g.w));
+      if (pass == 0) cnt = (double)(unsigned)(gc >> 32);
     }
     const double total = wave_sum64(part);
-    if (pass == 0) n_total = (int)wave_sum64(cnt);   // integers: exact in any order
+    if (pass == 0) n_total = (int)wave_sum64(cnt);
     const float nxt = (n_total > 0) ? tdist_next_sigma(total, n_total) : sigma;
     const bool done = (n_total == 0) || tdist_converged(nxt, sigma);
     sigma = nxt;
@@ -2001,10 +2011,13 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
         wgt = robust_weight(r, a.robust, a.huber_delta, 1.0f);
         valid = true;
       }
-      if (kTdist && vb < nblk) {
+      if (kTdist && w < nblk) {   // (workgroup-uniform: the scale passes hold workgroup barriers; a half without a virtual block adds zeros)
         // t-distribution weights need the scale of ALL residuals of this evaluation first (ref: src/lm_optimizer.cpp:257-261)
+        __shared__ double td_ws_sh[2][8];
+        __shared__ int td_cnt_sh[8];
         const float sg = fine_tdist_sigma(xbuf + kFineScaleOff, vb * 4 + (tl >> 6), 4 * nblk,
-                                          ((a.fine_epoch & 0xfffu) << 20) | (((unsigned)ev & 0x3ffu) << 10), r * r, valid, local, wait_limit, &bail_sh);
+                                          ((a.fine_epoch & 0xfffu) << 20) | (((unsigned)ev & 0x3ffu) << 10), r * r, valid, local, wait_limit, &bail_sh,
+                                          td_ws_sh, td_cnt_sh);
         if (valid) wgt = robust_weight(r, 2, a.huber_delta, sg * sg);
       }
       rows_store(rows_sh, RowBuf<kLmBlock>::W, tl, J, wgt, r, valid);   // (the state machine's closing barrier separates this

@@ -666,8 +666,8 @@ def drive_leg(api, seq, warmup, steps, local_rank=0, details=None):
 def saturated_leg(api, seq, warmup, steps, local_rank=0):
     """A keyframe at the reference's point cap (ref: src/depth_estimate.cpp:300-304,333-339: up to 80 points in each of 512 blocks):
     the 'dense' drive selects ~39 800 of the 40 960 slots and keeps ~28 000 inverse depths on level 0 — 110+ virtual blocks, more
-    than the persistent launch's 32 workgroups hold in registers (64), so level 0 runs on a step launch per evaluation behind the
-    persistent launch (levels 3 - 1). Reported: frames/s as the headline measures it, launches per Solve, Solves redone (none: the
+    than the persistent launch's 32 workgroups hold in registers (64), so level 0 takes two passes per evaluation inside the
+    persistent launch (its points re-read; levels 3 - 1 as always). Reported: frames/s as the headline measures it, launches per Solve, Solves redone (none: the
     persistent launch never gives up), and the same drive with the persistent launch off (ODO_LM_NO_FINE): bit-identical poses."""
     d_on, d_off = {}, {}
     r = drive_leg(api, seq, warmup, steps, local_rank, details=d_on)
@@ -683,7 +683,7 @@ def saturated_leg(api, seq, warmup, steps, local_rank=0):
     r["step_launches_only"] = dict(frames_per_s=r_off["frames_per_s"], launches_per_solve=round(float(np.mean(d_off["launches"][warmup:])), 2))
     r["poses_bit_identical_to_step_launches_only"] = bool(np.array_equal(d_on["poses"], d_off["poses"]))
     r["what"] = ("odometry_amd/synth.py drive 'dense' (1 / f^1.2 textures: the point selection hits its cap of 80 per block); same steps / "
-                 "warm-up as the headline, own tracker; level 0 (> 64 virtual blocks) on step launches behind the persistent launch")
+                 "warm-up as the headline, own tracker; level 0 (110 virtual blocks) inside the persistent launch, two passes per evaluation: launches_per_solve 2 = coarse + persistent, no step launch")
     return r
 
 

@@ -1181,7 +1181,17 @@ static inline int lm_list_blocks(int npts) {
 // 160 CUs by the step launches. t-distribution weights (robust == 2): the coarse launch takes every level it can hold (1 024 points).
 static void lm_plan_levels(const odo_lm* m, int stop, int fine_k, int* min_level_out, int* fine_lo_out) {
   static const int coarse_env = getenv("ODO_COARSE_MAX") ? atoi(getenv("ODO_COARSE_MAX")) : -1;
-  auto fits = [&](int l) { const int nblk = lm_list_blocks(m->npts[l]); return nblk <= 2 * fine_k && m->npts[l] <= nblk * kLmBlock; };
+  // A level of up to 2 K virtual blocks stays in the workgroups' registers (one pass per evaluation). Levels of up to 4 K — a
+  // keyframe near the reference's selection cap: 28 k points = 110 virtual blocks on level 0 — take TWO passes per evaluation with
+  // their points re-read: 3 930 frames/s on bench.py's saturated drive against 3 860 with that level on step launches behind the
+  // launch (round 3 measured the opposite on another level shape; ODO_LM_FINE_PASSES=1 restores it, 3 allows three passes).
+  // t-distribution weights: one pass only (the scale iteration needs every residual of the level in registers).
+  static const int fine_passes_env = getenv("ODO_LM_FINE_PASSES") ? atoi(getenv("ODO_LM_FINE_PASSES")) : 2;
+  const int fine_passes = (m->robust == 2 || fine_passes_env < 1) ? 1 : fine_passes_env;
+  auto fits = [&](int l) {
+    const int nblk = lm_list_blocks(m->npts[l]);
+    return nblk <= 2 * fine_k * fine_passes && nblk <= kFineRowsMax && m->npts[l] <= nblk * kLmBlock;
+  };
   int min_level = m->n_levels, fine_lo = m->n_levels;
   for (int pass = 0; pass < 2; pass++) {
     const bool want_fine = fine_k > 0 && pass == 0;

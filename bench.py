@@ -1200,7 +1200,8 @@ def main():
             # spread of the timed steps (host clock per step; their sum is the timed region): noise vs regression for a reader
             us = step_s * 1e6
             out["step_us"] = dict(median=round(float(np.median(us)), 1), p10=round(float(np.percentile(us, 10)), 1),
-                                  p90=round(float(np.percentile(us, 90)), 1), min=round(float(us.min()), 1), max=round(float(us.max()), 1))
+                                  p90=round(float(np.percentile(us, 90)), 1), min=round(float(us.min()), 1), max=round(float(us.max()), 1),
+                                  slowest_step=int(np.argmax(us)), first_step=round(float(us[0]), 1))
             # does the tracker track? absolute poses of the first pass over the drive against the synthetic ground truth
             # (ref: run_odometry_kitti_offline.cpp:361-372 prints this mean translation error)
             m = min(n_total, args.unique_frames - 1)

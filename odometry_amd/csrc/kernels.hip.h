@@ -1691,12 +1691,21 @@ constexpr int kFineChunk = 8;                    // rows a folding thread keeps 
 constexpr unsigned kFineWaitTicks = 400000u;     // default bound of one wait, in ticks of the 100 MHz wall clock: 4 ms — three orders of
                                                  // magnitude above a normal exchange (~1 us), short enough that a give-up is a hiccup of one
                                                  // frame, not a stall (StepArgs::fine_wait overrides: ODO_LM_FINE_WAIT_US)
-// A bounded wait: the clock is looked at every 32nd poll only (s_memrealtime is a scalar memory operation of ~100 cycles).
+// A bounded wait: the clocks are looked at every 32nd poll only (s_memrealtime is a scalar memory operation of ~100 cycles).
+// The bound is met when `limit` ticks of the 100 MHz wall clock have passed AND as many SHADER cycles as that time holds at the
+// nominal 2.4 GHz: in the first milliseconds of a process (the shader clock ramps up from 95 MHz) and under power capping everything
+// a wait is for — another persistent kernel vacating its CUs, the slowest workgroup's evaluation — takes longer in wall-clock time,
+// and a fixed wall-clock bound then gives up on launches that are merely slow (seen: one depth job in ~ 400 frames at the start of a
+// process against one in 5 700 later — 0.7 ms inside a 20-step measurement).
 struct FineDeadline {
-  unsigned long long t0;
+  unsigned long long t0, c0;
   unsigned limit;
+  static __device__ __forceinline__ FineDeadline begin(unsigned limit_ticks) {
+    return FineDeadline{(unsigned long long)wall_clock64(), (unsigned long long)__builtin_readcyclecounter(), limit_ticks};
+  }
   __device__ __forceinline__ bool expired(int spin) const {
-    return (spin & 31) == 31 && (unsigned long long)wall_clock64() - t0 > (unsigned long long)limit;
+    if ((spin & 31) != 31 || !((unsigned long long)wall_clock64() - t0 > (unsigned long long)limit)) return false;
+    return (unsigned long long)__builtin_readcyclecounter() - c0 > 24ull * (unsigned long long)limit;
   }
 };
 // ComputeScaleNaive over a DENSE level (ref: src/lm_optimizer.cpp:338-358; up to 2 M residuals): the fixed-point iteration of
@@ -1762,7 +1771,7 @@ __global__ void __launch_bounds__(kTsThreads) lm_tdist_scale_multi_kernel(const 
       }
       double a = 0.0, c = 0.0;
       bool all = true;
-      const FineDeadline dl = {(unsigned long long)wall_clock64(), wait_limit};
+      const FineDeadline dl = FineDeadline::begin(wait_limit);
       for (int gg = lane; gg < G; gg += 64) {
         const unsigned long long* theirs = xbuf + ((size_t)(pass & 1) * kTsMaxWg + gg) * 4;
         unsigned long long w0 = 0, w1 = 0, w2 = 0;
@@ -1890,10 +1899,10 @@ __device__ __forceinline__ float fine_tdist_sigma(unsigned long long* __restrict
     FineG2 g = {0, 0, 0, 0};
     unsigned long long gc = 0;
     bool all = false;
-    FineDeadline dl = {0ull, wait_limit};
+    FineDeadline dl = {0ull, 0ull, wait_limit};
     __builtin_amdgcn_s_setprio(0);
     for (int spin = 0; !all; spin++) {
-      if (spin == 1) dl.t0 = (unsigned long long)wall_clock64();
+      if (spin == 1) dl = FineDeadline::begin(wait_limit);
       if (spin > 0) { if (dl.expired(spin)) break; __builtin_amdgcn_s_sleep(1); }
       bool mine = true;
       if (lane < nvb) {
@@ -1956,7 +1965,7 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
     bool same = true, got = false;
     if (t < K) {
       unsigned long long pw = 0;
-      const FineDeadline dl = {(unsigned long long)wall_clock64(), wait_limit};
+      const FineDeadline dl = FineDeadline::begin(wait_limit);
       for (int spin = 0; !got; spin++) {
         pw = __hip_atomic_load(place + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         got = ((unsigned)pw == tag_base);
@@ -2064,9 +2073,9 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
       for (int b0 = fseg; b0 < nblk; b0 += 8 * kFineChunk) {
         FineG2 g2[kFineChunk];   // {hi granule, lo granule} of one double: one 16-byte load that bypasses L1
         bool all = false;
-        FineDeadline dl = {0ull, wait_limit};
+        FineDeadline dl = {0ull, 0ull, wait_limit};
         for (int spin = 0; !all; spin++) {
-          if (spin == 1) dl.t0 = (unsigned long long)wall_clock64();   // the first pass succeeds three times in four: no clock read then
+          if (spin == 1) dl = FineDeadline::begin(wait_limit);   // the first pass succeeds three times in four: no clock read then
           if (spin > 0) { if (dl.expired(spin)) break; __builtin_amdgcn_s_sleep(1); }
           all = true;
 #pragma unroll
@@ -2761,7 +2770,7 @@ __global__ void __launch_bounds__(kDpThreads) depth_lm_persistent_kernel(DepthPe
   if (t < kDpK) {   // thread i asks about workgroup i
     unsigned long long pw = 0;
     bool got = false;
-    const FineDeadline dl = {(unsigned long long)wall_clock64(), wait_limit};
+    const FineDeadline dl = FineDeadline::begin(wait_limit);
     for (int spin = 0; !got; spin++) {
       pw = __hip_atomic_load(place + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       got = ((unsigned)pw == a.epoch + 1u);
@@ -2789,9 +2798,9 @@ __global__ void __launch_bounds__(kDpThreads) depth_lm_persistent_kernel(DepthPe
         const unsigned long long* buf = a.xbuf + (size_t)((k - 1) & 1) * kDlmBlocks * 2;
         FineG2 q[(kDlmBlocks + 63) / 64];
         bool all = false;
-        FineDeadline dl = {0ull, wait_limit};
+        FineDeadline dl = {0ull, 0ull, wait_limit};
         for (int spin = 0; !all; spin++) {
-          if (spin == 1) dl.t0 = (unsigned long long)wall_clock64();
+          if (spin == 1) dl = FineDeadline::begin(wait_limit);
           if (spin > 0 && dl.expired(spin)) break;
           bool mine = true;
 #pragma unroll

@@ -2898,7 +2898,13 @@ __global__ void __launch_bounds__(kDpThreads) depth_lm_persistent_kernel(DepthPe
   }
   __syncthreads();
   const bool bailed = bail_sh != 0;   // (workgroup-uniform behind the barrier)
-  if (bailed && t == 0) __hip_atomic_store(a.gave_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (bailed && t == 0) {
+    __hip_atomic_store(a.gave_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // diagnostic words behind the flag (ODO_LOG_GIVEUPS prints them): a workgroup that gave up, its XCC id, whether it had been
+    // placed (0: the wait for the other workgroups' placement words ran out; 1: a wait for an iteration's sums), how many gave up
+    a.gave_up[1] = g; a.gave_up[2] = fine_xcc_id(); a.gave_up[3] = placed ? 1 : 0;
+    atomicAdd(a.gave_up + 4, 1);
+  }
   // ---- write-back + filters (:176-191) and the per-block counts of depth_finalize_kernel ----
   bool good = false;
   if (ok && !bailed) {

@@ -2479,8 +2479,8 @@ extern "C" int odo_depth_create(odo_ctx* ctx, float grad_th, float ssd_th, float
   d->persist_wait = getenv("ODO_DEPTH_WAIT_US") ? (unsigned)(100L * atol(getenv("ODO_DEPTH_WAIT_US"))) : 50000u;
   HIP_OK(hipMalloc((void**)&d->d_xbuf, sizeof(unsigned long long) * kDpXbufWords));
   HIP_OK(hipMemset(d->d_xbuf, 0, sizeof(unsigned long long) * kDpXbufWords));
-  HIP_OK(hipMalloc((void**)&d->d_gave_up, sizeof(int)));
-  HIP_OK(hipMemset(d->d_gave_up, 0, sizeof(int)));
+  HIP_OK(hipMalloc((void**)&d->d_gave_up, sizeof(int) * 8));   // [0] the flag, [1..5] diagnostics of the last give-up
+  HIP_OK(hipMemset(d->d_gave_up, 0, sizeof(int) * 8));
   HIP_OK(hipEventCreateWithFlags(&d->prep_ev, hipEventDisableTiming));
   *out = d;
   return 0;
@@ -2701,7 +2701,13 @@ static int depth_finish(odo_depth* d, bool full_sync = true) {
     // the persistent depth-LM launch gave up (its workgroups could not all be resident within the wait bound): the caller runs the
     // job again — on the step launches, which need no co-residency (depth_run_checked / tracker_job_run)
     d->persist_bails++;
-    if (getenv("ODO_LOG_GIVEUPS")) fprintf(stderr, "[odometry_hip] depth-LM persistent launch gave up (launch epoch %u, %d clean jobs before)\n", d->persist_epoch, d->persist_clean);
+    if (getenv("ODO_LOG_GIVEUPS")) {
+      int dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      (void)hipMemcpy(dg, d->d_gave_up, sizeof(dg), hipMemcpyDeviceToHost);
+      (void)hipMemset(d->d_gave_up + 1, 0, sizeof(int) * 7);
+      fprintf(stderr, "[odometry_hip] depth-LM persistent launch gave up (launch epoch %u, %d clean jobs before): %d of 80 workgroups, e.g. workgroup %d "
+              "on XCC %d, %s\n", d->persist_epoch, d->persist_clean, dg[4], dg[1], dg[2], dg[3] ? "waiting for an iteration's sums" : "waiting for the others to be placed");
+    }
     if (fine_note_giveup(&d->persist_strikes, &d->persist_clean, &d->persist_offs)) d->persist = 0;
     d->persist_off_once = 1;
     return 2;

@@ -1035,6 +1035,8 @@ def main():
     # would land somewhere inside the timed loop. The loop itself allocates next to nothing, so the collector is parked.
     gc.collect()
     gc.disable()
+    if os.environ.get("ODO_LOG_GIVEUPS"):
+        print("[bench phase] timed region", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     if os.environ.get("ODO_BENCH_STEP_TIMES") and args.sequences == 0:   # diagnostic: per-step wall times, the slowest ones on stderr
         st = []
@@ -1062,6 +1064,8 @@ def main():
         gatherer.flush()
     barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("ODO_LOG_GIVEUPS"):
+        print("[bench phase] timed region over", file=sys.stderr, flush=True)
     gc.enable()
     ev_timed = trk.event_stats_ex() if ev_in_timed else None
     if ev_in_timed:
@@ -1236,6 +1240,8 @@ def main():
                 want = poses_abs[0, args.warmup:].reshape(-1, 4, 4).transpose(0, 2, 1)[:, :3, :]
                 out["pose_gather"]["rank0_rows_match_tracked_poses"] = bool(np.array_equal(mine, want))
         if world == 1 and args.cpu_frames > 0:
+            if os.environ.get("ODO_LOG_GIVEUPS"):
+                print("[bench phase] cpu_baseline + plain GPU pass", file=sys.stderr, flush=True)
             n = min(args.cpu_frames, args.steps, args.unique_frames - 1)
             try:
                 cb = cpu_baseline(seq, n, max(min(n, 20), n // 2))   # >= 20 frames of each shape whenever the run has them
@@ -1288,6 +1294,8 @@ def main():
                 legs = set(args.extras.split(","))
 
                 def leg(key, fn):   # a side measurement that fails must not take the headline JSON line with it
+                    if os.environ.get("ODO_LOG_GIVEUPS"):
+                        print(f"[bench phase] leg {key}", file=sys.stderr, flush=True)
                     try:
                         r = fn()
                         if key is None:

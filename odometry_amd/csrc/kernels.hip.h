@@ -2123,8 +2123,25 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
   }
 }
 // grid = 8 * K blocks: the class (blockIdx.x & 7) that sits on the optimiser's home XCD takes part, the others return at once
+// "The dispatch of a pose-LM persistent launch is in progress": block 0 of its grid writes the launch's epoch into word 0 on entry, the
+// last block into word 1 — the dispatcher deals the blocks of a grid in order, so word 0 != word 1 means that some blocks of that
+// launch have not been dispatched yet. Read by depth_lm_persistent_kernel, whose own dispatch can be what they are waiting for: every
+// block of a launch visits the XCD the dispatcher deals it to, also the seven eighths that return at once, and a pose-LM block (416
+// VGPRs per SIMD) finds no CU on an XCD filled with the depth launch's 80 workgroups while the depth launch's next block finds none
+// on the XCD the pose LM's resident workgroups fill: two half-dispatched persistent launches, each waiting for workgroups that are
+// never dispatched (seen with ODO_LOG_GIVEUPS: all 80 depth workgroups resident in the end, the last of the grid 0.5 ms behind the
+// first; about once per process start — launches 4 and 8 of bench.py's tracker — and once in ~ 5 000 frames later).
+__device__ unsigned g_lm_fine_dispatch[2];
+__device__ __forceinline__ bool lm_fine_mid_dispatch() {
+  return __hip_atomic_load(&g_lm_fine_dispatch[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
+         __hip_atomic_load(&g_lm_fine_dispatch[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 template <bool kTdist>
 __device__ __forceinline__ void lm_fine_entry(const StepArgs& a, int K, unsigned long long* __restrict__ xbuf, int fault, int lo_level) {
+  if (threadIdx.x == 0) {
+    if (blockIdx.x == 0) __hip_atomic_store(&g_lm_fine_dispatch[0], a.fine_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x == gridDim.x - 1) __hip_atomic_store(&g_lm_fine_dispatch[1], a.fine_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (!fine_on_home(a.fine_home) || lm_chain_skip(a)) return;
   const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve, a.span};
   lm_fine_body<kTdist>(a, q, K, (int)(blockIdx.x >> 3), xbuf, fault, lo_level);
@@ -2718,7 +2735,7 @@ constexpr int kDpVb = kDpThreads / kDlmBlock;    // virtual blocks per workgroup
 constexpr int kDpK = kDlmBlocks / kDpVb;         // workgroups: 80 (they wait for each other: all must be resident at once — three fit a CU.
                                                  // 40 x 1 024 threads would need <= 64 VGPRs to fit two per CU: 13 spills)
 constexpr int kDpMaxIters = 250;                 // the 8-bit iteration field of the tags
-constexpr int kDpXbufWords = 2 * kDlmBlocks * 2 + kDpK;   // two parities of 160 pairs + one placement word per workgroup
+constexpr int kDpXbufWords = 2 * kDlmBlocks * 2 + kDpK + 2;   // two parities of 160 pairs + one placement word per workgroup + the "launch abandoned" word
 static_assert(kDlmBlocks % kDpVb == 0 && kDpK <= kDpThreads, "every workgroup owns the same number of virtual blocks; one thread per workgroup");
 struct DepthPersistArgs {
   const float *left, *right;
@@ -2753,8 +2770,10 @@ __global__ void __launch_bounds__(kDpThreads) depth_lm_persistent_kernel(DepthPe
   __shared__ int fold_n, local_sh, bail_sh;
   unsigned long long* place = a.xbuf + 2 * kDlmBlocks * 2;
   const unsigned ep = (a.epoch & 0xffu) << 8;
+  unsigned long long* abandoned = place + kDpK;   // = epoch + 1 once a workgroup of this launch has given up: the ones dispatched later follow at once
   if (t == 0) {
-    local_sh = 1; bail_sh = 0;
+    local_sh = 1;
+    bail_sh = (__hip_atomic_load(abandoned, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)(a.epoch + 1u)) ? 1 : 0;
     __hip_atomic_store(place + g, ((unsigned long long)(unsigned)fine_xcc_id() << 32) | (a.epoch + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // ---- my slot: everything an iteration needs, in registers ----
@@ -2775,8 +2794,16 @@ __global__ void __launch_bounds__(kDpThreads) depth_lm_persistent_kernel(DepthPe
       pw = __hip_atomic_load(place + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       got = ((unsigned)pw == a.epoch + 1u);
       if (!got && dl.expired(spin)) break;
+      // 60 us without the others AND a pose-LM persistent launch half dispatched: the two launches are in each other's way (see
+      // g_lm_fine_dispatch) and this one, which is not the frame's critical chain, yields at once instead of after the whole bound
+      if (!got && (spin & 31) == 31 &&
+          (((unsigned long long)wall_clock64() - dl.t0 > 6000ull && lm_fine_mid_dispatch()) ||
+           __hip_atomic_load(abandoned, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)(a.epoch + 1u))) break;
     }
-    if (!got) bail_sh = 1;
+    if (!got) {
+      bail_sh = 1;
+      __hip_atomic_store(abandoned, (unsigned long long)(a.epoch + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     else if ((int)(pw >> 32) != fine_xcc_id()) local_sh = 0;
   }
   __syncthreads();

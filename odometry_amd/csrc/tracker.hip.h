@@ -276,6 +276,14 @@ static void tracker_worker_main(odo_tracker* t) {
       if (++idle_spins > 20000000) std::this_thread::sleep_for(std::chrono::microseconds(200));
       continue;
     }
+    // A job that was already waiting when the previous one finished starts in the MIDDLE of a frame (a frame that was not announced
+    // brings two jobs at once; so does a depth stream that has fallen behind): its persistent depth launch would then be dispatched
+    // while the pose LM's persistent launch holds its XCD, and the two can end up waiting for each other's undispatched workgroups
+    // (see g_lm_fine_dispatch) — the depth launch gives up after its whole wait bound and the job runs twice, 0.9 ms in all. Such a
+    // job takes the launch-per-iteration path from the start (0.06 ms slower, hidden); in step with the frames every job starts
+    // with its frame, under the pose LM's coarse launch, and keeps the persistent launch.
+    static const bool persist_always = getenv("ODO_DEPTH_PERSIST_ALWAYS") != nullptr;
+    if (idle_spins == 0 && done > 0 && !persist_always) t->depth->persist_off_once = 1;
     idle_spins = 0;
     const auto w0 = std::chrono::steady_clock::now();
     (void)tracker_job_run(t, &t->jobs[done & 1], false);

@@ -2714,6 +2714,13 @@ static int depth_finish(odo_depth* d, bool full_sync = true) {
   }
   if (d->persist_cfg) {
     const bool used = d->persist && !d->persist_off_once;
+    if (getenv("ODO_LOG_GIVEUPS")) {   // (diagnostic) how many jobs took which path, at process exit
+      static long n_persist = 0, n_step = 0;
+      static bool hooked = false;
+      static long* counts[2] = {&n_persist, &n_step};
+      (used ? n_persist : n_step)++;
+      if (!hooked) { hooked = true; atexit([] { fprintf(stderr, "[odometry_hip] depth jobs: %ld on the persistent launch, %ld on step launches\n", *counts[0], *counts[1]); }); }
+    }
     d->persist_off_once = 0;
     if (fine_note_clean(used, &d->persist_strikes, &d->persist_clean, &d->persist_offs)) d->persist = 1;
   }

@@ -13,6 +13,11 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 rm -rf $OUT   # (gpurun MERGES what a call writes into the caller's gpurun_out/: use a fresh tag per collection there, or delete
 mkdir -p $OUT  #  the local copy first — rocprofv3 names its files by PID, and PIDs repeat from box to box)
 cd /tmp && export TMPDIR=/tmp
+# Under rocprofv3 every launch costs the host several times what it costs unprofiled, so the tracker's depth worker always finds its
+# next job already waiting and (tracker_worker_main's rule for jobs that start in the middle of a frame) would send nearly all of
+# them down the launch-per-iteration path — 4 % of the jobs unprofiled (ODO_LOG_GIVEUPS=1 prints the split at exit). The profiled runs
+# keep the unprofiled run's path:
+export ODO_DEPTH_PERSIST_ALWAYS=1
 BENCH="python3 $GRAFT_REPO_ROOT/bench.py --cpu-frames 0 --extras dense,disparity,single,batched,saturated"
 timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH --steps 1000 --warmup 50 > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err < /dev/null
 # 1b. the driver's own short run (python bench.py --steps 20 --warmup 5), side legs off: the averages bench.py's roofline line must agree with

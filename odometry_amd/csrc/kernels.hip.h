@@ -2757,11 +2757,18 @@ struct DepthPersistArgs {
   int* gave_up;                 // device word: set to 1 by a workgroup whose wait ran out (depth_stats_kernel reads and clears it)
   int fault;                    // test hook (ODO_DEPTH_PERSIST_FAULT): virtual block 0's pair is never published
   unsigned long long* dbg;      // diagnostic (ODO_DEPTH_STAMPS): cycle sums of workgroup 0's phases, else null
-  int home;                     // the XCC id of the XCD this estimator's persistent launch runs on (fine_on_home)
+  int home;                     // the XCC id of the XCD this estimator's persistent launch runs on (fine_on_home); < 0: by block class
+  int cls;                      // the block class (blockIdx % 8) that takes part when home < 0
 };
 __global__ void __launch_bounds__(kDpThreads) depth_lm_persistent_kernel(DepthPersistArgs a) {
   const unsigned wait_limit = a.wait_ticks ? a.wait_ticks : kFineWaitTicks;
-  if (!fine_on_home(a.home)) return;   // the block class on the estimator's home XCD — never the pose LM's — takes part
+  // Which eighth of the grid takes part: block class `cls` (blocks with blockIdx % 8 == cls land on one XCD: the dispatcher deals every
+  // grid round-robin from the same XCD). NOT the pose LM's class 0: on one XCD the two persistent launches cannot share a CU (416 +
+  // 160 VGPRs per SIMD), so whenever they overlapped in time one waited for the other's CUs, and when both were dispatched at the same
+  // moment each got part of the XCD and waited for workgroups that could not be placed (ODO_LOG_GIVEUPS: 76 of 80 workgroups entered
+  // together, the last four only when the first ones had given up — on XCC 6, the pose LM's, every time). home >= 0: by XCC id.
+  if (a.home >= 0 ? fine_xcc_id() != a.home : (int)(blockIdx.x & 7u) != a.cls) return;
+  const unsigned long long t_entry = (unsigned long long)wall_clock64();
   const int g = (int)(blockIdx.x >> 3), t = threadIdx.x, lane = t & 63, wv = t >> 6;
   __shared__ double sh_e[kDpThreads / 64];
   __shared__ int sh_n[kDpThreads / 64];
@@ -2816,7 +2823,9 @@ __global__ void __launch_bounds__(kDpThreads) depth_lm_persistent_kernel(DepthPe
   auto lap = [&](unsigned long long& sum) {
     if (a.dbg) { const unsigned long long now = __builtin_readcyclecounter(); sum += now - c_last; c_last = now; }
   };
+  int exit_k = -1;
   for (int k = 0; placed && !st.done; k++) {   // (st: every thread derives the same state)
+    exit_k = k;
     c_it++;
     if (k > 0) {
       if (t < 64) {
@@ -2931,6 +2940,9 @@ __global__ void __launch_bounds__(kDpThreads) depth_lm_persistent_kernel(DepthPe
     // placed (0: the wait for the other workgroups' placement words ran out; 1: a wait for an iteration's sums), how many gave up
     a.gave_up[1] = g; a.gave_up[2] = fine_xcc_id(); a.gave_up[3] = placed ? 1 : 0;
     atomicAdd(a.gave_up + 4, 1);
+    // per workgroup: the iteration it was in (-1: never placed), the 100 MHz clock at its entry and at its exit (low 32 bits)
+    a.gave_up[16 + 4 * g] = exit_k; a.gave_up[16 + 4 * g + 1] = (int)(unsigned)t_entry; a.gave_up[16 + 4 * g + 2] = (int)(unsigned)wall_clock64();
+    a.gave_up[16 + 4 * g + 3] = fine_xcc_id();
   }
   // ---- write-back + filters (:176-191) and the per-block counts of depth_finalize_kernel ----
   bool good = false;

@@ -2479,8 +2479,8 @@ extern "C" int odo_depth_create(odo_ctx* ctx, float grad_th, float ssd_th, float
   d->persist_wait = getenv("ODO_DEPTH_WAIT_US") ? (unsigned)(100L * atol(getenv("ODO_DEPTH_WAIT_US"))) : 50000u;
   HIP_OK(hipMalloc((void**)&d->d_xbuf, sizeof(unsigned long long) * kDpXbufWords));
   HIP_OK(hipMemset(d->d_xbuf, 0, sizeof(unsigned long long) * kDpXbufWords));
-  HIP_OK(hipMalloc((void**)&d->d_gave_up, sizeof(int) * 8));   // [0] the flag, [1..5] diagnostics of the last give-up
-  HIP_OK(hipMemset(d->d_gave_up, 0, sizeof(int) * 8));
+  HIP_OK(hipMalloc((void**)&d->d_gave_up, sizeof(int) * 512));   // [0] the flag, then diagnostics of the last give-up
+  HIP_OK(hipMemset(d->d_gave_up, 0, sizeof(int) * 512));
   HIP_OK(hipEventCreateWithFlags(&d->prep_ev, hipEventDisableTiming));
   *out = d;
   return 0;
@@ -2627,6 +2627,8 @@ static int depth_job_persistent(odo_depth* d, DepthJob* j) {
   a.max_iters = d->max_iters; a.photo_th = d->photo_th; a.min_depth = d->min_depth; a.max_depth = d->max_depth;
   a.val = j->val; a.dep = j->dep; a.counts = d->d_counts; a.xbuf = d->d_xbuf; a.epoch = d->persist_epoch; a.wait_ticks = d->persist_wait;
   a.gave_up = d->d_gave_up; a.fault = d->persist_fault; a.home = d->persist_home;
+  static const int depth_cls = getenv("ODO_DEPTH_CLASS") ? (atoi(getenv("ODO_DEPTH_CLASS")) & 7) : 4;   // (the pose LM's launch: class 0)
+  a.cls = depth_cls;
   static unsigned long long* dbg_buf = [] {
     unsigned long long* p = nullptr;
     if (getenv("ODO_DEPTH_STAMPS") && hipHostMalloc((void**)&p, 256, hipHostMallocMapped) == hipSuccess) memset(p, 0, 256);
@@ -2702,9 +2704,17 @@ static int depth_finish(odo_depth* d, bool full_sync = true) {
     // job again — on the step launches, which need no co-residency (depth_run_checked / tracker_job_run)
     d->persist_bails++;
     if (getenv("ODO_LOG_GIVEUPS")) {
-      int dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      int dg[512];
       (void)hipMemcpy(dg, d->d_gave_up, sizeof(dg), hipMemcpyDeviceToHost);
-      (void)hipMemset(d->d_gave_up + 1, 0, sizeof(int) * 7);
+      (void)hipMemset(d->d_gave_up + 1, 0, sizeof(int) * 511);
+      {   // when each workgroup entered and left (us after the first entry) and the iteration it was in (-1: never placed)
+        unsigned t0 = 0xffffffffu;
+        for (int i = 0; i < 80; i++) if ((unsigned)dg[16 + 4 * i + 1] < t0 && dg[16 + 4 * i + 2] != 0) t0 = (unsigned)dg[16 + 4 * i + 1];
+        fprintf(stderr, "[odometry_hip]    workgroup: iteration, entry us, exit us, XCC:");
+        for (int i = 0; i < 80; i += 1)
+          if (i < 6 || i >= 74 || dg[16 + 4 * i] != dg[16 + 4 * 40]) fprintf(stderr, " %d: %d %.0f %.0f %d;", i, dg[16 + 4 * i], ((unsigned)dg[16 + 4 * i + 1] - t0) * 0.01, ((unsigned)dg[16 + 4 * i + 2] - t0) * 0.01, dg[16 + 4 * i + 3]);
+        fprintf(stderr, "\n");
+      }
       fprintf(stderr, "[odometry_hip] depth-LM persistent launch gave up (launch epoch %u, %d clean jobs before): %d of 80 workgroups, e.g. workgroup %d "
               "on XCC %d, %s\n", d->persist_epoch, d->persist_clean, dg[4], dg[1], dg[2], dg[3] ? "waiting for an iteration's sums" : "waiting for the others to be placed");
     }

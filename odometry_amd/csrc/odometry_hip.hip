@@ -622,6 +622,7 @@ struct odo_lm {
   int* d_ts_gave_up;
   unsigned ts_epoch;
   int ts_multi;                    // 0: ODO_TDIST_SINGLE=1 (the single-workgroup scale kernel for every level)
+  int fine_passes;                 // passes per evaluation a level may take inside the persistent launch (lm_plan_levels; ODO_LM_FINE_PASSES)
   int ts_fault;                    // test hook (ODO_TDIST_MULTI_FAULT): a workgroup never publishes
   unsigned ts_wait;                // wait bound in ticks of the 100 MHz clock (ODO_LM_FINE_WAIT_US), 0: 4 ms
   // host-mapped progress words the update kernel writes (early-exit polling)
@@ -746,6 +747,7 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
   HIP_OK(hipMemset(m->d_ts_gave_up, 0, sizeof(int)));
   m->ts_epoch = 0;
   m->ts_multi = getenv("ODO_TDIST_SINGLE") ? 0 : 1;
+  m->fine_passes = getenv("ODO_LM_FINE_PASSES") ? atoi(getenv("ODO_LM_FINE_PASSES")) : 2;
   m->ts_fault = getenv("ODO_TDIST_MULTI_FAULT") ? 1 : 0;
   m->ts_wait = getenv("ODO_LM_FINE_WAIT_US") ? (unsigned)(100L * atol(getenv("ODO_LM_FINE_WAIT_US"))) : 0u;
   HIP_OK(hipHostMalloc((void**)&m->h_out, sizeof(float) * 48, hipHostMallocDefault));
@@ -1186,8 +1188,7 @@ static void lm_plan_levels(const odo_lm* m, int stop, int fine_k, int* min_level
   // their points re-read: 3 930 frames/s on bench.py's saturated drive against 3 860 with that level on step launches behind the
   // launch (round 3 measured the opposite on another level shape; ODO_LM_FINE_PASSES=1 restores it, 3 allows three passes).
   // t-distribution weights: one pass only (the scale iteration needs every residual of the level in registers).
-  static const int fine_passes_env = getenv("ODO_LM_FINE_PASSES") ? atoi(getenv("ODO_LM_FINE_PASSES")) : 2;
-  const int fine_passes = (m->robust == 2 || fine_passes_env < 1) ? 1 : fine_passes_env;
+  const int fine_passes = (m->robust == 2 || m->fine_passes < 1) ? 1 : m->fine_passes;
   auto fits = [&](int l) {
     const int nblk = lm_list_blocks(m->npts[l]);
     return nblk <= 2 * fine_k * fine_passes && nblk <= kFineRowsMax && m->npts[l] <= nblk * kLmBlock;

@@ -352,23 +352,36 @@ def single_pair_leg(api, seq):
 
 
 def shim_leg(api, seq, n_frames=100, passes=3):
-    """The drop-in surface, PCIe included. (1) shim_path: examples/run_odometry_synth.cpp — the reference runner's frame loop
-    written against include/odometry_shim.hpp (host-resident frames in page-locked stand-in Mats; device mirrors, lazy
-    downloads) — compiled with g++ and timed by its own clock over `passes` fresh runs of the first n_frames frames; its
-    pose_to_keyframe of every frame must equal the device-resident tracker's bit for bit. (2) pcie_inclusive: the same loop
-    through the host-buffer entry points of the C ABI (odo_pyramid_create / odo_depth_compute on pageable numpy arrays: every
-    input staged and uploaded at every use, every output downloaded at once) — what a build against real cv::Mat does."""
+    """The drop-in surface, PCIe included: examples/run_odometry_synth.cpp — the reference runner's frame loop written against
+    include/odometry_shim.hpp — compiled with g++ and timed by its own clock over `passes` fresh runs of the first n_frames frames,
+    in the runner shapes that matter (set-up and every transfer inside the clock; pose_to_keyframe of every frame must equal the
+    device-resident tracker's bit for bit):
+      shim_path                  stand-in odometry::Mat (page-locked, mirrored), every frame preloaded in its own Mat
+      shim_path_load_per_frame   the reference runner's own frame source: the two Mats of a frame are refilled INSIDE the loop from
+                                 8-bit images, as load_data does after decoding (run_odometry_kitti_offline.cpp:200,334-359) — no
+                                 frame is known before its turn; stand-in Mat and cv::Mat builds
+      shim_path_cvmat            the build INTEGRATION.md prescribes (-DODOMETRY_SHIM_WITH_OPENCV -DODOMETRY_SHIM_WITH_EIGEN, here
+                                 against tests/stubs: pageable cv::Mat, nothing reports writes — fingerprint-checked device mirrors),
+                                 every frame preloaded in its own cv::Mat
+    cv::Mat rows come three ways: outputs in host memory when ComputeDepth returns (the reference's contract; default),
+    ODOMETRY_SHIM_LAZY_OUTPUTS=1 (left_disp / left_dep stay on the device until odometry::Download), and the default again with glibc
+    told to keep the pages of the runner's per-frame output Mats (MALLOC_TRIM_THRESHOLD_ / MALLOC_MMAP_THRESHOLD_: three fresh Mats per
+    frame otherwise cost ~1 000 page faults per frame, in ComputeDepth's copy-out and in the Mats' destructors).
+    pcie_inclusive: the same loop through the host-buffer entry points of the C ABI from Python (odo_pyramid_create /
+    odo_depth_compute on pageable numpy arrays: every input staged and uploaded at every use, every output downloaded at once)."""
     import re
     import subprocess
     import tempfile
     out = {}
     L, R = seq["left"][:n_frames], seq["right"][:n_frames]
+    lib = ["-L" + os.path.join(ROOT, "odometry_amd", "lib"), "-lodometry_hip", "-Wl,-rpath," + os.path.join(ROOT, "odometry_amd", "lib")]
+    src = os.path.join(ROOT, "examples", "run_odometry_synth.cpp")
+    keep_pages = {"MALLOC_TRIM_THRESHOLD_": "268435456", "MALLOC_MMAP_THRESHOLD_": "33554432", "MALLOC_TOP_PAD_": "67108864"}
     with tempfile.TemporaryDirectory(dir="/tmp") as td:
-        exe = os.path.join(td, "run_odometry_synth")
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
-                               os.path.join(ROOT, "examples", "run_odometry_synth.cpp"), "-o", exe,
-                               "-L" + os.path.join(ROOT, "odometry_amd", "lib"), "-lodometry_hip",
-                               "-Wl,-rpath," + os.path.join(ROOT, "odometry_amd", "lib")])
+        exe, exe_cv = os.path.join(td, "run_odometry_synth"), os.path.join(td, "run_odometry_synth_cv")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), src, "-o", exe] + lib)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-DODOMETRY_SHIM_WITH_OPENCV", "-DODOMETRY_SHIM_WITH_EIGEN",
+                               "-I" + os.path.join(ROOT, "tests", "stubs"), "-I" + os.path.join(ROOT, "include"), src, "-o", exe_cv] + lib)
         frames = os.path.join(td, "frames.bin")
         with open(frames, "wb") as f:
             np.array([len(L), L[0].shape[0], L[0].shape[1]], np.int32).tofile(f)
@@ -376,12 +389,39 @@ def shim_leg(api, seq, n_frames=100, passes=3):
                 l.astype(np.float32).tofile(f)
                 r.astype(np.float32).tofile(f)
         rel = os.path.join(td, "rel.bin")
-        p = subprocess.run([exe, frames, "--time", str(passes), "--rel-bin", rel], stdout=subprocess.DEVNULL,
-                           stderr=subprocess.PIPE, text=True, timeout=600)
-        m = re.search(r"SHIM_FPS ([\d.]+) FRAMES (\d+) PASSES (\d+)", p.stderr or "")
-        if p.returncode != 0 or not m:
-            raise RuntimeError("shim runner failed: " + (p.stderr or "")[-1500:])
-        shim_rel = np.fromfile(rel, np.float32).reshape(-1, 4, 4).transpose(0, 2, 1)
+
+        def run(binary, extra=(), env=None):
+            e = dict(os.environ)
+            e.update(env or {})
+            p = subprocess.run([binary, frames, "--time", str(passes), "--rel-bin", rel] + list(extra), stdout=subprocess.DEVNULL,
+                               stderr=subprocess.PIPE, text=True, timeout=600, env=e)
+            m = re.search(r"SHIM_FPS ([\d.]+) FRAMES (\d+) PASSES (\d+)", p.stderr or "")
+            if p.returncode != 0 or not m:
+                raise RuntimeError("shim runner failed: " + (p.stderr or "")[-1500:])
+            st = re.search(r"SHIM_STATS (.*)", p.stderr or "")
+            stats = dict(zip(st.group(1).split()[0::2], map(int, st.group(1).split()[1::2]))) if st else {}
+            return m, np.fromfile(rel, np.float32).reshape(-1, 4, 4).transpose(0, 2, 1), stats
+        m, shim_rel, _ = run(exe)
+        shapes = {}
+        for key, binary, extra, env in (
+                ("standin_load_per_frame", exe, ["--load-per-frame"], None),
+                ("cvmat_preloaded", exe_cv, [], None),
+                ("cvmat_preloaded_lazy_outputs", exe_cv, [], {"ODOMETRY_SHIM_LAZY_OUTPUTS": "1"}),
+                ("cvmat_preloaded_malloc_keeps_pages", exe_cv, [], keep_pages),
+                ("cvmat_load_per_frame", exe_cv, ["--load-per-frame"], None),
+                ("cvmat_load_per_frame_lazy_outputs", exe_cv, ["--load-per-frame"], {"ODOMETRY_SHIM_LAZY_OUTPUTS": "1"}),
+                ("cvmat_load_per_frame_malloc_keeps_pages", exe_cv, ["--load-per-frame"], keep_pages)):
+            try:
+                mm, r2, stats = run(binary, extra, env)
+                shapes[key] = dict(frames_per_s=float(mm.group(1)), poses_bit_identical_to_shim_path=bool(np.array_equal(r2, shim_rel)))
+                if stats.get("uploads"):
+                    n_tracked = int(mm.group(2)) + (len(L) - 1)    # (the statistics include the untimed first run)
+                    shapes[key]["image_uploads_per_frame"] = round(stats["uploads"] / n_tracked, 2)
+                    shapes[key]["fingerprint_passes_per_frame"] = round(stats["fingerprints"] / n_tracked, 2)
+                    shapes[key]["depth_jobs_started_ahead_and_adopted"] = stats.get("early_adopted", 0)
+                    shapes[key]["mirror_verify_failures"] = stats.get("verify_failures", 0)
+            except Exception as e:   # noqa: BLE001
+                shapes[key] = dict(error=f"{type(e).__name__}: {e}"[:300])
     # the same frames through the device-resident tracker: bit-identical pose_to_keyframe
     trk = api.Tracker(0)
     dev = [(trk.upload_frame(l), trk.upload_frame(r)) for l, r in zip(L, R)]
@@ -392,8 +432,21 @@ def shim_leg(api, seq, n_frames=100, passes=3):
     trk.close()
     out["shim_path"] = dict(frames_per_s=float(m.group(1)), frames=int(m.group(2)), passes=int(m.group(3)),
                             poses_bit_identical_to_tracker=same,
-                            what="examples/run_odometry_synth.cpp --time: runner loop over include/odometry_shim.hpp, host-resident "
-                                 "frames, set-up and PCIe inside the clock")
+                            what="examples/run_odometry_synth.cpp --time: runner loop over include/odometry_shim.hpp, every frame "
+                                 "preloaded in its own page-locked stand-in Mat, set-up and PCIe inside the clock")
+
+    out["shim_path_load_per_frame"] = dict(
+        standin=shapes.get("standin_load_per_frame"), cvmat=shapes.get("cvmat_load_per_frame"),
+        cvmat_lazy_outputs=shapes.get("cvmat_load_per_frame_lazy_outputs"),
+        cvmat_malloc_keeps_pages=shapes.get("cvmat_load_per_frame_malloc_keeps_pages"),
+        what="the reference runner's frame source: gray[0] / gray[1] refilled inside the loop by convertTo from 8-bit images "
+             "(run_odometry_kitti_offline.cpp:200,334-359 minus the PNG decoding); the load is inside the clock")
+    out["shim_path_cvmat"] = dict(
+        preloaded=shapes.get("cvmat_preloaded"), preloaded_lazy_outputs=shapes.get("cvmat_preloaded_lazy_outputs"),
+        preloaded_malloc_keeps_pages=shapes.get("cvmat_preloaded_malloc_keeps_pages"),
+        what="-DODOMETRY_SHIM_WITH_OPENCV -DODOMETRY_SHIM_WITH_EIGEN against tests/stubs, the loop of shim_path: every frame in its own "
+             "pageable cv::Mat the classes have never seen (no stereo partner known before ComputeDepth names it: the depth job cannot "
+             "run beside the Solve; the load-per-frame rows, where the same two Mats return every frame, can)")
     # (2) eager host-buffer path of the C ABI
     ctx = api.Context(0)
     de = api.DepthEstimator(8.0, 900.0, 15.0, 0.1, 30.0, 0.01, 28.0, 0.995, 50, 4, None, None,

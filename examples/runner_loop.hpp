@@ -36,11 +36,32 @@ inline io::Pose34 to_pose34(const Affine4f& T) {
   return p;
 }
 
+// Where the frames come from — the runner's load_data(data_path, gray, frame_id) (:200,334-359), which refills the SAME two Mats
+// every frame: imread, then gray_8u.convertTo(gray[i], PixelType).
+//   PreloadedFrames   every frame already sits in its own PixelType Mat; load() hands out headers (no pixels move)
+//   LoadPerFrame      the frames are kept as 8-bit images (imread's output); load() converts the pair into gray[0] / gray[1] INSIDE the
+//                     frame loop, exactly as load_data does after decoding — no frame is known to the classes before its turn
+struct PreloadedFrames {
+  const std::vector<Mat>&left, &right;
+  unsigned size() const { return (unsigned)left.size(); }
+  void load(std::vector<Mat>& gray, unsigned id) const { gray[0] = left[id]; gray[1] = right[id]; }
+};
+struct LoadPerFrame {
+  const std::vector<Mat>&left_8u, &right_8u;
+  unsigned size() const { return (unsigned)left_8u.size(); }
+  void load(std::vector<Mat>& gray, unsigned id) const { left_8u[id].convertTo(gray[0], PixelType); right_8u[id].convertTo(gray[1], PixelType); }
+};
+
 // Returns the number of keyframes created after the first one, or -1 if frame 0 could not be initialised.
 // rel (optional): pose_to_keyframe of every frame (what Solve returned), for bit-exact comparisons.
-inline int track_sequence(const std::vector<Mat>& left, const std::vector<Mat>& right, const Affine4f& pose0,
-                          std::vector<io::Pose34>& pred, bool verbose = true, std::vector<Affine4f>* rel = nullptr) {
-  const unsigned num_frames = (unsigned)left.size();
+template <class FrameSource>
+inline int track_sequence(const FrameSource& frames, const Affine4f& pose0, std::vector<io::Pose34>& pred, bool verbose = true,
+                          std::vector<Affine4f>* rel = nullptr) {
+  const unsigned num_frames = frames.size();
+  std::vector<Mat> pre_gray(2), cur_gray(2);                            // :93-94
+  frames.load(pre_gray, 0);                                             // :95
+  const std::vector<Mat>&left = pre_gray;                               // (frame 0 below)
+  const Mat& right0 = pre_gray[1];
   const unsigned num_pyramid = 4;
   const auto t_setup = std::chrono::steady_clock::now();
   const float baseline = 386.1448f / 718.856f;                          // :41
@@ -57,7 +78,7 @@ inline int track_sequence(const std::vector<Mat>& left, const std::vector<Mat>& 
   const Scalar init_val(0);                                             // :99-101
   Mat pre_left_val(left[0].rows, left[0].cols, CV_8U, init_val), pre_left_disp(left[0].rows, left[0].cols, PixelType, init_val),
       pre_left_dep(left[0].rows, left[0].cols, PixelType, init_val);
-  if (depth_estimator.ComputeDepth(left[0], right[0], pre_left_val, pre_left_disp, pre_left_dep) == -1) {  // :102
+  if (depth_estimator.ComputeDepth(left[0], right0, pre_left_val, pre_left_disp, pre_left_dep) == -1) {  // :102
     std::cout << "Init 0-th frame failed!" << std::endl;
     return -1;
   }
@@ -75,7 +96,7 @@ inline int track_sequence(const std::vector<Mat>& left, const std::vector<Mat>& 
   // ODO_RUNNER_PHASES=1: host time per phase of the frame loop, mean over the frames, on stderr (diagnostic)
   const bool phases = std::getenv("ODO_RUNNER_PHASES") != nullptr;
   const double setup_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_setup).count();
-  double ph[7] = {0, 0, 0, 0, 0, 0, 0};
+  double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto lap = [&](std::chrono::steady_clock::time_point& t0, int i) {
     if (!phases) return;
@@ -86,7 +107,9 @@ inline int track_sequence(const std::vector<Mat>& left, const std::vector<Mat>& 
   for (unsigned frame_id = 1; frame_id < num_frames; frame_id++) {     // :198
     auto tp = now();
     {
-    ImagePyramid cur_img_pyramid(num_pyramid, left[frame_id], true);   // :205
+    frames.load(cur_gray, frame_id);                                   // :200
+    lap(tp, 7);
+    ImagePyramid cur_img_pyramid(num_pyramid, cur_gray[0], true);      // :205
     lap(tp, 0);
     pose_to_keyframe = pose_estimator.Solve(std::get<0>(keyframes[current_kf]), std::get<1>(keyframes[current_kf]),
                                             cur_img_pyramid);          // :215
@@ -96,14 +119,14 @@ inline int track_sequence(const std::vector<Mat>& left, const std::vector<Mat>& 
     Mat cur_left_val(left[0].rows, left[0].cols, CV_8U, init_val), cur_left_disp(left[0].rows, left[0].cols, PixelType),
         cur_left_dep(left[0].rows, left[0].cols, PixelType);
     lap(tp, 2);
-    if (depth_estimator.ComputeDepth(left[frame_id], right[frame_id], cur_left_val, cur_left_disp, cur_left_dep) == -1) {
+    if (depth_estimator.ComputeDepth(cur_gray[0], cur_gray[1], cur_left_val, cur_left_disp, cur_left_dep) == -1) {
       std::cout << "    depth failed!" << std::endl;                   // :230-232
       break;
     }
     lap(tp, 3);
     delete pre_img_pyramid_ptr;
     delete pre_dep_pyramid_ptr;
-    pre_img_pyramid_ptr = new ImagePyramid(num_pyramid, left[frame_id], true);       // :251
+    pre_img_pyramid_ptr = new ImagePyramid(num_pyramid, cur_gray[0], true);          // :251
     pre_dep_pyramid_ptr = new DepthPyramid(num_pyramid, cur_left_dep, false);        // :252
     lap(tp, 4);
 
@@ -132,12 +155,17 @@ inline int track_sequence(const std::vector<Mat>& left, const std::vector<Mat>& 
   }
   if (phases && num_frames > 1) {
     const double n = num_frames - 1;
+    std::fprintf(stderr, "[runner phases] load_data :200 %.1f  ", ph[7] / n);
     std::fprintf(stderr, "[runner phases] ImagePyramid :205 %.1f  Solve :215 %.1f  pose + output Mats %.1f  ComputeDepth :229 %.1f  "
                  "pyramids :251-252 %.1f  keyframe test + Reset %.1f  end of the frame's scope %.1f us per frame; constructors + frame 0: %.0f us once\n", ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ph[5] / n, ph[6] / n, setup_us);
   }
   delete pre_img_pyramid_ptr;
   delete pre_dep_pyramid_ptr;
   return (int)current_kf;
+}
+inline int track_sequence(const std::vector<Mat>& left, const std::vector<Mat>& right, const Affine4f& pose0,
+                          std::vector<io::Pose34>& pred, bool verbose = true, std::vector<Affine4f>* rel = nullptr) {
+  return track_sequence(PreloadedFrames{left, right}, pose0, pred, verbose, rel);
 }
 
 }  // namespace odometry

@@ -88,9 +88,28 @@ int odo_ctx_upload_wait(odo_ctx* ctx, unsigned long ticket);
 int odo_ctx_stream_wait(odo_ctx* waiter, odo_ctx* signaller);
 /* The same in two halves: odo_ctx_mark names the point `ctx`'s stream has been filled up to (returns a non-zero mark), and
  * odo_ctx_stream_wait_mark orders `waiter` behind that point — not behind what was queued on `signaller` since (a mark older
- * than the last eight falls back to "everything queued so far"). */
+ * than the last 32 falls back to "everything queued so far"). */
 unsigned long odo_ctx_mark(odo_ctx* ctx);
 int odo_ctx_stream_wait_mark(odo_ctx* waiter, odo_ctx* signaller, unsigned long mark);
+/* Host waits until `ctx`'s stream has passed `mark` (odo_ctx_mark). */
+int odo_ctx_wait_mark(odo_ctx* ctx, unsigned long mark);
+/* Images in host memory the library cannot watch — a cv::Mat (ref: run_odometry_kitti_offline.cpp:200,334-359 refills the same two
+ * Mats every frame; the classes of include/odometry_shim.hpp see them three times per frame, :205 / :229 / :251). A device mirror
+ * of such an image may be reused only if the bytes are still the ones that were uploaded:
+ *   odo_host_fingerprint       64-bit fingerprint of all pixels (rows of row_bytes bytes, src_pitch apart; one read of the image);
+ *   odo_dev_upload_fp_async    odo_dev_upload_2d_async through the pinned staging ring, *fp = the fingerprint of exactly the bytes
+ *                              that were staged (fused with the copy; the caller may rewrite the image once the call has returned);
+ *   odo_dev_download_async     device -> a block from odo_host_alloc, asynchronous on ctx's stream (ComputeDepth's outputs are staged
+ *                              on the host beside the pose LM, ref: src/depth_estimate.cpp:33-78 fills left_val / left_disp / left_dep);
+ *   odo_host_copy_fingerprint  host -> host copy (staging block -> the caller's cv::Mat), returns the fingerprint of what was written.
+ * Not cryptographic: it guards against a caller rewriting its buffer, not against an adversary. No device needed for the two
+ * host-only calls. */
+unsigned long long odo_host_fingerprint(const void* src_host, size_t src_pitch, size_t row_bytes, int rows);
+unsigned long long odo_host_copy_fingerprint(void* dst_host, size_t dst_pitch, const void* src_host, size_t src_pitch, size_t row_bytes,
+                                             int rows);
+int odo_dev_upload_fp_async(odo_ctx* ctx, void* dst_dev, const void* src_host, size_t src_pitch, size_t row_bytes, int rows,
+                            unsigned long long* fp);
+int odo_dev_download_async(odo_ctx* ctx, void* dst_pinned_host, const void* src_dev, size_t bytes);
 int odo_dev_alloc_async(odo_ctx* ctx, size_t bytes, void** out_dev, int* is_async);
 int odo_dev_free_async(odo_ctx* ctx, void* dev, size_t bytes, int is_async);
 

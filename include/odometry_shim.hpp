@@ -18,11 +18,13 @@
 #ifndef ODOMETRY_SHIM_HPP
 #define ODOMETRY_SHIM_HPP
 
+#include <atomic>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "odometry_hip.h"
@@ -32,6 +34,9 @@
 #endif
 #ifdef ODOMETRY_SHIM_WITH_EIGEN
 #include <Eigen/Core>
+#endif
+#if defined(__SSE2__)
+#include <emmintrin.h>
 #endif
 
 #ifndef PixelType
@@ -69,12 +74,193 @@ inline float* affine_data(Affine4f& a) { return a.m; }
 #endif
 
 // ------------------------------------------------------------------------------------------------
+// What the classes did on this thread (diagnostics and tests; the cv::Mat build counts all of it, the stand-in build the look-ahead).
+struct ShimStats {
+  unsigned long uploads = 0;          // images staged and sent to the device
+  unsigned long fingerprints = 0;     // full-image fingerprint passes
+  unsigned long unchanged = 0;        // uses of a Mat whose mirror was found current
+  unsigned long changed = 0;          // uses of a known Mat whose content had changed since its upload
+  unsigned long early_adopted = 0;    // ComputeDepth calls that found their job started ahead
+  unsigned long early_dropped = 0;    // jobs started ahead for images that then did not come (or had changed)
+  unsigned long delivered = 0;        // output images copied into host memory
+  unsigned long verify_failures = 0;  // ODOMETRY_SHIM_VERIFY_MIRRORS: mirrors that differed from an "unchanged" Mat
+};
+namespace detail { inline ShimStats& stats() { static thread_local ShimStats s; return s; } }
+inline const ShimStats& shim_stats() { return detail::stats(); }
+// ------------------------------------------------------------------------------------------------
 #ifdef ODOMETRY_SHIM_WITH_OPENCV
 typedef cv::Mat Mat;
 typedef cv::Size Size;
 typedef cv::Scalar Scalar;
 enum { kInterLinear = cv::INTER_LINEAR, kBorderConstant = cv::BORDER_CONSTANT, kMap32FC1 = CV_32FC1 };
 inline double scalar0(const Scalar& s) { return s[0]; }
+// A cv::Mat knows nothing about the device and reports no writes. What the stand-in Mat below carries inside — a device mirror, a
+// content stamp — is kept here in a per-thread table of RECORDS keyed by the pixels' address and geometry, made safe by two rules:
+//   * the records of a STEREO PAIR (ComputeDepth's two inputs) hold a header copy of the Mat (cv::Mat headers share their buffer by
+//     reference count), so the buffer can neither be released nor its address be handed to another image while the record lives —
+//     the classes read such a buffer again on their own initiative (the stereo partner's upload is started from Solve, before
+//     ComputeDepth names it). All other records hold nothing: their pixels are only ever looked at while the caller hands the Mat in,
+//     and holding the runner's per-frame output Mats (:226-228) would keep the allocator from recycling their buffers (fresh pages
+//     every frame: page faults worth 200 us);
+//   * a record remembers the 64-bit FINGERPRINT of the bytes that were uploaded (odo_dev_upload_fp_async: fused with the staging
+//     copy). Every later use of the Mat in a call into a shim class fingerprints all its pixels again (odo_host_fingerprint: one read
+//     of the image, ~20-40 us per KITTI frame) before the mirror — or anything derived from it: the :251 pyramid, a ComputeDepth started
+//     ahead — is used; a caller who rewrote the buffer in between gets a fresh upload and fresh results. A cheap sample of 48 words
+//     goes first: a refilled frame is recognised as changed without the full pass.
+// ODOMETRY_SHIM_VERIFY_MIRRORS=1 (environment) additionally downloads the mirror and compares it byte for byte whenever the
+// fingerprint says "unchanged", and counts disagreements (ShimStats::verify_failures; must stay 0).
+// Outputs (ComputeDepth's left_val / left_disp / left_dep): by default all three are in host memory when ComputeDepth returns, as in
+// the reference (src/depth_estimate.cpp:33-78). With ODOMETRY_SHIM_LAZY_OUTPUTS=1 left_disp and left_dep stay on the device — the
+// runner never reads them on the host: left_dep only goes to DepthPyramid (run_odometry_kitti_offline.cpp:252) — until
+// odometry::Download(mat) is called for them; left_val (summed by the runner, :236) is always delivered.
+namespace detail {
+inline odo_ctx* context();
+inline odo_ctx* side_context();
+inline unsigned long long next_stamp() { static std::atomic<unsigned long long> s{0}; return ++s; }
+// Every public method of a shim class is one "call": a Mat is checked at most once per call (the caller cannot write while we run).
+inline unsigned long long& call_epoch() { static thread_local unsigned long long e = 1; return e; }
+struct CallScope { CallScope() { ++call_epoch(); } };
+constexpr int kSampleWords = 48;
+struct MatBuf : std::enable_shared_from_this<MatBuf> {
+  Mat keep;                  // header copy: pins the pixel buffer
+  bool keepalive = false;    // false for a header over user data (cv::Mat::u == nullptr): nothing pins those bytes — never read ahead
+  uint8_t* host = nullptr;
+  size_t bytes = 0, pitch = 0, row_bytes = 0;   // bytes = rows * row_bytes (the dense image on the device)
+  int rows = 0, cols = 0, type = 0;
+  void* dev = nullptr;
+  int dev_async = 0;
+  odo_ctx *ctx = nullptr, *side = nullptr;
+  bool host_valid = true, dev_valid = false, side_pending = false;
+  bool pinned = false;
+  unsigned long long fp = 0;
+  bool fp_known = false;
+  unsigned long long sample[kSampleWords];
+  unsigned long long stamp = 0, checked = 0;
+  MatBuf* next = nullptr;    // (a cv::Mat has no creation order to guess a partner from)
+  std::shared_ptr<MatBuf> successor() { return nullptr; }
+  void bind() { if (ctx != context()) { if (ctx) free_mirror(); ctx = context(); side = side_context(); } }
+  void free_mirror() {
+    if (!dev) return;
+    if (side_pending) odo_ctx_stream_wait(ctx, side);
+    odo_dev_free_async(ctx, dev, bytes, dev_async);
+    dev = nullptr; dev_valid = false; side_pending = false;
+  }
+  ~MatBuf() { free_mirror(); }
+  const uint8_t* sample_at(int i) const {
+    const int y = (int)(((long long)i * rows) / kSampleWords);
+    const size_t span = row_bytes >= 8 ? row_bytes - 8 : 0;
+    const size_t x = span ? (((size_t)i * 2654435761u) % span) & ~(size_t)7 : 0;
+    return host + (size_t)y * pitch + x;
+  }
+  void take_sample() { if (row_bytes >= 8) for (int i = 0; i < kSampleWords; i++) std::memcpy(&sample[i], sample_at(i), 8); }
+  bool sample_same() const {
+    if (row_bytes < 8) return true;
+    for (int i = 0; i < kSampleWords; i++) { unsigned long long w; std::memcpy(&w, sample_at(i), 8); if (w != sample[i]) return false; }
+    return true;
+  }
+  void content_changed() { stamp = next_stamp(); dev_valid = false; side_pending = false; fp_known = false; }
+  // Is the mirror (and everything keyed by `stamp`) still the image in host memory? Once per call into a shim class.
+  void validate() {
+    if (checked == call_epoch()) return;
+    checked = call_epoch();
+    if (!host_valid) return;              // (lazy outputs: the device copy is the image; the host bytes are stale by contract)
+    if (!fp_known) { content_changed(); return; }
+    bool same = sample_same();
+    if (same) { stats().fingerprints++; same = odo_host_fingerprint(host, pitch, row_bytes, rows) == fp; }
+    if (!same) { stats().changed++; content_changed(); return; }
+    stats().unchanged++;
+    static const bool verify = std::getenv("ODOMETRY_SHIM_VERIFY_MIRRORS") != nullptr;
+    if (verify && dev && dev_valid) {
+      std::vector<uint8_t> tmp(bytes);
+      if (side_pending) { odo_ctx_stream_wait(ctx, side); side_pending = false; }
+      odo_dev_download(ctx, tmp.data(), dev, bytes);
+      for (int y = 0; y < rows; y++)
+        if (std::memcmp(tmp.data() + (size_t)y * row_bytes, host + (size_t)y * pitch, row_bytes) != 0) {
+          stats().verify_failures++;
+          std::cout << "odometry_hip: a device mirror differs from a cv::Mat whose fingerprint had not changed" << std::endl;
+          content_changed();
+          return;
+        }
+    }
+  }
+  // The image goes to the device through the pinned staging ring of `to` (the main or the side context), fingerprinted on the way.
+  bool upload(odo_ctx* to) {
+    if (odo_dev_upload_fp_async(to, dev, host, pitch, row_bytes, rows, &fp) != 0) return false;
+    stats().uploads++;
+    take_sample();
+    fp_known = true; dev_valid = true; host_valid = true;
+    side_pending = (to == side);
+    return true;
+  }
+  // The device copy (a kernel's output) comes to the host now: synchronous.
+  void deliver_now() {
+    if (!dev) return;
+    if (side_pending) { odo_ctx_stream_wait(ctx, side); side_pending = false; }
+    if (pitch == row_bytes) odo_dev_download(ctx, host, dev, bytes);
+    else {   // (a view: through a dense temporary)
+      std::vector<uint8_t> tmp(bytes);
+      odo_dev_download(ctx, tmp.data(), dev, bytes);
+      for (int y = 0; y < rows; y++) std::memcpy(host + (size_t)y * pitch, tmp.data() + (size_t)y * row_bytes, row_bytes);
+    }
+    stats().fingerprints++;
+    fp = odo_host_fingerprint(host, pitch, row_bytes, rows);
+    finish_delivery();
+  }
+  // ... or was staged in page-locked memory beside the pose LM and is copied out (fingerprinted on the way).
+  void deliver_from(const void* staged) {
+    fp = odo_host_copy_fingerprint(host, pitch, staged, row_bytes, row_bytes, rows);
+    finish_delivery();
+  }
+  void finish_delivery() { stats().delivered++; take_sample(); fp_known = true; host_valid = true; checked = call_epoch(); }
+};
+// least recently used first; the oldest record (and its mirror, and its hold on the caller's buffer) goes when the table is full
+struct MatTable {
+  std::vector<std::shared_ptr<MatBuf>> recs;
+  // hold: the Mat comes in as an input (see above)
+  std::shared_ptr<MatBuf> find(const Mat& m, bool create, bool hold = false) {
+    if (m.empty()) return nullptr;
+    for (size_t i = recs.size(); i-- > 0;) {
+      MatBuf& r = *recs[i];
+      if (r.host == m.data && r.rows == m.rows && r.cols == m.cols && r.pitch == (size_t)m.step && r.type == m.type()) {
+        std::shared_ptr<MatBuf> hit = recs[i];
+        if (i + 1 != recs.size()) { recs.erase(recs.begin() + (long)i); recs.push_back(hit); }
+        if (hold && !hit->keepalive && m.u != nullptr) { hit->keep = m; hit->keepalive = true; }
+        return hit;
+      }
+    }
+    if (!create) return nullptr;
+    auto b = std::make_shared<MatBuf>();
+    if (hold && m.u != nullptr) { b->keep = m; b->keepalive = true; }
+    b->host = m.data; b->rows = m.rows; b->cols = m.cols; b->type = m.type();
+    b->pitch = (size_t)m.step; b->row_bytes = (size_t)m.cols * m.elemSize(); b->bytes = b->row_bytes * (size_t)m.rows;
+    b->stamp = next_stamp();
+    static const size_t cap = std::getenv("ODOMETRY_SHIM_MAT_RECORDS") ? (size_t)std::atoi(std::getenv("ODOMETRY_SHIM_MAT_RECORDS")) : 24;
+    while (recs.size() >= (cap < 4 ? 4 : cap)) recs.erase(recs.begin());
+    recs.push_back(b);
+    return b;
+  }
+};
+inline MatTable& mat_table() { static thread_local MatTable t; return t; }
+inline bool lazy_outputs() { static const bool on = std::getenv("ODOMETRY_SHIM_LAZY_OUTPUTS") != nullptr; return on; }
+// the stand-in's helpers of the same names: the partner's mirror block first (before the main stream is marked), its upload later
+inline void prefetch_reserve(const std::shared_ptr<MatBuf>& sp) {
+  MatBuf& b = *sp;
+  if (!b.keepalive) return;
+  b.bind();
+  if (!b.dev && odo_dev_alloc_async(b.ctx, b.bytes, &b.dev, &b.dev_async) != 0) b.dev = nullptr;
+}
+inline void prefetch_to_device(const std::shared_ptr<MatBuf>& sp) {
+  MatBuf& b = *sp;
+  if (!b.keepalive || !b.dev || b.ctx != context()) return;
+  b.validate();                      // (the caller has usually refilled it since the last frame: the sample says so at once)
+  if (!b.dev_valid && b.host_valid) (void)b.upload(b.side);
+}
+}  // namespace detail
+// ODOMETRY_SHIM_LAZY_OUTPUTS=1: brings a ComputeDepth output that was left on the device into the Mat's host memory.
+inline void Download(Mat& m) {
+  auto b = detail::mat_table().find(m, false);
+  if (b && !b->host_valid && b->dev && b->dev_valid) b->deliver_now();
+}
 #else
 enum { CV_8U = 0, CV_32F = 5, CV_64F = 6, CV_32FC1 = 5 };
 enum { INTER_LINEAR = 1, BORDER_CONSTANT = 0 };
@@ -106,28 +292,57 @@ inline double scalar0(const Scalar& s) { return s.val[0]; }
 // written through afterwards — the shim cannot see such a write (the mirror would go stale). Fetch the pointer again after
 // the call, as the reference's own code does (it calls ptr<T>() / at<T>() per row / per pixel).
 namespace detail {
+inline void convert_8u_32f(const uint8_t* s, float* d, size_t n) {   // (whatever optimisation level the includer compiles with)
+  size_t i = 0;
+#if defined(__SSE2__)
+  const __m128i z = _mm_setzero_si128();
+  for (; i + 16 <= n; i += 16) {
+    const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s + i));
+    const __m128i lo = _mm_unpacklo_epi8(v, z), hi = _mm_unpackhi_epi8(v, z);
+    _mm_storeu_ps(d + i, _mm_cvtepi32_ps(_mm_unpacklo_epi16(lo, z)));
+    _mm_storeu_ps(d + i + 4, _mm_cvtepi32_ps(_mm_unpackhi_epi16(lo, z)));
+    _mm_storeu_ps(d + i + 8, _mm_cvtepi32_ps(_mm_unpacklo_epi16(hi, z)));
+    _mm_storeu_ps(d + i + 12, _mm_cvtepi32_ps(_mm_unpackhi_epi16(hi, z)));
+  }
+#endif
+  for (; i < n; i++) d[i] = (float)s[i];
+}
 inline odo_ctx* context();
 inline odo_ctx* side_context();
-inline unsigned long long next_stamp() { static thread_local unsigned long long s = 0; return ++s; }
+// Content stamps are process-wide (a Mat may be created on one thread and used on another: equal stamps must mean equal content).
+inline unsigned long long next_stamp() { static std::atomic<unsigned long long> s{0}; return ++s; }
+struct MatBuf;
+// The live buffers of a thread in creation order (the stereo-partner guess). A buffer may be destroyed on another thread than the
+// one that created it: the list is its own heap object (kept alive by its members) and every link is touched under its lock.
+struct BufList { std::mutex mu; MatBuf* tail = nullptr; };
+inline const std::shared_ptr<BufList>& buf_list() { static thread_local std::shared_ptr<BufList> l = std::make_shared<BufList>(); return l; }
 struct MatBuf : std::enable_shared_from_this<MatBuf> {
   uint8_t* host = nullptr;
   size_t bytes = 0;
   bool pinned = false;
   void* dev = nullptr;        // device mirror (allocated on first use by an estimator)
   int dev_async = 0;
+  odo_ctx *ctx = nullptr, *side = nullptr;   // the contexts of the thread the mirror belongs to (its free list, its two streams)
   bool host_valid = true, dev_valid = false;
   unsigned long upload_ticket = 0;  // != 0: an asynchronous DMA issued with this ticket may still be reading `host`
   bool upload_on_side = false;      // ... on the side context's stream (a stereo partner uploaded ahead of its first use)
-  void free_mirror() {              // stream-ordered release to the main context's free list: behind what either stream has queued on the block
+  // (a buffer that wanders to another thread's classes gives up the mirror it had on the first thread's streams)
+  void bind() { if (ctx != context()) { if (ctx) { wait_upload(); free_mirror(); } ctx = context(); side = side_context(); } }
+  void free_mirror() {              // stream-ordered release to the owning context's free list: behind what either stream has queued on the block
     if (!dev) return;
-    if (side_pending) odo_ctx_stream_wait(context(), side_context());
-    odo_dev_free_async(context(), dev, bytes, dev_async);
+    if (side_pending) odo_ctx_stream_wait(ctx, side);
+    odo_dev_free_async(ctx, dev, bytes, dev_async);
     dev = nullptr; dev_valid = false; side_pending = false;
   }
   bool side_pending = false;        // the main stream has not been ordered behind that upload yet
   unsigned long long stamp;         // names the CONTENT: renewed whenever host code may have written or a kernel has (keys the
                                     // pyramid cache and the prepared front half of ComputeDepth)
-  MatBuf *prev = nullptr, *next = nullptr;   // live buffers of this thread in creation order (stereo-partner guess)
+  std::shared_ptr<BufList> list;             // the creating thread's list
+  MatBuf *prev = nullptr, *next = nullptr;   // ... in creation order (stereo-partner guess); guarded by list->mu
+  std::shared_ptr<MatBuf> successor() {      // the buffer created right after this one, if it is still alive
+    std::lock_guard<std::mutex> lk(list->mu);
+    return next ? next->weak_from_this().lock() : nullptr;
+  }
   bool fill_pending = false;                 // Mat(rows, cols, type, value): the fill is done on the first host access
   double fill_value = 0.0;
   int fill_type = 0;
@@ -143,10 +358,10 @@ struct MatBuf : std::enable_shared_from_this<MatBuf> {
   MatBuf(const MatBuf&) = delete;
   MatBuf& operator=(const MatBuf&) = delete;
   void wait_upload() {  // the DMA out of `host` (if any) has finished: the block may be rewritten / recycled
-    if (upload_ticket) { odo_ctx_upload_wait(upload_on_side ? side_context() : context(), upload_ticket); upload_ticket = 0; }
+    if (upload_ticket) { odo_ctx_upload_wait(upload_on_side ? side : ctx, upload_ticket); upload_ticket = 0; }
   }
   void sync_host() {  // host copy current (lazy download; a pending fill is void once a kernel has overwritten the image)
-    if (!host_valid && dev) { odo_dev_download(context(), host, dev, bytes); upload_ticket = 0; fill_pending = false; }
+    if (!host_valid && dev) { odo_dev_download(ctx, host, dev, bytes); upload_ticket = 0; fill_pending = false; }
     else materialize_fill();
     host_valid = true;
   }
@@ -154,7 +369,6 @@ struct MatBuf : std::enable_shared_from_this<MatBuf> {
   // Mat the moment a constructor it was passed to has returned), the host copy is brought up to date, the mirror is void.
   void touch() { wait_upload(); sync_host(); dev_valid = false; side_pending = false; stamp = next_stamp(); }
 };
-inline MatBuf*& matbuf_tail() { static thread_local MatBuf* t = nullptr; return t; }
 // Page-locked blocks are expensive to create (hipHostMalloc): per-frame Mats recycle them through a small free list.
 struct PinnedPool {
   std::vector<std::pair<size_t, void*>> free_;
@@ -200,29 +414,34 @@ inline bool prefetch_eligible(const MatBuf& b) { return b.pinned && b.host_valid
 inline void prefetch_reserve(const std::shared_ptr<MatBuf>& sp) {
   MatBuf& b = *sp;
   if (!prefetch_eligible(b)) return;
-  if (!b.dev && odo_dev_alloc_async(context(), b.bytes, &b.dev, &b.dev_async) != 0) { b.dev = nullptr; return; }
+  b.bind();
+  if (!b.dev && odo_dev_alloc_async(b.ctx, b.bytes, &b.dev, &b.dev_async) != 0) { b.dev = nullptr; return; }
   mirror_lru().use(sp);
 }
 // Second half: the copy, on the side stream (already ordered behind the mark).
 inline void prefetch_to_device(const std::shared_ptr<MatBuf>& sp) {
   MatBuf& b = *sp;
   if (!prefetch_eligible(b) || !b.dev) return;
-  if (odo_dev_upload_async(side_context(), b.dev, b.host, b.bytes) != 0) return;
-  b.upload_ticket = odo_ctx_upload_ticket(side_context());
+  if (odo_dev_upload_async(b.side, b.dev, b.host, b.bytes) != 0) return;
+  b.upload_ticket = odo_ctx_upload_ticket(b.side);
   b.upload_on_side = true;
   b.side_pending = true;
   b.dev_valid = true;
 }
-inline MatBuf::MatBuf(size_t n) : bytes(n), stamp(next_stamp()) {
+inline MatBuf::MatBuf(size_t n) : bytes(n), stamp(next_stamp()), list(buf_list()) {
   if (n >= (64u << 10)) { host = static_cast<uint8_t*>(pinned_pool().get(n)); pinned = host != nullptr; }
   if (!host) host = static_cast<uint8_t*>(std::malloc(n ? n : 1));
-  prev = matbuf_tail();
+  std::lock_guard<std::mutex> lk(list->mu);
+  prev = list->tail;
   if (prev) prev->next = this;
-  matbuf_tail() = this;
+  list->tail = this;
 }
 inline MatBuf::~MatBuf() {
-  if (prev) prev->next = next;
-  if (next) next->prev = prev; else matbuf_tail() = prev;
+  {
+    std::lock_guard<std::mutex> lk(list->mu);
+    if (prev) prev->next = next;
+    if (next) next->prev = prev; else list->tail = prev;
+  }
   free_mirror();
   if (pinned) {
     wait_upload();  // a DMA may still be reading the block (a retired ticket costs nothing)
@@ -246,6 +465,7 @@ class Mat {
     buf_->fill_pending = true; buf_->fill_value = fill; buf_->fill_type = type_;
   }
   void create(int r, int c, int type) {
+    if (buf_ && rows == r && cols == c && type_ == type) return;   // cv::Mat::create keeps a fitting buffer
     rows = r; cols = c; type_ = type;
     buf_ = std::make_shared<detail::MatBuf>((size_t)r * c * elemSize());
   }
@@ -263,23 +483,32 @@ class Mat {
   template <class T> const T& at(int y, int x) const { return ptr<T>(y)[x]; }
   void copyTo(Mat& dst) const {
     dst.create(rows, cols, type_);
-    if (buf_) { buf_->sync_host(); std::memcpy(dst.buf_->host, buf_->host, buf_->bytes); }
+    if (buf_ && dst.buf_ != buf_) { buf_->sync_host(); dst.buf_->touch(); std::memcpy(dst.buf_->host, buf_->host, buf_->bytes); }
+  }
+  // the one conversion the runner uses: imread's 8-bit image to PixelType (ref: run_odometry_kitti_offline.cpp:348,358); dst keeps its
+  // buffer when it fits (the runner refills the same two Mats every frame)
+  void convertTo(Mat& dst, int rtype) const {
+    if (rtype == type_) { copyTo(dst); return; }
+    if (empty() || type_ != CV_8U || rtype != CV_32F) { std::cout << "odometry_hip: Mat::convertTo converts CV_8U to CV_32F only" << std::endl; return; }
+    dst.create(rows, cols, rtype);
+    detail::convert_8u_32f(ptr<uint8_t>(), dst.ptr<float>(), (size_t)rows * cols);
   }
   Mat clone() const { Mat m; copyTo(m); return m; }
   // -- device side, for the shim's classes only --
   // Device copy of the pixels for reading (uploads when the mirror is missing or stale). Null on failure.
   const void* device_in() const {
     detail::MatBuf& b = *buf_;
-    if (!b.dev && odo_dev_alloc_async(detail::context(), b.bytes, &b.dev, &b.dev_async) != 0) return nullptr;
+    b.bind();
+    if (!b.dev && odo_dev_alloc_async(b.ctx, b.bytes, &b.dev, &b.dev_async) != 0) return nullptr;
     detail::mirror_lru().use(buf_);
     if (!b.dev_valid) {
       b.materialize_fill();
-      if (odo_dev_upload_async(detail::context(), b.dev, b.host, b.bytes) != 0) return nullptr;
-      b.upload_ticket = b.pinned ? odo_ctx_upload_ticket(detail::context()) : 0;
+      if (odo_dev_upload_async(b.ctx, b.dev, b.host, b.bytes) != 0) return nullptr;
+      b.upload_ticket = b.pinned ? odo_ctx_upload_ticket(b.ctx) : 0;
       b.upload_on_side = false;
       b.dev_valid = true;
     } else if (b.side_pending) {   // uploaded ahead on the side stream: the main stream's work goes behind that copy
-      if (odo_ctx_stream_wait(detail::context(), detail::side_context()) != 0) return nullptr;
+      if (odo_ctx_stream_wait(b.ctx, b.side) != 0) return nullptr;
       b.side_pending = false;
     }
     return b.dev;
@@ -288,9 +517,10 @@ class Mat {
   // Device buffer a kernel is about to overwrite completely: afterwards the device holds the truth, the host copy is stale.
   void* device_out() {
     detail::MatBuf& b = *buf_;
+    b.bind();
     b.wait_upload();
-    if (b.side_pending) { odo_ctx_stream_wait(detail::context(), detail::side_context()); b.side_pending = false; }
-    if (!b.dev && odo_dev_alloc_async(detail::context(), b.bytes, &b.dev, &b.dev_async) != 0) return nullptr;
+    if (b.side_pending) { odo_ctx_stream_wait(b.ctx, b.side); b.side_pending = false; }
+    if (!b.dev && odo_dev_alloc_async(b.ctx, b.bytes, &b.dev, &b.dev_async) != 0) return nullptr;
     b.dev_valid = true;
     b.host_valid = false;
     b.fill_pending = false;
@@ -301,6 +531,7 @@ class Mat {
   // without allocating (ComputeDepth started ahead writes into blocks reserved for its outputs before their Mats exist).
   void adopt_device(void* block, int async_flag) {
     detail::MatBuf& b = *buf_;
+    b.bind();
     b.wait_upload();
     b.free_mirror();
     b.dev = block; b.dev_async = async_flag;
@@ -313,6 +544,8 @@ class Mat {
   int type_ = CV_32F;
   std::shared_ptr<detail::MatBuf> buf_;
 };
+namespace detail { inline bool lazy_outputs() { return false; } }
+inline void Download(Mat& m) { const Mat& c = m; if (!c.empty()) (void)c.ptr<uint8_t>(); }   // (any const access brings the host copy up to date)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -458,38 +691,83 @@ inline odo_ctx* side_context() {
   }
   return ctx;
 }
-// Device view of an input / output image for both Mat flavours. With the stand-in Mat the view borrows the Mat's mirror
-// (no copy when it is current); with cv::Mat there is nothing to hang a mirror on and nothing that reports writes, so every
-// input is staged and uploaded into a stream-ordered scratch block and every output is downloaded before the call returns.
+// Device view of an input / output image for both Mat flavours: the Mat's mirror (no copy when it is current). The stand-in Mat
+// carries its mirror itself and voids it on every non-const access; a cv::Mat's mirror lives in the record table above and is
+// checked against the Mat's pixels by fingerprint, once per call into a shim class.
 #ifdef ODOMETRY_SHIM_WITH_OPENCV
-// (a cv::Mat may be a view: its rows lie m.step bytes apart. Inputs are uploaded row by row into a dense device image; outputs
-// must be continuous — the callers check, with the reference's own message, ref: src/depth_estimate.cpp:259-263 — and a view handed
-// in as an output yields no device buffer instead of bytes in the wrong place.)
-struct DevIn {
-  void* dev = nullptr; int async_ = 0; size_t n = 0;
-  explicit DevIn(const Mat& m) : n(m.total() * m.elemSize()) {
-    if (m.empty() || odo_dev_alloc_async(context(), n, &dev, &async_) != 0) { dev = nullptr; return; }
-    const size_t row_bytes = (size_t)m.cols * m.elemSize();
-    const int rc = m.isContinuous() ? odo_dev_upload_async(context(), dev, m.data, n)
-                                    : odo_dev_upload_2d_async(context(), dev, m.data, (size_t)m.step, row_bytes, m.rows);
-    if (rc != 0) { odo_dev_free_async(context(), dev, n, async_); dev = nullptr; }
+inline std::shared_ptr<MatBuf> buffer_of(const Mat& m) { return mat_table().find(m, true, false); }
+inline std::shared_ptr<MatBuf> held_buffer_of(const Mat& m) { return mat_table().find(m, true, true); }   // ComputeDepth's stereo pair
+// (an output left on the device — ODOMETRY_SHIM_LAZY_OUTPUTS — IS held: its record says "the host bytes are stale, do not look", and
+//  a recycled address with the same geometry would inherit that)
+inline std::shared_ptr<MatBuf> output_buffer_of(const Mat& m, bool hold = false) { return mat_table().find(m, true, hold); }
+inline unsigned long long content_stamp(const Mat& m) {
+  auto b = buffer_of(m);
+  if (!b) return 0;
+  b->validate();
+  return b->stamp;
+}
+inline unsigned long long output_stamp(const Mat& m) { auto b = output_buffer_of(m); return b ? b->stamp : 0; }   // (just written by us)
+inline size_t device_bytes(const Mat& m) { return m.total() * m.elemSize(); }
+// (a cv::Mat may be a view: its rows lie m.step bytes apart. Inputs are staged row by row into a dense device image; outputs must be
+// continuous — the callers check, with the reference's own message, ref: src/depth_estimate.cpp:259-263 — and a view handed in as an
+// output yields no device buffer instead of bytes in the wrong place.)
+inline const void* device_in(const Mat& m) {
+  auto sp = buffer_of(m);
+  if (!sp) return nullptr;
+  MatBuf& b = *sp;
+  b.bind();
+  b.validate();
+  if (!b.dev && odo_dev_alloc_async(b.ctx, b.bytes, &b.dev, &b.dev_async) != 0) { b.dev = nullptr; return nullptr; }
+  if (!b.dev_valid) {
+    if (!b.upload(b.ctx)) return nullptr;
+  } else if (b.side_pending) {   // uploaded ahead on the side stream: the main stream's work goes behind that copy
+    if (odo_ctx_stream_wait(b.ctx, b.side) != 0) return nullptr;
+    b.side_pending = false;
   }
-  ~DevIn() { if (dev) odo_dev_free_async(context(), dev, n, async_); }
-  DevIn(const DevIn&) = delete;
-  DevIn& operator=(const DevIn&) = delete;
+  return b.dev;
+}
+inline void* device_out(Mat& m, bool hold = false) {
+  if (m.empty() || !m.isContinuous()) return nullptr;
+  auto sp = output_buffer_of(m, hold);
+  MatBuf& b = *sp;
+  b.bind();
+  if (b.side_pending) { odo_ctx_stream_wait(b.ctx, b.side); b.side_pending = false; }
+  if (!b.dev && odo_dev_alloc_async(b.ctx, b.bytes, &b.dev, &b.dev_async) != 0) { b.dev = nullptr; return nullptr; }
+  b.content_changed();
+  b.dev_valid = true; b.host_valid = false; b.checked = call_epoch();
+  return b.dev;
+}
+inline void adopt_device(Mat& m, void* block, int async_flag, bool hold = false) {
+  auto sp = output_buffer_of(m, hold);
+  MatBuf& b = *sp;
+  b.bind();
+  b.free_mirror();
+  b.content_changed();
+  b.dev = block; b.dev_async = async_flag;
+  b.dev_valid = true; b.host_valid = false; b.checked = call_epoch();
+}
+struct DevIn {
+  const void* dev;
+  explicit DevIn(const Mat& m) : dev(device_in(m)) {}
   const void* get() const { return dev; }
 };
+// An output image: on the device while the call runs, in the Mat's host memory when the call returns — unless `lazy` (see above).
 struct DevOut {
-  Mat& m; void* dev = nullptr; int async_ = 0;
-  explicit DevOut(Mat& mm) : m(mm) {
-    if (!m.empty() && m.isContinuous()) odo_dev_alloc_async(context(), m.total() * m.elemSize(), &dev, &async_);
-  }
-  ~DevOut() { if (dev) { odo_dev_download(context(), m.data, dev, m.total() * m.elemSize()); odo_dev_free_async(context(), dev, m.total() * m.elemSize(), async_); } }
+  std::shared_ptr<MatBuf> b; void* dev; bool lazy;
+  explicit DevOut(Mat& m, bool lazy_ = false) : dev(device_out(m, lazy_)), lazy(lazy_) { if (dev) b = output_buffer_of(m); }
+  ~DevOut() { if (b && !lazy && !b->host_valid) b->deliver_now(); }
   DevOut(const DevOut&) = delete;
   DevOut& operator=(const DevOut&) = delete;
   void* get() { return dev; }
 };
 #else
+inline std::shared_ptr<MatBuf> buffer_of(const Mat& m) { return m.buffer(); }
+inline std::shared_ptr<MatBuf> held_buffer_of(const Mat& m) { return m.buffer(); }
+inline unsigned long long content_stamp(const Mat& m) { return m.content_stamp(); }
+inline unsigned long long output_stamp(const Mat& m) { return m.content_stamp(); }
+inline size_t device_bytes(const Mat& m) { return m.device_bytes(); }
+inline void adopt_device(Mat& m, void* block, int async_flag, bool = false) { m.adopt_device(block, async_flag); }
+struct CallScope { CallScope() {} };
 struct DevIn {
   const void* dev;
   explicit DevIn(const Mat& m) : dev(m.device_in()) {}
@@ -497,7 +775,7 @@ struct DevIn {
 };
 struct DevOut {
   void* dev;
-  explicit DevOut(Mat& m) : dev(m.device_out()) {}
+  explicit DevOut(Mat& m, bool = false) : dev(m.device_out()) {}
   void* get() { return dev; }
 };
 #endif
@@ -518,7 +796,6 @@ inline const Mat& pyr_level(const std::shared_ptr<PyrHandle>& h, int level) {
   }
   return h->host[level];
 }
-#ifndef ODOMETRY_SHIM_WITH_OPENCV
 // What the drop-in classes do AHEAD of the call that needs it (same launches and copies, earlier; ODOMETRY_SHIM_NO_LOOKAHEAD=1 in
 // the environment switches all of it off). The runner's frame is strictly serial — ImagePyramid(left) :205, Solve :215,
 // ComputeDepth(left, right) :229, ImagePyramid(left) again :251 — so whatever does not depend on the Solve's result is started
@@ -563,6 +840,14 @@ struct Lookahead {
   const MatBuf* next_guess_was = nullptr;        // what the previous frame's guess named (compared, never dereferenced)
   int pending_rows = 0, pending_cols = 0;
   unsigned long pending_mark = 0;                // the main stream's fill level then (odo_ctx_mark): the side stream goes behind THAT
+#ifdef ODOMETRY_SHIM_WITH_OPENCV
+  // cv::Mat outputs are host memory: the three images of a ComputeDepth started ahead are copied into page-locked staging blocks
+  // behind the job, still beside the Solve; ComputeDepth (:229) copies them on into its output Mats
+  void* out_stage[3] = {nullptr, nullptr, nullptr};
+  size_t out_stage_bytes[3] = {0, 0, 0};
+  unsigned long out_mark = 0;                    // the side stream's position behind the three copies; 0: nothing staged
+  ~Lookahead() { for (void* p : out_stage) if (p) odo_host_free(p); }
+#endif
 };
 inline Lookahead& lookahead() { static thread_local Lookahead l; return l; }
 // The three output blocks of a ComputeDepth started ahead go back to the free list: behind the job (side stream) when it was started.
@@ -627,6 +912,20 @@ inline void run_lookahead(odo_lm* lm = nullptr, const odo_pyr* cur_img = nullptr
           if (lm && cur_img) (void)odo_lm_candidate_begin(lm, side_context(), cur_img, hp->p, la.pending_mark);
         }
       }
+#ifdef ODOMETRY_SHIM_WITH_OPENCV
+      la.out_mark = 0;
+      bool staged = true;
+      for (int i = 0; i < 3 && staged; i++) {
+        if (i > 0 && lazy_outputs()) break;      // (left_disp / left_dep stay on the device)
+        if (la.out_stage_bytes[i] != e.bytes[i]) {
+          if (la.out_stage[i]) odo_host_free(la.out_stage[i]);
+          la.out_stage[i] = odo_host_alloc(e.bytes[i]);
+          la.out_stage_bytes[i] = la.out_stage[i] ? e.bytes[i] : 0;
+        }
+        staged = la.out_stage[i] && odo_dev_download_async(side_context(), la.out_stage[i], e.blk[i], e.bytes[i]) == 0;
+      }
+      if (staged) la.out_mark = odo_ctx_mark(side_context());
+#endif
     } else {
       (void)odo_depth_prepare_left_dev_marked(la.estimator, side_context(), static_cast<const float*>(lb->dev), la.pending_rows,
                                               la.pending_cols, lb->stamp, la.pending_mark);
@@ -659,7 +958,7 @@ inline void run_lookahead(odo_lm* lm = nullptr, const odo_pyr* cur_img = nullptr
 // What ImagePyramid's constructor records for the Solve that follows (run_lookahead issues it): once per image content.
 inline void record_lookahead(const Mat& in, int num_levels, bool smooth) {
   Lookahead& la = lookahead();
-  const std::shared_ptr<MatBuf>& lb = in.buffer();
+  const std::shared_ptr<MatBuf> lb = buffer_of(in);
   if (!lb || la.recorded_stamp == lb->stamp) return;   // (:251 builds the pyramid of the :205 image again)
   la.recorded_stamp = lb->stamp;
   la.pending_left = lb; la.pending_rows = in.rows; la.pending_cols = in.cols;
@@ -667,13 +966,13 @@ inline void record_lookahead(const Mat& in, int num_levels, bool smooth) {
   // the partner guess: the Mat ComputeDepth was given with this one last time, else the same-sized Mat created right after it
   std::shared_ptr<MatBuf> guess;
   if (la.last_left.lock().get() == lb.get()) guess = la.last_right.lock();
-  else if (lb->next && lb->next->bytes == lb->bytes) guess = lb->next->shared_from_this();
+  else if (auto nx = lb->successor()) { if (nx->bytes == lb->bytes) guess = nx; }
   if (guess && guess.get() != lb.get()) prefetch_reserve(guess);
   la.pending_partner = guess;
   // the next frame's left image: a sequence read into Mats pair by pair (ref: :334-359) has it right behind the partner
   std::shared_ptr<MatBuf> nxt;
-  if (guess && guess.get() != lb.get() && guess->next && guess->next != lb.get() && guess->next->bytes == lb->bytes)
-    nxt = guess->next->shared_from_this();
+  if (guess && guess.get() != lb.get())
+    if (auto nx = guess->successor()) { if (nx.get() != lb.get() && nx->bytes == lb->bytes) nxt = nx; }
   // ... but only once the guess has proved right: this left image IS what the previous frame's guess named (a runner that
   // refills two Mats per frame, ref: :200, never gets there — the same-sized Mat behind its partner is something else)
   const bool proven = la.next_guess_was == lb.get();
@@ -681,7 +980,8 @@ inline void record_lookahead(const Mat& in, int num_levels, bool smooth) {
   if (nxt && proven) prefetch_reserve(nxt); else nxt.reset();
   la.pending_next = nxt;
   std::shared_ptr<MatBuf> nxt_r;
-  if (nxt && nxt->next && nxt->next != lb.get() && nxt->next != guess.get() && nxt->next->bytes == lb->bytes) nxt_r = nxt->next->shared_from_this();
+  if (nxt)
+    if (auto nx = nxt->successor()) { if (nx.get() != lb.get() && nx.get() != guess.get() && nx->bytes == lb->bytes) nxt_r = nx; }
   if (nxt_r) prefetch_reserve(nxt_r);
   la.pending_next_r = nxt_r;
   // ... and the three output blocks of a ComputeDepth started ahead (recycled blocks: their earlier use is in front of the mark)
@@ -689,11 +989,10 @@ inline void record_lookahead(const Mat& in, int num_levels, bool smooth) {
   else early_release();
   la.pending_mark = odo_ctx_mark(context());
 }
-#endif
 inline std::shared_ptr<PyrHandle> make_pyr(int num_levels, const Mat& in, bool smooth, int kind, const char* what) {
-#ifndef ODOMETRY_SHIM_WITH_OPENCV
+  CallScope call;
   Lookahead& la = lookahead();
-  const unsigned long long stamp = in.content_stamp();
+  const unsigned long long stamp = (in.type() == PixelType && !in.empty()) ? content_stamp(in) : 0;
   if (la.on && stamp)
     for (auto& e : la.cache)
       if (e.stamp == stamp && e.levels == num_levels && e.smooth == (smooth ? 1 : 0) && e.kind == kind)
@@ -703,7 +1002,7 @@ inline std::shared_ptr<PyrHandle> make_pyr(int num_levels, const Mat& in, bool s
           if (e.on_side) {
             odo_ctx_stream_wait_mark(context(), side_context(), e.side_mark);   // (an overwritten mark: behind everything queued there)
             e.on_side = false;
-            if (in.buffer()) in.buffer()->side_pending = false;
+            if (auto ib = buffer_of(in)) ib->side_pending = false;
           }
           if (la.ahead_pyr.get() == hit.get()) la.ahead_pyr.reset();
           if (la.early_dep_pyr.get() == hit.get()) la.early_dep_pyr.reset();
@@ -712,7 +1011,6 @@ inline std::shared_ptr<PyrHandle> make_pyr(int num_levels, const Mat& in, bool s
           return hit;
         }
   if (kind == ODO_PYR_IMAGE) la.ahead_pyr.reset();   // (a pyramid built ahead for an image that did not come)
-#endif
   auto h = std::make_shared<PyrHandle>();
   h->host.resize(num_levels > 0 ? num_levels : 0);
   h->have.assign(num_levels > 0 ? num_levels : 0, 0);
@@ -727,14 +1025,12 @@ inline std::shared_ptr<PyrHandle> make_pyr(int num_levels, const Mat& in, bool s
     std::cout << what << std::endl;  // ref: src/image_pyramid.cpp:16-18,34-36 (prints, object stays unusable)
     h->p = nullptr;
   }
-#ifndef ODOMETRY_SHIM_WITH_OPENCV
   if (ok && la.on) {
     Lookahead::Entry& e = la.cache[la.cache_next++ % 8];
-    e.stamp = in.content_stamp(); e.levels = num_levels; e.smooth = smooth ? 1 : 0; e.kind = kind; e.h = h; e.on_side = false; e.side_mark = 0;
+    e.stamp = content_stamp(in); e.levels = num_levels; e.smooth = smooth ? 1 : 0; e.kind = kind; e.h = h; e.on_side = false; e.side_mark = 0;
     if (kind == ODO_PYR_IMAGE) record_lookahead(in, num_levels, smooth);
     else { la.dp_levels = num_levels; la.dp_smooth = smooth ? 1 : 0; }
   }
-#endif
   return h;
 }
 }  // namespace detail
@@ -805,12 +1101,11 @@ class LevenbergMarquardtOptimizer {  // ref: include/lm_optimizer.h:24-115
 
   Affine4f Solve(const ImagePyramid& kImagePyr1, const DepthPyramid& kDepthPyr1, const ImagePyramid& kImagePyr2) {
     Affine4f out;
-#ifndef ODOMETRY_SHIM_WITH_OPENCV
+    detail::CallScope call;
     // the Solve's launches first (odo_lm_solve_begin returns once they are queued), then what can run beside them
     if (kImagePyr1.handle() && kDepthPyr1.handle() && kImagePyr2.handle())
       (void)odo_lm_solve_begin(lm_, kImagePyr1.handle(), kDepthPyr1.handle(), kImagePyr2.handle());
     detail::run_lookahead(lm_, kImagePyr2.handle());
-#endif
     if (odo_lm_solve(lm_, kImagePyr1.handle(), kDepthPyr1.handle(), kImagePyr2.handle(), affine_data(out)) != 0)
       std::cout << "Optimize failed! " << std::endl;  // ref: src/lm_optimizer.cpp:60-65 (out = pseudo-identity)
     return out;
@@ -864,14 +1159,10 @@ class DepthEstimator {  // ref: include/depth_estimate.h:24-121
     if (odo_depth_create(detail::context(), grad_th, ssd_th, photo_th, min_depth, max_depth, lambda, huber_delta, precision,
                          max_iters, boundary, Kp, baseline, max_residuals, 0, 0, &d_) != 0)
       std::cout << "odometry_hip: " << odo_last_error() << std::endl;
-#ifndef ODOMETRY_SHIM_WITH_OPENCV
     else detail::lookahead().estimator = d_;
-#endif
   }
   ~DepthEstimator() {
-#ifndef ODOMETRY_SHIM_WITH_OPENCV
     if (detail::lookahead().estimator == d_) { detail::early_release(); detail::lookahead().estimator = nullptr; }
-#endif
     odo_depth_destroy(d_);
   }
   DepthEstimator(const DepthEstimator&) = delete;
@@ -894,19 +1185,25 @@ class DepthEstimator {  // ref: include/depth_estimate.h:24-121
     std::cout << "computing disparity ..." << std::endl;
     int st = -1;
     bool collected = false;
-#ifndef ODOMETRY_SHIM_WITH_OPENCV
+    detail::CallScope call;
     {
       detail::Lookahead& la = detail::lookahead();
       la.pending_left.reset();   // (a lookahead nobody issued: too late for it now)
-      // the job started ahead from ImagePyramid's constructor / Solve, if it was started for exactly these two images
+      // the job started ahead from ImagePyramid's constructor / Solve, if it was started for exactly these two images (a cv::Mat's
+      // pixels are fingerprinted here: a caller who rewrote one of them since the upload gets a fresh job)
       detail::Lookahead::Early& e = la.early;
-      const detail::MatBuf *lb = left_img.buffer().get(), *rb = right_img.buffer().get();
+      const std::shared_ptr<detail::MatBuf> lsp = detail::held_buffer_of(left_img), rsp = detail::held_buffer_of(right_img);
+      const detail::MatBuf *lb = lsp.get(), *rb = rsp.get();
+#ifdef ODOMETRY_SHIM_WITH_OPENCV
+      if (e.started && lsp && rsp) { lsp->validate(); rsp->validate(); }
+#endif
       if (e.started && e.est == d_ && lb && rb && lb->dev == e.left_dev && lb->dev_valid && lb->stamp == e.left_stamp &&
           rb->dev == e.right_dev && rb->dev_valid && rb->stamp == e.right_stamp && left_img.rows == e.rows && left_img.cols == e.cols &&
-          left_val.device_bytes() == e.bytes[0] && left_disp.device_bytes() == e.bytes[1] && left_dep.device_bytes() == e.bytes[2]) {
-        left_val.adopt_device(e.blk[0], e.async_[0]);
-        left_disp.adopt_device(e.blk[1], e.async_[1]);
-        left_dep.adopt_device(e.blk[2], e.async_[2]);
+          detail::device_bytes(left_val) == e.bytes[0] && detail::device_bytes(left_disp) == e.bytes[1] &&
+          detail::device_bytes(left_dep) == e.bytes[2]) {
+        detail::adopt_device(left_val, e.blk[0], e.async_[0]);
+        detail::adopt_device(left_disp, e.blk[1], e.async_[1], detail::lazy_outputs());
+        detail::adopt_device(left_dep, e.blk[2], e.async_[2], detail::lazy_outputs());
         int persist_on = 0, redone_before = 0, redone_after = 0;
         odo_depth_persistent_stats(d_, &persist_on, &redone_before);
         st = odo_depth_compute_end_dev(d_, static_cast<const float*>(e.left_dev), static_cast<const float*>(e.right_dev), e.rows, e.cols,
@@ -915,40 +1212,49 @@ class DepthEstimator {  // ref: include/depth_estimate.h:24-121
         e.blk[0] = e.blk[1] = e.blk[2] = nullptr;   // (the Mats own them now)
         e.reserved = e.started = false;
         collected = true;
+        detail::stats().early_adopted++;
         odo_depth_persistent_stats(d_, &persist_on, &redone_after);
+#ifdef ODOMETRY_SHIM_WITH_OPENCV
+        {  // the outputs reach the caller's host memory: out of the staging blocks filled beside the Solve, or (the job had to be run
+           // again, nothing was staged) straight from the device
+          Mat* outs[3] = {&left_val, &left_disp, &left_dep};
+          const bool staged = la.out_mark != 0 && redone_after == redone_before && st == 0;
+          if (staged) odo_ctx_wait_mark(detail::side_context(), la.out_mark);
+          for (int i = 0; i < 3; i++) {
+            if (i > 0 && detail::lazy_outputs()) break;
+            auto ob = detail::output_buffer_of(*outs[i]);
+            if (staged) ob->deliver_from(la.out_stage[i]); else ob->deliver_now();
+          }
+          la.out_mark = 0;
+        }
+#endif
         // the :252 pyramid was built from this block beside the Solve: DepthPyramid finds it — unless the job had to be run again
         // (its persistent launch gave up: the block was rewritten after the pyramid had been built from it)
         if (la.early_dep_pyr && st == 0 && redone_after == redone_before) {
           detail::Lookahead::Entry& ce = la.cache[la.cache_next++ % 8];
-          ce.stamp = left_dep.content_stamp(); ce.levels = la.dp_levels; ce.smooth = la.dp_smooth; ce.kind = ODO_PYR_DEPTH;
+          ce.stamp = detail::output_stamp(left_dep); ce.levels = la.dp_levels; ce.smooth = la.dp_smooth; ce.kind = ODO_PYR_DEPTH;
           ce.h = la.early_dep_pyr; ce.on_side = true; ce.side_mark = la.early_dep_mark;
         } else {
           la.early_dep_pyr.reset();
         }
-        la.last_left = left_img.buffer(); la.last_right = right_img.buffer();
+        la.last_left = lsp; la.last_right = rsp;
       } else {
+        if (e.started) detail::stats().early_dropped++;
         detail::early_release();   // (the library drops the job itself at its next call)
         la.early_dep_pyr.reset();
       }
     }
-#endif
     if (!collected) {
       detail::DevIn l(left_img), r(right_img);
-      detail::DevOut v(left_val), ds(left_disp), dp(left_dep);
+      detail::DevOut v(left_val), ds(left_disp, detail::lazy_outputs()), dp(left_dep, detail::lazy_outputs());
       if (l.get() && r.get() && v.get() && ds.get() && dp.get()) {
-#ifdef ODOMETRY_SHIM_WITH_OPENCV
-        st = odo_depth_compute_dev(d_, static_cast<const float*>(l.get()), static_cast<const float*>(r.get()), left_img.rows,
-                                   left_img.cols, static_cast<uint8_t*>(v.get()), static_cast<float*>(ds.get()),
-                                   static_cast<float*>(dp.get()));
-#else
         // (the left image's content stamp lets the estimator pick up the half prepared from ImagePyramid's constructor)
         st = odo_depth_compute_dev_stamped(d_, static_cast<const float*>(l.get()), static_cast<const float*>(r.get()), left_img.rows,
                                            left_img.cols, static_cast<uint8_t*>(v.get()), static_cast<float*>(ds.get()),
-                                           static_cast<float*>(dp.get()), left_img.content_stamp());
+                                           static_cast<float*>(dp.get()), detail::content_stamp(left_img));
         detail::Lookahead& la = detail::lookahead();
-        la.last_left = left_img.buffer(); la.last_right = right_img.buffer();
+        la.last_left = detail::buffer_of(left_img); la.last_right = detail::buffer_of(right_img);
         la.est_rows = left_img.rows; la.est_cols = left_img.cols;
-#endif
       }
     }
     int iters = 0, nsel = 0, nmatch = 0, nvalid = 0;

@@ -60,6 +60,11 @@ SIGNATURES = {
     "odo_host_free": (None, [_vp]),
     "odo_dev_upload_async": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "odo_dev_upload_2d_async": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, C.c_int]),
+    "odo_ctx_wait_mark": (C.c_int, [_vp, C.c_ulong]),
+    "odo_host_fingerprint": (C.c_ulonglong, [_vp, C.c_size_t, C.c_size_t, C.c_int]),
+    "odo_host_copy_fingerprint": (C.c_ulonglong, [_vp, C.c_size_t, _vp, C.c_size_t, C.c_size_t, C.c_int]),
+    "odo_dev_upload_fp_async": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_ulonglong)]),
+    "odo_dev_download_async": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "odo_dev_alloc_async": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp), C.POINTER(C.c_int)]),
     "odo_dev_free_async": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int]),
     "odo_pyramid_create": (C.c_int, [_vp, _fp, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),

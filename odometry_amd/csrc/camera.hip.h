@@ -191,9 +191,8 @@ extern "C" int odo_camera_download_maps(const odo_camera* c, float* mapx_host, f
   if (!c || !c->configured) return fail("odo_camera_download_maps: not configured");
   HIP_OK(hipSetDevice(c->ctx->device));
   const size_t bytes = (size_t)c->map_rows * c->map_cols * sizeof(float);
-  if (mapx_host) HIP_OK(hipMemcpyAsync(mapx_host, c->d_mapx, bytes, hipMemcpyDeviceToHost, c->ctx->stream));
-  if (mapy_host) HIP_OK(hipMemcpyAsync(mapy_host, c->d_mapy, bytes, hipMemcpyDeviceToHost, c->ctx->stream));
-  HIP_OK(hipStreamSynchronize(c->ctx->stream));
+  if (mapx_host && copy_to_user_host(c->ctx, mapx_host, c->d_mapx, bytes)) return -1;
+  if (mapy_host && copy_to_user_host(c->ctx, mapy_host, c->d_mapy, bytes)) return -1;
   return 0;
 }
 
@@ -230,11 +229,9 @@ extern "C" int odo_camera_undistort_rectify(odo_camera* c, const float* src, int
     HIP_OK(hipMalloc((void**)&c->d_dst, db));
     c->dst_cap = db;
   }
-  HIP_OK(hipMemcpyAsync(c->d_src, src, sb, hipMemcpyHostToDevice, c->ctx->stream));
+  if (upload_rows_async(c->ctx, c->d_src, src, sb, sb, 1)) return -1;
   if (odo_camera_undistort_rectify_dev(c, c->d_src, src_rows, src_cols, c->d_dst, border_value)) return -1;
-  HIP_OK(hipMemcpyAsync(dst, c->d_dst, db, hipMemcpyDeviceToHost, c->ctx->stream));
-  HIP_OK(hipStreamSynchronize(c->ctx->stream));
-  return 0;
+  return copy_to_user_host(c->ctx, dst, c->d_dst, db);
 }
 
 extern "C" int odo_camera_destroy(odo_camera* c) {

@@ -102,6 +102,8 @@ struct odo_ctx {
   unsigned long up_issued, up_retired;
   hipEvent_t sw_ev[32];  // odo_ctx_stream_wait / odo_ctx_mark: events recorded on this stream for other streams to wait on (ring)
   unsigned long sw_next;
+  void* bounce;          // pinned: downloads into caller memory that is not page-locked go through it (copy_to_user_host)
+  size_t bounce_cap;
   // per-sequence argument table of the batched Solves issued on this stream (odo_lm_solve_batch): per context, because the
   // launches a finished Solve still has queued read it, and only the stream orders the next upload behind them
   void* lm_batch_h;   // pinned
@@ -211,6 +213,7 @@ extern "C" int odo_ctx_destroy(odo_ctx* c) {
     (void)hipEventDestroy(c->stage_ev[i]);
     if (c->stage[i]) (void)hipHostFree(c->stage[i]);
   }
+  if (c->bounce) (void)hipHostFree(c->bounce);
   if (c->pool) { for (auto& b : *c->pool) { if (b.ev) (void)hipEventDestroy(b.ev); (void)hipFree(b.p); } delete c->pool; }
   if (c->pool_events) { for (auto& e : *c->pool_events) (void)hipEventDestroy(e); delete c->pool_events; }
   for (auto& e : c->up_ev) if (e) (void)hipEventDestroy(e);
@@ -262,6 +265,7 @@ extern "C" int odo_dev_free(odo_ctx* c, void* p) {
 // Uploads from any other host memory go through the context's pinned staging ring (one CPU copy, then the same DMA).
 // Either way the call returns as soon as the caller may reuse / release its buffer, without waiting for the device.
 #include <map>
+#include "host_fp.h"
 static std::mutex g_pin_mu;
 static std::map<const char*, size_t> g_pinned;  // start -> bytes of every live odo_host_alloc block
 static bool host_is_pinned(const void* p, size_t bytes) {
@@ -285,6 +289,29 @@ extern "C" void odo_host_free(void* p) {
     g_pinned.erase((const char*)p);
   }
   (void)hipHostFree(p);
+}
+// Device -> caller's host memory, synchronous. The runtime is never handed a pageable pointer: for a large copy it page-locks the
+// caller's pages on the fly and keeps them registered, and when the caller later frees that memory (a per-frame cv::Mat) the unmap
+// notifier evicts every queue of the process for milliseconds (measured round 5: a Solve in flight went from 0.3 to 23 ms).
+// Page-locked destinations (odo_host_alloc) are written in place; anything else through the context's pinned bounce block.
+static int copy_to_user_host(odo_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return 0;
+  if (host_is_pinned(dst, bytes)) {
+    HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+  }
+  std::lock_guard<std::mutex> lk(*c->mu);
+  if (c->bounce_cap < bytes) {
+    if (c->bounce) HIP_OK(hipHostFree(c->bounce));
+    c->bounce = nullptr; c->bounce_cap = 0;
+    HIP_OK(hipHostMalloc(&c->bounce, bytes, hipHostMallocDefault));
+    c->bounce_cap = bytes;
+  }
+  HIP_OK(hipMemcpyAsync(c->bounce, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_OK(hipStreamSynchronize(c->stream));
+  memcpy(dst, c->bounce, bytes);
+  return 0;
 }
 // dst (device, dense rows of row_bytes) <- src (host, pitch src_pitch), `rows` rows; asynchronous on the context's stream.
 static int upload_rows_async(odo_ctx* c, void* dst, const void* src, size_t src_pitch, size_t row_bytes, int rows) {
@@ -369,7 +396,7 @@ extern "C" int odo_ctx_stream_wait(odo_ctx* waiter, odo_ctx* signaller) {
 }
 extern "C" int odo_dev_upload(odo_ctx* c, void* dst, const void* src, size_t bytes) {
   if (!c) return fail("NULL ctx");
-  HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  if (upload_rows_async(c, dst, src, bytes, bytes, 1)) return -1;   // (staged: no pageable pointer reaches the runtime)
   HIP_OK(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -381,11 +408,57 @@ extern "C" int odo_dev_upload_2d_async(odo_ctx* c, void* dst, const void* src, s
   if (!c || !dst || !src || rows < 1 || src_pitch < row_bytes) return fail("odo_dev_upload_2d_async: bad arg");
   return upload_rows_async(c, dst, src, src_pitch, row_bytes, rows);
 }
-extern "C" int odo_dev_download(odo_ctx* c, void* dst, const void* src, size_t bytes) {
-  if (!c) return fail("NULL ctx");
-  HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
-  HIP_OK(hipStreamSynchronize(c->stream));
+// ---- images in memory the library cannot watch (cv::Mat): fingerprints, staged uploads that fingerprint what they stage,
+// downloads into page-locked memory that are copied out (and fingerprinted) later — see host_fp.h
+extern "C" unsigned long long odo_host_fingerprint(const void* src, size_t src_pitch, size_t row_bytes, int rows) {
+  if (!src || rows < 1 || src_pitch < row_bytes) return 0;
+  return hostfp::image(src, src_pitch, row_bytes, rows, nullptr, 0);
+}
+extern "C" unsigned long long odo_host_copy_fingerprint(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t row_bytes,
+                                                        int rows) {
+  if (!dst || !src || rows < 1 || src_pitch < row_bytes || dst_pitch < row_bytes) return 0;
+  return hostfp::image(src, src_pitch, row_bytes, rows, dst, dst_pitch);
+}
+extern "C" int odo_dev_upload_fp_async(odo_ctx* c, void* dst, const void* src, size_t src_pitch, size_t row_bytes, int rows,
+                                       unsigned long long* fp) {
+  if (!c || !dst || !src || !fp || rows < 1 || src_pitch < row_bytes) return fail("odo_dev_upload_fp_async: bad arg");
+  const size_t total = row_bytes * (size_t)rows;
+  std::lock_guard<std::mutex> lk(*c->mu);
+  const int slot = c->stage_next;
+  c->stage_next = (slot + 1) % kStageSlots;
+  if (c->stage_busy[slot]) { HIP_OK(hipEventSynchronize(c->stage_ev[slot])); c->stage_busy[slot] = 0; }
+  if (c->stage_cap[slot] < total) {
+    if (c->stage[slot]) HIP_OK(hipHostFree(c->stage[slot]));
+    c->stage[slot] = nullptr; c->stage_cap[slot] = 0;
+    HIP_OK(hipHostMalloc(&c->stage[slot], total, hipHostMallocDefault));
+    c->stage_cap[slot] = total;
+  }
+  *fp = hostfp::image(src, src_pitch, row_bytes, rows, c->stage[slot], row_bytes);   // the fingerprint of exactly the bytes that go up
+  HIP_OK(hipMemcpyAsync(dst, c->stage[slot], total, hipMemcpyHostToDevice, c->stream));
+  HIP_OK(hipEventRecord(c->stage_ev[slot], c->stream));
+  c->stage_busy[slot] = 1;
   return 0;
+}
+extern "C" int odo_dev_download_async(odo_ctx* c, void* dst_pinned, const void* src, size_t bytes) {
+  if (!c || !dst_pinned || !src) return fail("odo_dev_download_async: NULL arg");
+  if (!host_is_pinned(dst_pinned, bytes)) return fail("odo_dev_download_async: the destination is not an odo_host_alloc block");
+  HIP_OK(hipMemcpyAsync(dst_pinned, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  return 0;
+}
+extern "C" int odo_ctx_wait_mark(odo_ctx* c, unsigned long mark) {
+  if (!c) return fail("odo_ctx_wait_mark: NULL ctx");
+  hipEvent_t ev = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(*c->mu);
+    if (mark != 0 && mark <= c->sw_next && c->sw_next - mark < 32) ev = c->sw_ev[mark % 32];
+  }
+  if (ev) HIP_OK(hipEventSynchronize(ev));     // (a ring entry re-recorded since: a later point of the same stream — implies the mark)
+  else HIP_OK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+extern "C" int odo_dev_download(odo_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (!c || !dst || !src) return fail("odo_dev_download: NULL arg");
+  return copy_to_user_host(c, dst, src, bytes);
 }
 // Recycled scratch for per-frame images of the drop-in path (see dev_alloc_any): the release does not synchronise.
 extern "C" int odo_dev_alloc_async(odo_ctx* c, size_t bytes, void** out, int* is_async) {
@@ -552,10 +625,7 @@ extern "C" int odo_pyramid_download(const odo_pyr* p, int level, float* dst) {
   if (!p || !dst) return fail("odo_pyramid_download: NULL arg");
   if (level < 0 || level >= p->levels)  // ref: src/image_pyramid.cpp:22-25 exits the process; here: -1
     return fail("Requested image pyramid does not exist! Max pyramid id: %d", p->levels - 1);
-  HIP_OK(hipMemcpyAsync(dst, p->dev + p->off[level], sizeof(float) * (size_t)p->r[level] * p->c[level],
-                        hipMemcpyDeviceToHost, p->ctx->stream));
-  HIP_OK(hipStreamSynchronize(p->ctx->stream));
-  return 0;
+  return copy_to_user_host(p->ctx, dst, p->dev + p->off[level], sizeof(float) * (size_t)p->r[level] * p->c[level]);
 }
 extern "C" const float* odo_pyramid_level_dev(const odo_pyr* p, int level) {
   if (!p || level < 0 || level >= p->levels) return nullptr;
@@ -2761,18 +2831,16 @@ static int depth_host(odo_depth* d, const float* left, const float* right, int r
   if (upload_rows_async(d->ctx, d->d_left, left, sizeof(float) * (size_t)cols, sizeof(float) * (size_t)cols, rows)) return -1;
   if (upload_rows_async(d->ctx, d->d_right, right, sizeof(float) * (size_t)cols, sizeof(float) * (size_t)cols, rows)) return -1;
   if (depth_run(d, d->d_left, d->d_right, rows, cols, d->d_val, d->d_disp, d->d_dep, stage)) return -1;
-  HIP_OK(hipMemcpyAsync(val, d->d_val, n, hipMemcpyDeviceToHost, s));
-  HIP_OK(hipMemcpyAsync(disp, d->d_disp, sizeof(float) * n, hipMemcpyDeviceToHost, s));
-  HIP_OK(hipMemcpyAsync(dep, d->d_dep, sizeof(float) * n, hipMemcpyDeviceToHost, s));
   int rc = depth_finish(d);
-  if (rc == 2) {   // the persistent launch gave up: the same job again on the step launches, outputs copied again
+  if (rc == 2) {   // the persistent launch gave up: the same job again on the step launches
     if (depth_run(d, d->d_left, d->d_right, rows, cols, d->d_val, d->d_disp, d->d_dep, stage)) return -1;
-    HIP_OK(hipMemcpyAsync(val, d->d_val, n, hipMemcpyDeviceToHost, s));
-    HIP_OK(hipMemcpyAsync(disp, d->d_disp, sizeof(float) * n, hipMemcpyDeviceToHost, s));
-    HIP_OK(hipMemcpyAsync(dep, d->d_dep, sizeof(float) * n, hipMemcpyDeviceToHost, s));
     rc = depth_finish(d);
   }
-  return rc == 0 ? 0 : -1;
+  if (rc != 0) return -1;
+  (void)s;
+  if (copy_to_user_host(d->ctx, val, d->d_val, n) || copy_to_user_host(d->ctx, disp, d->d_disp, sizeof(float) * n) ||
+      copy_to_user_host(d->ctx, dep, d->d_dep, sizeof(float) * n)) return -1;
+  return 0;
 }
 
 extern "C" int odo_depth_compute(odo_depth* d, const float* left, const float* right, int rows, int cols, uint8_t* val,

@@ -5,6 +5,10 @@
 //            :334-359): partner known from the last ComputeDepth, no next frame to send ahead
 //   swap     like refill, but the roles of the two Mats alternate every frame (the partner guess names the wrong image)
 //   poke     like vector, and the right image is modified between Solve and ComputeDepth (a job started ahead must be dropped)
+//   poke_left   like refill, and the LEFT image is modified in place between Solve (:215) and ComputeDepth (:229): the upload made for
+//            ImagePyramid (:205) no longer is the image — ComputeDepth and the keyframe pyramid must see the new pixels
+// Built twice by the test: with the stand-in Mat (writes are seen through ptr<T>() / at<T>()) and with -DODOMETRY_SHIM_WITH_OPENCV against
+// tests/stubs (a cv::Mat reports nothing: every use fingerprints the pixels). The last line on stderr: SHIM_STATS (ShimStats).
 // Prints one line per frame: pose bits and checksums of the three depth outputs. The test runs every mode with and without
 // ODOMETRY_SHIM_NO_LOOKAHEAD=1: same lines (poke: against its own look-ahead-off run).
 #include <cstdint>
@@ -63,6 +67,8 @@ int main(int argc, char** argv) {
       T = lm.Solve(*kf_img, *kf_dep, cur);
     }
     if (mode == "poke" && (k % 3) == 1) R.at<float>(rows / 2, cols / 2) += 1.0f;   // after anything was started ahead for R
+    if (mode == "poke_left" && (k % 3) == 1)                                        // a patch no sparse sample would notice
+      for (int y = 100; y < 108; y++) for (int x = 301; x < 309; x++) L.at<float>(y, x) = 255.0f - L.at<float>(y, x);
     Mat val(rows, cols, CV_8U, 0.0), disp(rows, cols, PixelType), dep(rows, cols, PixelType);
     const int st = de.ComputeDepth(L, R, val, disp, dep);
     if (k == 0 || (k % 4) == 0) {   // a new keyframe now and then
@@ -72,11 +78,15 @@ int main(int argc, char** argv) {
     } else {
       lm.Reset(T, 0.01f);
     }
+    Download(disp); Download(dep);   // (ODOMETRY_SHIM_LAZY_OUTPUTS=1 leaves them on the device until asked for; otherwise nothing to do)
     const Mat &cv = val, &cd = disp, &cp = dep;
     std::printf("%d %d %016llx %016llx %016llx %016llx\n", k, st, (unsigned long long)fnv(affine_data(T), 64),
                 (unsigned long long)fnv(cv.ptr<uint8_t>(), px), (unsigned long long)fnv(cd.ptr<float>(), px * 4),
                 (unsigned long long)fnv(cp.ptr<float>(), px * 4));
   }
   std::cout.rdbuf(keep);
+  const ShimStats& st = shim_stats();
+  std::fprintf(stderr, "SHIM_STATS uploads %lu fingerprints %lu unchanged %lu changed %lu early_adopted %lu early_dropped %lu delivered %lu verify_failures %lu\n",
+               st.uploads, st.fingerprints, st.unchanged, st.changed, st.early_adopted, st.early_dropped, st.delivered, st.verify_failures);
   return 0;
 }

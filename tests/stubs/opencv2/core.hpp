@@ -1,7 +1,8 @@
 // tests/stubs/opencv2/core.hpp — TEST SCAFFOLDING ONLY: a minimal stand-in for <opencv2/core.hpp>, written from OpenCV's documented
-// public API (cv::Mat: rows, cols, data, step, type(), total(), elemSize(), isContinuous(), ptr / at, create / clone / copyTo,
-// reference-counted header copies, ROI views, user-data headers with a row step; cv::Scalar, cv::Size, cv::Rect and the constants the
-// drop-in classes name). This image has no OpenCV; the stub exists so that the -DODOMETRY_SHIM_WITH_OPENCV branch of
+// public API (cv::Mat: rows, cols, data, step, u, type(), total(), elemSize(), isContinuous(), ptr / at, create / clone / copyTo /
+// convertTo (8U -> 32F, as the runner's load_data uses it), reference-counted header copies — the count lives in the UMatData that the
+// public member `u` points to; u == nullptr for a header over user data, as in OpenCV —, ROI views, user-data headers with a row step;
+// cv::Scalar, cv::Size, cv::Rect and the constants the drop-in classes name). This image has no OpenCV; the stub exists so that the -DODOMETRY_SHIM_WITH_OPENCV branch of
 // include/odometry_shim.hpp — the one a maintainer of the reference would build — goes through a compiler and a GPU run
 // (tests/test_gpu_shim.py). It is not part of the product and implements no image processing.
 #pragma once
@@ -9,6 +10,9 @@
 #include <cstdint>
 #include <cstring>
 #include <cstdlib>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #define CV_8U 0
 #define CV_32F 5
@@ -50,14 +54,20 @@ struct MatStep {
   size_t operator[](int i) const { return p[i]; }
 };
 
+struct UMatData {   // (OpenCV: the allocation a Mat header refers to; only what the stand-in needs)
+  int refcount;
+  uchar* origdata;
+};
+
 class Mat {
  public:
   enum { AUTO_STEP = 0 };
   int flags, dims, rows, cols;
   uchar* data;
+  UMatData* u;   // nullptr: the pixels are user data this header does not own
   MatStep step;
 
-  Mat() : flags(0), dims(0), rows(0), cols(0), data(nullptr), type_(0), base_(nullptr), refcount_(nullptr) {}
+  Mat() : flags(0), dims(0), rows(0), cols(0), data(nullptr), u(nullptr), type_(0) {}
   Mat(int r, int c, int type) : Mat() { create(r, c, type); }
   Mat(int r, int c, int type, const Scalar& s) : Mat() { create(r, c, type); setTo(s); }
   // header over user data: no copy, no ownership; `step_bytes` = distance between rows (AUTO_STEP: no padding)
@@ -65,18 +75,18 @@ class Mat {
     rows = r; cols = c; type_ = type; dims = 2; data = static_cast<uchar*>(user);
     step.p[1] = elemSize(); step.p[0] = step_bytes == AUTO_STEP ? (size_t)c * elemSize() : step_bytes;
   }
-  Mat(const Mat& m) : flags(m.flags), dims(m.dims), rows(m.rows), cols(m.cols), data(m.data), step(m.step), type_(m.type_), base_(m.base_),
-                      refcount_(m.refcount_) { if (refcount_) ++*refcount_; }
+  Mat(const Mat& m) : flags(m.flags), dims(m.dims), rows(m.rows), cols(m.cols), data(m.data), u(m.u), step(m.step), type_(m.type_) {
+    if (u) ++u->refcount;
+  }
   Mat(const Mat& m, const Rect& roi) : Mat(m) {   // a view: shares the pixels, keeps the parent's row step
     rows = roi.height; cols = roi.width;
     data = m.data + (size_t)roi.y * m.step.p[0] + (size_t)roi.x * m.elemSize();
   }
   Mat& operator=(const Mat& m) {
     if (this != &m) {
-      if (m.refcount_) ++*m.refcount_;
+      if (m.u) ++m.u->refcount;
       release();
-      flags = m.flags; dims = m.dims; rows = m.rows; cols = m.cols; data = m.data; step = m.step; type_ = m.type_; base_ = m.base_;
-      refcount_ = m.refcount_;
+      flags = m.flags; dims = m.dims; rows = m.rows; cols = m.cols; data = m.data; step = m.step; type_ = m.type_; u = m.u;
     }
     return *this;
   }
@@ -84,18 +94,43 @@ class Mat {
   Mat operator()(const Rect& roi) const { return Mat(*this, roi); }
 
   void create(int r, int c, int type) {
-    if (data && rows == r && cols == c && type_ == type && isContinuous() && refcount_) return;   // cv::Mat::create keeps a fitting buffer
+    if (data && rows == r && cols == c && type_ == type) return;   // cv::Mat::create keeps a fitting buffer (whoever else refers to it)
     release();
     rows = r; cols = c; type_ = type; dims = 2;
     step.p[1] = elemSize(); step.p[0] = (size_t)c * elemSize();
     const size_t n = (size_t)r * step.p[0];
-    base_ = static_cast<uchar*>(std::malloc(n ? n : 1));
-    data = base_;
-    refcount_ = new int(1);
+    u = new UMatData{1, static_cast<uchar*>(std::malloc(n ? n : 1))};
+    data = u->origdata;
   }
   void release() {
-    if (refcount_ && --*refcount_ == 0) { std::free(base_); delete refcount_; }
-    base_ = nullptr; refcount_ = nullptr; data = nullptr; rows = cols = 0;
+    if (u && --u->refcount == 0) { std::free(u->origdata); delete u; }
+    u = nullptr; data = nullptr; rows = cols = 0;
+  }
+  // the one conversion the runner uses: imread's 8-bit image to PixelType (ref: run_odometry_kitti_offline.cpp:348,358)
+  void convertTo(Mat& dst, int rtype) const {
+    dst.create(rows, cols, rtype);
+    for (int y = 0; y < rows; y++) {
+      const uchar* sp = data + (size_t)y * step.p[0];
+      uchar* dp = dst.data + (size_t)y * dst.step.p[0];
+      if (type_ == CV_8U && rtype == CV_32F) {   // (OpenCV's convertTo is vectorised: so is the stand-in's, whatever -O level the test builds with)
+        int x = 0;
+#if defined(__SSE2__)
+        const __m128i z = _mm_setzero_si128();
+        for (; x + 16 <= cols; x += 16) {
+          const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(sp + x));
+          const __m128i lo = _mm_unpacklo_epi8(v, z), hi = _mm_unpackhi_epi8(v, z);
+          float* d = reinterpret_cast<float*>(dp) + x;
+          _mm_storeu_ps(d, _mm_cvtepi32_ps(_mm_unpacklo_epi16(lo, z)));
+          _mm_storeu_ps(d + 4, _mm_cvtepi32_ps(_mm_unpackhi_epi16(lo, z)));
+          _mm_storeu_ps(d + 8, _mm_cvtepi32_ps(_mm_unpacklo_epi16(hi, z)));
+          _mm_storeu_ps(d + 12, _mm_cvtepi32_ps(_mm_unpackhi_epi16(hi, z)));
+        }
+#endif
+        for (; x < cols; x++) reinterpret_cast<float*>(dp)[x] = (float)sp[x];
+      }
+      else if (type_ == rtype) std::memcpy(dp, sp, (size_t)cols * elemSize());
+      else std::abort();
+    }
   }
   Mat clone() const { Mat m; copyTo(m); return m; }
   void copyTo(Mat& dst) const {
@@ -103,13 +138,14 @@ class Mat {
     for (int y = 0; y < rows; y++) std::memcpy(dst.data + (size_t)y * dst.step.p[0], data + (size_t)y * step.p[0], (size_t)cols * elemSize());
   }
   Mat& setTo(const Scalar& s) {
-    for (int y = 0; y < rows; y++)
+    for (int y = 0; y < rows; y++) {
+      uchar* row = data + (size_t)y * step.p[0];
+      if (type_ == CV_8U || s[0] == 0.0) { std::memset(row, type_ == CV_8U ? (int)s[0] : 0, (size_t)cols * elemSize()); continue; }
       for (int x = 0; x < cols; x++) {
-        uchar* p = data + (size_t)y * step.p[0] + (size_t)x * elemSize();
-        if (type_ == CV_32F) *reinterpret_cast<float*>(p) = (float)s[0];
-        else if (type_ == CV_64F) *reinterpret_cast<double*>(p) = s[0];
-        else *p = (uchar)s[0];
+        if (type_ == CV_32F) reinterpret_cast<float*>(row)[x] = (float)s[0];
+        else reinterpret_cast<double*>(row)[x] = s[0];
       }
+    }
     return *this;
   }
   int type() const { return type_; }
@@ -126,7 +162,5 @@ class Mat {
 
  private:
   int type_;
-  uchar* base_;
-  int* refcount_;
 };
 }  // namespace cv

@@ -90,41 +90,123 @@ def test_shim_poses_bit_identical_to_tracker(tmp_path):
     assert np.array_equal(np.fromfile(rel_off, np.float32), np.fromfile(rel, np.float32))
 
 
-def test_lookahead_survives_refilled_swapped_and_poked_mats(tmp_path, monkeypatch):
-    """What the drop-in classes start ahead (the partner's upload, the whole ComputeDepth, the next frame's upload and pyramid) is keyed
-    by content stamps: two Mats refilled per frame like the reference's load_data, the two Mats swapping roles every frame, and a right
-    image modified between Solve and ComputeDepth all give the poses and depth outputs of a run with the look-ahead switched off,
-    bit for bit — and the refilled runs give those of the run with every frame in its own Mat."""
-    from odometry_amd import synth
-    seq = synth.make_sequence(10, seed=3)
-    L, R = seq["left"], seq["right"]
-    frames = str(tmp_path / "frames.bin")
-    with open(frames, "wb") as f:
+def _write_frames(path, L, R):
+    with open(path, "wb") as f:
         np.array([len(L), L[0].shape[0], L[0].shape[1]], np.int32).tofile(f)
         for l, r in zip(L, R):
             l.astype(np.float32).tofile(f)
             r.astype(np.float32).tofile(f)
-    exe = _build(tmp_path, "tests/shim_lookahead_harness.cpp", "shim_lookahead_harness")
 
-    def run(mode, off):
-        env = dict(os.environ)
+
+def _harness_runner(exe, frames, n):
+    def run(mode, off=False, **extra_env):
+        env = dict(os.environ, **extra_env)
         if off:
             env["ODOMETRY_SHIM_NO_LOOKAHEAD"] = "1"
         out = subprocess.run([exe, frames, mode], capture_output=True, text=True, timeout=300, env=env)
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
         lines = out.stdout.strip().splitlines()
-        assert len(lines) == len(L) and all(ln.split()[1] == "0" for ln in lines), out.stdout[-2000:]
-        return lines
+        assert len(lines) == n and all(ln.split()[1] == "0" for ln in lines), out.stdout[-2000:]
+        st = re.search(r"SHIM_STATS (.*)", out.stderr)
+        stats = dict(zip(st.group(1).split()[0::2], map(int, st.group(1).split()[1::2])))
+        return lines, stats
+    return run
 
-    base = run("vector", True)
+
+def test_lookahead_survives_refilled_swapped_and_poked_mats(tmp_path, monkeypatch):
+    """What the drop-in classes start ahead (the partner's upload, the whole ComputeDepth, the next frame's upload and pyramid) is keyed
+    by content stamps: two Mats refilled per frame like the reference's load_data, the two Mats swapping roles every frame, a right
+    image modified between Solve and ComputeDepth and a LEFT image modified in place between Solve (:215) and ComputeDepth (:229) all
+    give the poses and depth outputs of a run with the look-ahead switched off, bit for bit — and the refilled runs give those of the
+    run with every frame in its own Mat."""
+    from odometry_amd import synth
+    seq = synth.make_sequence(10, seed=3)
+    L, R = seq["left"], seq["right"]
+    frames = str(tmp_path / "frames.bin")
+    _write_frames(frames, L, R)
+    run = _harness_runner(_build(tmp_path, "tests/shim_lookahead_harness.cpp", "shim_lookahead_harness"), frames, len(L))
+    base, _ = run("vector", True)
     for mode in ("vector", "refill", "swap"):
-        assert run(mode, False) == base, mode
-    assert run("refill", True) == base and run("swap", True) == base
-    poked = run("poke", True)
-    assert poked != base and run("poke", False) == poked
+        lines, stats = run(mode)
+        assert lines == base, mode
+        if mode != "swap":
+            assert stats["early_adopted"] >= len(L) - 2, (mode, stats)     # ComputeDepth ran beside the Solve
+    assert run("refill", True)[0] == base and run("swap", True)[0] == base
+    poked = run("poke", True)[0]
+    assert poked != base and run("poke")[0] == poked
+    poked_left = run("poke_left", True)[0]
+    assert poked_left != base and poked_left != poked and run("poke_left")[0] == poked_left
     # a persistent depth launch that gives up inside the job started ahead: ComputeDepth runs the job again
     monkeypatch.setenv("ODO_DEPTH_PERSIST_FAULT", "1")
-    assert run("vector", False) == base and run("refill", False) == base
+    assert run("vector")[0] == base and run("refill")[0] == base
+
+
+def test_cv_mat_build_has_the_lookahead_and_detects_in_place_writes(tmp_path, monkeypatch):
+    """The build INTEGRATION.md prescribes (-DODOMETRY_SHIM_WITH_OPENCV, here against tests/stubs): a cv::Mat reports no writes, so its
+    device mirror is keyed by the pixels' address and checked by a full-image fingerprint at every use.
+      * the same lines as the stand-in build in every mode of tests/shim_lookahead_harness.cpp, look-ahead on and off;
+      * refill (the reference's load_data shape): ONE upload per image per frame — the left image of :205 is still the mirror at :229
+        and :251 —, and ComputeDepth of every frame but the first two is found finished beside the Solve;
+      * poke / poke_left: a right image modified between Solve and ComputeDepth, and a LEFT image modified IN PLACE between :205 and
+        :229 (an 8x8 patch the 48-word sample cannot see), are detected by the fingerprint: the job started ahead is dropped, the new
+        pixels are uploaded, results equal the look-ahead-off run;
+      * ODOMETRY_SHIM_VERIFY_MIRRORS=1 (every "unchanged" verdict checked by downloading the mirror and comparing bytes): no failure;
+      * ODOMETRY_SHIM_LAZY_OUTPUTS=1 (left_disp / left_dep stay on the device until odometry::Download): the same lines."""
+    from odometry_amd import synth
+    seq = synth.make_sequence(10, seed=3)
+    L, R = seq["left"], seq["right"]
+    n = len(L)
+    frames = str(tmp_path / "frames.bin")
+    _write_frames(frames, L, R)
+    std = _harness_runner(_build(tmp_path, "tests/shim_lookahead_harness.cpp", "harness_std"), frames, n)
+    cv = _harness_runner(_build_cv(tmp_path, "tests/shim_lookahead_harness.cpp", "harness_cv"), frames, n)
+    base = std("vector", True)[0]
+    for mode in ("vector", "refill", "swap"):
+        for off in (False, True):
+            assert cv(mode, off)[0] == base, (mode, off)
+    lines, st = cv("refill")
+    assert st["uploads"] == 2 * n, st                                  # one per image per frame
+    assert st["early_adopted"] >= n - 2 and st["early_dropped"] == 0, st
+    assert st["delivered"] == 3 * n and st["verify_failures"] == 0, st
+    assert st["changed"] >= 2 * (n - 1) - 2, st                        # every refill was noticed
+    for mode in ("poke", "poke_left"):
+        want = std(mode, True)[0]
+        got, st = cv(mode)
+        assert got == want and cv(mode, True)[0] == want, mode
+        if mode == "poke_left":   # (refill shape; in "poke" every frame sits in a cv::Mat never seen before: nothing is started ahead)
+            assert st["early_dropped"] >= 3, (mode, st)                # frames 1, 4, 7: the job started ahead was for other pixels
+    # every "unchanged" verdict re-checked against the mirror's bytes
+    lines, st = cv("refill", ODOMETRY_SHIM_VERIFY_MIRRORS="1")
+    assert lines == base and st["verify_failures"] == 0 and st["unchanged"] > n, st
+    lines, st = cv("poke_left", ODOMETRY_SHIM_VERIFY_MIRRORS="1")
+    assert lines == std("poke_left", True)[0] and st["verify_failures"] == 0, st
+    # outputs left on the device until asked for
+    lines, st = cv("refill", ODOMETRY_SHIM_LAZY_OUTPUTS="1")
+    assert lines == base and st["delivered"] == 3 * n, st              # (val by ComputeDepth, the other two by the harness's Download)
+    assert cv("vector", ODOMETRY_SHIM_LAZY_OUTPUTS="1")[0] == base
+    # a persistent depth launch that gives up inside the job started ahead: ComputeDepth runs the job again, outputs re-delivered
+    monkeypatch.setenv("ODO_DEPTH_PERSIST_FAULT", "1")
+    assert cv("refill")[0] == base and cv("vector")[0] == base
+
+
+def test_runner_with_load_data_inside_the_loop(tmp_path):
+    """examples/run_odometry_synth.cpp --load-per-frame — the two Mats of a frame refilled inside the loop by convertTo from 8-bit
+    images, the reference runner's own frame source (run_odometry_kitti_offline.cpp:200,334-359) — in both builds: the poses of the
+    run with every frame preloaded, bit for bit, pass after pass."""
+    from odometry_amd import synth
+    seq = synth.make_sequence(14, seed=0)     # past the first keyframe switch (frame 9)
+    frames = str(tmp_path / "frames.bin")
+    _write_frames(frames, seq["left"], seq["right"])
+    want = None
+    for exe in (_build(tmp_path, "examples/run_odometry_synth.cpp", "synth_std"),
+                _build_cv(tmp_path, "examples/run_odometry_synth.cpp", "synth_cv")):
+        for extra in ([], ["--load-per-frame"]):
+            rel = exe + ".rel"
+            out = subprocess.run([exe, frames, "--time", "2", "--rel-bin", rel] + extra, capture_output=True, text=True, timeout=300)
+            assert out.returncode == 0 and "SHIM_MISMATCH" not in out.stderr, out.stdout[-1500:] + out.stderr[-1500:]
+            got = np.fromfile(rel, np.float32)
+            want = got if want is None else want
+            assert got.shape == want.shape and np.array_equal(got, want), (exe, extra)
 
 
 _CV_FLAGS = ["-DODOMETRY_SHIM_WITH_OPENCV", "-DODOMETRY_SHIM_WITH_EIGEN", "-I" + os.path.join(ROOT, "tests", "stubs")]

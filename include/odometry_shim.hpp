@@ -19,6 +19,10 @@
 #define ODOMETRY_SHIM_HPP
 
 #include <atomic>
+#ifdef ODOMETRY_SHIM_PHASES
+#include <chrono>
+#include <cstdio>
+#endif
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -1194,9 +1198,17 @@ class DepthEstimator {  // ref: include/depth_estimate.h:24-121
       detail::Lookahead::Early& e = la.early;
       const std::shared_ptr<detail::MatBuf> lsp = detail::held_buffer_of(left_img), rsp = detail::held_buffer_of(right_img);
       const detail::MatBuf *lb = lsp.get(), *rb = rsp.get();
+#ifdef ODOMETRY_SHIM_PHASES
+      static double ph_[6] = {0, 0, 0, 0, 0, 0}; static long phn_ = 0;
+      auto t_ = std::chrono::steady_clock::now();
+      auto lap_ = [&](int i) { auto n_ = std::chrono::steady_clock::now(); ph_[i] += std::chrono::duration<double, std::micro>(n_ - t_).count(); t_ = n_; };
+#else
+      auto lap_ = [](int) {};
+#endif
 #ifdef ODOMETRY_SHIM_WITH_OPENCV
       if (e.started && lsp && rsp) { lsp->validate(); rsp->validate(); }
 #endif
+      lap_(0);
       if (e.started && e.est == d_ && lb && rb && lb->dev == e.left_dev && lb->dev_valid && lb->stamp == e.left_stamp &&
           rb->dev == e.right_dev && rb->dev_valid && rb->stamp == e.right_stamp && left_img.rows == e.rows && left_img.cols == e.cols &&
           detail::device_bytes(left_val) == e.bytes[0] && detail::device_bytes(left_disp) == e.bytes[1] &&
@@ -1209,6 +1221,7 @@ class DepthEstimator {  // ref: include/depth_estimate.h:24-121
         st = odo_depth_compute_end_dev(d_, static_cast<const float*>(e.left_dev), static_cast<const float*>(e.right_dev), e.rows, e.cols,
                                        static_cast<uint8_t*>(e.blk[0]), static_cast<float*>(e.blk[1]), static_cast<float*>(e.blk[2]),
                                        e.left_stamp, e.right_stamp);
+        lap_(1);
         e.blk[0] = e.blk[1] = e.blk[2] = nullptr;   // (the Mats own them now)
         e.reserved = e.started = false;
         collected = true;
@@ -1220,13 +1233,18 @@ class DepthEstimator {  // ref: include/depth_estimate.h:24-121
           Mat* outs[3] = {&left_val, &left_disp, &left_dep};
           const bool staged = la.out_mark != 0 && redone_after == redone_before && st == 0;
           if (staged) odo_ctx_wait_mark(detail::side_context(), la.out_mark);
+          lap_(2);
           for (int i = 0; i < 3; i++) {
             if (i > 0 && detail::lazy_outputs()) break;
             auto ob = detail::output_buffer_of(*outs[i]);
             if (staged) ob->deliver_from(la.out_stage[i]); else ob->deliver_now();
           }
           la.out_mark = 0;
+          lap_(3);
         }
+#endif
+#ifdef ODOMETRY_SHIM_PHASES
+        if (++phn_ % 199 == 0) std::fprintf(stderr, "[ComputeDepth phases] validate L,R %.1f  adopt + wait for the job %.1f  wait for the staged copies %.1f  copy out %.1f us\n", ph_[0] / phn_, ph_[1] / phn_, ph_[2] / phn_, ph_[3] / phn_);
 #endif
         // the :252 pyramid was built from this block beside the Solve: DepthPyramid finds it — unless the job had to be run again
         // (its persistent launch gave up: the block was rewritten after the pyramid had been built from it)

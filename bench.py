@@ -681,7 +681,7 @@ def tracking_summary(e_abs, e_rel):
     return d
 
 
-def drive_leg(api, seq, warmup, steps, local_rank=0, details=None):
+def drive_leg(api, seq, warmup, steps, local_rank=0, details=None, oracle_frames=10):
     """One pass of the runner's loop over a resident sequence with the next pair announced (the timed run's configuration), on a
     tracker of its own: frames/s over `steps` frames after `warmup`, LM evaluations per frame, tracking error vs ground truth.
     details (a dict, optional): filled with the poses, the keyframes' level-0 point counts, launches per Solve, persistent-launch stats."""
@@ -712,8 +712,19 @@ def drive_leg(api, seq, warmup, steps, local_rank=0, details=None):
         details["poses"] = pk.copy()
         details["persistent"] = trk.persistent_stats()
     trk.close()
+    # the first oracle_frames frames against the CPU oracle's runner (the checker; outside every clock)
+    dmax = None
+    if oracle_frames > 0:
+        from oracle import runner as orunner
+        ref = orunner.OracleRunner()
+        ref.init(seq["left"][0], seq["right"][0])
+        dmax = 0.0
+        for k in range(min(oracle_frames, warmup + steps)):
+            c = ref.track(seq["left"][k + 1], seq["right"][k + 1])
+            dmax = max(dmax, float(np.abs(pk[k].reshape(4, 4).T.astype(np.float64) - c["pose_to_keyframe"]).max()))
     return dict(frames_per_s=round(steps / dt, 1), frames=steps, warmup=warmup, lm_evals_per_frame=round(float(np.mean(evals[warmup:])), 2),
-                keyframes=int(sum(flags)) + 1, tracking_error_vs_ground_truth_m=tracking_summary(e_abs, e_rel))
+                keyframes=int(sum(flags)) + 1, tracking_error_vs_ground_truth_m=tracking_summary(e_abs, e_rel),
+                pose_max_abs_delta_vs_oracle=dmax, oracle_frames=min(oracle_frames, warmup + steps) if oracle_frames > 0 else 0)
 
 
 def saturated_leg(api, seq, warmup, steps, local_rank=0):
@@ -726,7 +737,7 @@ def saturated_leg(api, seq, warmup, steps, local_rank=0):
     r = drive_leg(api, seq, warmup, steps, local_rank, details=d_on)
     os.environ["ODO_LM_NO_FINE"] = "1"
     try:
-        r_off = drive_leg(api, seq, warmup, steps, local_rank, details=d_off)
+        r_off = drive_leg(api, seq, warmup, steps, local_rank, details=d_off, oracle_frames=0)
     finally:
         del os.environ["ODO_LM_NO_FINE"]
     r["level0_points_mean"] = int(np.mean(d_on["level0_points"]))

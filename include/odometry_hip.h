@@ -240,12 +240,18 @@ int odo_lm_launch_stats(const odo_lm* lm, int* n_active_launches, int* n_total_l
  * launch gave up waiting for one of its workgroups and that were redone on the step launches (results unaffected): this
  * optimiser's own Solves plus the batched Solves (odo_lm_solve_batch, odo_tracker_batch) of its context. */
 int odo_lm_persistent_stats(const odo_lm* lm, int* workgroups, int* fallbacks);
-/* Its give-up policy. A wait inside the launch is bounded by the device wall clock (4 ms; ODO_LM_FINE_WAIT_US), so a give-up costs
- * that + one redo of the Solve on the step launches. Three give-ups switch the launch off; it is tried again after *retry_after
+/* Its give-up policy. A wait inside the launch is bounded by the device wall clock (4 ms; ODO_LM_FINE_WAIT_US) — stretched while the
+ * shader clock runs below nominal (process start, power cap), but never beyond 4 x the bound (16 ms) —, so a give-up costs that + one
+ * redo of the Solve on the step launches. Three give-ups switch the launch off; it is tried again after *retry_after
  * Solves — 4 096, doubling with every further switch-off up to 2^20 — and 1 024 clean Solves with the launch on forget all of it.
  * *strikes = give-ups that count at the moment (3: switched off), *solves_until_retry = Solves left on the step launches before the
  * next try (0 while the launch is on). */
 int odo_lm_persistent_backoff(const odo_lm* lm, int* strikes, int* retry_after, int* solves_until_retry);
+/* ComputeScaleNaive over levels too large for one workgroup (ref: src/lm_optimizer.cpp:338-358; dense levels, robust mode 2):
+ * *multi_launches = scale iterations issued on the multi-workgroup kernel, *fallbacks = those redone by the single-workgroup kernel
+ * queued behind it because the launch gave up waiting for a workgroup. The two kernels add in different orders: a Solve with a
+ * fall-back may differ from one without in the last bits of sigma (and so of the pose). Synchronises the optimiser's stream. */
+int odo_lm_tdist_stats(odo_lm* lm, long* multi_launches, int* fallbacks);
 
 /* Diagnostic: cycle-counter stamps at the phase boundaries of one LM update launch ("update kernel"). */
 int odo_debug_update_stamps(odo_lm* lm, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img, int level,
@@ -309,8 +315,9 @@ int odo_depth_time_stages(odo_depth* d, const float* left_dev, const float* righ
                           float us[3], double* candidates, int* n_selected);
 /* ReportStatus data (ref: src/depth_estimate.cpp:465-468) + counts printed by ComputeDepth (:62,74). */
 int odo_depth_report(const odo_depth* d, int* iters, float* cost, int* n_selected, int* n_matched, int* n_valid);
-/* DepthOptimization (ref: src/depth_estimate.cpp:141-191) runs as ONE persistent launch (depth_lm_persistent_kernel: 32 workgroups
- * of one XCD, every point's state in registers, one tagged 16-byte pair per 256 points and iteration through L2) instead of a launch
+/* DepthOptimization (ref: src/depth_estimate.cpp:141-191) runs as ONE persistent launch (depth_lm_persistent_kernel: 80 workgroups of
+ * 512 threads on one XCD, one point slot per thread with its state in registers, one tagged 16-byte pair {error sum, count} per
+ * workgroup and iteration through L2) instead of a launch
  * per iteration; the step launches are its fall-back, bit-identical. *on = 1 while the persistent launch is in use (0: off, by
  * choice — ODO_DEPTH_NO_PERSIST — or after three give-ups, with the pose LM's back-off: odo_lm_persistent_backoff), *fallbacks =
  * ComputeDepth calls whose launch gave up waiting for one of its workgroups and that were run again on the step launches. */

@@ -98,6 +98,7 @@ SIGNATURES = {
     "odo_lm_launch_stats": (C.c_int, [_vp, _ip, _ip, _dp]),
     "odo_lm_persistent_stats": (C.c_int, [_vp, _ip, _ip]),
     "odo_lm_persistent_backoff": (C.c_int, [_vp, _ip, _ip, _ip]),
+    "odo_lm_tdist_stats": (C.c_int, [_vp, C.POINTER(C.c_long), _ip]),
     "odo_debug_update_stamps": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _fp, C.POINTER(C.c_ulonglong)]),
     "odo_debug_solve": (C.c_int, [_vp, _dp, C.c_float, _fp]),
     "odo_depth_create": (C.c_int, [_vp] + [C.c_float] * 8 + [C.c_int, C.c_int, C.POINTER(Intrinsics), C.c_float,

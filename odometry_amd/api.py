@@ -260,6 +260,12 @@ class LevenbergMarquardtOptimizer:
         L.check(self.ctx.lib.odo_lm_persistent_stats(self.h, C.byref(k), C.byref(f)), "odo_lm_persistent_stats")
         return k.value, f.value
 
+    def tdist_stats(self):
+        """(scale iterations issued on the multi-workgroup kernel, those redone by its single-workgroup fall-back)"""
+        a, b = C.c_long(0), C.c_int(0)
+        L.check(self.ctx.lib.odo_lm_tdist_stats(self.h, C.byref(a), C.byref(b)), "odo_lm_tdist_stats")
+        return a.value, b.value
+
     def persistent_backoff(self):
         """(give-ups that count — 3: switched off —, Solves a switched-off launch waits before its next try, Solves left until then)"""
         a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)

@@ -892,7 +892,10 @@ __global__ void __launch_bounds__(1024) lm_tdist_scale_kernel(const float* __res
   if (only_if) {
     if (__hip_atomic_load(only_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
     __syncthreads();   // (every thread has read the flag)
-    if (threadIdx.x == 0) __hip_atomic_store(only_if, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(only_if, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      only_if[1] += 1;   // scale passes redone here, for odo_lm_tdist_stats: this kernel sums in another association than the multi-workgroup
+    }                    // launch, so after a give-up sigma (and the pose) may differ in the last bits from a run without one
   }
   __shared__ double shs[1024];
   __shared__ int shn[1024];
@@ -1028,6 +1031,7 @@ struct StepArgs {
   int min_level;        // lm_coarse_kernel: levels >= min_level run inside the workgroup (n_levels = none)
   int fine_lo;          // lm_fine_kernel_batch: the persistent launch takes levels [fine_lo, min_level) (>= min_level: none)
   unsigned long long* xbuf;  // ... and exchanges this sequence's partial rows through this buffer (kFineXbufWords words)
+  unsigned fine_dispatch;    // process-wide number of this persistent launch (g_lm_fine_dispatch; epochs are per optimiser and may coincide)
   unsigned fine_epoch;       // tags of the exchange: (fine_epoch << 8) + evaluation; the host never repeats an epoch on a buffer it has not cleared
   unsigned fine_wait;        // bound of one wait of the persistent launch in wall-clock ticks (0: kFineWaitTicks)
   int fine_home;             // the XCC id of the XCD this optimiser's persistent launch runs on (fine_on_home; < 0: class 0 wherever it lands)
@@ -1696,7 +1700,9 @@ constexpr unsigned kFineWaitTicks = 400000u;     // default bound of one wait, i
 // nominal 2.4 GHz: in the first milliseconds of a process (the shader clock ramps up from 95 MHz) and under power capping everything
 // a wait is for — another persistent kernel vacating its CUs, the slowest workgroup's evaluation — takes longer in wall-clock time,
 // and a fixed wall-clock bound then gives up on launches that are merely slow (seen: one depth job in ~ 400 frames at the start of a
-// process against one in 5 700 later — 0.7 ms inside a 20-step measurement).
+// process against one in 5 700 later — 0.7 ms inside a 20-step measurement). The stretch is capped: at 4 x `limit` of wall-clock
+// time the wait is over whatever the cycle counter says — the worst case a host-side timeout has to allow for is 16 ms for the pose
+// LM's default (4 ms) and 2 ms for the depth launch's (0.5 ms).
 struct FineDeadline {
   unsigned long long t0, c0;
   unsigned limit;
@@ -1704,7 +1710,10 @@ struct FineDeadline {
     return FineDeadline{(unsigned long long)wall_clock64(), (unsigned long long)__builtin_readcyclecounter(), limit_ticks};
   }
   __device__ __forceinline__ bool expired(int spin) const {
-    if ((spin & 31) != 31 || !((unsigned long long)wall_clock64() - t0 > (unsigned long long)limit)) return false;
+    if ((spin & 31) != 31) return false;
+    const unsigned long long dt = (unsigned long long)wall_clock64() - t0;
+    if (dt <= (unsigned long long)limit) return false;
+    if (dt > 4ull * (unsigned long long)limit) return true;   // (a hard wall-clock cap whatever the shader clock does: 4 x the bound)
     return (unsigned long long)__builtin_readcyclecounter() - c0 > 24ull * (unsigned long long)limit;
   }
 };
@@ -2039,8 +2048,10 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
         if (my_q < ODO_NACC && my_s == 0 && !(fault && vb == 0)) fine_publish(buf, vb, my_q, accq, tag, local);   // fault: row 0 never appears
       }
     } else {
-      // (Not reached today: the host sends only levels that fit, lm_fused_begin / lm_fill_step_args fits(). Kept as the general form
-      //  — and because without it the register allocator gives this kernel 245 VGPRs instead of 203, see test_kernel_register_budgets.)
+      // Levels of more virtual blocks than the 2 K the workgroups keep in registers (lm_plan_levels: up to 2 K x fine_passes, two
+      // passes by default — a keyframe near the reference's point cap, bench.py's `saturated_keyframe`): the points are re-read from
+      // L2 every evaluation, pass by pass. (The register allocator also needs this branch: without it the kernel takes 245 VGPRs
+      // instead of 203, see test_kernel_register_budgets.)
       const int rounds = (L.n + nblk * kLmBlock - 1) / (nblk * kLmBlock);  // > 1 only beyond 160 x 256 points (a round without
       for (int vb0 = w; vb0 < nblk; vb0 += 2 * K) {                        //  points adds zero rows: the sums do not change)
         const int vb = vb0 + half * K;
@@ -2062,7 +2073,7 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
           if (my_q < ODO_NACC) accq = rows_accumulate<kLmBlock, kS>(rows_sh, rowA, rowB, my_s, accq);
         }
         accq = rows_butterfly8(accq);
-        if (vb < nblk && my_q < ODO_NACC && my_s == 0) fine_publish(buf, vb, my_q, accq, tag, local);
+        if (vb < nblk && my_q < ODO_NACC && my_s == 0 && !(fault && vb == 0)) fine_publish(buf, vb, my_q, accq, tag, local);   // fault: as above
       }
     }
     lap(c_eval);
@@ -2123,8 +2134,8 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
   }
 }
 // grid = 8 * K blocks: the class (blockIdx.x & 7) that sits on the optimiser's home XCD takes part, the others return at once
-// "The dispatch of a pose-LM persistent launch is in progress": block 0 of its grid writes the launch's epoch into word 0 on entry, the
-// last block into word 1 — the dispatcher deals the blocks of a grid in order, so word 0 != word 1 means that some blocks of that
+// "The dispatch of a pose-LM persistent launch is in progress": block 0 of its grid writes the launch's number (process-wide, from the
+// host: several optimisers in one process never write the same value) into word 0 on entry, the last block into word 1 — the dispatcher deals the blocks of a grid in order, so word 0 != word 1 means that some blocks of that
 // launch have not been dispatched yet. Read by depth_lm_persistent_kernel, whose own dispatch can be what they are waiting for: every
 // block of a launch visits the XCD the dispatcher deals it to, also the seven eighths that return at once, and a pose-LM block (416
 // VGPRs per SIMD) finds no CU on an XCD filled with the depth launch's 80 workgroups while the depth launch's next block finds none
@@ -2139,8 +2150,8 @@ __device__ __forceinline__ bool lm_fine_mid_dispatch() {
 template <bool kTdist>
 __device__ __forceinline__ void lm_fine_entry(const StepArgs& a, int K, unsigned long long* __restrict__ xbuf, int fault, int lo_level) {
   if (threadIdx.x == 0) {
-    if (blockIdx.x == 0) __hip_atomic_store(&g_lm_fine_dispatch[0], a.fine_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (blockIdx.x == gridDim.x - 1) __hip_atomic_store(&g_lm_fine_dispatch[1], a.fine_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x == 0) __hip_atomic_store(&g_lm_fine_dispatch[0], a.fine_dispatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x == gridDim.x - 1) __hip_atomic_store(&g_lm_fine_dispatch[1], a.fine_dispatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (!fine_on_home(a.fine_home) || lm_chain_skip(a)) return;
   const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve, a.span};
@@ -2166,6 +2177,10 @@ __global__ void __launch_bounds__(kFineThreads) lm_fine_kernel_batch(const StepA
     const int mine = fine_xcc_id();
 #pragma unroll
     for (int c = 0; c < 8; c++) if (xcc.id[c] == mine) r = c;
+  }
+  if (threadIdx.x == 0 && n > 0) {   // (the batched launch is a pose-LM persistent launch like any other: see g_lm_fine_dispatch)
+    if (blockIdx.x == 0) __hip_atomic_store(&g_lm_fine_dispatch[0], table[0].fine_dispatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x == gridDim.x - 1) __hip_atomic_store(&g_lm_fine_dispatch[1], table[0].fine_dispatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   const int wa = (int)(blockIdx.x >> 3);
   const int i = (wa / K) * 8 + r, w = wa % K;

@@ -694,6 +694,7 @@ struct odo_lm {
   int ts_multi;                    // 0: ODO_TDIST_SINGLE=1 (the single-workgroup scale kernel for every level)
   int fine_passes;                 // passes per evaluation a level may take inside the persistent launch (lm_plan_levels; ODO_LM_FINE_PASSES)
   int ts_fault;                    // test hook (ODO_TDIST_MULTI_FAULT): a workgroup never publishes
+  long ts_multi_launches;          // lm_tdist_scale_multi_kernel launches so far (odo_lm_tdist_stats)
   unsigned ts_wait;                // wait bound in ticks of the 100 MHz clock (ODO_LM_FINE_WAIT_US), 0: 4 ms
   // host-mapped progress words the update kernel writes (early-exit polling)
   int* h_prog;
@@ -813,8 +814,8 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
   HIP_OK(hipMalloc((void**)&m->d_scale, sizeof(float)));
   HIP_OK(hipMalloc((void**)&m->d_ts_xbuf, sizeof(unsigned long long) * kTsXbufWords));
   HIP_OK(hipMemset(m->d_ts_xbuf, 0, sizeof(unsigned long long) * kTsXbufWords));
-  HIP_OK(hipMalloc((void**)&m->d_ts_gave_up, sizeof(int)));
-  HIP_OK(hipMemset(m->d_ts_gave_up, 0, sizeof(int)));
+  HIP_OK(hipMalloc((void**)&m->d_ts_gave_up, 2 * sizeof(int)));   // {the launch in flight gave up, scale passes redone by the fall-back so far}
+  HIP_OK(hipMemset(m->d_ts_gave_up, 0, 2 * sizeof(int)));
   m->ts_epoch = 0;
   m->ts_multi = getenv("ODO_TDIST_SINGLE") ? 0 : 1;
   m->fine_passes = getenv("ODO_LM_FINE_PASSES") ? atoi(getenv("ODO_LM_FINE_PASSES")) : 2;
@@ -1088,7 +1089,10 @@ static inline int lm_grid_for(const odo_lm* m, int level, int rows, int cols) {
 // (<= 2 * kFineKMax virtual blocks = 16 384 points): one workgroup in the fused kernels' summation order — the same sigma bit for
 // bit on every pipeline. Larger levels only ever run here (27 k-point lists of a dense pyramid's coarse levels, dense levels of up
 // to 2 M residuals): lm_tdist_scale_multi_kernel on up to 128 workgroups, with the single-workgroup kernel queued behind it as its
-// fall-back (a no-op unless the launch gave up).
+// fall-back (a no-op unless the launch gave up). The fall-back adds in another order (strided per-thread sums and a tree) than the
+// multi-workgroup launch (per thread ascending, eight waves, G workgroups): sigma after a give-up may differ in the last bits from a
+// clean run — results stay within every tolerance, but "bit-identical on every pipeline" is a statement about runs without give-ups.
+// odo_lm_tdist_stats counts them.
 static void lm_launch_scale(odo_lm* m, int n, int level) {
   hipStream_t s = m->ctx->stream;
   if (n <= 2 * kFineKMax * kLmBlock) {
@@ -1105,6 +1109,7 @@ static void lm_launch_scale(odo_lm* m, int n, int level) {
     hipLaunchKernelGGL(lm_tdist_scale_kernel, dim3(1), dim3(1024), 0, s, m->d_res, n, m->ust, level, m->d_scale, single_order, (int*)nullptr);
     return;
   }
+  m->ts_multi_launches++;
   m->ts_epoch = (m->ts_epoch + 1) & 0x3fffffu;   // 22 bits beside the 10-bit pass number: cleared when it starts over
   if (m->ts_epoch == 0) {
     (void)hipMemsetAsync(m->d_ts_xbuf, 0, sizeof(unsigned long long) * kTsXbufWords, s);
@@ -1220,6 +1225,9 @@ static inline int lm_job_progress(const odo_lm* m) {
 }
 static inline bool lm_job_finished(const odo_lm* m) { return ((volatile int*)m->h_prog)[1] == m->job.token; }
 
+// Every pose-LM persistent launch of the process has its own number (g_lm_fine_dispatch in kernels.hip.h: "half dispatched" = the first
+// and the last block of a grid have written different numbers; the per-optimiser epochs below may coincide across optimisers).
+static unsigned lm_fine_next_dispatch() { static std::atomic<unsigned> n{0}; return ++n; }
 // The exchange buffer's tags are (epoch << 8) + evaluation. An epoch is used for one launch; when the 24 bits are exhausted the
 // buffer is cleared on the stream (tag 0 = never valid) before they start over, so a granule left by an old launch — a row beyond
 // the levels of every Solve since — can never carry the tag a new launch waits for.
@@ -1452,6 +1460,7 @@ static int lm_fused_begin_job(odo_lm* m, LmJob& jb, const odo_pyr* kf_img, const
     a.seq = jb.seq; a.first_of_solve = (jb.seq == 0) ? 1 : 0;
     a.span = lm_span_slot(m, jb.launches, false);
     a.fine_epoch = lm_fine_next_epoch(m);
+    a.fine_dispatch = lm_fine_next_dispatch();
     a.fine_wait = m->fine_wait;
     a.fine_home = m->fine_home;
     if (m->robust == 2)
@@ -1615,7 +1624,8 @@ static int lm_chain_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_de
   return 0;
 }
 // After the Solve in flight has been collected: what its guard told the chained Solve — 1 it runs, 2 its launches return at once,
-// 0 there is none / unknown (treated as "returns at once" by the caller after a stream sync).
+// 0 there is none / unknown (its launches then saw a guard without their token and return at once: the caller treats 0 as 2, no
+// stream sync needed — the chained launches are harmless either way and the next Solve is issued behind them).
 static int lm_chain_verdict(odo_lm* m, int token_of_collected, int slot_of_collected) {
   if (!m->chained.active || m->chained.a.chain_in_token != token_of_collected) return 0;
   volatile int* w = (volatile int*)(m->h_res + 48 * slot_of_collected) + 43;
@@ -1819,6 +1829,7 @@ static void lm_fill_step_args(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* c
   a.fine_lo = fine_lo;
   a.xbuf = m->d_xbuf;
   a.fine_epoch = (fine_lo < min_level) ? lm_fine_next_epoch(m) : 0u;   // (a sequence that only carries its state exchanges nothing)
+  a.fine_dispatch = lm_fine_next_dispatch();
   a.fine_wait = m->fine_wait;
   a.fine_home = m->fine_home;
   int above = 0;   // evaluations the coarse and the persistent launch can take
@@ -2337,6 +2348,16 @@ extern "C" int odo_lm_persistent_stats(const odo_lm* m, int* workgroups, int* fa
 }
 // Back-off state of the persistent launch: give-ups that count (3 = switched off), the interval after which a switched-off launch
 // is tried again (doubles with every switch-off), and the Solves left until then (0 while the launch is on).
+extern "C" int odo_lm_tdist_stats(odo_lm* m, long* multi_launches, int* fallbacks) {
+  if (!m) return fail("odo_lm_tdist_stats: NULL lm");
+  HIP_OK(hipSetDevice(m->ctx->device));
+  HIP_OK(hipStreamSynchronize(m->ctx->stream));
+  int w[2] = {0, 0};
+  HIP_OK(hipMemcpy(w, m->d_ts_gave_up, sizeof(w), hipMemcpyDeviceToHost));
+  if (multi_launches) *multi_launches = m->ts_multi_launches;
+  if (fallbacks) *fallbacks = w[1];
+  return 0;
+}
 extern "C" int odo_lm_persistent_backoff(const odo_lm* m, int* strikes, int* retry_after, int* solves_until_retry) {
   if (!m) return fail("odo_lm_persistent_backoff: NULL lm");
   const int ra = fine_retry_after(m->fine_offs);

@@ -61,7 +61,7 @@ struct odo_tracker {
   // keyframe decision are known then — the next Solve's launches go out on the LM stream while the depth stream finishes and
   // the host does its bookkeeping (odo_lm_solve_begin). Same launches, earlier; ODO_NO_EARLY_SOLVE=1 turns it off.
   int early_solve;
-  int chain_solve;           // 1: ... and queued BEHIND this frame's Solve before its result exists (lm_chain_begin; ODO_NO_CHAIN_SOLVE=1: off)
+  int chain_solve;           // 1: ... and queued BEHIND this frame's Solve before its result exists (lm_chain_begin; opt-in: ODO_CHAIN_SOLVE=1 — measured no faster)
   long chain_used, chain_wasted;   // chained Solves adopted / that ran for nothing (the host's keyframe test disagreed with the guard)
   double dbg_pre_us, dbg_spin_us, dbg_chain_us, dbg_verdict_us, dbg_post_us; long dbg_n;   // ODO_TRACK_DEBUG: host time per call, by phase
   int depth_ahead;           // 1: with the next PAIR announced, the next frame's stream-B job is posted a frame early (ODO_NO_DEPTH_AHEAD=1: off)

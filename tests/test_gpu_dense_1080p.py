@@ -104,6 +104,15 @@ def test_dense_1080p_tdistribution_solve_matches_oracle(api, O, scene, variant, 
     assert tr[-1]["level"] == 0 and max(t["n_res"] for t in tr) > 1.5e6
     d = se3_log_norm(ref["pose"], T)
     assert d < 1e-5, f"pose delta {d} vs oracle"
+    # odo_lm_tdist_stats: the multi-workgroup launch took the large levels; its fall-back ran exactly when a workgroup never published
+    # (the two kernels add in different orders: after a fall-back sigma may differ in the last bits, which is why they are counted)
+    multi, fallbacks = lm.tdist_stats()
+    if variant == "single":
+        assert multi == 0 and fallbacks == 0
+    elif variant == "multi":
+        assert multi > 0 and fallbacks == 0
+    else:
+        assert multi > 0 and fallbacks == multi
 
 
 def test_dense_1080p_stream_matches_oracle(api, O, scene):

@@ -765,13 +765,15 @@ def _trace_key(tr):
 def test_two_pass_levels_inside_the_persistent_launch_equal_step_launches(api, kitti_seq, monkeypatch):
     """A level of 65-128 virtual blocks (a keyframe near the reference's 40 960-point selection cap, ref: src/depth_estimate.cpp:
     300-339) takes two passes per evaluation inside the persistent launch: the whole Solve is two launches, and pose and trace are
-    those of the same level on step launches behind the persistent launch (ODO_LM_FINE_PASSES=1) and of step launches only."""
+    those of the same level on step launches behind the persistent launch (ODO_LM_FINE_PASSES=1), of step launches only, and of a
+    persistent launch whose two-pass level is forced to give up (ODO_LM_FINE_FAULT: redone on the step launches)."""
     from odometry_amd import synth
     L0, L1 = kitti_seq["left"][0], kitti_seq["left"][1]
     inv = synth.semi_dense_inverse_depth(kitti_seq["depth"][0], L0, stride_keep=0.2, seed=5)
     p0, d0, p1 = api.ImagePyramid(4, L0, True), api.DepthPyramid(4, inv, False), api.ImagePyramid(4, L1, True)
     runs = {}
-    for name, env in (("two passes", {}), ("step launches behind", {"ODO_LM_FINE_PASSES": "1"}), ("step launches only", {"ODO_LM_NO_FINE": "1"})):
+    for name, env in (("two passes", {}), ("step launches behind", {"ODO_LM_FINE_PASSES": "1"}), ("step launches only", {"ODO_LM_NO_FINE": "1"}),
+                      ("two passes, forced give-up", {"ODO_LM_FINE_FAULT": "1", "ODO_LM_FINE_WAIT_US": "300"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, 1, 28.0)
@@ -783,8 +785,11 @@ def test_two_pass_levels_inside_the_persistent_launch_equal_step_launches(api, k
     n0 = runs["two passes"][3][0]
     assert 64 * 256 < n0 <= 128 * 256, n0                       # level 0: 65-128 virtual blocks
     assert runs["two passes"][2] == 2 and runs["step launches behind"][2] > 2 and runs["two passes"][4][1] == 0
-    for name in ("step launches behind", "step launches only"):
+    for name in ("step launches behind", "step launches only", "two passes, forced give-up"):
         assert np.array_equal(runs[name][0], runs["two passes"][0]) and runs[name][1] == runs["two passes"][1], name
+    # virtual block 0 of a two-pass level never published (the test hook reaches that branch of lm_fine_body too): the launch gave up
+    # within its bound and the Solve was redone on the step launches
+    assert runs["two passes, forced give-up"][4][1] == 1, runs["two passes, forced give-up"][4]
     for o in (p0, d0, p1):
         o.close()
 

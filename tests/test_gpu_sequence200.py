@@ -87,6 +87,79 @@ def test_all_200_frames_of_the_headline_drive_match_the_oracle_runner(drives, or
     print(f"hints={hints}: 199 frames, {n_kf} keyframes, worst log-norm vs oracle {worst:.3g}")
 
 
+def _oracle_rows(seq, n):
+    from oracle import runner as orunner
+    ref = orunner.OracleRunner()
+    ref.init(seq["left"][0], seq["right"][0])
+    rows = []
+    for k in range(1, n):
+        c = ref.track(seq["left"][k], seq["right"][k])
+        keep = (k % 10 == 0) or c["new_keyframe"]
+        rows.append(dict(pose_to_keyframe=c["pose_to_keyframe"], abs_pose=c["abs_pose"], new_keyframe=c["new_keyframe"],
+                         motion=c["motion"], solve_status=c["solve_status"], n_valid=c["n_valid"],
+                         val=c["val"] if keep else None, disp=c["disp"] if keep else None, dep=c["dep"] if keep else None))
+    return rows, ref.n_keyframes
+
+
+def _track_against(seq, rows, n, hints=True):
+    """The device-resident tracker over the first n frames against the oracle runner's rows; returns what the tests assert on."""
+    from odometry_amd import api
+    trk = api.Tracker(0)
+    dev = [(trk.upload_frame(l), trk.upload_frame(r)) for l, r in zip(seq["left"][:n], seq["right"][:n])]
+    trk.init(*dev[0])
+    worst, launches, l0 = 0.0, [], []
+    for k in range(1, n):
+        if hints and k + 1 < n:
+            trk.hint_next(*dev[k + 1])
+        g = trk.track(*dev[k])
+        c = rows[k - 1]
+        d_kf, d_abs = _check_frame(k, g, c, trk.stats()["n_valid_depth"])
+        worst = max(worst, d_kf, d_abs)
+        pts, nl = trk.lm_points()
+        launches.append(nl)
+        l0.append(pts[0])
+        if c["val"] is not None:
+            val, disp, dep = trk.outputs(376, 1241)
+            assert np.array_equal(val, c["val"]), f"frame {k}: mask"
+            assert np.array_equal(disp, c["disp"]), f"frame {k}: disparity"
+            np.testing.assert_allclose(dep, c["dep"], rtol=0, atol=1e-7, err_msg=f"frame {k}: inverse depth")
+    out = dict(worst=worst, launches=launches, level0=l0, n_keyframes=trk.stats()["n_keyframes"], persistent=trk.persistent_stats())
+    trk.close()
+    return out
+
+
+def test_saturated_keyframe_drive_matches_the_oracle_runner():
+    """bench.py's `saturated_keyframe` drive ('dense': the point selection at its cap of 80 per block, ref: src/depth_estimate.cpp:
+    300-339; ~28 k points on level 0 = 110 virtual blocks, the two-pass path of the persistent launch) against the ORACLE runner, not
+    against another HIP pipeline: first 30 frames, next pair announced — pose log-norm < 1e-5 per frame, keyframe decisions, valid-depth
+    counts, depth outputs on a stride; every Solve is two launches (coarse + persistent) and none is redone on the step launches."""
+    import bench
+    n = 30
+    seq = bench.render_sequence(n, 0, min(8, os.cpu_count() or 1), drive="dense")
+    rows, n_kf = _oracle_rows(seq, n)
+    r = _track_against(seq, rows, n)
+    assert r["n_keyframes"] == n_kf
+    assert max(r["level0"]) > 16384 * 1.5                       # level 0 beyond what 64 resident virtual blocks hold: two passes
+    assert set(r["launches"][2:]) == {2}, r["launches"]         # coarse + persistent launch, no step launch
+    pk, redone = r["persistent"]
+    assert pk > 0 and redone == 0
+    print(f"dense drive: {n - 1} frames, {n_kf} keyframes, level-0 points up to {max(r['level0'])}, worst log-norm vs oracle {r['worst']:.3g}")
+
+
+def test_stress_drive_matches_the_oracle_runner():
+    """bench.py's `stress_drive` ('corridor': the reference's keyframe policy loses track at its first switch there and promotes a
+    keyframe on most frames afterwards — lambda-break chains, candidate-list adoption on nearly every frame) against the oracle runner
+    over 60 frames, with and without the next pair announced."""
+    import bench
+    n = 60
+    seq = bench.render_sequence(n, 0, min(8, os.cpu_count() or 1), drive="corridor")
+    rows, n_kf = _oracle_rows(seq, n)
+    for hints in (True, False):
+        r = _track_against(seq, rows, n, hints)
+        assert r["n_keyframes"] == n_kf and n_kf >= 10, (r["n_keyframes"], n_kf)   # a keyframe on most frames once track is lost
+        print(f"corridor drive, hints={hints}: {n - 1} frames, {n_kf} keyframes, worst log-norm vs oracle {r['worst']:.3g}")
+
+
 def test_batched_tracker_all_200_frames_two_drives_match_their_oracle_runners(drives, oracle_runs):
     from odometry_amd import api
     S = 2

@@ -289,27 +289,74 @@ def dense_1080p_leg(api, synth, n_frames=5, passes=3):
 
 
 def disparity_leg(api, seq, trk):
-    """BASELINE.json configs[4]: stereo disparity line search at 1241x376, reference range and +-128 px."""
+    """BASELINE.json configs[4]: stereo disparity line search at 1241x376, reference range and +-128 px — with the runner's
+    DepthEstimator arguments (run_odometry_kitti_offline.cpp:58-70: the operating point of every tracked frame) and with
+    test_disparity.cpp's own (:68-75: 35-grey-level selection threshold, 3-17 m window, 100 depth-LM iterations). Per case: the three
+    front-end kernels event-timed on device-resident images, the whole ComputeDepth on device-resident images (median wall time of 10
+    calls), and the CPU oracle on one pinned core beside them (oracle/cpu_baseline.py --depth: the checker timed as a baseline,
+    outside every GPU clock)."""
+    import subprocess
+    import tempfile
+    from oracle import cpu_baseline as cb
     out = {}
+    cpu = {}
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            path = os.path.join(td, "pair.npz")
+            np.savez(path, left=seq["left"][0], right=seq["right"][0])
+            p = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--depth", path],
+                               capture_output=True, text=True, timeout=900)
+            cpu = json.loads(p.stdout.strip().splitlines()[-1]) if p.returncode == 0 else dict(error=p.stderr[-500:])
+    except Exception as e:   # noqa: BLE001
+        cpu = dict(error=f"{type(e).__name__}: {e}"[:300])
     ctx = api.Context(0)
     l_dev, r_dev = ctx.upload(seq["left"][0]), ctx.upload(seq["right"][0])
-    for name, md in (("full_range", 0), ("max128", 128)):
-        de = api.DepthEstimator(8.0, 900.0, 15.0, 0.1, 30.0, 0.01, 28.0, 0.995, 50, 4, None, None,
-                                float(np.float32(386.1448) / np.float32(718.856)), 80000, ctx=ctx, max_disparity=md)
-        t = de.time_stages(l_dev, r_dev, 376, 1241, reps=20)
-        scan_s = t["scan_us"] * 1e-6
-        tf = t["candidates"] * 24.0 / scan_s / 1e12          # SURVEY 8(d): ~24 flop per candidate (8 sub, 8 mul, 7 add, 1 compare)
-        l1 = t["candidates"] * 8 * 4.0 / scan_s / 1e9        # eight 4-byte taps per candidate, served by the vector L1
-        out[name] = dict(scan_us=round(t["scan_us"], 2), select_us=round(t["select_us"], 2), blur_us=round(t["blur_us"], 2),
-                         selected_points=t["n_selected"], ssd_candidates=int(t["candidates"]),
-                         gcandidates_per_s=round(t["candidates"] / scan_s / 1e9, 2),
-                         roofline=dict(kernel="depth_disparity_kernel", bound="valu/l1", flop_per_candidate=24,
-                                       achieved=round(tf, 2), peak=VALU_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tf / VALU_F32_PEAK_TFLOPS, 4),
-                                       l1_achieved_gbs=round(l1, 1), l1_peak_gbs=round(L1_PEAK_GBS, 1), l1_frac=round(l1 / L1_PEAK_GBS, 4),
-                                       hbm_new_bytes="~0: both blurred images (3.7 MB) are L2 / Infinity-Cache resident"))
-        de.close()
-    ctx.free(l_dev)
-    ctx.free(r_dev)
+    n = 376 * 1241
+    v_dev, d_dev, p_dev = ctx.alloc(n), ctx.alloc(4 * n), ctx.alloc(4 * n)
+    base = float(np.float32(386.1448) / np.float32(718.856))
+    for pname, a in cb.DEPTH_PARAM_SETS.items():
+        for name, md in (("full_range", 0), ("max128", 128)):
+            de = api.DepthEstimator(*a[:10], None, None, base, a[10], ctx=ctx, max_disparity=md)
+            t = de.time_stages(l_dev, r_dev, 376, 1241, reps=20)
+            whole = []
+            for _ in range(12):
+                ctx.synchronize()
+                t0 = time.perf_counter()
+                de.compute_dev(l_dev, r_dev, 376, 1241, v_dev, d_dev, p_dev)
+                whole.append(time.perf_counter() - t0)
+            rep = de.report()
+            scan_s = t["scan_us"] * 1e-6
+            tf = t["candidates"] * 24.0 / scan_s / 1e12          # SURVEY 8(d): ~24 flop per candidate (8 sub, 8 mul, 7 add, 1 compare)
+            l1 = t["candidates"] * 8 * 4.0 / scan_s / 1e9        # eight 4-byte taps per candidate, served by the vector L1
+            row = dict(scan_us=round(t["scan_us"], 2), select_us=round(t["select_us"], 2), blur_us=round(t["blur_us"], 2),
+                       compute_depth_us=round(float(np.median(whole[2:])) * 1e6, 1), depth_lm_iterations=rep["iters"],
+                       selected_points=t["n_selected"], ssd_candidates=int(t["candidates"]),
+                       gcandidates_per_s=round(t["candidates"] / scan_s / 1e9, 2),
+                       roofline=dict(kernel="depth_disparity_kernel", bound="valu/l1", flop_per_candidate=24,
+                                     achieved=round(tf, 2), peak=VALU_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tf / VALU_F32_PEAK_TFLOPS, 4),
+                                     l1_achieved_gbs=round(l1, 1), l1_peak_gbs=round(L1_PEAK_GBS, 1), l1_frac=round(l1 / L1_PEAK_GBS, 4),
+                                     hbm_new_bytes="~0: both blurred images (3.7 MB) are L2 / Infinity-Cache resident"))
+            c = (cpu.get("cases") or {}).get(f"{pname}.{name}")
+            if c:
+                row.update(cpu_scan_ms=c["cpu_scan_ms"], cpu_disparity_stage_ms=c["cpu_disparity_stage_ms"],
+                           cpu_compute_depth_ms=c["cpu_compute_depth_ms"],
+                           iterations_equal_cpu=bool(c["depth_lm_iterations"] == rep["iters"]),
+                           selected_points_equal_cpu=bool(c["selected_points"] == t["n_selected"]))
+            key = name if pname == "runner" else f"test_disparity_cpp.{name}"
+            out[key] = row
+            de.close()
+    out["parameters"] = dict(runner="DepthEstimator(8, 900, 15, 0.1, 30, 0.01, 28, 0.995, 50, 4, .., 80000) — run_odometry_kitti_offline.cpp:58-70 "
+                                    "(rows full_range / max128)",
+                             test_disparity_cpp="DepthEstimator(35, 1000, 10, 3, 17, 0.01, 28, 0.995, 100, 4, .., 5000) — test_disparity.cpp:68-75, "
+                                                "on the same KITTI-shaped pair with the KITTI baseline (its own dataset is not 376x1241 and "
+                                                "would not pass the guard of src/depth_estimate.cpp:46-49)")
+    if "cases" in cpu:
+        out["cpu"] = dict(kind="port", cores=1, host_cpu=cpu.get("host_cpu"), build=cpu.get("build"),
+                          what="oracle/cpu_baseline.py --depth: median of 5 runs on one pinned core")
+    else:
+        out["cpu_error"] = cpu.get("error")
+    for q in (l_dev, r_dev, v_dev, d_dev, p_dev):
+        ctx.free(q)
     ctx.close()
     return out
 

@@ -2857,11 +2857,12 @@ static int depth_host(odo_depth* d, const float* left, const float* right, int r
     if (depth_run(d, d->d_left, d->d_right, rows, cols, d->d_val, d->d_disp, d->d_dep, stage)) return -1;
     rc = depth_finish(d);
   }
-  if (rc != 0) return -1;
   (void)s;
+  // the outputs reach the caller whatever the status: the reference has written left_val / left_dep back (ref: src/depth_estimate.cpp:
+  // 176-191) before it returns -1 for "number of valid after optimization is too small" (:192-194)
   if (copy_to_user_host(d->ctx, val, d->d_val, n) || copy_to_user_host(d->ctx, disp, d->d_disp, sizeof(float) * n) ||
       copy_to_user_host(d->ctx, dep, d->d_dep, sizeof(float) * n)) return -1;
-  return 0;
+  return rc == 0 ? 0 : -1;
 }
 
 extern "C" int odo_depth_compute(odo_depth* d, const float* left, const float* right, int rows, int cols, uint8_t* val,

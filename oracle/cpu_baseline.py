@@ -23,7 +23,63 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+# DepthEstimator constructor arguments (grad_th, ssd_th, photo_th, min_depth, max_depth, lambda, huber_delta, precision, max_iters,
+# boundary, max_residuals): the runner's (ref: run_odometry_kitti_offline.cpp:58-70) and test_disparity.cpp's own (ref: :68-75)
+DEPTH_PARAM_SETS = {
+    "runner": (8.0, 900.0, 15.0, 0.1, 30.0, 0.01, 28.0, 0.995, 50, 4, 80000),
+    "test_disparity_cpp": (35.0, 1000.0, 10.0, 3.0, 17.0, 0.01, 28.0, 0.995, 100, 4, 5000),
+}
+
+
+def depth_main(path):
+    """--depth <pair.npz with left[H,W], right[H,W]>: BASELINE.json configs[4] on one pinned core — the epipolar scan alone
+    (ref: src/depth_estimate.cpp:345-398 on the blurred pair and the selection mask), DisparityDepthEstimate (:244-401: blur +
+    selection + scan) and the whole ComputeDepth (:33-78), per parameter set and search range; medians of 5 runs after one warm-up."""
+    cpu = sorted(os.sched_getaffinity(0))[0]
+    os.sched_setaffinity(0, {cpu})
+    from oracle import oracle as O
+    so, flags = O.build_native()
+    os.environ["ODO_ORACLE_SO"] = so
+    d = np.load(path)
+    L, R = np.ascontiguousarray(d["left"], np.float32), np.ascontiguousarray(d["right"], np.float32)
+    lb, rb = O.blur3x3(L), O.blur3x3(R)
+    out = {}
+    for name, a in DEPTH_PARAM_SETS.items():
+        for rng, md in (("full_range", 0), ("max128", 128)):
+            prm = O.depth_params(grad_th=a[0], ssd_th=a[1], photo_th=a[2], min_depth=a[3], max_depth=a[4], lam=a[5], huber_delta=a[6],
+                                 precision=a[7], max_iters=a[8], boundary=a[9], max_residuals=a[10], max_disparity=md)
+            s1 = O.compute_depth(L, R, prm, stage=1)
+            t = {"scan": [], "stage1": [], "full": []}
+            full = None
+            for rep in range(6):
+                t0 = time.perf_counter()
+                O.disparity_scan(lb, rb, s1["val"], boundary=a[9], ssd_th=a[1], max_disparity=md)
+                t1 = time.perf_counter()
+                O.compute_depth(L, R, prm, stage=1)
+                t2 = time.perf_counter()
+                full = O.compute_depth(L, R, prm, stage=2)
+                t3 = time.perf_counter()
+                if rep:
+                    t["scan"].append(t1 - t0); t["stage1"].append(t2 - t1); t["full"].append(t3 - t2)
+            out[f"{name}.{rng}"] = dict(cpu_scan_ms=round(float(np.median(t["scan"])) * 1e3, 2),
+                                        cpu_disparity_stage_ms=round(float(np.median(t["stage1"])) * 1e3, 2),
+                                        cpu_compute_depth_ms=round(float(np.median(t["full"])) * 1e3, 2),
+                                        selected_points=int(s1["n_selected"]), depth_lm_iterations=int(full["iters"]),
+                                        valid_depths=int(full["n_valid"]))
+    cpu_model = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    print(json.dumps(dict(cases=out, build=flags, pinned_to_cpu=cpu, host_cpu=cpu_model, cores=1)))
+
+
 def main():
+    if sys.argv[1] == "--depth":
+        return depth_main(sys.argv[2])
     path, n = sys.argv[1], int(sys.argv[2])
     n_ref = int(sys.argv[3]) if len(sys.argv) > 3 else n
     cpu = sorted(os.sched_getaffinity(0))[0]

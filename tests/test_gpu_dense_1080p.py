@@ -112,7 +112,7 @@ def test_dense_1080p_tdistribution_solve_matches_oracle(api, O, scene, variant, 
     elif variant == "multi":
         assert multi > 0 and fallbacks == 0
     else:
-        assert multi > 0 and fallbacks == multi
+        assert multi > 0 and 0 < fallbacks <= multi     # (launches queued for a level the loop had already left return at once, both kernels)
 
 
 def test_dense_1080p_stream_matches_oracle(api, O, scene):

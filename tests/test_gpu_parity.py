@@ -331,6 +331,57 @@ def test_depth_lm_persistent_launch_and_its_fallback_give_the_same_depths(O, kit
         assert same(b, on[0])
 
 
+@pytest.mark.parametrize("precision", [0.995, 1.0])
+@pytest.mark.parametrize("max_disparity", [0, 128])
+def test_compute_depth_with_test_disparity_cpp_parameters(O, max_disparity, precision, monkeypatch):
+    """BASELINE.json configs[4] by its own program's parameters: test_disparity.cpp:68-75 constructs DepthEstimator(35, 1000, 10, 3, 17,
+    0.01, 28, 0.995, 100, 4, nullptr, nullptr, baseline, 5000) — another operating point than the runner's (8, 900, 15, 0.1, 30, ..., 50):
+    a 35-grey-level selection threshold, a 3-17 m depth window and a 100-iteration budget for the inverse-depth LM, all inside the
+    persistent launch. Whole ComputeDepth on a KITTI-shaped pair (the reference's 376x1241 guard; KITTI baseline) against the oracle,
+    reference range and +-128 px: mask and disparity bit-exact, inverse depth to 1e-7, iteration count and cost equal; the persistent
+    launch and the step launches agree bit for bit. (max_residuals = 5000 is a buffer size the reference overruns when more points are
+    valid, ref: src/depth_estimate.cpp:105-110 — undefined there, ignored here and in the oracle.) On the drives' textures the
+    precision stop (0.995) ends the loop after 13-21 iterations; precision = 1.0 (a stop that never fires) makes the loop use its whole
+    100-iteration budget inside the one launch."""
+    from odometry_amd import api, synth
+    seq = synth.make_sequence(2, seed=0, drive="dense")
+    L, R = seq["left"][1], seq["right"][1]
+    base = float(np.float32(386.1448) / np.float32(718.856))
+    prm = O.depth_params(grad_th=35.0, ssd_th=1000.0, photo_th=10.0, min_depth=3.0, max_depth=17.0, lam=0.01, huber_delta=28.0,
+                         precision=precision, max_iters=100, boundary=4, max_residuals=5000, max_disparity=max_disparity)
+    ref = O.compute_depth(L, R, prm, stage=2)
+    ref_scan = O.compute_depth(L, R, prm, stage=1)
+    assert ref["n_selected"] > 1000 and 0 < ref["n_valid"] <= ref["n_matched"]
+    assert ref["iters"] > 15 if precision < 1.0 else ref["iters"] >= 60, ref["iters"]
+    # (at this operating point the drive keeps ~500 depths: 498 with the precision stop — "number of valid after optimization is too
+    #  small", status -1, ref: src/depth_estimate.cpp:192-194 — and 528 without; the status is part of the parity)
+    assert ref["status"] == (0 if ref["n_valid"] >= 500 else -1)
+
+    def run():
+        de = api.DepthEstimator(35.0, 1000.0, 10.0, 3.0, 17.0, 0.01, 28.0, precision, 100, 4, None, None, base, 5000, max_disparity=max_disparity)
+        val, disp, dep = _bufs(L.shape)
+        st = de.ComputeDepth(L, R, val, disp, dep)
+        rep, ps = de.report(), de.persistent_stats()
+        v1, d1, p1 = _bufs(L.shape)
+        assert de.DisparityDepthEstimate(L, R, v1, d1, p1) == 0                      # DisparityDepthEstimate alone (:244-401)
+        de.close()
+        return st, val, disp, dep, rep, ps, (v1, d1, p1)
+
+    st, val, disp, dep, rep, ps, scan = run()
+    assert st == ref["status"] and ps == (1, 0)                               # one persistent launch, never gave up
+    assert np.array_equal(scan[0], ref_scan["val"]) and np.array_equal(scan[1], ref_scan["disp"]) and np.array_equal(scan[2], ref_scan["dep"])
+    assert np.array_equal(val, ref["val"]) and np.array_equal(disp, ref["disp"])
+    np.testing.assert_allclose(dep, ref["dep"], rtol=0, atol=1e-7)
+    assert rep["iters"] == ref["iters"] and rep["n_selected"] == ref["n_selected"] and rep["n_matched"] == ref["n_matched"]
+    assert rep["n_valid"] == ref["n_valid"] and abs(rep["cost"] - ref["cost"]) <= 1e-6 * abs(ref["cost"])
+    if max_disparity:
+        assert float(disp.max()) <= max_disparity
+    monkeypatch.setenv("ODO_DEPTH_NO_PERSIST", "1")
+    st2, val2, disp2, dep2, rep2, ps2, _ = run()
+    assert ps2 == (0, 0) and st2 == st and rep2 == rep
+    assert np.array_equal(val2, val) and np.array_equal(disp2, disp) and np.array_equal(dep2, dep)
+
+
 def test_compute_depth_started_ahead_on_another_stream_gives_the_same_outputs(kitti_seq, monkeypatch):
     """odo_depth_compute_begin_dev / _end_dev (what the drop-in classes do beside the Solve): the whole ComputeDepth enqueued on a second
     context's stream and collected later is bit-identical to odo_depth_compute_dev; a job collected with other stamps, or never

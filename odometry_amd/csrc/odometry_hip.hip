@@ -744,6 +744,7 @@ struct odo_lm {
   int fine_k;
   int fine_bails;   // Solves whose persistent launch gave up and that were redone on the step launches (lifetime count)
   int fine_k_cfg;   // the configured number of workgroups (fine_k is 0 while the launch is switched off after three strikes)
+  int fine_k_last;  // what the last persistent launch was issued with (lm_fine_launch_k)
   int fine_strikes; // give-ups that count towards switching off; a long run of clean Solves forgives them
   int fine_clean;   // Solves since the last give-up (persistent launch on) / since it was switched off (off)
   int fine_offs;    // times the launch has been switched off since the last forgiveness: the retry interval doubles with each (fine_retry_after)
@@ -1291,6 +1292,23 @@ static void lm_plan_levels(const odo_lm* m, int stop, int fine_k, int* min_level
   *fine_lo_out = fine_lo;
 }
 
+// Workgroups the persistent launch of levels [fine_lo, min_level) is issued with. The plan above is made for fine_k (32: every CU of
+// an XCD); the launch leaves TWO of those CUs free when that changes nothing about the plan — every level needs as many passes with 30
+// workgroups as with 32 (levels of 61-64 and 121-128 virtual blocks are the exceptions). A block of another persistent launch that is
+// dealt to this XCD only to return at once then finds a CU instead of waiting for the whole Solve: the depth launch's give-ups halve
+// (14 -> 6-7 in 40 000 frames at the same frame rate). Sums are the same bit for bit: the fold order is
+// per virtual block, not per workgroup. ODO_LM_FINE_K pins the number.
+static int lm_fine_launch_k(const odo_lm* m, int fine_lo, int min_level) {
+  static const bool pinned = getenv("ODO_LM_FINE_K") != nullptr;
+  const int k = m->fine_k, spare = 2;
+  if (pinned || k <= 16) return k;
+  for (int l = fine_lo; l < min_level; l++) {
+    const int nblk = lm_list_blocks(m->npts[l]);
+    if ((nblk + 2 * k - 1) / (2 * k) != (nblk + 2 * (k - spare) - 1) / (2 * (k - spare))) return k;
+  }
+  return k - spare;
+}
+
 // Lowest level of the coarse-to-fine run of point-list levels the fused pipeline can take (it starts at the coarsest level):
 // 0 = the whole Solve, n_levels = nothing (the Solve runs on the unfused pipeline from the start). fine_k: workgroups of the
 // persistent launch this Solve may use.
@@ -1463,10 +1481,12 @@ static int lm_fused_begin_job(odo_lm* m, LmJob& jb, const odo_pyr* kf_img, const
     a.fine_dispatch = lm_fine_next_dispatch();
     a.fine_wait = m->fine_wait;
     a.fine_home = m->fine_home;
+    const int k_use = lm_fine_launch_k(m, fine_lo, min_level);
+    m->fine_k_last = k_use;
     if (m->robust == 2)
-      hipLaunchKernelGGL(lm_fine_tdist_kernel, dim3(8 * m->fine_k), dim3(kFineThreads), 0, s, a, m->fine_k, m->d_xbuf, m->fine_fault, fine_lo);
+      hipLaunchKernelGGL(lm_fine_tdist_kernel, dim3(8 * k_use), dim3(kFineThreads), 0, s, a, k_use, m->d_xbuf, m->fine_fault, fine_lo);
     else
-      hipLaunchKernelGGL(lm_fine_kernel, dim3(8 * m->fine_k), dim3(kFineThreads), 0, s, a, m->fine_k, m->d_xbuf, m->fine_fault, fine_lo);
+      hipLaunchKernelGGL(lm_fine_kernel, dim3(8 * k_use), dim3(kFineThreads), 0, s, a, k_use, m->d_xbuf, m->fine_fault, fine_lo);
     jb.seq++;
     jb.launches++;
     if (fine_lo <= stop) {   // nothing left for step launches
@@ -2342,7 +2362,7 @@ extern "C" int odo_lm_trace(const odo_lm* mc, odo_lm_trace_row* rows, int cap, i
 
 extern "C" int odo_lm_persistent_stats(const odo_lm* m, int* workgroups, int* fallbacks) {
   if (!m) return fail("odo_lm_persistent_stats: NULL lm");
-  if (workgroups) *workgroups = m->fine_k;
+  if (workgroups) *workgroups = (m->fine_k > 0 && m->fine_k_last > 0) ? m->fine_k_last : m->fine_k;
   if (fallbacks) *fallbacks = m->fine_bails + m->ctx->batch_fine_bails;   // its own Solves + its context's batched Solves
   return 0;
 }

@@ -807,10 +807,7 @@ extern "C" int odo_depth_time_stages(odo_depth* d, const float* left_dev, const 
                           d->d_br, rows, cols, d->d_val, d->d_disp, d->d_dep);
     hipExtLaunchKernelGGL(depth_select_kernel, dim3(kSelBlocks), dim3(kSelThreads), 0, s, e[2], e[3], 0,
                           (const float*)d->d_bl, rows, cols, d->boundary, d->grad_th, d->d_val, d->d_pts, d->d_cnt);
-    hipExtLaunchKernelGGL(depth_disparity_kernel, dim3(kSelBlocks * kSelCap / 4), dim3(256), 0, s, e[4], e[5], 0,
-                          (const float*)d->d_bl, (const float*)d->d_br, rows, cols, d->boundary, d->max_disparity, d->ssd_th,
-                          d->K.f0, d->baseline, (const uint32_t*)d->d_pts, (const int*)d->d_cnt, d->d_disp, d->d_dep, d->d_d0,
-                          d->d_matched);
+    depth_launch_scan(d, s, rows, cols, d->d_disp, d->d_dep, e[4], e[5]);
     HIP_OK(hipStreamSynchronize(s));
     if (r >= 0)
       for (int k = 0; k < 3; k++) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, e[2 * k], e[2 * k + 1])); tot[k] += ms * 1000.0; }

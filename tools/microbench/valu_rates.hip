@@ -6,7 +6,7 @@
 #include <stdlib.h>
 #define CK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #e, hipGetErrorString(e_)); exit(1); } } while (0)
 
-enum { FMA32, PKFMA32, FMA64, CVT64, CVT32, RCP32, RCP64, MUL32, ADD64, MIX };
+enum { FMA32, PKFMA32, FMA64, CVT64, CVT32, RCP32, RCP64, MUL32, ADD64, MIX, PKMUL32, PKADD32, ADD32 };
 constexpr int kIters = 2048, kChains = 8;
 
 template <int OP>
@@ -21,6 +21,9 @@ __global__ void __launch_bounds__(256) k(float* out, float seed) {
       if (OP == FMA32) { asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c)); }
       if (OP == MUL32) { asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m)); }
       if (OP == PKFMA32) { asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(m2), "v"(c2)); }
+      if (OP == PKMUL32) { asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(m2)); }
+      if (OP == PKADD32) { asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(c2)); }
+      if (OP == ADD32) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c)); }
       if (OP == FMA64) { asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[i]) : "v"(dm), "v"(dc)); }
       if (OP == ADD64) { asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[i]) : "v"(dc)); }
       if (OP == CVT64) { asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d[i]) : "v"(a[i])); }
@@ -54,7 +57,11 @@ static void run(const char* name, int per_iter_instr) {
 int main() {
   run<FMA32>("v_fma_f32", 1);
   run<MUL32>("v_mul_f32", 1);
+  run<ADD32>("v_add_f32", 1);
   run<PKFMA32>("v_pk_fma_f32", 1);
+  run<PKMUL32>("v_pk_mul_f32", 1);
+  run<PKADD32>("v_pk_add_f32", 1);
+  if (getenv("VALU_RATES_F32_ONLY")) return 0;
   run<FMA64>("v_fma_f64", 1);
   run<ADD64>("v_add_f64", 1);
   run<CVT64>("cvt_f64_f32", 1);

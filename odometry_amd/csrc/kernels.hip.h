@@ -2457,6 +2457,14 @@ __global__ void __launch_bounds__(kSelThreads) depth_select_kernel(const float* 
 // rows of a (tile, 256-column chunk) staged in LDS by 512-thread workgroups with a 64-bit atomic-min merge and a resolve kernel
 // (35.1 + 3.9 us: per (point, chunk) bookkeeping outweighs the cheaper taps). With ONE candidate per point the kernel still
 // takes 8 .. 11 us in every shape: the floor is the per-point chain of dependent trips to L2, not the scan.
+// Round 5 (profiles/r05_scan_rows_ab.md, commit 95f24c6): a workgroup per IMAGE ROW — the five right rows y - 2 .. y + 2 staged in
+// LDS once (25 KB), the row's points listed in LDS with their left taps, a wave per point reading taps with ds_read_b128 — removes
+// that chain altogether (staging + list: 6 us) and is still 2 x slower (32-35 us with 2-8 workgroups per row, static assignment): rows
+// hold 0 .. 500 points and up to 4.7 x the mean number of candidates, and what bounds the scan is VALU issue — 26 instructions per
+// candidate + ~150 per point = 7 M wave-instructions, ~13 us on 1 024 SIMDs at the measured 4 cycles each —, which the wave-per-slot
+// grid spreads evenly and a row-wise grid does not. (An LDS work counter fetched by `if (lane == 0) atomicAdd` in front of
+// readfirstlane made hipcc 7.2 build a loop that never ended; fetched by all lanes it cost 75 us.) -fno-slp-vectorize (the packed
+// v_pk_add / v_pk_mul_f32 the compiler picks here issue at 8 cycles against 3 + 3): 2 %.
 struct __attribute__((packed, aligned(4))) ScanF4 { float v[4]; };
 struct __attribute__((packed, aligned(4))) ScanF2 { float v[2]; };
 template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
@@ -2480,21 +2488,14 @@ __device__ __forceinline__ void depth_disparity_kernel_body(const float* __restr
                                                                float* __restrict__ dep, float* __restrict__ d0,
                                                                uint8_t* __restrict__ matched) {
   const int lane = threadIdx.x & 63;
-#ifndef ODO_SCAN_ORDER
-#define ODO_SCAN_ORDER 0
-#endif
   int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));  // wave-uniform
-#if ODO_SCAN_ORDER == 1
-  {  // heaviest first: a point's work grows with its column (candidates [bnd, x)), so the selection blocks go out right to left
-    const int bb = slot / kSelCap;
-    slot = ((bb / 32) * 32 + (31 - bb % 32)) * kSelCap + slot % kSelCap;
-  }
-#elif ODO_SCAN_ORDER == 2
-  {  // column-major over the 16 x 32 selection blocks, right to left
+  if (max_disp <= 0) {
+    // Reference range [bnd, x): a point's work grows with its column, and the dispatcher hands out blocks in order — the 16 x 32
+    // selection blocks go out column by column from the RIGHT, heaviest first, so the launch does not end on its longest points
+    // (17.8 -> 16.7 us on bench.py's frame; with a +-128 px window every point costs the same and the plain order is 4 % faster).
     const int bb = slot / kSelCap;
     slot = ((bb % 16) * 32 + (31 - bb / 16)) * kSelCap + slot % kSelCap;
   }
-#endif
   const int b = slot / kSelCap, k = slot % kSelCap;
   if (b >= kSelBlocks) return;
   const uint32_t pk = pts[slot];  // requested with the count, not after it (an unused slot's word is never looked at)
@@ -2595,186 +2596,6 @@ __global__ void __launch_bounds__(256) depth_disparity_kernel(const float* __res
                                                                float* __restrict__ dep, float* __restrict__ d0,
                                                                uint8_t* __restrict__ matched) {
   depth_disparity_kernel_body(L, R, rows, cols, bnd, max_disp, ssd_th, f0, baseline, pts, cnt, disp, dep, d0, matched);
-}
-
-// The same scan with a workgroup per IMAGE ROW (round 5). Every point of row y searches the same five right-image rows y - 2 .. y + 2:
-// the workgroup stages them in LDS once (25 KB at 1241 columns), finds the row's points in the 32 selection blocks the row crosses
-// (their slots are contiguous there: raster order) and writes a list {x | slot, eight left taps} into LDS; its eight waves then take
-// points from the list (an LDS counter) and scan with taps from LDS — 16-byte reads, the rows stored shifted by 0 / 1 / 2 floats so
-// that every four-candidate read is aligned. Nothing per (point, chunk): a point's chain of dependent trips to L2 (arguments ->
-// count + coordinates -> left taps -> right taps) becomes LDS latency, and the taps no longer go through the vector L1. Two
-// workgroups per row (blockIdx.y: every other list entry) for balance — a row holds 0 .. 500 points. Same arithmetic, same
-// candidate order per lane, same argmin: bit-identical to depth_disparity_kernel, which stays for the batched tracker and for
-// images too wide for LDS (ODO_SCAN_ROWS=0 selects it everywhere).
-constexpr int kScanRowThreads = 512;
-constexpr int kScanRowCap = 704;     // list entries of one round (a row with more points takes another round)
-constexpr int kScanRowEntry = 9;     // words per entry: x | slot << 16, eight left taps
-__host__ __device__ __forceinline__ int scan_rows_pitch(int cols) { return (cols + 8 + 3) & ~3; }
-template <int CTRL> __device__ __forceinline__ int dpp_row_min(int v) { const int o = dpp_i<CTRL>(v); return o < v ? o : v; }
-__global__ void __launch_bounds__(kScanRowThreads) depth_disparity_rows_kernel(const float* __restrict__ L, const float* __restrict__ R,
-                                                                               int rows, int cols, int bnd, int max_disp, float ssd_th,
-                                                                               float f0, float baseline, const uint32_t* __restrict__ pts,
-                                                                               const int* __restrict__ cnt, float* __restrict__ disp,
-                                                                               float* __restrict__ dep, float* __restrict__ d0,
-                                                                               uint8_t* __restrict__ matched, int dbg) {
-  extern __shared__ __attribute__((aligned(16))) float scan_lds[];
-  const int pitch = scan_rows_pitch(cols);
-  float* sPP = scan_lds;               // row y - 2, column c at [c]
-  float* sP = scan_lds + pitch;        // row y - 1, column c at [c + 1]
-  float* sC = scan_lds + 2 * pitch;    // row y,     column c at [c + 2]
-  float* sN = scan_lds + 3 * pitch;    // row y + 1, column c at [c + 1]
-  float* sNN = scan_lds + 4 * pitch;   // row y + 2, column c at [c]
-  unsigned* list = reinterpret_cast<unsigned*>(scan_lds + 5 * pitch);
-  __shared__ int blk_cnt[32], blk_first[32], blk_off[33];
-  __shared__ int next_sh;
-  const int t = threadIdx.x, lane = t & 63;
-  const int bh = (rows - bnd * 2) / 16;
-  const int y = bnd + (int)blockIdx.x, br = (int)blockIdx.x / bh;   // grid.x = 16 * bh rows of the selection area
-  const int part = (int)blockIdx.y, split = (int)gridDim.y;
-  for (int c = t; c < cols; c += kScanRowThreads) {
-    sPP[c] = R[(size_t)(y - 2) * cols + c];
-    sP[c + 1] = R[(size_t)(y - 1) * cols + c];
-    sC[c + 2] = R[(size_t)y * cols + c];
-    sN[c + 1] = R[(size_t)(y + 1) * cols + c];
-    sNN[c] = R[(size_t)(y + 2) * cols + c];
-  }
-  if (dbg == 1) { __syncthreads(); if (t == 0) d0[0] = sC[5]; return; }
-  // the row's points: 16 threads per selection block look at its slots (raster order: the slots of row y are contiguous)
-  const int j = t >> 4, sub = t & 15, b = br * 32 + j;
-  const int nb = cnt[b];
-  int first = 1 << 30, count = 0;
-  for (int k = sub; k < nb; k += 16)
-    if ((int)(pts[b * kSelCap + k] >> 16) == y) { count++; first = k < first ? k : first; }
-  count += dpp_i<0xB1>(count); count += dpp_i<0x4E>(count); count += dpp_i<0x141>(count); count += dpp_i<0x140>(count);   // over the 16 lanes
-  first = dpp_row_min<0xB1>(first); first = dpp_row_min<0x4E>(first); first = dpp_row_min<0x141>(first); first = dpp_row_min<0x140>(first);
-  if (sub == 0) { blk_cnt[j] = count; blk_first[j] = first; }
-  __syncthreads();
-  if (t == 0) {
-    int o = 0;
-    for (int q = 0; q < 32; q++) { blk_off[q] = o; o += blk_cnt[q]; }
-    blk_off[32] = o;
-  }
-  __syncthreads();
-  const int total = blk_off[32];
-  if (dbg == 2) { if (t == 0) d0[0] = (float)total; return; }
-  for (int round_lo = 0; round_lo < total; round_lo += kScanRowCap) {
-    const int n_round = (total - round_lo < kScanRowCap) ? total - round_lo : kScanRowCap;
-    for (int q = sub; q < count; q += 16) {   // (count / first: the group's values, in every one of its lanes)
-      const int e = blk_off[j] + q - round_lo;
-      if (e >= 0 && e < n_round) {
-        const int k = first + q, slot = b * kSelCap + k;
-        const int x = (int)(pts[slot] & 0xffffu);
-        unsigned* en = list + e * kScanRowEntry;
-        en[0] = (unsigned)x | ((unsigned)slot << 16);
-        const float* lc = L + (size_t)y * cols + x;
-        en[1] = __float_as_uint(lc[2 * cols]); en[2] = __float_as_uint(lc[cols - 1]); en[3] = __float_as_uint(lc[2]);
-        en[4] = __float_as_uint(lc[0]); en[5] = __float_as_uint(lc[-2]); en[6] = __float_as_uint(lc[1 - cols]);
-        en[7] = __float_as_uint(lc[-1 - cols]); en[8] = __float_as_uint(lc[-2 * cols]);     // :380-381, ssd8_tree's lane order
-      }
-    }
-    if (t == 0) next_sh = 0;
-    __syncthreads();
-    if (dbg == 3) { if (t == 0) d0[0] = __uint_as_float(list[0]); return; }
-    int stat_i = (t >> 6);
-    for (;;) {
-      // the next list entry for this wave. Every lane takes part in the atomic (lane 0 adds 1, the others 0; lane 0's return value
-      // is the counter before ITS add): with the usual `if (lane == 0) i = atomicAdd(..)` in front of readfirstlane, hipcc 7.2 built
-      // a loop around the body that retired only lane 0 per trip and never ended (the wave re-ran entry `part` with 63 lanes).
-      int i;
-      if (dbg == 4) { i = part + split * stat_i; stat_i += kScanRowThreads / 64; }
-      else { i = atomicAdd(&next_sh, lane == 0 ? 1 : 0); i = part + split * __builtin_amdgcn_readfirstlane(i); }
-      if (i >= n_round) break;
-      const unsigned* en = list + i * kScanRowEntry;
-      const unsigned w0 = en[0];
-      const int x = (int)(w0 & 0xffffu), slot = (int)(w0 >> 16);
-      float Lp[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) Lp[u] = __uint_as_float(en[1 + u]);
-      int lo = bnd;
-      if (max_disp > 0 && x - max_disp > lo) lo = x - max_disp;
-      float best = 1e+10f;  // :367
-      int match = 0x7fffffff;
-      int base = lo;
-      if (x - lo >= 4 * kWave + 3) {
-        // up to three candidates in front of the first aligned column, one per lane
-        const int al = (lo + 3) & ~3;
-        const int c = lo + lane;
-        if (c < al) {
-          const float Rq[8] = {sNN[c], sN[c], sC[c + 4], sC[c + 2], sC[c], sP[c + 2], sP[c], sPP[c]};
-          const float sd = ssd8_tree(Lp, Rq);
-          if (sd < best) { best = sd; match = c; }
-        }
-        // :382 — four consecutive candidates per lane while a whole 256-candidate trip fits below x
-        for (base = al; base + 4 * kWave <= x; base += 4 * kWave) {
-          const int c0 = base + 4 * lane;
-          const float4 C0 = *reinterpret_cast<const float4*>(sC + c0), C1 = *reinterpret_cast<const float4*>(sC + c0 + 4);
-          const float4 P0 = *reinterpret_cast<const float4*>(sP + c0);
-          const float2 P1 = *reinterpret_cast<const float2*>(sP + c0 + 4);
-          const float4 N0 = *reinterpret_cast<const float4*>(sN + c0);
-          const float4 NN = *reinterpret_cast<const float4*>(sNN + c0);
-          const float4 PP = *reinterpret_cast<const float4*>(sPP + c0);
-          const float C[8] = {C0.x, C0.y, C0.z, C0.w, C1.x, C1.y, C1.z, C1.w};   // rc[c0 - 2 + i]
-          const float P[6] = {P0.x, P0.y, P0.z, P0.w, P1.x, P1.y};               // rp[c0 - 1 + i]
-          const float Nn[4] = {N0.x, N0.y, N0.z, N0.w};                          // rn[c0 - 1 + i]
-          const float Nv[4] = {NN.x, NN.y, NN.z, NN.w}, Pv[4] = {PP.x, PP.y, PP.z, PP.w};
-#pragma unroll
-          for (int u = 0; u < 4; u++) {  // ascending columns: the strict < keeps the first minimum
-            const float Rq[8] = {Nv[u], Nn[u], C[u + 4], C[u + 2], C[u], P[u + 2], P[u], Pv[u]};
-            const float sd = ssd8_tree(Lp, Rq);
-            if (sd < best) { best = sd; match = c0 + u; }
-          }
-        }
-      }
-      // the rest: lanes = consecutive candidate columns, two per lane and trip
-      int rx = base + lane;
-      for (; rx + kWave < x; rx += 2 * kWave) {
-        float Rq[2][8];
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-          const int c = rx + u * kWave;
-          Rq[u][0] = sNN[c]; Rq[u][1] = sN[c]; Rq[u][2] = sC[c + 4]; Rq[u][3] = sC[c + 2]; Rq[u][4] = sC[c];
-          Rq[u][5] = sP[c + 2]; Rq[u][6] = sP[c]; Rq[u][7] = sPP[c];
-        }
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-          const float sd = ssd8_tree(Lp, Rq[u]);
-          if (sd < best) { best = sd; match = rx + u * kWave; }
-        }
-      }
-      for (; rx < x; rx += kWave) {
-        const float Rq[8] = {sNN[rx], sN[rx], sC[rx + 4], sC[rx + 2], sC[rx], sP[rx + 2], sP[rx], sPP[rx]};
-        const float sd = ssd8_tree(Lp, Rq);
-        if (sd < best) { best = sd; match = rx; }  // :385-386
-      }
-      scan_min_step<0xB1>(best, match);
-      scan_min_step<0x4E>(best, match);
-      scan_min_step<0x141>(best, match);
-      scan_min_step<0x140>(best, match);
-      float wb = lane_f(best, 0);
-      int wm = __builtin_amdgcn_readlane(match, 0);
-#pragma unroll
-      for (int r = 1; r < 4; r++) {
-        const float ob = lane_f(best, 16 * r);
-        const int om = __builtin_amdgcn_readlane(match, 16 * r);
-        const bool take = ob < wb || (ob == wb && om < wm);
-        wb = take ? ob : wb;
-        wm = take ? om : wm;
-      }
-      if (lane == 0) {
-        float dd = 0.0f;
-        const bool hit = !(wb > ssd_th);  // :388
-        if (hit) {
-          const float dsp = (float)(x - wm);     // :391
-          dd = dsp / (f0 * baseline);            // :394
-          disp[(size_t)y * cols + x] = dsp;
-          dep[(size_t)y * cols + x] = dd;
-        }
-        d0[slot] = dd;
-        matched[slot] = hit ? 1 : 0;
-      }
-    }
-    __syncthreads();   // the list is rewritten by the next round
-  }
 }
 
 struct DepthLmStats {

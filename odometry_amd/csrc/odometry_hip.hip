@@ -2667,24 +2667,13 @@ struct DepthJob {
   bool waiting;
 };
 
-// The epipolar scan: a workgroup per image row with the five right rows in LDS (depth_disparity_rows_kernel) where they fit, else a
-// wave per point slot with taps through the vector L1 (ODO_SCAN_ROWS=0: always; ODO_SCAN_SPLIT: workgroups per row, default 2).
-// e0 / e1 (optional): dispatch-bound start / stop events (odo_depth_time_stages).
+// The epipolar scan (depth_disparity_kernel: a wave per point slot). e0 / e1 (optional): dispatch-bound start / stop events
+// (odo_depth_time_stages).
 static void depth_launch_scan(const odo_depth* d, hipStream_t s, int rows, int cols, float* disp, float* dep, hipEvent_t e0 = nullptr,
                               hipEvent_t e1 = nullptr) {
-  static const bool rows_on = !getenv("ODO_SCAN_ROWS") || atoi(getenv("ODO_SCAN_ROWS")) != 0;
-  static const int split = getenv("ODO_SCAN_SPLIT") ? (atoi(getenv("ODO_SCAN_SPLIT")) > 0 ? atoi(getenv("ODO_SCAN_SPLIT")) : 1) : 2;
-  const int bh = (rows - d->boundary * 2) / 16;
-  const size_t lds = sizeof(float) * ((size_t)5 * scan_rows_pitch(cols) + (size_t)kScanRowCap * kScanRowEntry);
-  if (rows_on && bh > 0 && lds <= (64u << 10) && cols < 65536)
-    hipExtLaunchKernelGGL(depth_disparity_rows_kernel, dim3(16 * bh, split), dim3(kScanRowThreads), lds, s, e0, e1, 0,
-                          (const float*)d->d_bl, (const float*)d->d_br, rows, cols, d->boundary, d->max_disparity, d->ssd_th, d->K.f0,
-                          d->baseline, (const uint32_t*)d->d_pts, (const int*)d->d_cnt, disp, dep, d->d_d0, d->d_matched,
-                          getenv("ODO_SCAN_DBG") ? atoi(getenv("ODO_SCAN_DBG")) : 0);
-  else
-    hipExtLaunchKernelGGL(depth_disparity_kernel, dim3(kSelBlocks * kSelCap / 4), dim3(256), 0, s, e0, e1, 0, (const float*)d->d_bl,
-                          (const float*)d->d_br, rows, cols, d->boundary, d->max_disparity, d->ssd_th, d->K.f0, d->baseline,
-                          (const uint32_t*)d->d_pts, (const int*)d->d_cnt, disp, dep, d->d_d0, d->d_matched);
+  hipExtLaunchKernelGGL(depth_disparity_kernel, dim3(kSelBlocks * kSelCap / 4), dim3(256), 0, s, e0, e1, 0, (const float*)d->d_bl,
+                        (const float*)d->d_br, rows, cols, d->boundary, d->max_disparity, d->ssd_th, d->K.f0, d->baseline,
+                        (const uint32_t*)d->d_pts, (const int*)d->d_cnt, disp, dep, d->d_d0, d->d_matched);
 }
 
 static int depth_job_begin(odo_depth* d, DepthJob* j, const float* left, const float* right, int rows, int cols,

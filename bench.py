@@ -92,6 +92,21 @@ def load_traffic(key="lm_residual_bytes_per_launch"):
     return None, None
 
 
+def lm_traffic(fine, drive):
+    """roofline.traffic of the LM kernels per frame-launch pair: on the default drive the HEADLINE-ONLY passes (lm_fine_kernel +
+    lm_coarse_kernel bytes per launch, one launch of each per Solve) when profiles/pmc_traffic.json holds them; else the passes of the
+    whole bench command, whose averages mix the headline's launches with the stress and saturated legs'."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        j = json.load(open(p))
+    except Exception:
+        return None, None
+    if fine and drive == "natural" and "lm_fine_bytes_per_launch_headline" in j:
+        return (j["lm_fine_bytes_per_launch_headline"] + j.get("lm_coarse_bytes_per_launch_headline", 0),
+                j["headline_only"]["source"] + ": " + j["headline_only"]["command"] + "; lm_fine_kernel + lm_coarse_kernel, FETCH x 2 + WRITE, KB x 1024")
+    return load_traffic("lm_fine_bytes_per_launch" if fine else "lm_residual_bytes_per_launch")
+
+
 def cpu_baseline(seq, n_frames, n_reference_shape):
     """The oracle (CPU restatement) stepping the first n_frames frames of the same sequence on ONE pinned host core, in a child
     process, measured as BASELINE.md section 3 prescribes (oracle/cpu_baseline.py: -O3 -march=native build, 3 warm-up
@@ -1243,8 +1258,7 @@ def main():
         fine_key = "lm_fine_kernel" if fine else "lm_step_kernel"
         roof = dict(bound="hbm", kernel="LM evaluation kernels (lm_coarse_kernel + %s)" % fine_key,
                     achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 6),
-                    traffic=load_traffic("lm_fine_bytes_per_launch" if fine else "lm_residual_bytes_per_launch")[0],
-                    traffic_source=load_traffic()[1], measured=how,
+                    traffic=lm_traffic(fine, args.drive)[0], traffic_source=lm_traffic(fine, args.drive)[1], measured=how,
                     evaluations_per_frame=round(ev["active_launches"] / n_frames_ev, 2),
                     algorithmic_bytes_per_frame=round(ev["bytes"] / n_frames_ev, 1),
                     kernel_us_per_frame=round(kernel_us_per_frame, 2),

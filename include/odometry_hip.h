@@ -306,6 +306,20 @@ int odo_depth_compute_begin_dev(odo_depth* d, odo_ctx* side, const float* left_d
 int odo_depth_compute_end_dev(odo_depth* d, const float* left_dev, const float* right_dev, int rows, int cols, uint8_t* val_dev,
                               float* disp_dev, float* dep_dev, unsigned long long left_stamp, unsigned long long right_stamp);
 int odo_depth_early_pending(const odo_depth* d);
+/* The three output images handed over SPARSELY, for callers whose images live in host memory they own (cv::Mat): the images are zero
+ * everywhere but at the selected points (ref: src/depth_estimate.cpp:388-397,176-191 write at the points only; the zero fill is forced
+ * deviation #14), so {pixel index, val, disp, dep} per point slot — odo_depth_compact_bytes() = 532 KB instead of 4.2 MB at KITTI size —
+ * crosses PCIe, and the host rebuilds the images: odo_depth_compact_outputs_async queues the gather and the copy into `dst_pinned`
+ * (an odo_host_alloc block) on `on`'s stream, behind the job that wrote val_dev / disp_dev / dep_dev there (the estimator's point list of
+ * that job must still be current: call it before the estimator's next ComputeDepth); odo_host_scatter_outputs, once the copy has
+ * completed (odo_ctx_mark / odo_ctx_wait_mark), zero-fills the caller's three images and writes the points, and returns the
+ * fingerprint (odo_host_fingerprint) of the inverse-depth image it wrote — the one output the runner hands back in (DepthPyramid,
+ * ref: run_odometry_kitti_offline.cpp:252). Host-only, no device needed for the second call. */
+size_t odo_depth_compact_bytes(void);
+int odo_depth_compact_outputs_async(odo_depth* d, odo_ctx* on, const uint8_t* val_dev, const float* disp_dev, const float* dep_dev, int cols,
+                                    void* dst_pinned);
+int odo_host_scatter_outputs(const void* compact, int rows, int cols, uint8_t* val, size_t val_pitch, float* disp, size_t disp_pitch,
+                             float* dep, size_t dep_pitch, unsigned long long* dep_fingerprint);
 /* Disparity stage only (DisparityDepthEstimate, ref: src/depth_estimate.cpp:244-401). */
 int odo_depth_disparity(odo_depth* d, const float* left, const float* right, int rows, int cols, uint8_t* val,
                         float* disp, float* dep);

@@ -845,11 +845,14 @@ struct Lookahead {
   int pending_rows = 0, pending_cols = 0;
   unsigned long pending_mark = 0;                // the main stream's fill level then (odo_ctx_mark): the side stream goes behind THAT
 #ifdef ODOMETRY_SHIM_WITH_OPENCV
-  // cv::Mat outputs are host memory: the three images of a ComputeDepth started ahead are copied into page-locked staging blocks
-  // behind the job, still beside the Solve; ComputeDepth (:229) copies them on into its output Mats
-  void* out_stage[3] = {nullptr, nullptr, nullptr};
+  // cv::Mat outputs are host memory. The three images of a ComputeDepth started ahead are zero but at the selected points: the points
+  // {pixel, val, disp, dep} are gathered and copied into ONE page-locked block behind the job, still beside the Solve (532 KB instead
+  // of three dense images, 4.2 MB: the copy no longer outlasts the Solve), and ComputeDepth (:229) rebuilds the images in its output
+  // Mats from it (odo_host_scatter_outputs). ODOMETRY_SHIM_LAZY_OUTPUTS: only left_val, as a dense copy.
+  void* out_stage[3] = {nullptr, nullptr, nullptr};   // [0]: the compact block, or left_val's dense copy (lazy outputs)
   size_t out_stage_bytes[3] = {0, 0, 0};
-  unsigned long out_mark = 0;                    // the side stream's position behind the three copies; 0: nothing staged
+  unsigned long out_mark = 0;                    // the side stream's position behind the copy; 0: nothing staged
+  bool out_compact = false;
   ~Lookahead() { for (void* p : out_stage) if (p) odo_host_free(p); }
 #endif
 };
@@ -918,16 +921,18 @@ inline void run_lookahead(odo_lm* lm = nullptr, const odo_pyr* cur_img = nullptr
       }
 #ifdef ODOMETRY_SHIM_WITH_OPENCV
       la.out_mark = 0;
-      bool staged = true;
-      for (int i = 0; i < 3 && staged; i++) {
-        if (i > 0 && lazy_outputs()) break;      // (left_disp / left_dep stay on the device)
-        if (la.out_stage_bytes[i] != e.bytes[i]) {
-          if (la.out_stage[i]) odo_host_free(la.out_stage[i]);
-          la.out_stage[i] = odo_host_alloc(e.bytes[i]);
-          la.out_stage_bytes[i] = la.out_stage[i] ? e.bytes[i] : 0;
-        }
-        staged = la.out_stage[i] && odo_dev_download_async(side_context(), la.out_stage[i], e.blk[i], e.bytes[i]) == 0;
+      la.out_compact = !lazy_outputs();
+      const size_t need = la.out_compact ? odo_depth_compact_bytes() : e.bytes[0];
+      if (la.out_stage_bytes[0] != need) {
+        if (la.out_stage[0]) odo_host_free(la.out_stage[0]);
+        la.out_stage[0] = odo_host_alloc(need);
+        la.out_stage_bytes[0] = la.out_stage[0] ? need : 0;
       }
+      const bool staged = la.out_stage[0] &&
+          (la.out_compact ? odo_depth_compact_outputs_async(la.estimator, side_context(), static_cast<const uint8_t*>(e.blk[0]),
+                                                            static_cast<const float*>(e.blk[1]), static_cast<const float*>(e.blk[2]), e.cols,
+                                                            la.out_stage[0])
+                          : odo_dev_download_async(side_context(), la.out_stage[0], e.blk[0], e.bytes[0])) == 0;
       if (staged) la.out_mark = odo_ctx_mark(side_context());
 #endif
     } else {
@@ -1234,10 +1239,25 @@ class DepthEstimator {  // ref: include/depth_estimate.h:24-121
           const bool staged = la.out_mark != 0 && redone_after == redone_before && st == 0;
           if (staged) odo_ctx_wait_mark(detail::side_context(), la.out_mark);
           lap_(2);
-          for (int i = 0; i < 3; i++) {
-            if (i > 0 && detail::lazy_outputs()) break;
-            auto ob = detail::output_buffer_of(*outs[i]);
-            if (staged) ob->deliver_from(la.out_stage[i]); else ob->deliver_now();
+          if (staged && la.out_compact && !detail::lazy_outputs()) {
+            unsigned long long dep_fp = 0;
+            if (odo_host_scatter_outputs(la.out_stage[0], e.rows, e.cols, left_val.data, (size_t)left_val.step, left_disp.ptr<float>(),
+                                         (size_t)left_disp.step, left_dep.ptr<float>(), (size_t)left_dep.step, &dep_fp) == 0) {
+              for (int i = 0; i < 3; i++) {
+                auto ob = detail::output_buffer_of(*outs[i]);
+                ob->fp = dep_fp;
+                ob->finish_delivery();
+                if (i < 2) ob->fp_known = false;   // (left_val / left_disp never come back as inputs: no fingerprint pass spent on them —
+              }                                    //  if one ever does, it is simply uploaded again)
+            } else {
+              for (int i = 0; i < 3; i++) detail::output_buffer_of(*outs[i])->deliver_now();
+            }
+          } else {
+            for (int i = 0; i < 3; i++) {
+              if (i > 0 && detail::lazy_outputs()) break;
+              auto ob = detail::output_buffer_of(*outs[i]);
+              if (staged && !la.out_compact && i == 0) ob->deliver_from(la.out_stage[0]); else ob->deliver_now();
+            }
           }
           la.out_mark = 0;
           lap_(3);

@@ -61,6 +61,9 @@ SIGNATURES = {
     "odo_dev_upload_async": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "odo_dev_upload_2d_async": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, C.c_int]),
     "odo_ctx_wait_mark": (C.c_int, [_vp, C.c_ulong]),
+    "odo_depth_compact_bytes": (C.c_size_t, []),
+    "odo_depth_compact_outputs_async": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
+    "odo_host_scatter_outputs": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_ulonglong)]),
     "odo_host_fingerprint": (C.c_ulonglong, [_vp, C.c_size_t, C.c_size_t, C.c_int]),
     "odo_host_copy_fingerprint": (C.c_ulonglong, [_vp, C.c_size_t, _vp, C.c_size_t, C.c_size_t, C.c_int]),
     "odo_dev_upload_fp_async": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_ulonglong)]),

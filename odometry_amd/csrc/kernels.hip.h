@@ -2598,6 +2598,28 @@ __global__ void __launch_bounds__(256) depth_disparity_kernel(const float* __res
   depth_disparity_kernel_body(L, R, rows, cols, bnd, max_disp, ssd_th, f0, baseline, pts, cnt, disp, dep, d0, matched);
 }
 
+// ComputeDepth's three output images are zero everywhere but at the selected points (ref: src/depth_estimate.cpp:388-397,176-191 write
+// at the points; the images are zero-filled in front, forced deviation #14): per point slot {pixel index, val, disp, dep}, 13 bytes
+// instead of 9 per pixel — what a caller whose images live in host memory it owns (cv::Mat) needs to rebuild them there. Unused
+// slots get index 0xffffffff.
+__global__ void __launch_bounds__(256) depth_compact_outputs_kernel(const uint32_t* __restrict__ pts, const int* __restrict__ cnt, int cols,
+                                                                    const uint8_t* __restrict__ val, const float* __restrict__ disp,
+                                                                    const float* __restrict__ dep, uint32_t* __restrict__ o_idx,
+                                                                    float* __restrict__ o_disp, float* __restrict__ o_dep,
+                                                                    uint8_t* __restrict__ o_val) {
+  const int s = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (s >= kSelBlocks * kSelCap) return;
+  uint32_t idx = 0xffffffffu;
+  float ds = 0.0f, dp = 0.0f;
+  uint8_t v = 0;
+  if ((s % kSelCap) < cnt[s / kSelCap]) {
+    const uint32_t pk = pts[s];
+    idx = (pk >> 16) * (uint32_t)cols + (pk & 0xffffu);
+    v = val[idx]; ds = disp[idx]; dp = dep[idx];
+  }
+  o_idx[s] = idx; o_disp[s] = ds; o_dep[s] = dp; o_val[s] = v;
+}
+
 struct DepthLmStats {
   int iters;
   float cost;

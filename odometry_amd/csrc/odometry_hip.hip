@@ -2510,6 +2510,7 @@ struct odo_depth {
   uint32_t* d_pts;
   int* d_cnt;
   uint8_t* d_matched;
+  void* d_compact;                // odo_depth_compact_outputs_async: {idx u32, disp f32, dep f32, val u8} x point slots
   DepthLmState* d_lmstate;
   double* d_part_e;
   int* d_part_n;
@@ -2613,7 +2614,7 @@ extern "C" int odo_depth_destroy(odo_depth* d) {
   if (d->prep_ev) (void)hipEventSynchronize(d->prep_ev);   // a half / a whole job started ahead on another stream writes these buffers
   depth_free_images(d);
   void* dv[] = {d->d_pts, d->d_cnt, d->d_d0, d->d_scratch, d->d_matched, d->d_lmstate, d->d_part_e, d->d_part_n, d->d_counts, d->d_xbuf,
-                d->d_gave_up};
+                d->d_gave_up, d->d_compact};
   for (void* q : dv) if (q) (void)hipFree(q);
   (void)hipHostFree(d->h_stats); (void)hipHostFree(d->h_prog);
   if (d->prep_ev) (void)hipEventDestroy(d->prep_ev);
@@ -2941,6 +2942,51 @@ extern "C" int odo_depth_compute_dev_stamped(odo_depth* d, const float* left_dev
 // The whole of ComputeDepth(left, right) enqueued on `side`'s stream, without waiting: the call returns once the launches are out.
 // Returns 0: started; 1: not started (the depth LM would need host-paced step launches: persistent launch off / switched off);
 // -1: error. odo_depth_compute_end_dev with the same arguments collects it.
+// ---- sparse hand-over of the three output images (callers that own host memory: cv::Mat) ----
+constexpr size_t kCompactSlots = (size_t)kSelBlocks * kSelCap;
+extern "C" size_t odo_depth_compact_bytes(void) { return kCompactSlots * 13; }
+extern "C" int odo_depth_compact_outputs_async(odo_depth* d, odo_ctx* on, const uint8_t* val_dev, const float* disp_dev,
+                                               const float* dep_dev, int cols, void* dst_pinned) {
+  if (!d || !on || !val_dev || !disp_dev || !dep_dev || !dst_pinned || cols < 1) return fail("odo_depth_compact_outputs_async: bad arg");
+  if (!host_is_pinned(dst_pinned, kCompactSlots * 13)) return fail("odo_depth_compact_outputs_async: dst is not an odo_host_alloc block of odo_depth_compact_bytes()");
+  HIP_OK(hipSetDevice(d->ctx->device));
+  if (!d->d_compact) HIP_OK(hipMalloc(&d->d_compact, kCompactSlots * 13));
+  char* c = (char*)d->d_compact;
+  hipLaunchKernelGGL(depth_compact_outputs_kernel, dim3((unsigned)((kCompactSlots + 255) / 256)), dim3(256), 0, on->stream,
+                     (const uint32_t*)d->d_pts, (const int*)d->d_cnt, cols, val_dev, disp_dev, dep_dev, (uint32_t*)c,
+                     (float*)(c + kCompactSlots * 4), (float*)(c + kCompactSlots * 8), (uint8_t*)(c + kCompactSlots * 12));
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpyAsync(dst_pinned, d->d_compact, kCompactSlots * 13, hipMemcpyDeviceToHost, on->stream));
+  return 0;
+}
+extern "C" int odo_host_scatter_outputs(const void* compact, int rows, int cols, uint8_t* val, size_t val_pitch, float* disp,
+                                        size_t disp_pitch, float* dep, size_t dep_pitch, unsigned long long* dep_fingerprint) {
+  if (!compact || !val || !disp || !dep || rows < 1 || cols < 1 || val_pitch < (size_t)cols || disp_pitch < sizeof(float) * (size_t)cols ||
+      dep_pitch < sizeof(float) * (size_t)cols)
+    return fail("odo_host_scatter_outputs: bad arg");
+  const char* c = (const char*)compact;
+  const uint32_t* idx = (const uint32_t*)c;
+  const float* cd = (const float*)(c + kCompactSlots * 4);
+  const float* cp = (const float*)(c + kCompactSlots * 8);
+  const uint8_t* cv = (const uint8_t*)(c + kCompactSlots * 12);
+  for (int y = 0; y < rows; y++) {
+    memset(val + (size_t)y * val_pitch, 0, (size_t)cols);
+    memset((char*)disp + (size_t)y * disp_pitch, 0, sizeof(float) * (size_t)cols);
+    memset((char*)dep + (size_t)y * dep_pitch, 0, sizeof(float) * (size_t)cols);
+  }
+  const uint32_t npx = (uint32_t)rows * (uint32_t)cols;
+  for (size_t s = 0; s < kCompactSlots; s++) {
+    const uint32_t i = idx[s];
+    if (i >= npx) continue;
+    const uint32_t y = i / (uint32_t)cols, x = i - y * (uint32_t)cols;
+    val[(size_t)y * val_pitch + x] = cv[s];
+    *(float*)((char*)disp + (size_t)y * disp_pitch + (size_t)x * 4) = cd[s];
+    *(float*)((char*)dep + (size_t)y * dep_pitch + (size_t)x * 4) = cp[s];
+  }
+  if (dep_fingerprint) *dep_fingerprint = hostfp::image(dep, dep_pitch, sizeof(float) * (size_t)cols, rows, nullptr, 0);
+  return 0;
+}
+
 extern "C" int odo_depth_compute_begin_dev(odo_depth* d, odo_ctx* side, const float* left_dev, const float* right_dev, int rows, int cols,
                                            uint8_t* val_dev, float* disp_dev, float* dep_dev, unsigned long long left_stamp,
                                            unsigned long long right_stamp, unsigned long mark) {

@@ -4,7 +4,7 @@
 # Passes (each its own run; counters never share a run with tracing beyond --kernel-trace):
 #   1. --kernel-trace --stats of the bench command (no child processes: the CPU-baseline and shim legs spawn programs)
 #   1b. the same of the driver's short run (--steps 20 --warmup 5)
-#   2. --pmc FETCH_SIZE   3. --pmc WRITE_SIZE   of the same command with fewer steps
+#   2. --pmc FETCH_SIZE   3. --pmc WRITE_SIZE   of the same command with fewer steps; 2b / 3b: of the headline alone
 #   4. --pmc SQ_* of the dense-kernel microbenchmark (issue-bound evidence) + its plain output (A/B table)
 #   5. the VALU instruction-rate microbenchmark
 set -u
@@ -24,6 +24,11 @@ timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/st
 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats20 -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-frames 0 --no-extras --steps 20 --warmup 5 > $OUT/bench_profiled_steps20.json 2> $OUT/bench_profiled_steps20.err < /dev/null
 timeout -k 5 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH --steps 199 --warmup 5 > /dev/null 2>&1 < /dev/null
 timeout -k 5 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH --steps 199 --warmup 5 > /dev/null 2>&1 < /dev/null
+# 2b / 3b. the same two counters of the HEADLINE ALONE (no side legs, no stress drive): lm_fine_kernel's traffic per launch on the very
+# kernel configuration bench.py's roofline line is printed for (the mixed passes above average three legs' launches)
+HEAD="python3 $GRAFT_REPO_ROOT/bench.py --cpu-frames 0 --no-extras --no-stress --steps 199 --warmup 5"
+timeout -k 5 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_headline -- $HEAD > /dev/null 2>&1 < /dev/null
+timeout -k 5 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_headline -- $HEAD > /dev/null 2>&1 < /dev/null
 F="-O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fhip-fp32-correctly-rounded-divide-sqrt"
 hipcc $F -o /tmp/dense_ablate $GRAFT_REPO_ROOT/tools/microbench/dense_ablate.hip 2> $OUT/build.log
 timeout -k 5 120 /tmp/dense_ablate > $OUT/dense_ablate.log 2>&1 < /dev/null

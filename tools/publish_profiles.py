@@ -34,6 +34,13 @@ def main():
     for sub, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         subprocess.check_call([sys.executable, summ, "pmc", one(os.path.join(src, sub, "*", "*_counter_collection.csv")), counter,
                                os.path.join(dst, f"{rnd}_{sub}.json")])
+    head = {}
+    for sub, counter in (("pmc_fetch_headline", "FETCH_SIZE"), ("pmc_write_headline", "WRITE_SIZE")):
+        g = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))
+        if g:
+            out = os.path.join(dst, f"{rnd}_{sub}.json")
+            subprocess.check_call([sys.executable, summ, "pmc", g[0], counter, out])
+            head[counter] = json.load(open(out))[counter]
     for kind in ("steps20", "default"):
         p = os.path.join(ROOT, "gpurun_out", f"{tag}_bench_{kind}.json")
         if os.path.exists(p) and os.path.getsize(p) > 0:
@@ -57,6 +64,23 @@ def main():
         if kern in f and kern in w and key in d:
             n, a, b = fw(kern)
             d[key]["dispatches"], d[key]["FETCH_SIZE_KB_per_launch_raw"], d[key]["WRITE_SIZE_KB_per_launch"] = n, a, b
+    if len(head) == 2:   # the headline alone: what bench.py's roofline.traffic of the default drive repeats
+        hf, hw = head["FETCH_SIZE"], head["WRITE_SIZE"]
+        hl = {}
+        for key, kern in (("lm_fine_kernel", "odo::lm_fine_kernel"), ("lm_coarse_kernel", "odo::lm_coarse_kernel"),
+                          ("depth_lm_persistent_kernel", "odo::depth_lm_persistent_kernel"), ("depth_disparity_kernel", "odo::depth_disparity_kernel")):
+            if kern in hf and kern in hw:
+                a, b = hf[kern]["per_dispatch"], hw[kern]["per_dispatch"]
+                hl[key] = dict(dispatches=hf[kern]["dispatches"], FETCH_SIZE_KB_per_launch_raw=round(a, 1), WRITE_SIZE_KB_per_launch=round(b, 2),
+                               bytes_per_launch=int(round((a * 2 + b) * 1024)))
+        d["headline_only"] = dict(
+            command="python3 bench.py --cpu-frames 0 --no-extras --no-stress --steps 199 --warmup 5 (two separate --pmc passes)",
+            source=f"profiles/{rnd}_pmc_fetch_headline.json + profiles/{rnd}_pmc_write_headline.json", kernels=hl)
+        if "lm_fine_kernel" in hl:
+            d["lm_fine_bytes_per_launch_headline"] = hl["lm_fine_kernel"]["bytes_per_launch"]
+        if "lm_coarse_kernel" in hl:
+            d["lm_coarse_bytes_per_launch_headline"] = hl["lm_coarse_kernel"]["bytes_per_launch"]
+    d["source"] = d["source"].replace("round 4", f"round {int(rnd[1:])}").replace("r04_", f"{rnd}_")
     json.dump(d, open(tp, "w"), indent=1)
     print("lm_fine_kernel", fw("odo::lm_fine_kernel"), "lm_coarse_kernel", fw("odo::lm_coarse_kernel"), "lm_step_kernel", fw("odo::lm_step_kernel"))
 

@@ -429,6 +429,11 @@ odo_ctx* odo_tracker_ctx(odo_tracker* t);
 typedef struct odo_tracker_batch odo_tracker_batch;
 int odo_tracker_batch_create(int device, const odo_tracker_params* p, int n_sequences, odo_tracker_batch** out);
 int odo_tracker_batch_destroy(odo_tracker_batch* b);
+/* The inverse-depth LM of a lock step (ref: src/depth_estimate.cpp:141-168,200-242) in ONE persistent launch for all sequences — each on
+ * an XCD of its own, beside the batched pose LM's — instead of a launch per iteration: up to four sequences (more share their XCDs with
+ * the pose LM, where the 80 workgroups of a sequence do not fit). *on = 1 while it is in use, *chains_redone = lock steps whose launch
+ * gave up and whose depth jobs were run again on the launches per iteration (results unaffected; three switch it off). */
+int odo_tracker_batch_depth_persistent_stats(const odo_tracker_batch* b, int* on, int* chains_redone);
 int odo_tracker_batch_size(const odo_tracker_batch* b);
 /* The pose optimiser of one slot (launch statistics of the batched Solves live with the first slot's: odo_lm_event_timing). */
 odo_lm* odo_tracker_batch_lm(odo_tracker_batch* b, int slot);

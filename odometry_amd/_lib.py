@@ -151,6 +151,7 @@ SIGNATURES = {
     "odo_gather_destroy": (C.c_int, [_vp]),
     "odo_tracker_batch_create": (C.c_int, [C.c_int, C.POINTER(TrackerParams), C.c_int, C.POINTER(_vp)]),
     "odo_tracker_batch_destroy": (C.c_int, [_vp]),
+    "odo_tracker_batch_depth_persistent_stats": (C.c_int, [_vp, _ip, _ip]),
     "odo_tracker_batch_quiesce": (C.c_int, [_vp]),
     "odo_tracker_batch_size": (C.c_int, [_vp]),
     "odo_tracker_batch_ctx": (_vp, [_vp]),

@@ -793,6 +793,12 @@ class TrackerBatch:
             out.append(a)
         return out
 
+    def depth_persistent_stats(self):
+        """(1 while the lock step's inverse-depth LMs run in one persistent launch, lock steps whose launch gave up and were redone)"""
+        a, b = C.c_int(0), C.c_int(0)
+        L.check(self.lib.odo_tracker_batch_depth_persistent_stats(self.h, C.byref(a), C.byref(b)), "odo_tracker_batch_depth_persistent_stats")
+        return a.value, b.value
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.odo_tracker_batch_quiesce(self.h)   # see Tracker.close

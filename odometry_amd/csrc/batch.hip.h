@@ -30,6 +30,7 @@ struct BatchSeq {
   DepthLmStats* stats;  // host-mapped
   int* dprog;           // host-mapped progress words: [0] launches consumed, [1] LM stopped, [4] job complete (token)
   int dtoken;
+  int* gave_up;         // the estimator's give-up word when the depth LM ran in the persistent launch (else null)
   // keyframe-candidate point lists
   KfLevels kl;
   int* rowcnt;
@@ -94,7 +95,7 @@ __global__ void __launch_bounds__(kDlmBlock) depth_stats_batch_kernel(const Batc
                                                                       int with_lists) {
   const BatchSeq& q = tab[blockIdx.y];
   if (with_lists && threadIdx.x < ODO_MAX_LEVELS_K) q.npts_host[threadIdx.x] = q.npts[threadIdx.x];
-  depth_stats_kernel_body(run_lm, n_launches, q.counts, q.dstate, q.stats, q.dprog + 4, q.dtoken);
+  depth_stats_kernel_body(run_lm, n_launches, q.counts, q.dstate, q.stats, q.dprog + 4, q.dtoken, q.gave_up);
 }
 
 }  // namespace odo
@@ -119,6 +120,11 @@ struct BatchChain {
   bool poll, waiting, with_lists;
   int err;
   std::chrono::steady_clock::time_point wait_since;
+  // DepthOptimization of every entry in ONE persistent launch (depth_lm_persistent_batch_kernel) instead of a launch per iteration
+  bool persistent;           // this run of the chain used it
+  bool no_persist_once;      // the chain is being run again after a give-up: step launches
+  DepthPersistArgs* h_ptab;  // pinned, S entries
+  DepthPersistArgs* d_ptab;
 };
 
 struct odo_tracker_batch {
@@ -161,6 +167,7 @@ struct odo_tracker_batch {
   std::vector<int> ids;    // slots of the lock step in flight (pose LM)
   bool with_lists;
   hipEvent_t ev_a;         // a point on stream A (the rebuild of next_img on stream C goes behind an abandoned early Solve)
+  int depth_persist_bails, depth_persist_strikes, depth_persist_clean;   // chains run again after a give-up (lifetime) / strikes that count / clean chains since
   int dead;                // 1: a wait timed out with work in flight — every later call fails fast
   double tm_frame_us, tm_head_us, tm_solve_us, tm_depth_wait_us; long tm_frames;  // host-clock averages (diagnostics)
 };
@@ -192,6 +199,8 @@ extern "C" int odo_tracker_batch_destroy(odo_tracker_batch* b) {
   for (BatchChain* c : {&b->late, &b->ahead}) {
     if (c->h_tab) (void)hipHostFree(c->h_tab);
     if (c->d_tab) (void)hipFree(c->d_tab);
+    if (c->h_ptab) (void)hipHostFree(c->h_ptab);
+    if (c->d_ptab) (void)hipFree(c->d_ptab);
   }
   if (b->h_pyr) (void)hipHostFree(b->h_pyr);
   if (b->d_pyr) (void)hipFree(b->d_pyr);
@@ -203,6 +212,14 @@ extern "C" int odo_tracker_batch_destroy(odo_tracker_batch* b) {
   odo_ctx_destroy(b->ctx_b);
   odo_ctx_destroy(b->ctx_a);
   delete b;
+  return 0;
+}
+
+extern "C" int odo_tracker_batch_depth_persistent_stats(const odo_tracker_batch* b, int* on, int* chains_redone) {
+  if (!b) return fail("odo_tracker_batch_depth_persistent_stats: NULL tracker");
+  if (on) *on = (b->S <= 4 && b->depth_persist_strikes < 3 && b->depth[0] && b->depth[0]->persist_cfg &&
+                 (!getenv("ODO_BATCH_DEPTH_PERSIST") || atoi(getenv("ODO_BATCH_DEPTH_PERSIST")) != 0)) ? 1 : 0;
+  if (chains_redone) *chains_redone = b->depth_persist_bails;
   return 0;
 }
 
@@ -219,7 +236,11 @@ extern "C" int odo_tracker_batch_create(int device, const odo_tracker_params* p,
   b->p = *p; b->S = S;
   b->ctx_a = b->ctx_b = b->ctx_c = nullptr; b->h_pyr = b->d_pyr = nullptr; b->h_cand_npts = b->d_cand_npts = nullptr;
   b->ev_cur_img = b->ev_next = b->ev_a = nullptr; b->dead = 0;
-  for (BatchChain* c : {&b->late, &b->ahead}) { c->h_tab = c->d_tab = nullptr; c->stage = 0; c->err = 0; c->img_ready = nullptr; c->complete.store(0); }
+  for (BatchChain* c : {&b->late, &b->ahead}) {
+    c->h_tab = c->d_tab = nullptr; c->stage = 0; c->err = 0; c->img_ready = nullptr; c->complete.store(0);
+    c->h_ptab = c->d_ptab = nullptr; c->persistent = c->no_persist_once = false;
+  }
+  b->depth_persist_bails = b->depth_persist_strikes = b->depth_persist_clean = 0;
   b->w_ring[0] = b->w_ring[1] = nullptr; b->w_posted.store(0); b->w_done.store(0); b->w_quit.store(0);
   b->tm_frame_us = b->tm_head_us = b->tm_solve_us = b->tm_depth_wait_us = 0.0; b->tm_frames = 0;
   b->overlap = (p->overlap_depth != 0) && !getenv("ODO_BATCH_NO_OVERLAP");
@@ -261,6 +282,8 @@ extern "C" int odo_tracker_batch_create(int device, const odo_tracker_params* p,
   for (BatchChain* c : {&b->late, &b->ahead}) {
     ok = ok && hipHostMalloc((void**)&c->h_tab, sizeof(BatchSeq) * (size_t)S, hipHostMallocDefault) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->d_tab, sizeof(BatchSeq) * (size_t)S) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&c->h_ptab, sizeof(DepthPersistArgs) * (size_t)S, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_ptab, sizeof(DepthPersistArgs) * (size_t)S) == hipSuccess;
   }
   ok = ok && hipHostMalloc((void**)&b->h_pyr, sizeof(BatchSeq) * 2 * (size_t)S, hipHostMallocDefault) == hipSuccess;
   ok = ok && hipMalloc((void**)&b->d_pyr, sizeof(BatchSeq) * 2 * (size_t)S) == hipSuccess;
@@ -315,6 +338,8 @@ static int batch_build_pyramids(odo_tracker_batch* b, const std::vector<int>& sl
   return 0;
 }
 
+static bool batch_depth_persist_ok(const odo_tracker_batch* b, const BatchChain* c);
+static int batch_chain_run(odo_tracker_batch* b, BatchChain* c);
 // Fills and uploads a chain's table and enqueues the front of its depth job (blur, point selection, disparity scan) on stream s.
 // The chain describes the job: ids, the pairs (left / right per slot), which image pyramid the candidate lists read, the
 // frame tag. Entry e writes the slot's next output parity.
@@ -322,7 +347,7 @@ static int batch_chain_begin(odo_tracker_batch* b, BatchChain* c, hipStream_t s)
   const odo_tracker_params& p = b->p;
   const int n = (int)c->ids.size();
   c->par.assign(n, 0); c->tag.assign(n, -1); c->stats.assign(n, DepthLmStats());
-  c->stage = 0; c->err = 0; c->k = 0; c->n_launches = 0; c->waiting = false;
+  c->stage = 0; c->err = 0; c->k = 0; c->n_launches = 0; c->waiting = false; c->persistent = false;
   if (n == 0) { c->stage = 3; return 0; }
   for (int e = 0; e < n; e++) {
     const int i = c->ids[e];
@@ -344,6 +369,7 @@ static int batch_chain_begin(odo_tracker_batch* b, BatchChain* c, hipStream_t s)
     q.val = b->d_val[par][i]; q.matched = d->d_matched; q.pts = d->d_pts; q.cnt = d->d_cnt;
     q.dstate = d->d_lmstate; q.part_e = d->d_part_e; q.part_n = d->d_part_n; q.counts = d->d_counts;
     q.stats = d->d_stats_map; q.dprog = d->d_prog;
+    q.gave_up = batch_depth_persist_ok(b, c) ? d->d_gave_up : nullptr;
     d->token++;
     q.dtoken = d->token;
     d->h_prog[0] = 0; d->h_prog[1] = 0;  // the slot's previous job is complete: nobody is polling these
@@ -377,8 +403,9 @@ static int batch_chain_tail(odo_tracker_batch* b, BatchChain* c, hipStream_t s) 
   const odo_depth* d = b->depth[0];
   const int n = (int)c->ids.size();
   const BatchSeq* tab = c->d_tab;
-  hipLaunchKernelGGL(depth_finalize_batch_kernel, dim3(kDlmBlocks, n), dim3(kDlmBlock), 0, s, tab, 1, p.cols, d->photo_th,
-                     d->min_depth, d->max_depth);
+  if (!c->persistent)   // (the persistent launch writes back and counts itself)
+    hipLaunchKernelGGL(depth_finalize_batch_kernel, dim3(kDlmBlocks, n), dim3(kDlmBlock), 0, s, tab, 1, p.cols, d->photo_th,
+                       d->min_depth, d->max_depth);
   hipLaunchKernelGGL(depth_pyramid_batch_kernel, grid2d(p.cols, p.rows, n), dim3(256), 0, s, tab);  // :252
   const int rows_total = batch_rows_total(b);
   const int with_lists = (c->with_lists && rows_total > 0) ? 1 : 0;
@@ -394,8 +421,48 @@ static int batch_chain_tail(odo_tracker_batch* b, BatchChain* c, hipStream_t s) 
 }
 
 // Issues at most one depth-LM launch (all slots of the chain) per call; enqueues the tail once every slot's LM has stopped.
+// The inverse-depth LM of every entry in one persistent launch: up to four sequences, each on an XCD of its own (block classes 4 .. 7;
+// the batched pose LM's sequences sit on 0 .. 3 with all 32 CUs of their XCDs). More sequences than that share XCDs with the pose LM
+// (16 of 32 CUs each at S = 8) where 80 workgroups of 512 threads do not fit beside it: those keep the launch per iteration.
+// ODO_BATCH_DEPTH_PERSIST=0: off. A sequence whose launch gives up (a wait ran out: its workgroups were not all resident) makes the
+// whole chain run again on the step launches (batch_chain_run); three such chains switch the launch off for this tracker.
+static bool batch_depth_persist_ok(const odo_tracker_batch* b, const BatchChain* c) {
+  static const bool on = !getenv("ODO_BATCH_DEPTH_PERSIST") || atoi(getenv("ODO_BATCH_DEPTH_PERSIST")) != 0;
+  const odo_depth* d0 = b->depth[0];
+  return on && !c->no_persist_once && b->depth_persist_strikes < 3 && (int)c->ids.size() <= 4 && d0->persist_cfg && d0->max_iters <= kDpMaxIters &&
+         c->h_ptab && c->d_ptab;
+}
+static int batch_chain_persistent(odo_tracker_batch* b, BatchChain* c, hipStream_t s) {
+  const int n = (int)c->ids.size();
+  for (int e = 0; e < n; e++) {
+    odo_depth* d = b->depth[c->ids[e]];
+    const BatchSeq& q = c->h_tab[e];
+    if ((++d->persist_epoch & 0xffu) == 0u)
+      HIP_OK(hipMemsetAsync(d->d_xbuf, 0, sizeof(unsigned long long) * 2 * kDlmBlocks * 2, s));
+    DepthPersistArgs& a = c->h_ptab[e];
+    memset(&a, 0, sizeof(a));
+    a.left = q.left; a.right = q.right; a.cols = b->p.cols; a.pts = d->d_pts; a.cnt = d->d_cnt; a.d0 = d->d_d0; a.matched = d->d_matched;
+    a.state_out = d->d_lmstate;
+    a.tx = d->baseline; a.fx = d->K.f0; a.huber_delta = d->huber_delta; a.lambda0 = d->lambda; a.precision = d->precision;
+    a.max_iters = d->max_iters; a.photo_th = d->photo_th; a.min_depth = d->min_depth; a.max_depth = d->max_depth;
+    a.val = q.val; a.dep = q.dep; a.counts = d->d_counts; a.xbuf = d->d_xbuf; a.epoch = d->persist_epoch; a.wait_ticks = d->persist_wait;
+    a.gave_up = d->d_gave_up; a.fault = d->persist_fault; a.home = -1; a.cls = 4;
+  }
+  HIP_OK(hipMemcpyAsync(c->d_ptab, c->h_ptab, sizeof(DepthPersistArgs) * (size_t)n, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(depth_lm_persistent_batch_kernel, dim3(8 * kDpK), dim3(kDpThreads), 0, s, (const DepthPersistArgs*)c->d_ptab, n,
+                     device_xcc_ids(b->ctx_b->device));
+  HIP_OK(hipGetLastError());
+  c->persistent = true;
+  c->n_launches = 0;
+  return 0;
+}
+
 static void batch_chain_pump(odo_tracker_batch* b, BatchChain* c, hipStream_t s) {
   if (c->stage != 1) return;
+  if (c->k == 0 && batch_depth_persist_ok(b, c)) {
+    if (batch_chain_persistent(b, c, s) || batch_chain_tail(b, c, s)) { c->err = 1; c->stage = 0; }
+    return;
+  }
   const odo_depth* d0 = b->depth[0];
   bool all_stopped = true;
   int min_prog = 1 << 30;
@@ -444,6 +511,22 @@ static int batch_chain_run(odo_tracker_batch* b, BatchChain* c) {
   }
   std::atomic_thread_fence(std::memory_order_acquire);
   for (size_t e = 0; e < c->ids.size(); e++) c->stats[e] = *b->depth[c->ids[e]]->h_stats;
+  if (c->persistent) {
+    bool gave_up = false;
+    for (const DepthLmStats& st : c->stats) gave_up = gave_up || st.status == -2;
+    if (gave_up && !c->no_persist_once) {
+      // a persistent launch gave up: the same chain again on the launches per iteration (same output parity, same tags)
+      b->depth_persist_bails++;
+      b->depth_persist_strikes++;
+      b->depth_persist_clean = 0;
+      for (int i : c->ids) b->next_par[i] ^= 1;
+      c->no_persist_once = true;
+      const int rc = batch_chain_run(b, c);
+      c->no_persist_once = false;
+      return rc;
+    }
+    if (!gave_up && b->depth_persist_strikes > 0 && ++b->depth_persist_clean >= 1024) { b->depth_persist_strikes = 0; b->depth_persist_clean = 0; }
+  }
   c->stage = 3;
   c->complete.store(1, std::memory_order_release);
   return 0;

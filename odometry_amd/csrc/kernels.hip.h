@@ -2812,16 +2812,11 @@ struct DepthPersistArgs {
   int home;                     // the XCC id of the XCD this estimator's persistent launch runs on (fine_on_home); < 0: by block class
   int cls;                      // the block class (blockIdx % 8) that takes part when home < 0
 };
-__global__ void __launch_bounds__(kDpThreads) depth_lm_persistent_kernel(DepthPersistArgs a) {
+// (the launch's workgroup g of kDpK; which blocks of the grid those are is the kernel's business)
+__device__ __forceinline__ void depth_lm_persistent_body(const DepthPersistArgs& a, const int g) {
   const unsigned wait_limit = a.wait_ticks ? a.wait_ticks : kFineWaitTicks;
-  // Which eighth of the grid takes part: block class `cls` (blocks with blockIdx % 8 == cls land on one XCD: the dispatcher deals every
-  // grid round-robin from the same XCD). NOT the pose LM's class 0: on one XCD the two persistent launches cannot share a CU (416 +
-  // 160 VGPRs per SIMD), so whenever they overlapped in time one waited for the other's CUs, and when both were dispatched at the same
-  // moment each got part of the XCD and waited for workgroups that could not be placed (ODO_LOG_GIVEUPS: 76 of 80 workgroups entered
-  // together, the last four only when the first ones had given up — on XCC 6, the pose LM's, every time). home >= 0: by XCC id.
-  if (a.home >= 0 ? fine_xcc_id() != a.home : (int)(blockIdx.x & 7u) != a.cls) return;
   const unsigned long long t_entry = (unsigned long long)wall_clock64();
-  const int g = (int)(blockIdx.x >> 3), t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   __shared__ double sh_e[kDpThreads / 64];
   __shared__ int sh_n[kDpThreads / 64];
   __shared__ int sh_c[kDpThreads / 64][3];
@@ -3019,6 +3014,29 @@ __global__ void __launch_bounds__(kDpThreads) depth_lm_persistent_kernel(DepthPe
     a.dbg[0] += c_gather; a.dbg[1] += c_decide; a.dbg[2] += c_eval; a.dbg[3] += c_sum; a.dbg[4] += c_it; a.dbg[5] += 1;
     a.dbg[6] += local ? 1 : 0; a.dbg[7] += __builtin_readcyclecounter() - c_begin;
   }
+}
+
+__global__ void __launch_bounds__(kDpThreads) depth_lm_persistent_kernel(DepthPersistArgs a) {
+  // Which eighth of the grid takes part: block class `cls` (blocks with blockIdx % 8 == cls land on one XCD: the dispatcher deals every
+  // grid round-robin from the same XCD). NOT the pose LM's class 0: on one XCD the two persistent launches cannot share a CU (416 +
+  // 160 VGPRs per SIMD), so whenever they overlapped in time one waited for the other's CUs, and when both were dispatched at the same
+  // moment each got part of the XCD and waited for workgroups that could not be placed (ODO_LOG_GIVEUPS: 76 of 80 workgroups entered
+  // together, the last four only when the first ones had given up — on XCC 6, the pose LM's, every time). home >= 0: by XCC id.
+  if (a.home >= 0 ? fine_xcc_id() != a.home : (int)(blockIdx.x & 7u) != a.cls) return;
+  depth_lm_persistent_body(a, (int)(blockIdx.x >> 3));
+}
+// Batched twin (odo_tracker_batch, up to four sequences): sequence j's 80 workgroups are block class (tab[0].cls + j) % 8 — an XCD of its
+// own beside the batched pose LM's, whose sequences sit on classes 0 .. 3 —, each with its own exchange buffer, epoch and give-up word.
+__global__ void __launch_bounds__(kDpThreads) depth_lm_persistent_batch_kernel(const DepthPersistArgs* __restrict__ tab, int n, XccIds xcc) {
+  int r = (int)(blockIdx.x & 7u);   // the XCD this block sits on, named as lm_fine_kernel_batch names it (XCC ids unknown: the block class)
+  if (xcc.id[0] >= 0) {
+    const int mine = fine_xcc_id();
+#pragma unroll
+    for (int c = 0; c < 8; c++) if (xcc.id[c] == mine) r = c;
+  }
+  const int j = (r - tab[0].cls) & 7;
+  if (j >= n) return;
+  depth_lm_persistent_body(tab[j], (int)(blockIdx.x >> 3));
 }
 
 // Write-back + filters (ref: src/depth_estimate.cpp:176-191) and per-block counts {valid, selected, matched}.

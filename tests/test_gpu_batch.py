@@ -527,3 +527,47 @@ def test_batched_persistent_launch_falls_back_without_changing_a_pose(api, kitti
         for a, b in zip(poses, ref[0]):
             assert np.array_equal(a, b)
     del p0, d0, curs
+
+
+@pytest.mark.parametrize("pairs", [False, True])
+def test_batched_depth_lm_in_one_persistent_launch_and_its_fallback(api, drives, pairs, monkeypatch):
+    """The lock step's inverse-depth LMs run in ONE persistent launch, every sequence on an XCD of its own
+    (depth_lm_persistent_batch_kernel; up to four sequences), instead of a launch per iteration: the separate trackers' poses, keyframe
+    decisions, statistics and depth outputs bit for bit (the parametrised test above covers the default); switched off
+    (ODO_BATCH_DEPTH_PERSIST=0) the same again; and with a pair that never appears (ODO_DEPTH_PERSIST_FAULT) every one of the first
+    three chains gives up within its wait bound, is run again on the launches per iteration, and the launch stays off afterwards —
+    nothing changes in the results."""
+    n_seq, n_frames = 3, 8
+    seqs = drives[:n_seq]
+    singles = [_track_single(api, s, n_frames) for s in seqs]
+
+    def run():
+        tb = api.TrackerBatch(n_seq, overlap_depth=2)
+        L = [[tb.upload_frame(f) for f in s["left"][:n_frames]] for s in seqs]
+        R = [[tb.upload_frame(f) for f in s["right"][:n_frames]] for s in seqs]
+        tb.init([L[i][0] for i in range(n_seq)], [R[i][0] for i in range(n_seq)])
+        for k in range(1, n_frames):
+            if pairs and k + 1 < n_frames:
+                tb.hint_next([L[i][k + 1] for i in range(n_seq)], [R[i][k + 1] for i in range(n_seq)])
+            res = tb.track([L[i][k] for i in range(n_seq)], [R[i][k] for i in range(n_seq)])
+            st = tb.stats()
+            for i in range(n_seq):
+                ref = singles[i][0][k - 1]
+                assert res[i]["status"] == 0
+                assert np.array_equal(res[i]["pose_to_keyframe"], ref["pose_to_keyframe"]), f"sequence {i} frame {k}"
+                assert res[i]["new_keyframe"] == ref["new_keyframe"] and st[i] == ref["stats"], f"sequence {i} frame {k}"
+        rows, cols = seqs[0]["left"][0].shape
+        for i in range(n_seq):
+            for a, b in zip(tb.outputs(i, rows, cols), singles[i][1]):
+                assert np.array_equal(a, b)
+        ps = tb.depth_persistent_stats()
+        tb.close()
+        return ps
+
+    assert run() == (1, 0)                       # on, no chain redone
+    monkeypatch.setenv("ODO_BATCH_DEPTH_PERSIST", "0")
+    assert run() == (0, 0)
+    monkeypatch.delenv("ODO_BATCH_DEPTH_PERSIST")
+    monkeypatch.setenv("ODO_DEPTH_PERSIST_FAULT", "1")
+    monkeypatch.setenv("ODO_DEPTH_WAIT_US", "300")
+    assert run() == (0, 3)                       # three chains gave up and were redone, then the launch stayed off

@@ -60,7 +60,9 @@ def main():
                       ("depth_disparity_kernel", "odo::depth_disparity_kernel"),
                       ("lm_dense_eval_kernel_1080p", "void odo::lm_dense_eval_kernel<256, 0, 4>"),
                       ("lm_dense_eval_batch_kernel", "void odo::lm_dense_eval_batch_kernel<256, 0, 4>"),
-                      ("depth_lm_persistent_kernel", "odo::depth_lm_persistent_kernel"), ("lm_fine_tdist_kernel", "odo::lm_fine_tdist_kernel")):
+                      ("depth_lm_persistent_kernel", "odo::depth_lm_persistent_kernel"), ("lm_fine_tdist_kernel", "odo::lm_fine_tdist_kernel"),
+                      ("lm_step_kernel", "odo::lm_step_kernel"), ("lm_fine_kernel_batch", "odo::lm_fine_kernel_batch"),
+                      ("lm_coarse_kernel_batch", "odo::lm_coarse_kernel_batch")):
         if kern in f and kern in w and key in d:
             n, a, b = fw(kern)
             d[key]["dispatches"], d[key]["FETCH_SIZE_KB_per_launch_raw"], d[key]["WRITE_SIZE_KB_per_launch"] = n, a, b

@@ -77,3 +77,40 @@ def test_scalar_and_avx2_forms_agree():
         assert p.returncode == 0, p.stderr[-1500:]
         outs.append(p.stdout.split())
     assert len(outs[0]) == 6 and outs[0] == outs[1]
+
+
+def test_scatter_rebuilds_the_three_output_images_from_the_point_slots():
+    """odo_host_scatter_outputs (host only): ComputeDepth's outputs handed over as {pixel index, disp, dep, val} per point slot are
+    rebuilt in caller memory — zero everywhere else, whatever the caller's buffers held, also through row pitches — and the returned
+    fingerprint is odo_host_fingerprint of the inverse-depth image that was written."""
+    import ctypes as C
+    from odometry_amd import _lib
+    lib = _lib.load()
+    rows, cols, slots = 376, 1241, 512 * 80
+    assert lib.odo_depth_compact_bytes() == slots * 13
+    rng = np.random.default_rng(7)
+    n = 23000
+    pix = rng.choice(rows * cols, n, replace=False).astype(np.uint32)
+    where = np.sort(rng.choice(slots, n, replace=False))
+    idx = np.full(slots, 0xFFFFFFFF, np.uint32)
+    idx[where] = pix
+    disp, dep = np.zeros(slots, np.float32), np.zeros(slots, np.float32)
+    disp[where] = rng.integers(1, 200, n).astype(np.float32)
+    dep[where] = rng.random(n).astype(np.float32)
+    val = np.zeros(slots, np.uint8)
+    val[where] = rng.integers(0, 2, n).astype(np.uint8)
+    compact = np.concatenate([idx.view(np.uint8), disp.view(np.uint8), dep.view(np.uint8), val])
+    want_v, want_d, want_p = np.zeros(rows * cols, np.uint8), np.zeros(rows * cols, np.float32), np.zeros(rows * cols, np.float32)
+    want_v[pix], want_d[pix], want_p[pix] = val[where], disp[where], dep[where]
+    for pad in (0, 5):
+        ov = np.full((rows, cols + pad), 9, np.uint8)
+        od = np.full((rows, cols + pad), -1.0, np.float32)
+        op = np.full((rows, cols + pad), -2.0, np.float32)
+        fp = C.c_ulonglong(0)
+        assert lib.odo_host_scatter_outputs(compact.ctypes.data, rows, cols, ov.ctypes.data, ov.strides[0], od.ctypes.data, od.strides[0],
+                                            op.ctypes.data, op.strides[0], C.byref(fp)) == 0
+        assert np.array_equal(ov[:, :cols].reshape(-1), want_v) and np.array_equal(od[:, :cols].reshape(-1), want_d)
+        assert np.array_equal(op[:, :cols].reshape(-1), want_p)
+        if pad:
+            assert (ov[:, cols:] == 9).all() and (od[:, cols:] == -1.0).all()          # nothing written beyond a row's pixels
+        assert fp.value == lib.odo_host_fingerprint(op.ctypes.data, op.strides[0], cols * 4, rows)

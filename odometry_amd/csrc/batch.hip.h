@@ -429,7 +429,8 @@ static int batch_chain_tail(odo_tracker_batch* b, BatchChain* c, hipStream_t s) 
 static bool batch_depth_persist_ok(const odo_tracker_batch* b, const BatchChain* c) {
   static const bool on = !getenv("ODO_BATCH_DEPTH_PERSIST") || atoi(getenv("ODO_BATCH_DEPTH_PERSIST")) != 0;
   const odo_depth* d0 = b->depth[0];
-  return on && !c->no_persist_once && b->depth_persist_strikes < 3 && (int)c->ids.size() <= 4 && d0->persist_cfg && d0->max_iters <= kDpMaxIters &&
+  static const int max_n = getenv("ODO_BATCH_DEPTH_PERSIST_MAX") ? atoi(getenv("ODO_BATCH_DEPTH_PERSIST_MAX")) : 4;
+  return on && !c->no_persist_once && b->depth_persist_strikes < 3 && (int)c->ids.size() <= max_n && (int)c->ids.size() <= 8 && d0->persist_cfg && d0->max_iters <= kDpMaxIters &&
          c->h_ptab && c->d_ptab;
 }
 static int batch_chain_persistent(odo_tracker_batch* b, BatchChain* c, hipStream_t s) {

@@ -114,3 +114,13 @@ def test_scatter_rebuilds_the_three_output_images_from_the_point_slots():
         if pad:
             assert (ov[:, cols:] == 9).all() and (od[:, cols:] == -1.0).all()          # nothing written beyond a row's pixels
         assert fp.value == lib.odo_host_fingerprint(op.ctypes.data, op.strides[0], cols * 4, rows)
+
+
+def test_fingerprint_code_is_clean_under_the_sanitizers(tmp_path):
+    """odometry_amd/csrc/host_fp.h on its own under -fsanitize=address,undefined (CPU build; GPU sanitizers are not available here):
+    every length 0 .. 5 000 and pitched images in exactly-sized heap blocks — no read or write past a caller's buffer, AVX2 = scalar."""
+    exe = str(tmp_path / "host_fp_harness")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           os.path.join(ROOT, "tests", "host_fp_harness.cpp"), "-o", exe])
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and p.stdout.strip().endswith("OK"), p.stdout[-1500:] + p.stderr[-3000:]

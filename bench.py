@@ -426,9 +426,10 @@ def shim_leg(api, seq, n_frames=100, passes=3):
                                  against tests/stubs: pageable cv::Mat, nothing reports writes — fingerprint-checked device mirrors),
                                  every frame preloaded in its own cv::Mat
     cv::Mat rows come three ways: outputs in host memory when ComputeDepth returns (the reference's contract; default),
-    ODOMETRY_SHIM_LAZY_OUTPUTS=1 (left_disp / left_dep stay on the device until odometry::Download), and the default again with glibc
-    told to keep the pages of the runner's per-frame output Mats (MALLOC_TRIM_THRESHOLD_ / MALLOC_MMAP_THRESHOLD_: three fresh Mats per
-    frame otherwise cost ~1 000 page faults per frame, in ComputeDepth's copy-out and in the Mats' destructors).
+    ODOMETRY_SHIM_LAZY_OUTPUTS=1 (left_disp / left_dep stay on the device until odometry::Download), and the default again with
+    ODOMETRY_SHIM_NO_MALLOPT=1: without the header's one-time mallopt() that tells glibc to keep the pages of the runner's per-frame
+    output Mats (three fresh Mats per frame otherwise cost ~1 000 page faults per frame, in ComputeDepth's copy-out and in the Mats'
+    destructors).
     pcie_inclusive: the same loop through the host-buffer entry points of the C ABI from Python (odo_pyramid_create /
     odo_depth_compute on pageable numpy arrays: every input staged and uploaded at every use, every output downloaded at once)."""
     import re
@@ -438,7 +439,7 @@ def shim_leg(api, seq, n_frames=100, passes=3):
     L, R = seq["left"][:n_frames], seq["right"][:n_frames]
     lib = ["-L" + os.path.join(ROOT, "odometry_amd", "lib"), "-lodometry_hip", "-Wl,-rpath," + os.path.join(ROOT, "odometry_amd", "lib")]
     src = os.path.join(ROOT, "examples", "run_odometry_synth.cpp")
-    keep_pages = {"MALLOC_TRIM_THRESHOLD_": "268435456", "MALLOC_MMAP_THRESHOLD_": "33554432", "MALLOC_TOP_PAD_": "67108864"}
+    no_mallopt = {"ODOMETRY_SHIM_NO_MALLOPT": "1"}
     with tempfile.TemporaryDirectory(dir="/tmp") as td:
         exe, exe_cv = os.path.join(td, "run_odometry_synth"), os.path.join(td, "run_odometry_synth_cv")
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), src, "-o", exe] + lib)
@@ -469,10 +470,10 @@ def shim_leg(api, seq, n_frames=100, passes=3):
                 ("standin_load_per_frame", exe, ["--load-per-frame"], None),
                 ("cvmat_preloaded", exe_cv, [], None),
                 ("cvmat_preloaded_lazy_outputs", exe_cv, [], {"ODOMETRY_SHIM_LAZY_OUTPUTS": "1"}),
-                ("cvmat_preloaded_malloc_keeps_pages", exe_cv, [], keep_pages),
+                ("cvmat_preloaded_default_allocator", exe_cv, [], no_mallopt),
                 ("cvmat_load_per_frame", exe_cv, ["--load-per-frame"], None),
                 ("cvmat_load_per_frame_lazy_outputs", exe_cv, ["--load-per-frame"], {"ODOMETRY_SHIM_LAZY_OUTPUTS": "1"}),
-                ("cvmat_load_per_frame_malloc_keeps_pages", exe_cv, ["--load-per-frame"], keep_pages)):
+                ("cvmat_load_per_frame_default_allocator", exe_cv, ["--load-per-frame"], no_mallopt)):
             try:
                 mm, r2, stats = run(binary, extra, env)
                 shapes[key] = dict(frames_per_s=float(mm.group(1)), poses_bit_identical_to_shim_path=bool(np.array_equal(r2, shim_rel)))
@@ -500,12 +501,12 @@ def shim_leg(api, seq, n_frames=100, passes=3):
     out["shim_path_load_per_frame"] = dict(
         standin=shapes.get("standin_load_per_frame"), cvmat=shapes.get("cvmat_load_per_frame"),
         cvmat_lazy_outputs=shapes.get("cvmat_load_per_frame_lazy_outputs"),
-        cvmat_malloc_keeps_pages=shapes.get("cvmat_load_per_frame_malloc_keeps_pages"),
+        cvmat_default_allocator=shapes.get("cvmat_load_per_frame_default_allocator"),
         what="the reference runner's frame source: gray[0] / gray[1] refilled inside the loop by convertTo from 8-bit images "
              "(run_odometry_kitti_offline.cpp:200,334-359 minus the PNG decoding); the load is inside the clock")
     out["shim_path_cvmat"] = dict(
         preloaded=shapes.get("cvmat_preloaded"), preloaded_lazy_outputs=shapes.get("cvmat_preloaded_lazy_outputs"),
-        preloaded_malloc_keeps_pages=shapes.get("cvmat_preloaded_malloc_keeps_pages"),
+        preloaded_default_allocator=shapes.get("cvmat_preloaded_default_allocator"),
         what="-DODOMETRY_SHIM_WITH_OPENCV -DODOMETRY_SHIM_WITH_EIGEN against tests/stubs, the loop of shim_path: every frame in its own "
              "pageable cv::Mat the classes have never seen (no stereo partner known before ComputeDepth names it: the depth job cannot "
              "run beside the Solve; the load-per-frame rows, where the same two Mats return every frame, can)")

@@ -42,6 +42,9 @@
 #if defined(__SSE2__)
 #include <emmintrin.h>
 #endif
+#if defined(ODOMETRY_SHIM_WITH_OPENCV) && defined(__GLIBC__)
+#include <malloc.h>
+#endif
 
 #ifndef PixelType
 #ifdef ODOMETRY_SHIM_WITH_OPENCV
@@ -674,6 +677,21 @@ namespace detail {
 inline odo_ctx* context() {
   static thread_local odo_ctx* ctx = nullptr;
   if (!ctx) {
+#if defined(ODOMETRY_SHIM_WITH_OPENCV) && defined(__GLIBC__)
+    // The runner allocates three fresh 0.5-1.9 MB cv::Mats per frame (ref: run_odometry_kitti_offline.cpp:226-228) and frees them at the
+    // end of the frame; with glibc's default trim / mmap thresholds every one of those buffers goes back to the kernel and comes back
+    // as fresh pages: ~1 000 page faults per frame (400 us at KITTI size), in ComputeDepth's copy-out and in the Mats' destructors.
+    // The header is compiled into the runner: once per process it tells the allocator to keep such blocks (what the environment
+    // variables MALLOC_TRIM_THRESHOLD_ / MALLOC_MMAP_THRESHOLD_ / MALLOC_TOP_PAD_ do). ODOMETRY_SHIM_NO_MALLOPT=1: leave it alone.
+    static const bool tuned = [] {
+      if (std::getenv("ODOMETRY_SHIM_NO_MALLOPT")) return false;
+      mallopt(M_MMAP_THRESHOLD, 32 << 20);
+      mallopt(M_TRIM_THRESHOLD, 256 << 20);
+      mallopt(M_TOP_PAD, 64 << 20);
+      return true;
+    }();
+    (void)tuned;
+#endif
     const char* dev = std::getenv("ODOMETRY_HIP_DEVICE");
     if (odo_ctx_create(dev ? std::atoi(dev) : 0, &ctx) != 0) {
       std::cout << "odometry_hip: " << odo_last_error() << std::endl;

@@ -28,15 +28,6 @@ run() {  # label, exe, extra args, env...
     echo -n "$label [$same] "; env "$@" $exe /tmp/frames_shapes.bin $extra --time $PASSES 2>&1 >/dev/null | grep -E "SHIM_FPS|SHIM_MISMATCH" | tr '\n' ' '; echo
   done
 }
-if [ "${QUICK:-0}" = "1" ]; then
-  M="MALLOC_TRIM_THRESHOLD_=268435456 MALLOC_MMAP_THRESHOLD_=33554432 MALLOC_TOP_PAD_=67108864"
-  for t in 1 4 1 4; do
-    run "cv load-per-frame, malloc keeps, threads $t" /tmp/ros_cv "--load-per-frame" ODO_HOST_THREADS=$t $M
-    run "cv load-per-frame, lazy, threads $t        " /tmp/ros_cv "--load-per-frame" ODO_HOST_THREADS=$t ODOMETRY_SHIM_LAZY_OUTPUTS=1
-    echo "== phases threads $t"; env $M ODO_HOST_THREADS=$t ODO_RUNNER_PHASES=1 /tmp/ros_cv /tmp/frames_shapes.bin --load-per-frame --time 1 2>&1 >/dev/null | grep -E "runner phases" | tail -1
-  done
-  exit 0
-fi
 run "stand-in preloaded           " /tmp/ros_std "" X=1
 run "stand-in load-per-frame      " /tmp/ros_std "--load-per-frame" X=1
 run "stand-in preloaded, no ahead " /tmp/ros_std "" ODOMETRY_SHIM_NO_LOOKAHEAD=1
@@ -44,14 +35,14 @@ run "cv::Mat preloaded            " /tmp/ros_cv "" X=1
 run "cv::Mat load-per-frame       " /tmp/ros_cv "--load-per-frame" X=1
 run "cv::Mat load-per-frame, lazy " /tmp/ros_cv "--load-per-frame" ODOMETRY_SHIM_LAZY_OUTPUTS=1
 run "cv::Mat preloaded, lazy      " /tmp/ros_cv "" ODOMETRY_SHIM_LAZY_OUTPUTS=1
-M="MALLOC_TRIM_THRESHOLD_=268435456 MALLOC_MMAP_THRESHOLD_=33554432 MALLOC_TOP_PAD_=67108864"   # the runner's per-frame Mats keep their pages
-run "cv::Mat load-per-frame, malloc keeps pages" /tmp/ros_cv "--load-per-frame" $M
-run "cv::Mat preloaded, malloc keeps pages     " /tmp/ros_cv "" $M
-run "cv::Mat load-per-frame, lazy, malloc keeps" /tmp/ros_cv "--load-per-frame" ODOMETRY_SHIM_LAZY_OUTPUTS=1 $M
+M="ODOMETRY_SHIM_NO_MALLOPT=1"   # glibc's default thresholds: the runner's per-frame Mats lose their pages every frame
+run "cv::Mat load-per-frame, default allocator " /tmp/ros_cv "--load-per-frame" $M
+run "cv::Mat preloaded, default allocator      " /tmp/ros_cv "" $M
+run "cv::Mat load-per-frame, lazy, default alloc" /tmp/ros_cv "--load-per-frame" ODOMETRY_SHIM_LAZY_OUTPUTS=1 $M
 run "cv::Mat load-per-frame, no ahead" /tmp/ros_cv "--load-per-frame" ODOMETRY_SHIM_NO_LOOKAHEAD=1
 run "cv::Mat load-per-frame, verify  " /tmp/ros_cv "--load-per-frame" ODOMETRY_SHIM_VERIFY_MIRRORS=1
-echo "== /tmp/ros_cv --load-per-frame, malloc keeps pages"; env $M ODO_RUNNER_PHASES=1 /tmp/ros_cv /tmp/frames_shapes.bin --load-per-frame --time 1 2>&1 >/dev/null | grep -E "runner phases|SHIM_STATS" | tail -2
-echo "== /tmp/ros_cv, malloc keeps pages"; env $M ODO_RUNNER_PHASES=1 /tmp/ros_cv /tmp/frames_shapes.bin --time 1 2>&1 >/dev/null | grep -E "runner phases|SHIM_STATS" | tail -2
+echo "== /tmp/ros_cv --load-per-frame, default allocator"; env $M ODO_RUNNER_PHASES=1 /tmp/ros_cv /tmp/frames_shapes.bin --load-per-frame --time 1 2>&1 >/dev/null | grep -E "runner phases|SHIM_STATS" | tail -2
+echo "== /tmp/ros_cv, default allocator"; env $M ODO_RUNNER_PHASES=1 /tmp/ros_cv /tmp/frames_shapes.bin --time 1 2>&1 >/dev/null | grep -E "runner phases|SHIM_STATS" | tail -2
 for exe in /tmp/ros_std /tmp/ros_cv; do
   for extra in "" "--load-per-frame"; do
     echo "== $exe $extra"; ODO_RUNNER_PHASES=1 $exe /tmp/frames_shapes.bin $extra --time 1 2>&1 >/dev/null | grep -E "runner phases|SHIM_STATS" | tail -3

@@ -189,6 +189,38 @@ def test_cv_mat_build_has_the_lookahead_and_detects_in_place_writes(tmp_path, mo
     assert cv("refill")[0] == base and cv("vector")[0] == base
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_walk_over_caller_behaviour_same_results_in_every_build(tmp_path, seed):
+    """tests/shim_fuzz_harness.cpp: 80 random operations a caller can perform on the classes' images — refill in place, small in-place
+    writes to images and to ComputeDepth's inverse-depth output, pyramids of Mats and of header copies, ComputeDepth with left and right
+    exchanged, into reused or fresh outputs, outputs handed back in, Solve + ComputeDepth + the :251-252 pyramids back to back. The
+    stand-in build with the look-ahead off (writes seen through ptr<T>(), nothing started ahead) defines the lines; the stand-in build
+    with the look-ahead on and the cv::Mat build (every decision rests on fingerprints; also with ODOMETRY_SHIM_VERIFY_MIRRORS and with
+    lazy outputs) must print the same."""
+    from odometry_amd import synth
+    seq = synth.make_sequence(6, seed=4)
+    frames = str(tmp_path / "frames.bin")
+    _write_frames(frames, seq["left"], seq["right"])
+    exes = {"std": _build(tmp_path, "tests/shim_fuzz_harness.cpp", "fuzz_std"), "cv": _build_cv(tmp_path, "tests/shim_fuzz_harness.cpp", "fuzz_cv")}
+
+    def run(which, **env):
+        out = subprocess.run([exes[which], frames, str(seed), "80"], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+        st = re.search(r"SHIM_STATS (.*)", out.stderr)
+        return out.stdout.strip().splitlines(), dict(zip(st.group(1).split()[0::2], map(int, st.group(1).split()[1::2])))
+
+    want, _ = run("std", ODOMETRY_SHIM_NO_LOOKAHEAD="1")
+    assert len(want) > 60 and sum("depth" in ln for ln in want) > 10 and sum("solve" in ln for ln in want) > 5
+    assert run("std")[0] == want
+    got, st = run("cv")
+    assert got == want, next((a, b) for a, b in zip(got, want) if a != b)
+    assert st["unchanged"] > 10 and st["changed"] > 5                      # mirrors were reused AND in-place writes were noticed
+    got, st = run("cv", ODOMETRY_SHIM_VERIFY_MIRRORS="1")
+    assert got == want and st["verify_failures"] == 0
+    assert run("cv", ODOMETRY_SHIM_LAZY_OUTPUTS="1")[0] == want
+    assert run("cv", ODOMETRY_SHIM_NO_LOOKAHEAD="1")[0] == want
+
+
 def test_runner_with_load_data_inside_the_loop(tmp_path):
     """examples/run_odometry_synth.cpp --load-per-frame — the two Mats of a frame refilled inside the loop by convertTo from 8-bit
     images, the reference runner's own frame source (run_odometry_kitti_offline.cpp:200,334-359) — in both builds: the poses of the

@@ -318,6 +318,17 @@ static inline dim3 batch_pyr_grid(const odo_tracker_batch* b, int n) {
   return dim3((b->p.cols + kPT - 1) / kPT, (b->p.rows + kPT - 1) / kPT, n);
 }
 
+// Keyframe-candidate point lists of every frame built AHEAD on the depth stream (13 us of chip time per frame; a frame that is then
+// promoted, one in eight, hands its lists over by a buffer swap), or built by the first Solve against a new keyframe (~60 us in front
+// of that lock step's launches)? Ahead while the lock step is latency-bound — up to four sequences: S = 4 9 470-9 520 frames/s
+// against 9 330-9 390 —, lazily once the chip is throughput-bound on the front end of that many frames: S = 8 13 290-13 420 ->
+// 14 000-14 180 (round 5). ODO_NO_CAND_LISTS=1 / ODO_CAND_LISTS=1 force one or the other. Results are the same either way.
+static bool batch_lists_ahead(int n_in_step) {
+  if (getenv("ODO_NO_CAND_LISTS")) return false;
+  if (getenv("ODO_CAND_LISTS")) return true;
+  return n_in_step <= 4;
+}
+
 // One pyramid-only launch: the image pyramids `dst[i]` of `src[i]` for the listed slots, on stream s, through table rows
 // [row0, row0 + n) of the pyramid table.
 static int batch_build_pyramids(odo_tracker_batch* b, const std::vector<int>& slots, const std::vector<const float*>& src,
@@ -633,7 +644,7 @@ static int batch_init_set(odo_tracker_batch* b, const float* const* left_dev, co
   const odo_tracker_params& p = b->p;
   const int n = (int)b->ids.size();
   if (n == 0) return 0;
-  b->with_lists = !getenv("ODO_NO_CAND_LISTS");
+  b->with_lists = batch_lists_ahead(n);
   for (int i : b->ids) {
     b->frame_id[i] = 0; b->alive[i] = 0; b->hint_next[i] = b->hint_next_right[i] = b->prefetched[i] = nullptr;
     b->res_left[i] = b->res_right[i] = nullptr;
@@ -738,7 +749,7 @@ extern "C" int odo_tracker_batch_track(odo_tracker_batch* b, const float* const*
     b->ids.push_back(i);
   }
   const int n = (int)b->ids.size();
-  b->with_lists = !getenv("ODO_NO_CAND_LISTS");
+  b->with_lists = batch_lists_ahead(n);
   hipStream_t sa = b->ctx_a->stream;
   hipStream_t sb = b->overlap ? b->ctx_b->stream : sa;
   hipStream_t sc = b->ctx_c->stream;

@@ -112,10 +112,13 @@ def _track_single(api, seq, n_frames):
     return out, maps
 
 
-@pytest.mark.parametrize("n_seq,overlap,pairs", [(1, 2, False), (3, 2, False), (3, 0, False), (3, 2, True), (1, 2, True), (3, 0, True)])
+@pytest.mark.parametrize("n_seq,overlap,pairs", [(1, 2, False), (3, 2, False), (3, 0, False), (3, 2, True), (1, 2, True), (3, 0, True),
+                                                 (6, 2, True), (6, 2, False)])
 def test_batched_tracker_is_bit_identical_to_separate_trackers(api, drives, n_seq, overlap, pairs):
+    """(more than four sequences: the keyframe-candidate lists are built by the first Solve against a new keyframe instead of ahead
+    for every frame, and the depth LMs run on a launch per iteration — batch_lists_ahead, batch_depth_persist_ok)"""
     n_frames = 11
-    seqs = drives[:n_seq]
+    seqs = [drives[i % len(drives)] for i in range(n_seq)]
     singles = [_track_single(api, s, n_frames) for s in seqs]
     assert any(r["new_keyframe"] for r in singles[0][0])          # the comparison covers a keyframe switch
     tb = api.TrackerBatch(n_seq, overlap_depth=overlap)

@@ -3,20 +3,24 @@
 hipcc cross-compiles without a GPU. Flags that matter for parity:
   -ffp-contract=off                          every fp32 op rounds once (arithmetic spec)
   -fhip-fp32-correctly-rounded-divide-sqrt   IEEE fp32 divide / sqrt on the device
+and one that matters for speed:
+  -fno-slp-vectorize                         no packed fp32 (v_pk_mul_f32 / v_pk_add_f32 issue at 8 cycles against 3 for the scalar
+                                             forms on gfx950, tools/microbench/valu_rates.hip, and need their operands in register
+                                             pairs): lm_fine_kernel 208 -> 168 VGPRs, the pose-LM chain 4 % shorter (round 5)
 """
 import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "odometry_hip.hip")
-SRC_DENSE = os.path.join(_HERE, "csrc", "dense_kernels.hip")   # compiled with -fno-slp-vectorize (see dense.hip.h)
+SRC_DENSE = os.path.join(_HERE, "csrc", "dense_kernels.hip")   # its own translation unit (see dense.hip.h)
 DEPS = [SRC, SRC_DENSE, os.path.join(_HERE, "csrc", "kernels.hip.h"), os.path.join(_HERE, "csrc", "odo_math.h"), os.path.join(_HERE, "csrc", "tracker.hip.h"), os.path.join(_HERE, "csrc", "batch.hip.h"), os.path.join(_HERE, "csrc", "gather.hip.h"), os.path.join(_HERE, "csrc", "camera.hip.h"),
         os.path.join(_HERE, "csrc", "dense.hip.h"), os.path.join(_HERE, "csrc", "host_fp.h"),
-        os.path.join(os.path.dirname(_HERE), "include", "odometry_hip.h")]
+        os.path.join(os.path.dirname(_HERE), "include", "odometry_hip.h"), os.path.abspath(__file__)]   # (this file: the flags)
 LIB = os.path.join(_HERE, "lib", "libodometry_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC"] + os.environ.get("ODO_EXTRA_HIPCC_FLAGS", "").split()   # A/B builds
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize", "-fPIC"] + os.environ.get("ODO_EXTRA_HIPCC_FLAGS", "").split()   # A/B builds
 
 
 def needs_build():
@@ -34,7 +38,7 @@ def build(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     o_main, o_dense = os.path.join(objdir, "odometry_hip.o"), os.path.join(objdir, "dense_kernels.o")
     cmds = [[HIPCC] + FLAGS + ["-c", "-o", o_main, SRC],
-            [HIPCC] + FLAGS + ["-fno-slp-vectorize", "-c", "-o", o_dense, SRC_DENSE],
+            [HIPCC] + FLAGS + ["-c", "-o", o_dense, SRC_DENSE],
             [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, o_main, o_dense]]
     procs = []
     for cmd in cmds[:2]:   # the two translation units compile side by side

@@ -13,10 +13,10 @@
 #include <string.h>
 #include "odo_math.h"
 
-// The kernels below are compiled in a translation unit of their own (dense_kernels.hip, -fno-slp-vectorize: hipcc's SLP
-// vectoriser turns pairs of fp32 operations into v_pk_mul_f32 / v_pk_fma_f32, measured at ~9.5 cycles per wave-instruction
-// against ~3.3 for a scalar fp32 operation — tools/microbench/valu_rates.hip); everything else sees only the level
-// description, its host-side helpers and the launcher declared at the end.
+// The kernels below are compiled in a translation unit of their own (dense_kernels.hip; round 2 gave it -fno-slp-vectorize: hipcc's
+// SLP vectoriser turns pairs of fp32 operations into v_pk_mul_f32 / v_pk_fma_f32, measured at ~9.5 cycles per wave-instruction
+// against ~3.3 for a scalar fp32 operation — tools/microbench/valu_rates.hip; since round 5 the whole library is built that
+// way); everything else sees only the level description, its host-side helpers and the launcher declared at the end.
 namespace odo {
 
 #ifdef ODO_DENSE_KERNELS

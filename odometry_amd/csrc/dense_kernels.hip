@@ -1,5 +1,5 @@
-// dense_kernels.hip — the dense-level evaluation kernels (dense.hip.h) as a translation unit of their own, compiled with
-// -fno-slp-vectorize (see dense.hip.h), plus their host-side launcher.
+// dense_kernels.hip — the dense-level evaluation kernels (dense.hip.h) as a translation unit of their own (compiles beside the
+// main one; see dense.hip.h), plus their host-side launcher.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #define ODO_DENSE_KERNELS 1

@@ -2464,7 +2464,8 @@ __global__ void __launch_bounds__(kSelThreads) depth_select_kernel(const float* 
 // candidate + ~150 per point = 7 M wave-instructions, ~13 us on 1 024 SIMDs at the measured 4 cycles each —, which the wave-per-slot
 // grid spreads evenly and a row-wise grid does not. (An LDS work counter fetched by `if (lane == 0) atomicAdd` in front of
 // readfirstlane made hipcc 7.2 build a loop that never ended; fetched by all lanes it cost 75 us.) -fno-slp-vectorize (the packed
-// v_pk_add / v_pk_mul_f32 the compiler picks here issue at 8 cycles against 3 + 3): 2 %.
+// v_pk_add / v_pk_mul_f32 the compiler picks here issue at 8 cycles against 3 + 3): 2 % here — and 4 % of the pose-LM chain, which is
+// why the whole library is built with it (build.py).
 struct __attribute__((packed, aligned(4))) ScanF4 { float v[4]; };
 struct __attribute__((packed, aligned(4))) ScanF2 { float v[2]; };
 template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {

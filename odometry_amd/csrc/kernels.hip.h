@@ -651,6 +651,10 @@ __device__ __forceinline__ void solve_damped_wave_regs(const double* acc, float 
       const double prow = __shfl(a, c * 8 + j, 64);
       const double mycol = __shfl(a, (i < 6 ? i : 5) * 8 + c, 64);
       if (in && i > c && j >= c) {
+        // (Round 5, measured and dropped: the division spelled out as the compiler's own sequence — v_div_scale, v_rcp_f64, two
+        //  Newton steps, v_div_fmas, v_div_fixup — with the pivot's refined reciprocal computed under the latency of the two
+        //  gathers and used whenever v_div_scale scales nothing: bit-identical, five dependent fp64 operations off the chain per
+        //  column, and 2 % SLOWER over the whole frame, 3 485 -> 3 408 frames/s.)
         const double f = mycol / piv;
         a = a - f * prow;
       }
@@ -1146,6 +1150,170 @@ __device__ __forceinline__ void lm_state_machine(bool pending, const StepLevel* 
   __syncthreads();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same state machine for the kernels that run MANY evaluations per launch (lm_coarse_kernel, lm_fine_kernel): wave 0 keeps the
+// part of the state an evaluation reads and writes in registers from one evaluation to the next (LmHot, wave-uniform) instead of
+// copying all 64 dwords out of LDS and back every time, and only what the other waves read goes to LDS per evaluation: T, level,
+// active, status, finished. Same operations on the same values as lm_decide / solve_damped / lm_apply_step / lm_begin_level:
+//   * `last` is not carried: every path through :131-143 leaves last == cur (accept: last = cur = inc; reject: cur = last), so the
+//     reject branch copies nothing and lm_hot_store writes cur into both;
+//   * cur.matrix() — the C of se3_left_update, :153 — is not recomputed from the quaternion every evaluation: it IS the T of the
+//     evaluation in which cur was the candidate (se3_to_colmajor of the same seven floats), taken over on accept (Tc); a level's
+//     first T = matrix(inc = cur) is Tc as well (:115).
+// Round 5: the single wave that runs this issues one instruction per >= 4 cycles whatever its EXEC mask
+// (tools/microbench/exec_mask_rates.hip), so the state machine's time is its instruction count.
+// ---------------------------------------------------------------------------------------------------------------
+struct LmHot {
+  Se3 cur, inc;
+  float Tc[12];   // cur.matrix(): rows 0..2 of columns 0..3 (column-major, as in LmState::T without its constant bottom row)
+  float lambda, err_last;
+  int level, iter, max_iters, active, status, finished, n_evals, stop_reason;
+};
+__device__ __forceinline__ void lm_hot_load(LmHot& h, const LmState& s) {   // wave 0, every lane
+  h.cur = s.cur; h.inc = s.inc;
+  float M[16];
+  se3_to_colmajor(s.cur, M);
+#pragma unroll
+  for (int c = 0; c < 4; c++)
+#pragma unroll
+    for (int r = 0; r < 3; r++) h.Tc[c * 3 + r] = M[c * 4 + r];
+  h.lambda = s.lambda; h.err_last = s.err_last;
+  h.level = s.level; h.iter = s.iter; h.max_iters = s.max_iters; h.active = s.active; h.status = s.status; h.finished = s.finished;
+  h.n_evals = s.n_evals; h.stop_reason = s.stop_reason;
+}
+__device__ __forceinline__ void lm_hot_store(const LmHot& h, LmState& s) {  // one lane
+  s.cur = h.cur; s.inc = h.inc; s.last = h.cur;
+  s.lambda = h.lambda; s.err_last = h.err_last;
+  s.level = h.level; s.iter = h.iter; s.max_iters = h.max_iters; s.active = h.active; s.status = h.status; s.finished = h.finished;
+  s.n_evals = h.n_evals; s.stop_reason = h.stop_reason;
+  s.pending = 0;
+}
+// All threads of the block call it (it ends with a block barrier); acc_sh holds the 29 sums of the evaluation at s_sh.T.
+__device__ __forceinline__ void lm_state_machine_hot(LmHot& h, const StepLevel* lv, int n_levels, float lambda0, float precision,
+                                                     LmState& s_sh, const double* acc_sh, LmTraceRow* __restrict__ trace,
+                                                     float* __restrict__ cost_stat, bool publisher,
+                                                     unsigned long long* smdbg = nullptr, int stop_level = 0) {
+  const int t = threadIdx.x;
+  if (t < 64) {
+    unsigned long long c0 = smdbg ? __builtin_readcyclecounter() : 0, c1 = c0, c2 = c0, c3 = c0;
+    const int iter0 = h.iter, lvl0 = h.level;
+    const float err_last0 = h.err_last;
+    // the T of the evaluation being consumed = matrix(inc): cur's on accept (read ahead of the decision: one LDS trip beside the sums')
+    float Tprev[12];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+      for (int r = 0; r < 3; r++) Tprev[c * 3 + r] = s_sh.T[c * 4 + r];
+    // ---- lm_decide (odo_math.h; ref: src/lm_optimizer.cpp:123-143) ----
+    h.n_evals++;
+    if (t == 0) s_sh.iters_level[lvl0 & 7] += 1;
+    bool need_step = false;
+    float err_now = 0.0f;
+    bool have_err = false;
+    if (!(acc_sh[28] > 0.0)) {                           // :244-248 -> :123-126
+      h.status = -1;
+      h.active = 0;
+    } else {
+      err_now = (float)(acc_sh[27] / acc_sh[28]);        // :129
+      have_err = true;
+      if (err_now > h.err_last) {                        // :131
+        h.lambda = h.lambda * 5.0f;
+        if (h.lambda > 1e+5f) { h.active = 0; h.stop_reason = 2; }
+        else need_step = true;                           // (cur = last: they are equal)
+      } else {
+        h.cur = h.inc;                                   // (and last = cur)
+#pragma unroll
+        for (int i = 0; i < 12; i++) h.Tc[i] = Tprev[i];
+        const float err_diff = err_now / h.err_last;
+        if (err_diff > precision) { h.active = 0; h.stop_reason = 1; }
+        else {
+          h.err_last = err_now;
+          h.lambda = fmaxf(h.lambda / 5.0f, 1e-5f);
+          need_step = true;
+        }
+      }
+    }
+    if (smdbg) { c1 = __builtin_readcyclecounter(); c2 = c1; c3 = c1; }
+    float d[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    bool new_T = false;
+    float Tn[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) Tn[i] = 0.0f;
+    if (need_step) {
+      solve_damped_wave_regs(acc_sh, h.lambda, d);       // :145-151
+      if (smdbg) { asm volatile("" ::"v"(d[0]), "v"(d[5])); c2 = __builtin_readcyclecounter(); }
+      Se3 dd;
+      se3_exp_wave(d, &dd);                              // :152
+      const float C[16] = {h.Tc[0], h.Tc[1], h.Tc[2], 0.0f, h.Tc[3], h.Tc[4], h.Tc[5], 0.0f,
+                           h.Tc[6], h.Tc[7], h.Tc[8], 0.0f, h.Tc[9], h.Tc[10], h.Tc[11], 1.0f};
+      se3_left_update_mat(dd, C, &h.inc);                // :153
+      se3_to_colmajor(h.inc, Tn);
+      new_T = true;
+      h.iter++;                                          // :154
+      if (!(h.max_iters > h.iter)) { h.active = 0; h.stop_reason = 3; }
+      if (smdbg) { asm volatile("" ::"v"(Tn[0]), "v"(Tn[14])); c3 = __builtin_readcyclecounter(); }
+    }
+    if (smdbg && t == 0) { smdbg[0] += c1 - c0; smdbg[1] += c2 - c1; smdbg[2] += c3 - c2; smdbg[3] += 1; }
+    if (t == 0) {
+      if (have_err) s_sh.err_now = err_now;
+      if (need_step) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) s_sh.delta[i] = d[i];
+      }
+    }
+    if (publisher && t == 0 && trace) {   // (see lm_state_machine)
+      const int ev = h.n_evals - 1;
+      const float e = s_sh.err_now;
+      if (ev < kTraceCap) {
+        LmTraceRow& r = trace[ev];
+        r.level = lvl0;
+        r.iter = iter0;
+        r.n_res = (int)acc_sh[28];
+        r.err = e;
+        r.accepted = (h.status == 0 && !(e > err_last0)) ? 1 : 0;
+        r.stop = (h.stop_reason == 3 || h.active) ? 0 : h.stop_reason;
+        r.lambda_after = h.lambda;
+#pragma unroll
+        for (int i = 0; i < 6; i++) r.delta[i] = (h.active || h.stop_reason == 3) ? d[i] : 0.0f;
+      }
+      const int evals_this_level = s_sh.iters_level[lvl0 & 7];
+      if (iter0 == 0 && evals_this_level == 1) cost_stat[lvl0 * 2 + 0] = e;
+      cost_stat[lvl0 * 2 + 1] = e;
+    }
+    if (lv) {
+      while (!h.active && h.status == 0 && !h.finished) {
+        const int next = (h.level < 0) ? n_levels - 1 : h.level - 1;
+        if (next < stop_level) { h.finished = 1; break; }
+        h.stop_reason = 0;
+        // lm_begin_level (ref: src/lm_optimizer.cpp:110-115)
+        h.level = next;
+        h.iter = 0;
+        h.err_last = 1e+10f;
+        h.lambda = lambda0;
+        h.inc = h.cur;
+        h.max_iters = lv[next].max_iters;
+        h.active = (h.status == 0 && h.max_iters > 0) ? 1 : 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+#pragma unroll
+          for (int r = 0; r < 3; r++) Tn[c * 4 + r] = h.Tc[c * 3 + r];
+          Tn[c * 4 + 3] = (c == 3) ? 1.0f : 0.0f;
+        }
+        new_T = true;
+      }
+      if (h.status != 0) h.finished = 1;
+    }
+    if (t == 0) {   // what the other waves read
+      if (new_T) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) s_sh.T[i] = Tn[i];
+      }
+      s_sh.level = h.level; s_sh.active = h.active; s_sh.status = h.status; s_sh.finished = h.finished;
+    }
+  }
+  __syncthreads();
+}
+
 // Sums the per-block partials in a fixed order and advances the LM state machine by one evaluation
 // (accept / reject, damped 6x6 solve, exp, left-compose; ref: src/lm_optimizer.cpp:129-154). One workgroup:
 // all threads fold the partials, wave 0 runs lm_state_machine.
@@ -1523,6 +1691,8 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
   // state in (or initialised), a pending evaluation of an earlier launch consumed, pyramid walk started
   lm_fused_prologue(q.st_in, q.part_in, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, red_sh, acc_sh, a.trace, a.cost_stat, true,
                     q.first_of_solve ? a.init : nullptr, a.stop_level, a.chain_in_token ? a.chain_pose : nullptr);
+  LmHot hot;                    // wave 0's copy of the state between evaluations (lm_state_machine_hot; the other waves never look at theirs)
+  lm_hot_load(hot, s_sh);
   if (a.dbg && threadIdx.x == 0 && q.seq < 56) a.dbg[16 + 2 * q.seq] = wall_clock64();
   unsigned long long c_eval = 0, c_red = 0, c_sm = 0, c_it = 0, c_last = a.dbg ? __builtin_readcyclecounter() : 0;
   const unsigned long long c_begin = c_last;
@@ -1641,10 +1811,11 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
       //  a wave's LDS accesses stay in order; the other waves wait at the state machine's closing barrier)
     }
     lap(c_red);
-    lm_state_machine(true, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, acc_sh, a.trace, a.cost_stat, true,
-                     a.dbg ? a.dbg + 8 : nullptr, a.stop_level);
+    lm_state_machine_hot(hot, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, acc_sh, a.trace, a.cost_stat, true,
+                         a.dbg ? a.dbg + 8 : nullptr, a.stop_level);
     lap(c_sm);
   }
+  if (threadIdx.x == 0) lm_hot_store(hot, s_sh);   // (read back by wave 0 only, below: a wave's LDS accesses stay in order)
   lm_fused_publish(s_sh, q.st_out, a.host_prog, q.seq, a.token, a.cost_stat, a.out, a.done_flag, a.final_state, chain_out_of(a));
   if (a.dbg && threadIdx.x == 0) {
     if (q.seq < 56) a.dbg[16 + 2 * q.seq + 1] = wall_clock64();
@@ -1969,6 +2140,8 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
   // state in (left by the coarse launch, or initialised), a pending evaluation of an earlier launch consumed, pyramid walk started
   lm_fused_prologue(q.st_in, q.part_in, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, fold_sh, acc_sh, a.trace, a.cost_stat,
                     publisher, q.first_of_solve ? a.init : nullptr, a.stop_level, a.chain_in_token ? a.chain_pose : nullptr);
+  LmHot hot;                    // wave 0's copy of the state between evaluations (lm_state_machine_hot)
+  lm_hot_load(hot, s_sh);
   // does every workgroup of this launch share my XCD? (wave 0, lane i asks about workgroup i; the answer is the same everywhere)
   if (t < 64) {
     bool same = true, got = false;
@@ -2121,10 +2294,11 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
     lap(c_xchg);
     if (bail_sh) break;
     // ---- (d): the state machine, every workgroup for itself ----
-    lm_state_machine(true, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, acc_sh, a.trace, a.cost_stat, publisher, nullptr,
-                     a.stop_level);
+    lm_state_machine_hot(hot, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, acc_sh, a.trace, a.cost_stat, publisher, nullptr,
+                         a.stop_level);
     lap(c_sm);
   }
+  if (t == 0) lm_hot_store(hot, s_sh);
   if (bail_sh && t == 0) { s_sh.status = -2; s_sh.active = 0; s_sh.finished = 1; }   // -2: gave up waiting (the host redoes the Solve)
   __syncthreads();
   if (publisher) {

@@ -379,15 +379,21 @@ ODO_HD void se3_exp(const float a[6], Se3* o) {
 }
 
 // inc = SE3(delta.matrix() * cur.matrix()) (lm_optimizer.cpp:152-153): plain 4x4 fp32 product, k ascending.
-ODO_HD void se3_left_update(const Se3& delta, const Se3& cur, Se3* out) {
-  float D[16], C[16], M[16];
+// se3_left_update_mat: the same with cur.matrix() handed in (C, column-major, as se3_to_colmajor writes it) — the persistent LM
+// kernels keep the matrix of the current estimate from the time it was computed as the candidate's (lm_state_machine_hot).
+ODO_HD void se3_left_update_mat(const Se3& delta, const float C[16], Se3* out) {
+  float D[16], M[16];
   se3_to_colmajor(delta, D);
-  se3_to_colmajor(cur, C);
   for (int i = 0; i < 4; i++)
     for (int j = 0; j < 4; j++)
       M[j * 4 + i] = ((D[0 * 4 + i] * C[j * 4 + 0] + D[1 * 4 + i] * C[j * 4 + 1]) + D[2 * 4 + i] * C[j * 4 + 2]) +
                      D[3 * 4 + i] * C[j * 4 + 3];
   se3_from_colmajor(M, out);
+}
+ODO_HD void se3_left_update(const Se3& delta, const Se3& cur, Se3* out) {
+  float C[16];
+  se3_to_colmajor(cur, C);
+  se3_left_update_mat(delta, C, out);
 }
 
 // Damped normal equations A = JtWJ + lambda*diag(JtWJ), b = -JtWr (lm_optimizer.cpp:145-151), solved in fp64

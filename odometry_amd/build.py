@@ -7,6 +7,12 @@ and one that matters for speed:
   -fno-slp-vectorize                         no packed fp32 (v_pk_mul_f32 / v_pk_add_f32 issue at 8 cycles against 3 for the scalar
                                              forms on gfx950, tools/microbench/valu_rates.hip, and need their operands in register
                                              pairs): lm_fine_kernel 208 -> 168 VGPRs, the pose-LM chain 4 % shorter (round 5)
+  -mllvm -amdgpu-sched-strategy=iterative-ilp
+                                             the LM state machine is ONE wave working through ~1 200 dependent instructions per
+                                             evaluation: the ILP-first list scheduler orders them 3.5 % faster over the whole frame than
+                                             the default occupancy-first one (3 465 -> 3 595 frames/s over 199 steps; max-ilp: - 0.5 %,
+                                             iterative-minreg: - 2 %, iterative-maxocc: + 1.3 %, -O2: +- 0; tools/ab_lib.sh). Batched
+                                             tracker: S = 2 + 1 %, S = 4 - 1.8 %, S = 8 - 0.6 % (lm_fine_kernel_batch 208 -> 229 VGPRs)
 """
 import os
 import subprocess
@@ -20,7 +26,7 @@ DEPS = [SRC, SRC_DENSE, os.path.join(_HERE, "csrc", "kernels.hip.h"), os.path.jo
 LIB = os.path.join(_HERE, "lib", "libodometry_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize", "-fPIC"] + os.environ.get("ODO_EXTRA_HIPCC_FLAGS", "").split()   # A/B builds
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-fPIC"] + os.environ.get("ODO_EXTRA_HIPCC_FLAGS", "").split()   # A/B builds
 
 
 def needs_build():

@@ -425,7 +425,9 @@ def shim_leg(api, seq, n_frames=100, passes=3):
       shim_path_cvmat            the build INTEGRATION.md prescribes (-DODOMETRY_SHIM_WITH_OPENCV -DODOMETRY_SHIM_WITH_EIGEN, here
                                  against tests/stubs: pageable cv::Mat, nothing reports writes — fingerprint-checked device mirrors),
                                  every frame preloaded in its own cv::Mat
-    cv::Mat rows come three ways: outputs in host memory when ComputeDepth returns (the reference's contract; default),
+    cv::Mat rows come four ways: outputs in host memory when ComputeDepth returns (the reference's contract; default: built while Solve
+    waits and handed over by header assignment where the caller's output Mat is the caller's alone), the same written into the
+    caller's buffers always (ODOMETRY_SHIM_KEEP_OUTPUT_BUFFERS=1),
     ODOMETRY_SHIM_LAZY_OUTPUTS=1 (left_disp / left_dep stay on the device until odometry::Download), and the default again with
     ODOMETRY_SHIM_NO_MALLOPT=1: without the header's one-time mallopt() that tells glibc to keep the pages of the runner's per-frame
     output Mats (three fresh Mats per frame otherwise cost ~1 000 page faults per frame, in ComputeDepth's copy-out and in the Mats'
@@ -472,6 +474,7 @@ def shim_leg(api, seq, n_frames=100, passes=3):
                 ("cvmat_preloaded_lazy_outputs", exe_cv, [], {"ODOMETRY_SHIM_LAZY_OUTPUTS": "1"}),
                 ("cvmat_preloaded_default_allocator", exe_cv, [], no_mallopt),
                 ("cvmat_load_per_frame", exe_cv, ["--load-per-frame"], None),
+                ("cvmat_load_per_frame_outputs_in_place", exe_cv, ["--load-per-frame"], {"ODOMETRY_SHIM_KEEP_OUTPUT_BUFFERS": "1"}),
                 ("cvmat_load_per_frame_lazy_outputs", exe_cv, ["--load-per-frame"], {"ODOMETRY_SHIM_LAZY_OUTPUTS": "1"}),
                 ("cvmat_load_per_frame_default_allocator", exe_cv, ["--load-per-frame"], no_mallopt)):
             try:
@@ -482,6 +485,7 @@ def shim_leg(api, seq, n_frames=100, passes=3):
                     shapes[key]["image_uploads_per_frame"] = round(stats["uploads"] / n_tracked, 2)
                     shapes[key]["fingerprint_passes_per_frame"] = round(stats["fingerprints"] / n_tracked, 2)
                     shapes[key]["depth_jobs_started_ahead_and_adopted"] = stats.get("early_adopted", 0)
+                    shapes[key]["output_sets_built_while_solve_waited"] = stats.get("outputs_prepared", 0)
                     shapes[key]["mirror_verify_failures"] = stats.get("verify_failures", 0)
             except Exception as e:   # noqa: BLE001
                 shapes[key] = dict(error=f"{type(e).__name__}: {e}"[:300])
@@ -500,6 +504,7 @@ def shim_leg(api, seq, n_frames=100, passes=3):
 
     out["shim_path_load_per_frame"] = dict(
         standin=shapes.get("standin_load_per_frame"), cvmat=shapes.get("cvmat_load_per_frame"),
+        cvmat_outputs_in_place=shapes.get("cvmat_load_per_frame_outputs_in_place"),
         cvmat_lazy_outputs=shapes.get("cvmat_load_per_frame_lazy_outputs"),
         cvmat_default_allocator=shapes.get("cvmat_load_per_frame_default_allocator"),
         what="the reference runner's frame source: gray[0] / gray[1] refilled inside the loop by convertTo from 8-bit images "
@@ -1278,7 +1283,7 @@ def main():
         if fine:
             roof[fine_key] = dict(launches_per_frame=round(step_launches / n_frames_ev, 2), launch_us=round(step_span, 2),
                                   exec_span_us=round(step_span, 2),
-                                  what="every evaluation of the levels the coarse launch leaves, in one persistent launch: 32 workgroups "
+                                  what="every evaluation of the levels the coarse launch leaves, in one persistent launch: 30 workgroups (32 where a level of 61-64 or 121-128 virtual blocks would need another pass) "
                                        "of one XCD exchange their partial rows through L2 (DESIGN.md section 5.1); us per evaluation = "
                                        "(coarse + fine) exec spans / evaluations_per_frame",
                                   us_per_evaluation_both_kernels=round(kernel_us_per_frame / max(ev["active_launches"] / n_frames_ev, 1e-9), 2))

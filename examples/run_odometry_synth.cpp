@@ -104,8 +104,9 @@ int main(int argc, char** argv) {
     }
     std::fprintf(stderr, "SHIM_FPS %.1f FRAMES %zu PASSES %d\n", (double)(n - 1) * passes / secs, (n - 1) * (size_t)passes, passes);
     const ShimStats& st = shim_stats();
-    std::fprintf(stderr, "SHIM_STATS uploads %lu fingerprints %lu unchanged %lu changed %lu early_adopted %lu early_dropped %lu delivered %lu verify_failures %lu\n",
-                 st.uploads, st.fingerprints, st.unchanged, st.changed, st.early_adopted, st.early_dropped, st.delivered, st.verify_failures);
+    std::fprintf(stderr, "SHIM_STATS uploads %lu fingerprints %lu unchanged %lu changed %lu early_adopted %lu early_dropped %lu delivered %lu outputs_prepared %lu verify_failures %lu\n",
+                 st.uploads, st.fingerprints, st.unchanged, st.changed, st.early_adopted, st.early_dropped, st.delivered, st.outputs_prepared,
+                 st.verify_failures);
     std::cout.rdbuf(keep);
   }
   return 0;

@@ -93,6 +93,8 @@ unsigned long odo_ctx_mark(odo_ctx* ctx);
 int odo_ctx_stream_wait_mark(odo_ctx* waiter, odo_ctx* signaller, unsigned long mark);
 /* Host waits until `ctx`'s stream has passed `mark` (odo_ctx_mark). */
 int odo_ctx_wait_mark(odo_ctx* ctx, unsigned long mark);
+/* Has the stream passed that mark? 1 yes, 0 not yet (never blocks), -1 on error. */
+int odo_ctx_mark_reached(odo_ctx* ctx, unsigned long mark);
 /* Images in host memory the library cannot watch — a cv::Mat (ref: run_odometry_kitti_offline.cpp:200,334-359 refills the same two
  * Mats every frame; the classes of include/odometry_shim.hpp see them three times per frame, :205 / :229 / :251). A device mirror
  * of such an image may be reused only if the bytes are still the ones that were uploaded:
@@ -152,6 +154,11 @@ int odo_lm_solve(odo_lm* lm, const odo_pyr* kf_img, const odo_pyr* kf_dep, const
  * other pyramids, abandons it. Returns 0 started, 1 nothing started (this Solve does not use the fused pipeline), -1 error.
  * While a started Solve is in flight the optimiser's trace / report of the previous Solve are being overwritten. */
 int odo_lm_solve_begin(odo_lm* lm, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img);
+/* Host work for the time a Solve leaves the calling thread idle (ref: src/lm_optimizer.cpp:73-160 keeps the CPU busy for the whole
+ * Solve; here the thread inside odo_lm_solve spins on the device's completion word for ~0.25 ms): `fn(arg)` is called over and over
+ * from that wait loop, on the caller's thread, until the result is there — keep each call short (~10 us: the result is noticed between
+ * calls). NULL removes it. Not for an optimiser owned by odo_tracker / odo_tracker_batch (they feed their depth stream from there). */
+int odo_lm_set_idle_callback(odo_lm* lm, void (*fn)(void*), void* arg);
 /* Keyframe-candidate point lists built ahead of the Solve that may need them (the point lists are what the validity test of
  * ComputeResidualJacobianNaive selects, ref: src/lm_optimizer.cpp:190-198; the runner promotes a frame to keyframe AFTER its Solve,
  * run_odometry_kitti_offline.cpp:258-260, so the first Solve against a new keyframe would build them in front of its first launch):
@@ -320,6 +327,10 @@ int odo_depth_compact_outputs_async(odo_depth* d, odo_ctx* on, const uint8_t* va
                                     void* dst_pinned);
 int odo_host_scatter_outputs(const void* compact, int rows, int cols, uint8_t* val, size_t val_pitch, float* disp, size_t disp_pitch,
                              float* dep, size_t dep_pitch, unsigned long long* dep_fingerprint);
+/* The same into images the caller has ALREADY zero-filled (the fill needs nothing from the device: a caller with idle time before the
+ * compact block arrives does it then, odo_lm_set_idle_callback). */
+int odo_host_scatter_outputs_prezeroed(const void* compact, int rows, int cols, uint8_t* val, size_t val_pitch, float* disp,
+                                       size_t disp_pitch, float* dep, size_t dep_pitch, unsigned long long* dep_fingerprint);
 /* Disparity stage only (DisparityDepthEstimate, ref: src/depth_estimate.cpp:244-401). */
 int odo_depth_disparity(odo_depth* d, const float* left, const float* right, int rows, int cols, uint8_t* val,
                         float* disp, float* dep);

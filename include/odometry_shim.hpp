@@ -90,6 +90,7 @@ struct ShimStats {
   unsigned long early_adopted = 0;    // ComputeDepth calls that found their job started ahead
   unsigned long early_dropped = 0;    // jobs started ahead for images that then did not come (or had changed)
   unsigned long delivered = 0;        // output images copied into host memory
+  unsigned long outputs_prepared = 0; // ComputeDepth calls whose output images had been built while Solve waited (cv::Mat build)
   unsigned long verify_failures = 0;  // ODOMETRY_SHIM_VERIFY_MIRRORS: mirrors that differed from an "unchanged" Mat
 };
 namespace detail { inline ShimStats& stats() { static thread_local ShimStats s; return s; } }
@@ -871,10 +872,105 @@ struct Lookahead {
   size_t out_stage_bytes[3] = {0, 0, 0};
   unsigned long out_mark = 0;                    // the side stream's position behind the copy; 0: nothing staged
   bool out_compact = false;
+  // ... and they are rebuilt AHEAD as well: the thread inside Solve spins for ~0.25 ms (the reference's Solve keeps the CPU busy all
+  // that time, ref: src/lm_optimizer.cpp:73-160); from that wait loop (odo_lm_set_idle_callback, a few us per call) the three images are
+  // zero-filled, and — once the compact block has arrived — the points written, in Mats of the shim's own. ComputeDepth (:229) hands
+  // them over by header assignment where that cannot be observed: a caller's output Mat that is empty, or whose buffer nobody else
+  // refers to (cv::Mat::u->refcount == 1 — the runner's, ref: run_odometry_kitti_offline.cpp:226-228), ends up with a buffer of the
+  // right size, type and content either way; any other output Mat (a header some other Mat shares, user memory, a view) is written
+  // in place as before. ONE RULE follows, the one every OpenCV function with an output Mat has: a raw pointer taken from an output
+  // Mat before ComputeDepth is not that Mat's data pointer afterwards. ODOMETRY_SHIM_KEEP_OUTPUT_BUFFERS=1: always write in place.
+  struct Prepared {
+    Mat img[3];                 // val (CV_8U), disp, dep (PixelType)
+    int phase = 0;              // 0 none; 1 zero fill under way; 2 zero-filled, the compact block still to come; 3 complete; -1 failed
+    size_t zeroed = 0;          // phase 1: bytes of the three images (one after the other) done so far
+    unsigned long long dep_fp = 0;
+    int rows = 0, cols = 0;
+    unsigned long mark = 0;     // the out_mark this belongs to
+  } prep;
+  std::vector<Mat> pool;        // output Mats handed out before: reused once the caller has let go of them (refcount back to 1)
   ~Lookahead() { for (void* p : out_stage) if (p) odo_host_free(p); }
 #endif
 };
 inline Lookahead& lookahead() { static thread_local Lookahead l; return l; }
+#ifdef ODOMETRY_SHIM_WITH_OPENCV
+inline bool keep_output_buffers() { static const bool on = std::getenv("ODOMETRY_SHIM_KEEP_OUTPUT_BUFFERS") != nullptr; return on; }
+inline void prep_drop(Lookahead& la) {
+  for (Mat& m : la.prep.img) m.release();
+  la.prep.phase = 0; la.prep.mark = 0;
+}
+inline Mat prep_take(Lookahead& la, int rows, int cols, int type) {
+  for (Mat& m : la.pool)
+    if (m.rows == rows && m.cols == cols && m.type() == type && m.u && m.u->refcount == 1) {
+      if (auto r = mat_table().find(m, false)) r->content_changed();   // (what the table knew about these bytes is void)
+      return m;
+    }
+  Mat m(rows, cols, type);
+  if (la.pool.size() >= 12) la.pool.erase(la.pool.begin());
+  la.pool.push_back(m);
+  return m;
+}
+// Called where the compact copy has just been queued (run_lookahead).
+inline void prep_begin(Lookahead& la, int rows, int cols) {
+  prep_drop(la);
+  if (keep_output_buffers() || !la.out_mark || !la.out_compact) return;
+  la.prep.img[0] = prep_take(la, rows, cols, CV_8U);
+  la.prep.img[1] = prep_take(la, rows, cols, PixelType);
+  la.prep.img[2] = prep_take(la, rows, cols, PixelType);
+  la.prep.rows = rows; la.prep.cols = cols; la.prep.zeroed = 0; la.prep.mark = la.out_mark; la.prep.phase = 1;
+}
+// One short piece of the work (<= 256 KB of zero fill, or the scatter once the block is there). block: wait for the block.
+inline void prep_step(Lookahead& la, bool block) {
+  Lookahead::Prepared& q = la.prep;
+  if (q.phase == 1) {
+    size_t off = q.zeroed, left = 256u << 10;
+    for (int i = 0; i < 3 && left; i++) {
+      const size_t n = q.img[i].total() * q.img[i].elemSize();
+      if (off >= n) { off -= n; continue; }
+      const size_t take = (n - off < left) ? n - off : left;
+      std::memset(q.img[i].data + off, 0, take);
+      q.zeroed += take; left -= take; off = 0;
+    }
+    if (left) q.phase = 2;   // (ran out of image before running out of budget)
+    return;
+  }
+  if (q.phase == 2) {
+    if (block) { if (odo_ctx_wait_mark(side_context(), q.mark) != 0) { q.phase = -1; return; } }
+    else {
+      const int r = odo_ctx_mark_reached(side_context(), q.mark);
+      if (r == 0) return;
+      if (r < 0) { q.phase = -1; return; }
+    }
+    q.phase = odo_host_scatter_outputs_prezeroed(la.out_stage[0], q.rows, q.cols, q.img[0].data, (size_t)q.img[0].step, q.img[1].ptr<float>(),
+                                                 (size_t)q.img[1].step, q.img[2].ptr<float>(), (size_t)q.img[2].step, &q.dep_fp) == 0 ? 3 : -1;
+  }
+}
+inline void solve_idle(void*) { Lookahead& la = lookahead(); if (la.prep.phase == 1 || la.prep.phase == 2) prep_step(la, false); }
+inline bool prep_finish(Lookahead& la) {
+  while (la.prep.phase == 1 || la.prep.phase == 2) prep_step(la, true);
+  return la.prep.phase == 3;
+}
+// May this output Mat get a new buffer without anyone being able to tell?
+inline bool prep_swappable(const Mat& m, int rows, int cols, int type) {
+  if (m.empty()) return true;
+  return m.u != nullptr && m.u->refcount == 1 && m.rows == rows && m.cols == cols && m.type() == type && m.isContinuous();
+}
+// ComputeDepth, before its outputs' records are touched: the prepared Mats take the place of the caller's (or nothing happens).
+inline bool prep_swap_in(Lookahead& la, Mat& val, Mat& disp, Mat& dep) {
+  Lookahead::Prepared& q = la.prep;
+  static const bool dbg = std::getenv("ODOMETRY_SHIM_DEBUG_PREP") != nullptr;
+  if (dbg) std::fprintf(stderr, "[prep] phase %d mark %lu out_mark %lu zeroed %zu swappable %d %d %d (refcounts %d %d %d)\n", q.phase, q.mark, la.out_mark, q.zeroed,
+                        (int)prep_swappable(val, q.rows, q.cols, CV_8U), (int)prep_swappable(disp, q.rows, q.cols, PixelType),
+                        (int)prep_swappable(dep, q.rows, q.cols, PixelType), val.u ? val.u->refcount : -1, disp.u ? disp.u->refcount : -1,
+                        dep.u ? dep.u->refcount : -1);
+  if (q.phase == 0 || q.phase == -1 || q.mark == 0 || q.mark != la.out_mark) return false;
+  if (!prep_swappable(val, q.rows, q.cols, CV_8U) || !prep_swappable(disp, q.rows, q.cols, PixelType) ||
+      !prep_swappable(dep, q.rows, q.cols, PixelType))
+    return false;
+  val = q.img[0]; disp = q.img[1]; dep = q.img[2];   // (q.img keeps its headers until prep_drop: prep_finish may still have to write)
+  return true;
+}
+#endif
 // The three output blocks of a ComputeDepth started ahead go back to the free list: behind the job (side stream) when it was started.
 inline void early_release() {
   Lookahead::Early& e = lookahead().early;
@@ -922,6 +1018,27 @@ inline void run_lookahead(odo_lm* lm = nullptr, const odo_pyr* cur_img = nullptr
                                     la.pending_mark) == 0) {
       e.started = true; e.est = la.estimator;
       e.left_dev = lb->dev; e.right_dev = guess->dev; e.left_stamp = lb->stamp; e.right_stamp = guess->stamp;
+#ifdef ODOMETRY_SHIM_WITH_OPENCV
+      auto stage_outputs = [&]() {
+      // (first behind the job: the sooner the compact block is on the host, the more of the output images is built while Solve waits)
+      la.out_mark = 0;
+      la.out_compact = !lazy_outputs();
+      const size_t need = la.out_compact ? odo_depth_compact_bytes() : e.bytes[0];
+      if (la.out_stage_bytes[0] != need) {
+        if (la.out_stage[0]) odo_host_free(la.out_stage[0]);
+        la.out_stage[0] = odo_host_alloc(need);
+        la.out_stage_bytes[0] = la.out_stage[0] ? need : 0;
+      }
+      const bool staged = la.out_stage[0] &&
+          (la.out_compact ? odo_depth_compact_outputs_async(la.estimator, side_context(), static_cast<const uint8_t*>(e.blk[0]),
+                                                            static_cast<const float*>(e.blk[1]), static_cast<const float*>(e.blk[2]), e.cols,
+                                                            la.out_stage[0])
+                          : odo_dev_download_async(side_context(), la.out_stage[0], e.blk[0], e.bytes[0])) == 0;
+      if (staged) la.out_mark = odo_ctx_mark(side_context());
+      prep_begin(la, e.rows, e.cols);
+      };
+      stage_outputs();   // (behind the pyramid and the lists instead: 1 525-1 538 against 1 565-1 590 frames/s)
+#endif
       // ... and behind it, still beside the Solve: the frame's depth pyramid (:252, with what the last DepthPyramid was built with)
       // and the keyframe-candidate point lists of (this image pyramid, that depth pyramid) — if the runner promotes this frame
       // (:258-260), the next Solve finds its lists built (odo_lm_candidate_begin) instead of building them in front of its launches
@@ -937,22 +1054,6 @@ inline void run_lookahead(odo_lm* lm = nullptr, const odo_pyr* cur_img = nullptr
           if (lm && cur_img) (void)odo_lm_candidate_begin(lm, side_context(), cur_img, hp->p, la.pending_mark);
         }
       }
-#ifdef ODOMETRY_SHIM_WITH_OPENCV
-      la.out_mark = 0;
-      la.out_compact = !lazy_outputs();
-      const size_t need = la.out_compact ? odo_depth_compact_bytes() : e.bytes[0];
-      if (la.out_stage_bytes[0] != need) {
-        if (la.out_stage[0]) odo_host_free(la.out_stage[0]);
-        la.out_stage[0] = odo_host_alloc(need);
-        la.out_stage_bytes[0] = la.out_stage[0] ? need : 0;
-      }
-      const bool staged = la.out_stage[0] &&
-          (la.out_compact ? odo_depth_compact_outputs_async(la.estimator, side_context(), static_cast<const uint8_t*>(e.blk[0]),
-                                                            static_cast<const float*>(e.blk[1]), static_cast<const float*>(e.blk[2]), e.cols,
-                                                            la.out_stage[0])
-                          : odo_dev_download_async(side_context(), la.out_stage[0], e.blk[0], e.bytes[0])) == 0;
-      if (staged) la.out_mark = odo_ctx_mark(side_context());
-#endif
     } else {
       (void)odo_depth_prepare_left_dev_marked(la.estimator, side_context(), static_cast<const float*>(lb->dev), la.pending_rows,
                                               la.pending_cols, lb->stamp, la.pending_mark);
@@ -1015,6 +1116,9 @@ inline void record_lookahead(const Mat& in, int num_levels, bool smooth) {
   if (la.estimator && in.rows == la.est_rows && in.cols == la.est_cols && guess && guess.get() != lb.get()) early_reserve(in.rows, in.cols);
   else early_release();
   la.pending_mark = odo_ctx_mark(context());
+  // (Round 5, cv::Mat build, measured and dropped: the partner's staging copy + upload from HERE instead of from Solve — the side
+  //  stream's chain then ends ~45 us sooner, inside the Solve, but the copy sits in front of the Solve's launches: 1 686-1 710 against
+  //  1 672-1 703 frames/s.)
 }
 inline std::shared_ptr<PyrHandle> make_pyr(int num_levels, const Mat& in, bool smooth, int kind, const char* what) {
   CallScope call;
@@ -1121,6 +1225,9 @@ class LevenbergMarquardtOptimizer {  // ref: include/lm_optimizer.h:24-115
     if (odo_lm_create(detail::context(), lambda, precision, kMaxIterations.data(), (int)kMaxIterations.size(),
                       affine_data(kRelativeInit), robust_est, huber_delta, Kp, &lm_) != 0)
       std::cout << "odometry_hip: " << odo_last_error() << std::endl;
+#ifdef ODOMETRY_SHIM_WITH_OPENCV
+    else (void)odo_lm_set_idle_callback(lm_, &detail::solve_idle, nullptr);   // ComputeDepth's output images are built while Solve waits
+#endif
   }
   ~LevenbergMarquardtOptimizer() { odo_lm_destroy(lm_); }
   LevenbergMarquardtOptimizer(const LevenbergMarquardtOptimizer&) = delete;
@@ -1236,6 +1343,9 @@ class DepthEstimator {  // ref: include/depth_estimate.h:24-121
           rb->dev == e.right_dev && rb->dev_valid && rb->stamp == e.right_stamp && left_img.rows == e.rows && left_img.cols == e.cols &&
           detail::device_bytes(left_val) == e.bytes[0] && detail::device_bytes(left_disp) == e.bytes[1] &&
           detail::device_bytes(left_dep) == e.bytes[2]) {
+#ifdef ODOMETRY_SHIM_WITH_OPENCV
+        const bool swapped = detail::prep_swap_in(la, left_val, left_disp, left_dep);   // (see Lookahead::Prepared)
+#endif
         detail::adopt_device(left_val, e.blk[0], e.async_[0]);
         detail::adopt_device(left_disp, e.blk[1], e.async_[1], detail::lazy_outputs());
         detail::adopt_device(left_dep, e.blk[2], e.async_[2], detail::lazy_outputs());
@@ -1255,11 +1365,14 @@ class DepthEstimator {  // ref: include/depth_estimate.h:24-121
            // again, nothing was staged) straight from the device
           Mat* outs[3] = {&left_val, &left_disp, &left_dep};
           const bool staged = la.out_mark != 0 && redone_after == redone_before && st == 0;
-          if (staged) odo_ctx_wait_mark(detail::side_context(), la.out_mark);
+          const bool prepared = staged && swapped && detail::prep_finish(la);   // (built while Solve waited: usually nothing is left to do)
+          if (staged && !prepared) odo_ctx_wait_mark(detail::side_context(), la.out_mark);
           lap_(2);
           if (staged && la.out_compact && !detail::lazy_outputs()) {
-            unsigned long long dep_fp = 0;
-            if (odo_host_scatter_outputs(la.out_stage[0], e.rows, e.cols, left_val.data, (size_t)left_val.step, left_disp.ptr<float>(),
+            unsigned long long dep_fp = la.prep.dep_fp;
+            if (prepared) detail::stats().outputs_prepared++;
+            if (prepared ||
+                odo_host_scatter_outputs(la.out_stage[0], e.rows, e.cols, left_val.data, (size_t)left_val.step, left_disp.ptr<float>(),
                                          (size_t)left_disp.step, left_dep.ptr<float>(), (size_t)left_dep.step, &dep_fp) == 0) {
               for (int i = 0; i < 3; i++) {
                 auto ob = detail::output_buffer_of(*outs[i]);
@@ -1278,6 +1391,7 @@ class DepthEstimator {  // ref: include/depth_estimate.h:24-121
             }
           }
           la.out_mark = 0;
+          detail::prep_drop(la);
           lap_(3);
         }
 #endif
@@ -1298,6 +1412,9 @@ class DepthEstimator {  // ref: include/depth_estimate.h:24-121
         if (e.started) detail::stats().early_dropped++;
         detail::early_release();   // (the library drops the job itself at its next call)
         la.early_dep_pyr.reset();
+#ifdef ODOMETRY_SHIM_WITH_OPENCV
+        detail::prep_drop(la);
+#endif
       }
     }
     if (!collected) {

@@ -61,9 +61,11 @@ SIGNATURES = {
     "odo_dev_upload_async": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "odo_dev_upload_2d_async": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, C.c_int]),
     "odo_ctx_wait_mark": (C.c_int, [_vp, C.c_ulong]),
+    "odo_ctx_mark_reached": (C.c_int, [_vp, C.c_ulong]),
     "odo_depth_compact_bytes": (C.c_size_t, []),
     "odo_depth_compact_outputs_async": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "odo_host_scatter_outputs": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_ulonglong)]),
+    "odo_host_scatter_outputs_prezeroed": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_ulonglong)]),
     "odo_host_fingerprint": (C.c_ulonglong, [_vp, C.c_size_t, C.c_size_t, C.c_int]),
     "odo_host_copy_fingerprint": (C.c_ulonglong, [_vp, C.c_size_t, _vp, C.c_size_t, C.c_size_t, C.c_int]),
     "odo_dev_upload_fp_async": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_ulonglong)]),
@@ -93,6 +95,7 @@ SIGNATURES = {
     "odo_lm_event_stats2": (C.c_int, [_vp, _dp, C.POINTER(C.c_long)]),
     "odo_lm_event_stats_ex": (C.c_int, [_vp, _dp]),
     "odo_lm_solve_begin": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "odo_lm_set_idle_callback": (C.c_int, [_vp, _vp, _vp]),
     "odo_lm_candidate_begin": (C.c_int, [_vp, _vp, _vp, _vp, C.c_ulong]),
     "odo_lm_solve_batch": (C.c_int, [C.c_int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _fp, C.POINTER(C.c_int)]),
     "odo_lm_set_sampling": (C.c_int, [_vp, C.c_int]),

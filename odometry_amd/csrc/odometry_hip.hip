@@ -434,6 +434,9 @@ extern "C" int odo_dev_upload_fp_async(odo_ctx* c, void* dst, const void* src, s
     c->stage_cap[slot] = total;
   }
   *fp = hostfp::image(src, src_pitch, row_bytes, rows, c->stage[slot], row_bytes);   // the fingerprint of exactly the bytes that go up
+  // (Round 5, measured and dropped: the image sent in 256 KB - 1 MB pieces, each piece's DMA queued from inside the copy loop while the
+  //  next piece is copied and hashed — the frame got SLOWER with every extra piece, cv::Mat runner 1 568 -> 1 558 / 1 535 / 1 438
+  //  frames/s for 2 / 4 / 8 pieces: a hipMemcpyAsync call costs the host more than the overlap gives back.)
   HIP_OK(hipMemcpyAsync(dst, c->stage[slot], total, hipMemcpyHostToDevice, c->stream));
   HIP_OK(hipEventRecord(c->stage_ev[slot], c->stream));
   c->stage_busy[slot] = 1;
@@ -455,6 +458,18 @@ extern "C" int odo_ctx_wait_mark(odo_ctx* c, unsigned long mark) {
   if (ev) HIP_OK(hipEventSynchronize(ev));     // (a ring entry re-recorded since: a later point of the same stream — implies the mark)
   else HIP_OK(hipStreamSynchronize(c->stream));
   return 0;
+}
+extern "C" int odo_ctx_mark_reached(odo_ctx* c, unsigned long mark) {
+  if (!c) return fail("odo_ctx_mark_reached: NULL ctx");
+  hipEvent_t ev = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(*c->mu);
+    if (mark != 0 && mark <= c->sw_next && c->sw_next - mark < 32) ev = c->sw_ev[mark % 32];
+  }
+  const hipError_t e = ev ? hipEventQuery(ev) : hipStreamQuery(c->stream);
+  if (e == hipSuccess) return 1;
+  if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+  return fail("odo_ctx_mark_reached: %s", hipGetErrorString(e));
 }
 extern "C" int odo_dev_download(odo_ctx* c, void* dst, const void* src, size_t bytes) {
   if (!c || !dst || !src) return fail("odo_dev_download: NULL arg");
@@ -1583,6 +1598,12 @@ static bool lm_job_matches(const odo_lm* m, const odo_pyr* kf_img, const odo_pyr
   const LmJob& jb = m->job;
   return jb.active && jb.kf_img == kf_img && jb.kf_dep == kf_dep && jb.cur_img == cur_img && jb.kf_img_ver == kf_img->version &&
          jb.kf_dep_ver == kf_dep->version && jb.cur_ver == cur_img->version;
+}
+
+extern "C" int odo_lm_set_idle_callback(odo_lm* m, void (*fn)(void*), void* arg) {
+  if (!m) return fail("odo_lm_set_idle_callback: NULL optimiser");
+  m->idle_pump = fn; m->idle_arg = arg;
+  return 0;
 }
 
 // Starts the Solve that a following odo_lm_solve(lm, kf_img, kf_dep, cur_img) will collect. Returns 0 when started (or already
@@ -2959,8 +2980,8 @@ extern "C" int odo_depth_compact_outputs_async(odo_depth* d, odo_ctx* on, const 
   HIP_OK(hipMemcpyAsync(dst_pinned, d->d_compact, kCompactSlots * 13, hipMemcpyDeviceToHost, on->stream));
   return 0;
 }
-extern "C" int odo_host_scatter_outputs(const void* compact, int rows, int cols, uint8_t* val, size_t val_pitch, float* disp,
-                                        size_t disp_pitch, float* dep, size_t dep_pitch, unsigned long long* dep_fingerprint) {
+static int host_scatter_outputs(const void* compact, int rows, int cols, uint8_t* val, size_t val_pitch, float* disp, size_t disp_pitch,
+                                float* dep, size_t dep_pitch, unsigned long long* dep_fingerprint, bool zero_first) {
   if (!compact || !val || !disp || !dep || rows < 1 || cols < 1 || val_pitch < (size_t)cols || disp_pitch < sizeof(float) * (size_t)cols ||
       dep_pitch < sizeof(float) * (size_t)cols)
     return fail("odo_host_scatter_outputs: bad arg");
@@ -2969,11 +2990,12 @@ extern "C" int odo_host_scatter_outputs(const void* compact, int rows, int cols,
   const float* cd = (const float*)(c + kCompactSlots * 4);
   const float* cp = (const float*)(c + kCompactSlots * 8);
   const uint8_t* cv = (const uint8_t*)(c + kCompactSlots * 12);
-  for (int y = 0; y < rows; y++) {
-    memset(val + (size_t)y * val_pitch, 0, (size_t)cols);
-    memset((char*)disp + (size_t)y * disp_pitch, 0, sizeof(float) * (size_t)cols);
-    memset((char*)dep + (size_t)y * dep_pitch, 0, sizeof(float) * (size_t)cols);
-  }
+  if (zero_first)
+    for (int y = 0; y < rows; y++) {
+      memset(val + (size_t)y * val_pitch, 0, (size_t)cols);
+      memset((char*)disp + (size_t)y * disp_pitch, 0, sizeof(float) * (size_t)cols);
+      memset((char*)dep + (size_t)y * dep_pitch, 0, sizeof(float) * (size_t)cols);
+    }
   const uint32_t npx = (uint32_t)rows * (uint32_t)cols;
   for (size_t s = 0; s < kCompactSlots; s++) {
     const uint32_t i = idx[s];
@@ -2985,6 +3007,14 @@ extern "C" int odo_host_scatter_outputs(const void* compact, int rows, int cols,
   }
   if (dep_fingerprint) *dep_fingerprint = hostfp::image(dep, dep_pitch, sizeof(float) * (size_t)cols, rows, nullptr, 0);
   return 0;
+}
+extern "C" int odo_host_scatter_outputs(const void* compact, int rows, int cols, uint8_t* val, size_t val_pitch, float* disp,
+                                        size_t disp_pitch, float* dep, size_t dep_pitch, unsigned long long* dep_fingerprint) {
+  return host_scatter_outputs(compact, rows, cols, val, val_pitch, disp, disp_pitch, dep, dep_pitch, dep_fingerprint, true);
+}
+extern "C" int odo_host_scatter_outputs_prezeroed(const void* compact, int rows, int cols, uint8_t* val, size_t val_pitch, float* disp,
+                                                  size_t disp_pitch, float* dep, size_t dep_pitch, unsigned long long* dep_fingerprint) {
+  return host_scatter_outputs(compact, rows, cols, val, val_pitch, disp, disp_pitch, dep, dep_pitch, dep_fingerprint, false);
 }
 
 extern "C" int odo_depth_compute_begin_dev(odo_depth* d, odo_ctx* side, const float* left_dev, const float* right_dev, int rows, int cols,

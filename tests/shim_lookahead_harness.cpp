@@ -7,6 +7,9 @@
 //   poke     like vector, and the right image is modified between Solve and ComputeDepth (a job started ahead must be dropped)
 //   poke_left   like refill, and the LEFT image is modified in place between Solve (:215) and ComputeDepth (:229): the upload made for
 //            ImagePyramid (:205) no longer is the image — ComputeDepth and the keyframe pyramid must see the new pixels
+//   shared_outputs   like refill, but ComputeDepth's output Mats are not the caller's alone: left_disp has a second header, left_dep (cv::Mat
+//            build) lies in user memory — the cv::Mat build must then write them IN PLACE (it otherwise hands over images it built while
+//            Solve waited, by header assignment); the checksums are taken through the OTHER header / the user memory
 // Built twice by the test: with the stand-in Mat (writes are seen through ptr<T>() / at<T>()) and with -DODOMETRY_SHIM_WITH_OPENCV against
 // tests/stubs (a cv::Mat reports nothing: every use fingerprints the pixels). The last line on stderr: SHIM_STATS (ShimStats).
 // Prints one line per frame: pose bits and checksums of the three depth outputs. The test runs every mode with and without
@@ -70,7 +73,20 @@ int main(int argc, char** argv) {
     if (mode == "poke_left" && (k % 3) == 1)                                        // a patch no sparse sample would notice
       for (int y = 100; y < 108; y++) for (int x = 301; x < 309; x++) L.at<float>(y, x) = 255.0f - L.at<float>(y, x);
     Mat val(rows, cols, CV_8U, 0.0), disp(rows, cols, PixelType), dep(rows, cols, PixelType);
+    Mat disp_other;
+    static std::vector<float> user_dep;
+    if (mode == "shared_outputs") {
+      disp_other = disp;   // a second header: whoever holds it must see the results
+#ifdef ODOMETRY_SHIM_WITH_OPENCV
+      user_dep.assign(px, -1.0f);
+      dep = Mat(rows, cols, PixelType, user_dep.data());   // user memory: nothing but these bytes may receive the image
+#endif
+    }
     const int st = de.ComputeDepth(L, R, val, disp, dep);
+#ifdef ODOMETRY_SHIM_WITH_OPENCV
+    if (mode == "shared_outputs" && (disp_other.data != disp.data || dep.data != reinterpret_cast<unsigned char*>(user_dep.data()))) return 3;
+#endif
+    if (mode == "shared_outputs") disp = disp_other;
     if (k == 0 || (k % 4) == 0) {   // a new keyframe now and then
       kf_img.reset(new ImagePyramid(4, L, true));
       kf_dep.reset(new DepthPyramid(4, dep, false));
@@ -86,7 +102,8 @@ int main(int argc, char** argv) {
   }
   std::cout.rdbuf(keep);
   const ShimStats& st = shim_stats();
-  std::fprintf(stderr, "SHIM_STATS uploads %lu fingerprints %lu unchanged %lu changed %lu early_adopted %lu early_dropped %lu delivered %lu verify_failures %lu\n",
-               st.uploads, st.fingerprints, st.unchanged, st.changed, st.early_adopted, st.early_dropped, st.delivered, st.verify_failures);
+  std::fprintf(stderr, "SHIM_STATS uploads %lu fingerprints %lu unchanged %lu changed %lu early_adopted %lu early_dropped %lu delivered %lu outputs_prepared %lu verify_failures %lu\n",
+               st.uploads, st.fingerprints, st.unchanged, st.changed, st.early_adopted, st.early_dropped, st.delivered, st.outputs_prepared,
+               st.verify_failures);
   return 0;
 }

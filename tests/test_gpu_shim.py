@@ -151,7 +151,10 @@ def test_cv_mat_build_has_the_lookahead_and_detects_in_place_writes(tmp_path, mo
         :229 (an 8x8 patch the 48-word sample cannot see), are detected by the fingerprint: the job started ahead is dropped, the new
         pixels are uploaded, results equal the look-ahead-off run;
       * ODOMETRY_SHIM_VERIFY_MIRRORS=1 (every "unchanged" verdict checked by downloading the mirror and comparing bytes): no failure;
-      * ODOMETRY_SHIM_LAZY_OUTPUTS=1 (left_disp / left_dep stay on the device until odometry::Download): the same lines."""
+      * ODOMETRY_SHIM_LAZY_OUTPUTS=1 (left_disp / left_dep stay on the device until odometry::Download): the same lines;
+      * the three output images are built while Solve waits and handed over by header assignment when the caller's output Mats are
+        theirs alone (refill: every frame but the first two) — and written IN PLACE when they are not (shared_outputs: a second header
+        on left_disp, left_dep in user memory; ODOMETRY_SHIM_KEEP_OUTPUT_BUFFERS=1): the same lines either way."""
     from odometry_amd import synth
     seq = synth.make_sequence(10, seed=3)
     L, R = seq["left"], seq["right"]
@@ -169,6 +172,12 @@ def test_cv_mat_build_has_the_lookahead_and_detects_in_place_writes(tmp_path, mo
     assert st["early_adopted"] >= n - 2 and st["early_dropped"] == 0, st
     assert st["delivered"] == 3 * n and st["verify_failures"] == 0, st
     assert st["changed"] >= 2 * (n - 1) - 2, st                        # every refill was noticed
+    assert st["outputs_prepared"] >= n - 2, st                         # the output images were built while Solve waited
+    lines, st = cv("shared_outputs")
+    assert lines == base and st["outputs_prepared"] == 0 and st["early_adopted"] >= n - 2, st   # ... and never swapped in under a second header
+    assert std("shared_outputs")[0] == base
+    lines, st = cv("refill", ODOMETRY_SHIM_KEEP_OUTPUT_BUFFERS="1")
+    assert lines == base and st["outputs_prepared"] == 0, st
     for mode in ("poke", "poke_left"):
         want = std(mode, True)[0]
         got, st = cv(mode)

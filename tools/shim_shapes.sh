@@ -33,6 +33,7 @@ run "stand-in load-per-frame      " /tmp/ros_std "--load-per-frame" X=1
 run "stand-in preloaded, no ahead " /tmp/ros_std "" ODOMETRY_SHIM_NO_LOOKAHEAD=1
 run "cv::Mat preloaded            " /tmp/ros_cv "" X=1
 run "cv::Mat load-per-frame       " /tmp/ros_cv "--load-per-frame" X=1
+run "cv::Mat load-per-frame, in place" /tmp/ros_cv "--load-per-frame" ODOMETRY_SHIM_KEEP_OUTPUT_BUFFERS=1
 run "cv::Mat load-per-frame, lazy " /tmp/ros_cv "--load-per-frame" ODOMETRY_SHIM_LAZY_OUTPUTS=1
 run "cv::Mat preloaded, lazy      " /tmp/ros_cv "" ODOMETRY_SHIM_LAZY_OUTPUTS=1
 M="ODOMETRY_SHIM_NO_MALLOPT=1"   # glibc's default thresholds: the runner's per-frame Mats lose their pages every frame

@@ -114,6 +114,20 @@ def test_scatter_rebuilds_the_three_output_images_from_the_point_slots():
         if pad:
             assert (ov[:, cols:] == 9).all() and (od[:, cols:] == -1.0).all()          # nothing written beyond a row's pixels
         assert fp.value == lib.odo_host_fingerprint(op.ctypes.data, op.strides[0], cols * 4, rows)
+        # the same into images the caller zero-filled beforehand (the cv::Mat build of the shim does that while Solve waits): same images,
+        # same fingerprint; and it really does not fill — whatever else the buffers held stays
+        zv, zd, zp = np.zeros_like(ov), np.zeros_like(od), np.zeros_like(op)
+        fz = C.c_ulonglong(0)
+        assert lib.odo_host_scatter_outputs_prezeroed(compact.ctypes.data, rows, cols, zv.ctypes.data, zv.strides[0], zd.ctypes.data,
+                                                      zd.strides[0], zp.ctypes.data, zp.strides[0], C.byref(fz)) == 0
+        assert np.array_equal(zv[:, :cols], ov[:, :cols]) and np.array_equal(zd[:, :cols], od[:, :cols]) and np.array_equal(zp[:, :cols], op[:, :cols])
+        assert fz.value == fp.value
+        sv, sd, sp = np.full_like(ov, 7), np.full_like(od, 3.0), np.full_like(op, 4.0)
+        assert lib.odo_host_scatter_outputs_prezeroed(compact.ctypes.data, rows, cols, sv.ctypes.data, sv.strides[0], sd.ctypes.data,
+                                                      sd.strides[0], sp.ctypes.data, sp.strides[0], None) == 0
+        untouched = np.ones(rows * cols, bool)
+        untouched[pix] = False
+        assert (sd[:, :cols].reshape(-1)[untouched] == 3.0).all() and np.array_equal(sd[:, :cols].reshape(-1)[pix], disp[where])
 
 
 def test_fingerprint_code_is_clean_under_the_sanitizers(tmp_path):

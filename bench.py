@@ -1155,6 +1155,12 @@ def main():
 
     if my_seq_ids and args.sequences == 0:
         run_sequence(0, False)
+    # The harness is Python: with torch imported a generation-2 garbage collection takes ~30 ms (140 frames' worth) and
+    # would land somewhere inside the timed loop. The loop itself allocates next to nothing, so the collector is parked — and the
+    # collection runs HERE, in front of the barrier, not between the barrier and the clock: 30 ms of idle time there let the GPU fall
+    # back to its idle clocks, and the first timed step paid for the ramp.
+    gc.collect()
+    gc.disable()
     barrier()
     trk.timing()  # reset the host-clock diagnostics
     step_s = np.zeros(args.steps, np.float64)   # wall time of every timed step of this rank's first sequence (spread diagnostics)
@@ -1163,10 +1169,6 @@ def main():
     ev_in_timed = args.event_sample > 0 and args.sequences == 0
     if ev_in_timed:
         trk.event_timing(args.event_sample)
-    # The harness is Python: with torch imported a generation-2 garbage collection takes ~30 ms (140 frames' worth) and
-    # would land somewhere inside the timed loop. The loop itself allocates next to nothing, so the collector is parked.
-    gc.collect()
-    gc.disable()
     if os.environ.get("ODO_LOG_GIVEUPS"):
         print("[bench phase] timed region", file=sys.stderr, flush=True)
     t0 = time.perf_counter()

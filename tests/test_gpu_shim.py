@@ -39,12 +39,26 @@ def test_cpp_runner_over_shim(tmp_path, kitti_seq):
     assert "LM Optimizer failed! Invalid camera pointer!" in out.stdout   # the reference's null-camera warning
 
 
+_BUILT = {}   # (source, flavour) -> executable: a program is compiled once per test session (the header is ~1 500 lines: 5-10 s each time)
+
+
+def _build_once(src, flavour, flags):
+    import atexit
+    import shutil
+    import tempfile
+    if (src, flavour) not in _BUILT:
+        d = tempfile.mkdtemp(prefix="odo_shim_build_", dir="/tmp")
+        atexit.register(shutil.rmtree, d, True)
+        exe = os.path.join(d, os.path.splitext(os.path.basename(src))[0] + "_" + flavour)
+        subprocess.check_call(["g++", "-O2", "-std=c++17"] + flags + ["-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, src), "-o", exe,
+                               "-L" + os.path.join(ROOT, "odometry_amd", "lib"), "-lodometry_hip",
+                               "-Wl,-rpath," + os.path.join(ROOT, "odometry_amd", "lib")])
+        _BUILT[(src, flavour)] = exe
+    return _BUILT[(src, flavour)]
+
+
 def _build(tmp_path, src, name):
-    exe = str(tmp_path / name)
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, src), "-o", exe,
-                           "-L" + os.path.join(ROOT, "odometry_amd", "lib"), "-lodometry_hip",
-                           "-Wl,-rpath," + os.path.join(ROOT, "odometry_amd", "lib")])
-    return exe
+    return _build_once(src, "std", [])
 
 
 def test_shim_mat_device_mirror(tmp_path):
@@ -228,6 +242,7 @@ def test_random_walk_over_caller_behaviour_same_results_in_every_build(tmp_path,
     assert got == want and st["verify_failures"] == 0
     assert run("cv", ODOMETRY_SHIM_LAZY_OUTPUTS="1")[0] == want
     assert run("cv", ODOMETRY_SHIM_NO_LOOKAHEAD="1")[0] == want
+    assert run("cv", ODOMETRY_SHIM_KEEP_OUTPUT_BUFFERS="1")[0] == want      # outputs always written in place, never handed over
 
 
 def test_runner_with_load_data_inside_the_loop(tmp_path):
@@ -256,12 +271,7 @@ _CV_FLAGS = ["-DODOMETRY_SHIM_WITH_OPENCV", "-DODOMETRY_SHIM_WITH_EIGEN", "-I" +
 def _build_cv(tmp_path, src, name):
     """The cv::Mat / Eigen branch of the shim — the one a maintainer of the reference builds — against tests/stubs (this image has
     neither library: the stubs are written from the documented APIs, test scaffolding only)."""
-    exe = str(tmp_path / name)
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Werror"] + _CV_FLAGS +
-                          ["-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, src), "-o", exe,
-                           "-L" + os.path.join(ROOT, "odometry_amd", "lib"), "-lodometry_hip",
-                           "-Wl,-rpath," + os.path.join(ROOT, "odometry_amd", "lib")])
-    return exe
+    return _build_once(src, "cv", ["-Wall", "-Werror"] + _CV_FLAGS)
 
 
 def test_opencv_eigen_branch_tracks_bit_identically_to_the_stand_in_build(tmp_path):

@@ -958,11 +958,6 @@ inline bool prep_swappable(const Mat& m, int rows, int cols, int type) {
 // ComputeDepth, before its outputs' records are touched: the prepared Mats take the place of the caller's (or nothing happens).
 inline bool prep_swap_in(Lookahead& la, Mat& val, Mat& disp, Mat& dep) {
   Lookahead::Prepared& q = la.prep;
-  static const bool dbg = std::getenv("ODOMETRY_SHIM_DEBUG_PREP") != nullptr;
-  if (dbg) std::fprintf(stderr, "[prep] phase %d mark %lu out_mark %lu zeroed %zu swappable %d %d %d (refcounts %d %d %d)\n", q.phase, q.mark, la.out_mark, q.zeroed,
-                        (int)prep_swappable(val, q.rows, q.cols, CV_8U), (int)prep_swappable(disp, q.rows, q.cols, PixelType),
-                        (int)prep_swappable(dep, q.rows, q.cols, PixelType), val.u ? val.u->refcount : -1, disp.u ? disp.u->refcount : -1,
-                        dep.u ? dep.u->refcount : -1);
   if (q.phase == 0 || q.phase == -1 || q.mark == 0 || q.mark != la.out_mark) return false;
   if (!prep_swappable(val, q.rows, q.cols, CV_8U) || !prep_swappable(disp, q.rows, q.cols, PixelType) ||
       !prep_swappable(dep, q.rows, q.cols, PixelType))
@@ -1019,8 +1014,8 @@ inline void run_lookahead(odo_lm* lm = nullptr, const odo_pyr* cur_img = nullptr
       e.started = true; e.est = la.estimator;
       e.left_dev = lb->dev; e.right_dev = guess->dev; e.left_stamp = lb->stamp; e.right_stamp = guess->stamp;
 #ifdef ODOMETRY_SHIM_WITH_OPENCV
-      auto stage_outputs = [&]() {
-      // (first behind the job: the sooner the compact block is on the host, the more of the output images is built while Solve waits)
+      // (first behind the job: the sooner the compact block is on the host, the more of the output images is built while Solve waits;
+      //  behind the pyramid and the lists instead: 1 525-1 538 against 1 565-1 590 frames/s)
       la.out_mark = 0;
       la.out_compact = !lazy_outputs();
       const size_t need = la.out_compact ? odo_depth_compact_bytes() : e.bytes[0];
@@ -1036,8 +1031,6 @@ inline void run_lookahead(odo_lm* lm = nullptr, const odo_pyr* cur_img = nullptr
                           : odo_dev_download_async(side_context(), la.out_stage[0], e.blk[0], e.bytes[0])) == 0;
       if (staged) la.out_mark = odo_ctx_mark(side_context());
       prep_begin(la, e.rows, e.cols);
-      };
-      stage_outputs();   // (behind the pyramid and the lists instead: 1 525-1 538 against 1 565-1 590 frames/s)
 #endif
       // ... and behind it, still beside the Solve: the frame's depth pyramid (:252, with what the last DepthPyramid was built with)
       // and the keyframe-candidate point lists of (this image pyramid, that depth pyramid) — if the runner promotes this frame

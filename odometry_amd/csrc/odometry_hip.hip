@@ -436,7 +436,10 @@ extern "C" int odo_dev_upload_fp_async(odo_ctx* c, void* dst, const void* src, s
   *fp = hostfp::image(src, src_pitch, row_bytes, rows, c->stage[slot], row_bytes);   // the fingerprint of exactly the bytes that go up
   // (Round 5, measured and dropped: the image sent in 256 KB - 1 MB pieces, each piece's DMA queued from inside the copy loop while the
   //  next piece is copied and hashed — the frame got SLOWER with every extra piece, cv::Mat runner 1 568 -> 1 558 / 1 535 / 1 438
-  //  frames/s for 2 / 4 / 8 pieces: a hipMemcpyAsync call costs the host more than the overlap gives back.)
+  //  frames/s for 2 / 4 / 8 pieces: a hipMemcpyAsync call costs the host more than the overlap gives back. The other direction —
+  //  ONE launch queued first whose blocks fetch the staging block over PCIe piece by piece as the copy loop announces the pieces with
+  //  plain stores into page-locked memory — was built as well: bit-identical, the Solve behind the upload starts 8 us sooner, and the
+  //  copy loop the device reads behind gets 18 us slower: 1 555-1 730 against 1 579-1 711 frames/s, nothing.)
   HIP_OK(hipMemcpyAsync(dst, c->stage[slot], total, hipMemcpyHostToDevice, c->stream));
   HIP_OK(hipEventRecord(c->stage_ev[slot], c->stream));
   c->stage_busy[slot] = 1;

@@ -500,6 +500,9 @@ class Mat {
     if (empty() || type_ != CV_8U || rtype != CV_32F) { std::cout << "odometry_hip: Mat::convertTo converts CV_8U to CV_32F only" << std::endl; return; }
     dst.create(rows, cols, rtype);
     detail::convert_8u_32f(ptr<uint8_t>(), dst.ptr<float>(), (size_t)rows * cols);
+    // (Round 5, measured and dropped: sending dst up from HERE, on the side stream, so that the image has crossed PCIe by the time
+    //  ImagePyramid asks for it — the Solve behind it starts 8 us sooner and the three runtime calls per image cost load_data 16 us
+    //  each: 2 085-2 304 against 2 287-2 324 frames/s in the runner's load-per-frame shape.)
   }
   Mat clone() const { Mat m; copyTo(m); return m; }
   // -- device side, for the shim's classes only --

@@ -1714,6 +1714,11 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
   const int my_q = tl / kS, my_s = tl % kS;
   int rowA = 0, rowB = 0;
   if (my_q < ODO_NACC) rows_of_quantity(my_q, &rowA, &rowB);
+  // the keyframe points of the level stay in registers from iteration to iteration (as in lm_fine_body): one dependent trip to L2 / L1
+  // less in every evaluation of a level that is a latency chain of ~200 points on four waves
+  PointK cpt[kCoarseRounds];
+  bool cpt_ok[kCoarseRounds] = {false, false};
+  int cpt_level = -1;
   for (int guard = 0; guard < 4096; guard++) {
     const bool run = (s_sh.active != 0 && s_sh.status == 0 && s_sh.level >= min_level);  // block-uniform
     if (!run) break;
@@ -1723,8 +1728,16 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
 #pragma unroll
     for (int i = 0; i < 16; i++) T[i] = s_sh.T[i];
     const int nvb = L.nblk;  // = ceil(n / 256), at least 1 (lm_grid_for)
-    // (Keeping each thread's points in registers across iterations and staging the 29 KB level image in LDS was
-    // measured: no faster. With 8 waves on one CU the evaluation is VALU-issue bound, not latency bound.)
+    if (s_sh.level != cpt_level) {
+      cpt_level = s_sh.level;
+#pragma unroll
+      for (int rd = 0; rd < kCoarseRounds; rd++) {
+        const int vb = 2 * rd + half, idx = vb * kLmBlock + tl;
+        cpt_ok[rd] = vb < nvb && idx < L.n;
+        if (cpt_ok[rd]) cpt[rd] = load_point(L.pl, idx);
+      }
+    }
+    // (Staging the 29 KB level image in LDS as well was measured: no faster.)
     // t-distribution weights (ref: src/lm_optimizer.cpp:257-261,338-358) need the scale of ALL residuals of the evaluation before any
     // weight: the residuals of every round are evaluated first and kept (with their Jacobian rows) in registers, then the scale
     // iteration runs over them (coarse_tdist_sigma), then the rounds go through the row sums as usual
@@ -1735,11 +1748,7 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
       float e2[kCoarseRounds];
 #pragma unroll
       for (int rd = 0; rd < kCoarseRounds; rd++) {
-        const int vb = 2 * rd + half, idx = vb * kLmBlock + tl;
-        if (vb < nvb && idx < L.n) {
-          const PointK p = load_point(L.pl, idx);
-          td_valid[rd] = point_residual(p, T, L.k, L.I2, L.rows, L.cols, &td_r[rd], td_J[rd]);
-        }
+        if (cpt_ok[rd]) td_valid[rd] = point_residual(cpt[rd], T, L.k, L.I2, L.rows, L.cols, &td_r[rd], td_J[rd]);
         e2[rd] = td_r[rd] * td_r[rd];
       }
       const float sg = coarse_tdist_sigma(sc_part, sc_cnt, e2, td_valid, (nvb + 1) / 2);
@@ -1749,7 +1758,6 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
     for (int vb0 = 0; vb0 < 2 * kCoarseRounds; vb0 += 2) {  // one round per 512 points (kCoarseMaxPoints: two)
       if (vb0 >= nvb) break;
       const int vb = vb0 + half;
-      const int idx = vb * kLmBlock + tl;
       float r = 0.0f, w = 0.0f, J[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
       bool valid = false;
       if (a.robust == 2) {
@@ -1757,9 +1765,8 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
 #pragma unroll
         for (int i = 0; i < 6; i++) J[i] = td_J[vb0 / 2][i];
         if (valid) w = robust_weight(r, 2, a.huber_delta, td_scale_sqr);
-      } else if (vb < nvb && idx < L.n) {
-        const PointK p = load_point(L.pl, idx);
-        if (point_residual(p, T, L.k, L.I2, L.rows, L.cols, &r, J)) {
+      } else if (cpt_ok[vb0 / 2]) {
+        if (point_residual(cpt[vb0 / 2], T, L.k, L.I2, L.rows, L.cols, &r, J)) {
           w = robust_weight(r, a.robust, a.huber_delta, 1.0f);
           valid = true;
         }

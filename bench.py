@@ -303,7 +303,7 @@ def dense_1080p_leg(api, synth, n_frames=5, passes=3):
                      "(28 fp64 FMAs, 23 fp32<->fp64 conversions, 3 + 1 reciprocals); see DESIGN.md section 5.1")
 
 
-def disparity_leg(api, seq, trk):
+def disparity_leg(api, seq, trk, time_cpu=True):
     """BASELINE.json configs[4]: stereo disparity line search at 1241x376, reference range and +-128 px — with the runner's
     DepthEstimator arguments (run_odometry_kitti_offline.cpp:58-70: the operating point of every tracked frame) and with
     test_disparity.cpp's own (:68-75: 35-grey-level selection threshold, 3-17 m window, 100 depth-LM iterations). Per case: the three
@@ -314,14 +314,18 @@ def disparity_leg(api, seq, trk):
     import tempfile
     from oracle import cpu_baseline as cb
     out = {}
-    cpu = {}
+    cpu = dict(error="skipped (--no-child-processes)")
     try:
+        if not time_cpu:   # under rocprofv3 a child would inherit the profiler's preload: spawn nothing
+            raise InterruptedError
         with tempfile.TemporaryDirectory(dir="/tmp") as td:
             path = os.path.join(td, "pair.npz")
             np.savez(path, left=seq["left"][0], right=seq["right"][0])
             p = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--depth", path],
                                capture_output=True, text=True, timeout=900)
             cpu = json.loads(p.stdout.strip().splitlines()[-1]) if p.returncode == 0 else dict(error=p.stderr[-500:])
+    except InterruptedError:
+        pass
     except Exception as e:   # noqa: BLE001
         cpu = dict(error=f"{type(e).__name__}: {e}"[:300])
     ctx = api.Context(0)
@@ -885,6 +889,135 @@ def configs3_leg(api, seqs, my_ids, n_sequences, world, rank, local_rank, backen
                      "(odo_tracker_batch), schedule-based pose gather" % (n_sequences, world))
 
 
+COMPACT_MAX_BYTES = 4096   # the driver reads the LAST stdout line; round 5's 21 KB line came back unparsed
+
+
+def _dig(d, *path, default=None):
+    """d[path[0]][path[1]]... or `default` when any key / index is missing (legs may have failed or been skipped)."""
+    for k in path:
+        try:
+            d = d[k]
+        except (KeyError, IndexError, TypeError):
+            return default
+    return d
+
+
+def _finite(o):
+    """Strict JSON: NaN / Infinity become null, numpy scalars become Python ones."""
+    if isinstance(o, dict):
+        return {str(k): _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    if isinstance(o, (np.floating, np.integer, np.bool_)):
+        o = o.item()
+    if isinstance(o, float) and (o != o or o in (float("inf"), float("-inf"))):
+        return None
+    return o
+
+
+def compact_result(out):
+    """The contract line: scalars only, <= COMPACT_MAX_BYTES, strict ASCII JSON. Everything else of `out` (notes, per-level tables,
+    every side leg in full) lives in bench_details.json. Tolerant of missing legs: absent numbers are null."""
+    cfg, roof, cb = out.get("config", {}), out.get("roofline", {}), out.get("cpu_baseline")
+    fine_key = "lm_fine_kernel" if "lm_fine_kernel" in roof else "lm_step_kernel"
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    workload = ("configs[3] %s distinct synthetic KITTI-shaped sequences dealt round-robin over the ranks" % cfg.get("sequences")
+                if out.get("scaling") == "strong" else "configs[1] synthetic KITTI-shaped stereo drive")
+    line["config"] = dict(workload=workload + ", 1241x376, 4 levels, semi-dense, runner params",
+                          drive=cfg.get("drive"), unique_frames=cfg.get("unique_frames"),
+                          sequences_per_gpu=cfg.get("sequences_per_gpu"), sequences=cfg.get("sequences"),
+                          next_frame_announced=bool(cfg.get("next_frame_pyramid_prefetch")))
+    line["roofline"] = dict(bound=roof.get("bound"), kernel="lm_coarse_kernel+" + fine_key, achieved=roof.get("achieved"),
+                            peak=roof.get("peak"), unit=roof.get("unit"), frac=roof.get("frac"), traffic=roof.get("traffic"),
+                            traffic_source=(roof.get("traffic_source") or "")[:96] or None,
+                            algorithmic_bytes_per_frame=roof.get("algorithmic_bytes_per_frame"),
+                            evaluations_per_frame=roof.get("evaluations_per_frame"),
+                            kernel_us_per_frame=roof.get("kernel_us_per_frame"),
+                            coarse_us=_dig(roof, "lm_coarse_kernel", "launch_us"), fine_us=_dig(roof, fine_key, "launch_us"),
+                            kernel_time_fits_in_step=roof.get("kernel_time_fits_in_step"))
+    if cb is not None:
+        line["cpu_baseline"] = dict(value=cb.get("value"), unit=cb.get("unit"), cores=cb.get("cores"), kind=cb.get("kind"),
+                                    sample=(cb.get("sample") or "")[:120], host_cpu=cb.get("host_cpu"),
+                                    host_logical_cpus=cb.get("host_logical_cpus"), solve_ms=cb.get("solve_ms"),
+                                    compute_depth_ms=cb.get("compute_depth_ms"),
+                                    fused=dict(value=_dig(cb, "fused", "value"), unit="frames/s"),
+                                    gpu_same_sample_fps=_dig(cb, "gpu_same_sample", "value"))
+    for k in ("pose_max_abs_delta_vs_oracle", "speedup_vs_cpu", "speedup_vs_cpu_fused", "value_without_announced_frames",
+              "timed_run_poses_bit_identical_to_plain_pass", "timed_run_passes_repeat_bit_for_bit", "lm_evals_per_frame", "keyframes"):
+        if k in out:
+            line[k] = out[k]
+    if "step_us" in out:
+        line["step_us_median"] = _dig(out, "step_us", "median")
+    # one scalar per side leg
+    side = dict(
+        dense_1080p_frac=_dig(out, "roofline_dense_1080p", "frac"),
+        dense_1080p_launch_us=_dig(out, "roofline_dense_1080p", "launch_us"),
+        dense_1080p_fps=_dig(out, "roofline_dense_1080p", "frames_per_s"),
+        scan_us=_dig(out, "disparity_1241x376", "full_range", "scan_us"),
+        scan_max128_us=_dig(out, "disparity_1241x376", "max128", "scan_us"),
+        compute_depth_us=_dig(out, "disparity_1241x376", "full_range", "compute_depth_us"),
+        single_pair_huber_ms=_dig(out, "single_pair_1241x376", "huber", "gpu_solve_ms"),
+        single_pair_tdist_ms=_dig(out, "single_pair_1241x376", "t_distribution", "gpu_solve_ms"),
+        stress_drive_fps=_dig(out, "stress_drive", "frames_per_s"),
+        saturated_keyframe_fps=_dig(out, "saturated_keyframe", "frames_per_s"),
+        shim_standin_preloaded_fps=_dig(out, "shim_path", "frames_per_s"),
+        shim_cvmat_load_per_frame_fps=_dig(out, "shim_path_load_per_frame", "cvmat", "frames_per_s"),
+        shim_cvmat_preloaded_fps=_dig(out, "shim_path_cvmat", "preloaded", "frames_per_s"),
+        pcie_inclusive_fps=_dig(out, "pcie_inclusive", "frames_per_s"))
+    for b in _dig(out, "batched_sequences", "batched", default=[]) or []:
+        side["batched_s%d_fps" % b.get("sequences", 0)] = b.get("frames_per_s")
+    line.update({k: v for k, v in side.items() if v is not None})
+    if "pose_gather" in out:   # N > 1: the evidence that the exchange spanned N ranks on N devices, scalars only
+        pg = out["pose_gather"]
+        line["pose_gather"] = {k: pg.get(k) for k in ("backend", "rccl_ranks_seen", "distinct_devices", "complete", "collectives",
+                                                      "rank0_rows_match_tracked_poses")}
+    if "per_rank" in out:
+        line["per_rank"] = dict(frames_per_s=_dig(out, "per_rank", "frames_per_s"),
+                                slowest_over_fastest_seconds=_dig(out, "per_rank", "slowest_over_fastest_seconds"))
+    for k in out:
+        if k.startswith("configs3_sequences_") and isinstance(out[k], dict):
+            line[k] = dict(frames_per_s=out[k].get("frames_per_s"), scaling=out[k].get("scaling"),
+                           gather_complete=_dig(out[k], "pose_gather", "complete"))
+    errs = sorted(k for k in out if k.endswith("_error"))
+    if errs:
+        line["failed_legs"] = errs
+    line["details"] = out.get("details_file", "bench_details.json")
+    return _finite(line)
+
+
+def format_result_line(out):
+    """compact_result(out) as one ASCII line of strict JSON that fits COMPACT_MAX_BYTES: should a future key push it over, the
+    optional side scalars are dropped from the end until it fits (the contract keys never are)."""
+    line = compact_result(out)
+    text = json.dumps(line, allow_nan=False, ensure_ascii=True, separators=(",", ":"))
+    contract = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "details"}
+    while len(text) >= COMPACT_MAX_BYTES:
+        extra = [k for k in line if k not in contract]
+        if not extra:
+            break
+        line.pop(extra[-1])
+        line["truncated"] = True
+        contract.add("truncated")
+        text = json.dumps(line, allow_nan=False, ensure_ascii=True, separators=(",", ":"))
+    return text
+
+
+def emit_result(out, details_path="bench_details.json"):
+    """Full record -> bench_details.json (and one stderr line); the compact contract line -> the LAST line of stdout."""
+    full = _finite(out)
+    try:
+        with open(details_path, "w") as f:
+            json.dump(full, f, allow_nan=False, indent=1)
+            f.write("\n")
+    except OSError as e:
+        print(f"bench.py: could not write {details_path}: {e}", file=sys.stderr)
+    print("[bench details] " + json.dumps(full, allow_nan=False), file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    print(format_result_line(out), flush=True)
+
+
 def launch_ranks(n, argv, timeout=3600):
     """`bench.py --gpus N` started plainly (no WORLD_SIZE): start the N ranks as a child torch.distributed.run — one process per
     GPU, rendezvous on 127.0.0.1 — BEFORE this process has touched the GPU (it never does), relay rank 0's JSON line, and return
@@ -990,6 +1123,13 @@ def main():
     ap.add_argument("--configs3", type=int, default=11,
                     help="N > 1 runs: after the headline region, BASELINE.json configs[3] as an extra key of the same line — this "
                          "many distinct sequences (11 = KITTI 00-10) dealt over the ranks, batched ranks (0 = skip)")
+    ap.add_argument("--no-child-processes", action="store_true",
+                    help="profiled runs: the disparity leg does not spawn oracle/cpu_baseline.py (its CPU columns are omitted); use "
+                         "with --cpu-frames 0 and without the shim leg so that the profiled process has no children at all")
+    ap.add_argument("--details", default="bench_details.json",
+                    help="file the full record goes to (notes, per-level tables, every side leg); stdout's last line is the compact one")
+    ap.add_argument("--no-causal", action="store_true",
+                    help="skip the second pass that times the same steps with no frame announced ahead (value_without_announced_frames)")
     ap.add_argument("--launch-probe", default="", help=argparse.SUPPRESS)
     ap.add_argument("--no-batch", action="store_true",
                     help="--sequences: a rank that holds several sequences tracks them one after the other (one odo_tracker) instead "
@@ -1098,7 +1238,7 @@ def main():
     poses_abs = np.zeros((n_my, n_total, 16), np.float32)
     kf_flags = np.zeros((n_my, n_total), np.int32)
 
-    def step(j, k, dv, publish):
+    def step(j, k, dv, publish, announce=True):
         """Step k (frame order[k]) of this rank's j-th sequence, whose frames are dv."""
         i = order[k]
         if begins_pass(order, k):
@@ -1106,7 +1246,7 @@ def main():
         # Frames are resident: the next frame is announced, so its pyramid and the head of its Solve overlap this frame's tail
         # (odo_tracker_hint_next). Not across the start of the clock: the last warm-up step announces nothing, so no work of
         # the first timed step runs before t0.
-        if not args.no_prefetch and k + 1 < n_total and k + 1 != args.warmup:
+        if announce and not args.no_prefetch and k + 1 < n_total and k + 1 != args.warmup:
             trk.hint_next(*dv[order[k + 1]])
         kf_flags[j, k] = trk.track_into(dv[i][0], dv[i][1], poses_kf[j, k], poses_abs[j, k])
         if publish and gatherer is not None:    # RCCL all_gather over xGMI every gather_every frames
@@ -1333,137 +1473,163 @@ def main():
                    lm_evals_per_frame=round(float(np.mean(evals)), 2),
                    host_us_per_frame={k: round(v, 1) for k, v in host_timing.items()},
                    keyframes=trk.stats()["n_keyframes"])
-        if args.sequences == 0 and my_seq_ids:
-            # spread of the timed steps (host clock per step; their sum is the timed region): noise vs regression for a reader
-            us = step_s * 1e6
-            out["step_us"] = dict(median=round(float(np.median(us)), 1), p10=round(float(np.percentile(us, 10)), 1),
-                                  p90=round(float(np.percentile(us, 90)), 1), min=round(float(us.min()), 1), max=round(float(us.max()), 1),
-                                  slowest_step=int(np.argmax(us)), first_step=round(float(us[0]), 1))
-            # does the tracker track? absolute poses of the first pass over the drive against the synthetic ground truth
-            # (ref: run_odometry_kitti_offline.cpp:361-372 prints this mean translation error)
-            m = min(n_total, args.unique_frames - 1)
-            e_abs, e_rel = tracking_error(poses_abs[0, :m], seq["poses"], order[:m], poses_kf[0, :m], kf_flags[0, :m])
-            out["tracking_error_vs_ground_truth_m"] = dict(
-                tracking_summary(e_abs, e_rel),
-                note="first pass over the drive (warm-up frames included). rel = this frame's pose_to_keyframe against the true motion "
-                     "since its keyframe; abs = absolute pose, which keeps every earlier miss: a keyframe switch whose first Solve "
-                     "misses (the reference resets to the pose relative to the OLD keyframe, ref: run_odometry_kitti_offline.cpp:"
-                     "261-262) bakes its error into all later absolute poses")
-        if c3 is not None:
-            out["configs3_sequences_%d" % args.configs3] = c3
-        if world > 1:
-            fr = [per_rank[r] / t if t > 0 else 0.0 for r, t in enumerate(rank_elapsed)]
-            out["per_rank"] = dict(frames=per_rank, seconds=[round(t, 4) for t in rank_elapsed], frames_per_s=[round(f, 1) for f in fr],
-                                   slowest_over_fastest_seconds=round(max(rank_elapsed) / max(min(rank_elapsed), 1e-9), 3))
-        if args.sequences == 0 and n_total > args.unique_frames - 1:
-            # determinism of the timed run: every later pass over the drive (re-initialised on frame 0) repeats the first one
-            per = args.unique_frames - 1
-            same = all(np.array_equal(poses_kf[0, k], poses_kf[0, k % per]) and np.array_equal(poses_abs[0, k], poses_abs[0, k % per])
-                       for k in range(per, n_total))
-            out["timed_run_passes_repeat_bit_for_bit"] = bool(same)
-        if gatherer is not None:
-            # the exchange itself, checked: every rank's rows arrived on rank 0, and rank 0's own rows are the poses it tracked
-            got = [int(gatherer.rows(r).shape[0]) for r in range(world)]
-            out["pose_gather"] = dict(rows_per_rank=got, complete=(got == per_rank), collectives=gatherer.issued,
-                                      rows_per_collective=gatherer.every, backend=exchange["backend"],
-                                      rccl_ranks_seen=exchange["ranks_seen"] if exchange["backend"] == "nccl" else None,
-                                      ranks_seen=exchange["ranks_seen"], distinct_devices=exchange["distinct_devices"])
-            if my_seq_ids:
-                mine = gatherer.poses(0, seq_id=my_seq_ids[0])
-                want = poses_abs[0, args.warmup:].reshape(-1, 4, 4).transpose(0, 2, 1)[:, :3, :]
-                out["pose_gather"]["rank0_rows_match_tracked_poses"] = bool(np.array_equal(mine, want))
-        if world == 1 and args.cpu_frames > 0:
-            if os.environ.get("ODO_LOG_GIVEUPS"):
-                print("[bench phase] cpu_baseline + plain GPU pass", file=sys.stderr, flush=True)
-            n = min(args.cpu_frames, args.steps, args.unique_frames - 1)
-            try:
-                cb = cpu_baseline(seq, n, max(min(n, 20), n // 2))   # >= 20 frames of each shape whenever the run has them
-            except Exception as e:   # noqa: BLE001 — the headline line is printed regardless: fall back to this process
-                out["cpu_baseline_error"] = f"{type(e).__name__}: {e}"[:500]
-                cb = cpu_baseline_inprocess(seq, n)
-            cpu_poses = [np.array(p) for p in cb.pop("poses")]
-            # fresh GPU pass over the same frames from the same start: full-pipeline parity next to the timing
-            trk2 = api.Tracker(local_rank, overlap_depth=0 if args.no_overlap else args.overlap)
-            dev2 = [(trk2.upload_frame(l), trk2.upload_frame(r)) for l, r in zip(seq["left"][:n + 1], seq["right"][:n + 1])]
-            trk2.init(*dev2[0])
-            gpu_poses = []
-            torch.cuda.synchronize()
-            tg = time.perf_counter()
-            for j in range(1, n + 1):
-                gpu_poses.append(trk2.track(*dev2[j])["pose_to_keyframe"])
-            torch.cuda.synchronize()
-            gpu_same_fps = n / (time.perf_counter() - tg)   # the GPU on exactly the frames the CPU sample covers
-            dmax = max(float(np.abs(gpu_poses[j].astype(np.float64) - cpu_poses[j]).max()) for j in range(n))
-            trk2.close()
-            ref, fus = cb["reference_shape"], cb["fused"]
-            out["cpu_baseline"] = dict(
-                value=ref["frames_per_s"], unit="frames/s", cores=1, kind="port", host_cpu=cb["host_cpu"],
-                host_logical_cpus=cb["host_logical_cpus"], build=cb["build"], pinned_to_cpu=cb["pinned_to_cpu"],
-                sample=f"frames 1..{ref['frames']} of the same sequence after {cb['warmup_frames']} warm-up frames, one pinned core, "
-                       f"per-frame median; LM pass shaped like the reference (ComputeResidualJacobianNaive + OptimizeCameraPose: "
-                       f"materialised N x 6 Jacobian, per-pixel pow / GetCxLevel, separate fp32 product passes), {ref['total_s']} s",
-                solve_ms=ref["solve_ms_median"], compute_depth_ms=ref["compute_depth_ms_median"], frame_ms=ref["frame_ms_median"],
-                fused=dict(value=fus["frames_per_s"], unit="frames/s", cores=1, solve_ms=fus["solve_ms_median"],
-                           compute_depth_ms=fus["compute_depth_ms_median"], frame_ms=fus["frame_ms_median"],
-                           sample=f"frames 1..{fus['frames']}, the parity oracle itself (one residual / Jacobian pass, fp64 sums), "
-                                  f"{fus['total_s']} s"),
-                gpu_same_sample=dict(value=round(gpu_same_fps, 1), unit="frames/s"))
-            out["pose_max_abs_delta_vs_oracle"] = dmax
-            # the timed run itself (next frame announced: pyramid prefetch, early Solve, depth stream a frame ahead) against this
-            # plain pass over the same frames: the first pass of the drive, before any re-initialisation
-            if args.sequences == 0:
-                m = min(n, n_total, args.unique_frames - 1)
-                timed = poses_kf[0, :m].reshape(m, 4, 4).transpose(0, 2, 1)
-                out["timed_run_poses_bit_identical_to_plain_pass"] = bool(
-                    all(np.array_equal(timed[j], gpu_poses[j]) for j in range(m)))
-                out["timed_run_frames_checked"] = m
-            # like for like: the start of a drive is its most expensive stretch (40-70 LM evaluations per frame against
-            # ~25 later), so the ratios are taken on the same frames, not against the whole-run rate
-            out["speedup_vs_cpu"] = round(gpu_same_fps / ref["frames_per_s"], 1)
-            out["speedup_vs_cpu_fused"] = round(gpu_same_fps / fus["frames_per_s"], 1)
-        if world == 1 and not args.no_extras:
-            import contextlib
-            with contextlib.redirect_stdout(sys.stderr):  # the mirrored classes print the reference's own messages
-                legs = set(args.extras.split(","))
+        out["details_file"] = args.details
+        try:   # whatever fails below, the contract line is printed (a failing side measurement is named in it)
+            if world == 1 and args.sequences == 0 and my_seq_ids and not args.no_prefetch and not args.no_causal:
+                # The causal rate: the same warm-up + steps with NO frame announced ahead (what a live camera allows). The poses of
+                # this pass must repeat the timed run's bit for bit (announcing only moves work earlier).
+                keep_kf, keep_abs = poses_kf.copy(), poses_abs.copy()
+                trk.init(*dev[0])
+                for k in range(args.warmup):
+                    step(0, k, dev, False, announce=False)
+                gc.collect()
+                gc.disable()
+                torch.cuda.synchronize()
+                tc = time.perf_counter()
+                for k in range(args.warmup, n_total):
+                    step(0, k, dev, False, announce=False)
+                torch.cuda.synchronize()
+                causal_s = time.perf_counter() - tc
+                gc.enable()
+                out["value_without_announced_frames"] = round(args.steps / causal_s, 2)
+                out["unannounced_pass_poses_bit_identical"] = bool(np.array_equal(poses_kf, keep_kf) and np.array_equal(poses_abs, keep_abs))
+                poses_kf[:], poses_abs[:] = keep_kf, keep_abs
+            if args.sequences == 0 and my_seq_ids:
+                # spread of the timed steps (host clock per step; their sum is the timed region): noise vs regression for a reader
+                us = step_s * 1e6
+                out["step_us"] = dict(median=round(float(np.median(us)), 1), p10=round(float(np.percentile(us, 10)), 1),
+                                      p90=round(float(np.percentile(us, 90)), 1), min=round(float(us.min()), 1), max=round(float(us.max()), 1),
+                                      slowest_step=int(np.argmax(us)), first_step=round(float(us[0]), 1))
+                # does the tracker track? absolute poses of the first pass over the drive against the synthetic ground truth
+                # (ref: run_odometry_kitti_offline.cpp:361-372 prints this mean translation error)
+                m = min(n_total, args.unique_frames - 1)
+                e_abs, e_rel = tracking_error(poses_abs[0, :m], seq["poses"], order[:m], poses_kf[0, :m], kf_flags[0, :m])
+                out["tracking_error_vs_ground_truth_m"] = dict(
+                    tracking_summary(e_abs, e_rel),
+                    note="first pass over the drive (warm-up frames included). rel = this frame's pose_to_keyframe against the true motion "
+                         "since its keyframe; abs = absolute pose, which keeps every earlier miss: a keyframe switch whose first Solve "
+                         "misses (the reference resets to the pose relative to the OLD keyframe, ref: run_odometry_kitti_offline.cpp:"
+                         "261-262) bakes its error into all later absolute poses")
+            if c3 is not None:
+                out["configs3_sequences_%d" % args.configs3] = c3
+            if world > 1:
+                fr = [per_rank[r] / t if t > 0 else 0.0 for r, t in enumerate(rank_elapsed)]
+                out["per_rank"] = dict(frames=per_rank, seconds=[round(t, 4) for t in rank_elapsed], frames_per_s=[round(f, 1) for f in fr],
+                                       slowest_over_fastest_seconds=round(max(rank_elapsed) / max(min(rank_elapsed), 1e-9), 3))
+            if args.sequences == 0 and n_total > args.unique_frames - 1:
+                # determinism of the timed run: every later pass over the drive (re-initialised on frame 0) repeats the first one
+                per = args.unique_frames - 1
+                same = all(np.array_equal(poses_kf[0, k], poses_kf[0, k % per]) and np.array_equal(poses_abs[0, k], poses_abs[0, k % per])
+                           for k in range(per, n_total))
+                out["timed_run_passes_repeat_bit_for_bit"] = bool(same)
+            if gatherer is not None:
+                # the exchange itself, checked: every rank's rows arrived on rank 0, and rank 0's own rows are the poses it tracked
+                got = [int(gatherer.rows(r).shape[0]) for r in range(world)]
+                out["pose_gather"] = dict(rows_per_rank=got, complete=(got == per_rank), collectives=gatherer.issued,
+                                          rows_per_collective=gatherer.every, backend=exchange["backend"],
+                                          rccl_ranks_seen=exchange["ranks_seen"] if exchange["backend"] == "nccl" else None,
+                                          ranks_seen=exchange["ranks_seen"], distinct_devices=exchange["distinct_devices"])
+                if my_seq_ids:
+                    mine = gatherer.poses(0, seq_id=my_seq_ids[0])
+                    want = poses_abs[0, args.warmup:].reshape(-1, 4, 4).transpose(0, 2, 1)[:, :3, :]
+                    out["pose_gather"]["rank0_rows_match_tracked_poses"] = bool(np.array_equal(mine, want))
+            if world == 1 and args.cpu_frames > 0:
+                if os.environ.get("ODO_LOG_GIVEUPS"):
+                    print("[bench phase] cpu_baseline + plain GPU pass", file=sys.stderr, flush=True)
+                n = min(args.cpu_frames, args.steps, args.unique_frames - 1)
+                try:
+                    cb = cpu_baseline(seq, n, max(min(n, 20), n // 2))   # >= 20 frames of each shape whenever the run has them
+                except Exception as e:   # noqa: BLE001 — the headline line is printed regardless: fall back to this process
+                    out["cpu_baseline_error"] = f"{type(e).__name__}: {e}"[:500]
+                    cb = cpu_baseline_inprocess(seq, n)
+                cpu_poses = [np.array(p) for p in cb.pop("poses")]
+                # fresh GPU pass over the same frames from the same start: full-pipeline parity next to the timing
+                trk2 = api.Tracker(local_rank, overlap_depth=0 if args.no_overlap else args.overlap)
+                dev2 = [(trk2.upload_frame(l), trk2.upload_frame(r)) for l, r in zip(seq["left"][:n + 1], seq["right"][:n + 1])]
+                trk2.init(*dev2[0])
+                gpu_poses = []
+                torch.cuda.synchronize()
+                tg = time.perf_counter()
+                for j in range(1, n + 1):
+                    gpu_poses.append(trk2.track(*dev2[j])["pose_to_keyframe"])
+                torch.cuda.synchronize()
+                gpu_same_fps = n / (time.perf_counter() - tg)   # the GPU on exactly the frames the CPU sample covers
+                dmax = max(float(np.abs(gpu_poses[j].astype(np.float64) - cpu_poses[j]).max()) for j in range(n))
+                trk2.close()
+                ref, fus = cb["reference_shape"], cb["fused"]
+                out["cpu_baseline"] = dict(
+                    value=ref["frames_per_s"], unit="frames/s", cores=1, kind="port", host_cpu=cb["host_cpu"],
+                    host_logical_cpus=cb["host_logical_cpus"], build=cb["build"], pinned_to_cpu=cb["pinned_to_cpu"],
+                    sample=f"frames 1..{ref['frames']} of the same sequence after {cb['warmup_frames']} warm-up frames, one pinned core, "
+                           f"per-frame median; LM pass shaped like the reference (ComputeResidualJacobianNaive + OptimizeCameraPose: "
+                           f"materialised N x 6 Jacobian, per-pixel pow / GetCxLevel, separate fp32 product passes), {ref['total_s']} s",
+                    solve_ms=ref["solve_ms_median"], compute_depth_ms=ref["compute_depth_ms_median"], frame_ms=ref["frame_ms_median"],
+                    fused=dict(value=fus["frames_per_s"], unit="frames/s", cores=1, solve_ms=fus["solve_ms_median"],
+                               compute_depth_ms=fus["compute_depth_ms_median"], frame_ms=fus["frame_ms_median"],
+                               sample=f"frames 1..{fus['frames']}, the parity oracle itself (one residual / Jacobian pass, fp64 sums), "
+                                      f"{fus['total_s']} s"),
+                    gpu_same_sample=dict(value=round(gpu_same_fps, 1), unit="frames/s"))
+                out["pose_max_abs_delta_vs_oracle"] = dmax
+                # the timed run itself (next frame announced: pyramid prefetch, early Solve, depth stream a frame ahead) against this
+                # plain pass over the same frames: the first pass of the drive, before any re-initialisation
+                if args.sequences == 0:
+                    m = min(n, n_total, args.unique_frames - 1)
+                    timed = poses_kf[0, :m].reshape(m, 4, 4).transpose(0, 2, 1)
+                    out["timed_run_poses_bit_identical_to_plain_pass"] = bool(
+                        all(np.array_equal(timed[j], gpu_poses[j]) for j in range(m)))
+                    out["timed_run_frames_checked"] = m
+                # like for like: the start of a drive is its most expensive stretch (40-70 LM evaluations per frame against
+                # ~25 later), so the ratios are taken on the same frames, not against the whole-run rate
+                out["speedup_vs_cpu"] = round(gpu_same_fps / ref["frames_per_s"], 1)
+                out["speedup_vs_cpu_fused"] = round(gpu_same_fps / fus["frames_per_s"], 1)
+            if world == 1 and not args.no_extras:
+                import contextlib
+                with contextlib.redirect_stdout(sys.stderr):  # the mirrored classes print the reference's own messages
+                    legs = set(args.extras.split(","))
 
-                def leg(key, fn):   # a side measurement that fails must not take the headline JSON line with it
-                    if os.environ.get("ODO_LOG_GIVEUPS"):
-                        print(f"[bench phase] leg {key}", file=sys.stderr, flush=True)
-                    try:
-                        r = fn()
-                        if key is None:
-                            out.update(r)
-                        else:
-                            out[key] = r
-                    except Exception as e:   # noqa: BLE001
-                        out[(key or "shim_path") + "_error"] = f"{type(e).__name__}: {e}"[:500]
-                if stress_seq is not None:
-                    def stress():
-                        r = drive_leg(api, stress_seq, args.warmup, args.steps, local_rank)
-                        r["what"] = ("the 'corridor' drive of rounds 1-2 (value noise + hard-edged tiles): the reference's keyframe policy "
-                                     "loses track at its first keyframe switch there and re-promotes a keyframe on most frames; same "
-                                     "steps / warm-up as the headline, own tracker")
-                        return r
-                    leg("stress_drive", stress)
-                if saturated_seq is not None:
-                    leg("saturated_keyframe", lambda: saturated_leg(api, saturated_seq, args.warmup, args.steps, local_rank))
-                if "dense" in legs:
-                    leg("roofline_dense_1080p", lambda: dense_1080p_leg(api, synth))
-                if "disparity" in legs:
-                    leg("disparity_1241x376", lambda: disparity_leg(api, seq, trk))
-                if "single" in legs:
-                    leg("single_pair_1241x376", lambda: single_pair_leg(api, seq))
-                if "batched" in legs and batch_seqs is not None:
-                    leg("batched_sequences", lambda: batched_sequences_leg(api, batch_seqs))
-                if "shim" in legs:
-                    leg(None, lambda: shim_leg(api, seq, n_frames=min(200, args.unique_frames)))
-                if "multi" in legs:   # last, with every other stream of this process gone (streams share hardware queues)
-                    trk.close()
-                    leg("multi_sequence_1gpu", lambda: [multi_sequence_leg(api, seq, order, n, 200) for n in (2, 4, 8)])
-                if "multiproc" in legs:   # opt-in: child processes that share this GPU
-                    trk.close()
-                    leg("multi_process_1gpu", multi_process_leg)
-        print(json.dumps(out))
+                    def leg(key, fn):   # a side measurement that fails must not take the headline JSON line with it
+                        if os.environ.get("ODO_LOG_GIVEUPS"):
+                            print(f"[bench phase] leg {key}", file=sys.stderr, flush=True)
+                        try:
+                            r = fn()
+                            if key is None:
+                                out.update(r)
+                            else:
+                                out[key] = r
+                        except Exception as e:   # noqa: BLE001
+                            out[(key or "shim_path") + "_error"] = f"{type(e).__name__}: {e}"[:500]
+                    if stress_seq is not None:
+                        def stress():
+                            r = drive_leg(api, stress_seq, args.warmup, args.steps, local_rank)
+                            r["what"] = ("the 'corridor' drive of rounds 1-2 (value noise + hard-edged tiles): the reference's keyframe policy "
+                                         "loses track at its first keyframe switch there and re-promotes a keyframe on most frames; same "
+                                         "steps / warm-up as the headline, own tracker")
+                            return r
+                        leg("stress_drive", stress)
+                    if saturated_seq is not None:
+                        leg("saturated_keyframe", lambda: saturated_leg(api, saturated_seq, args.warmup, args.steps, local_rank))
+                    if "dense" in legs:
+                        leg("roofline_dense_1080p", lambda: dense_1080p_leg(api, synth))
+                    if "disparity" in legs:
+                        leg("disparity_1241x376", lambda: disparity_leg(api, seq, trk, time_cpu=not args.no_child_processes))
+                    if "single" in legs:
+                        leg("single_pair_1241x376", lambda: single_pair_leg(api, seq))
+                    if "batched" in legs and batch_seqs is not None:
+                        leg("batched_sequences", lambda: batched_sequences_leg(api, batch_seqs))
+                    if "shim" in legs:
+                        leg(None, lambda: shim_leg(api, seq, n_frames=min(200, args.unique_frames)))
+                    if "multi" in legs:   # last, with every other stream of this process gone (streams share hardware queues)
+                        trk.close()
+                        leg("multi_sequence_1gpu", lambda: [multi_sequence_leg(api, seq, order, n, 200) for n in (2, 4, 8)])
+                    if "multiproc" in legs:   # opt-in: child processes that share this GPU
+                        trk.close()
+                        leg("multi_process_1gpu", multi_process_leg)
+        except Exception as e:   # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            out["bench_error"] = f"{type(e).__name__}: {e}"[:300]
+        finally:
+            emit_result(out, args.details)
     trk.close()
     if world > 1:
         dist.destroy_process_group()

@@ -13,19 +13,42 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_bench(extra, world=2, timeout=900, no_extras=True):
+def _run_bench(extra, world=2, timeout=900, no_extras=True, tmp_path=None):
+    """Returns the full record (bench_details.json); the compact stdout line is checked here for the contract: ONE line, strict
+    JSON, under 4 KB, carrying the headline keys (the 21 KB line came back unparsed from the driver)."""
+    import tempfile
+    details = os.path.join(tempfile.mkdtemp(prefix="odo_bench_"), "details.json")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, ODO_BENCH_SHARE_GPU="1", ODO_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--cpu-frames", "0"] + (["--no-extras"] if no_extras else []) + extra
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--cpu-frames", "0", "--details", details] + (["--no-extras"] if no_extras else []) + extra
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]     # rank 0 prints ONE JSON line
-    return json.loads(lines[0])
+    assert p.stdout.rstrip().splitlines()[-1] == lines[0]      # ... and it is the LAST line of stdout
+    assert len(lines[0]) < 4096 and lines[0].isascii()
+    line = json.loads(lines[0], parse_constant=lambda c: pytest.fail("non-strict JSON constant " + c))
+    full = json.load(open(details))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in line, k
+        if k not in ("config", "roofline"):
+            assert line[k] == full[k], k
+    assert line["config"]["workload"] and "model" not in line["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in line["roofline"], k
+    # N > 1: the exchange's evidence and the per-rank rates are in the compact line itself, scalars / flat lists only
+    pg = line["pose_gather"]
+    for k in ("backend", "rccl_ranks_seen", "distinct_devices", "complete"):
+        assert k in pg and not isinstance(pg[k], (dict, list)), k
+    assert pg["complete"] == full["pose_gather"]["complete"]
+    assert len(line["per_rank"]["frames_per_s"]) == world
+    full["_line"] = line
+    return full
 
 
 def test_bench_two_ranks_uneven_sequences():
@@ -54,6 +77,8 @@ def test_bench_two_ranks_carries_configs3_and_exchange_evidence():
     assert out["pose_gather"]["ranks_seen"] == 2 and out["pose_gather"]["backend"] == "gloo"
     assert out["pose_gather"]["distinct_devices"] == 1           # this test shares ONE device between the ranks on purpose
     assert len(out["per_rank"]["frames_per_s"]) == 2 and out["per_rank"]["slowest_over_fastest_seconds"] >= 1.0
+    assert out["_line"]["configs3_sequences_3"]["frames_per_s"] == out["configs3_sequences_3"]["frames_per_s"]
+    assert out["_line"]["configs3_sequences_3"]["gather_complete"] is True
     c3 = out["configs3_sequences_3"]
     assert c3["frames_per_rank"] == [16, 8] and c3["pose_gather"]["complete"] and c3["sequences_in_lock_step_on_rank0"] == 2
     assert c3["frames_per_s"] > 0

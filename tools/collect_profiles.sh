@@ -18,15 +18,15 @@ cd /tmp && export TMPDIR=/tmp
 # them down the launch-per-iteration path — 4 % of the jobs unprofiled (ODO_LOG_GIVEUPS=1 prints the split at exit). The profiled runs
 # keep the unprofiled run's path:
 export ODO_DEPTH_PERSIST_ALWAYS=1
-BENCH="python3 $GRAFT_REPO_ROOT/bench.py --cpu-frames 0 --extras dense,disparity,single,batched,saturated"
+BENCH="python3 $GRAFT_REPO_ROOT/bench.py --cpu-frames 0 --no-child-processes --details $OUT/bench_profiled_details.json --extras dense,disparity,single,batched,saturated"
 timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH --steps 1000 --warmup 50 > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err < /dev/null
 # 1b. the driver's own short run (python bench.py --steps 20 --warmup 5), side legs off: the averages bench.py's roofline line must agree with
-timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats20 -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-frames 0 --no-extras --steps 20 --warmup 5 > $OUT/bench_profiled_steps20.json 2> $OUT/bench_profiled_steps20.err < /dev/null
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats20 -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-frames 0 --no-extras --details $OUT/bench_profiled_steps20_details.json --steps 20 --warmup 5 > $OUT/bench_profiled_steps20.json 2> $OUT/bench_profiled_steps20.err < /dev/null
 timeout -k 5 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH --steps 199 --warmup 5 > /dev/null 2>&1 < /dev/null
 timeout -k 5 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH --steps 199 --warmup 5 > /dev/null 2>&1 < /dev/null
 # 2b / 3b. the same two counters of the HEADLINE ALONE (no side legs, no stress drive): lm_fine_kernel's traffic per launch on the very
 # kernel configuration bench.py's roofline line is printed for (the mixed passes above average three legs' launches)
-HEAD="python3 $GRAFT_REPO_ROOT/bench.py --cpu-frames 0 --no-extras --no-stress --steps 199 --warmup 5"
+HEAD="python3 $GRAFT_REPO_ROOT/bench.py --cpu-frames 0 --no-extras --no-stress --details /tmp/head_details.json --steps 199 --warmup 5"
 timeout -k 5 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_headline -- $HEAD > /dev/null 2>&1 < /dev/null
 timeout -k 5 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_headline -- $HEAD > /dev/null 2>&1 < /dev/null
 F="-O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fhip-fp32-correctly-rounded-divide-sqrt"

@@ -1,14 +1,19 @@
-"""Prints the headline numbers of bench.py JSON lines: python tools/show_bench.py <file> [...]  (or JSON lines on stdin when
+"""Prints the headline numbers of bench.py records (bench_details.json, or the JSON lines of earlier rounds): python tools/show_bench.py <file> [...]  (or JSON lines on stdin when
 no file is given AND stdin is not a terminal; never blocks on an interactive stdin)."""
 import json
 import sys
 
 
 def show(lines):
-    for line in lines:
-        if '"metric"' not in line:
+    text = "".join(lines)
+    try:   # bench_details.json (one indented record) ...
+        records = [json.loads(text)]
+    except ValueError:   # ... or JSON lines (the records of rounds 1-5 under profiles/)
+        records = [json.loads(line) for line in text.splitlines() if '"metric"' in line]
+    for d in records:
+        if 'lm_coarse_kernel' not in d.get('roofline', {}):
+            print('compact line (details in', d.get('details'), '):', json.dumps(d, indent=1))
             continue
-        d = json.loads(line)
         r = d['roofline']
         print('fps', d['value'], 'ms', d['ms_per_step'], 'host', d['host_us_per_frame'])
         fk = 'lm_fine_kernel' if 'lm_fine_kernel' in r else 'lm_step_kernel'

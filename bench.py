@@ -429,13 +429,13 @@ def shim_leg(api, seq, n_frames=100, passes=3):
       shim_path_cvmat            the build INTEGRATION.md prescribes (-DODOMETRY_SHIM_WITH_OPENCV -DODOMETRY_SHIM_WITH_EIGEN, here
                                  against tests/stubs: pageable cv::Mat, nothing reports writes — fingerprint-checked device mirrors),
                                  every frame preloaded in its own cv::Mat
-    cv::Mat rows come four ways: outputs in host memory when ComputeDepth returns (the reference's contract; default: built while Solve
-    waits and handed over by header assignment where the caller's output Mat is the caller's alone), the same written into the
-    caller's buffers always (ODOMETRY_SHIM_KEEP_OUTPUT_BUFFERS=1),
-    ODOMETRY_SHIM_LAZY_OUTPUTS=1 (left_disp / left_dep stay on the device until odometry::Download), and the default again with
-    ODOMETRY_SHIM_NO_MALLOPT=1: without the header's one-time mallopt() that tells glibc to keep the pages of the runner's per-frame
-    output Mats (three fresh Mats per frame otherwise cost ~1 000 page faults per frame, in ComputeDepth's copy-out and in the Mats'
-    destructors).
+    cv::Mat rows: the DEFAULT (outputs written into the caller's own buffers before ComputeDepth returns — the reference's contract,
+    src/depth_estimate.cpp:176-191,388-397 — and the process's allocator left alone), ODOMETRY_SHIM_LAZY_OUTPUTS=1 (left_disp /
+    left_dep stay on the device until odometry::Download), and the two opt-ins of round 5's defaults (ADVICE r05: both changed what a
+    caller can observe, so both are off unless asked for): ODOMETRY_SHIM_TUNE_MALLOC=1 (one-time mallopt() that tells glibc to keep
+    the pages of the runner's three fresh output Mats per frame: ~1 000 page faults per frame otherwise) and, on top of it,
+    ODOMETRY_SHIM_SWAP_OUTPUTS=1 (outputs built while Solve waits and handed over by header assignment where the caller's output Mat
+    is the caller's alone).
     pcie_inclusive: the same loop through the host-buffer entry points of the C ABI from Python (odo_pyramid_create /
     odo_depth_compute on pageable numpy arrays: every input staged and uploaded at every use, every output downloaded at once)."""
     import re
@@ -445,7 +445,8 @@ def shim_leg(api, seq, n_frames=100, passes=3):
     L, R = seq["left"][:n_frames], seq["right"][:n_frames]
     lib = ["-L" + os.path.join(ROOT, "odometry_amd", "lib"), "-lodometry_hip", "-Wl,-rpath," + os.path.join(ROOT, "odometry_amd", "lib")]
     src = os.path.join(ROOT, "examples", "run_odometry_synth.cpp")
-    no_mallopt = {"ODOMETRY_SHIM_NO_MALLOPT": "1"}
+    tune = {"ODOMETRY_SHIM_TUNE_MALLOC": "1"}
+    tune_swap = {"ODOMETRY_SHIM_TUNE_MALLOC": "1", "ODOMETRY_SHIM_SWAP_OUTPUTS": "1"}
     with tempfile.TemporaryDirectory(dir="/tmp") as td:
         exe, exe_cv = os.path.join(td, "run_odometry_synth"), os.path.join(td, "run_odometry_synth_cv")
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), src, "-o", exe] + lib)
@@ -476,11 +477,11 @@ def shim_leg(api, seq, n_frames=100, passes=3):
                 ("standin_load_per_frame", exe, ["--load-per-frame"], None),
                 ("cvmat_preloaded", exe_cv, [], None),
                 ("cvmat_preloaded_lazy_outputs", exe_cv, [], {"ODOMETRY_SHIM_LAZY_OUTPUTS": "1"}),
-                ("cvmat_preloaded_default_allocator", exe_cv, [], no_mallopt),
+                ("cvmat_preloaded_tuned_malloc", exe_cv, [], tune),
                 ("cvmat_load_per_frame", exe_cv, ["--load-per-frame"], None),
-                ("cvmat_load_per_frame_outputs_in_place", exe_cv, ["--load-per-frame"], {"ODOMETRY_SHIM_KEEP_OUTPUT_BUFFERS": "1"}),
                 ("cvmat_load_per_frame_lazy_outputs", exe_cv, ["--load-per-frame"], {"ODOMETRY_SHIM_LAZY_OUTPUTS": "1"}),
-                ("cvmat_load_per_frame_default_allocator", exe_cv, ["--load-per-frame"], no_mallopt)):
+                ("cvmat_load_per_frame_tuned_malloc", exe_cv, ["--load-per-frame"], tune),
+                ("cvmat_load_per_frame_tuned_malloc_swapped_outputs", exe_cv, ["--load-per-frame"], tune_swap)):
             try:
                 mm, r2, stats = run(binary, extra, env)
                 shapes[key] = dict(frames_per_s=float(mm.group(1)), poses_bit_identical_to_shim_path=bool(np.array_equal(r2, shim_rel)))
@@ -508,14 +509,14 @@ def shim_leg(api, seq, n_frames=100, passes=3):
 
     out["shim_path_load_per_frame"] = dict(
         standin=shapes.get("standin_load_per_frame"), cvmat=shapes.get("cvmat_load_per_frame"),
-        cvmat_outputs_in_place=shapes.get("cvmat_load_per_frame_outputs_in_place"),
         cvmat_lazy_outputs=shapes.get("cvmat_load_per_frame_lazy_outputs"),
-        cvmat_default_allocator=shapes.get("cvmat_load_per_frame_default_allocator"),
+        cvmat_tuned_malloc=shapes.get("cvmat_load_per_frame_tuned_malloc"),
+        cvmat_tuned_malloc_swapped_outputs=shapes.get("cvmat_load_per_frame_tuned_malloc_swapped_outputs"),
         what="the reference runner's frame source: gray[0] / gray[1] refilled inside the loop by convertTo from 8-bit images "
              "(run_odometry_kitti_offline.cpp:200,334-359 minus the PNG decoding); the load is inside the clock")
     out["shim_path_cvmat"] = dict(
         preloaded=shapes.get("cvmat_preloaded"), preloaded_lazy_outputs=shapes.get("cvmat_preloaded_lazy_outputs"),
-        preloaded_default_allocator=shapes.get("cvmat_preloaded_default_allocator"),
+        preloaded_tuned_malloc=shapes.get("cvmat_preloaded_tuned_malloc"),
         what="-DODOMETRY_SHIM_WITH_OPENCV -DODOMETRY_SHIM_WITH_EIGEN against tests/stubs, the loop of shim_path: every frame in its own "
              "pageable cv::Mat the classes have never seen (no stereo partner known before ComputeDepth names it: the depth job cannot "
              "run beside the Solve; the load-per-frame rows, where the same two Mats return every frame, can)")
@@ -963,6 +964,7 @@ def compact_result(out):
         saturated_keyframe_fps=_dig(out, "saturated_keyframe", "frames_per_s"),
         shim_standin_preloaded_fps=_dig(out, "shim_path", "frames_per_s"),
         shim_cvmat_load_per_frame_fps=_dig(out, "shim_path_load_per_frame", "cvmat", "frames_per_s"),
+        shim_cvmat_load_per_frame_opt_ins_fps=_dig(out, "shim_path_load_per_frame", "cvmat_tuned_malloc_swapped_outputs", "frames_per_s"),
         shim_cvmat_preloaded_fps=_dig(out, "shim_path_cvmat", "preloaded", "frames_per_s"),
         pcie_inclusive_fps=_dig(out, "pcie_inclusive", "frames_per_s"))
     for b in _dig(out, "batched_sequences", "batched", default=[]) or []:

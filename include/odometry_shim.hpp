@@ -685,13 +685,18 @@ inline odo_ctx* context() {
     // The runner allocates three fresh 0.5-1.9 MB cv::Mats per frame (ref: run_odometry_kitti_offline.cpp:226-228) and frees them at the
     // end of the frame; with glibc's default trim / mmap thresholds every one of those buffers goes back to the kernel and comes back
     // as fresh pages: ~1 000 page faults per frame (400 us at KITTI size), in ComputeDepth's copy-out and in the Mats' destructors.
-    // The header is compiled into the runner: once per process it tells the allocator to keep such blocks (what the environment
-    // variables MALLOC_TRIM_THRESHOLD_ / MALLOC_MMAP_THRESHOLD_ / MALLOC_TOP_PAD_ do). ODOMETRY_SHIM_NO_MALLOPT=1: leave it alone.
+    // Telling the allocator to keep such blocks is worth +6 % (runner shape) to +17 % (preloaded frames), but it is a PROCESS-WIDE policy
+    // (up to 256 MB never trimmed, 64 MB top padding) and a header has no business changing it silently: it is OPT-IN —
+    // ODOMETRY_SHIM_TUNE_MALLOC=1 makes the three mallopt() calls below, once per process, and says so on stderr. The same effect
+    // without the header's help: MALLOC_MMAP_THRESHOLD_=33554432 MALLOC_TRIM_THRESHOLD_=268435456 MALLOC_TOP_PAD_=67108864 in the
+    // runner's environment.
     static const bool tuned = [] {
-      if (std::getenv("ODOMETRY_SHIM_NO_MALLOPT")) return false;
+      if (!std::getenv("ODOMETRY_SHIM_TUNE_MALLOC")) return false;
       mallopt(M_MMAP_THRESHOLD, 32 << 20);
       mallopt(M_TRIM_THRESHOLD, 256 << 20);
       mallopt(M_TOP_PAD, 64 << 20);
+      std::fprintf(stderr, "odometry_shim: ODOMETRY_SHIM_TUNE_MALLOC set: mallopt(M_MMAP_THRESHOLD, 32 MB), mallopt(M_TRIM_THRESHOLD, "
+                           "256 MB), mallopt(M_TOP_PAD, 64 MB) for this process\n");
       return true;
     }();
     (void)tuned;
@@ -881,8 +886,10 @@ struct Lookahead {
   // them over by header assignment where that cannot be observed: a caller's output Mat that is empty, or whose buffer nobody else
   // refers to (cv::Mat::u->refcount == 1 — the runner's, ref: run_odometry_kitti_offline.cpp:226-228), ends up with a buffer of the
   // right size, type and content either way; any other output Mat (a header some other Mat shares, user memory, a view) is written
-  // in place as before. ONE RULE follows, the one every OpenCV function with an output Mat has: a raw pointer taken from an output
-  // Mat before ComputeDepth is not that Mat's data pointer afterwards. ODOMETRY_SHIM_KEEP_OUTPUT_BUFFERS=1: always write in place.
+  // in place as before. ONE RULE would follow, the one every OpenCV function with an output Mat has: a raw pointer taken from an output
+  // Mat before ComputeDepth is not that Mat's data pointer afterwards. The reference writes its outputs in place
+  // (ref: src/depth_estimate.cpp:176-191,388-397), so a caller that is valid against it may hold such a pointer: the hand-over is
+  // therefore OPT-IN (ODOMETRY_SHIM_SWAP_OUTPUTS=1); by default every output is written into the caller's own buffer.
   struct Prepared {
     Mat img[3];                 // val (CV_8U), disp, dep (PixelType)
     int phase = 0;              // 0 none; 1 zero fill under way; 2 zero-filled, the compact block still to come; 3 complete; -1 failed
@@ -897,7 +904,10 @@ struct Lookahead {
 };
 inline Lookahead& lookahead() { static thread_local Lookahead l; return l; }
 #ifdef ODOMETRY_SHIM_WITH_OPENCV
-inline bool keep_output_buffers() { static const bool on = std::getenv("ODOMETRY_SHIM_KEEP_OUTPUT_BUFFERS") != nullptr; return on; }
+inline bool keep_output_buffers() {   // (ODOMETRY_SHIM_KEEP_OUTPUT_BUFFERS: the round-5 opt-out, still honoured)
+  static const bool on = std::getenv("ODOMETRY_SHIM_SWAP_OUTPUTS") == nullptr || std::getenv("ODOMETRY_SHIM_KEEP_OUTPUT_BUFFERS") != nullptr;
+  return on;
+}
 inline void prep_drop(Lookahead& la) {
   for (Mat& m : la.prep.img) m.release();
   la.prep.phase = 0; la.prep.mark = 0;

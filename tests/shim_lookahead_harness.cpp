@@ -10,6 +10,9 @@
 //   shared_outputs   like refill, but ComputeDepth's output Mats are not the caller's alone: left_disp has a second header, left_dep (cv::Mat
 //            build) lies in user memory — the cv::Mat build must then write them IN PLACE (it otherwise hands over images it built while
 //            Solve waited, by header assignment); the checksums are taken through the OTHER header / the user memory
+//   raw_pointers   like refill, and the caller keeps the raw data pointers of its three output Mats from BEFORE ComputeDepth and reads the
+//            results through them — valid against the reference, which writes in place (ref: src/depth_estimate.cpp:176-191,388-397);
+//            exit code 4 if an output Mat came back with another buffer (what ODOMETRY_SHIM_SWAP_OUTPUTS=1 does, hence opt-in)
 // Built twice by the test: with the stand-in Mat (writes are seen through ptr<T>() / at<T>()) and with -DODOMETRY_SHIM_WITH_OPENCV against
 // tests/stubs (a cv::Mat reports nothing: every use fingerprints the pixels). The last line on stderr: SHIM_STATS (ShimStats).
 // Prints one line per frame: pose bits and checksums of the three depth outputs. The test runs every mode with and without
@@ -82,7 +85,13 @@ int main(int argc, char** argv) {
       dep = Mat(rows, cols, PixelType, user_dep.data());   // user memory: nothing but these bytes may receive the image
 #endif
     }
+#ifdef ODOMETRY_SHIM_WITH_OPENCV
+    const unsigned char* raw_before[3] = {val.data, disp.data, dep.data};
+#endif
     const int st = de.ComputeDepth(L, R, val, disp, dep);
+#ifdef ODOMETRY_SHIM_WITH_OPENCV
+    if (mode == "raw_pointers" && (val.data != raw_before[0] || disp.data != raw_before[1] || dep.data != raw_before[2])) return 4;
+#endif
 #ifdef ODOMETRY_SHIM_WITH_OPENCV
     if (mode == "shared_outputs" && (disp_other.data != disp.data || dep.data != reinterpret_cast<unsigned char*>(user_dep.data()))) return 3;
 #endif

@@ -166,9 +166,11 @@ def test_cv_mat_build_has_the_lookahead_and_detects_in_place_writes(tmp_path, mo
         pixels are uploaded, results equal the look-ahead-off run;
       * ODOMETRY_SHIM_VERIFY_MIRRORS=1 (every "unchanged" verdict checked by downloading the mirror and comparing bytes): no failure;
       * ODOMETRY_SHIM_LAZY_OUTPUTS=1 (left_disp / left_dep stay on the device until odometry::Download): the same lines;
-      * the three output images are built while Solve waits and handed over by header assignment when the caller's output Mats are
-        theirs alone (refill: every frame but the first two) — and written IN PLACE when they are not (shared_outputs: a second header
-        on left_disp, left_dep in user memory; ODOMETRY_SHIM_KEEP_OUTPUT_BUFFERS=1): the same lines either way."""
+      * outputs are written IN PLACE by default (the reference does, ref: src/depth_estimate.cpp:176-191,388-397 — a raw
+        pointer taken from an output Mat before ComputeDepth stays that Mat's data pointer: mode raw_pointers); with the opt-in
+        ODOMETRY_SHIM_SWAP_OUTPUTS=1 the three output images are built while Solve waits and handed over by header assignment when
+        the caller's output Mats are theirs alone (refill: every frame but the first two) — and still written in place when they are
+        not (shared_outputs: a second header on left_disp, left_dep in user memory): the same lines either way."""
     from odometry_amd import synth
     seq = synth.make_sequence(10, seed=3)
     L, R = seq["left"], seq["right"]
@@ -186,12 +188,21 @@ def test_cv_mat_build_has_the_lookahead_and_detects_in_place_writes(tmp_path, mo
     assert st["early_adopted"] >= n - 2 and st["early_dropped"] == 0, st
     assert st["delivered"] == 3 * n and st["verify_failures"] == 0, st
     assert st["changed"] >= 2 * (n - 1) - 2, st                        # every refill was noticed
-    assert st["outputs_prepared"] >= n - 2, st                         # the output images were built while Solve waited
-    lines, st = cv("shared_outputs")
+    assert st["outputs_prepared"] == 0, st                             # default: every output written into the caller's buffer
+    lines, st = cv("raw_pointers")                                     # (exit code 4 = an output Mat came back with another buffer)
+    assert lines == base and st["outputs_prepared"] == 0 and st["early_adopted"] >= n - 2, st
+    assert std("raw_pointers")[0] == base
+    swap = dict(ODOMETRY_SHIM_SWAP_OUTPUTS="1")
+    lines, st = cv("refill", **swap)
+    assert lines == base and st["outputs_prepared"] >= n - 2, st       # opt-in: the output images were built while Solve waited
+    lines, st = cv("shared_outputs", **swap)
     assert lines == base and st["outputs_prepared"] == 0 and st["early_adopted"] >= n - 2, st   # ... and never swapped in under a second header
-    assert std("shared_outputs")[0] == base
-    lines, st = cv("refill", ODOMETRY_SHIM_KEEP_OUTPUT_BUFFERS="1")
+    assert std("shared_outputs")[0] == base and cv("shared_outputs")[0] == base
+    lines, st = cv("refill", ODOMETRY_SHIM_SWAP_OUTPUTS="1", ODOMETRY_SHIM_KEEP_OUTPUT_BUFFERS="1")   # round 5's opt-out still wins
     assert lines == base and st["outputs_prepared"] == 0, st
+    exe_cv = _build_cv(tmp_path, "tests/shim_lookahead_harness.cpp", "harness_cv")
+    p = subprocess.run([exe_cv, frames, "raw_pointers"], capture_output=True, text=True, timeout=300, env=dict(os.environ, **swap))
+    assert p.returncode == 4, p.returncode                             # the hand-over IS observable through a raw pointer: hence opt-in
     for mode in ("poke", "poke_left"):
         want = std(mode, True)[0]
         got, st = cv(mode)
@@ -242,7 +253,7 @@ def test_random_walk_over_caller_behaviour_same_results_in_every_build(tmp_path,
     assert got == want and st["verify_failures"] == 0
     assert run("cv", ODOMETRY_SHIM_LAZY_OUTPUTS="1")[0] == want
     assert run("cv", ODOMETRY_SHIM_NO_LOOKAHEAD="1")[0] == want
-    assert run("cv", ODOMETRY_SHIM_KEEP_OUTPUT_BUFFERS="1")[0] == want      # outputs always written in place, never handed over
+    assert run("cv", ODOMETRY_SHIM_SWAP_OUTPUTS="1")[0] == want             # opt-in: outputs handed over by header assignment where unobservable
 
 
 def test_runner_with_load_data_inside_the_loop(tmp_path):

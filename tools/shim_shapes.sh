@@ -33,17 +33,19 @@ run "stand-in load-per-frame      " /tmp/ros_std "--load-per-frame" X=1
 run "stand-in preloaded, no ahead " /tmp/ros_std "" ODOMETRY_SHIM_NO_LOOKAHEAD=1
 run "cv::Mat preloaded            " /tmp/ros_cv "" X=1
 run "cv::Mat load-per-frame       " /tmp/ros_cv "--load-per-frame" X=1
-run "cv::Mat load-per-frame, in place" /tmp/ros_cv "--load-per-frame" ODOMETRY_SHIM_KEEP_OUTPUT_BUFFERS=1
+run "cv::Mat load-per-frame, swapped outputs" /tmp/ros_cv "--load-per-frame" ODOMETRY_SHIM_SWAP_OUTPUTS=1
 run "cv::Mat load-per-frame, lazy " /tmp/ros_cv "--load-per-frame" ODOMETRY_SHIM_LAZY_OUTPUTS=1
 run "cv::Mat preloaded, lazy      " /tmp/ros_cv "" ODOMETRY_SHIM_LAZY_OUTPUTS=1
-M="ODOMETRY_SHIM_NO_MALLOPT=1"   # glibc's default thresholds: the runner's per-frame Mats lose their pages every frame
-run "cv::Mat load-per-frame, default allocator " /tmp/ros_cv "--load-per-frame" $M
-run "cv::Mat preloaded, default allocator      " /tmp/ros_cv "" $M
-run "cv::Mat load-per-frame, lazy, default alloc" /tmp/ros_cv "--load-per-frame" ODOMETRY_SHIM_LAZY_OUTPUTS=1 $M
+M="ODOMETRY_SHIM_TUNE_MALLOC=1"   # opt-in: glibc keeps the pages of the runner's per-frame Mats (default thresholds: lost every frame)
+run "cv::Mat load-per-frame, tuned malloc      " /tmp/ros_cv "--load-per-frame" $M
+run "cv::Mat load-per-frame, tuned malloc + swapped outputs" /tmp/ros_cv "--load-per-frame" $M ODOMETRY_SHIM_SWAP_OUTPUTS=1
+run "cv::Mat preloaded, tuned malloc           " /tmp/ros_cv "" $M
+run "cv::Mat preloaded, tuned malloc + swapped outputs" /tmp/ros_cv "" $M ODOMETRY_SHIM_SWAP_OUTPUTS=1
+run "cv::Mat load-per-frame, lazy, tuned malloc" /tmp/ros_cv "--load-per-frame" ODOMETRY_SHIM_LAZY_OUTPUTS=1 $M
 run "cv::Mat load-per-frame, no ahead" /tmp/ros_cv "--load-per-frame" ODOMETRY_SHIM_NO_LOOKAHEAD=1
 run "cv::Mat load-per-frame, verify  " /tmp/ros_cv "--load-per-frame" ODOMETRY_SHIM_VERIFY_MIRRORS=1
-echo "== /tmp/ros_cv --load-per-frame, default allocator"; env $M ODO_RUNNER_PHASES=1 /tmp/ros_cv /tmp/frames_shapes.bin --load-per-frame --time 1 2>&1 >/dev/null | grep -E "runner phases|SHIM_STATS" | tail -2
-echo "== /tmp/ros_cv, default allocator"; env $M ODO_RUNNER_PHASES=1 /tmp/ros_cv /tmp/frames_shapes.bin --time 1 2>&1 >/dev/null | grep -E "runner phases|SHIM_STATS" | tail -2
+echo "== /tmp/ros_cv --load-per-frame, tuned malloc"; env $M ODO_RUNNER_PHASES=1 /tmp/ros_cv /tmp/frames_shapes.bin --load-per-frame --time 1 2>&1 >/dev/null | grep -E "runner phases|SHIM_STATS" | tail -2
+echo "== /tmp/ros_cv, tuned malloc"; env $M ODO_RUNNER_PHASES=1 /tmp/ros_cv /tmp/frames_shapes.bin --time 1 2>&1 >/dev/null | grep -E "runner phases|SHIM_STATS" | tail -2
 for exe in /tmp/ros_std /tmp/ros_cv; do
   for extra in "" "--load-per-frame"; do
     echo "== $exe $extra"; ODO_RUNNER_PHASES=1 $exe /tmp/frames_shapes.bin $extra --time 1 2>&1 >/dev/null | grep -E "runner phases|SHIM_STATS" | tail -3

@@ -1,0 +1,5 @@
+// include/compat/depth_estimate.h — forwarding header of the drop-in build: the reference's callers include "depth_estimate.h" / "include/depth_estimate.h"
+// (ref: run_odometry_kitti_offline.cpp:14-19, test_disparity.cpp:12-13, include/depth_estimate.h); with -I<repo>/include/compat -I<repo>/include
+// in front of the reference's own include directories they get the MI355X classes instead, without an edit.
+#pragma once
+#include "odometry_shim.hpp"

@@ -122,6 +122,7 @@ struct BatchChain {
   std::chrono::steady_clock::time_point wait_since;
   // DepthOptimization of every entry in ONE persistent launch (depth_lm_persistent_batch_kernel) instead of a launch per iteration
   bool persistent;           // this run of the chain used it
+  bool use_persistent;       // decided ONCE per run, in batch_chain_begin (the tables' gave_up pointers and the launch choice must agree)
   bool no_persist_once;      // the chain is being run again after a give-up: step launches
   DepthPersistArgs* h_ptab;  // pinned, S entries
   DepthPersistArgs* d_ptab;
@@ -238,7 +239,7 @@ extern "C" int odo_tracker_batch_create(int device, const odo_tracker_params* p,
   b->ev_cur_img = b->ev_next = b->ev_a = nullptr; b->dead = 0;
   for (BatchChain* c : {&b->late, &b->ahead}) {
     c->h_tab = c->d_tab = nullptr; c->stage = 0; c->err = 0; c->img_ready = nullptr; c->complete.store(0);
-    c->h_ptab = c->d_ptab = nullptr; c->persistent = c->no_persist_once = false;
+    c->h_ptab = c->d_ptab = nullptr; c->persistent = c->no_persist_once = c->use_persistent = false;
   }
   b->depth_persist_bails = b->depth_persist_strikes = b->depth_persist_clean = 0;
   b->w_ring[0] = b->w_ring[1] = nullptr; b->w_posted.store(0); b->w_done.store(0); b->w_quit.store(0);
@@ -359,6 +360,8 @@ static int batch_chain_begin(odo_tracker_batch* b, BatchChain* c, hipStream_t s)
   const int n = (int)c->ids.size();
   c->par.assign(n, 0); c->tag.assign(n, -1); c->stats.assign(n, DepthLmStats());
   c->stage = 0; c->err = 0; c->k = 0; c->n_launches = 0; c->waiting = false; c->persistent = false;
+  // batch_depth_persist_ok reads state another chain's give-up can change (depth_persist_strikes): asked once, here
+  c->use_persistent = batch_depth_persist_ok(b, c);
   if (n == 0) { c->stage = 3; return 0; }
   for (int e = 0; e < n; e++) {
     const int i = c->ids[e];
@@ -380,7 +383,7 @@ static int batch_chain_begin(odo_tracker_batch* b, BatchChain* c, hipStream_t s)
     q.val = b->d_val[par][i]; q.matched = d->d_matched; q.pts = d->d_pts; q.cnt = d->d_cnt;
     q.dstate = d->d_lmstate; q.part_e = d->d_part_e; q.part_n = d->d_part_n; q.counts = d->d_counts;
     q.stats = d->d_stats_map; q.dprog = d->d_prog;
-    q.gave_up = batch_depth_persist_ok(b, c) ? d->d_gave_up : nullptr;
+    q.gave_up = c->use_persistent ? d->d_gave_up : nullptr;
     d->token++;
     q.dtoken = d->token;
     d->h_prog[0] = 0; d->h_prog[1] = 0;  // the slot's previous job is complete: nobody is polling these
@@ -471,7 +474,7 @@ static int batch_chain_persistent(odo_tracker_batch* b, BatchChain* c, hipStream
 
 static void batch_chain_pump(odo_tracker_batch* b, BatchChain* c, hipStream_t s) {
   if (c->stage != 1) return;
-  if (c->k == 0 && batch_depth_persist_ok(b, c)) {
+  if (c->k == 0 && c->use_persistent) {
     if (batch_chain_persistent(b, c, s) || batch_chain_tail(b, c, s)) { c->err = 1; c->stage = 0; }
     return;
   }

@@ -294,24 +294,57 @@ extern "C" void odo_host_free(void* p) {
 // caller's pages on the fly and keeps them registered, and when the caller later frees that memory (a per-frame cv::Mat) the unmap
 // notifier evicts every queue of the process for milliseconds (measured round 5: a Solve in flight went from 0.3 to 23 ms).
 // Page-locked destinations (odo_host_alloc) are written in place; anything else through the context's pinned bounce block.
+// Several downloads, queued back to back and waited for ONCE (odo_depth_compute's three outputs). The context's mutex is held only
+// to take the bounce block out of the context and to put it back (holding it across hipStreamSynchronize stalled every
+// other thread that needs the context — upload tickets, odo_ctx_mark_reached from Solve's idle callback — for the whole device
+// wait); a second thread downloading at the same time finds no block and brings its own.
+static int copy_many_to_user_host(odo_ctx* c, int n, void* const* dst, const void* const* src, const size_t* bytes) {
+  size_t need = 0;
+  bool all_pinned = true;
+  for (int i = 0; i < n; i++) {
+    if (!bytes[i]) continue;
+    if (!host_is_pinned(dst[i], bytes[i])) { all_pinned = false; need += (bytes[i] + 255) & ~(size_t)255; }
+  }
+  void* blk = nullptr;
+  size_t cap = 0;
+  if (!all_pinned) {
+    {
+      std::lock_guard<std::mutex> lk(*c->mu);
+      blk = c->bounce; cap = c->bounce_cap;
+      c->bounce = nullptr; c->bounce_cap = 0;
+    }
+    if (cap < need) {
+      if (blk) HIP_OK(hipHostFree(blk));
+      blk = nullptr; cap = 0;
+      HIP_OK(hipHostMalloc(&blk, need, hipHostMallocDefault));
+      cap = need;
+    }
+  }
+  int rc = 0;
+  size_t off = 0;
+  for (int i = 0; i < n && !rc; i++) {
+    if (!bytes[i]) continue;
+    const bool pinned = all_pinned || host_is_pinned(dst[i], bytes[i]);
+    void* to = pinned ? dst[i] : (void*)((char*)blk + off);
+    if (hipMemcpyAsync(to, src[i], bytes[i], hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = fail("copy_to_user_host: hipMemcpyAsync failed");
+    if (!pinned) off += (bytes[i] + 255) & ~(size_t)255;
+  }
+  if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = fail("copy_to_user_host: hipStreamSynchronize failed");
+  off = 0;
+  for (int i = 0; i < n; i++) {
+    if (!bytes[i] || all_pinned || host_is_pinned(dst[i], bytes[i])) continue;
+    if (!rc) memcpy(dst[i], (const char*)blk + off, bytes[i]);
+    off += (bytes[i] + 255) & ~(size_t)255;
+  }
+  if (blk) {
+    std::lock_guard<std::mutex> lk(*c->mu);
+    if (c->bounce_cap < cap) { std::swap(c->bounce, blk); std::swap(c->bounce_cap, cap); }
+  }
+  if (blk) (void)hipHostFree(blk);   // (the context already holds a block at least as large: another thread put it back first)
+  return rc;
+}
 static int copy_to_user_host(odo_ctx* c, void* dst, const void* src, size_t bytes) {
-  if (bytes == 0) return 0;
-  if (host_is_pinned(dst, bytes)) {
-    HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_OK(hipStreamSynchronize(c->stream));
-    return 0;
-  }
-  std::lock_guard<std::mutex> lk(*c->mu);
-  if (c->bounce_cap < bytes) {
-    if (c->bounce) HIP_OK(hipHostFree(c->bounce));
-    c->bounce = nullptr; c->bounce_cap = 0;
-    HIP_OK(hipHostMalloc(&c->bounce, bytes, hipHostMallocDefault));
-    c->bounce_cap = bytes;
-  }
-  HIP_OK(hipMemcpyAsync(c->bounce, src, bytes, hipMemcpyDeviceToHost, c->stream));
-  HIP_OK(hipStreamSynchronize(c->stream));
-  memcpy(dst, c->bounce, bytes);
-  return 0;
+  return copy_many_to_user_host(c, 1, &dst, &src, &bytes);
 }
 // dst (device, dense rows of row_bytes) <- src (host, pitch src_pitch), `rows` rows; asynchronous on the context's stream.
 static int upload_rows_async(odo_ctx* c, void* dst, const void* src, size_t src_pitch, size_t row_bytes, int rows) {
@@ -2912,8 +2945,12 @@ static int depth_host(odo_depth* d, const float* left, const float* right, int r
   (void)s;
   // the outputs reach the caller whatever the status: the reference has written left_val / left_dep back (ref: src/depth_estimate.cpp:
   // 176-191) before it returns -1 for "number of valid after optimization is too small" (:192-194)
-  if (copy_to_user_host(d->ctx, val, d->d_val, n) || copy_to_user_host(d->ctx, disp, d->d_disp, sizeof(float) * n) ||
-      copy_to_user_host(d->ctx, dep, d->d_dep, sizeof(float) * n)) return -1;
+  {   // the three outputs: queued back to back, one wait
+    void* const dsts[3] = {val, disp, dep};
+    const void* const srcs[3] = {d->d_val, d->d_disp, d->d_dep};
+    const size_t sizes[3] = {n, sizeof(float) * n, sizeof(float) * n};
+    if (copy_many_to_user_host(d->ctx, 3, dsts, srcs, sizes)) return -1;
+  }
   return rc == 0 ? 0 : -1;
 }
 

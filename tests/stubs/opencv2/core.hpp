@@ -2,19 +2,21 @@
 // public API (cv::Mat: rows, cols, data, step, u, type(), total(), elemSize(), isContinuous(), ptr / at, create / clone / copyTo /
 // convertTo (8U -> 32F, as the runner's load_data uses it), reference-counted header copies — the count lives in the UMatData that the
 // public member `u` points to; u == nullptr for a header over user data, as in OpenCV —, ROI views, user-data headers with a row step;
-// cv::Scalar, cv::Size, cv::Rect and the constants the drop-in classes name). This image has no OpenCV; the stub exists so that the -DODOMETRY_SHIM_WITH_OPENCV branch of
+// cv::Scalar, cv::Size, cv::Rect, cv::Point, cv::sum, Mat::mul and the constants the drop-in classes and the reference's callers name). This image has no OpenCV; the stub exists so that the -DODOMETRY_SHIM_WITH_OPENCV branch of
 // include/odometry_shim.hpp — the one a maintainer of the reference would build — goes through a compiler and a GPU run
 // (tests/test_gpu_shim.py). It is not part of the product and implements no image processing.
 #pragma once
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#include <cmath>
 #include <cstdlib>
 #if defined(__SSE2__)
 #include <emmintrin.h>
 #endif
 
 #define CV_8U 0
+#define CV_16U 2
 #define CV_32F 5
 #define CV_64F 6
 #define CV_8UC1 0
@@ -38,6 +40,11 @@ struct Size {
   int width, height;
   Size() : width(0), height(0) {}
   Size(int w, int h) : width(w), height(h) {}
+};
+struct Point {
+  int x, y;
+  Point() : x(0), y(0) {}
+  Point(int x_, int y_) : x(x_), y(y_) {}
 };
 struct Rect {
   int x, y, width, height;
@@ -106,13 +113,19 @@ class Mat {
     if (u && --u->refcount == 0) { std::free(u->origdata); delete u; }
     u = nullptr; data = nullptr; rows = cols = 0;
   }
-  // the one conversion the runner uses: imread's 8-bit image to PixelType (ref: run_odometry_kitti_offline.cpp:348,358)
-  void convertTo(Mat& dst, int rtype) const {
-    dst.create(rows, cols, rtype);
+  // the conversions the reference's callers use: imread's 8-bit image to PixelType (ref: run_odometry_kitti_offline.cpp:348,358;
+  // test_disparity.cpp:144 with a scale), and the result images of save_to_vis (:443-445: float -> 8-bit, 8-bit -> 16-bit), saturating
+  // and rounding to nearest as cv::saturate_cast does
+  void convertTo(Mat& dst, int rtype, double alpha = 1.0, double beta = 0.0) const {
+    const Mat src(*this);             // (dst may be *this: a header of the source outlives dst.create)
+    dst.create(rows, cols, rtype);    // cv::Mat::create keeps a fitting buffer: a Mat refilled every frame keeps its address
+    const int rows = src.rows, cols = src.cols, type_ = src.type_;
+    const MatStep step = src.step;
+    const uchar* const data = src.data;
     for (int y = 0; y < rows; y++) {
       const uchar* sp = data + (size_t)y * step.p[0];
       uchar* dp = dst.data + (size_t)y * dst.step.p[0];
-      if (type_ == CV_8U && rtype == CV_32F) {   // (OpenCV's convertTo is vectorised: so is the stand-in's, whatever -O level the test builds with)
+      if (type_ == CV_8U && rtype == CV_32F && alpha == 1.0 && beta == 0.0) {   // (OpenCV's convertTo is vectorised: so is the stand-in's, whatever -O level the test builds with)
         int x = 0;
 #if defined(__SSE2__)
         const __m128i z = _mm_setzero_si128();
@@ -128,9 +141,36 @@ class Mat {
 #endif
         for (; x < cols; x++) reinterpret_cast<float*>(dp)[x] = (float)sp[x];
       }
-      else if (type_ == rtype) std::memcpy(dp, sp, (size_t)cols * elemSize());
-      else std::abort();
+      else if (type_ == rtype && alpha == 1.0 && beta == 0.0) std::memmove(dp, sp, (size_t)cols * src.elemSize());
+      else
+        for (int x = 0; x < cols; x++) {
+          const double v = alpha * src.get(sp, x) + beta;
+          if (rtype == CV_32F) reinterpret_cast<float*>(dp)[x] = (float)v;
+          else if (rtype == CV_64F) reinterpret_cast<double*>(dp)[x] = v;
+          else {
+            const double hi = rtype == CV_8U ? 255.0 : 65535.0, r = std::nearbyint(v < 0.0 ? 0.0 : v > hi ? hi : v);
+            if (rtype == CV_8U) dp[x] = (uchar)r; else reinterpret_cast<uint16_t*>(dp)[x] = (uint16_t)r;
+          }
+        }
     }
+  }
+  // per-element product (ref: test_disparity.cpp:165, two 8-bit masks), saturating
+  Mat mul(const Mat& o) const {
+    Mat out(rows, cols, type_);
+    for (int y = 0; y < rows; y++)
+      for (int x = 0; x < cols; x++) {
+        const double v = get(data + (size_t)y * step.p[0], x) * o.get(o.data + (size_t)y * o.step.p[0], x);
+        uchar* dp = out.data + (size_t)y * out.step.p[0];
+        if (type_ == CV_32F) reinterpret_cast<float*>(dp)[x] = (float)v;
+        else if (type_ == CV_64F) reinterpret_cast<double*>(dp)[x] = v;
+        else if (type_ == CV_16U) reinterpret_cast<uint16_t*>(dp)[x] = (uint16_t)(v > 65535.0 ? 65535.0 : v);
+        else dp[x] = (uchar)(v > 255.0 ? 255.0 : v);
+      }
+    return out;
+  }
+  double get(const uchar* row, int x) const {   // (stub helper: element x of a row as double)
+    return type_ == CV_32F ? (double)reinterpret_cast<const float*>(row)[x] : type_ == CV_64F ? reinterpret_cast<const double*>(row)[x]
+         : type_ == CV_16U ? (double)reinterpret_cast<const uint16_t*>(row)[x] : (double)row[x];
   }
   Mat clone() const { Mat m; copyTo(m); return m; }
   void copyTo(Mat& dst) const {
@@ -151,7 +191,7 @@ class Mat {
   int type() const { return type_; }
   int depth() const { return type_; }
   int channels() const { return 1; }
-  size_t elemSize() const { return type_ == CV_64F ? 8 : type_ == CV_32F ? 4 : 1; }
+  size_t elemSize() const { return type_ == CV_64F ? 8 : type_ == CV_32F ? 4 : type_ == CV_16U ? 2 : 1; }
   size_t total() const { return (size_t)rows * cols; }
   bool isContinuous() const { return rows <= 1 || step.p[0] == (size_t)cols * elemSize(); }
   bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
@@ -163,4 +203,10 @@ class Mat {
  private:
   int type_;
 };
+// sum of all elements (ref: run_odometry_kitti_offline.cpp:235, test_disparity.cpp:85,165)
+inline Scalar sum(const Mat& m) {
+  double s = 0.0;
+  for (int y = 0; y < m.rows; y++) { const uchar* row = m.data + (size_t)y * m.step.p[0]; for (int x = 0; x < m.cols; x++) s += m.get(row, x); }
+  return Scalar(s);
+}
 }  // namespace cv

@@ -36,16 +36,23 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
+LIB_STAMPS = os.path.join(_HERE, "lib", "libodometry_hip_stamps.so")   # diagnostic build: phase stamps compiled in (kernels.hip.h ODO_DBG)
+
+
+def build(force=False, verbose=False, stamps=False):
+    """stamps=True: the diagnostic twin lib/libodometry_hip_stamps.so (-DODO_PHASE_STAMPS=1; use it through ODOMETRY_HIP_LIB with
+    ODO_COARSE_STAMPS=1 / ODO_DEPTH_STAMPS=1). The product library has every stamp compiled out."""
+    if not stamps and not force and not needs_build():
         return LIB
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    objdir = os.path.join(os.path.dirname(LIB), "obj")
+    lib = LIB_STAMPS if stamps else LIB
+    flags = FLAGS + (["-DODO_PHASE_STAMPS=1"] if stamps else [])
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
+    objdir = os.path.join(os.path.dirname(lib), "obj_stamps" if stamps else "obj")
     os.makedirs(objdir, exist_ok=True)
     o_main, o_dense = os.path.join(objdir, "odometry_hip.o"), os.path.join(objdir, "dense_kernels.o")
-    cmds = [[HIPCC] + FLAGS + ["-c", "-o", o_main, SRC],
-            [HIPCC] + FLAGS + ["-c", "-o", o_dense, SRC_DENSE],
-            [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, o_main, o_dense]]
+    cmds = [[HIPCC] + flags + ["-c", "-o", o_main, SRC],
+            [HIPCC] + flags + ["-c", "-o", o_dense, SRC_DENSE],
+            [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, o_main, o_dense]]
     procs = []
     for cmd in cmds[:2]:   # the two translation units compile side by side
         if verbose:
@@ -57,8 +64,9 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmds[2]))
     subprocess.check_call(cmds[2])
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force=True, verbose=True, stamps="--stamps" in sys.argv))

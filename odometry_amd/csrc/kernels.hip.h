@@ -4,6 +4,20 @@
 #include <hip/hip_runtime.h>
 #include "odo_math.h"
 
+// Phase stamps (ODO_COARSE_STAMPS / ODO_DEPTH_STAMPS: cycle sums of the persistent kernels' phases, the launch timeline) are a
+// DIAGNOSTIC BUILD: -DODO_PHASE_STAMPS=1 (python -m odometry_amd.build --stamps -> lib/libodometry_hip_stamps.so). In the product
+// build ODO_DBG() is a constant null pointer and every stamp — the counter reads, the laps, the LDS words — is compiled out: left in
+// as run-time branches on a kernel argument they cost the headline 1.5 % (round 6: 3 618 -> 3 561 frames/s when the state machine's
+// sums moved to LDS; profiles/r06_state_machine_ab.md), by what they do to register allocation and scheduling, not by executing.
+#ifndef ODO_PHASE_STAMPS
+#define ODO_PHASE_STAMPS 0
+#endif
+#if ODO_PHASE_STAMPS
+#define ODO_DBG(a) ((a).dbg)
+#else
+#define ODO_DBG(a) ((unsigned long long*)nullptr)
+#endif
+
 namespace odo {
 
 constexpr int kWave = 64;
@@ -716,16 +730,20 @@ __device__ __forceinline__ void sincos_pair_lanes(float xa_f, float xb_f, float*
   const int q = (int)((long long)kf & 3);
   const double sra = readlane_d(v, 0), cra = readlane_d(v, 1), srb = readlane_d(v, 2), crb = readlane_d(v, 3);
   const int qa = __builtin_amdgcn_readlane(q, 0), qb = __builtin_amdgcn_readlane(q, 2);
-  {
-    double s_, c_;
-    if (qa == 0) { s_ = sra; c_ = cra; } else if (qa == 1) { s_ = cra; c_ = -sra; } else if (qa == 2) { s_ = -sra; c_ = -cra; } else { s_ = -cra; c_ = sra; }
-    *sa = (float)s_; *ca = (float)c_;
-  }
-  {
-    double s_, c_;
-    if (qb == 0) { s_ = srb; c_ = crb; } else if (qb == 1) { s_ = crb; c_ = -srb; } else if (qb == 2) { s_ = -srb; c_ = -crb; } else { s_ = -crb; c_ = srb; }
-    *sb = (float)s_; *cb = (float)c_;
-  }
+  // odo::sincos_f's quadrant table — q 0: (s, c), 1: (c, -s), 2: (-s, -c), 3: (-c, s) — without its four-way branch: swap on bit 0,
+  // the sine's sign from bit 1, the cosine's from bit 1 of q + 1; on the wave-uniform bit patterns, so a handful of scalar selects and
+  // XORs (the branches compiled to ~50 scalar instructions and eight jumps per pair). Negation = the sign bit, as -x is.
+  auto quadrant = [](double sr, double cr, int qq, float* s_out, float* c_out) {
+    const unsigned long long sb = (unsigned long long)__double_as_longlong(sr), cb_ = (unsigned long long)__double_as_longlong(cr);
+    const bool swap = (qq & 1) != 0;
+    unsigned long long s0 = swap ? cb_ : sb, c0 = swap ? sb : cb_;
+    s0 ^= (unsigned long long)(unsigned)(qq & 2) << 62;
+    c0 ^= (unsigned long long)(unsigned)((qq + 1) & 2) << 62;
+    *s_out = (float)__longlong_as_double((long long)s0);
+    *c_out = (float)__longlong_as_double((long long)c0);
+  };
+  quadrant(sra, cra, qa, sa, ca);
+  quadrant(srb, crb, qb, sb, cb);
 }
 
 // odo::se3_exp with the two sincos calls replaced by one sincos_pair_lanes (same operations otherwise, same order).
@@ -1553,7 +1571,7 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const StepLaunch
   // The last block of the grid evaluates no points: it publishes the state, the trace row and the host progress word
   // (a system-scope release, ~0.5 us) while the other blocks are still evaluating.
   const bool publisher = (blockIdx.x == gridDim.x - 1);
-  if (a.dbg && publisher && threadIdx.x == 0 && q.seq < 56) a.dbg[16 + 2 * q.seq] = wall_clock64();  // diagnostic timeline
+  if (ODO_DBG(a) && publisher && threadIdx.x == 0 && q.seq < 56) ODO_DBG(a)[16 + 2 * q.seq] = wall_clock64();  // diagnostic timeline
   lm_fused_prologue(q.st_in, q.part_in, a.lv, a.n_levels, a.lambda0, a.precision, s_sh, fold_sh, acc_sh, a.trace, a.cost_stat,
                     publisher, q.first_of_solve ? a.init : nullptr, a.stop_level);   // (a chained Solve has no step launches: lm_chain_begin)
   const bool run = (s_sh.active != 0 && s_sh.status == 0);  // block-uniform
@@ -1593,7 +1611,7 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const StepLaunch
     if (threadIdx.x == 0 && run) { s_sh.pending = 1; s_sh.pending_nblk = L.nblk; }
     __syncthreads();
     lm_fused_publish(s_sh, q.st_out, a.host_prog, q.seq, a.token, a.cost_stat, a.out, a.done_flag, a.final_state, chain_out_of(a));
-    if (a.dbg && threadIdx.x == 0 && q.seq < 56) a.dbg[16 + 2 * q.seq + 1] = wall_clock64();
+    if (ODO_DBG(a) && threadIdx.x == 0 && q.seq < 56) ODO_DBG(a)[16 + 2 * q.seq + 1] = wall_clock64();
   }
   lm_span_end(q.span);
 }
@@ -1683,9 +1701,14 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
   // The level table moves to LDS (static-index copy): every later access indexes it with the level read from the state,
   // and a dynamic index into the by-value kernel argument makes the compiler mirror all of `a` in scratch memory.
   __shared__ StepLevel lv_sh[ODO_MAX_LEVELS_K];
+  // ODO_COARSE_STAMPS: the state machine's phase sums stay in LDS and go out ONCE, at exit — round 5 added them to the host-mapped
+  // counters from inside the loop (four read-modify-writes over PCIe per iteration), which the "state-machine" lap then measured
+  __shared__ unsigned long long sm_sh[4];
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int l = 0; l < ODO_MAX_LEVELS_K; l++) lv_sh[l] = a.lv[l];
+#pragma unroll
+    for (int i = 0; i < 4; i++) sm_sh[i] = 0;
   }
   __syncthreads();
   // state in (or initialised), a pending evaluation of an earlier launch consumed, pyramid walk started
@@ -1693,11 +1716,11 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
                     q.first_of_solve ? a.init : nullptr, a.stop_level, a.chain_in_token ? a.chain_pose : nullptr);
   LmHot hot;                    // wave 0's copy of the state between evaluations (lm_state_machine_hot; the other waves never look at theirs)
   lm_hot_load(hot, s_sh);
-  if (a.dbg && threadIdx.x == 0 && q.seq < 56) a.dbg[16 + 2 * q.seq] = wall_clock64();
-  unsigned long long c_eval = 0, c_red = 0, c_sm = 0, c_it = 0, c_last = a.dbg ? __builtin_readcyclecounter() : 0;
+  if (ODO_DBG(a) && threadIdx.x == 0 && q.seq < 56) ODO_DBG(a)[16 + 2 * q.seq] = wall_clock64();
+  unsigned long long c_eval = 0, c_red = 0, c_sm = 0, c_it = 0, c_last = ODO_DBG(a) ? __builtin_readcyclecounter() : 0;
   const unsigned long long c_begin = c_last;
   auto lap = [&](unsigned long long& sum) {
-    if (a.dbg) { const unsigned long long now = __builtin_readcyclecounter(); sum += now - c_last; c_last = now; }
+    if (ODO_DBG(a)) { const unsigned long long now = __builtin_readcyclecounter(); sum += now - c_last; c_last = now; }
   };
   // Accumulation order = the step / fine kernels': virtual blocks of 256 points (29 x 8 sub-lane chains over every eighth row, an
   // 8-lane butterfly), their 232-B partial rows folded segment by segment (lm_fused_prologue's order). A level therefore gives the
@@ -1819,15 +1842,17 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
     }
     lap(c_red);
     lm_state_machine_hot(hot, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, acc_sh, a.trace, a.cost_stat, true,
-                         a.dbg ? a.dbg + 8 : nullptr, a.stop_level);
+                         ODO_DBG(a) ? sm_sh : nullptr, a.stop_level);
     lap(c_sm);
   }
   if (threadIdx.x == 0) lm_hot_store(hot, s_sh);   // (read back by wave 0 only, below: a wave's LDS accesses stay in order)
   lm_fused_publish(s_sh, q.st_out, a.host_prog, q.seq, a.token, a.cost_stat, a.out, a.done_flag, a.final_state, chain_out_of(a));
-  if (a.dbg && threadIdx.x == 0) {
-    if (q.seq < 56) a.dbg[16 + 2 * q.seq + 1] = wall_clock64();
-    a.dbg[0] += c_eval; a.dbg[1] += c_red; a.dbg[2] += c_sm; a.dbg[3] += c_it;
-    a.dbg[4] += __builtin_readcyclecounter() - c_begin; a.dbg[5] += 1;
+  if (ODO_DBG(a) && threadIdx.x == 0) {
+    if (q.seq < 56) ODO_DBG(a)[16 + 2 * q.seq + 1] = wall_clock64();
+    ODO_DBG(a)[0] += c_eval; ODO_DBG(a)[1] += c_red; ODO_DBG(a)[2] += c_sm; ODO_DBG(a)[3] += c_it;
+    ODO_DBG(a)[4] += __builtin_readcyclecounter() - c_begin; ODO_DBG(a)[5] += 1;
+#pragma unroll
+    for (int i = 0; i < 4; i++) ODO_DBG(a)[8 + i] += sm_sh[i];
   }
   lm_span_end(q.span);
 }
@@ -2131,6 +2156,7 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
   __shared__ StepLevel lv_sh[ODO_MAX_LEVELS_K];  // dynamic level index: keep the by-value argument out of scratch memory
   __shared__ float rows_sh2[2][kRowFloats * RowBuf<kLmBlock>::W];
   __shared__ int bail_sh, local_sh;
+  __shared__ unsigned long long sm_sh[4];   // ODO_COARSE_STAMPS: phase sums of the publisher's state machine, flushed once at exit
   float* rows_sh = rows_sh2[half];
   const unsigned tag_base = a.fine_epoch << 8;   // unique per launch on this buffer (lm_fine_next_epoch): a stale granule cannot pass for a new one
   unsigned long long* place = xbuf + 2 * kFineRowsMax * kFineGran;  // [K] {xcc id, launch epoch} words
@@ -2140,6 +2166,8 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
     for (int l = 0; l < ODO_MAX_LEVELS_K; l++) lv_sh[l] = a.lv[l];
     bail_sh = 0;
     local_sh = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) sm_sh[i] = 0;
     // where am I? (agent-scope store: this exchange must work at any placement)
     __hip_atomic_store(place + w, ((unsigned long long)(unsigned)fine_xcc_id() << 32) | tag_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -2177,9 +2205,9 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
   PointK pt;
   bool pt_ok = false;
   int pt_level = -1;
-  unsigned long long c_eval = 0, c_xchg = 0, c_sm = 0, c_it = 0, c_last = a.dbg ? __builtin_readcyclecounter() : 0;
+  unsigned long long c_eval = 0, c_xchg = 0, c_sm = 0, c_it = 0, c_last = ODO_DBG(a) ? __builtin_readcyclecounter() : 0;
   auto lap = [&](unsigned long long& sum) {
-    if (a.dbg) { const unsigned long long now = __builtin_readcyclecounter(); sum += now - c_last; c_last = now; }
+    if (ODO_DBG(a)) { const unsigned long long now = __builtin_readcyclecounter(); sum += now - c_last; c_last = now; }
   };
   for (int ev = 0; ev < 4096; ev++) {
     const bool run = (s_sh.active != 0 && s_sh.status == 0 && !s_sh.finished && !bail_sh && s_sh.level >= lo_level);  // block-uniform
@@ -2301,8 +2329,8 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
     lap(c_xchg);
     if (bail_sh) break;
     // ---- (d): the state machine, every workgroup for itself ----
-    lm_state_machine_hot(hot, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, acc_sh, a.trace, a.cost_stat, publisher, nullptr,
-                         a.stop_level);
+    lm_state_machine_hot(hot, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, acc_sh, a.trace, a.cost_stat, publisher,
+                         (ODO_DBG(a) && publisher) ? sm_sh : nullptr, a.stop_level);
     lap(c_sm);
   }
   if (t == 0) lm_hot_store(hot, s_sh);
@@ -2310,7 +2338,9 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
   __syncthreads();
   if (publisher) {
     lm_fused_publish(s_sh, q.st_out, a.host_prog, q.seq, a.token, a.cost_stat, a.out, a.done_flag, a.final_state, chain_out_of(a));
-    if (a.dbg && t == 0) { a.dbg[128] += c_eval; a.dbg[129] += c_xchg; a.dbg[130] += c_sm; a.dbg[131] += c_it; a.dbg[132] += 1; a.dbg[133] += local ? 1 : 0; }
+    if (ODO_DBG(a) && t == 0) { ODO_DBG(a)[128] += c_eval; ODO_DBG(a)[129] += c_xchg; ODO_DBG(a)[130] += c_sm; ODO_DBG(a)[131] += c_it; ODO_DBG(a)[132] += 1; ODO_DBG(a)[133] += local ? 1 : 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) ODO_DBG(a)[136 + i] += sm_sh[i]; }
     if (t == 0 && q.span) atomicMax(q.span + 1, (unsigned long long)wall_clock64());
   }
 }
@@ -3047,10 +3077,10 @@ __device__ __forceinline__ void depth_lm_persistent_body(const DepthPersistArgs&
   DepthLmState st;
   depth_lm_begin(&st, a.lambda0, a.max_iters);      // :92-96
   const bool placed = bail_sh == 0;   // (workgroup-uniform: read behind the barrier above)
-  unsigned long long c_gather = 0, c_decide = 0, c_eval = 0, c_sum = 0, c_it = 0, c_last = a.dbg ? __builtin_readcyclecounter() : 0;
+  unsigned long long c_gather = 0, c_decide = 0, c_eval = 0, c_sum = 0, c_it = 0, c_last = ODO_DBG(a) ? __builtin_readcyclecounter() : 0;
   const unsigned long long c_begin = c_last;
   auto lap = [&](unsigned long long& sum) {
-    if (a.dbg) { const unsigned long long now = __builtin_readcyclecounter(); sum += now - c_last; c_last = now; }
+    if (ODO_DBG(a)) { const unsigned long long now = __builtin_readcyclecounter(); sum += now - c_last; c_last = now; }
   };
   int exit_k = -1;
   for (int k = 0; placed && !st.done; k++) {   // (st: every thread derives the same state)
@@ -3111,7 +3141,7 @@ __device__ __forceinline__ void depth_lm_persistent_body(const DepthPersistArgs&
         }
       }
       depth_lm_advance(&st, mode, a.max_iters);       // :167, :141
-      if (a.dbg) asm volatile("" ::"v"(tmp));
+      if (ODO_DBG(a)) asm volatile("" ::"v"(tmp));
       lap(c_decide);
       if (st.done) break;
     }
@@ -3134,7 +3164,7 @@ __device__ __forceinline__ void depth_lm_persistent_body(const DepthPersistArgs&
         bb = -r_diff * w_i * r_i;                                                                // :235
       }
     }
-    if (a.dbg) asm volatile("" ::"v"(esum));
+    if (ODO_DBG(a)) asm volatile("" ::"v"(esum));
     lap(c_eval);
     {
       const double ws = wave_sum64(esum);
@@ -3192,9 +3222,9 @@ __device__ __forceinline__ void depth_lm_persistent_body(const DepthPersistArgs&
     a.counts[(g * kDpVb + j) * 3 + qn] = (sh_c[4 * j][qn] + sh_c[4 * j + 1][qn]) + (sh_c[4 * j + 2][qn] + sh_c[4 * j + 3][qn]);
   }
   if (g == 0 && t == 0) *a.state_out = st;
-  if (a.dbg && g == 0 && t == 0) {
-    a.dbg[0] += c_gather; a.dbg[1] += c_decide; a.dbg[2] += c_eval; a.dbg[3] += c_sum; a.dbg[4] += c_it; a.dbg[5] += 1;
-    a.dbg[6] += local ? 1 : 0; a.dbg[7] += __builtin_readcyclecounter() - c_begin;
+  if (ODO_DBG(a) && g == 0 && t == 0) {
+    ODO_DBG(a)[0] += c_gather; ODO_DBG(a)[1] += c_decide; ODO_DBG(a)[2] += c_eval; ODO_DBG(a)[3] += c_sum; ODO_DBG(a)[4] += c_it; ODO_DBG(a)[5] += 1;
+    ODO_DBG(a)[6] += local ? 1 : 0; ODO_DBG(a)[7] += __builtin_readcyclecounter() - c_begin;
   }
 }
 

@@ -1470,7 +1470,11 @@ static int lm_fused_begin_job(odo_lm* m, LmJob& jb, const odo_pyr* kf_img, const
   memcpy(a.kf_rule, m->kf_rule, sizeof(a.kf_rule));
     static unsigned long long* dbg_buf = [] {
       unsigned long long* p = nullptr;
-      if (getenv("ODO_COARSE_STAMPS") && hipHostMalloc((void**)&p, 2048, hipHostMallocMapped) == hipSuccess) memset(p, 0, 2048);
+      if (getenv("ODO_COARSE_STAMPS")) {
+        if (!ODO_PHASE_STAMPS) fprintf(stderr, "odometry_hip: ODO_COARSE_STAMPS needs the diagnostic build (python -m odometry_amd.build --stamps; "
+                                               "ODOMETRY_HIP_LIB=.../libodometry_hip_stamps.so): this library has its phase stamps compiled out\n");
+        else if (hipHostMalloc((void**)&p, 2048, hipHostMallocMapped) == hipSuccess) memset(p, 0, 2048);
+      }
       return p;
     }();
     a.dbg = dbg_buf;
@@ -1498,8 +1502,11 @@ static int lm_fused_begin_job(odo_lm* m, LmJob& jb, const odo_pyr* kf_img, const
               "%.2f, same-XCD launches %.0f %%\n", (double)dbg_buf[128] / dbg_buf[131], (double)dbg_buf[129] / dbg_buf[131],
               (double)dbg_buf[130] / dbg_buf[131], (double)dbg_buf[131] / dbg_buf[132], 100.0 * (double)dbg_buf[133] / dbg_buf[132]);
     if (dbg_buf && dbg_buf[5] > 0 && dbg_buf[5] % 100 == 0 && dbg_buf[11] > 0)
-      fprintf(stderr, "[state machine] decide %.0f solve %.0f exp/compose %.0f cycles per evaluation\n",
+      fprintf(stderr, "[state machine] coarse launch: decide %.0f solve %.0f exp/compose %.0f cycles per evaluation\n",
               (double)dbg_buf[8] / dbg_buf[11], (double)dbg_buf[9] / dbg_buf[11], (double)dbg_buf[10] / dbg_buf[11]);
+    if (dbg_buf && dbg_buf[132] > 0 && dbg_buf[132] % 100 == 0 && dbg_buf[139] > 0)
+      fprintf(stderr, "[state machine] fine launch (publisher workgroup): decide %.0f solve %.0f exp/compose %.0f cycles per evaluation\n",
+              (double)dbg_buf[136] / dbg_buf[139], (double)dbg_buf[137] / dbg_buf[139], (double)dbg_buf[138] / dbg_buf[139]);
   LmState* st[2] = {m->d_state, m->d_state + 1};
   double* part[2] = {m->d_partials, m->d_partials + (size_t)kLmMaxBlocks * ODO_NACC};
   // which kernel takes which level (lm_plan_levels): the coarse launch levels >= min_level, the persistent launch
@@ -2808,7 +2815,10 @@ static int depth_job_persistent(odo_depth* d, DepthJob* j) {
   a.cls = depth_cls;
   static unsigned long long* dbg_buf = [] {
     unsigned long long* p = nullptr;
-    if (getenv("ODO_DEPTH_STAMPS") && hipHostMalloc((void**)&p, 256, hipHostMallocMapped) == hipSuccess) memset(p, 0, 256);
+    if (getenv("ODO_DEPTH_STAMPS")) {
+      if (!ODO_PHASE_STAMPS) fprintf(stderr, "odometry_hip: ODO_DEPTH_STAMPS needs the diagnostic build (python -m odometry_amd.build --stamps)\n");
+      else if (hipHostMalloc((void**)&p, 256, hipHostMallocMapped) == hipSuccess) memset(p, 0, 256);
+    }
     return p;
   }();
   a.dbg = dbg_buf;

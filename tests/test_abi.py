@@ -96,7 +96,9 @@ def test_kernel_register_budgets():
     fine = {k: v for k, v in kernels.items() if "lm_fine_kernel" in k}
     assert len(fine) == 2, fine      # the single tracker's and the batched tracker's
     for k, v in fine.items():
-        assert v[0] <= (232 if "batch" in k else 208), (k, v)   # (batched twin: 229 since the ILP-first scheduler, build.py)
+        # (batched twin: 229 since the ILP-first scheduler, 233 with round 6's branch-free quadrant selects: the allocation granule is 8 —
+        #  240 either way from 233, and two waves per SIMD up to 256)
+        assert v[0] <= (240 if "batch" in k else 208), (k, v)
     # depth_lm_persistent_kernel: its 80 workgroups of 512 threads wait for each other, so ALL must be resident on the 32 CUs of one
     # XCD at once: 640 waves / 128 SIMDs = 5 waves per SIMD -> at most 512 / 5 = 102 -> 96 VGPRs (allocation granule 8)
     dp = [v for k, v in kernels.items() if "depth_lm_persistent_kernel" in k]

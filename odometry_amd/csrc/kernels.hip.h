@@ -1689,6 +1689,11 @@ __device__ __forceinline__ float coarse_tdist_sigma(double (*part)[kCoarseChunks
   }
   return sigma;
 }
+// kFull = false: the trackers' build — Huber / L2 weights and no per-evaluation trace rows (an optimiser nobody asked to record):
+// the t-distribution scale passes with their td_* registers and the trace / cost-statistics writes are compiled out, not branched
+// around (+ 1.5 % on the headline, profiles/r06_state_machine_ab.md: what a single latency-bound wave does not execute still costs
+// it registers and scheduling freedom). kFull = true: everything decided at run time from StepArgs (robust == 2, trace != NULL).
+template <bool kFull>
 __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaunch& q, int min_level) {
   if (lm_chain_skip(a)) return;
   // The pose LM is the latency-critical chain of a frame, while the depth stream floods the CUs with throughput work
@@ -1712,7 +1717,7 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
   }
   __syncthreads();
   // state in (or initialised), a pending evaluation of an earlier launch consumed, pyramid walk started
-  lm_fused_prologue(q.st_in, q.part_in, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, red_sh, acc_sh, a.trace, a.cost_stat, true,
+  lm_fused_prologue(q.st_in, q.part_in, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, red_sh, acc_sh, (kFull ? a.trace : (LmTraceRow*)nullptr), a.cost_stat, true,
                     q.first_of_solve ? a.init : nullptr, a.stop_level, a.chain_in_token ? a.chain_pose : nullptr);
   LmHot hot;                    // wave 0's copy of the state between evaluations (lm_state_machine_hot; the other waves never look at theirs)
   lm_hot_load(hot, s_sh);
@@ -1767,7 +1772,7 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
     float td_r[kCoarseRounds] = {0.0f, 0.0f}, td_J[kCoarseRounds][6] = {{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}};
     bool td_valid[kCoarseRounds] = {false, false};
     float td_scale_sqr = 1.0f;
-    if (a.robust == 2) {
+    if ((kFull && a.robust == 2)) {
       float e2[kCoarseRounds];
 #pragma unroll
       for (int rd = 0; rd < kCoarseRounds; rd++) {
@@ -1783,7 +1788,7 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
       const int vb = vb0 + half;
       float r = 0.0f, w = 0.0f, J[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
       bool valid = false;
-      if (a.robust == 2) {
+      if ((kFull && a.robust == 2)) {
         r = td_r[vb0 / 2]; valid = td_valid[vb0 / 2];
 #pragma unroll
         for (int i = 0; i < 6; i++) J[i] = td_J[vb0 / 2][i];
@@ -1841,7 +1846,7 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
       //  a wave's LDS accesses stay in order; the other waves wait at the state machine's closing barrier)
     }
     lap(c_red);
-    lm_state_machine_hot(hot, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, acc_sh, a.trace, a.cost_stat, true,
+    lm_state_machine_hot(hot, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, acc_sh, (kFull ? a.trace : (LmTraceRow*)nullptr), a.cost_stat, true,
                          ODO_DBG(a) ? sm_sh : nullptr, a.stop_level);
     lap(c_sm);
   }
@@ -1857,9 +1862,13 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
   lm_span_end(q.span);
 }
 
-__global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int min_level) {
+__global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int min_level) {   // Huber / L2, nothing recorded
   const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve, a.span};
-  lm_coarse_body(a, q, min_level);
+  lm_coarse_body<false>(a, q, min_level);
+}
+__global__ void __launch_bounds__(kCoarseBlock) lm_coarse_full_kernel(StepArgs a, int min_level) {   // t-distribution weights and / or trace rows
+  const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve, a.span};
+  lm_coarse_body<true>(a, q, min_level);
 }
 // Batched twin (see lm_step_kernel_batch): one workgroup per sequence, each with its own min_level (a sequence without a
 // coarse level only initialises its state, begins its first level and publishes).
@@ -1867,7 +1876,7 @@ __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel_batch(const Ste
                                                                        unsigned long long* span) {
   const StepArgs& a = table[blockIdx.y];
   const StepLaunch q = {a.st2[seq & 1], a.st2[(seq + 1) & 1], a.part2[seq & 1], a.part2[(seq + 1) & 1], seq, first_of_solve, span};
-  lm_coarse_body(a, q, a.min_level);
+  lm_coarse_body<true>(a, q, a.min_level);
 }
 
 // =============================================================================================
@@ -2143,7 +2152,8 @@ __device__ __forceinline__ float fine_tdist_sigma(unsigned long long* __restrict
 // kTdist: the t-distribution build (robust == 2: the scale passes of fine_tdist_sigma in front of the weights). A template
 // parameter, not a branch: the Huber / L2 kernel's register count is part of how it shares its CUs with the depth stream
 // (tests/test_abi.py::test_kernel_register_budgets), and the scale loop's gather registers would cost it 27 VGPRs.
-template <bool kTdist>
+// kTrace = false: no per-evaluation trace rows / cost statistics (see lm_coarse_body's kFull) — the trackers' optimisers.
+template <bool kTdist, bool kTrace>
 __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch& q, int K, int w, unsigned long long* __restrict__ xbuf,
                                              int fault, int lo_level) {
   __builtin_amdgcn_s_setprio(3);  // see lm_coarse_kernel
@@ -2173,7 +2183,7 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
   }
   __syncthreads();
   // state in (left by the coarse launch, or initialised), a pending evaluation of an earlier launch consumed, pyramid walk started
-  lm_fused_prologue(q.st_in, q.part_in, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, fold_sh, acc_sh, a.trace, a.cost_stat,
+  lm_fused_prologue(q.st_in, q.part_in, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, fold_sh, acc_sh, (kTrace ? a.trace : (LmTraceRow*)nullptr), a.cost_stat,
                     publisher, q.first_of_solve ? a.init : nullptr, a.stop_level, a.chain_in_token ? a.chain_pose : nullptr);
   LmHot hot;                    // wave 0's copy of the state between evaluations (lm_state_machine_hot)
   lm_hot_load(hot, s_sh);
@@ -2329,7 +2339,7 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
     lap(c_xchg);
     if (bail_sh) break;
     // ---- (d): the state machine, every workgroup for itself ----
-    lm_state_machine_hot(hot, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, acc_sh, a.trace, a.cost_stat, publisher,
+    lm_state_machine_hot(hot, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, acc_sh, (kTrace ? a.trace : (LmTraceRow*)nullptr), a.cost_stat, publisher,
                          (ODO_DBG(a) && publisher) ? sm_sh : nullptr, a.stop_level);
     lap(c_sm);
   }
@@ -2358,7 +2368,7 @@ __device__ __forceinline__ bool lm_fine_mid_dispatch() {
   return __hip_atomic_load(&g_lm_fine_dispatch[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
          __hip_atomic_load(&g_lm_fine_dispatch[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-template <bool kTdist>
+template <bool kTdist, bool kTrace>
 __device__ __forceinline__ void lm_fine_entry(const StepArgs& a, int K, unsigned long long* __restrict__ xbuf, int fault, int lo_level) {
   if (threadIdx.x == 0) {
     if (blockIdx.x == 0) __hip_atomic_store(&g_lm_fine_dispatch[0], a.fine_dispatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2366,16 +2376,21 @@ __device__ __forceinline__ void lm_fine_entry(const StepArgs& a, int K, unsigned
   }
   if (!fine_on_home(a.fine_home) || lm_chain_skip(a)) return;
   const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve, a.span};
-  lm_fine_body<kTdist>(a, q, K, (int)(blockIdx.x >> 3), xbuf, fault, lo_level);
+  lm_fine_body<kTdist, kTrace>(a, q, K, (int)(blockIdx.x >> 3), xbuf, fault, lo_level);
 }
 __global__ void __launch_bounds__(kFineThreads) lm_fine_kernel(StepArgs a, int K, unsigned long long* __restrict__ xbuf, int fault,
                                                                int lo_level) {
-  lm_fine_entry<false>(a, K, xbuf, fault, lo_level);
+  lm_fine_entry<false, false>(a, K, xbuf, fault, lo_level);
+}
+// The same for an optimiser that records its trace rows (odo_lm_set_record: the LevenbergMarquardtOptimizer objects of the tests).
+__global__ void __launch_bounds__(kFineThreads) lm_fine_trace_kernel(StepArgs a, int K, unsigned long long* __restrict__ xbuf, int fault,
+                                                                     int lo_level) {
+  lm_fine_entry<false, true>(a, K, xbuf, fault, lo_level);
 }
 // The same with t-distribution weights (a.robust == 2).
 __global__ void __launch_bounds__(kFineThreads) lm_fine_tdist_kernel(StepArgs a, int K, unsigned long long* __restrict__ xbuf, int fault,
                                                                      int lo_level) {
-  lm_fine_entry<true>(a, K, xbuf, fault, lo_level);
+  lm_fine_entry<true, true>(a, K, xbuf, fault, lo_level);
 }
 // Batched twin: the sequences of a batched Solve each get an XCD (sequence i: the blocks with blockIdx.x % 8 == i % 8; beyond
 // eight sequences two or more share an XCD, K workgroups each). grid = 8 * K * ceil(n / 8). A sequence whose levels do not
@@ -2403,10 +2418,10 @@ __global__ void __launch_bounds__(kFineThreads) lm_fine_kernel_batch(const StepA
     // nothing to evaluate here, but the launch number is the whole batch's: one workgroup carries the sequence's state from this
     // launch's input buffer to its output buffer (prologue + publish, no level at or above lo_level = none), as a step launch of a
     // finished sequence does
-    if (w == 0) lm_fine_body<false>(a, q, 1, 0, a.xbuf, 0, ODO_MAX_LEVELS_K + 1);
+    if (w == 0) lm_fine_body<false, true>(a, q, 1, 0, a.xbuf, 0, ODO_MAX_LEVELS_K + 1);
     return;
   }
-  lm_fine_body<false>(a, q, K, w, a.xbuf, fault, a.fine_lo);   // (a batched Solve never carries t-distribution weights: lm_batch_begin)
+  lm_fine_body<false, true>(a, q, K, w, a.xbuf, fault, a.fine_lo);   // (a batched Solve never carries t-distribution weights: lm_batch_begin)
 }
 
 // End of a fused Solve when no step launch has reported it (no launch was issued at all, or the host is not polling):

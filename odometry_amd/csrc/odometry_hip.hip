@@ -855,6 +855,7 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
   HIP_OK(hipSetDevice(ctx->device));
   // the single-workgroup coarse kernel reduces through 118 KB of LDS (gfx950: up to 160 KB per workgroup)
   HIP_OK(hipFuncSetAttribute((const void*)lm_coarse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kCoarseLdsBytes));
+  HIP_OK(hipFuncSetAttribute((const void*)lm_coarse_full_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kCoarseLdsBytes));
   HIP_OK(hipMalloc((void**)&m->d_state, sizeof(LmState) * 3));                          // double-buffered (fused pipeline) + continuation
   m->ust = m->d_state; m->upo = 0;
   m->fuse_dense_max = getenv("ODO_FUSE_DENSE_MAX") ? atoi(getenv("ODO_FUSE_DENSE_MAX")) : 131072;
@@ -1522,7 +1523,9 @@ static int lm_fused_begin_job(odo_lm* m, LmJob& jb, const odo_pyr* kf_img, const
     a.part_in = part[jb.seq & 1]; a.part_out = part[(jb.seq + 1) & 1];
     a.seq = jb.seq; a.first_of_solve = 1;
     a.span = lm_span_slot(m, 0, true);
-    hipLaunchKernelGGL(lm_coarse_kernel, dim3(1), dim3(kCoarseBlock), kCoarseLdsBytes, s, a, min_level);
+    // the trackers' optimisers (Huber / L2, nothing recorded) run the build without the scale passes and the trace writes
+    if (m->robust != 2 && !a.trace) hipLaunchKernelGGL(lm_coarse_kernel, dim3(1), dim3(kCoarseBlock), kCoarseLdsBytes, s, a, min_level);
+    else hipLaunchKernelGGL(lm_coarse_full_kernel, dim3(1), dim3(kCoarseBlock), kCoarseLdsBytes, s, a, min_level);
     jb.seq++;
     jb.launches++;
   }
@@ -1543,6 +1546,8 @@ static int lm_fused_begin_job(odo_lm* m, LmJob& jb, const odo_pyr* kf_img, const
     m->fine_k_last = k_use;
     if (m->robust == 2)
       hipLaunchKernelGGL(lm_fine_tdist_kernel, dim3(8 * k_use), dim3(kFineThreads), 0, s, a, k_use, m->d_xbuf, m->fine_fault, fine_lo);
+    else if (a.trace)
+      hipLaunchKernelGGL(lm_fine_trace_kernel, dim3(8 * k_use), dim3(kFineThreads), 0, s, a, k_use, m->d_xbuf, m->fine_fault, fine_lo);
     else
       hipLaunchKernelGGL(lm_fine_kernel, dim3(8 * k_use), dim3(kFineThreads), 0, s, a, k_use, m->d_xbuf, m->fine_fault, fine_lo);
     jb.seq++;

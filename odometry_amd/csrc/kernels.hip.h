@@ -1689,7 +1689,8 @@ __device__ __forceinline__ float coarse_tdist_sigma(double (*part)[kCoarseChunks
   }
   return sigma;
 }
-// kFull = false: the trackers' build — Huber / L2 weights and no per-evaluation trace rows (an optimiser nobody asked to record):
+// kFull = false: the trackers' build — Huber / L2 weights, floor sampling (the parity mode) and no per-evaluation trace rows (an
+// optimiser nobody asked to record):
 // the t-distribution scale passes with their td_* registers and the trace / cost-statistics writes are compiled out, not branched
 // around (+ 1.5 % on the headline, profiles/r06_state_machine_ab.md: what a single latency-bound wave does not execute still costs
 // it registers and scheduling freedom). kFull = true: everything decided at run time from StepArgs (robust == 2, trace != NULL).
@@ -1776,7 +1777,7 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
       float e2[kCoarseRounds];
 #pragma unroll
       for (int rd = 0; rd < kCoarseRounds; rd++) {
-        if (cpt_ok[rd]) td_valid[rd] = point_residual(cpt[rd], T, L.k, L.I2, L.rows, L.cols, &td_r[rd], td_J[rd]);
+        if (cpt_ok[rd]) td_valid[rd] = point_residual<kFull>(cpt[rd], T, L.k, L.I2, L.rows, L.cols, &td_r[rd], td_J[rd]);
         e2[rd] = td_r[rd] * td_r[rd];
       }
       const float sg = coarse_tdist_sigma(sc_part, sc_cnt, e2, td_valid, (nvb + 1) / 2);
@@ -1794,8 +1795,8 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
         for (int i = 0; i < 6; i++) J[i] = td_J[vb0 / 2][i];
         if (valid) w = robust_weight(r, 2, a.huber_delta, td_scale_sqr);
       } else if (cpt_ok[vb0 / 2]) {
-        if (point_residual(cpt[vb0 / 2], T, L.k, L.I2, L.rows, L.cols, &r, J)) {
-          w = robust_weight(r, a.robust, a.huber_delta, 1.0f);
+        if (point_residual<kFull>(cpt[vb0 / 2], T, L.k, L.I2, L.rows, L.cols, &r, J)) {
+          w = robust_weight(r, kFull ? a.robust : (a.robust == 1 ? 1 : 0), a.huber_delta, 1.0f);
           valid = true;
         }
       }
@@ -2243,8 +2244,8 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
       }
       float r = 0.0f, wgt = 0.0f, J[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
       bool valid = false;
-      if (pt_ok && point_residual(pt, T, L.k, L.I2, L.rows, L.cols, &r, J)) {
-        wgt = robust_weight(r, a.robust, a.huber_delta, 1.0f);
+      if (pt_ok && point_residual<kTdist || kTrace>(pt, T, L.k, L.I2, L.rows, L.cols, &r, J)) {
+        wgt = robust_weight(r, (kTdist || kTrace) ? a.robust : (a.robust == 1 ? 1 : 0), a.huber_delta, 1.0f);
         valid = true;
       }
       if (kTdist && w < nblk) {   // (workgroup-uniform: the scale passes hold workgroup barriers; a half without a virtual block adds zeros)
@@ -2280,8 +2281,8 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
           bool valid = false;
           if (vb < nblk && idx < L.n) {
             const PointK p = load_point(L.pl, idx);
-            if (point_residual(p, T, L.k, L.I2, L.rows, L.cols, &r, J)) {
-              wgt = robust_weight(r, a.robust, a.huber_delta, 1.0f);
+            if (point_residual<kTdist || kTrace>(p, T, L.k, L.I2, L.rows, L.cols, &r, J)) {
+              wgt = robust_weight(r, (kTdist || kTrace) ? a.robust : (a.robust == 1 ? 1 : 0), a.huber_delta, 1.0f);
               valid = true;
             }
           }

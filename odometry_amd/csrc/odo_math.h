@@ -176,9 +176,12 @@ ODO_HD void residual_jacobian_bilinear(const PointK& p, float i00, float i10, fl
   J[5] = gx * p.jw05 + gy * p.jw15;
 }
 // Warp + sample + Jacobian row in the level's sampling mode. Returns false when the point produces no residual.
+// kMayBilinear = false: a caller that is never launched with bilinear sampling on (the trackers' lean LM kernels) compiles the
+// non-parity path out instead of branching around it.
+template <bool kMayBilinear = true>
 ODO_HD bool point_residual(const PointK& p, const float* T, const LevelK& k, const float* I2, int rows, int cols, float* r,
                            float J[6]) {
-  if (k.bilinear) {
+  if (kMayBilinear && k.bilinear) {
     float u, v, a, b;
     int x0, y0;
     if (!warp_point_uv(p, T, k, &u, &v) || !bilinear_cell(u, v, rows, cols, &x0, &y0, &a, &b)) return false;

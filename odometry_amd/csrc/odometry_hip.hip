@@ -1524,7 +1524,7 @@ static int lm_fused_begin_job(odo_lm* m, LmJob& jb, const odo_pyr* kf_img, const
     a.seq = jb.seq; a.first_of_solve = 1;
     a.span = lm_span_slot(m, 0, true);
     // the trackers' optimisers (Huber / L2, nothing recorded) run the build without the scale passes and the trace writes
-    if (m->robust != 2 && !a.trace) hipLaunchKernelGGL(lm_coarse_kernel, dim3(1), dim3(kCoarseBlock), kCoarseLdsBytes, s, a, min_level);
+    if (m->robust != 2 && !a.trace && !m->bilinear) hipLaunchKernelGGL(lm_coarse_kernel, dim3(1), dim3(kCoarseBlock), kCoarseLdsBytes, s, a, min_level);
     else hipLaunchKernelGGL(lm_coarse_full_kernel, dim3(1), dim3(kCoarseBlock), kCoarseLdsBytes, s, a, min_level);
     jb.seq++;
     jb.launches++;
@@ -1546,7 +1546,7 @@ static int lm_fused_begin_job(odo_lm* m, LmJob& jb, const odo_pyr* kf_img, const
     m->fine_k_last = k_use;
     if (m->robust == 2)
       hipLaunchKernelGGL(lm_fine_tdist_kernel, dim3(8 * k_use), dim3(kFineThreads), 0, s, a, k_use, m->d_xbuf, m->fine_fault, fine_lo);
-    else if (a.trace)
+    else if (a.trace || m->bilinear)   // (the lean build has neither the trace writes nor the bilinear sampling path)
       hipLaunchKernelGGL(lm_fine_trace_kernel, dim3(8 * k_use), dim3(kFineThreads), 0, s, a, k_use, m->d_xbuf, m->fine_fault, fine_lo);
     else
       hipLaunchKernelGGL(lm_fine_kernel, dim3(8 * k_use), dim3(kFineThreads), 0, s, a, k_use, m->d_xbuf, m->fine_fault, fine_lo);

@@ -20,13 +20,26 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "odometry_hip.hip")
 SRC_DENSE = os.path.join(_HERE, "csrc", "dense_kernels.hip")   # its own translation unit (see dense.hip.h)
-DEPS = [SRC, SRC_DENSE, os.path.join(_HERE, "csrc", "kernels.hip.h"), os.path.join(_HERE, "csrc", "odo_math.h"), os.path.join(_HERE, "csrc", "tracker.hip.h"), os.path.join(_HERE, "csrc", "batch.hip.h"), os.path.join(_HERE, "csrc", "gather.hip.h"), os.path.join(_HERE, "csrc", "camera.hip.h"),
+SRC_BATCH = os.path.join(_HERE, "csrc", "lm_batch_kernels.hip")   # the batched LM kernels: their own unit AND their own scheduler
+DEPS = [SRC, SRC_DENSE, SRC_BATCH, os.path.join(_HERE, "csrc", "kernels.hip.h"), os.path.join(_HERE, "csrc", "odo_math.h"), os.path.join(_HERE, "csrc", "tracker.hip.h"), os.path.join(_HERE, "csrc", "batch.hip.h"), os.path.join(_HERE, "csrc", "gather.hip.h"), os.path.join(_HERE, "csrc", "camera.hip.h"),
         os.path.join(_HERE, "csrc", "dense.hip.h"), os.path.join(_HERE, "csrc", "host_fp.h"),
         os.path.join(os.path.dirname(_HERE), "include", "odometry_hip.h"), os.path.abspath(__file__)]   # (this file: the flags)
 LIB = os.path.join(_HERE, "lib", "libodometry_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-fPIC"] + os.environ.get("ODO_EXTRA_HIPCC_FLAGS", "").split()   # A/B builds
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize", "-mllvm",
+         "-amdgpu-sched-strategy=" + os.environ.get("ODO_SCHED", "iterative-ilp"), "-fPIC"] + os.environ.get("ODO_EXTRA_HIPCC_FLAGS", "").split()   # A/B builds
+# lm_batch_kernels.hip: the occupancy-first list scheduler. Round 6, batched tracker at S = 1 / 2 / 4 / 8 (frames/s, two runs):
+#   iterative-ilp 3 340-3 380 / 5 820-5 860 / 9 090-9 100 / 13 970-14 040 | default 3 690 / 6 500-6 520 / 10 510-10 630 / 13 820-13 840 |
+#   iterative-maxocc 3 680-3 690 / 6 480-6 490 / 10 390-10 410 / 14 290-14 430 — and the single tracker's headline under each of them
+#   3 772-3 779 | 3 664-3 736 | 3 725-3 730: hence two units.
+SCHED_BATCH = os.environ.get("ODO_SCHED_BATCH", "iterative-maxocc")
+
+
+def _flags_for(src, flags):
+    if src != SRC_BATCH:
+        return flags
+    return [("-amdgpu-sched-strategy=" + SCHED_BATCH) if f.startswith("-amdgpu-sched-strategy=") else f for f in flags]
 
 
 def needs_build():
@@ -49,21 +62,22 @@ def build(force=False, verbose=False, stamps=False):
     os.makedirs(os.path.dirname(lib), exist_ok=True)
     objdir = os.path.join(os.path.dirname(lib), "obj_stamps" if stamps else "obj")
     os.makedirs(objdir, exist_ok=True)
-    o_main, o_dense = os.path.join(objdir, "odometry_hip.o"), os.path.join(objdir, "dense_kernels.o")
-    cmds = [[HIPCC] + flags + ["-c", "-o", o_main, SRC],
-            [HIPCC] + flags + ["-c", "-o", o_dense, SRC_DENSE],
-            [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, o_main, o_dense]]
+    o_main, o_dense, o_batch = (os.path.join(objdir, n) for n in ("odometry_hip.o", "dense_kernels.o", "lm_batch_kernels.o"))
+    cmds = [[HIPCC] + _flags_for(SRC, flags) + ["-c", "-o", o_main, SRC],
+            [HIPCC] + _flags_for(SRC_DENSE, flags) + ["-c", "-o", o_dense, SRC_DENSE],
+            [HIPCC] + _flags_for(SRC_BATCH, flags) + ["-c", "-o", o_batch, SRC_BATCH],
+            [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, o_main, o_dense, o_batch]]
     procs = []
-    for cmd in cmds[:2]:   # the two translation units compile side by side
+    for cmd in cmds[:3]:   # the three translation units compile side by side
         if verbose:
             print(" ".join(cmd))
         procs.append(subprocess.Popen(cmd))
-    for pr, cmd in zip(procs, cmds[:2]):
+    for pr, cmd in zip(procs, cmds[:3]):
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
     if verbose:
-        print(" ".join(cmds[2]))
-    subprocess.check_call(cmds[2])
+        print(" ".join(cmds[3]))
+    subprocess.check_call(cmds[3])
     return lib
 
 

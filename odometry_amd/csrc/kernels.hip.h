@@ -18,6 +18,22 @@
 #define ODO_DBG(a) ((unsigned long long*)nullptr)
 #endif
 
+// Translation units. odometry_hip.hip is the main one (ILP-first machine scheduler: the single tracker's LM chain is one wave working
+// through ~1 200 dependent instructions per evaluation). lm_batch_kernels.hip compiles the BATCHED LM kernels — lm_step_kernel_batch,
+// lm_coarse_kernel_batch, lm_fine_kernel_batch: throughput kernels with S sequences in flight — with the occupancy-first scheduler,
+// which is worth 10-14 % to them at S = 1 ... 4 and costs the single tracker 1.3 % (profiles/r06_state_machine_ab.md, section 5):
+// it includes this header with ODO_LM_BATCH_TU set and every kernel a never-instantiated template (nothing of them is emitted), defines the three
+// launchers declared at the end of this header, and nothing else.
+#ifndef ODO_KERNEL
+#define ODO_KERNEL __global__      // a kernel definition
+#define ODO_KERNEL_T __global__    // ... one that is a template already
+#endif
+#ifdef ODO_LM_BATCH_TU
+#define ODO_DEVICE_VAR static __device__
+#else
+#define ODO_DEVICE_VAR __device__
+#endif
+
 namespace odo {
 
 constexpr int kWave = 64;
@@ -63,7 +79,7 @@ __device__ __forceinline__ void blur3x3_kernel_body(int side, const float* __res
   }
   dst[(size_t)y * cols + x] = t[1] * 0.5f + (t[0] + t[2]) * 0.25f;
 }
-__global__ void __launch_bounds__(256) blur3x3_kernel(const float* __restrict__ src0, float* __restrict__ dst0,
+ODO_KERNEL void __launch_bounds__(256) blur3x3_kernel(const float* __restrict__ src0, float* __restrict__ dst0,
                                                        const float* __restrict__ src1, float* __restrict__ dst1,
                                                        int rows, int cols, uint8_t* __restrict__ zero_u8 = nullptr,
                                                        float* __restrict__ zero_f0 = nullptr,
@@ -73,7 +89,7 @@ __global__ void __launch_bounds__(256) blur3x3_kernel(const float* __restrict__ 
 
 // 5x5 pyrDown [1,4,6,4,1]/16 per axis sampled at (2x,2y), reflect-101, dst = (rows/2, cols/2)
 // (cv::pyrDown; ref: src/image_processing_global.cpp:38,46). Horizontal pass recomputed per source row.
-__global__ void __launch_bounds__(256) pyrdown_kernel(const float* __restrict__ src, int rows, int cols,
+ODO_KERNEL void __launch_bounds__(256) pyrdown_kernel(const float* __restrict__ src, int rows, int cols,
                                                        float* __restrict__ dst) {
   const int dr = rows / 2, dc = cols / 2;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -95,7 +111,7 @@ __global__ void __launch_bounds__(256) pyrdown_kernel(const float* __restrict__ 
 // cv::medianBlur(src, dst, 3) on fp32 (ref: src/image_processing_global.cpp:77, DepthPyramid with smooth = true): median of the
 // 3x3 neighbourhood, replicated border, by the 19-exchange sorting network for nine values (a selection: bit-exact by definition).
 __device__ __forceinline__ void med_cx(float& a, float& b) { const float lo = fminf(a, b), hi = fmaxf(a, b); a = lo; b = hi; }
-__global__ void __launch_bounds__(256) median3x3_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+ODO_KERNEL void __launch_bounds__(256) median3x3_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= cols || y >= rows) return;
   const int xm = x > 0 ? x - 1 : 0, xp = x + 1 < cols ? x + 1 : cols - 1;
@@ -111,7 +127,7 @@ __global__ void __launch_bounds__(256) median3x3_kernel(const float* __restrict_
   dst[(size_t)y * cols + x] = p4;
 }
 
-__global__ void __launch_bounds__(256) decimate_odd_kernel(const float* __restrict__ src, int cols,
+ODO_KERNEL void __launch_bounds__(256) decimate_odd_kernel(const float* __restrict__ src, int cols,
                                                             float* __restrict__ dst, int dr, int dc) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -270,12 +286,12 @@ __device__ __forceinline__ void image_pyramid_fused_kernel_body(const float* __r
     }
   }
 }
-__global__ void __launch_bounds__(kPyrThreads) image_pyramid_fused_kernel(const float* __restrict__ src, PyrOut o) {
+ODO_KERNEL void __launch_bounds__(kPyrThreads) image_pyramid_fused_kernel(const float* __restrict__ src, PyrOut o) {
   image_pyramid_fused_kernel_body<kPyrThreads>(src, o);
 }
 // Large images (many more tiles than CUs): 256 threads per tile, eight tiles resident per CU instead of two.
 constexpr int kPyrThreadsWide = 256;
-__global__ void __launch_bounds__(kPyrThreadsWide) image_pyramid_fused_wide_kernel(const float* __restrict__ src, PyrOut o) {
+ODO_KERNEL void __launch_bounds__(kPyrThreadsWide) image_pyramid_fused_wide_kernel(const float* __restrict__ src, PyrOut o) {
   image_pyramid_fused_kernel_body<kPyrThreadsWide>(src, o);
 }
 
@@ -298,7 +314,7 @@ __device__ __forceinline__ void depth_pyramid_fused_kernel_body(const float* src
     }
   }
 }
-__global__ void __launch_bounds__(256) depth_pyramid_fused_kernel(const float* src, PyrOut o) {
+ODO_KERNEL void __launch_bounds__(256) depth_pyramid_fused_kernel(const float* src, PyrOut o) {
   depth_pyramid_fused_kernel_body(src, o);
 }
 
@@ -373,7 +389,7 @@ __device__ __forceinline__ void block_reduce_acc_2r(const double acc[ODO_NACC], 
 // D1/I1; the five I2 taps of neighbouring pixels land in neighbouring cache lines (L1/L2 resident).
 // Writes one 29-vector of fp64 partials per block. `expect_level` guards against stale launches: once the
 // level's loop has stopped (state->active == 0) the launch returns immediately.
-__global__ void __launch_bounds__(kLmBlock) lm_residual_dense_kernel(LevelView v, LevelK k, const LmState* __restrict__ st,
+ODO_KERNEL void __launch_bounds__(kLmBlock) lm_residual_dense_kernel(LevelView v, LevelK k, const LmState* __restrict__ st,
                                                                       int expect_level, int robust, float huber_delta,
                                                                       const float* __restrict__ scale_sqr_ptr,
                                                                       double* __restrict__ partials) {
@@ -459,7 +475,7 @@ __device__ __forceinline__ void kf_count_kernel_body(KL kl, int* __restrict__ ro
 }
 // npts_zero: the per-level totals kf_fill_kernel writes (levels without interior rows stay at 0), cleared here so that no
 // memset operation is needed in front of the pair of launches.
-__global__ void __launch_bounds__(256) kf_count_kernel(KfLevels kl, int* __restrict__ rowcnt, int* __restrict__ npts_zero) {
+ODO_KERNEL void __launch_bounds__(256) kf_count_kernel(KfLevels kl, int* __restrict__ rowcnt, int* __restrict__ npts_zero) {
   if (npts_zero && blockIdx.x == 0 && threadIdx.x < ODO_MAX_LEVELS_K) npts_zero[threadIdx.x] = 0;
   kf_count_kernel_body<KfLevels>(kl, rowcnt);
 }
@@ -533,7 +549,7 @@ __device__ __forceinline__ void kf_fill_kernel_body(KL kl, int l, PointList pl, 
   // the last row of a level knows the level's total
   if (t == 0 && (int)blockIdx.x == kl.row_base[l + 1] - 1) npts[l] = base_sh;
 }
-__global__ void __launch_bounds__(256) kf_fill_kernel(KfLevels kl, float f0, float cx0, float cy0,
+ODO_KERNEL void __launch_bounds__(256) kf_fill_kernel(KfLevels kl, float f0, float cx0, float cy0,
                                                       const int* __restrict__ rowcnt, int* __restrict__ npts, PointList pl0, PointList pl1,
                                                       PointList pl2, PointList pl3, PointList pl4, PointList pl5,
                                                       PointList pl6, PointList pl7, int dense_above) {
@@ -554,7 +570,7 @@ __device__ __forceinline__ PointK load_point(const PointList& pl, int i) {
 
 // Residual / Jacobian / normal-equation pass over a keyframe point list (semi-dense levels): one point per thread
 // (grid-stride beyond the block cap), 52 B of list + five I2 taps per point. Same arithmetic as the dense scan.
-__global__ void __launch_bounds__(kLmBlock) lm_residual_list_kernel(PointList pl, int n, const float* __restrict__ I2, int rows,
+ODO_KERNEL void __launch_bounds__(kLmBlock) lm_residual_list_kernel(PointList pl, int n, const float* __restrict__ I2, int rows,
                                                                      int cols, LevelK k, const LmState* __restrict__ st,
                                                                      int expect_level, int robust, float huber_delta,
                                                                      const float* __restrict__ scale_sqr_ptr,
@@ -578,7 +594,7 @@ __global__ void __launch_bounds__(kLmBlock) lm_residual_list_kernel(PointList pl
 }
 
 // t-distribution pass 1 over a point list: residual per point (NaN = skipped).
-__global__ void __launch_bounds__(kLmBlock) lm_residual_only_list_kernel(PointList pl, int n, const float* __restrict__ I2,
+ODO_KERNEL void __launch_bounds__(kLmBlock) lm_residual_only_list_kernel(PointList pl, int n, const float* __restrict__ I2,
                                                                           int rows, int cols, LevelK k,
                                                                           const LmState* __restrict__ st, int expect_level,
                                                                           float* __restrict__ res) {
@@ -596,7 +612,7 @@ __global__ void __launch_bounds__(kLmBlock) lm_residual_only_list_kernel(PointLi
 
 // t-distribution mode (robust == 2) needs every residual before any weight
 // (ComputeScaleNaive, ref: src/lm_optimizer.cpp:338-358): pass 1 stores r per interior pixel (NaN = skipped).
-__global__ void __launch_bounds__(kLmBlock) lm_residual_only_kernel(LevelView v, LevelK k, const LmState* __restrict__ st,
+ODO_KERNEL void __launch_bounds__(kLmBlock) lm_residual_only_kernel(LevelView v, LevelK k, const LmState* __restrict__ st,
                                                                      int expect_level, float* __restrict__ res) {
   if (!(st->active != 0 && st->level == expect_level)) return;
   float T[16];
@@ -905,7 +921,7 @@ constexpr int kTdistMaxPasses = 1000;   // the restatement's guard (a scale iter
 // sigma bit for bit whichever pipeline evaluates the level. Otherwise (dense levels: up to millions of residuals) a strided
 // per-thread sum and a tree.
 constexpr int kTdistChunksMax = 640;   // 64-point chunks of the largest point-list level (160 virtual blocks)
-__global__ void __launch_bounds__(1024) lm_tdist_scale_kernel(const float* __restrict__ res, int n,
+ODO_KERNEL void __launch_bounds__(1024) lm_tdist_scale_kernel(const float* __restrict__ res, int n,
                                                                const LmState* __restrict__ st, int expect_level,
                                                                float* __restrict__ scale_sqr_out, int list_order,
                                                                int* __restrict__ only_if = nullptr) {
@@ -1401,7 +1417,7 @@ __device__ __forceinline__ void lm_update_body(LmState* __restrict__ st, const d
   ODO_STAMP(7);
 }
 template <bool STAMP>
-__global__ void __launch_bounds__(kUpdThreads) lm_update_kernel(LmState* __restrict__ st, const double* __restrict__ partials,
+ODO_KERNEL_T void __launch_bounds__(kUpdThreads) lm_update_kernel(LmState* __restrict__ st, const double* __restrict__ partials,
                                                          int nblk, int expect_level, float precision, int max_iters,
                                                          LmTraceRow* __restrict__ trace, float* __restrict__ cost_stat,
                                                          int* __restrict__ host_prog, int seq,
@@ -1423,7 +1439,7 @@ struct UpdItem {
   const float* init;   // lm_begin_solve_batch_kernel: affine_init_, column-major, device memory
   float* out;          // lm_finalize_batch_kernel: 26 result floats, device memory
 };
-__global__ void __launch_bounds__(kUpdThreads) lm_update_batch_kernel(const UpdItem* __restrict__ items, int seq) {
+ODO_KERNEL void __launch_bounds__(kUpdThreads) lm_update_batch_kernel(const UpdItem* __restrict__ items, int seq) {
   const UpdItem& q = items[blockIdx.x];
   lm_update_body<false>(q.st, q.partials, q.nblk, q.expect_level, q.precision, q.max_iters, q.trace, q.cost_stat, q.host_prog, seq,
                         nullptr);
@@ -1616,19 +1632,21 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const StepLaunch
   lm_span_end(q.span);
 }
 
-__global__ void __launch_bounds__(kLmBlock) lm_step_kernel(StepArgs a) {
+ODO_KERNEL void __launch_bounds__(kLmBlock) lm_step_kernel(StepArgs a) {
   const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve, a.span};
   lm_step_body(a, q);
 }
 // Several independent Solves in the SAME launches: blockIdx.y picks the sequence's entry of a table in device memory that
 // stays constant for the whole Solve; every sequence runs its own state machine and finishes in its own time (the blocks of
 // a finished sequence return after the prologue). grid = (largest grid of any sequence, number of sequences).
-__global__ void __launch_bounds__(kLmBlock) lm_step_kernel_batch(const StepArgs* __restrict__ table, int seq, int first_of_solve,
+#ifdef ODO_LM_BATCH_TU
+static __global__ void __launch_bounds__(kLmBlock) lm_step_kernel_batch(const StepArgs* __restrict__ table, int seq, int first_of_solve,
                                                                  unsigned long long* span) {
   const StepArgs& a = table[blockIdx.y];
   const StepLaunch q = {a.st2[seq & 1], a.st2[(seq + 1) & 1], a.part2[seq & 1], a.part2[(seq + 1) & 1], seq, first_of_solve, span};
   lm_step_body(a, q);
 }
+#endif  // ODO_LM_BATCH_TU
 
 // Coarse pyramid levels inside ONE workgroup. A level with a few thousand points does not fill more than a handful of
 // CUs, so spreading it over blocks only buys kernel boundaries and trips through L2 for the state and the partial
@@ -1863,22 +1881,33 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
   lm_span_end(q.span);
 }
 
-__global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int min_level) {   // Huber / L2, nothing recorded
+ODO_KERNEL void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int min_level) {   // Huber / L2, nothing recorded
   const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve, a.span};
   lm_coarse_body<false>(a, q, min_level);
 }
-__global__ void __launch_bounds__(kCoarseBlock) lm_coarse_full_kernel(StepArgs a, int min_level) {   // t-distribution weights and / or trace rows
+ODO_KERNEL void __launch_bounds__(kCoarseBlock) lm_coarse_full_kernel(StepArgs a, int min_level) {   // t-distribution weights and / or trace rows
   const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve, a.span};
   lm_coarse_body<true>(a, q, min_level);
 }
 // Batched twin (see lm_step_kernel_batch): one workgroup per sequence, each with its own min_level (a sequence without a
 // coarse level only initialises its state, begins its first level and publishes).
-__global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel_batch(const StepArgs* __restrict__ table, int seq, int first_of_solve,
-                                                                       unsigned long long* span) {
+// (lean = every sequence of the table is a trackers' optimiser — Huber / L2, floor sampling, nothing recorded: see lm_coarse_body)
+template <bool kFull>
+__device__ __forceinline__ void lm_coarse_batch_entry(const StepArgs* __restrict__ table, int seq, int first_of_solve, unsigned long long* span) {
   const StepArgs& a = table[blockIdx.y];
   const StepLaunch q = {a.st2[seq & 1], a.st2[(seq + 1) & 1], a.part2[seq & 1], a.part2[(seq + 1) & 1], seq, first_of_solve, span};
-  lm_coarse_body<true>(a, q, a.min_level);
+  lm_coarse_body<kFull>(a, q, a.min_level);
 }
+#ifdef ODO_LM_BATCH_TU
+static __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel_batch(const StepArgs* __restrict__ table, int seq, int first_of_solve,
+                                                                       unsigned long long* span) {
+  lm_coarse_batch_entry<false>(table, seq, first_of_solve, span);
+}
+static __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_full_kernel_batch(const StepArgs* __restrict__ table, int seq, int first_of_solve,
+                                                                            unsigned long long* span) {
+  lm_coarse_batch_entry<true>(table, seq, first_of_solve, span);
+}
+#endif  // ODO_LM_BATCH_TU
 
 // =============================================================================================
 // The fine levels in ONE launch: a persistent kernel whose K workgroups exchange their partial sums through L2.
@@ -1941,7 +1970,7 @@ struct FineDeadline {
 // single-workgroup kernel, queued behind it with only_if = gave_up, does the level.
 constexpr int kTsThreads = 512, kTsPerThread = 32, kTsMaxWg = 128;
 constexpr int kTsXbufWords = 2 * kTsMaxWg * 4;   // [pass parity][workgroup]{sum hi | tag, sum lo | tag, count | tag, -}
-__global__ void __launch_bounds__(kTsThreads) lm_tdist_scale_multi_kernel(const float* __restrict__ res, int n,
+ODO_KERNEL void __launch_bounds__(kTsThreads) lm_tdist_scale_multi_kernel(const float* __restrict__ res, int n,
                                                                           const LmState* __restrict__ st, int expect_level,
                                                                           float* __restrict__ scale_sqr_out,
                                                                           unsigned long long* __restrict__ xbuf, unsigned epoch,
@@ -2072,7 +2101,7 @@ __device__ __forceinline__ int fine_xcc_id() {
 __device__ __forceinline__ bool fine_on_home(int home) {
   return home >= 0 ? fine_xcc_id() == home : (blockIdx.x & 7u) == 0u;
 }
-__global__ void xcc_probe_kernel(int* __restrict__ out) {
+ODO_KERNEL void xcc_probe_kernel(int* __restrict__ out) {
   if (threadIdx.x == 0) out[blockIdx.x] = fine_xcc_id();
 }
 struct XccIds { int id[8]; };   // the eight XCC ids of the device (id[0] < 0: unknown)
@@ -2364,7 +2393,7 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
 // on the XCD the pose LM's resident workgroups fill: two half-dispatched persistent launches, each waiting for workgroups that are
 // never dispatched (seen with ODO_LOG_GIVEUPS: all 80 depth workgroups resident in the end, the last of the grid 0.5 ms behind the
 // first; about once per process start — launches 4 and 8 of bench.py's tracker — and once in ~ 5 000 frames later).
-__device__ unsigned g_lm_fine_dispatch[2];
+ODO_DEVICE_VAR unsigned g_lm_fine_dispatch[2];   // (the batched TU's own copy is never used: its kernels get the main one's address as an argument)
 __device__ __forceinline__ bool lm_fine_mid_dispatch() {
   return __hip_atomic_load(&g_lm_fine_dispatch[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
          __hip_atomic_load(&g_lm_fine_dispatch[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2379,25 +2408,26 @@ __device__ __forceinline__ void lm_fine_entry(const StepArgs& a, int K, unsigned
   const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve, a.span};
   lm_fine_body<kTdist, kTrace>(a, q, K, (int)(blockIdx.x >> 3), xbuf, fault, lo_level);
 }
-__global__ void __launch_bounds__(kFineThreads) lm_fine_kernel(StepArgs a, int K, unsigned long long* __restrict__ xbuf, int fault,
+ODO_KERNEL void __launch_bounds__(kFineThreads) lm_fine_kernel(StepArgs a, int K, unsigned long long* __restrict__ xbuf, int fault,
                                                                int lo_level) {
   lm_fine_entry<false, false>(a, K, xbuf, fault, lo_level);
 }
 // The same for an optimiser that records its trace rows (odo_lm_set_record: the LevenbergMarquardtOptimizer objects of the tests).
-__global__ void __launch_bounds__(kFineThreads) lm_fine_trace_kernel(StepArgs a, int K, unsigned long long* __restrict__ xbuf, int fault,
+ODO_KERNEL void __launch_bounds__(kFineThreads) lm_fine_trace_kernel(StepArgs a, int K, unsigned long long* __restrict__ xbuf, int fault,
                                                                      int lo_level) {
   lm_fine_entry<false, true>(a, K, xbuf, fault, lo_level);
 }
 // The same with t-distribution weights (a.robust == 2).
-__global__ void __launch_bounds__(kFineThreads) lm_fine_tdist_kernel(StepArgs a, int K, unsigned long long* __restrict__ xbuf, int fault,
+ODO_KERNEL void __launch_bounds__(kFineThreads) lm_fine_tdist_kernel(StepArgs a, int K, unsigned long long* __restrict__ xbuf, int fault,
                                                                      int lo_level) {
   lm_fine_entry<true, true>(a, K, xbuf, fault, lo_level);
 }
 // Batched twin: the sequences of a batched Solve each get an XCD (sequence i: the blocks with blockIdx.x % 8 == i % 8; beyond
 // eight sequences two or more share an XCD, K workgroups each). grid = 8 * K * ceil(n / 8). A sequence whose levels do not
 // fit (fine_lo >= min_level) takes no part: its blocks return at once and its levels follow on the batched step launches.
-__global__ void __launch_bounds__(kFineThreads) lm_fine_kernel_batch(const StepArgs* __restrict__ table, int n, int K, int seq,
-                                                                     int first_of_solve, unsigned long long* span, int fault, XccIds xcc) {
+template <bool kTrace>
+__device__ __forceinline__ void lm_fine_batch_entry(const StepArgs* __restrict__ table, int n, int K, int seq, int first_of_solve,
+                                                    unsigned long long* span, int fault, const XccIds& xcc, unsigned* dispatch_words) {
   // sequence i on the i-th XCD of the device, whichever block class sits there in this launch (XCC ids unknown: on class i % 8, as dealt)
   int r = (int)(blockIdx.x & 7u);
   if (xcc.id[0] >= 0) {
@@ -2406,8 +2436,9 @@ __global__ void __launch_bounds__(kFineThreads) lm_fine_kernel_batch(const StepA
     for (int c = 0; c < 8; c++) if (xcc.id[c] == mine) r = c;
   }
   if (threadIdx.x == 0 && n > 0) {   // (the batched launch is a pose-LM persistent launch like any other: see g_lm_fine_dispatch)
-    if (blockIdx.x == 0) __hip_atomic_store(&g_lm_fine_dispatch[0], table[0].fine_dispatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (blockIdx.x == gridDim.x - 1) __hip_atomic_store(&g_lm_fine_dispatch[1], table[0].fine_dispatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (dispatch_words = the main translation unit's g_lm_fine_dispatch: the depth launches, compiled there, read that one)
+    if (blockIdx.x == 0) __hip_atomic_store(&dispatch_words[0], table[0].fine_dispatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x == gridDim.x - 1) __hip_atomic_store(&dispatch_words[1], table[0].fine_dispatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   const int wa = (int)(blockIdx.x >> 3);
   const int i = (wa / K) * 8 + r, w = wa % K;
@@ -2419,11 +2450,23 @@ __global__ void __launch_bounds__(kFineThreads) lm_fine_kernel_batch(const StepA
     // nothing to evaluate here, but the launch number is the whole batch's: one workgroup carries the sequence's state from this
     // launch's input buffer to its output buffer (prologue + publish, no level at or above lo_level = none), as a step launch of a
     // finished sequence does
-    if (w == 0) lm_fine_body<false, true>(a, q, 1, 0, a.xbuf, 0, ODO_MAX_LEVELS_K + 1);
+    if (w == 0) lm_fine_body<false, kTrace>(a, q, 1, 0, a.xbuf, 0, ODO_MAX_LEVELS_K + 1);
     return;
   }
-  lm_fine_body<false, true>(a, q, K, w, a.xbuf, fault, a.fine_lo);   // (a batched Solve never carries t-distribution weights: lm_batch_begin)
+  lm_fine_body<false, kTrace>(a, q, K, w, a.xbuf, fault, a.fine_lo);   // (a batched Solve never carries t-distribution weights: lm_batch_begin)
 }
+#ifdef ODO_LM_BATCH_TU
+static __global__ void __launch_bounds__(kFineThreads) lm_fine_kernel_batch(const StepArgs* __restrict__ table, int n, int K, int seq,
+                                                                     int first_of_solve, unsigned long long* span, int fault, XccIds xcc,
+                                                                     unsigned* dispatch_words) {
+  lm_fine_batch_entry<false>(table, n, K, seq, first_of_solve, span, fault, xcc, dispatch_words);   // lean: nothing recorded, floor sampling
+}
+static __global__ void __launch_bounds__(kFineThreads) lm_fine_trace_kernel_batch(const StepArgs* __restrict__ table, int n, int K, int seq,
+                                                                           int first_of_solve, unsigned long long* span, int fault, XccIds xcc,
+                                                                     unsigned* dispatch_words) {
+  lm_fine_batch_entry<true>(table, n, K, seq, first_of_solve, span, fault, xcc, dispatch_words);
+}
+#endif  // ODO_LM_BATCH_TU
 
 // End of a fused Solve when no step launch has reported it (no launch was issued at all, or the host is not polling):
 // consume the last pending evaluation, then hand the result over like lm_fused_publish does.
@@ -2440,7 +2483,7 @@ struct FinalizeArgs {
   int first_of_solve;  // no evaluation was launched (all budgets 0): the state comes from `init`
   float init[16];
 };
-__global__ void __launch_bounds__(kLmBlock) lm_fused_finalize_kernel(FinalizeArgs a) {
+ODO_KERNEL void __launch_bounds__(kLmBlock) lm_fused_finalize_kernel(FinalizeArgs a) {
   __shared__ LmState s_sh;
   __shared__ double fold_sh[8 * 32];
   __shared__ double acc_sh[32];
@@ -2451,7 +2494,7 @@ __global__ void __launch_bounds__(kLmBlock) lm_fused_finalize_kernel(FinalizeArg
 }
 
 // Test entry for solve_damped_wave (one wavefront).
-__global__ void solve_damped_wave_test_kernel(const double* __restrict__ acc_in, float lambda, float* __restrict__ out) {
+ODO_KERNEL void solve_damped_wave_test_kernel(const double* __restrict__ acc_in, float lambda, float* __restrict__ out) {
   __shared__ double acc_sh[32];
   __shared__ float delta_sh[6];
   if (threadIdx.x < ODO_NACC) acc_sh[threadIdx.x] = acc_in[threadIdx.x];
@@ -2461,7 +2504,7 @@ __global__ void solve_damped_wave_test_kernel(const double* __restrict__ acc_in,
   if (threadIdx.x < 6) out[threadIdx.x] = delta_sh[threadIdx.x];
 }
 
-__global__ void lm_begin_solve_kernel(LmState* __restrict__ st, const float* __restrict__ init, float* __restrict__ cost_stat) {
+ODO_KERNEL void lm_begin_solve_kernel(LmState* __restrict__ st, const float* __restrict__ init, float* __restrict__ cost_stat) {
   if (threadIdx.x == 0) {
     LmState s;
     float m[16];
@@ -2474,7 +2517,7 @@ __global__ void lm_begin_solve_kernel(LmState* __restrict__ st, const float* __r
   }
 }
 
-__global__ void lm_begin_level_kernel(LmState* __restrict__ st, int level, float lambda0, int max_iters) {
+ODO_KERNEL void lm_begin_level_kernel(LmState* __restrict__ st, int level, float lambda0, int max_iters) {
   if (threadIdx.x == 0) {
     LmState s = *st;
     s.stop_reason = 0;
@@ -2486,9 +2529,9 @@ __global__ void lm_begin_level_kernel(LmState* __restrict__ st, int level, float
 // affine_ = current_estimate.matrix() (ref: src/lm_optimizer.cpp:158), or the pseudo-identity whose (3,3)
 // is 0 on failure (ref: :48-52,60-65). out[16] = pose, out[16] = status as float.
 __device__ __forceinline__ void lm_finalize_body(const LmState* __restrict__ st, float* __restrict__ out);
-__global__ void lm_finalize_kernel(const LmState* __restrict__ st, float* __restrict__ out) { lm_finalize_body(st, out); }
-__global__ void lm_finalize_batch_kernel(const UpdItem* __restrict__ items) { lm_finalize_body(items[blockIdx.x].st, items[blockIdx.x].out); }
-__global__ void lm_begin_solve_batch_kernel(const UpdItem* __restrict__ items) {
+ODO_KERNEL void lm_finalize_kernel(const LmState* __restrict__ st, float* __restrict__ out) { lm_finalize_body(st, out); }
+ODO_KERNEL void lm_finalize_batch_kernel(const UpdItem* __restrict__ items) { lm_finalize_body(items[blockIdx.x].st, items[blockIdx.x].out); }
+ODO_KERNEL void lm_begin_solve_batch_kernel(const UpdItem* __restrict__ items) {
   if (threadIdx.x == 0) {
     const UpdItem& q = items[blockIdx.x];
     LmState s;
@@ -2501,7 +2544,7 @@ __global__ void lm_begin_solve_batch_kernel(const UpdItem* __restrict__ items) {
     for (int i = 0; i < 16; i++) q.cost_stat[i] = 0.0f;
   }
 }
-__global__ void lm_begin_level_batch_kernel(const UpdItem* __restrict__ items) {
+ODO_KERNEL void lm_begin_level_batch_kernel(const UpdItem* __restrict__ items) {
   if (threadIdx.x == 0) {
     const UpdItem& q = items[blockIdx.x];
     LmState s = *q.st;
@@ -2658,7 +2701,7 @@ __device__ __forceinline__ void depth_select_kernel_body(const float* __restrict
   }
   if (t == 0) cnt[b] = (base_sh < kSelCap) ? base_sh : kSelCap;
 }
-__global__ void __launch_bounds__(kSelThreads) depth_select_kernel(const float* __restrict__ L, int rows, int cols, int bnd,
+ODO_KERNEL void __launch_bounds__(kSelThreads) depth_select_kernel(const float* __restrict__ L, int rows, int cols, int bnd,
                                                                     float grad_th, uint8_t* __restrict__ val,
                                                                     uint32_t* __restrict__ pts, int* __restrict__ cnt) {
   depth_select_kernel_body(L, rows, cols, bnd, grad_th, val, pts, cnt);
@@ -2817,7 +2860,7 @@ __device__ __forceinline__ void depth_disparity_kernel_body(const float* __restr
     matched[slot] = hit ? 1 : 0;  // counted later by a reduction (a single-address atomic serialises at ~12 ns each)
   }
 }
-__global__ void __launch_bounds__(256) depth_disparity_kernel(const float* __restrict__ L, const float* __restrict__ R,
+ODO_KERNEL void __launch_bounds__(256) depth_disparity_kernel(const float* __restrict__ L, const float* __restrict__ R,
                                                                int rows, int cols, int bnd, int max_disp, float ssd_th,
                                                                float f0, float baseline, const uint32_t* __restrict__ pts,
                                                                const int* __restrict__ cnt, float* __restrict__ disp,
@@ -2830,7 +2873,7 @@ __global__ void __launch_bounds__(256) depth_disparity_kernel(const float* __res
 // at the points; the images are zero-filled in front, forced deviation #14): per point slot {pixel index, val, disp, dep}, 13 bytes
 // instead of 9 per pixel — what a caller whose images live in host memory it owns (cv::Mat) needs to rebuild them there. Unused
 // slots get index 0xffffffff.
-__global__ void __launch_bounds__(256) depth_compact_outputs_kernel(const uint32_t* __restrict__ pts, const int* __restrict__ cnt, int cols,
+ODO_KERNEL void __launch_bounds__(256) depth_compact_outputs_kernel(const uint32_t* __restrict__ pts, const int* __restrict__ cnt, int cols,
                                                                     const uint8_t* __restrict__ val, const float* __restrict__ disp,
                                                                     const float* __restrict__ dep, uint32_t* __restrict__ o_idx,
                                                                     float* __restrict__ o_disp, float* __restrict__ o_dep,
@@ -2983,7 +3026,7 @@ __device__ __forceinline__ void depth_lm_step_kernel_body(
     if (blockIdx.x == 0) { state[(k + 1) & 1] = st; dlm_report(host_prog, k, 0); }
   }
 }
-__global__ void __launch_bounds__(kDlmBlock) depth_lm_step_kernel(
+ODO_KERNEL void __launch_bounds__(kDlmBlock) depth_lm_step_kernel(
     int k, const float* __restrict__ left, const float* __restrict__ right, int cols, const uint32_t* __restrict__ pts,
     const int* __restrict__ cnt, const float* __restrict__ d0, float* __restrict__ scratch /* 6 x nslots */,
     DepthLmState* __restrict__ state /* [2] */, double* __restrict__ part_e /* [2][blocks] */,
@@ -3244,7 +3287,7 @@ __device__ __forceinline__ void depth_lm_persistent_body(const DepthPersistArgs&
   }
 }
 
-__global__ void __launch_bounds__(kDpThreads) depth_lm_persistent_kernel(DepthPersistArgs a) {
+ODO_KERNEL void __launch_bounds__(kDpThreads) depth_lm_persistent_kernel(DepthPersistArgs a) {
   // Which eighth of the grid takes part: block class `cls` (blocks with blockIdx % 8 == cls land on one XCD: the dispatcher deals every
   // grid round-robin from the same XCD). NOT the pose LM's class 0: on one XCD the two persistent launches cannot share a CU (416 +
   // 160 VGPRs per SIMD), so whenever they overlapped in time one waited for the other's CUs, and when both were dispatched at the same
@@ -3255,7 +3298,7 @@ __global__ void __launch_bounds__(kDpThreads) depth_lm_persistent_kernel(DepthPe
 }
 // Batched twin (odo_tracker_batch, up to four sequences): sequence j's 80 workgroups are block class (tab[0].cls + j) % 8 — an XCD of its
 // own beside the batched pose LM's, whose sequences sit on classes 0 .. 3 —, each with its own exchange buffer, epoch and give-up word.
-__global__ void __launch_bounds__(kDpThreads) depth_lm_persistent_batch_kernel(const DepthPersistArgs* __restrict__ tab, int n, XccIds xcc) {
+ODO_KERNEL void __launch_bounds__(kDpThreads) depth_lm_persistent_batch_kernel(const DepthPersistArgs* __restrict__ tab, int n, XccIds xcc) {
   int r = (int)(blockIdx.x & 7u);   // the XCD this block sits on, named as lm_fine_kernel_batch names it (XCC ids unknown: the block class)
   if (xcc.id[0] >= 0) {
     const int mine = fine_xcc_id();
@@ -3303,7 +3346,7 @@ __device__ __forceinline__ void depth_finalize_kernel_body(int run_lm, int cols,
   }
   if (t < 3) counts[blockIdx.x * 3 + t] = sh[t][0];
 }
-__global__ void __launch_bounds__(kDlmBlock) depth_finalize_kernel(int run_lm, int cols, const uint32_t* __restrict__ pts,
+ODO_KERNEL void __launch_bounds__(kDlmBlock) depth_finalize_kernel(int run_lm, int cols, const uint32_t* __restrict__ pts,
                                                                    const int* __restrict__ cnt,
                                                                    const uint8_t* __restrict__ matched,
                                                                    const float* __restrict__ scratch, float photo_th,
@@ -3339,11 +3382,18 @@ __device__ __forceinline__ void depth_stats_kernel_body(int run_lm, int n_launch
     __hip_atomic_store(done_flag, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
-__global__ void __launch_bounds__(kDlmBlock) depth_stats_kernel(int run_lm, int n_launches, const int* __restrict__ counts,
+ODO_KERNEL void __launch_bounds__(kDlmBlock) depth_stats_kernel(int run_lm, int n_launches, const int* __restrict__ counts,
                                                                 const DepthLmState* __restrict__ state,
                                                                 DepthLmStats* __restrict__ stats /* host-mapped */,
                                                                 int* __restrict__ done_flag, int token, int* __restrict__ gave_up) {
   depth_stats_kernel_body(run_lm, n_launches, counts, state, stats, done_flag, token, gave_up);
 }
+
+// Launchers of the batched LM kernels (defined in lm_batch_kernels.hip, see the top of this header). lean: every sequence of the table
+// is a trackers' optimiser (Huber / L2, floor sampling, nothing recorded). dispatch_words: device address of g_lm_fine_dispatch.
+void launch_lm_step_batch(int grid_x, int n, hipStream_t s, const StepArgs* table, int seq, int first_of_solve, unsigned long long* span);
+void launch_lm_coarse_batch(bool lean, int n, hipStream_t s, const StepArgs* table, int seq, int first_of_solve, unsigned long long* span);
+void launch_lm_fine_batch(bool lean, int blocks, hipStream_t s, const StepArgs* table, int n, int K, int seq, int first_of_solve,
+                          unsigned long long* span, int fault, const XccIds& xcc, unsigned* dispatch_words);
 
 }  // namespace odo

@@ -1976,8 +1976,8 @@ static void lm_batch_pump(odo_ctx* cx, bool block, void (*idle)(void*), void* id
       if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { jb.poll_ok = false; break; }  // never hang
     }
     if (lm_batch_all_finished(jb)) break;
-    hipLaunchKernelGGL(lm_step_kernel_batch, dim3(jb.grid, jb.n), dim3(kLmBlock), 0, s, (const StepArgs*)cx->lm_batch_d, jb.seq,
-                       (jb.seq == 0) ? 1 : 0, lm_span_slot(jb.lms[0], jb.launches, false));
+    launch_lm_step_batch(jb.grid, jb.n, s, (const StepArgs*)cx->lm_batch_d, jb.seq, (jb.seq == 0) ? 1 : 0,
+                         lm_span_slot(jb.lms[0], jb.launches, false));
     jb.seq++; jb.launches++;
     if (!jb.poll_ok && jb.it >= jb.budget) break;
     jb.it++;
@@ -2032,8 +2032,10 @@ static int lm_batch_begin(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
   if (cx->batch_fine_strikes >= 3 || lms[0]->fine_k_cfg <= 0 || getenv("ODO_LM_NO_FINE")) fine_k = 0;
   if (jb.fine_off_once) { fine_k = 0; jb.fine_off_once = false; }
   int grid = 1, budget = 0, any_coarse = 0, any_fine = 0;
+  bool lean = true;   // every sequence a trackers' optimiser (Huber / L2, floor sampling, nothing recorded): the lean kernel builds
   for (int i = 0; i < n; i++) {
     odo_lm* m = lms[i];
+    if (m->robust == 2 || m->record || m->bilinear) lean = false;
     jb.kf_img_ver[i] = kf_img[i]->version; jb.kf_dep_ver[i] = kf_dep[i]->version; jb.cur_ver[i] = cur_img[i]->version;
     jb.reset_gen[i] = m->reset_gen;
     m->token = (m->token % 0x3ffff) + 1;
@@ -2052,15 +2054,16 @@ static int lm_batch_begin(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
   if (lms[0]->ev_on > 0) lms[0]->ev_phase = lm_ev_next_phase(lms[0]);
   lms[0]->last_coarse_batch = any_coarse;
   if (any_coarse) {
-    hipLaunchKernelGGL(lm_coarse_kernel_batch, dim3(1, n), dim3(kCoarseBlock), kCoarseLdsBytes, s, (const StepArgs*)d_table, jb.seq, 1,
-                       lm_span_slot(lms[0], 0, true));
+    launch_lm_coarse_batch(lean, n, s, (const StepArgs*)d_table, jb.seq, 1, lm_span_slot(lms[0], 0, true));
     jb.seq++; jb.launches++;
   }
   jb.fine_used = any_fine != 0;
   if (any_fine) {
-    hipLaunchKernelGGL(lm_fine_kernel_batch, dim3(8 * fine_k * per_xcd), dim3(kFineThreads), 0, s, (const StepArgs*)d_table, n, fine_k,
-                       jb.seq, (jb.seq == 0) ? 1 : 0, lm_span_slot(lms[0], jb.launches, false), lms[0]->fine_fault,
-                       lms[0]->fine_home >= 0 ? device_xcc_ids(cx->device) : XccIds{{-1, -1, -1, -1, -1, -1, -1, -1}});
+    unsigned* dispatch_words = nullptr;   // the main unit's g_lm_fine_dispatch on this device (the batched kernels live in their own unit)
+    HIP_OK(hipGetSymbolAddress((void**)&dispatch_words, HIP_SYMBOL(g_lm_fine_dispatch)));
+    launch_lm_fine_batch(lean, 8 * fine_k * per_xcd, s, (const StepArgs*)d_table, n, fine_k, jb.seq, (jb.seq == 0) ? 1 : 0,
+                         lm_span_slot(lms[0], jb.launches, false), lms[0]->fine_fault,
+                         lms[0]->fine_home >= 0 ? device_xcc_ids(cx->device) : XccIds{{-1, -1, -1, -1, -1, -1, -1, -1}}, dispatch_words);
     jb.seq++; jb.launches++;
   }
   jb.active = 1;

@@ -36,6 +36,15 @@ timeout -k 5 120 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_
 timeout -k 5 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_ablate -- /tmp/dense_ablate 1920 1080 "1024 x 256" > /dev/null 2>&1 < /dev/null
 hipcc -O3 --offload-arch=gfx950 -o /tmp/valu_rates $GRAFT_REPO_ROOT/tools/microbench/valu_rates.hip 2>> $OUT/build.log
 timeout -k 5 120 /tmp/valu_rates > $OUT/valu_rates.log 2>&1 < /dev/null
+# 6. (round 6, VERDICT r05 task 2) the dense 1080p leg alone — configs[2] — with its per-dispatch trace kept, so that level 0 of
+#    lm_dense_eval_kernel is its own row (tools/summarize_profile.py grids: rows per kernel AND grid size), and one SQ pass of the
+#    same command; 7. the SQ pass of the headline (the LM chain's wait / issue split)
+DENSE="python3 $GRAFT_REPO_ROOT/bench.py --cpu-frames 0 --no-child-processes --no-causal --extras dense --no-stress --details $OUT/bench_dense_details.json --steps 20 --warmup 5"
+SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_dense -- $DENSE > $OUT/bench_dense.json 2> $OUT/bench_dense.err < /dev/null
+for f in $(find $OUT/stats_dense -name "*_kernel_trace.csv"); do mv $f ${f%_kernel_trace.csv}_dispatches.csv; done
+timeout -k 5 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT/pmc_sq_dense -- $DENSE > /dev/null 2>&1 < /dev/null
+timeout -k 5 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT/pmc_sq_headline -- $HEAD --no-causal > /dev/null 2>&1 < /dev/null
 # keep the per-kernel stats and the counter collections (what the summaries are made from); drop the per-dispatch traces
 find $OUT -name "*_kernel_trace.csv" -delete
 find $OUT -name "*_agent_info.csv" -delete

@@ -2,6 +2,8 @@
 
     python tools/summarize_profile.py stats  <kernel_stats.csv> <out.md> "<command line>"
     python tools/summarize_profile.py pmc    <counter_collection.csv> <COUNTER> <out.json-fragment>
+    python tools/summarize_profile.py sq     <counter_collection.csv> <out.json> "<command line>" [kernel substring]
+    python tools/summarize_profile.py grids  <kernel_trace.csv> <out.md> "<command line>" <kernel substring>   (rows per kernel AND grid)
 """
 import csv
 import json
@@ -33,11 +35,33 @@ def pmc(path, counter, out):
     json.dump({counter: res}, open(out, "w"), indent=1)
 
 
-def sq(path, out, command):
+def grids(path, out, cmd, sub):
+    """Per-dispatch trace -> one row per (kernel, grid size): a kernel launched on every pyramid level (lm_dense_eval_kernel) gets a row
+    per level instead of one mixed average."""
+    agg = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        name = r.get("Kernel_Name", "")
+        if sub not in name:
+            continue
+        grid = (int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0), int(r.get("Grid_Size_Y", 1) or 1))
+        wg = int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 1)) or 1)
+        agg[(name.split("(")[0][:80], grid, wg)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    with open(out, "w") as f:
+        f.write(f"rocprofv3 --kernel-trace of `{cmd}`, dispatches of kernels matching `{sub}` by grid size\n\n")
+        f.write("| kernel | grid (threads x, y) | workgroups | calls | avg ns | min ns | max ns |\n|---|---|---|---|---|---|---|\n")
+        for (name, grid, wg), d in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+            f.write(f"| `{name}` | {grid[0]} x {grid[1]} | {grid[0] // max(wg, 1) * grid[1]} | {len(d)} | {sum(d) / len(d):.0f} | {min(d)} | {max(d)} |\n")
+
+
+def sq(path, out, command, only=None):
     """Every counter of one --pmc SQ_* pass, per kernel and dispatch, with the ratios that say "latency chain" or "issue-bound"."""
     agg = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"].split("(")[0]
+        if only and only not in k:
+            continue
+        if only:   # a kernel launched on several grids (one per pyramid level): one entry per grid
+            k = f"{k} [grid {r.get('Grid_Size', r.get('Grid_Size_X', '?'))}]"
         a = agg[k][r["Counter_Name"]]
         a[0] += float(r["Counter_Value"])
         a[1] += 1
@@ -60,6 +84,8 @@ if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3], sys.argv[4])
     elif sys.argv[1] == "sq":
-        sq(sys.argv[2], sys.argv[3], sys.argv[4])
+        sq(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else None)
+    elif sys.argv[1] == "grids":
+        grids(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])

@@ -36,10 +36,22 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fn
 SCHED_BATCH = os.environ.get("ODO_SCHED_BATCH", "iterative-maxocc")
 
 
+SCHED_DENSE = os.environ.get("ODO_SCHED_DENSE", "")   # dense_kernels.hip: "" = the main unit's
+
+
 def _flags_for(src, flags):
-    if src != SRC_BATCH:
+    sched = SCHED_BATCH if src == SRC_BATCH else SCHED_DENSE if src == SRC_DENSE else ""
+    if not sched:
         return flags
-    return [("-amdgpu-sched-strategy=" + SCHED_BATCH) if f.startswith("-amdgpu-sched-strategy=") else f for f in flags]
+    if sched == "default":   # the compiler's own choice: drop the option (and the -mllvm in front of it)
+        out = []
+        for f in flags:
+            if f.startswith("-amdgpu-sched-strategy="):
+                out.pop()
+                continue
+            out.append(f)
+        return out
+    return [("-amdgpu-sched-strategy=" + sched) if f.startswith("-amdgpu-sched-strategy=") else f for f in flags]
 
 
 def needs_build():

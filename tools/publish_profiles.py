@@ -26,7 +26,7 @@ def main():
     src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
     summ = os.path.join(ROOT, "tools", "summarize_profile.py")
     cmd_all = "python3 bench.py --cpu-frames 0 --extras dense,disparity,single,batched,saturated --steps 1000 --warmup 50"
-    cmd_20 = "python3 bench.py --cpu-frames 0 --no-extras --steps 20 --warmup 5"
+    cmd_20 = "python3 bench.py --cpu-frames 0 --no-extras --steps 20 --warmup 5 (the driver's command with the side legs and the CPU sample off; since round 6 it includes the unannounced second pass: twice the launches)"
     for sub, name, cmd in (("stats", "kernel_stats", cmd_all), ("stats20", "kernel_stats_steps20", cmd_20)):
         csvp = one(os.path.join(src, sub, "*", "*_kernel_stats.csv"))
         subprocess.check_call([sys.executable, summ, "stats", csvp, os.path.join(dst, f"{rnd}_{name}.md"), cmd])
@@ -41,10 +41,25 @@ def main():
             out = os.path.join(dst, f"{rnd}_{sub}.json")
             subprocess.check_call([sys.executable, summ, "pmc", g[0], counter, out])
             head[counter] = json.load(open(out))[counter]
+    # round 6: the dense leg by grid size (level 0 of lm_dense_eval_kernel its own row), its SQ counters, the headline's SQ counters
+    g = glob.glob(os.path.join(src, "stats_dense", "*", "*_dispatches.csv"))
+    cmd_dense = "python3 bench.py --cpu-frames 0 --no-child-processes --no-causal --extras dense --no-stress --steps 20 --warmup 5"
+    if g:
+        subprocess.check_call([sys.executable, summ, "grids", g[0], os.path.join(dst, f"{rnd}_dense_by_grid.md"), cmd_dense, "lm_dense_eval"])
+    g = glob.glob(os.path.join(src, "pmc_sq_dense", "*", "*_counter_collection.csv"))
+    if g:
+        subprocess.check_call([sys.executable, summ, "sq", g[0], os.path.join(dst, f"{rnd}_dense_kernel_sq.json"), cmd_dense + " (one --pmc SQ_* pass)", "lm_dense_eval"])
+    g = glob.glob(os.path.join(src, "pmc_sq_headline", "*", "*_counter_collection.csv"))
+    if g:
+        subprocess.check_call([sys.executable, summ, "sq", g[0], os.path.join(dst, f"{rnd}_lm_kernels_sq.json"),
+                               "python3 bench.py --cpu-frames 0 --no-extras --no-stress --no-causal --steps 199 --warmup 5 (one --pmc SQ_* pass)"])
     for kind in ("steps20", "default"):
         p = os.path.join(ROOT, "gpurun_out", f"{tag}_bench_{kind}.json")
         if os.path.exists(p) and os.path.getsize(p) > 0:
             shutil.copy(p, os.path.join(dst, f"{rnd}_bench_{kind}.json"))
+        p = os.path.join(ROOT, "gpurun_out", f"{tag}_bench_{kind}_details.json")   # round 6: the full record beside the compact line
+        if os.path.exists(p) and os.path.getsize(p) > 0:
+            shutil.copy(p, os.path.join(dst, f"{rnd}_bench_{kind}_details.json"))
     # pmc_traffic.json: what bench.py's roofline.traffic repeats
     tp = os.path.join(dst, "pmc_traffic.json")
     d = json.load(open(tp))
@@ -82,7 +97,8 @@ def main():
             d["lm_fine_bytes_per_launch_headline"] = hl["lm_fine_kernel"]["bytes_per_launch"]
         if "lm_coarse_kernel" in hl:
             d["lm_coarse_bytes_per_launch_headline"] = hl["lm_coarse_kernel"]["bytes_per_launch"]
-    d["source"] = d["source"].replace("round 4", f"round {int(rnd[1:])}").replace("r04_", f"{rnd}_")
+    import re
+    d["source"] = re.sub(r"r0\d_", f"{rnd}_", re.sub(r"round \d", f"round {int(rnd[1:])}", d["source"]))
     json.dump(d, open(tp, "w"), indent=1)
     print("lm_fine_kernel", fw("odo::lm_fine_kernel"), "lm_coarse_kernel", fw("odo::lm_coarse_kernel"), "lm_step_kernel", fw("odo::lm_step_kernel"))
 

@@ -51,24 +51,55 @@ def grids(path, out, cmd, sub):
         f.write("| kernel | grid (threads x, y) | workgroups | calls | avg ns | min ns | max ns |\n|---|---|---|---|---|---|---|\n")
         for (name, grid, wg), d in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
             f.write(f"| `{name}` | {grid[0]} x {grid[1]} | {grid[0] // max(wg, 1) * grid[1]} | {len(d)} | {sum(d) / len(d):.0f} | {min(d)} | {max(d)} |\n")
+        # A kernel whose grid is capped (lm_dense_eval_kernel: 1 024 workgroups whatever the level) shows one grid for every pyramid level:
+        # its durations then fall into separate modes (a level has a quarter of the pixels of the one below) — split where consecutive
+        # sorted durations jump by more than 30 %
+        f.write("\nDuration modes per (kernel, grid) — one mode per pyramid level where the grid is capped:\n\n")
+        f.write("| kernel | grid | mode | calls | avg ns | min ns | max ns |\n|---|---|---|---|---|---|---|\n")
+        for (name, grid, wg), d in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+            d = sorted(d)
+            modes, cur = [], [d[0]]
+            for x in d[1:]:
+                if x > 1.3 * cur[-1]:
+                    modes.append(cur)
+                    cur = []
+                cur.append(x)
+            modes.append(cur)
+            for i, m in enumerate(modes):
+                f.write(f"| `{name}` | {grid[0]} x {grid[1]} | {i} | {len(m)} | {sum(m) / len(m):.0f} | {m[0]} | {m[-1]} |\n")
 
 
 def sq(path, out, command, only=None):
-    """Every counter of one --pmc SQ_* pass, per kernel and dispatch, with the ratios that say "latency chain" or "issue-bound"."""
-    agg = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    """Every counter of one --pmc SQ_* pass, per kernel and dispatch, with the ratios that say "latency chain" or "issue-bound".
+    only: restrict to kernels containing this substring AND split their dispatches into modes of SQ_INSTS_VALU (a kernel whose grid is
+    capped runs every pyramid level on the same grid: a level has a quarter of the instructions of the one below — one entry per mode)."""
+    per = defaultdict(lambda: defaultdict(dict))   # kernel -> dispatch id -> counter -> value
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"].split("(")[0]
         if only and only not in k:
             continue
-        if only:   # a kernel launched on several grids (one per pyramid level): one entry per grid
-            k = f"{k} [grid {r.get('Grid_Size', r.get('Grid_Size_X', '?'))}]"
-        a = agg[k][r["Counter_Name"]]
-        a[0] += float(r["Counter_Value"])
-        a[1] += 1
+        per[k][r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
+    groups = {}
+    for k, disp in per.items():
+        rows = list(disp.values())
+        if only:
+            rows.sort(key=lambda c: c.get("SQ_INSTS_VALU", 0.0))
+            modes, cur = [], [rows[0]]
+            for c in rows[1:]:
+                if c.get("SQ_INSTS_VALU", 0.0) > 1.3 * max(cur[-1].get("SQ_INSTS_VALU", 0.0), 1.0):
+                    modes.append(cur)
+                    cur = []
+                cur.append(c)
+            modes.append(cur)
+            for i, m in enumerate(modes):
+                groups[f"{k} [mode {i} of {len(modes)} by SQ_INSTS_VALU]"] = m
+        else:
+            groups[k] = rows
     res = {}
-    for k, cs in agg.items():
-        row = {c: round(v[0] / max(v[1], 1), 1) for c, v in cs.items()}
-        row["dispatches"] = max(v[1] for v in cs.values())
+    for k, rows in groups.items():
+        names = set().union(*[set(c) for c in rows])
+        row = {c: round(sum(r.get(c, 0.0) for r in rows) / len(rows), 1) for c in sorted(names)}
+        row["dispatches"] = len(rows)
         wc = row.get("SQ_WAVE_CYCLES", 0.0)
         if wc:
             for c, name in (("SQ_WAIT_ANY", "wait_any"), ("SQ_WAIT_INST_ANY", "wait_inst_any"), ("SQ_ACTIVE_INST_ANY", "active_inst_any")):
@@ -76,6 +107,10 @@ def sq(path, out, command, only=None):
                     row[name + "_frac_of_wave_cycles"] = round(row[c] / wc, 3)
         if row.get("SQ_WAVES"):
             row["valu_insts_per_wave"] = round(row.get("SQ_INSTS_VALU", 0.0) / row["SQ_WAVES"], 1)
+        if row.get("SQ_BUSY_CYCLES") and row.get("SQ_ACTIVE_INST_VALU"):
+            # SQ_ACTIVE_INST_VALU: cycles (x4, per SIMD) a VALU instruction is in flight, summed over the chip's SQs; against busy cycles x SIMDs
+            row["valu_busy_note"] = "SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES = %.2f (per-SE aggregation: compare between builds, not with 1.0)" % (
+                row["SQ_ACTIVE_INST_VALU"] / row["SQ_BUSY_CYCLES"])
         res[k] = row
     json.dump({"command": command, "per_dispatch": res}, open(out, "w"), indent=1)
 

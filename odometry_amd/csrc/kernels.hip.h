@@ -568,6 +568,37 @@ __device__ __forceinline__ PointK load_point(const PointList& pl, int i) {
   return p;
 }
 
+// odo::point_residual for the persistent kernels, whose level table lives in LDS: a pointer read from LDS is a generic pointer in a
+// vector register pair — the five taps became FLAT loads (counted on the LDS counter as well as the memory one: every wait for an
+// LDS read then also waits for them) behind 64-bit address arithmetic per tap. Here the image base is pinned to a scalar register
+// pair (it is wave-uniform) and the taps are GLOBAL loads at base + a 32-bit byte offset. Same taps, same arithmetic.
+__device__ __forceinline__ const float* lm_uniform_ptr(const float* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffu)), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return (const float*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ float ldg_f32(const float* base_uniform, unsigned byte_off) {
+  typedef __attribute__((address_space(1))) const char GlobalBytes;
+  typedef __attribute__((address_space(1))) const float GlobalFloat;
+  return *(GlobalFloat*)((GlobalBytes*)base_uniform + byte_off);
+}
+template <bool kMayBilinear>
+__device__ __forceinline__ bool point_residual_g(const PointK& p, const float* T, const LevelK& k, const float* I2_uniform, int rows,
+                                                 int cols, float* r, float J[6]) {
+  if (kMayBilinear && k.bilinear) return point_residual<true>(p, T, k, I2_uniform, rows, cols, r, J);
+  int ui, vi;
+  if (!warp_point(p, T, k, rows, cols, &ui, &vi)) return false;
+  // (ref: lm_optimizer.cpp:215-217, image_processing_global.h:62-69 — odo::residual_jacobian's taps)
+  const int px = (ui - 1 >= 0) ? ui - 1 : 0, nx = (ui + 1 < cols) ? ui + 1 : cols - 1;
+  const int py = (vi - 1 >= 0) ? vi - 1 : 0, ny = (vi + 1 < rows) ? vi + 1 : rows - 1;
+  const unsigned row = (unsigned)vi * (unsigned)cols, ucols = (unsigned)cols;
+  const float tc = ldg_f32(I2_uniform, (row + (unsigned)ui) * 4u), tl = ldg_f32(I2_uniform, (row + (unsigned)px) * 4u),
+              tr = ldg_f32(I2_uniform, (row + (unsigned)nx) * 4u), tu = ldg_f32(I2_uniform, ((unsigned)py * ucols + (unsigned)ui) * 4u),
+              td = ldg_f32(I2_uniform, ((unsigned)ny * ucols + (unsigned)ui) * 4u);
+  residual_jacobian_taps(p, tc, tl, tr, tu, td, r, J);
+  return true;
+}
+
 // Residual / Jacobian / normal-equation pass over a keyframe point list (semi-dense levels): one point per thread
 // (grid-stride beyond the block cap), 52 B of list + five I2 taps per point. Same arithmetic as the dense scan.
 ODO_KERNEL void __launch_bounds__(kLmBlock) lm_residual_list_kernel(PointList pl, int n, const float* __restrict__ I2, int rows,
@@ -1771,6 +1802,7 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
     if (!run) break;
     c_it++;
     const StepLevel& L = lv_sh[s_sh.level];
+    const float* I2u = lm_uniform_ptr(L.I2);   // (point_residual_g)
     float T[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) T[i] = s_sh.T[i];
@@ -1795,7 +1827,7 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
       float e2[kCoarseRounds];
 #pragma unroll
       for (int rd = 0; rd < kCoarseRounds; rd++) {
-        if (cpt_ok[rd]) td_valid[rd] = point_residual<kFull>(cpt[rd], T, L.k, L.I2, L.rows, L.cols, &td_r[rd], td_J[rd]);
+        if (cpt_ok[rd]) td_valid[rd] = point_residual_g<kFull>(cpt[rd], T, L.k, I2u, L.rows, L.cols, &td_r[rd], td_J[rd]);
         e2[rd] = td_r[rd] * td_r[rd];
       }
       const float sg = coarse_tdist_sigma(sc_part, sc_cnt, e2, td_valid, (nvb + 1) / 2);
@@ -1813,7 +1845,7 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
         for (int i = 0; i < 6; i++) J[i] = td_J[vb0 / 2][i];
         if (valid) w = robust_weight(r, 2, a.huber_delta, td_scale_sqr);
       } else if (cpt_ok[vb0 / 2]) {
-        if (point_residual<kFull>(cpt[vb0 / 2], T, L.k, L.I2, L.rows, L.cols, &r, J)) {
+        if (point_residual_g<kFull>(cpt[vb0 / 2], T, L.k, I2u, L.rows, L.cols, &r, J)) {
           w = robust_weight(r, kFull ? a.robust : (a.robust == 1 ? 1 : 0), a.huber_delta, 1.0f);
           valid = true;
         }
@@ -2254,6 +2286,7 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
     if (!run) break;   // (a level below lo_level has begun: the step launches behind this one carry on from the state it leaves)
     c_it++;
     const StepLevel& L = lv_sh[s_sh.level];
+    const float* I2u = lm_uniform_ptr(L.I2);   // (point_residual_g)
     const int nblk = L.nblk;
     const unsigned tag = tag_base + 1u + (unsigned)(ev % 255);   // never tag_base itself: that is the placement word's
     unsigned long long* buf = xbuf + (size_t)(ev & 1) * kFineRowsMax * kFineGran;
@@ -2273,7 +2306,7 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
       }
       float r = 0.0f, wgt = 0.0f, J[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
       bool valid = false;
-      if (pt_ok && point_residual<kTdist || kTrace>(pt, T, L.k, L.I2, L.rows, L.cols, &r, J)) {
+      if (pt_ok && point_residual_g<kTdist || kTrace>(pt, T, L.k, I2u, L.rows, L.cols, &r, J)) {
         wgt = robust_weight(r, (kTdist || kTrace) ? a.robust : (a.robust == 1 ? 1 : 0), a.huber_delta, 1.0f);
         valid = true;
       }
@@ -2310,7 +2343,7 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
           bool valid = false;
           if (vb < nblk && idx < L.n) {
             const PointK p = load_point(L.pl, idx);
-            if (point_residual<kTdist || kTrace>(p, T, L.k, L.I2, L.rows, L.cols, &r, J)) {
+            if (point_residual_g<kTdist || kTrace>(p, T, L.k, I2u, L.rows, L.cols, &r, J)) {
               wgt = robust_weight(r, (kTdist || kTrace) ? a.robust : (a.robust == 1 ? 1 : 0), a.huber_delta, 1.0f);
               valid = true;
             }

@@ -595,7 +595,17 @@ __device__ __forceinline__ bool point_residual_g(const PointK& p, const float* T
   const float tc = ldg_f32(I2_uniform, (row + (unsigned)ui) * 4u), tl = ldg_f32(I2_uniform, (row + (unsigned)px) * 4u),
               tr = ldg_f32(I2_uniform, (row + (unsigned)nx) * 4u), tu = ldg_f32(I2_uniform, ((unsigned)py * ucols + (unsigned)ui) * 4u),
               td = ldg_f32(I2_uniform, ((unsigned)ny * ucols + (unsigned)ui) * 4u);
-  residual_jacobian_taps(p, tc, tl, tr, tu, td, r, J);
+  // odo::residual_jacobian_taps without its two products by the zeros of Jw — J[0] = gx fx_z + gy 0, J[1] = gx 0 + gy fx_z (ref:
+  // lm_optimizer.cpp:235, jw(1,0) = jw(0,1) = 0): for finite gradients the sum with a signed zero can only turn a -0 into a +0, and a
+  // zero entry of J reaches the sums as a zero addend of accumulators that start at +0 — every sum is the same bit pattern.
+  const float gx = 0.5f * (tr - tl), gy = 0.5f * (td - tu);
+  *r = tc - p.i1;
+  J[0] = gx * p.fx_z;
+  J[1] = gy * p.fx_z;
+  J[2] = gx * p.jw02 + gy * p.jw12;
+  J[3] = gx * p.jw03 + gy * p.jw13;
+  J[4] = gx * p.jw04 + gy * p.jw14;
+  J[5] = gx * p.jw05 + gy * p.jw15;
   return true;
 }
 
@@ -874,6 +884,20 @@ __device__ __forceinline__ void rows_store(float* __restrict__ rows, int W, int 
   }
   rows[12 * W + p] = valid ? r : 0.0f;
   rows[13 * W + p] = valid ? r * w : 0.0f;
+  rows[14 * W + p] = valid ? 1.0f : 0.0f;
+}
+// The same for callers that hand in all-zero J, w, r for a point without a residual (every caller below initialises them so and
+// writes them only behind a successful point_residual): the fourteen selects against `valid` are then no-ops — fourteen
+// instructions per point in a phase that is issue-bound at two waves per SIMD.
+__device__ __forceinline__ void rows_store_z(float* __restrict__ rows, int W, int t, const float J[6], float w, float r, bool valid) {
+  const int p = (t % kRowSub) * (W / kRowSub) + t / kRowSub;
+#pragma unroll
+  for (int a = 0; a < 6; a++) {
+    rows[a * W + p] = J[a];
+    rows[(6 + a) * W + p] = J[a] * w;
+  }
+  rows[12 * W + p] = r;
+  rows[13 * W + p] = r * w;
   rows[14 * W + p] = valid ? 1.0f : 0.0f;
 }
 // Which two rows quantity q multiplies: q < 21: (JW[a], J[b]) for the upper triangle in row-major order;
@@ -1851,7 +1875,7 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
         }
       }
       if (vb0 > 0) __syncthreads();  // the previous round's rows have been consumed
-      rows_store(rows_sh, RowBuf<kLmBlock>::W, tl, J, w, r, valid);
+      rows_store_z(rows_sh, RowBuf<kLmBlock>::W, tl, J, w, r, valid);
       __syncthreads();  // rows visible (and, first round, everyone has read s_sh.T)
       if (vb0 == 0) lap(c_eval);
       double accq = 0.0;
@@ -2319,7 +2343,7 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
                                           td_ws_sh, td_cnt_sh);
         if (valid) wgt = robust_weight(r, 2, a.huber_delta, sg * sg);
       }
-      rows_store(rows_sh, RowBuf<kLmBlock>::W, tl, J, wgt, r, valid);   // (the state machine's closing barrier separates this
+      rows_store_z(rows_sh, RowBuf<kLmBlock>::W, tl, J, wgt, r, valid);   // (the state machine's closing barrier separates this
       __syncthreads();                                                  //  from the previous evaluation's row sums)
       if (bail_sh) break;   // (block-uniform behind the barrier) a scale pass ran out of time
       if (vb < nblk) {
@@ -2349,7 +2373,7 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
             }
           }
           __syncthreads();  // the previous round's rows have been consumed
-          rows_store(rows_sh, RowBuf<kLmBlock>::W, tl, J, wgt, r, valid);
+          rows_store_z(rows_sh, RowBuf<kLmBlock>::W, tl, J, wgt, r, valid);
           __syncthreads();
           if (my_q < ODO_NACC) accq = rows_accumulate<kLmBlock, kS>(rows_sh, rowA, rowB, my_s, accq);
         }

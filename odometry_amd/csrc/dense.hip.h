@@ -19,6 +19,21 @@
 // way); everything else sees only the level description, its host-side helpers and the launcher declared at the end.
 namespace odo {
 
+// The fp64 forms of the shared-reciprocal division below (see there): also used by the persistent LM kernels' warp
+// (kernels.hip.h point_residual_g), hence outside the dense unit's guard.
+__device__ __forceinline__ double rcp_refined_d(double b) {
+  double y = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-b, y, 1.0);
+  return __builtin_fma(y, e, y);
+}
+__device__ __forceinline__ double div_shared_d(double a, double b, double y) {
+  const double q0 = a * y;
+  const double r0 = __builtin_fma(-b, q0, a);
+  return __builtin_fma(r0, y, q0);
+}
+
 #ifdef ODO_DENSE_KERNELS
 // ---------------------------------------------------------------------------------------------
 // Shared-reciprocal division.
@@ -50,18 +65,6 @@ __device__ __forceinline__ float recip_shared(float b, float y) {  // 1.0f / b: 
   const float q1 = __builtin_fmaf(r0, y, y);
   const float r1 = __builtin_fmaf(-b, q1, 1.0f);
   return __builtin_fmaf(r1, y, q1);
-}
-__device__ __forceinline__ double rcp_refined_d(double b) {
-  double y = __builtin_amdgcn_rcp(b);
-  double e = __builtin_fma(-b, y, 1.0);
-  y = __builtin_fma(y, e, y);
-  e = __builtin_fma(-b, y, 1.0);
-  return __builtin_fma(y, e, y);
-}
-__device__ __forceinline__ double div_shared_d(double a, double b, double y) {
-  const double q0 = a * y;
-  const double r0 = __builtin_fma(-b, q0, a);
-  return __builtin_fma(r0, y, q0);
 }
 
 #endif  // ODO_DENSE_KERNELS

@@ -586,8 +586,21 @@ template <bool kMayBilinear>
 __device__ __forceinline__ bool point_residual_g(const PointK& p, const float* T, const LevelK& k, const float* I2_uniform, int rows,
                                                  int cols, float* r, float J[6]) {
   if (kMayBilinear && k.bilinear) return point_residual<true>(p, T, k, I2_uniform, rows, cols, r, J);
-  int ui, vi;
-  if (!warp_point(p, T, k, rows, cols, &ui, &vi)) return false;
+  // odo::warp_point (ref: include/image_processing_global.h:42-59) with ONE fp64 reciprocal for both image coordinates (dense.hip.h,
+  // "Shared-reciprocal division": 13 fp64 operations instead of 22). u = float(fl * double(t0) / double(t2) + double(cx)): the
+  // operands are floats, so as doubles they are normal, every quotient stays inside the double range, v_div_scale rescales nothing
+  // and the compiler's division sequence IS rcp_refined_d + div_shared_d operation for operation whenever t0, t1, t2 are finite. When
+  // one of them is not (a pose gone to infinity), both forms give a non-finite u or v and the point is skipped below either way.
+  const float t0 = ((T[0] * p.X + T[4] * p.Y) + T[8] * p.Z) + T[12];
+  const float t1 = ((T[1] * p.X + T[5] * p.Y) + T[9] * p.Z) + T[13];
+  const float t2 = ((T[2] * p.X + T[6] * p.Y) + T[10] * p.Z) + T[14];
+  if (!(t2 > 0.0f)) return false;
+  const double t2d = (double)t2, y = rcp_refined_d(t2d);
+  const float u = (float)(div_shared_d(k.fl * (double)t0, t2d, y) + (double)k.cx);
+  const float v = (float)(div_shared_d(k.fl * (double)t1, t2d, y) + (double)k.cy);
+  const float fu = floorf(u), fv = floorf(v);
+  if (!(fu < (float)cols) || !(fv < (float)rows) || !(fu >= 0.0f) || !(fv >= 0.0f)) return false;
+  const int ui = (int)fu, vi = (int)fv;
   // (ref: lm_optimizer.cpp:215-217, image_processing_global.h:62-69 — odo::residual_jacobian's taps)
   const int px = (ui - 1 >= 0) ? ui - 1 : 0, nx = (ui + 1 < cols) ? ui + 1 : cols - 1;
   const int py = (vi - 1 >= 0) ? vi - 1 : 0, ny = (vi + 1 < rows) ? vi + 1 : rows - 1;

@@ -18,17 +18,18 @@
 #define ODO_DBG(a) ((unsigned long long*)nullptr)
 #endif
 
-// Translation units. odometry_hip.hip is the main one (ILP-first machine scheduler: the single tracker's LM chain is one wave working
-// through ~1 200 dependent instructions per evaluation). lm_batch_kernels.hip compiles the BATCHED LM kernels — lm_step_kernel_batch,
-// lm_coarse_kernel_batch, lm_fine_kernel_batch: throughput kernels with S sequences in flight — with the occupancy-first scheduler,
-// which is worth 10-14 % to them at S = 1 ... 4 and costs the single tracker 1.3 % (profiles/r06_state_machine_ab.md, section 5):
-// it includes this header with ODO_LM_BATCH_TU set and every kernel a never-instantiated template (nothing of them is emitted), defines the three
-// launchers declared at the end of this header, and nothing else.
+// Translation units. The machine scheduler that suits a kernel depends on what binds it (profiles/r06_state_machine_ab.md, section
+// 5): the single tracker's LM chain — lm_coarse_kernel, lm_fine_kernel and their variants — is ONE wave working through ~1 200
+// dependent instructions per evaluation and wants the ILP-first list scheduler (+ 1.3-3 % on the headline); every other kernel of
+// the library is a throughput kernel and wants the occupancy-first one (the batched LM kernels + 10-14 % at S = 1 ... 4, the batched
+// tracker + 3 % at S = 8). So the chain kernels compile in a unit of their own, lm_chain_kernels.hip: it includes this header with
+// ODO_LM_CHAIN_TU set — every other kernel is then a never-instantiated template (declared, never emitted) —, defines the launchers
+// declared at the end of this header, and nothing else. odometry_hip.hip (the main unit) does not see the chain kernels at all.
 #ifndef ODO_KERNEL
 #define ODO_KERNEL __global__      // a kernel definition
 #define ODO_KERNEL_T __global__    // ... one that is a template already
 #endif
-#ifdef ODO_LM_BATCH_TU
+#ifdef ODO_LM_CHAIN_TU
 #define ODO_DEVICE_VAR static __device__
 #else
 #define ODO_DEVICE_VAR __device__
@@ -1707,14 +1708,12 @@ ODO_KERNEL void __launch_bounds__(kLmBlock) lm_step_kernel(StepArgs a) {
 // Several independent Solves in the SAME launches: blockIdx.y picks the sequence's entry of a table in device memory that
 // stays constant for the whole Solve; every sequence runs its own state machine and finishes in its own time (the blocks of
 // a finished sequence return after the prologue). grid = (largest grid of any sequence, number of sequences).
-#ifdef ODO_LM_BATCH_TU
-static __global__ void __launch_bounds__(kLmBlock) lm_step_kernel_batch(const StepArgs* __restrict__ table, int seq, int first_of_solve,
+ODO_KERNEL void __launch_bounds__(kLmBlock) lm_step_kernel_batch(const StepArgs* __restrict__ table, int seq, int first_of_solve,
                                                                  unsigned long long* span) {
   const StepArgs& a = table[blockIdx.y];
   const StepLaunch q = {a.st2[seq & 1], a.st2[(seq + 1) & 1], a.part2[seq & 1], a.part2[(seq + 1) & 1], seq, first_of_solve, span};
   lm_step_body(a, q);
 }
-#endif  // ODO_LM_BATCH_TU
 
 // Coarse pyramid levels inside ONE workgroup. A level with a few thousand points does not fill more than a handful of
 // CUs, so spreading it over blocks only buys kernel boundaries and trips through L2 for the state and the partial
@@ -1950,14 +1949,16 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
   lm_span_end(q.span);
 }
 
-ODO_KERNEL void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int min_level) {   // Huber / L2, nothing recorded
+#ifdef ODO_LM_CHAIN_TU   // (the chain unit: see the top of this header)
+static __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int min_level) {   // Huber / L2, nothing recorded
   const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve, a.span};
   lm_coarse_body<false>(a, q, min_level);
 }
-ODO_KERNEL void __launch_bounds__(kCoarseBlock) lm_coarse_full_kernel(StepArgs a, int min_level) {   // t-distribution weights and / or trace rows
+static __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_full_kernel(StepArgs a, int min_level) {   // t-distribution weights and / or trace rows
   const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve, a.span};
   lm_coarse_body<true>(a, q, min_level);
 }
+#endif  // ODO_LM_CHAIN_TU
 // Batched twin (see lm_step_kernel_batch): one workgroup per sequence, each with its own min_level (a sequence without a
 // coarse level only initialises its state, begins its first level and publishes).
 // (lean = every sequence of the table is a trackers' optimiser — Huber / L2, floor sampling, nothing recorded: see lm_coarse_body)
@@ -1967,16 +1968,14 @@ __device__ __forceinline__ void lm_coarse_batch_entry(const StepArgs* __restrict
   const StepLaunch q = {a.st2[seq & 1], a.st2[(seq + 1) & 1], a.part2[seq & 1], a.part2[(seq + 1) & 1], seq, first_of_solve, span};
   lm_coarse_body<kFull>(a, q, a.min_level);
 }
-#ifdef ODO_LM_BATCH_TU
-static __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel_batch(const StepArgs* __restrict__ table, int seq, int first_of_solve,
+ODO_KERNEL void __launch_bounds__(kCoarseBlock) lm_coarse_kernel_batch(const StepArgs* __restrict__ table, int seq, int first_of_solve,
                                                                        unsigned long long* span) {
   lm_coarse_batch_entry<false>(table, seq, first_of_solve, span);
 }
-static __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_full_kernel_batch(const StepArgs* __restrict__ table, int seq, int first_of_solve,
+ODO_KERNEL void __launch_bounds__(kCoarseBlock) lm_coarse_full_kernel_batch(const StepArgs* __restrict__ table, int seq, int first_of_solve,
                                                                             unsigned long long* span) {
   lm_coarse_batch_entry<true>(table, seq, first_of_solve, span);
 }
-#endif  // ODO_LM_BATCH_TU
 
 // =============================================================================================
 // The fine levels in ONE launch: a persistent kernel whose K workgroups exchange their partial sums through L2.
@@ -2463,35 +2462,39 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
 // on the XCD the pose LM's resident workgroups fill: two half-dispatched persistent launches, each waiting for workgroups that are
 // never dispatched (seen with ODO_LOG_GIVEUPS: all 80 depth workgroups resident in the end, the last of the grid 0.5 ms behind the
 // first; about once per process start — launches 4 and 8 of bench.py's tracker — and once in ~ 5 000 frames later).
-ODO_DEVICE_VAR unsigned g_lm_fine_dispatch[2];   // (the batched TU's own copy is never used: its kernels get the main one's address as an argument)
+ODO_DEVICE_VAR unsigned g_lm_fine_dispatch[2];   // (the chain unit's own copy is never used: its kernels get the main unit's address as an argument)
 __device__ __forceinline__ bool lm_fine_mid_dispatch() {
   return __hip_atomic_load(&g_lm_fine_dispatch[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
          __hip_atomic_load(&g_lm_fine_dispatch[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <bool kTdist, bool kTrace>
-__device__ __forceinline__ void lm_fine_entry(const StepArgs& a, int K, unsigned long long* __restrict__ xbuf, int fault, int lo_level) {
+__device__ __forceinline__ void lm_fine_entry(const StepArgs& a, int K, unsigned long long* __restrict__ xbuf, int fault, int lo_level,
+                                              unsigned* dispatch_words) {
+  // (dispatch_words = the MAIN unit's g_lm_fine_dispatch, handed over as an argument: the depth launches, compiled there, read it)
   if (threadIdx.x == 0) {
-    if (blockIdx.x == 0) __hip_atomic_store(&g_lm_fine_dispatch[0], a.fine_dispatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (blockIdx.x == gridDim.x - 1) __hip_atomic_store(&g_lm_fine_dispatch[1], a.fine_dispatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x == 0) __hip_atomic_store(&dispatch_words[0], a.fine_dispatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x == gridDim.x - 1) __hip_atomic_store(&dispatch_words[1], a.fine_dispatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (!fine_on_home(a.fine_home) || lm_chain_skip(a)) return;
   const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve, a.span};
   lm_fine_body<kTdist, kTrace>(a, q, K, (int)(blockIdx.x >> 3), xbuf, fault, lo_level);
 }
-ODO_KERNEL void __launch_bounds__(kFineThreads) lm_fine_kernel(StepArgs a, int K, unsigned long long* __restrict__ xbuf, int fault,
-                                                               int lo_level) {
-  lm_fine_entry<false, false>(a, K, xbuf, fault, lo_level);
+#ifdef ODO_LM_CHAIN_TU
+static __global__ void __launch_bounds__(kFineThreads) lm_fine_kernel(StepArgs a, int K, unsigned long long* __restrict__ xbuf, int fault,
+                                                               int lo_level, unsigned* dispatch_words) {
+  lm_fine_entry<false, false>(a, K, xbuf, fault, lo_level, dispatch_words);
 }
 // The same for an optimiser that records its trace rows (odo_lm_set_record: the LevenbergMarquardtOptimizer objects of the tests).
-ODO_KERNEL void __launch_bounds__(kFineThreads) lm_fine_trace_kernel(StepArgs a, int K, unsigned long long* __restrict__ xbuf, int fault,
-                                                                     int lo_level) {
-  lm_fine_entry<false, true>(a, K, xbuf, fault, lo_level);
+static __global__ void __launch_bounds__(kFineThreads) lm_fine_trace_kernel(StepArgs a, int K, unsigned long long* __restrict__ xbuf, int fault,
+                                                                     int lo_level, unsigned* dispatch_words) {
+  lm_fine_entry<false, true>(a, K, xbuf, fault, lo_level, dispatch_words);
 }
 // The same with t-distribution weights (a.robust == 2).
-ODO_KERNEL void __launch_bounds__(kFineThreads) lm_fine_tdist_kernel(StepArgs a, int K, unsigned long long* __restrict__ xbuf, int fault,
-                                                                     int lo_level) {
-  lm_fine_entry<true, true>(a, K, xbuf, fault, lo_level);
+static __global__ void __launch_bounds__(kFineThreads) lm_fine_tdist_kernel(StepArgs a, int K, unsigned long long* __restrict__ xbuf, int fault,
+                                                                     int lo_level, unsigned* dispatch_words) {
+  lm_fine_entry<true, true>(a, K, xbuf, fault, lo_level, dispatch_words);
 }
+#endif  // ODO_LM_CHAIN_TU
 // Batched twin: the sequences of a batched Solve each get an XCD (sequence i: the blocks with blockIdx.x % 8 == i % 8; beyond
 // eight sequences two or more share an XCD, K workgroups each). grid = 8 * K * ceil(n / 8). A sequence whose levels do not
 // fit (fine_lo >= min_level) takes no part: its blocks return at once and its levels follow on the batched step launches.
@@ -2506,7 +2509,6 @@ __device__ __forceinline__ void lm_fine_batch_entry(const StepArgs* __restrict__
     for (int c = 0; c < 8; c++) if (xcc.id[c] == mine) r = c;
   }
   if (threadIdx.x == 0 && n > 0) {   // (the batched launch is a pose-LM persistent launch like any other: see g_lm_fine_dispatch)
-    // (dispatch_words = the main translation unit's g_lm_fine_dispatch: the depth launches, compiled there, read that one)
     if (blockIdx.x == 0) __hip_atomic_store(&dispatch_words[0], table[0].fine_dispatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (blockIdx.x == gridDim.x - 1) __hip_atomic_store(&dispatch_words[1], table[0].fine_dispatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -2525,18 +2527,16 @@ __device__ __forceinline__ void lm_fine_batch_entry(const StepArgs* __restrict__
   }
   lm_fine_body<false, kTrace>(a, q, K, w, a.xbuf, fault, a.fine_lo);   // (a batched Solve never carries t-distribution weights: lm_batch_begin)
 }
-#ifdef ODO_LM_BATCH_TU
-static __global__ void __launch_bounds__(kFineThreads) lm_fine_kernel_batch(const StepArgs* __restrict__ table, int n, int K, int seq,
+ODO_KERNEL void __launch_bounds__(kFineThreads) lm_fine_kernel_batch(const StepArgs* __restrict__ table, int n, int K, int seq,
                                                                      int first_of_solve, unsigned long long* span, int fault, XccIds xcc,
                                                                      unsigned* dispatch_words) {
   lm_fine_batch_entry<false>(table, n, K, seq, first_of_solve, span, fault, xcc, dispatch_words);   // lean: nothing recorded, floor sampling
 }
-static __global__ void __launch_bounds__(kFineThreads) lm_fine_trace_kernel_batch(const StepArgs* __restrict__ table, int n, int K, int seq,
+ODO_KERNEL void __launch_bounds__(kFineThreads) lm_fine_trace_kernel_batch(const StepArgs* __restrict__ table, int n, int K, int seq,
                                                                            int first_of_solve, unsigned long long* span, int fault, XccIds xcc,
                                                                      unsigned* dispatch_words) {
   lm_fine_batch_entry<true>(table, n, K, seq, first_of_solve, span, fault, xcc, dispatch_words);
 }
-#endif  // ODO_LM_BATCH_TU
 
 // End of a fused Solve when no step launch has reported it (no launch was issued at all, or the host is not polling):
 // consume the last pending evaluation, then hand the result over like lm_fused_publish does.
@@ -3459,11 +3459,12 @@ ODO_KERNEL void __launch_bounds__(kDlmBlock) depth_stats_kernel(int run_lm, int 
   depth_stats_kernel_body(run_lm, n_launches, counts, state, stats, done_flag, token, gave_up);
 }
 
-// Launchers of the batched LM kernels (defined in lm_batch_kernels.hip, see the top of this header). lean: every sequence of the table
-// is a trackers' optimiser (Huber / L2, floor sampling, nothing recorded). dispatch_words: device address of g_lm_fine_dispatch.
-void launch_lm_step_batch(int grid_x, int n, hipStream_t s, const StepArgs* table, int seq, int first_of_solve, unsigned long long* span);
-void launch_lm_coarse_batch(bool lean, int n, hipStream_t s, const StepArgs* table, int seq, int first_of_solve, unsigned long long* span);
-void launch_lm_fine_batch(bool lean, int blocks, hipStream_t s, const StepArgs* table, int n, int K, int seq, int first_of_solve,
-                          unsigned long long* span, int fault, const XccIds& xcc, unsigned* dispatch_words);
+// Launchers of the single tracker's chain kernels (defined in lm_chain_kernels.hip, see the top of this header).
+// variant of the fine launch: 0 = lean (Huber / L2, floor sampling, nothing recorded), 1 = trace rows and / or bilinear sampling, 2 =
+// t-distribution weights. dispatch_words: device address of the main unit's g_lm_fine_dispatch.
+hipError_t lm_chain_setup();   // the coarse kernels' dynamic LDS limit; once per process and device
+void launch_lm_coarse(bool lean, hipStream_t s, const StepArgs& a, int min_level);
+void launch_lm_fine(int variant, int blocks, hipStream_t s, const StepArgs& a, int K, unsigned long long* xbuf, int fault, int lo_level,
+                    unsigned* dispatch_words);
 
 }  // namespace odo

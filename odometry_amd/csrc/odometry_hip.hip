@@ -854,8 +854,7 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
   memcpy(m->init, init_colmajor, sizeof(m->init));
   HIP_OK(hipSetDevice(ctx->device));
   // the single-workgroup coarse kernel reduces through 118 KB of LDS (gfx950: up to 160 KB per workgroup)
-  HIP_OK(hipFuncSetAttribute((const void*)lm_coarse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kCoarseLdsBytes));
-  HIP_OK(hipFuncSetAttribute((const void*)lm_coarse_full_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kCoarseLdsBytes));
+  HIP_OK(lm_chain_setup());   // (the chain kernels live in lm_chain_kernels.hip: their dynamic LDS limit)
   HIP_OK(hipMalloc((void**)&m->d_state, sizeof(LmState) * 3));                          // double-buffered (fused pipeline) + continuation
   m->ust = m->d_state; m->upo = 0;
   m->fuse_dense_max = getenv("ODO_FUSE_DENSE_MAX") ? atoi(getenv("ODO_FUSE_DENSE_MAX")) : 131072;
@@ -1524,8 +1523,7 @@ static int lm_fused_begin_job(odo_lm* m, LmJob& jb, const odo_pyr* kf_img, const
     a.seq = jb.seq; a.first_of_solve = 1;
     a.span = lm_span_slot(m, 0, true);
     // the trackers' optimisers (Huber / L2, nothing recorded) run the build without the scale passes and the trace writes
-    if (m->robust != 2 && !a.trace && !m->bilinear) hipLaunchKernelGGL(lm_coarse_kernel, dim3(1), dim3(kCoarseBlock), kCoarseLdsBytes, s, a, min_level);
-    else hipLaunchKernelGGL(lm_coarse_full_kernel, dim3(1), dim3(kCoarseBlock), kCoarseLdsBytes, s, a, min_level);
+    launch_lm_coarse(m->robust != 2 && !a.trace && !m->bilinear, s, a, min_level);
     jb.seq++;
     jb.launches++;
   }
@@ -1544,12 +1542,10 @@ static int lm_fused_begin_job(odo_lm* m, LmJob& jb, const odo_pyr* kf_img, const
     a.fine_home = m->fine_home;
     const int k_use = lm_fine_launch_k(m, fine_lo, min_level);
     m->fine_k_last = k_use;
-    if (m->robust == 2)
-      hipLaunchKernelGGL(lm_fine_tdist_kernel, dim3(8 * k_use), dim3(kFineThreads), 0, s, a, k_use, m->d_xbuf, m->fine_fault, fine_lo);
-    else if (a.trace || m->bilinear)   // (the lean build has neither the trace writes nor the bilinear sampling path)
-      hipLaunchKernelGGL(lm_fine_trace_kernel, dim3(8 * k_use), dim3(kFineThreads), 0, s, a, k_use, m->d_xbuf, m->fine_fault, fine_lo);
-    else
-      hipLaunchKernelGGL(lm_fine_kernel, dim3(8 * k_use), dim3(kFineThreads), 0, s, a, k_use, m->d_xbuf, m->fine_fault, fine_lo);
+    unsigned* dispatch_words = nullptr;   // this unit's g_lm_fine_dispatch on this device: what the depth launches read
+    HIP_OK(hipGetSymbolAddress((void**)&dispatch_words, HIP_SYMBOL(g_lm_fine_dispatch)));
+    // the lean build has neither the trace writes nor the bilinear sampling path
+    launch_lm_fine(m->robust == 2 ? 2 : (a.trace || m->bilinear) ? 1 : 0, 8 * k_use, s, a, k_use, m->d_xbuf, m->fine_fault, fine_lo, dispatch_words);
     jb.seq++;
     jb.launches++;
     if (fine_lo <= stop) {   // nothing left for step launches
@@ -1976,8 +1972,8 @@ static void lm_batch_pump(odo_ctx* cx, bool block, void (*idle)(void*), void* id
       if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { jb.poll_ok = false; break; }  // never hang
     }
     if (lm_batch_all_finished(jb)) break;
-    launch_lm_step_batch(jb.grid, jb.n, s, (const StepArgs*)cx->lm_batch_d, jb.seq, (jb.seq == 0) ? 1 : 0,
-                         lm_span_slot(jb.lms[0], jb.launches, false));
+    hipLaunchKernelGGL(lm_step_kernel_batch, dim3(jb.grid, jb.n), dim3(kLmBlock), 0, s, (const StepArgs*)cx->lm_batch_d, jb.seq,
+                       (jb.seq == 0) ? 1 : 0, lm_span_slot(jb.lms[0], jb.launches, false));
     jb.seq++; jb.launches++;
     if (!jb.poll_ok && jb.it >= jb.budget) break;
     jb.it++;
@@ -2054,16 +2050,21 @@ static int lm_batch_begin(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
   if (lms[0]->ev_on > 0) lms[0]->ev_phase = lm_ev_next_phase(lms[0]);
   lms[0]->last_coarse_batch = any_coarse;
   if (any_coarse) {
-    launch_lm_coarse_batch(lean, n, s, (const StepArgs*)d_table, jb.seq, 1, lm_span_slot(lms[0], 0, true));
+    if (lean) hipLaunchKernelGGL(lm_coarse_kernel_batch, dim3(1, n), dim3(kCoarseBlock), kCoarseLdsBytes, s, (const StepArgs*)d_table, jb.seq, 1,
+                                 lm_span_slot(lms[0], 0, true));
+    else hipLaunchKernelGGL(lm_coarse_full_kernel_batch, dim3(1, n), dim3(kCoarseBlock), kCoarseLdsBytes, s, (const StepArgs*)d_table, jb.seq, 1,
+                            lm_span_slot(lms[0], 0, true));
     jb.seq++; jb.launches++;
   }
   jb.fine_used = any_fine != 0;
   if (any_fine) {
-    unsigned* dispatch_words = nullptr;   // the main unit's g_lm_fine_dispatch on this device (the batched kernels live in their own unit)
+    unsigned* dispatch_words = nullptr;   // g_lm_fine_dispatch on this device
     HIP_OK(hipGetSymbolAddress((void**)&dispatch_words, HIP_SYMBOL(g_lm_fine_dispatch)));
-    launch_lm_fine_batch(lean, 8 * fine_k * per_xcd, s, (const StepArgs*)d_table, n, fine_k, jb.seq, (jb.seq == 0) ? 1 : 0,
-                         lm_span_slot(lms[0], jb.launches, false), lms[0]->fine_fault,
-                         lms[0]->fine_home >= 0 ? device_xcc_ids(cx->device) : XccIds{{-1, -1, -1, -1, -1, -1, -1, -1}}, dispatch_words);
+    const XccIds xcc_ids = lms[0]->fine_home >= 0 ? device_xcc_ids(cx->device) : XccIds{{-1, -1, -1, -1, -1, -1, -1, -1}};
+    if (lean) hipLaunchKernelGGL(lm_fine_kernel_batch, dim3(8 * fine_k * per_xcd), dim3(kFineThreads), 0, s, (const StepArgs*)d_table, n, fine_k, jb.seq,
+                                 (jb.seq == 0) ? 1 : 0, lm_span_slot(lms[0], jb.launches, false), lms[0]->fine_fault, xcc_ids, dispatch_words);
+    else hipLaunchKernelGGL(lm_fine_trace_kernel_batch, dim3(8 * fine_k * per_xcd), dim3(kFineThreads), 0, s, (const StepArgs*)d_table, n, fine_k, jb.seq,
+                            (jb.seq == 0) ? 1 : 0, lm_span_slot(lms[0], jb.launches, false), lms[0]->fine_fault, xcc_ids, dispatch_words);
     jb.seq++; jb.launches++;
   }
   jb.active = 1;

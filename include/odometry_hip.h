@@ -198,6 +198,11 @@ typedef struct {
   float delta[6];
 } odo_lm_trace_row;
 int odo_lm_trace(const odo_lm* lm, odo_lm_trace_row* rows, int cap, int* n_rows);
+/* Recording on (1, the default of odo_lm_create) / off (0). Off: the optimiser's Solves run the lean builds of the LM kernels —
+ * no per-evaluation trace rows, no per-level cost statistics (odo_lm_trace returns -1, odo_lm_report's costs read 0; its
+ * evaluation counts stay) —, ~2 % less time per Solve. The drop-in LevenbergMarquardtOptimizer switches it off: the reference's
+ * ShowReport prints statistics nobody ever wrote (ref: src/lm_optimizer.cpp:364-371). Not while a Solve is in flight. */
+int odo_lm_set_record(odo_lm* lm, int on);
 /* Roofline leg of bench.py (any size / intrinsics, e.g. the dense 1920x1080 config): `reps` event-bracketed launches of
  * the evaluation kernel on `level` at pose T; mean / min launch time, algorithmic bytes of one launch, residual count. */
 int odo_lm_time_eval(odo_lm* lm, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img, int level,

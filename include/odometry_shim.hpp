@@ -1231,8 +1231,13 @@ class LevenbergMarquardtOptimizer {  // ref: include/lm_optimizer.h:24-115
     if (odo_lm_create(detail::context(), lambda, precision, kMaxIterations.data(), (int)kMaxIterations.size(),
                       affine_data(kRelativeInit), robust_est, huber_delta, Kp, &lm_) != 0)
       std::cout << "odometry_hip: " << odo_last_error() << std::endl;
+#ifndef ODOMETRY_SHIM_REAL_REPORT
+    // ShowReport prints the reference's never-written statistics (zeros, see there) and nothing else of this class reads the
+    // per-evaluation trace: the Solves run the lean LM kernels (odo_lm_set_record)
+    else (void)odo_lm_set_record(lm_, 0);
+#endif
 #ifdef ODOMETRY_SHIM_WITH_OPENCV
-    else (void)odo_lm_set_idle_callback(lm_, &detail::solve_idle, nullptr);   // ComputeDepth's output images are built while Solve waits
+    if (lm_) (void)odo_lm_set_idle_callback(lm_, &detail::solve_idle, nullptr);   // ComputeDepth's output images are built while Solve waits
 #endif
   }
   ~LevenbergMarquardtOptimizer() { odo_lm_destroy(lm_); }

@@ -88,6 +88,7 @@ SIGNATURES = {
     "odo_lm_destroy": (C.c_int, [_vp]),
     "odo_lm_accumulate": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _fp, _dp]),
     "odo_lm_trace": (C.c_int, [_vp, C.POINTER(LmTraceRow), C.c_int, _ip]),
+    "odo_lm_set_record": (C.c_int, [_vp, C.c_int]),
     "odo_lm_time_eval": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _fp, C.c_int, _fp, _fp, _dp, _ip]),
     "odo_lm_time_eval_batch": (C.c_int, [C.c_int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.c_int, _fp, C.c_int, _fp, _fp, _dp, _ip]),
     "odo_lm_event_timing": (C.c_int, [_vp, C.c_int]),

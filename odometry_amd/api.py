@@ -222,6 +222,11 @@ class LevenbergMarquardtOptimizer:
                                             acc.ctypes.data_as(C.POINTER(C.c_double)))
         return st, acc
 
+    def set_record(self, on):
+        """odo_lm_set_record: off = no trace rows / cost statistics, the Solves run the lean LM kernels (what the trackers' own
+        optimisers and the drop-in C++ class do)."""
+        L.check(self.ctx.lib.odo_lm_set_record(self.h, 1 if on else 0), "odo_lm_set_record")
+
     def trace(self):
         rows = (L.LmTraceRow * 128)()
         n = C.c_int(0)

@@ -2416,10 +2416,15 @@ extern "C" int odo_lm_report(const odo_lm* m, int iters[4], float cost[4][2]) {
   return 0;
 }
 
+extern "C" int odo_lm_set_record(odo_lm* m, int on) {
+  if (!m) return fail("odo_lm_set_record: NULL arg");
+  m->record = on ? 1 : 0;
+  return 0;
+}
 extern "C" int odo_lm_trace(const odo_lm* mc, odo_lm_trace_row* rows, int cap, int* n_rows) {
   odo_lm* m = const_cast<odo_lm*>(mc);
   if (!m || !n_rows) return fail("NULL arg");
-  if (!m->record) return fail("odo_lm_trace: this optimiser does not record its trace (a tracker's own; ODO_LM_TRACE=1 keeps it)");
+  if (!m->record) return fail("odo_lm_trace: this optimiser does not record its trace (odo_lm_set_record(lm, 0), or a tracker's own: ODO_LM_TRACE=1 keeps it)");
   if (m->trace_stale) {
     HIP_OK(hipMemcpyAsync(m->h_trace, m->d_trace, sizeof(LmTraceRow) * kTraceCap, hipMemcpyDeviceToHost, m->ctx->stream));
     HIP_OK(hipStreamSynchronize(m->ctx->stream));

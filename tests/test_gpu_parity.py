@@ -165,6 +165,28 @@ def test_lm_solve_pose_parity(api, O, kitti_seq, robust, mode):
     assert abs(T[2, 3] - gt[2, 3]) < 0.05
 
 
+@pytest.mark.parametrize("robust", [1, 0])
+def test_lean_kernels_give_the_recording_kernels_pose_bit_for_bit(api, O, kitti_seq, robust):
+    """odo_lm_set_record(lm, 0) — what the trackers' own optimisers and the drop-in C++ class run — selects the lean builds of
+    lm_coarse_kernel / lm_fine_kernel (no trace rows, no cost statistics, no t-distribution or bilinear path compiled in); a
+    recording optimiser runs lm_coarse_full_kernel / lm_fine_trace_kernel. Same pose, same evaluation counts, bit for bit; the lean
+    one has no trace to hand out."""
+    L0, L1, inv, p0, d0, p1, *_ = _kitti_pyrs(api, O, kitti_seq)
+    rec = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, robust, 28.0)
+    lean = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, robust, 28.0)
+    lean.set_record(False)
+    Ta, Tb = rec.Solve(p0, d0, p1), lean.Solve(p0, d0, p1)
+    assert rec.last_status == 0 and lean.last_status == 0
+    assert np.array_equal(np.asarray(Ta).view(np.uint32), np.asarray(Tb).view(np.uint32))
+    assert rec.launch_stats()[0] == lean.launch_stats()[0]        # evaluations
+    assert len(rec.trace()) == rec.launch_stats()[0]
+    with pytest.raises(Exception):
+        lean.trace()
+    lean.set_record(True)                                          # ... and back: the next Solve records again
+    Tc = lean.Solve(p0, d0, p1)
+    assert np.array_equal(np.asarray(Ta).view(np.uint32), np.asarray(Tc).view(np.uint32)) and len(lean.trace()) == rec.launch_stats()[0]
+
+
 def test_lm_solve_sequence_with_reset(api, O, kitti_seq):
     """Reset(pose, lambda) then track the next frame against the same keyframe (runner usage :215,:268)."""
     from odometry_amd import synth

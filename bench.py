@@ -398,6 +398,7 @@ def single_pair_leg(api, seq):
     out = {}
     for name, robust in (("t_distribution", 2), ("huber", 1)):
         lm = api.LevenbergMarquardtOptimizer(0.01, 0.995, [10, 20, 30, 30], np.eye(4), None, robust, 28.0, ctx=ctx)
+        lm.set_record(False)   # as the drop-in C++ class does (nothing reads the per-evaluation trace here): the lean LM kernels
         ts = []
         for _ in range(12):
             t0 = time.perf_counter()

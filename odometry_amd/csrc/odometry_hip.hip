@@ -807,6 +807,7 @@ struct odo_lm {
   int fused;  // 1 = one launch per evaluation (robust 0/1); 0 = separate residual / update kernels
   int mode;  // 0 auto (list when <= half of the interior has depth), 1 always dense scan, 2 always list
   int bilinear;  // odo_lm_set_sampling: 1 = bilinear sampling of the current image (non-parity option)
+  unsigned* dispatch_words;   // device address of g_lm_fine_dispatch on this optimiser's device (looked up once, at creation)
   int dense_plain_div;  // 1 = dense levels use the plain IEEE divisions only (ODO_DENSE_PLAIN_DIV: A/B of the shared-reciprocal path)
   void (*idle_pump)(void*);  // called while the host waits for the device (the tracker feeds its depth stream here)
   void* idle_arg;
@@ -855,6 +856,7 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
   HIP_OK(hipSetDevice(ctx->device));
   // the single-workgroup coarse kernel reduces through 118 KB of LDS (gfx950: up to 160 KB per workgroup)
   HIP_OK(lm_chain_setup());   // (the chain kernels live in lm_chain_kernels.hip: their dynamic LDS limit)
+  HIP_OK(hipGetSymbolAddress((void**)&m->dispatch_words, HIP_SYMBOL(g_lm_fine_dispatch)));
   HIP_OK(hipMalloc((void**)&m->d_state, sizeof(LmState) * 3));                          // double-buffered (fused pipeline) + continuation
   m->ust = m->d_state; m->upo = 0;
   m->fuse_dense_max = getenv("ODO_FUSE_DENSE_MAX") ? atoi(getenv("ODO_FUSE_DENSE_MAX")) : 131072;
@@ -1542,8 +1544,7 @@ static int lm_fused_begin_job(odo_lm* m, LmJob& jb, const odo_pyr* kf_img, const
     a.fine_home = m->fine_home;
     const int k_use = lm_fine_launch_k(m, fine_lo, min_level);
     m->fine_k_last = k_use;
-    unsigned* dispatch_words = nullptr;   // this unit's g_lm_fine_dispatch on this device: what the depth launches read
-    HIP_OK(hipGetSymbolAddress((void**)&dispatch_words, HIP_SYMBOL(g_lm_fine_dispatch)));
+    unsigned* const dispatch_words = m->dispatch_words;   // this unit's g_lm_fine_dispatch: what the depth launches read
     // the lean build has neither the trace writes nor the bilinear sampling path
     launch_lm_fine(m->robust == 2 ? 2 : (a.trace || m->bilinear) ? 1 : 0, 8 * k_use, s, a, k_use, m->d_xbuf, m->fine_fault, fine_lo, dispatch_words);
     jb.seq++;
@@ -2058,8 +2059,7 @@ static int lm_batch_begin(int n, odo_lm* const* lms, const odo_pyr* const* kf_im
   }
   jb.fine_used = any_fine != 0;
   if (any_fine) {
-    unsigned* dispatch_words = nullptr;   // g_lm_fine_dispatch on this device
-    HIP_OK(hipGetSymbolAddress((void**)&dispatch_words, HIP_SYMBOL(g_lm_fine_dispatch)));
+    unsigned* const dispatch_words = lms[0]->dispatch_words;   // g_lm_fine_dispatch on this device
     const XccIds xcc_ids = lms[0]->fine_home >= 0 ? device_xcc_ids(cx->device) : XccIds{{-1, -1, -1, -1, -1, -1, -1, -1}};
     if (lean) hipLaunchKernelGGL(lm_fine_kernel_batch, dim3(8 * fine_k * per_xcd), dim3(kFineThreads), 0, s, (const StepArgs*)d_table, n, fine_k, jb.seq,
                                  (jb.seq == 0) ? 1 : 0, lm_span_slot(lms[0], jb.launches, false), lms[0]->fine_fault, xcc_ids, dispatch_words);

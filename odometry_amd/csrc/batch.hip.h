@@ -216,9 +216,15 @@ extern "C" int odo_tracker_batch_destroy(odo_tracker_batch* b) {
   return 0;
 }
 
+// Largest lock step whose inverse-depth LMs run in ONE persistent launch (ODO_BATCH_DEPTH_PERSIST_MAX; the launch places at most
+// eight sequences). Round 6: 8 — see batch_depth_persist_ok.
+static int batch_depth_persist_max() {
+  static const int n = getenv("ODO_BATCH_DEPTH_PERSIST_MAX") ? atoi(getenv("ODO_BATCH_DEPTH_PERSIST_MAX")) : 8;
+  return n < 8 ? n : 8;
+}
 extern "C" int odo_tracker_batch_depth_persistent_stats(const odo_tracker_batch* b, int* on, int* chains_redone) {
   if (!b) return fail("odo_tracker_batch_depth_persistent_stats: NULL tracker");
-  if (on) *on = (b->S <= 4 && b->depth_persist_strikes < 3 && b->depth[0] && b->depth[0]->persist_cfg &&
+  if (on) *on = (b->S <= batch_depth_persist_max() && b->depth_persist_strikes < 3 && b->depth[0] && b->depth[0]->persist_cfg &&
                  (!getenv("ODO_BATCH_DEPTH_PERSIST") || atoi(getenv("ODO_BATCH_DEPTH_PERSIST")) != 0)) ? 1 : 0;
   if (chains_redone) *chains_redone = b->depth_persist_bails;
   return 0;
@@ -435,16 +441,19 @@ static int batch_chain_tail(odo_tracker_batch* b, BatchChain* c, hipStream_t s) 
 }
 
 // Issues at most one depth-LM launch (all slots of the chain) per call; enqueues the tail once every slot's LM has stopped.
-// The inverse-depth LM of every entry in one persistent launch: up to four sequences, each on an XCD of its own (block classes 4 .. 7;
-// the batched pose LM's sequences sit on 0 .. 3 with all 32 CUs of their XCDs). More sequences than that share XCDs with the pose LM
-// (16 of 32 CUs each at S = 8) where 80 workgroups of 512 threads do not fit beside it: those keep the launch per iteration.
+// The inverse-depth LM of every entry in one persistent launch: up to eight sequences. Up to four each have an XCD of their own (block
+// classes 4 .. 7; the batched pose LM's sequences sit on 0 .. 3 with all 32 CUs of their XCDs); more than that share XCDs with the
+// pose LM (16 of 32 CUs each at S = 8). Round 5 kept S > 4 on the launch per iteration: the persistent launch was no faster there
+// (its 80 workgroups of 512 threads held the CUs the front end of eight frames was short of). With round 6's builds — the depth
+// kernels under the occupancy-first scheduler: depth_lm_persistent_batch_kernel 62 VGPRs, eight waves per SIMD; the batched pose
+// launch 203 — it is: S = 8 14 230-14 450 -> 16 600-17 050 frames/s, no chain redone in 20 000 lock steps (tools/batch_soak.py 8),
+// every pass bit-identical; S = 5 / 6: 12 370 / 14 010. S > 8 keeps the launch per iteration.
 // ODO_BATCH_DEPTH_PERSIST=0: off. A sequence whose launch gives up (a wait ran out: its workgroups were not all resident) makes the
 // whole chain run again on the step launches (batch_chain_run); three such chains switch the launch off for this tracker.
 static bool batch_depth_persist_ok(const odo_tracker_batch* b, const BatchChain* c) {
   static const bool on = !getenv("ODO_BATCH_DEPTH_PERSIST") || atoi(getenv("ODO_BATCH_DEPTH_PERSIST")) != 0;
   const odo_depth* d0 = b->depth[0];
-  static const int max_n = getenv("ODO_BATCH_DEPTH_PERSIST_MAX") ? atoi(getenv("ODO_BATCH_DEPTH_PERSIST_MAX")) : 4;
-  return on && !c->no_persist_once && b->depth_persist_strikes < 3 && (int)c->ids.size() <= max_n && (int)c->ids.size() <= 8 && d0->persist_cfg && d0->max_iters <= kDpMaxIters &&
+  return on && !c->no_persist_once && b->depth_persist_strikes < 3 && (int)c->ids.size() <= batch_depth_persist_max() && d0->persist_cfg && d0->max_iters <= kDpMaxIters &&
          c->h_ptab && c->d_ptab;
 }
 static int batch_chain_persistent(odo_tracker_batch* b, BatchChain* c, hipStream_t s) {

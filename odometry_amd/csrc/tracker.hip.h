@@ -286,6 +286,10 @@ static void tracker_worker_main(odo_tracker* t) {
     if (idle_spins == 0 && done > 0 && !persist_always) t->depth->persist_off_once = 1;
     idle_spins = 0;
     const auto w0 = std::chrono::steady_clock::now();
+#ifdef ODO_DIAG   // diagnostic build only (tools/interference_probe.py): the stream-B job left out, to price what it costs the pose LM beside it
+    static const bool diag_skip = getenv("ODO_DIAG_SKIP_DEPTH") != nullptr;
+    if (diag_skip && done >= 2) { t->jobs[done & 1].rc = 0; t->w_done.store(done + 1, std::memory_order_release); continue; }
+#endif
     (void)tracker_job_run(t, &t->jobs[done & 1], false);
     t->tm_depth_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
     t->w_done.store(done + 1, std::memory_order_release);

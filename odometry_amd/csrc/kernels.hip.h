@@ -1166,6 +1166,17 @@ struct StepLaunch {
   int seq, first_of_solve;
   unsigned long long* span;
 };
+// The level table of a launch's StepArgs into LDS, by all threads at once (a dword each). `src` = the StepArgs itself, whose first member
+// the table is: the kernarg segment of a single launch (lm_kernarg_words: the StepArgs is the kernel's first parameter) or the
+// sequence's entry of a batched launch's table. Thread 0 copying it member by member went through scalar loads in rounds of what the
+// scalar registers hold — three to four dependent trips to device memory, 4.1 us of the coarse launch's 5.8 us in front of its first
+// evaluation (profiles/r06_relaunch_path.md).
+static_assert(offsetof(StepArgs, lv) == 0, "lm_copy_levels reads the level table at offset 0 of the StepArgs");
+__device__ __forceinline__ const unsigned* lm_kernarg_words() { return (const unsigned*)__builtin_amdgcn_kernarg_segment_ptr(); }
+__device__ __forceinline__ void lm_copy_levels(StepLevel* lv_sh, const unsigned* __restrict__ src) {
+  constexpr int kWords = (int)(sizeof(StepLevel) * ODO_MAX_LEVELS_K / sizeof(unsigned));
+  for (int i = (int)threadIdx.x; i < kWords; i += (int)blockDim.x) ((unsigned*)lv_sh)[i] = src[i];
+}
 // In a batched launch (gridDim.y sequences) one block in eight takes part, a different residue per sequence: several hundred
 // atomics on one address serialise in the L2 (~10 ns each: ~4 us for the 424 blocks of an S = 8 step launch, on a 16 us kernel).
 __device__ __forceinline__ bool lm_span_block() {
@@ -1779,8 +1790,17 @@ __device__ __forceinline__ float coarse_tdist_sigma(double (*part)[kCoarseChunks
 // the t-distribution scale passes with their td_* registers and the trace / cost-statistics writes are compiled out, not branched
 // around (+ 1.5 % on the headline, profiles/r06_state_machine_ab.md: what a single latency-bound wave does not execute still costs
 // it registers and scheduling freedom). kFull = true: everything decided at run time from StepArgs (robust == 2, trace != NULL).
+#if ODO_PHASE_STAMPS
+// Diagnostic build: where the wall clock of a Solve goes OUTSIDE the evaluation loops (100 MHz ticks, device memory, thread 0 of the
+// publishing workgroup at exit): [0] / [1] exit stamps of the last coarse / fine launch, [4..8] coarse prologue, loop, epilogue, previous
+// fine exit -> this entry, launches; [9..13] the same for the fine launch (with coarse exit -> fine entry). Read by lm_chain_diag_read.
+ODO_DEVICE_VAR unsigned long long g_lm_diag[24];   // [16..18] coarse prologue: entry -> level table in LDS, -> lm_fused_prologue done, -> hot state loaded
+#endif
 template <bool kFull>
-__device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaunch& q, int min_level) {
+__device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaunch& q, int min_level, const unsigned* __restrict__ lv_src) {
+#if ODO_PHASE_STAMPS
+  const unsigned long long w_entry = (unsigned long long)wall_clock64();
+#endif
   if (lm_chain_skip(a)) return;
   // The pose LM is the latency-critical chain of a frame, while the depth stream floods the CUs with throughput work
   // (selection, SSD scan) at the same time: raise this workgroup's issue priority on the SIMDs it shares with them.
@@ -1795,21 +1815,26 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
   // ODO_COARSE_STAMPS: the state machine's phase sums stay in LDS and go out ONCE, at exit — round 5 added them to the host-mapped
   // counters from inside the loop (four read-modify-writes over PCIe per iteration), which the "state-machine" lap then measured
   __shared__ unsigned long long sm_sh[4];
+  lm_copy_levels(lv_sh, lv_src);
   if (threadIdx.x == 0) {
-#pragma unroll
-    for (int l = 0; l < ODO_MAX_LEVELS_K; l++) lv_sh[l] = a.lv[l];
 #pragma unroll
     for (int i = 0; i < 4; i++) sm_sh[i] = 0;
   }
   __syncthreads();
+#if ODO_PHASE_STAMPS
+  const unsigned long long w_p1 = (unsigned long long)wall_clock64();
+#endif
   // state in (or initialised), a pending evaluation of an earlier launch consumed, pyramid walk started
   lm_fused_prologue(q.st_in, q.part_in, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, red_sh, acc_sh, (kFull ? a.trace : (LmTraceRow*)nullptr), a.cost_stat, true,
                     q.first_of_solve ? a.init : nullptr, a.stop_level, a.chain_in_token ? a.chain_pose : nullptr);
+#if ODO_PHASE_STAMPS
+  const unsigned long long w_p2 = (unsigned long long)wall_clock64();
+#endif
   LmHot hot;                    // wave 0's copy of the state between evaluations (lm_state_machine_hot; the other waves never look at theirs)
   lm_hot_load(hot, s_sh);
   if (ODO_DBG(a) && threadIdx.x == 0 && q.seq < 56) ODO_DBG(a)[16 + 2 * q.seq] = wall_clock64();
   unsigned long long c_eval = 0, c_red = 0, c_sm = 0, c_it = 0, c_last = ODO_DBG(a) ? __builtin_readcyclecounter() : 0;
-  const unsigned long long c_begin = c_last;
+  const unsigned long long c_begin = c_last, w_begin = ODO_DBG(a) ? (unsigned long long)wall_clock64() : 0;
   auto lap = [&](unsigned long long& sum) {
     if (ODO_DBG(a)) { const unsigned long long now = __builtin_readcyclecounter(); sum += now - c_last; c_last = now; }
   };
@@ -1937,12 +1962,25 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
                          ODO_DBG(a) ? sm_sh : nullptr, a.stop_level);
     lap(c_sm);
   }
+#if ODO_PHASE_STAMPS
+  const unsigned long long w_loop_end = (unsigned long long)wall_clock64();
+#endif
   if (threadIdx.x == 0) lm_hot_store(hot, s_sh);   // (read back by wave 0 only, below: a wave's LDS accesses stay in order)
   lm_fused_publish(s_sh, q.st_out, a.host_prog, q.seq, a.token, a.cost_stat, a.out, a.done_flag, a.final_state, chain_out_of(a));
+#if ODO_PHASE_STAMPS
+  if (ODO_DBG(a) && threadIdx.x == 0) {
+    const unsigned long long now = (unsigned long long)wall_clock64();
+    g_lm_diag[4] += w_begin - w_entry; g_lm_diag[5] += w_loop_end - w_begin; g_lm_diag[6] += now - w_loop_end;
+    g_lm_diag[16] += w_p1 - w_entry; g_lm_diag[17] += w_p2 - w_p1; g_lm_diag[18] += w_begin - w_p2;
+    if (g_lm_diag[1] && w_entry > g_lm_diag[1] && w_entry - g_lm_diag[1] < 100000ull) { g_lm_diag[7] += w_entry - g_lm_diag[1]; g_lm_diag[3] += w_entry - g_lm_diag[2]; g_lm_diag[14] += 1; }
+    g_lm_diag[0] = now; g_lm_diag[8] += 1;
+  }
+#endif
   if (ODO_DBG(a) && threadIdx.x == 0) {
     if (q.seq < 56) ODO_DBG(a)[16 + 2 * q.seq + 1] = wall_clock64();
     ODO_DBG(a)[0] += c_eval; ODO_DBG(a)[1] += c_red; ODO_DBG(a)[2] += c_sm; ODO_DBG(a)[3] += c_it;
     ODO_DBG(a)[4] += __builtin_readcyclecounter() - c_begin; ODO_DBG(a)[5] += 1;
+    ODO_DBG(a)[6] += (unsigned long long)wall_clock64() - w_begin;   // 100 MHz ticks beside the shader cycles of [4]: the shader clock under this load
 #pragma unroll
     for (int i = 0; i < 4; i++) ODO_DBG(a)[8 + i] += sm_sh[i];
   }
@@ -1952,11 +1990,11 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
 #ifdef ODO_LM_CHAIN_TU   // (the chain unit: see the top of this header)
 static __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int min_level) {   // Huber / L2, nothing recorded
   const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve, a.span};
-  lm_coarse_body<false>(a, q, min_level);
+  lm_coarse_body<false>(a, q, min_level, lm_kernarg_words());
 }
 static __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_full_kernel(StepArgs a, int min_level) {   // t-distribution weights and / or trace rows
   const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve, a.span};
-  lm_coarse_body<true>(a, q, min_level);
+  lm_coarse_body<true>(a, q, min_level, lm_kernarg_words());
 }
 #endif  // ODO_LM_CHAIN_TU
 // Batched twin (see lm_step_kernel_batch): one workgroup per sequence, each with its own min_level (a sequence without a
@@ -1966,7 +2004,7 @@ template <bool kFull>
 __device__ __forceinline__ void lm_coarse_batch_entry(const StepArgs* __restrict__ table, int seq, int first_of_solve, unsigned long long* span) {
   const StepArgs& a = table[blockIdx.y];
   const StepLaunch q = {a.st2[seq & 1], a.st2[(seq + 1) & 1], a.part2[seq & 1], a.part2[(seq + 1) & 1], seq, first_of_solve, span};
-  lm_coarse_body<kFull>(a, q, a.min_level);
+  lm_coarse_body<kFull>(a, q, a.min_level, (const unsigned*)&table[blockIdx.y]);
 }
 ODO_KERNEL void __launch_bounds__(kCoarseBlock) lm_coarse_kernel_batch(const StepArgs* __restrict__ table, int seq, int first_of_solve,
                                                                        unsigned long long* span) {
@@ -2253,7 +2291,10 @@ __device__ __forceinline__ float fine_tdist_sigma(unsigned long long* __restrict
 // kTrace = false: no per-evaluation trace rows / cost statistics (see lm_coarse_body's kFull) — the trackers' optimisers.
 template <bool kTdist, bool kTrace>
 __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch& q, int K, int w, unsigned long long* __restrict__ xbuf,
-                                             int fault, int lo_level) {
+                                             int fault, int lo_level, const unsigned* __restrict__ lv_src) {
+#if ODO_PHASE_STAMPS
+  const unsigned long long w_entry = (unsigned long long)wall_clock64();
+#endif
   __builtin_amdgcn_s_setprio(3);  // see lm_coarse_kernel
   const int t = threadIdx.x, tl = t & (kLmBlock - 1), half = t >> 8;
   const bool publisher = (w == 0);
@@ -2269,9 +2310,8 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
   const unsigned tag_base = a.fine_epoch << 8;   // unique per launch on this buffer (lm_fine_next_epoch): a stale granule cannot pass for a new one
   unsigned long long* place = xbuf + 2 * kFineRowsMax * kFineGran;  // [K] {xcc id, launch epoch} words
   const unsigned wait_limit = a.fine_wait ? a.fine_wait : kFineWaitTicks;
+  lm_copy_levels(lv_sh, lv_src);
   if (t == 0) {
-#pragma unroll
-    for (int l = 0; l < ODO_MAX_LEVELS_K; l++) lv_sh[l] = a.lv[l];
     bail_sh = 0;
     local_sh = 0;
 #pragma unroll
@@ -2314,6 +2354,7 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
   bool pt_ok = false;
   int pt_level = -1;
   unsigned long long c_eval = 0, c_xchg = 0, c_sm = 0, c_it = 0, c_last = ODO_DBG(a) ? __builtin_readcyclecounter() : 0;
+  const unsigned long long c_begin = c_last, w_begin = ODO_DBG(a) ? (unsigned long long)wall_clock64() : 0;
   auto lap = [&](unsigned long long& sum) {
     if (ODO_DBG(a)) { const unsigned long long now = __builtin_readcyclecounter(); sum += now - c_last; c_last = now; }
   };
@@ -2442,15 +2483,31 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
                          (ODO_DBG(a) && publisher) ? sm_sh : nullptr, a.stop_level);
     lap(c_sm);
   }
+#if ODO_PHASE_STAMPS
+  const unsigned long long w_loop_end = (unsigned long long)wall_clock64();
+#endif
   if (t == 0) lm_hot_store(hot, s_sh);
   if (bail_sh && t == 0) { s_sh.status = -2; s_sh.active = 0; s_sh.finished = 1; }   // -2: gave up waiting (the host redoes the Solve)
   __syncthreads();
   if (publisher) {
     lm_fused_publish(s_sh, q.st_out, a.host_prog, q.seq, a.token, a.cost_stat, a.out, a.done_flag, a.final_state, chain_out_of(a));
+#if ODO_PHASE_STAMPS
+    const unsigned long long w_published = (unsigned long long)wall_clock64();
+#endif
     if (ODO_DBG(a) && t == 0) { ODO_DBG(a)[128] += c_eval; ODO_DBG(a)[129] += c_xchg; ODO_DBG(a)[130] += c_sm; ODO_DBG(a)[131] += c_it; ODO_DBG(a)[132] += 1; ODO_DBG(a)[133] += local ? 1 : 0;
+      ODO_DBG(a)[134] += __builtin_readcyclecounter() - c_begin; ODO_DBG(a)[135] += (unsigned long long)wall_clock64() - w_begin;
 #pragma unroll
       for (int i = 0; i < 4; i++) ODO_DBG(a)[136 + i] += sm_sh[i]; }
     if (t == 0 && q.span) atomicMax(q.span + 1, (unsigned long long)wall_clock64());
+#if ODO_PHASE_STAMPS
+    if (ODO_DBG(a) && t == 0) {
+      const unsigned long long now = w_published;   // (the stamped build's own counter updates over PCIe follow it)
+      g_lm_diag[2] = w_loop_end;
+      g_lm_diag[9] += w_begin - w_entry; g_lm_diag[10] += w_loop_end - w_begin; g_lm_diag[11] += now - w_loop_end;
+      if (g_lm_diag[0] && w_entry > g_lm_diag[0] && w_entry - g_lm_diag[0] < 100000ull) { g_lm_diag[12] += w_entry - g_lm_diag[0]; g_lm_diag[15] += 1; }
+      g_lm_diag[1] = now; g_lm_diag[13] += 1;
+    }
+#endif
   }
 }
 // grid = 8 * K blocks: the class (blockIdx.x & 7) that sits on the optimiser's home XCD takes part, the others return at once
@@ -2477,7 +2534,7 @@ __device__ __forceinline__ void lm_fine_entry(const StepArgs& a, int K, unsigned
   }
   if (!fine_on_home(a.fine_home) || lm_chain_skip(a)) return;
   const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve, a.span};
-  lm_fine_body<kTdist, kTrace>(a, q, K, (int)(blockIdx.x >> 3), xbuf, fault, lo_level);
+  lm_fine_body<kTdist, kTrace>(a, q, K, (int)(blockIdx.x >> 3), xbuf, fault, lo_level, lm_kernarg_words());
 }
 #ifdef ODO_LM_CHAIN_TU
 static __global__ void __launch_bounds__(kFineThreads) lm_fine_kernel(StepArgs a, int K, unsigned long long* __restrict__ xbuf, int fault,
@@ -2522,10 +2579,10 @@ __device__ __forceinline__ void lm_fine_batch_entry(const StepArgs* __restrict__
     // nothing to evaluate here, but the launch number is the whole batch's: one workgroup carries the sequence's state from this
     // launch's input buffer to its output buffer (prologue + publish, no level at or above lo_level = none), as a step launch of a
     // finished sequence does
-    if (w == 0) lm_fine_body<false, kTrace>(a, q, 1, 0, a.xbuf, 0, ODO_MAX_LEVELS_K + 1);
+    if (w == 0) lm_fine_body<false, kTrace>(a, q, 1, 0, a.xbuf, 0, ODO_MAX_LEVELS_K + 1, (const unsigned*)&table[i]);
     return;
   }
-  lm_fine_body<false, kTrace>(a, q, K, w, a.xbuf, fault, a.fine_lo);   // (a batched Solve never carries t-distribution weights: lm_batch_begin)
+  lm_fine_body<false, kTrace>(a, q, K, w, a.xbuf, fault, a.fine_lo, (const unsigned*)&table[i]);   // (a batched Solve never carries t-distribution weights: lm_batch_begin)
 }
 ODO_KERNEL void __launch_bounds__(kFineThreads) lm_fine_kernel_batch(const StepArgs* __restrict__ table, int n, int K, int seq,
                                                                      int first_of_solve, unsigned long long* span, int fault, XccIds xcc,
@@ -3462,6 +3519,9 @@ ODO_KERNEL void __launch_bounds__(kDlmBlock) depth_stats_kernel(int run_lm, int 
 // Launchers of the single tracker's chain kernels (defined in lm_chain_kernels.hip, see the top of this header).
 // variant of the fine launch: 0 = lean (Huber / L2, floor sampling, nothing recorded), 1 = trace rows and / or bilinear sampling, 2 =
 // t-distribution weights. dispatch_words: device address of the main unit's g_lm_fine_dispatch.
+#if ODO_PHASE_STAMPS
+void lm_chain_diag_read(unsigned long long out[24]);
+#endif
 hipError_t lm_chain_setup();   // the coarse kernels' dynamic LDS limit; once per process and device
 void launch_lm_coarse(bool lean, hipStream_t s, const StepArgs& a, int min_level);
 void launch_lm_fine(int variant, int blocks, hipStream_t s, const StepArgs& a, int K, unsigned long long* xbuf, int fault, int lo_level,

@@ -34,4 +34,10 @@ void launch_lm_fine(int variant, int blocks, hipStream_t s, const StepArgs& a, i
     hipLaunchKernelGGL(lm_fine_kernel, dim3(blocks), dim3(kFineThreads), 0, s, a, K, xbuf, fault, lo_level, dispatch_words);
 }
 
+#if ODO_PHASE_STAMPS
+void lm_chain_diag_read(unsigned long long out[24]) {   // diagnostic build: the wall-clock sums the chain kernels keep in device memory
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lm_diag), sizeof(unsigned long long) * 24) != hipSuccess) memset(out, 0, sizeof(unsigned long long) * 24);
+}
+#endif
+
 }  // namespace odo

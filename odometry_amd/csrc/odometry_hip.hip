@@ -1273,6 +1273,10 @@ static int lm_span_collect(odo_lm* m) {
   m->span_kind->clear();
   return 0;
 }
+// ODO_TRACK_DEBUG: host-side laps of the relaunch path (result seen -> next Solve's launches issued), printed by odo_tracker_track.
+static double g_lap_us[12]; static long g_lap_n; static std::chrono::steady_clock::time_point g_lap_t;
+static inline void lap_start() { g_lap_t = std::chrono::steady_clock::now(); }
+static inline void lap(int i) { const auto n = std::chrono::steady_clock::now(); g_lap_us[i] += std::chrono::duration<double, std::micro>(n - g_lap_t).count(); g_lap_t = n; }
 static inline int lm_job_progress(const odo_lm* m) {
   const int v = ((volatile int*)m->h_prog)[0];
   return ((v >> kProgSeqBits) == m->job.token) ? (v & ((1 << kProgSeqBits) - 1)) : 0;
@@ -1503,6 +1507,20 @@ static int lm_fused_begin_job(odo_lm* m, LmJob& jb, const odo_pyr* kf_img, const
       fprintf(stderr, "[fine stamps] per evaluation: eval + publish %.0f gather + fold %.0f state-machine %.0f cycles; evaluations/launch "
               "%.2f, same-XCD launches %.0f %%\n", (double)dbg_buf[128] / dbg_buf[131], (double)dbg_buf[129] / dbg_buf[131],
               (double)dbg_buf[130] / dbg_buf[131], (double)dbg_buf[131] / dbg_buf[132], 100.0 * (double)dbg_buf[133] / dbg_buf[132]);
+#if ODO_PHASE_STAMPS
+    if (dbg_buf && dbg_buf[5] > 0 && dbg_buf[5] % 500 == 0) {
+      unsigned long long g[24];
+      lm_chain_diag_read(g);
+      if (g[8] && g[13])
+        fprintf(stderr, "[wall clock outside the loops] fine loop end -> next coarse entry %.2f us; coarse: previous fine exit -> entry %.2f us, prologue %.2f, loop %.2f, epilogue %.2f; fine: coarse exit -> "
+                "entry %.2f us, prologue %.2f, loop %.2f, epilogue %.2f\n", 0.01 * g[3] / (g[14] ? g[14] : 1), 0.01 * g[7] / (g[14] ? g[14] : 1), 0.01 * g[4] / g[8], 0.01 * g[5] / g[8], 0.01 * g[6] / g[8],
+                0.01 * g[12] / (g[15] ? g[15] : 1), 0.01 * g[9] / g[13], 0.01 * g[10] / g[13], 0.01 * g[11] / g[13]);
+      if (g[8]) fprintf(stderr, "[coarse prologue] entry -> level table in LDS %.2f us, lm_fused_prologue %.2f, hot state %.2f\n", 0.01 * g[16] / g[8], 0.01 * g[17] / g[8], 0.01 * g[18] / g[8]);
+    }
+#endif
+    if (dbg_buf && dbg_buf[5] > 0 && dbg_buf[5] % 100 == 0 && dbg_buf[6] > 0 && dbg_buf[135] > 0)
+      fprintf(stderr, "[shader clock] inside the coarse launch %.0f MHz, inside the fine launch %.0f MHz (cycle counter / 100 MHz wall clock)\n",
+              (double)dbg_buf[4] / (double)dbg_buf[6] * 100.0, (double)dbg_buf[134] / (double)dbg_buf[135] * 100.0);
     if (dbg_buf && dbg_buf[5] > 0 && dbg_buf[5] % 100 == 0 && dbg_buf[11] > 0)
       fprintf(stderr, "[state machine] coarse launch: decide %.0f solve %.0f exp/compose %.0f cycles per evaluation\n",
               (double)dbg_buf[8] / dbg_buf[11], (double)dbg_buf[9] / dbg_buf[11], (double)dbg_buf[10] / dbg_buf[11]);
@@ -1525,7 +1543,9 @@ static int lm_fused_begin_job(odo_lm* m, LmJob& jb, const odo_pyr* kf_img, const
     a.seq = jb.seq; a.first_of_solve = 1;
     a.span = lm_span_slot(m, 0, true);
     // the trackers' optimisers (Huber / L2, nothing recorded) run the build without the scale passes and the trace writes
+    lap(6);
     launch_lm_coarse(m->robust != 2 && !a.trace && !m->bilinear, s, a, min_level);
+    lap(7);
     jb.seq++;
     jb.launches++;
   }
@@ -1656,13 +1676,17 @@ extern "C" int odo_lm_set_idle_callback(odo_lm* m, void (*fn)(void*), void* arg)
 extern "C" int odo_lm_solve_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img) {
   if (lm_check_pyrs(m, kf_img, kf_dep, cur_img)) return -1;
   HIP_OK(hipSetDevice(m->ctx->device));
+  lap(4);
   if (lm_job_matches(m, kf_img, kf_dep, cur_img)) return 0;
   m->job.active = 0;
   if (lm_prepare_keyframe(m, kf_img, kf_dep)) return -1;
   if (!lm_fused_eligible(m)) return 1;
+  lap(5);
   if (lm_fused_begin(m, kf_img, kf_dep, cur_img)) return -1;
+  lap(8);
   lm_fused_pump(m, false);
   HIP_OK(hipGetLastError());
+  lap(9);
   return 0;
 }
 
@@ -1804,6 +1828,7 @@ fused_again:
       }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
+    lap_start();
     memcpy(m->h_out, m->h_res + 48 * slot, sizeof(float) * 42);
     if (m->h_out[16] == -2.0f && m->fine_k > 0) {
       // The persistent launch gave up: one of its workgroups never showed up within the wait bound (they wait for each other,

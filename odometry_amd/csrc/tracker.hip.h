@@ -63,9 +63,11 @@ struct odo_tracker {
   int early_solve;
   int chain_solve;           // 1: ... and queued BEHIND this frame's Solve before its result exists (lm_chain_begin; opt-in: ODO_CHAIN_SOLVE=1 — measured no faster)
   long chain_used, chain_wasted;   // chained Solves adopted / that ran for nothing (the host's keyframe test disagreed with the guard)
-  double dbg_pre_us, dbg_spin_us, dbg_chain_us, dbg_verdict_us, dbg_post_us; long dbg_n;   // ODO_TRACK_DEBUG: host time per call, by phase
+  double dbg_pre_us, dbg_spin_us, dbg_chain_us, dbg_verdict_us, dbg_post_us, dbg_relaunch_us; long dbg_n, dbg_relaunch_n;   // ODO_TRACK_DEBUG: host time per call, by phase
   int depth_ahead;           // 1: with the next PAIR announced, the next frame's stream-B job is posted a frame early (ODO_NO_DEPTH_AHEAD=1: off)
   hipEvent_t ev_next;        // stream C: next_img is complete
+  int next_ready;            // 1: ev_next was seen complete by the host while it waited for the Solve (tracker_poll_next): the next Solve's
+                             // launches then go out without a wait packet in front of them (1.5 us of host time + the packet's processing)
 };
 
 static void tracker_worker_main(odo_tracker* t);
@@ -139,14 +141,14 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
   t->cand_lists = getenv("ODO_NO_CAND_LISTS") ? 0 : 1;
   t->tm_solve_us = t->tm_depth_us = t->tm_frame_us = t->tm_wait_us = 0.0; t->tm_frames = 0;
   t->w_posted.store(0); t->w_done.store(0); t->w_quit.store(0);
-  t->ev_next = nullptr;
+  t->ev_next = nullptr; t->next_ready = 0;
   t->early_solve = getenv("ODO_NO_EARLY_SOLVE") ? 0 : 1;
   // Chained Solves are OFF unless ODO_CHAIN_SOLVE=1: measured (round 4) they close the 14 us the GPU idles between
   // two Solves (rocprofv3: fine -> next coarse gap 14.2 -> 0.0 us) and the frame rate does not move (3 250 both ways): the LM
   // kernels' own wall time grows by what the gap gave (same cycle counts: the clock, not the work).
   t->chain_solve = (t->early_solve && getenv("ODO_CHAIN_SOLVE") && !getenv("ODO_NO_CHAIN_SOLVE")) ? 1 : 0;
   t->chain_used = t->chain_wasted = 0;
-  t->dbg_pre_us = t->dbg_spin_us = t->dbg_chain_us = t->dbg_verdict_us = t->dbg_post_us = 0.0; t->dbg_n = 0;
+  t->dbg_pre_us = t->dbg_spin_us = t->dbg_chain_us = t->dbg_verdict_us = t->dbg_post_us = t->dbg_relaunch_us = 0.0; t->dbg_n = t->dbg_relaunch_n = 0;
   t->depth_ahead = getenv("ODO_NO_DEPTH_AHEAD") ? 0 : 1;
   t->p = *p;
   float eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
@@ -223,6 +225,13 @@ static void tracker_job_pump_one(odo_tracker* t, TrackerJob* j) {
     if (depth_job_stats(t->depth, &j->dj)) j->err = 1;  // completion word AFTER the pyramids: it covers them too
     j->stage = 3;
   }
+}
+// Called from the Solve's wait loop (overlap_depth == 2, next frame announced): has stream C finished the next frame's pyramid?
+static void tracker_poll_next(void* arg) {
+  odo_tracker* t = (odo_tracker*)arg;
+  if (t->next_ready) return;
+  if (hipEventQuery(t->ev_next) == hipSuccess) t->next_ready = 1;
+  else (void)hipGetLastError();   // (hipErrorNotReady is not an error, and must not be the thread's last error when the next HIP_OK looks)
 }
 static void tracker_job_pump(void* arg) {
   odo_tracker* t = (odo_tracker*)arg;
@@ -459,7 +468,9 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
   }
   // ---- the next frame: its pyramid on stream C right away; with the pair announced its stream-B job goes into the ring too
   // (the helper runs it as soon as it is done with this frame's: the depth stream works a frame ahead of the pose LM)
+  t->next_ready = 0;
   if (early && tracker_next_pyramid(t, next_left)) return -1;
+  if (early && p.overlap_depth == 2 && !t->chain_solve) { t->lm->idle_pump = tracker_poll_next; t->lm->idle_arg = t; }
   if (ahead) {
     const long n = t->w_posted.load(std::memory_order_relaxed);
     TrackerJob* ja = &t->jobs[n & 1];   // the other slot: this frame's job is n - 1 (or done long ago)
@@ -500,6 +511,7 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
   const auto s0 = std::chrono::steady_clock::now();
   const int st = odo_lm_solve(t->lm, t->kf_img, t->kf_dep, t->cur_img, T);             // :215 (collects an early start)
   const int solved_token = t->lm->last_token, solved_slot = t->lm->last_slot;
+  lap(0);
   const auto s1 = std::chrono::steady_clock::now();
   t->tm_solve_us += std::chrono::duration<double, std::micro>(s1 - s0).count();
   t->lm->idle_pump = nullptr;
@@ -523,12 +535,15 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
   if (solve_status) *solve_status = st;
   if (is_new_keyframe) *is_new_keyframe = 0;
   if (motion_mag) *motion_mag = 0.0f;
+  lap(1);
   const float mag = motion_magnitude(T, p.keyframe_weight);                            // :253-257 (odo_math.h: the guard's own function)
   const bool promote = mag > p.keyframe_motion_th;                                     // :258
   // The next Solve's inputs: keyframe (unchanged unless this frame is promoted), next frame's pyramid (stream C, ev_next),
   // initial pose = T (:261 / :268 Reset). Started here, it runs while stream B finishes this frame's depth.
   auto start_next_solve = [&]() -> int {
-    if (hipStreamWaitEvent(t->ctx_a->stream, t->ev_next, 0) != hipSuccess) return 1;
+    lap(2);
+    if (!t->next_ready && hipStreamWaitEvent(t->ctx_a->stream, t->ev_next, 0) != hipSuccess) return 1;
+    lap(3);
     return odo_lm_solve_begin(t->lm, t->kf_img, t->kf_dep, t->next_img) < 0 ? -1 : 0;
   };
   bool reset_done = false;
@@ -556,6 +571,8 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
     odo_lm_reset(t->lm, T, 0.01f);                                                     // :268
     reset_done = true;
     if (start_next_solve() < 0) return -1;
+    t->dbg_relaunch_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - s1).count();
+    t->dbg_relaunch_n++;
   }
   // ---- collect this frame's stream-B job
   if (p.overlap_depth == 2) {
@@ -597,10 +614,16 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
   t->tm_frame_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - f0).count();
   t->tm_frames++;
   t->dbg_post_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - s1).count();
+  g_lap_n++;
+  if ((t->dbg_n + 1) % 500 == 0 && getenv("ODO_TRACK_DEBUG"))
+    fprintf(stderr, "[relaunch laps us] result seen -> Solve returned %.2f | pose math %.2f | magnitude + reset %.2f | WaitEvent %.2f | check + SetDevice %.2f | "
+            "keyframe check %.2f | args %.2f | coarse launch %.2f | fine launch %.2f | pump + GetLastError %.2f\n", g_lap_us[0] / g_lap_n, g_lap_us[1] / g_lap_n,
+            g_lap_us[2] / g_lap_n, g_lap_us[3] / g_lap_n, g_lap_us[4] / g_lap_n, g_lap_us[5] / g_lap_n, g_lap_us[6] / g_lap_n, g_lap_us[7] / g_lap_n, g_lap_us[8] / g_lap_n,
+            g_lap_us[9] / g_lap_n);
   if (++t->dbg_n % 500 == 0 && getenv("ODO_TRACK_DEBUG"))
     fprintf(stderr, "[track] per call: before the chain %.1f us, waiting for the next pyramid %.1f, chain launches %.1f, guard verdict %.1f, "
-            "after the Solve returned %.1f\n", t->dbg_pre_us / t->dbg_n, t->dbg_spin_us / t->dbg_n, t->dbg_chain_us / t->dbg_n,
-            t->dbg_verdict_us / t->dbg_n, t->dbg_post_us / t->dbg_n);
+            "after the Solve returned %.1f (Solve returned -> the next Solve's launches issued: %.2f)\n", t->dbg_pre_us / t->dbg_n, t->dbg_spin_us / t->dbg_n, t->dbg_chain_us / t->dbg_n,
+            t->dbg_verdict_us / t->dbg_n, t->dbg_post_us / t->dbg_n, t->dbg_relaunch_us / (t->dbg_relaunch_n ? t->dbg_relaunch_n : 1));
   return 0;
 }
 

@@ -1,5 +1,5 @@
-import csv,glob,statistics as st
-k=glob.glob("gpurun_out/gap_prof/*/*kernel_trace.csv")[0]
+import csv,glob,sys,statistics as st
+k=glob.glob((sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/gap_prof")+"/*/*kernel_trace.csv")[0]
 ops=[]
 for r in csv.DictReader(open(k)): ops.append((int(r["Start_Timestamp"]),int(r["End_Timestamp"]),r["Kernel_Name"].split("(")[0].replace("odo::","")))
 ops.sort()

@@ -1807,7 +1807,9 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
   __builtin_amdgcn_s_setprio(3);
   lm_span_begin(q.span);
   __shared__ LmState s_sh;
-  extern __shared__ double red_sh[];  // kCoarseLdsBytes: reduction buffer; its head doubles as the fold scratch
+  extern __shared__ __attribute__((aligned(16))) double red_sh[];  // kCoarseLdsBytes: reduction buffer; its head doubles as the fold scratch
+                                                                   // (16-byte aligned whatever static LDS precedes it: the row sums read it with ds_read_b128 —
+                                                                   //  68 bytes of static LDS in front of it cost the coarse launch 1 us per iteration)
   __shared__ double acc_sh[32];
   // The level table moves to LDS (static-index copy): every later access indexes it with the level read from the state,
   // and a dynamic index into the by-value kernel argument makes the compiler mirror all of `a` in scratch memory.

@@ -1273,10 +1273,16 @@ static int lm_span_collect(odo_lm* m) {
   m->span_kind->clear();
   return 0;
 }
-// ODO_TRACK_DEBUG: host-side laps of the relaunch path (result seen -> next Solve's launches issued), printed by odo_tracker_track.
+// Diagnostic build (-DODO_DIAG) + ODO_TRACK_DEBUG: host-side laps of the relaunch path (result seen -> next Solve's launches issued),
+// printed by odo_tracker_track. Compiled out of the product.
+#ifdef ODO_DIAG
 static double g_lap_us[12]; static long g_lap_n; static std::chrono::steady_clock::time_point g_lap_t;
 static inline void lap_start() { g_lap_t = std::chrono::steady_clock::now(); }
 static inline void lap(int i) { const auto n = std::chrono::steady_clock::now(); g_lap_us[i] += std::chrono::duration<double, std::micro>(n - g_lap_t).count(); g_lap_t = n; }
+#else
+static inline void lap_start() {}
+static inline void lap(int) {}
+#endif
 static inline int lm_job_progress(const odo_lm* m) {
   const int v = ((volatile int*)m->h_prog)[0];
   return ((v >> kProgSeqBits) == m->job.token) ? (v & ((1 << kProgSeqBits) - 1)) : 0;
@@ -1673,9 +1679,15 @@ extern "C" int odo_lm_set_idle_callback(odo_lm* m, void (*fn)(void*), void* arg)
 
 // Starts the Solve that a following odo_lm_solve(lm, kf_img, kf_dep, cur_img) will collect. Returns 0 when started (or already
 // running), 1 when this Solve does not run on the fused pipeline (nothing started: odo_lm_solve does all of it), -1 on error.
+// set_device = false: the caller has made the optimiser's device current on this thread already (odo_tracker_track: the call sits between
+// one Solve's result and the next Solve's first launch, where 0.3-0.5 us of hipSetDevice is 0.3-0.5 us of every frame)
+static int lm_solve_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img, bool set_device);
 extern "C" int odo_lm_solve_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img) {
+  return lm_solve_begin(m, kf_img, kf_dep, cur_img, true);
+}
+static int lm_solve_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img, bool set_device) {
   if (lm_check_pyrs(m, kf_img, kf_dep, cur_img)) return -1;
-  HIP_OK(hipSetDevice(m->ctx->device));
+  if (set_device) HIP_OK(hipSetDevice(m->ctx->device));
   lap(4);
   if (lm_job_matches(m, kf_img, kf_dep, cur_img)) return 0;
   m->job.active = 0;

@@ -527,14 +527,18 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
   // still reports its pose (and the runner then leaves its loop).
   memcpy(t->pose_to_kf, T, sizeof(T));
   float inv[16], cur[16];
-  if (!invert4(T, inv))   // singular pose_to_keyframe (the failure pseudo-identity has (3,3) = 0): Eigen's inverse() of a
-    for (int i = 0; i < 16; i++) inv[i] = __builtin_nanf("");  // singular matrix is inf / NaN, not zeros
-  matmul4(t->kf_abs, inv, cur);                                                        // :218
-  if (pose_to_keyframe) memcpy(pose_to_keyframe, T, sizeof(T));
-  if (abs_pose) memcpy(abs_pose, cur, sizeof(cur));
-  if (solve_status) *solve_status = st;
-  if (is_new_keyframe) *is_new_keyframe = 0;
-  if (motion_mag) *motion_mag = 0.0f;
+  // (called once the next Solve's launches are out — the keyframe test below needs T only, and every host instruction in front of those
+  //  launches is idle time of the pose-LM chain)
+  auto write_pose = [&]() {
+    if (!invert4(T, inv))   // singular pose_to_keyframe (the failure pseudo-identity has (3,3) = 0): Eigen's inverse() of a
+      for (int i = 0; i < 16; i++) inv[i] = __builtin_nanf("");  // singular matrix is inf / NaN, not zeros
+    matmul4(t->kf_abs, inv, cur);                                                        // :218
+    if (pose_to_keyframe) memcpy(pose_to_keyframe, T, sizeof(T));
+    if (abs_pose) memcpy(abs_pose, cur, sizeof(cur));
+    if (solve_status) *solve_status = st;
+    if (is_new_keyframe) *is_new_keyframe = 0;
+    if (motion_mag) *motion_mag = 0.0f;
+  };
   lap(1);
   const float mag = motion_magnitude(T, p.keyframe_weight);                            // :253-257 (odo_math.h: the guard's own function)
   const bool promote = mag > p.keyframe_motion_th;                                     // :258
@@ -544,7 +548,7 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
     lap(2);
     if (!t->next_ready && hipStreamWaitEvent(t->ctx_a->stream, t->ev_next, 0) != hipSuccess) return 1;
     lap(3);
-    return odo_lm_solve_begin(t->lm, t->kf_img, t->kf_dep, t->next_img) < 0 ? -1 : 0;
+    return lm_solve_begin(t->lm, t->kf_img, t->kf_dep, t->next_img, false) < 0 ? -1 : 0;   // (the device is current: set at the top of this call)
   };
   bool reset_done = false;
   const auto v0 = std::chrono::steady_clock::now();
@@ -570,10 +574,11 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
   if (early && !promote && !reset_done) {
     odo_lm_reset(t->lm, T, 0.01f);                                                     // :268
     reset_done = true;
-    if (start_next_solve() < 0) return -1;
+    if (start_next_solve() < 0) { write_pose(); return -1; }
     t->dbg_relaunch_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - s1).count();
     t->dbg_relaunch_n++;
   }
+  write_pose();
   // ---- collect this frame's stream-B job
   if (p.overlap_depth == 2) {
     if (tracker_wait_job(t, my_job)) { t->lm->job.active = 0; return -1; }
@@ -614,12 +619,14 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
   t->tm_frame_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - f0).count();
   t->tm_frames++;
   t->dbg_post_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - s1).count();
+#ifdef ODO_DIAG
   g_lap_n++;
   if ((t->dbg_n + 1) % 500 == 0 && getenv("ODO_TRACK_DEBUG"))
     fprintf(stderr, "[relaunch laps us] result seen -> Solve returned %.2f | pose math %.2f | magnitude + reset %.2f | WaitEvent %.2f | check + SetDevice %.2f | "
             "keyframe check %.2f | args %.2f | coarse launch %.2f | fine launch %.2f | pump + GetLastError %.2f\n", g_lap_us[0] / g_lap_n, g_lap_us[1] / g_lap_n,
             g_lap_us[2] / g_lap_n, g_lap_us[3] / g_lap_n, g_lap_us[4] / g_lap_n, g_lap_us[5] / g_lap_n, g_lap_us[6] / g_lap_n, g_lap_us[7] / g_lap_n, g_lap_us[8] / g_lap_n,
             g_lap_us[9] / g_lap_n);
+#endif
   if (++t->dbg_n % 500 == 0 && getenv("ODO_TRACK_DEBUG"))
     fprintf(stderr, "[track] per call: before the chain %.1f us, waiting for the next pyramid %.1f, chain launches %.1f, guard verdict %.1f, "
             "after the Solve returned %.1f (Solve returned -> the next Solve's launches issued: %.2f)\n", t->dbg_pre_us / t->dbg_n, t->dbg_spin_us / t->dbg_n, t->dbg_chain_us / t->dbg_n,

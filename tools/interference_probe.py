@@ -15,7 +15,7 @@ T = np.zeros(16, np.float32); A = np.zeros(16, np.float32)
 per = []
 poses = []
 gc.collect(); gc.disable()
-for rep in range(60):
+for rep in range(160):
     trk.init(*dev[0])
     ts = []
     for i in range(1, 8):
@@ -24,7 +24,7 @@ for rep in range(60):
         f = trk.track_into(dev[i][0], dev[i][1], T, A)
         ts.append(time.perf_counter() - t0)
         assert not f, "keyframe switch inside the probe"
-        if rep == 59: poses.append(T.copy())
+        if rep == 159: poses.append(T.copy())
     if rep >= 4: per.append(ts[1:])
     trk.lib.odo_tracker_quiesce(trk.h)
 gc.enable()

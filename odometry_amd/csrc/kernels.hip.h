@@ -2356,6 +2356,9 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
   bool pt_ok = false;
   int pt_level = -1;
   unsigned long long c_eval = 0, c_xchg = 0, c_sm = 0, c_it = 0, c_last = ODO_DBG(a) ? __builtin_readcyclecounter() : 0;
+#if ODO_PHASE_STAMPS
+  unsigned long long c_first = 0, n_first = 0;   // the first evaluation of every level (keyframe points and taps not in this XCD's L2 yet)
+#endif
   const unsigned long long c_begin = c_last, w_begin = ODO_DBG(a) ? (unsigned long long)wall_clock64() : 0;
   auto lap = [&](unsigned long long& sum) {
     if (ODO_DBG(a)) { const unsigned long long now = __builtin_readcyclecounter(); sum += now - c_last; c_last = now; }
@@ -2373,6 +2376,9 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
 #pragma unroll
     for (int i = 0; i < 16; i++) T[i] = s_sh.T[i];
     // ---- (a) + (b): my virtual blocks, two at a time (half h of the workgroup works on virtual block vb0 + h * K) ----
+#if ODO_PHASE_STAMPS
+    const bool first_of_level = (s_sh.level != pt_level);
+#endif
     const bool resident = (nblk <= 2 * K) && (L.n <= nblk * kLmBlock);  // one point per thread covers my share of the level
     if (resident) {
       // The keyframe point stays in registers for the whole level: one trip to L2 per level instead of one per evaluation.
@@ -2436,7 +2442,11 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
         if (vb < nblk && my_q < ODO_NACC && my_s == 0 && !(fault && vb == 0)) fine_publish(buf, vb, my_q, accq, tag, local);   // fault: as above
       }
     }
+#if ODO_PHASE_STAMPS
+    { const unsigned long long before = c_eval; lap(c_eval); if (first_of_level) { c_first += c_eval - before; n_first++; } }
+#else
     lap(c_eval);
+#endif
     // ---- (c): gather every row in the fold's order (lm_fused_prologue: segment seg adds rows seg, seg + 8, ... ascending) ----
     double v = 0.0;
     __builtin_amdgcn_s_setprio(0);  // waiting is not urgent: the depth stream's waves on this CU go first while we poll
@@ -2505,6 +2515,7 @@ __device__ __forceinline__ void lm_fine_body(const StepArgs& a, const StepLaunch
     if (ODO_DBG(a) && t == 0) {
       const unsigned long long now = w_published;   // (the stamped build's own counter updates over PCIe follow it)
       g_lm_diag[2] = w_loop_end;
+      g_lm_diag[19] += c_first; g_lm_diag[20] += n_first;
       g_lm_diag[9] += w_begin - w_entry; g_lm_diag[10] += w_loop_end - w_begin; g_lm_diag[11] += now - w_loop_end;
       if (g_lm_diag[0] && w_entry > g_lm_diag[0] && w_entry - g_lm_diag[0] < 100000ull) { g_lm_diag[12] += w_entry - g_lm_diag[0]; g_lm_diag[15] += 1; }
       g_lm_diag[1] = now; g_lm_diag[13] += 1;

@@ -1521,6 +1521,7 @@ static int lm_fused_begin_job(odo_lm* m, LmJob& jb, const odo_pyr* kf_img, const
         fprintf(stderr, "[wall clock outside the loops] fine loop end -> next coarse entry %.2f us; coarse: previous fine exit -> entry %.2f us, prologue %.2f, loop %.2f, epilogue %.2f; fine: coarse exit -> "
                 "entry %.2f us, prologue %.2f, loop %.2f, epilogue %.2f\n", 0.01 * g[3] / (g[14] ? g[14] : 1), 0.01 * g[7] / (g[14] ? g[14] : 1), 0.01 * g[4] / g[8], 0.01 * g[5] / g[8], 0.01 * g[6] / g[8],
                 0.01 * g[12] / (g[15] ? g[15] : 1), 0.01 * g[9] / g[13], 0.01 * g[10] / g[13], 0.01 * g[11] / g[13]);
+      if (g[20]) fprintf(stderr, "[fine launch] eval + publish of a level's FIRST evaluation: %.0f cycles (%.1f per launch)\n", (double)g[19] / g[20], (double)g[20] / g[13]);
       if (g[8]) fprintf(stderr, "[coarse prologue] entry -> level table in LDS %.2f us, lm_fused_prologue %.2f, hot state %.2f\n", 0.01 * g[16] / g[8], 0.01 * g[17] / g[8], 0.01 * g[18] / g[8]);
     }
 #endif

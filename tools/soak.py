@@ -21,9 +21,15 @@ trk = api.Tracker(0)
 dev = [(trk.upload_frame(l), trk.upload_frame(r)) for l, r in zip(seq["left"], seq["right"])]
 n = len(dev)
 first = None
-frame_ms = []
+# (frame times go into a preallocated array and the collector is off inside the loop: a Python list of a million floats is reallocated —
+#  and copied — as it grows, and a generation-2 collection walks it: both showed up as "frames" of several milliseconds)
+import gc   # noqa: E402
+frame_ms = np.zeros(n_total + n, np.float64)
+n_ms = 0
 done = 0
 identical = True
+gc.collect()
+gc.disable()
 t_all = time.perf_counter()
 while done < n_total:
     trk.init(*dev[0])
@@ -33,7 +39,8 @@ while done < n_total:
             trk.hint_next(*dev[k + 1])
         t0 = time.perf_counter()
         trk.track_into(dev[k][0], dev[k][1], pk[k - 1], pa[k - 1])
-        frame_ms.append((time.perf_counter() - t0) * 1e3)
+        frame_ms[n_ms] = (time.perf_counter() - t0) * 1e3
+        n_ms += 1
     done += n - 1
     if first is None:
         first = pk.copy()
@@ -41,7 +48,8 @@ while done < n_total:
         identical = identical and bool(np.array_equal(first, pk))
 trk._sync()
 dt = time.perf_counter() - t_all
-fm = np.array(frame_ms)
+gc.enable()
+fm = frame_ms[:n_ms]
 pose_k, pose_redone = trk.persistent_stats()
 _, depth_redone = trk.depth_persistent_stats()
 trk.close()

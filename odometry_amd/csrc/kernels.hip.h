@@ -1158,6 +1158,12 @@ struct StepArgs {
   // bench.py roofline: a sampled launch records its own execution span — span[0] = min over blocks of the device wall clock
   // (100 MHz) at entry, span[1] = max at exit; NULL: not sampled (two fire-and-forget device-scope atomics per block when on)
   unsigned long long* span;
+  // An ARMED coarse launch (lm_coarse_armed_kernel; the tracker's next Solve, queued behind the Solve in flight before that one has
+  // returned — lm_arm_begin): host-mapped, 17 data-tagged granules {value, tag = token} that the HOST writes once that Solve has
+  // returned and the runner's keyframe test is done: [0..15] the initial pose (what Reset hands the Solve, ref:
+  // run_odometry_kitti_offline.cpp:261,268), [16] 1 = go, 2 = return at once. Neither the host's launch call nor the dispatch lies
+  // between two Solves: the launch starts the moment the persistent launch in front of it retires, and finds its word waiting. NULL: not armed.
+  unsigned long long* arm;
 };
 // What changes from launch to launch of one Solve.
 struct StepLaunch {
@@ -1796,12 +1802,14 @@ __device__ __forceinline__ float coarse_tdist_sigma(double (*part)[kCoarseChunks
 // fine exit -> this entry, launches; [9..13] the same for the fine launch (with coarse exit -> fine entry). Read by lm_chain_diag_read.
 ODO_DEVICE_VAR unsigned long long g_lm_diag[24];   // [16..18] coarse prologue: entry -> level table in LDS, -> lm_fused_prologue done, -> hot state loaded
 #endif
-template <bool kFull>
+constexpr unsigned long long kArmWaitTicks = 200000000ull;   // an armed launch waits at most 2 s of the 100 MHz wall clock for its word; then it reports a
+                                                             // give-up (status -2: the host redoes the Solve on the step launches, like a persistent launch's)
+template <bool kFull, bool kArmed = false>
 __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaunch& q, int min_level, const unsigned* __restrict__ lv_src) {
 #if ODO_PHASE_STAMPS
   const unsigned long long w_entry = (unsigned long long)wall_clock64();
 #endif
-  if (lm_chain_skip(a)) return;
+  if (!kArmed && lm_chain_skip(a)) return;
   // The pose LM is the latency-critical chain of a frame, while the depth stream floods the CUs with throughput work
   // (selection, SSD scan) at the same time: raise this workgroup's issue priority on the SIMDs it shares with them.
   __builtin_amdgcn_s_setprio(3);
@@ -1822,13 +1830,45 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
 #pragma unroll
     for (int i = 0; i < 4; i++) sm_sh[i] = 0;
   }
-  __syncthreads();
+  __shared__ __attribute__((aligned(16))) float arm_pose_sh[16];
+  __shared__ __attribute__((aligned(16))) int arm_verdict_sh4[4];
+  if (kArmed) {
+    // The first wave reads the host's word (one read of host memory per pass: the trip over PCIe paces the loop). 17 granules, every
+    // one tagged with this Solve's token: no flag, no fence. Normally the word is there: the host wrote it while the launch in front
+    // of this one was retiring.
+    if (threadIdx.x < 64) {
+      const int lane = (int)threadIdx.x;
+      unsigned long long g = 0;
+      bool got = false;
+      const unsigned long long t0 = (unsigned long long)wall_clock64();
+      for (int spin = 0; !got; spin++) {
+        if (lane < 17) g = __hip_atomic_load(a.arm + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        got = __all(lane >= 17 || (int)(g >> 32) == a.token);
+        if (!got && (spin & 15) == 15 && (unsigned long long)wall_clock64() - t0 > kArmWaitTicks) break;
+      }
+      if (lane < 16) arm_pose_sh[lane] = __uint_as_float((unsigned)g);
+      if (lane == 16) arm_verdict_sh4[0] = got ? (int)(unsigned)g : 3;
+    }
+    __syncthreads();
+    if (arm_verdict_sh4[0] == 3) {   // nobody answered (a host thread that lost its processor for seconds, a dead process): a give-up, reported
+      if (threadIdx.x < 64) {        // like the persistent launch's — the launches queued behind this one find a finished Solve
+        if (threadIdx.x < (int)(sizeof(LmState) / sizeof(int))) ((int*)&s_sh)[threadIdx.x] = 0;
+        if (threadIdx.x == 0) { s_sh.status = -2; s_sh.active = 0; s_sh.finished = 1; }
+      }
+      __syncthreads();
+      lm_fused_publish(s_sh, q.st_out, a.host_prog, q.seq, a.token, a.cost_stat, a.out, a.done_flag, a.final_state);
+      return;
+    }
+    if (arm_verdict_sh4[0] != 1) return;   // the keyframe changes or the Solve before this one failed: nothing was touched
+  } else {
+    __syncthreads();
+  }
 #if ODO_PHASE_STAMPS
   const unsigned long long w_p1 = (unsigned long long)wall_clock64();
 #endif
   // state in (or initialised), a pending evaluation of an earlier launch consumed, pyramid walk started
   lm_fused_prologue(q.st_in, q.part_in, lv_sh, a.n_levels, a.lambda0, a.precision, s_sh, red_sh, acc_sh, (kFull ? a.trace : (LmTraceRow*)nullptr), a.cost_stat, true,
-                    q.first_of_solve ? a.init : nullptr, a.stop_level, a.chain_in_token ? a.chain_pose : nullptr);
+                    kArmed ? arm_pose_sh : (q.first_of_solve ? a.init : nullptr), a.stop_level, (!kArmed && a.chain_in_token) ? a.chain_pose : nullptr);
 #if ODO_PHASE_STAMPS
   const unsigned long long w_p2 = (unsigned long long)wall_clock64();
 #endif
@@ -1993,6 +2033,10 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
 static __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_kernel(StepArgs a, int min_level) {   // Huber / L2, nothing recorded
   const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve, a.span};
   lm_coarse_body<false>(a, q, min_level, lm_kernarg_words());
+}
+static __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_armed_kernel(StepArgs a, int min_level) {   // lm_coarse_kernel waiting for the host's word (StepArgs::arm)
+  const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve, a.span};
+  lm_coarse_body<false, true>(a, q, min_level, lm_kernarg_words());
 }
 static __global__ void __launch_bounds__(kCoarseBlock) lm_coarse_full_kernel(StepArgs a, int min_level) {   // t-distribution weights and / or trace rows
   const StepLaunch q = {a.st_in, a.st_out, a.part_in, a.part_out, a.seq, a.first_of_solve, a.span};
@@ -3537,6 +3581,7 @@ void lm_chain_diag_read(unsigned long long out[24]);
 #endif
 hipError_t lm_chain_setup();   // the coarse kernels' dynamic LDS limit; once per process and device
 void launch_lm_coarse(bool lean, hipStream_t s, const StepArgs& a, int min_level);
+void launch_lm_coarse_armed(hipStream_t s, const StepArgs& a, int min_level);   // lean build only (a trackers' optimiser)
 void launch_lm_fine(int variant, int blocks, hipStream_t s, const StepArgs& a, int K, unsigned long long* xbuf, int fault, int lo_level,
                     unsigned* dispatch_words);
 

@@ -16,7 +16,13 @@ hipError_t lm_chain_setup() {
   // the single-workgroup coarse kernel reduces through its dynamic LDS block (gfx950: up to 160 KB per workgroup)
   hipError_t e = hipFuncSetAttribute((const void*)lm_coarse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kCoarseLdsBytes);
   if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)lm_coarse_armed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kCoarseLdsBytes);
+  if (e != hipSuccess) return e;
   return hipFuncSetAttribute((const void*)lm_coarse_full_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kCoarseLdsBytes);
+}
+
+void launch_lm_coarse_armed(hipStream_t s, const StepArgs& a, int min_level) {
+  hipLaunchKernelGGL(lm_coarse_armed_kernel, dim3(1), dim3(kCoarseBlock), kCoarseLdsBytes, s, a, min_level);
 }
 
 void launch_lm_coarse(bool lean, hipStream_t s, const StepArgs& a, int min_level) {

@@ -717,6 +717,7 @@ struct LmJob {
   int slot;   // which of the two host-mapped result blocks its finishing launch writes (a chained Solve takes the other one)
   bool poll, result_by_launch, issued_all;
   double bytes_per_level[ODO_MAX_LEVELS];
+  int fine_lo;          // lm_plan_levels' answer at begin (an armed Solve's persistent launch is issued later: lm_arm_go)
 };
 
 struct odo_lm {
@@ -824,6 +825,12 @@ struct odo_lm {
   // A Solve queued BEHIND the one in flight before its result exists (lm_chain_begin: the trackers' next Solve): it starts from the
   // pose the finishing launch of `job` leaves in d_chain_pose, if the guard in d_chain_guard lets it (success, keyframe kept).
   LmJob chained;
+  // Armed Solves (the single tracker; lm_arm_begin / lm_arm_go / lm_arm_abort): the NEXT Solve's coarse launch is queued behind the
+  // Solve in flight before that Solve's result exists, and reads the host's word (StepArgs::arm) when it starts.
+  LmJob armed;
+  int arm_on;                                                 // lm_enable_arming was called (the tracker's optimiser)
+  unsigned long long* h_arm; unsigned long long* d_arm_map;   // host-mapped: 17 tagged granules (pose + verdict), one armed Solve at a time
+  long arm_used, arm_aborted;
   float* d_chain_pose;     // [16]
   int* d_chain_guard;
   float kf_rule[7];        // the runner's keyframe test (six weights, threshold): lm_set_chain_rule
@@ -925,8 +932,10 @@ extern "C" int odo_lm_create(odo_ctx* ctx, float lambda, float precision, const 
   return 0;
 }
 
+static void lm_arm_abort(odo_lm* m);
 extern "C" int odo_lm_destroy(odo_lm* m) {
   if (!m) return 0;
+  lm_arm_abort(m);   // (an armed launch would hold the stream until its word came)
   if (m->ahead.ev) { (void)hipEventSynchronize(m->ahead.ev); (void)hipEventDestroy(m->ahead.ev); }   // lists being built ahead on another stream
   (void)hipStreamSynchronize(m->ctx->stream);
   void* dv[] = {m->d_state, m->d_partials, m->d_xbuf, m->d_init, m->d_out, m->d_trace, m->d_scale, m->d_res, m->d_chain_pose, m->d_ts_xbuf, m->d_ts_gave_up,
@@ -944,6 +953,7 @@ extern "C" int odo_lm_destroy(odo_lm* m) {
   if (m->d_span) (void)hipFree(m->d_span);
   delete m->span_kind;
   (void)hipHostFree(m->h_out); (void)hipHostFree(m->h_trace); (void)hipHostFree(m->h_prog); (void)hipHostFree(m->h_res); (void)hipHostFree(m->h_done);
+  if (m->h_arm) (void)hipHostFree(m->h_arm);
   delete m;
   return 0;
 }
@@ -1425,20 +1435,56 @@ static inline bool fine_note_clean(bool on, int* strikes, int* clean, int* offs)
 // Keyframe lists must be current (lm_prepare_keyframe) and the Solve fused-eligible.
 // chain_in_token != 0: a chained Solve (lm_chain_begin) behind the Solve with that token: only if the coarse + persistent launches
 // cover all of it (returns 1 without launching anything otherwise), lambda0 = chain_lambda (what Reset will set).
+// The persistent launch of a job whose coarse launch is out: levels [jb.fine_lo, jb.min_level) in ONE launch behind it; if they are the
+// rest of the Solve it reports the result itself.
+static void lm_job_launch_fine(odo_lm* m, LmJob& jb) {
+  StepArgs& a = jb.a;
+  const int fine_lo = jb.fine_lo, min_level = jb.min_level, stop = jb.stop_level;
+  LmState* st[2] = {m->d_state, m->d_state + 1};
+  double* part[2] = {m->d_partials, m->d_partials + (size_t)kLmMaxBlocks * ODO_NACC};
+  int fine_budget = 0;
+  for (int l = fine_lo; l < min_level; l++) fine_budget += m->max_iters[l] > 0 ? m->max_iters[l] : 0;
+  if (!(fine_lo < min_level && fine_budget > 0)) return;
+  jb.budget -= fine_budget;
+  a.st_in = st[jb.seq & 1]; a.st_out = st[(jb.seq + 1) & 1];
+  a.part_in = part[jb.seq & 1]; a.part_out = part[(jb.seq + 1) & 1];
+  a.seq = jb.seq; a.first_of_solve = (jb.seq == 0) ? 1 : 0;
+  a.arm = nullptr;
+  a.span = lm_span_slot(m, jb.launches, false);
+  a.fine_epoch = lm_fine_next_epoch(m);
+  a.fine_dispatch = lm_fine_next_dispatch();
+  a.fine_wait = m->fine_wait;
+  a.fine_home = m->fine_home;
+  const int k_use = lm_fine_launch_k(m, fine_lo, min_level);
+  m->fine_k_last = k_use;
+  unsigned* const dispatch_words = m->dispatch_words;   // this unit's g_lm_fine_dispatch: what the depth launches read
+  // the lean build has neither the trace writes nor the bilinear sampling path
+  launch_lm_fine(m->robust == 2 ? 2 : (a.trace || m->bilinear) ? 1 : 0, 8 * k_use, m->ctx->stream, a, k_use, m->d_xbuf, m->fine_fault, fine_lo, dispatch_words);
+  jb.seq++;
+  jb.launches++;
+  if (fine_lo <= stop) {   // nothing left for step launches
+    jb.issued_all = true;
+    jb.result_by_launch = true;
+  }
+}
 static int lm_fused_begin_job(odo_lm* m, LmJob& jb, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img,
-                              int chain_in_token, float chain_lambda);
+                              int chain_in_token, float chain_lambda, bool arm = false);
+static void lm_arm_abort(odo_lm* m);
 static int lm_fused_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img) {
   m->chained.active = 0;   // (a chained Solve belongs to the job it was queued behind)
+  if (m->armed.active) lm_arm_abort(m);   // (an armed Solve the caller never resolved — a redo of the Solve in flight —: it returns at once)
   return lm_fused_begin_job(m, m->job, kf_img, kf_dep, cur_img, 0, 0.0f);
 }
 static int lm_fused_begin_job(odo_lm* m, LmJob& jb, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img,
-                              int chain_in_token, float chain_lambda) {
+                              int chain_in_token, float chain_lambda, bool arm) {
   hipStream_t s = m->ctx->stream;
-  if (chain_in_token) {   // feasibility first: nothing is launched for a Solve that would need step launches or the unfused pipeline
+  if (chain_in_token || arm) {   // feasibility first: nothing is launched for a Solve that would need step launches or the unfused pipeline
     const int stop0 = lm_fused_stop_level(m);
     int ml = 0, fl = 0;
     lm_plan_levels(m, stop0, m->fine_k, &ml, &fl);
     if (stop0 != 0 || !((fl <= stop0 && fl < ml) || (ml <= stop0 && ml < m->n_levels))) return 1;
+    // an armed Solve: a coarse launch that reads the host's word + the persistent launch for the rest, lean kernels only
+    if (arm && !(ml < m->n_levels && fl <= stop0 && fl < ml && m->robust != 2 && !m->record && !m->bilinear)) return 1;
   }
   jb.kf_img = kf_img; jb.kf_dep = kf_dep; jb.cur_img = cur_img;
   jb.kf_img_ver = kf_img->version; jb.kf_dep_ver = kf_dep->version; jb.cur_ver = cur_img->version;
@@ -1470,7 +1516,7 @@ static int lm_fused_begin_job(odo_lm* m, LmJob& jb, const odo_pyr* kf_img, const
     budget += m->max_iters[l] > 0 ? m->max_iters[l] : 0;
     jb.bytes_per_level[l] = lm_level_bytes(m, l, L.rows, L.cols, L.nblk);
   }
-  a.lambda0 = chain_in_token ? chain_lambda : m->lambda; a.precision = m->precision; a.robust = m->robust; a.huber_delta = m->huber_delta;
+  a.lambda0 = (chain_in_token || arm) ? chain_lambda : m->lambda; a.precision = m->precision; a.robust = m->robust; a.huber_delta = m->huber_delta;
   a.trace = m->record ? m->d_trace : nullptr; a.cost_stat = m->record ? m->d_cost : nullptr; a.host_prog = m->d_prog;
   a.out = m->d_res_map + 48 * jb.slot; a.done_flag = m->d_done + jb.slot; a.token = jb.token;
   a.stop_level = stop;
@@ -1551,41 +1597,18 @@ static int lm_fused_begin_job(odo_lm* m, LmJob& jb, const odo_pyr* kf_img, const
     a.span = lm_span_slot(m, 0, true);
     // the trackers' optimisers (Huber / L2, nothing recorded) run the build without the scale passes and the trace writes
     lap(6);
-    launch_lm_coarse(m->robust != 2 && !a.trace && !m->bilinear, s, a, min_level);
+    if (arm) { a.arm = m->d_arm_map; launch_lm_coarse_armed(s, a, min_level); }
+    else launch_lm_coarse(m->robust != 2 && !a.trace && !m->bilinear, s, a, min_level);
     lap(7);
     jb.seq++;
     jb.launches++;
   }
-  int fine_budget = 0;
-  for (int l = fine_lo; l < min_level; l++) fine_budget += m->max_iters[l] > 0 ? m->max_iters[l] : 0;
-  if (fine_lo < min_level && fine_budget > 0) {
-    // levels [fine_lo, min_level) in ONE persistent launch; if they are the rest of the Solve it reports the result itself
-    budget -= fine_budget;
-    a.st_in = st[jb.seq & 1]; a.st_out = st[(jb.seq + 1) & 1];
-    a.part_in = part[jb.seq & 1]; a.part_out = part[(jb.seq + 1) & 1];
-    a.seq = jb.seq; a.first_of_solve = (jb.seq == 0) ? 1 : 0;
-    a.span = lm_span_slot(m, jb.launches, false);
-    a.fine_epoch = lm_fine_next_epoch(m);
-    a.fine_dispatch = lm_fine_next_dispatch();
-    a.fine_wait = m->fine_wait;
-    a.fine_home = m->fine_home;
-    const int k_use = lm_fine_launch_k(m, fine_lo, min_level);
-    m->fine_k_last = k_use;
-    unsigned* const dispatch_words = m->dispatch_words;   // this unit's g_lm_fine_dispatch: what the depth launches read
-    // the lean build has neither the trace writes nor the bilinear sampling path
-    launch_lm_fine(m->robust == 2 ? 2 : (a.trace || m->bilinear) ? 1 : 0, 8 * k_use, s, a, k_use, m->d_xbuf, m->fine_fault, fine_lo, dispatch_words);
-    jb.seq++;
-    jb.launches++;
-    if (fine_lo <= stop) {   // nothing left for step launches
-      jb.issued_all = true;
-      jb.result_by_launch = true;
-    }
-  }
+  jb.grid = grid; jb.budget = budget; jb.min_level = min_level; jb.fine_lo = fine_lo;
+  if (!arm) lm_job_launch_fine(m, jb);   // (an armed Solve's persistent launch follows the host's word: lm_arm_go)
   if (min_level <= stop && min_level < m->n_levels) {   // the coarse launch covers the whole fused part: it reports the result itself
     jb.issued_all = true;
     jb.result_by_launch = true;
   }
-  jb.grid = grid; jb.budget = budget; jb.min_level = min_level;
   jb.active = 1;
   return 0;
 }
@@ -1766,6 +1789,63 @@ static void lm_chain_adopt(odo_lm* m) {
   m->chained.active = 0;
 }
 
+// ---- armed Solves (the single tracker) ------------------------------------------------------------------------------------
+// Between the last evaluation of one Solve and the first of the next lie the result's trip to the host, the runner's keyframe test, a
+// launch call (3 us) and the dispatch. An armed Solve has its coarse launch queued behind the Solve in flight BEFORE that one has
+// returned; it starts the moment the launch in front of it retires and reads the host's word: lm_arm_go writes the pose Reset would set
+// (ref: run_odometry_kitti_offline.cpp:268) and issues the persistent launch behind it; lm_arm_abort tells it to return (new keyframe,
+// failure). The host's own keyframe test decides, nothing is guessed on the device (unlike the chained Solves above), and the
+// arithmetic is the unarmed Solve's. (The same on a second stream, resident while it waits: tools/experiments/armed_solve — slower.)
+static int lm_enable_arming(odo_lm* m) {
+  if (m->arm_on) return 0;
+  HIP_OK(hipHostMalloc((void**)&m->h_arm, sizeof(unsigned long long) * 32, hipHostMallocMapped | hipHostMallocCoherent));
+  memset(m->h_arm, 0, sizeof(unsigned long long) * 32);
+  HIP_OK(hipHostGetDevicePointer((void**)&m->d_arm_map, m->h_arm, 0));
+  m->arm_on = 1;
+  return 0;
+}
+// Queues the coarse launch of the Solve of `next_img` against the keyframe of the Solve in flight (m->job, all of whose launches must
+// be out: a coarse + a persistent launch) behind it; next_img must be complete (the caller has seen its event). lambda: what Reset
+// will set. Returns 0 armed, 1 not possible (nothing was launched).
+static int lm_arm_begin(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* next_img, float lambda) {
+  if (m->armed.active) lm_arm_abort(m);
+  // (m->job describes the Solve in flight also while odo_lm_solve is collecting it — it clears `active` first —, which is when the
+  //  tracker calls this, from that Solve's wait loop)
+  if (!m->arm_on || !m->fused || !m->job.issued_all || !m->job.result_by_launch || m->job.launches != 2) return 1;
+  if (m->job.kf_img != kf_img || m->job.kf_dep != kf_dep || m->job.kf_img_ver != kf_img->version || m->job.kf_dep_ver != kf_dep->version) return 1;
+  if (lm_check_pyrs(m, kf_img, kf_dep, next_img)) return 1;
+  if (!lm_fused_eligible(m)) return 1;
+  const int rc = lm_fused_begin_job(m, m->armed, kf_img, kf_dep, next_img, 0, lambda, true);
+  if (rc != 0) { m->armed.active = 0; return 1; }
+  return 0;
+}
+static void lm_arm_write(odo_lm* m, const float pose[16], int verdict) {
+  volatile unsigned long long* w = m->h_arm;
+  const unsigned long long tag = (unsigned long long)(unsigned)m->armed.token << 32;
+  for (int i = 0; i < 16; i++) { unsigned bits = 0; if (pose) memcpy(&bits, &pose[i], 4); w[i] = tag | bits; }
+  std::atomic_thread_fence(std::memory_order_release);
+  w[16] = tag | (unsigned)verdict;
+  std::atomic_thread_fence(std::memory_order_seq_cst);   // out of the store buffer now
+}
+// The Solve in flight has returned `pose` and the keyframe stays: the armed Solve starts from it (call after odo_lm_reset(pose, lambda))
+// and becomes the job in flight. Returns 1 when there is no armed Solve any more (told to return by a redo of the Solve in flight).
+static int lm_arm_go(odo_lm* m, const float pose[16]) {
+  if (!m->armed.active) return 1;
+  lm_arm_write(m, pose, 1);
+  lm_job_launch_fine(m, m->armed);
+  m->job = m->armed;
+  m->job.active = 1;
+  m->armed.active = 0;
+  m->arm_used++;
+  return 0;
+}
+static void lm_arm_abort(odo_lm* m) {
+  if (!m->armed.active) return;
+  lm_arm_write(m, nullptr, 2);
+  m->armed.active = 0;
+  m->arm_aborted++;
+}
+
 extern "C" int odo_lm_solve(odo_lm* m, const odo_pyr* kf_img, const odo_pyr* kf_dep, const odo_pyr* cur_img,
                             float out_colmajor[16]) {
   if (!out_colmajor) return fail("odo_lm_solve: NULL out");
@@ -1834,6 +1914,7 @@ fused_again:
       if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { ok = false; break; }
     }
     if (!ok) {  // never hang: drain the stream; if no launch reported (it should have), finalize explicitly
+      lm_arm_abort(m);   // (an armed launch queued behind this Solve would hold the stream until its word came)
       HIP_OK(hipStreamSynchronize(s));
       if (done[0] != token) {
         launch_finalize();
@@ -1854,6 +1935,7 @@ fused_again:
       started = false;
       launches = 0;
       m->chained.active = 0;   // (a Solve chained behind this one sees a guard without its token and returns at once)
+      lm_arm_abort(m);         // (... and an armed one is told to return: it sits in this stream)
       HIP_OK(hipStreamSynchronize(s));
       fused = lm_fused_eligible(m);   // (t-distribution weights: without the persistent launch the fused part may be empty)
       goto fused_again;

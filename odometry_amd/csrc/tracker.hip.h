@@ -66,6 +66,8 @@ struct odo_tracker {
   double dbg_pre_us, dbg_spin_us, dbg_chain_us, dbg_verdict_us, dbg_post_us, dbg_relaunch_us; long dbg_n, dbg_relaunch_n;   // ODO_TRACK_DEBUG: host time per call, by phase
   int depth_ahead;           // 1: with the next PAIR announced, the next frame's stream-B job is posted a frame early (ODO_NO_DEPTH_AHEAD=1: off)
   hipEvent_t ev_next;        // stream C: next_img is complete
+  int arm_enabled;           // armed Solves are in use (lm_enable_arming; ODO_NO_ARM=1 turns them off)
+  int arm_pending, arm_on;   // the next Solve is to be armed from the wait loop (tracker_poll_next) / has been armed and waits for its word
   int next_ready;            // 1: ev_next was seen complete by the host while it waited for the Solve (tracker_poll_next): the next Solve's
                              // launches then go out without a wait packet in front of them (1.5 us of host time + the packet's processing)
 };
@@ -104,6 +106,7 @@ extern "C" int odo_tracker_destroy(odo_tracker* t) {
   if (t->ctx_a) (void)hipStreamSynchronize(t->ctx_a->stream);
   if (t->ctx_b) (void)hipStreamSynchronize(t->ctx_b->stream);
   if (t->ctx_c) (void)hipStreamSynchronize(t->ctx_c->stream);
+  if (t->lm && getenv("ODO_TRACK_DEBUG")) fprintf(stderr, "[track] armed Solves: %ld started on the host's word, %ld told to return\n", t->lm->arm_used, t->lm->arm_aborted);
   odo_lm_destroy(t->lm);
   odo_depth_destroy(t->depth);
   odo_pyr* ps[] = {t->kf_img, t->kf_dep, t->cur_img, t->pre_img, t->pre_dep[0], t->pre_dep[1], t->next_img};
@@ -141,7 +144,7 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
   t->cand_lists = getenv("ODO_NO_CAND_LISTS") ? 0 : 1;
   t->tm_solve_us = t->tm_depth_us = t->tm_frame_us = t->tm_wait_us = 0.0; t->tm_frames = 0;
   t->w_posted.store(0); t->w_done.store(0); t->w_quit.store(0);
-  t->ev_next = nullptr; t->next_ready = 0;
+  t->ev_next = nullptr; t->next_ready = 0; t->arm_pending = t->arm_on = t->arm_enabled = 0;
   t->early_solve = getenv("ODO_NO_EARLY_SOLVE") ? 0 : 1;
   // Chained Solves are OFF unless ODO_CHAIN_SOLVE=1: measured (round 4) they close the 14 us the GPU idles between
   // two Solves (rocprofv3: fine -> next coarse gap 14.2 -> 0.0 us) and the frame rate does not move (3 250 both ways): the LM
@@ -180,6 +183,10 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
   ok = ok && hipEventCreateWithFlags(&t->ev_cur_img, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&t->ev_next, hipEventDisableTiming) == hipSuccess;
   if (ok && !getenv("ODO_LM_TRACE")) t->lm->record = 0;   // nobody reads the per-evaluation rows / cost statistics of a tracker's Solves
+  // Armed Solves (lm_arm_begin): with the helper thread only (overlap_depth == 2: the calling thread does nothing but the pose LM's
+  // launches); ODO_NO_ARM=1 turns them off.
+  t->arm_enabled = 0;
+  if (ok && p->overlap_depth == 2 && !getenv("ODO_NO_ARM") && !t->chain_solve) { ok = lm_enable_arming(t->lm) == 0; t->arm_enabled = ok ? 1 : 0; }
   if (ok) lm_set_chain_rule(t->lm, p->keyframe_weight, p->keyframe_motion_th);
   if (!ok) {
     char keep[512];
@@ -229,9 +236,17 @@ static void tracker_job_pump_one(odo_tracker* t, TrackerJob* j) {
 // Called from the Solve's wait loop (overlap_depth == 2, next frame announced): has stream C finished the next frame's pyramid?
 static void tracker_poll_next(void* arg) {
   odo_tracker* t = (odo_tracker*)arg;
-  if (t->next_ready) return;
-  if (hipEventQuery(t->ev_next) == hipSuccess) t->next_ready = 1;
-  else (void)hipGetLastError();   // (hipErrorNotReady is not an error, and must not be the thread's last error when the next HIP_OK looks)
+  if (!t->next_ready) {
+    if (hipEventQuery(t->ev_next) == hipSuccess) t->next_ready = 1;
+    else (void)hipGetLastError();   // (hipErrorNotReady is not an error, and must not be the thread's last error when the next HIP_OK looks)
+    return;
+  }
+  // The next frame's pyramid is complete: its Solve can be ARMED (lm_arm_begin) — the coarse launch queued behind this frame's Solve, no
+  // wait packet in front of it.
+  if (t->arm_pending) {
+    t->arm_pending = 0;
+    t->arm_on = lm_arm_begin(t->lm, t->kf_img, t->kf_dep, t->next_img, 0.01f) == 0;
+  }
 }
 static void tracker_job_pump(void* arg) {
   odo_tracker* t = (odo_tracker*)arg;
@@ -332,6 +347,7 @@ extern "C" int odo_tracker_quiesce(odo_tracker* t) {
   HIP_OK(hipSetDevice(t->ctx_a->device));
   if (tracker_wait_idle(t)) return -1;
   t->ahead_job = -1;
+  lm_arm_abort(t->lm);   // (an armed launch would hold stream A until its word came)
   HIP_OK(hipStreamSynchronize(t->ctx_a->stream));
   HIP_OK(hipStreamSynchronize(t->ctx_b->stream));
   HIP_OK(hipStreamSynchronize(t->ctx_c->stream));
@@ -471,6 +487,17 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
   t->next_ready = 0;
   if (early && tracker_next_pyramid(t, next_left)) return -1;
   if (early && p.overlap_depth == 2 && !t->chain_solve) { t->lm->idle_pump = tracker_poll_next; t->lm->idle_arg = t; }
+  // ---- the next frame's Solve ARMED: its coarse launch is queued behind this frame's Solve from the wait loop, as soon as the next
+  // pyramid is complete, and reads this frame's pose and the keyframe decision from a word the host writes (lm_arm_go / lm_arm_abort
+  // below). This frame's Solve must be in flight (started early in the last call); otherwise the next Solve starts the ordinary way.
+  struct ArmGuard {   // whatever path leaves this call: an armed launch never stays without its word
+    odo_tracker* t;
+    ~ArmGuard() { t->arm_pending = 0; if (t->arm_on) { t->arm_on = 0; lm_arm_abort(t->lm); } }
+  } arm_guard{t};
+  t->arm_pending = 0; t->arm_on = 0;
+  if (early && t->arm_enabled && had_prefetch && p.overlap_depth == 2 && !t->chain_solve && lm_job_matches(t->lm, t->kf_img, t->kf_dep, t->cur_img) &&
+      t->lm->job.launches == 2)
+    t->arm_pending = 1;
   if (ahead) {
     const long n = t->w_posted.load(std::memory_order_relaxed);
     TrackerJob* ja = &t->jobs[n & 1];   // the other slot: this frame's job is n - 1 (or done long ago)
@@ -571,6 +598,16 @@ extern "C" int odo_tracker_track(odo_tracker* t, const float* left, const float*
     }
   }
   t->dbg_verdict_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - v0).count();
+  t->arm_pending = 0;
+  if (t->arm_on) {
+    t->arm_on = 0;
+    if (!promote && st == 0) {
+      odo_lm_reset(t->lm, T, 0.01f);                                                   // :268 (the pose and lambda the armed Solve starts from)
+      if (lm_arm_go(t->lm, T) == 0) reset_done = true;
+    } else {
+      lm_arm_abort(t->lm);
+    }
+  }
   if (early && !promote && !reset_done) {
     odo_lm_reset(t->lm, T, 0.01f);                                                     // :268
     reset_done = true;

@@ -432,6 +432,11 @@ int odo_tracker_timing(odo_tracker* t, double out[4]);
  * Opt-in (ODO_CHAIN_SOLVE=1): it closes the GPU's idle gap between two Solves and does not change the frame rate. *adopted = chained Solves that became the next Solve, *wasted = chained Solves that ran for
  * nothing because the two keyframe tests disagreed (an ulp of atan2f: expected never). */
 int odo_tracker_chain_stats(const odo_tracker* t, long* adopted, long* wasted);
+/* Armed Solves (round 6; the default with the next pair announced, ODO_NO_ARM=1 turns them off): the next frame's Solve has its
+ * coarse launch queued behind this frame's before this frame's result exists and starts on a word the host writes after the runner's
+ * keyframe test (ref: run_odometry_kitti_offline.cpp:253-268) — same launches, same arithmetic, no launch call and no dispatch between
+ * two Solves. started: Solves that began that way; returned: armed launches told to return (new keyframe, failed Solve). */
+int odo_tracker_arm_stats(const odo_tracker* t, long* started, long* returned);
 odo_lm* odo_tracker_lm(odo_tracker* t);
 odo_depth* odo_tracker_depth(odo_tracker* t);   /* its depth estimator (odo_depth_persistent_stats, odo_depth_report) */
 odo_ctx* odo_tracker_ctx(odo_tracker* t);

@@ -135,6 +135,7 @@ SIGNATURES = {
     "odo_tracker_timing": (C.c_int, [_vp, _dp]),
     "odo_tracker_lm": (_vp, [_vp]),
     "odo_tracker_chain_stats": (C.c_int, [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
+    "odo_tracker_arm_stats": (C.c_int, [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "odo_tracker_depth": (C.c_void_p, [_vp]),
     "odo_tracker_batch_lm": (_vp, [_vp, C.c_int]),
     "odo_tracker_ctx": (_vp, [_vp]),

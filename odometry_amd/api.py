@@ -639,6 +639,12 @@ class Tracker:
         L.check(self.lib.odo_tracker_chain_stats(self.h, C.byref(a), C.byref(b)), "odo_tracker_chain_stats")
         return a.value, b.value
 
+    def arm_stats(self):
+        """(Solves that started armed — coarse launch queued ahead, started by the host's word —, armed launches told to return)"""
+        a, b = C.c_long(0), C.c_long(0)
+        L.check(self.lib.odo_tracker_arm_stats(self.h, C.byref(a), C.byref(b)), "odo_tracker_arm_stats")
+        return a.value, b.value
+
     def depth_persistent_stats(self):
         """(1 while the depth LM runs as one persistent launch, ComputeDepth jobs run again on the step launches)"""
         d = C.c_void_p(self.lib.odo_tracker_depth(self.h))

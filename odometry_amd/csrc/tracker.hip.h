@@ -718,6 +718,12 @@ extern "C" int odo_tracker_chain_stats(const odo_tracker* t, long* adopted, long
   if (wasted) *wasted = t->chain_wasted;
   return 0;
 }
+extern "C" int odo_tracker_arm_stats(const odo_tracker* t, long* started, long* returned) {
+  if (!t) return fail("NULL tracker");
+  if (started) *started = t->lm->arm_used;
+  if (returned) *returned = t->lm->arm_aborted;
+  return 0;
+}
 extern "C" odo_lm* odo_tracker_lm(odo_tracker* t) { return t ? t->lm : nullptr; }
 extern "C" odo_depth* odo_tracker_depth(odo_tracker* t) { return t ? t->depth : nullptr; }
 extern "C" odo_ctx* odo_tracker_ctx(odo_tracker* t) { return t ? t->ctx_a : nullptr; }

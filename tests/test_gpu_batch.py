@@ -285,6 +285,54 @@ def test_early_start_of_the_next_solve_changes_nothing(api, drives, overlap, pai
                 assert np.array_equal(ma, mb), k
 
 
+def test_armed_solves_change_nothing(api, monkeypatch):
+    """Armed Solves (odo_tracker_arm_stats; the default with the next pair announced): the next frame's coarse launch is queued behind
+    this frame's Solve before its result exists and starts on a word the host writes after the keyframe test (ref:
+    run_odometry_kitti_offline.cpp:253-268). Same launches, same arithmetic: poses, keyframe decisions and depth statistics must be
+    those of a tracker with ODO_NO_ARM=1 — across keyframe switches (the armed launch is told to return), with a wrong announcement,
+    with a frame that is not announced, and with a re-initialisation behind an announcement — and the armed path must actually run."""
+    from odometry_amd import synth
+    n = 26
+    seq = synth.make_sequence(n, seed=0)   # (switches keyframe at frames 9 and 18)
+
+    def run(armed):
+        if armed:
+            monkeypatch.delenv("ODO_NO_ARM", raising=False)
+        else:
+            monkeypatch.setenv("ODO_NO_ARM", "1")
+        trk = api.Tracker(0, overlap_depth=2)
+        dev = [(trk.upload_frame(l), trk.upload_frame(r)) for l, r in zip(seq["left"][:n], seq["right"][:n])]
+        out = []
+        for rep in range(2):
+            trk.init(*dev[0])
+            for k in range(1, n):
+                if k == 5:
+                    trk.hint_next(*dev[0])          # wrong announcement: the next frame is 6
+                elif k == 11:
+                    pass                            # no announcement
+                elif k + 1 < n:
+                    trk.hint_next(*dev[k + 1])
+                else:
+                    trk.hint_next(*dev[1])          # announced, but the sequence is re-initialised instead
+                r = trk.track(*dev[k])
+                r["stats"] = trk.stats()
+                out.append(r)
+        st = trk.arm_stats()
+        trk.close()
+        return out, st
+
+    plain, st0 = run(False)
+    armed, st1 = run(True)
+    assert st0 == (0, 0)
+    assert st1[0] >= 20 and st1[1] >= 1, st1          # most Solves start on the host's word; keyframe switches send launches home
+    assert any(r["new_keyframe"] for r in plain)
+    for k, (a, b) in enumerate(zip(plain, armed)):
+        assert np.array_equal(a["pose_to_keyframe"], b["pose_to_keyframe"]), k
+        assert np.array_equal(a["abs_pose"], b["abs_pose"]), k
+        assert a["new_keyframe"] == b["new_keyframe"] and a["motion"] == b["motion"] and a["solve_status"] == b["solve_status"]
+        assert a["stats"] == b["stats"], k
+
+
 def test_candidate_lists_built_ahead_give_the_same_solve(api, kitti_seq):
     """odo_lm_candidate_begin: the point lists of a frame that may become the keyframe, built on another stream while the optimiser
     solves against the current keyframe. A Solve against exactly those pyramids adopts them (same pose and trace as an optimiser that

@@ -1825,6 +1825,9 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
   // ODO_COARSE_STAMPS: the state machine's phase sums stay in LDS and go out ONCE, at exit — round 5 added them to the host-mapped
   // counters from inside the loop (four read-modify-writes over PCIe per iteration), which the "state-machine" lap then measured
   __shared__ unsigned long long sm_sh[4];
+  // (an armed launch: the first read of the host's word travels beside the level table's loads)
+  unsigned long long arm_g0 = 0;
+  if (kArmed && threadIdx.x < 17) arm_g0 = __hip_atomic_load(a.arm + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   lm_copy_levels(lv_sh, lv_src);
   if (threadIdx.x == 0) {
 #pragma unroll
@@ -1838,8 +1841,8 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
     // of this one was retiring.
     if (threadIdx.x < 64) {
       const int lane = (int)threadIdx.x;
-      unsigned long long g = 0;
-      bool got = false;
+      unsigned long long g = arm_g0;
+      bool got = __all(lane >= 17 || (int)(g >> 32) == a.token);
       const unsigned long long t0 = (unsigned long long)wall_clock64();
       for (int spin = 0; !got; spin++) {
         if (lane < 17) g = __hip_atomic_load(a.arm + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -1587,6 +1587,15 @@ static int lm_fused_begin_job(odo_lm* m, LmJob& jb, const odo_pyr* kf_img, const
   int min_level = m->n_levels, fine_lo = m->n_levels;
   lm_plan_levels(m, stop, m->fine_k, &min_level, &fine_lo);
   m->last_coarse = (min_level < m->n_levels) ? 1 : 0;
+  // The host-mapped progress words are what the step launches' pump reads. A Solve that is all coarse + persistent launch has no
+  // pump: its launches skip the two system-scope stores (one a release) at their exits — the launch behind them starts that much earlier.
+  {
+    int fb = 0;
+    for (int l = fine_lo; l < min_level; l++) fb += m->max_iters[l] > 0 ? m->max_iters[l] : 0;
+    const bool fine_covers = fine_lo < min_level && fb > 0 && fine_lo <= stop;
+    const bool coarse_covers = min_level <= stop && min_level < m->n_levels;
+    if (fine_covers || coarse_covers) a.host_prog = nullptr;
+  }
   if (min_level < m->n_levels) {
     int coarse_budget = 0;
     for (int l = min_level; l < m->n_levels; l++) coarse_budget += m->max_iters[l] > 0 ? m->max_iters[l] : 0;

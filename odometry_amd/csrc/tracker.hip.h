@@ -187,7 +187,9 @@ extern "C" int odo_tracker_create(int device, const odo_tracker_params* p, odo_t
   // launches); ODO_NO_ARM=1 turns them off.
   t->arm_enabled = 0;
   if (ok && p->overlap_depth == 2 && !getenv("ODO_NO_ARM") && !t->chain_solve) { ok = lm_enable_arming(t->lm) == 0; t->arm_enabled = ok ? 1 : 0; }
-  if (ok) lm_set_chain_rule(t->lm, p->keyframe_weight, p->keyframe_motion_th);
+  // (only a tracker that chains its Solves needs the finishing launch to leave pose + guard word on the device: sixteen stores and two
+  //  releases between the last evaluation and the launch's exit, which an armed launch behind it waits for)
+  if (ok && t->chain_solve) lm_set_chain_rule(t->lm, p->keyframe_weight, p->keyframe_motion_th);
   if (!ok) {
     char keep[512];
     snprintf(keep, sizeof(keep), "%s", g_err);

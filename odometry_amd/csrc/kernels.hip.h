@@ -1617,7 +1617,8 @@ __device__ __forceinline__ void lm_write_result(const LmState& s, const float* c
   out[16] = (float)s.status;
   out[17] = (float)s.n_evals;
   for (int i = 0; i < 8; i++) out[18 + i] = (float)s.iters_level[i];
-  for (int i = 0; i < 16; i++) out[26 + i] = cost_stat ? cost_stat[i] : 0.0f;
+  if (cost_stat) { for (int i = 0; i < 16; i++) out[26 + i] = cost_stat[i]; }   // (an optimiser that records nothing: the host fills in the zeros —
+                                                                                //  sixteen stores to host memory less in front of the completion word)
   __hip_atomic_store(done_flag, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // the host has the result from here on
   if (chain.on) {
     // ... and the Solve queued behind this launch gets its start: pose, then the guard (the launch ends behind these stores). The

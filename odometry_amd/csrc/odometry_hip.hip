@@ -1933,6 +1933,7 @@ fused_again:
     std::atomic_thread_fence(std::memory_order_acquire);
     lap_start();
     memcpy(m->h_out, m->h_res + 48 * slot, sizeof(float) * 42);
+    if (!m->record) memset(&m->h_out[26], 0, sizeof(float) * 16);   // (cost statistics nobody asked for: lm_write_result leaves them out)
     if (m->h_out[16] == -2.0f && m->fine_k > 0) {
       // The persistent launch gave up: one of its workgroups never showed up within the wait bound (they wait for each other,
       // so all of them must be resident at once: another client of this GPU can hold the CUs they need). Nothing is lost but
@@ -2399,6 +2400,7 @@ collect_again:
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     memcpy(m->h_out, m->h_res, sizeof(float) * 42);
+    if (!m->record) memset(&m->h_out[26], 0, sizeof(float) * 16);
   }
   if (!redone && jb.fine_used) {
     // a sequence's persistent workgroups gave up waiting for each other (status -2: they could not all be resident): the whole

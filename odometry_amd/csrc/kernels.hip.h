@@ -1848,7 +1848,7 @@ __device__ __forceinline__ void lm_coarse_body(const StepArgs& a, const StepLaun
       for (int spin = 0; !got; spin++) {
         if (lane < 17) g = __hip_atomic_load(a.arm + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         got = __all(lane >= 17 || (int)(g >> 32) == a.token);
-        if (!got && (spin & 15) == 15 && (unsigned long long)wall_clock64() - t0 > kArmWaitTicks) break;
+        if (!got && (spin & 15) == 15 && (unsigned long long)wall_clock64() - t0 > (a.fine_wait ? (unsigned long long)a.fine_wait : kArmWaitTicks)) break;
       }
       if (lane < 16) arm_pose_sh[lane] = __uint_as_float((unsigned)g);
       if (lane == 16) arm_verdict_sh4[0] = got ? (int)(unsigned)g : 3;

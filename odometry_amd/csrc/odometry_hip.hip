@@ -831,6 +831,7 @@ struct odo_lm {
   int arm_on;                                                 // lm_enable_arming was called (the tracker's optimiser)
   unsigned long long* h_arm; unsigned long long* d_arm_map;   // host-mapped: 17 tagged granules (pose + verdict), one armed Solve at a time
   long arm_used, arm_aborted;
+  long arm_fault_at; unsigned arm_wait;   // test hook (ODO_ARM_FAULT) / the armed launch's wait bound in ticks (ODO_ARM_WAIT_US; 0: 2 s), read by lm_enable_arming
   float* d_chain_pose;     // [16]
   int* d_chain_guard;
   float kf_rule[7];        // the runner's keyframe test (six weights, threshold): lm_set_chain_rule
@@ -1606,7 +1607,11 @@ static int lm_fused_begin_job(odo_lm* m, LmJob& jb, const odo_pyr* kf_img, const
     a.span = lm_span_slot(m, 0, true);
     // the trackers' optimisers (Huber / L2, nothing recorded) run the build without the scale passes and the trace writes
     lap(6);
-    if (arm) { a.arm = m->d_arm_map; launch_lm_coarse_armed(s, a, min_level); }
+    if (arm) {
+      // (ODO_ARM_WAIT_US: the bound of the armed launch's wait for its word, default 2 s — StepArgs::fine_wait carries it, in ticks)
+      a.arm = m->d_arm_map; a.fine_wait = m->arm_wait;
+      launch_lm_coarse_armed(s, a, min_level);
+    }
     else launch_lm_coarse(m->robust != 2 && !a.trace && !m->bilinear, s, a, min_level);
     lap(7);
     jb.seq++;
@@ -1810,6 +1815,8 @@ static int lm_enable_arming(odo_lm* m) {
   HIP_OK(hipHostMalloc((void**)&m->h_arm, sizeof(unsigned long long) * 32, hipHostMallocMapped | hipHostMallocCoherent));
   memset(m->h_arm, 0, sizeof(unsigned long long) * 32);
   HIP_OK(hipHostGetDevicePointer((void**)&m->d_arm_map, m->h_arm, 0));
+  m->arm_fault_at = getenv("ODO_ARM_FAULT") ? atol(getenv("ODO_ARM_FAULT")) : 0;
+  m->arm_wait = getenv("ODO_ARM_WAIT_US") ? (unsigned)(100L * atol(getenv("ODO_ARM_WAIT_US"))) : 0u;
   m->arm_on = 1;
   return 0;
 }
@@ -1840,7 +1847,9 @@ static void lm_arm_write(odo_lm* m, const float pose[16], int verdict) {
 // and becomes the job in flight. Returns 1 when there is no armed Solve any more (told to return by a redo of the Solve in flight).
 static int lm_arm_go(odo_lm* m, const float pose[16]) {
   if (!m->armed.active) return 1;
-  lm_arm_write(m, pose, 1);
+  // test hook (ODO_ARM_FAULT=n): the n-th word is never written — the armed launch runs into its bound and reports a give-up, the
+  // Solve is redone the ordinary way
+  if (!(m->arm_fault_at > 0 && m->arm_used + 1 == m->arm_fault_at)) lm_arm_write(m, pose, 1);
   lm_job_launch_fine(m, m->armed);
   m->job = m->armed;
   m->job.active = 1;

@@ -333,6 +333,42 @@ def test_armed_solves_change_nothing(api, monkeypatch):
         assert a["stats"] == b["stats"], k
 
 
+def test_armed_launch_without_its_word_gives_up_and_the_solve_is_redone(api, monkeypatch):
+    """ODO_ARM_FAULT=3: the third armed launch never gets its word. It must run into its (here: 20 ms) bound, report a give-up like a
+    persistent launch's, and the Solve must be redone on the ordinary launches — same poses as a tracker without armed Solves, the
+    give-up counted (odo_lm_persistent_stats), tracking goes on armed afterwards."""
+    from odometry_amd import synth
+    n = 26
+    seq = synth.make_sequence(n, seed=0)
+
+    def run(env):
+        for k in ("ODO_NO_ARM", "ODO_ARM_FAULT", "ODO_ARM_WAIT_US"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        trk = api.Tracker(0, overlap_depth=2)
+        dev = [(trk.upload_frame(l), trk.upload_frame(r)) for l, r in zip(seq["left"][:n], seq["right"][:n])]
+        out = []
+        for rep in range(2):
+            trk.init(*dev[0])
+            for k in range(1, n):
+                if k + 1 < n:
+                    trk.hint_next(*dev[k + 1])
+                out.append(trk.track(*dev[k]))
+        st, redone = trk.arm_stats(), trk.persistent_stats()[1]
+        trk.close()
+        return out, st, redone
+
+    plain, _, redone0 = run({"ODO_NO_ARM": "1"})
+    hurt, st, redone1 = run({"ODO_ARM_FAULT": "3", "ODO_ARM_WAIT_US": "20000"})
+    if st[0] < 3:   # (a Solve is armed from its wait loop: a host that is never behind the GPU arms nothing)
+        pytest.skip("fewer than three armed Solves in 50 frames: %r" % (st,))
+    assert redone0 == 0 and redone1 == 1, (redone0, redone1)
+    for k, (a, b) in enumerate(zip(plain, hurt)):
+        assert np.array_equal(a["pose_to_keyframe"], b["pose_to_keyframe"]), k
+        assert a["new_keyframe"] == b["new_keyframe"] and a["solve_status"] == b["solve_status"]
+
+
 def test_candidate_lists_built_ahead_give_the_same_solve(api, kitti_seq):
     """odo_lm_candidate_begin: the point lists of a frame that may become the keyframe, built on another stream while the optimiser
     solves against the current keyframe. A Solve against exactly those pyramids adopts them (same pose and trace as an optimiser that
